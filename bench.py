@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py -- VP-Transformer training throughput (BASELINE.json configs[1]) on N MI355X GPUs.
+
+A "step" = one pass of run_models.py:37-44 over one synthetic batch of B=4096 trajectories per GPU
+(MTIO mix, zero-grad, forward, MTIO loss, backward, AdamW), executed by libmansy_hip.so.
+Inputs are resident in HBM before the timed region.  N>1: one process per GPU (torch.distributed /
+RCCL), data parallel over trajectories ("weak" scaling: 4096 per GPU), ONE all-reduce of the flat
+gradient buffer per step.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     dominant kernel = gemm_f32_kernel (exact-fp32 MFMA).  achieved = exact GEMM FLOPs
+               (sum 2MNK over launches; KV-cached decoder => this IS the algorithmic minimum of SURVEY
+               8d up to the attention/elementwise terms) / summed launch duration from HIP events recorded on
+               the launch stream in a separate instrumented leg of the same workload.
+               `model_frac` = trajectories/s x 0.522 GFLOP / peak (whole-step MFMA utilisation, north_star).
+  cpu_baseline the oracle (CPU restatement, torch fp32, autograd) timed on the host cores on a bounded
+               sample (B=32 steps for ~15 s), kind "port".
+"""
+import argparse
+import ctypes
+import json
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_TRAJ = 0.522e9          # fwd+bwd algorithmic FLOPs per trajectory (d=ff=512, S=T=10, 2+2 layers)
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: FP32 matrix peak (spec)
+
+
+def cpu_baseline(seconds=15.0):
+    import torch
+    from oracle import vp_oracle as vo
+    B, S, T, d = 32, 10, 10, 512
+    sd = vo.make_state_dict(d, 5, bias=True)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()
+              if v.dtype.is_floating_point and 'running_' not in k and k != 'positional_embedding.pe'}
+    full = dict(sd)
+    full.update(params)
+    orc = vo.VPOracle(full, fut_window=T)
+    h, c, f = vo.synthetic_trajectories(B, S, T, seed=5)
+    m = {k: torch.zeros_like(v) for k, v in params.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in params.items()}
+    n, t0 = 0, time.time()
+    while True:
+        src, cur, gt = vo.mtio_mix(h, c, f, 3, True, None)
+        loss = orc.loss_function(orc.process_src_current(src, cur, train=True), gt)
+        for p in params.values():
+            p.grad = None
+        loss.backward()
+        with torch.no_grad():
+            for k, p in params.items():
+                p1, m[k], v2[k] = vo.adamw_step(p, p.grad, m[k], v2[k], step=n + 1)
+                p.copy_(p1)
+        n += 1
+        if time.time() - t0 > seconds and n >= 2:
+            break
+    dt = time.time() - t0
+    return {'value': round(n * B / dt, 2), 'unit': 'trajectories/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'{n} train steps of B={B} (S=T=10, d=512, 2+2 layers, dropout off, KV-cached oracle) in {dt:.1f}s'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=4096, help='trajectories per GPU')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+
+    from mansy_immersivevideostreaming_amd.viewport_prediction.models import ViewportTransformerMTIO, FusedAdamW
+    from mansy_immersivevideostreaming_amd._lib import lib, check
+    from oracle import vp_oracle as vo      # input generator only (synthetic_trajectories)
+
+    B, S, T, d = args.batch, 10, 10, 512
+    torch.manual_seed(5)
+    random.seed(5)
+    np.random.seed(5)
+    model = ViewportTransformerMTIO(in_channel=2, fut_window=T, d_model=d, dim_feedforward=d, device=dev).to(dev)
+    model.train()
+    opt = FusedAdamW(model, lr=1e-4)
+    h, c, f = (t.to(dev) for t in vo.synthetic_trajectories(B, S, T, seed=5 + rank))
+
+    grad_sync = None
+    if world > 1:
+        inv = 1.0 / world
+
+        def grad_sync(g):
+            dist.all_reduce(g)
+            g.mul_(inv)
+
+    def step():
+        return model.train_step(h, c, f, opt, grad_sync=grad_sync)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    loss_val = float(loss.item())
+    value = world * B * args.steps / dt
+
+    # ---- roofline leg (rank 0): HIP events around every GEMM launch of the same workload
+    roof = None
+    if rank == 0:
+        L = lib()
+        check(L.mansy_prof_gemm_enable(1), 'prof_enable')
+        nprof = max(1, min(args.steps, 3))
+        for _ in range(nprof):
+            model.train_step(h, c, f, opt, grad_sync=None)
+        ms, n, fl = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double()
+        check(L.mansy_prof_gemm_collect(ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), 'prof_collect')
+        check(L.mansy_prof_gemm_enable(0), 'prof_disable')
+        achieved = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        roof = {'bound': 'mfma', 'kernel': 'gemm_f32_kernel (v_mfma_f32_32x32x2_f32)', 'achieved': round(achieved, 2),
+                'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                'traffic': None,
+                'launches_per_step': n.value // nprof, 'avg_launch_us': round(ms.value * 1e3 / max(n.value, 1), 2),
+                'gemm_flops_per_step': fl.value / nprof, 'gemm_ms_per_step': round(ms.value / nprof, 3),
+                'algorithmic_flops_per_step': FLOP_PER_TRAJ * B,
+                'model_frac': round(value / world * FLOP_PER_TRAJ / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+
+    if rank == 0:
+        out = {
+            'metric': 'viewport-trajectories/sec (VP train)', 'value': round(value, 1), 'unit': 'trajectories/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'VP Transformer train step (fwd+loss+bwd+AdamW), B={B}/GPU synthetic torus-walk '
+                                   f'trajectories len 21 (hist 10 + cur 1 + pred 10), d=512, 8 heads, 2+2 layers, dropout on, '
+                                   f'fp32 MFMA', 'global_batch': B * world, 'parallelism': f'dp{world}'},
+            'final_loss': loss_val,
+            'roofline': roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,124 @@
+/* libmansy_hip.so -- C ABI of the MI355X-native MANSY hot path (gfx950).
+ *
+ * The reference (duowuyms/MANSY_ImmersiveVideoStreaming) is pure Python and has no FFI; its seams
+ * are Python classes.  Each entry point below replaces the arithmetic behind one of those seams and
+ * is what the host-side mirrors in mansy_immersivevideostreaming_amd/ bind through ctypes:
+ *
+ *   mansy_vp_forward / mansy_vp_backward / mansy_vp_train_step / mansy_vp_sample
+ *        ViewportTransformerMTIO.forward/_process_src_current/sample
+ *        (viewport_prediction/models/mtio.py:65-166, models/customized_transformer.py:13-83)
+ *        + the train-loop body (viewport_prediction/run_models.py:37-44)
+ *   mansy_mtio_loss_fwd_bwd   ViewportTransformerMTIO.loss_function (mtio.py:94-104, utils/common.py:73-80)
+ *   mansy_adamw_step          torch.optim.AdamW as used at run_models.py:29,44; Adam+L2 at run_mansy.py:216
+ *   mansy_tilemap / _iou / _or_groups
+ *        find_tiles_covered_by_viewport + IoU (viewport_prediction/utils/common.py:37-58,83-127;
+ *        utils/results.py:13-31; predict.py:36-47)
+ *
+ * Conventions: plain pointers and sizes only; every pointer is DEVICE memory owned by the caller
+ * (PyTorch's allocator in the shipped host code); no ownership transfer; workspaces are sized by the
+ * *_workspace_bytes query; every call is asynchronous on `stream` (a hipStream_t passed as void*);
+ * return 0 on success, negative MANSY_E* otherwise, message via mansy_last_error().
+ */
+#ifndef MANSY_HIP_H
+#define MANSY_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* mansy_last_error(void);
+int mansy_abi_version(void);
+
+/* ------------------------------------------------------------------ viewport predictor */
+typedef struct mansy_vp_config {
+  int B, S, T;                 /* batch, history window, future window */
+  int d_model, n_head, d_ff;   /* 512, 8 (nn.Transformer default), 512 */
+  int n_enc, n_dec;            /* --block-num */
+  int in_ch;                   /* in_channel * num_head = 6 */
+  int has_bias;                /* 1: torch<=2.0 layout (biases), 0: torch>=2.1 layout (bias-free) */
+  float p_pe, p_drop;          /* 0.2 (mtio.py:49), 0.1 (nn.Transformer default); 0 disables */
+  float ln_eps, bn_eps, bn_momentum;
+  int max_len;                 /* rows of the positional table (5000) */
+} mansy_vp_config;
+
+/* ordered parameter table (names are the reference state_dict keys) */
+int mansy_vp_num_params(const mansy_vp_config* cfg);
+int mansy_vp_param_info(const mansy_vp_config* cfg, int idx, char* name, int name_len, long long* numel,
+                        int* ndim, long long shape[4]);
+size_t mansy_vp_workspace_bytes(const mansy_vp_config* cfg);
+/* named activation slabs inside the workspace (for parity tests / debugging) */
+int mansy_vp_ws_lookup(const mansy_vp_config* cfg, const char* name, long long* offset_bytes, long long* numel);
+
+/* src [B,S,in_ch], cur [B,in_ch] -> pred [B,T,in_ch].  train != 0: dropout (hash RNG keyed by seed)
+ * + BatchNorm batch statistics and running-stat update; train == 0: eval. */
+int mansy_vp_forward(const mansy_vp_config* cfg, const float* const* params, const float* pe, float* bn_running_mean,
+                     float* bn_running_var, long long* bn_num_batches, const float* src, const float* cur, float* pred,
+                     void* workspace, int train, uint32_t seed, void* stream);
+/* Accumulates (+=) parameter gradients of sum(pred * dpred) into grads[]; needs the workspace of the
+ * preceding train-mode forward with the same seed. */
+int mansy_vp_backward(const mansy_vp_config* cfg, const float* const* params, float* const* grads, const float* src,
+                      const float* dpred, void* workspace, uint32_t seed, void* stream);
+/* history [B,S,c], current [B,1,c] (c = in_ch/3) -> out [B,T,c]: heads replicated, eval forward,
+ * 3-head mean, wrap to [0,1] (mtio.py:106-133). */
+int mansy_vp_sample(const mansy_vp_config* cfg, const float* const* params, const float* pe, float* bn_running_mean,
+                    float* bn_running_var, const float* history, const float* current, float* out, void* workspace,
+                    void* stream);
+/* One training step (run_models.py:37-44): MTIO mix (perm1/perm2 device int32[B], NULL => replicate branch),
+ * zero grads, forward, MTIO loss, backward, AdamW over the flat parameter buffer.  params/grads point into
+ * flat_p/flat_g.  loss_out: device float.  step <= 0 skips the AdamW update (data-parallel callers all-reduce
+ * flat_g over RCCL first and then call mansy_adamw_step). */
+int mansy_vp_train_step(const mansy_vp_config* cfg, const float* const* params, float* const* grads, float* flat_p,
+                        float* flat_g, float* flat_m, float* flat_v, long long n_flat, const float* pe,
+                        float* bn_running_mean, float* bn_running_var, long long* bn_num_batches, const float* history,
+                        const float* current, const float* future, const int* perm1, const int* perm2, float lr,
+                        float beta1, float beta2, float eps, float weight_decay, int step, float* loss_out,
+                        void* workspace, uint32_t seed, void* stream);
+
+int mansy_mtio_mix(const float* x, const int* perm1, const int* perm2, float* out, int B, int L, int c, void* stream);
+/* loss = sum_heads mean_{B,T}( sum_xy e^2 / 2 ); dpred may be NULL.  scratch: 8 bytes device. */
+int mansy_mtio_loss_fwd_bwd(const float* pred, const float* gt, int B, int T, int C, double* scratch, float* loss_out,
+                            float* dpred, void* stream);
+int mansy_adamw_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                     float eps, float weight_decay, int step, int decoupled, void* stream);
+int mansy_ensemble_wrap(const float* pred, float* out, long long rows, int heads, int c, void* stream);
+
+/* ------------------------------------------------------------------ tile hit map */
+int mansy_tilemap(const float* xy, long long n, int W, int H, int tile_num_w, int tile_num_h, int fov_w, int fov_h,
+                  uint64_t* maps, void* stream);
+int mansy_tilemap_iou(const uint64_t* a, const uint64_t* b, long long n, double* iou, void* stream);
+int mansy_tilemap_or_groups(const uint64_t* maps, long long ngroups, int group, uint64_t* out, void* stream);
+
+/* ------------------------------------------------------------------ single kernels (unit-test surface) */
+typedef struct mansy_gemm_epilogue {
+  const float* bias; int relu; const float* mask_src; int mask_ld; float mask_scale;
+  float drop_p; uint32_t drop_seed; uint32_t drop_site; const float* resid; int resid_ld; int accumulate;
+} mansy_gemm_epilogue;
+int mansy_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb, int b_kmajor, float* C, int ldc,
+                   int M, int N, int K, const mansy_gemm_epilogue* ep, int force_tile, int force_splitk, void* stream);
+typedef struct mansy_attn_shape {
+  int nb, H, Lq, Lk, dh;
+  long long q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;
+  float scale;
+} mansy_attn_shape;
+int mansy_attn_fwd(const float* Q, const float* K, const float* V, float* O, float* P_save, const mansy_attn_shape* s,
+                   float drop_p, uint32_t seed, uint32_t site, void* stream);
+int mansy_attn_bwd(const float* Q, const float* K, const float* V, const float* P_save, const float* dO, float* dQ,
+                   float* dK, float* dV, const mansy_attn_shape* s, float drop_p, uint32_t seed, uint32_t site,
+                   int accum_kv, void* stream);
+int mansy_layernorm_fwd(const float* a, const float* b, const float* w, const float* bias, float* z_out, float* y,
+                        float* mean, float* rstd, int rows, int C, float eps, void* stream);
+int mansy_layernorm_bwd(const float* dy, const float* z, const float* mean, const float* rstd, const float* w, float* dz,
+                        float* dz_drop, float drop_p, uint32_t seed, uint32_t site, float* dw, float* dbias, int rows,
+                        int C, void* stream);
+
+/* ------------------------------------------------------------------ measurement hooks (bench.py) */
+/* HIP events around every GEMM launch on its own stream; collect() = device sync + summed ms, count, FLOPs. */
+int mansy_prof_gemm_enable(int on);
+int mansy_prof_gemm_collect(double* total_ms, long long* launches, double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

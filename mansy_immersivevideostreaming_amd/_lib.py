@@ -1,0 +1,101 @@
+"""ctypes binding of libmansy_hip.so (include/mansy_hip.h).  There is NO CPU fallback: if the
+library is missing or a call fails this raises."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libmansy_hip.so')
+
+c_int, c_float, c_void_p, c_ll, c_u32 = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_uint32
+
+
+class MansyError(RuntimeError):
+    pass
+
+
+class VPConfig(ctypes.Structure):
+    _fields_ = [(n, c_int) for n in ('B', 'S', 'T', 'd_model', 'n_head', 'd_ff', 'n_enc', 'n_dec', 'in_ch', 'has_bias')] + \
+               [(n, c_float) for n in ('p_pe', 'p_drop', 'ln_eps', 'bn_eps', 'bn_momentum')] + [('max_len', c_int)]
+
+
+class GemmEpilogue(ctypes.Structure):
+    _fields_ = [('bias', c_void_p), ('relu', c_int), ('mask_src', c_void_p), ('mask_ld', c_int), ('mask_scale', c_float),
+                ('drop_p', c_float), ('drop_seed', c_u32), ('drop_site', c_u32), ('resid', c_void_p), ('resid_ld', c_int),
+                ('accumulate', c_int)]
+
+
+class AttnShape(ctypes.Structure):
+    _fields_ = [(n, c_int) for n in ('nb', 'H', 'Lq', 'Lk', 'dh')] + \
+               [(n, c_ll) for n in ('q_bs', 'q_rs', 'k_bs', 'k_rs', 'v_bs', 'v_rs', 'o_bs', 'o_rs')] + [('scale', c_float)]
+
+
+# name -> argtypes (restype int unless listed in _RESTYPES); must list every symbol of include/mansy_hip.h
+P = c_void_p
+_PROTOS = {
+    'mansy_last_error': [],
+    'mansy_abi_version': [],
+    'mansy_vp_num_params': [P],
+    'mansy_vp_param_info': [P, c_int, ctypes.c_char_p, c_int, P, P, P],
+    'mansy_vp_workspace_bytes': [P],
+    'mansy_vp_ws_lookup': [P, ctypes.c_char_p, P, P],
+    'mansy_vp_forward': [P, P, P, P, P, P, P, P, P, P, c_int, c_u32, P],
+    'mansy_vp_backward': [P, P, P, P, P, P, c_u32, P],
+    'mansy_vp_sample': [P, P, P, P, P, P, P, P, P, P],
+    'mansy_vp_train_step': [P, P, P, P, P, P, P, c_ll, P, P, P, P, P, P, P, P, P, c_float, c_float, c_float, c_float,
+                            c_float, c_int, P, P, c_u32, P],
+    'mansy_mtio_mix': [P, P, P, P, c_int, c_int, c_int, P],
+    'mansy_mtio_loss_fwd_bwd': [P, P, c_int, c_int, c_int, P, P, P, P],
+    'mansy_adamw_step': [P, P, P, P, c_ll, c_float, c_float, c_float, c_float, c_float, c_int, c_int, P],
+    'mansy_ensemble_wrap': [P, P, c_ll, c_int, c_int, P],
+    'mansy_tilemap': [P, c_ll, c_int, c_int, c_int, c_int, c_int, c_int, P, P],
+    'mansy_tilemap_iou': [P, P, c_ll, P, P],
+    'mansy_tilemap_or_groups': [P, c_ll, c_int, P, P],
+    'mansy_gemm_f32': [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, P, c_int, c_int, P],
+    'mansy_attn_fwd': [P, P, P, P, P, P, c_float, c_u32, c_u32, P],
+    'mansy_attn_bwd': [P, P, P, P, P, P, P, P, P, c_float, c_u32, c_u32, c_int, P],
+    'mansy_layernorm_fwd': [P, P, P, P, P, P, P, P, c_int, c_int, c_float, P],
+    'mansy_layernorm_bwd': [P, P, P, P, P, P, P, c_float, c_u32, c_u32, P, P, c_int, c_int, P],
+    'mansy_prof_gemm_enable': [c_int],
+    'mansy_prof_gemm_collect': [P, P, P],
+}
+_RESTYPES = {'mansy_last_error': ctypes.c_char_p, 'mansy_vp_workspace_bytes': ctypes.c_size_t}
+
+_lib = None
+
+
+def declared_symbols():
+    return sorted(_PROTOS)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MansyError(
+                f'{LIB_PATH} not found: build it with `python -m mansy_immersivevideostreaming_amd.build_ext` '
+                '(there is no CPU fallback for the HIP path)')
+        L = ctypes.CDLL(LIB_PATH)
+        for name, args in _PROTOS.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = _RESTYPES.get(name, c_int)
+        _lib = L
+    return _lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = lib().mansy_last_error()
+        raise MansyError(f'{what} failed ({rc}): {msg.decode() if msg else ""}')
+
+
+def ptr(t):
+    """Device (or host) pointer of a torch tensor / None."""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,205 @@
+// Fused small-sequence multi-head attention (forward + backward) for the viewport Transformer:
+// encoder self-attention (S x S, S <= 16), KV-cached decoder self-attention (1 x (i+1)) and
+// cross-attention over the distilled memory (1 x M).  Reference arithmetic:
+// torch.nn.MultiheadAttention inside nn.Transformer{Encoder,Decoder}Layer:
+// softmax(Q K^T / sqrt(dh)) with attention-probability dropout, then P V.
+//
+// One 64-lane wavefront per (batch, head): everything lives in registers / a private LDS slice,
+// QK^T + softmax + dropout + PV in one kernel, no HBM round trip for the score matrix.
+// These blocks (<= 16x16x64) cannot fill an MFMA tile; the kernel is HBM/latency-bound and its
+// job is coalesced 256-byte row reads and zero extra traffic.
+#include "mansy_kernels.h"
+
+namespace {
+
+constexpr int LMAX = 16;
+constexpr int DH_LD = 65;            // padded row (floats) -> conflict-free column-strided reads
+constexpr int WAVES = 4;
+
+struct AttnPtrs {
+  const float* Q; const float* K; const float* V; float* O; float* P;
+  const float* dO; float* dQ; float* dK; float* dV;
+};
+
+__device__ __forceinline__ void load_rows(const float* base, long long rs, int L, int dh, int lane, float* lds) {
+  for (int i = 0; i < L; ++i)
+    if (lane < dh) lds[i * DH_LD + lane] = base[i * rs + lane];
+}
+
+__global__ __launch_bounds__(64 * WAVES) void attn_fwd_kernel(AttnPtrs p, AttnShape s, MansyDrop drop) {
+  __shared__ float sQ[WAVES][LMAX * DH_LD];
+  __shared__ float sK[WAVES][LMAX * DH_LD];
+  __shared__ float sP[WAVES][LMAX * (LMAX + 1)];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long bh = (long long)blockIdx.x * WAVES + wave;
+  const bool active = bh < (long long)s.nb * s.H;
+  const int b = active ? (int)(bh / s.H) : 0, h = active ? (int)(bh % s.H) : 0;
+  const int Lq = s.Lq, Lk = s.Lk, dh = s.dh;
+  const float* Qb = p.Q + b * s.q_bs + h * dh;
+  const float* Kb = p.K + b * s.k_bs + h * dh;
+  const float* Vb = p.V + b * s.v_bs + h * dh;
+  float* q_l = sQ[wave]; float* k_l = sK[wave]; float* p_l = sP[wave];
+  if (active) {
+    load_rows(Qb, s.q_rs, Lq, dh, lane, q_l);
+    load_rows(Kb, s.k_rs, Lk, dh, lane, k_l);
+  }
+  __syncthreads();
+  if (active) {
+    for (int pr = lane; pr < Lq * Lk; pr += 64) {
+      const int i = pr / Lk, j = pr % Lk;
+      float acc = 0.f;
+      for (int d = 0; d < dh; ++d) acc = fmaf(q_l[i * DH_LD + d], k_l[j * DH_LD + d], acc);
+      p_l[i * (LMAX + 1) + j] = acc * s.scale;
+    }
+  }
+  __syncthreads();
+  if (active && lane < Lq) {
+    const int i = lane;
+    float m = -INFINITY;
+    for (int j = 0; j < Lk; ++j) m = fmaxf(m, p_l[i * (LMAX + 1) + j]);
+    float sum = 0.f;
+    for (int j = 0; j < Lk; ++j) { const float e = expf(p_l[i * (LMAX + 1) + j] - m); p_l[i * (LMAX + 1) + j] = e; sum += e; }
+    const float inv = 1.f / sum;
+    const float ds = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
+    for (int j = 0; j < Lk; ++j) {
+      float pv = p_l[i * (LMAX + 1) + j] * inv;
+      const long long pidx = (bh * Lq + i) * Lk + j;
+      if (p.P) p.P[pidx] = pv;
+      if (drop.p > 0.f) pv = mansy_keep(drop.seed, drop.site, (uint32_t)pidx, drop.p) ? pv * ds : 0.f;
+      p_l[i * (LMAX + 1) + j] = pv;
+    }
+  }
+  __syncthreads();
+  if (active && lane < dh) {
+    float v[LMAX];
+#pragma unroll
+    for (int j = 0; j < LMAX; ++j) v[j] = j < Lk ? Vb[j * s.v_rs + lane] : 0.f;
+    float* Ob = p.O + b * s.o_bs + h * dh;
+    for (int i = 0; i < Lq; ++i) {
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < LMAX; ++j) if (j < Lk) acc = fmaf(p_l[i * (LMAX + 1) + j], v[j], acc);
+      Ob[i * s.o_rs + lane] = acc;
+    }
+  }
+}
+
+__global__ __launch_bounds__(64 * WAVES) void attn_bwd_kernel(AttnPtrs p, AttnShape s, MansyDrop drop, int accum_kv) {
+  __shared__ float sA[WAVES][LMAX * DH_LD];   // dO rows
+  __shared__ float sB[WAVES][LMAX * DH_LD];   // V rows
+  __shared__ float sP[WAVES][LMAX * (LMAX + 1)];    // P (pre-dropout)
+  __shared__ float sD[WAVES][LMAX * (LMAX + 1)];    // dropped P, later dS
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long bh = (long long)blockIdx.x * WAVES + wave;
+  const bool active = bh < (long long)s.nb * s.H;
+  const int b = active ? (int)(bh / s.H) : 0, h = active ? (int)(bh % s.H) : 0;
+  const int Lq = s.Lq, Lk = s.Lk, dh = s.dh;
+  const float* Qb = p.Q + b * s.q_bs + h * dh;
+  const float* Kb = p.K + b * s.k_bs + h * dh;
+  const float* Vb = p.V + b * s.v_bs + h * dh;
+  const float* dOb = p.dO + b * s.o_bs + h * dh;
+  float* do_l = sA[wave]; float* v_l = sB[wave]; float* p_l = sP[wave]; float* d_l = sD[wave];
+  const float ds = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
+  if (active) {
+    load_rows(dOb, s.o_rs, Lq, dh, lane, do_l);
+    load_rows(Vb, s.v_rs, Lk, dh, lane, v_l);
+    for (int pr = lane; pr < Lq * Lk; pr += 64) {
+      const int i = pr / Lk, j = pr % Lk;
+      const long long pidx = (bh * Lq + i) * Lk + j;
+      const float pv = p.P[pidx];
+      p_l[i * (LMAX + 1) + j] = pv;
+      float keepf = 1.f;
+      if (drop.p > 0.f) keepf = mansy_keep(drop.seed, drop.site, (uint32_t)pidx, drop.p) ? ds : 0.f;
+      d_l[i * (LMAX + 1) + j] = pv * keepf;    // dropped probabilities (for dV)
+    }
+  }
+  __syncthreads();
+  // dV[j][d] = sum_i Pd[i][j] dO[i][d]
+  if (active && lane < dh) {
+    float* dVb = p.dV + b * s.v_bs + h * dh;
+    for (int j = 0; j < Lk; ++j) {
+      float acc = 0.f;
+      for (int i = 0; i < Lq; ++i) acc = fmaf(d_l[i * (LMAX + 1) + j], do_l[i * DH_LD + lane], acc);
+      float* dst = dVb + j * s.v_rs + lane;
+      *dst = accum_kv ? *dst + acc : acc;
+    }
+  }
+  __syncthreads();
+  // dPd[i][j] = sum_d dO[i][d] V[j][d] ; dP = dPd * keep
+  if (active) {
+    for (int pr = lane; pr < Lq * Lk; pr += 64) {
+      const int i = pr / Lk, j = pr % Lk;
+      float acc = 0.f;
+      for (int d = 0; d < dh; ++d) acc = fmaf(do_l[i * DH_LD + d], v_l[j * DH_LD + d], acc);
+      float keepf = 1.f;
+      if (drop.p > 0.f) keepf = mansy_keep(drop.seed, drop.site, (uint32_t)((bh * Lq + i) * Lk + j), drop.p) ? ds : 0.f;
+      d_l[i * (LMAX + 1) + j] = acc * keepf;   // dP (wrt pre-dropout probabilities)
+    }
+  }
+  __syncthreads();
+  if (active && lane < Lq) {
+    const int i = lane;
+    float delta = 0.f;
+    for (int j = 0; j < Lk; ++j) delta = fmaf(p_l[i * (LMAX + 1) + j], d_l[i * (LMAX + 1) + j], delta);
+    for (int j = 0; j < Lk; ++j)
+      d_l[i * (LMAX + 1) + j] = p_l[i * (LMAX + 1) + j] * (d_l[i * (LMAX + 1) + j] - delta) * s.scale;   // dS
+  }
+  __syncthreads();
+  if (active && lane < dh) {
+    float kq[LMAX];
+    // dQ[i][d] = sum_j dS[i][j] K[j][d]
+#pragma unroll
+    for (int j = 0; j < LMAX; ++j) kq[j] = j < Lk ? Kb[j * s.k_rs + lane] : 0.f;
+    float* dQb = p.dQ + b * s.q_bs + h * dh;
+    for (int i = 0; i < Lq; ++i) {
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < LMAX; ++j) if (j < Lk) acc = fmaf(d_l[i * (LMAX + 1) + j], kq[j], acc);
+      dQb[i * s.q_rs + lane] = acc;
+    }
+    // dK[j][d] = sum_i dS[i][j] Q[i][d]
+#pragma unroll
+    for (int i = 0; i < LMAX; ++i) kq[i] = i < Lq ? Qb[i * s.q_rs + lane] : 0.f;
+    float* dKb = p.dK + b * s.k_bs + h * dh;
+    for (int j = 0; j < Lk; ++j) {
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < LMAX; ++i) if (i < Lq) acc = fmaf(d_l[i * (LMAX + 1) + j], kq[i], acc);
+      float* dst = dKb + j * s.k_rs + lane;
+      *dst = accum_kv ? *dst + acc : acc;
+    }
+  }
+}
+
+int check_shape(const AttnShape& s) {
+  MANSY_REQUIRE(s.Lq >= 1 && s.Lq <= LMAX && s.Lk >= 1 && s.Lk <= LMAX, "attn: sequence length %d x %d outside [1,%d]", s.Lq, s.Lk, LMAX);
+  MANSY_REQUIRE(s.dh >= 1 && s.dh <= 64, "attn: head dim %d outside [1,64]", s.dh);
+  MANSY_REQUIRE(s.nb >= 0 && s.H >= 1, "attn: bad batch/head count");
+  return MANSY_OK;
+}
+
+}  // namespace
+
+int mansy_launch_attn_fwd(const float* Q, const float* K, const float* V, float* O, float* P_save, const AttnShape& s,
+                          MansyDrop drop, hipStream_t st) {
+  int rc = check_shape(s); if (rc) return rc;
+  MANSY_REQUIRE(Q && K && V && O, "attn_fwd: null pointer");
+  const long long n = (long long)s.nb * s.H;
+  if (n == 0) return MANSY_OK;
+  AttnPtrs p = {Q, K, V, O, P_save, nullptr, nullptr, nullptr, nullptr};
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(mansy_ceil_div(n, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop);
+  MANSY_LAUNCH_CHECK();
+  return MANSY_OK;
+}
+
+int mansy_launch_attn_bwd(const float* Q, const float* K, const float* V, const float* P_save, const float* dO, float* dQ,
+                          float* dK, float* dV, const AttnShape& s, MansyDrop drop, int accum_kv, hipStream_t st) {
+  int rc = check_shape(s); if (rc) return rc;
+  MANSY_REQUIRE(Q && K && V && P_save && dO && dQ && dK && dV, "attn_bwd: null pointer");
+  const long long n = (long long)s.nb * s.H;
+  if (n == 0) return MANSY_OK;
+  AttnPtrs p = {Q, K, V, nullptr, const_cast<float*>(P_save), dO, dQ, dK, dV};
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(mansy_ceil_div(n, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop, accum_kv);
+  MANSY_LAUNCH_CHECK();
+  return MANSY_OK;
+}

@@ -1,0 +1,91 @@
+// C-ABI shims (include/mansy_hip.h) over the C++ launch API, plus error reporting.
+#include <stdarg.h>
+#include "mansy_kernels.h"
+#include "../../include/mansy_hip.h"
+
+static thread_local char g_err[1024] = "";
+
+extern "C" void mansy_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" {
+
+const char* mansy_last_error(void) { return g_err; }
+int mansy_abi_version(void) { return 1; }
+
+int mansy_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb, int b_kmajor, float* C, int ldc, int M, int N,
+                   int K, const mansy_gemm_epilogue* ep, int force_tile, int force_splitk, void* stream) {
+  GemmEpilogue e;
+  if (ep) {
+    e.bias = ep->bias; e.relu = ep->relu; e.mask_src = ep->mask_src; e.mask_ld = ep->mask_ld; e.mask_scale = ep->mask_scale;
+    e.drop.p = ep->drop_p; e.drop.seed = ep->drop_seed; e.drop.site = ep->drop_site;
+    e.resid = ep->resid; e.resid_ld = ep->resid_ld; e.accumulate = ep->accumulate;
+  }
+  MANSY_REQUIRE(force_tile == 0 || force_tile == 64 || force_tile == 128, "gemm: force_tile must be 0, 64 or 128");
+  return mansy_launch_gemm_f32(A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, e, force_tile, force_splitk, (hipStream_t)stream);
+}
+
+static AttnShape to_shape(const mansy_attn_shape* s) {
+  AttnShape a;
+  a.nb = s->nb; a.H = s->H; a.Lq = s->Lq; a.Lk = s->Lk; a.dh = s->dh;
+  a.q_bs = s->q_bs; a.q_rs = s->q_rs; a.k_bs = s->k_bs; a.k_rs = s->k_rs; a.v_bs = s->v_bs; a.v_rs = s->v_rs;
+  a.o_bs = s->o_bs; a.o_rs = s->o_rs; a.scale = s->scale;
+  return a;
+}
+
+int mansy_attn_fwd(const float* Q, const float* K, const float* V, float* O, float* P_save, const mansy_attn_shape* s, float drop_p,
+                   uint32_t seed, uint32_t site, void* stream) {
+  MANSY_REQUIRE(s, "attn_fwd: null shape");
+  MansyDrop d = {drop_p, seed, site};
+  return mansy_launch_attn_fwd(Q, K, V, O, P_save, to_shape(s), d, (hipStream_t)stream);
+}
+int mansy_attn_bwd(const float* Q, const float* K, const float* V, const float* P_save, const float* dO, float* dQ, float* dK,
+                   float* dV, const mansy_attn_shape* s, float drop_p, uint32_t seed, uint32_t site, int accum_kv, void* stream) {
+  MANSY_REQUIRE(s, "attn_bwd: null shape");
+  MansyDrop d = {drop_p, seed, site};
+  return mansy_launch_attn_bwd(Q, K, V, P_save, dO, dQ, dK, dV, to_shape(s), d, accum_kv, (hipStream_t)stream);
+}
+int mansy_layernorm_fwd(const float* a, const float* b, const float* w, const float* bias, float* z_out, float* y, float* mean,
+                        float* rstd, int rows, int C, float eps, void* stream) {
+  return mansy_launch_layernorm_fwd(a, b, w, bias, z_out, y, mean, rstd, rows, C, eps, (hipStream_t)stream);
+}
+int mansy_layernorm_bwd(const float* dy, const float* z, const float* mean, const float* rstd, const float* w, float* dz,
+                        float* dz_drop, float drop_p, uint32_t seed, uint32_t site, float* dw, float* dbias, int rows, int C,
+                        void* stream) {
+  MansyDrop d = {drop_p, seed, site};
+  return mansy_launch_layernorm_bwd(dy, z, mean, rstd, w, dz, dz_drop, d, dw, dbias, rows, C, (hipStream_t)stream);
+}
+
+int mansy_mtio_mix(const float* x, const int* perm1, const int* perm2, float* out, int B, int L, int c, void* stream) {
+  return mansy_launch_mtio_mix(x, perm1, perm2, out, B, L, c, (hipStream_t)stream);
+}
+int mansy_mtio_loss_fwd_bwd(const float* pred, const float* gt, int B, int T, int C, double* scratch, float* loss_out, float* dpred,
+                            void* stream) {
+  MANSY_REQUIRE(B >= 1 && T >= 1 && C >= 1, "mtio_loss: bad shape");
+  return mansy_launch_mtio_loss(pred, gt, (long long)B * T * C, 1.f / (2.f * (float)B * (float)T), scratch, loss_out, dpred,
+                                (hipStream_t)stream);
+}
+int mansy_adamw_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, int step, int decoupled, void* stream) {
+  return mansy_launch_adamw(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, decoupled, (hipStream_t)stream);
+}
+int mansy_ensemble_wrap(const float* pred, float* out, long long rows, int heads, int c, void* stream) {
+  return mansy_launch_ensemble_wrap(pred, out, rows, heads, c, (hipStream_t)stream);
+}
+
+int mansy_tilemap(const float* xy, long long n, int W, int H, int tile_num_w, int tile_num_h, int fov_w, int fov_h, uint64_t* maps,
+                  void* stream) {
+  return mansy_launch_tilemap(xy, n, W, H, tile_num_w, tile_num_h, fov_w, fov_h, (unsigned long long*)maps, (hipStream_t)stream);
+}
+int mansy_tilemap_iou(const uint64_t* a, const uint64_t* b, long long n, double* iou, void* stream) {
+  return mansy_launch_tilemap_iou((const unsigned long long*)a, (const unsigned long long*)b, n, iou, (hipStream_t)stream);
+}
+int mansy_tilemap_or_groups(const uint64_t* maps, long long ngroups, int group, uint64_t* out, void* stream) {
+  return mansy_launch_tilemap_or_groups((const unsigned long long*)maps, ngroups, group, (unsigned long long*)out, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,292 @@
+// Exact-fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32), LDS-tiled, with fused
+// epilogues.  This is the MFMA-bound kernel of the viewport-prediction Transformer
+// (reference arithmetic: torch.nn.Transformer Linear layers).
+//
+// Block: 256 threads = 4 waves (2x2), tile BM x BN in {128x128, 64x64}, BK = 32.
+// Each wave owns a (BM/2) x (BN/2) sub-tile = TM x TN MFMA blocks of 32x32.
+// LDS images keep the global orientation of each operand (no transposes on the way in):
+//   K-contiguous operand  -> tile[rows][BK+4]   (fragments read as 2 x ds_read_b128 per 8 k)
+//   K-major operand       -> tile[BK][rows+4]   (fragments read with ds_read_b32, conflict-free)
+// The 32x32x2 MFMA consumes k = {0,1} from lane halves h = lane>>5; because the sum over k is
+// order-free as long as A and B agree, lane half h is given k in [16h, 16h+16) of the BK block,
+// so a K-contiguous fragment is 16 consecutive floats of one LDS row.
+// Global->LDS staging is register double-buffered (loads for tile t+1 issued before the MFMAs of
+// tile t, written to the other LDS buffer afterwards): one barrier per K-tile.
+#include <vector>
+#include "mansy_kernels.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int KC_LD = BK + 4;   // K-contiguous LDS row stride (floats)
+constexpr int NT = 256;
+
+struct GemmParams {
+  const float* A; const float* B; float* C;
+  int lda, ldb, ldc;
+  int M, N, K;
+  int k_per_split;
+  int vec_ok;
+  GemmEpilogue ep;
+};
+
+template <int R, bool KMAJ>
+struct TileGeom {
+  static constexpr int LOADS = R * BK / 4 / NT;                    // float4 per thread
+  static constexpr int LDS_FLOATS = KMAJ ? BK * (R + 4) : R * KC_LD;
+};
+
+// Load one operand tile (R rows x BK k) into registers with bounds guards.
+template <int R, bool KMAJ>
+__device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, int row0, int nrows, int k0, int k_end,
+                                          float4 (&reg)[TileGeom<R, KMAJ>::LOADS], int tid, int vec_ok) {
+#pragma unroll
+  for (int i = 0; i < TileGeom<R, KMAJ>::LOADS; ++i) {
+    const int idx = tid + i * NT;
+    int gr, gk0;            // global row / first k of this float4 (K-contig) or k row / first col (K-major)
+    long long off;
+    int lim_inner, inner0;  // bounds on the contiguous axis
+    bool outer_ok;
+    if (!KMAJ) {
+      const int r = idx >> 3, c4 = idx & 7;
+      gr = row0 + r; gk0 = k0 + c4 * 4;
+      off = (long long)gr * ld + gk0;
+      outer_ok = gr < nrows; inner0 = gk0; lim_inner = k_end;
+    } else {
+      constexpr int C4 = R / 4;
+      const int kr = idx / C4, c4 = idx % C4;
+      gk0 = k0 + kr; gr = row0 + c4 * 4;
+      off = (long long)gk0 * ld + gr;
+      outer_ok = gk0 < k_end; inner0 = gr; lim_inner = nrows;
+    }
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (outer_ok) {
+      if (vec_ok && inner0 + 3 < lim_inner) {
+        v = *reinterpret_cast<const float4*>(P + off);
+      } else {
+        if (inner0 + 0 < lim_inner) v.x = P[off + 0];
+        if (inner0 + 1 < lim_inner) v.y = P[off + 1];
+        if (inner0 + 2 < lim_inner) v.z = P[off + 2];
+        if (inner0 + 3 < lim_inner) v.w = P[off + 3];
+      }
+    }
+    reg[i] = v;
+  }
+}
+
+template <int R, bool KMAJ>
+__device__ __forceinline__ void store_tile(float* __restrict__ lds, const float4 (&reg)[TileGeom<R, KMAJ>::LOADS], int tid) {
+#pragma unroll
+  for (int i = 0; i < TileGeom<R, KMAJ>::LOADS; ++i) {
+    const int idx = tid + i * NT;
+    if (!KMAJ) {
+      const int r = idx >> 3, c4 = idx & 7;
+      *reinterpret_cast<float4*>(lds + r * KC_LD + c4 * 4) = reg[i];
+    } else {
+      constexpr int C4 = R / 4;
+      const int kr = idx / C4, c4 = idx % C4;
+      *reinterpret_cast<float4*>(lds + kr * (R + 4) + c4 * 4) = reg[i];
+    }
+  }
+}
+
+// Read an 8-k fragment chunk for one 32-row MFMA block: out[kk] = tile(row = rb + r, k = 16h + 8*chunk + kk)
+template <int R, bool KMAJ>
+__device__ __forceinline__ void read_frag(const float* __restrict__ lds, int rb, int r, int h, int chunk, float (&out)[8]) {
+  if (!KMAJ) {
+    const float4* p = reinterpret_cast<const float4*>(lds + (rb + r) * KC_LD + h * 16 + chunk * 8);
+    const float4 v0 = p[0], v1 = p[1];
+    out[0] = v0.x; out[1] = v0.y; out[2] = v0.z; out[3] = v0.w;
+    out[4] = v1.x; out[5] = v1.y; out[6] = v1.z; out[7] = v1.w;
+  } else {
+    const float* p = lds + (h * 16 + chunk * 8) * (R + 4) + rb + r;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) out[kk] = p[kk * (R + 4)];
+  }
+}
+
+template <int BM, int BN, bool AK, bool BKM>
+__global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmParams p) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int A_FLOATS = TileGeom<BM, AK>::LDS_FLOATS;
+  constexpr int B_FLOATS = TileGeom<BN, BKM>::LDS_FLOATS;
+  __shared__ __attribute__((aligned(16))) float smem[2 * (A_FLOATS + B_FLOATS)];
+  constexpr int STAGE = A_FLOATS + B_FLOATS;   // stage s: A at smem + s*STAGE, B right after it
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int k_begin = blockIdx.z * p.k_per_split;
+  const int k_end = min(p.K, k_begin + p.k_per_split);
+  const int nk = (k_end - k_begin + BK - 1) / BK;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  float4 ra[TileGeom<BM, AK>::LOADS], rb[TileGeom<BN, BKM>::LOADS];
+  if (nk > 0) {
+    load_tile<BM, AK>(p.A, p.lda, m0, p.M, k_begin, k_end, ra, tid, p.vec_ok);
+    load_tile<BN, BKM>(p.B, p.ldb, n0, p.N, k_begin, k_end, rb, tid, p.vec_ok);
+    store_tile<BM, AK>(smem, ra, tid);
+    store_tile<BN, BKM>(smem + A_FLOATS, rb, tid);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      const int k0 = k_begin + (kt + 1) * BK;
+      load_tile<BM, AK>(p.A, p.lda, m0, p.M, k0, k_end, ra, tid, p.vec_ok);
+      load_tile<BN, BKM>(p.B, p.ldb, n0, p.N, k0, k_end, rb, tid, p.vec_ok);
+    }
+    const float* a_l = smem + cur * STAGE;
+    const float* b_l = a_l + A_FLOATS;
+#pragma unroll
+    for (int chunk = 0; chunk < 2; ++chunk) {
+      float af[TM][8], bf[TN][8];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) read_frag<BM, AK>(a_l, wm * (BM / 2) + i * 32, r, h, chunk, af[i]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) read_frag<BN, BKM>(b_l, wn * (BN / 2) + j * 32, r, h, chunk, bf[j]);
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      store_tile<BM, AK>(smem + (cur ^ 1) * STAGE, ra, tid);
+      store_tile<BN, BKM>(smem + (cur ^ 1) * STAGE + A_FLOATS, rb, tid);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  const GemmEpilogue& ep = p.ep;
+  const bool atomic = ep.accumulate || gridDim.z > 1;
+  const float drop_scale = ep.drop.p > 0.f ? 1.f / (1.f - ep.drop.p) : 1.f;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * (BN / 2) + j * 32 + r;
+      if (col >= p.N) continue;
+      const float bias = ep.bias ? ep.bias[col] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (row >= p.M) continue;
+        float v = acc[i][j][e] + bias;
+        if (ep.relu) v = fmaxf(v, 0.f);
+        if (ep.mask_src) v = ep.mask_src[(long long)row * ep.mask_ld + col] > 0.f ? v * ep.mask_scale : 0.f;
+        if (ep.drop.p > 0.f)
+          v = mansy_keep(ep.drop.seed, ep.drop.site, (uint32_t)row * (uint32_t)p.N + (uint32_t)col, ep.drop.p) ? v * drop_scale : 0.f;
+        if (ep.resid) v += ep.resid[(long long)row * ep.resid_ld + col];
+        float* dst = p.C + (long long)row * p.ldc + col;
+        if (atomic) atomicAdd(dst, v); else *dst = v;
+      }
+    }
+  }
+}
+
+template <int BM, int BN>
+int launch_cfg(const GemmParams& p, int a_kmajor, int b_kmajor, int splits, hipStream_t st) {
+  dim3 grid(mansy_ceil_div(p.N, BN), mansy_ceil_div(p.M, BM), splits);
+  dim3 block(NT);
+  if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false>), grid, block, 0, st, p);
+  else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true>), grid, block, 0, st, p);
+  else if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, true>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false>), grid, block, 0, st, p);
+  MANSY_LAUNCH_CHECK();
+  return MANSY_OK;
+}
+
+// ---- optional launch timing (bench.py roofline leg): HIP events around every GEMM launch
+struct ProfState {
+  bool on = false;
+  std::vector<hipEvent_t> ev;     // pairs
+  size_t used = 0;
+  double flops = 0.0;
+};
+ProfState g_prof;
+
+}  // namespace
+
+extern "C" int mansy_prof_gemm_enable(int on) {
+  g_prof.on = on != 0;
+  g_prof.used = 0;
+  g_prof.flops = 0.0;
+  return MANSY_OK;
+}
+// Synchronises the device, returns the summed duration (ms) of the GEMM launches recorded since enable,
+// their count and their exact FLOPs (2*M*N*K each); resets the recorder.
+extern "C" int mansy_prof_gemm_collect(double* total_ms, long long* launches, double* flops) {
+  MANSY_HIP_CHECK(hipDeviceSynchronize());
+  double ms = 0.0;
+  for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+    float t = 0.f;
+    MANSY_HIP_CHECK(hipEventElapsedTime(&t, g_prof.ev[i], g_prof.ev[i + 1]));
+    ms += t;
+  }
+  if (total_ms) *total_ms = ms;
+  if (launches) *launches = (long long)(g_prof.used / 2);
+  if (flops) *flops = g_prof.flops;
+  g_prof.used = 0;
+  g_prof.flops = 0.0;
+  return MANSY_OK;
+}
+
+static int gemm_dispatch(const GemmParams& p, int tile, int a_kmajor, int b_kmajor, int splits, hipStream_t st) {
+  if (tile == 128) return launch_cfg<128, 128>(p, a_kmajor, b_kmajor, splits, st);
+  return launch_cfg<64, 64>(p, a_kmajor, b_kmajor, splits, st);
+}
+
+int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb, int b_kmajor, float* C, int ldc,
+                          int M, int N, int K, const GemmEpilogue& ep, int force_tile, int force_splitk, hipStream_t st) {
+  MANSY_REQUIRE(A && B && C, "gemm: null pointer");
+  MANSY_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm: negative dimension");
+  if (M == 0 || N == 0) return MANSY_OK;
+  GemmParams p;
+  p.A = A; p.B = B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.ep = ep;
+  p.vec_ok = ((lda % 4) == 0) && ((ldb % 4) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
+             ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+  // tile choice: 128x128 when it alone fills the chip, else 64x64
+  const long long t128 = (long long)mansy_ceil_div(M, 128) * mansy_ceil_div(N, 128);
+  int tile = force_tile ? force_tile : (t128 >= 192 ? 128 : 64);
+  const long long tiles = tile == 128 ? t128 : (long long)mansy_ceil_div(M, 64) * mansy_ceil_div(N, 64);
+  // split-K only for plain accumulating products (dW = dY^T X): partial sums are atomically added
+  int splits = 1;
+  const bool plain = !ep.bias && !ep.relu && !ep.mask_src && ep.drop.p == 0.f && !ep.resid;
+  if (force_splitk > 0) splits = force_splitk;
+  else if (plain && ep.accumulate && tiles < 256) {
+    splits = (int)((512 + tiles - 1) / tiles);
+    const int max_splits = K / (BK * 8) > 0 ? K / (BK * 8) : 1;
+    if (splits > max_splits) splits = max_splits;
+  }
+  MANSY_REQUIRE(splits == 1 || plain, "gemm: split-K requires a plain epilogue");
+  int kps = mansy_ceil_div(mansy_ceil_div(K, splits), BK) * BK;
+  if (kps <= 0) kps = BK;
+  splits = K > 0 ? mansy_ceil_div(K, kps) : 1;
+  p.k_per_split = kps;
+  if (!g_prof.on) return gemm_dispatch(p, tile, a_kmajor, b_kmajor, splits, st);
+  if (g_prof.used + 2 > g_prof.ev.size()) {
+    for (int i = 0; i < 2; ++i) { hipEvent_t e; MANSY_HIP_CHECK(hipEventCreate(&e)); g_prof.ev.push_back(e); }
+  }
+  MANSY_HIP_CHECK(hipEventRecord(g_prof.ev[g_prof.used], st));
+  const int rc = gemm_dispatch(p, tile, a_kmajor, b_kmajor, splits, st);
+  MANSY_HIP_CHECK(hipEventRecord(g_prof.ev[g_prof.used + 1], st));
+  g_prof.used += 2;
+  g_prof.flops += 2.0 * (double)M * (double)N * (double)K;
+  return rc;
+}

@@ -1,0 +1,117 @@
+// Internal C++ launch API shared by the engine (vp_engine.hip, ppo_engine.hip) and the
+// C-ABI test shims (capi.hip).  Every function enqueues on `st` and returns a MANSY_* status.
+#pragma once
+#include "mansy_common.h"
+
+// ---------------------------------------------------------------- GEMM (gemm_f32.hip)
+// C[M,N] (+)= A[M,K] * B[K,N] in exact fp32 on v_mfma_f32_32x32x2_f32.
+//   a_kmajor == 0: A(m,k) at A[m*lda + k]      (row-major [M,K],  "K-contiguous")
+//   a_kmajor == 1: A(m,k) at A[k*lda + m]      (row-major [K,M],  i.e. A^T stored)
+//   b_kmajor == 0: B(k,n) at B[n*ldb + k]      (row-major [N,K],  torch Linear weight)
+//   b_kmajor == 1: B(k,n) at B[k*ldb + n]      (row-major [K,N])
+// Epilogue order: +bias[n] -> relu -> mask (mask_src[m,n] > 0 ? v*mask_scale : 0)
+//                 -> dropout(site, idx = m*N+n) -> +resid[m,n] -> store / atomicAdd.
+struct GemmEpilogue {
+  const float* bias = nullptr;
+  int relu = 0;
+  const float* mask_src = nullptr;
+  int mask_ld = 0;
+  float mask_scale = 1.f;
+  MansyDrop drop = {0.f, 0u, 0u};
+  const float* resid = nullptr;
+  int resid_ld = 0;
+  int accumulate = 0;   // C += result (atomicAdd); forced when split-K > 1
+};
+int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb, int b_kmajor,
+                          float* C, int ldc, int M, int N, int K, const GemmEpilogue& ep, int force_tile,
+                          int force_splitk, hipStream_t st);
+
+// ---------------------------------------------------------------- attention (attn.hip)
+struct AttnShape {
+  int nb;          // batch entries
+  int H;           // heads
+  int Lq, Lk;      // <= 16 each
+  int dh;          // <= 64
+  // strides in floats: element (b, row, h, d) at base + b*bs + row*rs + h*dh + d
+  long long q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;
+  float scale;
+};
+// P_save: [nb*H, Lq, Lk] softmax probabilities BEFORE dropout (needed by backward); may be null in eval.
+int mansy_launch_attn_fwd(const float* Q, const float* K, const float* V, float* O, float* P_save,
+                          const AttnShape& s, MansyDrop drop, hipStream_t st);
+// dQ is overwritten; dK/dV are accumulated (+=) when accum_kv != 0, else overwritten.
+// dq/dk/dv use the q/k/v strides of `s`; dO uses the o strides.
+int mansy_launch_attn_bwd(const float* Q, const float* K, const float* V, const float* P_save, const float* dO,
+                          float* dQ, float* dK, float* dV, const AttnShape& s, MansyDrop drop, int accum_kv,
+                          hipStream_t st);
+
+// ---------------------------------------------------------------- norms (norm.hip)
+// z = a (+ b);  y = LN(z) * w (+ bias).  z_out may be null (not saved) or alias a when b == null.
+int mansy_launch_layernorm_fwd(const float* a, const float* b, const float* w, const float* bias, float* z_out,
+                               float* y, float* mean, float* rstd, int rows, int C, float eps, hipStream_t st);
+// dz = LN'(dy); dz_drop (optional) = dz * dropout-mask(drop) ; dw += sum dy*xhat ; dbias += sum dy.
+// add_to (optional): dz += add_to (an extra gradient flowing into z's consumers' sum), applied before outputs.
+int mansy_launch_layernorm_bwd(const float* dy, const float* z, const float* mean, const float* rstd, const float* w,
+                               float* dz, float* dz_drop, MansyDrop drop, float* dw, float* dbias, int rows, int C,
+                               hipStream_t st);
+
+// BatchNorm1d(train) + ELU + MaxPool1d(3,2,1) of the DistillLayer on conv output [B*S, C].
+struct DistillShape { int B, S, M, C; };
+// stats_d: device scratch of 4*C doubles (sum, sumsq, and 2 for backward); zeroed by the launcher.
+int mansy_launch_distill_fwd(const float* conv, const float* bn_w, const float* bn_b, float* run_mean, float* run_var,
+                             long long* num_batches, float* mean_out, float* rstd_out, float* mem, unsigned char* argmax,
+                             double* stats_d, const DistillShape& s, int train, float eps, float momentum,
+                             hipStream_t st);
+// dconv [B*S,C] from dmem [B*M,C]; dbn_w/dbn_b accumulated (+=).  g_tmp: [B*S,C] scratch.
+int mansy_launch_distill_bwd(const float* conv, const float* dmem, const unsigned char* argmax, const float* bn_w,
+                             const float* bn_b, const float* mean, const float* rstd, float* g_tmp, float* dconv,
+                             float* dbn_w, float* dbn_b, double* stats_d, const DistillShape& s, hipStream_t st);
+
+// ---------------------------------------------------------------- elementwise (elementwise.hip)
+// out[r, c] = sum_k x[r,k] W[c,k] + b[c] + pe[pos(r), c], dropout(site, r*C+c).
+// pos(r) = pos_fixed if pos_fixed >= 0 else (r % S).
+int mansy_launch_embed_fwd(const float* x, int in_ch, const float* W, const float* b, const float* pe, float* out,
+                           int rows, int C, int S, int pos_fixed, MansyDrop drop, hipStream_t st);
+// dE = dX * dropmask (stored, for the deferred dW) ; dtok[r,k] = sum_c dE[r,c] W[c,k]  (dtok may be null)
+int mansy_launch_embed_bwd(const float* dX, const float* W, float* dE, float* dtok, int in_ch, int rows, int C,
+                           MansyDrop drop, hipStream_t st);
+// out[c*small_n + k] (c_major=1) or out[k*C + c] (c_major=0)  +=  sum_r small[r,k] * big[r,c]; bsum[...] += sums.
+//   embed:     small = tok [R,6],  big = dE [R,C]   -> dW[C,6] (c_major=1), db[C]  = sum_r big[r,c]
+//   predictor: small = dz  [R,6],  big = h  [R,C]   -> dW[6,C] (c_major=0), db[6]  = sum_r small[r,k]
+int mansy_launch_outer_reduce(const float* small_, int small_n, const float* big, int rows, int C, float* out,
+                              int c_major, float* bsum_big, float* bsum_small, hipStream_t st);
+// y[r,k] = sigmoid(sum_c h[r,c] W[k,c] + b[k]); written to y_a[r*ya_stride + k] and (optional) y_b likewise.
+int mansy_launch_predictor_fwd(const float* h, const float* W, const float* b, float* y_a, long long ya_stride,
+                               float* y_b, long long yb_stride, int rows, int C, int out_ch, hipStream_t st);
+// dz[r,k] = (dy_a[r*sa+k] + (dy_b ? dy_b[r*sb+k] : 0)) * y(1-y) ; dh[r,c] = sum_k dz[r,k] W[k,c]
+int mansy_launch_predictor_bwd(const float* dy_a, long long sa, const float* dy_b, long long sb, const float* y,
+                               long long sy, const float* W, float* dz, float* dh, int rows, int C, int out_ch,
+                               hipStream_t st);
+// MTIO loss (mtio.py:94-104): loss = 1/(2*B*T) * sum e^2 over [n] elements, e = periodic distance; dpred optional.
+int mansy_launch_mtio_loss(const float* pred, const float* gt, long long n, float inv_2bt, double* loss_accum,
+                           float* loss_out, float* dpred, hipStream_t st);
+int mansy_launch_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2,
+                       float eps, float wd, int step, int decoupled, hipStream_t st);
+// im2col for the circular k=3 conv: col[b*S+s, ci*3+t] = x[b, (s+t-1) mod S, ci]
+int mansy_launch_im2col3(const float* x, float* col, int B, int S, int C, hipStream_t st);
+// dx[b,s,ci] = sum_t dcol[b, (s-t+1) mod S, ci*3+t]
+int mansy_launch_col2im3(const float* dcol, float* dx, int B, int S, int C, hipStream_t st);
+// colsum: out[c] += sum_r x[r*ld + c]
+int mansy_launch_colsum(const float* x, int ld, int rows, int C, float* out, hipStream_t st);
+// y = a + b (n floats)
+int mansy_launch_add(const float* a, const float* b, float* y, long long n, hipStream_t st);
+// MTIO channel mix (mtio.py:72-90): out[b, l, k*c + j] = x[perm_k[b], l, j] ; perm null => identity
+int mansy_launch_mtio_mix(const float* x, const int* perm1, const int* perm2, float* out, int B, int L, int c,
+                          hipStream_t st);
+// ensemble mean over heads + wrap to [0,1] (mtio.py:125-133, utils/common.py:61-70): pred [B,T,heads*c] -> [B,T,c]
+int mansy_launch_ensemble_wrap(const float* pred, float* out, long long rows, int heads, int c, hipStream_t st);
+// transpose-copy [T,B,C] <-> [B,T,C]
+int mansy_launch_tb_to_bt(const float* src, float* dst, int T, int B, int C, hipStream_t st);
+
+// ---------------------------------------------------------------- tile map (tilemap.hip)
+int mansy_launch_tilemap(const float* xy, long long n, int W, int H, int nw, int nh, int fov_w, int fov_h,
+                         unsigned long long* maps, hipStream_t st);
+int mansy_launch_tilemap_iou(const unsigned long long* a, const unsigned long long* b, long long n, double* iou,
+                             hipStream_t st);
+int mansy_launch_tilemap_or_groups(const unsigned long long* maps, long long ngroups, int group, unsigned long long* out,
+                                   hipStream_t st);

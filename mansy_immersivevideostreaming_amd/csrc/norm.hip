@@ -1,0 +1,309 @@
+// LayerNorm (+ fused residual add) forward/backward and the DistillLayer tail
+// (BatchNorm1d -> ELU -> MaxPool1d(3,2,1)) forward/backward.
+// Reference arithmetic: nn.LayerNorm inside nn.Transformer layers (post-norm: norm(x + sublayer(x)));
+// DistillLayer: viewport_prediction/models/customized_transformer.py:13-36.
+// All HBM-bound: one wavefront per row with 16-byte accesses, column sums reduced in registers
+// -> LDS -> one atomic per column per workgroup.
+#include "mansy_kernels.h"
+
+namespace {
+
+constexpr int LN_MAXV = 4;     // float4 per lane -> C <= 1024
+
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                            const float* __restrict__ w, const float* __restrict__ bias,
+                                                            float* __restrict__ z_out, float* __restrict__ y,
+                                                            float* __restrict__ mean, float* __restrict__ rstd, int rows, int C,
+                                                            float eps) {
+  const int lane = threadIdx.x & 63;
+  const int wave_global = (blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * 256) >> 6;
+  const int nv = C >> 8;     // float4 per lane (C multiple of 256)
+  for (int row = wave_global; row < rows; row += nwaves) {
+    float4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      if (i < nv) {
+        const long long off = (long long)row * C + (i * 64 + lane) * 4;
+        float4 x = *reinterpret_cast<const float4*>(a + off);
+        if (b) { const float4 r = *reinterpret_cast<const float4*>(b + off); x.x += r.x; x.y += r.y; x.z += r.z; x.w += r.w; }
+        if (z_out) *reinterpret_cast<float4*>(z_out + off) = x;
+        v[i] = x;
+        s += (x.x + x.y) + (x.z + x.w);
+      }
+    }
+    const float mu = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      if (i < nv) {
+        const float dx = v[i].x - mu, dy = v[i].y - mu, dz = v[i].z - mu, dw = v[i].w - mu;
+        q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+      }
+    }
+    const float var = wave_sum(q) / (float)C;
+    const float rs = 1.0f / sqrtf(var + eps);
+    if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      if (i < nv) {
+        const int c = (i * 64 + lane) * 4;
+        const float4 ww = *reinterpret_cast<const float4*>(w + c);
+        float4 o;
+        o.x = (v[i].x - mu) * rs * ww.x; o.y = (v[i].y - mu) * rs * ww.y;
+        o.z = (v[i].z - mu) * rs * ww.z; o.w = (v[i].w - mu) * rs * ww.w;
+        if (bias) { const float4 bb = *reinterpret_cast<const float4*>(bias + c); o.x += bb.x; o.y += bb.y; o.z += bb.z; o.w += bb.w; }
+        *reinterpret_cast<float4*>(y + (long long)row * C + c) = o;
+      }
+    }
+  }
+}
+
+// Generic (any C) one-wave-per-row fallback used when C is not a multiple of 256.
+__global__ __launch_bounds__(256) void layernorm_fwd_generic(const float* __restrict__ a, const float* __restrict__ b,
+                                                             const float* __restrict__ w, const float* __restrict__ bias,
+                                                             float* __restrict__ z_out, float* __restrict__ y,
+                                                             float* __restrict__ mean, float* __restrict__ rstd, int rows, int C,
+                                                             float eps) {
+  const int lane = threadIdx.x & 63;
+  const int wave_global = (blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * 256) >> 6;
+  for (int row = wave_global; row < rows; row += nwaves) {
+    const long long base = (long long)row * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) { float x = a[base + c]; if (b) x += b[base + c]; s += x; }
+    const float mu = wave_sum(s) / (float)C;
+    float q = 0.f;
+    for (int c = lane; c < C; c += 64) { float x = a[base + c]; if (b) x += b[base + c]; const float d = x - mu; q += d * d; }
+    const float rs = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+    if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
+    for (int c = lane; c < C; c += 64) {
+      float x = a[base + c]; if (b) x += b[base + c];
+      if (z_out) z_out[base + c] = x;
+      float o = (x - mu) * rs * w[c];
+      if (bias) o += bias[c];
+      y[base + c] = o;
+    }
+  }
+}
+
+// dz = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy * w
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ w, float* __restrict__ dz,
+                                                            float* __restrict__ dz_drop, MansyDrop drop, float* __restrict__ dw,
+                                                            float* __restrict__ dbias, int rows, int C) {
+  extern __shared__ float red[];      // [4 waves][2][C]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wave_global = (blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * 256) >> 6;
+  const float dsc = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
+  float* my_dw = red + (wave * 2 + 0) * C;
+  float* my_db = red + (wave * 2 + 1) * C;
+  for (int c = lane; c < C; c += 64) { my_dw[c] = 0.f; my_db[c] = 0.f; }
+  for (int row = wave_global; row < rows; row += nwaves) {
+    const long long base = (long long)row * C;
+    const float mu = mean[row], rs = rstd[row];
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      const float g = dy[base + c] * w[c];
+      const float xh = (z[base + c] - mu) * rs;
+      s1 += g; s2 += g * xh;
+    }
+    s1 = wave_sum(s1) / (float)C; s2 = wave_sum(s2) / (float)C;
+    for (int c = lane; c < C; c += 64) {
+      const float d = dy[base + c];
+      const float xh = (z[base + c] - mu) * rs;
+      const float o = rs * (d * w[c] - s1 - xh * s2);
+      dz[base + c] = o;
+      if (dz_drop) {
+        float od = o;
+        if (drop.p > 0.f) od = mansy_keep(drop.seed, drop.site, (uint32_t)(base + c), drop.p) ? o * dsc : 0.f;
+        dz_drop[base + c] = od;
+      }
+      my_dw[c] += d * xh;
+      my_db[c] += d;
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < 4; ++wv) { a0 += red[(wv * 2 + 0) * C + c]; a1 += red[(wv * 2 + 1) * C + c]; }
+    if (dw) atomicAdd(dw + c, a0);
+    if (dbias) atomicAdd(dbias + c, a1);
+  }
+}
+
+// ------------------------------------------------------------------ DistillLayer tail
+// column sums of x and x^2 over rows -> doubles
+__global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__ x, int rows, int C, double* __restrict__ stats) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const int r0 = blockIdx.y, rstep = gridDim.y;
+  double s = 0.0, q = 0.0;
+  for (int r = r0; r < rows; r += rstep) { const double v = x[(long long)r * C + c]; s += v; q += v * v; }
+  atomicAdd(stats + c, s);
+  atomicAdd(stats + C + c, q);
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, int n, int C, float* run_mean, float* run_var,
+                                   long long* num_batches, float* mean_out, float* rstd_out, int train, float eps, float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && train && num_batches) *num_batches += 1;
+  if (c >= C) return;
+  if (train) {
+    const double mu = stats[c] / n;
+    double var = stats[C + c] / n - mu * mu;
+    if (var < 0) var = 0;
+    mean_out[c] = (float)mu;
+    rstd_out[c] = (float)(1.0 / sqrt(var + (double)eps));
+    const double var_u = n > 1 ? var * ((double)n / (double)(n - 1)) : var;
+    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)mu;
+    run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)var_u;
+  } else {
+    mean_out[c] = run_mean[c];
+    rstd_out[c] = 1.0f / sqrtf(run_var[c] + eps);
+  }
+}
+
+__device__ __forceinline__ float elu1(float v) { return v > 0.f ? v : expm1f(v); }
+
+__global__ __launch_bounds__(256) void bn_elu_pool_kernel(const float* __restrict__ conv, const float* __restrict__ bn_w,
+                                                          const float* __restrict__ bn_b, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, float* __restrict__ mem,
+                                                          unsigned char* __restrict__ argmax, DistillShape s) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)s.B * s.M * s.C;
+  if (idx >= total) return;
+  const int c = (int)(idx % s.C);
+  const int m = (int)((idx / s.C) % s.M);
+  const int b = (int)(idx / ((long long)s.C * s.M));
+  const float mu = mean[c], sc = rstd[c] * bn_w[c], sh = bn_b[c];
+  float best = -INFINITY; int bi = 0;
+  for (int t = -1; t <= 1; ++t) {
+    const int sp = 2 * m + t;
+    if (sp < 0 || sp >= s.S) continue;
+    const float v = elu1((conv[((long long)b * s.S + sp) * s.C + c] - mu) * sc + sh);
+    if (v > best) { best = v; bi = sp; }     // first maximum wins (torch max_pool1d tie rule)
+  }
+  mem[idx] = best;
+  if (argmax) argmax[idx] = (unsigned char)bi;
+}
+
+// stage 1: g[b,s,c] = dL/d(BN output) ; column sums of g and g*xhat -> doubles (stats[2C..4C))
+__global__ __launch_bounds__(256) void distill_bwd_stage1(const float* __restrict__ conv, const float* __restrict__ dmem,
+                                                          const unsigned char* __restrict__ argmax, const float* __restrict__ bn_w,
+                                                          const float* __restrict__ bn_b, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, float* __restrict__ g, double* __restrict__ stats,
+                                                          DistillShape s) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= s.C) return;
+  const float mu = mean[c], rs = rstd[c], w = bn_w[c], sh = bn_b[c];
+  double sg = 0.0, sgx = 0.0;
+  const int rows = s.B * s.S;
+  for (int r = blockIdx.y; r < rows; r += gridDim.y) {
+    const int b = r / s.S, sp = r % s.S;
+    float up = 0.f;
+    // pooling windows containing sp: 2m-1 <= sp <= 2m+1  <=>  m in [sp/2, (sp+1)/2]
+    for (int m = sp / 2; m <= (sp + 1) / 2; ++m) {
+      if (m >= s.M) continue;
+      const long long mi = ((long long)b * s.M + m) * s.C + c;
+      if (argmax[mi] == (unsigned char)sp) up += dmem[mi];
+    }
+    const float xh = (conv[(long long)r * s.C + c] - mu) * rs;
+    const float ypre = xh * w + sh;
+    const float gg = up * (ypre > 0.f ? 1.f : expf(ypre));
+    g[(long long)r * s.C + c] = gg;
+    sg += gg; sgx += (double)gg * xh;
+  }
+  atomicAdd(stats + 2 * s.C + c, sg);
+  atomicAdd(stats + 3 * s.C + c, sgx);
+}
+
+__global__ __launch_bounds__(256) void distill_bwd_stage2(const float* __restrict__ conv, const float* __restrict__ g,
+                                                          const float* __restrict__ bn_w, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, const double* __restrict__ stats,
+                                                          float* __restrict__ dconv, float* __restrict__ dbn_w, float* __restrict__ dbn_b,
+                                                          DistillShape s) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)s.B * s.S * s.C;
+  if (idx >= total) return;
+  const int c = (int)(idx % s.C);
+  const double n = (double)s.B * s.S;
+  const float sg = (float)(stats[2 * s.C + c] / n), sgx = (float)(stats[3 * s.C + c] / n);
+  const float rs = rstd[c];
+  const float xh = (conv[idx] - mean[c]) * rs;
+  dconv[idx] = bn_w[c] * rs * (g[idx] - sg - xh * sgx);
+  if (idx < s.C) {   // first row's threads publish the parameter gradients
+    atomicAdd(dbn_w + c, (float)stats[3 * s.C + c]);
+    atomicAdd(dbn_b + c, (float)stats[2 * s.C + c]);
+  }
+}
+
+}  // namespace
+
+int mansy_launch_layernorm_fwd(const float* a, const float* b, const float* w, const float* bias, float* z_out, float* y,
+                               float* mean, float* rstd, int rows, int C, float eps, hipStream_t st) {
+  MANSY_REQUIRE(a && w && y, "layernorm_fwd: null pointer");
+  if (rows <= 0) return MANSY_OK;
+  const int grid = min(mansy_ceil_div(rows, 4), 2048);
+  if ((C % 256) == 0 && C <= 256 * LN_MAXV)
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid), dim3(256), 0, st, a, b, w, bias, z_out, y, mean, rstd, rows, C, eps);
+  else
+    hipLaunchKernelGGL(layernorm_fwd_generic, dim3(grid), dim3(256), 0, st, a, b, w, bias, z_out, y, mean, rstd, rows, C, eps);
+  MANSY_LAUNCH_CHECK();
+  return MANSY_OK;
+}
+
+int mansy_launch_layernorm_bwd(const float* dy, const float* z, const float* mean, const float* rstd, const float* w,
+                               float* dz, float* dz_drop, MansyDrop drop, float* dw, float* dbias, int rows, int C,
+                               hipStream_t st) {
+  MANSY_REQUIRE(dy && z && mean && rstd && w && dz, "layernorm_bwd: null pointer");
+  if (rows <= 0) return MANSY_OK;
+  const int grid = min(mansy_ceil_div(rows, 16), 1024);
+  const size_t lds = (size_t)4 * 2 * C * sizeof(float);
+  MANSY_REQUIRE(lds <= 64 * 1024, "layernorm_bwd: C=%d too large", C);
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias,
+                     rows, C);
+  MANSY_LAUNCH_CHECK();
+  return MANSY_OK;
+}
+
+int mansy_launch_distill_fwd(const float* conv, const float* bn_w, const float* bn_b, float* run_mean, float* run_var,
+                             long long* num_batches, float* mean_out, float* rstd_out, float* mem, unsigned char* argmax,
+                             double* stats_d, const DistillShape& s, int train, float eps, float momentum, hipStream_t st) {
+  MANSY_REQUIRE(conv && bn_w && bn_b && run_mean && run_var && mean_out && rstd_out && mem && stats_d, "distill_fwd: null pointer");
+  MANSY_REQUIRE(s.M == (s.S - 1) / 2 + 1, "distill_fwd: M must be floor((S-1)/2)+1");
+  MANSY_REQUIRE(s.S <= 255, "distill_fwd: S too large");
+  const int rows = s.B * s.S;
+  if (train) {
+    MANSY_HIP_CHECK(hipMemsetAsync(stats_d, 0, sizeof(double) * 4 * s.C, st));
+    dim3 grid(mansy_ceil_div(s.C, 256), min(rows, 512));
+    hipLaunchKernelGGL(colstats_kernel, grid, dim3(256), 0, st, conv, rows, s.C, stats_d);
+  }
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(mansy_ceil_div(s.C, 256)), dim3(256), 0, st, stats_d, rows, s.C, run_mean, run_var,
+                     num_batches, mean_out, rstd_out, train, eps, momentum);
+  const long long total = (long long)s.B * s.M * s.C;
+  hipLaunchKernelGGL(bn_elu_pool_kernel, dim3(mansy_ceil_div(total, 256)), dim3(256), 0, st, conv, bn_w, bn_b, mean_out, rstd_out,
+                     mem, argmax, s);
+  MANSY_LAUNCH_CHECK();
+  return MANSY_OK;
+}
+
+int mansy_launch_distill_bwd(const float* conv, const float* dmem, const unsigned char* argmax, const float* bn_w,
+                             const float* bn_b, const float* mean, const float* rstd, float* g_tmp, float* dconv, float* dbn_w,
+                             float* dbn_b, double* stats_d, const DistillShape& s, hipStream_t st) {
+  MANSY_REQUIRE(conv && dmem && argmax && bn_w && bn_b && mean && rstd && g_tmp && dconv && dbn_w && dbn_b && stats_d,
+                "distill_bwd: null pointer");
+  const int rows = s.B * s.S;
+  MANSY_HIP_CHECK(hipMemsetAsync(stats_d + 2 * s.C, 0, sizeof(double) * 2 * s.C, st));
+  dim3 grid1(mansy_ceil_div(s.C, 256), min(rows, 512));
+  hipLaunchKernelGGL(distill_bwd_stage1, grid1, dim3(256), 0, st, conv, dmem, argmax, bn_w, bn_b, mean, rstd, g_tmp, stats_d, s);
+  const long long total = (long long)rows * s.C;
+  hipLaunchKernelGGL(distill_bwd_stage2, dim3(mansy_ceil_div(total, 256)), dim3(256), 0, st, conv, g_tmp, bn_w, mean, rstd, stats_d,
+                     dconv, dbn_w, dbn_b, s);
+  MANSY_LAUNCH_CHECK();
+  return MANSY_OK;
+}

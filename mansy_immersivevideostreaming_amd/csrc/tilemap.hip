@@ -1,0 +1,104 @@
+// Per-tile viewport hit map + IoU, integer and bit-exact:
+//   find_block_covered_by_point / find_tiles_covered_by_viewport / _find_regions_covered_by_fov
+//   (viewport_prediction/utils/common.py:37-58, 83-127), pixel centre int(x*W), int(y*H)
+//   (utils/results.py:15-18, predict.py:40-43), IoU (results.py:21, predict.py:46).
+// One thread per (sample, t) point; output one uint64 per point (bit row*nw+col), coalesced 8-byte
+// stores.  The wrap-around cases collapse to: columns/rows of the FoV rectangle taken modulo the
+// frame, evaluated with the reference's "an exact multiple belongs to the lower tile" rule on each
+// of the (<= 2 x 2) wrapped regions.
+#include "mansy_kernels.h"
+
+namespace {
+
+__device__ __forceinline__ int pymod(int a, int m) { int r = a % m; return r < 0 ? r + m : r; }
+__device__ __forceinline__ int block_of(int x, int bw) {   // find_block_covered_by_point, x >= 0
+  int w = x / bw;
+  if (x > 0 && x % bw == 0) w -= 1;
+  return w;
+}
+// 1-D interval split exactly as _find_regions_covered_by_fov does per axis:
+//   lo >= 0 && hi <= size : [lo,hi]
+//   lo <  0 && hi <= size : [0,hi] and [lo % size, size]
+//   lo >= 0 && hi >  size : [0, hi % size] and [lo, size]
+// returns the count (0 if neither, which the reference cannot reach for fov < size)
+__device__ __forceinline__ int split_axis(int lo, int hi, int size, int (&a)[2], int (&b)[2]) {
+  if (lo >= 0 && hi <= size) { a[0] = lo; b[0] = hi; return 1; }
+  if (lo < 0 && hi <= size) { a[0] = 0; b[0] = hi; a[1] = pymod(lo, size); b[1] = size; return 2; }
+  if (lo >= 0 && hi > size) { a[0] = 0; b[0] = pymod(hi, size); a[1] = lo; b[1] = size; return 2; }
+  return 0;
+}
+__device__ __forceinline__ unsigned range_mask(int t1, int t2, int n) {   // numpy slice [t1 : t2+1] clipped to [0,n)
+  const int a = t1 < 0 ? 0 : t1, b = t2 + 1 > n ? n : t2 + 1;
+  if (b <= a) return 0u;
+  return ((b >= 32 ? 0xFFFFFFFFu : ((1u << b) - 1u))) & ~((1u << a) - 1u);
+}
+
+__device__ unsigned long long tilemap_px(int x, int y, int W, int H, int tw, int th, int nw, int nh, int fov_w, int fov_h) {
+  const int hw = fov_w / 2, hh = fov_h / 2;
+  int xa[2], xb[2], ya[2], yb[2];
+  const int nx = split_axis(x - hw, x + hw, W, xa, xb);
+  const int ny = split_axis(y - hh, y + hh, H, ya, yb);
+  unsigned long long m = 0ull;
+  for (int j = 0; j < ny; ++j) {
+    const unsigned rows = range_mask(block_of(ya[j], th), block_of(yb[j], th), nh);
+    for (int i = 0; i < nx; ++i) {
+      const unsigned cols = range_mask(block_of(xa[i], tw), block_of(xb[i], tw), nw);
+      for (int r = 0; r < nh; ++r)
+        if ((rows >> r) & 1u) m |= (unsigned long long)cols << (r * nw);
+    }
+  }
+  return m;
+}
+
+__global__ __launch_bounds__(256) void tilemap_kernel(const float* __restrict__ xy, long long n, int W, int H, int nw, int nh, int fov_w,
+                                                      int fov_h, unsigned long long* __restrict__ maps) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float2 p = *reinterpret_cast<const float2*>(xy + 2 * i);
+  // np.float32 * python int stays float32 under numpy>=2 (and under value-based casting): round to f32, then truncate
+  const int px = (int)(p.x * (float)W), py = (int)(p.y * (float)H);
+  maps[i] = tilemap_px(px, py, W, H, W / nw, H / nh, nw, nh, fov_w, fov_h);
+}
+
+__global__ __launch_bounds__(256) void tilemap_iou_kernel(const unsigned long long* __restrict__ a, const unsigned long long* __restrict__ b,
+                                                          long long n, double* __restrict__ iou) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  iou[i] = (double)__popcll(a[i] & b[i]) / (double)__popcll(a[i] | b[i]);
+}
+
+__global__ __launch_bounds__(256) void tilemap_or_kernel(const unsigned long long* __restrict__ maps, long long ngroups, int group,
+                                                         unsigned long long* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= ngroups) return;
+  unsigned long long m = 0ull;
+  for (int k = 0; k < group; ++k) m |= maps[i * group + k];
+  out[i] = m;
+}
+
+}  // namespace
+
+int mansy_launch_tilemap(const float* xy, long long n, int W, int H, int nw, int nh, int fov_w, int fov_h, unsigned long long* maps,
+                         hipStream_t st) {
+  MANSY_REQUIRE(xy && maps, "tilemap: null pointer");
+  MANSY_REQUIRE(nw >= 1 && nh >= 1 && nw * nh <= 64 && nw <= 32 && nh <= 32, "tilemap: grid %dx%d does not fit a uint64 map", nw, nh);
+  MANSY_REQUIRE(fov_w < W && fov_h < H, "tilemap: FoV must be smaller than the frame");
+  if (n <= 0) return MANSY_OK;
+  hipLaunchKernelGGL(tilemap_kernel, dim3(mansy_ceil_div(n, 256)), dim3(256), 0, st, xy, n, W, H, nw, nh, fov_w, fov_h, maps);
+  MANSY_LAUNCH_CHECK();
+  return MANSY_OK;
+}
+int mansy_launch_tilemap_iou(const unsigned long long* a, const unsigned long long* b, long long n, double* iou, hipStream_t st) {
+  MANSY_REQUIRE(a && b && iou, "tilemap_iou: null pointer");
+  if (n <= 0) return MANSY_OK;
+  hipLaunchKernelGGL(tilemap_iou_kernel, dim3(mansy_ceil_div(n, 256)), dim3(256), 0, st, a, b, n, iou);
+  MANSY_LAUNCH_CHECK();
+  return MANSY_OK;
+}
+int mansy_launch_tilemap_or_groups(const unsigned long long* maps, long long ngroups, int group, unsigned long long* out, hipStream_t st) {
+  MANSY_REQUIRE(maps && out && group >= 1, "tilemap_or: bad arguments");
+  if (ngroups <= 0) return MANSY_OK;
+  hipLaunchKernelGGL(tilemap_or_kernel, dim3(mansy_ceil_div(ngroups, 256)), dim3(256), 0, st, maps, ngroups, group, out);
+  MANSY_LAUNCH_CHECK();
+  return MANSY_OK;
+}

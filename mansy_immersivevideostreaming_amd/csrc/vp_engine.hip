@@ -1,0 +1,525 @@
+// Viewport-prediction engine: the whole MTIO Transformer forward, hand-derived backward and the
+// fused train step, sequenced on one HIP stream with no host synchronisation (hipGraph-capturable).
+//
+// What it computes (reference): ViewportTransformerMTIO._process_src_current / sample / loss and
+// the train-loop body -- viewport_prediction/models/mtio.py:65-166, models/customized_transformer.py
+// :13-83, run_models.py:37-44.  How (MI355X-first, not the reference's structure):
+//   * decoder = KV-cached incremental decoder: step i computes ONE new token per sample instead of
+//     re-running all i+1 positions (55 -> 10 token-positions per trajectory); identical function and
+//     gradients when dropout is off (causal mask => earlier positions never change).
+//   * every per-step activation lives in a step-major slab [T][B][C]; the recurrent backward only runs
+//     the dX-type products per step, and ALL weight gradients of the decoder are deferred to one
+//     dW = dY^T X GEMM per weight over the stacked [T*B] rows (reduce dim 40 960 at B = 4096).
+//   * all dense products run on the fp32 MFMA kernel (gemm_f32.hip) with bias/ReLU/dropout/mask/
+//     residual fused in the epilogue; attention is the fused one-wave-per-(batch,head) kernel.
+#include <string>
+#include <vector>
+#include "mansy_kernels.h"
+#include "../../include/mansy_hip.h"
+
+namespace {
+
+constexpr int MAXL = 8;
+
+inline uint32_t site_pe_src() { return 1u; }
+inline uint32_t site_enc(int l, int k) { return 100u + l * 8 + k; }
+inline uint32_t site_pe_tgt(int i) { return 1000u + i; }
+inline uint32_t site_dec(int l, int i, int k) { return 10000u + (l * 64 + i) * 8 + k; }
+
+struct LinearP { const float* w = nullptr; const float* b = nullptr; float* gw = nullptr; float* gb = nullptr; };
+typedef LinearP NormP;
+struct EncLayerP { LinearP in_proj, out_proj, lin1, lin2; NormP n1, n2; };
+struct DecLayerP { LinearP sa_in, sa_out, ca_in, ca_out, lin1, lin2; NormP n1, n2, n3; };
+struct VPParams {
+  LinearP emb; EncLayerP enc[MAXL]; NormP enc_norm; DecLayerP dec[MAXL]; NormP dec_norm;
+  LinearP conv; NormP bn; LinearP pred;
+};
+
+struct ParamInfo { std::string name; long long numel; int ndim; long long shape[4]; };
+
+void add_param(std::vector<ParamInfo>& v, const std::string& name, long long a, long long b = 0, long long c = 0) {
+  ParamInfo p; p.name = name; p.shape[0] = a; p.shape[1] = b; p.shape[2] = c; p.shape[3] = 0;
+  p.ndim = c ? 3 : (b ? 2 : 1);
+  p.numel = a * (b ? b : 1) * (c ? c : 1);
+  v.push_back(p);
+}
+
+// Order == the reference model's state_dict order (parameters only).
+std::vector<ParamInfo> param_table(const mansy_vp_config& c) {
+  std::vector<ParamInfo> v;
+  const long long d = c.d_model, f = c.d_ff;
+  const bool hb = c.has_bias != 0;
+  add_param(v, "embedding.linear.weight", d, c.in_ch);
+  add_param(v, "embedding.linear.bias", d);
+  auto mha = [&](const std::string& p) {
+    add_param(v, p + "in_proj_weight", 3 * d, d);
+    if (hb) add_param(v, p + "in_proj_bias", 3 * d);
+    add_param(v, p + "out_proj.weight", d, d);
+    if (hb) add_param(v, p + "out_proj.bias", d);
+  };
+  auto lin = [&](const std::string& p, long long o, long long i) {
+    add_param(v, p + ".weight", o, i);
+    if (hb) add_param(v, p + ".bias", o);
+  };
+  auto norm = [&](const std::string& p) {
+    add_param(v, p + ".weight", d);
+    if (hb) add_param(v, p + ".bias", d);
+  };
+  for (int l = 0; l < c.n_enc; ++l) {
+    const std::string p = "transformer.encoder.layers." + std::to_string(l) + ".";
+    mha(p + "self_attn.");
+    lin(p + "linear1", f, d); lin(p + "linear2", d, f);
+    norm(p + "norm1"); norm(p + "norm2");
+  }
+  norm("transformer.encoder.norm");
+  for (int l = 0; l < c.n_dec; ++l) {
+    const std::string p = "transformer.decoder.layers." + std::to_string(l) + ".";
+    mha(p + "self_attn."); mha(p + "multihead_attn.");
+    lin(p + "linear1", f, d); lin(p + "linear2", d, f);
+    norm(p + "norm1"); norm(p + "norm2"); norm(p + "norm3");
+  }
+  norm("transformer.decoder.norm");
+  add_param(v, "transformer.distill_layer.downConv.weight", d, d, 3);
+  add_param(v, "transformer.distill_layer.downConv.bias", d);
+  add_param(v, "transformer.distill_layer.norm.weight", d);
+  add_param(v, "transformer.distill_layer.norm.bias", d);
+  add_param(v, "predictor.0.weight", c.in_ch, d);
+  add_param(v, "predictor.0.bias", c.in_ch);
+  return v;
+}
+
+void bind_params(const mansy_vp_config& c, const float* const* params, float* const* grads, VPParams& P) {
+  int k = 0;
+  const bool hb = c.has_bias != 0;
+  auto nextw = [&](LinearP& L, bool bias) {
+    L.w = params[k]; L.gw = grads ? grads[k] : nullptr; ++k;
+    if (bias) { L.b = params[k]; L.gb = grads ? grads[k] : nullptr; ++k; }
+  };
+  nextw(P.emb, true);
+  for (int l = 0; l < c.n_enc; ++l) {
+    EncLayerP& e = P.enc[l];
+    nextw(e.in_proj, hb); nextw(e.out_proj, hb); nextw(e.lin1, hb); nextw(e.lin2, hb); nextw(e.n1, hb); nextw(e.n2, hb);
+  }
+  nextw(P.enc_norm, hb);
+  for (int l = 0; l < c.n_dec; ++l) {
+    DecLayerP& e = P.dec[l];
+    nextw(e.sa_in, hb); nextw(e.sa_out, hb); nextw(e.ca_in, hb); nextw(e.ca_out, hb);
+    nextw(e.lin1, hb); nextw(e.lin2, hb); nextw(e.n1, hb); nextw(e.n2, hb); nextw(e.n3, hb);
+  }
+  nextw(P.dec_norm, hb);
+  nextw(P.conv, true);
+  nextw(P.bn, true);
+  nextw(P.pred, true);
+}
+
+// ------------------------------------------------------------------------------ workspace layout
+struct EncBuf { float *qkv, *P, *ao, *z1, *m1, *r1, *y1, *h, *z2, *m2, *r2, *y2; };
+struct DecBuf {
+  float *memkv, *qkv, *P1, *ao1, *z1, *m1, *r1, *y1, *qc, *P2, *ao2, *z2, *m2, *r2, *y2, *h, *z3, *m3, *r3, *y3;
+  float *dqkv, *dbr1, *dqc, *dbr2, *da, *dbr3, *dmemkv;   // backward slabs (deferred dW operands)
+};
+struct Work {
+  float *src6, *cur6, *fut6, *pred_bt, *dpred_bt;           // train_step staging
+  float *x0; EncBuf enc[MAXL]; float *enc_out, *me, *re;
+  float *col, *conv, *bn_mean, *bn_rstd, *mem; unsigned char* argmax; double* stats;
+  float *tok_all, *emb_all; DecBuf dec[MAXL]; float *dec_out, *md, *rd;
+  float *t_enc, *t_dec;                                     // GEMM-out temporaries
+  float *g_a, *g_b, *g_c, *g_wide, *g_ff;                   // encoder backward temporaries [N, .]
+  float *s_a, *s_b, *s_c, *s_tok;                           // decoder step backward temporaries [B, .]
+  float *dE_all, *dz_all, *dmem;
+  double* loss_acc;
+};
+struct BufInfo { std::string name; size_t off; size_t bytes; };
+
+struct Layout {
+  std::vector<BufInfo> bufs;
+  size_t total = 0;
+  char* base = nullptr;
+  void* add(const std::string& name, size_t bytes) {
+    const size_t off = (total + 255) & ~size_t(255);
+    total = off + bytes;
+    bufs.push_back({name, off, bytes});
+    return base ? (void*)(base + off) : nullptr;
+  }
+  float* f(const std::string& name, size_t n) { return (float*)add(name, n * sizeof(float)); }
+};
+
+void build_layout(const mansy_vp_config& c, Layout& L, Work& W) {
+  const size_t B = c.B, S = c.S, T = c.T, d = c.d_model, f = c.d_ff, H = c.n_head, C6 = c.in_ch;
+  const size_t M = (S - 1) / 2 + 1, N = B * S, TB = T * B;
+  W.src6 = L.f("src6", N * C6); W.cur6 = L.f("cur6", B * C6); W.fut6 = L.f("fut6", TB * C6);
+  W.pred_bt = L.f("pred_bt", TB * C6); W.dpred_bt = L.f("dpred_bt", TB * C6);
+  W.x0 = L.f("enc.x0", N * d);
+  for (int l = 0; l < c.n_enc; ++l) {
+    const std::string p = "enc" + std::to_string(l) + ".";
+    EncBuf& e = W.enc[l];
+    e.qkv = L.f(p + "qkv", N * 3 * d); e.P = L.f(p + "P", B * H * S * S); e.ao = L.f(p + "ao", N * d);
+    e.z1 = L.f(p + "z1", N * d); e.m1 = L.f(p + "m1", N); e.r1 = L.f(p + "r1", N); e.y1 = L.f(p + "y1", N * d);
+    e.h = L.f(p + "h", N * f);
+    e.z2 = L.f(p + "z2", N * d); e.m2 = L.f(p + "m2", N); e.r2 = L.f(p + "r2", N); e.y2 = L.f(p + "y2", N * d);
+  }
+  W.enc_out = L.f("enc.out", N * d); W.me = L.f("enc.me", N); W.re = L.f("enc.re", N);
+  W.col = L.f("dis.col", N * 3 * d); W.conv = L.f("dis.conv", N * d);
+  W.bn_mean = L.f("dis.bn_mean", d); W.bn_rstd = L.f("dis.bn_rstd", d);
+  W.mem = L.f("mem", B * M * d);
+  W.argmax = (unsigned char*)L.add("dis.argmax", B * M * d);
+  W.stats = (double*)L.add("dis.stats", 4 * d * sizeof(double));
+  W.tok_all = L.f("tok_all", (T + 1) * B * C6);
+  W.emb_all = L.f("dec.emb", TB * d);
+  for (int l = 0; l < c.n_dec; ++l) {
+    const std::string p = "dec" + std::to_string(l) + ".";
+    DecBuf& e = W.dec[l];
+    e.memkv = L.f(p + "memkv", B * M * 2 * d);
+    e.qkv = L.f(p + "qkv", TB * 3 * d); e.P1 = L.f(p + "P1", TB * H * T); e.ao1 = L.f(p + "ao1", TB * d);
+    e.z1 = L.f(p + "z1", TB * d); e.m1 = L.f(p + "m1", TB); e.r1 = L.f(p + "r1", TB); e.y1 = L.f(p + "y1", TB * d);
+    e.qc = L.f(p + "qc", TB * d); e.P2 = L.f(p + "P2", TB * H * M); e.ao2 = L.f(p + "ao2", TB * d);
+    e.z2 = L.f(p + "z2", TB * d); e.m2 = L.f(p + "m2", TB); e.r2 = L.f(p + "r2", TB); e.y2 = L.f(p + "y2", TB * d);
+    e.h = L.f(p + "h", TB * f);
+    e.z3 = L.f(p + "z3", TB * d); e.m3 = L.f(p + "m3", TB); e.r3 = L.f(p + "r3", TB); e.y3 = L.f(p + "y3", TB * d);
+    e.dqkv = L.f(p + "dqkv", TB * 3 * d); e.dbr1 = L.f(p + "dbr1", TB * d); e.dqc = L.f(p + "dqc", TB * d);
+    e.dbr2 = L.f(p + "dbr2", TB * d); e.da = L.f(p + "da", TB * f); e.dbr3 = L.f(p + "dbr3", TB * d);
+    e.dmemkv = L.f(p + "dmemkv", B * M * 2 * d);
+  }
+  W.dec_out = L.f("dec.out", TB * d); W.md = L.f("dec.md", TB); W.rd = L.f("dec.rd", TB);
+  W.t_enc = L.f("tmp.t_enc", N * d); W.t_dec = L.f("tmp.t_dec", B * d);
+  W.g_a = L.f("tmp.g_a", N * d); W.g_b = L.f("tmp.g_b", N * d); W.g_c = L.f("tmp.g_c", N * d);
+  W.g_wide = L.f("tmp.g_wide", N * 3 * d); W.g_ff = L.f("tmp.g_ff", N * f);
+  W.s_a = L.f("tmp.s_a", B * d); W.s_b = L.f("tmp.s_b", B * d); W.s_c = L.f("tmp.s_c", B * d);
+  W.s_tok = L.f("tmp.s_tok", B * C6);
+  W.dE_all = L.f("dec.dE", TB * d); W.dz_all = L.f("dec.dz", TB * C6); W.dmem = L.f("dmem", B * M * d);
+  W.loss_acc = (double*)L.add("loss_acc", 64);
+}
+
+int check_cfg(const mansy_vp_config* c) {
+  MANSY_REQUIRE(c, "vp: null config");
+  MANSY_REQUIRE(c->B >= 1 && c->S >= 1 && c->S <= 16 && c->T >= 1 && c->T <= 16, "vp: need B>=1, 1<=S,T<=16 (got B=%d S=%d T=%d)", c->B, c->S, c->T);
+  MANSY_REQUIRE(c->n_head >= 1 && c->d_model % c->n_head == 0 && c->d_model / c->n_head <= 64, "vp: d_model/n_head must be an integer <= 64");
+  MANSY_REQUIRE(c->d_model % 4 == 0 && c->d_ff % 4 == 0, "vp: d_model and d_ff must be multiples of 4");
+  MANSY_REQUIRE(c->n_enc >= 1 && c->n_enc <= MAXL && c->n_dec >= 1 && c->n_dec <= MAXL, "vp: 1..%d layers supported", MAXL);
+  MANSY_REQUIRE(c->in_ch >= 1 && c->in_ch <= 8 && c->in_ch % 3 == 0, "vp: in_ch must be 3*in_channel <= 8");
+  MANSY_REQUIRE(c->max_len >= c->S && c->max_len >= c->T, "vp: positional table too short");
+  MANSY_REQUIRE(c->p_pe >= 0.f && c->p_pe < 1.f && c->p_drop >= 0.f && c->p_drop < 1.f, "vp: dropout p outside [0,1)");
+  return MANSY_OK;
+}
+
+#define RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+
+struct Eng {
+  const mansy_vp_config& c;
+  VPParams P;
+  Work W;
+  hipStream_t st;
+  bool train;
+  uint32_t seed;
+  int B, S, T, d, f, H, dh, M, N, TB, C6;
+  float drop_scale;
+
+  Eng(const mansy_vp_config& cfg, hipStream_t s, bool tr, uint32_t sd) : c(cfg), st(s), train(tr), seed(sd) {
+    B = c.B; S = c.S; T = c.T; d = c.d_model; f = c.d_ff; H = c.n_head; dh = d / H; M = (S - 1) / 2 + 1;
+    N = B * S; TB = T * B; C6 = c.in_ch;
+    drop_scale = (train && c.p_drop > 0.f) ? 1.f / (1.f - c.p_drop) : 1.f;
+  }
+  MansyDrop dr(uint32_t site, float p) const { MansyDrop x; x.p = train ? p : 0.f; x.seed = seed; x.site = site; return x; }
+
+  // Y[rows,N] = X[rows,K] W[N,K]^T (+b) with epilogue
+  int lin_fwd(const float* X, int rows, int K, const float* w, const float* b, int Nout, float* Y, int relu, MansyDrop drop) {
+    GemmEpilogue ep; ep.bias = b; ep.relu = relu; ep.drop = drop;
+    return mansy_launch_gemm_f32(X, K, 0, w, K, 0, Y, Nout, rows, Nout, K, ep, 0, 0, st);
+  }
+  // dX[rows,K] = dY[rows,N] W[N,K] (+resid) (mask)
+  int lin_dx(const float* dY, int rows, int Nout, const float* w, int K, float* dX, const float* resid, const float* mask_src,
+             float mask_scale) {
+    GemmEpilogue ep; ep.resid = resid; ep.resid_ld = K; ep.mask_src = mask_src; ep.mask_ld = K; ep.mask_scale = mask_scale;
+    return mansy_launch_gemm_f32(dY, Nout, 0, w, K, 1, dX, K, rows, K, Nout, ep, 0, 0, st);
+  }
+  // gw[N,K] += dY[rows,N]^T X[rows,K] ; gb[N] += colsum(dY)
+  int lin_dw(const float* dY, const float* X, int rows, int Nout, int K, float* gw, float* gb) {
+    GemmEpilogue ep; ep.accumulate = 1;
+    RC(mansy_launch_gemm_f32(dY, Nout, 1, X, K, 1, gw, K, Nout, K, rows, ep, 0, 0, st));
+    if (gb) RC(mansy_launch_colsum(dY, Nout, rows, Nout, gb, st));
+    return MANSY_OK;
+  }
+  int ln_fwd(const float* a, const float* b, const NormP& n, float* z, float* y, float* m, float* r, int rows) {
+    return mansy_launch_layernorm_fwd(a, b, n.w, n.b, z, y, m, r, rows, d, c.ln_eps, st);
+  }
+  int ln_bwd(const float* dy, const float* z, const float* m, const float* r, const NormP& n, float* dz, float* dz_drop,
+             MansyDrop drop, int rows) {
+    return mansy_launch_layernorm_bwd(dy, z, m, r, n.w, dz, dz_drop, drop, n.gw, n.gb, rows, d, st);
+  }
+
+  AttnShape enc_shape() const {
+    AttnShape s; s.nb = B; s.H = H; s.Lq = S; s.Lk = S; s.dh = dh;
+    s.q_bs = s.k_bs = s.v_bs = (long long)S * 3 * d; s.q_rs = s.k_rs = s.v_rs = 3 * d;
+    s.o_bs = (long long)S * d; s.o_rs = d; s.scale = 1.f / sqrtf((float)dh);
+    return s;
+  }
+  AttnShape self_shape(int i) const {   // query = slab i, keys = slabs 0..i
+    AttnShape s; s.nb = B; s.H = H; s.Lq = 1; s.Lk = i + 1; s.dh = dh;
+    s.q_bs = 3 * d; s.q_rs = 0; s.k_bs = s.v_bs = 3 * d; s.k_rs = s.v_rs = (long long)B * 3 * d;
+    s.o_bs = d; s.o_rs = 0; s.scale = 1.f / sqrtf((float)dh);
+    return s;
+  }
+  AttnShape cross_shape() const {
+    AttnShape s; s.nb = B; s.H = H; s.Lq = 1; s.Lk = M; s.dh = dh;
+    s.q_bs = d; s.q_rs = 0; s.k_bs = s.v_bs = (long long)M * 2 * d; s.k_rs = s.v_rs = 2 * d;
+    s.o_bs = d; s.o_rs = 0; s.scale = 1.f / sqrtf((float)dh);
+    return s;
+  }
+
+  // ------------------------------------------------------------------ forward
+  int forward(const float* src, const float* cur, const float* pe, float* bn_rm, float* bn_rv, long long* bn_nbt, float* pred_bt) {
+    RC(mansy_launch_embed_fwd(src, C6, P.emb.w, P.emb.b, pe, W.x0, N, d, S, -1, dr(site_pe_src(), c.p_pe), st));
+    const float* x = W.x0;
+    for (int l = 0; l < c.n_enc; ++l) {
+      const EncLayerP& p = P.enc[l]; EncBuf& e = W.enc[l];
+      RC(lin_fwd(x, N, d, p.in_proj.w, p.in_proj.b, 3 * d, e.qkv, 0, mansy_no_drop()));
+      RC(mansy_launch_attn_fwd(e.qkv, e.qkv + d, e.qkv + 2 * d, e.ao, e.P, enc_shape(), dr(site_enc(l, 0), c.p_drop), st));
+      RC(lin_fwd(e.ao, N, d, p.out_proj.w, p.out_proj.b, d, W.t_enc, 0, dr(site_enc(l, 1), c.p_drop)));
+      RC(ln_fwd(x, W.t_enc, p.n1, e.z1, e.y1, e.m1, e.r1, N));
+      RC(lin_fwd(e.y1, N, d, p.lin1.w, p.lin1.b, f, e.h, 1, dr(site_enc(l, 2), c.p_drop)));
+      RC(lin_fwd(e.h, N, f, p.lin2.w, p.lin2.b, d, W.t_enc, 0, dr(site_enc(l, 3), c.p_drop)));
+      RC(ln_fwd(e.y1, W.t_enc, p.n2, e.z2, e.y2, e.m2, e.r2, N));
+      x = e.y2;
+    }
+    RC(ln_fwd(x, nullptr, P.enc_norm, nullptr, W.enc_out, W.me, W.re, N));
+    // DistillLayer: circular conv k=3 as one K=3d GEMM on the im2col image, then BN+ELU+maxpool
+    RC(mansy_launch_im2col3(W.enc_out, W.col, B, S, d, st));
+    RC(lin_fwd(W.col, N, 3 * d, P.conv.w, P.conv.b, d, W.conv, 0, mansy_no_drop()));
+    DistillShape ds = {B, S, M, d};
+    RC(mansy_launch_distill_fwd(W.conv, P.bn.w, P.bn.b, bn_rm, bn_rv, bn_nbt, W.bn_mean, W.bn_rstd, W.mem, W.argmax, W.stats, ds,
+                                train ? 1 : 0, c.bn_eps, c.bn_momentum, st));
+    for (int l = 0; l < c.n_dec; ++l) {
+      const DecLayerP& p = P.dec[l];
+      RC(lin_fwd(W.mem, B * M, d, p.ca_in.w + (size_t)d * d, p.ca_in.b ? p.ca_in.b + d : nullptr, 2 * d, W.dec[l].memkv, 0, mansy_no_drop()));
+    }
+    MANSY_HIP_CHECK(hipMemcpyAsync(W.tok_all, cur, sizeof(float) * B * C6, hipMemcpyDeviceToDevice, st));
+    for (int i = 0; i < T; ++i) {
+      const float* tok = W.tok_all + (size_t)i * B * C6;
+      float* emb = W.emb_all + (size_t)i * B * d;
+      RC(mansy_launch_embed_fwd(tok, C6, P.emb.w, P.emb.b, pe, emb, B, d, 1, i, dr(site_pe_tgt(i), c.p_pe), st));
+      const float* xi = emb;
+      for (int l = 0; l < c.n_dec; ++l) {
+        const DecLayerP& p = P.dec[l]; DecBuf& e = W.dec[l];
+        const size_t o = (size_t)i * B;
+        float* qkv_i = e.qkv + o * 3 * d;
+        RC(lin_fwd(xi, B, d, p.sa_in.w, p.sa_in.b, 3 * d, qkv_i, 0, mansy_no_drop()));
+        RC(mansy_launch_attn_fwd(qkv_i, e.qkv + d, e.qkv + 2 * d, e.ao1 + o * d, e.P1 + o * H * T, self_shape(i),
+                                 dr(site_dec(l, i, 0), c.p_drop), st));
+        RC(lin_fwd(e.ao1 + o * d, B, d, p.sa_out.w, p.sa_out.b, d, W.t_dec, 0, dr(site_dec(l, i, 1), c.p_drop)));
+        RC(ln_fwd(xi, W.t_dec, p.n1, e.z1 + o * d, e.y1 + o * d, e.m1 + o, e.r1 + o, B));
+        RC(lin_fwd(e.y1 + o * d, B, d, p.ca_in.w, p.ca_in.b, d, e.qc + o * d, 0, mansy_no_drop()));
+        RC(mansy_launch_attn_fwd(e.qc + o * d, e.memkv, e.memkv + d, e.ao2 + o * d, e.P2 + o * H * M, cross_shape(),
+                                 dr(site_dec(l, i, 2), c.p_drop), st));
+        RC(lin_fwd(e.ao2 + o * d, B, d, p.ca_out.w, p.ca_out.b, d, W.t_dec, 0, dr(site_dec(l, i, 3), c.p_drop)));
+        RC(ln_fwd(e.y1 + o * d, W.t_dec, p.n2, e.z2 + o * d, e.y2 + o * d, e.m2 + o, e.r2 + o, B));
+        RC(lin_fwd(e.y2 + o * d, B, d, p.lin1.w, p.lin1.b, f, e.h + o * f, 1, dr(site_dec(l, i, 4), c.p_drop)));
+        RC(lin_fwd(e.h + o * f, B, f, p.lin2.w, p.lin2.b, d, W.t_dec, 0, dr(site_dec(l, i, 5), c.p_drop)));
+        RC(ln_fwd(e.y2 + o * d, W.t_dec, p.n3, e.z3 + o * d, e.y3 + o * d, e.m3 + o, e.r3 + o, B));
+        xi = e.y3 + o * d;
+      }
+      const size_t o = (size_t)i * B;
+      RC(ln_fwd(xi, nullptr, P.dec_norm, nullptr, W.dec_out + o * d, W.md + o, W.rd + o, B));
+      RC(mansy_launch_predictor_fwd(W.dec_out + o * d, P.pred.w, P.pred.b, W.tok_all + (size_t)(i + 1) * B * C6, C6,
+                                    pred_bt ? pred_bt + (size_t)i * C6 : nullptr, (long long)T * C6, B, d, C6, st));
+    }
+    return MANSY_OK;
+  }
+
+  // ------------------------------------------------------------------ backward
+  int backward(const float* src, const float* dpred_bt) {
+    const float ms = drop_scale;
+    for (int l = 0; l < c.n_dec; ++l) {
+      MANSY_HIP_CHECK(hipMemsetAsync(W.dec[l].dqkv, 0, sizeof(float) * (size_t)TB * 3 * d, st));
+      MANSY_HIP_CHECK(hipMemsetAsync(W.dec[l].dmemkv, 0, sizeof(float) * (size_t)B * M * 2 * d, st));
+    }
+    const float* pred_tb = W.tok_all + (size_t)B * C6;
+    for (int i = T - 1; i >= 0; --i) {
+      const size_t o = (size_t)i * B;
+      // predictor + final decoder LayerNorm
+      RC(mansy_launch_predictor_bwd(dpred_bt + (size_t)i * C6, (long long)T * C6, i < T - 1 ? W.s_tok : nullptr, C6,
+                                    pred_tb + o * C6, C6, P.pred.w, W.dz_all + o * C6, W.s_a, B, d, C6, st));
+      const float* last_y = W.dec[c.n_dec - 1].y3 + o * d;
+      RC(ln_bwd(W.s_a, last_y, W.md + o, W.rd + o, P.dec_norm, W.s_b, nullptr, mansy_no_drop(), B));
+      float* gx = W.s_b;     // gradient wrt the current layer's output
+      float* gz = W.s_a;     // scratch for residual-path gradients
+      float* gt = W.s_c;
+      for (int l = c.n_dec - 1; l >= 0; --l) {
+        const DecLayerP& p = P.dec[l]; DecBuf& e = W.dec[l];
+        // norm3( y2 + drop(lin2(h)) )
+        RC(ln_bwd(gx, e.z3 + o * d, e.m3 + o, e.r3 + o, p.n3, gz, e.dbr3 + o * d, dr(site_dec(l, i, 5), c.p_drop), B));
+        RC(lin_dx(e.dbr3 + o * d, B, d, p.lin2.w, f, e.da + o * f, nullptr, e.h + o * f, ms));
+        RC(lin_dx(e.da + o * f, B, f, p.lin1.w, d, gt, gz, nullptr, 1.f));                 // gt = d/dy2
+        // norm2( y1 + drop(ca_out(ao2)) )
+        RC(ln_bwd(gt, e.z2 + o * d, e.m2 + o, e.r2 + o, p.n2, gz, e.dbr2 + o * d, dr(site_dec(l, i, 3), c.p_drop), B));
+        RC(lin_dx(e.dbr2 + o * d, B, d, p.ca_out.w, d, gt, nullptr, nullptr, 1.f));         // gt = d/dao2
+        RC(mansy_launch_attn_bwd(e.qc + o * d, e.memkv, e.memkv + d, e.P2 + o * H * M, gt, e.dqc + o * d, e.dmemkv, e.dmemkv + d,
+                                 cross_shape(), dr(site_dec(l, i, 2), c.p_drop), 1, st));
+        RC(lin_dx(e.dqc + o * d, B, d, p.ca_in.w, d, gt, gz, nullptr, 1.f));                // gt = d/dy1
+        // norm1( x + drop(sa_out(ao1)) )
+        RC(ln_bwd(gt, e.z1 + o * d, e.m1 + o, e.r1 + o, p.n1, gz, e.dbr1 + o * d, dr(site_dec(l, i, 1), c.p_drop), B));
+        RC(lin_dx(e.dbr1 + o * d, B, d, p.sa_out.w, d, gt, nullptr, nullptr, 1.f));         // gt = d/dao1
+        float* dqkv_i = e.dqkv + o * 3 * d;
+        RC(mansy_launch_attn_bwd(e.qkv + o * 3 * d, e.qkv + d, e.qkv + 2 * d, e.P1 + o * H * T, gt, dqkv_i, e.dqkv + d, e.dqkv + 2 * d,
+                                 self_shape(i), dr(site_dec(l, i, 0), c.p_drop), 1, st));
+        RC(lin_dx(dqkv_i, B, 3 * d, p.sa_in.w, d, gx, gz, nullptr, 1.f));                   // gx = d/d(layer input)
+      }
+      // embedding of the fed-back token: dE slab (masked) + gradient wrt pred_{i-1}
+      RC(mansy_launch_embed_bwd(gx, P.emb.w, W.dE_all + o * d, W.s_tok, C6, B, d, dr(site_pe_tgt(i), c.p_pe), st));
+    }
+    // ---- deferred decoder weight gradients: one reduce-dim-(T*B) GEMM per weight
+    RC(mansy_launch_outer_reduce(W.dz_all, C6, W.dec_out, TB, d, P.pred.gw, 0, nullptr, P.pred.gb, st));
+    RC(mansy_launch_outer_reduce(W.tok_all, C6, W.dE_all, TB, d, P.emb.gw, 1, P.emb.gb, nullptr, st));
+    for (int l = 0; l < c.n_dec; ++l) {
+      const DecLayerP& p = P.dec[l]; DecBuf& e = W.dec[l];
+      const float* x_all = l == 0 ? W.emb_all : W.dec[l - 1].y3;
+      RC(lin_dw(e.dqkv, x_all, TB, 3 * d, d, p.sa_in.gw, p.sa_in.gb));
+      RC(lin_dw(e.dbr1, e.ao1, TB, d, d, p.sa_out.gw, p.sa_out.gb));
+      RC(lin_dw(e.dqc, e.y1, TB, d, d, p.ca_in.gw, p.ca_in.gb));
+      RC(lin_dw(e.dmemkv, W.mem, B * M, 2 * d, d, p.ca_in.gw + (size_t)d * d, p.ca_in.gb ? p.ca_in.gb + d : nullptr));
+      RC(lin_dw(e.dbr2, e.ao2, TB, d, d, p.ca_out.gw, p.ca_out.gb));
+      RC(lin_dw(e.da, e.y2, TB, f, d, p.lin1.gw, p.lin1.gb));
+      RC(lin_dw(e.dbr3, e.h, TB, d, f, p.lin2.gw, p.lin2.gb));
+      RC(lin_dx(e.dmemkv, B * M, 2 * d, p.ca_in.w + (size_t)d * d, d, W.dmem, l == 0 ? nullptr : W.dmem, nullptr, 1.f));
+    }
+    // ---- DistillLayer
+    DistillShape ds = {B, S, M, d};
+    RC(mansy_launch_distill_bwd(W.conv, W.dmem, W.argmax, P.bn.w, P.bn.b, W.bn_mean, W.bn_rstd, W.g_a, W.g_b, P.bn.gw, P.bn.gb, W.stats,
+                                ds, st));
+    RC(lin_dw(W.g_b, W.col, N, d, 3 * d, P.conv.gw, P.conv.gb));
+    RC(lin_dx(W.g_b, N, d, P.conv.w, 3 * d, W.g_wide, nullptr, nullptr, 1.f));
+    RC(mansy_launch_col2im3(W.g_wide, W.g_a, B, S, d, st));
+    // ---- encoder
+    const float* last = W.enc[c.n_enc - 1].y2;
+    RC(ln_bwd(W.g_a, last, W.me, W.re, P.enc_norm, W.g_b, nullptr, mansy_no_drop(), N));
+    float* gx = W.g_b; float* gz = W.g_a; float* gt = W.g_c;
+    for (int l = c.n_enc - 1; l >= 0; --l) {
+      const EncLayerP& p = P.enc[l]; EncBuf& e = W.enc[l];
+      const float* x_in = l == 0 ? W.x0 : W.enc[l - 1].y2;
+      RC(ln_bwd(gx, e.z2, e.m2, e.r2, p.n2, gz, gt, dr(site_enc(l, 3), c.p_drop), N));        // gt = d/d(lin2 out)
+      RC(lin_dw(gt, e.h, N, d, f, p.lin2.gw, p.lin2.gb));
+      RC(lin_dx(gt, N, d, p.lin2.w, f, W.g_ff, nullptr, e.h, ms));                             // g_ff = d/d(lin1 pre-act)
+      RC(lin_dw(W.g_ff, e.y1, N, f, d, p.lin1.gw, p.lin1.gb));
+      RC(lin_dx(W.g_ff, N, f, p.lin1.w, d, gt, gz, nullptr, 1.f));                             // gt = d/dy1
+      RC(ln_bwd(gt, e.z1, e.m1, e.r1, p.n1, gz, gx, dr(site_enc(l, 1), c.p_drop), N));         // gx = d/d(out_proj out)
+      RC(lin_dw(gx, e.ao, N, d, d, p.out_proj.gw, p.out_proj.gb));
+      RC(lin_dx(gx, N, d, p.out_proj.w, d, gt, nullptr, nullptr, 1.f));                        // gt = d/dao
+      RC(mansy_launch_attn_bwd(e.qkv, e.qkv + d, e.qkv + 2 * d, e.P, gt, W.g_wide, W.g_wide + d, W.g_wide + 2 * d, enc_shape(),
+                               dr(site_enc(l, 0), c.p_drop), 0, st));
+      RC(lin_dw(W.g_wide, x_in, N, 3 * d, d, p.in_proj.gw, p.in_proj.gb));
+      RC(lin_dx(W.g_wide, N, 3 * d, p.in_proj.w, d, gx, gz, nullptr, 1.f));                    // gx = d/d(layer input)
+    }
+    RC(mansy_launch_embed_bwd(gx, P.emb.w, gt, nullptr, C6, N, d, dr(site_pe_src(), c.p_pe), st));
+    RC(mansy_launch_outer_reduce(src, C6, gt, N, d, P.emb.gw, 1, P.emb.gb, nullptr, st));
+    return MANSY_OK;
+  }
+};
+
+int setup(const mansy_vp_config* cfg, void* workspace, Layout& L, Work& W) {
+  RC(check_cfg(cfg));
+  L.base = (char*)workspace;
+  build_layout(*cfg, L, W);
+  return MANSY_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mansy_vp_num_params(const mansy_vp_config* cfg) {
+  if (check_cfg(cfg)) return MANSY_EINVAL;
+  return (int)param_table(*cfg).size();
+}
+
+int mansy_vp_param_info(const mansy_vp_config* cfg, int idx, char* name, int name_len, long long* numel, int* ndim, long long shape[4]) {
+  RC(check_cfg(cfg));
+  const std::vector<ParamInfo> t = param_table(*cfg);
+  MANSY_REQUIRE(idx >= 0 && idx < (int)t.size(), "vp_param_info: index %d out of range", idx);
+  if (name && name_len > 0) { strncpy(name, t[idx].name.c_str(), name_len - 1); name[name_len - 1] = 0; }
+  if (numel) *numel = t[idx].numel;
+  if (ndim) *ndim = t[idx].ndim;
+  if (shape) for (int i = 0; i < 4; ++i) shape[i] = t[idx].shape[i];
+  return MANSY_OK;
+}
+
+size_t mansy_vp_workspace_bytes(const mansy_vp_config* cfg) {
+  Layout L; Work W;
+  if (setup(cfg, nullptr, L, W)) return 0;
+  return L.total + 256;
+}
+
+int mansy_vp_ws_lookup(const mansy_vp_config* cfg, const char* name, long long* offset_bytes, long long* numel) {
+  Layout L; Work W;
+  RC(setup(cfg, nullptr, L, W));
+  for (const BufInfo& b : L.bufs)
+    if (b.name == name) { if (offset_bytes) *offset_bytes = (long long)b.off; if (numel) *numel = (long long)(b.bytes / 4); return MANSY_OK; }
+  mansy_set_error("vp_ws_lookup: unknown buffer '%s'", name);
+  return MANSY_EINVAL;
+}
+
+int mansy_vp_forward(const mansy_vp_config* cfg, const float* const* params, const float* pe, float* bn_running_mean,
+                     float* bn_running_var, long long* bn_num_batches, const float* src, const float* cur, float* pred,
+                     void* workspace, int train, uint32_t seed, void* stream) {
+  MANSY_REQUIRE(params && pe && bn_running_mean && bn_running_var && src && cur && pred && workspace, "vp_forward: null pointer");
+  Layout L; Work W;
+  RC(setup(cfg, workspace, L, W));
+  Eng e(*cfg, (hipStream_t)stream, train != 0, seed);
+  e.W = W;
+  bind_params(*cfg, params, nullptr, e.P);
+  return e.forward(src, cur, pe, bn_running_mean, bn_running_var, bn_num_batches, pred);
+}
+
+int mansy_vp_backward(const mansy_vp_config* cfg, const float* const* params, float* const* grads, const float* src,
+                      const float* dpred, void* workspace, uint32_t seed, void* stream) {
+  MANSY_REQUIRE(params && grads && src && dpred && workspace, "vp_backward: null pointer");
+  Layout L; Work W;
+  RC(setup(cfg, workspace, L, W));
+  Eng e(*cfg, (hipStream_t)stream, true, seed);
+  e.W = W;
+  bind_params(*cfg, params, grads, e.P);
+  return e.backward(src, dpred);
+}
+
+int mansy_vp_sample(const mansy_vp_config* cfg, const float* const* params, const float* pe, float* bn_running_mean,
+                    float* bn_running_var, const float* history, const float* current, float* out, void* workspace, void* stream) {
+  MANSY_REQUIRE(params && pe && history && current && out && workspace, "vp_sample: null pointer");
+  Layout L; Work W;
+  RC(setup(cfg, workspace, L, W));
+  hipStream_t st = (hipStream_t)stream;
+  Eng e(*cfg, st, false, 0u);
+  e.W = W;
+  bind_params(*cfg, params, nullptr, e.P);
+  const int c = cfg->in_ch / 3;
+  RC(mansy_launch_mtio_mix(history, nullptr, nullptr, W.src6, cfg->B, cfg->S, c, st));
+  RC(mansy_launch_mtio_mix(current, nullptr, nullptr, W.cur6, cfg->B, 1, c, st));
+  RC(e.forward(W.src6, W.cur6, pe, bn_running_mean, bn_running_var, nullptr, W.pred_bt));
+  return mansy_launch_ensemble_wrap(W.pred_bt, out, (long long)cfg->B * cfg->T, 3, c, st);
+}
+
+int mansy_vp_train_step(const mansy_vp_config* cfg, const float* const* params, float* const* grads, float* flat_p, float* flat_g,
+                        float* flat_m, float* flat_v, long long n_flat, const float* pe, float* bn_running_mean,
+                        float* bn_running_var, long long* bn_num_batches, const float* history, const float* current,
+                        const float* future, const int* perm1, const int* perm2, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, int step, float* loss_out, void* workspace, uint32_t seed, void* stream) {
+  MANSY_REQUIRE(params && grads && flat_p && flat_g && flat_m && flat_v && pe && history && current && future && loss_out && workspace,
+                "vp_train_step: null pointer");
+  MANSY_REQUIRE((perm1 == nullptr) == (perm2 == nullptr), "vp_train_step: perm1/perm2 must both be set or both NULL");
+  Layout L; Work W;
+  RC(setup(cfg, workspace, L, W));
+  hipStream_t st = (hipStream_t)stream;
+  Eng e(*cfg, st, true, seed);
+  e.W = W;
+  bind_params(*cfg, params, grads, e.P);
+  const int c = cfg->in_ch / 3;
+  RC(mansy_launch_mtio_mix(history, perm1, perm2, W.src6, cfg->B, cfg->S, c, st));
+  RC(mansy_launch_mtio_mix(current, perm1, perm2, W.cur6, cfg->B, 1, c, st));
+  RC(mansy_launch_mtio_mix(future, perm1, perm2, W.fut6, cfg->B, cfg->T, c, st));
+  MANSY_HIP_CHECK(hipMemsetAsync(flat_g, 0, sizeof(float) * (size_t)n_flat, st));
+  RC(e.forward(W.src6, W.cur6, pe, bn_running_mean, bn_running_var, bn_num_batches, W.pred_bt));
+  const long long n = (long long)cfg->B * cfg->T * cfg->in_ch;
+  RC(mansy_launch_mtio_loss(W.pred_bt, W.fut6, n, 1.f / (2.f * (float)cfg->B * (float)cfg->T), W.loss_acc, loss_out, W.dpred_bt, st));
+  RC(e.backward(W.src6, W.dpred_bt));
+  if (step <= 0) return MANSY_OK;
+  return mansy_launch_adamw(flat_p, flat_g, flat_m, flat_v, n_flat, lr, beta1, beta2, eps, weight_decay, step, 1, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,133 @@
+"""Thin torch-tensor front-ends for the single-kernel C-ABI entry points (unit-test surface and building
+blocks for the host mirrors).  Tensors must live on the GPU; nothing here computes on the CPU."""
+import ctypes
+import math
+
+import torch
+
+from ._lib import AttnShape, GemmEpilogue, MansyError, check, lib, ptr, stream_ptr
+
+
+def _gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise MansyError('HIP kernels need cuda (ROCm) tensors')
+
+
+def gemm(A, B, a_kmajor=False, b_kmajor=False, bias=None, relu=False, mask_src=None, mask_scale=1.0, drop=None,
+         resid=None, out=None, accumulate=False, force_tile=0, force_splitk=0):
+    """C = A·B with A logical [M,K] (stored [K,M] if a_kmajor) and B logical [K,N]
+    (stored [N,K] if not b_kmajor -- a torch Linear weight -- or [K,N] if b_kmajor)."""
+    _gpu(A, B)
+    A, B = A.contiguous(), B.contiguous()
+    M, K = (A.shape[1], A.shape[0]) if a_kmajor else A.shape
+    N = B.shape[1] if b_kmajor else B.shape[0]
+    Kb = B.shape[0] if b_kmajor else B.shape[1]
+    assert K == Kb, (A.shape, B.shape)
+    if out is None:
+        out = torch.zeros(M, N, dtype=torch.float32, device=A.device) if accumulate else \
+            torch.empty(M, N, dtype=torch.float32, device=A.device)
+    ep = GemmEpilogue()
+    ep.bias = ptr(bias).value if bias is not None else None
+    ep.relu = int(relu)
+    if mask_src is not None:
+        ep.mask_src, ep.mask_ld = mask_src.data_ptr(), mask_src.stride(0)
+    ep.mask_scale = mask_scale
+    if drop is not None:
+        ep.drop_p, ep.drop_seed, ep.drop_site = drop
+    if resid is not None:
+        ep.resid, ep.resid_ld = resid.data_ptr(), resid.stride(0)
+    ep.accumulate = int(accumulate)
+    check(lib().mansy_gemm_f32(ptr(A), A.stride(0), int(a_kmajor), ptr(B), B.stride(0), int(b_kmajor), ptr(out), out.stride(0),
+                               M, N, K, ctypes.byref(ep), force_tile, force_splitk, stream_ptr(A.device)), 'mansy_gemm_f32')
+    return out
+
+
+def _attn_shape(nb, H, Lq, Lk, dh, q, k, v, o):
+    s = AttnShape(nb=nb, H=H, Lq=Lq, Lk=Lk, dh=dh, scale=1.0 / math.sqrt(dh))
+    s.q_bs, s.q_rs = q
+    s.k_bs, s.k_rs = k
+    s.v_bs, s.v_rs = v
+    s.o_bs, s.o_rs = o
+    return s
+
+
+def attn_fwd_packed(qkv, H, drop=None, save_p=True):
+    """Encoder-style self attention on a packed projection qkv [B,L,3d] -> (out [B,L,d], P [B*H,L,L])."""
+    _gpu(qkv)
+    B, L, d3 = qkv.shape
+    d = d3 // 3
+    s = _attn_shape(B, H, L, L, d // H, (L * d3, d3), (L * d3, d3), (L * d3, d3), (L * d, d))
+    out = torch.empty(B, L, d, dtype=torch.float32, device=qkv.device)
+    P = torch.empty(B * H, L, L, dtype=torch.float32, device=qkv.device) if save_p else None
+    p, seed, site = drop if drop is not None else (0.0, 0, 0)
+    base = qkv.data_ptr()
+    check(lib().mansy_attn_fwd(base, base + 4 * d, base + 8 * d, ptr(out), ptr(P), ctypes.byref(s), p, seed, site,
+                               stream_ptr(qkv.device)), 'mansy_attn_fwd')
+    return out, P
+
+
+def attn_bwd_packed(qkv, P, dout, H, drop=None):
+    _gpu(qkv, P, dout)
+    B, L, d3 = qkv.shape
+    d = d3 // 3
+    s = _attn_shape(B, H, L, L, d // H, (L * d3, d3), (L * d3, d3), (L * d3, d3), (L * d, d))
+    dqkv = torch.empty_like(qkv)
+    p, seed, site = drop if drop is not None else (0.0, 0, 0)
+    base, gb = qkv.data_ptr(), dqkv.data_ptr()
+    check(lib().mansy_attn_bwd(base, base + 4 * d, base + 8 * d, ptr(P), ptr(dout.contiguous()), gb, gb + 4 * d, gb + 8 * d,
+                               ctypes.byref(s), p, seed, site, 0, stream_ptr(qkv.device)), 'mansy_attn_bwd')
+    return dqkv
+
+
+def layernorm_fwd(a, b, w, bias, eps=1e-5):
+    _gpu(a, w)
+    rows, C = a.shape
+    z = torch.empty_like(a)
+    y = torch.empty_like(a)
+    mean = torch.empty(rows, dtype=torch.float32, device=a.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=a.device)
+    check(lib().mansy_layernorm_fwd(ptr(a), ptr(b), ptr(w), ptr(bias), ptr(z), ptr(y), ptr(mean), ptr(rstd), rows, C, eps,
+                                    stream_ptr(a.device)), 'mansy_layernorm_fwd')
+    return y, z, mean, rstd
+
+
+def layernorm_bwd(dy, z, mean, rstd, w, drop=None, want_bias=True):
+    _gpu(dy, z, w)
+    rows, C = dy.shape
+    dz = torch.empty_like(dy)
+    dz_drop = torch.empty_like(dy)
+    dw = torch.zeros(C, dtype=torch.float32, device=dy.device)
+    db = torch.zeros(C, dtype=torch.float32, device=dy.device) if want_bias else None
+    p, seed, site = drop if drop is not None else (0.0, 0, 0)
+    check(lib().mansy_layernorm_bwd(ptr(dy), ptr(z), ptr(mean), ptr(rstd), ptr(w), ptr(dz), ptr(dz_drop), p, seed, site, ptr(dw),
+                                    ptr(db), rows, C, stream_ptr(dy.device)), 'mansy_layernorm_bwd')
+    return dz, dz_drop, dw, db
+
+
+def tilemap(xy, W=2560, H=1440, nw=8, nh=8, fov_w=600, fov_h=300):
+    """xy [...,2] float32 normalised centres -> uint64 hit maps as int64 tensor [...] (bit row*nw+col)."""
+    _gpu(xy)
+    xy = xy.contiguous().float()
+    n = xy.numel() // 2
+    out = torch.empty(xy.shape[:-1], dtype=torch.int64, device=xy.device)
+    check(lib().mansy_tilemap(ptr(xy), n, W, H, nw, nh, fov_w, fov_h, ptr(out), stream_ptr(xy.device)), 'mansy_tilemap')
+    return out
+
+
+def tilemap_iou(a, b):
+    _gpu(a, b)
+    a, b = a.contiguous(), b.contiguous()
+    out = torch.empty(a.shape, dtype=torch.float64, device=a.device)
+    check(lib().mansy_tilemap_iou(ptr(a), ptr(b), a.numel(), ptr(out), stream_ptr(a.device)), 'mansy_tilemap_iou')
+    return out
+
+
+def tilemap_or_groups(maps, group):
+    """maps [n*group] -> [n]: OR of each run of `group` consecutive maps (predict.py:39-45)."""
+    _gpu(maps)
+    maps = maps.contiguous()
+    n = maps.numel() // group
+    out = torch.empty(n, dtype=torch.int64, device=maps.device)
+    check(lib().mansy_tilemap_or_groups(ptr(maps), n, group, ptr(out), stream_ptr(maps.device)), 'mansy_tilemap_or_groups')
+    return out
