@@ -74,6 +74,9 @@ def lib():
             raise MansyError(
                 f'{LIB_PATH} not found: build it with `python -m mansy_immersivevideostreaming_amd.build_ext` '
                 '(there is no CPU fallback for the HIP path)')
+        # torch first: it loads the HIP runtime (libamdhip64) that owns the tensors/streams we are handed;
+        # loading ours first would bring up a second, disjoint runtime ("no ROCm-capable device").
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, args in _PROTOS.items():
             fn = getattr(L, name)

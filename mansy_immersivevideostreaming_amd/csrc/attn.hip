@@ -171,6 +171,97 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_kernel(AttnPtrs p, AttnSh
   }
 }
 
+// ---- Lq == 1 (KV-cached decoder self-attention and cross-attention): one wave per (batch, head), lane = head-dim
+// element; scores via wave reductions, everything in registers, no LDS and no barriers.  Pure HBM streaming:
+// forward reads (2 Lk + 1) rows of 256 B and writes one; backward additionally read-modify-writes 2 Lk rows.
+__global__ __launch_bounds__(64 * WAVES) void attn_fwd_q1_kernel(AttnPtrs p, AttnShape s, MansyDrop drop) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long bh = (long long)blockIdx.x * WAVES + wave;
+  if (bh >= (long long)s.nb * s.H) return;
+  const int b = (int)(bh / s.H), h = (int)(bh % s.H);
+  const int Lk = s.Lk, dh = s.dh;
+  const bool on = lane < dh;
+  const float* Kb = p.K + b * s.k_bs + h * dh + lane;
+  const float* Vb = p.V + b * s.v_bs + h * dh + lane;
+  const float q = on ? p.Q[b * s.q_bs + h * dh + lane] : 0.f;
+  float sc[LMAX], v[LMAX];
+#pragma unroll
+  for (int j = 0; j < LMAX; ++j) {
+    const float kj = (on && j < Lk) ? Kb[j * s.k_rs] : 0.f;
+    v[j] = (on && j < Lk) ? Vb[j * s.v_rs] : 0.f;
+    sc[j] = q * kj;
+  }
+  float m = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < LMAX; ++j) {
+    if (j < Lk) { sc[j] = wave_sum(sc[j]) * s.scale; m = fmaxf(m, sc[j]); }
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < LMAX; ++j) if (j < Lk) { sc[j] = expf(sc[j] - m); sum += sc[j]; }
+  const float inv = 1.f / sum;
+  const float ds = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
+  float o = 0.f;
+#pragma unroll
+  for (int j = 0; j < LMAX; ++j) {
+    if (j < Lk) {
+      float pv = sc[j] * inv;
+      const long long pidx = bh * Lk + j;
+      if (p.P && lane == j) p.P[pidx] = pv;
+      if (drop.p > 0.f) pv = mansy_keep(drop.seed, drop.site, (uint32_t)pidx, drop.p) ? pv * ds : 0.f;
+      o = fmaf(pv, v[j], o);
+    }
+  }
+  if (on) p.O[b * s.o_bs + h * dh + lane] = o;
+}
+
+__global__ __launch_bounds__(64 * WAVES) void attn_bwd_q1_kernel(AttnPtrs p, AttnShape s, MansyDrop drop, int accum_kv) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long bh = (long long)blockIdx.x * WAVES + wave;
+  if (bh >= (long long)s.nb * s.H) return;
+  const int b = (int)(bh / s.H), h = (int)(bh % s.H);
+  const int Lk = s.Lk, dh = s.dh;
+  const bool on = lane < dh;
+  const float* Kb = p.K + b * s.k_bs + h * dh + lane;
+  const float* Vb = p.V + b * s.v_bs + h * dh + lane;
+  float* dKb = p.dK + b * s.k_bs + h * dh + lane;
+  float* dVb = p.dV + b * s.v_bs + h * dh + lane;
+  const float q = on ? p.Q[b * s.q_bs + h * dh + lane] : 0.f;
+  const float dO = on ? p.dO[b * s.o_bs + h * dh + lane] : 0.f;
+  const float ds = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
+  float k[LMAX], dP[LMAX], P[LMAX], keepf[LMAX], dk_old[LMAX], dv_old[LMAX];
+#pragma unroll
+  for (int j = 0; j < LMAX; ++j) {
+    const bool in = on && j < Lk;
+    k[j] = in ? Kb[j * s.k_rs] : 0.f;
+    const float vj = in ? Vb[j * s.v_rs] : 0.f;
+    dk_old[j] = (in && accum_kv) ? dKb[j * s.k_rs] : 0.f;
+    dv_old[j] = (in && accum_kv) ? dVb[j * s.v_rs] : 0.f;
+    dP[j] = dO * vj;
+    P[j] = j < Lk ? p.P[bh * Lk + j] : 0.f;
+    keepf[j] = 1.f;
+    if (drop.p > 0.f && j < Lk) keepf[j] = mansy_keep(drop.seed, drop.site, (uint32_t)(bh * Lk + j), drop.p) ? ds : 0.f;
+  }
+  float delta = 0.f;
+#pragma unroll
+  for (int j = 0; j < LMAX; ++j) {
+    if (j < Lk) { dP[j] = wave_sum(dP[j]) * keepf[j]; delta = fmaf(P[j], dP[j], delta); }
+  }
+  float dq = 0.f;
+#pragma unroll
+  for (int j = 0; j < LMAX; ++j) {
+    if (j < Lk) {
+      const float dS = P[j] * (dP[j] - delta) * s.scale;
+      dq = fmaf(dS, k[j], dq);
+      if (on) {
+        dKb[j * s.k_rs] = dk_old[j] + dS * q;
+        dVb[j * s.v_rs] = dv_old[j] + P[j] * keepf[j] * dO;
+      }
+    }
+  }
+  if (on) p.dQ[b * s.q_bs + h * dh + lane] = dq;
+}
+
 int check_shape(const AttnShape& s) {
   MANSY_REQUIRE(s.Lq >= 1 && s.Lq <= LMAX && s.Lk >= 1 && s.Lk <= LMAX, "attn: sequence length %d x %d outside [1,%d]", s.Lq, s.Lk, LMAX);
   MANSY_REQUIRE(s.dh >= 1 && s.dh <= 64, "attn: head dim %d outside [1,64]", s.dh);
@@ -187,7 +278,8 @@ int mansy_launch_attn_fwd(const float* Q, const float* K, const float* V, float*
   const long long n = (long long)s.nb * s.H;
   if (n == 0) return MANSY_OK;
   AttnPtrs p = {Q, K, V, O, P_save, nullptr, nullptr, nullptr, nullptr};
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(mansy_ceil_div(n, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop);
+  if (s.Lq == 1) hipLaunchKernelGGL(attn_fwd_q1_kernel, dim3(mansy_ceil_div(n, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop);
+  else hipLaunchKernelGGL(attn_fwd_kernel, dim3(mansy_ceil_div(n, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }
@@ -199,7 +291,8 @@ int mansy_launch_attn_bwd(const float* Q, const float* K, const float* V, const 
   const long long n = (long long)s.nb * s.H;
   if (n == 0) return MANSY_OK;
   AttnPtrs p = {Q, K, V, nullptr, const_cast<float*>(P_save), dO, dQ, dK, dV};
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(mansy_ceil_div(n, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop, accum_kv);
+  if (s.Lq == 1) hipLaunchKernelGGL(attn_bwd_q1_kernel, dim3(mansy_ceil_div(n, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop, accum_kv);
+  else hipLaunchKernelGGL(attn_bwd_kernel, dim3(mansy_ceil_div(n, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop, accum_kv);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }

@@ -38,56 +38,60 @@ struct TileGeom {
   static constexpr int LDS_FLOATS = KMAJ ? BK * (R + 4) : R * KC_LD;
 };
 
-// Load one operand tile (R rows x BK k) into registers with bounds guards.
-template <int R, bool KMAJ>
+// Load one operand tile (R rows x BK k) into registers.  Branch-free: every address is clamped into the operand,
+// so the loads of a K-tile issue back to back and ONE vmcnt wait sits in front of the LDS stores (guards written
+// as branches made hipcc serialise every load).  Rows/columns beyond the matrix read a duplicate of the last valid
+// one -- harmless, those accumulators are never stored.  Only k >= k_end must contribute exact zeros; that select is
+// applied in store_tile (after the MFMAs of the current tile) so it does not pull the vmcnt wait forward.
+// VEC: 16-byte loads (ld % 4 == 0, 16-byte aligned base, contiguous-axis extent % 4 == 0).
+template <int R, bool KMAJ, bool VEC>
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, int row0, int nrows, int k0, int k_end,
-                                          float4 (&reg)[TileGeom<R, KMAJ>::LOADS], int tid, int vec_ok) {
+                                          float4 (&reg)[TileGeom<R, KMAJ>::LOADS], int tid) {
 #pragma unroll
   for (int i = 0; i < TileGeom<R, KMAJ>::LOADS; ++i) {
     const int idx = tid + i * NT;
-    int gr, gk0;            // global row / first k of this float4 (K-contig) or k row / first col (K-major)
-    long long off;
-    int lim_inner, inner0;  // bounds on the contiguous axis
-    bool outer_ok;
+    int outer, outer_lim, inner0, lim_inner;
     if (!KMAJ) {
-      const int r = idx >> 3, c4 = idx & 7;
-      gr = row0 + r; gk0 = k0 + c4 * 4;
-      off = (long long)gr * ld + gk0;
-      outer_ok = gr < nrows; inner0 = gk0; lim_inner = k_end;
+      outer = row0 + (idx >> 3); outer_lim = nrows; inner0 = k0 + (idx & 7) * 4; lim_inner = k_end;
     } else {
       constexpr int C4 = R / 4;
-      const int kr = idx / C4, c4 = idx % C4;
-      gk0 = k0 + kr; gr = row0 + c4 * 4;
-      off = (long long)gk0 * ld + gr;
-      outer_ok = gk0 < k_end; inner0 = gr; lim_inner = nrows;
+      outer = k0 + idx / C4; outer_lim = k_end; inner0 = row0 + (idx % C4) * 4; lim_inner = nrows;
     }
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (outer_ok) {
-      if (vec_ok && inner0 + 3 < lim_inner) {
-        v = *reinterpret_cast<const float4*>(P + off);
-      } else {
-        if (inner0 + 0 < lim_inner) v.x = P[off + 0];
-        if (inner0 + 1 < lim_inner) v.y = P[off + 1];
-        if (inner0 + 2 < lim_inner) v.z = P[off + 2];
-        if (inner0 + 3 < lim_inner) v.w = P[off + 3];
-      }
+    const long long base = (long long)min(outer, outer_lim - 1) * ld;
+    float4 v;
+    if (VEC) {
+      v = *reinterpret_cast<const float4*>(P + base + min(inner0, lim_inner - 4));
+    } else {
+      v.x = P[base + min(inner0 + 0, lim_inner - 1)];
+      v.y = P[base + min(inner0 + 1, lim_inner - 1)];
+      v.z = P[base + min(inner0 + 2, lim_inner - 1)];
+      v.w = P[base + min(inner0 + 3, lim_inner - 1)];
     }
     reg[i] = v;
   }
 }
 
+// Write the staged registers to the LDS image, zeroing k >= k_end (K tail of the last tile / split).
 template <int R, bool KMAJ>
-__device__ __forceinline__ void store_tile(float* __restrict__ lds, const float4 (&reg)[TileGeom<R, KMAJ>::LOADS], int tid) {
+__device__ __forceinline__ void store_tile(float* __restrict__ lds, const float4 (&reg)[TileGeom<R, KMAJ>::LOADS], int tid, int k0,
+                                           int k_end) {
 #pragma unroll
   for (int i = 0; i < TileGeom<R, KMAJ>::LOADS; ++i) {
     const int idx = tid + i * NT;
+    float4 v = reg[i];
     if (!KMAJ) {
       const int r = idx >> 3, c4 = idx & 7;
-      *reinterpret_cast<float4*>(lds + r * KC_LD + c4 * 4) = reg[i];
+      const int k = k0 + c4 * 4;
+      if (k + 0 >= k_end) v.x = 0.f;
+      if (k + 1 >= k_end) v.y = 0.f;
+      if (k + 2 >= k_end) v.z = 0.f;
+      if (k + 3 >= k_end) v.w = 0.f;
+      *reinterpret_cast<float4*>(lds + r * KC_LD + c4 * 4) = v;
     } else {
       constexpr int C4 = R / 4;
       const int kr = idx / C4, c4 = idx % C4;
-      *reinterpret_cast<float4*>(lds + kr * (R + 4) + c4 * 4) = reg[i];
+      if (k0 + kr >= k_end) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(lds + kr * (R + 4) + c4 * 4) = v;
     }
   }
 }
@@ -107,7 +111,7 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ lds, int rb,
   }
 }
 
-template <int BM, int BN, bool AK, bool BKM>
+template <int BM, int BN, bool AK, bool BKM, bool VEC>
 __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmParams p) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int A_FLOATS = TileGeom<BM, AK>::LDS_FLOATS;
@@ -134,10 +138,10 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmParams p) {
 
   float4 ra[TileGeom<BM, AK>::LOADS], rb[TileGeom<BN, BKM>::LOADS];
   if (nk > 0) {
-    load_tile<BM, AK>(p.A, p.lda, m0, p.M, k_begin, k_end, ra, tid, p.vec_ok);
-    load_tile<BN, BKM>(p.B, p.ldb, n0, p.N, k_begin, k_end, rb, tid, p.vec_ok);
-    store_tile<BM, AK>(smem, ra, tid);
-    store_tile<BN, BKM>(smem + A_FLOATS, rb, tid);
+    load_tile<BM, AK, VEC>(p.A, p.lda, m0, p.M, k_begin, k_end, ra, tid);
+    load_tile<BN, BKM, VEC>(p.B, p.ldb, n0, p.N, k_begin, k_end, rb, tid);
+    store_tile<BM, AK>(smem, ra, tid, k_begin, k_end);
+    store_tile<BN, BKM>(smem + A_FLOATS, rb, tid, k_begin, k_end);
   }
   __syncthreads();
 
@@ -145,8 +149,8 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmParams p) {
     const int cur = kt & 1;
     if (kt + 1 < nk) {
       const int k0 = k_begin + (kt + 1) * BK;
-      load_tile<BM, AK>(p.A, p.lda, m0, p.M, k0, k_end, ra, tid, p.vec_ok);
-      load_tile<BN, BKM>(p.B, p.ldb, n0, p.N, k0, k_end, rb, tid, p.vec_ok);
+      load_tile<BM, AK, VEC>(p.A, p.lda, m0, p.M, k0, k_end, ra, tid);
+      load_tile<BN, BKM, VEC>(p.B, p.ldb, n0, p.N, k0, k_end, rb, tid);
     }
     const float* a_l = smem + cur * STAGE;
     const float* b_l = a_l + A_FLOATS;
@@ -166,13 +170,15 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmParams p) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
     }
     if (kt + 1 < nk) {
-      store_tile<BM, AK>(smem + (cur ^ 1) * STAGE, ra, tid);
-      store_tile<BN, BKM>(smem + (cur ^ 1) * STAGE + A_FLOATS, rb, tid);
+      const int k0n = k_begin + (kt + 1) * BK;
+      store_tile<BM, AK>(smem + (cur ^ 1) * STAGE, ra, tid, k0n, k_end);
+      store_tile<BN, BKM>(smem + (cur ^ 1) * STAGE + A_FLOATS, rb, tid, k0n, k_end);
     }
     __syncthreads();
   }
 
-  // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+  // Loads (mask / residual) are hoisted into unconditional clamped-address batches; only the stores are predicated.
   const GemmEpilogue& ep = p.ep;
   const bool atomic = ep.accumulate || gridDim.z > 1;
   const float drop_scale = ep.drop.p > 0.f ? 1.f / (1.f - ep.drop.p) : 1.f;
@@ -181,33 +187,60 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmParams p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = n0 + wn * (BN / 2) + j * 32 + r;
-      if (col >= p.N) continue;
-      const float bias = ep.bias ? ep.bias[col] : 0.f;
+      const int colc = min(col, p.N - 1);
+      const int row_base = m0 + wm * (BM / 2) + i * 32 + 4 * h;
+      const float bias = ep.bias ? ep.bias[colc] : 0.f;
+      float v[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int row = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (row >= p.M) continue;
-        float v = acc[i][j][e] + bias;
-        if (ep.relu) v = fmaxf(v, 0.f);
-        if (ep.mask_src) v = ep.mask_src[(long long)row * ep.mask_ld + col] > 0.f ? v * ep.mask_scale : 0.f;
-        if (ep.drop.p > 0.f)
-          v = mansy_keep(ep.drop.seed, ep.drop.site, (uint32_t)row * (uint32_t)p.N + (uint32_t)col, ep.drop.p) ? v * drop_scale : 0.f;
-        if (ep.resid) v += ep.resid[(long long)row * ep.resid_ld + col];
-        float* dst = p.C + (long long)row * p.ldc + col;
-        if (atomic) atomicAdd(dst, v); else *dst = v;
+        v[e] = acc[i][j][e] + bias;
+        if (ep.relu) v[e] = fmaxf(v[e], 0.f);
+      }
+      if (ep.mask_src) {
+        float mk[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          mk[e] = ep.mask_src[(long long)min(row_base + (e & 3) + 8 * (e >> 2), p.M - 1) * ep.mask_ld + colc];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = mk[e] > 0.f ? v[e] * ep.mask_scale : 0.f;
+      }
+      if (ep.drop.p > 0.f) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const uint32_t row = (uint32_t)(row_base + (e & 3) + 8 * (e >> 2));
+          v[e] = mansy_keep(ep.drop.seed, ep.drop.site, row * (uint32_t)p.N + (uint32_t)col, ep.drop.p) ? v[e] * drop_scale : 0.f;
+        }
+      }
+      if (ep.resid) {
+        float rr[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          rr[e] = ep.resid[(long long)min(row_base + (e & 3) + 8 * (e >> 2), p.M - 1) * ep.resid_ld + colc];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] += rr[e];
+      }
+      if (col < p.N) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = row_base + (e & 3) + 8 * (e >> 2);
+          if (row < p.M) {
+            float* dst = p.C + (long long)row * p.ldc + col;
+            if (atomic) atomicAdd(dst, v[e]); else *dst = v[e];
+          }
+        }
       }
     }
   }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool VEC>
 int launch_cfg(const GemmParams& p, int a_kmajor, int b_kmajor, int splits, hipStream_t st) {
   dim3 grid(mansy_ceil_div(p.N, BN), mansy_ceil_div(p.M, BM), splits);
   dim3 block(NT);
-  if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false>), grid, block, 0, st, p);
-  else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true>), grid, block, 0, st, p);
-  else if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, true>), grid, block, 0, st, p);
-  else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false>), grid, block, 0, st, p);
+  if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false, VEC>), grid, block, 0, st, p);
+  else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true, VEC>), grid, block, 0, st, p);
+  else if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, true, VEC>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false, VEC>), grid, block, 0, st, p);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }
@@ -248,8 +281,12 @@ extern "C" int mansy_prof_gemm_collect(double* total_ms, long long* launches, do
 }
 
 static int gemm_dispatch(const GemmParams& p, int tile, int a_kmajor, int b_kmajor, int splits, hipStream_t st) {
-  if (tile == 128) return launch_cfg<128, 128>(p, a_kmajor, b_kmajor, splits, st);
-  return launch_cfg<64, 64>(p, a_kmajor, b_kmajor, splits, st);
+  if (p.vec_ok) {
+    if (tile == 128) return launch_cfg<128, 128, true>(p, a_kmajor, b_kmajor, splits, st);
+    return launch_cfg<64, 64, true>(p, a_kmajor, b_kmajor, splits, st);
+  }
+  if (tile == 128) return launch_cfg<128, 128, false>(p, a_kmajor, b_kmajor, splits, st);
+  return launch_cfg<64, 64, false>(p, a_kmajor, b_kmajor, splits, st);
 }
 
 int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb, int b_kmajor, float* C, int ldc,
@@ -260,14 +297,17 @@ int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B,
   GemmParams p;
   p.A = A; p.B = B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.ep = ep;
   p.vec_ok = ((lda % 4) == 0) && ((ldb % 4) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
-             ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
-  // tile choice: 128x128 when it alone fills the chip, else 64x64
+             ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (K % 4 == 0) && (!a_kmajor || M % 4 == 0) &&
+             (!b_kmajor || N % 4 == 0);
+  const bool plain = !ep.bias && !ep.relu && !ep.mask_src && ep.drop.p == 0.f && !ep.resid;
+  // tile choice: 128x128 when it alone fills the chip -- or when split-K can make up the workgroups (dW products:
+  // 64x64 tiles re-stream both operands through L2 four times as often) -- else 64x64
   const long long t128 = (long long)mansy_ceil_div(M, 128) * mansy_ceil_div(N, 128);
-  int tile = force_tile ? force_tile : (t128 >= 192 ? 128 : 64);
+  const bool can_split = plain && ep.accumulate && K >= 4096;
+  int tile = force_tile ? force_tile : ((t128 >= 192 || can_split) ? 128 : 64);
   const long long tiles = tile == 128 ? t128 : (long long)mansy_ceil_div(M, 64) * mansy_ceil_div(N, 64);
   // split-K only for plain accumulating products (dW = dY^T X): partial sums are atomically added
   int splits = 1;
-  const bool plain = !ep.bias && !ep.relu && !ep.mask_src && ep.drop.p == 0.f && !ep.resid;
   if (force_splitk > 0) splits = force_splitk;
   else if (plain && ep.accumulate && tiles < 256) {
     splits = (int)((512 + tiles - 1) / tiles);

@@ -136,6 +136,83 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   }
 }
 
+// Vectorised backward for C % 256 == 0, C <= 1024: float4 per lane, column sums kept in registers.
+__global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __restrict__ dy, const float* __restrict__ z,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                const float* __restrict__ w, float* __restrict__ dz,
+                                                                float* __restrict__ dz_drop, MansyDrop drop, float* __restrict__ dw,
+                                                                float* __restrict__ dbias, int rows, int C) {
+  extern __shared__ float red[];      // [4 waves][2][C]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wave_global = (blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * 256) >> 6;
+  const int nv = C >> 8;
+  const float dsc = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
+  const float invC = 1.f / (float)C;
+  float4 ww[LN_MAXV], adw[LN_MAXV], adb[LN_MAXV];
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    adw[i] = make_float4(0.f, 0.f, 0.f, 0.f); adb[i] = adw[i];
+    ww[i] = i < nv ? *reinterpret_cast<const float4*>(w + (i * 64 + lane) * 4) : adw[i];
+  }
+  for (int row = wave_global; row < rows; row += nwaves) {
+    const long long base = (long long)row * C;
+    const float mu = mean[row], rs = rstd[row];
+    float4 d[LN_MAXV], xh[LN_MAXV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      if (i < nv) {
+        const long long off = base + (i * 64 + lane) * 4;
+        d[i] = *reinterpret_cast<const float4*>(dy + off);
+        const float4 zz = *reinterpret_cast<const float4*>(z + off);
+        xh[i] = make_float4((zz.x - mu) * rs, (zz.y - mu) * rs, (zz.z - mu) * rs, (zz.w - mu) * rs);
+        const float gx = d[i].x * ww[i].x, gy = d[i].y * ww[i].y, gz = d[i].z * ww[i].z, gw = d[i].w * ww[i].w;
+        s1 += (gx + gy) + (gz + gw);
+        s2 += (gx * xh[i].x + gy * xh[i].y) + (gz * xh[i].z + gw * xh[i].w);
+      }
+    }
+    s1 = wave_sum(s1) * invC; s2 = wave_sum(s2) * invC;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      if (i < nv) {
+        const long long off = base + (i * 64 + lane) * 4;
+        float4 o;
+        o.x = rs * (d[i].x * ww[i].x - s1 - xh[i].x * s2); o.y = rs * (d[i].y * ww[i].y - s1 - xh[i].y * s2);
+        o.z = rs * (d[i].z * ww[i].z - s1 - xh[i].z * s2); o.w = rs * (d[i].w * ww[i].w - s1 - xh[i].w * s2);
+        *reinterpret_cast<float4*>(dz + off) = o;
+        if (dz_drop) {
+          float4 od = o;
+          if (drop.p > 0.f) {
+            od.x = mansy_keep(drop.seed, drop.site, (uint32_t)(off + 0), drop.p) ? o.x * dsc : 0.f;
+            od.y = mansy_keep(drop.seed, drop.site, (uint32_t)(off + 1), drop.p) ? o.y * dsc : 0.f;
+            od.z = mansy_keep(drop.seed, drop.site, (uint32_t)(off + 2), drop.p) ? o.z * dsc : 0.f;
+            od.w = mansy_keep(drop.seed, drop.site, (uint32_t)(off + 3), drop.p) ? o.w * dsc : 0.f;
+          }
+          *reinterpret_cast<float4*>(dz_drop + off) = od;
+        }
+        adw[i].x += d[i].x * xh[i].x; adw[i].y += d[i].y * xh[i].y; adw[i].z += d[i].z * xh[i].z; adw[i].w += d[i].w * xh[i].w;
+        adb[i].x += d[i].x; adb[i].y += d[i].y; adb[i].z += d[i].z; adb[i].w += d[i].w;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    if (i < nv) {
+      *reinterpret_cast<float4*>(red + (wave * 2 + 0) * C + (i * 64 + lane) * 4) = adw[i];
+      *reinterpret_cast<float4*>(red + (wave * 2 + 1) * C + (i * 64 + lane) * 4) = adb[i];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < 4; ++wv) { a0 += red[(wv * 2 + 0) * C + c]; a1 += red[(wv * 2 + 1) * C + c]; }
+    if (dw) atomicAdd(dw + c, a0);
+    if (dbias) atomicAdd(dbias + c, a1);
+  }
+}
+
 // ------------------------------------------------------------------ DistillLayer tail
 // column sums of x and x^2 over rows -> doubles
 __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__ x, int rows, int C, double* __restrict__ stats) {
@@ -265,8 +342,12 @@ int mansy_launch_layernorm_bwd(const float* dy, const float* z, const float* mea
   const int grid = min(mansy_ceil_div(rows, 16), 1024);
   const size_t lds = (size_t)4 * 2 * C * sizeof(float);
   MANSY_REQUIRE(lds <= 64 * 1024, "layernorm_bwd: C=%d too large", C);
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias,
-                     rows, C);
+  if ((C % 256) == 0 && C <= 256 * LN_MAXV)
+    hipLaunchKernelGGL(layernorm_bwd_vec_kernel, dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias,
+                       rows, C);
+  else
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias,
+                       rows, C);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }

@@ -221,7 +221,7 @@ class ViewportTransformerMTIO(nn.Module):
             self._ws = {key: ws}       # keep one live workspace (largest user is B=4096: ~6.5 GB)
         return ws
 
-    def _buffers(self):
+    def _engine_buffers(self):
         bn = self.transformer.distill_layer.norm
         return self.positional_embedding.pe, bn.running_mean, bn.running_var, bn.num_batches_tracked
 
@@ -288,7 +288,7 @@ class ViewportTransformerMTIO(nn.Module):
         cfg = self._cfg(B, S)
         ws = self._workspace(cfg)
         arr, _ = self._pointers()
-        pe, rm, rv, _nbt = self._buffers()
+        pe, rm, rv, _nbt = self._engine_buffers()
         out = torch.empty(B, self.fut_window, self.in_channel, dtype=torch.float32, device=history.device)
         check(lib().mansy_vp_sample(ctypes.byref(cfg), arr, ptr(pe), ptr(rm), ptr(rv), ptr(history), ptr(current), ptr(out),
                                     ptr(ws), stream_ptr(history.device)), 'mansy_vp_sample')
@@ -310,7 +310,7 @@ class ViewportTransformerMTIO(nn.Module):
         perms = self._perms_to_device(self._mix_decision(B), history.device)
         p1, p2 = perms if perms is not None else (None, None)
         arr, garr = self._pointers(self._flat_g)
-        pe, rm, rv, nbt = self._buffers()
+        pe, rm, rv, nbt = self._engine_buffers()
         optimizer._ensure_state()
         optimizer.step_count += 1
         g = optimizer.param_groups[0]
@@ -335,7 +335,7 @@ class _VPFunction(torch.autograd.Function):
         cfg = model._cfg(B, S)
         ws = model._workspace(cfg)
         arr, _ = model._pointers()
-        pe, rm, rv, nbt = model._buffers()
+        pe, rm, rv, nbt = model._engine_buffers()
         seed = model._next_seed() if model.training else 0
         pred = torch.empty(B, model.fut_window, cfg.in_ch, dtype=torch.float32, device=src.device)
         check(lib().mansy_vp_forward(ctypes.byref(cfg), arr, ptr(pe), ptr(rm), ptr(rv), ptr(nbt), ptr(src), ptr(cur.reshape(B, -1)),
