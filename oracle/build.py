@@ -16,7 +16,7 @@ def build(force=False):
     srcs = [os.path.join(HERE, s) for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
     if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in srcs):
         return out
-    subprocess.check_call(['gcc', '-O2', '-std=c99', '-shared', '-fPIC', '-o', out] + srcs + ['-lm'])
+    subprocess.check_call(['gcc', '-O2', '-std=c99', '-ffp-contract=off', '-shared', '-fPIC', '-o', out] + srcs + ['-lm'])
     return out
 
 
