@@ -90,6 +90,51 @@ int mansy_tilemap(const float* xy, long long n, int W, int H, int tile_num_w, in
 int mansy_tilemap_iou(const uint64_t* a, const uint64_t* b, long long n, double* iou, void* stream);
 int mansy_tilemap_or_groups(const uint64_t* maps, long long ngroups, int group, uint64_t* out, void* stream);
 
+/* ------------------------------------------------------------------ vectorised streaming environment
+ * Replaces MANSYEnv.reset/step (bitrate_selection/envs/mansy_env.py:99-248) + Simulator/NetworkTrace/PlaybackBuffer/
+ * HMDTrace (bitrate_selection/simulators/*.py) + QoEModel.calculate_qoe (utils/qoe.py:22-34) + action2rates /
+ * allocate_tile_rates (utils/common.py:101-193) for N environments at once.  One observation = one row of
+ * MANSY_OBS_LD floats with the reference's dict keys at fixed offsets: */
+#define MANSY_OBS_DIM 779
+#define MANSY_OBS_LD 780
+#define MANSY_O_THROUGHPUT 0   /* 'throughput'               [8]   */
+#define MANSY_O_SIZE 8         /* 'next_chunk_size'          [5,64] */
+#define MANSY_O_QUALITY 328    /* 'next_chunk_quality'       [5,64] */
+#define MANSY_O_PRED_VP 648    /* 'pred_viewport'            [64]  */
+#define MANSY_O_VP_ACC 712     /* 'viewport_acc'             [8]   */
+#define MANSY_O_PAST_Q 720     /* 'past_viewport_qualities'  [8]   */
+#define MANSY_O_PAST_VAR 728   /* 'past_quality_variances'   [8]   */
+#define MANSY_O_PAST_REBUF 736 /* 'past_rebuffering'         [8]   */
+#define MANSY_O_BUFFER 744     /* 'buffer'                   [1]   */
+#define MANSY_O_QOE_W 745      /* 'qoe_weight'               [3]   */
+#define MANSY_O_ACT_1HOT 748   /* 'action_one_hot'           [15]  */
+#define MANSY_O_RATES_IN 763   /* 'rates_inside'             [8]   */
+#define MANSY_O_RATES_OUT 771  /* 'rates_outside'            [8]   */
+
+typedef struct mansy_env_tables {
+  const int32_t* size; const float* quality; const int32_t* video_len; int n_chunk_max;     /* [n_video][n_chunk_max][5][64] */
+  const uint8_t* vp_gt; const uint8_t* vp_pred; const double* vp_acc;                        /* [n_vp][n_vpchunk_max][64] / [..] */
+  const int32_t* vp_start; const int32_t* vp_end; int n_vpchunk_max;
+  const double* trace_bw; const int32_t* trace_len; int trace_len_max;                       /* [n_trace][trace_len_max] bytes/s */
+  const int32_t* samples; int n_sample; const float* qoe_w;                                  /* [n_sample][4], [n_qoe][3] */
+  int video_rates[5]; int startup_download; int chunk_length; double max_size; double max_throughput;
+  int train_identifier_reward;   /* 1: reward = qoe / sum(w) (mode == 'train' and use_identifier, mansy_env.py:168-177) */
+} mansy_env_tables;
+/* finished-episode records: 8 doubles each = (sample_id, env, n_steps, sum qoe, sum qoe1, sum qoe2, sum qoe3, qoe index) */
+typedef struct mansy_env_episode_log { double* records; unsigned int* count; int capacity; } mansy_env_episode_log;
+
+int mansy_env_state_bytes(void);
+/* env i starts at sample (seed + index_offset + i) % worker_num and strides by worker_num (mansy_env.py:55-56,100-101) */
+int mansy_env_init(void* state, int n_env, int index_offset, int worker_num, int seed, void* stream);
+int mansy_env_reset(const mansy_env_tables* T, void* state, int n_env, float* obs, void* stream);
+/* obs_next: state after the action (terminal observation when done); obs_cur (optional): same, except that finished
+ * environments are reset and show the first observation of their next episode (vector-env auto-reset). */
+int mansy_env_step(const mansy_env_tables* T, void* state, int n_env, const int* actions, float* obs_next, float* obs_cur,
+                   float* reward, unsigned char* done, float* qoe_parts, const mansy_env_episode_log* elog, void* stream);
+/* pred_viewport [n,64] (0/1 floats), actions [n] -> rate version per tile [n,64] */
+int mansy_allocate_tile_rates(const float* pred_viewport, const int* actions, int n, const int video_rates[5], int* versions,
+                              void* stream);
+
 /* ------------------------------------------------------------------ single kernels (unit-test surface) */
 typedef struct mansy_gemm_epilogue {
   const float* bias; int relu; const float* mask_src; int mask_ld; float mask_scale;

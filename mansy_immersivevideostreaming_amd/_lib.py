@@ -24,6 +24,19 @@ class GemmEpilogue(ctypes.Structure):
                 ('accumulate', c_int)]
 
 
+class EnvTables(ctypes.Structure):
+    _fields_ = [('size', c_void_p), ('quality', c_void_p), ('video_len', c_void_p), ('n_chunk_max', c_int),
+                ('vp_gt', c_void_p), ('vp_pred', c_void_p), ('vp_acc', c_void_p), ('vp_start', c_void_p), ('vp_end', c_void_p),
+                ('n_vpchunk_max', c_int), ('trace_bw', c_void_p), ('trace_len', c_void_p), ('trace_len_max', c_int),
+                ('samples', c_void_p), ('n_sample', c_int), ('qoe_w', c_void_p), ('video_rates', c_int * 5),
+                ('startup_download', c_int), ('chunk_length', c_int), ('max_size', ctypes.c_double),
+                ('max_throughput', ctypes.c_double), ('train_identifier_reward', c_int)]
+
+
+class EpisodeLog(ctypes.Structure):
+    _fields_ = [('records', c_void_p), ('count', c_void_p), ('capacity', c_int)]
+
+
 class AttnShape(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ('nb', 'H', 'Lq', 'Lk', 'dh')] + \
                [(n, c_ll) for n in ('q_bs', 'q_rs', 'k_bs', 'k_rs', 'v_bs', 'v_rs', 'o_bs', 'o_rs')] + [('scale', c_float)]
@@ -55,6 +68,11 @@ _PROTOS = {
     'mansy_attn_bwd': [P, P, P, P, P, P, P, P, P, c_float, c_u32, c_u32, c_int, P],
     'mansy_layernorm_fwd': [P, P, P, P, P, P, P, P, c_int, c_int, c_float, P],
     'mansy_layernorm_bwd': [P, P, P, P, P, P, P, c_float, c_u32, c_u32, P, P, c_int, c_int, P],
+    'mansy_env_state_bytes': [],
+    'mansy_env_init': [P, c_int, c_int, c_int, c_int, P],
+    'mansy_env_reset': [P, P, c_int, P, P],
+    'mansy_env_step': [P, P, c_int, P, P, P, P, P, P, P, P],
+    'mansy_allocate_tile_rates': [P, P, c_int, P, P, P],
     'mansy_prof_gemm_enable': [c_int],
     'mansy_prof_gemm_collect': [P, P, P],
 }

@@ -1,0 +1,316 @@
+// Device-resident vectorised streaming environment: one 64-lane wavefront per environment, lane = tile
+// (the reference's 8x8 tiling is exactly one wave).  Reference semantics:
+//   MANSYEnv.reset / step                bitrate_selection/envs/mansy_env.py:99-248
+//   action2rates, allocate_tile_rates    bitrate_selection/utils/common.py:101-119, 142-193
+//   Simulator / NetworkTrace / PlaybackBuffer / HMDTrace  bitrate_selection/simulators/*.py
+//   QoEModel.calculate_qoe               bitrate_selection/utils/qoe.py:22-34
+// Bit-exactness contract (checked against oracle/env.c, itself pinned on reference trajectories):
+//   * ring index of the pyramid allocation = 8-neighbour BFS depth on the torus == toroidal Chebyshev distance,
+//     computed by <= 4 bit-parallel dilations of the 64-bit predicted-viewport mask (rows are bytes);
+//   * chunk size = exact integer wave reduction; download time / buffer / rebuffer in IEEE double with FMA
+//     contraction OFF (Python floats); QoE sums are SEQUENTIAL float32 adds in tile order (Python sum() over a
+//     float32 array), done with v_readlane in a fixed order -- never a tree reduction.
+// Tables (manifests, viewport maps, traces) stay resident in HBM; an env step touches 2 x 1280 B of manifest rows,
+// 2 x 64 B of viewport maps, a few trace bins and writes one 3 120-byte observation row (coalesced 256-B pieces).
+#include "mansy_kernels.h"
+#include "../../include/mansy_hip.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int NTL = 64, NR = 5, PAST_K = 8, N_ACTION = 15;
+constexpr int OBS_LD = MANSY_OBS_LD;
+__constant__ int A2R[N_ACTION][2] = {{1,0},{2,0},{3,0},{4,0},{2,1},{3,1},{4,1},{3,2},{4,2},{4,3},{0,0},{1,1},{2,2},{3,3},{4,4}};
+
+struct EnvState {           // per-environment record (AoS, 256 bytes)
+  int worker_id, worker_num, sample_id;
+  int video, vp, trace, qoe;
+  int next_chunk, end_chunk;
+  int cur_idx, has_prev, log_n;
+  double cur_time, buf_size, last_chunk_accuracy;
+  double log_qoe, log_qoe1, log_qoe2, log_qoe3;
+  float prev_vq, buffer0;
+  float past_throughput[PAST_K], past_acc[PAST_K], past_in[PAST_K], past_out[PAST_K], past_q[PAST_K], past_var[PAST_K],
+      past_rebuf[PAST_K];
+};
+
+__device__ __forceinline__ unsigned long long dilate8(unsigned long long m) {
+  // columns +-1 with wrap inside each row byte, then rows +-1 with wrap (rotate by 8 bits)
+  const unsigned long long l = ((m << 1) & 0xFEFEFEFEFEFEFEFEull) | ((m >> 7) & 0x0101010101010101ull);
+  const unsigned long long r = ((m >> 1) & 0x7F7F7F7F7F7F7F7Full) | ((m << 7) & 0x8080808080808080ull);
+  const unsigned long long h = m | l | r;
+  return h | (h << 8) | (h >> 56) | (h >> 8) | (h << 56);
+}
+
+__device__ __forceinline__ int closest_rate_version(const int* rates, int rate) {
+  int ver = 0, gap = abs(rates[0] - rate);
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const int g = abs(rates[i] - rate);
+    if (g < gap) { ver = i; gap = g; }
+    else if (g == gap && rates[i] < rates[ver]) ver = i;
+  }
+  return ver;
+}
+
+__device__ __forceinline__ float seq_sum64(float x) {      // ((..(0 + x0) + x1) ..) + x63, float32, tile order
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < NTL; ++t) s = s + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), t));
+  return s;
+}
+
+__device__ __forceinline__ int wave_isum(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ void write_obs(const mansy_env_tables& T, const EnvState& s, int chunk, int action, int lane, float* __restrict__ obs) {
+  const size_t mrow = ((size_t)s.video * T.n_chunk_max + chunk) * NR * NTL;
+  const float inv_rate = (float)T.video_rates[NR - 1];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    obs[MANSY_O_SIZE + r * NTL + lane] = (float)T.size[mrow + r * NTL + lane] / (float)T.max_size;
+    obs[MANSY_O_QUALITY + r * NTL + lane] = T.quality[mrow + r * NTL + lane] / inv_rate;
+  }
+  obs[MANSY_O_PRED_VP + lane] = (float)T.vp_pred[((size_t)s.vp * T.n_vpchunk_max + (chunk - T.vp_start[s.vp])) * NTL + lane];
+  // the 68 scalar slots: 0..7 throughput | 712..743 acc,q,var,rebuf | 744 buffer | 745..747 qoe_w | 748..762 one-hot |
+  // 763..778 rates in/out | 779 pad
+  if (lane < PAST_K) {
+    obs[MANSY_O_THROUGHPUT + lane] = s.past_throughput[lane];
+    obs[MANSY_O_VP_ACC + lane] = s.past_acc[lane];
+    obs[MANSY_O_PAST_Q + lane] = s.past_q[lane];
+    obs[MANSY_O_PAST_VAR + lane] = s.past_var[lane];
+    obs[MANSY_O_PAST_REBUF + lane] = s.past_rebuf[lane];
+    obs[MANSY_O_RATES_IN + lane] = s.past_in[lane];
+    obs[MANSY_O_RATES_OUT + lane] = s.past_out[lane];
+  }
+  const float* w = T.qoe_w + 3 * s.qoe;
+  const float wsum = (w[0] + w[1]) + w[2];
+  if (lane < 3) obs[MANSY_O_QOE_W + lane] = w[lane] / wsum;
+  if (lane < N_ACTION) obs[MANSY_O_ACT_1HOT + lane] = (lane == action) ? 1.f : 0.f;
+  if (lane == 0) { obs[MANSY_O_BUFFER] = s.buffer0 / (float)T.startup_download; obs[MANSY_OBS_DIM] = 0.f; }
+}
+
+__device__ void do_reset(const mansy_env_tables& T, EnvState& s) {
+  s.sample_id = s.worker_id % T.n_sample;   // (reference: IndexError if worker_id >= len(samples); wrap instead)
+  s.worker_id = (s.worker_id + s.worker_num) % T.n_sample;
+  const int* sm = T.samples + 4 * s.sample_id;
+  s.video = sm[0]; s.vp = sm[1]; s.trace = sm[2]; s.qoe = sm[3];
+  s.buf_size = (double)(T.chunk_length * 3);
+  s.cur_time = 0.0; s.cur_idx = 0;
+  const int end_chunk = T.vp_end[s.vp], vlen1 = T.video_len[s.video] - 1;
+  s.end_chunk = end_chunk < vlen1 ? end_chunk : vlen1;
+  s.next_chunk = T.startup_download + 1;
+  s.has_prev = 0; s.prev_vq = 0.f;
+  s.last_chunk_accuracy = T.vp_acc[(size_t)s.vp * T.n_vpchunk_max + (s.next_chunk - T.vp_start[s.vp])];
+#pragma unroll
+  for (int i = 0; i < PAST_K; ++i) {
+    s.past_throughput[i] = 0.f; s.past_acc[i] = 0.f; s.past_in[i] = 0.f; s.past_out[i] = 0.f; s.past_q[i] = 0.f; s.past_var[i] = 0.f;
+    s.past_rebuf[i] = 0.f;
+  }
+  s.buffer0 = (float)s.buf_size;
+  s.log_qoe = s.log_qoe1 = s.log_qoe2 = s.log_qoe3 = 0.0; s.log_n = 0;
+}
+
+__device__ __forceinline__ void roll_push(float* ring, float v) {
+#pragma unroll
+  for (int i = PAST_K - 1; i > 0; --i) ring[i] = ring[i - 1];
+  ring[0] = v;
+}
+
+__global__ __launch_bounds__(256) void env_init_kernel(EnvState* st, int n_env, int index_offset, int worker_num, int seed) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n_env) return;
+  EnvState s;
+  memset(&s, 0, sizeof(s));
+  s.worker_num = worker_num;
+  s.worker_id = (seed + index_offset + e) % worker_num;      // tianshou venv.seed(seed): env i gets seed + i (mansy_env.py:253-256)
+  st[e] = s;
+}
+
+__global__ __launch_bounds__(256) void env_reset_kernel(mansy_env_tables T, EnvState* st, int n_env, float* obs) {
+  const int e = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (e >= n_env) return;
+  EnvState s = st[e];                  // every lane holds the (uniform) record; lane 0 writes it back
+  do_reset(T, s);
+  write_obs(T, s, s.next_chunk, -1, lane, obs + (size_t)e * OBS_LD);
+  if (lane == 0) st[e] = s;
+}
+
+__global__ __launch_bounds__(256) void env_step_kernel(mansy_env_tables T, EnvState* st, int n_env, const int* __restrict__ actions,
+                                                       float* obs_next, float* obs_cur, float* reward, unsigned char* done,
+                                                       float* qoe_parts, mansy_env_episode_log elog) {
+  const int e = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (e >= n_env) return;
+  EnvState s = st[e];
+  const int action = actions[e];
+  const int rin = (action >= 0 && action < N_ACTION) ? A2R[action][0] : 0;
+  const int rout = (action >= 0 && action < N_ACTION) ? A2R[action][1] : 0;
+  const int chunk = s.next_chunk;
+  const size_t vrow = ((size_t)s.vp * T.n_vpchunk_max + (chunk - T.vp_start[s.vp])) * NTL;
+  const bool in_pred = T.vp_pred[vrow + lane] == 1;
+  const float gv = (float)T.vp_gt[vrow + lane];
+  // ---- pyramid tile-rate allocation
+  unsigned long long m = __ballot(in_pred);
+  int dist = ((m >> lane) & 1ull) ? 0 : -1;
+  if (m == 0ull) dist = 0;                              // empty prediction: BFS queue empty => every scale stays 0
+  else {
+#pragma unroll
+    for (int sidx = 1; sidx <= 4; ++sidx) {
+      m = dilate8(m);
+      if (dist < 0 && ((m >> lane) & 1ull)) dist = sidx;
+    }
+  }
+  int rates[NR];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) rates[i] = T.video_rates[i];
+  const int ver = dist == 0 ? rin : closest_rate_version(rates, rates[rout] / (dist > 0 ? dist : 1));
+  // ---- Simulator.simulate_download
+  const size_t mrow = ((size_t)s.video * T.n_chunk_max + chunk) * NR * NTL;
+  const int chunk_size = wave_isum(T.size[mrow + ver * NTL + lane]);
+  const float tq = T.quality[mrow + ver * NTL + lane];
+  const double* bw = T.trace_bw + (size_t)s.trace * T.trace_len_max;
+  const int tlen = T.trace_len[s.trace];
+  const double start = s.cur_time;
+  double size = (double)chunk_size;
+  while (size > 0) {
+    const double fl = floor(s.cur_time + 1);
+    const double remain = (fl - s.cur_time) * bw[s.cur_idx];
+    if (size >= remain) { s.cur_idx = (s.cur_idx + 1) % tlen; s.cur_time = fl; size -= remain; }
+    else { s.cur_time += size / bw[s.cur_idx]; size = 0; }
+  }
+  const double download_time = s.cur_time - start;
+  double rebuf = 0.0;
+  if (download_time > s.buf_size) { rebuf = download_time - s.buf_size; s.buf_size = (double)T.chunk_length; }
+  else s.buf_size = s.buf_size - download_time + (double)T.chunk_length;
+  s.next_chunk += 1;
+  const bool over = s.next_chunk > s.end_chunk;
+  // ---- QoE (sequential float32 sums in tile order)
+  const float s_vq = seq_sum64(gv * tq), s_v = seq_sum64(gv);
+  float vq = s_vq / s_v;
+  const float s_var = seq_sum64(gv * fabsf(tq - vq));
+  const float max_rate = (float)rates[NR - 1];
+  const float intra = (s_var / s_v) / max_rate;
+  vq = vq / max_rate;
+  const float inter = s.has_prev ? fabsf(vq - s.prev_vq) : 0.f;
+  s.prev_vq = vq; s.has_prev = 1;
+  const float* w = T.qoe_w + 3 * s.qoe;
+  const float qoe1 = vq, qoe3 = intra + inter;
+  const float qoe = w[0] * qoe1 - w[1] * (float)rebuf - w[2] * qoe3;
+  const float wsum = (w[0] + w[1]) + w[2];
+  const float rew = T.train_identifier_reward ? qoe / wsum : qoe;
+  s.log_qoe += (double)qoe; s.log_qoe1 += (double)qoe1; s.log_qoe2 += rebuf; s.log_qoe3 += (double)qoe3; s.log_n += 1;
+  // ---- history rings
+  roll_push(s.past_throughput, (float)(((double)chunk_size / download_time) / T.max_throughput));
+  roll_push(s.past_acc, (float)s.last_chunk_accuracy);
+  roll_push(s.past_in, (float)((double)rates[rin] / (double)rates[NR - 1]));
+  roll_push(s.past_out, (float)((double)rates[rout] / (double)rates[NR - 1]));
+  s.buffer0 = (float)s.buf_size;
+  roll_push(s.past_q, qoe1);
+  roll_push(s.past_rebuf, (float)(rebuf / (double)T.startup_download));
+  roll_push(s.past_var, qoe3);
+  if (!over) s.last_chunk_accuracy = T.vp_acc[(size_t)s.vp * T.n_vpchunk_max + (s.next_chunk - T.vp_start[s.vp])];
+  write_obs(T, s, over ? chunk : s.next_chunk, action, lane, obs_next + (size_t)e * OBS_LD);
+  if (lane == 0) {
+    reward[e] = rew;
+    done[e] = over ? 1 : 0;
+    if (qoe_parts) { qoe_parts[4 * e + 0] = qoe; qoe_parts[4 * e + 1] = qoe1; qoe_parts[4 * e + 2] = (float)rebuf; qoe_parts[4 * e + 3] = qoe3; }
+  }
+  if (over) {
+    if (lane == 0 && elog.records && elog.count) {       // episode summary for the CSV log (mansy_env.py:271-290)
+      const unsigned slot = atomicAdd(elog.count, 1u);
+      if (slot < (unsigned)elog.capacity) {
+        double* r = elog.records + (size_t)slot * 8;
+        r[0] = (double)s.sample_id; r[1] = (double)e; r[2] = (double)s.log_n; r[3] = s.log_qoe; r[4] = s.log_qoe1; r[5] = s.log_qoe2;
+        r[6] = s.log_qoe3; r[7] = (double)s.qoe;
+      }
+    }
+    if (obs_cur) {            // auto-reset: the observation the policy sees next comes from the new episode
+      do_reset(T, s);
+      write_obs(T, s, s.next_chunk, -1, lane, obs_cur + (size_t)e * OBS_LD);
+    }
+  } else if (obs_cur && obs_cur != obs_next) {
+    write_obs(T, s, s.next_chunk, action, lane, obs_cur + (size_t)e * OBS_LD);
+  }
+  if (lane == 0) st[e] = s;
+}
+
+__global__ __launch_bounds__(256) void alloc_rates_kernel(const float* __restrict__ pred_vp, const int* __restrict__ actions, int n,
+                                                          mansy_env_tables T, int* __restrict__ versions) {
+  const int e = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (e >= n) return;
+  const int action = actions[e];
+  const int rin = (action >= 0 && action < N_ACTION) ? A2R[action][0] : 0;
+  const int rout = (action >= 0 && action < N_ACTION) ? A2R[action][1] : 0;
+  unsigned long long m = __ballot(pred_vp[(size_t)e * NTL + lane] == 1.0f);
+  int dist = ((m >> lane) & 1ull) ? 0 : -1;
+  if (m == 0ull) dist = 0;
+  else {
+#pragma unroll
+    for (int sidx = 1; sidx <= 4; ++sidx) { m = dilate8(m); if (dist < 0 && ((m >> lane) & 1ull)) dist = sidx; }
+  }
+  int rates[NR];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) rates[i] = T.video_rates[i];
+  versions[(size_t)e * NTL + lane] = dist == 0 ? rin : closest_rate_version(rates, rates[rout] / (dist > 0 ? dist : 1));
+}
+
+int check_tables(const mansy_env_tables* T) {
+  MANSY_REQUIRE(T, "env: null tables");
+  MANSY_REQUIRE(T->size && T->quality && T->video_len && T->vp_gt && T->vp_pred && T->vp_acc && T->vp_start && T->vp_end && T->trace_bw &&
+                    T->trace_len && T->samples && T->qoe_w, "env: null table pointer");
+  MANSY_REQUIRE(T->n_sample >= 1 && T->n_chunk_max >= 1 && T->n_vpchunk_max >= 1 && T->trace_len_max >= 1, "env: empty tables");
+  return MANSY_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mansy_env_state_bytes(void) { return (int)sizeof(EnvState); }
+
+int mansy_env_init(void* state, int n_env, int index_offset, int worker_num, int seed, void* stream) {
+  MANSY_REQUIRE(state && n_env >= 1 && worker_num >= 1, "env_init: bad arguments");
+  hipLaunchKernelGGL(env_init_kernel, dim3(mansy_ceil_div(n_env, 256)), dim3(256), 0, (hipStream_t)stream, (EnvState*)state, n_env,
+                     index_offset, worker_num, seed);
+  MANSY_LAUNCH_CHECK();
+  return MANSY_OK;
+}
+
+int mansy_env_reset(const mansy_env_tables* T, void* state, int n_env, float* obs, void* stream) {
+  int rc = check_tables(T); if (rc) return rc;
+  MANSY_REQUIRE(state && obs && n_env >= 1, "env_reset: bad arguments");
+  hipLaunchKernelGGL(env_reset_kernel, dim3(mansy_ceil_div((long long)n_env * 64, 256)), dim3(256), 0, (hipStream_t)stream, *T,
+                     (EnvState*)state, n_env, obs);
+  MANSY_LAUNCH_CHECK();
+  return MANSY_OK;
+}
+
+int mansy_env_step(const mansy_env_tables* T, void* state, int n_env, const int* actions, float* obs_next, float* obs_cur, float* reward,
+                   unsigned char* done, float* qoe_parts, const mansy_env_episode_log* elog, void* stream) {
+  int rc = check_tables(T); if (rc) return rc;
+  MANSY_REQUIRE(state && actions && obs_next && reward && done && n_env >= 1, "env_step: bad arguments");
+  mansy_env_episode_log el = {nullptr, nullptr, 0};
+  if (elog) el = *elog;
+  hipLaunchKernelGGL(env_step_kernel, dim3(mansy_ceil_div((long long)n_env * 64, 256)), dim3(256), 0, (hipStream_t)stream, *T,
+                     (EnvState*)state, n_env, actions, obs_next, obs_cur, reward, done, qoe_parts, el);
+  MANSY_LAUNCH_CHECK();
+  return MANSY_OK;
+}
+
+int mansy_allocate_tile_rates(const float* pred_viewport, const int* actions, int n, const int video_rates[5], int* versions, void* stream) {
+  MANSY_REQUIRE(pred_viewport && actions && versions && video_rates && n >= 0, "allocate_tile_rates: bad arguments");
+  if (n == 0) return MANSY_OK;
+  mansy_env_tables T;
+  memset(&T, 0, sizeof(T));
+  for (int i = 0; i < 5; ++i) T.video_rates[i] = video_rates[i];
+  hipLaunchKernelGGL(alloc_rates_kernel, dim3(mansy_ceil_div((long long)n * 64, 256)), dim3(256), 0, (hipStream_t)stream, pred_viewport,
+                     actions, n, T, versions);
+  MANSY_LAUNCH_CHECK();
+  return MANSY_OK;
+}
+
+}  // extern "C"

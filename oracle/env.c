@@ -151,7 +151,7 @@ static void write_obs(const oracle_env_tables *T, const oracle_env_state *s, int
 
 /* mansy_env.py:99-152 */
 void oracle_env_reset(const oracle_env_tables *T, oracle_env_state *s, float *obs) {
-    s->sample_id = s->worker_id;
+    s->sample_id = s->worker_id % T->n_sample;   /* reference: IndexError if worker_id >= len(samples); wrap instead */
     s->worker_id = (s->worker_id + s->worker_num) % T->n_sample;
     const int32_t *sm = T->samples + 4 * s->sample_id;
     s->video = sm[0]; s->vp = sm[1]; s->trace = sm[2]; s->qoe = sm[3];

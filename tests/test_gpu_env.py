@@ -1,0 +1,91 @@
+"""GPU parity of the vectorised environment kernel (csrc/env.hip through the C ABI): bit-exact against trajectories of
+the imported reference (tests/golden/env_reference.npz) and, with many environments + auto-reset over long runs, against
+the sequential C oracle (oracle/env.c) on synthetic tables of the bench shape."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import env as oenv  # noqa: E402
+
+Z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'env_reference.npz'))
+TAGS = ['train_id', 'valid_w3', 'train_noid']
+FIELDS = ('size', 'quality', 'video_len', 'vp_gt', 'vp_pred', 'vp_acc', 'vp_start', 'vp_end', 'trace_bw', 'trace_len', 'samples')
+
+
+@pytest.fixture(scope='module')
+def E():
+    if not torch.cuda.is_available():
+        pytest.fail('GPU tests need a ROCm device (no CPU fallback exists)')
+    from mansy_immersivevideostreaming_amd.bitrate_selection.envs import mansy_env
+    return mansy_env
+
+
+def u32(t):
+    return np.ascontiguousarray(t).view(np.uint32)
+
+
+@pytest.mark.parametrize('tag', TAGS)
+def test_reference_trajectories_bit_exact(E, tag):
+    arrays = {k: Z[f'{tag}/{k}'] for k in FIELDS}
+    seed, worker_num, _, n_ep, tir = (int(x) for x in Z[f'{tag}/meta'])
+    T = E.EnvTables(arrays, Z[f'{tag}/qoe_w'], 'cuda', train_identifier_reward=bool(tir))
+    env = E.MANSYVecEnv(T, 1, seed=seed, index_offset=0, worker_num=worker_num)
+    act = torch.zeros(1, dtype=torch.int32, device='cuda')
+    for e in range(n_ep):
+        obs = env.reset().cpu().numpy()[0, :779]
+        ref_obs = Z[f'{tag}/ep{e}/obs']
+        np.testing.assert_array_equal(u32(obs), u32(ref_obs[0]))
+        for t, a in enumerate(Z[f'{tag}/ep{e}/act']):
+            act[0] = int(a)
+            o, r, d, _ = env.step(act, auto_reset=False)
+            o = o.cpu().numpy()[0, :779]
+            assert bool(d.item()) == bool(Z[f'{tag}/ep{e}/done'][t]), (e, t)
+            assert u32(np.float32(r.item())) == u32(Z[f'{tag}/ep{e}/rew'][t]), (e, t, r.item(), Z[f'{tag}/ep{e}/rew'][t])
+            bad = np.nonzero(u32(o) != u32(ref_obs[t + 1]))[0]
+            assert bad.size == 0, (e, t, bad[:10], o[bad[:10]], ref_obs[t + 1][bad[:10]])
+
+
+def test_many_envs_autoreset_vs_oracle(E):
+    """256 environments, 130 steps (> 2 episodes each) on synthetic bench-shaped tables; every observation, reward and
+    done flag equals the sequential C oracle stepping the same actions."""
+    T = E.EnvTables.synthetic('cuda', n_video=5, n_user=4, n_trace=6, n_chunk=60, seed=3, n_sample=37)
+    OT = oenv.EnvTables({k: T.host[k] for k in FIELDS}, T.host['qoe_w'], train_identifier_reward=True)
+    N, steps, seed = 256, 130, 9
+    venv = E.MANSYVecEnv(T, N, seed=seed)
+    oenvs = [oenv.Env(OT, seed=seed + i, worker_num=N) for i in range(N)]
+    obs = venv.reset().cpu().numpy()
+    cur = np.stack([e.reset() for e in oenvs])
+    np.testing.assert_array_equal(u32(obs[:, :779]), u32(cur))
+    rs = np.random.RandomState(1)
+    n_done = 0
+    for t in range(steps):
+        a = rs.randint(0, 15, size=N).astype(np.int32)
+        o, r, d, _ = venv.step(torch.from_numpy(a).cuda())
+        o, r, d, on = o.cpu().numpy(), r.cpu().numpy(), d.cpu().numpy(), venv.obs_next.cpu().numpy()
+        for i, e in enumerate(oenvs):
+            oo, rr, dd, _ = e.step(int(a[i]))
+            assert dd == bool(d[i]) and u32(np.float32(rr)) == u32(r[i]), (t, i)
+            assert (u32(on[i, :779]) == u32(oo)).all(), (t, i)
+            if dd:
+                oo = e.reset()
+                n_done += 1
+            assert (u32(o[i, :779]) == u32(oo)).all(), (t, i)
+    assert n_done >= 2 * N
+    rec = venv.pop_episode_log()
+    assert len(rec) == n_done and (rec[:, 2] >= 40).all()
+
+
+def test_allocate_tile_rates_kernel_bit_exact(E):
+    from mansy_immersivevideostreaming_amd._lib import check, lib, ptr, stream_ptr
+    import ctypes
+    pv, ver = Z['alloc/pred_viewport'], Z['alloc/versions']          # reference known answers, [40,64] / [40,15,64]
+    P = torch.from_numpy(np.repeat(pv, 15, axis=0).copy()).cuda()
+    A = torch.from_numpy(np.tile(np.arange(15, dtype=np.int32), pv.shape[0])).cuda()
+    out = torch.zeros(P.shape[0], 64, dtype=torch.int32, device='cuda')
+    rates = (ctypes.c_int * 5)(1, 5, 8, 16, 35)
+    check(lib().mansy_allocate_tile_rates(ptr(P), ptr(A), P.shape[0], rates, ptr(out), stream_ptr()), 'alloc')
+    np.testing.assert_array_equal(out.cpu().numpy().reshape(ver.shape), ver)
