@@ -135,6 +135,36 @@ int mansy_env_step(const mansy_env_tables* T, void* state, int n_env, const int*
 int mansy_allocate_tile_rates(const float* pred_viewport, const int* actions, int n, const int video_rates[5], int* versions,
                               void* stream);
 
+/* ------------------------------------------------------------------ bitrate-selection networks + PPO
+ * Replaces FeatureNet/Actor/Critic/QoEIdentifier.forward (bitrate_selection/models/mansy.py:26-155),
+ * calculate_indentifier_reward / train_identifier (utils/mansy_utils.py:9-49), the relabel loop (models/mansy_ppo.py:41-51)
+ * and tianshou==0.4.8's PPOPolicy.process_fn/learn arithmetic behind mansy_ppo.py:53-55.
+ * kind 0 = actor-critic (28 unique tensors: shared feature net, actor head, critic head), kind 1 = identifier (24).
+ * `params`/`grads`: device pointers in mansy_net_param_info order.  obs rows are MANSY_OBS_LD floats. */
+int mansy_net_num_params(int kind);
+int mansy_net_param_info(int kind, int idx, char* name, int name_len, long long* numel, int* ndim, long long shape[4]);
+size_t mansy_ppo_workspace_bytes(int max_batch);
+/* logits [B,16] (15 used; nullable), value [B] (nullable), optional Categorical sampling: act int32 [B], logp [B];
+ * u [B] external uniforms in [0,1) or NULL => counter hash (seed, site, row) */
+int mansy_policy_forward(const float* const* params, const float* obs, int B, float* logits, float* value, int* act, float* logp,
+                         const float* u, uint32_t seed, uint32_t site, void* workspace, int max_batch, void* stream);
+int mansy_policy_evaluate(const float* const* params, const float* obs, int B, const int* act, float* logp, float* value,
+                          void* workspace, int max_batch, void* stream);
+int mansy_identifier_forward(const float* const* params, const float* obs, int B, float* pred /* [B,16], 3 used */, void* workspace,
+                             int max_batch, void* stream);
+int mansy_identifier_train_step(const float* const* params, float* const* grads, float* flat_p, float* flat_g, float* flat_m,
+                                float* flat_v, long long n_flat, const float* obs, int B, float lr, float weight_decay, int step,
+                                float* loss_out, void* workspace, int max_batch, void* stream);
+int mansy_identifier_relabel(const float* const* params, const float* obs, float* rew, float* id_rew, int B, float lamb,
+                             void* workspace, int max_batch, void* stream);
+int mansy_gae_returns(const float* rew, const float* v_s, const float* v_next, const unsigned char* done, int T, int N, double gamma,
+                      double gae_lambda, int rew_norm, double* rms, double* scratch, float* returns, float* adv, void* stream);
+int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, float* flat_p, float* flat_g, float* flat_m,
+                             float* flat_v, long long n_flat, const float* obs_all, const int* idx, const int* act_all,
+                             const float* adv_all, const float* logp_old_all, const float* v_old_all, const float* ret_all, int mb,
+                             float eps_clip, float vf_coef, float ent_coef, int norm_adv, int value_clip, float max_grad_norm, float lr,
+                             float weight_decay, int step, float* stats, void* workspace, int max_batch, void* stream);
+
 /* ------------------------------------------------------------------ single kernels (unit-test surface) */
 typedef struct mansy_gemm_epilogue {
   const float* bias; int relu; const float* mask_src; int mask_ld; float mask_scale;

@@ -73,10 +73,22 @@ _PROTOS = {
     'mansy_env_reset': [P, P, c_int, P, P],
     'mansy_env_step': [P, P, c_int, P, P, P, P, P, P, P, P],
     'mansy_allocate_tile_rates': [P, P, c_int, P, P, P],
+    'mansy_net_num_params': [c_int],
+    'mansy_net_param_info': [c_int, c_int, ctypes.c_char_p, c_int, P, P, P],
+    'mansy_ppo_workspace_bytes': [c_int],
+    'mansy_policy_forward': [P, P, c_int, P, P, P, P, P, c_u32, c_u32, P, c_int, P],
+    'mansy_policy_evaluate': [P, P, c_int, P, P, P, P, c_int, P],
+    'mansy_identifier_forward': [P, P, c_int, P, P, c_int, P],
+    'mansy_identifier_train_step': [P, P, P, P, P, P, c_ll, P, c_int, c_float, c_float, c_int, P, P, c_int, P],
+    'mansy_identifier_relabel': [P, P, P, P, c_int, c_float, P, c_int, P],
+    'mansy_gae_returns': [P, P, P, P, c_int, c_int, ctypes.c_double, ctypes.c_double, c_int, P, P, P, P, P],
+    'mansy_ppo_minibatch_step': [P, P, P, P, P, P, c_ll, P, P, P, P, P, P, P, c_int, c_float, c_float, c_float, c_int, c_int, c_float,
+                                 c_float, c_float, c_int, P, P, c_int, P],
     'mansy_prof_gemm_enable': [c_int],
     'mansy_prof_gemm_collect': [P, P, P],
 }
-_RESTYPES = {'mansy_last_error': ctypes.c_char_p, 'mansy_vp_workspace_bytes': ctypes.c_size_t}
+_RESTYPES = {'mansy_last_error': ctypes.c_char_p, 'mansy_vp_workspace_bytes': ctypes.c_size_t,
+             'mansy_ppo_workspace_bytes': ctypes.c_size_t}
 
 _lib = None
 

@@ -1,0 +1,277 @@
+"""PPO policy with the QoE-identifier reward relabel (reference: bitrate_selection/models/mansy_ppo.py:14-59 on top of
+tianshou==0.4.8's PPOPolicy; net construction at run_mansy.py:205-251), plus the vectorised rollout collector and the
+device-resident rollout buffer that replace tianshou's Collector / VectorReplayBuffer for this path.
+
+Everything numerical happens in libmansy_hip.so; this file sequences engine calls:
+  collect   : T x [policy forward + Categorical sample (1 call) -> env step (1 call)], transitions written in place into
+              step-major slabs [T][N][...] (no per-step host traffic)
+  update    : identifier relabel (1 call) -> critic(obs), critic(obs_next), logp_old (3 calls) -> GAE + return normaliser
+              (1 call) -> repeat x minibatches of `mansy_ppo_minibatch_step` (1 call each)
+tianshou semantics are restated from the 0.4.8 release (T2, parity unpinned -- see oracle/ppo_oracle.py).
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ..._lib import MansyError, check, lib, ptr, stream_ptr
+from ..envs.mansy_env import OBS_LD
+from .mansy import MAXOUT, NetEngine
+
+
+class RolloutBuffer:
+    """[T][N] step-major slabs on the device (what VectorReplayBuffer holds for one collect)."""
+
+    def __init__(self, T, N, device):
+        self.T, self.N, self.device = T, N, device
+        f32 = dict(dtype=torch.float32, device=device)
+        self.obs = torch.zeros(T, N, OBS_LD, **f32)
+        self.obs_next = torch.zeros(T, N, OBS_LD, **f32)
+        self.act = torch.zeros(T, N, dtype=torch.int32, device=device)
+        self.logp = torch.zeros(T, N, **f32)
+        self.rew = torch.zeros(T, N, **f32)
+        self.done = torch.zeros(T, N, dtype=torch.uint8, device=device)
+        self.filled = 0
+
+    def __len__(self):
+        return self.filled * self.N
+
+    def reset(self):
+        self.filled = 0
+
+
+class VecCollector:
+    """Collector counterpart: steps N device environments with the policy, filling a RolloutBuffer."""
+
+    def __init__(self, policy, venv, seed=0):
+        self.policy, self.venv = policy, venv
+        self.obs = None
+        self.seed = int(seed) & 0x7FFFFFFF
+        self.step_count = 0
+        self.env_step = 0
+
+    def reset_env(self):
+        self.obs = self.venv.reset()
+
+    def collect(self, n_step, buffer):
+        """n_step environment steps in total (n_step / N per environment); returns {'n/st': ..}."""
+        N = self.venv.n_env
+        T = max(1, n_step // N)
+        if buffer.T < T or buffer.N != N:
+            raise MansyError('rollout buffer too small')
+        if self.obs is None:
+            self.reset_env()
+        eng = self.policy.engine
+        buffer.reset()
+        for t in range(T):
+            buffer.obs[t].copy_(self.obs)
+            _, _, act, logp = eng._policy_forward(self.obs, False, True, None, self.seed, self.step_count * N)
+            buffer.act[t].copy_(act)
+            buffer.logp[t].copy_(logp)
+            self.obs, _, _, _ = self.venv.step(act, auto_reset=True, obs_next_out=buffer.obs_next[t], reward_out=buffer.rew[t],
+                                               done_out=buffer.done[t])
+            self.step_count += 1
+        buffer.filled = T
+        self.env_step += T * N
+        return {'n/st': T * N}
+
+
+def split_indices(length, size, shuffle=True, merge_last=True):
+    """T2: tianshou Batch.split(size, shuffle=True, merge_last=True) index chunks (np.random.permutation)."""
+    if size == -1:
+        size = length
+    indices = np.random.permutation(length) if shuffle else np.arange(length)
+    merge_last = merge_last and length % size > 0
+    for idx in range(0, length, size):
+        if merge_last and idx + size + size >= length:
+            yield indices[idx:]
+            break
+        yield indices[idx:idx + size]
+
+
+class _ActorCritic(nn.Module):
+    """tianshou.utils.net.common.ActorCritic: only here so state_dict() carries the `_actor_critic.*` duplicates."""
+
+    def __init__(self, actor, critic):
+        super().__init__()
+        self.actor, self.critic = actor, critic
+
+
+class _Result:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class PPOPolicy(nn.Module):
+    """Reference signature (mansy_ppo.py:14-33 + the tianshou keyword arguments used at run_mansy.py:231-251).  `optim` is
+    accepted for signature compatibility; its lr / weight_decay are read from it and the fused Adam(L2) kernel does the step."""
+
+    def __init__(self, actor, critic, optim, dist_fn, eps_clip=0.2, dual_clip=None, value_clip=False, advantage_normalization=True,
+                 recompute_advantage=False, args=None, identifier=None, discount_factor=0.99, max_grad_norm=None, vf_coef=0.5,
+                 ent_coef=0.01, reward_normalization=False, gae_lambda=0.95, max_batchsize=256, action_space=None, action_scaling=False,
+                 identifier_optim=None, **kwargs):
+        super().__init__()
+        if dual_clip is not None or recompute_advantage:
+            raise MansyError('dual_clip / recompute_advantage are not on the reference run configuration (run_mansy.py:308-311)')
+        self.actor, self.critic = actor, critic
+        self._actor_critic = _ActorCritic(actor, critic)
+        self.identifier = identifier
+        self.optim, self.dist_fn, self.args = optim, dist_fn, args
+        self.identifier_optim = identifier_optim
+        self._eps_clip, self._value_clip, self._norm_adv = eps_clip, bool(value_clip), bool(advantage_normalization)
+        self._gamma, self._lambda, self._grad_norm = discount_factor, gae_lambda, max_grad_norm
+        self._weight_vf, self._weight_ent, self._rew_norm = vf_coef, ent_coef, bool(reward_normalization)
+        self.cnt, self.observe_round = 0, 1000
+        self.updating = False
+        self.lr_scheduler = None
+        self.engine = NetEngine(actor=actor, critic=critic, identifier=identifier, max_batch=4096)
+        self._rms = None
+        self._seed_ctr = 0
+
+    # ---- plumbing ---------------------------------------------------------------------------------------------
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        for f in (self.engine.ac, self.engine.idn):
+            if f is not None:
+                f.flatten()
+        self._rms = None
+        return out
+
+    def _hyper(self, optim, default_lr):
+        if optim is None:
+            return default_lr, 0.0
+        g = optim.param_groups[0]
+        return g['lr'], g.get('weight_decay', 0.0)
+
+    def ret_rms(self):
+        """tianshou RunningMeanStd state [mean, var, count] as device doubles."""
+        dev = self.engine.device
+        if self._rms is None or self._rms.device != dev:
+            self._rms = torch.tensor([0.0, 1.0, 0.0], dtype=torch.float64, device=dev)
+        return self._rms
+
+    # ---- reference API ----------------------------------------------------------------------------------------
+    def forward(self, batch, state=None, **kwargs):
+        """tianshou PGPolicy.forward: Batch(logits, act, state, dist); `batch.obs` dict/Batch of numpy arrays or tensor."""
+        from .mansy import obs_to_tensor
+        obs = batch.obs if hasattr(batch, 'obs') else batch['obs']
+        t = obs_to_tensor(obs, self.engine.device)
+        self._seed_ctr += 1
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        logits, _, act, _ = self.engine.policy_forward(t, want_value=False, sample=True, seed=seed, site=self._seed_ctr)
+        return _Result(logits=logits, act=act.long(), state=state, dist=self.dist_fn(logits) if self.dist_fn else None)
+
+    def train_identifier(self, buffer, update_round=2, verbose=True):
+        """utils/mansy_utils.py:9-39 on the collected buffer: np.random.shuffle, 80/20 split, `update_round` full-batch
+        MSE steps with Adam(lr, L2), then the validation loss."""
+        eng = self.engine
+        n = len(buffer)
+        obs = buffer.obs[:buffer.filled].reshape(n, OBS_LD)
+        idx = np.arange(n)
+        np.random.shuffle(idx)
+        idx_t = torch.from_numpy(idx).to(obs.device)
+        obs = obs.index_select(0, idx_t)
+        ntr = int(n * 0.8)
+        tr, va = obs[:ntr].contiguous(), obs[ntr:].contiguous()
+        lr, wd = self._hyper(self.identifier_optim, 1e-4)
+        f = eng.idn
+        losses = []
+        for _ in range(update_round):
+            f.step += 1
+            losses.append(self._identifier_step(tr, lr, wd, f.step))
+        vloss = self._identifier_step(va, lr, wd, 0) if len(va) else None
+        if verbose:
+            for l in losses:
+                print('identifier loss is: ', l.item())
+            if vloss is not None:
+                print('identifier validation loss is: ', vloss.item())
+        return losses, vloss
+
+    def _identifier_step(self, obs, lr, wd, step):
+        eng, f = self.engine, self.engine.idn
+        B = obs.shape[0]
+        if B > eng.max_batch:
+            raise MansyError(f'identifier batch {B} exceeds engine max_batch {eng.max_batch}')
+        arr, garr = f.pointers(grads=True)
+        loss = torch.empty((), dtype=torch.float32, device=obs.device)
+        check(lib().mansy_identifier_train_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(obs), B, lr, wd,
+                                                step, ptr(loss), ptr(eng.workspace()), eng.max_batch, stream_ptr(obs.device)),
+              'mansy_identifier_train_step')
+        return loss
+
+    def relabel(self, buffer, lamb):
+        """mansy_ppo.py:41-48, batched: rew <- (1 - lamb) rew + lamb (1 - MSE(identifier(obs, obs.action_one_hot), obs.qoe_weight))."""
+        eng = self.engine
+        n = len(buffer)
+        obs = buffer.obs[:buffer.filled].reshape(n, OBS_LD)
+        rew = buffer.rew[:buffer.filled].reshape(n)
+        arr, _ = eng.idn.pointers()
+        for s in range(0, n, eng.max_batch):
+            e = min(n, s + eng.max_batch)
+            check(lib().mansy_identifier_relabel(arr, ptr(obs[s:e]), ptr(rew[s:e]), None, e - s, float(lamb), ptr(eng.workspace()), eng.max_batch,
+                                                 stream_ptr(obs.device)), 'mansy_identifier_relabel')
+        self.cnt += n
+
+    def process_fn(self, buffer):
+        """T2: A2CPolicy._compute_returns + PPOPolicy.process_fn: v_s, v_s_, GAE, normalised returns, logp_old."""
+        eng = self.engine
+        T, N = buffer.filled, buffer.N
+        n = T * N
+        dev = buffer.obs.device
+        obs = buffer.obs[:T].reshape(n, OBS_LD)
+        obs_next = buffer.obs_next[:T].reshape(n, OBS_LD)
+        act = buffer.act[:T].reshape(n)
+        arr, _ = eng.ac.pointers()
+        v_s = torch.empty(n, dtype=torch.float32, device=dev)
+        v_next = torch.empty(n, dtype=torch.float32, device=dev)
+        logp_old = torch.empty(n, dtype=torch.float32, device=dev)
+        for s in range(0, n, eng.max_batch):
+            e = min(n, s + eng.max_batch)
+            check(lib().mansy_policy_evaluate(arr, ptr(obs[s:e]), e - s, ptr(act[s:e]), ptr(logp_old[s:e]), ptr(v_s[s:e]), ptr(eng.workspace()),
+                                              eng.max_batch, stream_ptr(dev)), 'mansy_policy_evaluate')
+            check(lib().mansy_policy_evaluate(arr, ptr(obs_next[s:e]), e - s, None, None, ptr(v_next[s:e]), ptr(eng.workspace()), eng.max_batch,
+                                              stream_ptr(dev)), 'mansy_policy_evaluate')
+        returns = torch.empty(n, dtype=torch.float32, device=dev)
+        adv = torch.empty(n, dtype=torch.float32, device=dev)
+        scratch = torch.empty(n + 2, dtype=torch.float64, device=dev)
+        check(lib().mansy_gae_returns(ptr(buffer.rew[:T]), ptr(v_s), ptr(v_next), ptr(buffer.done[:T]), T, N, self._gamma, self._lambda,
+                                      int(self._rew_norm), ptr(self.ret_rms()), ptr(scratch), ptr(returns), ptr(adv), stream_ptr(dev)),
+              'mansy_gae_returns')
+        return dict(obs=obs, act=act, v_s=v_s, logp_old=logp_old, returns=returns, adv=adv, n=n)
+
+    def learn(self, data, batch_size, repeat):
+        """T2: PPOPolicy.learn: `repeat` passes over shuffled minibatches (np.random.permutation, merge_last)."""
+        eng, f = self.engine, self.engine.ac
+        n, dev = data['n'], data['obs'].device
+        lr, wd = self._hyper(self.optim, 5e-4)
+        losses = {'loss': [], 'loss/clip': [], 'loss/vf': [], 'loss/ent': []}
+        stats_all = []
+        for _ in range(repeat):
+            for chunk in split_indices(n, batch_size):
+                idx = torch.from_numpy(chunk.astype(np.int32)).to(dev)
+                f.step += 1
+                stats = torch.empty(4, dtype=torch.float32, device=dev)
+                arr, garr = f.pointers(grads=True)
+                check(lib().mansy_ppo_minibatch_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(data['obs']),
+                                                     ptr(idx), ptr(data['act']), ptr(data['adv']), ptr(data['logp_old']), ptr(data['v_s']),
+                                                     ptr(data['returns']), idx.numel(), self._eps_clip, self._weight_vf, self._weight_ent,
+                                                     int(self._norm_adv), int(self._value_clip), float(self._grad_norm or 0.0), lr, wd, f.step,
+                                                     ptr(stats), ptr(eng.workspace()), eng.max_batch, stream_ptr(dev)), 'mansy_ppo_minibatch_step')
+                stats_all.append(stats)
+        st = torch.stack(stats_all).cpu().numpy()
+        for j, k in enumerate(('loss', 'loss/clip', 'loss/vf', 'loss/ent')):
+            losses[k] = st[:, j].tolist()
+        return losses
+
+    def update(self, sample_size, buffer, is_train=False, batch_size=512, repeat=2, **kwargs):
+        """mansy_ppo.py:36-59."""
+        if buffer is None or len(buffer) == 0:
+            return {}
+        if self.args is not None and getattr(self.args, 'use_identifier', False) and is_train:
+            self.relabel(buffer, self.args.lamb)
+        self.updating = True
+        data = self.process_fn(buffer)
+        result = self.learn(data, batch_size, repeat)
+        self.updating = False
+        return result

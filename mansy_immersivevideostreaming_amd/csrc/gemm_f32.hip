@@ -194,7 +194,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         v[e] = acc[i][j][e] + bias;
-        if (ep.relu) v[e] = fmaxf(v[e], 0.f);
+        if (ep.relu) v[e] = v[e] > 0.f ? v[e] : v[e] * ep.relu_slope;
       }
       if (ep.mask_src) {
         float mk[16];
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmParams p) {
         for (int e = 0; e < 16; ++e)
           mk[e] = ep.mask_src[(long long)min(row_base + (e & 3) + 8 * (e >> 2), p.M - 1) * ep.mask_ld + colc];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = mk[e] > 0.f ? v[e] * ep.mask_scale : 0.f;
+        for (int e = 0; e < 16; ++e) v[e] = mk[e] > 0.f ? v[e] * ep.mask_scale : v[e] * ep.mask_neg;
       }
       if (ep.drop.p > 0.f) {
 #pragma unroll

@@ -9,14 +9,16 @@
 //   a_kmajor == 1: A(m,k) at A[k*lda + m]      (row-major [K,M],  i.e. A^T stored)
 //   b_kmajor == 0: B(k,n) at B[n*ldb + k]      (row-major [N,K],  torch Linear weight)
 //   b_kmajor == 1: B(k,n) at B[k*ldb + n]      (row-major [K,N])
-// Epilogue order: +bias[n] -> relu -> mask (mask_src[m,n] > 0 ? v*mask_scale : 0)
+// Epilogue order: +bias[n] -> (leaky) relu -> mask (mask_src[m,n] > 0 ? v*mask_scale : v*mask_neg)
 //                 -> dropout(site, idx = m*N+n) -> +resid[m,n] -> store / atomicAdd.
 struct GemmEpilogue {
   const float* bias = nullptr;
   int relu = 0;
+  float relu_slope = 0.f;   // LeakyReLU negative slope (0 = ReLU)
   const float* mask_src = nullptr;
   int mask_ld = 0;
   float mask_scale = 1.f;
+  float mask_neg = 0.f;
   MansyDrop drop = {0.f, 0u, 0u};
   const float* resid = nullptr;
   int resid_ld = 0;

@@ -1,0 +1,649 @@
+// Bitrate-selection engine: policy/value/identifier networks, rollout action sampling, identifier training and
+// reward relabel, GAE, and the PPO minibatch update -- each a single C-ABI call that enqueues its whole kernel
+// sequence on one HIP stream (no host sync; hipGraph-capturable).
+//
+// Reference semantics: FeatureNet/Actor/Critic/QoEIdentifier (bitrate_selection/models/mansy.py:5-155),
+// calculate_indentifier_reward + train_identifier (utils/mansy_utils.py:9-49), relabel loop (models/mansy_ppo.py:41-51),
+// tianshou==0.4.8 PPOPolicy.process_fn/learn + A2CPolicy._compute_returns (T2, restated in oracle/ppo_oracle.py).
+//
+// MI355X-first structure:
+//   * the ten branches of a FeatureNet are dense layers on disjoint column ranges of the 780-float observation row,
+//     so the whole net is ONE block-diagonal product  F = LeakyReLU(obs[B,K] * Wbd[1280,K]^T + b)  on the fp32 MFMA GEMM
+//     (K = 748 policy / 764 identifier); Wbd is re-packed from the compact reference-layout parameters after every
+//     optimiser step (3.8 MB) and its gradient is un-packed from one dWbd = dPre^T obs product;
+//   * actor and critic share F inside a minibatch (the reference evaluates the shared FeatureNet twice);
+//   * 128->{15,1,3} output layers, residual add, softmax/sampling, PPO loss and its gradient are fused row-wise kernels.
+#include <string>
+#include <vector>
+#include "mansy_kernels.h"
+#include "../../include/mansy_hip.h"
+
+namespace {
+
+constexpr int HID = 128, NB = 10, FEAT = HID * NB, OBS_LD = MANSY_OBS_LD, NACT = 15, MAXOUT = 16;
+constexpr float SLOPE = 0.01f;
+constexpr int K_POLICY = 748, K_IDENT = 764;
+constexpr int RESID_COL = FEAT - HID;      // 10th branch output is the residual of every head
+
+struct Branch { int off, len; };
+__host__ __device__ inline Branch branch_geom(int j, int identifier) {
+  const int off[NB] = {0, 8, 328, 648, 712, 720, 728, 736, 744, identifier ? MANSY_O_ACT_1HOT : MANSY_O_QOE_W};
+  const int len[NB] = {8, 320, 320, 64, 8, 8, 8, 8, 1, identifier ? 15 : 3};
+  Branch b; b.off = off[j]; b.len = len[j];
+  return b;
+}
+
+struct NetP {                  // one network = feature net + head
+  const float* bw[NB]; const float* bb[NB]; const float* fc_w; const float* fc_b; const float* out_w; const float* out_b;
+  float* gbw[NB]; float* gbb[NB]; float* gfc_w; float* gfc_b; float* gout_w; float* gout_b;
+};
+
+struct ParamInfo { std::string name; long long numel; int ndim; long long shape[4]; };
+void addp(std::vector<ParamInfo>& v, const std::string& n, long long a, long long b = 0, long long c = 0) {
+  ParamInfo p; p.name = n; p.shape[0] = a; p.shape[1] = b; p.shape[2] = c; p.shape[3] = 0; p.ndim = c ? 3 : (b ? 2 : 1);
+  p.numel = a * (b ? b : 1) * (c ? c : 1); v.push_back(p);
+}
+void add_fnet(std::vector<ParamInfo>& v, const std::string& p, int identifier) {
+  static const char* names[8] = {"conv1d1", "conv1d2", "conv1d3", "conv1d4", "conv1d5", "conv1d6", "conv1d7", "conv1d8"};
+  static const int cin[8] = {1, 5, 5, 1, 1, 1, 1, 1};
+  static const int kk[8] = {8, 64, 64, 64, 8, 8, 8, 8};
+  for (int j = 0; j < 8; ++j) { addp(v, p + names[j] + ".0.weight", HID, cin[j], kk[j]); addp(v, p + names[j] + ".0.bias", HID); }
+  addp(v, p + "fc1.0.weight", HID, 1); addp(v, p + "fc1.0.bias", HID);
+  addp(v, p + "fc2.0.weight", HID, identifier ? 15 : 3); addp(v, p + "fc2.0.bias", HID);
+}
+// kind 0: actor-critic (unique tensors: shared feature net, actor head, critic head) ; kind 1: identifier
+std::vector<ParamInfo> net_table(int kind) {
+  std::vector<ParamInfo> v;
+  if (kind == 0) {
+    add_fnet(v, "actor.feature_net.", 0);
+    addp(v, "actor.fc.0.weight", HID, FEAT); addp(v, "actor.fc.0.bias", HID); addp(v, "actor.out.weight", NACT, HID); addp(v, "actor.out.bias", NACT);
+    addp(v, "critic.fc.0.weight", HID, FEAT); addp(v, "critic.fc.0.bias", HID); addp(v, "critic.out.weight", 1, HID); addp(v, "critic.out.bias", 1);
+  } else {
+    add_fnet(v, "identifier.feature_net.", 1);
+    addp(v, "identifier.fc.0.weight", HID, FEAT); addp(v, "identifier.fc.0.bias", HID); addp(v, "identifier.out.weight", 3, HID);
+    addp(v, "identifier.out.bias", 3);
+  }
+  return v;
+}
+// bind: params[0..19] feature net, then head(s)
+void bind_net(const float* const* params, float* const* grads, int head_base, NetP& n) {
+  for (int j = 0; j < NB; ++j) {
+    n.bw[j] = params[2 * j]; n.bb[j] = params[2 * j + 1];
+    n.gbw[j] = grads ? grads[2 * j] : nullptr; n.gbb[j] = grads ? grads[2 * j + 1] : nullptr;
+  }
+  n.fc_w = params[head_base]; n.fc_b = params[head_base + 1]; n.out_w = params[head_base + 2]; n.out_b = params[head_base + 3];
+  n.gfc_w = grads ? grads[head_base] : nullptr; n.gfc_b = grads ? grads[head_base + 1] : nullptr;
+  n.gout_w = grads ? grads[head_base + 2] : nullptr; n.gout_b = grads ? grads[head_base + 3] : nullptr;
+}
+
+// ------------------------------------------------------------------------------------ kernels
+struct PackArgs { const float* bw[NB]; const float* bb[NB]; };
+__global__ __launch_bounds__(256) void pack_wbd_kernel(PackArgs a, int identifier, int K, float* __restrict__ Wbd, float* __restrict__ bbd) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)FEAT * K) return;
+  const int col = (int)(idx % K), row = (int)(idx / K);
+  const int j = row / HID, r = row % HID;
+  const Branch g = branch_geom(j, identifier);
+  float v = 0.f;
+  if (col >= g.off && col < g.off + g.len) v = a.bw[j][r * g.len + (col - g.off)];
+  Wbd[idx] = v;
+  if (col == 0) bbd[row] = a.bb[j][r];
+}
+struct UnpackArgs { float* gbw[NB]; };
+__global__ __launch_bounds__(256) void unpack_dwbd_kernel(const float* __restrict__ dWbd, int identifier, int K, UnpackArgs a) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)FEAT * K) return;
+  const int col = (int)(idx % K), row = (int)(idx / K);
+  const int j = row / HID, r = row % HID;
+  const Branch g = branch_geom(j, identifier);
+  if (col >= g.off && col < g.off + g.len) a.gbw[j][r * g.len + (col - g.off)] += dWbd[idx];
+}
+struct BiasGradArgs { float* gbb[NB]; };
+__global__ __launch_bounds__(256) void scatter_bias_grad_kernel(const float* __restrict__ dbbd, BiasGradArgs a) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= FEAT) return;
+  a.gbb[row / HID][row % HID] += dbbd[row];
+}
+
+// one wave per row: H = A1 + F[:, resid] ; out[k] = H . Wout[k] + b[k] (k < n_out <= 16), optional sigmoid;
+// optional categorical sample (inverse CDF on softmax(out)) with log-prob.
+__global__ __launch_bounds__(256) void head_out_kernel(const float* __restrict__ A1, const float* __restrict__ F, const float* __restrict__ Wout,
+                                                       const float* __restrict__ bout, int n_out, int sigmoid, float* __restrict__ H,
+                                                       float* __restrict__ out, int out_ld, int rows, const float* __restrict__ u_ext,
+                                                       uint32_t seed, uint32_t site, int* __restrict__ act, float* __restrict__ logp) {
+  const int lane = threadIdx.x & 63;
+  const int row = (blockIdx.x * 256 + threadIdx.x) >> 6;
+  if (row >= rows) return;
+  const float h0 = A1[(size_t)row * HID + lane] + F[(size_t)row * FEAT + RESID_COL + lane];
+  const float h1 = A1[(size_t)row * HID + 64 + lane] + F[(size_t)row * FEAT + RESID_COL + 64 + lane];
+  if (H) { H[(size_t)row * HID + lane] = h0; H[(size_t)row * HID + 64 + lane] = h1; }
+  float o[MAXOUT];
+#pragma unroll
+  for (int k = 0; k < MAXOUT; ++k) {
+    o[k] = 0.f;
+    if (k < n_out) {
+      float p = h0 * Wout[k * HID + lane] + h1 * Wout[k * HID + 64 + lane];
+      p = wave_sum(p) + bout[k];
+      if (sigmoid) p = 1.f / (1.f + expf(-p));
+      o[k] = p;
+    }
+  }
+  if (out && lane < n_out) {
+    float mine = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXOUT; ++k) if (k == lane) mine = o[k];
+    out[(size_t)row * out_ld + lane] = mine;
+  }
+  if (act) {                       // Categorical(logits).sample() by inverse CDF; log_prob of the sample
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < MAXOUT; ++k) if (k < n_out) m = fmaxf(m, o[k]);
+    float e[MAXOUT], s = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXOUT; ++k) { e[k] = k < n_out ? expf(o[k] - m) : 0.f; s += e[k]; }
+    const float u = u_ext ? u_ext[row] : mansy_uniform01(seed, site, (uint32_t)row);
+    float c = 0.f; int a = n_out - 1; bool found = false;
+#pragma unroll
+    for (int k = 0; k < MAXOUT; ++k) {
+      if (k < n_out) { c += e[k] / s; if (!found && c > u) { a = k; found = true; } }
+    }
+    if (lane == 0) {
+      act[row] = a;
+      float oa = 0.f;
+#pragma unroll
+      for (int k = 0; k < MAXOUT; ++k) if (k == a) oa = o[k];
+      if (logp) logp[row] = (oa - m) - logf(s);
+    }
+  }
+}
+
+// backward of the output layer + residual: dH[r,c] = sum_k g[r,k] Wout[k,c] ; dA1 = dH * leaky'(A1) ;
+// gWout[k,c] += sum_r g[r,k] H[r,c] ; gbout[k] += sum_r g[r,k]   (g already includes sigmoid' when needed)
+__global__ __launch_bounds__(256) void head_out_bwd_kernel(const float* __restrict__ g, int g_ld, const float* __restrict__ A1,
+                                                           const float* __restrict__ H, const float* __restrict__ Wout, int n_out,
+                                                           float* __restrict__ dH, float* __restrict__ dA1, float* __restrict__ gWout,
+                                                           float* __restrict__ gbout, int rows) {
+  __shared__ float sw[MAXOUT * HID];
+  __shared__ float sb[MAXOUT];
+  for (int i = threadIdx.x; i < MAXOUT * HID; i += 256) sw[i] = 0.f;
+  if (threadIdx.x < MAXOUT) sb[threadIdx.x] = 0.f;
+  __syncthreads();
+  const int c = threadIdx.x & 127;                 // two rows per pass
+  const int half = threadIdx.x >> 7;
+  float aw[MAXOUT], ab[MAXOUT];
+#pragma unroll
+  for (int k = 0; k < MAXOUT; ++k) { aw[k] = 0.f; ab[k] = 0.f; }
+  for (int row = blockIdx.x * 2 + half; row < rows; row += gridDim.x * 2) {
+    float acc = 0.f;
+    const float hv = H[(size_t)row * HID + c];
+#pragma unroll
+    for (int k = 0; k < MAXOUT; ++k) {
+      if (k < n_out) {
+        const float gk = g[(size_t)row * g_ld + k];
+        acc = fmaf(gk, Wout[k * HID + c], acc);
+        aw[k] = fmaf(gk, hv, aw[k]);
+        if (c == 0) ab[k] += gk;
+      }
+    }
+    dH[(size_t)row * HID + c] = acc;
+    const float a1 = A1[(size_t)row * HID + c];
+    dA1[(size_t)row * HID + c] = a1 > 0.f ? acc : acc * SLOPE;
+  }
+#pragma unroll
+  for (int k = 0; k < MAXOUT; ++k) {
+    if (k < n_out) { atomicAdd(&sw[k * HID + c], aw[k]); if (c == 0) atomicAdd(&sb[k], ab[k]); }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_out * HID; i += 256) atomicAdd(gWout + i, sw[i]);
+  if (threadIdx.x < n_out) atomicAdd(gbout + threadIdx.x, sb[threadIdx.x]);
+}
+
+// dPre = (dF + [residual grads in the last 128 columns]) * leaky'(F)
+__global__ __launch_bounds__(256) void featgrad_finish_kernel(float* __restrict__ dF, const float* __restrict__ dH_a, const float* __restrict__ dH_b,
+                                                              const float* __restrict__ F, long long n) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n) return;
+  const int col = (int)(idx % FEAT);
+  const long long row = idx / FEAT;
+  float v = dF[idx];
+  if (col >= RESID_COL) {
+    v += dH_a[row * HID + (col - RESID_COL)];
+    if (dH_b) v += dH_b[row * HID + (col - RESID_COL)];
+  }
+  dF[idx] = F[idx] > 0.f ? v : v * SLOPE;
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx, int n, int ld,
+                                                          float* __restrict__ dst) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int ld4 = ld / 4;
+  if (t >= (long long)n * ld4) return;
+  const int r = (int)(t / ld4), c4 = (int)(t % ld4);
+  reinterpret_cast<float4*>(dst)[(size_t)r * ld4 + c4] = reinterpret_cast<const float4*>(src)[(size_t)idx[r] * ld4 + c4];
+}
+
+// PPO minibatch loss + gradient wrt logits/value (T2: tianshou 0.4.8 PPOPolicy.learn).  One block, rows strided.
+// stats: [0] loss [1] clip [2] vf [3] ent ; adv normalised with the minibatch mean / unbiased std (two-pass).
+struct PPOLossArgs {
+  const float* logits; const float* value; const int* act; const float* adv; const float* logp_old; const float* v_old; const float* ret;
+  const int* idx;          // minibatch row -> buffer row for act/adv/logp_old/v_old/ret (logits/value are minibatch-local)
+  int n; float eps_clip, vf_coef, ent_coef; int norm_adv, value_clip; float adv_eps;
+  int value_ld, dvalue_ld;
+  float* dlogits; float* dvalue; float* stats;
+};
+__device__ float block_sum(float v, float* sh) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
+  return t;
+}
+__global__ __launch_bounds__(1024) void ppo_loss_kernel(PPOLossArgs a) {
+  __shared__ float sh[16];
+  const int n = a.n;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += a.adv[a.idx ? a.idx[i] : i];
+  const float mean = block_sum(s, sh) / (float)n;
+  float q = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) { const float d = a.adv[a.idx ? a.idx[i] : i] - mean; q += d * d; }
+  const float var = block_sum(q, sh) / (float)(n > 1 ? n - 1 : 1);
+  const float stdv = sqrtf(var);
+  float l_clip = 0.f, l_vf = 0.f, l_ent = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int bi = a.idx ? a.idx[i] : i;
+    float adv = a.adv[bi];
+    if (a.norm_adv) adv = (adv - mean) / (stdv + a.adv_eps);
+    const float* lg = a.logits + (size_t)i * MAXOUT;
+    float m = -INFINITY;
+    for (int k = 0; k < NACT; ++k) m = fmaxf(m, lg[k]);
+    float e[NACT], se = 0.f;
+    for (int k = 0; k < NACT; ++k) { e[k] = expf(lg[k] - m); se += e[k]; }
+    const float lse = logf(se);
+    const int act = a.act[bi];
+    const float logp = (lg[act] - m) - lse;
+    const float ratio = expf(logp - a.logp_old[bi]);
+    const float surr1 = ratio * adv;
+    const float rc = fminf(fmaxf(ratio, 1.f - a.eps_clip), 1.f + a.eps_clip);
+    const float surr2 = rc * adv;
+    l_clip += -fminf(surr1, surr2);
+    // d(-min(s1,s2))/dlogp: s1 branch -> -ratio*adv ; s2 branch -> -ratio*adv only while ratio is inside the clip range
+    float dlogp;
+    if (surr1 <= surr2) dlogp = -ratio * adv;
+    else dlogp = (ratio > 1.f - a.eps_clip && ratio < 1.f + a.eps_clip) ? -ratio * adv : 0.f;
+    dlogp /= (float)n;
+    float ent = 0.f;
+    for (int k = 0; k < NACT; ++k) { const float p = e[k] / se; const float lp = (lg[k] - m) - lse; ent -= p * lp; }
+    l_ent += ent;
+    for (int k = 0; k < NACT; ++k) {
+      const float p = e[k] / se, lp = (lg[k] - m) - lse;
+      float g = dlogp * ((k == act ? 1.f : 0.f) - p);
+      g += -a.ent_coef * (-p * (lp + ent)) / (float)n;        // d(-ent_coef * mean H)/dlogit_k = ent_coef * p_k (log p_k + H) / n
+      a.dlogits[(size_t)i * MAXOUT + k] = g;
+    }
+    a.dlogits[(size_t)i * MAXOUT + NACT] = 0.f;
+    const float v = a.value[(size_t)i * a.value_ld], ret = a.ret[bi];
+    float dv;
+    if (a.value_clip) {
+      const float vo = a.v_old[bi];
+      const float diff = v - vo;
+      const float vc = vo + fminf(fmaxf(diff, -a.eps_clip), a.eps_clip);
+      const float vf1 = (ret - v) * (ret - v), vf2 = (ret - vc) * (ret - vc);
+      if (vf1 >= vf2) { l_vf += vf1; dv = -2.f * (ret - v); }
+      else { l_vf += vf2; dv = (diff > -a.eps_clip && diff < a.eps_clip) ? -2.f * (ret - vc) : 0.f; }
+    } else { l_vf += (ret - v) * (ret - v); dv = -2.f * (ret - v); }
+    a.dvalue[(size_t)i * a.dvalue_ld] = a.vf_coef * dv / (float)n;
+  }
+  const float c = block_sum(l_clip, sh) / (float)n;
+  const float vfm = block_sum(l_vf, sh) / (float)n;
+  const float em = block_sum(l_ent, sh) / (float)n;
+  if (threadIdx.x == 0 && a.stats) { a.stats[0] = c + a.vf_coef * vfm - a.ent_coef * em; a.stats[1] = c; a.stats[2] = vfm; a.stats[3] = em; }
+}
+
+// MSE(pred[B,3], obs[:,745:748]) forward + gradient wrt the PRE-sigmoid output (pred = sigmoid(z))
+__global__ __launch_bounds__(256) void ident_mse_kernel(const float* __restrict__ pred, const float* __restrict__ obs, int B, float* __restrict__ dz,
+                                                        double* __restrict__ acc) {
+  double local = 0.0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < B * 3; i += gridDim.x * 256) {
+    const int r = i / 3, k = i % 3;
+    const float p = pred[(size_t)r * MAXOUT + k];
+    const float d = p - obs[(size_t)r * OBS_LD + MANSY_O_QOE_W + k];
+    local += (double)(d * d);
+    if (dz) dz[(size_t)r * MAXOUT + k] = (2.f * d / (float)(B * 3)) * p * (1.f - p);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o, 64);
+  if ((threadIdx.x & 63) == 0) atomicAdd(acc, local);
+}
+__global__ void ident_mse_finish(const double* acc, int B, float* loss) { *loss = (float)(*acc / (double)(B * 3)); }
+
+// rew <- (1 - lamb) * rew + lamb * (1 - mean_k (pred_k - w_k)^2)     (mansy_ppo.py:43-48, mansy_utils.py:42-49)
+__global__ __launch_bounds__(256) void relabel_kernel(const float* __restrict__ pred, const float* __restrict__ obs, float* __restrict__ rew,
+                                                      float* __restrict__ id_rew, int B, float lamb) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= B) return;
+  float s = 0.f;
+  for (int k = 0; k < 3; ++k) { const float d = pred[(size_t)r * MAXOUT + k] - obs[(size_t)r * OBS_LD + MANSY_O_QOE_W + k]; s += d * d; }
+  const float ir = 1.f - s / 3.f;
+  if (id_rew) id_rew[r] = ir;
+  rew[r] = (1.f - lamb) * rew[r] + lamb * ir;
+}
+
+// GAE over [T][N] step-major slabs, one thread per environment, float64 like tianshou's numpy/numba path (T2).
+__global__ __launch_bounds__(256) void gae_kernel(const float* __restrict__ rew, const float* __restrict__ v_s, const float* __restrict__ v_next,
+                                                  const unsigned char* __restrict__ done, int T, int N, double gamma, double lam,
+                                                  const double* __restrict__ rms, int rew_norm, double eps, double* __restrict__ ret_unnorm,
+                                                  float* __restrict__ adv) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= N) return;
+  const double v_scale = rew_norm ? sqrt(rms[1] + eps) : 1.0;
+  double gae = 0.0;
+  for (int t = T - 1; t >= 0; --t) {
+    const size_t i = (size_t)t * N + e;
+    const double vs = (double)v_s[i] * v_scale;
+    const double dn = done[i] ? 1.0 : 0.0;
+    const double vn = (double)v_next[i] * v_scale * (1.0 - dn);
+    const double end = (done[i] || t == T - 1) ? 1.0 : 0.0;       // last collected index of an unfinished episode
+    const double delta = (double)rew[i] + gamma * vn - vs;
+    gae = delta + (1.0 - end) * gamma * lam * gae;
+    adv[i] = (float)gae;
+    ret_unnorm[i] = gae + vs;
+  }
+}
+// running return statistics (tianshou RunningMeanStd) updated on device: rms = [mean, var, count] doubles
+__global__ __launch_bounds__(1024) void ret_stats_kernel(const double* __restrict__ x, long long n, double* __restrict__ part) {
+  __shared__ double sh[2][16];
+  double s = 0.0, q = 0.0;
+  for (long long i = threadIdx.x; i < n; i += blockDim.x) { s += x[i]; q += x[i] * x[i]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s; sh[1][threadIdx.x >> 6] = q; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ts = 0.0, tq = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { ts += sh[0][i]; tq += sh[1][i]; }
+    part[0] = ts; part[1] = tq;
+  }
+}
+__global__ __launch_bounds__(256) void ret_finish_kernel(const double* __restrict__ ret_unnorm, long long n, const double* __restrict__ rms,
+                                                         int rew_norm, double eps, float* __restrict__ ret_out) {
+  // normalise with the OLD variance, then (thread 0 of block 0, after a grid-wide read of rms[1]) merge the batch
+  const double scale = rew_norm ? sqrt(rms[1] + eps) : 1.0;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) ret_out[i] = (float)(ret_unnorm[i] / scale);
+}
+__global__ void rms_merge_kernel(double* rms, const double* part, long long n) {
+  const double bm = part[0] / (double)n, bv = part[1] / (double)n - bm * bm;
+  const double delta = bm - rms[0], tot = rms[2] + (double)n;
+  const double new_mean = rms[0] + delta * (double)n / tot;
+  const double m2 = rms[1] * rms[2] + bv * (double)n + delta * delta * rms[2] * (double)n / tot;
+  rms[0] = new_mean; rms[1] = m2 / tot; rms[2] = tot;
+}
+
+// global L2-norm gradient clipping (torch.nn.utils.clip_grad_norm_): g *= max_norm / (norm + 1e-6) if that is < 1
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long long n, double* __restrict__ acc) {
+  double local = 0.0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) local += (double)g[i] * (double)g[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o, 64);
+  if ((threadIdx.x & 63) == 0) atomicAdd(acc, local);
+}
+__global__ __launch_bounds__(256) void clip_scale_kernel(float* __restrict__ g, long long n, const double* __restrict__ acc, float max_norm) {
+  const float norm = (float)sqrt(*acc);
+  const float coef = max_norm / (norm + 1e-6f);
+  if (coef >= 1.f) return;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) g[i] *= coef;
+}
+
+__global__ __launch_bounds__(256) void logp_kernel(const float* __restrict__ logits, const int* __restrict__ act, int B, float* __restrict__ logp) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= B) return;
+  const float* lg = logits + (size_t)r * MAXOUT;
+  float m = -INFINITY;
+  for (int k = 0; k < NACT; ++k) m = fmaxf(m, lg[k]);
+  float se = 0.f;
+  for (int k = 0; k < NACT; ++k) se += expf(lg[k] - m);
+  logp[r] = (lg[act[r]] - m) - logf(se);
+}
+
+// ------------------------------------------------------------------------------------ workspace
+struct PWork {
+  float *Wbd, *bbd, *F, *A1a, *Ha, *A1c, *Hc, *outa, *outc, *dHa, *dHc, *dA1a, *dA1c, *dF, *dWbd, *dbbd, *obs_mb, *gout, *gout_c;
+  double* acc;
+};
+size_t ppo_layout(int maxB, char* base, PWork& W) {
+  size_t tot = 0;
+  auto f = [&](size_t n) { const size_t off = (tot + 255) & ~size_t(255); tot = off + n * sizeof(float); return (float*)(base ? base + off : nullptr); };
+  W.Wbd = f((size_t)FEAT * K_IDENT); W.bbd = f(FEAT); W.F = f((size_t)maxB * FEAT);
+  W.A1a = f((size_t)maxB * HID); W.Ha = f((size_t)maxB * HID); W.A1c = f((size_t)maxB * HID); W.Hc = f((size_t)maxB * HID);
+  W.outa = f((size_t)maxB * MAXOUT); W.outc = f((size_t)maxB * MAXOUT);
+  W.dHa = f((size_t)maxB * HID); W.dHc = f((size_t)maxB * HID); W.dA1a = f((size_t)maxB * HID); W.dA1c = f((size_t)maxB * HID);
+  W.dF = f((size_t)maxB * FEAT); W.dWbd = f((size_t)FEAT * K_IDENT); W.dbbd = f(FEAT); W.obs_mb = f((size_t)maxB * OBS_LD);
+  W.gout = f((size_t)maxB * MAXOUT); W.gout_c = f((size_t)maxB * MAXOUT);
+  W.acc = (double*)f(16);
+  return tot + 256;
+}
+
+#define RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+
+struct PEng {
+  hipStream_t st; PWork W;
+  int pack(const NetP& n, int identifier) {
+    PackArgs a; for (int j = 0; j < NB; ++j) { a.bw[j] = n.bw[j]; a.bb[j] = n.bb[j]; }
+    const int K = identifier ? K_IDENT : K_POLICY;
+    hipLaunchKernelGGL(pack_wbd_kernel, dim3(mansy_ceil_div((long long)FEAT * K, 256)), dim3(256), 0, st, a, identifier, K, W.Wbd, W.bbd);
+    MANSY_LAUNCH_CHECK();
+    return MANSY_OK;
+  }
+  int featnet(const float* obs, int B, int identifier) {
+    const int K = identifier ? K_IDENT : K_POLICY;
+    GemmEpilogue ep; ep.bias = W.bbd; ep.relu = 1; ep.relu_slope = SLOPE;
+    return mansy_launch_gemm_f32(obs, OBS_LD, 0, W.Wbd, K, 0, W.F, FEAT, B, FEAT, K, ep, 0, 0, st);
+  }
+  int head(const NetP& n, int B, int n_out, int sigmoid, float* A1, float* H, float* out, const float* u, uint32_t seed, uint32_t site, int* act,
+           float* logp) {
+    GemmEpilogue ep; ep.bias = n.fc_b; ep.relu = 1; ep.relu_slope = SLOPE;
+    RC(mansy_launch_gemm_f32(W.F, FEAT, 0, n.fc_w, FEAT, 0, A1, HID, B, HID, FEAT, ep, 0, 0, st));
+    hipLaunchKernelGGL(head_out_kernel, dim3(mansy_ceil_div(B, 4)), dim3(256), 0, st, A1, W.F, n.out_w, n.out_b, n_out, sigmoid, H, out, MAXOUT, B, u,
+                       seed, site, act, logp);
+    MANSY_LAUNCH_CHECK();
+    return MANSY_OK;
+  }
+  // backward of one head given g = dL/d(out pre-sigmoid) [B,MAXOUT]: param grads + dF contribution (accumulate)
+  int head_bwd(const NetP& n, int B, int n_out, const float* g, const float* A1, const float* H, float* dH, float* dA1, bool accumulate_dF) {
+    hipLaunchKernelGGL(head_out_bwd_kernel, dim3(min(mansy_ceil_div(B, 2), 128)), dim3(256), 0, st, g, MAXOUT, A1, H, n.out_w, n_out, dH, dA1, n.gout_w,
+                       n.gout_b, B);
+    MANSY_LAUNCH_CHECK();
+    GemmEpilogue acc; acc.accumulate = 1;
+    RC(mansy_launch_gemm_f32(dA1, HID, 1, W.F, FEAT, 1, n.gfc_w, FEAT, HID, FEAT, B, acc, 0, 0, st));      // gfc_w += dA1^T F
+    RC(mansy_launch_colsum(dA1, HID, B, HID, n.gfc_b, st));
+    GemmEpilogue ep; if (accumulate_dF) { ep.resid = W.dF; ep.resid_ld = FEAT; }
+    return mansy_launch_gemm_f32(dA1, HID, 0, n.fc_w, FEAT, 1, W.dF, FEAT, B, FEAT, HID, ep, 0, 0, st);    // dF (+)= dA1 Wfc
+  }
+  int featnet_bwd(const NetP& n, const float* obs, int B, int identifier, const float* dHa, const float* dHb) {
+    const int K = identifier ? K_IDENT : K_POLICY;
+    hipLaunchKernelGGL(featgrad_finish_kernel, dim3(mansy_ceil_div((long long)B * FEAT, 256)), dim3(256), 0, st, W.dF, dHa, dHb, W.F, (long long)B * FEAT);
+    GemmEpilogue ep;
+    RC(mansy_launch_gemm_f32(W.dF, FEAT, 1, obs, OBS_LD, 1, W.dWbd, K, FEAT, K, B, ep, 0, 1, st));           // dWbd = dPre^T obs
+    UnpackArgs u; for (int j = 0; j < NB; ++j) u.gbw[j] = n.gbw[j];
+    hipLaunchKernelGGL(unpack_dwbd_kernel, dim3(mansy_ceil_div((long long)FEAT * K, 256)), dim3(256), 0, st, W.dWbd, identifier, K, u);
+    MANSY_HIP_CHECK(hipMemsetAsync(W.dbbd, 0, sizeof(float) * FEAT, st));
+    RC(mansy_launch_colsum(W.dF, FEAT, B, FEAT, W.dbbd, st));
+    BiasGradArgs bg; for (int j = 0; j < NB; ++j) bg.gbb[j] = n.gbb[j];
+    hipLaunchKernelGGL(scatter_bias_grad_kernel, dim3(mansy_ceil_div(FEAT, 256)), dim3(256), 0, st, W.dbbd, bg);
+    MANSY_LAUNCH_CHECK();
+    return MANSY_OK;
+  }
+  int clip_and_adam(float* flat_p, float* flat_g, float* m, float* v, long long n, float max_norm, float lr, float wd, int step) {
+    if (max_norm > 0.f) {
+      MANSY_HIP_CHECK(hipMemsetAsync(W.acc, 0, sizeof(double), st));
+      hipLaunchKernelGGL(sumsq_kernel, dim3(256), dim3(256), 0, st, flat_g, n, W.acc);
+      hipLaunchKernelGGL(clip_scale_kernel, dim3(256), dim3(256), 0, st, flat_g, n, W.acc, max_norm);
+      MANSY_LAUNCH_CHECK();
+    }
+    if (step <= 0) return MANSY_OK;      // gradients (clipped) only -- used by parity tests
+    return mansy_launch_adamw(flat_p, flat_g, m, v, n, lr, 0.9f, 0.999f, 1e-8f, wd, step, 0, st);   // Adam with L2 (run_mansy.py:216,226)
+  }
+};
+
+int setup(void* ws, int maxB, hipStream_t st, PEng& e) {
+  MANSY_REQUIRE(ws && maxB >= 1, "ppo: bad workspace / batch");
+  e.st = st;
+  ppo_layout(maxB, (char*)ws, e.W);
+  return MANSY_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mansy_net_num_params(int kind) { return (int)net_table(kind != 0).size(); }
+int mansy_net_param_info(int kind, int idx, char* name, int name_len, long long* numel, int* ndim, long long shape[4]) {
+  const std::vector<ParamInfo> t = net_table(kind != 0);
+  MANSY_REQUIRE(idx >= 0 && idx < (int)t.size(), "net_param_info: index %d out of range", idx);
+  if (name && name_len > 0) { strncpy(name, t[idx].name.c_str(), name_len - 1); name[name_len - 1] = 0; }
+  if (numel) *numel = t[idx].numel;
+  if (ndim) *ndim = t[idx].ndim;
+  if (shape) for (int i = 0; i < 4; ++i) shape[i] = t[idx].shape[i];
+  return MANSY_OK;
+}
+size_t mansy_ppo_workspace_bytes(int max_batch) { PWork W; return max_batch >= 1 ? ppo_layout(max_batch, nullptr, W) : 0; }
+
+// logits [B,16] (15 used), value [B] (nullable => actor only), optional sampling (act/logp; u nullable => hash RNG)
+int mansy_policy_forward(const float* const* params, const float* obs, int B, float* logits, float* value, int* act, float* logp,
+                         const float* u, uint32_t seed, uint32_t site, void* workspace, int max_batch, void* stream) {
+  MANSY_REQUIRE(params && obs && B >= 1 && B <= max_batch, "policy_forward: bad arguments (B=%d, max_batch=%d)", B, max_batch);
+  PEng e; RC(setup(workspace, max_batch, (hipStream_t)stream, e));
+  NetP a, c; bind_net(params, nullptr, 20, a); bind_net(params, nullptr, 24, c);
+  RC(e.pack(a, 0));
+  RC(e.featnet(obs, B, 0));
+  RC(e.head(a, B, NACT, 0, e.W.A1a, e.W.Ha, logits ? logits : e.W.outa, u, seed, site, act, logp));
+  if (value) {
+    RC(e.head(c, B, 1, 0, e.W.A1c, e.W.Hc, e.W.outc, nullptr, 0, 0, nullptr, nullptr));
+    MANSY_HIP_CHECK(hipMemcpy2DAsync(value, sizeof(float), e.W.outc, sizeof(float) * MAXOUT, sizeof(float), B, hipMemcpyDeviceToDevice, e.st));
+  }
+  return MANSY_OK;
+}
+
+int mansy_identifier_forward(const float* const* params, const float* obs, int B, float* pred, void* workspace, int max_batch, void* stream) {
+  MANSY_REQUIRE(params && obs && pred && B >= 1 && B <= max_batch, "identifier_forward: bad arguments");
+  PEng e; RC(setup(workspace, max_batch, (hipStream_t)stream, e));
+  NetP n; bind_net(params, nullptr, 20, n);
+  RC(e.pack(n, 1));
+  RC(e.featnet(obs, B, 1));
+  return e.head(n, B, 3, 1, e.W.A1a, e.W.Ha, pred, nullptr, 0, 0, nullptr, nullptr);
+}
+
+// one full-batch step of train_identifier (mansy_utils.py:20-31): MSE fwd + bwd + Adam(L2).  step <= 0: loss only (validation).
+int mansy_identifier_train_step(const float* const* params, float* const* grads, float* flat_p, float* flat_g, float* flat_m, float* flat_v,
+                                long long n_flat, const float* obs, int B, float lr, float weight_decay, int step, float* loss_out,
+                                void* workspace, int max_batch, void* stream) {
+  MANSY_REQUIRE(params && obs && loss_out && B >= 1 && B <= max_batch, "identifier_train_step: bad arguments");
+  PEng e; RC(setup(workspace, max_batch, (hipStream_t)stream, e));
+  NetP n; bind_net(params, grads, 20, n);
+  RC(e.pack(n, 1));
+  RC(e.featnet(obs, B, 1));
+  RC(e.head(n, B, 3, 1, e.W.A1a, e.W.Ha, e.W.outa, nullptr, 0, 0, nullptr, nullptr));
+  MANSY_HIP_CHECK(hipMemsetAsync(e.W.acc, 0, sizeof(double), e.st));
+  const bool train = step > 0;
+  if (train) MANSY_HIP_CHECK(hipMemsetAsync(e.W.gout, 0, sizeof(float) * (size_t)B * MAXOUT, e.st));
+  hipLaunchKernelGGL(ident_mse_kernel, dim3(min(mansy_ceil_div(B * 3, 256), 256)), dim3(256), 0, e.st, e.W.outa, obs, B, train ? e.W.gout : nullptr, e.W.acc);
+  hipLaunchKernelGGL(ident_mse_finish, dim3(1), dim3(1), 0, e.st, e.W.acc, B, loss_out);
+  MANSY_LAUNCH_CHECK();
+  if (!train) return MANSY_OK;
+  MANSY_REQUIRE(grads && flat_p && flat_g && flat_m && flat_v, "identifier_train_step: null optimiser buffers");
+  MANSY_HIP_CHECK(hipMemsetAsync(flat_g, 0, sizeof(float) * (size_t)n_flat, e.st));
+  RC(e.head_bwd(n, B, 3, e.W.gout, e.W.A1a, e.W.Ha, e.W.dHa, e.W.dA1a, false));
+  RC(e.featnet_bwd(n, obs, B, 1, e.W.dHa, nullptr));
+  return e.clip_and_adam(flat_p, flat_g, flat_m, flat_v, n_flat, 0.f, lr, weight_decay, step);
+}
+
+int mansy_identifier_relabel(const float* const* params, const float* obs, float* rew, float* id_rew, int B, float lamb, void* workspace,
+                             int max_batch, void* stream) {
+  MANSY_REQUIRE(params && obs && rew && B >= 1 && B <= max_batch, "identifier_relabel: bad arguments");
+  PEng e; RC(setup(workspace, max_batch, (hipStream_t)stream, e));
+  NetP n; bind_net(params, nullptr, 20, n);
+  RC(e.pack(n, 1));
+  RC(e.featnet(obs, B, 1));
+  RC(e.head(n, B, 3, 1, e.W.A1a, e.W.Ha, e.W.outa, nullptr, 0, 0, nullptr, nullptr));
+  hipLaunchKernelGGL(relabel_kernel, dim3(mansy_ceil_div(B, 256)), dim3(256), 0, e.st, e.W.outa, obs, rew, id_rew, B, lamb);
+  MANSY_LAUNCH_CHECK();
+  return MANSY_OK;
+}
+
+// log-prob of given actions under logits [B,16]
+int mansy_policy_evaluate(const float* const* params, const float* obs, int B, const int* act, float* logp, float* value, void* workspace,
+                          int max_batch, void* stream) {
+  MANSY_REQUIRE(params && obs && B >= 1 && B <= max_batch, "policy_evaluate: bad arguments");
+  PEng e; RC(setup(workspace, max_batch, (hipStream_t)stream, e));
+  NetP a, c; bind_net(params, nullptr, 20, a); bind_net(params, nullptr, 24, c);
+  RC(e.pack(a, 0));
+  RC(e.featnet(obs, B, 0));
+  if (logp) {
+    MANSY_REQUIRE(act, "policy_evaluate: logp needs actions");
+    RC(e.head(a, B, NACT, 0, e.W.A1a, e.W.Ha, e.W.outa, nullptr, 0, 0, nullptr, nullptr));
+    hipLaunchKernelGGL(logp_kernel, dim3(mansy_ceil_div(B, 256)), dim3(256), 0, e.st, e.W.outa, act, B, logp);
+    MANSY_LAUNCH_CHECK();
+  }
+  if (value) {
+    RC(e.head(c, B, 1, 0, e.W.A1c, e.W.Hc, e.W.outc, nullptr, 0, 0, nullptr, nullptr));
+    MANSY_HIP_CHECK(hipMemcpy2DAsync(value, sizeof(float), e.W.outc, sizeof(float) * MAXOUT, sizeof(float), B, hipMemcpyDeviceToDevice, e.st));
+  }
+  return MANSY_OK;
+}
+
+// rew / v_s / v_next / done: [T][N] step-major (T steps of N environments).  rms = device doubles [mean, var, count]
+// (tianshou RunningMeanStd).  scratch: T*N + 2 doubles.  T2 semantics: critic outputs are un-normalised by sqrt(var+eps)
+// before the scan, returns are re-normalised with the OLD variance, then the statistics absorb the un-normalised returns.
+int mansy_gae_returns(const float* rew, const float* v_s, const float* v_next, const unsigned char* done, int T, int N, double gamma, double gae_lambda,
+                      int rew_norm, double* rms, double* scratch, float* returns, float* adv, void* stream) {
+  MANSY_REQUIRE(rew && v_s && v_next && done && rms && scratch && returns && adv && T >= 1 && N >= 1, "gae_returns: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = (long long)T * N;
+  double* part = scratch + n;
+  hipLaunchKernelGGL(gae_kernel, dim3(mansy_ceil_div(N, 256)), dim3(256), 0, st, rew, v_s, v_next, done, T, N, (double)gamma, (double)gae_lambda,
+                     rms, rew_norm, 1e-8, scratch, adv);
+  hipLaunchKernelGGL(ret_stats_kernel, dim3(1), dim3(1024), 0, st, scratch, n, part);
+  hipLaunchKernelGGL(ret_finish_kernel, dim3(mansy_ceil_div(n, 256)), dim3(256), 0, st, scratch, n, rms, rew_norm, 1e-8, returns);
+  if (rew_norm) hipLaunchKernelGGL(rms_merge_kernel, dim3(1), dim3(1), 0, st, rms, part, n);
+  MANSY_LAUNCH_CHECK();
+  return MANSY_OK;
+}
+
+// One PPO minibatch update (T2: PPOPolicy.learn body): gather rows idx[0..mb) of the collected buffer, forward shared
+// FeatureNet + both heads, clipped loss / value loss / entropy, backward, global grad-norm clip, Adam(L2).
+int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, float* flat_p, float* flat_g, float* flat_m, float* flat_v,
+                             long long n_flat, const float* obs_all, const int* idx, const int* act_all, const float* adv_all,
+                             const float* logp_old_all, const float* v_old_all, const float* ret_all, int mb, float eps_clip, float vf_coef,
+                             float ent_coef, int norm_adv, int value_clip, float max_grad_norm, float lr, float weight_decay, int step,
+                             float* stats, void* workspace, int max_batch, void* stream) {
+  MANSY_REQUIRE(params && grads && flat_p && flat_g && flat_m && flat_v && obs_all && act_all && adv_all && logp_old_all && v_old_all && ret_all,
+                "ppo_minibatch_step: null pointer");
+  MANSY_REQUIRE(mb >= 2 && mb <= max_batch, "ppo_minibatch_step: bad minibatch size");
+  PEng e; RC(setup(workspace, max_batch, (hipStream_t)stream, e));
+  NetP a, c; bind_net(params, grads, 20, a); bind_net(params, grads, 24, c);
+  const float* obs = obs_all;
+  if (idx) {
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(mansy_ceil_div((long long)mb * (OBS_LD / 4), 256)), dim3(256), 0, e.st, obs_all, idx, mb, OBS_LD, e.W.obs_mb);
+    obs = e.W.obs_mb;
+  }
+  RC(e.pack(a, 0));
+  RC(e.featnet(obs, mb, 0));
+  RC(e.head(a, mb, NACT, 0, e.W.A1a, e.W.Ha, e.W.outa, nullptr, 0, 0, nullptr, nullptr));
+  RC(e.head(c, mb, 1, 0, e.W.A1c, e.W.Hc, e.W.outc, nullptr, 0, 0, nullptr, nullptr));
+  MANSY_HIP_CHECK(hipMemsetAsync(flat_g, 0, sizeof(float) * (size_t)n_flat, e.st));
+  MANSY_HIP_CHECK(hipMemsetAsync(e.W.gout_c, 0, sizeof(float) * (size_t)mb * MAXOUT, e.st));
+  PPOLossArgs la;
+  la.logits = e.W.outa; la.value = e.W.outc; la.value_ld = MAXOUT; la.act = act_all; la.adv = adv_all; la.logp_old = logp_old_all; la.v_old = v_old_all;
+  la.ret = ret_all; la.idx = idx; la.n = mb; la.eps_clip = eps_clip; la.vf_coef = vf_coef; la.ent_coef = ent_coef; la.norm_adv = norm_adv;
+  la.value_clip = value_clip; la.adv_eps = 1e-8f; la.dlogits = e.W.gout; la.dvalue = e.W.gout_c; la.dvalue_ld = MAXOUT; la.stats = stats;
+  hipLaunchKernelGGL(ppo_loss_kernel, dim3(1), dim3(1024), 0, e.st, la);
+  MANSY_LAUNCH_CHECK();
+  RC(e.head_bwd(a, mb, NACT, e.W.gout, e.W.A1a, e.W.Ha, e.W.dHa, e.W.dA1a, false));
+  RC(e.head_bwd(c, mb, 1, e.W.gout_c, e.W.A1c, e.W.Hc, e.W.dHc, e.W.dA1c, true));
+  RC(e.featnet_bwd(a, obs, mb, 0, e.W.dHa, e.W.dHc));
+  return e.clip_and_adam(flat_p, flat_g, flat_m, flat_v, n_flat, max_grad_norm, lr, weight_decay, step);
+}
+
+}  // extern "C"
