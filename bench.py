@@ -63,6 +63,120 @@ def cpu_baseline(seconds=15.0):
             'sample': f'{n} train steps of B={B} (S=T=10, d=512, 2+2 layers, dropout off, KV-cached oracle) in {dt:.1f}s'}
 
 
+def bench_ppo(rank, world, dev, mdist, cycles=5, warmup=2, n_env=256, steps_per_env=16):
+    """PPO env-steps/s (BASELINE configs[2]/[3]): 256 vectorised trace-sim envs per GPU on synthetic bench-shaped tables,
+    one cycle = collect 16 steps/env (4096 transitions/GPU) -> train_identifier (2 rounds) -> relabel -> PPO update
+    (minibatch 512, repeat 2), i.e. run_mansy.py --train --train-identifier --use-identifier with step_per_collect=4096."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from mansy_immersivevideostreaming_amd.bitrate_selection.envs.mansy_env import EnvTables, MANSYVecEnv
+    from mansy_immersivevideostreaming_amd.bitrate_selection.models import mansy as mm
+    from mansy_immersivevideostreaming_amd.bitrate_selection.models.mansy_ppo import PPOPolicy, RolloutBuffer, VecCollector
+
+    class A:
+        use_identifier, lamb = True, 0.5
+    torch.manual_seed(5)
+    np.random.seed(5 + rank)
+    fn = mm.FeatureNet(8, 64, 5, 128, device=dev)
+    actor, critic = mm.Actor(fn, 1280, 128, 15, dev), mm.Critic(fn, 1280, 128, dev)
+    ident = mm.QoEIdentifier(mm.QoEIdentifierFeatureNet(8, 64, 5, 15, 128, device=dev), 1280, 128, dev)
+    for m in list(actor.modules()) + list(critic.modules()) + list(ident.modules()):
+        if isinstance(m, torch.nn.Linear):
+            torch.nn.init.orthogonal_(m.weight, gain=np.sqrt(2))
+            torch.nn.init.zeros_(m.bias)
+    optim = torch.optim.Adam(actor.parameters(), lr=5e-4, weight_decay=1e-2)
+    ioptim = torch.optim.Adam(ident.parameters(), lr=1e-4, weight_decay=1e-2)
+    pol = PPOPolicy(actor, critic, optim, None, discount_factor=0.95, max_grad_norm=1.0, eps_clip=0.2, vf_coef=0.5, ent_coef=0.02,
+                    reward_normalization=1, advantage_normalization=1, value_clip=1, gae_lambda=0.95, action_space=15, args=A(),
+                    identifier=ident, identifier_optim=ioptim).to(dev)
+    pol.set_data_parallel(world, mdist.make_grad_sync(world))
+    tables = EnvTables.synthetic(dev, seed=5, train_identifier_reward=True, n_sample=max(240, n_env * world))
+    off, wnum = mdist.shard_envs(n_env, rank, world)
+    venv = MANSYVecEnv(tables, n_env, seed=5, index_offset=off, worker_num=wnum)
+    col = VecCollector(pol, venv, seed=5 + rank)
+    buf = RolloutBuffer(steps_per_env, n_env, dev)
+
+    def cycle():
+        col.collect(steps_per_env * n_env, buf)
+        pol.train_identifier(buf, 2, verbose=False)
+        return pol.update(0, buf, is_train=True, batch_size=512, repeat=2)
+    for _ in range(warmup):
+        cycle()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    t_collect = 0.0
+    for _ in range(cycles):
+        tc = time.perf_counter()
+        col.collect(steps_per_env * n_env, buf)
+        torch.cuda.synchronize()
+        t_collect += time.perf_counter() - tc
+        pol.train_identifier(buf, 2, verbose=False)
+        res = pol.update(0, buf, is_train=True, batch_size=512, repeat=2)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    steps = world * n_env * steps_per_env * cycles
+    return {'metric': 'PPO env-steps/sec', 'value': round(steps / dt, 1), 'unit': 'env-steps/s', 'n_gpus': world, 'cycles': cycles,
+            'ms_per_cycle': round(dt / cycles * 1e3, 3), 'rollout_only_env_steps_per_s': round(n_env * steps_per_env * cycles / t_collect, 1),
+            'rollout_step_latency_us': round(t_collect / (cycles * steps_per_env) * 1e6, 1), 'final_loss': float(np.mean(res['loss'])),
+            'config': {'workload': f'{n_env} device-resident envs/GPU x {steps_per_env} steps per collect (4096 transitions/GPU), '
+                                   'identifier train (2 full-batch rounds) + relabel + PPO update (minibatch 512, repeat 2), synthetic '
+                                   'Jin2022/4G-shaped tables, fp32', 'parallelism': f'dp{world}'},
+            'model_flops_per_env_step': 11.5e6, 'algorithmic_bytes_per_env_step': 29e3}
+
+
+def cpu_baseline_ppo(seconds=6.0):
+    """Reference-style rollout on one host core: sequential C-oracle env + B=1 oracle actor forward + sampling."""
+    import numpy as np
+    import torch
+    from oracle import env as oenv
+    from oracle import ppo_oracle as po
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    rs = np.random.RandomState(0)
+    arrays = _synthetic_arrays()          # same synthetic tables as the GPU leg, host copy
+    OT = oenv.EnvTables(arrays, np.array([[7, 1, 1], [1, 7, 1], [1, 1, 7], [3, 3, 3]], np.float32), train_identifier_reward=True)
+    env = oenv.Env(OT, seed=5, worker_num=1)
+    sd = po.make_policy_state_dict(5)
+    obs = env.reset()
+    n, t0 = 0, time.time()
+    row = np.zeros((1, 780), np.float32)
+    with torch.no_grad():
+        while time.time() - t0 < seconds:
+            row[0, :779] = obs
+            logits = po.actor_logits(sd, torch.from_numpy(row))
+            a = int(po.categorical_sample(logits, torch.from_numpy(rs.rand(1).astype(np.float32)))[0])
+            obs, r, done, _ = env.step(a)
+            if done:
+                obs = env.reset()
+            n += 1
+    dt = time.time() - t0
+    torch.set_num_threads(nthreads)
+    return {'value': round(n / dt, 1), 'unit': 'env-steps/s', 'cores': 1, 'kind': 'port',
+            'sample': f'{n} sequential env steps (C oracle env + B=1 oracle actor forward + sampling) in {dt:.1f}s'}
+
+
+def _synthetic_arrays():
+    """Host copy of EnvTables.synthetic's arrays (numpy only; no device)."""
+    import numpy as np
+    from mansy_immersivevideostreaming_amd.bitrate_selection.envs import mansy_env as me
+    captured = {}
+
+    class Cap(me.EnvTables):
+        def __init__(self, arrays, qoe_weights, device, **kw):
+            captured.update(arrays)
+    Cap.synthetic('cpu', seed=5, n_sample=240)
+    return captured
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -75,13 +189,8 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    from mansy_immersivevideostreaming_amd import dist as mdist
+    rank, world, local = mdist.init_process_group()
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
 
@@ -98,13 +207,7 @@ def main():
     opt = FusedAdamW(model, lr=1e-4)
     h, c, f = (t.to(dev) for t in vo.synthetic_trajectories(B, S, T, seed=5 + rank))
 
-    grad_sync = None
-    if world > 1:
-        inv = 1.0 / world
-
-        def grad_sync(g):
-            dist.all_reduce(g)
-            g.mul_(inv)
+    grad_sync = mdist.make_grad_sync(world)
 
     def step():
         return model.train_step(h, c, f, opt, grad_sync=grad_sync)
@@ -148,6 +251,8 @@ def main():
                 'algorithmic_flops_per_step': FLOP_PER_TRAJ * B,
                 'model_frac': round(value / world * FLOP_PER_TRAJ / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
 
+    ppo = bench_ppo(rank, world, dev, mdist, cycles=max(2, min(args.steps, 6)), warmup=2)
+
     if rank == 0:
         out = {
             'metric': 'viewport-trajectories/sec (VP train)', 'value': round(value, 1), 'unit': 'trajectories/s',
@@ -158,9 +263,11 @@ def main():
                                    f'fp32 MFMA', 'global_batch': B * world, 'parallelism': f'dp{world}'},
             'final_loss': loss_val,
             'roofline': roof,
+            'secondary': ppo,
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
+            out['secondary']['cpu_baseline'] = cpu_baseline_ppo()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

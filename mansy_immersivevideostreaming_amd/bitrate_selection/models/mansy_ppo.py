@@ -128,6 +128,16 @@ class PPOPolicy(nn.Module):
         self.engine = NetEngine(actor=actor, critic=critic, identifier=identifier, max_batch=4096)
         self._rms = None
         self._seed_ctr = 0
+        self.world, self.grad_sync = 1, None
+
+    def set_data_parallel(self, world, grad_sync):
+        """One process per GPU: `grad_sync(flat_grad)` averages a flat gradient buffer over ranks (dist.make_grad_sync)."""
+        self.world, self.grad_sync = int(world), grad_sync
+
+    def _clip_adam(self, f, max_norm, lr, wd):
+        scratch = torch.zeros(1, dtype=torch.float64, device=f.flat_p.device)
+        check(lib().mansy_clip_grad_adam(ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), float(max_norm), lr, wd, f.step,
+                                         ptr(scratch), stream_ptr(f.flat_p.device)), 'mansy_clip_grad_adam')
 
     # ---- plumbing ---------------------------------------------------------------------------------------------
     def _apply(self, fn, *a, **k):
@@ -195,9 +205,13 @@ class PPOPolicy(nn.Module):
             raise MansyError(f'identifier batch {B} exceeds engine max_batch {eng.max_batch}')
         arr, garr = f.pointers(grads=True)
         loss = torch.empty((), dtype=torch.float32, device=obs.device)
+        dp = self.grad_sync is not None and step > 0
         check(lib().mansy_identifier_train_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(obs), B, lr, wd,
-                                                step, ptr(loss), ptr(eng.workspace()), eng.max_batch, stream_ptr(obs.device)),
+                                                -1 if dp else step, ptr(loss), ptr(eng.workspace()), eng.max_batch, stream_ptr(obs.device)),
               'mansy_identifier_train_step')
+        if dp:
+            self.grad_sync(f.flat_g)
+            self._clip_adam(f, 0.0, lr, wd)
         return loss
 
     def relabel(self, buffer, lamb):
@@ -235,9 +249,19 @@ class PPOPolicy(nn.Module):
         returns = torch.empty(n, dtype=torch.float32, device=dev)
         adv = torch.empty(n, dtype=torch.float32, device=dev)
         scratch = torch.empty(n + 2, dtype=torch.float64, device=dev)
+        rms_local = self.ret_rms()
+        rms_use = rms_local
+        if self.world > 1:                      # normalise with the statistics of ALL ranks; accumulate only our own returns locally
+            from ...dist import global_running_moments
+            rms_use = global_running_moments(rms_local, self.world)
         check(lib().mansy_gae_returns(ptr(buffer.rew[:T]), ptr(v_s), ptr(v_next), ptr(buffer.done[:T]), T, N, self._gamma, self._lambda,
-                                      int(self._rew_norm), ptr(self.ret_rms()), ptr(scratch), ptr(returns), ptr(adv), stream_ptr(dev)),
+                                      int(self._rew_norm), ptr(rms_use), ptr(scratch), ptr(returns), ptr(adv), stream_ptr(dev)),
               'mansy_gae_returns')
+        if self.world > 1 and self._rew_norm:
+            from ...dist import merge_moments
+            x = scratch[:n]
+            merged = merge_moments(tuple(rms_local.tolist()), (x.mean().item(), x.var(unbiased=False).item(), float(n)))
+            rms_local.copy_(torch.tensor(merged, dtype=torch.float64, device=dev))
         return dict(obs=obs, act=act, v_s=v_s, logp_old=logp_old, returns=returns, adv=adv, n=n)
 
     def learn(self, data, batch_size, repeat):
@@ -253,11 +277,16 @@ class PPOPolicy(nn.Module):
                 f.step += 1
                 stats = torch.empty(4, dtype=torch.float32, device=dev)
                 arr, garr = f.pointers(grads=True)
+                dp = self.grad_sync is not None
                 check(lib().mansy_ppo_minibatch_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(data['obs']),
                                                      ptr(idx), ptr(data['act']), ptr(data['adv']), ptr(data['logp_old']), ptr(data['v_s']),
                                                      ptr(data['returns']), idx.numel(), self._eps_clip, self._weight_vf, self._weight_ent,
-                                                     int(self._norm_adv), int(self._value_clip), float(self._grad_norm or 0.0), lr, wd, f.step,
-                                                     ptr(stats), ptr(eng.workspace()), eng.max_batch, stream_ptr(dev)), 'mansy_ppo_minibatch_step')
+                                                     int(self._norm_adv), int(self._value_clip), 0.0 if dp else float(self._grad_norm or 0.0), lr, wd,
+                                                     0 if dp else f.step, ptr(stats), ptr(eng.workspace()), eng.max_batch, stream_ptr(dev)),
+                      'mansy_ppo_minibatch_step')
+                if dp:                              # raw local gradients -> RCCL average -> global-norm clip + Adam
+                    self.grad_sync(f.flat_g)
+                    self._clip_adam(f, float(self._grad_norm or 0.0), lr, wd)
                 stats_all.append(stats)
         st = torch.stack(stats_all).cpu().numpy()
         for j, k in enumerate(('loss', 'loss/clip', 'loss/vf', 'loss/ent')):

@@ -535,7 +535,8 @@ int mansy_identifier_forward(const float* const* params, const float* obs, int B
   return e.head(n, B, 3, 1, e.W.A1a, e.W.Ha, pred, nullptr, 0, 0, nullptr, nullptr);
 }
 
-// one full-batch step of train_identifier (mansy_utils.py:20-31): MSE fwd + bwd + Adam(L2).  step <= 0: loss only (validation).
+// one full-batch step of train_identifier (mansy_utils.py:20-31): MSE fwd + bwd + Adam(L2).
+// step == 0: loss only (validation); step < 0: loss + gradients into flat_g, no optimiser step.
 int mansy_identifier_train_step(const float* const* params, float* const* grads, float* flat_p, float* flat_g, float* flat_m, float* flat_v,
                                 long long n_flat, const float* obs, int B, float lr, float weight_decay, int step, float* loss_out,
                                 void* workspace, int max_batch, void* stream) {
@@ -546,7 +547,7 @@ int mansy_identifier_train_step(const float* const* params, float* const* grads,
   RC(e.featnet(obs, B, 1));
   RC(e.head(n, B, 3, 1, e.W.A1a, e.W.Ha, e.W.outa, nullptr, 0, 0, nullptr, nullptr));
   MANSY_HIP_CHECK(hipMemsetAsync(e.W.acc, 0, sizeof(double), e.st));
-  const bool train = step > 0;
+  const bool train = step != 0;        // step < 0: gradients only (data-parallel callers all-reduce, then mansy_clip_grad_adam)
   if (train) MANSY_HIP_CHECK(hipMemsetAsync(e.W.gout, 0, sizeof(float) * (size_t)B * MAXOUT, e.st));
   hipLaunchKernelGGL(ident_mse_kernel, dim3(min(mansy_ceil_div(B * 3, 256), 256)), dim3(256), 0, e.st, e.W.outa, obs, B, train ? e.W.gout : nullptr, e.W.acc);
   hipLaunchKernelGGL(ident_mse_finish, dim3(1), dim3(1), 0, e.st, e.W.acc, B, loss_out);
@@ -556,6 +557,7 @@ int mansy_identifier_train_step(const float* const* params, float* const* grads,
   MANSY_HIP_CHECK(hipMemsetAsync(flat_g, 0, sizeof(float) * (size_t)n_flat, e.st));
   RC(e.head_bwd(n, B, 3, e.W.gout, e.W.A1a, e.W.Ha, e.W.dHa, e.W.dA1a, false));
   RC(e.featnet_bwd(n, obs, B, 1, e.W.dHa, nullptr));
+  if (step < 0) return MANSY_OK;
   return e.clip_and_adam(flat_p, flat_g, flat_m, flat_v, n_flat, 0.f, lr, weight_decay, step);
 }
 
@@ -643,6 +645,16 @@ int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, fl
   RC(e.head_bwd(a, mb, NACT, e.W.gout, e.W.A1a, e.W.Ha, e.W.dHa, e.W.dA1a, false));
   RC(e.head_bwd(c, mb, 1, e.W.gout_c, e.W.A1c, e.W.Hc, e.W.dHc, e.W.dA1c, true));
   RC(e.featnet_bwd(a, obs, mb, 0, e.W.dHa, e.W.dHc));
+  return e.clip_and_adam(flat_p, flat_g, flat_m, flat_v, n_flat, max_grad_norm, lr, weight_decay, step);
+}
+
+// Global-norm clip (torch clip_grad_norm_ semantics; max_norm <= 0 disables) followed by Adam with L2 weight decay over
+// flat buffers.  Data-parallel callers run the minibatch step with step = 0 and max_grad_norm = 0 (raw gradients),
+// all-reduce flat_g over RCCL, then call this.  scratch: 8 bytes.
+int mansy_clip_grad_adam(float* flat_p, float* flat_g, float* flat_m, float* flat_v, long long n_flat, float max_grad_norm, float lr,
+                         float weight_decay, int step, double* scratch, void* stream) {
+  MANSY_REQUIRE(flat_p && flat_g && flat_m && flat_v && scratch && step >= 1, "clip_grad_adam: bad arguments");
+  PEng e; e.st = (hipStream_t)stream; e.W.acc = scratch;
   return e.clip_and_adam(flat_p, flat_g, flat_m, flat_v, n_flat, max_grad_norm, lr, weight_decay, step);
 }
 
