@@ -84,11 +84,20 @@ int mansy_adamw_step(float* p, const float* g, float* m, float* v, long long n, 
                      float eps, float weight_decay, int step, int decoupled, void* stream);
 int mansy_ensemble_wrap(const float* pred, float* out, long long rows, int heads, int c, void* stream);
 
+/* ViewportDataset.__getitem__ batched (viewport_prediction/utils/load_dataset.py:43-52): table [n_trace, L, c] resident
+ * in HBM, idx int32 [B,2] = (trace slot, timestep) -> history [B,S,c], current [B,1,c], future [B,T,c] */
+int mansy_traj_gather(const float* table, int L, int c, const int* idx, int B, int S, int T, float* hist, float* cur, float* fut,
+                      void* stream);
+/* mean_square_error (viewport_prediction/utils/common.py:73-80): per row of c coordinates */
+int mansy_periodic_mse(const float* a, const float* b, long long rows, int c, float* out, void* stream);
+
 /* ------------------------------------------------------------------ tile hit map */
 int mansy_tilemap(const float* xy, long long n, int W, int H, int tile_num_w, int tile_num_h, int fov_w, int fov_h,
                   uint64_t* maps, void* stream);
 int mansy_tilemap_iou(const uint64_t* a, const uint64_t* b, long long n, double* iou, void* stream);
 int mansy_tilemap_or_groups(const uint64_t* maps, long long ngroups, int group, uint64_t* out, void* stream);
+/* accuracy (IoU), recall, precision, f1 per point (viewport_prediction/utils/results.py:21-31): out double [n,4] */
+int mansy_tilemap_metrics(const uint64_t* gt, const uint64_t* pred, long long n, double* out, void* stream);
 
 /* ------------------------------------------------------------------ vectorised streaming environment
  * Replaces MANSYEnv.reset/step (bitrate_selection/envs/mansy_env.py:99-248) + Simulator/NetworkTrace/PlaybackBuffer/

@@ -60,6 +60,9 @@ _PROTOS = {
     'mansy_mtio_loss_fwd_bwd': [P, P, c_int, c_int, c_int, P, P, P, P],
     'mansy_adamw_step': [P, P, P, P, c_ll, c_float, c_float, c_float, c_float, c_float, c_int, c_int, P],
     'mansy_ensemble_wrap': [P, P, c_ll, c_int, c_int, P],
+    'mansy_traj_gather': [P, c_int, c_int, P, c_int, c_int, c_int, P, P, P, P],
+    'mansy_periodic_mse': [P, P, c_ll, c_int, P, P],
+    'mansy_tilemap_metrics': [P, P, c_ll, P, P],
     'mansy_tilemap': [P, c_ll, c_int, c_int, c_int, c_int, c_int, c_int, P, P],
     'mansy_tilemap_iou': [P, P, c_ll, P, P],
     'mansy_tilemap_or_groups': [P, c_ll, c_int, P, P],

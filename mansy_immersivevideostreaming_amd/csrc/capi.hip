@@ -77,6 +77,16 @@ int mansy_ensemble_wrap(const float* pred, float* out, long long rows, int heads
   return mansy_launch_ensemble_wrap(pred, out, rows, heads, c, (hipStream_t)stream);
 }
 
+int mansy_traj_gather(const float* table, int L, int c, const int* idx, int B, int S, int T, float* hist, float* cur, float* fut, void* stream) {
+  return mansy_launch_traj_gather(table, L, c, idx, B, S, T, hist, cur, fut, (hipStream_t)stream);
+}
+int mansy_periodic_mse(const float* a, const float* b, long long rows, int c, float* out, void* stream) {
+  return mansy_launch_periodic_mse(a, b, rows, c, out, (hipStream_t)stream);
+}
+int mansy_tilemap_metrics(const uint64_t* gt, const uint64_t* pred, long long n, double* out, void* stream) {
+  return mansy_launch_tilemap_metrics((const unsigned long long*)gt, (const unsigned long long*)pred, n, out, (hipStream_t)stream);
+}
+
 int mansy_tilemap(const float* xy, long long n, int W, int H, int tile_num_w, int tile_num_h, int fov_w, int fov_h, uint64_t* maps,
                   void* stream) {
   return mansy_launch_tilemap(xy, n, W, H, tile_num_w, tile_num_h, fov_w, fov_h, (unsigned long long*)maps, (hipStream_t)stream);

@@ -279,9 +279,57 @@ __global__ __launch_bounds__(256) void tb_to_bt_kernel(const float* __restrict__
   dst[idx] = src[((long long)t * B + b) * C + c];
 }
 
+// sliding-window gather (load_dataset.py:43-52): table [n_trace, L, c]; idx [B,2] = (trace slot, timestep)
+__global__ __launch_bounds__(256) void traj_gather_kernel(const float* __restrict__ table, int L, int c, const int* __restrict__ idx, int B, int S,
+                                                          int T, float* __restrict__ hist, float* __restrict__ cur, float* __restrict__ fut) {
+  const int W = S + 1 + T;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long long)B * W * c) return;
+  const int j = (int)(t % c);
+  const int w = (int)((t / c) % W);
+  const int b = (int)(t / ((long long)c * W));
+  const int slot = idx[2 * b], ts = idx[2 * b + 1];
+  const float v = table[((long long)slot * L + (ts - S + w)) * c + j];
+  if (w < S) hist[((long long)b * S + w) * c + j] = v;
+  else if (w == S) cur[(long long)b * c + j] = v;
+  else fut[((long long)b * T + (w - S - 1)) * c + j] = v;
+}
+
+// utils/common.py:73-80 per row: sum_j min(|a-b|,|a+1-b|,|a-1-b|)^2 / c
+__global__ __launch_bounds__(256) void periodic_mse_kernel(const float* __restrict__ a, const float* __restrict__ b, long long rows, int c,
+                                                           float* __restrict__ out) {
+  const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  float s = 0.f;
+  for (int j = 0; j < c; ++j) {
+    const float x = a[r * c + j], y = b[r * c + j];
+    float e = fabsf(x - y);
+    e = fminf(e, fabsf(x + 1.f - y));
+    e = fminf(e, fabsf(x - 1.f - y));
+    s += e * e;
+  }
+  out[r] = s / (float)c;
+}
+
 inline dim3 g1(long long n) { return dim3(mansy_ceil_div(n, 256)); }
 
 }  // namespace
+
+int mansy_launch_traj_gather(const float* table, int L, int c, const int* idx, int B, int S, int T, float* hist, float* cur, float* fut,
+                             hipStream_t st) {
+  MANSY_REQUIRE(table && idx && hist && cur && fut && L >= S + 1 + T, "traj_gather: bad arguments");
+  if (B <= 0) return MANSY_OK;
+  hipLaunchKernelGGL(traj_gather_kernel, g1((long long)B * (S + 1 + T) * c), dim3(256), 0, st, table, L, c, idx, B, S, T, hist, cur, fut);
+  MANSY_LAUNCH_CHECK();
+  return MANSY_OK;
+}
+int mansy_launch_periodic_mse(const float* a, const float* b, long long rows, int c, float* out, hipStream_t st) {
+  MANSY_REQUIRE(a && b && out && c >= 1, "periodic_mse: bad arguments");
+  if (rows <= 0) return MANSY_OK;
+  hipLaunchKernelGGL(periodic_mse_kernel, g1(rows), dim3(256), 0, st, a, b, rows, c, out);
+  MANSY_LAUNCH_CHECK();
+  return MANSY_OK;
+}
 
 int mansy_launch_embed_fwd(const float* x, int in_ch, const float* W, const float* b, const float* pe, float* out, int rows,
                            int C, int S, int pos_fixed, MansyDrop drop, hipStream_t st) {

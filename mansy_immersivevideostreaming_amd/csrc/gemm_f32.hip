@@ -304,13 +304,15 @@ int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B,
   // 64x64 tiles re-stream both operands through L2 four times as often) -- else 64x64
   const long long t128 = (long long)mansy_ceil_div(M, 128) * mansy_ceil_div(N, 128);
   const bool can_split = plain && ep.accumulate && K >= 4096;
-  int tile = force_tile ? force_tile : ((t128 >= 192 || can_split) ? 128 : 64);
+  // 512 = resident 128x128 workgroups (2 per CU): below one full round the 64x64 tiling (4x the workgroups) wins
+  int tile = force_tile ? force_tile : ((t128 >= 512 || can_split) ? 128 : 64);
   const long long tiles = tile == 128 ? t128 : (long long)mansy_ceil_div(M, 64) * mansy_ceil_div(N, 64);
   // split-K only for plain accumulating products (dW = dY^T X): partial sums are atomically added
   int splits = 1;
   if (force_splitk > 0) splits = force_splitk;
   else if (plain && ep.accumulate && tiles < 256) {
-    splits = (int)((512 + tiles - 1) / tiles);
+    splits = (int)(512 / tiles);            // fill ONE round of resident workgroups, never spill a few into a second
+    if (splits < 1) splits = 1;
     const int max_splits = K / (BK * 8) > 0 ? K / (BK * 8) : 1;
     if (splits > max_splits) splits = max_splits;
   }

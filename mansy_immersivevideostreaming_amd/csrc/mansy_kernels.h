@@ -110,7 +110,12 @@ int mansy_launch_ensemble_wrap(const float* pred, float* out, long long rows, in
 // transpose-copy [T,B,C] <-> [B,T,C]
 int mansy_launch_tb_to_bt(const float* src, float* dst, int T, int B, int C, hipStream_t st);
 
+int mansy_launch_traj_gather(const float* table, int L, int c, const int* idx, int B, int S, int T, float* hist, float* cur, float* fut,
+                             hipStream_t st);
+int mansy_launch_periodic_mse(const float* a, const float* b, long long rows, int c, float* out, hipStream_t st);
+
 // ---------------------------------------------------------------- tile map (tilemap.hip)
+int mansy_launch_tilemap_metrics(const unsigned long long* gt, const unsigned long long* pred, long long n, double* out, hipStream_t st);
 int mansy_launch_tilemap(const float* xy, long long n, int W, int H, int nw, int nh, int fov_w, int fov_h,
                          unsigned long long* maps, hipStream_t st);
 int mansy_launch_tilemap_iou(const unsigned long long* a, const unsigned long long* b, long long n, double* iou,

@@ -76,7 +76,30 @@ __global__ __launch_bounds__(256) void tilemap_or_kernel(const unsigned long lon
   out[i] = m;
 }
 
+// accuracy (IoU), recall, precision, f1 of results.py:21-31 from two maps; doubles [n,4]
+__global__ __launch_bounds__(256) void tilemap_metrics_kernel(const unsigned long long* __restrict__ gt, const unsigned long long* __restrict__ pred,
+                                                              long long n, double* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double tp = (double)__popcll(gt[i] & pred[i]);
+  const double uni = (double)__popcll(gt[i] | pred[i]);
+  const double fp = (double)__popcll(pred[i]) - tp, fn = (double)__popcll(gt[i]) - tp;
+  const double recall = tp / (tp + fn), precision = tp / (tp + fp);
+  out[4 * i + 0] = tp / uni;
+  out[4 * i + 1] = recall;
+  out[4 * i + 2] = precision;
+  out[4 * i + 3] = (recall + precision == 0.0) ? 0.0 : recall * precision * 2.0 / (recall + precision);
+}
+
 }  // namespace
+
+int mansy_launch_tilemap_metrics(const unsigned long long* gt, const unsigned long long* pred, long long n, double* out, hipStream_t st) {
+  MANSY_REQUIRE(gt && pred && out, "tilemap_metrics: null pointer");
+  if (n <= 0) return MANSY_OK;
+  hipLaunchKernelGGL(tilemap_metrics_kernel, dim3(mansy_ceil_div(n, 256)), dim3(256), 0, st, gt, pred, n, out);
+  MANSY_LAUNCH_CHECK();
+  return MANSY_OK;
+}
 
 int mansy_launch_tilemap(const float* xy, long long n, int W, int H, int nw, int nh, int fov_w, int fov_h, unsigned long long* maps,
                          hipStream_t st) {

@@ -1,0 +1,137 @@
+"""Host mirror of viewport_prediction/utils/load_dataset.py (pack_data :55-69, ViewportDataset :6-52, create_dataset
+:72-128) with the sliding-window gather on the device: all traces of a split live in ONE HBM table
+[n_trace, trace_len, 2]; a mini-batch is one `mansy_traj_gather` launch over (trace slot, timestep) index pairs instead
+of per-sample Python indexing + collate + H2D copy.
+
+`ViewportDataset.__getitem__` keeps the reference's return tuple (numpy views) for drop-in use; `DeviceLoader` is the
+fast path and reproduces torch DataLoader's batch order (RandomSampler draws the same torch RNG values)."""
+import os
+
+import numpy as np
+import torch
+
+from ..._lib import check, lib, ptr, stream_ptr
+
+
+class ViewportDataset:
+    def __init__(self, total_traces, videos, users, his_window, fut_window, trim_head, trim_tail, step):
+        self.total_traces = total_traces
+        self.videos, self.users = videos, users
+        self.history_window, self.future_window = his_window, fut_window
+        self.trim_head, self.trim_tail, self.step = trim_head, trim_tail, step
+        self.trace_indices = []
+        for video in videos:
+            for user in users:
+                trace = self.total_traces[video][user]
+                for timestep in range(self.trim_head, len(trace) - self.trim_tail, self.step):
+                    self.trace_indices.append((video, user, timestep))
+        self._device_table = None
+
+    def __len__(self):
+        return len(self.trace_indices)
+
+    def __getitem__(self, index):
+        video, user, timestep = self.trace_indices[index]
+        tr = self.total_traces[video][user]
+        return (tr[timestep - self.history_window:timestep], tr[timestep:timestep + 1],
+                tr[timestep + 1:timestep + self.future_window + 1], video, user, timestep)
+
+    # ---- device side ------------------------------------------------------------------------------------------
+    def to_device(self, device):
+        """Builds the HBM table once: [n_trace, Lmax, 2] + int32 [n_samples, 2] (slot, timestep)."""
+        if self._device_table is not None and self._device_table[0].device == torch.device(device):
+            return self._device_table
+        pairs = [(v, u) for v in self.videos for u in self.users]
+        slot = {p: i for i, p in enumerate(pairs)}
+        lmax = max(len(self.total_traces[v][u]) for v, u in pairs)
+        table = np.zeros((len(pairs), lmax, 2), np.float32)
+        for (v, u), i in slot.items():
+            tr = np.asarray(self.total_traces[v][u], np.float32)
+            table[i, :len(tr)] = tr
+        idx = np.array([(slot[(v, u)], t) for v, u, t in self.trace_indices], np.int32).reshape(-1, 2)
+        meta = np.array([(v, u, t) for v, u, t in self.trace_indices], np.int64).reshape(-1, 3)
+        self._device_table = (torch.from_numpy(table).to(device), torch.from_numpy(idx).to(device), meta)
+        return self._device_table
+
+    def gather(self, sample_ids, device):
+        """sample_ids: int64 numpy / tensor of dataset indices -> (history, current, future) device tensors + host ids."""
+        table, idx, meta = self.to_device(device)
+        ids = torch.as_tensor(sample_ids, dtype=torch.long)
+        sel = idx.index_select(0, ids.to(idx.device)).contiguous()
+        B, S, T = len(ids), self.history_window, self.future_window
+        hist = torch.empty(B, S, 2, dtype=torch.float32, device=table.device)
+        cur = torch.empty(B, 1, 2, dtype=torch.float32, device=table.device)
+        fut = torch.empty(B, T, 2, dtype=torch.float32, device=table.device)
+        check(lib().mansy_traj_gather(ptr(table), table.shape[1], 2, ptr(sel), B, S, T, ptr(hist), ptr(cur), ptr(fut), stream_ptr(table.device)),
+              'mansy_traj_gather')
+        m = meta[ids.numpy()]
+        return hist, cur, fut, m[:, 0], m[:, 1], m[:, 2]
+
+
+class DeviceLoader:
+    """DataLoader(dataset, batch_size, shuffle) counterpart yielding device tensors.  With shuffle=True the permutation is
+    drawn exactly like torch's RandomSampler (a seed from the global generator, then randperm on a private generator)."""
+
+    def __init__(self, dataset, batch_size, shuffle=False, device='cuda', drop_last=False):
+        self.dataset, self.batch_size, self.shuffle, self.device, self.drop_last = dataset, batch_size, shuffle, device, drop_last
+
+    def __len__(self):
+        n = len(self.dataset)
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        n = len(self.dataset)
+        # torch's DataLoader iterator first draws a `_base_seed` (worker seeding, drawn even with num_workers=0) ...
+        torch.empty((), dtype=torch.int64).random_()
+        if self.shuffle:
+            # ... then RandomSampler draws its own seed and permutes with a private generator
+            seed = int(torch.empty((), dtype=torch.int64).random_().item())
+            g = torch.Generator()
+            g.manual_seed(seed)
+            order = torch.randperm(n, generator=g)
+        else:
+            order = torch.arange(n)
+        for s in range(0, n, self.batch_size):
+            ids = order[s:s + self.batch_size]
+            if self.drop_last and len(ids) < self.batch_size:
+                break
+            h, c, f, v, u, t = self.dataset.gather(ids, self.device)
+            yield h, c, f, torch.from_numpy(v), torch.from_numpy(u), torch.from_numpy(t)
+
+
+def pack_data(dataset_dir, video_user_pairs, frequency):
+    pack_traces = {video: {} for video, _ in video_user_pairs}
+    for video, user in video_user_pairs:
+        data_path = os.path.join(dataset_dir, f'video{video}', f'{frequency}Hz', f'simple_{frequency}Hz_user{user}.npy')
+        data = np.load(data_path)
+        pack_traces[video][user] = data[:, 1:]       # column 0 is the timestamp
+    return pack_traces
+
+
+def create_dataset(dataset, config, his_window, fut_window, trim_head=None, trim_tail=None, frequency=None, sample_step=None,
+                   dataset_video_split=None, dataset_user_split=None, include=['train', 'valid', 'test', 'test_seen', 'test_unseen']):
+    dataset_dir = config.viewport_datasets_dir[dataset]
+    trim_head = config.trim_head if trim_head is None else trim_head
+    trim_tail = config.trim_tail if trim_tail is None else trim_tail
+    frequency = config.frequency if frequency is None else frequency
+    sample_step = config.sample_step if sample_step is None else sample_step
+    if dataset_video_split is None:
+        dataset_video_split = dict(config.video_split[dataset])
+    if dataset_user_split is None:
+        dataset_user_split = dict(config.user_split[dataset])
+    if 'test_seen' in include:
+        dataset_video_split['test_seen'] = dataset_video_split['test']
+        min_length = min(len(dataset_user_split['valid']), len(dataset_user_split['test']))
+        dataset_user_split['test_seen'] = dataset_user_split['valid'][:min_length]
+    if 'test_unseen' in include:
+        dataset_video_split['test_unseen'] = dataset_video_split['test']
+        min_length = min(len(dataset_user_split['valid']), len(dataset_user_split['test']))
+        dataset_user_split['test_unseen'] = dataset_user_split['test'][:min_length]
+    pairs = set()
+    for split in include:
+        for video in dataset_video_split[split]:
+            for user in dataset_user_split[split]:
+                pairs.add((video, user))
+    total_traces = pack_data(dataset_dir, list(pairs), frequency)
+    return [ViewportDataset(total_traces, dataset_video_split[split], dataset_user_split[split], his_window, fut_window, trim_head,
+                            trim_tail, sample_step) for split in include]

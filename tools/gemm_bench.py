@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Per-shape timing of the fp32 MFMA GEMM on the shapes the VP train step launches (B=4096)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mansy_immersivevideostreaming_amd import kernels as K
+
+SHAPES = [  # (name, a_kmajor, b_kmajor, M, N, K, accumulate, count per step)
+    ('enc qkv fwd NT', 0, 0, 40960, 1536, 512, 0, 2), ('enc 512 fwd NT', 0, 0, 40960, 512, 512, 0, 6), ('conv fwd NT', 0, 0, 40960, 512, 1536, 0, 1),
+    ('memkv NT', 0, 0, 20480, 1024, 512, 0, 2), ('dec qkv NT', 0, 0, 4096, 1536, 512, 0, 20), ('dec 512 NT', 0, 0, 4096, 512, 512, 0, 100),
+    ('dec dX NN', 0, 1, 4096, 512, 512, 0, 100), ('dec qkv dX NN', 0, 1, 4096, 512, 1536, 0, 20), ('enc dX NN', 0, 1, 40960, 512, 512, 0, 6),
+    ('enc qkv dX NN', 0, 1, 40960, 512, 1536, 0, 2), ('conv dX NN', 0, 1, 40960, 1536, 512, 0, 1),
+    ('dW 512x512 TN', 1, 1, 512, 512, 40960, 1, 16), ('dW 1536x512 TN', 1, 1, 1536, 512, 40960, 1, 4), ('dW conv 512x1536 TN', 1, 1, 512, 1536, 40960, 1, 1),
+    ('dW kv 1024x512 TN', 1, 1, 1024, 512, 20480, 1, 2),
+]
+tiles = [int(x) for x in sys.argv[1:]] or [0]
+tot = {t: 0.0 for t in tiles}
+for name, ak, bk, M, N, Kd, acc, cnt in SHAPES:
+    A = torch.randn((Kd, M) if ak else (M, Kd), device='cuda')
+    B = torch.randn((Kd, N) if bk else (N, Kd), device='cuda')
+    out = torch.zeros(M, N, device='cuda')
+    line = f'{name:22s} M={M:6d} N={N:5d} K={Kd:6d}'
+    for t in tiles:
+        for _ in range(3):
+            K.gemm(A, B, bool(ak), bool(bk), out=out, accumulate=bool(acc), force_tile=t)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 20
+        e0.record()
+        for _ in range(n):
+            K.gemm(A, B, bool(ak), bool(bk), out=out, accumulate=bool(acc), force_tile=t)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / n * 1e3
+        tf = 2.0 * M * N * Kd / us / 1e6
+        tot[t] += us * cnt
+        line += f' | tile {t:3d}: {us:8.1f} us {tf:6.1f} TF'
+    print(line)
+print('per-step GEMM total (ms):', {t: round(v / 1e3, 2) for t, v in tot.items()})
