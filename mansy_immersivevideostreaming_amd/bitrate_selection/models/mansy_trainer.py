@@ -1,0 +1,118 @@
+"""On-policy trainer counterpart of bitrate_selection/models/mansy_trainer.py (:18-95 `__next__`, :162-177
+`policy_update_fn`) on top of the vectorised collector: per epoch  collect step_per_collect -> [train identifier] ->
+relabel + PPO update -> reset buffer  until step_per_epoch, then checkpoint, validation episodes, best-model save.
+Order of operations and the callback signatures are the reference's (tianshou BaseTrainer semantics, T2)."""
+import time
+
+import numpy as np
+import torch
+
+from .mansy_ppo import RolloutBuffer, VecCollector
+
+
+def write_episode_log(log_path, tables, qoe_weights, records):
+    """mansy_env.py:271-290 rows from device episode records (sorted by catalogue position for a deterministic file)."""
+    import os
+    if not len(records):
+        return
+    if not os.path.exists(log_path):
+        with open(log_path, 'w', encoding='utf-8') as f:
+            f.write('video,user,trace,qoe_w1,qoe_w2,qoe_w3,qoe,qoe1,qoe2,qoe3\n')
+    with open(log_path, 'a', encoding='utf-8') as f:
+        for sid, _, n, sq, s1, s2, s3, qi in records:
+            w = np.array(qoe_weights[int(qi)], dtype=np.float32)
+            video, user, trace = tables.ids[3][int(sid)] if tables.ids is not None else (int(sid), -1, -1)
+            f.write(f'{video},{user},{trace},{w[0]},{w[1]},{w[2]},{round(sq / n / sum(w), 5)},{round(s1 / n, 5)},{round(s2 / n, 5)},'
+                    f'{round(s3 / n, 5)}\n')
+
+
+def run_episodes(policy, venv, n_episode, seed=0, reset=True):
+    """Test collector: step `venv` with sampled actions until n_episode episodes have finished; returns their returns.
+    reset=False continues from the environments' current state."""
+    eng = policy.engine
+    N = venv.n_env
+    obs = venv.reset() if reset else venv.obs
+    ret = torch.zeros(N, dtype=torch.float64, device=obs.device)
+    done_returns = []
+    step = 0
+    while len(done_returns) < n_episode:
+        _, _, act, _ = eng._policy_forward(obs, False, True, None, seed, step * N)
+        obs, rew, done, _ = venv.step(act, auto_reset=True)
+        ret += rew.double()
+        d = done.bool()
+        if d.any():
+            done_returns += ret[d].cpu().tolist()
+            ret[d] = 0
+        step += 1
+    return np.array(done_returns[:n_episode])
+
+
+class OnpolicyTrainer:
+    def __init__(self, policy, train_collector, test_collector, max_epoch, step_per_epoch, repeat_per_collect, episode_per_test, batch_size,
+                 step_per_collect=None, stop_fn=None, save_best_fn=None, save_checkpoint_fn=None, logger=None, args=None, identifier=None,
+                 identifier_optimizer=None, test_log=None, verbose=True, **kwargs):
+        self.policy, self.train_collector, self.test_collector = policy, train_collector, test_collector
+        self.max_epoch, self.step_per_epoch, self.repeat_per_collect = max_epoch, step_per_epoch, repeat_per_collect
+        self.episode_per_test, self.batch_size, self.step_per_collect = episode_per_test, batch_size, step_per_collect
+        self.stop_fn, self.save_best_fn, self.save_checkpoint_fn = stop_fn, save_best_fn, save_checkpoint_fn
+        self.args, self.identifier, self.identifier_optimizer = args, identifier, identifier_optimizer
+        self.test_log = test_log          # (log_path, tables, qoe_weights) for the validation CSV
+        self.verbose = verbose
+        self.epoch, self.env_step, self.gradient_step = 0, 0, 0
+        self.best_reward, self.best_reward_std, self.best_epoch = -np.inf, 0.0, 0
+        self.stop_fn_flag = False
+        N = train_collector.venv.n_env
+        self.buffer = RolloutBuffer(max(1, step_per_collect // N), N, train_collector.venv.device)
+        if identifier_optimizer is not None:
+            policy.identifier_optim = identifier_optimizer
+        self.start_time = time.time()
+
+    def __iter__(self):
+        return self
+
+    def test_step(self):
+        venv = self.test_collector.venv
+        rets = run_episodes(self.policy, venv, self.episode_per_test, seed=self.test_collector.seed)
+        if self.test_log is not None:
+            write_episode_log(self.test_log[0], self.test_log[1], self.test_log[2], venv.pop_episode_log()[:self.episode_per_test])
+        rew, rew_std = float(rets.mean()), float(rets.std())
+        if self.best_epoch == 0 or self.best_reward < rew:
+            self.best_epoch, self.best_reward, self.best_reward_std = self.epoch, rew, rew_std
+            if self.save_best_fn:
+                self.save_best_fn(self.policy)
+        if self.verbose:
+            print(f'Epoch #{self.epoch}: test_reward: {rew:.6f} ± {rew_std:.6f}, best_reward: {self.best_reward:.6f} ± '
+                  f'{self.best_reward_std:.6f} in #{self.best_epoch}', flush=True)
+        stop = bool(self.stop_fn and self.stop_fn(self.best_reward))
+        return {'test_reward': rew, 'test_reward_std': rew_std, 'best_reward': self.best_reward, 'best_epoch': self.best_epoch}, stop
+
+    def __next__(self):
+        self.epoch += 1
+        if self.epoch > self.max_epoch or self.stop_fn_flag:
+            raise StopIteration
+        self.policy.train()
+        epoch_stat, n_done, losses = {}, 0, {}
+        while n_done < self.step_per_epoch:
+            result = self.train_collector.collect(self.step_per_collect, self.buffer)
+            n_done += result['n/st']
+            self.env_step += result['n/st']
+            if self.args is not None and getattr(self.args, 'train_identifier', False):
+                print('==================== Start Training QOE identifier ====================')
+                self.policy.train_identifier(self.buffer, update_round=self.args.identifier_update_round)
+                print('==================== End Training identifier ====================')
+            losses = self.policy.update(0, self.buffer, batch_size=self.batch_size, repeat=self.repeat_per_collect, is_train=True)
+            self.buffer.reset()
+            self.gradient_step += max([1] + [len(v) for v in losses.values() if isinstance(v, list)])
+        if self.save_checkpoint_fn:
+            self.save_checkpoint_fn(self.epoch, self.env_step, self.gradient_step)
+        if self.test_collector is not None:
+            test_stat, self.stop_fn_flag = self.test_step()
+            epoch_stat.update(test_stat)
+        epoch_stat.update({k: float(np.mean(v)) for k, v in losses.items()})
+        epoch_stat.update({'gradient_step': self.gradient_step, 'env_step': self.env_step, 'n/st': n_done})
+        info = {'duration': time.time() - self.start_time, 'best_reward': self.best_reward, 'train_step': self.env_step}
+        return self.epoch, epoch_stat, info
+
+
+# the vectorised collector doubles as the "test collector" handle (policy + venv)
+TestCollector = VecCollector

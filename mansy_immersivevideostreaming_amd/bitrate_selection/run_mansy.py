@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""CLI counterpart of bitrate_selection/run_mansy.py (flags :283-337, net/optimiser/policy construction :205-251, train()
+:25-140, test() :143-176, checkpoint / result directory naming :58-61,193-199) on the HIP engine and the vectorised
+device environment.
+
+  python -m mansy_immersivevideostreaming_amd.bitrate_selection.run_mansy --train --test --epochs 10 --step-per-epoch 4096 \\
+      --step-per-collect 4096 --lr 0.0005 --batch-size 512 --train-dataset Jin2022 --test-dataset Jin2022 --test-on-seen \\
+      --qoe-test-ids 0 1 2 3 --lamb 0.5 --train-identifier --use-identifier --device cuda:0 [--train-num 256] [--config ../config.yml]
+
+`--train-num` (environments stepped per launch) is honoured here -- the reference forces 1 (run_mansy.py:37); with 1 the
+episode order equals the reference's.  Behaviour cloning (--bc / --init-from-bc) is out of scope (README: no gain)."""
+import argparse
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+from torch.distributions import Categorical
+
+from .envs.mansy_env import EnvTables, MANSYVecEnv
+from .models.mansy import Actor, Critic, FeatureNet, QoEIdentifier, QoEIdentifierFeatureNet
+from .models.mansy_ppo import PPOPolicy, VecCollector
+from .models.mansy_trainer import OnpolicyTrainer, run_episodes, write_episode_log
+from .utils.common import get_config_from_yml, read_log_file
+
+
+def train(args, config, policy, qoe_weights, identifier, identifier_optimizer, models_dir):
+    train_log_path = os.path.join(models_dir, 'train_log.csv')
+    valid_log_path = os.path.join(models_dir, 'valid_log.csv')
+    for p in (train_log_path, valid_log_path):
+        if os.path.exists(p):
+            os.remove(p)
+    dev = args.device
+    t_train = EnvTables.from_dataset(config, args.train_dataset, args.network_dataset, 'train', qoe_weights, dev, seed=args.seed,
+                                     use_identifier=args.use_identifier)
+    t_valid = EnvTables.from_dataset(config, args.train_dataset, args.network_dataset, 'valid', qoe_weights, dev, seed=args.seed,
+                                     use_identifier=args.use_identifier)
+    args.test_num = len(qoe_weights)
+    args.episode_per_test = t_valid.n_sample
+    print('Training num:', args.train_num)
+    print('Test num:', args.test_num)
+    print('Episode per test:', args.episode_per_test)
+    print('Training QoE weights:', qoe_weights)
+    train_env = MANSYVecEnv(t_train, args.train_num, seed=args.seed, worker_num=args.train_num)
+    valid_env = MANSYVecEnv(t_valid, args.test_num, seed=args.seed, worker_num=args.test_num)
+    checkpoint_path = os.path.join(models_dir, 'checkpoint.pth')
+    identifier_checkpoint_path = os.path.join(models_dir, 'identifier_checkpoint.pth')
+    best_policy_path = os.path.join(models_dir, 'best_policy.pth')
+    best_identifier_path = os.path.join(models_dir, 'best_identifier.pth')
+    if args.resume:
+        for path, mod, name in ((checkpoint_path, policy, 'agent'), (identifier_checkpoint_path, identifier, 'identifier')):
+            if os.path.exists(path):
+                mod.load_state_dict(torch.load(path, map_location=args.device))
+                print(f'Successfully loaded {name} from:', path)
+            else:
+                print(f'Failed to load {name}:', path, 'no such file')
+
+    def save_best_fn(policy):
+        torch.save(policy.state_dict(), best_policy_path)
+        torch.save(identifier.state_dict(), best_identifier_path)
+        print('Best policy save at ' + best_policy_path)
+        print('Best identifier save at ' + best_identifier_path)
+
+    def stop_fn(mean_rewards):
+        return mean_rewards >= args.reward_threshold
+
+    def save_checkpoint_fn(epoch, env_step, gradient_step):
+        torch.save(policy.state_dict(), checkpoint_path)
+        torch.save(identifier.state_dict(), identifier_checkpoint_path)
+        print('Checkpoint saved at ' + checkpoint_path)
+        print('Identifier checkpoint saved at ' + identifier_checkpoint_path)
+        return checkpoint_path
+
+    trainer = OnpolicyTrainer(policy, VecCollector(policy, train_env, seed=args.seed), VecCollector(policy, valid_env, seed=args.seed + 1),
+                              args.epochs, args.step_per_epoch, args.repeat_per_collect, episode_per_test=args.episode_per_test,
+                              batch_size=args.batch_size, step_per_collect=args.step_per_collect, stop_fn=stop_fn, save_best_fn=save_best_fn,
+                              save_checkpoint_fn=save_checkpoint_fn, args=args, identifier=identifier,
+                              identifier_optimizer=identifier_optimizer, test_log=(valid_log_path, t_valid, qoe_weights))
+    for epoch, epoch_stat, info in trainer:
+        print(f'Epoch: {epoch}')
+        print('loss:', epoch_stat.get('loss'), ' --- ', 'loss/clip:', epoch_stat.get('loss/clip'), ' --- ', 'loss/vf:', epoch_stat.get('loss/vf'),
+              ' --- ', 'loss/ent:', epoch_stat.get('loss/ent'))
+        write_episode_log(train_log_path, t_train, qoe_weights, train_env.pop_episode_log())
+    return trainer
+
+
+def test(args, config, policy, qoe_weights, identifier, models_dir, results_dir):
+    test_log_path = os.path.join(results_dir, 'results.csv')
+    if os.path.exists(test_log_path):
+        os.remove(test_log_path)
+    tables = EnvTables.from_dataset(config, args.test_dataset, args.network_dataset, 'test', qoe_weights, args.device, seed=args.seed)
+    policy_path = args.policy_path or os.path.join(models_dir, 'best_policy.pth')
+    if os.path.exists(policy_path):
+        policy.load_state_dict(torch.load(policy_path, map_location=args.device))
+        print('Successfully loaded agent from:', policy_path)
+    else:
+        raise FileExistsError(f'File not exist: {policy_path}')
+    n = tables.n_sample
+    n_env = min(args.test_envs, n)
+    venv = MANSYVecEnv(tables, n_env, seed=0, worker_num=n_env)       # env i plays samples i, i+n_env, ... : every combination once
+    first = {}
+    with torch.no_grad():
+        while len(first) < n:                                         # lock-step envs finish at slightly different times
+            run_episodes(policy, venv, n_env, seed=args.seed + len(first), reset=not first)
+            for r in venv.pop_episode_log():                          # keep the first completion of every catalogue entry
+                first.setdefault(int(r[0]), r)
+    ordered = [first[k] for k in sorted(first)]
+    write_episode_log(test_log_path, tables, qoe_weights, ordered)
+    read_log_file(test_log_path, verbose=args.verbose_table)
+    print('Results saved at:', test_log_path)
+
+
+def run(args, config):
+    np.random.seed(args.seed)
+    torch.manual_seed(args.seed)
+    torch.cuda.manual_seed_all(args.seed)
+    random.seed(args.seed)
+    if args.qoe_train_ids is None:
+        args.qoe_train_ids = list(range(len(config.qoe_split['train'])))
+    split = 'train' if args.test_on_seen else 'test'
+    if args.qoe_test_ids is None:
+        args.qoe_test_ids = list(range(len(config.qoe_split[split])))
+    prefix = f'epochs_{args.epochs}_bs_{args.batch_size}_lr_{args.lr}_gamma_{args.gamma}_seed_{args.seed}_ent_{args.ent_coef}_useid_{args.use_identifier}' \
+             f'_lambda_{args.lamb}_ilr_{args.identifier_lr}_iur_{args.identifier_update_round}_bc_{args.bc or args.init_from_bc}'
+    models_dir = os.path.join(config.bs_models_dir, args.model, args.train_dataset + '_' + args.network_dataset,
+                              'qoe' + '_'.join(map(str, args.qoe_train_ids)), prefix)
+    seen = 'seen_qoe' if args.test_on_seen else 'unseen_qoe'
+    results_dir = os.path.join(config.bs_results_dir, args.model, args.test_dataset + '_' + args.network_dataset,
+                               seen + '_'.join(map(str, args.qoe_test_ids)), prefix)
+    os.makedirs(models_dir, exist_ok=True)
+    os.makedirs(results_dir, exist_ok=True)
+    if args.bc or args.init_from_bc:
+        raise SystemExit('behaviour cloning is out of scope of the MI355X path (README: it does not help)')
+    # run_mansy.py:205-251
+    feature_dim = args.hidden_dim * 10
+    feature_net = FeatureNet(config.past_k, config.tile_total_num, len(config.video_rates), args.hidden_dim, device=args.device)
+    actor = Actor(feature_net, feature_dim=feature_dim, hidden_dim=args.hidden_dim, action_space=config.action_space, device=args.device)
+    critic = Critic(feature_net, feature_dim=feature_dim, hidden_dim=args.hidden_dim, device=args.device)
+    for m in list(actor.modules()) + list(critic.modules()):
+        if isinstance(m, torch.nn.Linear):
+            torch.nn.init.orthogonal_(m.weight, gain=np.sqrt(2))
+            torch.nn.init.zeros_(m.bias)
+    ac_params = list(actor.parameters()) + [p for n, p in critic.named_parameters() if not n.startswith('feature_net.')]
+    optimizer = torch.optim.Adam(ac_params, lr=args.lr, weight_decay=args.weight_decay)
+    identifier_feature_net = QoEIdentifierFeatureNet(config.past_k, config.tile_total_num, len(config.video_rates), config.action_space,
+                                                     args.hidden_dim, device=args.device)
+    identifier = QoEIdentifier(identifier_feature_net, feature_dim=feature_dim, hidden_dim=args.hidden_dim, device=args.device)
+    for m in identifier.modules():
+        if isinstance(m, torch.nn.Linear):
+            torch.nn.init.orthogonal_(m.weight, gain=np.sqrt(2))
+            torch.nn.init.zeros_(m.bias)
+    identifier_optimizer = torch.optim.Adam(identifier.parameters(), lr=args.identifier_lr, weight_decay=args.weight_decay)
+    policy = PPOPolicy(actor, critic, optimizer, lambda logits: Categorical(logits=logits), discount_factor=args.gamma,
+                       max_grad_norm=args.max_grad_norm, eps_clip=args.eps_clip, vf_coef=args.vf_coef, ent_coef=args.ent_coef,
+                       reward_normalization=args.rew_norm, advantage_normalization=args.norm_adv, recompute_advantage=args.recompute_adv,
+                       dual_clip=args.dual_clip, value_clip=args.value_clip, gae_lambda=args.gae_lambda, action_space=config.action_space,
+                       action_scaling=False, args=args, identifier=identifier, identifier_optim=identifier_optimizer).to(args.device)
+    if args.train:
+        qoe_weights = [config.qoe_split['train'][i] for i in args.qoe_train_ids]
+        train(args, config, policy, qoe_weights, identifier, identifier_optimizer, models_dir)
+    if args.test:
+        qoe_weights = [config.qoe_split[split][i] for i in args.qoe_test_ids]
+        test(args, config, policy, qoe_weights, identifier, models_dir, results_dir)
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument('--task', type=str, default='mansy')
+    p.add_argument('--reward-threshold', type=float, default=500000.0)
+    p.add_argument('--seed', type=int, default=5)
+    p.add_argument('--buffer-size', type=int, default=1000000)
+    p.add_argument('--lr', type=float, default=5e-4)
+    p.add_argument('--weight-decay', type=float, default=1e-2)
+    p.add_argument('--gamma', type=float, default=0.95)
+    p.add_argument('--epochs', type=int, default=1000)
+    p.add_argument('--step-per-epoch', type=int, default=4096)
+    p.add_argument('--step-per-collect', type=int, default=4096)
+    p.add_argument('--episode-per-collect', type=int, default=10)
+    p.add_argument('--repeat-per-collect', type=int, default=2)
+    p.add_argument('--batch-size', type=int, default=512)
+    p.add_argument('--train-num', type=int, default=1)
+    p.add_argument('--test-num', type=int)
+    p.add_argument('--episode-per-test', type=int)
+    p.add_argument('--device', type=str, default='cuda:0')
+    p.add_argument('--logdir', type=str, default='log_tensorboard')
+    p.add_argument('--vf-coef', type=float, default=0.5)
+    p.add_argument('--ent-coef', type=float, default=0.02)
+    p.add_argument('--eps-clip', type=float, default=0.2)
+    p.add_argument('--max-grad-norm', type=float, default=1)
+    p.add_argument('--gae-lambda', type=float, default=0.95)
+    p.add_argument('--rew-norm', type=int, default=1)
+    p.add_argument('--dual-clip', type=float, default=None)
+    p.add_argument('--value-clip', type=int, default=1)
+    p.add_argument('--norm-adv', type=int, default=1)
+    p.add_argument('--recompute-adv', type=int, default=0)
+    p.add_argument('--resume', action='store_true')
+    p.add_argument('--save-interval', type=int, default=4)
+    p.add_argument('--model', type=str, default='mansy')
+    p.add_argument('--hidden-dim', type=int, default=128)
+    p.add_argument('--identifier-lr', type=float, default=1e-4)
+    p.add_argument('--identifier-update-round', type=int, default=2)
+    p.add_argument('--identifier-epochs', type=int, default=1000)
+    p.add_argument('--lamb', type=float, default=0.5)
+    p.add_argument('--train', action='store_true')
+    p.add_argument('--train-identifier', action='store_true')
+    p.add_argument('--use-identifier', action='store_true')
+    p.add_argument('--test', action='store_true')
+    p.add_argument('--test-on-seen', action='store_true')
+    p.add_argument('--train-dataset', type=str, default='Jin2022')
+    p.add_argument('--test-dataset', type=str, default='Jin2022')
+    p.add_argument('--network-dataset', type=str, default='4G')
+    p.add_argument('--qoe-train-ids', type=int, nargs='*')
+    p.add_argument('--qoe-test-ids', type=int, nargs='*')
+    p.add_argument('--policy-path', type=str)
+    p.add_argument('--bc', action='store_true')
+    p.add_argument('--bc-max-steps', type=int, default=150)
+    p.add_argument('--bc-valid-per-step', type=int, default=50)
+    p.add_argument('--bc-identifier-max-steps', type=int, default=150)
+    p.add_argument('--init-from-bc', action='store_true')
+    p.add_argument('--config', type=str, default=None, help="path of config.yml (default '../config.yml' like the reference)")
+    p.add_argument('--test-envs', type=int, default=256, help='environments stepped per launch in --test')
+    p.add_argument('--verbose-table', action='store_true')
+    return p
+
+
+def main(argv=None):
+    args = build_parser().parse_known_args(argv)[0]          # unknown flags are ignored, as in the reference (:340)
+    print(args)
+    config = get_config_from_yml(args.config)
+    run(args, config)
+
+
+if __name__ == '__main__':
+    main()
