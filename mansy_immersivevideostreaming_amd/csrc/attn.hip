@@ -262,6 +262,118 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_q1_kernel(AttnPtrs p, Att
   if (on) p.dQ[b * s.q_bs + h * dh + lane] = dq;
 }
 
+// ---- Lq == 1, dh == 64, H % 4 == 0: FOUR heads per wave, 16 lanes x float4 per head.  A (batch, 4-head) group is 1 KiB of
+// contiguous q/k/v, so every load/store is a full-width 16-B-per-lane instruction (4x fewer memory instructions and waves
+// than one head per wave) and the score reductions stay inside 16-lane groups (4 shuffle steps).
+__device__ __forceinline__ float group16_sum(float v) {
+  v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+  return v;
+}
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) { return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); }
+
+__global__ __launch_bounds__(64 * WAVES) void attn_fwd_q1x4_kernel(AttnPtrs p, AttnShape s, MansyDrop drop) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int hg = s.H >> 2;                                  // head groups per batch entry
+  const long long g = (long long)blockIdx.x * WAVES + wave;
+  if (g >= (long long)s.nb * hg) return;
+  const int b = (int)(g / hg), h = (int)(g % hg) * 4 + (lane >> 4), c = lane & 15;
+  const long long bh = (long long)b * s.H + h;
+  const int Lk = s.Lk;
+  const int col = h * 64 + c * 4;
+  const float4 q = *reinterpret_cast<const float4*>(p.Q + b * s.q_bs + col);
+  const float* Kb = p.K + b * s.k_bs + col;
+  const float* Vb = p.V + b * s.v_bs + col;
+  float sc[LMAX];
+  float4 v[LMAX];
+#pragma unroll
+  for (int j = 0; j < LMAX; ++j) {
+    if (j < Lk) {
+      const float4 k = *reinterpret_cast<const float4*>(Kb + j * s.k_rs);
+      v[j] = *reinterpret_cast<const float4*>(Vb + j * s.v_rs);
+      sc[j] = dot4(q, k);
+    } else { sc[j] = 0.f; v[j] = make_float4(0.f, 0.f, 0.f, 0.f); }
+  }
+  float m = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < LMAX; ++j) if (j < Lk) { sc[j] = group16_sum(sc[j]) * s.scale; m = fmaxf(m, sc[j]); }
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < LMAX; ++j) if (j < Lk) { sc[j] = expf(sc[j] - m); sum += sc[j]; }
+  const float inv = 1.f / sum;
+  const float ds = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int j = 0; j < LMAX; ++j) {
+    if (j < Lk) {
+      float pv = sc[j] * inv;
+      const long long pidx = bh * Lk + j;
+      if (p.P && c == j) p.P[pidx] = pv;
+      if (drop.p > 0.f) pv = mansy_keep(drop.seed, drop.site, (uint32_t)pidx, drop.p) ? pv * ds : 0.f;
+      o.x = fmaf(pv, v[j].x, o.x); o.y = fmaf(pv, v[j].y, o.y); o.z = fmaf(pv, v[j].z, o.z); o.w = fmaf(pv, v[j].w, o.w);
+    }
+  }
+  *reinterpret_cast<float4*>(p.O + b * s.o_bs + col) = o;
+}
+
+__global__ __launch_bounds__(64 * WAVES) void attn_bwd_q1x4_kernel(AttnPtrs p, AttnShape s, MansyDrop drop, int accum_kv) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int hg = s.H >> 2;
+  const long long g = (long long)blockIdx.x * WAVES + wave;
+  if (g >= (long long)s.nb * hg) return;
+  const int b = (int)(g / hg), h = (int)(g % hg) * 4 + (lane >> 4);
+  const long long bh = (long long)b * s.H + h;
+  const int Lk = s.Lk;
+  const int col = h * 64 + (lane & 15) * 4;
+  const float4 q = *reinterpret_cast<const float4*>(p.Q + b * s.q_bs + col);
+  const float4 dO = *reinterpret_cast<const float4*>(p.dO + b * s.o_bs + col);
+  const float* Kb = p.K + b * s.k_bs + col;
+  const float* Vb = p.V + b * s.v_bs + col;
+  float* dKb = p.dK + b * s.k_bs + col;
+  float* dVb = p.dV + b * s.v_bs + col;
+  const float ds = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
+  float4 k[LMAX];
+  float dP[LMAX], P[LMAX], keepf[LMAX];
+#pragma unroll
+  for (int j = 0; j < LMAX; ++j) {
+    keepf[j] = 1.f; P[j] = 0.f; dP[j] = 0.f; k[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j < Lk) {
+      k[j] = *reinterpret_cast<const float4*>(Kb + j * s.k_rs);
+      const float4 vj = *reinterpret_cast<const float4*>(Vb + j * s.v_rs);
+      dP[j] = dot4(dO, vj);
+      P[j] = p.P[bh * Lk + j];
+      if (drop.p > 0.f) keepf[j] = mansy_keep(drop.seed, drop.site, (uint32_t)(bh * Lk + j), drop.p) ? ds : 0.f;
+    }
+  }
+  float delta = 0.f;
+#pragma unroll
+  for (int j = 0; j < LMAX; ++j) if (j < Lk) { dP[j] = group16_sum(dP[j]) * keepf[j]; delta = fmaf(P[j], dP[j], delta); }
+  float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int j = 0; j < LMAX; ++j) {
+    if (j < Lk) {
+      const float dS = P[j] * (dP[j] - delta) * s.scale;
+      dq.x = fmaf(dS, k[j].x, dq.x); dq.y = fmaf(dS, k[j].y, dq.y); dq.z = fmaf(dS, k[j].z, dq.z); dq.w = fmaf(dS, k[j].w, dq.w);
+      const float pd = P[j] * keepf[j];
+      float4 dk = make_float4(dS * q.x, dS * q.y, dS * q.z, dS * q.w);
+      float4 dv = make_float4(pd * dO.x, pd * dO.y, pd * dO.z, pd * dO.w);
+      if (accum_kv) {
+        const float4 ok = *reinterpret_cast<const float4*>(dKb + j * s.k_rs), ov = *reinterpret_cast<const float4*>(dVb + j * s.v_rs);
+        dk.x += ok.x; dk.y += ok.y; dk.z += ok.z; dk.w += ok.w;
+        dv.x += ov.x; dv.y += ov.y; dv.z += ov.z; dv.w += ov.w;
+      }
+      *reinterpret_cast<float4*>(dKb + j * s.k_rs) = dk;
+      *reinterpret_cast<float4*>(dVb + j * s.v_rs) = dv;
+    }
+  }
+  *reinterpret_cast<float4*>(p.dQ + b * s.q_bs + col) = dq;
+}
+
+static bool q1x4_ok(const AttnShape& s, const void* a, const void* b, const void* c, const void* d) {
+  auto al = [](const void* x) { return (reinterpret_cast<uintptr_t>(x) & 15) == 0; };
+  return s.Lq == 1 && s.dh == 64 && (s.H % 4) == 0 && (s.q_bs % 4) == 0 && (s.k_bs % 4) == 0 && (s.k_rs % 4) == 0 && (s.v_bs % 4) == 0 &&
+         (s.v_rs % 4) == 0 && (s.o_bs % 4) == 0 && al(a) && al(b) && al(c) && al(d);
+}
+
 int check_shape(const AttnShape& s) {
   MANSY_REQUIRE(s.Lq >= 1 && s.Lq <= LMAX && s.Lk >= 1 && s.Lk <= LMAX, "attn: sequence length %d x %d outside [1,%d]", s.Lq, s.Lk, LMAX);
   MANSY_REQUIRE(s.dh >= 1 && s.dh <= 64, "attn: head dim %d outside [1,64]", s.dh);
@@ -278,7 +390,9 @@ int mansy_launch_attn_fwd(const float* Q, const float* K, const float* V, float*
   const long long n = (long long)s.nb * s.H;
   if (n == 0) return MANSY_OK;
   AttnPtrs p = {Q, K, V, O, P_save, nullptr, nullptr, nullptr, nullptr};
-  if (s.Lq == 1) hipLaunchKernelGGL(attn_fwd_q1_kernel, dim3(mansy_ceil_div(n, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop);
+  if (q1x4_ok(s, Q, K, V, O))
+    hipLaunchKernelGGL(attn_fwd_q1x4_kernel, dim3(mansy_ceil_div(n / 4, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop);
+  else if (s.Lq == 1) hipLaunchKernelGGL(attn_fwd_q1_kernel, dim3(mansy_ceil_div(n, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop);
   else hipLaunchKernelGGL(attn_fwd_kernel, dim3(mansy_ceil_div(n, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
@@ -291,7 +405,9 @@ int mansy_launch_attn_bwd(const float* Q, const float* K, const float* V, const 
   const long long n = (long long)s.nb * s.H;
   if (n == 0) return MANSY_OK;
   AttnPtrs p = {Q, K, V, nullptr, const_cast<float*>(P_save), dO, dQ, dK, dV};
-  if (s.Lq == 1) hipLaunchKernelGGL(attn_bwd_q1_kernel, dim3(mansy_ceil_div(n, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop, accum_kv);
+  if (q1x4_ok(s, Q, K, V, dO) && q1x4_ok(s, dQ, dK, dV, dO))
+    hipLaunchKernelGGL(attn_bwd_q1x4_kernel, dim3(mansy_ceil_div(n / 4, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop, accum_kv);
+  else if (s.Lq == 1) hipLaunchKernelGGL(attn_bwd_q1_kernel, dim3(mansy_ceil_div(n, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop, accum_kv);
   else hipLaunchKernelGGL(attn_bwd_kernel, dim3(mansy_ceil_div(n, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop, accum_kv);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;

@@ -123,7 +123,18 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmParams p) {
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, h = lane >> 5;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // XCD-aware tile mapping (speed only, never correctness): workgroups are dealt round-robin over the 8 XCDs by linear id,
+  // so give XCD x the CONTIGUOUS logical tile range [x*nwg/8, (x+1)*nwg/8): the n-tiles that share an A row panel then hit
+  // one XCD's L2 instead of eight (PMC: 4.9x operand over-fetch before this remap).  Bijective for any nwg.
+  int tile_x = blockIdx.x, tile_y = blockIdx.y;
+  {
+    const int nwg = gridDim.x * gridDim.y, orig = blockIdx.y * gridDim.x + blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7, local = orig >> 3;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    tile_y = t / gridDim.x; tile_x = t - tile_y * gridDim.x;
+  }
+  const int m0 = tile_y * BM, n0 = tile_x * BN;
+  const bool first_n_tile = tile_x == 0;
   const int k_begin = blockIdx.z * p.k_per_split;
   const int k_end = min(p.K, k_begin + p.k_per_split);
   const int nk = (k_end - k_begin + BK - 1) / BK;
@@ -136,6 +147,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  float rowsum = 0.f;
   float4 ra[TileGeom<BM, AK>::LOADS], rb[TileGeom<BN, BKM>::LOADS];
   if (nk > 0) {
     load_tile<BM, AK, VEC>(p.A, p.lda, m0, p.M, k_begin, k_end, ra, tid);
@@ -154,6 +166,10 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmParams p) {
     }
     const float* a_l = smem + cur * STAGE;
     const float* b_l = a_l + A_FLOATS;
+    if (AK && p.ep.a_rowsum && first_n_tile && tid < BM) {       // bias gradient: row sums of the staged A tile (zeros beyond k_end)
+#pragma unroll
+      for (int kk = 0; kk < BK; ++kk) rowsum += a_l[kk * (BM + 4) + tid];
+    }
 #pragma unroll
     for (int chunk = 0; chunk < 2; ++chunk) {
       float af[TM][8], bf[TN][8];
@@ -176,6 +192,8 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmParams p) {
     }
     __syncthreads();
   }
+
+  if (AK && p.ep.a_rowsum && first_n_tile && tid < BM && m0 + tid < p.M) atomicAdd(p.ep.a_rowsum + m0 + tid, rowsum);
 
   // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
   // Loads (mask / residual) are hoisted into unconditional clamped-address batches; only the stores are predicated.

@@ -23,6 +23,7 @@ struct GemmEpilogue {
   const float* resid = nullptr;
   int resid_ld = 0;
   int accumulate = 0;   // C += result (atomicAdd); forced when split-K > 1
+  float* a_rowsum = nullptr;   // K-major A only: a_rowsum[m] += sum_k A(m,k)  (bias gradient riding on the dW product)
 };
 int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb, int b_kmajor,
                           float* C, int ldc, int M, int N, int K, const GemmEpilogue& ep, int force_tile,

@@ -234,10 +234,8 @@ struct Eng {
   }
   // gw[N,K] += dY[rows,N]^T X[rows,K] ; gb[N] += colsum(dY)
   int lin_dw(const float* dY, const float* X, int rows, int Nout, int K, float* gw, float* gb) {
-    GemmEpilogue ep; ep.accumulate = 1;
-    RC(mansy_launch_gemm_f32(dY, Nout, 1, X, K, 1, gw, K, Nout, K, rows, ep, 0, 0, st));
-    if (gb) RC(mansy_launch_colsum(dY, Nout, rows, Nout, gb, st));
-    return MANSY_OK;
+    GemmEpilogue ep; ep.accumulate = 1; ep.a_rowsum = gb;      // bias gradient = row sums of dY^T, taken from the staged A tiles
+    return mansy_launch_gemm_f32(dY, Nout, 1, X, K, 1, gw, K, Nout, K, rows, ep, 0, 0, st);
   }
   int ln_fwd(const float* a, const float* b, const NormP& n, float* z, float* y, float* m, float* r, int rows) {
     return mansy_launch_layernorm_fwd(a, b, n.w, n.b, z, y, m, r, rows, d, c.ln_eps, st);
