@@ -63,6 +63,16 @@ def cpu_baseline(seconds=15.0):
             'sample': f'{n} train steps of B={B} (S=T=10, d=512, 2+2 layers, dropout off, KV-cached oracle) in {dt:.1f}s'}
 
 
+def _pmc_traffic():
+    """HBM-side bytes per GEMM launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_gemm.json: FETCH_SIZE x2
+    gfx950 correction + WRITE_SIZE, separate passes); PMC cannot be collected from inside this process."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_gemm.json')
+    try:
+        return json.load(open(path))['traffic_bytes_per_launch']
+    except Exception:
+        return None
+
+
 def bench_ppo(rank, world, dev, mdist, cycles=5, warmup=2, n_env=256, steps_per_env=16):
     """PPO env-steps/s (BASELINE configs[2]/[3]): 256 vectorised trace-sim envs per GPU on synthetic bench-shaped tables,
     one cycle = collect 16 steps/env (4096 transitions/GPU) -> train_identifier (2 rounds) -> relabel -> PPO update
@@ -245,7 +255,7 @@ def main():
         achieved = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
         roof = {'bound': 'mfma', 'kernel': 'gemm_f32_kernel (v_mfma_f32_32x32x2_f32)', 'achieved': round(achieved, 2),
                 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                'traffic': None,
+                'traffic': _pmc_traffic(),
                 'launches_per_step': n.value // nprof, 'avg_launch_us': round(ms.value * 1e3 / max(n.value, 1), 2),
                 'gemm_flops_per_step': fl.value / nprof, 'gemm_ms_per_step': round(ms.value / nprof, 3),
                 'algorithmic_flops_per_step': FLOP_PER_TRAJ * B,
