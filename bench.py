@@ -214,6 +214,8 @@ def main():
     np.random.seed(5)
     model = ViewportTransformerMTIO(in_channel=2, fut_window=T, d_model=d, dim_feedforward=d, device=dev).to(dev)
     model.train()
+    if world > 1:
+        model.set_data_parallel(world)      # SyncBN for the DistillLayer: batch statistics over the GLOBAL mini-batch
     opt = FusedAdamW(model, lr=1e-4)
     h, c, f = (t.to(dev) for t in vo.synthetic_trajectories(B, S, T, seed=5 + rank))
 

@@ -41,7 +41,14 @@ typedef struct mansy_vp_config {
   float p_pe, p_drop;          /* 0.2 (mtio.py:49), 0.1 (nn.Transformer default); 0 disables */
   float ln_eps, bn_eps, bn_momentum;
   int max_len;                 /* rows of the positional table (5000) */
+  int bn_sync_world;           /* data-parallel ranks sharing DistillLayer BatchNorm statistics (<= 1: local) */
 } mansy_vp_config;
+
+/* SyncBN hook: with bn_sync_world > 1 the engine calls fn(which, user) after enqueuing the per-channel partial sums
+ * (which = 0: forward [sum, sumsq]; 1: backward [sum g, sum g*xhat]); the hook must all-reduce (SUM) the 2*d_model doubles at
+ * workspace slot "dis.stats" (+ 0 / + 2*d_model doubles) over the ranks, ordered on the same stream. */
+typedef int (*mansy_bn_sync_fn)(int which, void* user);
+int mansy_set_bn_sync_hook(mansy_bn_sync_fn fn, void* user);
 
 /* ordered parameter table (names are the reference state_dict keys) */
 int mansy_vp_num_params(const mansy_vp_config* cfg);

@@ -15,7 +15,10 @@ class MansyError(RuntimeError):
 
 class VPConfig(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ('B', 'S', 'T', 'd_model', 'n_head', 'd_ff', 'n_enc', 'n_dec', 'in_ch', 'has_bias')] + \
-               [(n, c_float) for n in ('p_pe', 'p_drop', 'ln_eps', 'bn_eps', 'bn_momentum')] + [('max_len', c_int)]
+               [(n, c_float) for n in ('p_pe', 'p_drop', 'ln_eps', 'bn_eps', 'bn_momentum')] + [('max_len', c_int), ('bn_sync_world', c_int)]
+
+
+BN_SYNC_FN = ctypes.CFUNCTYPE(c_int, c_int, c_void_p)
 
 
 class GemmEpilogue(ctypes.Structure):
@@ -88,6 +91,7 @@ _PROTOS = {
     'mansy_ppo_minibatch_step': [P, P, P, P, P, P, c_ll, P, P, P, P, P, P, P, c_int, c_float, c_float, c_float, c_int, c_int, c_float,
                                  c_float, c_float, c_int, P, P, c_int, P],
     'mansy_clip_grad_adam': [P, P, P, P, c_ll, c_float, c_float, c_float, c_int, P, P],
+    'mansy_set_bn_sync_hook': [P, P],
     'mansy_prof_gemm_enable': [c_int],
     'mansy_prof_gemm_collect': [P, P, P],
 }

@@ -12,7 +12,18 @@ extern "C" void mansy_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+static mansy_bn_sync_fn g_bn_hook = nullptr;
+static void* g_bn_user = nullptr;
+int mansy_bn_sync_invoke(int which) {
+  MANSY_REQUIRE(g_bn_hook, "bn_sync_world > 1 but no hook registered (mansy_set_bn_sync_hook)");
+  const int rc = g_bn_hook(which, g_bn_user);
+  MANSY_REQUIRE(rc == 0, "bn sync hook failed (%d)", rc);
+  return MANSY_OK;
+}
+
 extern "C" {
+
+int mansy_set_bn_sync_hook(mansy_bn_sync_fn fn, void* user) { g_bn_hook = fn; g_bn_user = user; return MANSY_OK; }
 
 const char* mansy_last_error(void) { return g_err; }
 int mansy_abi_version(void) { return 1; }

@@ -59,8 +59,10 @@ int mansy_launch_layernorm_bwd(const float* dy, const float* z, const float* mea
                                hipStream_t st);
 
 // BatchNorm1d(train) + ELU + MaxPool1d(3,2,1) of the DistillLayer on conv output [B*S, C].
-struct DistillShape { int B, S, M, C; };
-// stats_d: device scratch of 4*C doubles (sum, sumsq, and 2 for backward); zeroed by the launcher.
+struct DistillShape { int B, S, M, C; int sync_world = 1; };
+// Invokes the registered data-parallel hook (capi.hip: mansy_set_bn_sync_hook); which = 0 forward stats, 1 backward stats.
+int mansy_bn_sync_invoke(int which);
+// stats_d: device scratch of 6*C doubles ([sum, sumsq] forward, [sum g, sum g*xhat] backward global + local copy).
 int mansy_launch_distill_fwd(const float* conv, const float* bn_w, const float* bn_b, float* run_mean, float* run_var,
                              long long* num_batches, float* mean_out, float* rstd_out, float* mem, unsigned char* argmax,
                              double* stats_d, const DistillShape& s, int train, float eps, float momentum,

@@ -6,6 +6,8 @@
 // -> LDS -> one atomic per column per workgroup.
 #include "mansy_kernels.h"
 
+#define RC_HOOK(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+
 namespace {
 
 constexpr int LN_MAXV = 4;     // float4 per lane -> C <= 1024
@@ -308,14 +310,14 @@ __global__ __launch_bounds__(256) void distill_bwd_stage2(const float* __restric
   const long long total = (long long)s.B * s.S * s.C;
   if (idx >= total) return;
   const int c = (int)(idx % s.C);
-  const double n = (double)s.B * s.S;
+  const double n = (double)s.B * s.S * (s.sync_world > 1 ? s.sync_world : 1);
   const float sg = (float)(stats[2 * s.C + c] / n), sgx = (float)(stats[3 * s.C + c] / n);
   const float rs = rstd[c];
   const float xh = (conv[idx] - mean[c]) * rs;
   dconv[idx] = bn_w[c] * rs * (g[idx] - sg - xh * sgx);
   if (idx < s.C) {   // first row's threads publish the parameter gradients
-    atomicAdd(dbn_w + c, (float)stats[3 * s.C + c]);
-    atomicAdd(dbn_b + c, (float)stats[2 * s.C + c]);
+    atomicAdd(dbn_w + c, (float)stats[5 * s.C + c]);
+    atomicAdd(dbn_b + c, (float)stats[4 * s.C + c]);
   }
 }
 
@@ -360,11 +362,13 @@ int mansy_launch_distill_fwd(const float* conv, const float* bn_w, const float* 
   MANSY_REQUIRE(s.S <= 255, "distill_fwd: S too large");
   const int rows = s.B * s.S;
   if (train) {
-    MANSY_HIP_CHECK(hipMemsetAsync(stats_d, 0, sizeof(double) * 4 * s.C, st));
+    MANSY_HIP_CHECK(hipMemsetAsync(stats_d, 0, sizeof(double) * 6 * s.C, st));
     dim3 grid(mansy_ceil_div(s.C, 256), min(rows, 512));
     hipLaunchKernelGGL(colstats_kernel, grid, dim3(256), 0, st, conv, rows, s.C, stats_d);
+    if (s.sync_world > 1) RC_HOOK(mansy_bn_sync_invoke(0));     // SyncBN: all-reduce [sum, sumsq] (2C doubles) over the data-parallel ranks
   }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(mansy_ceil_div(s.C, 256)), dim3(256), 0, st, stats_d, rows, s.C, run_mean, run_var,
+  const int n_glob = rows * (train && s.sync_world > 1 ? s.sync_world : 1);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(mansy_ceil_div(s.C, 256)), dim3(256), 0, st, stats_d, n_glob, s.C, run_mean, run_var,
                      num_batches, mean_out, rstd_out, train, eps, momentum);
   const long long total = (long long)s.B * s.M * s.C;
   hipLaunchKernelGGL(bn_elu_pool_kernel, dim3(mansy_ceil_div(total, 256)), dim3(256), 0, st, conv, bn_w, bn_b, mean_out, rstd_out,
@@ -382,6 +386,9 @@ int mansy_launch_distill_bwd(const float* conv, const float* dmem, const unsigne
   MANSY_HIP_CHECK(hipMemsetAsync(stats_d + 2 * s.C, 0, sizeof(double) * 2 * s.C, st));
   dim3 grid1(mansy_ceil_div(s.C, 256), min(rows, 512));
   hipLaunchKernelGGL(distill_bwd_stage1, grid1, dim3(256), 0, st, conv, dmem, argmax, bn_w, bn_b, mean, rstd, g_tmp, stats_d, s);
+  // parameter gradients use THIS rank's sums (the gradient all-reduce averages them); the input gradient needs the global ones
+  MANSY_HIP_CHECK(hipMemcpyAsync(stats_d + 4 * s.C, stats_d + 2 * s.C, sizeof(double) * 2 * s.C, hipMemcpyDeviceToDevice, st));
+  if (s.sync_world > 1) RC_HOOK(mansy_bn_sync_invoke(1));       // SyncBN backward: all-reduce [sum g, sum g*xhat]
   const long long total = (long long)rows * s.C;
   hipLaunchKernelGGL(distill_bwd_stage2, dim3(mansy_ceil_div(total, 256)), dim3(256), 0, st, conv, g_tmp, bn_w, mean, rstd, stats_d,
                      dconv, dbn_w, dbn_b, s);

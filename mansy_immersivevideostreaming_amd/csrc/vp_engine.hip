@@ -163,7 +163,7 @@ void build_layout(const mansy_vp_config& c, Layout& L, Work& W) {
   W.bn_mean = L.f("dis.bn_mean", d); W.bn_rstd = L.f("dis.bn_rstd", d);
   W.mem = L.f("mem", B * M * d);
   W.argmax = (unsigned char*)L.add("dis.argmax", B * M * d);
-  W.stats = (double*)L.add("dis.stats", 4 * d * sizeof(double));
+  W.stats = (double*)L.add("dis.stats", 6 * d * sizeof(double));
   W.tok_all = L.f("tok_all", (T + 1) * B * C6);
   W.emb_all = L.f("dec.emb", TB * d);
   for (int l = 0; l < c.n_dec; ++l) {
@@ -283,7 +283,7 @@ struct Eng {
     // DistillLayer: circular conv k=3 as one K=3d GEMM on the im2col image, then BN+ELU+maxpool
     RC(mansy_launch_im2col3(W.enc_out, W.col, B, S, d, st));
     RC(lin_fwd(W.col, N, 3 * d, P.conv.w, P.conv.b, d, W.conv, 0, mansy_no_drop()));
-    DistillShape ds = {B, S, M, d};
+    DistillShape ds = {B, S, M, d, c.bn_sync_world > 1 ? c.bn_sync_world : 1};
     RC(mansy_launch_distill_fwd(W.conv, P.bn.w, P.bn.b, bn_rm, bn_rv, bn_nbt, W.bn_mean, W.bn_rstd, W.mem, W.argmax, W.stats, ds,
                                 train ? 1 : 0, c.bn_eps, c.bn_momentum, st));
     for (int l = 0; l < c.n_dec; ++l) {
@@ -380,7 +380,7 @@ struct Eng {
       RC(lin_dx(e.dmemkv, B * M, 2 * d, p.ca_in.w + (size_t)d * d, d, W.dmem, l == 0 ? nullptr : W.dmem, nullptr, 1.f));
     }
     // ---- DistillLayer
-    DistillShape ds = {B, S, M, d};
+    DistillShape ds = {B, S, M, d, c.bn_sync_world > 1 ? c.bn_sync_world : 1};
     RC(mansy_launch_distill_bwd(W.conv, W.dmem, W.argmax, P.bn.w, P.bn.b, W.bn_mean, W.bn_rstd, W.g_a, W.g_b, P.bn.gw, P.bn.gb, W.stats,
                                 ds, st));
     RC(lin_dw(W.g_b, W.col, N, d, 3 * d, P.conv.gw, P.conv.gb));

@@ -25,6 +25,29 @@ _N_HEAD = 8          # nn.Transformer default; mtio.py:56-58 never passes nhead
 _ATTN_DROPOUT = 0.1  # nn.Transformer default dropout
 
 
+_BN_SYNC = {'model': None, 'cfg': None}
+
+
+def _bn_sync_callback(which, user):
+    """Called by the engine (mansy_set_bn_sync_hook) between the partial-sum kernel and its consumer: all-reduce the
+    2*d_model doubles of the DistillLayer BatchNorm statistics over the data-parallel ranks."""
+    try:
+        m, cfg = _BN_SYNC['model'], _BN_SYNC['cfg']
+        off = ctypes.c_longlong()
+        check(lib().mansy_vp_ws_lookup(ctypes.byref(cfg), b'dis.stats', ctypes.byref(off), None), 'ws_lookup')
+        d = m.d_model
+        stats = m._workspace(cfg)[off.value:off.value + 6 * d * 8].view(torch.float64)
+        m._bn_allreduce(stats[which * 2 * d:(which * 2 + 2) * d])
+        return 0
+    except Exception:           # never let an exception cross the C boundary
+        import traceback
+        traceback.print_exc()
+        return 1
+
+
+_BN_SYNC_CFUNC = _lib.BN_SYNC_FN(_bn_sync_callback)
+
+
 class _Node(nn.Module):
     """Name-space node so parameters get the reference's dotted state_dict keys."""
 
@@ -65,6 +88,8 @@ class ViewportTransformerMTIO(nn.Module):
         self._ws = {}
         self._flat_p = None
         self._flat_g = None
+        self.bn_sync_world = 1
+        self._bn_allreduce = None
         self._build_parameters()
         self._flatten()
 
@@ -73,7 +98,21 @@ class ViewportTransformerMTIO(nn.Module):
         return VPConfig(B=B, S=S, T=self.fut_window, d_model=self.d_model, n_head=_N_HEAD, d_ff=self.dim_feedforward,
                         n_enc=self.num_encoder_layers, n_dec=self.num_decoder_layers, in_ch=self.in_channel * self.num_head,
                         has_bias=int(self.has_bias), p_pe=self.dropout_p, p_drop=self.attn_dropout_p, ln_eps=1e-5, bn_eps=1e-5,
-                        bn_momentum=0.1, max_len=_PE_MAX_LEN)
+                        bn_momentum=0.1, max_len=_PE_MAX_LEN, bn_sync_world=int(self.bn_sync_world))
+
+    def set_data_parallel(self, world, allreduce=None):
+        """SyncBN for the DistillLayer under data parallelism: `world` ranks share batch statistics; `allreduce(t)` sums a
+        float64 device tensor over the ranks in place (default: torch.distributed.all_reduce)."""
+        self.bn_sync_world = int(world)
+        if allreduce is None:
+            import torch.distributed as dist
+            allreduce = dist.all_reduce
+        self._bn_allreduce = allreduce
+        check(lib().mansy_set_bn_sync_hook(_BN_SYNC_CFUNC, None), 'mansy_set_bn_sync_hook')
+
+    def _arm_bn_sync(self, cfg):
+        if self.bn_sync_world > 1:
+            _BN_SYNC['model'], _BN_SYNC['cfg'] = self, cfg
 
     def _param_table(self):
         L = lib()
@@ -309,6 +348,7 @@ class ViewportTransformerMTIO(nn.Module):
         ws = self._workspace(cfg)
         perms = self._perms_to_device(self._mix_decision(B), history.device)
         p1, p2 = perms if perms is not None else (None, None)
+        self._arm_bn_sync(cfg)
         arr, garr = self._pointers(self._flat_g)
         pe, rm, rv, nbt = self._engine_buffers()
         optimizer._ensure_state()
@@ -337,6 +377,7 @@ class _VPFunction(torch.autograd.Function):
         arr, _ = model._pointers()
         pe, rm, rv, nbt = model._engine_buffers()
         seed = model._next_seed() if model.training else 0
+        model._arm_bn_sync(cfg)
         pred = torch.empty(B, model.fut_window, cfg.in_ch, dtype=torch.float32, device=src.device)
         check(lib().mansy_vp_forward(ctypes.byref(cfg), arr, ptr(pe), ptr(rm), ptr(rv), ptr(nbt), ptr(src), ptr(cur.reshape(B, -1)),
                                      ptr(pred), ptr(ws), int(model.training), seed, stream_ptr(src.device)), 'mansy_vp_forward')
@@ -349,6 +390,7 @@ class _VPFunction(torch.autograd.Function):
         if not ctx.train:
             raise _lib.MansyError('backward through an eval-mode forward is not supported (BatchNorm eval backward is not on the path)')
         gflat = torch.zeros_like(model._flat_p)
+        model._arm_bn_sync(ctx.cfg)
         arr, garr = model._pointers(gflat)
         ws = model._workspace(ctx.cfg)
         check(lib().mansy_vp_backward(ctypes.byref(ctx.cfg), arr, garr, ptr(ctx.src), ptr(dpred.contiguous()), ptr(ws), ctx.seed,

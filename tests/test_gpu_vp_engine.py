@@ -253,3 +253,45 @@ def test_bench_size_properties(MT):
     assert all(np.isfinite(losses)), losses
     assert losses[-1] < losses[0], losses
     assert torch.isfinite(m._flat_g).all() and torch.isfinite(m._flat_p).all()
+
+
+def test_syncbn_hook_two_identical_ranks_equal_single(MT):
+    """SyncBN plumbing: bn_sync_world=2 with an "all-reduce" that doubles the partial sums (= two ranks holding the same
+    shard) must reproduce the single-rank loss, gradients and running statistics exactly where the math is scale-free."""
+    z = np.load(GOLD[2])
+    h, c, f = (torch.from_numpy(z[k]).cuda() for k in ('history', 'current', 'future'))
+    res = []
+    for world in (1, 2):
+        m, sd = _build(MT, z)
+        m.train()
+        calls = []
+        if world == 2:
+            def fake_allreduce(t):
+                calls.append(t.numel())
+                t.mul_(2.0)
+            m.set_data_parallel(2, allreduce=fake_allreduce)
+        random.seed(3)
+        np.random.seed(3)
+        opt = MT.FusedAdamW(m, lr=1e-4)
+        opt.zero_grad()
+        pred, gt = m(h, c, f)
+        loss = m.loss_function(pred, gt)
+        loss.backward()
+        bn = m.transformer.distill_layer.norm
+        res.append((loss.item(), m._flat_g.clone(), bn.running_mean.clone(), bn.running_var.clone(), pred.detach().clone()))
+        if world == 2:
+            assert calls == [2 * int(z['d']), 2 * int(z['d'])]         # one forward + one backward synchronisation
+            m.set_data_parallel(1)
+    assert abs(res[0][0] - res[1][0]) < 1e-7
+    torch.testing.assert_close(res[0][4], res[1][4], rtol=0, atol=1e-6)
+    torch.testing.assert_close(res[0][2], res[1][2], rtol=1e-6, atol=1e-7)
+    n = int(z['B']) * int(z['S'])
+    # unbiased running variance uses the GLOBAL count: var_b * N/(N-1) with N doubled
+    vb0 = (res[0][3] - 0.9 * 1.0) / 0.1 * (n - 1) / n
+    vb1 = (res[1][3] - 0.9 * 1.0) / 0.1 * (2 * n - 1) / (2 * n)
+    ref_rv = torch.from_numpy(vo.make_state_dict(int(z['d']), int(z['wseed']), bias=bool(z['bias']))['transformer.distill_layer.norm.running_var'].numpy()).cuda()
+    vb0 = (res[0][3] - 0.9 * ref_rv) / 0.1 * (n - 1) / n
+    vb1 = (res[1][3] - 0.9 * ref_rv) / 0.1 * (2 * n - 1) / (2 * n)
+    torch.testing.assert_close(vb0, vb1, rtol=1e-4, atol=1e-6)
+    g0, g1 = res[0][1], res[1][1]
+    assert ((g0 - g1).norm() / g0.norm()).item() < 1e-5
