@@ -163,7 +163,8 @@ size_t mansy_ppo_workspace_bytes(int max_batch);
 /* logits [B,16] (15 used; nullable), value [B] (nullable), optional Categorical sampling: act int32 [B], logp [B];
  * u [B] external uniforms in [0,1) or NULL => counter hash (seed, site, row) */
 int mansy_policy_forward(const float* const* params, const float* obs, int B, float* logits, float* value, int* act, float* logp,
-                         const float* u, uint32_t seed, uint32_t site, void* workspace, int max_batch, void* stream);
+                         const float* u, uint32_t seed, uint32_t site, int reuse_packed /* 1: parameters unchanged since the
+                         previous policy call on this workspace */, void* workspace, int max_batch, void* stream);
 int mansy_policy_evaluate(const float* const* params, const float* obs, int B, const int* act, float* logp, float* value,
                           void* workspace, int max_batch, void* stream);
 int mansy_identifier_forward(const float* const* params, const float* obs, int B, float* pred /* [B,16], 3 used */, void* workspace,

@@ -270,16 +270,24 @@ class NetEngine:
             return out[0]
         return tuple(None if out[0][i] is None else torch.cat([o[i] for o in out]) for i in range(len(out[0])))
 
-    def _policy_forward(self, obs, want_value, sample, u, seed, site):
+    def _policy_forward(self, obs, want_value, sample, u, seed, site, out=None, reuse_packed=False):
+        """out: optional dict of preallocated tensors (logits [B,16], act, logp) -- the rollout writes straight into its slabs."""
         B = obs.shape[0]
         dev = obs.device
         arr, _ = self.ac.pointers()
-        logits = torch.empty(B, MAXOUT, dtype=torch.float32, device=dev)
+        out = out or {}
+        logits = out.get('logits')
+        if logits is None:
+            logits = torch.empty(B, MAXOUT, dtype=torch.float32, device=dev)
         value = torch.empty(B, dtype=torch.float32, device=dev) if want_value else None
-        act = torch.empty(B, dtype=torch.int32, device=dev) if sample else None
-        logp = torch.empty(B, dtype=torch.float32, device=dev) if sample else None
-        check(lib().mansy_policy_forward(arr, ptr(obs), B, ptr(logits), ptr(value), ptr(act), ptr(logp), ptr(u), seed, site, ptr(self.workspace()),
-                                         self.max_batch, stream_ptr(dev)), 'mansy_policy_forward')
+        act = out.get('act') if sample else None
+        logp = out.get('logp') if sample else None
+        if sample and act is None:
+            act = torch.empty(B, dtype=torch.int32, device=dev)
+        if sample and logp is None:
+            logp = torch.empty(B, dtype=torch.float32, device=dev)
+        check(lib().mansy_policy_forward(arr, ptr(obs), B, ptr(logits), ptr(value), ptr(act), ptr(logp), ptr(u), seed, site, int(reuse_packed),
+                                         ptr(self.workspace()), self.max_batch, stream_ptr(dev)), 'mansy_policy_forward')
         if sample:
             return logits[:, :15], value, act, logp
         return logits[:, :15], value

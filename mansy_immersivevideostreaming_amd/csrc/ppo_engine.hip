@@ -512,11 +512,11 @@ size_t mansy_ppo_workspace_bytes(int max_batch) { PWork W; return max_batch >= 1
 
 // logits [B,16] (15 used), value [B] (nullable => actor only), optional sampling (act/logp; u nullable => hash RNG)
 int mansy_policy_forward(const float* const* params, const float* obs, int B, float* logits, float* value, int* act, float* logp,
-                         const float* u, uint32_t seed, uint32_t site, void* workspace, int max_batch, void* stream) {
+                         const float* u, uint32_t seed, uint32_t site, int reuse_packed, void* workspace, int max_batch, void* stream) {
   MANSY_REQUIRE(params && obs && B >= 1 && B <= max_batch, "policy_forward: bad arguments (B=%d, max_batch=%d)", B, max_batch);
   PEng e; RC(setup(workspace, max_batch, (hipStream_t)stream, e));
   NetP a, c; bind_net(params, nullptr, 20, a); bind_net(params, nullptr, 24, c);
-  RC(e.pack(a, 0));
+  if (!reuse_packed) RC(e.pack(a, 0));      // rollouts: the block-diagonal image of the (unchanged) parameters is packed once per collect
   RC(e.featnet(obs, B, 0));
   RC(e.head(a, B, NACT, 0, e.W.A1a, e.W.Ha, logits ? logits : e.W.outa, u, seed, site, act, logp));
   if (value) {
