@@ -29,6 +29,7 @@ struct GemmParams {
   int M, N, K;
   int k_per_split;
   int vec_ok;
+  int c_vec_ok;      // 16-byte epilogue legal: C, bias, mask, resid 16-B aligned, their lds and N multiples of 4
   GemmEpilogue ep;
 };
 
@@ -196,10 +197,56 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmParams p) {
   if (AK && p.ep.a_rowsum && first_n_tile && tid < BM && m0 + tid < p.M) atomicAdd(p.ep.a_rowsum + m0 + tid, rowsum);
 
   // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-  // Loads (mask / residual) are hoisted into unconditional clamped-address batches; only the stores are predicated.
   const GemmEpilogue& ep = p.ep;
   const bool atomic = ep.accumulate || gridDim.z > 1;
   const float drop_scale = ep.drop.p > 0.f ? 1.f / (1.f - ep.drop.p) : 1.f;
+  if (!atomic && p.c_vec_ok) {
+    // Row-major 16-byte epilogue: the accumulators (one column per lane, 16 scattered rows) are transposed through the LDS
+    // staging buffers (free after the last barrier) so that bias / activation / mask / dropout / residual and the store all
+    // run on float4 rows: 16 global_store_dwordx4 per thread instead of 64 global_store_dword, coalesced 512-B row pieces.
+    constexpr int CLD = BN + 4;
+    static_assert(BM * CLD <= 2 * (A_FLOATS + B_FLOATS), "C tile must fit the staging LDS");
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          smem[(wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * CLD + wn * (BN / 2) + j * 32 + r] = acc[i][j][e];
+    __syncthreads();
+    constexpr int C4 = BN / 4;
+#pragma unroll 4
+    for (int idx = tid; idx < BM * C4; idx += NT) {
+      const int lr = idx / C4, c4 = idx % C4;
+      const int row = m0 + lr, col = n0 + c4 * 4;
+      if (row >= p.M || col >= p.N) continue;           // N % 4 == 0 on this path: a float4 is entirely in or out
+      float4 v = *reinterpret_cast<const float4*>(smem + lr * CLD + c4 * 4);
+      if (ep.bias) { const float4 b = *reinterpret_cast<const float4*>(ep.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+      if (ep.relu) {
+        v.x = v.x > 0.f ? v.x : v.x * ep.relu_slope; v.y = v.y > 0.f ? v.y : v.y * ep.relu_slope;
+        v.z = v.z > 0.f ? v.z : v.z * ep.relu_slope; v.w = v.w > 0.f ? v.w : v.w * ep.relu_slope;
+      }
+      if (ep.mask_src) {
+        const float4 mk = *reinterpret_cast<const float4*>(ep.mask_src + (long long)row * ep.mask_ld + col);
+        v.x = mk.x > 0.f ? v.x * ep.mask_scale : v.x * ep.mask_neg; v.y = mk.y > 0.f ? v.y * ep.mask_scale : v.y * ep.mask_neg;
+        v.z = mk.z > 0.f ? v.z * ep.mask_scale : v.z * ep.mask_neg; v.w = mk.w > 0.f ? v.w * ep.mask_scale : v.w * ep.mask_neg;
+      }
+      if (ep.drop.p > 0.f) {
+        const uint32_t base = (uint32_t)row * (uint32_t)p.N + (uint32_t)col;
+        v.x = mansy_keep(ep.drop.seed, ep.drop.site, base + 0, ep.drop.p) ? v.x * drop_scale : 0.f;
+        v.y = mansy_keep(ep.drop.seed, ep.drop.site, base + 1, ep.drop.p) ? v.y * drop_scale : 0.f;
+        v.z = mansy_keep(ep.drop.seed, ep.drop.site, base + 2, ep.drop.p) ? v.z * drop_scale : 0.f;
+        v.w = mansy_keep(ep.drop.seed, ep.drop.site, base + 3, ep.drop.p) ? v.w * drop_scale : 0.f;
+      }
+      if (ep.resid) {
+        const float4 rr = *reinterpret_cast<const float4*>(ep.resid + (long long)row * ep.resid_ld + col);
+        v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+      }
+      *reinterpret_cast<float4*>(p.C + (long long)row * p.ldc + col) = v;
+    }
+    return;
+  }
+  // Scalar path (atomics / unaligned): loads (mask / residual) hoisted into unconditional clamped-address batches.
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -317,6 +364,9 @@ int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B,
   p.vec_ok = ((lda % 4) == 0) && ((ldb % 4) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
              ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (K % 4 == 0) && (!a_kmajor || M % 4 == 0) &&
              (!b_kmajor || N % 4 == 0);
+  auto al16 = [](const void* x) { return (reinterpret_cast<uintptr_t>(x) & 15) == 0; };
+  p.c_vec_ok = al16(C) && (ldc % 4 == 0) && (N % 4 == 0) && (!ep.bias || al16(ep.bias)) &&
+               (!ep.mask_src || (al16(ep.mask_src) && ep.mask_ld % 4 == 0)) && (!ep.resid || (al16(ep.resid) && ep.resid_ld % 4 == 0));
   const bool plain = !ep.bias && !ep.relu && !ep.mask_src && ep.drop.p == 0.f && !ep.resid;
   // tile choice: 128x128 when it alone fills the chip -- or when split-K can make up the workgroups (dW products:
   // 64x64 tiles re-stream both operands through L2 four times as often) -- else 64x64
