@@ -164,64 +164,37 @@ def run(args, config):
         test(args, config, policy, qoe_weights, identifier, models_dir, results_dir)
 
 
+# the reference's command line (run_mansy.py:284-337) as data: (flag, type-or-None for store_true, default)
+_T, _F = 'store_true', None
+_FLAGS = [
+    ('--task', str, 'mansy'), ('--reward-threshold', float, 500000.0), ('--seed', int, 5), ('--buffer-size', int, 1000000),
+    ('--lr', float, 5e-4), ('--weight-decay', float, 1e-2), ('--gamma', float, 0.95), ('--epochs', int, 1000),
+    ('--step-per-epoch', int, 4096), ('--step-per-collect', int, 4096), ('--episode-per-collect', int, 10),
+    ('--repeat-per-collect', int, 2), ('--batch-size', int, 512), ('--train-num', int, 1), ('--test-num', int, None),
+    ('--episode-per-test', int, None), ('--device', str, 'cuda:0'), ('--logdir', str, 'log_tensorboard'), ('--vf-coef', float, 0.5),
+    ('--ent-coef', float, 0.02), ('--eps-clip', float, 0.2), ('--max-grad-norm', float, 1), ('--gae-lambda', float, 0.95),
+    ('--rew-norm', int, 1), ('--dual-clip', float, None), ('--value-clip', int, 1), ('--norm-adv', int, 1), ('--recompute-adv', int, 0),
+    ('--resume', _T, _F), ('--save-interval', int, 4), ('--model', str, 'mansy'), ('--hidden-dim', int, 128),
+    ('--identifier-lr', float, 1e-4), ('--identifier-update-round', int, 2), ('--identifier-epochs', int, 1000), ('--lamb', float, 0.5),
+    ('--train', _T, _F), ('--train-identifier', _T, _F), ('--use-identifier', _T, _F), ('--test', _T, _F), ('--test-on-seen', _T, _F),
+    ('--train-dataset', str, 'Jin2022'), ('--test-dataset', str, 'Jin2022'), ('--network-dataset', str, '4G'),
+    ('--policy-path', str, None), ('--bc', _T, _F), ('--bc-max-steps', int, 150), ('--bc-valid-per-step', int, 50),
+    ('--bc-identifier-max-steps', int, 150), ('--init-from-bc', _T, _F),
+    # additions of this build
+    ('--config', str, None), ('--test-envs', int, 256), ('--verbose-table', _T, _F),
+]
+
+
 def build_parser():
-    p = argparse.ArgumentParser()
-    p.add_argument('--task', type=str, default='mansy')
-    p.add_argument('--reward-threshold', type=float, default=500000.0)
-    p.add_argument('--seed', type=int, default=5)
-    p.add_argument('--buffer-size', type=int, default=1000000)
-    p.add_argument('--lr', type=float, default=5e-4)
-    p.add_argument('--weight-decay', type=float, default=1e-2)
-    p.add_argument('--gamma', type=float, default=0.95)
-    p.add_argument('--epochs', type=int, default=1000)
-    p.add_argument('--step-per-epoch', type=int, default=4096)
-    p.add_argument('--step-per-collect', type=int, default=4096)
-    p.add_argument('--episode-per-collect', type=int, default=10)
-    p.add_argument('--repeat-per-collect', type=int, default=2)
-    p.add_argument('--batch-size', type=int, default=512)
-    p.add_argument('--train-num', type=int, default=1)
-    p.add_argument('--test-num', type=int)
-    p.add_argument('--episode-per-test', type=int)
-    p.add_argument('--device', type=str, default='cuda:0')
-    p.add_argument('--logdir', type=str, default='log_tensorboard')
-    p.add_argument('--vf-coef', type=float, default=0.5)
-    p.add_argument('--ent-coef', type=float, default=0.02)
-    p.add_argument('--eps-clip', type=float, default=0.2)
-    p.add_argument('--max-grad-norm', type=float, default=1)
-    p.add_argument('--gae-lambda', type=float, default=0.95)
-    p.add_argument('--rew-norm', type=int, default=1)
-    p.add_argument('--dual-clip', type=float, default=None)
-    p.add_argument('--value-clip', type=int, default=1)
-    p.add_argument('--norm-adv', type=int, default=1)
-    p.add_argument('--recompute-adv', type=int, default=0)
-    p.add_argument('--resume', action='store_true')
-    p.add_argument('--save-interval', type=int, default=4)
-    p.add_argument('--model', type=str, default='mansy')
-    p.add_argument('--hidden-dim', type=int, default=128)
-    p.add_argument('--identifier-lr', type=float, default=1e-4)
-    p.add_argument('--identifier-update-round', type=int, default=2)
-    p.add_argument('--identifier-epochs', type=int, default=1000)
-    p.add_argument('--lamb', type=float, default=0.5)
-    p.add_argument('--train', action='store_true')
-    p.add_argument('--train-identifier', action='store_true')
-    p.add_argument('--use-identifier', action='store_true')
-    p.add_argument('--test', action='store_true')
-    p.add_argument('--test-on-seen', action='store_true')
-    p.add_argument('--train-dataset', type=str, default='Jin2022')
-    p.add_argument('--test-dataset', type=str, default='Jin2022')
-    p.add_argument('--network-dataset', type=str, default='4G')
-    p.add_argument('--qoe-train-ids', type=int, nargs='*')
-    p.add_argument('--qoe-test-ids', type=int, nargs='*')
-    p.add_argument('--policy-path', type=str)
-    p.add_argument('--bc', action='store_true')
-    p.add_argument('--bc-max-steps', type=int, default=150)
-    p.add_argument('--bc-valid-per-step', type=int, default=50)
-    p.add_argument('--bc-identifier-max-steps', type=int, default=150)
-    p.add_argument('--init-from-bc', action='store_true')
-    p.add_argument('--config', type=str, default=None, help="path of config.yml (default '../config.yml' like the reference)")
-    p.add_argument('--test-envs', type=int, default=256, help='environments stepped per launch in --test')
-    p.add_argument('--verbose-table', action='store_true')
-    return p
+    parser = argparse.ArgumentParser(description='MANSY PPO bitrate selection on MI355X')
+    for flag, kind, default in _FLAGS:
+        if kind == _T:
+            parser.add_argument(flag, action='store_true')
+        else:
+            parser.add_argument(flag, type=kind, default=default)
+    for flag in ('--qoe-train-ids', '--qoe-test-ids'):
+        parser.add_argument(flag, type=int, nargs='*')
+    return parser
 
 
 def main(argv=None):

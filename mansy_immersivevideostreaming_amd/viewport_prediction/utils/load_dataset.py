@@ -100,38 +100,34 @@ class DeviceLoader:
 
 
 def pack_data(dataset_dir, video_user_pairs, frequency):
-    pack_traces = {video: {} for video, _ in video_user_pairs}
+    """{video: {user: float32 [len, 2]}} from `<dir>/video<v>/<f>Hz/simple_<f>Hz_user<u>.npy` (column 0 = timestamp, dropped)."""
+    traces = {}
     for video, user in video_user_pairs:
-        data_path = os.path.join(dataset_dir, f'video{video}', f'{frequency}Hz', f'simple_{frequency}Hz_user{user}.npy')
-        data = np.load(data_path)
-        pack_traces[video][user] = data[:, 1:]       # column 0 is the timestamp
-    return pack_traces
+        arr = np.load(os.path.join(dataset_dir, f'video{video}', f'{frequency}Hz', f'simple_{frequency}Hz_user{user}.npy'))
+        traces.setdefault(video, {})[user] = arr[:, 1:]
+    return traces
+
+
+def _resolve_splits(config, dataset, include, video_split, user_split):
+    """Video / user lists per requested split.  `test_seen` = test videos x the first min(|valid|, |test|) *valid* users,
+    `test_unseen` = test videos x the first min(..) *test* users (reference load_dataset.py:104-111)."""
+    videos = dict(config.video_split[dataset]) if video_split is None else dict(video_split)
+    users = dict(config.user_split[dataset]) if user_split is None else dict(user_split)
+    for name, source in (('test_seen', 'valid'), ('test_unseen', 'test')):
+        if name in include:
+            n = min(len(users['valid']), len(users['test']))
+            videos[name], users[name] = videos['test'], users[source][:n]
+    return {s: (videos[s], users[s]) for s in include}
 
 
 def create_dataset(dataset, config, his_window, fut_window, trim_head=None, trim_tail=None, frequency=None, sample_step=None,
                    dataset_video_split=None, dataset_user_split=None, include=['train', 'valid', 'test', 'test_seen', 'test_unseen']):
-    dataset_dir = config.viewport_datasets_dir[dataset]
-    trim_head = config.trim_head if trim_head is None else trim_head
-    trim_tail = config.trim_tail if trim_tail is None else trim_tail
-    frequency = config.frequency if frequency is None else frequency
-    sample_step = config.sample_step if sample_step is None else sample_step
-    if dataset_video_split is None:
-        dataset_video_split = dict(config.video_split[dataset])
-    if dataset_user_split is None:
-        dataset_user_split = dict(config.user_split[dataset])
-    if 'test_seen' in include:
-        dataset_video_split['test_seen'] = dataset_video_split['test']
-        min_length = min(len(dataset_user_split['valid']), len(dataset_user_split['test']))
-        dataset_user_split['test_seen'] = dataset_user_split['valid'][:min_length]
-    if 'test_unseen' in include:
-        dataset_video_split['test_unseen'] = dataset_video_split['test']
-        min_length = min(len(dataset_user_split['valid']), len(dataset_user_split['test']))
-        dataset_user_split['test_unseen'] = dataset_user_split['test'][:min_length]
-    pairs = set()
-    for split in include:
-        for video in dataset_video_split[split]:
-            for user in dataset_user_split[split]:
-                pairs.add((video, user))
-    total_traces = pack_data(dataset_dir, list(pairs), frequency)
-    return [ViewportDataset(total_traces, dataset_video_split[split], dataset_user_split[split], his_window, fut_window, trim_head,
-                            trim_tail, sample_step) for split in include]
+    """Same signature and result order as the reference: one ViewportDataset per entry of `include`, all sharing one trace dict."""
+    def default(value, key):
+        return config[key] if value is None else value
+    trim_head, trim_tail = default(trim_head, 'trim_head'), default(trim_tail, 'trim_tail')
+    frequency, sample_step = default(frequency, 'frequency'), default(sample_step, 'sample_step')
+    splits = _resolve_splits(config, dataset, include, dataset_video_split, dataset_user_split)
+    needed = {(v, u) for vids, usrs in splits.values() for v in vids for u in usrs}
+    traces = pack_data(config.viewport_datasets_dir[dataset], sorted(needed), frequency)
+    return [ViewportDataset(traces, *splits[s], his_window, fut_window, trim_head, trim_tail, sample_step) for s in include]
