@@ -36,7 +36,8 @@ int mansy_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ld
     e.drop.p = ep->drop_p; e.drop.seed = ep->drop_seed; e.drop.site = ep->drop_site;
     e.resid = ep->resid; e.resid_ld = ep->resid_ld; e.accumulate = ep->accumulate;
   }
-  MANSY_REQUIRE(force_tile == 0 || force_tile == 64 || force_tile == 128, "gemm: force_tile must be 0, 64 or 128");
+  MANSY_REQUIRE(force_tile == 0 || force_tile == 64 || force_tile == 96 || force_tile == 128 || force_tile == -64 || force_tile == -128,
+                "gemm: force_tile must be 0, 64, 96 (128x64), 128, or -64 / -128 (register-staged loop)");
   return mansy_launch_gemm_f32(A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, e, force_tile, force_splitk, (hipStream_t)stream);
 }
 

@@ -112,91 +112,15 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ lds, int rb,
   }
 }
 
-template <int BM, int BN, bool AK, bool BKM, bool VEC>
-__global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmParams p) {
+// Epilogue shared by both main loops.  C/D layout of the 32x32 MFMA block: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+// `smem` is the (now idle) staging LDS, at least BM*(BN+4) floats; SMEM_FLOATS is its size.
+template <int BM, int BN, int SMEM_FLOATS>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[BM / 64][BN / 64 > 0 ? BN / 64 : 1], float* smem, int m0, int n0,
+                                              int tid) {
   constexpr int TM = BM / 64, TN = BN / 64;
-  constexpr int A_FLOATS = TileGeom<BM, AK>::LDS_FLOATS;
-  constexpr int B_FLOATS = TileGeom<BN, BKM>::LDS_FLOATS;
-  __shared__ __attribute__((aligned(16))) float smem[2 * (A_FLOATS + B_FLOATS)];
-  constexpr int STAGE = A_FLOATS + B_FLOATS;   // stage s: A at smem + s*STAGE, B right after it
-
-  const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, h = lane >> 5;
-  // XCD-aware tile mapping (speed only, never correctness): workgroups are dealt round-robin over the 8 XCDs by linear id,
-  // so give XCD x the CONTIGUOUS logical tile range [x*nwg/8, (x+1)*nwg/8): the n-tiles that share an A row panel then hit
-  // one XCD's L2 instead of eight (PMC: 4.9x operand over-fetch before this remap).  Bijective for any nwg.
-  int tile_x = blockIdx.x, tile_y = blockIdx.y;
-  {
-    const int nwg = gridDim.x * gridDim.y, orig = blockIdx.y * gridDim.x + blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7, local = orig >> 3;
-    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
-    tile_y = t / gridDim.x; tile_x = t - tile_y * gridDim.x;
-  }
-  const int m0 = tile_y * BM, n0 = tile_x * BN;
-  const bool first_n_tile = tile_x == 0;
-  const int k_begin = blockIdx.z * p.k_per_split;
-  const int k_end = min(p.K, k_begin + p.k_per_split);
-  const int nk = (k_end - k_begin + BK - 1) / BK;
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  float rowsum = 0.f;
-  float4 ra[TileGeom<BM, AK>::LOADS], rb[TileGeom<BN, BKM>::LOADS];
-  if (nk > 0) {
-    load_tile<BM, AK, VEC>(p.A, p.lda, m0, p.M, k_begin, k_end, ra, tid);
-    load_tile<BN, BKM, VEC>(p.B, p.ldb, n0, p.N, k_begin, k_end, rb, tid);
-    store_tile<BM, AK>(smem, ra, tid, k_begin, k_end);
-    store_tile<BN, BKM>(smem + A_FLOATS, rb, tid, k_begin, k_end);
-  }
-  __syncthreads();
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) {
-      const int k0 = k_begin + (kt + 1) * BK;
-      load_tile<BM, AK, VEC>(p.A, p.lda, m0, p.M, k0, k_end, ra, tid);
-      load_tile<BN, BKM, VEC>(p.B, p.ldb, n0, p.N, k0, k_end, rb, tid);
-    }
-    const float* a_l = smem + cur * STAGE;
-    const float* b_l = a_l + A_FLOATS;
-    if (AK && p.ep.a_rowsum && first_n_tile && tid < BM) {       // bias gradient: row sums of the staged A tile (zeros beyond k_end)
-#pragma unroll
-      for (int kk = 0; kk < BK; ++kk) rowsum += a_l[kk * (BM + 4) + tid];
-    }
-#pragma unroll
-    for (int chunk = 0; chunk < 2; ++chunk) {
-      float af[TM][8], bf[TN][8];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) read_frag<BM, AK>(a_l, wm * (BM / 2) + i * 32, r, h, chunk, af[i]);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) read_frag<BN, BKM>(b_l, wn * (BN / 2) + j * 32, r, h, chunk, bf[j]);
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
-    }
-    if (kt + 1 < nk) {
-      const int k0n = k_begin + (kt + 1) * BK;
-      store_tile<BM, AK>(smem + (cur ^ 1) * STAGE, ra, tid, k0n, k_end);
-      store_tile<BN, BKM>(smem + (cur ^ 1) * STAGE + A_FLOATS, rb, tid, k0n, k_end);
-    }
-    __syncthreads();
-  }
-
-  if (AK && p.ep.a_rowsum && first_n_tile && tid < BM && m0 + tid < p.M) atomicAdd(p.ep.a_rowsum + m0 + tid, rowsum);
-
-  // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
   const GemmEpilogue& ep = p.ep;
   const bool atomic = ep.accumulate || gridDim.z > 1;
   const float drop_scale = ep.drop.p > 0.f ? 1.f / (1.f - ep.drop.p) : 1.f;
@@ -205,7 +129,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmParams p) {
     // staging buffers (free after the last barrier) so that bias / activation / mask / dropout / residual and the store all
     // run on float4 rows: 16 global_store_dwordx4 per thread instead of 64 global_store_dword, coalesced 512-B row pieces.
     constexpr int CLD = BN + 4;
-    static_assert(BM * CLD <= 2 * (A_FLOATS + B_FLOATS), "C tile must fit the staging LDS");
+    static_assert(BM * CLD <= SMEM_FLOATS, "C tile must fit the staging LDS");
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -298,6 +222,253 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmParams p) {
   }
 }
 
+template <int BM, int BN, bool AK, bool BKM, bool VEC>
+__global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmParams p) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int A_FLOATS = TileGeom<BM, AK>::LDS_FLOATS;
+  constexpr int B_FLOATS = TileGeom<BN, BKM>::LDS_FLOATS;
+  __shared__ __attribute__((aligned(16))) float smem[2 * (A_FLOATS + B_FLOATS)];
+  constexpr int STAGE = A_FLOATS + B_FLOATS;   // stage s: A at smem + s*STAGE, B right after it
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  // XCD-aware tile mapping (speed only, never correctness): workgroups are dealt round-robin over the 8 XCDs by linear id,
+  // so give XCD x the CONTIGUOUS logical tile range [x*nwg/8, (x+1)*nwg/8): the n-tiles that share an A row panel then hit
+  // one XCD's L2 instead of eight (PMC: 4.9x operand over-fetch before this remap).  Bijective for any nwg.
+  int tile_x = blockIdx.x, tile_y = blockIdx.y;
+  {
+    const int nwg = gridDim.x * gridDim.y, orig = blockIdx.y * gridDim.x + blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7, local = orig >> 3;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    tile_y = t / gridDim.x; tile_x = t - tile_y * gridDim.x;
+  }
+  const int m0 = tile_y * BM, n0 = tile_x * BN;
+  const bool first_n_tile = tile_x == 0;
+  const int k_begin = blockIdx.z * p.k_per_split;
+  const int k_end = min(p.K, k_begin + p.k_per_split);
+  const int nk = (k_end - k_begin + BK - 1) / BK;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  float rowsum = 0.f;
+  float4 ra[TileGeom<BM, AK>::LOADS], rb[TileGeom<BN, BKM>::LOADS];
+  if (nk > 0) {
+    load_tile<BM, AK, VEC>(p.A, p.lda, m0, p.M, k_begin, k_end, ra, tid);
+    load_tile<BN, BKM, VEC>(p.B, p.ldb, n0, p.N, k_begin, k_end, rb, tid);
+    store_tile<BM, AK>(smem, ra, tid, k_begin, k_end);
+    store_tile<BN, BKM>(smem + A_FLOATS, rb, tid, k_begin, k_end);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      const int k0 = k_begin + (kt + 1) * BK;
+      load_tile<BM, AK, VEC>(p.A, p.lda, m0, p.M, k0, k_end, ra, tid);
+      load_tile<BN, BKM, VEC>(p.B, p.ldb, n0, p.N, k0, k_end, rb, tid);
+    }
+    const float* a_l = smem + cur * STAGE;
+    const float* b_l = a_l + A_FLOATS;
+    if (AK && p.ep.a_rowsum && first_n_tile && tid < BM) {       // bias gradient: row sums of the staged A tile (zeros beyond k_end)
+#pragma unroll
+      for (int kk = 0; kk < BK; ++kk) rowsum += a_l[kk * (BM + 4) + tid];
+    }
+#pragma unroll
+    for (int chunk = 0; chunk < 2; ++chunk) {
+      float af[TM][8], bf[TN][8];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) read_frag<BM, AK>(a_l, wm * (BM / 2) + i * 32, r, h, chunk, af[i]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) read_frag<BN, BKM>(b_l, wn * (BN / 2) + j * 32, r, h, chunk, bf[j]);
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      const int k0n = k_begin + (kt + 1) * BK;
+      store_tile<BM, AK>(smem + (cur ^ 1) * STAGE, ra, tid, k0n, k_end);
+      store_tile<BN, BKM>(smem + (cur ^ 1) * STAGE + A_FLOATS, rb, tid, k0n, k_end);
+    }
+    __syncthreads();
+  }
+
+  if (AK && p.ep.a_rowsum && first_n_tile && tid < BM && m0 + tid < p.M) atomicAdd(p.ep.a_rowsum + m0 + tid, rowsum);
+
+  gemm_epilogue<BM, BN, 2 * (A_FLOATS + B_FLOATS)>(p, acc, smem, m0, n0, tid);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LDS-DMA main loop (global_load_lds_dwordx4): the operand tiles go HBM/L2 -> LDS without passing through VGPRs, so there
+// is no staging register set, no ds_write pass and no select in the K loop (+6..13 % over the register-staged loop on the
+// VP shapes, tools/gemm_lab.hip).  Preconditions (checked by the dispatcher): 16-byte aligned operands with ld % 4 == 0,
+// K % 32 == 0 (no K tail to zero-fill: the DMA cannot), and for K-major operands the row count % 4 == 0.
+// One DMA wave-instruction writes 64 lanes x 16 B = 1 KiB of LDS *contiguously* (wave-uniform base in M0 + lane*16); only
+// the global source address is per lane.  LDS images are therefore unpadded:
+//   K-contiguous operand -> [R][32]: 128-B rows, 8 rows per instruction.  Bank conflicts of the ds_read_b128 fragment reads
+//                           are avoided by an XOR swizzle applied on the SOURCE side: slot c' of row holds k-chunk c' ^ (row & 7).
+//   K-major operand      -> [32][R]: fragment reads are ds_read_b32 along the row axis, conflict-free as is.
+// The DMA is issued through inline asm: hipcc would otherwise put s_waitcnt vmcnt(0) in front of every ds_read that
+// follows an LDS-DMA; completion is counted by hand (one vmcnt(0) + barrier per K-tile, the loads of tile t+1 having the
+// whole MFMA phase of tile t to land).
+// One DMA piece: per-lane source = sbase (SGPR pair, wave-uniform) + voff (VGPR, bytes); destination = LDS byte address
+// lds_dst (wave-uniform, via M0) + lane*16.  Keeping the tile corner in SGPRs and the per-lane offsets loop-invariant makes a
+// piece 3 scalar instructions + the load (per-lane 64-bit address arithmetic in the K loop cost ~8 % of the MFMA rate).
+__device__ __forceinline__ void glds16(unsigned voff, const float* sbase, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
+// Byte offsets of this lane's R/32 DMA pieces relative to the tile corner (row0, k0); piece i lands at LDS byte
+// (tile image) + i*4096 + wave*1024 + lane*16 for both layouts.
+template <int R, bool KMAJ>
+__device__ __forceinline__ void dma_offsets(int ld, int row0, int nrows, unsigned (&voff)[R / 32], int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int i = 0; i < R / 32; ++i) {
+    if (!KMAJ) {            // image [R][32]: 8 rows x 128 B per piece, k-chunk c of a row in slot c ^ (row & 7)
+      const int row = i * 32 + wave * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ (row & 7);
+      voff[i] = (unsigned)((min(row0 + row, nrows - 1) - row0) * ld + c * 4) * 4u;
+    } else {                // image [32][R], linear
+      constexpr int C4 = R / 4;
+      const int idx = (i * 4 + wave) * 64 + lane;
+      const int kr = idx / C4, c4 = idx % C4;
+      voff[i] = (unsigned)(kr * ld + (min(row0 + c4 * 4, nrows - 4) - row0)) * 4u;
+    }
+  }
+}
+
+template <int R, bool KMAJ>
+__device__ __forceinline__ void read_frag_dma(const float* __restrict__ lds, int rb, int r, int h, int chunk, float (&out)[8]) {
+  if (!KMAJ) {
+    const int row = rb + r, c0 = h * 4 + chunk * 2;
+    const float4 v0 = *reinterpret_cast<const float4*>(lds + row * BK + ((c0 + 0) ^ (row & 7)) * 4);
+    const float4 v1 = *reinterpret_cast<const float4*>(lds + row * BK + ((c0 + 1) ^ (row & 7)) * 4);
+    out[0] = v0.x; out[1] = v0.y; out[2] = v0.z; out[3] = v0.w;
+    out[4] = v1.x; out[5] = v1.y; out[6] = v1.z; out[7] = v1.w;
+  } else {
+    const float* q = lds + (h * 16 + chunk * 8) * R + rb + r;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) out[kk] = q[kk * R];
+  }
+}
+
+template <int BM, int BN, bool AK, bool BKM>
+__global__ __launch_bounds__(NT) void gemm_f32_dma_kernel(GemmParams p) {
+  constexpr int TM = BM / 64, TN = BN / 64, PA = BM / 32, PB = BN / 32;
+  constexpr int A_FLOATS = BM * BK, B_FLOATS = BN * BK, STAGE = A_FLOATS + B_FLOATS;
+  constexpr int C_FLOATS = BM * (BN + 4);
+  constexpr int SMEM_FLOATS = 2 * STAGE > C_FLOATS ? 2 * STAGE : C_FLOATS;
+  __shared__ __attribute__((aligned(1024))) float smem[SMEM_FLOATS];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  int tile_x, tile_y;
+  {   // XCD-aware bijective tile remap (see gemm_f32_kernel)
+    const int nwg = gridDim.x * gridDim.y, orig = blockIdx.y * gridDim.x + blockIdx.x;
+    const int q = nwg >> 3, rem = nwg & 7, xcd = orig & 7, local = orig >> 3;
+    const int t = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + local;
+    tile_y = t / gridDim.x; tile_x = t - tile_y * gridDim.x;
+  }
+  const int m0 = tile_y * BM, n0 = tile_x * BN;
+  const bool first_n_tile = tile_x == 0;
+  const int k_begin = blockIdx.z * p.k_per_split;
+  const int k_end = min(p.K, k_begin + p.k_per_split);
+  const int nk = (k_end - k_begin) / BK;          // K % BK == 0 and k_per_split % BK == 0 on this path
+
+  unsigned voa[PA], vob[PB];
+  dma_offsets<BM, AK>(p.lda, m0, p.M, voa, tid);
+  dma_offsets<BN, BKM>(p.ldb, n0, p.N, vob, tid);
+  // tile corners (wave-uniform -> SGPRs) and their per-K-tile strides
+  const float* sa = AK ? p.A + (long long)k_begin * p.lda + m0 : p.A + (long long)m0 * p.lda + k_begin;
+  const float* sb = BKM ? p.B + (long long)k_begin * p.ldb + n0 : p.B + (long long)n0 * p.ldb + k_begin;
+  const long long step_a = AK ? (long long)BK * p.lda : BK, step_b = BKM ? (long long)BK * p.ldb : BK;
+  const unsigned lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem + (unsigned)wave * 1024u);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  float rowsum = 0.f;
+  if (nk > 0) {
+#pragma unroll
+    for (int i = 0; i < PA; ++i) glds16(voa[i], sa, lds_wave + i * 4096u);
+#pragma unroll
+    for (int i = 0; i < PB; ++i) glds16(vob[i], sb, lds_wave + A_FLOATS * 4u + i * 4096u);
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of tile kt have landed ...
+    __builtin_amdgcn_s_barrier();                        // ... and everyone's; everyone is done reading tile kt-1
+    asm volatile("" ::: "memory");
+    sa += step_a; sb += step_b;                          // corners of tile kt+1
+    const unsigned lds_next = lds_wave + (unsigned)(cur ^ 1) * (STAGE * 4u);
+    if (kt + 1 < nk) {
+#pragma unroll
+      for (int i = 0; i < PA; ++i) glds16(voa[i], sa, lds_next + i * 4096u);
+#pragma unroll
+      for (int i = 0; i < PB; ++i) glds16(vob[i], sb, lds_next + A_FLOATS * 4u + i * 4096u);
+    }
+    const float* a_l = smem + cur * STAGE;
+    const float* b_l = a_l + A_FLOATS;
+    if (AK && p.ep.a_rowsum && first_n_tile && tid < BM) {       // bias gradient: row sums of the staged A tile
+#pragma unroll
+      for (int kk = 0; kk < BK; ++kk) rowsum += a_l[kk * BM + tid];
+    }
+#pragma unroll
+    for (int chunk = 0; chunk < 2; ++chunk) {
+      float af[TM][8], bf[TN][8];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) read_frag_dma<BM, AK>(a_l, wm * (BM / 2) + i * 32, r, h, chunk, af[i]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) read_frag_dma<BN, BKM>(b_l, wn * (BN / 2) + j * 32, r, h, chunk, bf[j]);
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // LDS reads retired before the barrier that frees this buffer
+  }
+  __syncthreads();                                        // staging LDS idle: the epilogue reuses it
+
+  if (AK && p.ep.a_rowsum && first_n_tile && tid < BM && m0 + tid < p.M) atomicAdd(p.ep.a_rowsum + m0 + tid, rowsum);
+  gemm_epilogue<BM, BN, SMEM_FLOATS>(p, acc, smem, m0, n0, tid);
+}
+
+template <int BM, int BN>
+int launch_dma(const GemmParams& p, int a_kmajor, int b_kmajor, int splits, hipStream_t st) {
+  dim3 grid(mansy_ceil_div(p.N, BN), mansy_ceil_div(p.M, BM), splits);
+  dim3 block(NT);
+  if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, false, false>), grid, block, 0, st, p);
+  else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, false, true>), grid, block, 0, st, p);
+  else if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, true, true>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, true, false>), grid, block, 0, st, p);
+  MANSY_LAUNCH_CHECK();
+  return MANSY_OK;
+}
+
 template <int BM, int BN, bool VEC>
 int launch_cfg(const GemmParams& p, int a_kmajor, int b_kmajor, int splits, hipStream_t st) {
   dim3 grid(mansy_ceil_div(p.N, BN), mansy_ceil_div(p.M, BM), splits);
@@ -345,7 +516,13 @@ extern "C" int mansy_prof_gemm_collect(double* total_ms, long long* launches, do
   return MANSY_OK;
 }
 
-static int gemm_dispatch(const GemmParams& p, int tile, int a_kmajor, int b_kmajor, int splits, hipStream_t st) {
+// tile codes: 128 -> 128x128, 96 -> 128x64 (LDS-DMA loop only), 64 -> 64x64
+static int gemm_dispatch(const GemmParams& p, int tile, bool dma, int a_kmajor, int b_kmajor, int splits, hipStream_t st) {
+  if (dma) {
+    if (tile == 128) return launch_dma<128, 128>(p, a_kmajor, b_kmajor, splits, st);
+    if (tile == 96) return launch_dma<128, 64>(p, a_kmajor, b_kmajor, splits, st);
+    return launch_dma<64, 64>(p, a_kmajor, b_kmajor, splits, st);
+  }
   if (p.vec_ok) {
     if (tile == 128) return launch_cfg<128, 128, true>(p, a_kmajor, b_kmajor, splits, st);
     return launch_cfg<64, 64, true>(p, a_kmajor, b_kmajor, splits, st);
@@ -354,6 +531,12 @@ static int gemm_dispatch(const GemmParams& p, int tile, int a_kmajor, int b_kmaj
   return launch_cfg<64, 64, false>(p, a_kmajor, b_kmajor, splits, st);
 }
 
+static long long tile_count(int M, int N, int tile) {
+  const int bm = tile == 64 ? 64 : 128, bn = tile == 128 ? 128 : 64;
+  return (long long)mansy_ceil_div(M, bm) * mansy_ceil_div(N, bn);
+}
+
+// force_tile: 0 = heuristics; 64 / 96 / 128 = that tile; negative = that tile on the register-staged loop (A/B tests).
 int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb, int b_kmajor, float* C, int ldc,
                           int M, int N, int K, const GemmEpilogue& ep, int force_tile, int force_splitk, hipStream_t st) {
   MANSY_REQUIRE(A && B && C, "gemm: null pointer");
@@ -368,13 +551,33 @@ int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B,
   p.c_vec_ok = al16(C) && (ldc % 4 == 0) && (N % 4 == 0) && (!ep.bias || al16(ep.bias)) &&
                (!ep.mask_src || (al16(ep.mask_src) && ep.mask_ld % 4 == 0)) && (!ep.resid || (al16(ep.resid) && ep.resid_ld % 4 == 0));
   const bool plain = !ep.bias && !ep.relu && !ep.mask_src && ep.drop.p == 0.f && !ep.resid;
-  // tile choice: 128x128 when it alone fills the chip -- or when split-K can make up the workgroups (dW products:
-  // 64x64 tiles re-stream both operands through L2 four times as often) -- else 64x64
-  const long long t128 = (long long)mansy_ceil_div(M, 128) * mansy_ceil_div(N, 128);
+  // LDS-DMA loop: whole 16-byte chunks and whole K-tiles only (it cannot zero-fill a K tail)
+  const bool dma = p.vec_ok && K >= BK && K % BK == 0 && force_tile >= 0;
   const bool can_split = plain && ep.accumulate && K >= 4096;
-  // 512 = resident 128x128 workgroups (2 per CU): below one full round the 64x64 tiling (4x the workgroups) wins
-  int tile = force_tile ? force_tile : ((t128 >= 512 || can_split) ? 128 : 64);
-  const long long tiles = tile == 128 ? t128 : (long long)mansy_ceil_div(M, 64) * mansy_ceil_div(N, 64);
+  int tile;
+  if (force_tile) {
+    tile = force_tile < 0 ? -force_tile : force_tile;
+    if (!dma && tile == 96) tile = 64;
+  } else if (dma) {
+    // LDS-DMA loop: 128x64 and 64x64 run the K loop at the same rate as 128x128 (tools/gemm_lab.hip) and quantise better
+    // over 256 CUs.  cost ~ (workgroups per CU, rounded up) x tile area / relative efficiency; a lone workgroup per CU
+    // (one wave per SIMD, nothing to overlap its barriers with) pays ~10 %.
+    const int cand[2] = {96, 64};
+    const double area_over_eff[2] = {8192.0 / 1.00, 4096.0 / 0.97};
+    double best = 0.0;
+    tile = 96;
+    for (int c = 0; c < 2; ++c) {
+      const long long per_cu = (tile_count(M, N, cand[c]) * (can_split ? 256 : 1) + 255) / 256;   // split-K fills the chip anyway
+      const double cost = (double)per_cu * area_over_eff[c] * (per_cu == 1 ? 1.1 : 1.0);
+      if (c == 0 || cost < best) { best = cost; tile = cand[c]; }
+    }
+  } else if (can_split) {
+    tile = 128;     // dW products: split-K makes up the workgroups; small tiles re-stream both operands through L2
+  } else {
+    // register-staged loop: 128x128 when it alone gives two full rounds of resident workgroups, else 64x64
+    tile = tile_count(M, N, 128) >= 512 ? 128 : 64;
+  }
+  const long long tiles = tile_count(M, N, tile);
   // split-K only for plain accumulating products (dW = dY^T X): partial sums are atomically added
   int splits = 1;
   if (force_splitk > 0) splits = force_splitk;
@@ -389,12 +592,12 @@ int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B,
   if (kps <= 0) kps = BK;
   splits = K > 0 ? mansy_ceil_div(K, kps) : 1;
   p.k_per_split = kps;
-  if (!g_prof.on) return gemm_dispatch(p, tile, a_kmajor, b_kmajor, splits, st);
+  if (!g_prof.on) return gemm_dispatch(p, tile, dma, a_kmajor, b_kmajor, splits, st);
   if (g_prof.used + 2 > g_prof.ev.size()) {
     for (int i = 0; i < 2; ++i) { hipEvent_t e; MANSY_HIP_CHECK(hipEventCreate(&e)); g_prof.ev.push_back(e); }
   }
   MANSY_HIP_CHECK(hipEventRecord(g_prof.ev[g_prof.used], st));
-  const int rc = gemm_dispatch(p, tile, a_kmajor, b_kmajor, splits, st);
+  const int rc = gemm_dispatch(p, tile, dma, a_kmajor, b_kmajor, splits, st);
   MANSY_HIP_CHECK(hipEventRecord(g_prof.ev[g_prof.used + 1], st));
   g_prof.used += 2;
   g_prof.flops += 2.0 * (double)M * (double)N * (double)K;

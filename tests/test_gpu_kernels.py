@@ -32,8 +32,8 @@ def _gemm_ref(A, B, a_kmajor, b_kmajor):
 
 
 @pytest.mark.parametrize('a_kmajor,b_kmajor', [(False, False), (False, True), (True, True), (True, False)])
-@pytest.mark.parametrize('M,N,K_', [(320, 512, 512), (4096, 1536, 512), (257, 130, 70), (64, 64, 32), (1000, 512, 1536), (33, 6, 5)])
-@pytest.mark.parametrize('tile', [0, 64, 128])
+@pytest.mark.parametrize('M,N,K_', [(320, 512, 512), (4096, 1536, 512), (257, 130, 70), (64, 64, 32), (1000, 512, 1536), (33, 6, 5), (260, 132, 96), (4, 4, 32)])
+@pytest.mark.parametrize('tile', [0, 64, 96, 128, -64, -128])    # 96 = 128x64; negative = register-staged loop (the LDS-DMA loop serves aligned K % 32 == 0 shapes)
 def test_gemm_layouts(K, a_kmajor, b_kmajor, M, N, K_, tile):
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K_)
     A = torch.randn((K_, M) if a_kmajor else (M, K_), generator=g).cuda()
