@@ -271,6 +271,10 @@ __device__ __forceinline__ float group16_sum(float v) {
 }
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) { return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); }
 
+// LKT = compile-time bound on the key rows (>= s.Lk): every K / V / P load of a wave is issued up front, unconditionally
+// (rows >= Lk re-read row Lk-1 and are masked out of the arithmetic).  With a runtime `if (j < Lk)` around each load hipcc
+// branches and waits per row: Lk dependent HBM round trips per wave, 3.5 us per cached step in the decode loop.
+template <int LKT>
 __global__ __launch_bounds__(64 * WAVES) void attn_fwd_q1x4_kernel(AttnPtrs p, AttnShape s, MansyDrop drop) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int hg = s.H >> 2;                                  // head groups per batch entry
@@ -283,38 +287,38 @@ __global__ __launch_bounds__(64 * WAVES) void attn_fwd_q1x4_kernel(AttnPtrs p, A
   const float4 q = *reinterpret_cast<const float4*>(p.Q + b * s.q_bs + col);
   const float* Kb = p.K + b * s.k_bs + col;
   const float* Vb = p.V + b * s.v_bs + col;
-  float sc[LMAX];
-  float4 v[LMAX];
+  float sc[LKT];
+  float4 k[LKT], v[LKT];
 #pragma unroll
-  for (int j = 0; j < LMAX; ++j) {
-    if (j < Lk) {
-      const float4 k = *reinterpret_cast<const float4*>(Kb + j * s.k_rs);
-      v[j] = *reinterpret_cast<const float4*>(Vb + j * s.v_rs);
-      sc[j] = dot4(q, k);
-    } else { sc[j] = 0.f; v[j] = make_float4(0.f, 0.f, 0.f, 0.f); }
+  for (int j = 0; j < LKT; ++j) {
+    const int jc = min(j, Lk - 1);
+    k[j] = *reinterpret_cast<const float4*>(Kb + jc * s.k_rs);
+    v[j] = *reinterpret_cast<const float4*>(Vb + jc * s.v_rs);
   }
   float m = -INFINITY;
 #pragma unroll
-  for (int j = 0; j < LMAX; ++j) if (j < Lk) { sc[j] = group16_sum(sc[j]) * s.scale; m = fmaxf(m, sc[j]); }
+  for (int j = 0; j < LKT; ++j) {
+    sc[j] = group16_sum(dot4(q, k[j])) * s.scale;
+    if (j < Lk) m = fmaxf(m, sc[j]);
+  }
   float sum = 0.f;
 #pragma unroll
-  for (int j = 0; j < LMAX; ++j) if (j < Lk) { sc[j] = expf(sc[j] - m); sum += sc[j]; }
+  for (int j = 0; j < LKT; ++j) { sc[j] = j < Lk ? expf(sc[j] - m) : 0.f; sum += sc[j]; }
   const float inv = 1.f / sum;
   const float ds = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
   float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-  for (int j = 0; j < LMAX; ++j) {
-    if (j < Lk) {
-      float pv = sc[j] * inv;
-      const long long pidx = bh * Lk + j;
-      if (p.P && c == j) p.P[pidx] = pv;
-      if (drop.p > 0.f) pv = mansy_keep(drop.seed, drop.site, (uint32_t)pidx, drop.p) ? pv * ds : 0.f;
-      o.x = fmaf(pv, v[j].x, o.x); o.y = fmaf(pv, v[j].y, o.y); o.z = fmaf(pv, v[j].z, o.z); o.w = fmaf(pv, v[j].w, o.w);
-    }
+  for (int j = 0; j < LKT; ++j) {
+    float pv = sc[j] * inv;                      // 0 for j >= Lk
+    const long long pidx = bh * Lk + j;
+    if (p.P && c == j && j < Lk) p.P[pidx] = pv;
+    if (drop.p > 0.f) pv = mansy_keep(drop.seed, drop.site, (uint32_t)pidx, drop.p) ? pv * ds : 0.f;
+    o.x = fmaf(pv, v[j].x, o.x); o.y = fmaf(pv, v[j].y, o.y); o.z = fmaf(pv, v[j].z, o.z); o.w = fmaf(pv, v[j].w, o.w);
   }
   *reinterpret_cast<float4*>(p.O + b * s.o_bs + col) = o;
 }
 
+template <int LKT>
 __global__ __launch_bounds__(64 * WAVES) void attn_bwd_q1x4_kernel(AttnPtrs p, AttnShape s, MansyDrop drop, int accum_kv) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int hg = s.H >> 2;
@@ -331,42 +335,78 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_q1x4_kernel(AttnPtrs p, A
   float* dKb = p.dK + b * s.k_bs + col;
   float* dVb = p.dV + b * s.v_bs + col;
   const float ds = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
-  float4 k[LMAX];
-  float dP[LMAX], P[LMAX], keepf[LMAX];
+  float4 k[LKT], vv[LKT];
+  float dP[LKT], P[LKT], keepf[LKT];
 #pragma unroll
-  for (int j = 0; j < LMAX; ++j) {
-    keepf[j] = 1.f; P[j] = 0.f; dP[j] = 0.f; k[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (j < Lk) {
-      k[j] = *reinterpret_cast<const float4*>(Kb + j * s.k_rs);
-      const float4 vj = *reinterpret_cast<const float4*>(Vb + j * s.v_rs);
-      dP[j] = dot4(dO, vj);
-      P[j] = p.P[bh * Lk + j];
-      if (drop.p > 0.f) keepf[j] = mansy_keep(drop.seed, drop.site, (uint32_t)(bh * Lk + j), drop.p) ? ds : 0.f;
-    }
+  for (int j = 0; j < LKT; ++j) {
+    const int jc = min(j, Lk - 1);
+    k[j] = *reinterpret_cast<const float4*>(Kb + jc * s.k_rs);
+    vv[j] = *reinterpret_cast<const float4*>(Vb + jc * s.v_rs);
+    P[j] = p.P[bh * Lk + jc];
   }
   float delta = 0.f;
 #pragma unroll
-  for (int j = 0; j < LMAX; ++j) if (j < Lk) { dP[j] = group16_sum(dP[j]) * keepf[j]; delta = fmaf(P[j], dP[j], delta); }
+  for (int j = 0; j < LKT; ++j) {
+    keepf[j] = 1.f;
+    if (drop.p > 0.f) keepf[j] = mansy_keep(drop.seed, drop.site, (uint32_t)(bh * Lk + j), drop.p) ? ds : 0.f;
+    if (j >= Lk) P[j] = 0.f;
+    dP[j] = group16_sum(dot4(dO, vv[j])) * keepf[j];
+    delta = fmaf(P[j], dP[j], delta);
+  }
   float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
+  float dS[LKT];
 #pragma unroll
-  for (int j = 0; j < LMAX; ++j) {
-    if (j < Lk) {
-      const float dS = P[j] * (dP[j] - delta) * s.scale;
-      dq.x = fmaf(dS, k[j].x, dq.x); dq.y = fmaf(dS, k[j].y, dq.y); dq.z = fmaf(dS, k[j].z, dq.z); dq.w = fmaf(dS, k[j].w, dq.w);
-      const float pd = P[j] * keepf[j];
-      float4 dk = make_float4(dS * q.x, dS * q.y, dS * q.z, dS * q.w);
-      float4 dv = make_float4(pd * dO.x, pd * dO.y, pd * dO.z, pd * dO.w);
-      if (accum_kv) {
-        const float4 ok = *reinterpret_cast<const float4*>(dKb + j * s.k_rs), ov = *reinterpret_cast<const float4*>(dVb + j * s.v_rs);
-        dk.x += ok.x; dk.y += ok.y; dk.z += ok.z; dk.w += ok.w;
-        dv.x += ov.x; dv.y += ov.y; dv.z += ov.z; dv.w += ov.w;
-      }
-      *reinterpret_cast<float4*>(dKb + j * s.k_rs) = dk;
-      *reinterpret_cast<float4*>(dVb + j * s.v_rs) = dv;
-    }
+  for (int j = 0; j < LKT; ++j) {
+    dS[j] = P[j] * (dP[j] - delta) * s.scale;      // 0 for j >= Lk
+    dq.x = fmaf(dS[j], k[j].x, dq.x); dq.y = fmaf(dS[j], k[j].y, dq.y); dq.z = fmaf(dS[j], k[j].z, dq.z); dq.w = fmaf(dS[j], k[j].w, dq.w);
   }
   *reinterpret_cast<float4*>(p.dQ + b * s.q_bs + col) = dq;
+  // dK / dV rows: read-modify-write in groups of 4 rows (8 loads in flight, then 8 stores)
+#pragma unroll
+  for (int j0 = 0; j0 < LKT; j0 += 4) {
+    float4 ok[4], ov[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { ok[u] = make_float4(0.f, 0.f, 0.f, 0.f); ov[u] = ok[u]; }
+    if (accum_kv) {                              // uniform: one branch around the whole group's loads
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (j0 + u < LKT) {
+          const int jc = min(j0 + u, Lk - 1);
+          ok[u] = *reinterpret_cast<const float4*>(dKb + jc * s.k_rs);
+          ov[u] = *reinterpret_cast<const float4*>(dVb + jc * s.v_rs);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u;
+      if (j < LKT && j < Lk) {
+        const float pd = P[j] * keepf[j];
+        const float4 dk = make_float4(ok[u].x + dS[j] * q.x, ok[u].y + dS[j] * q.y, ok[u].z + dS[j] * q.z, ok[u].w + dS[j] * q.w);
+        const float4 dv = make_float4(ov[u].x + pd * dO.x, ov[u].y + pd * dO.y, ov[u].z + pd * dO.z, ov[u].w + pd * dO.w);
+        *reinterpret_cast<float4*>(dKb + j * s.k_rs) = dk;
+        *reinterpret_cast<float4*>(dVb + j * s.v_rs) = dv;
+      }
+    }
+  }
 }
+
+// LKT buckets: exact for the decode lengths the engine produces (1..10), then 12 and 16
+#define MANSY_Q1X4_DISPATCH(KERNEL, Lk, ...)                                                               \
+  switch (Lk) {                                                                                            \
+    case 1: hipLaunchKernelGGL(KERNEL<1>, __VA_ARGS__); break;                                             \
+    case 2: hipLaunchKernelGGL(KERNEL<2>, __VA_ARGS__); break;                                             \
+    case 3: hipLaunchKernelGGL(KERNEL<3>, __VA_ARGS__); break;                                             \
+    case 4: hipLaunchKernelGGL(KERNEL<4>, __VA_ARGS__); break;                                             \
+    case 5: hipLaunchKernelGGL(KERNEL<5>, __VA_ARGS__); break;                                             \
+    case 6: hipLaunchKernelGGL(KERNEL<6>, __VA_ARGS__); break;                                             \
+    case 7: hipLaunchKernelGGL(KERNEL<7>, __VA_ARGS__); break;                                             \
+    case 8: hipLaunchKernelGGL(KERNEL<8>, __VA_ARGS__); break;                                             \
+    case 9: hipLaunchKernelGGL(KERNEL<9>, __VA_ARGS__); break;                                             \
+    case 10: hipLaunchKernelGGL(KERNEL<10>, __VA_ARGS__); break;                                           \
+    case 11: case 12: hipLaunchKernelGGL(KERNEL<12>, __VA_ARGS__); break;                                  \
+    default: hipLaunchKernelGGL(KERNEL<16>, __VA_ARGS__); break;                                           \
+  }
 
 static bool q1x4_ok(const AttnShape& s, const void* a, const void* b, const void* c, const void* d) {
   auto al = [](const void* x) { return (reinterpret_cast<uintptr_t>(x) & 15) == 0; };
@@ -391,7 +431,7 @@ int mansy_launch_attn_fwd(const float* Q, const float* K, const float* V, float*
   if (n == 0) return MANSY_OK;
   AttnPtrs p = {Q, K, V, O, P_save, nullptr, nullptr, nullptr, nullptr};
   if (q1x4_ok(s, Q, K, V, O))
-    hipLaunchKernelGGL(attn_fwd_q1x4_kernel, dim3(mansy_ceil_div(n / 4, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop);
+    MANSY_Q1X4_DISPATCH(attn_fwd_q1x4_kernel, s.Lk, dim3(mansy_ceil_div(n / 4, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop)
   else if (s.Lq == 1) hipLaunchKernelGGL(attn_fwd_q1_kernel, dim3(mansy_ceil_div(n, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop);
   else hipLaunchKernelGGL(attn_fwd_kernel, dim3(mansy_ceil_div(n, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop);
   MANSY_LAUNCH_CHECK();
@@ -406,7 +446,7 @@ int mansy_launch_attn_bwd(const float* Q, const float* K, const float* V, const 
   if (n == 0) return MANSY_OK;
   AttnPtrs p = {Q, K, V, nullptr, const_cast<float*>(P_save), dO, dQ, dK, dV};
   if (q1x4_ok(s, Q, K, V, dO) && q1x4_ok(s, dQ, dK, dV, dO))
-    hipLaunchKernelGGL(attn_bwd_q1x4_kernel, dim3(mansy_ceil_div(n / 4, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop, accum_kv);
+    MANSY_Q1X4_DISPATCH(attn_bwd_q1x4_kernel, s.Lk, dim3(mansy_ceil_div(n / 4, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop, accum_kv)
   else if (s.Lq == 1) hipLaunchKernelGGL(attn_bwd_q1_kernel, dim3(mansy_ceil_div(n, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop, accum_kv);
   else hipLaunchKernelGGL(attn_bwd_kernel, dim3(mansy_ceil_div(n, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop, accum_kv);
   MANSY_LAUNCH_CHECK();

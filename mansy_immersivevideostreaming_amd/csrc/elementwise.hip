@@ -8,25 +8,49 @@
 namespace {
 
 constexpr int MAX_IN = 8;   // in_channel * num_head = 6 in the reference
+// The small dimension (in_channel = 2, in_channel * num_head = 6) is a template parameter NS where it is one of the
+// reference's values, so its loops unroll without predicates; NS = 0 is the generic form: MAX_IN iterations, loads at a
+// clamped index and a 0/1 weight.  (A runtime `if (k < n)` around each load makes hipcc branch and wait vmcnt(0) per load.)
+template <int NS> __device__ __forceinline__ constexpr int small_bound() { return NS > 0 ? NS : MAX_IN; }
+template <int NS> __device__ __forceinline__ int small_idx(int k, int n) { return NS > 0 ? k : min(k, n - 1); }
+template <int NS> __device__ __forceinline__ float small_on(int k, int n) { return (NS > 0 || k < n) ? 1.f : 0.f; }
 
+// V consecutive channels per thread (V = 4: 16-byte stores; needs C % 4 == 0 and 16-byte aligned pe / out)
+template <int V, int NS>
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict__ x, int in_ch, const float* __restrict__ W,
                                                         const float* __restrict__ b, const float* __restrict__ pe,
                                                         float* __restrict__ out, int rows, int C, int S, int pos_fixed,
                                                         MansyDrop drop) {
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long idx = ((long long)blockIdx.x * 256 + threadIdx.x) * V;
   if (idx >= (long long)rows * C) return;
   const int c = (int)(idx % C);
   const int r = (int)(idx / C);
   const int pos = pos_fixed >= 0 ? pos_fixed : (r % S);
-  float acc = 0.f;
-  for (int k = 0; k < in_ch; ++k) acc = fmaf(x[(long long)r * in_ch + k], W[c * in_ch + k], acc);
-  if (b) acc += b[c];
-  acc += pe[(long long)pos * C + c];
-  if (drop.p > 0.f) acc = mansy_keep(drop.seed, drop.site, (uint32_t)idx, drop.p) ? acc * (1.f / (1.f - drop.p)) : 0.f;
-  out[idx] = acc;
+  constexpr int NK = small_bound<NS>();
+  float xin[NK];
+#pragma unroll
+  for (int k = 0; k < NK; ++k) xin[k] = x[(long long)r * in_ch + small_idx<NS>(k, in_ch)] * small_on<NS>(k, in_ch);
+  float acc[V], pev[V], bv[V];
+  if (V == 4) *reinterpret_cast<float4*>(pev) = *reinterpret_cast<const float4*>(pe + (long long)pos * C + c);
+  else pev[0] = pe[(long long)pos * C + c];
+#pragma unroll
+  for (int j = 0; j < V; ++j) bv[j] = b ? b[c + j] : 0.f;
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) a = fmaf(xin[k], W[(c + j) * in_ch + small_idx<NS>(k, in_ch)], a);
+    a += bv[j];
+    a += pev[j];
+    if (drop.p > 0.f) a = mansy_keep(drop.seed, drop.site, (uint32_t)(idx + j), drop.p) ? a * (1.f / (1.f - drop.p)) : 0.f;
+    acc[j] = a;
+  }
+  if (V == 4) *reinterpret_cast<float4*>(out + idx) = *reinterpret_cast<const float4*>(acc);
+  else out[idx] = acc[0];
 }
 
 // one wave per row: dE = dX*mask ; dtok[r,k] = sum_c dE[r,c] W[c,k]
+template <int V, int NS>
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dX, const float* __restrict__ W,
                                                         float* __restrict__ dE, float* __restrict__ dtok, int in_ch, int rows,
                                                         int C, MansyDrop drop) {
@@ -34,86 +58,146 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
   const int row = (blockIdx.x * 256 + threadIdx.x) >> 6;
   if (row >= rows) return;
   const float dsc = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
-  float acc[MAX_IN];
+  constexpr int NK = small_bound<NS>();
+  float acc[NK];
 #pragma unroll
-  for (int k = 0; k < MAX_IN; ++k) acc[k] = 0.f;
-  for (int c = lane; c < C; c += 64) {
+  for (int k = 0; k < NK; ++k) acc[k] = 0.f;
+  for (int c = lane * V; c < C; c += 64 * V) {
     const long long idx = (long long)row * C + c;
-    float g = dX[idx];
-    if (drop.p > 0.f) g = mansy_keep(drop.seed, drop.site, (uint32_t)idx, drop.p) ? g * dsc : 0.f;
-    if (dE) dE[idx] = g;
+    float g[V];
+    if (V == 4) *reinterpret_cast<float4*>(g) = *reinterpret_cast<const float4*>(dX + idx);
+    else g[0] = dX[idx];
 #pragma unroll
-    for (int k = 0; k < MAX_IN; ++k) if (k < in_ch) acc[k] = fmaf(g, W[c * in_ch + k], acc[k]);
+    for (int j = 0; j < V; ++j)
+      if (drop.p > 0.f) g[j] = mansy_keep(drop.seed, drop.site, (uint32_t)(idx + j), drop.p) ? g[j] * dsc : 0.f;
+    if (dE) {
+      if (V == 4) *reinterpret_cast<float4*>(dE + idx) = *reinterpret_cast<const float4*>(g);
+      else dE[idx] = g[0];
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j)
+#pragma unroll
+      for (int k = 0; k < NK; ++k) acc[k] = fmaf(g[j], W[(c + j) * in_ch + small_idx<NS>(k, in_ch)], acc[k]);
   }
   if (dtok) {
 #pragma unroll
-    for (int k = 0; k < MAX_IN; ++k) {
-      if (k < in_ch) {
-        const float s = wave_sum(acc[k]);
-        if (lane == 0) dtok[(long long)row * in_ch + k] = s;
-      }
+    for (int k = 0; k < NK; ++k) {
+      const float t = wave_sum(acc[k]);
+      if (lane == 0 && (NS > 0 || k < in_ch)) dtok[(long long)row * in_ch + k] = t;
     }
   }
 }
 
-// out += sum_r small[r,k] * big[r,c]; grid (C/256, row-chunks)
+// out += sum_r small[r,k] * big[r,c]  (the dW of the K<=8 linears: embedding, predictor) + optional column / small sums.
+// grid (ceil(C/256), row-chunks): a wave owns 256 columns (float4 per lane, V = 4) or 64 (V = 1) and every 4*gridDim.y-th
+// row; rows are unrolled by 4 so that four 1-KiB row pieces are in flight per wave; the 4 waves of a workgroup are combined
+// through LDS before the atomics.
+template <int V, int NS>
 __global__ __launch_bounds__(256) void outer_reduce_kernel(const float* __restrict__ small_, int small_n,
                                                            const float* __restrict__ big, int rows, int C,
                                                            float* __restrict__ out, int c_major, float* __restrict__ bsum_big,
                                                            float* __restrict__ bsum_small) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  const int r0 = blockIdx.y, rstep = gridDim.y;
-  float acc[MAX_IN];
-  float sb = 0.f;
+  constexpr int NK = small_bound<NS>();
+  __shared__ float red[4][NK + 1][64 * V];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + lane) * V;
+  const bool live = c < C;
+  float acc[NK][V], sb[V];
 #pragma unroll
-  for (int k = 0; k < MAX_IN; ++k) acc[k] = 0.f;
-  if (c < C) {
-    for (int r = r0; r < rows; r += rstep) {
-      const float v = big[(long long)r * C + c];
-      sb += v;
+  for (int k = 0; k < NK; ++k)
 #pragma unroll
-      for (int k = 0; k < MAX_IN; ++k) if (k < small_n) acc[k] = fmaf(small_[(long long)r * small_n + k], v, acc[k]);
+    for (int j = 0; j < V; ++j) acc[k][j] = 0.f;
+#pragma unroll
+  for (int j = 0; j < V; ++j) sb[j] = 0.f;
+  const int rstep = gridDim.y * 4;
+  for (int r0 = blockIdx.y * 4 + wave; r0 < rows; r0 += 4 * rstep) {
+    float v[4][V];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = r0 + u * rstep;
+      if (live && r < rows) {
+        if (V == 4) *reinterpret_cast<float4*>(v[u]) = *reinterpret_cast<const float4*>(big + (long long)r * C + c);
+        else v[u][0] = big[(long long)r * C + c];
+      } else {
+#pragma unroll
+        for (int j = 0; j < V; ++j) v[u][j] = 0.f;
+      }
     }
 #pragma unroll
-    for (int k = 0; k < MAX_IN; ++k)
-      if (k < small_n) atomicAdd(out + (c_major ? (long long)c * small_n + k : (long long)k * C + c), acc[k]);
-    if (bsum_big) atomicAdd(bsum_big + c, sb);
+    for (int u = 0; u < 4; ++u) {
+      const int r = min(r0 + u * rstep, rows - 1);      // v[u] is zero beyond the last row
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        const float sv = small_[(long long)r * small_n + small_idx<NS>(k, small_n)];
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[k][j] = fmaf(sv, v[u][j], acc[k][j]);
+      }
+#pragma unroll
+      for (int j = 0; j < V; ++j) sb[j] += v[u][j];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NK; ++k)
+#pragma unroll
+    for (int j = 0; j < V; ++j) red[wave][k][lane * V + j] = acc[k][j];
+#pragma unroll
+  for (int j = 0; j < V; ++j) red[wave][NK][lane * V + j] = sb[j];
+  __syncthreads();
+  // 256 threads over (NK + 1) x 64*V sums
+  for (int i = threadIdx.x; i < (NK + 1) * 64 * V; i += 256) {
+    const int k = i / (64 * V), cc = i % (64 * V);
+    const int col = blockIdx.x * 64 * V + cc;
+    if (col >= C) continue;
+    const float t = red[0][k][cc] + red[1][k][cc] + red[2][k][cc] + red[3][k][cc];
+    if (k < small_n) atomicAdd(out + (c_major ? (long long)col * small_n + k : (long long)k * C + col), t);
+    else if (k == NK && bsum_big) atomicAdd(bsum_big + col, t);
   }
   if (bsum_small && blockIdx.x == 0 && threadIdx.x < small_n) {
-    float s = 0.f;
-    for (int r = r0; r < rows; r += rstep) s += small_[(long long)r * small_n + threadIdx.x];
-    atomicAdd(bsum_small + threadIdx.x, s);
+    float t = 0.f;
+    for (int r = blockIdx.y; r < rows; r += gridDim.y) t += small_[(long long)r * small_n + threadIdx.x];
+    atomicAdd(bsum_small + threadIdx.x, t);
   }
 }
 
+template <int V, int NS>
 __global__ __launch_bounds__(256) void predictor_fwd_kernel(const float* __restrict__ h, const float* __restrict__ W,
                                                             const float* __restrict__ b, float* __restrict__ y_a, long long sa,
                                                             float* __restrict__ y_b, long long sb, int rows, int C, int out_ch) {
   const int lane = threadIdx.x & 63;
   const int row = (blockIdx.x * 256 + threadIdx.x) >> 6;
   if (row >= rows) return;
-  float acc[MAX_IN];
+  constexpr int NK = small_bound<NS>();
+  float acc[NK];
 #pragma unroll
-  for (int k = 0; k < MAX_IN; ++k) acc[k] = 0.f;
-  for (int c = lane; c < C; c += 64) {
-    const float v = h[(long long)row * C + c];
+  for (int k = 0; k < NK; ++k) acc[k] = 0.f;
+  for (int c = lane * V; c < C; c += 64 * V) {
+    float v[V], w[NK][V];
+    if (V == 4) *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(h + (long long)row * C + c);
+    else v[0] = h[(long long)row * C + c];
 #pragma unroll
-    for (int k = 0; k < MAX_IN; ++k) if (k < out_ch) acc[k] = fmaf(v, W[(long long)k * C + c], acc[k]);
+    for (int k = 0; k < NK; ++k) {
+      const float* wr = W + (long long)small_idx<NS>(k, out_ch) * C + c;
+      if (V == 4) *reinterpret_cast<float4*>(w[k]) = *reinterpret_cast<const float4*>(wr);
+      else w[k][0] = wr[0];
+    }
+#pragma unroll
+    for (int k = 0; k < NK; ++k)
+#pragma unroll
+      for (int j = 0; j < V; ++j) acc[k] = fmaf(v[j], w[k][j], acc[k]);
   }
 #pragma unroll
-  for (int k = 0; k < MAX_IN; ++k) {
-    if (k < out_ch) {
-      float s = wave_sum(acc[k]);
-      if (lane == 0) {
-        if (b) s += b[k];
-        const float y = 1.f / (1.f + expf(-s));
-        y_a[row * sa + k] = y;
-        if (y_b) y_b[row * sb + k] = y;
-      }
+  for (int k = 0; k < NK; ++k) {
+    float t = wave_sum(acc[k]);
+    if (lane == 0 && (NS > 0 || k < out_ch)) {
+      if (b) t += b[k];
+      const float y = 1.f / (1.f + expf(-t));
+      y_a[row * sa + k] = y;
+      if (y_b) y_b[row * sb + k] = y;
     }
   }
 }
 
+template <int V, int NS>
 __global__ __launch_bounds__(256) void predictor_bwd_kernel(const float* __restrict__ dy_a, long long sa, const float* __restrict__ dy_b,
                                                             long long sb, const float* __restrict__ y, long long sy,
                                                             const float* __restrict__ W, float* __restrict__ dz, float* __restrict__ dh,
@@ -121,27 +205,36 @@ __global__ __launch_bounds__(256) void predictor_bwd_kernel(const float* __restr
   const int lane = threadIdx.x & 63;
   const int row = (blockIdx.x * 256 + threadIdx.x) >> 6;
   if (row >= rows) return;
-  float g[MAX_IN];
+  constexpr int NK = small_bound<NS>();
+  float g[NK];
 #pragma unroll
-  for (int k = 0; k < MAX_IN; ++k) {
-    g[k] = 0.f;
-    if (k < out_ch) {
-      float d = dy_a[row * sa + k];
-      if (dy_b) d += dy_b[row * sb + k];
-      const float yy = y[row * sy + k];
-      g[k] = d * yy * (1.f - yy);
-      if (lane == 0) dz[(long long)row * out_ch + k] = g[k];
-    }
+  for (int k = 0; k < NK; ++k) {
+    const int kc = small_idx<NS>(k, out_ch);
+    float d = dy_a[row * sa + kc];
+    if (dy_b) d += dy_b[row * sb + kc];
+    const float yy = y[row * sy + kc];
+    g[k] = d * yy * (1.f - yy) * small_on<NS>(k, out_ch);
+    if (lane == 0 && (NS > 0 || k < out_ch)) dz[(long long)row * out_ch + k] = g[k];
   }
-  for (int c = lane; c < C; c += 64) {
-    float acc = 0.f;
+  for (int c = lane * V; c < C; c += 64 * V) {
+    float acc[V], w[NK][V];
 #pragma unroll
-    for (int k = 0; k < MAX_IN; ++k) if (k < out_ch) acc = fmaf(g[k], W[(long long)k * C + c], acc);
-    dh[(long long)row * C + c] = acc;
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const float* wr = W + (long long)small_idx<NS>(k, out_ch) * C + c;
+      if (V == 4) *reinterpret_cast<float4*>(w[k]) = *reinterpret_cast<const float4*>(wr);
+      else w[k][0] = wr[0];
+    }
+#pragma unroll
+    for (int k = 0; k < NK; ++k)
+#pragma unroll
+      for (int j = 0; j < V; ++j) acc[j] = fmaf(g[k], w[k][j], acc[j]);
+    if (V == 4) *reinterpret_cast<float4*>(dh + (long long)row * C + c) = *reinterpret_cast<const float4*>(acc);
+    else dh[(long long)row * C + c] = acc[0];
   }
 }
 
-// periodic distance e = min(|a-b|, |a+1-b|, |a-1-b|) ; loss += inv_2bt * e^2 ; d/da = inv_2bt * 2 e * sign(arg)
 __global__ __launch_bounds__(256) void mtio_loss_kernel(const float* __restrict__ pred, const float* __restrict__ gt, long long n,
                                                         float inv_2bt, double* __restrict__ accum, float* __restrict__ dpred) {
   __shared__ double part[4];
@@ -312,6 +405,20 @@ __global__ __launch_bounds__(256) void periodic_mse_kernel(const float* __restri
 }
 
 inline dim3 g1(long long n) { return dim3(mansy_ceil_div(n, 256)); }
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+// KERNEL<V, NS>: V = 4 when `vec`, NS = the small dimension when it is one of the reference's (2, 6), else generic
+#define MANSY_SMALL_DISPATCH(KERNEL, vec, ns, grid_v4, grid_v1, ...)                                                          \
+  do {                                                                                                                        \
+    if (vec) {                                                                                                                \
+      if ((ns) == 2) hipLaunchKernelGGL((KERNEL<4, 2>), grid_v4, dim3(256), 0, st, __VA_ARGS__);                              \
+      else if ((ns) == 6) hipLaunchKernelGGL((KERNEL<4, 6>), grid_v4, dim3(256), 0, st, __VA_ARGS__);                         \
+      else hipLaunchKernelGGL((KERNEL<4, 0>), grid_v4, dim3(256), 0, st, __VA_ARGS__);                                        \
+    } else {                                                                                                                  \
+      if ((ns) == 2) hipLaunchKernelGGL((KERNEL<1, 2>), grid_v1, dim3(256), 0, st, __VA_ARGS__);                              \
+      else if ((ns) == 6) hipLaunchKernelGGL((KERNEL<1, 6>), grid_v1, dim3(256), 0, st, __VA_ARGS__);                         \
+      else hipLaunchKernelGGL((KERNEL<1, 0>), grid_v1, dim3(256), 0, st, __VA_ARGS__);                                        \
+    }                                                                                                                         \
+  } while (0)
 
 }  // namespace
 
@@ -336,7 +443,8 @@ int mansy_launch_embed_fwd(const float* x, int in_ch, const float* W, const floa
   MANSY_REQUIRE(x && W && pe && out, "embed_fwd: null pointer");
   MANSY_REQUIRE(in_ch >= 1 && in_ch <= MAX_IN, "embed_fwd: in_ch %d unsupported", in_ch);
   if (rows <= 0) return MANSY_OK;
-  hipLaunchKernelGGL(embed_fwd_kernel, g1((long long)rows * C), dim3(256), 0, st, x, in_ch, W, b, pe, out, rows, C, S, pos_fixed, drop);
+  MANSY_SMALL_DISPATCH(embed_fwd_kernel, C % 4 == 0 && al16(pe) && al16(out), in_ch, g1((long long)rows * C / 4), g1((long long)rows * C),
+                       x, in_ch, W, b, pe, out, rows, C, S, pos_fixed, drop);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }
@@ -346,7 +454,8 @@ int mansy_launch_embed_bwd(const float* dX, const float* W, float* dE, float* dt
   MANSY_REQUIRE(dX && W, "embed_bwd: null pointer");
   MANSY_REQUIRE(in_ch >= 1 && in_ch <= MAX_IN, "embed_bwd: in_ch %d unsupported", in_ch);
   if (rows <= 0) return MANSY_OK;
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(mansy_ceil_div(rows, 4)), dim3(256), 0, st, dX, W, dE, dtok, in_ch, rows, C, drop);
+  MANSY_SMALL_DISPATCH(embed_bwd_kernel, C % 4 == 0 && al16(dX) && (!dE || al16(dE)), in_ch, dim3(mansy_ceil_div(rows, 4)),
+                       dim3(mansy_ceil_div(rows, 4)), dX, W, dE, dtok, in_ch, rows, C, drop);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }
@@ -356,8 +465,9 @@ int mansy_launch_outer_reduce(const float* small_, int small_n, const float* big
   MANSY_REQUIRE(small_ && big && out, "outer_reduce: null pointer");
   MANSY_REQUIRE(small_n >= 1 && small_n <= MAX_IN, "outer_reduce: small_n %d unsupported", small_n);
   if (rows <= 0) return MANSY_OK;
-  dim3 grid(mansy_ceil_div(C, 256), min(rows, 256));
-  hipLaunchKernelGGL(outer_reduce_kernel, grid, dim3(256), 0, st, small_, small_n, big, rows, C, out, c_major, bsum_big, bsum_small);
+  const int chunks = max(1, min(mansy_ceil_div(rows, 16), 256));
+  MANSY_SMALL_DISPATCH(outer_reduce_kernel, C % 4 == 0 && al16(big), small_n, dim3(mansy_ceil_div(C, 256), chunks),
+                       dim3(mansy_ceil_div(C, 64), chunks), small_, small_n, big, rows, C, out, c_major, bsum_big, bsum_small);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }
@@ -367,8 +477,8 @@ int mansy_launch_predictor_fwd(const float* h, const float* W, const float* b, f
   MANSY_REQUIRE(h && W && y_a, "predictor_fwd: null pointer");
   MANSY_REQUIRE(out_ch >= 1 && out_ch <= MAX_IN, "predictor_fwd: out_ch %d unsupported", out_ch);
   if (rows <= 0) return MANSY_OK;
-  hipLaunchKernelGGL(predictor_fwd_kernel, dim3(mansy_ceil_div(rows, 4)), dim3(256), 0, st, h, W, b, y_a, ya_stride, y_b, yb_stride,
-                     rows, C, out_ch);
+  MANSY_SMALL_DISPATCH(predictor_fwd_kernel, C % 4 == 0 && al16(h) && al16(W), out_ch, dim3(mansy_ceil_div(rows, 4)),
+                       dim3(mansy_ceil_div(rows, 4)), h, W, b, y_a, ya_stride, y_b, yb_stride, rows, C, out_ch);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }
@@ -378,8 +488,8 @@ int mansy_launch_predictor_bwd(const float* dy_a, long long sa, const float* dy_
   MANSY_REQUIRE(dy_a && y && W && dz && dh, "predictor_bwd: null pointer");
   MANSY_REQUIRE(out_ch >= 1 && out_ch <= MAX_IN, "predictor_bwd: out_ch %d unsupported", out_ch);
   if (rows <= 0) return MANSY_OK;
-  hipLaunchKernelGGL(predictor_bwd_kernel, dim3(mansy_ceil_div(rows, 4)), dim3(256), 0, st, dy_a, sa, dy_b, sb, y, sy, W, dz, dh,
-                     rows, C, out_ch);
+  MANSY_SMALL_DISPATCH(predictor_bwd_kernel, C % 4 == 0 && al16(W) && al16(dh), out_ch, dim3(mansy_ceil_div(rows, 4)),
+                       dim3(mansy_ceil_div(rows, 4)), dy_a, sa, dy_b, sb, y, sy, W, dz, dh, rows, C, out_ch);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }

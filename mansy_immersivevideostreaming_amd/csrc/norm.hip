@@ -157,17 +157,43 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
     adw[i] = make_float4(0.f, 0.f, 0.f, 0.f); adb[i] = adw[i];
     ww[i] = i < nv ? *reinterpret_cast<const float4*>(w + (i * 64 + lane) * 4) : adw[i];
   }
+  // the next row's dy / z are fetched while this row is reduced and written (a wave walks its rows serially otherwise:
+  // two dependent HBM round trips per row)
+  float4 dn[LN_MAXV], zn[LN_MAXV];
+  float mun = 0.f, rsn = 0.f;
+  if (wave_global < rows) {
+    mun = mean[wave_global]; rsn = rstd[wave_global];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      if (i < nv) {
+        const long long off = (long long)wave_global * C + (i * 64 + lane) * 4;
+        dn[i] = *reinterpret_cast<const float4*>(dy + off);
+        zn[i] = *reinterpret_cast<const float4*>(z + off);
+      }
+    }
+  }
   for (int row = wave_global; row < rows; row += nwaves) {
     const long long base = (long long)row * C;
-    const float mu = mean[row], rs = rstd[row];
-    float4 d[LN_MAXV], xh[LN_MAXV];
+    const float mu = mun, rs = rsn;
+    float4 d[LN_MAXV], zc[LN_MAXV], xh[LN_MAXV];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) { d[i] = dn[i]; zc[i] = zn[i]; }
+    if (row + nwaves < rows) {
+      mun = mean[row + nwaves]; rsn = rstd[row + nwaves];
+#pragma unroll
+      for (int i = 0; i < LN_MAXV; ++i) {
+        if (i < nv) {
+          const long long off = (long long)(row + nwaves) * C + (i * 64 + lane) * 4;
+          dn[i] = *reinterpret_cast<const float4*>(dy + off);
+          zn[i] = *reinterpret_cast<const float4*>(z + off);
+        }
+      }
+    }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i) {
       if (i < nv) {
-        const long long off = base + (i * 64 + lane) * 4;
-        d[i] = *reinterpret_cast<const float4*>(dy + off);
-        const float4 zz = *reinterpret_cast<const float4*>(z + off);
+        const float4 zz = zc[i];
         xh[i] = make_float4((zz.x - mu) * rs, (zz.y - mu) * rs, (zz.z - mu) * rs, (zz.w - mu) * rs);
         const float gx = d[i].x * ww[i].x, gy = d[i].y * ww[i].y, gz = d[i].z * ww[i].z, gw = d[i].w * ww[i].w;
         s1 += (gx + gy) + (gz + gw);

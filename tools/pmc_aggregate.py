@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Aggregates the rocprofv3 PMC passes of tools/gpu_prof.sh (gpurun_out/pmc_r: FETCH_SIZE, gpurun_out/pmc_w: WRITE_SIZE,
+separate runs) into profiles/<tag>_pmc_gemm.json: HBM-side bytes per GEMM launch.  FETCH_SIZE / WRITE_SIZE count KiB;
+on gfx950 FETCH_SIZE reports half of a wide streaming read (MI355X_MICROARCH.md, HBM / rocprofv3), hence the x2."""
+import csv, glob, json, os, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def total(dirname, counter):
+    files = sorted(glob.glob(os.path.join(ROOT, 'gpurun_out', dirname, '**', '*_counter_collection.csv'), recursive=True), key=os.path.getmtime)
+    if not files:
+        raise SystemExit(f'no counter_collection.csv under gpurun_out/{dirname}')
+    s, n = 0.0, 0
+    for r in csv.DictReader(open(files[-1])):
+        if r['Counter_Name'] == counter and 'gemm_f32' in r['Kernel_Name']:
+            s += float(r['Counter_Value']); n += 1
+    return s * 1024.0, n
+
+
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+alg = float(sys.argv[2]) if len(sys.argv) > 2 else 50011000.0
+fetch, n = total('pmc_r', 'FETCH_SIZE')
+write, n2 = total('pmc_w', 'WRITE_SIZE')
+assert n == n2 and n > 0, (n, n2)
+out = {'kernel': 'gemm_f32_dma_kernel / gemm_f32_kernel', 'launches': n, 'fetch_bytes_per_launch': 2.0 * fetch / n, 'write_bytes_per_launch': write / n,
+       'traffic_bytes_per_launch': (2.0 * fetch + write) / n, 'algorithmic_bytes_per_launch': alg,
+       'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over 2 train steps (B=4096, 285 GEMM launches per step); '
+               'FETCH_SIZE x2 per the gfx950 correction (MI355X_MICROARCH.md, HBM); the counters sit at the L2<->fabric boundary, so '
+               'Infinity-Cache hits are included'}
+path = os.path.join(ROOT, 'profiles', f'{tag}_pmc_gemm.json')
+json.dump(out, open(path, 'w'), indent=1)
+print(path, json.dumps(out)[:300])
