@@ -19,6 +19,7 @@ constexpr int WAVES = 4;
 struct AttnPtrs {
   const float* Q; const float* K; const float* V; float* O; float* P;
   const float* dO; float* dQ; float* dK; float* dV;
+  float* dS_out; float* Pk_out;     // q1x4 backward, deferred dK/dV: [nb*H, Lk] score gradients / dropped probabilities
 };
 
 __device__ __forceinline__ void load_rows(const float* base, long long rs, int L, int dh, int lane, float* lds) {
@@ -361,6 +362,14 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_q1x4_kernel(AttnPtrs p, A
     dq.x = fmaf(dS[j], k[j].x, dq.x); dq.y = fmaf(dS[j], k[j].y, dq.y); dq.z = fmaf(dS[j], k[j].z, dq.z); dq.w = fmaf(dS[j], k[j].w, dq.w);
   }
   *reinterpret_cast<float4*>(p.dQ + b * s.q_bs + col) = dq;
+  if (p.dS_out) {          // deferred dK / dV (mansy_launch_attn_kvgrad): keep this step's coefficients, touch no K/V gradient row
+    const int c = lane & 15;
+#pragma unroll
+    for (int j = 0; j < LKT; ++j) {
+      if (c == j && j < Lk) { p.dS_out[bh * Lk + j] = dS[j]; p.Pk_out[bh * Lk + j] = P[j] * keepf[j]; }
+    }
+    return;
+  }
   // dK / dV rows: read-modify-write in groups of 4 rows (8 loads in flight, then 8 stores)
 #pragma unroll
   for (int j0 = 0; j0 < LKT; j0 += 4) {
@@ -388,6 +397,57 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_q1x4_kernel(AttnPtrs p, A
         *reinterpret_cast<float4*>(dVb + j * s.v_rs) = dv;
       }
     }
+  }
+}
+
+// Deferred K/V gradients of a Lq == 1 attention evaluated at TT query steps against the SAME K/V rows (decoder
+// cross-attention: every step attends to the distilled memory):
+//   dK[j] = sum_i dS_i[j] * q_i        dV[j] = sum_i Pk_i[j] * dO_i
+// replaces TT read-modify-write passes over the K/V gradient rows (2 x Lk x 1 KiB per wave and step) by one pass that
+// reads the TT query / output-gradient rows once.  Same wave layout as the q1x4 kernels (4 heads x 16 lanes x float4).
+template <int TT>
+__global__ __launch_bounds__(64 * WAVES) void attn_kvgrad_q1x4_kernel(const float* __restrict__ Q_all, long long q_ts,
+                                                                      const float* __restrict__ dO_all, long long o_ts,
+                                                                      const float* __restrict__ dS_all, const float* __restrict__ Pk_all,
+                                                                      float* __restrict__ dK, float* __restrict__ dV, AttnShape s, int T,
+                                                                      int accum) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int hg = s.H >> 2;
+  const long long g = (long long)blockIdx.x * WAVES + wave;
+  if (g >= (long long)s.nb * hg) return;
+  const int b = (int)(g / hg), h = (int)(g % hg) * 4 + (lane >> 4), c = lane & 15;
+  const long long bh = (long long)b * s.H + h;
+  const int Lk = s.Lk;
+  const int col = h * 64 + c * 4;
+  const long long coef_ts = (long long)s.nb * s.H * Lk;
+  float4 q[TT], go[TT];
+  float aS[TT], aP[TT];
+#pragma unroll
+  for (int i = 0; i < TT; ++i) {
+    const int ic = min(i, T - 1);
+    q[i] = *reinterpret_cast<const float4*>(Q_all + ic * q_ts + b * s.q_bs + col);
+    go[i] = *reinterpret_cast<const float4*>(dO_all + ic * o_ts + b * s.o_bs + col);
+    const long long ci = ic * coef_ts + bh * Lk + min(c, Lk - 1);
+    aS[i] = i < T ? dS_all[ci] : 0.f;      // lane c of a head group holds coefficient j = c
+    aP[i] = i < T ? Pk_all[ci] : 0.f;
+  }
+  float* dKb = dK + b * s.k_bs + col;
+  float* dVb = dV + b * s.v_bs + col;
+  for (int j = 0; j < Lk; ++j) {
+    float4 dk = make_float4(0.f, 0.f, 0.f, 0.f), dv = dk;
+    if (accum) {
+      dk = *reinterpret_cast<const float4*>(dKb + j * s.k_rs);
+      dv = *reinterpret_cast<const float4*>(dVb + j * s.v_rs);
+    }
+    const int src = (lane & 48) + j;
+#pragma unroll
+    for (int i = 0; i < TT; ++i) {
+      const float a = __shfl(aS[i], src, 64), bb = __shfl(aP[i], src, 64);
+      dk.x = fmaf(a, q[i].x, dk.x); dk.y = fmaf(a, q[i].y, dk.y); dk.z = fmaf(a, q[i].z, dk.z); dk.w = fmaf(a, q[i].w, dk.w);
+      dv.x = fmaf(bb, go[i].x, dv.x); dv.y = fmaf(bb, go[i].y, dv.y); dv.z = fmaf(bb, go[i].z, dv.z); dv.w = fmaf(bb, go[i].w, dv.w);
+    }
+    *reinterpret_cast<float4*>(dKb + j * s.k_rs) = dk;
+    *reinterpret_cast<float4*>(dVb + j * s.v_rs) = dv;
   }
 }
 
@@ -429,7 +489,7 @@ int mansy_launch_attn_fwd(const float* Q, const float* K, const float* V, float*
   MANSY_REQUIRE(Q && K && V && O, "attn_fwd: null pointer");
   const long long n = (long long)s.nb * s.H;
   if (n == 0) return MANSY_OK;
-  AttnPtrs p = {Q, K, V, O, P_save, nullptr, nullptr, nullptr, nullptr};
+  AttnPtrs p = {Q, K, V, O, P_save, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   if (q1x4_ok(s, Q, K, V, O))
     MANSY_Q1X4_DISPATCH(attn_fwd_q1x4_kernel, s.Lk, dim3(mansy_ceil_div(n / 4, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop)
   else if (s.Lq == 1) hipLaunchKernelGGL(attn_fwd_q1_kernel, dim3(mansy_ceil_div(n, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop);
@@ -444,11 +504,45 @@ int mansy_launch_attn_bwd(const float* Q, const float* K, const float* V, const 
   MANSY_REQUIRE(Q && K && V && P_save && dO && dQ && dK && dV, "attn_bwd: null pointer");
   const long long n = (long long)s.nb * s.H;
   if (n == 0) return MANSY_OK;
-  AttnPtrs p = {Q, K, V, nullptr, const_cast<float*>(P_save), dO, dQ, dK, dV};
+  AttnPtrs p = {Q, K, V, nullptr, const_cast<float*>(P_save), dO, dQ, dK, dV, nullptr, nullptr};
   if (q1x4_ok(s, Q, K, V, dO) && q1x4_ok(s, dQ, dK, dV, dO))
     MANSY_Q1X4_DISPATCH(attn_bwd_q1x4_kernel, s.Lk, dim3(mansy_ceil_div(n / 4, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop, accum_kv)
   else if (s.Lq == 1) hipLaunchKernelGGL(attn_bwd_q1_kernel, dim3(mansy_ceil_div(n, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop, accum_kv);
   else hipLaunchKernelGGL(attn_bwd_kernel, dim3(mansy_ceil_div(n, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop, accum_kv);
+  MANSY_LAUNCH_CHECK();
+  return MANSY_OK;
+}
+
+// ---- deferred K/V gradients (decoder cross-attention).  Shape-only test; pointers must be 16-byte aligned.
+int mansy_attn_deferred_kv_ok(const AttnShape& s, int T) {
+  return s.Lq == 1 && s.dh == 64 && (s.H % 4) == 0 && s.Lk >= 1 && s.Lk <= LMAX && T >= 1 && T <= LMAX && (s.q_bs % 4) == 0 &&
+         (s.k_bs % 4) == 0 && (s.k_rs % 4) == 0 && (s.v_bs % 4) == 0 && (s.v_rs % 4) == 0 && (s.o_bs % 4) == 0;
+}
+// One step: dQ only; dS_out / Pk_out [nb*H, Lk] receive the coefficients mansy_launch_attn_kvgrad sums over the steps.
+int mansy_launch_attn_bwd_dq(const float* Q, const float* K, const float* V, const float* P_save, const float* dO, float* dQ,
+                             float* dS_out, float* Pk_out, const AttnShape& s, MansyDrop drop, hipStream_t st) {
+  int rc = check_shape(s); if (rc) return rc;
+  MANSY_REQUIRE(Q && K && V && P_save && dO && dQ && dS_out && Pk_out, "attn_bwd_dq: null pointer");
+  MANSY_REQUIRE(q1x4_ok(s, Q, K, V, dO) && q1x4_ok(s, dQ, K, V, dO), "attn_bwd_dq: shape / alignment not on the 4-heads-per-wave path");
+  const long long n = (long long)s.nb * s.H;
+  if (n == 0) return MANSY_OK;
+  AttnPtrs p = {Q, K, V, nullptr, const_cast<float*>(P_save), dO, dQ, nullptr, nullptr, dS_out, Pk_out};
+  MANSY_Q1X4_DISPATCH(attn_bwd_q1x4_kernel, s.Lk, dim3(mansy_ceil_div(n / 4, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop, 0)
+  MANSY_LAUNCH_CHECK();
+  return MANSY_OK;
+}
+// Q_all / dO_all: step i at + i*q_ts / + i*o_ts (batch strides from s); dS_all / Pk_all: [T][nb*H][Lk].
+int mansy_launch_attn_kvgrad(const float* Q_all, long long q_ts, const float* dO_all, long long o_ts, const float* dS_all,
+                             const float* Pk_all, float* dK, float* dV, const AttnShape& s, int T, int accum, hipStream_t st) {
+  MANSY_REQUIRE(Q_all && dO_all && dS_all && Pk_all && dK && dV, "attn_kvgrad: null pointer");
+  MANSY_REQUIRE(mansy_attn_deferred_kv_ok(s, T) && (q_ts % 4) == 0 && (o_ts % 4) == 0, "attn_kvgrad: unsupported shape");
+  auto al = [](const void* x) { return (reinterpret_cast<uintptr_t>(x) & 15) == 0; };
+  MANSY_REQUIRE(al(Q_all) && al(dO_all) && al(dK) && al(dV), "attn_kvgrad: pointers must be 16-byte aligned");
+  const long long n = (long long)s.nb * s.H;
+  if (n == 0) return MANSY_OK;
+#define MANSY_KVGRAD_ARGS dim3(mansy_ceil_div(n / 4, WAVES)), dim3(64 * WAVES), 0, st, Q_all, q_ts, dO_all, o_ts, dS_all, Pk_all, dK, dV, s, T, accum
+  MANSY_Q1X4_DISPATCH(attn_kvgrad_q1x4_kernel, T, MANSY_KVGRAD_ARGS)
+#undef MANSY_KVGRAD_ARGS
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }

@@ -48,6 +48,16 @@ int mansy_launch_attn_bwd(const float* Q, const float* K, const float* V, const 
                           float* dQ, float* dK, float* dV, const AttnShape& s, MansyDrop drop, int accum_kv,
                           hipStream_t st);
 
+// Deferred K/V gradients for a Lq == 1 attention evaluated at T steps against the same K/V rows (decoder cross-attention):
+// per step mansy_launch_attn_bwd_dq writes dQ and the step's coefficients (dS, dropped P: [nb*H, Lk] each); one
+// mansy_launch_attn_kvgrad then forms dK[j] = sum_i dS_i[j] q_i, dV[j] = sum_i Pk_i[j] dO_i (overwrites, or += when accum).
+// Q_all / dO_all hold step i at + i*q_ts / + i*o_ts; dS_all / Pk_all are [T][nb*H][Lk].
+int mansy_attn_deferred_kv_ok(const AttnShape& s, int T);
+int mansy_launch_attn_bwd_dq(const float* Q, const float* K, const float* V, const float* P_save, const float* dO, float* dQ,
+                             float* dS_out, float* Pk_out, const AttnShape& s, MansyDrop drop, hipStream_t st);
+int mansy_launch_attn_kvgrad(const float* Q_all, long long q_ts, const float* dO_all, long long o_ts, const float* dS_all,
+                             const float* Pk_all, float* dK, float* dV, const AttnShape& s, int T, int accum, hipStream_t st);
+
 // ---------------------------------------------------------------- norms (norm.hip)
 // z = a (+ b);  y = LN(z) * w (+ bias).  z_out may be null (not saved) or alias a when b == null.
 int mansy_launch_layernorm_fwd(const float* a, const float* b, const float* w, const float* bias, float* z_out,

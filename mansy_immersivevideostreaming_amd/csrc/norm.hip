@@ -139,97 +139,85 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 }
 
 // Vectorised backward for C % 256 == 0, C <= 1024: float4 per lane, column sums kept in registers.
+// NV = C / 256 float4 per lane and row.  A wave takes RB = 4 rows per iteration and issues all their dy / z loads before
+// touching any (16 KiB in flight per wave): with one row at a time a wave spends two dependent HBM round trips per row.
+template <int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __restrict__ dy, const float* __restrict__ z,
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 const float* __restrict__ w, float* __restrict__ dz,
                                                                 float* __restrict__ dz_drop, MansyDrop drop, float* __restrict__ dw,
                                                                 float* __restrict__ dbias, int rows, int C) {
+  constexpr int RB = 4;
   extern __shared__ float red[];      // [4 waves][2][C]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wave_global = (blockIdx.x * 256 + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * 256) >> 6;
-  const int nv = C >> 8;
   const float dsc = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
   const float invC = 1.f / (float)C;
-  float4 ww[LN_MAXV], adw[LN_MAXV], adb[LN_MAXV];
+  float4 ww[NV], adw[NV], adb[NV];
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     adw[i] = make_float4(0.f, 0.f, 0.f, 0.f); adb[i] = adw[i];
-    ww[i] = i < nv ? *reinterpret_cast<const float4*>(w + (i * 64 + lane) * 4) : adw[i];
+    ww[i] = *reinterpret_cast<const float4*>(w + (i * 64 + lane) * 4);
   }
-  // the next row's dy / z are fetched while this row is reduced and written (a wave walks its rows serially otherwise:
-  // two dependent HBM round trips per row)
-  float4 dn[LN_MAXV], zn[LN_MAXV];
-  float mun = 0.f, rsn = 0.f;
-  if (wave_global < rows) {
-    mun = mean[wave_global]; rsn = rstd[wave_global];
+  for (int row0 = wave_global * RB; row0 < rows; row0 += nwaves * RB) {
+    float4 d[RB][NV], zz[RB][NV];
+    float mu[RB], rs[RB];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      if (i < nv) {
-        const long long off = (long long)wave_global * C + (i * 64 + lane) * 4;
-        dn[i] = *reinterpret_cast<const float4*>(dy + off);
-        zn[i] = *reinterpret_cast<const float4*>(z + off);
+    for (int u = 0; u < RB; ++u) {
+      const int row = min(row0 + u, rows - 1);          // rows past the end re-read the last row; they are not written / summed
+      mu[u] = mean[row]; rs[u] = rstd[row];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const long long off = (long long)row * C + (i * 64 + lane) * 4;
+        d[u][i] = *reinterpret_cast<const float4*>(dy + off);
+        zz[u][i] = *reinterpret_cast<const float4*>(z + off);
       }
     }
-  }
-  for (int row = wave_global; row < rows; row += nwaves) {
-    const long long base = (long long)row * C;
-    const float mu = mun, rs = rsn;
-    float4 d[LN_MAXV], zc[LN_MAXV], xh[LN_MAXV];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) { d[i] = dn[i]; zc[i] = zn[i]; }
-    if (row + nwaves < rows) {
-      mun = mean[row + nwaves]; rsn = rstd[row + nwaves];
+    for (int u = 0; u < RB; ++u) {
+      const bool live = row0 + u < rows;
+      const long long base = (long long)(row0 + u) * C;
+      float4 xh[NV];
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int i = 0; i < LN_MAXV; ++i) {
-        if (i < nv) {
-          const long long off = (long long)(row + nwaves) * C + (i * 64 + lane) * 4;
-          dn[i] = *reinterpret_cast<const float4*>(dy + off);
-          zn[i] = *reinterpret_cast<const float4*>(z + off);
-        }
-      }
-    }
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      if (i < nv) {
-        const float4 zz = zc[i];
-        xh[i] = make_float4((zz.x - mu) * rs, (zz.y - mu) * rs, (zz.z - mu) * rs, (zz.w - mu) * rs);
-        const float gx = d[i].x * ww[i].x, gy = d[i].y * ww[i].y, gz = d[i].z * ww[i].z, gw = d[i].w * ww[i].w;
+      for (int i = 0; i < NV; ++i) {
+        const float4 t = zz[u][i];
+        xh[i] = make_float4((t.x - mu[u]) * rs[u], (t.y - mu[u]) * rs[u], (t.z - mu[u]) * rs[u], (t.w - mu[u]) * rs[u]);
+        const float gx = d[u][i].x * ww[i].x, gy = d[u][i].y * ww[i].y, gz = d[u][i].z * ww[i].z, gw = d[u][i].w * ww[i].w;
         s1 += (gx + gy) + (gz + gw);
         s2 += (gx * xh[i].x + gy * xh[i].y) + (gz * xh[i].z + gw * xh[i].w);
       }
-    }
-    s1 = wave_sum(s1) * invC; s2 = wave_sum(s2) * invC;
+      s1 = wave_sum(s1) * invC; s2 = wave_sum(s2) * invC;
+      if (live) {
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      if (i < nv) {
-        const long long off = base + (i * 64 + lane) * 4;
-        float4 o;
-        o.x = rs * (d[i].x * ww[i].x - s1 - xh[i].x * s2); o.y = rs * (d[i].y * ww[i].y - s1 - xh[i].y * s2);
-        o.z = rs * (d[i].z * ww[i].z - s1 - xh[i].z * s2); o.w = rs * (d[i].w * ww[i].w - s1 - xh[i].w * s2);
-        *reinterpret_cast<float4*>(dz + off) = o;
-        if (dz_drop) {
-          float4 od = o;
-          if (drop.p > 0.f) {
-            od.x = mansy_keep(drop.seed, drop.site, (uint32_t)(off + 0), drop.p) ? o.x * dsc : 0.f;
-            od.y = mansy_keep(drop.seed, drop.site, (uint32_t)(off + 1), drop.p) ? o.y * dsc : 0.f;
-            od.z = mansy_keep(drop.seed, drop.site, (uint32_t)(off + 2), drop.p) ? o.z * dsc : 0.f;
-            od.w = mansy_keep(drop.seed, drop.site, (uint32_t)(off + 3), drop.p) ? o.w * dsc : 0.f;
+        for (int i = 0; i < NV; ++i) {
+          const long long off = base + (i * 64 + lane) * 4;
+          const float4 di = d[u][i];
+          float4 o;
+          o.x = rs[u] * (di.x * ww[i].x - s1 - xh[i].x * s2); o.y = rs[u] * (di.y * ww[i].y - s1 - xh[i].y * s2);
+          o.z = rs[u] * (di.z * ww[i].z - s1 - xh[i].z * s2); o.w = rs[u] * (di.w * ww[i].w - s1 - xh[i].w * s2);
+          *reinterpret_cast<float4*>(dz + off) = o;
+          if (dz_drop) {
+            float4 od = o;
+            if (drop.p > 0.f) {
+              od.x = mansy_keep(drop.seed, drop.site, (uint32_t)(off + 0), drop.p) ? o.x * dsc : 0.f;
+              od.y = mansy_keep(drop.seed, drop.site, (uint32_t)(off + 1), drop.p) ? o.y * dsc : 0.f;
+              od.z = mansy_keep(drop.seed, drop.site, (uint32_t)(off + 2), drop.p) ? o.z * dsc : 0.f;
+              od.w = mansy_keep(drop.seed, drop.site, (uint32_t)(off + 3), drop.p) ? o.w * dsc : 0.f;
+            }
+            *reinterpret_cast<float4*>(dz_drop + off) = od;
           }
-          *reinterpret_cast<float4*>(dz_drop + off) = od;
+          adw[i].x += di.x * xh[i].x; adw[i].y += di.y * xh[i].y; adw[i].z += di.z * xh[i].z; adw[i].w += di.w * xh[i].w;
+          adb[i].x += di.x; adb[i].y += di.y; adb[i].z += di.z; adb[i].w += di.w;
         }
-        adw[i].x += d[i].x * xh[i].x; adw[i].y += d[i].y * xh[i].y; adw[i].z += d[i].z * xh[i].z; adw[i].w += d[i].w * xh[i].w;
-        adb[i].x += d[i].x; adb[i].y += d[i].y; adb[i].z += d[i].z; adb[i].w += d[i].w;
       }
     }
   }
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
-    if (i < nv) {
-      *reinterpret_cast<float4*>(red + (wave * 2 + 0) * C + (i * 64 + lane) * 4) = adw[i];
-      *reinterpret_cast<float4*>(red + (wave * 2 + 1) * C + (i * 64 + lane) * 4) = adb[i];
-    }
+  for (int i = 0; i < NV; ++i) {
+    *reinterpret_cast<float4*>(red + (wave * 2 + 0) * C + (i * 64 + lane) * 4) = adw[i];
+    *reinterpret_cast<float4*>(red + (wave * 2 + 1) * C + (i * 64 + lane) * 4) = adb[i];
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
@@ -370,10 +358,14 @@ int mansy_launch_layernorm_bwd(const float* dy, const float* z, const float* mea
   const int grid = min(mansy_ceil_div(rows, 16), 1024);     // 4 rows per wave: more workgroups only multiply the per-column atomics (measured slower)
   const size_t lds = (size_t)4 * 2 * C * sizeof(float);
   MANSY_REQUIRE(lds <= 64 * 1024, "layernorm_bwd: C=%d too large", C);
-  if ((C % 256) == 0 && C <= 256 * LN_MAXV)
-    hipLaunchKernelGGL(layernorm_bwd_vec_kernel, dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias,
-                       rows, C);
-  else
+  if ((C % 256) == 0 && C <= 256 * LN_MAXV) {
+    switch (C / 256) {
+      case 1: hipLaunchKernelGGL(layernorm_bwd_vec_kernel<1>, dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C); break;
+      case 2: hipLaunchKernelGGL(layernorm_bwd_vec_kernel<2>, dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C); break;
+      case 3: hipLaunchKernelGGL(layernorm_bwd_vec_kernel<3>, dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C); break;
+      default: hipLaunchKernelGGL(layernorm_bwd_vec_kernel<4>, dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C); break;
+    }
+  } else
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias,
                        rows, C);
   MANSY_LAUNCH_CHECK();

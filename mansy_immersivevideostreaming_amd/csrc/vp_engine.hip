@@ -117,6 +117,7 @@ struct EncBuf { float *qkv, *P, *ao, *z1, *m1, *r1, *y1, *h, *z2, *m2, *r2, *y2;
 struct DecBuf {
   float *memkv, *qkv, *P1, *ao1, *z1, *m1, *r1, *y1, *qc, *P2, *ao2, *z2, *m2, *r2, *y2, *h, *z3, *m3, *r3, *y3;
   float *dqkv, *dbr1, *dqc, *dbr2, *da, *dbr3, *dmemkv;   // backward slabs (deferred dW operands)
+  float *dao2, *dS2, *Pk2;                                // deferred cross-attention K/V gradient operands (attn.hip kvgrad)
 };
 struct Work {
   float *src6, *cur6, *fut6, *pred_bt, *dpred_bt;           // train_step staging
@@ -179,6 +180,7 @@ void build_layout(const mansy_vp_config& c, Layout& L, Work& W) {
     e.dqkv = L.f(p + "dqkv", TB * 3 * d); e.dbr1 = L.f(p + "dbr1", TB * d); e.dqc = L.f(p + "dqc", TB * d);
     e.dbr2 = L.f(p + "dbr2", TB * d); e.da = L.f(p + "da", TB * f); e.dbr3 = L.f(p + "dbr3", TB * d);
     e.dmemkv = L.f(p + "dmemkv", B * M * 2 * d);
+    e.dao2 = L.f(p + "dao2", TB * d); e.dS2 = L.f(p + "dS2", TB * H * M); e.Pk2 = L.f(p + "Pk2", TB * H * M);
   }
   W.dec_out = L.f("dec.out", TB * d); W.md = L.f("dec.md", TB); W.rd = L.f("dec.rd", TB);
   W.t_enc = L.f("tmp.t_enc", N * d); W.t_dec = L.f("tmp.t_dec", B * d);
@@ -326,9 +328,13 @@ struct Eng {
   // ------------------------------------------------------------------ backward
   int backward(const float* src, const float* dpred_bt) {
     const float ms = drop_scale;
+    // Cross-attention K/V gradients: every step attends to the same memory rows, so (where the 4-heads-per-wave kernels
+    // apply) the steps only record their coefficients and ONE pass per layer forms dK/dV -- instead of T read-modify-write
+    // passes over the [B*M, 2d] gradient rows.
+    const bool defer_cross = mansy_attn_deferred_kv_ok(cross_shape(), T) != 0;
     for (int l = 0; l < c.n_dec; ++l) {
       MANSY_HIP_CHECK(hipMemsetAsync(W.dec[l].dqkv, 0, sizeof(float) * (size_t)TB * 3 * d, st));
-      MANSY_HIP_CHECK(hipMemsetAsync(W.dec[l].dmemkv, 0, sizeof(float) * (size_t)B * M * 2 * d, st));
+      if (!defer_cross) MANSY_HIP_CHECK(hipMemsetAsync(W.dec[l].dmemkv, 0, sizeof(float) * (size_t)B * M * 2 * d, st));
     }
     const float* pred_tb = W.tok_all + (size_t)B * C6;
     for (int i = T - 1; i >= 0; --i) {
@@ -349,9 +355,16 @@ struct Eng {
         RC(lin_dx(e.da + o * f, B, f, p.lin1.w, d, gt, gz, nullptr, 1.f));                 // gt = d/dy2
         // norm2( y1 + drop(ca_out(ao2)) )
         RC(ln_bwd(gt, e.z2 + o * d, e.m2 + o, e.r2 + o, p.n2, gz, e.dbr2 + o * d, dr(site_dec(l, i, 3), c.p_drop), B));
-        RC(lin_dx(e.dbr2 + o * d, B, d, p.ca_out.w, d, gt, nullptr, nullptr, 1.f));         // gt = d/dao2
-        RC(mansy_launch_attn_bwd(e.qc + o * d, e.memkv, e.memkv + d, e.P2 + o * H * M, gt, e.dqc + o * d, e.dmemkv, e.dmemkv + d,
-                                 cross_shape(), dr(site_dec(l, i, 2), c.p_drop), 1, st));
+        if (defer_cross) {
+          float* dao2_i = e.dao2 + o * d;
+          RC(lin_dx(e.dbr2 + o * d, B, d, p.ca_out.w, d, dao2_i, nullptr, nullptr, 1.f));   // d/dao2, kept for the deferred dV
+          RC(mansy_launch_attn_bwd_dq(e.qc + o * d, e.memkv, e.memkv + d, e.P2 + o * H * M, dao2_i, e.dqc + o * d, e.dS2 + o * H * M,
+                                      e.Pk2 + o * H * M, cross_shape(), dr(site_dec(l, i, 2), c.p_drop), st));
+        } else {
+          RC(lin_dx(e.dbr2 + o * d, B, d, p.ca_out.w, d, gt, nullptr, nullptr, 1.f));       // gt = d/dao2
+          RC(mansy_launch_attn_bwd(e.qc + o * d, e.memkv, e.memkv + d, e.P2 + o * H * M, gt, e.dqc + o * d, e.dmemkv, e.dmemkv + d,
+                                   cross_shape(), dr(site_dec(l, i, 2), c.p_drop), 1, st));
+        }
         RC(lin_dx(e.dqc + o * d, B, d, p.ca_in.w, d, gt, gz, nullptr, 1.f));                // gt = d/dy1
         // norm1( x + drop(sa_out(ao1)) )
         RC(ln_bwd(gt, e.z1 + o * d, e.m1 + o, e.r1 + o, p.n1, gz, e.dbr1 + o * d, dr(site_dec(l, i, 1), c.p_drop), B));
@@ -373,6 +386,8 @@ struct Eng {
       RC(lin_dw(e.dqkv, x_all, TB, 3 * d, d, p.sa_in.gw, p.sa_in.gb));
       RC(lin_dw(e.dbr1, e.ao1, TB, d, d, p.sa_out.gw, p.sa_out.gb));
       RC(lin_dw(e.dqc, e.y1, TB, d, d, p.ca_in.gw, p.ca_in.gb));
+      if (defer_cross)
+        RC(mansy_launch_attn_kvgrad(e.qc, (long long)B * d, e.dao2, (long long)B * d, e.dS2, e.Pk2, e.dmemkv, e.dmemkv + d, cross_shape(), T, 0, st));
       RC(lin_dw(e.dmemkv, W.mem, B * M, 2 * d, d, p.ca_in.gw + (size_t)d * d, p.ca_in.gb ? p.ca_in.gb + d : nullptr));
       RC(lin_dw(e.dbr2, e.ao2, TB, d, d, p.ca_out.gw, p.ca_out.gb));
       RC(lin_dw(e.da, e.y2, TB, f, d, p.lin1.gw, p.lin1.gb));
