@@ -209,6 +209,23 @@ int mansy_layernorm_bwd(const float* dy, const float* z, const float* mean, cons
                         float* dz_drop, float drop_p, uint32_t seed, uint32_t site, float* dw, float* dbias, int rows,
                         int C, void* stream);
 
+/* Engine forms of the two kernels above (same arithmetic, restructured traffic), exposed for the parity tests:
+ *  - LayerNorm backward with per-workgroup partial weight-gradient sums: partials[mansy_layernorm_bwd_parts(rows)][2][C]
+ *    (overwritten, or added to when accumulate != 0); mansy_ln_partials_reduce adds them into dw / dbias (either may be null).
+ *  - Lq == 1 attention backward with deferred K/V gradients: per step mansy_attn_bwd_dq writes dQ and the step's
+ *    coefficients dS_out / Pk_out [nb*H, Lk]; mansy_attn_kvgrad forms dK[j] = sum_i dS_i[j] q_i, dV[j] = sum_i Pk_i[j] dO_i
+ *    from the T steps (Q_all / dO_all: step i at + i*q_ts / + i*o_ts floats; dS_all / Pk_all: [T][nb*H][Lk]). */
+int mansy_layernorm_bwd_parts(int rows);
+int mansy_layernorm_bwd_partial(const float* dy, const float* z, const float* mean, const float* rstd, const float* w, float* dz,
+                                float* dz_drop, float drop_p, uint32_t seed, uint32_t site, float* partials, int accumulate,
+                                int rows, int C, void* stream);
+int mansy_ln_partials_reduce(const float* partials, int nparts, int C, float* dw, float* dbias, void* stream);
+int mansy_attn_bwd_dq(const float* Q, const float* K, const float* V, const float* P_save, const float* dO, float* dQ,
+                      float* dS_out, float* Pk_out, const mansy_attn_shape* s, float drop_p, uint32_t seed, uint32_t site,
+                      void* stream);
+int mansy_attn_kvgrad(const float* Q_all, long long q_ts, const float* dO_all, long long o_ts, const float* dS_all,
+                      const float* Pk_all, float* dK, float* dV, const mansy_attn_shape* s, int T, int accum, void* stream);
+
 /* ------------------------------------------------------------------ measurement hooks (bench.py) */
 /* HIP events around every GEMM launch on its own stream; collect() = device sync + summed ms, count, FLOPs. */
 int mansy_prof_gemm_enable(int on);

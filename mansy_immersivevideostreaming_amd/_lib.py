@@ -74,6 +74,11 @@ _PROTOS = {
     'mansy_attn_bwd': [P, P, P, P, P, P, P, P, P, c_float, c_u32, c_u32, c_int, P],
     'mansy_layernorm_fwd': [P, P, P, P, P, P, P, P, c_int, c_int, c_float, P],
     'mansy_layernorm_bwd': [P, P, P, P, P, P, P, c_float, c_u32, c_u32, P, P, c_int, c_int, P],
+    'mansy_layernorm_bwd_parts': [c_int],
+    'mansy_layernorm_bwd_partial': [P, P, P, P, P, P, P, c_float, c_u32, c_u32, P, c_int, c_int, c_int, P],
+    'mansy_ln_partials_reduce': [P, c_int, c_int, P, P, P],
+    'mansy_attn_bwd_dq': [P, P, P, P, P, P, P, P, P, c_float, c_u32, c_u32, P],
+    'mansy_attn_kvgrad': [P, c_ll, P, c_ll, P, P, P, P, P, c_int, c_int, P],
     'mansy_env_state_bytes': [],
     'mansy_env_init': [P, c_int, c_int, c_int, c_int, P],
     'mansy_env_reset': [P, P, c_int, P, P],

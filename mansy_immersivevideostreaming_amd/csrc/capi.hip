@@ -72,6 +72,29 @@ int mansy_layernorm_bwd(const float* dy, const float* z, const float* mean, cons
   return mansy_launch_layernorm_bwd(dy, z, mean, rstd, w, dz, dz_drop, d, dw, dbias, rows, C, (hipStream_t)stream);
 }
 
+int mansy_layernorm_bwd_parts(int rows) { return mansy_ln_bwd_parts(rows); }
+int mansy_layernorm_bwd_partial(const float* dy, const float* z, const float* mean, const float* rstd, const float* w, float* dz,
+                                float* dz_drop, float drop_p, uint32_t seed, uint32_t site, float* partials, int accumulate,
+                                int rows, int C, void* stream) {
+  MansyDrop d = {drop_p, seed, site};
+  return mansy_launch_layernorm_bwd_partial(dy, z, mean, rstd, w, dz, dz_drop, d, partials, accumulate, rows, C, (hipStream_t)stream);
+}
+int mansy_ln_partials_reduce(const float* partials, int nparts, int C, float* dw, float* dbias, void* stream) {
+  return mansy_launch_ln_partials_reduce(partials, nparts, C, dw, dbias, (hipStream_t)stream);
+}
+int mansy_attn_bwd_dq(const float* Q, const float* K, const float* V, const float* P_save, const float* dO, float* dQ,
+                      float* dS_out, float* Pk_out, const mansy_attn_shape* s, float drop_p, uint32_t seed, uint32_t site,
+                      void* stream) {
+  MANSY_REQUIRE(s, "attn_bwd_dq: null shape");
+  MansyDrop d = {drop_p, seed, site};
+  return mansy_launch_attn_bwd_dq(Q, K, V, P_save, dO, dQ, dS_out, Pk_out, to_shape(s), d, (hipStream_t)stream);
+}
+int mansy_attn_kvgrad(const float* Q_all, long long q_ts, const float* dO_all, long long o_ts, const float* dS_all,
+                      const float* Pk_all, float* dK, float* dV, const mansy_attn_shape* s, int T, int accum, void* stream) {
+  MANSY_REQUIRE(s, "attn_kvgrad: null shape");
+  return mansy_launch_attn_kvgrad(Q_all, q_ts, dO_all, o_ts, dS_all, Pk_all, dK, dV, to_shape(s), T, accum, (hipStream_t)stream);
+}
+
 int mansy_mtio_mix(const float* x, const int* perm1, const int* perm2, float* out, int B, int L, int c, void* stream) {
   return mansy_launch_mtio_mix(x, perm1, perm2, out, B, L, c, (hipStream_t)stream);
 }

@@ -49,6 +49,50 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict_
   else out[idx] = acc[0];
 }
 
+// Many-row form (encoder: rows = B*S): a thread keeps its 4 channels' weights / bias in registers and walks rows, so a
+// row costs it the in_ch input loads (one cache line for the whole row), one positional float4 and one store -- the
+// per-element form above re-loads the 4 x in_ch weights for every output (35 load instructions per 4 outputs).
+// Needs C % 4 == 0 and (C/4) dividing 256; grid.x workgroups take contiguous row ranges.
+template <int NS>
+__global__ __launch_bounds__(256) void embed_fwd_rows_kernel(const float* __restrict__ x, int in_ch, const float* __restrict__ W,
+                                                             const float* __restrict__ b, const float* __restrict__ pe,
+                                                             float* __restrict__ out, int rows, int C, int S, int pos_fixed,
+                                                             MansyDrop drop, int rows_per_wg) {
+  constexpr int NK = small_bound<NS>();
+  const int C4 = C >> 2, rpi = 256 / C4;                 // rows per iteration of the workgroup
+  const int c = (threadIdx.x % C4) * 4, rsub = threadIdx.x / C4;
+  float wv[4][NK], bv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    bv[j] = b ? b[c + j] : 0.f;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) wv[j][k] = W[(c + j) * in_ch + small_idx<NS>(k, in_ch)] * small_on<NS>(k, in_ch);
+  }
+  const float dsc = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
+  const int r_begin = blockIdx.x * rows_per_wg, r_end = min(rows, r_begin + rows_per_wg);
+  for (int r = r_begin + rsub; r < r_end; r += rpi) {
+    const int pos = pos_fixed >= 0 ? pos_fixed : (r % S);
+    float xin[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) xin[k] = x[(long long)r * in_ch + small_idx<NS>(k, in_ch)];
+    const float4 pv = *reinterpret_cast<const float4*>(pe + (long long)pos * C + c);
+    const float pev[4] = {pv.x, pv.y, pv.z, pv.w};
+    const long long idx = (long long)r * C + c;
+    float acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < NK; ++k) a = fmaf(xin[k], wv[j][k], a);
+      a += bv[j];
+      a += pev[j];
+      if (drop.p > 0.f) a = mansy_keep(drop.seed, drop.site, (uint32_t)(idx + j), drop.p) ? a * dsc : 0.f;
+      acc[j] = a;
+    }
+    *reinterpret_cast<float4*>(out + idx) = *reinterpret_cast<const float4*>(acc);
+  }
+}
+
 // one wave per row: dE = dX*mask ; dtok[r,k] = sum_c dE[r,c] W[c,k]
 template <int V, int NS>
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dX, const float* __restrict__ W,
@@ -74,10 +118,12 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
       if (V == 4) *reinterpret_cast<float4*>(dE + idx) = *reinterpret_cast<const float4*>(g);
       else dE[idx] = g[0];
     }
+    if (dtok) {      // (the encoder side has no token gradient: the pass is then a masked copy)
 #pragma unroll
-    for (int j = 0; j < V; ++j)
+      for (int j = 0; j < V; ++j)
 #pragma unroll
-      for (int k = 0; k < NK; ++k) acc[k] = fmaf(g[j], W[(c + j) * in_ch + small_idx<NS>(k, in_ch)], acc[k]);
+        for (int k = 0; k < NK; ++k) acc[k] = fmaf(g[j], W[(c + j) * in_ch + small_idx<NS>(k, in_ch)], acc[k]);
+    }
   }
   if (dtok) {
 #pragma unroll
@@ -443,8 +489,17 @@ int mansy_launch_embed_fwd(const float* x, int in_ch, const float* W, const floa
   MANSY_REQUIRE(x && W && pe && out, "embed_fwd: null pointer");
   MANSY_REQUIRE(in_ch >= 1 && in_ch <= MAX_IN, "embed_fwd: in_ch %d unsupported", in_ch);
   if (rows <= 0) return MANSY_OK;
-  MANSY_SMALL_DISPATCH(embed_fwd_kernel, C % 4 == 0 && al16(pe) && al16(out), in_ch, g1((long long)rows * C / 4), g1((long long)rows * C),
-                       x, in_ch, W, b, pe, out, rows, C, S, pos_fixed, drop);
+  const bool vec = C % 4 == 0 && al16(pe) && al16(out);
+  if (vec && rows >= 8192 && 256 % (C / 4) == 0) {
+    const int rpw = 8 * (256 / (C / 4));                 // 8 iterations per workgroup
+    const dim3 grid(mansy_ceil_div(rows, rpw));
+    if (in_ch == 2) hipLaunchKernelGGL(embed_fwd_rows_kernel<2>, grid, dim3(256), 0, st, x, in_ch, W, b, pe, out, rows, C, S, pos_fixed, drop, rpw);
+    else if (in_ch == 6) hipLaunchKernelGGL(embed_fwd_rows_kernel<6>, grid, dim3(256), 0, st, x, in_ch, W, b, pe, out, rows, C, S, pos_fixed, drop, rpw);
+    else hipLaunchKernelGGL(embed_fwd_rows_kernel<0>, grid, dim3(256), 0, st, x, in_ch, W, b, pe, out, rows, C, S, pos_fixed, drop, rpw);
+  } else {
+    MANSY_SMALL_DISPATCH(embed_fwd_kernel, vec, in_ch, g1((long long)rows * C / 4), g1((long long)rows * C),
+                         x, in_ch, W, b, pe, out, rows, C, S, pos_fixed, drop);
+  }
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }

@@ -68,6 +68,16 @@ int mansy_launch_layernorm_bwd(const float* dy, const float* z, const float* mea
                                float* dz, float* dz_drop, MansyDrop drop, float* dw, float* dbias, int rows, int C,
                                hipStream_t st);
 
+// Engine form of the LayerNorm backward: weight-gradient column sums go to per-workgroup slots
+// partials[mansy_ln_bwd_parts(rows)][2][C] (overwritten, or added to when accumulate != 0) instead of atomics on
+// dw/dbias; mansy_launch_ln_partials_reduce then adds the slots into dw / dbias (either may be null).
+int mansy_ln_bwd_parts(int rows);
+bool mansy_ln_bwd_partial_ok(int C);
+int mansy_launch_layernorm_bwd_partial(const float* dy, const float* z, const float* mean, const float* rstd, const float* w,
+                                       float* dz, float* dz_drop, MansyDrop drop, float* partials, int accumulate, int rows, int C,
+                                       hipStream_t st);
+int mansy_launch_ln_partials_reduce(const float* partials, int nparts, int C, float* dw, float* dbias, hipStream_t st);
+
 // BatchNorm1d(train) + ELU + MaxPool1d(3,2,1) of the DistillLayer on conv output [B*S, C].
 struct DistillShape { int B, S, M, C; int sync_world = 1; };
 // Invokes the registered data-parallel hook (capi.hip: mansy_set_bn_sync_hook); which = 0 forward stats, 1 backward stats.

@@ -141,13 +141,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 // Vectorised backward for C % 256 == 0, C <= 1024: float4 per lane, column sums kept in registers.
 // NV = C / 256 float4 per lane and row.  A wave takes RB = 4 rows per iteration and issues all their dy / z loads before
 // touching any (16 KiB in flight per wave): with one row at a time a wave spends two dependent HBM round trips per row.
-template <int NV>
+// PART: the workgroup's column sums go to its own slot of `dw` = partials[gridDim.x][2][C] (stored, or added when
+// dbias != nullptr is used as the "accumulate" flag) instead of gridDim.x-way contended atomics on the C weight-gradient
+// addresses -- those serialise in L2 and were half of the kernel's time on [4096, 512] inputs.
+template <int NV, bool PART, int RB>
 __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __restrict__ dy, const float* __restrict__ z,
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 const float* __restrict__ w, float* __restrict__ dz,
                                                                 float* __restrict__ dz_drop, MansyDrop drop, float* __restrict__ dw,
                                                                 float* __restrict__ dbias, int rows, int C) {
-  constexpr int RB = 4;
   extern __shared__ float red[];      // [4 waves][2][C]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wave_global = (blockIdx.x * 256 + threadIdx.x) >> 6;
@@ -224,9 +226,39 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
     float a0 = 0.f, a1 = 0.f;
 #pragma unroll
     for (int wv = 0; wv < 4; ++wv) { a0 += red[(wv * 2 + 0) * C + c]; a1 += red[(wv * 2 + 1) * C + c]; }
-    if (dw) atomicAdd(dw + c, a0);
-    if (dbias) atomicAdd(dbias + c, a1);
+    if (PART) {
+      float* slot = dw + (size_t)blockIdx.x * 2 * C;
+      if (dbias) { a0 += slot[c]; a1 += slot[C + c]; }
+      slot[c] = a0; slot[C + c] = a1;
+    } else {
+      if (dw) atomicAdd(dw + c, a0);
+      if (dbias) atomicAdd(dbias + c, a1);
+    }
   }
+}
+
+// dw[c] += sum_p partials[p][0][c], dbias[c] += sum_p partials[p][1][c]; grid (ceil(C/64), 2, ceil(nparts/64)): a workgroup
+// sums 64 slots x 64 columns (4 slot-groups of 16, all 16 loads of a thread in flight) and adds its share atomically.
+__global__ __launch_bounds__(256) void ln_partials_reduce_kernel(const float* __restrict__ partials, int nparts, int C,
+                                                                 float* __restrict__ dw, float* __restrict__ dbias) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane, which = blockIdx.y;
+  float* dst = which == 0 ? dw : dbias;
+  if (!dst) return;
+  float acc = 0.f;
+  if (c < C) {
+    const float* src = partials + (size_t)which * C + c;
+    const int p0 = blockIdx.z * 64 + grp * 16;
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = src[(size_t)min(p0 + u, nparts - 1) * 2 * C];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc += p0 + u < nparts ? v[u] : 0.f;
+  }
+  red[grp][lane] = acc;
+  __syncthreads();
+  if (grp == 0 && c < C) atomicAdd(dst + c, (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
 }
 
 // ------------------------------------------------------------------ DistillLayer tail
@@ -360,10 +392,10 @@ int mansy_launch_layernorm_bwd(const float* dy, const float* z, const float* mea
   MANSY_REQUIRE(lds <= 64 * 1024, "layernorm_bwd: C=%d too large", C);
   if ((C % 256) == 0 && C <= 256 * LN_MAXV) {
     switch (C / 256) {
-      case 1: hipLaunchKernelGGL(layernorm_bwd_vec_kernel<1>, dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C); break;
-      case 2: hipLaunchKernelGGL(layernorm_bwd_vec_kernel<2>, dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C); break;
-      case 3: hipLaunchKernelGGL(layernorm_bwd_vec_kernel<3>, dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C); break;
-      default: hipLaunchKernelGGL(layernorm_bwd_vec_kernel<4>, dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C); break;
+      case 1: hipLaunchKernelGGL((layernorm_bwd_vec_kernel<1, false, 4>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C); break;
+      case 2: hipLaunchKernelGGL((layernorm_bwd_vec_kernel<2, false, 4>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C); break;
+      case 3: hipLaunchKernelGGL((layernorm_bwd_vec_kernel<3, false, 4>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C); break;
+      default: hipLaunchKernelGGL((layernorm_bwd_vec_kernel<4, false, 4>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C); break;
     }
   } else
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias,
@@ -410,6 +442,36 @@ int mansy_launch_distill_bwd(const float* conv, const float* dmem, const unsigne
   const long long total = (long long)rows * s.C;
   hipLaunchKernelGGL(distill_bwd_stage2, dim3(mansy_ceil_div(total, 256)), dim3(256), 0, st, conv, g_tmp, bn_w, mean, rstd, stats_d,
                      dconv, dbn_w, dbn_b, s);
+  MANSY_LAUNCH_CHECK();
+  return MANSY_OK;
+}
+
+// ---- LayerNorm backward with per-workgroup partial weight-gradient sums (no atomics): the engine's form.
+int mansy_ln_bwd_parts(int rows) { return min(mansy_ceil_div(rows, 16), 1024); }
+bool mansy_ln_bwd_partial_ok(int C) { return (C % 256) == 0 && C <= 256 * LN_MAXV; }
+// partials: [mansy_ln_bwd_parts(rows)][2][C]; accumulate != 0 adds to what the slots hold (decoder: one LayerNorm
+// applied at T steps), else the slots are overwritten.
+int mansy_launch_layernorm_bwd_partial(const float* dy, const float* z, const float* mean, const float* rstd, const float* w,
+                                       float* dz, float* dz_drop, MansyDrop drop, float* partials, int accumulate, int rows, int C,
+                                       hipStream_t st) {
+  MANSY_REQUIRE(dy && z && mean && rstd && w && dz && partials, "layernorm_bwd_partial: null pointer");
+  MANSY_REQUIRE(mansy_ln_bwd_partial_ok(C), "layernorm_bwd_partial: C=%d unsupported", C);
+  if (rows <= 0) return MANSY_OK;
+  const int grid = mansy_ln_bwd_parts(rows);
+  const size_t lds = (size_t)4 * 2 * C * sizeof(float);
+  float* flag = accumulate ? partials : nullptr;      // the kernel only tests it for null
+#define LNB(NV, RBV) hipLaunchKernelGGL((layernorm_bwd_vec_kernel<NV, true, RBV>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, partials, flag, rows, C)
+  if (C / 256 == 2) LNB(2, 4);
+  else if (C / 256 == 1) LNB(1, 4);
+  else if (C / 256 == 3) LNB(3, 4);
+  else LNB(4, 4);
+#undef LNB
+  MANSY_LAUNCH_CHECK();
+  return MANSY_OK;
+}
+int mansy_launch_ln_partials_reduce(const float* partials, int nparts, int C, float* dw, float* dbias, hipStream_t st) {
+  MANSY_REQUIRE(partials && nparts >= 1, "ln_partials_reduce: bad arguments");
+  hipLaunchKernelGGL(ln_partials_reduce_kernel, dim3(mansy_ceil_div(C, 64), 2, mansy_ceil_div(nparts, 64)), dim3(256), 0, st, partials, nparts, C, dw, dbias);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }

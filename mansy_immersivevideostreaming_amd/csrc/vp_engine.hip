@@ -128,6 +128,7 @@ struct Work {
   float *g_a, *g_b, *g_c, *g_wide, *g_ff;                   // encoder backward temporaries [N, .]
   float *s_a, *s_b, *s_c, *s_tok;                           // decoder step backward temporaries [B, .]
   float *dE_all, *dz_all, *dmem;
+  float *lnp_dec, *lnp_enc;                                 // LayerNorm weight-gradient partial sums (norm.hip)
   double* loss_acc;
 };
 struct BufInfo { std::string name; size_t off; size_t bytes; };
@@ -189,6 +190,9 @@ void build_layout(const mansy_vp_config& c, Layout& L, Work& W) {
   W.s_a = L.f("tmp.s_a", B * d); W.s_b = L.f("tmp.s_b", B * d); W.s_c = L.f("tmp.s_c", B * d);
   W.s_tok = L.f("tmp.s_tok", B * C6);
   W.dE_all = L.f("dec.dE", TB * d); W.dz_all = L.f("dec.dz", TB * C6); W.dmem = L.f("dmem", B * M * d);
+  // decoder: one slot set per LayerNorm (3 per layer + the final norm), accumulated over the T steps; encoder: one scratch set
+  W.lnp_dec = L.f("lnp.dec", (size_t)(3 * c.n_dec + 1) * mansy_ln_bwd_parts((int)B) * 2 * d);
+  W.lnp_enc = L.f("lnp.enc", (size_t)mansy_ln_bwd_parts((int)N) * 2 * d);
   W.loss_acc = (double*)L.add("loss_acc", 64);
 }
 
@@ -242,9 +246,17 @@ struct Eng {
   int ln_fwd(const float* a, const float* b, const NormP& n, float* z, float* y, float* m, float* r, int rows) {
     return mansy_launch_layernorm_fwd(a, b, n.w, n.b, z, y, m, r, rows, d, c.ln_eps, st);
   }
+  // part_slot < 0: encoder LayerNorm (applied once): partial sums into the scratch set, reduced into the gradient right away.
+  // part_slot >= 0: decoder LayerNorm #part_slot (applied at every step): accumulate into its slot set, reduced after the loop.
   int ln_bwd(const float* dy, const float* z, const float* m, const float* r, const NormP& n, float* dz, float* dz_drop,
-             MansyDrop drop, int rows) {
-    return mansy_launch_layernorm_bwd(dy, z, m, r, n.w, dz, dz_drop, drop, n.gw, n.gb, rows, d, st);
+             MansyDrop drop, int rows, int part_slot = -1) {
+    if (!mansy_ln_bwd_partial_ok(d)) return mansy_launch_layernorm_bwd(dy, z, m, r, n.w, dz, dz_drop, drop, n.gw, n.gb, rows, d, st);
+    if (part_slot < 0) {
+      RC(mansy_launch_layernorm_bwd_partial(dy, z, m, r, n.w, dz, dz_drop, drop, W.lnp_enc, 0, rows, d, st));
+      return mansy_launch_ln_partials_reduce(W.lnp_enc, mansy_ln_bwd_parts(rows), d, n.gw, n.gb, st);
+    }
+    float* slots = W.lnp_dec + (size_t)part_slot * mansy_ln_bwd_parts(B) * 2 * d;
+    return mansy_launch_layernorm_bwd_partial(dy, z, m, r, n.w, dz, dz_drop, drop, slots, 1, rows, d, st);
   }
 
   AttnShape enc_shape() const {
@@ -336,6 +348,9 @@ struct Eng {
       MANSY_HIP_CHECK(hipMemsetAsync(W.dec[l].dqkv, 0, sizeof(float) * (size_t)TB * 3 * d, st));
       if (!defer_cross) MANSY_HIP_CHECK(hipMemsetAsync(W.dec[l].dmemkv, 0, sizeof(float) * (size_t)B * M * 2 * d, st));
     }
+    const bool ln_parts = mansy_ln_bwd_partial_ok(d);
+    const size_t lnp_set = (size_t)mansy_ln_bwd_parts(B) * 2 * d;
+    if (ln_parts) MANSY_HIP_CHECK(hipMemsetAsync(W.lnp_dec, 0, sizeof(float) * (size_t)(3 * c.n_dec + 1) * lnp_set, st));
     const float* pred_tb = W.tok_all + (size_t)B * C6;
     for (int i = T - 1; i >= 0; --i) {
       const size_t o = (size_t)i * B;
@@ -343,18 +358,18 @@ struct Eng {
       RC(mansy_launch_predictor_bwd(dpred_bt + (size_t)i * C6, (long long)T * C6, i < T - 1 ? W.s_tok : nullptr, C6,
                                     pred_tb + o * C6, C6, P.pred.w, W.dz_all + o * C6, W.s_a, B, d, C6, st));
       const float* last_y = W.dec[c.n_dec - 1].y3 + o * d;
-      RC(ln_bwd(W.s_a, last_y, W.md + o, W.rd + o, P.dec_norm, W.s_b, nullptr, mansy_no_drop(), B));
+      RC(ln_bwd(W.s_a, last_y, W.md + o, W.rd + o, P.dec_norm, W.s_b, nullptr, mansy_no_drop(), B, 3 * c.n_dec));
       float* gx = W.s_b;     // gradient wrt the current layer's output
       float* gz = W.s_a;     // scratch for residual-path gradients
       float* gt = W.s_c;
       for (int l = c.n_dec - 1; l >= 0; --l) {
         const DecLayerP& p = P.dec[l]; DecBuf& e = W.dec[l];
         // norm3( y2 + drop(lin2(h)) )
-        RC(ln_bwd(gx, e.z3 + o * d, e.m3 + o, e.r3 + o, p.n3, gz, e.dbr3 + o * d, dr(site_dec(l, i, 5), c.p_drop), B));
+        RC(ln_bwd(gx, e.z3 + o * d, e.m3 + o, e.r3 + o, p.n3, gz, e.dbr3 + o * d, dr(site_dec(l, i, 5), c.p_drop), B, 3 * l + 2));
         RC(lin_dx(e.dbr3 + o * d, B, d, p.lin2.w, f, e.da + o * f, nullptr, e.h + o * f, ms));
         RC(lin_dx(e.da + o * f, B, f, p.lin1.w, d, gt, gz, nullptr, 1.f));                 // gt = d/dy2
         // norm2( y1 + drop(ca_out(ao2)) )
-        RC(ln_bwd(gt, e.z2 + o * d, e.m2 + o, e.r2 + o, p.n2, gz, e.dbr2 + o * d, dr(site_dec(l, i, 3), c.p_drop), B));
+        RC(ln_bwd(gt, e.z2 + o * d, e.m2 + o, e.r2 + o, p.n2, gz, e.dbr2 + o * d, dr(site_dec(l, i, 3), c.p_drop), B, 3 * l + 1));
         if (defer_cross) {
           float* dao2_i = e.dao2 + o * d;
           RC(lin_dx(e.dbr2 + o * d, B, d, p.ca_out.w, d, dao2_i, nullptr, nullptr, 1.f));   // d/dao2, kept for the deferred dV
@@ -367,7 +382,7 @@ struct Eng {
         }
         RC(lin_dx(e.dqc + o * d, B, d, p.ca_in.w, d, gt, gz, nullptr, 1.f));                // gt = d/dy1
         // norm1( x + drop(sa_out(ao1)) )
-        RC(ln_bwd(gt, e.z1 + o * d, e.m1 + o, e.r1 + o, p.n1, gz, e.dbr1 + o * d, dr(site_dec(l, i, 1), c.p_drop), B));
+        RC(ln_bwd(gt, e.z1 + o * d, e.m1 + o, e.r1 + o, p.n1, gz, e.dbr1 + o * d, dr(site_dec(l, i, 1), c.p_drop), B, 3 * l + 0));
         RC(lin_dx(e.dbr1 + o * d, B, d, p.sa_out.w, d, gt, nullptr, nullptr, 1.f));         // gt = d/dao1
         float* dqkv_i = e.dqkv + o * 3 * d;
         RC(mansy_launch_attn_bwd(e.qkv + o * 3 * d, e.qkv + d, e.qkv + 2 * d, e.P1 + o * H * T, gt, dqkv_i, e.dqkv + d, e.dqkv + 2 * d,
@@ -376,6 +391,15 @@ struct Eng {
       }
       // embedding of the fed-back token: dE slab (masked) + gradient wrt pred_{i-1}
       RC(mansy_launch_embed_bwd(gx, P.emb.w, W.dE_all + o * d, W.s_tok, C6, B, d, dr(site_pe_tgt(i), c.p_pe), st));
+    }
+    if (ln_parts) {   // decoder LayerNorm weight gradients: slot sets -> gradients
+      const int np = mansy_ln_bwd_parts(B);
+      for (int l = 0; l < c.n_dec; ++l) {
+        RC(mansy_launch_ln_partials_reduce(W.lnp_dec + (size_t)(3 * l + 0) * lnp_set, np, d, P.dec[l].n1.gw, P.dec[l].n1.gb, st));
+        RC(mansy_launch_ln_partials_reduce(W.lnp_dec + (size_t)(3 * l + 1) * lnp_set, np, d, P.dec[l].n2.gw, P.dec[l].n2.gb, st));
+        RC(mansy_launch_ln_partials_reduce(W.lnp_dec + (size_t)(3 * l + 2) * lnp_set, np, d, P.dec[l].n3.gw, P.dec[l].n3.gb, st));
+      }
+      RC(mansy_launch_ln_partials_reduce(W.lnp_dec + (size_t)(3 * c.n_dec) * lnp_set, np, d, P.dec_norm.gw, P.dec_norm.gb, st));
     }
     // ---- deferred decoder weight gradients: one reduce-dim-(T*B) GEMM per weight
     RC(mansy_launch_outer_reduce(W.dz_all, C6, W.dec_out, TB, d, P.pred.gw, 0, nullptr, P.pred.gb, st));

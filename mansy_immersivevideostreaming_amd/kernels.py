@@ -105,6 +105,67 @@ def layernorm_bwd(dy, z, mean, rstd, w, drop=None, want_bias=True):
     return dz, dz_drop, dw, db
 
 
+def layernorm_bwd_partial(dy, z, mean, rstd, w, drop=None, partials=None, accumulate=False):
+    """Engine form: weight-gradient column sums into per-workgroup slots; returns (dz, dz_drop, partials [parts, 2, C])."""
+    _gpu(dy, z, w)
+    rows, C = dy.shape
+    dz = torch.empty_like(dy)
+    dz_drop = torch.empty_like(dy)
+    parts = lib().mansy_layernorm_bwd_parts(rows)
+    if partials is None:
+        partials = torch.zeros(parts, 2, C, dtype=torch.float32, device=dy.device)
+    p, seed, site = drop if drop is not None else (0.0, 0, 0)
+    check(lib().mansy_layernorm_bwd_partial(ptr(dy), ptr(z), ptr(mean), ptr(rstd), ptr(w), ptr(dz), ptr(dz_drop), p, seed, site,
+                                            ptr(partials), int(accumulate), rows, C, stream_ptr(dy.device)), 'mansy_layernorm_bwd_partial')
+    return dz, dz_drop, partials
+
+
+def ln_partials_reduce(partials, dw, db):
+    parts, _, C = partials.shape
+    check(lib().mansy_ln_partials_reduce(ptr(partials), parts, C, ptr(dw), ptr(db), stream_ptr(partials.device)), 'mansy_ln_partials_reduce')
+    return dw, db
+
+
+def attn_cross_deferred(q_all, memkv, P_all, dO_all, H, drop_sites=None, p_drop=0.0, seed=0):
+    """Decoder cross-attention backward the engine's way: q_all / dO_all [T, B, d], memkv [B, M, 2d] (K | V), P_all [T, B*H, M].
+    Returns (dq_all [T, B, d], dmemkv [B, M, 2d])."""
+    _gpu(q_all, memkv, P_all, dO_all)
+    T, B, d = q_all.shape
+    M = memkv.shape[1]
+    s = _attn_shape(B, H, 1, M, d // H, (d, 0), (M * 2 * d, 2 * d), (M * 2 * d, 2 * d), (d, 0))
+    dq = torch.empty_like(q_all)
+    dS = torch.empty(T, B * H, M, dtype=torch.float32, device=q_all.device)
+    Pk = torch.empty_like(dS)
+    dkv = torch.empty_like(memkv)
+    kb = memkv.data_ptr()
+    st = stream_ptr(q_all.device)
+    for i in range(T):
+        site = drop_sites[i] if drop_sites is not None else 0
+        check(lib().mansy_attn_bwd_dq(ptr(q_all[i]), kb, kb + 4 * d, ptr(P_all[i]), ptr(dO_all[i]), ptr(dq[i]), ptr(dS[i]), ptr(Pk[i]),
+                                      ctypes.byref(s), p_drop, seed, site, st), 'mansy_attn_bwd_dq')
+    gb = dkv.data_ptr()
+    check(lib().mansy_attn_kvgrad(ptr(q_all), B * d, ptr(dO_all), B * d, ptr(dS), ptr(Pk), gb, gb + 4 * d, ctypes.byref(s), T, 0, st),
+          'mansy_attn_kvgrad')
+    return dq, dkv
+
+
+def attn_cross_stepwise(q_all, memkv, P_all, dO_all, H, drop_sites=None, p_drop=0.0, seed=0):
+    """Same gradients through T accumulating mansy_attn_bwd calls (the read-modify-write form)."""
+    _gpu(q_all, memkv, P_all, dO_all)
+    T, B, d = q_all.shape
+    M = memkv.shape[1]
+    s = _attn_shape(B, H, 1, M, d // H, (d, 0), (M * 2 * d, 2 * d), (M * 2 * d, 2 * d), (d, 0))
+    dq = torch.empty_like(q_all)
+    dkv = torch.zeros_like(memkv)
+    kb, gb = memkv.data_ptr(), dkv.data_ptr()
+    st = stream_ptr(q_all.device)
+    for i in range(T):
+        site = drop_sites[i] if drop_sites is not None else 0
+        check(lib().mansy_attn_bwd(ptr(q_all[i]), kb, kb + 4 * d, ptr(P_all[i]), ptr(dO_all[i]), ptr(dq[i]), gb, gb + 4 * d,
+                                   ctypes.byref(s), p_drop, seed, site, 1, st), 'mansy_attn_bwd')
+    return dq, dkv
+
+
 def tilemap(xy, W=2560, H=1440, nw=8, nh=8, fov_w=600, fov_h=300):
     """xy [...,2] float32 normalised centres -> uint64 hit maps as int64 tensor [...] (bit row*nw+col)."""
     _gpu(xy)

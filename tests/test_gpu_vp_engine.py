@@ -15,6 +15,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+from oracle import rng as orng  # noqa: E402
 from oracle import vp_oracle as vo  # noqa: E402
 
 GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'golden', 'vp_*.npz')))
@@ -253,6 +254,33 @@ def test_bench_size_properties(MT):
     assert all(np.isfinite(losses)), losses
     assert losses[-1] < losses[0], losses
     assert torch.isfinite(m._flat_g).all() and torch.isfinite(m._flat_p).all()
+
+
+def test_bench_size_encoder_embedding_with_dropout(MT):
+    """The many-row embedding kernel (rows = B*S = 40960) against torch + the shared-hash dropout mask."""
+    import ctypes
+    from mansy_immersivevideostreaming_amd._lib import check, lib, ptr, stream_ptr
+    torch.manual_seed(7)
+    m = MT.ViewportTransformerMTIO(in_channel=2, fut_window=10, d_model=512, dim_feedforward=512, device='cuda').to('cuda')
+    m.train()
+    h, c, _ = (t.cuda() for t in vo.synthetic_trajectories(4096, 10, 10, seed=7))
+    src, cur = torch.cat([h] * 3, -1).contiguous(), torch.cat([c] * 3, -1).reshape(4096, 6).contiguous()
+    B, S, _ = src.shape
+    cfg = m._cfg(B, S)
+    ws = m._workspace(cfg)
+    arr, _ = m._pointers()
+    pe, rm, rv, nbt = m._engine_buffers()
+    pred = torch.empty(B, 10, 6, device='cuda')
+    seed = 99
+    check(lib().mansy_vp_forward(ctypes.byref(cfg), arr, ptr(pe), ptr(rm), ptr(rv), ptr(nbt), ptr(src), ptr(cur), ptr(pred),
+                                 ptr(ws), 1, seed, stream_ptr()), 'fwd')
+    x0 = m.ws_tensor(cfg, 'enc.x0').reshape(B * S, 512)
+    W, b = m.embedding.linear.weight, m.embedding.linear.bias
+    ref = src.reshape(B * S, 6).double() @ W.double().t() + (b.double() if b is not None else 0) + pe.reshape(-1, 512)[:S].double().repeat(B, 1)
+    p = m.dropout_p
+    keep = torch.from_numpy(orng.keep_mask(seed, vo.SITE_PE_SRC, B * S * 512, p)).reshape(B * S, 512).cuda()
+    ref = torch.where(keep, ref / (1 - p), torch.zeros_like(ref))
+    torch.testing.assert_close(x0.double(), ref, rtol=0, atol=2e-6)
 
 
 def test_syncbn_hook_two_identical_ranks_equal_single(MT):
