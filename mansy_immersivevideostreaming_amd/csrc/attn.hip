@@ -266,10 +266,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_q1_kernel(AttnPtrs p, Att
 // ---- Lq == 1, dh == 64, H % 4 == 0: FOUR heads per wave, 16 lanes x float4 per head.  A (batch, 4-head) group is 1 KiB of
 // contiguous q/k/v, so every load/store is a full-width 16-B-per-lane instruction (4x fewer memory instructions and waves
 // than one head per wave) and the score reductions stay inside 16-lane groups (4 shuffle steps).
-__device__ __forceinline__ float group16_sum(float v) {
-  v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
-  return v;
-}
+__device__ __forceinline__ float group16_sum(float v) { return row16_sum(v); }
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) { return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); }
 
 // LKT = compile-time bound on the key rows (>= s.Lk): every K / V / P load of a wave is issued up front, unconditionally
@@ -451,6 +448,166 @@ __global__ __launch_bounds__(64 * WAVES) void attn_kvgrad_q1x4_kernel(const floa
   }
 }
 
+// ---- Lq == Lk == S <= 10, dh == 64, H % 4 == 0 (encoder self-attention): four heads per wave, 16 lanes x float4 per head,
+// every Q / K / V (/ dO) row of the (batch, 4-head) group loaded up front as full 1-KiB wave accesses.  Lane c of a head
+// group owns score column j = c (softmax output, dropout mask, dS); columns are broadcast inside the 16-lane group when
+// a sum over j needs them.  ST = compile-time S bound (rows >= S re-read row S-1 and are masked).
+template <int ST>
+__global__ __launch_bounds__(64 * WAVES) void attn_fwd_sx4_kernel(AttnPtrs p, AttnShape s, MansyDrop drop) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int hg = s.H >> 2;
+  const long long g = (long long)blockIdx.x * WAVES + wave;
+  if (g >= (long long)s.nb * hg) return;
+  const int b = (int)(g / hg), h = (int)(g % hg) * 4 + (lane >> 4), c = lane & 15, gbase = lane & 48;
+  const long long bh = (long long)b * s.H + h;
+  const int S = s.Lk;
+  const int col = h * 64 + c * 4;
+  const float* Qb = p.Q + b * s.q_bs + col;
+  const float* Kb = p.K + b * s.k_bs + col;
+  const float* Vb = p.V + b * s.v_bs + col;
+  float* Ob = p.O + b * s.o_bs + col;
+  float4 q[ST], k[ST], v[ST];
+#pragma unroll
+  for (int j = 0; j < ST; ++j) {
+    const int jc = min(j, S - 1);
+    q[j] = *reinterpret_cast<const float4*>(Qb + jc * s.q_rs);
+    k[j] = *reinterpret_cast<const float4*>(Kb + jc * s.k_rs);
+    v[j] = *reinterpret_cast<const float4*>(Vb + jc * s.v_rs);
+  }
+  const float ds = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
+#pragma unroll
+  for (int i = 0; i < ST; ++i) {
+    if (i < S) {
+      float sc[ST];
+      float m = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < ST; ++j) {
+        sc[j] = group16_sum(dot4(q[i], k[j])) * s.scale;
+        if (j < S) m = fmaxf(m, sc[j]);
+      }
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < ST; ++j) { sc[j] = j < S ? expf(sc[j] - m) : 0.f; sum += sc[j]; }
+      const float inv = 1.f / sum;
+      float pc = 0.f;                               // this lane's column
+#pragma unroll
+      for (int j = 0; j < ST; ++j) if (c == j) pc = sc[j] * inv;
+      const long long prow = (bh * S + i) * S;
+      if (c < S && p.P) p.P[prow + c] = pc;
+      if (drop.p > 0.f) pc = mansy_keep(drop.seed, drop.site, (uint32_t)(prow + c), drop.p) ? pc * ds : 0.f;
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int j = 0; j < ST; ++j) {
+        const float pv = __shfl(pc, gbase + j, 64);      // 0 for j >= S
+        o.x = fmaf(pv, v[j].x, o.x); o.y = fmaf(pv, v[j].y, o.y); o.z = fmaf(pv, v[j].z, o.z); o.w = fmaf(pv, v[j].w, o.w);
+      }
+      *reinterpret_cast<float4*>(Ob + i * s.o_rs) = o;
+    }
+  }
+}
+
+template <int ST>
+__global__ __launch_bounds__(64 * WAVES) void attn_bwd_sx4_kernel(AttnPtrs p, AttnShape s, MansyDrop drop, int accum_kv) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int hg = s.H >> 2;
+  const long long g = (long long)blockIdx.x * WAVES + wave;
+  if (g >= (long long)s.nb * hg) return;
+  const int b = (int)(g / hg), h = (int)(g % hg) * 4 + (lane >> 4), c = lane & 15, gbase = lane & 48;
+  const long long bh = (long long)b * s.H + h;
+  const int S = s.Lk;
+  const int col = h * 64 + c * 4;
+  const float* Qb = p.Q + b * s.q_bs + col;
+  const float* Kb = p.K + b * s.k_bs + col;
+  const float* Vb = p.V + b * s.v_bs + col;
+  const float* Gb = p.dO + b * s.o_bs + col;
+  float4 k[ST], v[ST], go[ST];
+  float pc[ST];                                     // P[i][c]: this lane's column of every row
+  const int cc = min(c, S - 1);
+#pragma unroll
+  for (int j = 0; j < ST; ++j) {
+    const int jc = min(j, S - 1);
+    k[j] = *reinterpret_cast<const float4*>(Kb + jc * s.k_rs);
+    v[j] = *reinterpret_cast<const float4*>(Vb + jc * s.v_rs);
+    go[j] = *reinterpret_cast<const float4*>(Gb + jc * s.o_rs);
+    pc[j] = p.P[(bh * S + jc) * S + cc];
+  }
+  const float ds = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
+  float dSc[ST], Pdc[ST];                           // dS[i][c], dropped P[i][c]
+  float* dQb = p.dQ + b * s.q_bs + col;
+#pragma unroll
+  for (int i = 0; i < ST; ++i) {
+    dSc[i] = 0.f; Pdc[i] = 0.f;
+    if (i < S) {
+      float dpc = 0.f;
+#pragma unroll
+      for (int j = 0; j < ST; ++j) {
+        const float t = group16_sum(dot4(go[i], v[j]));
+        if (c == j) dpc = t;
+      }
+      float kc = 1.f;
+      if (drop.p > 0.f) kc = mansy_keep(drop.seed, drop.site, (uint32_t)((bh * S + i) * S + c), drop.p) ? ds : 0.f;
+      const float Pc = c < S ? pc[i] : 0.f;
+      const float dPk = dpc * kc;
+      const float delta = group16_sum(Pc * dPk);
+      dSc[i] = Pc * (dPk - delta) * s.scale;
+      Pdc[i] = Pc * kc;
+      float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int j = 0; j < ST; ++j) {
+        const float a = __shfl(dSc[i], gbase + j, 64);
+        dq.x = fmaf(a, k[j].x, dq.x); dq.y = fmaf(a, k[j].y, dq.y); dq.z = fmaf(a, k[j].z, dq.z); dq.w = fmaf(a, k[j].w, dq.w);
+      }
+      *reinterpret_cast<float4*>(dQb + i * s.q_rs) = dq;
+    }
+  }
+  // K / V rows are dead from here; the Q rows take their registers (fetched only now: all five row sets at once would
+  // need > 256 VGPRs at S = 10 and halve the occupancy)
+  asm volatile("" ::: "memory");
+  float4 q[ST];
+#pragma unroll
+  for (int j = 0; j < ST; ++j) q[j] = *reinterpret_cast<const float4*>(Qb + min(j, S - 1) * s.q_rs);
+  float* dKb = p.dK + b * s.k_bs + col;
+  float* dVb = p.dV + b * s.v_bs + col;
+#pragma unroll
+  for (int j = 0; j < ST; ++j) {
+    if (j < S) {
+      float4 dk = make_float4(0.f, 0.f, 0.f, 0.f), dv = dk;
+      if (accum_kv) {
+        dk = *reinterpret_cast<const float4*>(dKb + j * s.k_rs);
+        dv = *reinterpret_cast<const float4*>(dVb + j * s.v_rs);
+      }
+#pragma unroll
+      for (int i = 0; i < ST; ++i) {               // rows i >= S carry zeros
+        const float a = __shfl(dSc[i], gbase + j, 64), bb = __shfl(Pdc[i], gbase + j, 64);
+        dk.x = fmaf(a, q[i].x, dk.x); dk.y = fmaf(a, q[i].y, dk.y); dk.z = fmaf(a, q[i].z, dk.z); dk.w = fmaf(a, q[i].w, dk.w);
+        dv.x = fmaf(bb, go[i].x, dv.x); dv.y = fmaf(bb, go[i].y, dv.y); dv.z = fmaf(bb, go[i].z, dv.z); dv.w = fmaf(bb, go[i].w, dv.w);
+      }
+      *reinterpret_cast<float4*>(dKb + j * s.k_rs) = dk;
+      *reinterpret_cast<float4*>(dVb + j * s.v_rs) = dv;
+    }
+  }
+}
+
+constexpr int SX4_MAX = 10;     // 4 x S float4 row sets + coefficients fit the register file up to here
+#define MANSY_SX4_DISPATCH(KERNEL, S_, ...)                                                                \
+  switch (S_) {                                                                                            \
+    case 2: hipLaunchKernelGGL(KERNEL<2>, __VA_ARGS__); break;                                             \
+    case 3: hipLaunchKernelGGL(KERNEL<3>, __VA_ARGS__); break;                                             \
+    case 4: hipLaunchKernelGGL(KERNEL<4>, __VA_ARGS__); break;                                             \
+    case 5: hipLaunchKernelGGL(KERNEL<5>, __VA_ARGS__); break;                                             \
+    case 6: hipLaunchKernelGGL(KERNEL<6>, __VA_ARGS__); break;                                             \
+    case 7: hipLaunchKernelGGL(KERNEL<7>, __VA_ARGS__); break;                                             \
+    case 8: hipLaunchKernelGGL(KERNEL<8>, __VA_ARGS__); break;                                             \
+    case 9: hipLaunchKernelGGL(KERNEL<9>, __VA_ARGS__); break;                                             \
+    default: hipLaunchKernelGGL(KERNEL<10>, __VA_ARGS__); break;                                           \
+  }
+static bool sx4_ok(const AttnShape& s, const void* a, const void* b, const void* c, const void* d) {
+  auto al = [](const void* x) { return (reinterpret_cast<uintptr_t>(x) & 15) == 0; };
+  return s.Lq == s.Lk && s.Lk >= 2 && s.Lk <= SX4_MAX && s.dh == 64 && (s.H % 4) == 0 && (s.q_bs % 4) == 0 && (s.q_rs % 4) == 0 &&
+         (s.k_bs % 4) == 0 && (s.k_rs % 4) == 0 && (s.v_bs % 4) == 0 && (s.v_rs % 4) == 0 && (s.o_bs % 4) == 0 && (s.o_rs % 4) == 0 &&
+         al(a) && al(b) && al(c) && al(d);
+}
+
 // LKT buckets: exact for the decode lengths the engine produces (1..10), then 12 and 16
 #define MANSY_Q1X4_DISPATCH(KERNEL, Lk, ...)                                                               \
   switch (Lk) {                                                                                            \
@@ -492,6 +649,8 @@ int mansy_launch_attn_fwd(const float* Q, const float* K, const float* V, float*
   AttnPtrs p = {Q, K, V, O, P_save, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   if (q1x4_ok(s, Q, K, V, O))
     MANSY_Q1X4_DISPATCH(attn_fwd_q1x4_kernel, s.Lk, dim3(mansy_ceil_div(n / 4, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop)
+  else if (sx4_ok(s, Q, K, V, O))
+    MANSY_SX4_DISPATCH(attn_fwd_sx4_kernel, s.Lk, dim3(mansy_ceil_div(n / 4, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop)
   else if (s.Lq == 1) hipLaunchKernelGGL(attn_fwd_q1_kernel, dim3(mansy_ceil_div(n, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop);
   else hipLaunchKernelGGL(attn_fwd_kernel, dim3(mansy_ceil_div(n, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop);
   MANSY_LAUNCH_CHECK();
@@ -507,6 +666,8 @@ int mansy_launch_attn_bwd(const float* Q, const float* K, const float* V, const 
   AttnPtrs p = {Q, K, V, nullptr, const_cast<float*>(P_save), dO, dQ, dK, dV, nullptr, nullptr};
   if (q1x4_ok(s, Q, K, V, dO) && q1x4_ok(s, dQ, dK, dV, dO))
     MANSY_Q1X4_DISPATCH(attn_bwd_q1x4_kernel, s.Lk, dim3(mansy_ceil_div(n / 4, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop, accum_kv)
+  else if (sx4_ok(s, Q, K, V, dO) && sx4_ok(s, dQ, dK, dV, dO))
+    MANSY_SX4_DISPATCH(attn_bwd_sx4_kernel, s.Lk, dim3(mansy_ceil_div(n / 4, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop, accum_kv)
   else if (s.Lq == 1) hipLaunchKernelGGL(attn_bwd_q1_kernel, dim3(mansy_ceil_div(n, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop, accum_kv);
   else hipLaunchKernelGGL(attn_bwd_kernel, dim3(mansy_ceil_div(n, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop, accum_kv);
   MANSY_LAUNCH_CHECK();

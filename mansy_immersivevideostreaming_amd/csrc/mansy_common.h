@@ -55,15 +55,31 @@ struct MansyDrop {   // a dropout site; p == 0 disables
 };
 static inline MansyDrop mansy_no_drop() { MansyDrop d; d.p = 0.f; d.seed = 0; d.site = 0; return d; }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane reductions on the VALU (DPP row rotations inside each 16-lane row, v_readlane across the four rows) instead of
+// __shfl_xor, which hipcc lowers to ds_bpermute_b32 -- an LDS-pipe round trip per step.
+template <int CTRL>
+__device__ __forceinline__ float mansy_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float mansy_lane(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+// sum / max over each aligned group of 16 lanes, result in all 16 (row_ror:8,4,2,1)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += mansy_dpp<0x128>(v); v += mansy_dpp<0x124>(v); v += mansy_dpp<0x122>(v); v += mansy_dpp<0x121>(v);
   return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, mansy_dpp<0x128>(v)); v = fmaxf(v, mansy_dpp<0x124>(v)); v = fmaxf(v, mansy_dpp<0x122>(v)); v = fmaxf(v, mansy_dpp<0x121>(v));
   return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row16_sum(v);
+  return (mansy_lane(v, 0) + mansy_lane(v, 16)) + (mansy_lane(v, 32) + mansy_lane(v, 48));
+}
+__device__ __forceinline__ float wave_max(float v) {
+  v = row16_max(v);
+  return fmaxf(fmaxf(mansy_lane(v, 0), mansy_lane(v, 16)), fmaxf(mansy_lane(v, 32), mansy_lane(v, 48)));
 }
 
 static inline int mansy_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }

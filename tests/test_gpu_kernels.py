@@ -88,7 +88,7 @@ def test_gemm_splitk_accumulate(K):
     assert (err <= 2e-6 * bound + 1e-6).all()
 
 
-@pytest.mark.parametrize('B,L,d,H', [(5, 10, 512, 8), (3, 16, 64, 8), (7, 5, 128, 8), (2, 1, 512, 8)])
+@pytest.mark.parametrize('B,L,d,H', [(5, 10, 512, 8), (3, 16, 64, 8), (7, 5, 128, 8), (2, 1, 512, 8), (9, 5, 512, 8), (4, 2, 512, 8), (3, 7, 256, 4), (2, 12, 512, 8)])
 @pytest.mark.parametrize('p', [0.0, 0.1])
 def test_attention_fwd_bwd(K, B, L, d, H, p):
     g = torch.Generator().manual_seed(L * 100 + d)
