@@ -8,7 +8,7 @@ RCCL), data parallel over trajectories ("weak" scaling: 4096 per GPU), ONE all-r
 gradient buffer per step.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     dominant kernel = gemm_f32_kernel (exact-fp32 MFMA).  achieved = exact GEMM FLOPs
+  roofline     dominant kernel = gemm_f32_dma_kernel (exact-fp32 MFMA, LDS-DMA staged).  achieved = exact GEMM FLOPs
                (sum 2MNK over launches; KV-cached decoder => this IS the algorithmic minimum of SURVEY
                8d up to the attention/elementwise terms) / summed launch duration from HIP events recorded on
                the launch stream in a separate instrumented leg of the same workload.
@@ -64,11 +64,13 @@ def cpu_baseline(seconds=15.0):
 
 
 def _pmc_traffic():
-    """HBM-side bytes per GEMM launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_gemm.json: FETCH_SIZE x2
-    gfx950 correction + WRITE_SIZE, separate passes); PMC cannot be collected from inside this process."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_gemm.json')
+    """HBM-side bytes per GEMM launch from the newest committed rocprofv3 PMC aggregate (profiles/r*_pmc_gemm.json, written by
+    tools/pmc_aggregate.py from separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 per the gfx950 correction); PMC cannot
+    be collected from inside this process."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_gemm.json')))
     try:
-        return json.load(open(path))['traffic_bytes_per_launch']
+        return json.load(open(files[-1]))['traffic_bytes_per_launch']
     except Exception:
         return None
 
@@ -255,7 +257,7 @@ def main():
         check(L.mansy_prof_gemm_collect(ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), 'prof_collect')
         check(L.mansy_prof_gemm_enable(0), 'prof_disable')
         achieved = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
-        roof = {'bound': 'mfma', 'kernel': 'gemm_f32_kernel (v_mfma_f32_32x32x2_f32)', 'achieved': round(achieved, 2),
+        roof = {'bound': 'mfma', 'kernel': 'gemm_f32_dma_kernel (v_mfma_f32_32x32x2_f32, LDS-DMA staged)', 'achieved': round(achieved, 2),
                 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                 'traffic': _pmc_traffic(),
                 'launches_per_step': n.value // nprof, 'avg_launch_us': round(ms.value * 1e3 / max(n.value, 1), 2),

@@ -386,7 +386,6 @@ __global__ __launch_bounds__(NT) void gemm_f32_dma_kernel(GemmParams p) {
     tile_y = t / gridDim.x; tile_x = t - tile_y * gridDim.x;
   }
   const int m0 = tile_y * BM, n0 = tile_x * BN;
-  const bool first_n_tile = tile_x == 0;
   const int k_begin = blockIdx.z * p.k_per_split;
   const int k_end = min(p.K, k_begin + p.k_per_split);
   const int nk = (k_end - k_begin) / BK;          // K % BK == 0 and k_per_split % BK == 0 on this path
@@ -430,9 +429,10 @@ __global__ __launch_bounds__(NT) void gemm_f32_dma_kernel(GemmParams p) {
     }
     const float* a_l = smem + cur * STAGE;
     const float* b_l = a_l + A_FLOATS;
-    if (AK && p.ep.a_rowsum && first_n_tile && tid < BM) {       // bias gradient: row sums of the staged A tile
-#pragma unroll
-      for (int kk = 0; kk < BK; ++kk) rowsum += a_l[kk * BM + tid];
+    if (AK && p.ep.a_rowsum && tid < BM) {       // bias gradient: row sums of the staged A tile.  Every n-tile of this
+      // row panel stages the same A tile, so they share the BK rows (a single n-tile doing all of them ran ~1.3x longer
+      // than its neighbours and set the kernel's tail)
+      for (int kk = tile_x; kk < BK; kk += gridDim.x) rowsum += a_l[kk * BM + tid];
     }
 #pragma unroll
     for (int chunk = 0; chunk < 2; ++chunk) {
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_dma_kernel(GemmParams p) {
   }
   __syncthreads();                                        // staging LDS idle: the epilogue reuses it
 
-  if (AK && p.ep.a_rowsum && first_n_tile && tid < BM && m0 + tid < p.M) atomicAdd(p.ep.a_rowsum + m0 + tid, rowsum);
+  if (AK && p.ep.a_rowsum && tile_x < BK && tid < BM && m0 + tid < p.M) atomicAdd(p.ep.a_rowsum + m0 + tid, rowsum);
   gemm_epilogue<BM, BN, SMEM_FLOATS>(p, acc, smem, m0, n0, tid);
 }
 
