@@ -122,7 +122,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, h = lane >> 5;
   const GemmEpilogue& ep = p.ep;
-  const bool atomic = ep.accumulate || gridDim.z > 1;
+  const bool atomic = ep.accumulate || (gridDim.z > 1 && ep.split_slab == 0);
+  float* const Cz = p.C + (long long)blockIdx.z * ep.split_slab;          // own slab per K split in slab mode
   const float drop_scale = ep.drop.p > 0.f ? 1.f / (1.f - ep.drop.p) : 1.f;
   if (!atomic && p.c_vec_ok) {
     // Row-major 16-byte epilogue: the accumulators (one column per lane, 16 scattered rows) are transposed through the LDS
@@ -166,7 +167,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
         const float4 rr = *reinterpret_cast<const float4*>(ep.resid + (long long)row * ep.resid_ld + col);
         v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
       }
-      *reinterpret_cast<float4*>(p.C + (long long)row * p.ldc + col) = v;
+      *reinterpret_cast<float4*>(Cz + (long long)row * p.ldc + col) = v;
     }
     return;
   }
@@ -213,7 +214,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
         for (int e = 0; e < 16; ++e) {
           const int row = row_base + (e & 3) + 8 * (e >> 2);
           if (row < p.M) {
-            float* dst = p.C + (long long)row * p.ldc + col;
+            float* dst = Cz + (long long)row * p.ldc + col;
             if (atomic) atomicAdd(dst, v[e]); else *dst = v[e];
           }
         }
@@ -386,9 +387,13 @@ __global__ __launch_bounds__(NT) void gemm_f32_dma_kernel(GemmParams p) {
     tile_y = t / gridDim.x; tile_x = t - tile_y * gridDim.x;
   }
   const int m0 = tile_y * BM, n0 = tile_x * BN;
-  const int k_begin = blockIdx.z * p.k_per_split;
-  const int k_end = min(p.K, k_begin + p.k_per_split);
-  const int nk = (k_end - k_begin) / BK;          // K % BK == 0 and k_per_split % BK == 0 on this path
+  int k_begin = blockIdx.z * p.k_per_split;
+  int k_end = min(p.K, k_begin + p.k_per_split);
+  if (BN == 64 && p.ep.tile_krange) {             // structurally-zero K-tiles of this column tile are skipped
+    k_begin = max(k_begin, p.ep.tile_krange[2 * tile_x]);
+    k_end = min(k_end, p.ep.tile_krange[2 * tile_x + 1]);
+  }
+  const int nk = max(0, (k_end - k_begin) / BK);  // K % BK == 0 and k_per_split % BK == 0 on this path
 
   unsigned voa[PA], vob[PB];
   dma_offsets<BM, AK>(p.lda, m0, p.M, voa, tid);
@@ -588,6 +593,7 @@ int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B,
     if (splits > max_splits) splits = max_splits;
   }
   MANSY_REQUIRE(splits == 1 || plain, "gemm: split-K requires a plain epilogue");
+  MANSY_REQUIRE(ep.split_slab == 0 || (!ep.accumulate && (ep.split_slab % 4) == 0), "gemm: slab split-K stores, it does not accumulate");
   int kps = mansy_ceil_div(mansy_ceil_div(K, splits), BK) * BK;
   if (kps <= 0) kps = BK;
   splits = K > 0 ? mansy_ceil_div(K, kps) : 1;
@@ -602,4 +608,12 @@ int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B,
   g_prof.used += 2;
   g_prof.flops += 2.0 * (double)M * (double)N * (double)K;
   return rc;
+}
+
+
+int mansy_gemm_effective_splits(int K, int requested) {
+  if (requested <= 1 || K <= 0) return 1;
+  int kps = mansy_ceil_div(mansy_ceil_div(K, requested), BK) * BK;
+  if (kps <= 0) kps = BK;
+  return mansy_ceil_div(K, kps);
 }

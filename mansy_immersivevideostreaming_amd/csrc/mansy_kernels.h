@@ -24,7 +24,16 @@ struct GemmEpilogue {
   int resid_ld = 0;
   int accumulate = 0;   // C += result (atomicAdd); forced when split-K > 1
   float* a_rowsum = nullptr;   // K-major A only: a_rowsum[m] += sum_k A(m,k)  (bias gradient riding on the dW product)
+  // > 0 (with force_splitk > 1 and an otherwise plain epilogue): K split z stores its partial product to its own slab
+  // C + z*split_slab (floats) with ordinary stores -- no atomics, no zero-fill; the consumer sums
+  // mansy_gemm_effective_splits(K, force_splitk) slabs (skinny products: few output tiles, long K).
+  long long split_slab = 0;
+  // optional, LDS-DMA loop with 64-column tiles only (a pure speed hint: B must be zero outside the ranges): per 64-column
+  // tile t the K range [tile_krange[2t], tile_krange[2t+1]) (multiples of 32) that holds all of B's non-zeros for those
+  // columns -- block-diagonal weights (FeatureNet) skip the K-tiles that are structurally zero.
+  const int* tile_krange = nullptr;
 };
+int mansy_gemm_effective_splits(int K, int requested);
 int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb, int b_kmajor,
                           float* C, int ldc, int M, int N, int K, const GemmEpilogue& ep, int force_tile,
                           int force_splitk, hipStream_t st);

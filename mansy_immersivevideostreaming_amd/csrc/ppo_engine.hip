@@ -23,6 +23,8 @@ namespace {
 constexpr int HID = 128, NB = 10, FEAT = HID * NB, OBS_LD = MANSY_OBS_LD, NACT = 15, MAXOUT = 16;
 constexpr float SLOPE = 0.01f;
 constexpr int K_POLICY = 748, K_IDENT = 764;
+constexpr int KP = 768;                     // K of the packed block-diagonal image: padded to whole 32-wide K-tiles (LDS-DMA GEMM loop)
+static_assert(KP <= MANSY_OBS_LD && KP % 32 == 0 && KP >= 764, "packed K must cover both nets and stay inside an observation row");
 constexpr int RESID_COL = FEAT - HID;      // 10th branch output is the residual of every head
 
 struct Branch { int off, len; };
@@ -78,14 +80,22 @@ void bind_net(const float* const* params, float* const* grads, int head_base, Ne
 
 // ------------------------------------------------------------------------------------ kernels
 struct PackArgs { const float* bw[NB]; const float* bb[NB]; };
-__global__ __launch_bounds__(256) void pack_wbd_kernel(PackArgs a, int identifier, int K, float* __restrict__ Wbd, float* __restrict__ bbd) {
+// Wbd [FEAT, KP] (columns >= K and everything off the block diagonal zero), bbd [FEAT], and per 64-feature column tile of
+// the product the K range that holds its branch's weights (GemmEpilogue::tile_krange).
+__global__ __launch_bounds__(256) void pack_wbd_kernel(PackArgs a, int identifier, int K, float* __restrict__ Wbd, float* __restrict__ bbd,
+                                                       int* __restrict__ krange) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (long long)FEAT * K) return;
-  const int col = (int)(idx % K), row = (int)(idx / K);
+  if (idx < FEAT / 64) {
+    const Branch g = branch_geom((int)idx * 64 / HID, identifier);
+    krange[2 * idx] = g.off / 32 * 32;
+    krange[2 * idx + 1] = min(KP, (g.off + g.len + 31) / 32 * 32);
+  }
+  if (idx >= (long long)FEAT * KP) return;
+  const int col = (int)(idx % KP), row = (int)(idx / KP);
   const int j = row / HID, r = row % HID;
   const Branch g = branch_geom(j, identifier);
   float v = 0.f;
-  if (col >= g.off && col < g.off + g.len) v = a.bw[j][r * g.len + (col - g.off)];
+  if (col < K && col >= g.off && col < g.off + g.len) v = a.bw[j][r * g.len + (col - g.off)];
   Wbd[idx] = v;
   if (col == 0) bbd[row] = a.bb[j][r];
 }
@@ -107,15 +117,31 @@ __global__ __launch_bounds__(256) void scatter_bias_grad_kernel(const float* __r
 
 // one wave per row: H = A1 + F[:, resid] ; out[k] = H . Wout[k] + b[k] (k < n_out <= 16), optional sigmoid;
 // optional categorical sample (inverse CDF on softmax(out)) with log-prob.
-__global__ __launch_bounds__(256) void head_out_kernel(const float* __restrict__ A1, const float* __restrict__ F, const float* __restrict__ Wout,
-                                                       const float* __restrict__ bout, int n_out, int sigmoid, float* __restrict__ H,
-                                                       float* __restrict__ out, int out_ld, int rows, const float* __restrict__ u_ext,
-                                                       uint32_t seed, uint32_t site, int* __restrict__ act, float* __restrict__ logp) {
+// nsplit > 0: A1 is not yet formed -- sum the nsplit K-split slabs of the fc product (slab stride `slab` floats), add the fc
+// bias, apply the LeakyReLU and store A1 (the backward reads it); nsplit == 0: A1 holds the activated fc output already.
+__global__ __launch_bounds__(256) void head_out_kernel(float* __restrict__ A1, const float* __restrict__ A1pre, int nsplit, long long slab,
+                                                       const float* __restrict__ fc_b, const float* __restrict__ F,
+                                                       const float* __restrict__ Wout, const float* __restrict__ bout, int n_out, int sigmoid,
+                                                       float* __restrict__ H, float* __restrict__ out, int out_ld, int rows,
+                                                       const float* __restrict__ u_ext, uint32_t seed, uint32_t site, int* __restrict__ act,
+                                                       float* __restrict__ logp) {
   const int lane = threadIdx.x & 63;
   const int row = (blockIdx.x * 256 + threadIdx.x) >> 6;
   if (row >= rows) return;
-  const float h0 = A1[(size_t)row * HID + lane] + F[(size_t)row * FEAT + RESID_COL + lane];
-  const float h1 = A1[(size_t)row * HID + 64 + lane] + F[(size_t)row * FEAT + RESID_COL + 64 + lane];
+  float a0, a1;
+  if (nsplit > 0) {
+    a0 = fc_b[lane]; a1 = fc_b[64 + lane];
+    for (int z = 0; z < nsplit; ++z) {
+      a0 += A1pre[z * slab + (size_t)row * HID + lane];
+      a1 += A1pre[z * slab + (size_t)row * HID + 64 + lane];
+    }
+    a0 = a0 > 0.f ? a0 : a0 * SLOPE; a1 = a1 > 0.f ? a1 : a1 * SLOPE;
+    A1[(size_t)row * HID + lane] = a0; A1[(size_t)row * HID + 64 + lane] = a1;
+  } else {
+    a0 = A1[(size_t)row * HID + lane]; a1 = A1[(size_t)row * HID + 64 + lane];
+  }
+  const float h0 = a0 + F[(size_t)row * FEAT + RESID_COL + lane];
+  const float h1 = a1 + F[(size_t)row * FEAT + RESID_COL + 64 + lane];
   if (H) { H[(size_t)row * HID + lane] = h0; H[(size_t)row * HID + 64 + lane] = h1; }
   float o[MAXOUT];
 #pragma unroll
@@ -410,17 +436,35 @@ __global__ __launch_bounds__(256) void logp_kernel(const float* __restrict__ log
 // ------------------------------------------------------------------------------------ workspace
 struct PWork {
   float *Wbd, *bbd, *F, *A1a, *Ha, *A1c, *Hc, *outa, *outc, *dHa, *dHc, *dA1a, *dA1c, *dF, *dWbd, *dbbd, *obs_mb, *gout, *gout_c;
+  float* A1s;      // split-K slabs of a head's fc product (head())
+  int* krange;     // per 64-feature tile K range of the packed block-diagonal image
   double* acc;
 };
+// The head's fc product is [B,1280] x [1280,128]: 2 column tiles however large K is, so for B <= 2048 it is split over K
+// into slabs (GemmEpilogue::split_slab) that head_out_kernel sums -- 16x fewer K-tiles on the critical path at B = 256.
+inline int head_split_request(int B) {
+  const int tiles = mansy_ceil_div(B, 64) * (HID / 64);
+  const int req = 256 / tiles;
+  return req < 2 ? 1 : (req > 16 ? 16 : req);
+}
+inline int head_slab_rows(int maxB) {
+  int rows = maxB;
+  for (int B = 1; B <= maxB; B = B < 64 ? 64 : B + 64) {
+    const int r = mansy_gemm_effective_splits(FEAT, head_split_request(B)) * B;
+    if (r > rows) rows = r;
+  }
+  return rows + 64;
+}
 size_t ppo_layout(int maxB, char* base, PWork& W) {
   size_t tot = 0;
   auto f = [&](size_t n) { const size_t off = (tot + 255) & ~size_t(255); tot = off + n * sizeof(float); return (float*)(base ? base + off : nullptr); };
-  W.Wbd = f((size_t)FEAT * K_IDENT); W.bbd = f(FEAT); W.F = f((size_t)maxB * FEAT);
+  W.Wbd = f((size_t)FEAT * KP); W.bbd = f(FEAT); W.krange = (int*)f(2 * FEAT / 64); W.F = f((size_t)maxB * FEAT);
   W.A1a = f((size_t)maxB * HID); W.Ha = f((size_t)maxB * HID); W.A1c = f((size_t)maxB * HID); W.Hc = f((size_t)maxB * HID);
   W.outa = f((size_t)maxB * MAXOUT); W.outc = f((size_t)maxB * MAXOUT);
   W.dHa = f((size_t)maxB * HID); W.dHc = f((size_t)maxB * HID); W.dA1a = f((size_t)maxB * HID); W.dA1c = f((size_t)maxB * HID);
   W.dF = f((size_t)maxB * FEAT); W.dWbd = f((size_t)FEAT * K_IDENT); W.dbbd = f(FEAT); W.obs_mb = f((size_t)maxB * OBS_LD);
   W.gout = f((size_t)maxB * MAXOUT); W.gout_c = f((size_t)maxB * MAXOUT);
+  W.A1s = f((size_t)head_slab_rows(maxB) * HID);
   W.acc = (double*)f(16);
   return tot + 256;
 }
@@ -432,21 +476,30 @@ struct PEng {
   int pack(const NetP& n, int identifier) {
     PackArgs a; for (int j = 0; j < NB; ++j) { a.bw[j] = n.bw[j]; a.bb[j] = n.bb[j]; }
     const int K = identifier ? K_IDENT : K_POLICY;
-    hipLaunchKernelGGL(pack_wbd_kernel, dim3(mansy_ceil_div((long long)FEAT * K, 256)), dim3(256), 0, st, a, identifier, K, W.Wbd, W.bbd);
+    hipLaunchKernelGGL(pack_wbd_kernel, dim3(mansy_ceil_div((long long)FEAT * KP, 256)), dim3(256), 0, st, a, identifier, K, W.Wbd, W.bbd, W.krange);
     MANSY_LAUNCH_CHECK();
     return MANSY_OK;
   }
   int featnet(const float* obs, int B, int identifier) {
     const int K = identifier ? K_IDENT : K_POLICY;
-    GemmEpilogue ep; ep.bias = W.bbd; ep.relu = 1; ep.relu_slope = SLOPE;
-    return mansy_launch_gemm_f32(obs, OBS_LD, 0, W.Wbd, K, 0, W.F, FEAT, B, FEAT, K, ep, 0, 0, st);
+    (void)K;      // the packed image spans KP columns (zero beyond K); obs rows are OBS_LD >= KP floats
+    GemmEpilogue ep; ep.bias = W.bbd; ep.relu = 1; ep.relu_slope = SLOPE; ep.tile_krange = W.krange;
+    return mansy_launch_gemm_f32(obs, OBS_LD, 0, W.Wbd, KP, 0, W.F, FEAT, B, FEAT, KP, ep, 0, 0, st);
   }
   int head(const NetP& n, int B, int n_out, int sigmoid, float* A1, float* H, float* out, const float* u, uint32_t seed, uint32_t site, int* act,
            float* logp) {
-    GemmEpilogue ep; ep.bias = n.fc_b; ep.relu = 1; ep.relu_slope = SLOPE;
-    RC(mansy_launch_gemm_f32(W.F, FEAT, 0, n.fc_w, FEAT, 0, A1, HID, B, HID, FEAT, ep, 0, 0, st));
-    hipLaunchKernelGGL(head_out_kernel, dim3(mansy_ceil_div(B, 4)), dim3(256), 0, st, A1, W.F, n.out_w, n.out_b, n_out, sigmoid, H, out, MAXOUT, B, u,
-                       seed, site, act, logp);
+    const int req = head_split_request(B);
+    int nsplit = 0;
+    if (req > 1) {
+      nsplit = mansy_gemm_effective_splits(FEAT, req);
+      GemmEpilogue ep; ep.split_slab = (long long)B * HID;
+      RC(mansy_launch_gemm_f32(W.F, FEAT, 0, n.fc_w, FEAT, 0, W.A1s, HID, B, HID, FEAT, ep, 0, req, st));
+    } else {
+      GemmEpilogue ep; ep.bias = n.fc_b; ep.relu = 1; ep.relu_slope = SLOPE;
+      RC(mansy_launch_gemm_f32(W.F, FEAT, 0, n.fc_w, FEAT, 0, A1, HID, B, HID, FEAT, ep, 0, 0, st));
+    }
+    hipLaunchKernelGGL(head_out_kernel, dim3(mansy_ceil_div(B, 4)), dim3(256), 0, st, A1, W.A1s, nsplit, (long long)B * HID, n.fc_b, W.F, n.out_w,
+                       n.out_b, n_out, sigmoid, H, out, MAXOUT, B, u, seed, site, act, logp);
     MANSY_LAUNCH_CHECK();
     return MANSY_OK;
   }

@@ -14,6 +14,6 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 tot = sum(int(r['TotalDurationNs']) for r in rows); n = sum(int(r['Calls']) for r in rows)
 print('total kernel ms per cycle', tot / 12 / 1e6, 'launches per cycle', n / 12)
-for r in rows[:14]:
+for r in rows[:30]:
     print(f"{r['Name'][:70]:70s} calls/cyc={int(r['Calls'])/12:7.1f} avg_us={float(r['AverageNs'])/1e3:8.1f} ms/cyc={int(r['TotalDurationNs'])/12/1e6:7.3f}")
 PY
