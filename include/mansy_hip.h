@@ -182,7 +182,9 @@ int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, fl
                              float eps_clip, float vf_coef, float ent_coef, int norm_adv, int value_clip, float max_grad_norm, float lr,
                              float weight_decay, int step, float* stats, void* workspace, int max_batch, void* stream);
 
-/* clip_grad_norm_ (max_norm <= 0: off) + Adam with L2 weight decay over flat buffers (data-parallel second half) */
+/* clip_grad_norm_ (max_norm <= 0: off) + Adam with L2 weight decay over flat buffers (data-parallel second half).
+ * scratch: MANSY_CLIP_SCRATCH_DOUBLES doubles of device memory (gradient-norm partial sums; need not be zeroed). */
+#define MANSY_CLIP_SCRATCH_DOUBLES 64
 int mansy_clip_grad_adam(float* flat_p, float* flat_g, float* flat_m, float* flat_v, long long n_flat, float max_grad_norm, float lr,
                          float weight_decay, int step, double* scratch, void* stream);
 

@@ -185,7 +185,7 @@ class PPOPolicy(nn.Module):
         self.world, self.grad_sync = int(world), grad_sync
 
     def _clip_adam(self, f, max_norm, lr, wd):
-        scratch = torch.zeros(1, dtype=torch.float64, device=f.flat_p.device)
+        scratch = torch.empty(64, dtype=torch.float64, device=f.flat_p.device)      # MANSY_CLIP_SCRATCH_DOUBLES
         check(lib().mansy_clip_grad_adam(ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), float(max_norm), lr, wd, f.step,
                                          ptr(scratch), stream_ptr(f.flat_p.device)), 'mansy_clip_grad_adam')
 

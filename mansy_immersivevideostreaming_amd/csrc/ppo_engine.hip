@@ -226,8 +226,9 @@ __global__ __launch_bounds__(256) void head_out_bwd_kernel(const float* __restri
 
 // dPre = (dF + [residual grads in the last 128 columns]) * leaky'(F)
 __global__ __launch_bounds__(256) void featgrad_finish_kernel(float* __restrict__ dF, const float* __restrict__ dH_a, const float* __restrict__ dH_b,
-                                                              const float* __restrict__ F, long long n) {
+                                                              const float* __restrict__ F, long long n, float* __restrict__ dbbd_zero) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx < FEAT) dbbd_zero[idx] = 0.f;        // the dWbd product that follows accumulates the packed bias gradient here
   if (idx >= n) return;
   const int col = (int)(idx % FEAT);
   const long long row = idx / FEAT;
@@ -408,20 +409,53 @@ __global__ void rms_merge_kernel(double* rms, const double* part, long long n) {
 }
 
 // global L2-norm gradient clipping (torch.nn.utils.clip_grad_norm_): g *= max_norm / (norm + 1e-6) if that is < 1
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long long n, double* __restrict__ acc) {
+// squared-gradient partial sums: NORM_PARTS workgroups, one double each (no zero-fill, no atomics); consumers add them up
+constexpr int NORM_PARTS = MANSY_CLIP_SCRATCH_DOUBLES;
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long long n, double* __restrict__ parts) {
+  __shared__ double red[256];
   double local = 0.0;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) local += (double)g[i] * (double)g[i];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o, 64);
-  if ((threadIdx.x & 63) == 0) atomicAdd(acc, local);
+  const long long n4 = n >> 2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(g)[i];
+    local += ((double)v.x * (double)v.x + (double)v.y * (double)v.y) + ((double)v.z * (double)v.z + (double)v.w * (double)v.w);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) { const float t = g[(n4 << 2) + threadIdx.x]; local += (double)t * (double)t; }
+  red[threadIdx.x] = local;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) parts[blockIdx.x] = red[0];
 }
-__global__ __launch_bounds__(256) void clip_scale_kernel(float* __restrict__ g, long long n, const double* __restrict__ acc, float max_norm) {
-  const float norm = (float)sqrt(*acc);
-  const float coef = max_norm / (norm + 1e-6f);
+__device__ __forceinline__ float clip_coef(const double* __restrict__ parts, float max_norm) {
+  double t = 0.0;
+  for (int i = 0; i < NORM_PARTS; ++i) t += parts[i];
+  const float coef = max_norm / ((float)sqrt(t) + 1e-6f);
+  return coef < 1.f ? coef : 1.f;
+}
+__global__ __launch_bounds__(256) void clip_scale_kernel(float* __restrict__ g, long long n, const double* __restrict__ parts, float max_norm) {
+  const float coef = clip_coef(parts, max_norm);
   if (coef >= 1.f) return;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) g[i] *= coef;
 }
-
+// Adam with L2 weight decay (torch.optim.Adam(weight_decay=wd)) on gradients scaled by the global-norm clip coefficient:
+// clip_grad_norm_ + step in one pass (the stored gradient is left unscaled; it is zeroed before its next use).
+__global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
+                                                       float wd, float bc1, float sqrt_bc2, const double* __restrict__ parts,
+                                                       float max_norm) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float coef = clip_coef(parts, max_norm);
+  const float pp = p[i];
+  const float grad = g[i] * coef + wd * pp;
+  const float mm = m[i] + (grad - m[i]) * (1.f - b1);
+  const float vv = v[i] * b2 + (1.f - b2) * grad * grad;
+  const float denom = sqrtf(vv) / sqrt_bc2 + eps;
+  p[i] = pp - (lr / bc1) * (mm / denom);
+  m[i] = mm; v[i] = vv;
+}
 __global__ __launch_bounds__(256) void logp_kernel(const float* __restrict__ logits, const int* __restrict__ act, int B, float* __restrict__ logp) {
   const int r = blockIdx.x * 256 + threadIdx.x;
   if (r >= B) return;
@@ -465,7 +499,7 @@ size_t ppo_layout(int maxB, char* base, PWork& W) {
   W.dF = f((size_t)maxB * FEAT); W.dWbd = f((size_t)FEAT * K_IDENT); W.dbbd = f(FEAT); W.obs_mb = f((size_t)maxB * OBS_LD);
   W.gout = f((size_t)maxB * MAXOUT); W.gout_c = f((size_t)maxB * MAXOUT);
   W.A1s = f((size_t)head_slab_rows(maxB) * HID);
-  W.acc = (double*)f(16);
+  W.acc = (double*)f(2 * 64);      // NORM_PARTS doubles (gradient-norm partial sums; also the identifier-loss accumulator)
   return tot + 256;
 }
 
@@ -508,21 +542,19 @@ struct PEng {
     hipLaunchKernelGGL(head_out_bwd_kernel, dim3(min(mansy_ceil_div(B, 2), 128)), dim3(256), 0, st, g, MAXOUT, A1, H, n.out_w, n_out, dH, dA1, n.gout_w,
                        n.gout_b, B);
     MANSY_LAUNCH_CHECK();
-    GemmEpilogue acc; acc.accumulate = 1;
+    GemmEpilogue acc; acc.accumulate = 1; acc.a_rowsum = n.gfc_b;                                           // gfc_b += column sums of dA1
     RC(mansy_launch_gemm_f32(dA1, HID, 1, W.F, FEAT, 1, n.gfc_w, FEAT, HID, FEAT, B, acc, 0, 0, st));      // gfc_w += dA1^T F
-    RC(mansy_launch_colsum(dA1, HID, B, HID, n.gfc_b, st));
     GemmEpilogue ep; if (accumulate_dF) { ep.resid = W.dF; ep.resid_ld = FEAT; }
     return mansy_launch_gemm_f32(dA1, HID, 0, n.fc_w, FEAT, 1, W.dF, FEAT, B, FEAT, HID, ep, 0, 0, st);    // dF (+)= dA1 Wfc
   }
   int featnet_bwd(const NetP& n, const float* obs, int B, int identifier, const float* dHa, const float* dHb) {
     const int K = identifier ? K_IDENT : K_POLICY;
-    hipLaunchKernelGGL(featgrad_finish_kernel, dim3(mansy_ceil_div((long long)B * FEAT, 256)), dim3(256), 0, st, W.dF, dHa, dHb, W.F, (long long)B * FEAT);
-    GemmEpilogue ep;
+    hipLaunchKernelGGL(featgrad_finish_kernel, dim3(mansy_ceil_div((long long)B * FEAT, 256)), dim3(256), 0, st, W.dF, dHa, dHb, W.F, (long long)B * FEAT,
+                       W.dbbd);
+    GemmEpilogue ep; ep.a_rowsum = W.dbbd;                                                                   // dbbd = column sums of dPre
     RC(mansy_launch_gemm_f32(W.dF, FEAT, 1, obs, OBS_LD, 1, W.dWbd, K, FEAT, K, B, ep, 0, 1, st));           // dWbd = dPre^T obs
     UnpackArgs u; for (int j = 0; j < NB; ++j) u.gbw[j] = n.gbw[j];
     hipLaunchKernelGGL(unpack_dwbd_kernel, dim3(mansy_ceil_div((long long)FEAT * K, 256)), dim3(256), 0, st, W.dWbd, identifier, K, u);
-    MANSY_HIP_CHECK(hipMemsetAsync(W.dbbd, 0, sizeof(float) * FEAT, st));
-    RC(mansy_launch_colsum(W.dF, FEAT, B, FEAT, W.dbbd, st));
     BiasGradArgs bg; for (int j = 0; j < NB; ++j) bg.gbb[j] = n.gbb[j];
     hipLaunchKernelGGL(scatter_bias_grad_kernel, dim3(mansy_ceil_div(FEAT, 256)), dim3(256), 0, st, W.dbbd, bg);
     MANSY_LAUNCH_CHECK();
@@ -530,13 +562,17 @@ struct PEng {
   }
   int clip_and_adam(float* flat_p, float* flat_g, float* m, float* v, long long n, float max_norm, float lr, float wd, int step) {
     if (max_norm > 0.f) {
-      MANSY_HIP_CHECK(hipMemsetAsync(W.acc, 0, sizeof(double), st));
-      hipLaunchKernelGGL(sumsq_kernel, dim3(256), dim3(256), 0, st, flat_g, n, W.acc);
-      hipLaunchKernelGGL(clip_scale_kernel, dim3(256), dim3(256), 0, st, flat_g, n, W.acc, max_norm);
+      hipLaunchKernelGGL(sumsq_kernel, dim3(NORM_PARTS), dim3(256), 0, st, flat_g, n, W.acc);
+      if (step <= 0) hipLaunchKernelGGL(clip_scale_kernel, dim3(256), dim3(256), 0, st, flat_g, n, W.acc, max_norm);   // parity tests: clipped gradients
       MANSY_LAUNCH_CHECK();
     }
-    if (step <= 0) return MANSY_OK;      // gradients (clipped) only -- used by parity tests
-    return mansy_launch_adamw(flat_p, flat_g, m, v, n, lr, 0.9f, 0.999f, 1e-8f, wd, step, 0, st);   // Adam with L2 (run_mansy.py:216,226)
+    if (step <= 0) return MANSY_OK;
+    if (max_norm <= 0.f) return mansy_launch_adamw(flat_p, flat_g, m, v, n, lr, 0.9f, 0.999f, 1e-8f, wd, step, 0, st);   // Adam with L2 (run_mansy.py:216,226)
+    const double bc1 = 1.0 - pow(0.9, (double)step), bc2 = 1.0 - pow(0.999, (double)step);
+    hipLaunchKernelGGL(clip_adam_kernel, dim3(mansy_ceil_div(n, 256)), dim3(256), 0, st, flat_p, flat_g, m, v, n, lr, 0.9f, 0.999f, 1e-8f, wd,
+                       (float)bc1, (float)sqrt(bc2), W.acc, max_norm);
+    MANSY_LAUNCH_CHECK();
+    return MANSY_OK;
   }
 };
 
@@ -703,7 +739,7 @@ int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, fl
 
 // Global-norm clip (torch clip_grad_norm_ semantics; max_norm <= 0 disables) followed by Adam with L2 weight decay over
 // flat buffers.  Data-parallel callers run the minibatch step with step = 0 and max_grad_norm = 0 (raw gradients),
-// all-reduce flat_g over RCCL, then call this.  scratch: 8 bytes.
+// all-reduce flat_g over RCCL, then call this.  scratch: MANSY_CLIP_SCRATCH_DOUBLES doubles.
 int mansy_clip_grad_adam(float* flat_p, float* flat_g, float* flat_m, float* flat_v, long long n_flat, float max_grad_norm, float lr,
                          float weight_decay, int step, double* scratch, void* stream) {
   MANSY_REQUIRE(flat_p && flat_g && flat_m && flat_v && scratch && step >= 1, "clip_grad_adam: bad arguments");
