@@ -116,14 +116,14 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ lds, int rb,
 // `smem` is the (now idle) staging LDS, at least BM*(BN+4) floats; SMEM_FLOATS is its size.
 template <int BM, int BN, int SMEM_FLOATS>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[BM / 64][BN / 64 > 0 ? BN / 64 : 1], float* smem, int m0, int n0,
-                                              int tid) {
+                                              int tid, int split) {
   constexpr int TM = BM / 64, TN = BN / 64;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, h = lane >> 5;
   const GemmEpilogue& ep = p.ep;
   const bool atomic = ep.accumulate || (gridDim.z > 1 && ep.split_slab == 0);
-  float* const Cz = p.C + (long long)blockIdx.z * ep.split_slab;          // own slab per K split in slab mode
+  float* const Cz = p.C + (long long)split * ep.split_slab;               // own slab per K split in slab mode
   const float drop_scale = ep.drop.p > 0.f ? 1.f / (1.f - ep.drop.p) : 1.f;
   if (!atomic && p.c_vec_ok) {
     // Row-major 16-byte epilogue: the accumulators (one column per lane, 16 scattered rows) are transposed through the LDS
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmParams p) {
 
   if (AK && p.ep.a_rowsum && first_n_tile && tid < BM && m0 + tid < p.M) atomicAdd(p.ep.a_rowsum + m0 + tid, rowsum);
 
-  gemm_epilogue<BM, BN, 2 * (A_FLOATS + B_FLOATS)>(p, acc, smem, m0, n0, tid);
+  gemm_epilogue<BM, BN, 2 * (A_FLOATS + B_FLOATS)>(p, acc, smem, m0, n0, tid, blockIdx.z);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -380,14 +380,19 @@ __global__ __launch_bounds__(NT) void gemm_f32_dma_kernel(GemmParams p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, h = lane >> 5;
   int tile_x, tile_y;
-  {   // XCD-aware bijective tile remap (see gemm_f32_kernel)
-    const int nwg = gridDim.x * gridDim.y, orig = blockIdx.y * gridDim.x + blockIdx.x;
+  int split;
+  {   // XCD-aware bijective remap (see gemm_f32_kernel), here over the whole 3-D grid with the K split slowest: XCD x gets the
+      // contiguous logical range [x*nwg/8, (x+1)*nwg/8), i.e. whole K splits when there are >= 8 of them -- every tile of a
+      // split then streams the same operand rows through ONE L2 (dW products: operands fetched once instead of 2-4x).
+    const int per_split = gridDim.x * gridDim.y, nwg = per_split * gridDim.z;
+    const int orig = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     const int q = nwg >> 3, rem = nwg & 7, xcd = orig & 7, local = orig >> 3;
-    const int t = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + local;
+    int t = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + local;
+    split = t / per_split; t -= split * per_split;
     tile_y = t / gridDim.x; tile_x = t - tile_y * gridDim.x;
   }
   const int m0 = tile_y * BM, n0 = tile_x * BN;
-  int k_begin = blockIdx.z * p.k_per_split;
+  int k_begin = split * p.k_per_split;
   int k_end = min(p.K, k_begin + p.k_per_split);
   if (BN == 64 && p.ep.tile_krange) {             // structurally-zero K-tiles of this column tile are skipped
     k_begin = max(k_begin, p.ep.tile_krange[2 * tile_x]);
@@ -459,7 +464,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_dma_kernel(GemmParams p) {
   __syncthreads();                                        // staging LDS idle: the epilogue reuses it
 
   if (AK && p.ep.a_rowsum && tile_x < BK && tid < BM && m0 + tid < p.M) atomicAdd(p.ep.a_rowsum + m0 + tid, rowsum);
-  gemm_epilogue<BM, BN, SMEM_FLOATS>(p, acc, smem, m0, n0, tid);
+  gemm_epilogue<BM, BN, SMEM_FLOATS>(p, acc, smem, m0, n0, tid, split);
 }
 
 template <int BM, int BN>
