@@ -563,6 +563,17 @@ int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B,
   const bool plain = !ep.bias && !ep.relu && !ep.mask_src && ep.drop.p == 0.f && !ep.resid;
   // LDS-DMA loop: whole 16-byte chunks and whole K-tiles only (it cannot zero-fill a K tail)
   const bool dma = p.vec_ok && K >= BK && K % BK == 0 && force_tile >= 0;
+  if (!dma && p.vec_ok && force_tile >= 0 && plain && K % BK != 0 && K >= 8 * BK && ep.split_slab == 0 && !ep.tile_krange) {
+    // long reduce dimension that is not a multiple of the K-tile (e.g. a dW over 3 276 rows): whole K-tiles on the LDS-DMA
+    // loop, the < 32 leftover as a second, accumulating launch of the register-staged loop (sums and row sums are additive)
+    const int Kmain = K / BK * BK;
+    const int rc = mansy_launch_gemm_f32(A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, Kmain, ep, force_tile, force_splitk, st);
+    if (rc) return rc;
+    GemmEpilogue tail = ep; tail.accumulate = 1;
+    const float* A2 = a_kmajor ? A + (long long)Kmain * lda : A + Kmain;
+    const float* B2 = b_kmajor ? B + (long long)Kmain * ldb : B + Kmain;
+    return mansy_launch_gemm_f32(A2, lda, a_kmajor, B2, ldb, b_kmajor, C, ldc, M, N, K - Kmain, tail, -64, 1, st);
+  }
   const bool can_split = plain && ep.accumulate && K >= 4096;
   int tile;
   if (force_tile) {

@@ -88,6 +88,26 @@ def test_gemm_splitk_accumulate(K):
     assert (err <= 2e-6 * bound + 1e-6).all()
 
 
+@pytest.mark.parametrize('rows,accumulate', [(3276, True), (3276, False), (300, False), (1028, True)])
+def test_gemm_long_k_with_tail(K, rows, accumulate):
+    """Reduce dimension not a multiple of the K-tile: whole K-tiles on the LDS-DMA loop + the leftover rows as a second,
+    accumulating launch (the PPO identifier's dW over int(0.8 * 4096) = 3276 transitions)."""
+    g = torch.Generator().manual_seed(rows)
+    dY = torch.randn(rows, 128, generator=g).cuda()
+    X = torch.randn(rows, 764, generator=g).cuda()
+    out = torch.full((128, 764), 0.5, device='cuda')
+    K.gemm(dY, X, a_kmajor=True, b_kmajor=True, out=out, accumulate=accumulate)
+    ref = dY.double().t() @ X.double() + (0.5 if accumulate else 0.0)
+    bound = dY.double().abs().t() @ X.double().abs()
+    assert ((out.double() - ref).abs() <= 2e-6 * bound + 1e-6).all()
+    # K-contiguous operands too
+    A = torch.randn(200, rows, generator=g).cuda()
+    W = torch.randn(96, rows, generator=g).cuda()
+    o2 = K.gemm(A, W)
+    r2 = A.double() @ W.double().t()
+    assert ((o2.double() - r2).abs() <= 2e-6 * (A.double().abs() @ W.double().abs().t()) + 1e-6).all()
+
+
 @pytest.mark.parametrize('B,L,d,H', [(5, 10, 512, 8), (3, 16, 64, 8), (7, 5, 128, 8), (2, 1, 512, 8), (9, 5, 512, 8), (4, 2, 512, 8), (3, 7, 256, 4), (2, 12, 512, 8)])
 @pytest.mark.parametrize('p', [0.0, 0.1])
 def test_attention_fwd_bwd(K, B, L, d, H, p):
