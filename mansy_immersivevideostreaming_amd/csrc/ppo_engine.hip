@@ -79,7 +79,7 @@ void bind_net(const float* const* params, float* const* grads, int head_base, Ne
 }
 
 // ------------------------------------------------------------------------------------ kernels
-struct PackArgs { const float* bw[NB]; const float* bb[NB]; };
+struct PackArgs { const float* bw[NB]; const float* bb[NB]; const float* fc_a; const float* fc_c; float* Wfc2; };
 // Wbd [FEAT, KP] (columns >= K and everything off the block diagonal zero), bbd [FEAT], and per 64-feature column tile of
 // the product the K range that holds its branch's weights (GemmEpilogue::tile_krange).
 __global__ __launch_bounds__(256) void pack_wbd_kernel(PackArgs a, int identifier, int K, float* __restrict__ Wbd, float* __restrict__ bbd,
@@ -90,7 +90,11 @@ __global__ __launch_bounds__(256) void pack_wbd_kernel(PackArgs a, int identifie
     krange[2 * idx] = g.off / 32 * 32;
     krange[2 * idx + 1] = min(KP, (g.off + g.len + 31) / 32 * 32);
   }
-  if (idx >= (long long)FEAT * KP) return;
+  if (idx >= (long long)FEAT * KP) {            // tail of the grid: [actor.fc | critic.fc] stacked to one [2*HID, FEAT] operand
+    const long long i2 = idx - (long long)FEAT * KP;
+    if (a.Wfc2 && i2 < 2LL * HID * FEAT) a.Wfc2[i2] = i2 < (long long)HID * FEAT ? a.fc_a[i2] : a.fc_c[i2 - (long long)HID * FEAT];
+    return;
+  }
   const int col = (int)(idx % KP), row = (int)(idx / KP);
   const int j = row / HID, r = row % HID;
   const Branch g = branch_geom(j, identifier);
@@ -115,26 +119,32 @@ __global__ __launch_bounds__(256) void scatter_bias_grad_kernel(const float* __r
   a.gbb[row / HID][row % HID] += dbbd[row];
 }
 
-// one wave per row: H = A1 + F[:, resid] ; out[k] = H . Wout[k] + b[k] (k < n_out <= 16), optional sigmoid;
-// optional categorical sample (inverse CDF on softmax(out)) with log-prob.
-// nsplit > 0: A1 is not yet formed -- sum the nsplit K-split slabs of the fc product (slab stride `slab` floats), add the fc
-// bias, apply the LeakyReLU and store A1 (the backward reads it); nsplit == 0: A1 holds the activated fc output already.
-__global__ __launch_bounds__(256) void head_out_kernel(float* __restrict__ A1, const float* __restrict__ A1pre, int nsplit, long long slab,
-                                                       const float* __restrict__ fc_b, const float* __restrict__ F,
-                                                       const float* __restrict__ Wout, const float* __restrict__ bout, int n_out, int sigmoid,
-                                                       float* __restrict__ H, float* __restrict__ out, int out_ld, int rows,
-                                                       const float* __restrict__ u_ext, uint32_t seed, uint32_t site, int* __restrict__ act,
-                                                       float* __restrict__ logp) {
+// one wave per (row, head): H = A1 + F[:, resid] ; out[k] = H . Wout[k] + b[k] (k < n_out <= 16), optional sigmoid;
+// optional categorical sample (inverse CDF on softmax(out)) with log-prob.  blockIdx.y selects the head (actor / critic share
+// one launch in the PPO update).
+// nsplit > 0: A1 is not yet formed -- sum the nsplit K-split slabs of the fc product (slab stride `slab` floats, row stride
+// pre_ld, this head's columns from pre_col), add the fc bias, apply the LeakyReLU and store A1 (the backward reads it);
+// nsplit == 0: A1 holds the activated fc output already.
+struct HeadOut {
+  float* A1; const float* fc_b; const float* Wout; const float* bout; int n_out; int sigmoid; float* H; float* out; int pre_col;
+  int* act; float* logp;
+};
+struct HeadOutArgs { HeadOut h[2]; };
+__global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const float* __restrict__ A1pre, int nsplit, long long slab, int pre_ld,
+                                                       const float* __restrict__ F, int out_ld, int rows, const float* __restrict__ u_ext,
+                                                       uint32_t seed, uint32_t site) {
+  const HeadOut& d = args.h[blockIdx.y];
+  float* __restrict__ A1 = d.A1; const float* __restrict__ Wout = d.Wout; const float* __restrict__ bout = d.bout;
+  float* __restrict__ H = d.H; float* __restrict__ out = d.out; int* __restrict__ act = d.act; float* __restrict__ logp = d.logp;
+  const int n_out = d.n_out, sigmoid = d.sigmoid;
   const int lane = threadIdx.x & 63;
   const int row = (blockIdx.x * 256 + threadIdx.x) >> 6;
   if (row >= rows) return;
   float a0, a1;
   if (nsplit > 0) {
-    a0 = fc_b[lane]; a1 = fc_b[64 + lane];
-    for (int z = 0; z < nsplit; ++z) {
-      a0 += A1pre[z * slab + (size_t)row * HID + lane];
-      a1 += A1pre[z * slab + (size_t)row * HID + 64 + lane];
-    }
+    a0 = d.fc_b[lane]; a1 = d.fc_b[64 + lane];
+    const float* pre = A1pre + (size_t)row * pre_ld + d.pre_col;
+    for (int z = 0; z < nsplit; ++z) { a0 += pre[z * slab + lane]; a1 += pre[z * slab + 64 + lane]; }
     a0 = a0 > 0.f ? a0 : a0 * SLOPE; a1 = a1 > 0.f ? a1 : a1 * SLOPE;
     A1[(size_t)row * HID + lane] = a0; A1[(size_t)row * HID + 64 + lane] = a1;
   } else {
@@ -185,10 +195,16 @@ __global__ __launch_bounds__(256) void head_out_kernel(float* __restrict__ A1, c
 
 // backward of the output layer + residual: dH[r,c] = sum_k g[r,k] Wout[k,c] ; dA1 = dH * leaky'(A1) ;
 // gWout[k,c] += sum_r g[r,k] H[r,c] ; gbout[k] += sum_r g[r,k]   (g already includes sigmoid' when needed)
-__global__ __launch_bounds__(256) void head_out_bwd_kernel(const float* __restrict__ g, int g_ld, const float* __restrict__ A1,
-                                                           const float* __restrict__ H, const float* __restrict__ Wout, int n_out,
-                                                           float* __restrict__ dH, float* __restrict__ dA1, float* __restrict__ gWout,
-                                                           float* __restrict__ gbout, int rows) {
+struct HeadBwd {
+  const float* g; int g_ld; const float* A1; const float* H; const float* Wout; int n_out; float* dH; float* dA1; int dA1_ld; float* gWout;
+  float* gbout;
+};
+struct HeadBwdArgs { HeadBwd h[2]; };
+__global__ __launch_bounds__(256) void head_out_bwd_kernel(HeadBwdArgs args, int rows) {
+  const HeadBwd& d = args.h[blockIdx.y];
+  const float* __restrict__ g = d.g; const int g_ld = d.g_ld; const float* __restrict__ A1 = d.A1; const float* __restrict__ H = d.H;
+  const float* __restrict__ Wout = d.Wout; const int n_out = d.n_out; float* __restrict__ dH = d.dH; float* __restrict__ dA1 = d.dA1;
+  const int dA1_ld = d.dA1_ld; float* __restrict__ gWout = d.gWout; float* __restrict__ gbout = d.gbout;
   __shared__ float sw[MAXOUT * HID];
   __shared__ float sb[MAXOUT];
   for (int i = threadIdx.x; i < MAXOUT * HID; i += 256) sw[i] = 0.f;
@@ -213,7 +229,7 @@ __global__ __launch_bounds__(256) void head_out_bwd_kernel(const float* __restri
     }
     dH[(size_t)row * HID + c] = acc;
     const float a1 = A1[(size_t)row * HID + c];
-    dA1[(size_t)row * HID + c] = a1 > 0.f ? acc : acc * SLOPE;
+    dA1[(size_t)row * dA1_ld + c] = a1 > 0.f ? acc : acc * SLOPE;
   }
 #pragma unroll
   for (int k = 0; k < MAXOUT; ++k) {
@@ -470,14 +486,15 @@ __global__ __launch_bounds__(256) void logp_kernel(const float* __restrict__ log
 // ------------------------------------------------------------------------------------ workspace
 struct PWork {
   float *Wbd, *bbd, *F, *A1a, *Ha, *A1c, *Hc, *outa, *outc, *dHa, *dHc, *dA1a, *dA1c, *dF, *dWbd, *dbbd, *obs_mb, *gout, *gout_c;
-  float* A1s;      // split-K slabs of a head's fc product (head())
+  float* A1s;      // split-K slabs of a head's fc product (head(), head_pair())
+  float *Wfc2, *dA1p;   // [actor.fc | critic.fc] stacked [2*HID, FEAT]; their dA1 side by side [B, 2*HID]
   int* krange;     // per 64-feature tile K range of the packed block-diagonal image
   double* acc;
 };
 // The head's fc product is [B,1280] x [1280,128]: 2 column tiles however large K is, so for B <= 2048 it is split over K
 // into slabs (GemmEpilogue::split_slab) that head_out_kernel sums -- 16x fewer K-tiles on the critical path at B = 256.
-inline int head_split_request(int B) {
-  const int tiles = mansy_ceil_div(B, 64) * (HID / 64);
+inline int head_split_request(int B, int n_cols = HID) {
+  const int tiles = mansy_ceil_div(B, 64) * (n_cols / 64);
   const int req = 256 / tiles;
   return req < 2 ? 1 : (req > 16 ? 16 : req);
 }
@@ -498,7 +515,8 @@ size_t ppo_layout(int maxB, char* base, PWork& W) {
   W.dHa = f((size_t)maxB * HID); W.dHc = f((size_t)maxB * HID); W.dA1a = f((size_t)maxB * HID); W.dA1c = f((size_t)maxB * HID);
   W.dF = f((size_t)maxB * FEAT); W.dWbd = f((size_t)FEAT * K_IDENT); W.dbbd = f(FEAT); W.obs_mb = f((size_t)maxB * OBS_LD);
   W.gout = f((size_t)maxB * MAXOUT); W.gout_c = f((size_t)maxB * MAXOUT);
-  W.A1s = f((size_t)head_slab_rows(maxB) * HID);
+  W.A1s = f((size_t)head_slab_rows(maxB) * 2 * HID);
+  W.Wfc2 = f((size_t)2 * HID * FEAT); W.dA1p = f((size_t)maxB * 2 * HID);
   W.acc = (double*)f(2 * 64);      // NORM_PARTS doubles (gradient-norm partial sums; also the identifier-loss accumulator)
   return tot + 256;
 }
@@ -507,10 +525,13 @@ size_t ppo_layout(int maxB, char* base, PWork& W) {
 
 struct PEng {
   hipStream_t st; PWork W;
-  int pack(const NetP& n, int identifier) {
+  // pair != nullptr: also stack the fc weights of (n, *pair) for head_pair()
+  int pack(const NetP& n, int identifier, const NetP* pair = nullptr) {
     PackArgs a; for (int j = 0; j < NB; ++j) { a.bw[j] = n.bw[j]; a.bb[j] = n.bb[j]; }
+    a.fc_a = n.fc_w; a.fc_c = pair ? pair->fc_w : nullptr; a.Wfc2 = pair ? W.Wfc2 : nullptr;
     const int K = identifier ? K_IDENT : K_POLICY;
-    hipLaunchKernelGGL(pack_wbd_kernel, dim3(mansy_ceil_div((long long)FEAT * KP, 256)), dim3(256), 0, st, a, identifier, K, W.Wbd, W.bbd, W.krange);
+    const long long threads = (long long)FEAT * KP + (pair ? 2LL * HID * FEAT : 0);
+    hipLaunchKernelGGL(pack_wbd_kernel, dim3(mansy_ceil_div(threads, 256)), dim3(256), 0, st, a, identifier, K, W.Wbd, W.bbd, W.krange);
     MANSY_LAUNCH_CHECK();
     return MANSY_OK;
   }
@@ -532,20 +553,54 @@ struct PEng {
       GemmEpilogue ep; ep.bias = n.fc_b; ep.relu = 1; ep.relu_slope = SLOPE;
       RC(mansy_launch_gemm_f32(W.F, FEAT, 0, n.fc_w, FEAT, 0, A1, HID, B, HID, FEAT, ep, 0, 0, st));
     }
-    hipLaunchKernelGGL(head_out_kernel, dim3(mansy_ceil_div(B, 4)), dim3(256), 0, st, A1, W.A1s, nsplit, (long long)B * HID, n.fc_b, W.F, n.out_w,
-                       n.out_b, n_out, sigmoid, H, out, MAXOUT, B, u, seed, site, act, logp);
+    HeadOutArgs ha;
+    ha.h[0] = {A1, n.fc_b, n.out_w, n.out_b, n_out, sigmoid, H, out, 0, act, logp};
+    ha.h[1] = ha.h[0];
+    hipLaunchKernelGGL(head_out_kernel, dim3(mansy_ceil_div(B, 4), 1), dim3(256), 0, st, ha, W.A1s, nsplit, (long long)B * HID, HID, W.F, MAXOUT, B, u,
+                       seed, site);
+    MANSY_LAUNCH_CHECK();
+    return MANSY_OK;
+  }
+  // actor + critic on the shared features in one product ([B,1280] x [1280,256], K-split slabs) and one head_out launch
+  int head_pair(const NetP& a, const NetP& c, int B) {
+    const int req = head_split_request(B, 2 * HID);
+    const int nsplit = mansy_gemm_effective_splits(FEAT, req);
+    GemmEpilogue ep; ep.split_slab = (long long)B * 2 * HID;
+    RC(mansy_launch_gemm_f32(W.F, FEAT, 0, W.Wfc2, FEAT, 0, W.A1s, 2 * HID, B, 2 * HID, FEAT, ep, 0, req, st));
+    HeadOutArgs ha;
+    ha.h[0] = {W.A1a, a.fc_b, a.out_w, a.out_b, NACT, 0, W.Ha, W.outa, 0, nullptr, nullptr};
+    ha.h[1] = {W.A1c, c.fc_b, c.out_w, c.out_b, 1, 0, W.Hc, W.outc, HID, nullptr, nullptr};
+    hipLaunchKernelGGL(head_out_kernel, dim3(mansy_ceil_div(B, 4), 2), dim3(256), 0, st, ha, W.A1s, nsplit, (long long)B * 2 * HID, 2 * HID, W.F, MAXOUT,
+                       B, nullptr, 0u, 0u);
     MANSY_LAUNCH_CHECK();
     return MANSY_OK;
   }
   // backward of one head given g = dL/d(out pre-sigmoid) [B,MAXOUT]: param grads + dF contribution (accumulate)
   int head_bwd(const NetP& n, int B, int n_out, const float* g, const float* A1, const float* H, float* dH, float* dA1, bool accumulate_dF) {
-    hipLaunchKernelGGL(head_out_bwd_kernel, dim3(min(mansy_ceil_div(B, 2), 128)), dim3(256), 0, st, g, MAXOUT, A1, H, n.out_w, n_out, dH, dA1, n.gout_w,
-                       n.gout_b, B);
+    HeadBwdArgs hb;
+    hb.h[0] = {g, MAXOUT, A1, H, n.out_w, n_out, dH, dA1, HID, n.gout_w, n.gout_b};
+    hb.h[1] = hb.h[0];
+    hipLaunchKernelGGL(head_out_bwd_kernel, dim3(min(mansy_ceil_div(B, 2), 128), 1), dim3(256), 0, st, hb, B);
     MANSY_LAUNCH_CHECK();
     GemmEpilogue acc; acc.accumulate = 1; acc.a_rowsum = n.gfc_b;                                           // gfc_b += column sums of dA1
     RC(mansy_launch_gemm_f32(dA1, HID, 1, W.F, FEAT, 1, n.gfc_w, FEAT, HID, FEAT, B, acc, 0, 0, st));      // gfc_w += dA1^T F
     GemmEpilogue ep; if (accumulate_dF) { ep.resid = W.dF; ep.resid_ld = FEAT; }
     return mansy_launch_gemm_f32(dA1, HID, 0, n.fc_w, FEAT, 1, W.dF, FEAT, B, FEAT, HID, ep, 0, 0, st);    // dF (+)= dA1 Wfc
+  }
+  // both heads' backward: one output-layer launch, the two fc weight gradients, ONE dF = [dA1a | dA1c] [Wfc_a ; Wfc_c] product
+  int head_bwd_pair(const NetP& a, const NetP& c, int B) {
+    HeadBwdArgs hb;
+    hb.h[0] = {W.gout, MAXOUT, W.A1a, W.Ha, a.out_w, NACT, W.dHa, W.dA1p, 2 * HID, a.gout_w, a.gout_b};
+    hb.h[1] = {W.gout_c, MAXOUT, W.A1c, W.Hc, c.out_w, 1, W.dHc, W.dA1p + HID, 2 * HID, c.gout_w, c.gout_b};
+    hipLaunchKernelGGL(head_out_bwd_kernel, dim3(min(mansy_ceil_div(B, 2), 128), 2), dim3(256), 0, st, hb, B);
+    MANSY_LAUNCH_CHECK();
+    GemmEpilogue acc; acc.accumulate = 1;
+    acc.a_rowsum = a.gfc_b;
+    RC(mansy_launch_gemm_f32(W.dA1p, 2 * HID, 1, W.F, FEAT, 1, a.gfc_w, FEAT, HID, FEAT, B, acc, 0, 0, st));
+    acc.a_rowsum = c.gfc_b;
+    RC(mansy_launch_gemm_f32(W.dA1p + HID, 2 * HID, 1, W.F, FEAT, 1, c.gfc_w, FEAT, HID, FEAT, B, acc, 0, 0, st));
+    GemmEpilogue ep;
+    return mansy_launch_gemm_f32(W.dA1p, 2 * HID, 0, W.Wfc2, FEAT, 1, W.dF, FEAT, B, FEAT, 2 * HID, ep, 0, 0, st);
   }
   int featnet_bwd(const NetP& n, const float* obs, int B, int identifier, const float* dHa, const float* dHb) {
     const int K = identifier ? K_IDENT : K_POLICY;
@@ -719,10 +774,9 @@ int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, fl
     hipLaunchKernelGGL(gather_rows_kernel, dim3(mansy_ceil_div((long long)mb * (OBS_LD / 4), 256)), dim3(256), 0, e.st, obs_all, idx, mb, OBS_LD, e.W.obs_mb);
     obs = e.W.obs_mb;
   }
-  RC(e.pack(a, 0));
+  RC(e.pack(a, 0, &c));
   RC(e.featnet(obs, mb, 0));
-  RC(e.head(a, mb, NACT, 0, e.W.A1a, e.W.Ha, e.W.outa, nullptr, 0, 0, nullptr, nullptr));
-  RC(e.head(c, mb, 1, 0, e.W.A1c, e.W.Hc, e.W.outc, nullptr, 0, 0, nullptr, nullptr));
+  RC(e.head_pair(a, c, mb));
   MANSY_HIP_CHECK(hipMemsetAsync(flat_g, 0, sizeof(float) * (size_t)n_flat, e.st));
   MANSY_HIP_CHECK(hipMemsetAsync(e.W.gout_c, 0, sizeof(float) * (size_t)mb * MAXOUT, e.st));
   PPOLossArgs la;
@@ -731,8 +785,7 @@ int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, fl
   la.value_clip = value_clip; la.adv_eps = 1e-8f; la.dlogits = e.W.gout; la.dvalue = e.W.gout_c; la.dvalue_ld = MAXOUT; la.stats = stats;
   hipLaunchKernelGGL(ppo_loss_kernel, dim3(1), dim3(1024), 0, e.st, la);
   MANSY_LAUNCH_CHECK();
-  RC(e.head_bwd(a, mb, NACT, e.W.gout, e.W.A1a, e.W.Ha, e.W.dHa, e.W.dA1a, false));
-  RC(e.head_bwd(c, mb, 1, e.W.gout_c, e.W.A1c, e.W.Hc, e.W.dHc, e.W.dA1c, true));
+  RC(e.head_bwd_pair(a, c, mb));
   RC(e.featnet_bwd(a, obs, mb, 0, e.W.dHa, e.W.dHc));
   return e.clip_and_adam(flat_p, flat_g, flat_m, flat_v, n_flat, max_grad_norm, lr, weight_decay, step);
 }
