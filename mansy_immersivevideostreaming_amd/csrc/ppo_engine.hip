@@ -154,15 +154,17 @@ __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const f
   const float h1 = a1 + F[(size_t)row * FEAT + RESID_COL + 64 + lane];
   if (H) { H[(size_t)row * HID + lane] = h0; H[(size_t)row * HID + 64 + lane] = h1; }
   float o[MAXOUT];
+  float w0[MAXOUT], w1[MAXOUT], bo[MAXOUT];     // loads first, at clamped indices: a predicate around each would serialise them
 #pragma unroll
   for (int k = 0; k < MAXOUT; ++k) {
-    o[k] = 0.f;
-    if (k < n_out) {
-      float p = h0 * Wout[k * HID + lane] + h1 * Wout[k * HID + 64 + lane];
-      p = wave_sum(p) + bout[k];
-      if (sigmoid) p = 1.f / (1.f + expf(-p));
-      o[k] = p;
-    }
+    const int kc = min(k, n_out - 1);
+    w0[k] = Wout[kc * HID + lane]; w1[k] = Wout[kc * HID + 64 + lane]; bo[k] = bout[kc];
+  }
+#pragma unroll
+  for (int k = 0; k < MAXOUT; ++k) {
+    float p = wave_sum(h0 * w0[k] + h1 * w1[k]) + bo[k];
+    if (sigmoid) p = 1.f / (1.f + expf(-p));
+    o[k] = k < n_out ? p : 0.f;
   }
   if (out && lane < n_out) {
     float mine = 0.f;
@@ -215,17 +217,21 @@ __global__ __launch_bounds__(256) void head_out_bwd_kernel(HeadBwdArgs args, int
   float aw[MAXOUT], ab[MAXOUT];
 #pragma unroll
   for (int k = 0; k < MAXOUT; ++k) { aw[k] = 0.f; ab[k] = 0.f; }
+  float wk[MAXOUT];                                  // this thread's column of the output weights (row-invariant)
+#pragma unroll
+  for (int k = 0; k < MAXOUT; ++k) wk[k] = Wout[min(k, n_out - 1) * HID + c];
   for (int row = blockIdx.x * 2 + half; row < rows; row += gridDim.x * 2) {
     float acc = 0.f;
     const float hv = H[(size_t)row * HID + c];
+    float gk[MAXOUT];
+#pragma unroll
+    for (int k = 0; k < MAXOUT; ++k) gk[k] = k < g_ld ? g[(size_t)row * g_ld + k] : 0.f;      // g rows are g_ld (>= n_out) wide
 #pragma unroll
     for (int k = 0; k < MAXOUT; ++k) {
-      if (k < n_out) {
-        const float gk = g[(size_t)row * g_ld + k];
-        acc = fmaf(gk, Wout[k * HID + c], acc);
-        aw[k] = fmaf(gk, hv, aw[k]);
-        if (c == 0) ab[k] += gk;
-      }
+      const float gm = k < n_out ? gk[k] : 0.f;
+      acc = fmaf(gm, wk[k], acc);
+      aw[k] = fmaf(gm, hv, aw[k]);
+      if (c == 0) ab[k] += gm;
     }
     dH[(size_t)row * HID + c] = acc;
     const float a1 = A1[(size_t)row * HID + c];
