@@ -338,35 +338,67 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   }
 }
 
+// circular k=3 im2col for the DistillLayer conv: col[row, ci*3 + t] = x[(b, (s + t - 1) mod S), ci].
+// V = 4: a thread takes 4 channels: three 16-byte row reads (s-1, s, s+1), three 16-byte stores (12 contiguous floats).
+template <int V>
 __global__ __launch_bounds__(256) void im2col3_kernel(const float* __restrict__ x, float* __restrict__ col, int B, int S, int C) {
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;     // over [B*S, C*3]
-  const long long total = (long long)B * S * C * 3;
-  if (idx >= total) return;
-  const int kk = (int)(idx % (3 * C));
-  const long long row = idx / (3 * C);
-  const int ci = kk / 3, t = kk % 3;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;     // over [B*S, C/V]
+  const int CV = C / V;
+  if (idx >= (long long)B * S * CV) return;
+  const int ci = (int)(idx % CV) * V;
+  const long long row = idx / CV;
   const int s = (int)(row % S);
   const long long b = row / S;
-  int sp = s + t - 1; if (sp < 0) sp += S; if (sp >= S) sp -= S;
-  col[idx] = x[(b * S + sp) * C + ci];
+  const int sm = s == 0 ? S - 1 : s - 1, sp = s == S - 1 ? 0 : s + 1;
+  float r0[V], r1[V], r2[V], o[3 * V];
+  if (V == 4) {
+    *reinterpret_cast<float4*>(r0) = *reinterpret_cast<const float4*>(x + (b * S + sm) * C + ci);
+    *reinterpret_cast<float4*>(r1) = *reinterpret_cast<const float4*>(x + (b * S + s) * C + ci);
+    *reinterpret_cast<float4*>(r2) = *reinterpret_cast<const float4*>(x + (b * S + sp) * C + ci);
+  } else {
+    r0[0] = x[(b * S + sm) * C + ci]; r1[0] = x[(b * S + s) * C + ci]; r2[0] = x[(b * S + sp) * C + ci];
+  }
+#pragma unroll
+  for (int j = 0; j < V; ++j) { o[3 * j] = r0[j]; o[3 * j + 1] = r1[j]; o[3 * j + 2] = r2[j]; }
+  float* dst = col + row * (3LL * C) + 3 * ci;
+  if (V == 4) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) *reinterpret_cast<float4*>(dst + 4 * q) = *reinterpret_cast<const float4*>(o + 4 * q);
+  } else {
+    dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
+  }
 }
+// dx[(b,s), ci] = sum_t dcol[(b, (s - t + 1) mod S), ci*3 + t].  V = 4: the 12 contiguous floats of each of the three
+// source rows are read as 3 float4 (a third of each is used; the other two thirds are the neighbours' and hit L2).
+template <int V>
 __global__ __launch_bounds__(256) void col2im3_kernel(const float* __restrict__ dcol, float* __restrict__ dx, int B, int S, int C) {
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;     // over [B*S, C]
-  const long long total = (long long)B * S * C;
-  if (idx >= total) return;
-  const int ci = (int)(idx % C);
-  const long long row = idx / C;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;     // over [B*S, C/V]
+  const int CV = C / V;
+  if (idx >= (long long)B * S * CV) return;
+  const int ci = (int)(idx % CV) * V;
+  const long long row = idx / CV;
   const int s = (int)(row % S);
   const long long b = row / S;
-  float acc = 0.f;
+  float acc[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) acc[j] = 0.f;
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
     int so = s - t + 1; if (so < 0) so += S; if (so >= S) so -= S;       // output position that read x[s] with tap t
-    acc += dcol[(b * S + so) * (3LL * C) + ci * 3 + t];
+    const float* src = dcol + (b * S + so) * (3LL * C) + 3 * ci;
+    float v[3 * V];
+    if (V == 4) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) *reinterpret_cast<float4*>(v + 4 * q) = *reinterpret_cast<const float4*>(src + 4 * q);
+    } else {
+      v[0] = src[0]; v[1] = src[1]; v[2] = src[2];
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] += v[3 * j + t];
   }
-  dx[idx] = acc;
+  if (V == 4) *reinterpret_cast<float4*>(dx + row * C + ci) = *reinterpret_cast<const float4*>(acc);
+  else dx[row * C + ci] = acc[0];
 }
-
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int ld, int rows, int C, float* __restrict__ out) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
@@ -577,9 +609,9 @@ int mansy_launch_adamw(float* p, const float* g, float* m, float* v, long long n
 
 int mansy_launch_im2col3(const float* x, float* col, int B, int S, int C, hipStream_t st) {
   MANSY_REQUIRE(x && col, "im2col3: null pointer");
-  const long long total = (long long)B * S * C * 3;
-  if (total <= 0) return MANSY_OK;
-  hipLaunchKernelGGL(im2col3_kernel, g1(total), dim3(256), 0, st, x, col, B, S, C);
+  if ((long long)B * S * C <= 0) return MANSY_OK;
+  if (C % 4 == 0 && al16(x) && al16(col)) hipLaunchKernelGGL(im2col3_kernel<4>, g1((long long)B * S * C / 4), dim3(256), 0, st, x, col, B, S, C);
+  else hipLaunchKernelGGL(im2col3_kernel<1>, g1((long long)B * S * C), dim3(256), 0, st, x, col, B, S, C);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }
@@ -587,7 +619,8 @@ int mansy_launch_col2im3(const float* dcol, float* dx, int B, int S, int C, hipS
   MANSY_REQUIRE(dcol && dx, "col2im3: null pointer");
   const long long total = (long long)B * S * C;
   if (total <= 0) return MANSY_OK;
-  hipLaunchKernelGGL(col2im3_kernel, g1(total), dim3(256), 0, st, dcol, dx, B, S, C);
+  if (C % 4 == 0 && al16(dcol) && al16(dx)) hipLaunchKernelGGL(col2im3_kernel<4>, g1(total / 4), dim3(256), 0, st, dcol, dx, B, S, C);
+  else hipLaunchKernelGGL(col2im3_kernel<1>, g1(total), dim3(256), 0, st, dcol, dx, B, S, C);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }

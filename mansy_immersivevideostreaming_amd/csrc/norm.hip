@@ -318,33 +318,62 @@ __global__ __launch_bounds__(256) void bn_elu_pool_kernel(const float* __restric
 }
 
 // stage 1: g[b,s,c] = dL/d(BN output) ; column sums of g and g*xhat -> doubles (stats[2C..4C))
+// g = dL/d(BN output) through the max-pool scatter and the ELU; per-channel [sum g, sum g*xhat] in double.
+// V = 4: a thread owns 4 channels (16-byte accesses) and every 2*gridDim.y-th row (V = 1: 1 channel, every gridDim.y-th);
+// the pooled-gradient loads are unconditional (a predicate around them made each row a dependent round trip).
+template <int V>
 __global__ __launch_bounds__(256) void distill_bwd_stage1(const float* __restrict__ conv, const float* __restrict__ dmem,
                                                           const unsigned char* __restrict__ argmax, const float* __restrict__ bn_w,
                                                           const float* __restrict__ bn_b, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, float* __restrict__ g, double* __restrict__ stats,
                                                           DistillShape s) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= s.C) return;
-  const float mu = mean[c], rs = rstd[c], w = bn_w[c], sh = bn_b[c];
-  double sg = 0.0, sgx = 0.0;
+  const int CV = s.C / V;
+  const int tpr = CV < 256 ? CV : 256;                  // threads per row (CV a multiple of 256, or a divisor of it)
+  const int rsub = threadIdx.x / tpr, rpw = 256 / tpr;  // row sub-stream of this thread, row streams per workgroup
+  const int c = (blockIdx.x * tpr + threadIdx.x % tpr) * V;
+  if (c >= s.C || rsub >= rpw) return;
+  float mu[V], rs[V], w[V], sh[V];
+  double sg[V], sgx[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) { mu[j] = mean[c + j]; rs[j] = rstd[c + j]; w[j] = bn_w[c + j]; sh[j] = bn_b[c + j]; sg[j] = 0.0; sgx[j] = 0.0; }
   const int rows = s.B * s.S;
-  for (int r = blockIdx.y; r < rows; r += gridDim.y) {
+  for (int r = blockIdx.y * rpw + rsub; r < rows; r += gridDim.y * rpw) {
     const int b = r / s.S, sp = r % s.S;
-    float up = 0.f;
-    // pooling windows containing sp: 2m-1 <= sp <= 2m+1  <=>  m in [sp/2, (sp+1)/2]
-    for (int m = sp / 2; m <= (sp + 1) / 2; ++m) {
-      if (m >= s.M) continue;
-      const long long mi = ((long long)b * s.M + m) * s.C + c;
-      if (argmax[mi] == (unsigned char)sp) up += dmem[mi];
+    // pooling windows containing sp: 2m-1 <= sp <= 2m+1  <=>  m in {sp/2, (sp+1)/2} (the same window twice when sp is even)
+    const int m0 = min(sp / 2, s.M - 1), m1 = min((sp + 1) / 2, s.M - 1);
+    const bool two = (sp + 1) / 2 != sp / 2 && (sp + 1) / 2 < s.M;
+    const bool one = sp / 2 < s.M;
+    const long long i0 = ((long long)b * s.M + m0) * s.C + c, i1 = ((long long)b * s.M + m1) * s.C + c;
+    float d0[V], d1[V], xv[V];
+    unsigned char a0[V], a1[V];
+    if (V == 4) {
+      *reinterpret_cast<float4*>(d0) = *reinterpret_cast<const float4*>(dmem + i0);
+      *reinterpret_cast<float4*>(d1) = *reinterpret_cast<const float4*>(dmem + i1);
+      *reinterpret_cast<float4*>(xv) = *reinterpret_cast<const float4*>(conv + (long long)r * s.C + c);
+      *reinterpret_cast<uchar4*>(a0) = *reinterpret_cast<const uchar4*>(argmax + i0);
+      *reinterpret_cast<uchar4*>(a1) = *reinterpret_cast<const uchar4*>(argmax + i1);
+    } else {
+      d0[0] = dmem[i0]; d1[0] = dmem[i1]; xv[0] = conv[(long long)r * s.C + c]; a0[0] = argmax[i0]; a1[0] = argmax[i1];
     }
-    const float xh = (conv[(long long)r * s.C + c] - mu) * rs;
-    const float ypre = xh * w + sh;
-    const float gg = up * (ypre > 0.f ? 1.f : expf(ypre));
-    g[(long long)r * s.C + c] = gg;
-    sg += gg; sgx += (double)gg * xh;
+    float gg[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      float up = 0.f;
+      if (one && a0[j] == (unsigned char)sp) up += d0[j];
+      if (two && a1[j] == (unsigned char)sp) up += d1[j];
+      const float xh = (xv[j] - mu[j]) * rs[j];
+      const float ypre = xh * w[j] + sh[j];
+      gg[j] = up * (ypre > 0.f ? 1.f : expf(ypre));
+      sg[j] += gg[j]; sgx[j] += (double)gg[j] * xh;
+    }
+    if (V == 4) *reinterpret_cast<float4*>(g + (long long)r * s.C + c) = *reinterpret_cast<const float4*>(gg);
+    else g[(long long)r * s.C + c] = gg[0];
   }
-  atomicAdd(stats + 2 * s.C + c, sg);
-  atomicAdd(stats + 3 * s.C + c, sgx);
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    atomicAdd(stats + 2 * s.C + c + j, sg[j]);
+    atomicAdd(stats + 3 * s.C + c + j, sgx[j]);
+  }
 }
 
 __global__ __launch_bounds__(256) void distill_bwd_stage2(const float* __restrict__ conv, const float* __restrict__ g,
@@ -434,8 +463,16 @@ int mansy_launch_distill_bwd(const float* conv, const float* dmem, const unsigne
                 "distill_bwd: null pointer");
   const int rows = s.B * s.S;
   MANSY_HIP_CHECK(hipMemsetAsync(stats_d + 2 * s.C, 0, sizeof(double) * 2 * s.C, st));
-  dim3 grid1(mansy_ceil_div(s.C, 256), min(rows, 512));
-  hipLaunchKernelGGL(distill_bwd_stage1, grid1, dim3(256), 0, st, conv, dmem, argmax, bn_w, bn_b, mean, rstd, g_tmp, stats_d, s);
+  auto al = [](const void* x) { return (reinterpret_cast<uintptr_t>(x) & 15) == 0; };
+  const int cv = s.C / 4;
+  if (s.C % 4 == 0 && (cv % 256 == 0 || 256 % cv == 0) && al(conv) && al(dmem) && al(g_tmp) && (reinterpret_cast<uintptr_t>(argmax) & 3) == 0) {
+    const int tpr = cv < 256 ? cv : 256;
+    dim3 grid1(mansy_ceil_div(cv, tpr), min(mansy_ceil_div(rows, 256 / tpr), 256));
+    hipLaunchKernelGGL(distill_bwd_stage1<4>, grid1, dim3(256), 0, st, conv, dmem, argmax, bn_w, bn_b, mean, rstd, g_tmp, stats_d, s);
+  } else {
+    dim3 grid1(mansy_ceil_div(s.C, 256), min(rows, 512));
+    hipLaunchKernelGGL(distill_bwd_stage1<1>, grid1, dim3(256), 0, st, conv, dmem, argmax, bn_w, bn_b, mean, rstd, g_tmp, stats_d, s);
+  }
   // parameter gradients use THIS rank's sums (the gradient all-reduce averages them); the input gradient needs the global ones
   MANSY_HIP_CHECK(hipMemcpyAsync(stats_d + 4 * s.C, stats_d + 2 * s.C, sizeof(double) * 2 * s.C, hipMemcpyDeviceToDevice, st));
   if (s.sync_world > 1) RC_HOOK(mansy_bn_sync_invoke(1));       // SyncBN backward: all-reduce [sum g, sum g*xhat]

@@ -32,10 +32,15 @@ def make_grad_sync(world):
     if world <= 1:
         return None
     inv = 1.0 / world
+    # RCCL averages inside the collective (one launch instead of all-reduce + scale); gloo (CPU tests) has no AVG
+    use_avg = dist.is_initialized() and dist.get_backend() == 'nccl'
 
     def grad_sync(flat_g):
-        dist.all_reduce(flat_g)
-        flat_g.mul_(inv)
+        if use_avg:
+            dist.all_reduce(flat_g, op=dist.ReduceOp.AVG)
+        else:
+            dist.all_reduce(flat_g)
+            flat_g.mul_(inv)
     return grad_sync
 
 
