@@ -227,6 +227,11 @@ int mansy_attn_bwd_dq(const float* Q, const float* K, const float* V, const floa
                       void* stream);
 int mansy_attn_kvgrad(const float* Q_all, long long q_ts, const float* dO_all, long long o_ts, const float* dS_all,
                       const float* Pk_all, float* dK, float* dV, const mansy_attn_shape* s, int T, int accum, void* stream);
+/* KV-cached self-attention backward, "pull" form (steps T-1 -> 0; s->Lk == step + 1): writes dQ of the step, its coefficient
+ * rows in dS_all / Pk_all [T][nb*H][T], and row `step` of the K/V gradient slabs complete (own term + later steps' terms). */
+int mansy_attn_bwd_selfpull(const float* Q_all, long long q_ts, const float* K, const float* V, const float* P_save,
+                            const float* dO_all, long long o_ts, float* dQ, float* dK, float* dV, float* dS_all, float* Pk_all,
+                            const mansy_attn_shape* s, int T, int step, float drop_p, uint32_t seed, uint32_t site, void* stream);
 
 /* ------------------------------------------------------------------ measurement hooks (bench.py) */
 /* HIP events around every GEMM launch on its own stream; collect() = device sync + summed ms, count, FLOPs. */

@@ -79,6 +79,7 @@ _PROTOS = {
     'mansy_ln_partials_reduce': [P, c_int, c_int, P, P, P],
     'mansy_attn_bwd_dq': [P, P, P, P, P, P, P, P, P, c_float, c_u32, c_u32, P],
     'mansy_attn_kvgrad': [P, c_ll, P, c_ll, P, P, P, P, P, c_int, c_int, P],
+    'mansy_attn_bwd_selfpull': [P, c_ll, P, P, P, P, c_ll, P, P, P, P, P, P, c_int, c_int, c_float, c_u32, c_u32, P],
     'mansy_env_state_bytes': [],
     'mansy_env_init': [P, c_int, c_int, c_int, c_int, P],
     'mansy_env_reset': [P, P, c_int, P, P],

@@ -397,6 +397,87 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_q1x4_kernel(AttnPtrs p, A
   }
 }
 
+// KV-cached decoder SELF-attention backward at step `step` (keys/values = steps 0..step, Lk = step+1), "pull" form.
+// The steps run T-1 -> 0, so when step i is processed every later step i' > i has already recorded its coefficients
+// dS_{i'}[.] / Pk_{i'}[.] (this kernel stores row i for the earlier steps).  Row i of the K/V gradient is then complete:
+//   dK_i = sum_{i' >= i} dS_{i'}[i] q_{i'}        dV_i = sum_{i' >= i} Pk_{i'}[i] dO_{i'}
+// and is written ONCE, instead of every step read-modify-writing rows 0..i (2 x 2 x (i+1) row accesses -> 2 x (T-i) reads).
+struct SelfPull {
+  const float* Q_all; long long q_ts;      // query rows of all steps: step i at Q_all + i*q_ts (+ b*q_bs)
+  const float* dO_all; long long o_ts;     // attention-output gradients of all steps (steps > `step` already written)
+  float* dS_all; float* Pk_all;            // [T][nb*H][T] coefficient rows
+  int T, step;
+};
+template <int LKT>
+__global__ __launch_bounds__(64 * WAVES) void attn_bwd_selfpull_q1x4_kernel(AttnPtrs p, AttnShape s, MansyDrop drop, SelfPull sp) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int hg = s.H >> 2;
+  const long long g = (long long)blockIdx.x * WAVES + wave;
+  if (g >= (long long)s.nb * hg) return;
+  const int b = (int)(g / hg), h = (int)(g % hg) * 4 + (lane >> 4), c = lane & 15;
+  const long long bh = (long long)b * s.H + h, nbh = (long long)s.nb * s.H;
+  const int Lk = s.Lk;                       // == sp.step + 1
+  const int col = h * 64 + c * 4;
+  const float4 q = *reinterpret_cast<const float4*>(sp.Q_all + sp.step * sp.q_ts + b * s.q_bs + col);
+  const float4 dO = *reinterpret_cast<const float4*>(sp.dO_all + sp.step * sp.o_ts + b * s.o_bs + col);
+  const float* Kb = p.K + b * s.k_bs + col;
+  const float* Vb = p.V + b * s.v_bs + col;
+  const float ds = drop.p > 0.f ? 1.f / (1.f - drop.p) : 1.f;
+  float4 k[LKT], vv[LKT];
+  float dP[LKT], P[LKT], keepf[LKT];
+#pragma unroll
+  for (int j = 0; j < LKT; ++j) {
+    const int jc = min(j, Lk - 1);
+    k[j] = *reinterpret_cast<const float4*>(Kb + jc * s.k_rs);
+    vv[j] = *reinterpret_cast<const float4*>(Vb + jc * s.v_rs);
+    P[j] = p.P[bh * Lk + jc];
+  }
+  float delta = 0.f;
+#pragma unroll
+  for (int j = 0; j < LKT; ++j) {
+    keepf[j] = 1.f;
+    if (drop.p > 0.f) keepf[j] = mansy_keep(drop.seed, drop.site, (uint32_t)(bh * Lk + j), drop.p) ? ds : 0.f;
+    if (j >= Lk) P[j] = 0.f;
+    dP[j] = group16_sum(dot4(dO, vv[j])) * keepf[j];
+    delta = fmaf(P[j], dP[j], delta);
+  }
+  float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
+  float dS_own = 0.f, Pk_own = 0.f;          // coefficients (step, step): this step's term of its own K/V row
+  float* dS_row = sp.dS_all + ((long long)sp.step * nbh + bh) * sp.T;
+  float* Pk_row = sp.Pk_all + ((long long)sp.step * nbh + bh) * sp.T;
+#pragma unroll
+  for (int j = 0; j < LKT; ++j) {
+    const float dSj = P[j] * (dP[j] - delta) * s.scale;      // 0 for j >= Lk
+    const float Pkj = P[j] * keepf[j];
+    dq.x = fmaf(dSj, k[j].x, dq.x); dq.y = fmaf(dSj, k[j].y, dq.y); dq.z = fmaf(dSj, k[j].z, dq.z); dq.w = fmaf(dSj, k[j].w, dq.w);
+    if (j == Lk - 1) { dS_own = dSj; Pk_own = Pkj; }
+    if (c == j && j < Lk) { dS_row[j] = dSj; Pk_row[j] = Pkj; }
+  }
+  *reinterpret_cast<float4*>(p.dQ + b * s.q_bs + col) = dq;
+  float4 dk = make_float4(dS_own * q.x, dS_own * q.y, dS_own * q.z, dS_own * q.w);
+  float4 dv = make_float4(Pk_own * dO.x, Pk_own * dO.y, Pk_own * dO.z, Pk_own * dO.w);
+  for (int i0 = sp.step + 1; i0 < sp.T; i0 += 4) {          // later steps, four at a time: 8 row loads in flight
+    float4 qn[4], gn[4];
+    float a[4], bb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int ic = min(i0 + u, sp.T - 1);
+      qn[u] = *reinterpret_cast<const float4*>(sp.Q_all + ic * sp.q_ts + b * s.q_bs + col);
+      gn[u] = *reinterpret_cast<const float4*>(sp.dO_all + ic * sp.o_ts + b * s.o_bs + col);
+      const long long ci = ((long long)ic * nbh + bh) * sp.T + sp.step;
+      a[u] = sp.dS_all[ci]; bb[u] = sp.Pk_all[ci];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float au = i0 + u < sp.T ? a[u] : 0.f, bu = i0 + u < sp.T ? bb[u] : 0.f;
+      dk.x = fmaf(au, qn[u].x, dk.x); dk.y = fmaf(au, qn[u].y, dk.y); dk.z = fmaf(au, qn[u].z, dk.z); dk.w = fmaf(au, qn[u].w, dk.w);
+      dv.x = fmaf(bu, gn[u].x, dv.x); dv.y = fmaf(bu, gn[u].y, dv.y); dv.z = fmaf(bu, gn[u].z, dv.z); dv.w = fmaf(bu, gn[u].w, dv.w);
+    }
+  }
+  *reinterpret_cast<float4*>(p.dK + b * s.k_bs + sp.step * s.k_rs + col) = dk;
+  *reinterpret_cast<float4*>(p.dV + b * s.v_bs + sp.step * s.v_rs + col) = dv;
+}
+
 // Deferred K/V gradients of a Lq == 1 attention evaluated at TT query steps against the SAME K/V rows (decoder
 // cross-attention: every step attends to the distilled memory):
 //   dK[j] = sum_i dS_i[j] * q_i        dV[j] = sum_i Pk_i[j] * dO_i
@@ -704,6 +785,28 @@ int mansy_launch_attn_kvgrad(const float* Q_all, long long q_ts, const float* dO
 #define MANSY_KVGRAD_ARGS dim3(mansy_ceil_div(n / 4, WAVES)), dim3(64 * WAVES), 0, st, Q_all, q_ts, dO_all, o_ts, dS_all, Pk_all, dK, dV, s, T, accum
   MANSY_Q1X4_DISPATCH(attn_kvgrad_q1x4_kernel, T, MANSY_KVGRAD_ARGS)
 #undef MANSY_KVGRAD_ARGS
+  MANSY_LAUNCH_CHECK();
+  return MANSY_OK;
+}
+
+// ---- decoder self-attention backward, pull form (see attn_bwd_selfpull_q1x4_kernel).  s.Lk must equal step + 1.
+// Q_all / dO_all: step i at + i*q_ts / + i*o_ts floats; dS_all / Pk_all: [T][nb*H][T] (rows > step already written by the
+// calls for the later steps; this call writes row `step`).  dQ: this step's [nb, H*64]; dK / dV: K/V gradient slabs, row `step`
+// is overwritten.
+int mansy_attn_selfpull_ok(const AttnShape& s, int T) { return mansy_attn_deferred_kv_ok(s, T); }
+int mansy_launch_attn_bwd_selfpull(const float* Q_all, long long q_ts, const float* K, const float* V, const float* P_save,
+                                   const float* dO_all, long long o_ts, float* dQ, float* dK, float* dV, float* dS_all, float* Pk_all,
+                                   const AttnShape& s, int T, int step, MansyDrop drop, hipStream_t st) {
+  int rc = check_shape(s); if (rc) return rc;
+  MANSY_REQUIRE(Q_all && K && V && P_save && dO_all && dQ && dK && dV && dS_all && Pk_all, "attn_bwd_selfpull: null pointer");
+  MANSY_REQUIRE(step >= 0 && step < T && s.Lk == step + 1 && mansy_attn_selfpull_ok(s, T) && (q_ts % 4) == 0 && (o_ts % 4) == 0,
+                "attn_bwd_selfpull: unsupported shape (Lk=%d step=%d T=%d)", s.Lk, step, T);
+  MANSY_REQUIRE(q1x4_ok(s, Q_all, K, V, dO_all) && q1x4_ok(s, dQ, dK, dV, dO_all), "attn_bwd_selfpull: alignment");
+  const long long n = (long long)s.nb * s.H;
+  if (n == 0) return MANSY_OK;
+  AttnPtrs p = {nullptr, K, V, nullptr, const_cast<float*>(P_save), nullptr, dQ, dK, dV, nullptr, nullptr};
+  SelfPull sp = {Q_all, q_ts, dO_all, o_ts, dS_all, Pk_all, T, step};
+  MANSY_Q1X4_DISPATCH(attn_bwd_selfpull_q1x4_kernel, s.Lk, dim3(mansy_ceil_div(n / 4, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop, sp)
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }

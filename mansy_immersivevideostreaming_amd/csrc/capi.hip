@@ -95,6 +95,15 @@ int mansy_attn_kvgrad(const float* Q_all, long long q_ts, const float* dO_all, l
   return mansy_launch_attn_kvgrad(Q_all, q_ts, dO_all, o_ts, dS_all, Pk_all, dK, dV, to_shape(s), T, accum, (hipStream_t)stream);
 }
 
+int mansy_attn_bwd_selfpull(const float* Q_all, long long q_ts, const float* K, const float* V, const float* P_save,
+                            const float* dO_all, long long o_ts, float* dQ, float* dK, float* dV, float* dS_all, float* Pk_all,
+                            const mansy_attn_shape* s, int T, int step, float drop_p, uint32_t seed, uint32_t site, void* stream) {
+  MANSY_REQUIRE(s, "attn_bwd_selfpull: null shape");
+  MansyDrop d = {drop_p, seed, site};
+  return mansy_launch_attn_bwd_selfpull(Q_all, q_ts, K, V, P_save, dO_all, o_ts, dQ, dK, dV, dS_all, Pk_all, to_shape(s), T, step, d,
+                                        (hipStream_t)stream);
+}
+
 int mansy_mtio_mix(const float* x, const int* perm1, const int* perm2, float* out, int B, int L, int c, void* stream) {
   return mansy_launch_mtio_mix(x, perm1, perm2, out, B, L, c, (hipStream_t)stream);
 }

@@ -67,6 +67,14 @@ int mansy_launch_attn_bwd_dq(const float* Q, const float* K, const float* V, con
 int mansy_launch_attn_kvgrad(const float* Q_all, long long q_ts, const float* dO_all, long long o_ts, const float* dS_all,
                              const float* Pk_all, float* dK, float* dV, const AttnShape& s, int T, int accum, hipStream_t st);
 
+// KV-cached decoder self-attention backward, "pull" form: the steps run T-1 -> 0; the call for step i records its coefficient
+// rows and writes row i of the K/V gradient complete (own term + the terms of the later steps, read from the Q / dO slabs),
+// so no K/V gradient row is ever read-modify-written and the slab needs no zero-fill.  s.Lk == step + 1.
+int mansy_attn_selfpull_ok(const AttnShape& s, int T);
+int mansy_launch_attn_bwd_selfpull(const float* Q_all, long long q_ts, const float* K, const float* V, const float* P_save,
+                                   const float* dO_all, long long o_ts, float* dQ, float* dK, float* dV, float* dS_all, float* Pk_all,
+                                   const AttnShape& s, int T, int step, MansyDrop drop, hipStream_t st);
+
 // ---------------------------------------------------------------- norms (norm.hip)
 // z = a (+ b);  y = LN(z) * w (+ bias).  z_out may be null (not saved) or alias a when b == null.
 int mansy_launch_layernorm_fwd(const float* a, const float* b, const float* w, const float* bias, float* z_out,

@@ -118,6 +118,7 @@ struct DecBuf {
   float *memkv, *qkv, *P1, *ao1, *z1, *m1, *r1, *y1, *qc, *P2, *ao2, *z2, *m2, *r2, *y2, *h, *z3, *m3, *r3, *y3;
   float *dqkv, *dbr1, *dqc, *dbr2, *da, *dbr3, *dmemkv;   // backward slabs (deferred dW operands)
   float *dao2, *dS2, *Pk2;                                // deferred cross-attention K/V gradient operands (attn.hip kvgrad)
+  float *dao1, *dS1, *Pk1;                                // self-attention backward, pull form (attn.hip selfpull)
 };
 struct Work {
   float *src6, *cur6, *fut6, *pred_bt, *dpred_bt;           // train_step staging
@@ -182,6 +183,7 @@ void build_layout(const mansy_vp_config& c, Layout& L, Work& W) {
     e.dbr2 = L.f(p + "dbr2", TB * d); e.da = L.f(p + "da", TB * f); e.dbr3 = L.f(p + "dbr3", TB * d);
     e.dmemkv = L.f(p + "dmemkv", B * M * 2 * d);
     e.dao2 = L.f(p + "dao2", TB * d); e.dS2 = L.f(p + "dS2", TB * H * M); e.Pk2 = L.f(p + "Pk2", TB * H * M);
+    e.dao1 = L.f(p + "dao1", TB * d); e.dS1 = L.f(p + "dS1", TB * H * T); e.Pk1 = L.f(p + "Pk1", TB * H * T);
   }
   W.dec_out = L.f("dec.out", TB * d); W.md = L.f("dec.md", TB); W.rd = L.f("dec.rd", TB);
   W.t_enc = L.f("tmp.t_enc", N * d); W.t_dec = L.f("tmp.t_dec", B * d);
@@ -344,8 +346,11 @@ struct Eng {
     // apply) the steps only record their coefficients and ONE pass per layer forms dK/dV -- instead of T read-modify-write
     // passes over the [B*M, 2d] gradient rows.
     const bool defer_cross = mansy_attn_deferred_kv_ok(cross_shape(), T) != 0;
+    // Self-attention K/V gradients in pull form (same condition): row i of the gradient slab is written once, complete, by
+    // the call for step i -- no read-modify-write of rows 0..i at every step, no zero-fill of the slab.
+    const bool pull_self = mansy_attn_selfpull_ok(self_shape(T - 1), T) != 0;
     for (int l = 0; l < c.n_dec; ++l) {
-      MANSY_HIP_CHECK(hipMemsetAsync(W.dec[l].dqkv, 0, sizeof(float) * (size_t)TB * 3 * d, st));
+      if (!pull_self) MANSY_HIP_CHECK(hipMemsetAsync(W.dec[l].dqkv, 0, sizeof(float) * (size_t)TB * 3 * d, st));
       if (!defer_cross) MANSY_HIP_CHECK(hipMemsetAsync(W.dec[l].dmemkv, 0, sizeof(float) * (size_t)B * M * 2 * d, st));
     }
     const bool ln_parts = mansy_ln_bwd_partial_ok(d);
@@ -383,10 +388,17 @@ struct Eng {
         RC(lin_dx(e.dqc + o * d, B, d, p.ca_in.w, d, gt, gz, nullptr, 1.f));                // gt = d/dy1
         // norm1( x + drop(sa_out(ao1)) )
         RC(ln_bwd(gt, e.z1 + o * d, e.m1 + o, e.r1 + o, p.n1, gz, e.dbr1 + o * d, dr(site_dec(l, i, 1), c.p_drop), B, 3 * l + 0));
-        RC(lin_dx(e.dbr1 + o * d, B, d, p.sa_out.w, d, gt, nullptr, nullptr, 1.f));         // gt = d/dao1
         float* dqkv_i = e.dqkv + o * 3 * d;
-        RC(mansy_launch_attn_bwd(e.qkv + o * 3 * d, e.qkv + d, e.qkv + 2 * d, e.P1 + o * H * T, gt, dqkv_i, e.dqkv + d, e.dqkv + 2 * d,
-                                 self_shape(i), dr(site_dec(l, i, 0), c.p_drop), 1, st));
+        if (pull_self) {
+          RC(lin_dx(e.dbr1 + o * d, B, d, p.sa_out.w, d, e.dao1 + o * d, nullptr, nullptr, 1.f));   // d/dao1, kept: later rows of dV pull it
+          RC(mansy_launch_attn_bwd_selfpull(e.qkv, (long long)B * 3 * d, e.qkv + d, e.qkv + 2 * d, e.P1 + o * H * T, e.dao1, (long long)B * d,
+                                            dqkv_i, e.dqkv + d, e.dqkv + 2 * d, e.dS1, e.Pk1, self_shape(i), T, i,
+                                            dr(site_dec(l, i, 0), c.p_drop), st));
+        } else {
+          RC(lin_dx(e.dbr1 + o * d, B, d, p.sa_out.w, d, gt, nullptr, nullptr, 1.f));       // gt = d/dao1
+          RC(mansy_launch_attn_bwd(e.qkv + o * 3 * d, e.qkv + d, e.qkv + 2 * d, e.P1 + o * H * T, gt, dqkv_i, e.dqkv + d, e.dqkv + 2 * d,
+                                   self_shape(i), dr(site_dec(l, i, 0), c.p_drop), 1, st));
+        }
         RC(lin_dx(dqkv_i, B, 3 * d, p.sa_in.w, d, gx, gz, nullptr, 1.f));                   // gx = d/d(layer input)
       }
       // embedding of the fed-back token: dE slab (masked) + gradient wrt pred_{i-1}

@@ -166,6 +166,31 @@ def attn_cross_stepwise(q_all, memkv, P_all, dO_all, H, drop_sites=None, p_drop=
     return dq, dkv
 
 
+def attn_self_decode_bwd(qkv_all, P_all, dO_all, H, drop_sites=None, p_drop=0.0, seed=0, pull=True):
+    """KV-cached decoder self-attention backward over T steps.  qkv_all [T, B, 3d] (step-major slab = the KV cache),
+    P_all [T, B*H, T] (row i holds i+1 probabilities, packed with stride i+1 like the engine's), dO_all [T, B, d].
+    pull=True: the engine's pull form; False: T accumulating read-modify-write calls.  Returns dqkv_all [T, B, 3d]."""
+    _gpu(qkv_all, P_all, dO_all)
+    T, B, d3 = qkv_all.shape
+    d = d3 // 3
+    dqkv = torch.empty_like(qkv_all) if pull else torch.zeros_like(qkv_all)
+    dS = torch.empty(T, B * H, T, dtype=torch.float32, device=qkv_all.device)
+    Pk = torch.empty_like(dS)
+    base, gb = qkv_all.data_ptr(), dqkv.data_ptr()
+    st = stream_ptr(qkv_all.device)
+    for i in range(T - 1, -1, -1):
+        s = _attn_shape(B, H, 1, i + 1, d // H, (d3, 0), (d3, B * d3), (d3, B * d3), (d, 0))
+        site = drop_sites[i] if drop_sites is not None else 0
+        if pull:
+            check(lib().mansy_attn_bwd_selfpull(base, B * d3, base + 4 * d, base + 8 * d, ptr(P_all[i]), ptr(dO_all), B * d,
+                                                gb + 4 * i * B * d3, gb + 4 * d, gb + 8 * d, ptr(dS), ptr(Pk), ctypes.byref(s), T, i,
+                                                p_drop, seed, site, st), 'mansy_attn_bwd_selfpull')
+        else:
+            check(lib().mansy_attn_bwd(base + 4 * i * B * d3, base + 4 * d, base + 8 * d, ptr(P_all[i]), ptr(dO_all[i]),
+                                       gb + 4 * i * B * d3, gb + 4 * d, gb + 8 * d, ctypes.byref(s), p_drop, seed, site, 1, st), 'mansy_attn_bwd')
+    return dqkv
+
+
 def tilemap(xy, W=2560, H=1440, nw=8, nh=8, fov_w=600, fov_h=300):
     """xy [...,2] float32 normalised centres -> uint64 hit maps as int64 tensor [...] (bit row*nw+col)."""
     _gpu(xy)

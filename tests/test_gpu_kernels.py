@@ -213,6 +213,24 @@ def test_attn_cross_deferred_kv_grads_match_stepwise(K, T, B, M, p):
         torch.testing.assert_close(dq2.double(), qh.grad.reshape(T, B, d), rtol=0, atol=5e-5)
 
 
+@pytest.mark.parametrize('T,B,p', [(10, 33, 0.1), (4, 8, 0.0), (16, 5, 0.1), (1, 4, 0.1)])
+def test_attn_self_decode_pull_matches_stepwise(K, T, B, p):
+    """Pull-form self-attention backward (each K/V gradient row written once) == the read-modify-write form."""
+    H, d = 8, 512
+    g = torch.Generator().manual_seed(T * 10 + B)
+    qkv = torch.randn(T, B, 3 * d, generator=g).cuda()
+    dO = torch.randn(T, B, d, generator=g).cuda()
+    P = torch.zeros(T, B * H, T)
+    for i in range(T):        # row i: i+1 probabilities per (batch, head), packed with stride i+1 at the start of the step's block
+        pi = torch.softmax(torch.randn(B * H, i + 1, generator=g), dim=-1)
+        P[i].view(-1)[:B * H * (i + 1)] = pi.reshape(-1)
+    P = P.cuda()
+    sites = [10000 + 8 * i for i in range(T)]
+    ref = K.attn_self_decode_bwd(qkv, P, dO, H, sites, p, 321, pull=False)
+    got = K.attn_self_decode_bwd(qkv, P, dO, H, sites, p, 321, pull=True)
+    torch.testing.assert_close(got, ref, rtol=1e-5, atol=2e-5)
+
+
 def test_tilemap_bit_exact_vs_oracle_and_reference_goldens(K):
     from oracle import tilemap as tm
     z = np.load(os.path.join(G, 'tilemap_px.npz'))
