@@ -12,6 +12,9 @@ namespace {
 
 constexpr int LN_MAXV = 4;     // float4 per lane -> C <= 1024
 
+// NV = C / 256 float4 per lane.  One wave per row (several rows per wave when there are more rows than waves); every load of a
+// row is issued before its first store (z_out may alias a: the compiler keeps loads behind earlier stores).
+template <int NV>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                             const float* __restrict__ w, const float* __restrict__ bias,
                                                             float* __restrict__ z_out, float* __restrict__ y,
@@ -20,44 +23,49 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   const int lane = threadIdx.x & 63;
   const int wave_global = (blockIdx.x * 256 + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * 256) >> 6;
-  const int nv = C >> 8;     // float4 per lane (C multiple of 256)
+  float4 wv[NV], bv[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { wv[i] = *reinterpret_cast<const float4*>(w + (i * 64 + lane) * 4); bv[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+  if (bias) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) bv[i] = *reinterpret_cast<const float4*>(bias + (i * 64 + lane) * 4);
+  }
   for (int row = wave_global; row < rows; row += nwaves) {
-    float4 v[LN_MAXV];
+    const long long base = (long long)row * C + lane * 4;
+    float4 v[NV], rv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { v[i] = *reinterpret_cast<const float4*>(a + base + i * 256); rv[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    if (b) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) rv[i] = *reinterpret_cast<const float4*>(b + base + i * 256);
+    }
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      if (i < nv) {
-        const long long off = (long long)row * C + (i * 64 + lane) * 4;
-        float4 x = *reinterpret_cast<const float4*>(a + off);
-        if (b) { const float4 r = *reinterpret_cast<const float4*>(b + off); x.x += r.x; x.y += r.y; x.z += r.z; x.w += r.w; }
-        if (z_out) *reinterpret_cast<float4*>(z_out + off) = x;
-        v[i] = x;
-        s += (x.x + x.y) + (x.z + x.w);
-      }
+    for (int i = 0; i < NV; ++i) {
+      if (b) { v[i].x += rv[i].x; v[i].y += rv[i].y; v[i].z += rv[i].z; v[i].w += rv[i].w; }
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    if (z_out) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) *reinterpret_cast<float4*>(z_out + base + i * 256) = v[i];
     }
     const float mu = wave_sum(s) / (float)C;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      if (i < nv) {
-        const float dx = v[i].x - mu, dy = v[i].y - mu, dz = v[i].z - mu, dw = v[i].w - mu;
-        q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-      }
+    for (int i = 0; i < NV; ++i) {
+      const float dx = v[i].x - mu, dy = v[i].y - mu, dz = v[i].z - mu, dw = v[i].w - mu;
+      q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
     }
     const float var = wave_sum(q) / (float)C;
     const float rs = 1.0f / sqrtf(var + eps);
     if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      if (i < nv) {
-        const int c = (i * 64 + lane) * 4;
-        const float4 ww = *reinterpret_cast<const float4*>(w + c);
-        float4 o;
-        o.x = (v[i].x - mu) * rs * ww.x; o.y = (v[i].y - mu) * rs * ww.y;
-        o.z = (v[i].z - mu) * rs * ww.z; o.w = (v[i].w - mu) * rs * ww.w;
-        if (bias) { const float4 bb = *reinterpret_cast<const float4*>(bias + c); o.x += bb.x; o.y += bb.y; o.z += bb.z; o.w += bb.w; }
-        *reinterpret_cast<float4*>(y + (long long)row * C + c) = o;
-      }
+    for (int i = 0; i < NV; ++i) {
+      float4 o;
+      o.x = (v[i].x - mu) * rs * wv[i].x; o.y = (v[i].y - mu) * rs * wv[i].y;
+      o.z = (v[i].z - mu) * rs * wv[i].z; o.w = (v[i].w - mu) * rs * wv[i].w;
+      if (bias) { o.x += bv[i].x; o.y += bv[i].y; o.z += bv[i].z; o.w += bv[i].w; }
+      *reinterpret_cast<float4*>(y + base + i * 256) = o;
     }
   }
 }
@@ -403,9 +411,14 @@ int mansy_launch_layernorm_fwd(const float* a, const float* b, const float* w, c
   MANSY_REQUIRE(a && w && y, "layernorm_fwd: null pointer");
   if (rows <= 0) return MANSY_OK;
   const int grid = min(mansy_ceil_div(rows, 4), 2048);
-  if ((C % 256) == 0 && C <= 256 * LN_MAXV)
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid), dim3(256), 0, st, a, b, w, bias, z_out, y, mean, rstd, rows, C, eps);
-  else
+  if ((C % 256) == 0 && C <= 256 * LN_MAXV) {
+    switch (C / 256) {
+      case 1: hipLaunchKernelGGL(layernorm_fwd_kernel<1>, dim3(grid), dim3(256), 0, st, a, b, w, bias, z_out, y, mean, rstd, rows, C, eps); break;
+      case 2: hipLaunchKernelGGL(layernorm_fwd_kernel<2>, dim3(grid), dim3(256), 0, st, a, b, w, bias, z_out, y, mean, rstd, rows, C, eps); break;
+      case 3: hipLaunchKernelGGL(layernorm_fwd_kernel<3>, dim3(grid), dim3(256), 0, st, a, b, w, bias, z_out, y, mean, rstd, rows, C, eps); break;
+      default: hipLaunchKernelGGL(layernorm_fwd_kernel<4>, dim3(grid), dim3(256), 0, st, a, b, w, bias, z_out, y, mean, rstd, rows, C, eps); break;
+    }
+  } else
     hipLaunchKernelGGL(layernorm_fwd_generic, dim3(grid), dim3(256), 0, st, a, b, w, bias, z_out, y, mean, rstd, rows, C, eps);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
