@@ -103,20 +103,18 @@ __global__ __launch_bounds__(256) void pack_wbd_kernel(PackArgs a, int identifie
   Wbd[idx] = v;
   if (col == 0) bbd[row] = a.bb[j][r];
 }
-struct UnpackArgs { float* gbw[NB]; };
-__global__ __launch_bounds__(256) void unpack_dwbd_kernel(const float* __restrict__ dWbd, int identifier, int K, UnpackArgs a) {
+// packed gradients -> the compact reference-layout parameter gradients: block-diagonal entries of dWbd [FEAT, K] and the
+// packed bias gradient dbbd [FEAT] (first FEAT threads) are added to the ten branches' weight / bias gradients.
+struct UnpackArgs { float* gbw[NB]; float* gbb[NB]; };
+__global__ __launch_bounds__(256) void unpack_dwbd_kernel(const float* __restrict__ dWbd, const float* __restrict__ dbbd, int identifier, int K,
+                                                          UnpackArgs a) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx < FEAT) a.gbb[idx / HID][idx % HID] += dbbd[idx];
   if (idx >= (long long)FEAT * K) return;
   const int col = (int)(idx % K), row = (int)(idx / K);
   const int j = row / HID, r = row % HID;
   const Branch g = branch_geom(j, identifier);
   if (col >= g.off && col < g.off + g.len) a.gbw[j][r * g.len + (col - g.off)] += dWbd[idx];
-}
-struct BiasGradArgs { float* gbb[NB]; };
-__global__ __launch_bounds__(256) void scatter_bias_grad_kernel(const float* __restrict__ dbbd, BiasGradArgs a) {
-  const int row = blockIdx.x * 256 + threadIdx.x;
-  if (row >= FEAT) return;
-  a.gbb[row / HID][row % HID] += dbbd[row];
 }
 
 // one wave per (row, head): H = A1 + F[:, resid] ; out[k] = H . Wout[k] + b[k] (k < n_out <= 16), optional sigmoid;
@@ -614,10 +612,8 @@ struct PEng {
                        W.dbbd);
     GemmEpilogue ep; ep.a_rowsum = W.dbbd;                                                                   // dbbd = column sums of dPre
     RC(mansy_launch_gemm_f32(W.dF, FEAT, 1, obs, OBS_LD, 1, W.dWbd, K, FEAT, K, B, ep, 0, 1, st));           // dWbd = dPre^T obs
-    UnpackArgs u; for (int j = 0; j < NB; ++j) u.gbw[j] = n.gbw[j];
-    hipLaunchKernelGGL(unpack_dwbd_kernel, dim3(mansy_ceil_div((long long)FEAT * K, 256)), dim3(256), 0, st, W.dWbd, identifier, K, u);
-    BiasGradArgs bg; for (int j = 0; j < NB; ++j) bg.gbb[j] = n.gbb[j];
-    hipLaunchKernelGGL(scatter_bias_grad_kernel, dim3(mansy_ceil_div(FEAT, 256)), dim3(256), 0, st, W.dbbd, bg);
+    UnpackArgs u; for (int j = 0; j < NB; ++j) { u.gbw[j] = n.gbw[j]; u.gbb[j] = n.gbb[j]; }
+    hipLaunchKernelGGL(unpack_dwbd_kernel, dim3(mansy_ceil_div((long long)FEAT * K, 256)), dim3(256), 0, st, W.dWbd, W.dbbd, identifier, K, u);
     MANSY_LAUNCH_CHECK();
     return MANSY_OK;
   }
@@ -698,7 +694,7 @@ int mansy_identifier_train_step(const float* const* params, float* const* grads,
   RC(e.head(n, B, 3, 1, e.W.A1a, e.W.Ha, e.W.outa, nullptr, 0, 0, nullptr, nullptr));
   MANSY_HIP_CHECK(hipMemsetAsync(e.W.acc, 0, sizeof(double), e.st));
   const bool train = step != 0;        // step < 0: gradients only (data-parallel callers all-reduce, then mansy_clip_grad_adam)
-  if (train) MANSY_HIP_CHECK(hipMemsetAsync(e.W.gout, 0, sizeof(float) * (size_t)B * MAXOUT, e.st));
+  // (gout needs no zero-fill: head_out_bwd_kernel selects columns < n_out and never uses the rest)
   hipLaunchKernelGGL(ident_mse_kernel, dim3(min(mansy_ceil_div(B * 3, 256), 256)), dim3(256), 0, e.st, e.W.outa, obs, B, train ? e.W.gout : nullptr, e.W.acc);
   hipLaunchKernelGGL(ident_mse_finish, dim3(1), dim3(1), 0, e.st, e.W.acc, B, loss_out);
   MANSY_LAUNCH_CHECK();
@@ -784,7 +780,6 @@ int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, fl
   RC(e.featnet(obs, mb, 0));
   RC(e.head_pair(a, c, mb));
   MANSY_HIP_CHECK(hipMemsetAsync(flat_g, 0, sizeof(float) * (size_t)n_flat, e.st));
-  MANSY_HIP_CHECK(hipMemsetAsync(e.W.gout_c, 0, sizeof(float) * (size_t)mb * MAXOUT, e.st));
   PPOLossArgs la;
   la.logits = e.W.outa; la.value = e.W.outc; la.value_ld = MAXOUT; la.act = act_all; la.adv = adv_all; la.logp_old = logp_old_all; la.v_old = v_old_all;
   la.ret = ret_all; la.idx = idx; la.n = mb; la.eps_clip = eps_clip; la.vf_coef = vf_coef; la.ent_coef = ent_coef; la.norm_adv = norm_adv;
