@@ -322,6 +322,91 @@ __global__ __launch_bounds__(256) void lab_dma2(const float* __restrict__ A, con
   }
 }
 
+// lab_dma3: lab_dma2 (ORDER 0) with the K-tile depth BKT (32 / 64) and the number of LDS buffers NBUF (2 / 3) as parameters.
+// Row image = BKT floats; 16-B chunk c of a row in slot c ^ (row & 7) (low 3 bits).
+template <int BM, int BN, int BKT, int NBUF>
+__global__ __launch_bounds__(256) void lab_dma3(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N, int K) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int CPR = BKT / 4, RPI = 64 / CPR;            // chunks per row, rows per DMA piece
+  constexpr int PA = BM / (RPI * 4), PB = BN / (RPI * 4);  // pieces per wave
+  constexpr int AF = BM * BKT, BF = BN * BKT, STAGE = AF + BF;
+  constexpr int CF = BM * (BN + 4);
+  constexpr int SM = NBUF * STAGE > CF ? NBUF * STAGE : CF;
+  __shared__ __attribute__((aligned(1024))) float smem[SM];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+  int tile_x, tile_y; tile_coords(tile_x, tile_y);
+  const int m0 = tile_y * BM, n0 = tile_x * BN, nk = K / BKT;
+  unsigned voa[PA], vob[PB];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) { const int row = (i * 4 + wave) * RPI + lane / CPR; voa[i] = (unsigned)(row * K + (((lane % CPR) ^ (row & 7)) * 4)) * 4u; }
+#pragma unroll
+  for (int i = 0; i < PB; ++i) { const int row = (i * 4 + wave) * RPI + lane / CPR; vob[i] = (unsigned)(row * K + (((lane % CPR) ^ (row & 7)) * 4)) * 4u; }
+  const unsigned lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem + wave * 1024u);
+  const float* sa = A + (long long)m0 * K;
+  const float* sb = B + (long long)n0 * K;
+  f32x16 acc[TM][TN];
+  for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  auto issue = [&](int kt) {
+    const float* san = sa + kt * BKT;
+    const float* sbn = sb + kt * BKT;
+    const unsigned ldn = lds_wave + (kt % NBUF) * (STAGE * 4u);
+#pragma unroll
+    for (int i = 0; i < PA; ++i) glds16s(voa[i], san, ldn + i * 4096u);
+#pragma unroll
+    for (int i = 0; i < PB; ++i) glds16s(vob[i], sbn, ldn + AF * 4u + i * 4096u);
+  };
+#pragma unroll
+  for (int s = 0; s < NBUF - 1; ++s) if (s < nk) issue(s);
+  for (int kt = 0; kt < nk; ++kt) {
+    if (NBUF == 2 || kt + 1 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PB) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + NBUF - 1 < nk) issue(kt + NBUF - 1);
+    const float* a_l = smem + (kt % NBUF) * STAGE;
+    const float* b_l = a_l + AF;
+#pragma unroll
+    for (int chunk = 0; chunk < BKT / 16; ++chunk) {
+      float af[TM][8], bf[TN][8];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wm * (BM / 2) + i * 32 + r, c0 = h * (BKT / 8) + chunk * 2;
+        const float4 v0 = *reinterpret_cast<const float4*>(a_l + row * BKT + ((c0 + 0) ^ (row & 7)) * 4);
+        const float4 v1 = *reinterpret_cast<const float4*>(a_l + row * BKT + ((c0 + 1) ^ (row & 7)) * 4);
+        af[i][0] = v0.x; af[i][1] = v0.y; af[i][2] = v0.z; af[i][3] = v0.w; af[i][4] = v1.x; af[i][5] = v1.y; af[i][6] = v1.z; af[i][7] = v1.w;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = wn * (BN / 2) + j * 32 + r, c0 = h * (BKT / 8) + chunk * 2;
+        const float4 v0 = *reinterpret_cast<const float4*>(b_l + row * BKT + ((c0 + 0) ^ (row & 7)) * 4);
+        const float4 v1 = *reinterpret_cast<const float4*>(b_l + row * BKT + ((c0 + 1) ^ (row & 7)) * 4);
+        bf[j][0] = v0.x; bf[j][1] = v0.y; bf[j][2] = v0.z; bf[j][3] = v0.w; bf[j][4] = v1.x; bf[j][5] = v1.y; bf[j][6] = v1.z; bf[j][7] = v1.w;
+      }
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  constexpr int CLD = BN + 4, C4 = BN / 4;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) smem[(wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * CLD + wn * (BN / 2) + j * 32 + r] = acc[i][j][e];
+  __syncthreads();
+#pragma unroll 4
+  for (int idx = tid; idx < BM * C4; idx += 256) {
+    const int lr = idx / C4, c4 = idx % C4;
+    *reinterpret_cast<float4*>(C + (long long)(m0 + lr) * N + n0 + c4 * 4) = *reinterpret_cast<const float4*>(smem + lr * CLD + c4 * 4);
+  }
+}
+
 __global__ void fill_rand(float* p, long long n, unsigned seed) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     unsigned x = (unsigned)i * 2654435761u + seed; x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13;
@@ -360,14 +445,10 @@ void bench(const char* name, int BM, int BN, const float* A, const float* B, flo
 #define DMA(BM, BN, BKT, NBUF, WM, WN, PRIO) \
   bench("dma " #BM "x" #BN " bk" #BKT " nbuf" #NBUF " w" #WM "x" #WN " prio" #PRIO, BM, BN, A, B, C, M, N, K, LAUNCH((lab_dma<BM, BN, BKT, NBUF, WM, WN, PRIO>), BM, BN, 64 * WM * WN))
 
-#define DMA2(BM, BN, ORDER) bench("dma2 order" #ORDER, BM, BN, A, B, C, M, N, K, LAUNCH((lab_dma2<BM, BN, ORDER>), BM, BN, 256))
+#define DMA3(BM, BN, BKT, NBUF) bench("dma3 bk" #BKT " nbuf" #NBUF, BM, BN, A, B, C, M, N, K, LAUNCH((lab_dma3<BM, BN, BKT, NBUF>), BM, BN, 256))
 void suite(const float* A, const float* B, float* C, int M, int N, int K) {
-  DMA(128, 128, 32, 2, 2, 2, 0);
-  DMA2(128, 128, 0); DMA2(128, 128, 1); DMA2(128, 128, 2);
-  DMA(128, 64, 32, 2, 2, 2, 0);
-  DMA2(128, 64, 0); DMA2(128, 64, 1); DMA2(128, 64, 2);
-  DMA(64, 64, 32, 2, 2, 2, 0);
-  DMA2(64, 64, 0); DMA2(64, 64, 1); DMA2(64, 64, 2);
+  DMA3(64, 64, 32, 2); DMA3(64, 64, 64, 2); DMA3(64, 64, 32, 3); DMA3(64, 64, 64, 3);
+  DMA3(128, 64, 32, 2); DMA3(128, 64, 64, 2); DMA3(128, 64, 32, 3);
 }
 
 int main() {
@@ -377,7 +458,7 @@ int main() {
   hipLaunchKernelGGL(fill_rand, dim3(4096), dim3(256), 0, 0, A, na, 1u);
   hipLaunchKernelGGL(fill_rand, dim3(4096), dim3(256), 0, 0, B, nb, 2u);
   (void)hipDeviceSynchronize();
-  const int shapes[][3] = {{40960, 1536, 512}, {40960, 512, 512}, {20480, 512, 512}, {4096, 512, 512}, {4096, 1536, 512}, {40960, 512, 4096}};
+  const int shapes[][3] = {{4096, 512, 512}, {4096, 512, 1536}, {4096, 1536, 512}, {40960, 512, 512}, {40960, 1536, 512}};
   for (auto& sh : shapes) { suite(A, B, C, sh[0], sh[1], sh[2]); printf("\n"); }
   return 0;
 }
