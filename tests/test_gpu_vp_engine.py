@@ -326,7 +326,8 @@ def test_syncbn_hook_two_identical_ranks_equal_single(MT):
 
 
 @pytest.mark.parametrize('B,S,T,d,bias', [(1, 10, 10, 64, True), (3, 1, 1, 64, False), (2, 16, 16, 64, True), (5, 5, 15, 256, False),
-                                          (130, 7, 3, 128, True), (33, 2, 16, 64, True)])
+                                          (130, 7, 3, 128, True), (33, 2, 16, 64, True),
+                                          (4, 5, 15, 512, True), (3, 16, 16, 512, False), (6, 3, 12, 512, True)])   # dh = 64: 4-heads-per-wave kernels at every length bucket
 def test_edge_shapes_forward_loss_grads_vs_oracle(MT, B, S, T, d, bias):
     """Ragged / extreme shapes: single trajectory, window length 1, the maximum window 16, head dims 8/16/32, row counts that
     are not multiples of any tile -- forward, loss and every gradient against the oracle's autograd."""
