@@ -302,14 +302,22 @@ __global__ __launch_bounds__(1024) void ppo_loss_kernel(PPOLossArgs a) {
     const int bi = a.idx ? a.idx[i] : i;
     float adv = a.adv[bi];
     if (a.norm_adv) adv = (adv - mean) / (stdv + a.adv_eps);
-    const float* lg = a.logits + (size_t)i * MAXOUT;
+    float lg[MAXOUT];                                  // the row's logits in registers: four 16-byte loads, no dynamic global index
+#pragma unroll
+    for (int q4 = 0; q4 < MAXOUT / 4; ++q4)
+      *reinterpret_cast<float4*>(lg + 4 * q4) = *reinterpret_cast<const float4*>(a.logits + (size_t)i * MAXOUT + 4 * q4);
     float m = -INFINITY;
+#pragma unroll
     for (int k = 0; k < NACT; ++k) m = fmaxf(m, lg[k]);
     float e[NACT], se = 0.f;
+#pragma unroll
     for (int k = 0; k < NACT; ++k) { e[k] = expf(lg[k] - m); se += e[k]; }
     const float lse = logf(se);
     const int act = a.act[bi];
-    const float logp = (lg[act] - m) - lse;
+    float lg_act = 0.f;
+#pragma unroll
+    for (int k = 0; k < NACT; ++k) if (k == act) lg_act = lg[k];
+    const float logp = (lg_act - m) - lse;
     const float ratio = expf(logp - a.logp_old[bi]);
     const float surr1 = ratio * adv;
     const float rc = fminf(fmaxf(ratio, 1.f - a.eps_clip), 1.f + a.eps_clip);
@@ -321,15 +329,21 @@ __global__ __launch_bounds__(1024) void ppo_loss_kernel(PPOLossArgs a) {
     else dlogp = (ratio > 1.f - a.eps_clip && ratio < 1.f + a.eps_clip) ? -ratio * adv : 0.f;
     dlogp /= (float)n;
     float ent = 0.f;
+#pragma unroll
     for (int k = 0; k < NACT; ++k) { const float p = e[k] / se; const float lp = (lg[k] - m) - lse; ent -= p * lp; }
     l_ent += ent;
+    float gout[MAXOUT];
+#pragma unroll
     for (int k = 0; k < NACT; ++k) {
       const float p = e[k] / se, lp = (lg[k] - m) - lse;
       float g = dlogp * ((k == act ? 1.f : 0.f) - p);
       g += -a.ent_coef * (-p * (lp + ent)) / (float)n;        // d(-ent_coef * mean H)/dlogit_k = ent_coef * p_k (log p_k + H) / n
-      a.dlogits[(size_t)i * MAXOUT + k] = g;
+      gout[k] = g;
     }
-    a.dlogits[(size_t)i * MAXOUT + NACT] = 0.f;
+    gout[NACT] = 0.f;
+#pragma unroll
+    for (int q4 = 0; q4 < MAXOUT / 4; ++q4)
+      *reinterpret_cast<float4*>(a.dlogits + (size_t)i * MAXOUT + 4 * q4) = *reinterpret_cast<const float4*>(gout + 4 * q4);
     const float v = a.value[(size_t)i * a.value_ld], ret = a.ret[bi];
     float dv;
     if (a.value_clip) {
