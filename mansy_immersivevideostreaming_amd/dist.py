@@ -35,12 +35,17 @@ def make_grad_sync(world):
     # RCCL averages inside the collective (one launch instead of all-reduce + scale); gloo (CPU tests) has no AVG
     use_avg = dist.is_initialized() and dist.get_backend() == 'nccl'
 
+    state = {'avg': use_avg}
+
     def grad_sync(flat_g):
-        if use_avg:
-            dist.all_reduce(flat_g, op=dist.ReduceOp.AVG)
-        else:
-            dist.all_reduce(flat_g)
-            flat_g.mul_(inv)
+        if state['avg']:
+            try:
+                dist.all_reduce(flat_g, op=dist.ReduceOp.AVG)
+                return
+            except (RuntimeError, ValueError):      # a backend build without AVG: sum + scale from here on
+                state['avg'] = False
+        dist.all_reduce(flat_g)
+        flat_g.mul_(inv)
     return grad_sync
 
 
