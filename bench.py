@@ -247,12 +247,16 @@ def main():
 
     # ---- roofline leg (rank 0): HIP events around every GEMM launch of the same workload
     roof = None
+    # every rank runs these steps (the data-parallel step holds collectives: SyncBN statistics, gradient all-reduce -- a
+    # rank-0-only step would leave the other ranks in a different collective); only rank 0 records GEMM launch times
+    nprof = max(1, min(args.steps, 3))
+    L = lib()
     if rank == 0:
-        L = lib()
         check(L.mansy_prof_gemm_enable(1), 'prof_enable')
-        nprof = max(1, min(args.steps, 3))
-        for _ in range(nprof):
-            model.train_step(h, c, f, opt, grad_sync=None)
+    for _ in range(nprof):
+        step()
+    torch.cuda.synchronize()
+    if rank == 0:
         ms, n, fl = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double()
         check(L.mansy_prof_gemm_collect(ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), 'prof_collect')
         check(L.mansy_prof_gemm_enable(0), 'prof_disable')

@@ -13,18 +13,26 @@ def env_world():
     return int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('LOCAL_RANK', '0'))
 
 
+def local_device_index(local):
+    """GPU of this rank: LOCAL_RANK, except in the functional test of the multi-rank path on a box with fewer GPUs than ranks
+    (MANSY_SHARE_GPU=1 with MANSY_DIST_BACKEND=gloo: ranks share devices; RCCL itself refuses two ranks on one GPU)."""
+    if os.environ.get('MANSY_SHARE_GPU') == '1' and torch.cuda.is_available():
+        return local % torch.cuda.device_count()
+    return local
+
+
 def init_process_group(backend=None):
     rank, world, local = env_world()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            backend = os.environ.get('MANSY_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl':
             torch.cuda.set_device(local)
             dist.init_process_group(backend, device_id=torch.device('cuda', local))
         else:
             dist.init_process_group(backend)
-    return rank, world, local
+    return rank, world, local_device_index(local)
 
 
 def make_grad_sync(world):

@@ -1,0 +1,29 @@
+"""Functional test of the multi-rank code path on ONE GPU: two ranks share the device and talk over gloo
+(MANSY_DIST_BACKEND=gloo, MANSY_SHARE_GPU=1 -- RCCL itself refuses two ranks on one GPU).  Everything the 8-GPU bench does
+runs for real -- SyncBN statistics hook, flat-gradient all-reduce, sharded environments, return-normaliser merge, the
+barrier / max-over-ranks timing protocol and the rank-0 JSON line -- only the transport differs."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_share_one_gpu_over_gloo():
+    env = dict(os.environ, MANSY_DIST_BACKEND='gloo', MANSY_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29533', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--no-cpu-baseline',
+           '--batch', '256']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]            # rank 0 only
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['config']['parallelism'] == 'dp2' and out['config']['global_batch'] == 512
+    assert out['value'] > 0 and out['secondary']['value'] > 0 and out['secondary']['n_gpus'] == 2
+    assert out['roofline']['launches_per_step'] > 0
+    assert 0 < out['final_loss'] < 10
