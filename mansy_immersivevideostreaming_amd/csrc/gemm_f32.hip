@@ -1,17 +1,20 @@
 // Exact-fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32), LDS-tiled, with fused
 // epilogues.  This is the MFMA-bound kernel of the viewport-prediction Transformer
-// (reference arithmetic: torch.nn.Transformer Linear layers).
+// (reference arithmetic: torch.nn.Transformer Linear layers) and of the PPO nets.
 //
-// Block: 256 threads = 4 waves (2x2), tile BM x BN in {128x128, 64x64}, BK = 32.
-// Each wave owns a (BM/2) x (BN/2) sub-tile = TM x TN MFMA blocks of 32x32.
-// LDS images keep the global orientation of each operand (no transposes on the way in):
-//   K-contiguous operand  -> tile[rows][BK+4]   (fragments read as 2 x ds_read_b128 per 8 k)
-//   K-major operand       -> tile[BK][rows+4]   (fragments read with ds_read_b32, conflict-free)
-// The 32x32x2 MFMA consumes k = {0,1} from lane halves h = lane>>5; because the sum over k is
-// order-free as long as A and B agree, lane half h is given k in [16h, 16h+16) of the BK block,
-// so a K-contiguous fragment is 16 consecutive floats of one LDS row.
-// Global->LDS staging is register double-buffered (loads for tile t+1 issued before the MFMAs of
-// tile t, written to the other LDS buffer afterwards): one barrier per K-tile.
+// Two main loops share one epilogue (gemm_epilogue):
+//   gemm_f32_dma_kernel  the hot path: operand tiles go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4), unpadded
+//                        XOR-swizzled LDS images, tiles 128x64 / 64x64 (128x128 when forced), whole K-tiles only.
+//   gemm_f32_kernel      register-staged fallback for everything else (K % 32 != 0, unaligned / odd leading
+//                        dimensions): padded LDS rows, K tail zero-filled on the way into LDS.
+// Common structure: 256 threads = 4 waves (2x2), BK = 32, each wave owns a (BM/2) x (BN/2) sub-tile = TM x TN MFMA blocks
+// of 32x32, one barrier per K-tile, two LDS buffers.  LDS images keep the global orientation of each operand:
+//   K-contiguous operand  -> rows of BK floats (fragments: 2 x ds_read_b128 per 8 k)
+//   K-major operand       -> BK rows of `rows` floats (fragments: ds_read_b32, conflict-free)
+// The 32x32x2 MFMA consumes k = {0,1} from lane halves h = lane>>5; because the sum over k is order-free as long as A and
+// B agree, lane half h is given k in [16h, 16h+16) of the BK block, so a K-contiguous fragment is 16 consecutive floats
+// of one LDS row.  Split-K: atomics (dW products) or per-split slabs (skinny products); workgroups are remapped so that
+// the tiles sharing an operand panel -- and whole K splits -- land on one XCD's L2.
 #include <vector>
 #include "mansy_kernels.h"
 
