@@ -34,6 +34,8 @@ struct GemmParams {
   int vec_ok;
   int c_vec_ok;      // 16-byte epilogue legal: C, bias, mask, resid 16-B aligned, their lds and N multiples of 4
   GemmEpilogue ep;
+  // optional second problem of identical shape in the same launch (LDS-DMA loop; grid.z = 2 x splits, problem slowest)
+  const float* A2 = nullptr; const float* B2 = nullptr; float* C2 = nullptr; float* a_rowsum2 = nullptr; int splits_pp = 1;
 };
 
 template <int R, bool KMAJ>
@@ -119,14 +121,14 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ lds, int rb,
 // `smem` is the (now idle) staging LDS, at least BM*(BN+4) floats; SMEM_FLOATS is its size.
 template <int BM, int BN, int SMEM_FLOATS>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[BM / 64][BN / 64 > 0 ? BN / 64 : 1], float* smem, int m0, int n0,
-                                              int tid, int split) {
+                                              int tid, int split, float* Cbase) {
   constexpr int TM = BM / 64, TN = BN / 64;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, h = lane >> 5;
   const GemmEpilogue& ep = p.ep;
   const bool atomic = ep.accumulate || (gridDim.z > 1 && ep.split_slab == 0);
-  float* const Cz = p.C + (long long)split * ep.split_slab;               // own slab per K split in slab mode
+  float* const Cz = Cbase + (long long)split * ep.split_slab;             // own slab per K split in slab mode
   const float drop_scale = ep.drop.p > 0.f ? 1.f / (1.f - ep.drop.p) : 1.f;
   if (!atomic && p.c_vec_ok) {
     // Row-major 16-byte epilogue: the accumulators (one column per lane, 16 scattered rows) are transposed through the LDS
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmParams p) {
 
   if (AK && p.ep.a_rowsum && first_n_tile && tid < BM && m0 + tid < p.M) atomicAdd(p.ep.a_rowsum + m0 + tid, rowsum);
 
-  gemm_epilogue<BM, BN, 2 * (A_FLOATS + B_FLOATS)>(p, acc, smem, m0, n0, tid, blockIdx.z);
+  gemm_epilogue<BM, BN, 2 * (A_FLOATS + B_FLOATS)>(p, acc, smem, m0, n0, tid, blockIdx.z, p.C);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -417,6 +419,12 @@ __global__ __launch_bounds__(NT) void gemm_f32_dma_kernel(GemmParams p) {
     split = t / per_split; t -= split * per_split;
     tile_y = t / gridDim.x; tile_x = t - tile_y * gridDim.x;
   }
+  const float* Ap = p.A; const float* Bp = p.B; float* Cp = p.C; float* rowsum_dst = p.ep.a_rowsum;
+  if (p.A2) {                                       // two same-shape problems in one launch: the upper half of the splits is problem 2
+    const int prob = split / p.splits_pp;
+    split -= prob * p.splits_pp;
+    if (prob) { Ap = p.A2; Bp = p.B2; Cp = p.C2; rowsum_dst = p.a_rowsum2; }
+  }
   const int m0 = tile_y * BM, n0 = tile_x * BN;
   int k_begin = split * p.k_per_split;
   int k_end = min(p.K, k_begin + p.k_per_split);
@@ -430,8 +438,8 @@ __global__ __launch_bounds__(NT) void gemm_f32_dma_kernel(GemmParams p) {
   dma_offsets<BM, AK>(p.lda, m0, p.M, voa, tid);
   dma_offsets<BN, BKM>(p.ldb, n0, p.N, vob, tid);
   // tile corners (wave-uniform -> SGPRs) and their per-K-tile strides
-  const float* sa = AK ? p.A + (long long)k_begin * p.lda + m0 : p.A + (long long)m0 * p.lda + k_begin;
-  const float* sb = BKM ? p.B + (long long)k_begin * p.ldb + n0 : p.B + (long long)n0 * p.ldb + k_begin;
+  const float* sa = AK ? Ap + (long long)k_begin * p.lda + m0 : Ap + (long long)m0 * p.lda + k_begin;
+  const float* sb = BKM ? Bp + (long long)k_begin * p.ldb + n0 : Bp + (long long)n0 * p.ldb + k_begin;
   const long long step_a = AK ? (long long)BK * p.lda : BK, step_b = BKM ? (long long)BK * p.ldb : BK;
   const unsigned lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem + (unsigned)wave * 1024u);
 
@@ -465,7 +473,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_dma_kernel(GemmParams p) {
     }
     const float* a_l = smem + cur * STAGE;
     const float* b_l = a_l + A_FLOATS;
-    if (AK && p.ep.a_rowsum && tid < BM) {       // bias gradient: row sums of the staged A tile.  Every n-tile of this
+    if (AK && rowsum_dst && tid < BM) {          // bias gradient: row sums of the staged A tile.  Every n-tile of this
       // row panel stages the same A tile, so they share the BK rows (a single n-tile doing all of them ran ~1.3x longer
       // than its neighbours and set the kernel's tail)
       for (int kk = tile_x; kk < BK; kk += gridDim.x) rowsum += a_l[kk * BM + tid];
@@ -489,8 +497,8 @@ __global__ __launch_bounds__(NT) void gemm_f32_dma_kernel(GemmParams p) {
   }
   __syncthreads();                                        // staging LDS idle: the epilogue reuses it
 
-  if (AK && p.ep.a_rowsum && tile_x < BK && tid < BM && m0 + tid < p.M) atomicAdd(p.ep.a_rowsum + m0 + tid, rowsum);
-  gemm_epilogue<BM, BN, SMEM_FLOATS>(p, acc, smem, m0, n0, tid, split);
+  if (AK && rowsum_dst && tile_x < BK && tid < BM && m0 + tid < p.M) atomicAdd(rowsum_dst + m0 + tid, rowsum);
+  gemm_epilogue<BM, BN, SMEM_FLOATS>(p, acc, smem, m0, n0, tid, split, Cp);
 }
 
 template <int BM, int BN>
@@ -600,6 +608,20 @@ int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B,
     const float* B2 = b_kmajor ? B + (long long)Kmain * ldb : B + Kmain;
     return mansy_launch_gemm_f32(A2, lda, a_kmajor, B2, ldb, b_kmajor, C, ldc, M, N, K - Kmain, tail, -64, 1, st);
   }
+  if (ep.pair_A) {
+    MANSY_REQUIRE(ep.pair_B && ep.pair_C && plain && ep.accumulate && ep.split_slab == 0, "gemm: a paired product needs a plain accumulating epilogue");
+    auto al = [](const void* x) { return (reinterpret_cast<uintptr_t>(x) & 15) == 0; };
+    if (!dma || !al(ep.pair_A) || !al(ep.pair_B)) {        // no second-problem support off the LDS-DMA loop: two launches
+      GemmEpilogue e1 = ep; e1.pair_A = e1.pair_B = nullptr; e1.pair_C = e1.pair_rowsum = nullptr;
+      const int rc = mansy_launch_gemm_f32(A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, e1, force_tile, force_splitk, st);
+      if (rc) return rc;
+      e1.a_rowsum = ep.pair_rowsum;
+      return mansy_launch_gemm_f32(ep.pair_A, lda, a_kmajor, ep.pair_B, ldb, b_kmajor, ep.pair_C, ldc, M, N, K, e1, force_tile, force_splitk, st);
+    }
+    p.A2 = ep.pair_A; p.B2 = ep.pair_B; p.C2 = ep.pair_C; p.a_rowsum2 = ep.pair_rowsum;
+    p.c_vec_ok = 0;                                        // accumulating: the scalar (atomic) epilogue is used anyway
+  }
+  const int n_prob = p.A2 ? 2 : 1;
   const bool can_split = plain && ep.accumulate && K >= 4096;
   int tile;
   if (force_tile) {
@@ -624,7 +646,7 @@ int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B,
     // register-staged loop: 128x128 when it alone gives two full rounds of resident workgroups, else 64x64
     tile = tile_count(M, N, 128) >= 512 ? 128 : 64;
   }
-  const long long tiles = tile_count(M, N, tile);
+  const long long tiles = tile_count(M, N, tile) * n_prob;
   // split-K only for plain accumulating products (dW = dY^T X): partial sums are atomically added
   int splits = 1;
   if (force_splitk > 0) splits = force_splitk;
@@ -640,6 +662,8 @@ int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B,
   if (kps <= 0) kps = BK;
   splits = K > 0 ? mansy_ceil_div(K, kps) : 1;
   p.k_per_split = kps;
+  p.splits_pp = splits;
+  splits *= n_prob;                                        // grid.z: problem-major
   if (!g_prof.on) return gemm_dispatch(p, tile, dma, a_kmajor, b_kmajor, splits, st);
   if (g_prof.used + 2 > g_prof.ev.size()) {
     for (int i = 0; i < 2; ++i) { hipEvent_t e; MANSY_HIP_CHECK(hipEventCreate(&e)); g_prof.ev.push_back(e); }
@@ -648,7 +672,7 @@ int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B,
   const int rc = gemm_dispatch(p, tile, dma, a_kmajor, b_kmajor, splits, st);
   MANSY_HIP_CHECK(hipEventRecord(g_prof.ev[g_prof.used + 1], st));
   g_prof.used += 2;
-  g_prof.flops += 2.0 * (double)M * (double)N * (double)K;
+  g_prof.flops += 2.0 * (double)M * (double)N * (double)K * n_prob;
   return rc;
 }
 

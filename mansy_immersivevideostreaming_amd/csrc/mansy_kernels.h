@@ -32,6 +32,10 @@ struct GemmEpilogue {
   // tile t the K range [tile_krange[2t], tile_krange[2t+1]) (multiples of 32) that holds all of B's non-zeros for those
   // columns -- block-diagonal weights (FeatureNet) skip the K-tiles that are structurally zero.
   const int* tile_krange = nullptr;
+  // optional second product of identical shape / layout / leading dimensions in the SAME launch (plain accumulating
+  // epilogue only, e.g. two dW products sharing an operand): C2 += A2 * B2, a_rowsum2 like a_rowsum.  Falls back to two
+  // launches off the LDS-DMA loop.
+  const float* pair_A = nullptr; const float* pair_B = nullptr; float* pair_C = nullptr; float* pair_rowsum = nullptr;
 };
 int mansy_gemm_effective_splits(int K, int requested);
 int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb, int b_kmajor,

@@ -612,11 +612,10 @@ struct PEng {
     hb.h[1] = {W.gout_c, MAXOUT, W.A1c, W.Hc, c.out_w, 1, W.dHc, W.dA1p + HID, 2 * HID, c.gout_w, c.gout_b};
     hipLaunchKernelGGL(head_out_bwd_kernel, dim3(min(mansy_ceil_div(B, 2), 128), 2), dim3(256), 0, st, hb, B);
     MANSY_LAUNCH_CHECK();
-    GemmEpilogue acc; acc.accumulate = 1;
+    GemmEpilogue acc; acc.accumulate = 1;           // gfc_w_{a,c} += dA1_{a,c}^T F, gfc_b_{a,c} += column sums: two products, one launch
     acc.a_rowsum = a.gfc_b;
+    acc.pair_A = W.dA1p + HID; acc.pair_B = W.F; acc.pair_C = c.gfc_w; acc.pair_rowsum = c.gfc_b;
     RC(mansy_launch_gemm_f32(W.dA1p, 2 * HID, 1, W.F, FEAT, 1, a.gfc_w, FEAT, HID, FEAT, B, acc, 0, 0, st));
-    acc.a_rowsum = c.gfc_b;
-    RC(mansy_launch_gemm_f32(W.dA1p + HID, 2 * HID, 1, W.F, FEAT, 1, c.gfc_w, FEAT, HID, FEAT, B, acc, 0, 0, st));
     GemmEpilogue ep;
     return mansy_launch_gemm_f32(W.dA1p, 2 * HID, 0, W.Wfc2, FEAT, 1, W.dF, FEAT, B, FEAT, 2 * HID, ep, 0, 0, st);
   }
