@@ -79,7 +79,12 @@ void bind_net(const float* const* params, float* const* grads, int head_base, Ne
 }
 
 // ------------------------------------------------------------------------------------ kernels
-struct PackArgs { const float* bw[NB]; const float* bb[NB]; const float* fc_a; const float* fc_c; float* Wfc2; };
+struct PackArgs {
+  const float* bw[NB]; const float* bb[NB]; const float* fc_a; const float* fc_c; float* Wfc2;
+  // riders on the same launch (independent prologue work of a PPO minibatch step): gather the minibatch's observation rows,
+  // zero the flat gradient buffer
+  const float* g_src; const int* g_idx; float* g_dst; int g_rows; float* zero_ptr; long long zero_n;
+};
 // Wbd [FEAT, KP] (columns >= K and everything off the block diagonal zero), bbd [FEAT], and per 64-feature column tile of
 // the product the K range that holds its branch's weights (GemmEpilogue::tile_krange).
 __global__ __launch_bounds__(256) void pack_wbd_kernel(PackArgs a, int identifier, int K, float* __restrict__ Wbd, float* __restrict__ bbd,
@@ -90,9 +95,23 @@ __global__ __launch_bounds__(256) void pack_wbd_kernel(PackArgs a, int identifie
     krange[2 * idx] = g.off / 32 * 32;
     krange[2 * idx + 1] = min(KP, (g.off + g.len + 31) / 32 * 32);
   }
-  if (idx >= (long long)FEAT * KP) {            // tail of the grid: [actor.fc | critic.fc] stacked to one [2*HID, FEAT] operand
-    const long long i2 = idx - (long long)FEAT * KP;
-    if (a.Wfc2 && i2 < 2LL * HID * FEAT) a.Wfc2[i2] = i2 < (long long)HID * FEAT ? a.fc_a[i2] : a.fc_c[i2 - (long long)HID * FEAT];
+  if (idx >= (long long)FEAT * KP) {            // tail of the grid: [actor.fc | critic.fc] stacked to one [2*HID, FEAT] operand, then the riders
+    long long i2 = idx - (long long)FEAT * KP;
+    const long long n_fc = a.Wfc2 ? 2LL * HID * FEAT : 0;
+    if (i2 < n_fc) { a.Wfc2[i2] = i2 < (long long)HID * FEAT ? a.fc_a[i2] : a.fc_c[i2 - (long long)HID * FEAT]; return; }
+    i2 -= n_fc;
+    const long long n_g = (long long)a.g_rows * (OBS_LD / 4);
+    if (i2 < n_g) {
+      const int r = (int)(i2 / (OBS_LD / 4)), c4 = (int)(i2 % (OBS_LD / 4));
+      reinterpret_cast<float4*>(a.g_dst)[(size_t)r * (OBS_LD / 4) + c4] = reinterpret_cast<const float4*>(a.g_src)[(size_t)a.g_idx[r] * (OBS_LD / 4) + c4];
+      return;
+    }
+    i2 -= n_g;
+    if (i2 < (a.zero_n + 3) / 4) {
+      const long long e0 = i2 * 4;
+      if (e0 + 4 <= a.zero_n) *reinterpret_cast<float4*>(a.zero_ptr + e0) = make_float4(0.f, 0.f, 0.f, 0.f);
+      else for (long long e = e0; e < a.zero_n; ++e) a.zero_ptr[e] = 0.f;
+    }
     return;
   }
   const int col = (int)(idx % KP), row = (int)(idx / KP);
@@ -544,11 +563,15 @@ size_t ppo_layout(int maxB, char* base, PWork& W) {
 struct PEng {
   hipStream_t st; PWork W;
   // pair != nullptr: also stack the fc weights of (n, *pair) for head_pair()
-  int pack(const NetP& n, int identifier, const NetP* pair = nullptr) {
+  int pack(const NetP& n, int identifier, const NetP* pair = nullptr, const float* g_src = nullptr, const int* g_idx = nullptr, int g_rows = 0,
+           float* zero_ptr = nullptr, long long zero_n = 0) {
     PackArgs a; for (int j = 0; j < NB; ++j) { a.bw[j] = n.bw[j]; a.bb[j] = n.bb[j]; }
     a.fc_a = n.fc_w; a.fc_c = pair ? pair->fc_w : nullptr; a.Wfc2 = pair ? W.Wfc2 : nullptr;
+    a.g_src = g_src; a.g_idx = g_idx; a.g_dst = W.obs_mb; a.g_rows = g_src ? g_rows : 0;
+    a.zero_ptr = zero_ptr; a.zero_n = zero_ptr ? zero_n : 0;
+    MANSY_REQUIRE(!zero_ptr || (reinterpret_cast<uintptr_t>(zero_ptr) & 15) == 0, "pack: gradient buffer must be 16-byte aligned");
     const int K = identifier ? K_IDENT : K_POLICY;
-    const long long threads = (long long)FEAT * KP + (pair ? 2LL * HID * FEAT : 0);
+    const long long threads = (long long)FEAT * KP + (pair ? 2LL * HID * FEAT : 0) + (long long)a.g_rows * (OBS_LD / 4) + (a.zero_n + 3) / 4;
     hipLaunchKernelGGL(pack_wbd_kernel, dim3(mansy_ceil_div(threads, 256)), dim3(256), 0, st, a, identifier, K, W.Wbd, W.bbd, W.krange);
     MANSY_LAUNCH_CHECK();
     return MANSY_OK;
@@ -784,15 +807,11 @@ int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, fl
   MANSY_REQUIRE(mb >= 2 && mb <= max_batch, "ppo_minibatch_step: bad minibatch size");
   PEng e; RC(setup(workspace, max_batch, (hipStream_t)stream, e));
   NetP a, c; bind_net(params, grads, 20, a); bind_net(params, grads, 24, c);
-  const float* obs = obs_all;
-  if (idx) {
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(mansy_ceil_div((long long)mb * (OBS_LD / 4), 256)), dim3(256), 0, e.st, obs_all, idx, mb, OBS_LD, e.W.obs_mb);
-    obs = e.W.obs_mb;
-  }
-  RC(e.pack(a, 0, &c));
+  // one prologue launch: re-pack the block-diagonal / stacked weights, gather the minibatch rows, zero the gradient buffer
+  const float* obs = idx ? e.W.obs_mb : obs_all;
+  RC(e.pack(a, 0, &c, idx ? obs_all : nullptr, idx, mb, flat_g, n_flat));
   RC(e.featnet(obs, mb, 0));
   RC(e.head_pair(a, c, mb));
-  MANSY_HIP_CHECK(hipMemsetAsync(flat_g, 0, sizeof(float) * (size_t)n_flat, e.st));
   PPOLossArgs la;
   la.logits = e.W.outa; la.value = e.W.outc; la.value_ld = MAXOUT; la.act = act_all; la.adv = adv_all; la.logp_old = logp_old_all; la.v_old = v_old_all;
   la.ret = ret_all; la.idx = idx; la.n = mb; la.eps_clip = eps_clip; la.vf_coef = vf_coef; la.ent_coef = ent_coef; la.norm_adv = norm_adv;
