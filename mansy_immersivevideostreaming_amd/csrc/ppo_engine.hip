@@ -279,14 +279,6 @@ __global__ __launch_bounds__(256) void featgrad_finish_kernel(float* __restrict_
   dF[idx] = F[idx] > 0.f ? v : v * SLOPE;
 }
 
-__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx, int n, int ld,
-                                                          float* __restrict__ dst) {
-  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-  const int ld4 = ld / 4;
-  if (t >= (long long)n * ld4) return;
-  const int r = (int)(t / ld4), c4 = (int)(t % ld4);
-  reinterpret_cast<float4*>(dst)[(size_t)r * ld4 + c4] = reinterpret_cast<const float4*>(src)[(size_t)idx[r] * ld4 + c4];
-}
 
 // PPO minibatch loss + gradient wrt logits/value (T2: tianshou 0.4.8 PPOPolicy.learn).  One block, rows strided.
 // stats: [0] loss [1] clip [2] vf [3] ent ; adv normalised with the minibatch mean / unbiased std (two-pass).
