@@ -754,16 +754,18 @@ int mansy_policy_evaluate(const float* const* params, const float* obs, int B, c
   MANSY_REQUIRE(params && obs && B >= 1 && B <= max_batch, "policy_evaluate: bad arguments");
   PEng e; RC(setup(workspace, max_batch, (hipStream_t)stream, e));
   NetP a, c; bind_net(params, nullptr, 20, a); bind_net(params, nullptr, 24, c);
-  RC(e.pack(a, 0));
+  const bool both = logp && value;
+  RC(e.pack(a, 0, both ? &c : nullptr));
   RC(e.featnet(obs, B, 0));
+  if (logp) MANSY_REQUIRE(act, "policy_evaluate: logp needs actions");
+  if (both) RC(e.head_pair(a, c, B));                      // actor + critic in one stacked product
   if (logp) {
-    MANSY_REQUIRE(act, "policy_evaluate: logp needs actions");
-    RC(e.head(a, B, NACT, 0, e.W.A1a, e.W.Ha, e.W.outa, nullptr, 0, 0, nullptr, nullptr));
+    if (!both) RC(e.head(a, B, NACT, 0, e.W.A1a, e.W.Ha, e.W.outa, nullptr, 0, 0, nullptr, nullptr));
     hipLaunchKernelGGL(logp_kernel, dim3(mansy_ceil_div(B, 256)), dim3(256), 0, e.st, e.W.outa, act, B, logp);
     MANSY_LAUNCH_CHECK();
   }
   if (value) {
-    RC(e.head(c, B, 1, 0, e.W.A1c, e.W.Hc, e.W.outc, nullptr, 0, 0, nullptr, nullptr));
+    if (!both) RC(e.head(c, B, 1, 0, e.W.A1c, e.W.Hc, e.W.outc, nullptr, 0, 0, nullptr, nullptr));
     MANSY_HIP_CHECK(hipMemcpy2DAsync(value, sizeof(float), e.W.outc, sizeof(float) * MAXOUT, sizeof(float), B, hipMemcpyDeviceToDevice, e.st));
   }
   return MANSY_OK;
