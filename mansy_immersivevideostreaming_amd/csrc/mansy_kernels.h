@@ -113,6 +113,31 @@ int mansy_launch_distill_bwd(const float* conv, const float* dmem, const unsigne
                              const float* bn_b, const float* mean, const float* rstd, float* g_tmp, float* dconv,
                              float* dbn_w, float* dbn_b, double* stats_d, const DistillShape& s, hipStream_t st);
 
+// ---------------------------------------------------------------- fused decoder-step tail (dec_step.hip)
+// One launch for the four row-wise ops between the last product of decoder step i and the first of step i+1:
+//   z3 = a + b ; y3 = LN3(z3) ; dec_out = LN_dec(y3) ; tok = sigmoid(dec_out Wp^T + bp) ; emb_next = drop(tok We^T + be + pe_row)
+// (emb_next == nullptr on the last step).  Same arithmetic as the separate kernels.
+struct MansyDecTailFwd {
+  const float* a; const float* b; const float* n3_w; const float* n3_b; float* z3; float* y3; float* m3; float* r3;
+  const float* dn_w; const float* dn_b; float* dec_out; float* md; float* rd;
+  const float* pw; const float* pb; float* tok_next; float* pred_bt; long long pred_stride;
+  const float* ew; const float* eb; const float* pe_row; float* emb_next; MansyDrop edrop;
+  int rows, C, C6; float eps;
+};
+int mansy_dec_tail_ok(int C, int c6);
+int mansy_launch_dec_tail_fwd(const MansyDecTailFwd& p, hipStream_t st);
+// Backward mirror, at the start of backward step i: embedding backward of step i+1 (gx_next null on the last step), predictor
+// backward, final-norm backward, LayerNorm3 backward of the last layer.  part_dn / part_n3: LayerNorm weight-gradient slot sets
+// [n_slots][2][C] (accumulated; n_slots workgroups are launched).
+struct MansyDecHeadBwd {
+  const float* gx_next; const float* ew; float* dE_next; MansyDrop edrop;
+  const float* dpred; long long dpred_stride; const float* pred; const float* pw; float* dz;
+  const float* y3; const float* md; const float* rd; const float* dn_w; float* part_dn;
+  const float* z3; const float* m3; const float* r3; const float* n3_w; float* part_n3; float* gz; float* dbr3; MansyDrop drop3;
+  int rows, C, C6;
+};
+int mansy_launch_dec_head_bwd(const MansyDecHeadBwd& p, int n_slots, hipStream_t st);
+
 // ---------------------------------------------------------------- elementwise (elementwise.hip)
 // out[r, c] = sum_k x[r,k] W[c,k] + b[c] + pe[pos(r), c], dropout(site, r*C+c).
 // pos(r) = pos_fixed if pos_fixed >= 0 else (r % S).

@@ -307,10 +307,12 @@ struct Eng {
       RC(lin_fwd(W.mem, B * M, d, p.ca_in.w + (size_t)d * d, p.ca_in.b ? p.ca_in.b + d : nullptr, 2 * d, W.dec[l].memkv, 0, mansy_no_drop()));
     }
     MANSY_HIP_CHECK(hipMemcpyAsync(W.tok_all, cur, sizeof(float) * B * C6, hipMemcpyDeviceToDevice, st));
+    // the four row-wise ops between the last product of step i and the first of step i+1 run as one launch (dec_step.hip)
+    const bool fuse_tail = mansy_dec_tail_ok(d, C6) != 0;
     for (int i = 0; i < T; ++i) {
       const float* tok = W.tok_all + (size_t)i * B * C6;
       float* emb = W.emb_all + (size_t)i * B * d;
-      RC(mansy_launch_embed_fwd(tok, C6, P.emb.w, P.emb.b, pe, emb, B, d, 1, i, dr(site_pe_tgt(i), c.p_pe), st));
+      if (i == 0 || !fuse_tail) RC(mansy_launch_embed_fwd(tok, C6, P.emb.w, P.emb.b, pe, emb, B, d, 1, i, dr(site_pe_tgt(i), c.p_pe), st));
       const float* xi = emb;
       for (int l = 0; l < c.n_dec; ++l) {
         const DecLayerP& p = P.dec[l]; DecBuf& e = W.dec[l];
@@ -328,10 +330,26 @@ struct Eng {
         RC(ln_fwd(e.y1 + o * d, W.t_dec, p.n2, e.z2 + o * d, e.y2 + o * d, e.m2 + o, e.r2 + o, B));
         RC(lin_fwd(e.y2 + o * d, B, d, p.lin1.w, p.lin1.b, f, e.h + o * f, 1, dr(site_dec(l, i, 4), c.p_drop)));
         RC(lin_fwd(e.h + o * f, B, f, p.lin2.w, p.lin2.b, d, W.t_dec, 0, dr(site_dec(l, i, 5), c.p_drop)));
+        if (fuse_tail && l == c.n_dec - 1) break;             // LayerNorm3 of the last layer is the head of the fused tail
         RC(ln_fwd(e.y2 + o * d, W.t_dec, p.n3, e.z3 + o * d, e.y3 + o * d, e.m3 + o, e.r3 + o, B));
         xi = e.y3 + o * d;
       }
       const size_t o = (size_t)i * B;
+      if (fuse_tail) {
+        const DecLayerP& p = P.dec[c.n_dec - 1]; DecBuf& e = W.dec[c.n_dec - 1];
+        MansyDecTailFwd tp;
+        tp.a = e.y2 + o * d; tp.b = W.t_dec; tp.n3_w = p.n3.w; tp.n3_b = p.n3.b; tp.z3 = e.z3 + o * d; tp.y3 = e.y3 + o * d;
+        tp.m3 = e.m3 + o; tp.r3 = e.r3 + o;
+        tp.dn_w = P.dec_norm.w; tp.dn_b = P.dec_norm.b; tp.dec_out = W.dec_out + o * d; tp.md = W.md + o; tp.rd = W.rd + o;
+        tp.pw = P.pred.w; tp.pb = P.pred.b; tp.tok_next = W.tok_all + (size_t)(i + 1) * B * C6;
+        tp.pred_bt = pred_bt ? pred_bt + (size_t)i * C6 : nullptr; tp.pred_stride = (long long)T * C6;
+        const bool more = i + 1 < T;
+        tp.ew = P.emb.w; tp.eb = P.emb.b; tp.pe_row = pe + (size_t)(i + 1) * d; tp.emb_next = more ? W.emb_all + (size_t)(i + 1) * B * d : nullptr;
+        tp.edrop = dr(site_pe_tgt(i + 1), c.p_pe);
+        tp.rows = B; tp.C = d; tp.C6 = C6; tp.eps = c.ln_eps;
+        RC(mansy_launch_dec_tail_fwd(tp, st));
+        continue;
+      }
       RC(ln_fwd(xi, nullptr, P.dec_norm, nullptr, W.dec_out + o * d, W.md + o, W.rd + o, B));
       RC(mansy_launch_predictor_fwd(W.dec_out + o * d, P.pred.w, P.pred.b, W.tok_all + (size_t)(i + 1) * B * C6, C6,
                                     pred_bt ? pred_bt + (size_t)i * C6 : nullptr, (long long)T * C6, B, d, C6, st));
@@ -357,20 +375,40 @@ struct Eng {
     const size_t lnp_set = (size_t)mansy_ln_bwd_parts(B) * 2 * d;
     if (ln_parts) MANSY_HIP_CHECK(hipMemsetAsync(W.lnp_dec, 0, sizeof(float) * (size_t)(3 * c.n_dec + 1) * lnp_set, st));
     const float* pred_tb = W.tok_all + (size_t)B * C6;
+    // fused head of a backward step (dec_step.hip): embedding backward of step i+1 + predictor backward + final norm backward
+    // + LayerNorm3 backward of the last layer in one launch
+    const bool fuse_head = ln_parts && mansy_dec_tail_ok(d, C6) != 0;
     for (int i = T - 1; i >= 0; --i) {
       const size_t o = (size_t)i * B;
-      // predictor + final decoder LayerNorm
-      RC(mansy_launch_predictor_bwd(dpred_bt + (size_t)i * C6, (long long)T * C6, i < T - 1 ? W.s_tok : nullptr, C6,
-                                    pred_tb + o * C6, C6, P.pred.w, W.dz_all + o * C6, W.s_a, B, d, C6, st));
-      const float* last_y = W.dec[c.n_dec - 1].y3 + o * d;
-      RC(ln_bwd(W.s_a, last_y, W.md + o, W.rd + o, P.dec_norm, W.s_b, nullptr, mansy_no_drop(), B, 3 * c.n_dec));
       float* gx = W.s_b;     // gradient wrt the current layer's output
       float* gz = W.s_a;     // scratch for residual-path gradients
       float* gt = W.s_c;
+      if (fuse_head) {
+        const int L = c.n_dec - 1;
+        DecBuf& e = W.dec[L];
+        MansyDecHeadBwd hp;
+        const bool has_next = i < T - 1;           // gx still holds d/d(embedding input) of step i+1
+        hp.gx_next = has_next ? gx : nullptr; hp.ew = P.emb.w; hp.dE_next = has_next ? W.dE_all + (o + B) * d : nullptr;
+        hp.edrop = dr(site_pe_tgt(i + 1), c.p_pe);
+        hp.dpred = dpred_bt + (size_t)i * C6; hp.dpred_stride = (long long)T * C6; hp.pred = pred_tb + o * C6; hp.pw = P.pred.w;
+        hp.dz = W.dz_all + o * C6;
+        hp.y3 = e.y3 + o * d; hp.md = W.md + o; hp.rd = W.rd + o; hp.dn_w = P.dec_norm.w; hp.part_dn = W.lnp_dec + (size_t)(3 * c.n_dec) * lnp_set;
+        hp.z3 = e.z3 + o * d; hp.m3 = e.m3 + o; hp.r3 = e.r3 + o; hp.n3_w = P.dec[L].n3.w; hp.part_n3 = W.lnp_dec + (size_t)(3 * L + 2) * lnp_set;
+        hp.gz = gz; hp.dbr3 = e.dbr3 + o * d; hp.drop3 = dr(site_dec(L, i, 5), c.p_drop);
+        hp.rows = B; hp.C = d; hp.C6 = C6;
+        RC(mansy_launch_dec_head_bwd(hp, mansy_ln_bwd_parts(B), st));
+      } else {
+        // predictor + final decoder LayerNorm
+        RC(mansy_launch_predictor_bwd(dpred_bt + (size_t)i * C6, (long long)T * C6, i < T - 1 ? W.s_tok : nullptr, C6,
+                                      pred_tb + o * C6, C6, P.pred.w, W.dz_all + o * C6, W.s_a, B, d, C6, st));
+        const float* last_y = W.dec[c.n_dec - 1].y3 + o * d;
+        RC(ln_bwd(W.s_a, last_y, W.md + o, W.rd + o, P.dec_norm, W.s_b, nullptr, mansy_no_drop(), B, 3 * c.n_dec));
+      }
       for (int l = c.n_dec - 1; l >= 0; --l) {
         const DecLayerP& p = P.dec[l]; DecBuf& e = W.dec[l];
         // norm3( y2 + drop(lin2(h)) )
-        RC(ln_bwd(gx, e.z3 + o * d, e.m3 + o, e.r3 + o, p.n3, gz, e.dbr3 + o * d, dr(site_dec(l, i, 5), c.p_drop), B, 3 * l + 2));
+        if (!(fuse_head && l == c.n_dec - 1))
+          RC(ln_bwd(gx, e.z3 + o * d, e.m3 + o, e.r3 + o, p.n3, gz, e.dbr3 + o * d, dr(site_dec(l, i, 5), c.p_drop), B, 3 * l + 2));
         RC(lin_dx(e.dbr3 + o * d, B, d, p.lin2.w, f, e.da + o * f, nullptr, e.h + o * f, ms));
         RC(lin_dx(e.da + o * f, B, f, p.lin1.w, d, gt, gz, nullptr, 1.f));                 // gt = d/dy2
         // norm2( y1 + drop(ca_out(ao2)) )
@@ -401,8 +439,10 @@ struct Eng {
         }
         RC(lin_dx(dqkv_i, B, 3 * d, p.sa_in.w, d, gx, gz, nullptr, 1.f));                   // gx = d/d(layer input)
       }
-      // embedding of the fed-back token: dE slab (masked) + gradient wrt pred_{i-1}
-      RC(mansy_launch_embed_bwd(gx, P.emb.w, W.dE_all + o * d, W.s_tok, C6, B, d, dr(site_pe_tgt(i), c.p_pe), st));
+      // embedding of the fed-back token: dE slab (masked) + gradient wrt pred_{i-1}; fused into the head of step i-1, except
+      // for step 0 (its token is the observed current position: only the masked gradient for the deferred dW is needed)
+      if (!fuse_head) RC(mansy_launch_embed_bwd(gx, P.emb.w, W.dE_all + o * d, W.s_tok, C6, B, d, dr(site_pe_tgt(i), c.p_pe), st));
+      else if (i == 0) RC(mansy_launch_embed_bwd(gx, P.emb.w, W.dE_all, nullptr, C6, B, d, dr(site_pe_tgt(0), c.p_pe), st));
     }
     if (ln_parts) {   // decoder LayerNorm weight gradients: slot sets -> gradients
       const int np = mansy_ln_bwd_parts(B);
