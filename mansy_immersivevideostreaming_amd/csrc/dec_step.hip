@@ -149,12 +149,13 @@ __global__ __launch_bounds__(256) void dec_tail_fwd_kernel(MansyDecTailFwd p) {
 //   LayerNorm3 backward of the last layer -> gz (residual-path gradient) and dbr3 = gz * dropmask (the lin2 branch)
 // LayerNorm weight-gradient column sums go to per-workgroup slots like layernorm_bwd_vec_kernel<.., PART> (accumulated over
 // the steps): gridDim.x must be the slot count.
+constexpr int HEAD_WAVES = 8;     // 2 rows per wave at B = 4096 with the 256 LayerNorm slot workgroups: the per-row chain is ten dependent wave reductions
 template <int NV>
-__global__ __launch_bounds__(256) void dec_head_bwd_kernel(MansyDecHeadBwd p) {
-  extern __shared__ float red[];      // [4 waves][4][C]: (dw, db) of the final norm, (dw, db) of LayerNorm3
+__global__ __launch_bounds__(64 * HEAD_WAVES) void dec_head_bwd_kernel(MansyDecHeadBwd p) {
+  extern __shared__ float red[];      // [HEAD_WAVES][4][C]: (dw, db) of the final norm, (dw, db) of LayerNorm3
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wave_global = (blockIdx.x * 256 + threadIdx.x) >> 6;
-  const int nwaves = (gridDim.x * 256) >> 6;
+  const int wave_global = blockIdx.x * HEAD_WAVES + wave;
+  const int nwaves = gridDim.x * HEAD_WAVES;
   const int C = p.C;
   const float invC = 1.f / (float)C;
   const float esc = p.edrop.p > 0.f ? 1.f / (1.f - p.edrop.p) : 1.f;
@@ -295,11 +296,11 @@ __global__ __launch_bounds__(256) void dec_head_bwd_kernel(MansyDecHeadBwd p) {
     *reinterpret_cast<float4*>(red + (wave * 4 + 3) * C + c) = adb_3[i];
   }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < 4 * C; idx += 256) {
+  for (int idx = threadIdx.x; idx < 4 * C; idx += 64 * HEAD_WAVES) {
     const int which = idx / C, c = idx % C;
     float a = 0.f;
 #pragma unroll
-    for (int wv = 0; wv < 4; ++wv) a += red[(wv * 4 + which) * C + c];
+    for (int wv = 0; wv < HEAD_WAVES; ++wv) a += red[(wv * 4 + which) * C + c];
     float* slot = (which < 2 ? p.part_dn : p.part_n3) + (size_t)blockIdx.x * 2 * C + (which & 1) * C + c;
     *slot += a;
   }
@@ -307,7 +308,8 @@ __global__ __launch_bounds__(256) void dec_head_bwd_kernel(MansyDecHeadBwd p) {
 
 }  // namespace
 
-int mansy_dec_tail_ok(int C, int c6) { return (C % 256) == 0 && C >= 256 && C <= 1024 && c6 == C6; }
+// C in {256, 512}: the backward head keeps HEAD_WAVES x 4 x C floats of LDS (64 KiB at C = 512)
+int mansy_dec_tail_ok(int C, int c6) { return (C == 256 || C == 512) && c6 == C6; }
 
 int mansy_launch_dec_tail_fwd(const MansyDecTailFwd& p, hipStream_t st) {
   MANSY_REQUIRE(mansy_dec_tail_ok(p.C, p.C6), "dec_tail_fwd: unsupported width (C=%d, tokens of %d)", p.C, p.C6);
@@ -330,12 +332,13 @@ int mansy_launch_dec_head_bwd(const MansyDecHeadBwd& p, int n_slots, hipStream_t
   MANSY_REQUIRE(p.dpred && p.pred && p.pw && p.dz && p.y3 && p.md && p.rd && p.dn_w && p.part_dn && p.z3 && p.m3 && p.r3 && p.n3_w && p.part_n3 &&
                 p.gz && p.dbr3 && (!p.gx_next || (p.ew && p.dE_next)) && n_slots >= 1, "dec_head_bwd: null pointer");
   if (p.rows <= 0) return MANSY_OK;
-  const size_t lds = (size_t)4 * 4 * p.C * sizeof(float);
+  const size_t lds = (size_t)HEAD_WAVES * 4 * p.C * sizeof(float);
+  const dim3 block(64 * HEAD_WAVES);
   switch (p.C / 256) {
-    case 1: hipLaunchKernelGGL(dec_head_bwd_kernel<1>, dim3(n_slots), dim3(256), lds, st, p); break;
-    case 2: hipLaunchKernelGGL(dec_head_bwd_kernel<2>, dim3(n_slots), dim3(256), lds, st, p); break;
-    case 3: hipLaunchKernelGGL(dec_head_bwd_kernel<3>, dim3(n_slots), dim3(256), lds, st, p); break;
-    default: hipLaunchKernelGGL(dec_head_bwd_kernel<4>, dim3(n_slots), dim3(256), lds, st, p); break;
+    case 1: hipLaunchKernelGGL(dec_head_bwd_kernel<1>, dim3(n_slots), block, lds, st, p); break;
+    case 2: hipLaunchKernelGGL(dec_head_bwd_kernel<2>, dim3(n_slots), block, lds, st, p); break;
+    case 3: hipLaunchKernelGGL(dec_head_bwd_kernel<3>, dim3(n_slots), block, lds, st, p); break;
+    default: hipLaunchKernelGGL(dec_head_bwd_kernel<4>, dim3(n_slots), block, lds, st, p); break;
   }
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
