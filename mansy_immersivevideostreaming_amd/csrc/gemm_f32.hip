@@ -651,7 +651,9 @@ int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B,
   int splits = 1;
   if (force_splitk > 0) splits = force_splitk;
   else if (plain && ep.accumulate && tiles < 256) {
-    splits = (int)(512 / tiles);            // fill ONE round of resident workgroups, never spill a few into a second
+    // fill ONE round of resident workgroups, never spill a few into a second: 2 per CU for the 128x128 / 64x64 loops as
+    // dispatched here, 3 per CU for the 128x64 LDS-DMA loop (48 KB LDS, 136 VGPRs) -- tools/dw_split_sweep.py
+    splits = (int)(((dma && tile == 96) ? 768 : 512) / tiles);
     if (splits < 1) splits = 1;
     const int max_splits = K / (BK * 8) > 0 ? K / (BK * 8) : 1;
     if (splits > max_splits) splits = max_splits;
