@@ -23,7 +23,15 @@ constexpr int NTL = 64, NR = 5, PAST_K = 8, N_ACTION = 15;
 constexpr int OBS_LD = MANSY_OBS_LD;
 __constant__ int A2R[N_ACTION][2] = {{1,0},{2,0},{3,0},{4,0},{2,1},{3,1},{4,1},{3,2},{4,2},{4,3},{0,0},{1,1},{2,2},{3,3},{4,4}};
 
-struct EnvState {           // per-environment record (AoS, 256 bytes)
+typedef float RingMem[PAST_K];
+typedef float RingReg __attribute__((ext_vector_type(PAST_K)));
+
+// Per-environment record. EnvState (rings as float[8], AoS, 256 bytes) is the layout in HBM; EnvRegs (rings as 8-wide vector
+// values) is the copy a kernel works on. hipcc keeps a local record with array members in scratch memory for the whole kernel
+// (a lane-indexed ring read becomes a dynamically indexed private load, which pins the stack object); vector members are SSA
+// values, so the record lives in registers and a lane-indexed read is a select chain.
+template <typename Ring>
+struct EnvRec {
   int worker_id, worker_num, sample_id;
   int video, vp, trace, qoe;
   int next_chunk, end_chunk;
@@ -31,9 +39,26 @@ struct EnvState {           // per-environment record (AoS, 256 bytes)
   double cur_time, buf_size, last_chunk_accuracy;
   double log_qoe, log_qoe1, log_qoe2, log_qoe3;
   float prev_vq, buffer0;
-  float past_throughput[PAST_K], past_acc[PAST_K], past_in[PAST_K], past_out[PAST_K], past_q[PAST_K], past_var[PAST_K],
-      past_rebuf[PAST_K];
+  Ring past_throughput, past_acc, past_in, past_out, past_q, past_var, past_rebuf;
 };
+using EnvState = EnvRec<RingMem>;
+using EnvRegs = EnvRec<RingReg>;
+
+template <typename D, typename S>
+__device__ __forceinline__ void copy_state(D& d, const S& s) {   // member-wise: a whole-struct copy is a memcpy via the stack
+  d.worker_id = s.worker_id; d.worker_num = s.worker_num; d.sample_id = s.sample_id;
+  d.video = s.video; d.vp = s.vp; d.trace = s.trace; d.qoe = s.qoe;
+  d.next_chunk = s.next_chunk; d.end_chunk = s.end_chunk;
+  d.cur_idx = s.cur_idx; d.has_prev = s.has_prev; d.log_n = s.log_n;
+  d.cur_time = s.cur_time; d.buf_size = s.buf_size; d.last_chunk_accuracy = s.last_chunk_accuracy;
+  d.log_qoe = s.log_qoe; d.log_qoe1 = s.log_qoe1; d.log_qoe2 = s.log_qoe2; d.log_qoe3 = s.log_qoe3;
+  d.prev_vq = s.prev_vq; d.buffer0 = s.buffer0;
+#pragma unroll
+  for (int i = 0; i < PAST_K; ++i) {
+    d.past_throughput[i] = s.past_throughput[i]; d.past_acc[i] = s.past_acc[i]; d.past_in[i] = s.past_in[i]; d.past_out[i] = s.past_out[i];
+    d.past_q[i] = s.past_q[i]; d.past_var[i] = s.past_var[i]; d.past_rebuf[i] = s.past_rebuf[i];
+  }
+}
 
 __device__ __forceinline__ unsigned long long dilate8(unsigned long long m) {
   // columns +-1 with wrap inside each row byte, then rows +-1 with wrap (rotate by 8 bits)
@@ -43,14 +68,31 @@ __device__ __forceinline__ unsigned long long dilate8(unsigned long long m) {
   return h | (h << 8) | (h >> 56) | (h >> 8) | (h << 56);
 }
 
-__device__ __forceinline__ int closest_rate_version(const int* rates, int rate) {
-  int ver = 0, gap = abs(rates[0] - rate);
+// The five bitrates as named scalars (a local int[5] with a runtime index would live in scratch memory).
+struct Rates { int r0, r1, r2, r3, r4; };
+__device__ __forceinline__ Rates load_rates(const mansy_env_tables& T) {
+  Rates r = {T.video_rates[0], T.video_rates[1], T.video_rates[2], T.video_rates[3], T.video_rates[4]};
+  return r;
+}
+__device__ __forceinline__ int pick_rate(const Rates& r, int i) {
+  return i == 4 ? r.r4 : i == 3 ? r.r3 : i == 2 ? r.r2 : i == 1 ? r.r1 : r.r0;
+}
+__device__ __forceinline__ float pick_past(const RingReg& ring, int i) {
+  float v = ring[0];
 #pragma unroll
-  for (int i = 0; i < NR; ++i) {
-    const int g = abs(rates[i] - rate);
-    if (g < gap) { ver = i; gap = g; }
-    else if (g == gap && rates[i] < rates[ver]) ver = i;
-  }
+  for (int k = 1; k < PAST_K; ++k) v = i == k ? ring[k] : v;
+  return v;
+}
+__device__ __forceinline__ void closer(int cand, int cand_rate, int rate, int& ver, int& ver_rate, int& gap) {
+  const int g = abs(cand_rate - rate);
+  if (g < gap || (g == gap && cand_rate < ver_rate)) { ver = cand; ver_rate = cand_rate; gap = g; }
+}
+__device__ __forceinline__ int closest_rate_version(const Rates& r, int rate) {   // nearest bitrate, ties to the lower one
+  int ver = 0, ver_rate = r.r0, gap = abs(r.r0 - rate);
+  closer(1, r.r1, rate, ver, ver_rate, gap);
+  closer(2, r.r2, rate, ver, ver_rate, gap);
+  closer(3, r.r3, rate, ver, ver_rate, gap);
+  closer(4, r.r4, rate, ver, ver_rate, gap);
   return ver;
 }
 
@@ -67,7 +109,7 @@ __device__ __forceinline__ int wave_isum(int v) {
   return v;
 }
 
-__device__ void write_obs(const mansy_env_tables& T, const EnvState& s, int chunk, int action, int lane, float* __restrict__ obs) {
+__device__ __forceinline__ void write_obs(const mansy_env_tables& T, const EnvRegs& s, int chunk, int action, int lane, float* __restrict__ obs) {
   const size_t mrow = ((size_t)s.video * T.n_chunk_max + chunk) * NR * NTL;
   const float inv_rate = (float)T.video_rates[NR - 1];
 #pragma unroll
@@ -79,13 +121,13 @@ __device__ void write_obs(const mansy_env_tables& T, const EnvState& s, int chun
   // the 68 scalar slots: 0..7 throughput | 712..743 acc,q,var,rebuf | 744 buffer | 745..747 qoe_w | 748..762 one-hot |
   // 763..778 rates in/out | 779 pad
   if (lane < PAST_K) {
-    obs[MANSY_O_THROUGHPUT + lane] = s.past_throughput[lane];
-    obs[MANSY_O_VP_ACC + lane] = s.past_acc[lane];
-    obs[MANSY_O_PAST_Q + lane] = s.past_q[lane];
-    obs[MANSY_O_PAST_VAR + lane] = s.past_var[lane];
-    obs[MANSY_O_PAST_REBUF + lane] = s.past_rebuf[lane];
-    obs[MANSY_O_RATES_IN + lane] = s.past_in[lane];
-    obs[MANSY_O_RATES_OUT + lane] = s.past_out[lane];
+    obs[MANSY_O_THROUGHPUT + lane] = pick_past(s.past_throughput, lane);
+    obs[MANSY_O_VP_ACC + lane] = pick_past(s.past_acc, lane);
+    obs[MANSY_O_PAST_Q + lane] = pick_past(s.past_q, lane);
+    obs[MANSY_O_PAST_VAR + lane] = pick_past(s.past_var, lane);
+    obs[MANSY_O_PAST_REBUF + lane] = pick_past(s.past_rebuf, lane);
+    obs[MANSY_O_RATES_IN + lane] = pick_past(s.past_in, lane);
+    obs[MANSY_O_RATES_OUT + lane] = pick_past(s.past_out, lane);
   }
   const float* w = T.qoe_w + 3 * s.qoe;
   const float wsum = (w[0] + w[1]) + w[2];
@@ -94,7 +136,7 @@ __device__ void write_obs(const mansy_env_tables& T, const EnvState& s, int chun
   if (lane == 0) { obs[MANSY_O_BUFFER] = s.buffer0 / (float)T.startup_download; obs[MANSY_OBS_DIM] = 0.f; }
 }
 
-__device__ void do_reset(const mansy_env_tables& T, EnvState& s) {
+__device__ __forceinline__ void do_reset(const mansy_env_tables& T, EnvRegs& s) {
   s.sample_id = s.worker_id % T.n_sample;   // (reference: IndexError if worker_id >= len(samples); wrap instead)
   s.worker_id = (s.worker_id + s.worker_num) % T.n_sample;
   const int* sm = T.samples + 4 * s.sample_id;
@@ -115,29 +157,28 @@ __device__ void do_reset(const mansy_env_tables& T, EnvState& s) {
   s.log_qoe = s.log_qoe1 = s.log_qoe2 = s.log_qoe3 = 0.0; s.log_n = 0;
 }
 
-__device__ __forceinline__ void roll_push(float* ring, float v) {
-#pragma unroll
-  for (int i = PAST_K - 1; i > 0; --i) ring[i] = ring[i - 1];
+__device__ __forceinline__ void roll_push(RingReg& ring, float v) {
+  ring = __builtin_shufflevector(ring, ring, 0, 0, 1, 2, 3, 4, 5, 6);
   ring[0] = v;
 }
 
 __global__ __launch_bounds__(256) void env_init_kernel(EnvState* st, int n_env, int index_offset, int worker_num, int seed) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= n_env) return;
-  EnvState s;
-  memset(&s, 0, sizeof(s));
+  EnvRegs s = {};
   s.worker_num = worker_num;
   s.worker_id = (seed + index_offset + e) % worker_num;      // tianshou venv.seed(seed): env i gets seed + i (mansy_env.py:253-256)
-  st[e] = s;
+  copy_state(st[e], s);
 }
 
 __global__ __launch_bounds__(256) void env_reset_kernel(mansy_env_tables T, EnvState* st, int n_env, float* obs) {
   const int e = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (e >= n_env) return;
-  EnvState s = st[e];                  // every lane holds the (uniform) record; lane 0 writes it back
+  EnvRegs s;
+  copy_state(s, st[e]);                  // every lane holds the (uniform) record; lane 0 writes it back
   do_reset(T, s);
   write_obs(T, s, s.next_chunk, -1, lane, obs + (size_t)e * OBS_LD);
-  if (lane == 0) st[e] = s;
+  if (lane == 0) copy_state(st[e], s);
 }
 
 __global__ __launch_bounds__(256) void env_step_kernel(mansy_env_tables T, EnvState* st, int n_env, const int* __restrict__ actions,
@@ -145,7 +186,8 @@ __global__ __launch_bounds__(256) void env_step_kernel(mansy_env_tables T, EnvSt
                                                        float* qoe_parts, mansy_env_episode_log elog) {
   const int e = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (e >= n_env) return;
-  EnvState s = st[e];
+  EnvRegs s;
+  copy_state(s, st[e]);
   const int action = actions[e];
   const int rin = (action >= 0 && action < N_ACTION) ? A2R[action][0] : 0;
   const int rout = (action >= 0 && action < N_ACTION) ? A2R[action][1] : 0;
@@ -164,10 +206,8 @@ __global__ __launch_bounds__(256) void env_step_kernel(mansy_env_tables T, EnvSt
       if (dist < 0 && ((m >> lane) & 1ull)) dist = sidx;
     }
   }
-  int rates[NR];
-#pragma unroll
-  for (int i = 0; i < NR; ++i) rates[i] = T.video_rates[i];
-  const int ver = dist == 0 ? rin : closest_rate_version(rates, rates[rout] / (dist > 0 ? dist : 1));
+  const Rates rates = load_rates(T);
+  const int ver = dist == 0 ? rin : closest_rate_version(rates, pick_rate(rates, rout) / (dist > 0 ? dist : 1));
   // ---- Simulator.simulate_download
   const size_t mrow = ((size_t)s.video * T.n_chunk_max + chunk) * NR * NTL;
   const int chunk_size = wave_isum(T.size[mrow + ver * NTL + lane]);
@@ -192,7 +232,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(mansy_env_tables T, EnvSt
   const float s_vq = seq_sum64(gv * tq), s_v = seq_sum64(gv);
   float vq = s_vq / s_v;
   const float s_var = seq_sum64(gv * fabsf(tq - vq));
-  const float max_rate = (float)rates[NR - 1];
+  const float max_rate = (float)rates.r4;
   const float intra = (s_var / s_v) / max_rate;
   vq = vq / max_rate;
   const float inter = s.has_prev ? fabsf(vq - s.prev_vq) : 0.f;
@@ -206,8 +246,8 @@ __global__ __launch_bounds__(256) void env_step_kernel(mansy_env_tables T, EnvSt
   // ---- history rings
   roll_push(s.past_throughput, (float)(((double)chunk_size / download_time) / T.max_throughput));
   roll_push(s.past_acc, (float)s.last_chunk_accuracy);
-  roll_push(s.past_in, (float)((double)rates[rin] / (double)rates[NR - 1]));
-  roll_push(s.past_out, (float)((double)rates[rout] / (double)rates[NR - 1]));
+  roll_push(s.past_in, (float)((double)pick_rate(rates, rin) / (double)rates.r4));
+  roll_push(s.past_out, (float)((double)pick_rate(rates, rout) / (double)rates.r4));
   s.buffer0 = (float)s.buf_size;
   roll_push(s.past_q, qoe1);
   roll_push(s.past_rebuf, (float)(rebuf / (double)T.startup_download));
@@ -235,7 +275,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(mansy_env_tables T, EnvSt
   } else if (obs_cur && obs_cur != obs_next) {
     write_obs(T, s, s.next_chunk, action, lane, obs_cur + (size_t)e * OBS_LD);
   }
-  if (lane == 0) st[e] = s;
+  if (lane == 0) copy_state(st[e], s);
 }
 
 __global__ __launch_bounds__(256) void alloc_rates_kernel(const float* __restrict__ pred_vp, const int* __restrict__ actions, int n,
@@ -252,10 +292,8 @@ __global__ __launch_bounds__(256) void alloc_rates_kernel(const float* __restric
 #pragma unroll
     for (int sidx = 1; sidx <= 4; ++sidx) { m = dilate8(m); if (dist < 0 && ((m >> lane) & 1ull)) dist = sidx; }
   }
-  int rates[NR];
-#pragma unroll
-  for (int i = 0; i < NR; ++i) rates[i] = T.video_rates[i];
-  versions[(size_t)e * NTL + lane] = dist == 0 ? rin : closest_rate_version(rates, rates[rout] / (dist > 0 ? dist : 1));
+  const Rates rates = load_rates(T);
+  versions[(size_t)e * NTL + lane] = dist == 0 ? rin : closest_rate_version(rates, pick_rate(rates, rout) / (dist > 0 ? dist : 1));
 }
 
 int check_tables(const mansy_env_tables* T) {
