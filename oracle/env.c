@@ -9,9 +9,13 @@
  *   PlaybackBuffer.push_chunk            bitrate_selection/simulators/buffer.py:8-15
  *   HMDTrace.get_viewport                bitrate_selection/simulators/hmdtrace.py:16-23
  *   QoEModel.calculate_qoe               bitrate_selection/utils/qoe.py:22-34
+ *   ExpertEnv cache profile / choose_action   bitrate_selection/envs/expert_env.py:126-181, 358-422
+ *   ExpertSimulator.virtual_simulate_download_with_chunk_size, calculate_chunk_size_and_quality
+ *                                        bitrate_selection/simulators/simulator.py:127-158
+ *   QoEModelExpert.calculate_qoe_with_given_quality   bitrate_selection/utils/qoe.py:49-59
  *
  * Number semantics are those of THIS container (Python 3.10, numpy 2.2 / NEP 50), pinned by
- * tests/golden/env_*.npz which were produced by running the imported reference:
+ * tests/golden/env_reference.npz and expert_reference.npz which were produced by running the imported reference:
  *   - chunk size: exact integer sum; download time / buffer / rebuffer: Python floats (IEEE double,
  *     no FMA contraction -- build with -ffp-contract=off);
  *   - QoE: Python sum() over float32 arrays = sequential float32 accumulation in tile order;
@@ -241,3 +245,97 @@ int oracle_env_step(const oracle_env_tables *T, oracle_env_state *s, int action,
 
 int oracle_env_state_size(void) { return (int)sizeof(oracle_env_state); }
 int oracle_env_tables_size(void) { return (int)sizeof(oracle_env_tables); }
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * MPC expert (ExpertEnv).  Its reset/step are MANSYEnv's with reward = qoe (expert_env.py:184-330), i.e.
+ * oracle_env_reset / oracle_env_step with train_identifier_reward = 0; what it adds is the per-chunk profile cache and
+ * the exhaustive look-ahead search.
+ * Cache arrays: [n_vp][n_vpchunk_max][N_ACTION], chunk index relative to vp_start, filled for the chunks an episode can
+ * visit (startup_download + 1 .. min(vp_end, video_len - 1)), zero elsewhere.  vp_video[vp] = manifest slot of that
+ * viewport trace's video. */
+static void chunk_size_and_quality(const oracle_env_tables *T, int video, int chunk, const int32_t *ver, const uint8_t *gv,
+                                   long long *chunk_size, float *quality, float *var) {
+    /* simulator.py:146-158 + expert_env.py:162,172: exact integer size, float32 sequential sums in tile order */
+    const int32_t *sz = T->size + ((size_t)video * T->n_chunk_max + chunk) * NR * NT;
+    const float *ql = T->quality + ((size_t)video * T->n_chunk_max + chunk) * NR * NT;
+    long long cs = 0; float tq[NT];
+    for (int t = 0; t < NT; ++t) { cs += sz[ver[t] * NT + t]; tq[t] = ql[ver[t] * NT + t]; }
+    float s_vq = 0.f, s_v = 0.f;
+    for (int t = 0; t < NT; ++t) { s_vq += (float)gv[t] * tq[t]; s_v += (float)gv[t]; }
+    const float vq = s_vq / s_v;
+    float s_var = 0.f;
+    for (int t = 0; t < NT; ++t) s_var += (float)gv[t] * fabsf(tq[t] - vq);
+    *chunk_size = cs; *quality = vq; *var = s_var / s_v;
+}
+
+void oracle_expert_profile(const oracle_env_tables *T, const int32_t *vp_video, int n_vp, float *gt_quality, float *pred_quality,
+                           float *gt_var, float *pred_var, int64_t *gt_size, int64_t *pred_size) {
+    for (int vp = 0; vp < n_vp; ++vp) {
+        const int video = vp_video[vp];
+        int end_chunk = T->vp_end[vp];
+        if (T->video_len[video] - 1 < end_chunk) end_chunk = T->video_len[video] - 1;
+        for (int chunk = T->startup_download + 1; chunk <= end_chunk; ++chunk) {
+            const uint8_t *gv = vp_row(T, T->vp_gt, vp, chunk), *pv = vp_row(T, T->vp_pred, vp, chunk);
+            float gvf[NT], pvf[NT];
+            for (int i = 0; i < NT; ++i) { gvf[i] = (float)gv[i]; pvf[i] = (float)pv[i]; }
+            const size_t row = ((size_t)vp * T->n_vpchunk_max + (chunk - T->vp_start[vp])) * N_ACTION;
+            for (int a = 0; a < N_ACTION; ++a) {
+                int rin, rout; action2rates(a, &rin, &rout);
+                int32_t ver[NT]; long long cs;
+                oracle_allocate_tile_rates(rin, rout, gvf, T->video_rates, ver);
+                chunk_size_and_quality(T, video, chunk, ver, gv, &cs, gt_quality + row + a, gt_var + row + a);
+                gt_size[row + a] = cs;
+                oracle_allocate_tile_rates(rin, rout, pvf, T->video_rates, ver);
+                chunk_size_and_quality(T, video, chunk, ver, gv, &cs, pred_quality + row + a, pred_var + row + a);
+                pred_size[row + a] = cs;
+            }
+        }
+    }
+}
+
+/* expert_env.py:358-422 -- literal: every one of the action_space**horizon plans is scored over the first
+ * min(horizon, chunks left) steps; the first plan with the strictly largest float32 QoE sum wins; its first action is
+ * returned.  `best_value` / `best_index` (optional) expose the winning sum and plan index. */
+int oracle_expert_choose(const oracle_env_tables *T, const oracle_env_state *s, int horizon_cfg, const float *pred_quality,
+                         const float *pred_var, const int64_t *pred_size, float *best_value, long long *best_index) {
+    long long n_plans = 1;
+    for (int j = 0; j < horizon_cfg; ++j) n_plans *= N_ACTION;
+    int horizon = s->end_chunk - s->next_chunk + 1;
+    if (horizon_cfg < horizon) horizon = horizon_cfg;
+    const double *bw = T->trace_bw + (size_t)s->trace * T->trace_len_max;
+    const int tlen = T->trace_len[s->trace];
+    const float *w = T->qoe_w + 3 * s->qoe;
+    const float max_rate = (float)T->video_rates[NR - 1];
+    const size_t row0 = ((size_t)s->vp * T->n_vpchunk_max + (s->next_chunk - T->vp_start[s->vp])) * N_ACTION;
+    float best = -INFINITY; long long best_i = 0;
+    for (long long i = 0; i < n_plans; ++i) {
+        double cur_time = s->cur_time, buf = s->buf_size; int cur_idx = s->cur_idx;      /* record / restore */
+        int has_prev = s->has_prev; float prev = s->prev_vq;
+        float qoe_sum = 0.f; long long tmp = i;
+        for (int t = 0; t < horizon; ++t) {
+            const int a = (int)(tmp % N_ACTION); tmp /= N_ACTION;
+            const size_t k = row0 + (size_t)t * N_ACTION + a;
+            double size = (double)pred_size[k];
+            const double start = cur_time;
+            while (size > 0) {                                  /* network.py:22-35 */
+                double remain = (floor(cur_time + 1) - cur_time) * bw[cur_idx];
+                if (size >= remain) { cur_idx = (cur_idx + 1) % tlen; cur_time = floor(cur_time + 1); size -= remain; }
+                else { cur_time += size / bw[cur_idx]; size = 0; }
+            }
+            const double download_time = cur_time - start;
+            double rebuf = 0.0;                                 /* buffer.py:8-15 */
+            if (download_time > buf) { rebuf = download_time - buf; buf = (double)T->chunk_length; }
+            else buf = buf - download_time + (double)T->chunk_length;
+            const float vq = pred_quality[k] / max_rate, intra = pred_var[k] / max_rate;   /* qoe.py:49-59 */
+            const float inter = has_prev ? fabsf(vq - prev) : 0.0f;
+            prev = vq; has_prev = 1;
+            const float qoe3 = intra + inter;
+            const float qoe = w[0] * vq - w[1] * (float)rebuf - w[2] * qoe3;
+            qoe_sum = qoe_sum + qoe;
+        }
+        if (best < qoe_sum) { best = qoe_sum; best_i = i; }
+    }
+    if (best_value) *best_value = best;
+    if (best_index) *best_index = best_i;
+    return (int)(best_i % N_ACTION);      /* rates2action(action2rates(a)) == a for all 15 actions */
+}

@@ -93,3 +93,25 @@ def generate_environment_samples(nv, nu, nt, nq):
 def generate_environment_test_samples(nv, nu, nt, nq):
     """utils/common.py:87-98 (full product)."""
     return np.array([(i, j, k, l) for i in range(nv) for j in range(nu) for k in range(nt) for l in range(nq)], np.int32)
+
+
+class Expert:
+    """MPC expert over an `Env` (expert_env.py): profile cache + exhaustive look-ahead `choose_action`."""
+
+    def __init__(self, tables, vp_video, horizon):
+        self.L, self.T, self.horizon = _b.lib(), tables, int(horizon)
+        self.vp_video = np.ascontiguousarray(vp_video, dtype=np.int32)
+        n_vp, nvc = tables.a['vp_gt'].shape[:2]
+        self.cache = {k: np.zeros((n_vp, nvc, 15), np.int64 if 'size' in k else np.float32)
+                      for k in ('gt_quality', 'pred_quality', 'gt_var', 'pred_var', 'gt_size', 'pred_size')}
+        c = self.cache
+        self.L.oracle_expert_profile(ctypes.byref(tables.c), self.vp_video.ctypes.data_as(c_p), n_vp, *[
+            c[k].ctypes.data_as(c_p) for k in ('gt_quality', 'pred_quality', 'gt_var', 'pred_var', 'gt_size', 'pred_size')])
+
+    def choose_action(self, env, with_value=False):
+        c = self.cache
+        val, idx = ctypes.c_float(), ctypes.c_longlong()
+        a = self.L.oracle_expert_choose(ctypes.byref(self.T.c), env.state, self.horizon, c['pred_quality'].ctypes.data_as(c_p),
+                                        c['pred_var'].ctypes.data_as(c_p), c['pred_size'].ctypes.data_as(c_p), ctypes.byref(val),
+                                        ctypes.byref(idx))
+        return (int(a), np.float32(val.value), int(idx.value)) if with_value else int(a)
