@@ -151,6 +151,23 @@ int mansy_env_step(const mansy_env_tables* T, void* state, int n_env, const int*
 int mansy_allocate_tile_rates(const float* pred_viewport, const int* actions, int n, const int video_rates[5], int* versions,
                               void* stream);
 
+/* ------------------------------------------------------------------ MPC expert (demonstrations for behaviour cloning)
+ * Replaces ExpertEnv._profile_viewport_qualities_sizes and ExpertEnv.choose_action (bitrate_selection/envs/
+ * expert_env.py:126-181, 358-422) + ExpertSimulator.virtual_simulate_download_with_chunk_size /
+ * calculate_chunk_size_and_quality (simulators/simulator.py:127-158) + QoEModelExpert.calculate_qoe_with_given_quality
+ * (utils/qoe.py:49-59).  ExpertEnv.reset/step are mansy_env_reset/_step with train_identifier_reward = 0.
+ * Cache arrays are [n_vp][n_vpchunk_max][15] (chunk index relative to vp_start; entries of chunks no episode visits are
+ * zero); vp_video[vp] = manifest slot of that viewport trace's video.  Chunk sizes are int32 (64 tiles x < 2^25 bytes). */
+#define MANSY_EXPERT_MAX_HORIZON 6
+int mansy_expert_profile(const mansy_env_tables* T, const int* vp_video, int n_vp, float* gt_quality, float* pred_quality, float* gt_var,
+                         float* pred_var, int* gt_size, int* pred_size, void* stream);
+/* For each of n_env environments (state = the mansy_env_* records): first action of the best of the 15^horizon plans
+ * (first plan with the strictly largest float32 QoE sum).  keys: n_env uint64 workspace.  best_value / best_index
+ * (optional): winning score and plan index. */
+int mansy_expert_choose_action(const mansy_env_tables* T, const void* state, int n_env, int horizon, const float* pred_quality,
+                               const float* pred_var, const int* pred_size, unsigned long long* keys, int* actions, float* best_value,
+                               long long* best_index, void* stream);
+
 /* ------------------------------------------------------------------ bitrate-selection networks + PPO
  * Replaces FeatureNet/Actor/Critic/QoEIdentifier.forward (bitrate_selection/models/mansy.py:26-155),
  * calculate_indentifier_reward / train_identifier (utils/mansy_utils.py:9-49), the relabel loop (models/mansy_ppo.py:41-51)

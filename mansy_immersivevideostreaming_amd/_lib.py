@@ -85,6 +85,8 @@ _PROTOS = {
     'mansy_env_reset': [P, P, c_int, P, P],
     'mansy_env_step': [P, P, c_int, P, P, P, P, P, P, P, P],
     'mansy_allocate_tile_rates': [P, P, c_int, P, P, P],
+    'mansy_expert_profile': [P, P, c_int, P, P, P, P, P, P, P],
+    'mansy_expert_choose_action': [P, P, c_int, c_int, P, P, P, P, P, P, P, P],
     'mansy_net_num_params': [c_int],
     'mansy_net_param_info': [c_int, c_int, ctypes.c_char_p, c_int, P, P, P],
     'mansy_ppo_workspace_bytes': [c_int],

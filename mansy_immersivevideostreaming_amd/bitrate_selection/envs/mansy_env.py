@@ -86,12 +86,15 @@ class EnvTables:
 
     # ---- builders ------------------------------------------------------------------------------
     @classmethod
-    def from_dataset(cls, config, dataset, network_dataset, mode, qoe_weights, device, seed=0, use_identifier=False):
-        """Reads the files Simulator.__init__ reads (simulator.py:30-45): prediction pickles, manifests, traces."""
+    def from_dataset(cls, config, dataset, network_dataset, mode, qoe_weights, device, seed=0, use_identifier=False, samples=None):
+        """Reads the files Simulator.__init__ reads (simulator.py:30-45): prediction pickles, manifests, traces.
+        `samples`: explicit episode catalogue of (video, user, trace, qoe) list positions (ExpertEnv takes one)."""
         videos = config.video_split[dataset][mode]
         users = config.user_split[dataset][mode]
         traces = config.network_split[network_dataset][mode]
-        if mode != 'test':
+        if samples is not None:
+            samples = [tuple(int(x) for x in s) for s in samples]
+        elif mode != 'test':
             samples = generate_environment_samples(videos, users, traces, qoe_weights, seed=seed)
         else:
             samples = generate_environment_test_samples(videos, users, traces, qoe_weights)
