@@ -145,6 +145,44 @@ def bench_ppo(rank, world, dev, mdist, cycles=5, warmup=2, n_env=256, steps_per_
             'model_flops_per_env_step': 11.5e6, 'algorithmic_bytes_per_env_step': 29e3}
 
 
+def bench_expert(dev, horizon=4, n_env=256, reps=20, cpu=True):
+    """MPC expert: look-ahead decisions/s of the exhaustive 15^h plan search, all environments per launch,
+    next to the sequential C oracle's literal scan on one host core."""
+    import torch
+    from mansy_immersivevideostreaming_amd.bitrate_selection.envs import expert_env as X
+    T = X.EnvTables.synthetic(dev, seed=5, train_identifier_reward=False)
+    venv = X.ExpertVecEnv(T, n_env, horizon, seed=0)
+    venv.reset()
+    for _ in range(3):
+        venv.step(venv.choose_action())
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        venv.choose_action()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    out = {'metric': 'MPC expert decisions/sec', 'value': round(n_env / ms * 1e3, 1), 'unit': 'decisions/s', 'ms_per_call': round(ms, 4),
+           'plans_per_s': round(n_env * 15 ** horizon / ms * 1e3, 0),
+           'config': {'workload': f'{n_env} environments x 15^{horizon} plans per decision (run_expert.py --horizon {horizon}), '
+                                  'synthetic Jin2022/4G-shaped tables, f64 download integration + f32 QoE'}}
+    if cpu:
+        from oracle import env as oenv
+        OT = oenv.EnvTables({k: T.host[k] for k in T.FIELDS}, T.host['qoe_w'], train_identifier_reward=False)
+        ex = oenv.Expert(OT, venv.cache.vp_video.cpu().numpy(), horizon)
+        oe = oenv.Env(OT, seed=0, worker_num=n_env)
+        oe.reset()
+        k, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 1.0:
+            ex.choose_action(oe)
+            k += 1
+        dt = time.perf_counter() - t0
+        out['cpu_baseline'] = {'value': round(k / dt, 1), 'unit': 'decisions/s', 'cores': 1, 'kind': 'port',
+                               'sample': f'{k} decisions of the C oracle (literal 15^{horizon} scan) in {dt:.1f}s'}
+    return out
+
+
 def cpu_baseline_ppo(seconds=6.0):
     """Reference-style rollout on one host core: sequential C-oracle env + B=1 oracle actor forward + sampling."""
     import numpy as np
@@ -286,6 +324,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
             out['secondary']['cpu_baseline'] = cpu_baseline_ppo()
+        out['tertiary'] = bench_expert(dev, cpu=(world == 1 and not args.no_cpu_baseline))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -69,6 +69,20 @@ class ExpertCache:
         return out
 
 
+def dataset_cache(config, dataset, network_dataset, qoe_weights, device):
+    """The `<dataset>_cache.pkl` content of expert_env.py:92-111: the profile of EVERY (video, user) pair of the train, valid
+    and test splits (the simulator is built with trace 0 there: 'a random trace is just fine')."""
+    videos, users = [], []
+    for split in ('train', 'valid', 'test'):
+        videos += config.video_split[dataset][split]
+        users += config.user_split[dataset][split]
+    videos, users = list(set(videos)), list(set(users))
+    trace = config.network_split[network_dataset]['train'][:1]
+    samples = [(i, j, 0, 0) for i in range(len(videos)) for j in range(len(users))]
+    tables = EnvTables.from_dataset(config, dataset, network_dataset, 'train', qoe_weights, device, samples=samples, lists=(videos, users, trace))
+    return ExpertCache(tables).to_reference()
+
+
 class ExpertVecEnv(MANSYVecEnv):
     def __init__(self, tables, n_env, horizon, seed=0, index_offset=0, worker_num=None, cache=None, **kw):
         if not 1 <= int(horizon) <= MAX_HORIZON:
@@ -105,7 +119,7 @@ class ExpertEnv:
         self.tables = EnvTables.from_dataset(config, dataset, network_dataset, mode, qoe_weights, dev, seed=seed, samples=samples)
         self._venv = ExpertVecEnv(self.tables, 1, horizon, seed=0, worker_num=1)       # walks `samples` in order (expert_env.py:185)
         if cache_path and (refresh_cache or not os.path.exists(cache_path)):
-            pickle.dump(self._venv.cache.to_reference(), open(cache_path, 'wb'))
+            pickle.dump(dataset_cache(config, dataset, network_dataset, qoe_weights, dev), open(cache_path, 'wb'))
             print('Save expert cache at', cache_path)
         self._act = torch.zeros(1, dtype=torch.int32, device=self.tables.device)
         self.sample_id = -1
@@ -131,21 +145,7 @@ class ExpertEnv:
         obs, rew, done, _ = self._venv.step(self._act, auto_reset=False)
         over = bool(done[0].item())
         self.state = obs_to_dict(obs[0].cpu().numpy())
-        if over:
-            write_episode_log(self.log_path, self._venv.pop_episode_log(), self.tables, self.qoe_weights)
+        if over:       # expert_env.py:338-356 (same columns and rounding as MANSYEnv._log)
+            from ..models.mansy_trainer import write_episode_log
+            write_episode_log(self.log_path, self.tables, self.qoe_weights, self._venv.pop_episode_log())
         return self.state, np.float32(rew[0].item()), over, {}
-
-
-def write_episode_log(log_path, records, tables, qoe_weights):
-    """expert_env.py:338-356 (same columns and rounding as MANSYEnv._log) from the device-side episode accumulators."""
-    if not len(records):
-        return
-    if not os.path.exists(log_path):
-        with open(log_path, 'w', encoding='utf-8') as file:
-            file.write('video,user,trace,qoe_w1,qoe_w2,qoe_w3,qoe,qoe1,qoe2,qoe3\n')
-    with open(log_path, 'a', encoding='utf-8') as file:
-        for sid, _, n, sq, s1, s2, s3, qi in records:
-            w = np.array(qoe_weights[int(qi)], dtype=np.float32)
-            video, user, trace = tables.ids[3][int(sid)]
-            file.write(f'{video},{user},{trace},{w[0]},{w[1]},{w[2]},{round(sq / n / sum(w), 5)},{round(s1 / n, 5)},{round(s2 / n, 5)},'
-                       f'{round(s3 / n, 5)}\n')

@@ -86,12 +86,13 @@ class EnvTables:
 
     # ---- builders ------------------------------------------------------------------------------
     @classmethod
-    def from_dataset(cls, config, dataset, network_dataset, mode, qoe_weights, device, seed=0, use_identifier=False, samples=None):
+    def from_dataset(cls, config, dataset, network_dataset, mode, qoe_weights, device, seed=0, use_identifier=False, samples=None,
+                     lists=None):
         """Reads the files Simulator.__init__ reads (simulator.py:30-45): prediction pickles, manifests, traces.
-        `samples`: explicit episode catalogue of (video, user, trace, qoe) list positions (ExpertEnv takes one)."""
-        videos = config.video_split[dataset][mode]
-        users = config.user_split[dataset][mode]
-        traces = config.network_split[network_dataset][mode]
+        `samples`: explicit episode catalogue of (video, user, trace, qoe) list positions (ExpertEnv takes one);
+        `lists`: explicit (videos, users, traces) id lists instead of the split of `mode`."""
+        videos, users, traces = lists if lists is not None else (
+            config.video_split[dataset][mode], config.user_split[dataset][mode], config.network_split[network_dataset][mode])
         if samples is not None:
             samples = [tuple(int(x) for x in s) for s in samples]
         elif mode != 'test':

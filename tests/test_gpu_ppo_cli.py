@@ -121,3 +121,66 @@ def test_run_mansy_train_and_test_cli(tree):
     assert len(rows) == 1 + 1 * 1 * 1 * 2                        # test split: 1 video x 1 user x 1 trace x 2 preferences
     vrows = open(os.path.join(mdir, 'valid_log.csv')).read().splitlines()
     assert len(vrows) == 1 + 2 * 4                               # 2 epochs x episode_per_test (= 4 valid samples)
+
+
+def test_run_expert_cli_and_dropin_env(tree):
+    """run_expert counterpart: demonstrations / logs / cache under the reference's file names; every demonstration equals
+    the sequential C oracle's expert on the same tables; the drop-in single ExpertEnv reproduces the batched decisions."""
+    from mansy_immersivevideostreaming_amd.bitrate_selection import run_expert
+    from mansy_immersivevideostreaming_amd.bitrate_selection.envs.expert_env import ExpertCache, ExpertEnv
+    from mansy_immersivevideostreaming_amd.bitrate_selection.envs.mansy_env import EnvTables, generate_environment_samples, obs_to_dict
+    from mansy_immersivevideostreaming_amd.bitrate_selection.utils.common import get_config_from_yml
+    from oracle import env as oenv
+    root, cfg = tree
+    run_expert.main(['--train', '--valid', '--test', '--train-dataset', 'Toy', '--test-dataset', 'Toy', '--horizon', '2', '--refresh-cache',
+                     '--qoe-test-ids', '0', '1', '--env-num', '5', '--config', cfg])
+    mdir = os.path.join(root, 'models', 'bitrate_selection', 'expert', 'Toy_4G', 'qoe0_1_2_3')
+    rdir = os.path.join(root, 'results', 'bitrate_selection', 'expert', 'Toy_4G', 'unseen_qoe0_1')
+    config = get_config_from_yml(cfg)
+    qw = config.qoe_split['train']
+    videos, users, traces = config.video_split['Toy']['train'], config.user_split['Toy']['train'], config.network_split['4G']['train']
+    samples = generate_environment_samples(videos, users, traces, qw)
+    demos = pickle.load(open(os.path.join(mdir, 'train_demonstrations.pkl'), 'rb'))
+    assert len(demos) == len(samples) == 8 and os.path.exists(os.path.join(mdir, 'valid_demonstrations.pkl'))
+    rows = open(os.path.join(mdir, 'train_log.csv')).read().splitlines()
+    assert rows[0] == 'video,user,trace,qoe_w1,qoe_w2,qoe_w3,qoe,qoe1,qoe2,qoe3' and len(rows) == 1 + len(samples)
+    assert len(open(os.path.join(rdir, 'results.csv')).read().splitlines()) == 1 + 1 * 1 * 1 * 2
+    # oracle replay of every demonstration (5 environments striding over 8 samples in the CLI run)
+    T = EnvTables.from_dataset(config, 'Toy', '4G', 'train', qw, 'cuda', samples=samples)
+    OT = oenv.EnvTables({k: T.host[k] for k in T.FIELDS}, T.host['qoe_w'], train_identifier_reward=False)
+    ex = oenv.Expert(OT, ExpertCache(T).vp_video.cpu().numpy(), 2)
+    oe = oenv.Env(OT, seed=0, worker_num=1)
+    for sid, (vi, ui, ti, qi) in enumerate(samples):
+        d = demos[videos[vi], users[ui], traces[ti], tuple(qw[qi])]
+        obs = oe.reset()
+        assert oe.sample_id == sid
+        for t in range(len(d['act'])):
+            np.testing.assert_array_equal(d['obs'][t, :779].view(np.uint32), obs.view(np.uint32))
+            a = ex.choose_action(oe)
+            assert a == d['act'][t], (sid, t)
+            obs, _, done, _ = oe.step(a)
+            assert done == d['done'][t]
+        assert done
+        row = rows[1 + sid].split(',')
+        assert [int(x) for x in row[:3]] == [videos[vi], users[ui], traces[ti]]
+    # expert cache pickle: six nested dicts keyed (video, user) -> chunk -> (rate_in, rate_out)
+    cache = pickle.load(open(os.path.join(root, 'models', 'bitrate_selection', 'expert', 'Toy_cache.pkl'), 'rb'))
+    assert len(cache) == 6 and isinstance(cache[4][videos[0], users[0]][6][(1, 0)], int)
+    # drop-in single environment with the reference's constructor signature
+    log = os.path.join(root, 'expert_single.csv')
+    env = ExpertEnv(config, 'Toy', '4G', qw, samples[:2], mdir, os.path.join(root, 'single_cache.pkl'), log, config.startup_download, 2,
+                    refresh_cache=True, mode='train', seed=1)
+    for sid in range(env.sample_count()):
+        st = env.reset()
+        d = demos[env.current_video, env.current_user, env.current_trace, tuple(int(w) for w in env.current_qoe_weight)]
+        over, t = False, 0
+        while not over:
+            ref = obs_to_dict(d['obs'][t])
+            np.testing.assert_array_equal(st['pred_viewport'], ref['pred_viewport'])
+            np.testing.assert_array_equal(st['throughput'], ref['throughput'])
+            a = env.choose_action()
+            assert a == d['act'][t]
+            st, r, over, _ = env.step(a)
+            t += 1
+        assert t == len(d['act'])
+    assert len(open(log).read().splitlines()) == 3
