@@ -197,13 +197,24 @@ int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, fl
                              float* flat_v, long long n_flat, const float* obs_all, const int* idx, const int* act_all,
                              const float* adv_all, const float* logp_old_all, const float* v_old_all, const float* ret_all, int mb,
                              float eps_clip, float vf_coef, float ent_coef, int norm_adv, int value_clip, float max_grad_norm, float lr,
-                             float weight_decay, int step, float* stats, void* workspace, int max_batch, void* stream);
+                             float weight_decay, int step, long long tail_from, int tail_step, float* stats, void* workspace,
+                             int max_batch, void* stream);
+/* Behaviour cloning on expert demonstrations (behavior_cloning_pretraining, utils/mansy_utils.py:52-93): loss =
+ * CrossEntropy(actor logits, act) - ent_coef * mean entropy; Adam(L2) over the first n_update elements of the flat buffers
+ * (the critic head -- the tail -- has no gradient here and torch.optim.Adam skips it).  step <= 0: forward + loss only.
+ * stats: [loss, cross entropy, mean entropy]. */
+int mansy_bc_step(const float* const* params, float* const* grads, float* flat_p, float* flat_g, float* flat_m, float* flat_v,
+                  long long n_flat, long long n_update, const float* obs, const int* act, int B, float ent_coef, float lr,
+                  float weight_decay, int step, float* stats, void* workspace, int max_batch, void* stream);
 
 /* clip_grad_norm_ (max_norm <= 0: off) + Adam with L2 weight decay over flat buffers (data-parallel second half).
- * scratch: MANSY_CLIP_SCRATCH_DOUBLES doubles of device memory (gradient-norm partial sums; need not be zeroed). */
+ * scratch: MANSY_CLIP_SCRATCH_DOUBLES doubles of device memory (gradient-norm partial sums; need not be zeroed).
+ * tail_from >= 0 (here and in mansy_ppo_minibatch_step): elements [tail_from, n_flat) use Adam step count tail_step
+ * instead of step -- torch keeps one counter per parameter, and the critic head sees its first gradient only after the
+ * behaviour-cloning steps; pass -1 / 0 otherwise. */
 #define MANSY_CLIP_SCRATCH_DOUBLES 64
 int mansy_clip_grad_adam(float* flat_p, float* flat_g, float* flat_m, float* flat_v, long long n_flat, float max_grad_norm, float lr,
-                         float weight_decay, int step, double* scratch, void* stream);
+                         float weight_decay, int step, long long tail_from, int tail_step, double* scratch, void* stream);
 
 /* ------------------------------------------------------------------ single kernels (unit-test surface) */
 typedef struct mansy_gemm_epilogue {

@@ -97,8 +97,9 @@ _PROTOS = {
     'mansy_identifier_relabel': [P, P, P, P, c_int, c_float, P, c_int, P],
     'mansy_gae_returns': [P, P, P, P, c_int, c_int, ctypes.c_double, ctypes.c_double, c_int, P, P, P, P, P],
     'mansy_ppo_minibatch_step': [P, P, P, P, P, P, c_ll, P, P, P, P, P, P, P, c_int, c_float, c_float, c_float, c_int, c_int, c_float,
-                                 c_float, c_float, c_int, P, P, c_int, P],
-    'mansy_clip_grad_adam': [P, P, P, P, c_ll, c_float, c_float, c_float, c_int, P, P],
+                                 c_float, c_float, c_int, c_ll, c_int, P, P, c_int, P],
+    'mansy_bc_step': [P, P, P, P, P, P, c_ll, c_ll, P, P, c_int, c_float, c_float, c_float, c_int, P, P, c_int, P],
+    'mansy_clip_grad_adam': [P, P, P, P, c_ll, c_float, c_float, c_float, c_int, c_ll, c_int, P, P],
     'mansy_set_bn_sync_hook': [P, P],
     'mansy_prof_gemm_enable': [c_int],
     'mansy_prof_gemm_collect': [P, P, P],

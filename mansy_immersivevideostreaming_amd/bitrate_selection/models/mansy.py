@@ -54,6 +54,17 @@ class _Flat:
         self.params = None
         self.flat_p = self.flat_g = self.m = self.v = None
         self.step = 0
+        self.tail_lag = 0          # behaviour-cloning steps the critic head did not take part in (per-parameter Adam step)
+
+    def critic_head_index(self):
+        """Index of the first critic-head tensor (the tail of the actor-critic flat buffer)."""
+        return next(i for i, (name, _) in enumerate(self.table) if name.startswith('critic.') and '.feature_net.' not in name)
+
+    def tail(self):
+        """(tail_from, tail_step) of mansy_ppo_minibatch_step / mansy_clip_grad_adam."""
+        if self.kind != 0 or self.tail_lag == 0:
+            return -1, 0
+        return self.offsets[self.critic_head_index()], self.step - self.tail_lag
 
     def attach(self, params):
         """params: list of nn.Parameter in table order."""

@@ -187,7 +187,7 @@ class PPOPolicy(nn.Module):
     def _clip_adam(self, f, max_norm, lr, wd):
         scratch = torch.empty(64, dtype=torch.float64, device=f.flat_p.device)      # MANSY_CLIP_SCRATCH_DOUBLES
         check(lib().mansy_clip_grad_adam(ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), float(max_norm), lr, wd, f.step,
-                                         ptr(scratch), stream_ptr(f.flat_p.device)), 'mansy_clip_grad_adam')
+                                         *f.tail(), ptr(scratch), stream_ptr(f.flat_p.device)), 'mansy_clip_grad_adam')
 
     # ---- plumbing ---------------------------------------------------------------------------------------------
     def _apply(self, fn, *a, **k):
@@ -332,7 +332,8 @@ class PPOPolicy(nn.Module):
                                                      ptr(idx), ptr(data['act']), ptr(data['adv']), ptr(data['logp_old']), ptr(data['v_s']),
                                                      ptr(data['returns']), idx.numel(), self._eps_clip, self._weight_vf, self._weight_ent,
                                                      int(self._norm_adv), int(self._value_clip), 0.0 if dp else float(self._grad_norm or 0.0), lr, wd,
-                                                     0 if dp else f.step, ptr(stats), ptr(eng.workspace()), eng.max_batch, stream_ptr(dev)),
+                                                     0 if dp else f.step, *f.tail(), ptr(stats), ptr(eng.workspace()), eng.max_batch,
+                                                     stream_ptr(dev)),
                       'mansy_ppo_minibatch_step')
                 if dp:                              # raw local gradients -> RCCL average -> global-norm clip + Adam
                     self.grad_sync(f.flat_g)
@@ -342,6 +343,27 @@ class PPOPolicy(nn.Module):
         for j, k in enumerate(('loss', 'loss/clip', 'loss/vf', 'loss/ent')):
             losses[k] = st[:, j].tolist()
         return losses
+
+    def bc_step(self, obs, act, ent_coef=0.1, train=True):
+        """One behaviour-cloning step on a demonstration (utils/mansy_utils.py:60-69) or, with train=False, its validation
+        cross entropy (:71-78).  obs [B,780] float32, act [B] int32 device tensors.  Returns stats [loss, ce, entropy]."""
+        eng, f = self.engine, self.engine.ac
+        if obs.shape[0] > eng.max_batch:
+            raise MansyError(f'demonstration of {obs.shape[0]} transitions exceeds engine max_batch {eng.max_batch}')
+        lr, wd = self._hyper(self.optim, 5e-4)
+        stats = torch.empty(3, dtype=torch.float32, device=obs.device)
+        arr, garr = f.pointers(grads=True)
+        n_update = f.offsets[f.critic_head_index()]          # the critic head has no gradient: torch's Adam skips it
+        if train:
+            f.step += 1
+            f.tail_lag += 1
+        dp = train and self.grad_sync is not None
+        check(lib().mansy_bc_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), n_update, ptr(obs), ptr(act),
+                                  obs.shape[0], float(ent_coef), lr, wd, (f.step if train else 0), ptr(stats), ptr(eng.workspace()),
+                                  eng.max_batch, stream_ptr(obs.device)), 'mansy_bc_step')
+        if dp:
+            raise MansyError('behaviour cloning runs on one rank (the reference does it before training starts)')
+        return stats
 
     def update(self, sample_size, buffer, is_train=False, batch_size=512, repeat=2, **kwargs):
         """mansy_ppo.py:36-59."""

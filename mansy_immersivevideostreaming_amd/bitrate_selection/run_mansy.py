@@ -8,9 +8,11 @@ device environment.
       --qoe-test-ids 0 1 2 3 --lamb 0.5 --train-identifier --use-identifier --device cuda:0 [--train-num 256] [--config ../config.yml]
 
 `--train-num` (environments stepped per launch) is honoured here -- the reference forces 1 (run_mansy.py:37); with 1 the
-episode order equals the reference's.  Behaviour cloning (--bc / --init-from-bc) is out of scope (README: no gain)."""
+episode order equals the reference's.  `--bc` pre-trains on the demonstrations written by run_expert (:255-274)
+before PPO training; `--init-from-bc` starts from the behaviour-cloning checkpoints (:73-83)."""
 import argparse
 import os
+import pickle
 import random
 import sys
 
@@ -23,9 +25,10 @@ from .models.mansy import Actor, Critic, FeatureNet, QoEIdentifier, QoEIdentifie
 from .models.mansy_ppo import PPOPolicy, VecCollector
 from .models.mansy_trainer import OnpolicyTrainer, run_episodes, write_episode_log
 from .utils.common import get_config_from_yml, read_log_file
+from .utils.mansy_utils import behavior_cloning_pretraining
 
 
-def train(args, config, policy, qoe_weights, identifier, identifier_optimizer, models_dir):
+def train(args, config, policy, qoe_weights, identifier, identifier_optimizer, models_dir, policy_bc_path=None, identifier_bc_path=None):
     train_log_path = os.path.join(models_dir, 'train_log.csv')
     valid_log_path = os.path.join(models_dir, 'valid_log.csv')
     for p in (train_log_path, valid_log_path):
@@ -53,6 +56,13 @@ def train(args, config, policy, qoe_weights, identifier, identifier_optimizer, m
             if os.path.exists(path):
                 mod.load_state_dict(torch.load(path, map_location=args.device))
                 print(f'Successfully loaded {name} from:', path)
+            else:
+                print(f'Failed to load {name}:', path, 'no such file')
+    elif args.init_from_bc:
+        for path, mod, name in ((policy_bc_path, policy, 'agent'), (identifier_bc_path, identifier, 'identifier')):
+            if path and os.path.exists(path):
+                mod.load_state_dict(torch.load(path, map_location=args.device))
+                print(f'Successfully init {name} from behavior cloning:', path)
             else:
                 print(f'Failed to load {name}:', path, 'no such file')
 
@@ -130,8 +140,6 @@ def run(args, config):
                                seen + '_'.join(map(str, args.qoe_test_ids)), prefix)
     os.makedirs(models_dir, exist_ok=True)
     os.makedirs(results_dir, exist_ok=True)
-    if args.bc or args.init_from_bc:
-        raise SystemExit('behaviour cloning is out of scope of the MI355X path (README: it does not help)')
     # run_mansy.py:205-251
     feature_dim = args.hidden_dim * 10
     feature_net = FeatureNet(config.past_k, config.tile_total_num, len(config.video_rates), args.hidden_dim, device=args.device)
@@ -157,8 +165,24 @@ def run(args, config):
                        dual_clip=args.dual_clip, value_clip=args.value_clip, gae_lambda=args.gae_lambda, action_space=config.action_space,
                        action_scaling=False, args=args, identifier=identifier, identifier_optim=identifier_optimizer).to(args.device)
     if args.train:
+        bc_file_prefix = f'bc_ms_{args.bc_max_steps}_ims_{args.bc_identifier_max_steps}_ilr_{args.identifier_lr}_iur_{args.identifier_update_round}'
+        policy_bc_path = os.path.join(models_dir, bc_file_prefix + '_policy.pth')
+        identifier_bc_path = os.path.join(models_dir, bc_file_prefix + '_identifier.pth')
+        if args.bc:          # run_mansy.py:260-274: demonstrations written by run_expert --train --valid
+            demos_dir = os.path.join(config.bs_models_dir, 'expert', args.train_dataset + '_' + args.network_dataset,
+                                     'qoe' + '_'.join(map(str, args.qoe_train_ids)))
+            train_demos_path = os.path.join(demos_dir, 'train_demonstrations.pkl')
+            valid_demos_path = os.path.join(demos_dir, 'valid_demonstrations.pkl')
+            assert os.path.exists(train_demos_path) and os.path.exists(valid_demos_path)
+            train_demos = list(pickle.load(open(train_demos_path, 'rb')).values())
+            valid_demos = list(pickle.load(open(valid_demos_path, 'rb')).values())
+            behavior_cloning_pretraining(args, policy, identifier, optimizer, identifier_optimizer, train_demos, valid_demos,
+                                         max_steps=args.bc_max_steps, valid_per_step=args.bc_valid_per_step,
+                                         identifier_max_steps=args.bc_identifier_max_steps,
+                                         identifier_update_round=args.identifier_update_round, policy_save_path=policy_bc_path,
+                                         identifier_save_path=identifier_bc_path)
         qoe_weights = [config.qoe_split['train'][i] for i in args.qoe_train_ids]
-        train(args, config, policy, qoe_weights, identifier, identifier_optimizer, models_dir)
+        train(args, config, policy, qoe_weights, identifier, identifier_optimizer, models_dir, policy_bc_path, identifier_bc_path)
     if args.test:
         qoe_weights = [config.qoe_split[split][i] for i in args.qoe_test_ids]
         test(args, config, policy, qoe_weights, identifier, models_dir, results_dir)

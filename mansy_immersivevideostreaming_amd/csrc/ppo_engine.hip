@@ -373,6 +373,51 @@ __global__ __launch_bounds__(1024) void ppo_loss_kernel(PPOLossArgs a) {
   if (threadIdx.x == 0 && a.stats) { a.stats[0] = c + a.vf_coef * vfm - a.ent_coef * em; a.stats[1] = c; a.stats[2] = vfm; a.stats[3] = em; }
 }
 
+// Behaviour cloning: mean cross entropy of the expert actions minus ent_coef * mean entropy, and its gradient wrt the
+// logits (the value head receives a zero gradient).
+__global__ __launch_bounds__(1024) void bc_loss_kernel(const float* __restrict__ logits, const int* __restrict__ act, int n, float ent_coef,
+                                                       float* __restrict__ dlogits, float* __restrict__ dvalue, float* __restrict__ stats) {
+  __shared__ float sh[16];
+  float l_ce = 0.f, l_ent = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    float lg[MAXOUT];
+#pragma unroll
+    for (int q4 = 0; q4 < MAXOUT / 4; ++q4)
+      *reinterpret_cast<float4*>(lg + 4 * q4) = *reinterpret_cast<const float4*>(logits + (size_t)i * MAXOUT + 4 * q4);
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < NACT; ++k) m = fmaxf(m, lg[k]);
+    float e[NACT], se = 0.f;
+#pragma unroll
+    for (int k = 0; k < NACT; ++k) { e[k] = expf(lg[k] - m); se += e[k]; }
+    const float lse = logf(se);
+    const int a = act[i];
+    float ent = 0.f, lp_act = 0.f;
+#pragma unroll
+    for (int k = 0; k < NACT; ++k) {
+      const float p = e[k] / se, lp = (lg[k] - m) - lse;
+      ent -= p * lp;
+      if (k == a) lp_act = lp;
+    }
+    l_ce += -lp_act;
+    l_ent += ent;
+    float gout[MAXOUT];
+#pragma unroll
+    for (int k = 0; k < NACT; ++k) {
+      const float p = e[k] / se, lp = (lg[k] - m) - lse;
+      gout[k] = (p - (k == a ? 1.f : 0.f)) / (float)n + ent_coef * p * (lp + ent) / (float)n;
+    }
+    gout[NACT] = 0.f;
+#pragma unroll
+    for (int q4 = 0; q4 < MAXOUT / 4; ++q4)
+      *reinterpret_cast<float4*>(dlogits + (size_t)i * MAXOUT + 4 * q4) = *reinterpret_cast<const float4*>(gout + 4 * q4);
+    dvalue[(size_t)i * MAXOUT] = 0.f;
+  }
+  const float ce = block_sum(l_ce, sh) / (float)n;
+  const float em = block_sum(l_ent, sh) / (float)n;
+  if (threadIdx.x == 0) { stats[0] = ce - ent_coef * em; stats[1] = ce; stats[2] = em; }
+}
+
 // MSE(pred[B,3], obs[:,745:748]) forward + gradient wrt the PRE-sigmoid output (pred = sigmoid(z))
 __global__ __launch_bounds__(256) void ident_mse_kernel(const float* __restrict__ pred, const float* __restrict__ obs, int B, float* __restrict__ dz,
                                                         double* __restrict__ acc) {
@@ -645,17 +690,33 @@ struct PEng {
     MANSY_LAUNCH_CHECK();
     return MANSY_OK;
   }
-  int clip_and_adam(float* flat_p, float* flat_g, float* m, float* v, long long n, float max_norm, float lr, float wd, int step) {
+  // tail_from >= 0: elements [tail_from, n) carry Adam step count `tail_step` instead of `step` (parameters that received
+  // their first gradient later than the rest: torch keeps one step counter per parameter); tail_step <= 0 never happens
+  // with gradients present, so it is rejected.  The clip coefficient is the global one for both ranges.
+  int clip_and_adam(float* flat_p, float* flat_g, float* m, float* v, long long n, float max_norm, float lr, float wd, int step,
+                    long long tail_from = -1, int tail_step = 0) {
     if (max_norm > 0.f) {
       hipLaunchKernelGGL(sumsq_kernel, dim3(NORM_PARTS), dim3(256), 0, st, flat_g, n, W.acc);
       if (step <= 0) hipLaunchKernelGGL(clip_scale_kernel, dim3(256), dim3(256), 0, st, flat_g, n, W.acc, max_norm);   // parity tests: clipped gradients
       MANSY_LAUNCH_CHECK();
     }
     if (step <= 0) return MANSY_OK;
-    if (max_norm <= 0.f) return mansy_launch_adamw(flat_p, flat_g, m, v, n, lr, 0.9f, 0.999f, 1e-8f, wd, step, 0, st);   // Adam with L2 (run_mansy.py:216,226)
-    const double bc1 = 1.0 - pow(0.9, (double)step), bc2 = 1.0 - pow(0.999, (double)step);
-    hipLaunchKernelGGL(clip_adam_kernel, dim3(mansy_ceil_div(n, 256)), dim3(256), 0, st, flat_p, flat_g, m, v, n, lr, 0.9f, 0.999f, 1e-8f, wd,
-                       (float)bc1, (float)sqrt(bc2), W.acc, max_norm);
+    const bool lag = tail_from >= 0 && tail_from < n && tail_step != step;
+    if (lag) MANSY_REQUIRE(tail_step >= 1 && tail_from % 4 == 0, "adam: lagged tail needs tail_step >= 1 and a 16-byte aligned start");
+    const long long n_head = lag ? tail_from : n;
+    for (int part = 0; part < (lag ? 2 : 1); ++part) {
+      const long long o = part ? tail_from : 0, cnt = part ? n - tail_from : n_head;
+      const int stp = part ? tail_step : step;
+      if (cnt <= 0) continue;
+      if (max_norm <= 0.f) {                     // Adam with L2 (run_mansy.py:216,226)
+        int rc = mansy_launch_adamw(flat_p + o, flat_g + o, m + o, v + o, cnt, lr, 0.9f, 0.999f, 1e-8f, wd, stp, 0, st);
+        if (rc) return rc;
+        continue;
+      }
+      const double bc1 = 1.0 - pow(0.9, (double)stp), bc2 = 1.0 - pow(0.999, (double)stp);
+      hipLaunchKernelGGL(clip_adam_kernel, dim3(mansy_ceil_div(cnt, 256)), dim3(256), 0, st, flat_p + o, flat_g + o, m + o, v + o, cnt, lr, 0.9f,
+                         0.999f, 1e-8f, wd, (float)bc1, (float)sqrt(bc2), W.acc, max_norm);
+    }
     MANSY_LAUNCH_CHECK();
     return MANSY_OK;
   }
@@ -795,7 +856,7 @@ int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, fl
                              long long n_flat, const float* obs_all, const int* idx, const int* act_all, const float* adv_all,
                              const float* logp_old_all, const float* v_old_all, const float* ret_all, int mb, float eps_clip, float vf_coef,
                              float ent_coef, int norm_adv, int value_clip, float max_grad_norm, float lr, float weight_decay, int step,
-                             float* stats, void* workspace, int max_batch, void* stream) {
+                             long long tail_from, int tail_step, float* stats, void* workspace, int max_batch, void* stream) {
   MANSY_REQUIRE(params && grads && flat_p && flat_g && flat_m && flat_v && obs_all && act_all && adv_all && logp_old_all && v_old_all && ret_all,
                 "ppo_minibatch_step: null pointer");
   MANSY_REQUIRE(mb >= 2 && mb <= max_batch, "ppo_minibatch_step: bad minibatch size");
@@ -814,17 +875,40 @@ int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, fl
   MANSY_LAUNCH_CHECK();
   RC(e.head_bwd_pair(a, c, mb));
   RC(e.featnet_bwd(a, obs, mb, 0, e.W.dHa, e.W.dHc));
-  return e.clip_and_adam(flat_p, flat_g, flat_m, flat_v, n_flat, max_grad_norm, lr, weight_decay, step);
+  return e.clip_and_adam(flat_p, flat_g, flat_m, flat_v, n_flat, max_grad_norm, lr, weight_decay, step, tail_from, tail_step);
+}
+
+// Behaviour-cloning step (utils/mansy_utils.py:52-69): loss = CrossEntropy(actor logits, expert action) - ent_coef * mean
+// entropy; backward through the actor head and the shared feature net; Adam(L2) over the first n_update elements of the
+// flat buffers only -- the critic head (the tail of the buffer) has no gradient there and torch.optim.Adam skips
+// parameters whose .grad is None (no weight decay, no state).  step <= 0: forward + loss only (the validation pass,
+// :71-78; stats[1] is the plain cross entropy).  stats: [loss, cross entropy, mean entropy].
+int mansy_bc_step(const float* const* params, float* const* grads, float* flat_p, float* flat_g, float* flat_m, float* flat_v,
+                  long long n_flat, long long n_update, const float* obs, const int* act, int B, float ent_coef, float lr,
+                  float weight_decay, int step, float* stats, void* workspace, int max_batch, void* stream) {
+  MANSY_REQUIRE(params && obs && act && stats && B >= 1 && B <= max_batch, "bc_step: bad arguments");
+  MANSY_REQUIRE(step <= 0 || (grads && flat_p && flat_g && flat_m && flat_v && n_update >= 1 && n_update <= n_flat), "bc_step: bad buffers");
+  PEng e; RC(setup(workspace, max_batch, (hipStream_t)stream, e));
+  NetP a, c; bind_net(params, grads, 20, a); bind_net(params, grads, 24, c);
+  RC(e.pack(a, 0, &c, nullptr, nullptr, B, step > 0 ? flat_g : nullptr, step > 0 ? n_flat : 0));
+  RC(e.featnet(obs, B, 0));
+  RC(e.head_pair(a, c, B));
+  hipLaunchKernelGGL(bc_loss_kernel, dim3(1), dim3(1024), 0, e.st, e.W.outa, act, B, ent_coef, e.W.gout, e.W.gout_c, stats);
+  MANSY_LAUNCH_CHECK();
+  if (step <= 0) return MANSY_OK;
+  RC(e.head_bwd_pair(a, c, B));
+  RC(e.featnet_bwd(a, obs, B, 0, e.W.dHa, e.W.dHc));
+  return e.clip_and_adam(flat_p, flat_g, flat_m, flat_v, n_update, 0.f, lr, weight_decay, step);
 }
 
 // Global-norm clip (torch clip_grad_norm_ semantics; max_norm <= 0 disables) followed by Adam with L2 weight decay over
 // flat buffers.  Data-parallel callers run the minibatch step with step = 0 and max_grad_norm = 0 (raw gradients),
 // all-reduce flat_g over RCCL, then call this.  scratch: MANSY_CLIP_SCRATCH_DOUBLES doubles.
 int mansy_clip_grad_adam(float* flat_p, float* flat_g, float* flat_m, float* flat_v, long long n_flat, float max_grad_norm, float lr,
-                         float weight_decay, int step, double* scratch, void* stream) {
+                         float weight_decay, int step, long long tail_from, int tail_step, double* scratch, void* stream) {
   MANSY_REQUIRE(flat_p && flat_g && flat_m && flat_v && scratch && step >= 1, "clip_grad_adam: bad arguments");
   PEng e; e.st = (hipStream_t)stream; e.W.acc = scratch;
-  return e.clip_and_adam(flat_p, flat_g, flat_m, flat_v, n_flat, max_grad_norm, lr, weight_decay, step);
+  return e.clip_and_adam(flat_p, flat_g, flat_m, flat_v, n_flat, max_grad_norm, lr, weight_decay, step, tail_from, tail_step);
 }
 
 }  // extern "C"

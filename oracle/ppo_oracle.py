@@ -157,6 +157,15 @@ def ppo_loss(logits, value, act, adv, logp_old, v_old, returns, eps_clip=0.2, vf
     return loss, clip_loss, vf_loss, ent
 
 
+def bc_loss(logits, act, ent_coef=0.1):
+    """utils/mansy_utils.py:60-66: CrossEntropyLoss(logits, expert action) - 0.1 * Categorical(logits).entropy().mean()
+    -> (loss, cross entropy, mean entropy)."""
+    logp_all = torch.log_softmax(logits, dim=-1)
+    ce = -logp_all.gather(1, act.long()[:, None])[:, 0].mean()
+    ent = -(logp_all.exp() * logp_all).sum(-1).mean()
+    return ce - ent_coef * ent, ce, ent
+
+
 def categorical_sample(logits, u):
     """Inverse-CDF sample from softmax(logits) given uniforms u in [0,1): first index whose cumulative probability
     exceeds u (float32 sequential cumsum) -- the build's externally-driven sampler (SURVEY 8c determinism caveat)."""
