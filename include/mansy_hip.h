@@ -216,6 +216,41 @@ int mansy_bc_step(const float* const* params, float* const* grads, float* flat_p
 int mansy_clip_grad_adam(float* flat_p, float* flat_g, float* flat_m, float* flat_v, long long n_flat, float max_grad_norm, float lr,
                          float weight_decay, int step, long long tail_from, int tail_step, double* scratch, void* stream);
 
+/* ------------------------------------------------------------------ A2C baseline ("simple RL", the comparison agent)
+ * Replaces FeatureNet/Actor/Critic.forward (bitrate_selection/models/simple_rl.py:9-63), SimpleRLEnv's observation
+ * (envs/simple_rl_env.py:85-170: reset/step are MANSYEnv's simulator + QoE with a five-key observation) and
+ * tianshou==0.4.8's A2CPolicy.learn + torch.optim.RMSprop behind run_simple_rl.py:190-211.  Returns / advantages:
+ * mansy_gae_returns (A2CPolicy._compute_returns is the function PPO inherits).
+ * One observation = one row of MANSY_A2C_OBS_LD floats: */
+#define MANSY_A2C_OBS_LD 416
+#define MANSY_A2C_O_THROUGHPUT 0   /* 'throughput'    [1,8]  */
+#define MANSY_A2C_O_SIZE 8         /* 'chunk_sizes'   [5,64] */
+#define MANSY_A2C_O_REBUFFER 328   /* 'rebuffer'      [1]    */
+#define MANSY_A2C_O_LAST_RATES 329 /* 'last_bitrates' [2]    */
+#define MANSY_A2C_O_PRED_VP 331    /* 'pred_viewport' [64]   (395..415: zero padding) */
+/* 18 unique tensors in state_dict order: shared feature net (10), actor head (4), critic head (4) */
+int mansy_a2c_num_params(void);
+int mansy_a2c_param_info(int idx, char* name, int name_len, long long* numel, int* ndim, long long shape[4]);
+size_t mansy_a2c_workspace_bytes(int max_batch);
+/* rows of the five-key observation from the outputs of mansy_env_reset / mansy_env_step for the same step: obs [n,780],
+ * qoe_parts [n,4] and actions [n] of that step (actions == NULL: observations right after reset), fresh [n] (optional):
+ * rows whose environment was auto-reset (rebuffer / last_bitrates zero). */
+int mansy_a2c_obs(const float* obs, const float* qoe_parts, const int* actions, const unsigned char* fresh, int n, const int video_rates[5],
+                  float* out, void* stream);
+/* probs [B,16] (15 used: the reference's Actor returns softmax outputs as "logits"), value [B] (nullable), optional
+ * Categorical(probs) sampling: act int32 [B], logp [B]; u [B] external uniforms or NULL => counter hash (seed, site, row) */
+int mansy_a2c_forward(const float* const* params, const float* obs, int B, float* probs, float* value, int* act, float* logp, const float* u,
+                      uint32_t seed, uint32_t site, int reuse_packed, void* workspace, int max_batch, void* stream);
+/* loss = -(log_prob * adv).mean() + vf_coef * mse(ret, value) - ent_coef * entropy.mean(); clip_grad_norm_; RMSprop(lr, alpha,
+ * eps) over flat buffers.  apply == 0: gradients only.  stats: [loss, actor loss, value loss, entropy]. */
+int mansy_a2c_minibatch_step(const float* const* params, float* const* grads, float* flat_p, float* flat_g, float* flat_sq, long long n_flat,
+                             const float* obs_all, const int* idx, const int* act_all, const float* adv_all, const float* ret_all, int mb,
+                             float vf_coef, float ent_coef, float max_grad_norm, float lr, float alpha, float eps, int apply, float* stats,
+                             void* workspace, int max_batch, void* stream);
+/* data-parallel second half: clip_grad_norm_ + RMSprop over (all-reduced) flat gradients; scratch as mansy_clip_grad_adam */
+int mansy_clip_grad_rmsprop(float* flat_p, float* flat_g, float* flat_sq, long long n_flat, float max_grad_norm, float lr, float alpha,
+                            float eps, double* scratch, void* stream);
+
 /* ------------------------------------------------------------------ single kernels (unit-test surface) */
 typedef struct mansy_gemm_epilogue {
   const float* bias; int relu; const float* mask_src; int mask_ld; float mask_scale;

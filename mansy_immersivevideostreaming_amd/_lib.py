@@ -100,12 +100,20 @@ _PROTOS = {
                                  c_float, c_float, c_int, c_ll, c_int, P, P, c_int, P],
     'mansy_bc_step': [P, P, P, P, P, P, c_ll, c_ll, P, P, c_int, c_float, c_float, c_float, c_int, P, P, c_int, P],
     'mansy_clip_grad_adam': [P, P, P, P, c_ll, c_float, c_float, c_float, c_int, c_ll, c_int, P, P],
+    'mansy_a2c_num_params': [],
+    'mansy_a2c_param_info': [c_int, ctypes.c_char_p, c_int, P, P, P],
+    'mansy_a2c_workspace_bytes': [c_int],
+    'mansy_a2c_obs': [P, P, P, P, c_int, P, P, P],
+    'mansy_a2c_forward': [P, P, c_int, P, P, P, P, P, c_u32, c_u32, c_int, P, c_int, P],
+    'mansy_a2c_minibatch_step': [P, P, P, P, P, c_ll, P, P, P, P, P, c_int, c_float, c_float, c_float, c_float, c_float, c_float, c_int, P,
+                                 P, c_int, P],
+    'mansy_clip_grad_rmsprop': [P, P, P, c_ll, c_float, c_float, c_float, c_float, P, P],
     'mansy_set_bn_sync_hook': [P, P],
     'mansy_prof_gemm_enable': [c_int],
     'mansy_prof_gemm_collect': [P, P, P],
 }
 _RESTYPES = {'mansy_last_error': ctypes.c_char_p, 'mansy_vp_workspace_bytes': ctypes.c_size_t,
-             'mansy_ppo_workspace_bytes': ctypes.c_size_t}
+             'mansy_ppo_workspace_bytes': ctypes.c_size_t, 'mansy_a2c_workspace_bytes': ctypes.c_size_t}
 
 _lib = None
 

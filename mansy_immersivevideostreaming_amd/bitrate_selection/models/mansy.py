@@ -43,13 +43,16 @@ class _Flat:
 
     def __init__(self, kind):
         L = lib()
-        self.kind = kind
-        n = L.mansy_net_num_params(kind)
+        self.kind = kind          # 0 actor-critic, 1 identifier, 2 A2C baseline (simple_rl) actor-critic
+        n = L.mansy_a2c_num_params() if kind == 2 else L.mansy_net_num_params(kind)
         self.table = []
         for i in range(n):
             buf = ctypes.create_string_buffer(160)
             numel, nd, shape = ctypes.c_longlong(), ctypes.c_int(), (ctypes.c_longlong * 4)()
-            check(L.mansy_net_param_info(kind, i, buf, 160, ctypes.byref(numel), ctypes.byref(nd), shape), 'mansy_net_param_info')
+            if kind == 2:
+                check(L.mansy_a2c_param_info(i, buf, 160, ctypes.byref(numel), ctypes.byref(nd), shape), 'mansy_a2c_param_info')
+            else:
+                check(L.mansy_net_param_info(kind, i, buf, 160, ctypes.byref(numel), ctypes.byref(nd), shape), 'mansy_net_param_info')
             self.table.append((buf.value.decode(), tuple(shape[:nd.value])))
         self.params = None
         self.flat_p = self.flat_g = self.m = self.v = None

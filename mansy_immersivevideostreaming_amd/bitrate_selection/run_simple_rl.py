@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""CLI counterpart of bitrate_selection/run_simple_rl.py (flags :223-260, net / optimiser / policy construction :184-209,
+train() :21-118, test() :121-148, file naming :170-182) -- the A2C baseline of the comparison tables -- on the HIP engine and
+the vectorised device environment.
+
+  python -m mansy_immersivevideostreaming_amd.bitrate_selection.run_simple_rl --epochs 100 --step-per-epoch 6000 \\
+      --step-per-collect 2000 --batch-size 256 --train --train-dataset Jin2022 --test --test-dataset Jin2022 --qoe-train-id 0 \\
+      --qoe-test-ids 0 --test-on-seen --device cuda:0 --seed 1 [--config ../config.yml]
+
+The epoch loop is tianshou's OnpolicyTrainer order of operations (T2): collect `step_per_collect` -> update (`repeat_per_collect`
+passes of minibatches) until `step_per_epoch`, then checkpoint, `episode_per_test` validation episodes, best-model save."""
+import argparse
+import os
+import random
+import time
+
+import numpy as np
+import torch
+from torch.distributions import Categorical
+
+from .envs.mansy_env import EnvTables
+from .envs.simple_rl_env import SimpleRLVecEnv
+from .models.mansy_trainer import write_episode_log
+from .models.simple_rl import A2CBuffer, A2CCollector, A2CPolicy, Actor, Critic, FeatureNet
+from .utils.common import get_config_from_yml, read_log_file
+
+
+def run_episodes(policy, venv, n_episode, reset=True):
+    """Test collector: sampled actions until n_episode episodes have finished; returns their undiscounted returns."""
+    eng = policy.engine
+    obs = venv.reset() if reset else venv.obs
+    ret = torch.zeros(venv.n_env, dtype=torch.float64, device=obs.device)
+    done_returns, first = [], True
+    while len(done_returns) < n_episode:
+        _, _, act, _ = eng.forward(obs, want_value=False, sample=True, u=torch.rand(venv.n_env, device=obs.device), reuse_packed=not first)
+        first = False
+        obs, rew, done, _ = venv.step(act)
+        ret += rew.double()
+        d = done.bool()
+        if d.any():
+            done_returns += ret[d].cpu().tolist()
+            ret[d] = 0
+    return np.array(done_returns[:n_episode])
+
+
+def train(args, config, policy, qoe_weights, models_dir, file_prefix):
+    train_log_path = os.path.join(models_dir, file_prefix + '_train_log.csv')
+    valid_log_path = os.path.join(models_dir, file_prefix + '_valid_log.csv')
+    for p in (train_log_path, valid_log_path):
+        if os.path.exists(p):
+            os.remove(p)
+    t_train = EnvTables.from_dataset(config, args.train_dataset, args.network_dataset, 'train', qoe_weights, args.device, seed=args.seed,
+                                     use_identifier=True)           # train mode: reward = qoe / sum(w) (simple_rl_env.py:133-136)
+    t_valid = EnvTables.from_dataset(config, args.train_dataset, args.network_dataset, 'valid', qoe_weights, args.device, seed=args.seed)
+    args.episode_per_test = t_valid.n_sample
+    print('Training num:', args.train_num)
+    print('Test num:', args.test_num)
+    print('Episode per test:', args.episode_per_test)
+    print('Training QoE weights:', qoe_weights)
+    train_env = SimpleRLVecEnv(t_train, args.train_num, seed=args.seed, worker_num=args.train_num)
+    valid_env = SimpleRLVecEnv(t_valid, args.test_num, seed=args.seed, worker_num=args.test_num)
+    checkpoint_path = os.path.join(models_dir, file_prefix + '_checkpoint.pth')
+    best_policy_path = os.path.join(models_dir, file_prefix + '_best_policy.pth')
+    if args.resume:
+        if os.path.exists(checkpoint_path):
+            policy.load_state_dict(torch.load(checkpoint_path, map_location=args.device))
+            print('Successfully loaded agent from:', checkpoint_path)
+        else:
+            print('Failed to load agent:', checkpoint_path, 'no such file')
+    collector = A2CCollector(policy, train_env, seed=args.seed)
+    buffer = A2CBuffer(max(1, args.step_per_collect // args.train_num), args.train_num, args.device)
+    best_reward, best_std, best_epoch, env_step, gradient_step, start = -np.inf, 0.0, 0, 0, 0, time.time()
+    for epoch in range(1, args.epochs + 1):
+        n_done, losses = 0, {}
+        while n_done < args.step_per_epoch:
+            n = collector.collect(args.step_per_collect, buffer)['n/st']
+            n_done += n
+            env_step += n
+            losses = policy.update(0, buffer, batch_size=args.batch_size, repeat=args.repeat_per_collect)
+            buffer.reset()
+            gradient_step += len(losses.get('loss', [])) or 1
+        write_episode_log(train_log_path, t_train, qoe_weights, train_env.pop_episode_log())
+        torch.save(policy.state_dict(), checkpoint_path)
+        print('Checkpoint saved at ' + checkpoint_path)
+        rets = run_episodes(policy, valid_env, args.episode_per_test)
+        write_episode_log(valid_log_path, t_valid, qoe_weights, valid_env.pop_episode_log()[:args.episode_per_test])
+        rew, rew_std = float(rets.mean()), float(rets.std())
+        if best_epoch == 0 or best_reward < rew:
+            best_reward, best_std, best_epoch = rew, rew_std, epoch
+            torch.save(policy.state_dict(), best_policy_path)
+            print('Best policy save at ' + best_policy_path)
+        epoch_stat = {k: float(np.mean(v)) for k, v in losses.items()}
+        epoch_stat.update({'test_reward': rew, 'test_reward_std': rew_std, 'best_reward': best_reward, 'best_epoch': best_epoch,
+                           'gradient_step': gradient_step, 'env_step': env_step, 'n/st': n_done})
+        print(f'Epoch: {epoch}')
+        print(epoch_stat)
+        print({'duration': time.time() - start, 'best_reward': best_reward, 'train_step': env_step})
+        if best_reward >= args.reward_threshold:
+            break
+
+
+def test(args, config, policy, qoe_weights, models_dir, results_dir, file_prefix):
+    test_log_path = os.path.join(results_dir, file_prefix + '_results.csv')
+    if os.path.exists(test_log_path):
+        os.remove(test_log_path)
+    tables = EnvTables.from_dataset(config, args.test_dataset, args.network_dataset, 'test', qoe_weights, args.device, seed=args.seed)
+    policy_path = args.policy_path or os.path.join(models_dir, file_prefix + '_best_policy.pth')
+    if os.path.exists(policy_path):
+        policy.load_state_dict(torch.load(policy_path, map_location=args.device))
+        print('Successfully loaded agent from:', policy_path)
+    else:
+        raise FileExistsError(f'File not exist: {policy_path}')
+    n = tables.n_sample
+    n_env = min(args.test_envs, n)
+    venv = SimpleRLVecEnv(tables, n_env, seed=0, worker_num=n_env)       # env i plays samples i, i+n_env, ...: every combination once
+    first = {}
+    with torch.no_grad():
+        while len(first) < n:
+            run_episodes(policy, venv, n_env, reset=not first)
+            for r in venv.pop_episode_log():
+                first.setdefault(int(r[0]), r)
+    write_episode_log(test_log_path, tables, qoe_weights, [first[k] for k in sorted(first)])
+    read_log_file(test_log_path, verbose=args.verbose_table)
+    print('Results saved at:', test_log_path)
+
+
+def run(args, config):
+    assert args.qoe_train_id is not None
+    np.random.seed(args.seed)
+    torch.manual_seed(args.seed)
+    torch.cuda.manual_seed_all(args.seed)
+    random.seed(args.seed)
+    split = 'train' if args.test_on_seen else 'test'
+    if args.qoe_test_ids is None:
+        args.qoe_test_ids = list(range(len(config.qoe_split[split])))
+    models_dir = os.path.join(config.bs_models_dir, args.model, args.train_dataset + '_' + args.network_dataset, f'qoe{args.qoe_train_id}')
+    seen = 'seen_qoe' if args.test_on_seen else 'unseen_qoe'
+    results_dir = os.path.join(config.bs_results_dir, args.model, args.test_dataset + '_' + args.network_dataset,
+                               seen + '_'.join(map(str, args.qoe_test_ids)))
+    os.makedirs(models_dir, exist_ok=True)
+    os.makedirs(results_dir, exist_ok=True)
+    file_prefix = f'epochs_{args.epochs}_bs_{args.batch_size}_lr_{args.lr}_gamma_{args.gamma}_seed_{args.seed}_ent_{args.ent_coef}'
+    # run_simple_rl.py:184-209
+    feature_net = FeatureNet(config.past_k, config.tile_total_num, len(config.video_rates), device=args.device)
+    actor = Actor(feature_net, feature_dim=5 * 128, action_space=config.action_space, device=args.device)
+    critic = Critic(feature_net, feature_dim=5 * 128, device=args.device)
+    model = torch.nn.ModuleList([actor, critic])
+    for m in model.modules():
+        if isinstance(m, torch.nn.Linear):
+            torch.nn.init.orthogonal_(m.weight, gain=np.sqrt(2))
+            torch.nn.init.zeros_(m.bias)
+    optimizer = torch.optim.RMSprop(model.parameters(), lr=args.lr)
+    policy = A2CPolicy(actor, critic, optimizer, lambda logits: Categorical(logits), discount_factor=args.gamma, gae_lambda=args.gae_lambda,
+                       max_grad_norm=args.max_grad_norm, vf_coef=args.vf_coef, ent_coef=args.ent_coef, reward_normalization=args.rew_norm,
+                       action_scaling=True, action_bound_method=args.bound_action_method, action_space=config.action_space).to(args.device)
+    if args.train:
+        qoe_weights = [config.qoe_split['train'][args.qoe_train_id]]
+        train(args, config, policy, qoe_weights, models_dir, file_prefix)
+    if args.test:
+        qoe_weights = [config.qoe_split[split][i] for i in args.qoe_test_ids]
+        print('Testing QoE weights:', qoe_weights)
+        test(args, config, policy, qoe_weights, models_dir, results_dir, file_prefix)
+
+
+# the reference's command line (run_simple_rl.py:223-260) as data: (flag, type-or-None for store_true, default)
+_T = 'store_true'
+_FLAGS = [
+    ('--task', str, 'simple_rl'), ('--reward-threshold', float, 500000.0), ('--seed', int, 1), ('--buffer-size', int, 1000000), ('--lr', float, 1e-4),
+    ('--gamma', float, 0.99), ('--epochs', int, 100), ('--step-per-epoch', int, 2500), ('--step-per-collect', int, 1000),
+    ('--episode-per-collect', int, 10), ('--repeat-per-collect', int, 2), ('--batch-size', int, 256), ('--train-num', int, 10), ('--test-num', int, 9),
+    ('--episode-per-test', int, 50), ('--device', str, 'cuda:0'), ('--logdir', str, 'log_tensorboard'), ('--resume', _T, None), ('--rew-norm', int, 1),
+    ('--vf-coef', float, 0.5), ('--ent-coef', float, 0.1), ('--gae-lambda', float, 0.95), ('--bound-action-method', str, 'clip'), ('--lr-decay', int, 1),
+    ('--max-grad-norm', float, 0.5), ('--model', str, 'simple_rl'), ('--train', _T, None), ('--test', _T, None), ('--test-on-seen', _T, None),
+    ('--train-dataset', str, 'Jin2022'), ('--test-dataset', str, 'Jin2022'), ('--network-dataset', str, '4G'), ('--qoe-train-id', int, None),
+    ('--policy-path', str, None),
+    # additions of this build
+    ('--config', str, None), ('--test-envs', int, 256), ('--verbose-table', _T, None),
+]
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(description='A2C baseline on MI355X')
+    for flag, kind, default in _FLAGS:
+        if kind == _T:
+            parser.add_argument(flag, action='store_true')
+        else:
+            parser.add_argument(flag, type=kind, default=default)
+    parser.add_argument('--qoe-test-ids', type=int, nargs='*')
+    return parser
+
+
+def main(argv=None):
+    args = build_parser().parse_known_args(argv)[0]
+    print(args)
+    run(args, get_config_from_yml(args.config))
+
+
+if __name__ == '__main__':
+    main()
