@@ -145,6 +145,36 @@ def bench_ppo(rank, world, dev, mdist, cycles=5, warmup=2, n_env=256, steps_per_
             'model_flops_per_env_step': 11.5e6, 'algorithmic_bytes_per_env_step': 29e3}
 
 
+def bench_vp_inference(model, h, c, f, reps=5):
+    """V10 + V11: `sample()` (KV-cached autoregressive decode, 3-head ensemble mean, wrap) and the tile-map / IoU metric of
+    its output against the ground truth, as predict.py / the validation loop run them."""
+    import torch
+    from mansy_immersivevideostreaming_amd import kernels
+    was_training = model.training
+    model.eval()
+    with torch.no_grad():
+        pred = model.sample(h, c)
+        torch.cuda.synchronize()
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        for _ in range(reps):
+            pred = model.sample(h, c)
+        e1.record()
+        for _ in range(reps):
+            g = kernels.tilemap(f.contiguous(), 2560, 1440, 8, 8)
+            p = kernels.tilemap(pred.contiguous(), 2560, 1440, 8, 8)
+            iou = kernels.tilemap_iou(g.reshape(-1), p.reshape(-1))
+        e2.record()
+        torch.cuda.synchronize()
+    model.train(was_training)
+    B, T = pred.shape[0], pred.shape[1]
+    ms_s, ms_t = e0.elapsed_time(e1) / reps, e1.elapsed_time(e2) / reps
+    return {'metric': 'viewport-trajectories/sec (VP sample)', 'value': round(B / ms_s * 1e3, 1), 'unit': 'trajectories/s', 'ms_per_call': round(ms_s, 3),
+            'model_flops_per_trajectory': 0.174e9, 'tilemap_points_per_s': round(2 * B * T / ms_t * 1e3, 0), 'tilemap_ms': round(ms_t, 4),
+            'mean_iou': float(iou.mean().item()),
+            'config': {'workload': f'sample() B={B}, S=10, T={T}, d=512, eval mode + 2x{B * T} tile maps (8x8 tiles, 2560x1440) and IoU'}}
+
+
 def bench_expert(dev, horizon=4, n_env=256, reps=20, cpu=True):
     """MPC expert: look-ahead decisions/s of the exhaustive 15^h plan search, all environments per launch,
     next to the sequential C oracle's literal scan on one host core."""
@@ -325,6 +355,7 @@ def main():
             out['cpu_baseline'] = cpu_baseline()
             out['secondary']['cpu_baseline'] = cpu_baseline_ppo()
         out['tertiary'] = bench_expert(dev, cpu=(world == 1 and not args.no_cpu_baseline))
+        out['inference'] = bench_vp_inference(model, h, c, f)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
