@@ -119,14 +119,8 @@ def bench_ppo(rank, world, dev, mdist, cycles=5, warmup=2, n_env=256, steps_per_
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    t_collect = 0.0
     for _ in range(cycles):
-        tc = time.perf_counter()
-        col.collect(steps_per_env * n_env, buf)
-        torch.cuda.synchronize()
-        t_collect += time.perf_counter() - tc
-        pol.train_identifier(buf, 2, verbose=False)
-        res = pol.update(0, buf, is_train=True, batch_size=512, repeat=2)
+        res = cycle()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -135,6 +129,12 @@ def bench_ppo(rank, world, dev, mdist, cycles=5, warmup=2, n_env=256, steps_per_
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
+    # rollout alone (outside the timed region): policy forward + sampling + environment step, hipGraph-replayed collects
+    tc = time.perf_counter()
+    for _ in range(cycles):
+        col.collect(steps_per_env * n_env, buf)
+    torch.cuda.synchronize()
+    t_collect = time.perf_counter() - tc
     steps = world * n_env * steps_per_env * cycles
     return {'metric': 'PPO env-steps/sec', 'value': round(steps / dt, 1), 'unit': 'env-steps/s', 'n_gpus': world, 'cycles': cycles,
             'ms_per_cycle': round(dt / cycles * 1e3, 3), 'rollout_only_env_steps_per_s': round(n_env * steps_per_env * cycles / t_collect, 1),

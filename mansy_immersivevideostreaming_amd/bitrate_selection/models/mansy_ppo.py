@@ -140,6 +140,51 @@ def split_indices(length, size, shuffle=True, merge_last=True):
         yield indices[idx:idx + size]
 
 
+class LazyLosses(dict):
+    """The per-minibatch loss statistics of an update ({'loss': [...], ...} like tianshou's learn()), fetched from the device
+    on first access: an update that nobody inspects (every collect but the logged ones) costs no device-to-host sync."""
+
+    def __init__(self, names, stat_tensors):
+        super().__init__()
+        self._names, self._pending = names, stat_tensors
+        self.n_steps = sum(int(t.shape[0]) for t in stat_tensors)        # gradient steps taken (known without touching the device)
+
+    def _load(self):
+        if self._pending is not None:
+            st = torch.cat(self._pending).cpu().numpy()
+            self._pending = None
+            for j, k in enumerate(self._names):
+                super().__setitem__(k, st[:, j].tolist())
+
+    def __getitem__(self, k):
+        self._load()
+        return super().__getitem__(k)
+
+    def get(self, k, default=None):
+        self._load()
+        return super().get(k, default)
+
+    def __contains__(self, k):
+        return k in self._names
+
+    def __iter__(self):
+        return iter(self._names)
+
+    def __len__(self):
+        return len(self._names)
+
+    def keys(self):
+        return list(self._names)
+
+    def items(self):
+        self._load()
+        return super().items()
+
+    def values(self):
+        self._load()
+        return super().values()
+
+
 class _ActorCritic(nn.Module):
     """tianshou.utils.net.common.ActorCritic: only here so state_dict() carries the `_actor_critic.*` duplicates."""
 
@@ -319,15 +364,20 @@ class PPOPolicy(nn.Module):
         eng, f = self.engine, self.engine.ac
         n, dev = data['n'], data['obs'].device
         lr, wd = self._hyper(self.optim, 5e-4)
-        losses = {'loss': [], 'loss/clip': [], 'loss/vf': [], 'loss/ent': []}
         stats_all = []
+        dp = self.grad_sync is not None
         for _ in range(repeat):
-            for chunk in split_indices(n, batch_size):
-                idx = torch.from_numpy(chunk.astype(np.int32)).to(dev)
+            chunks = list(split_indices(n, batch_size))
+            # one upload of the whole permutation per pass; the minibatch index arrays are views into it
+            perm = torch.from_numpy(np.concatenate(chunks).astype(np.int32)).to(dev)
+            stats_pass = torch.empty(len(chunks), 4, dtype=torch.float32, device=dev)
+            off = 0
+            for k, chunk in enumerate(chunks):
+                idx = perm[off:off + len(chunk)]
+                off += len(chunk)
                 f.step += 1
-                stats = torch.empty(4, dtype=torch.float32, device=dev)
+                stats = stats_pass[k]
                 arr, garr = f.pointers(grads=True)
-                dp = self.grad_sync is not None
                 check(lib().mansy_ppo_minibatch_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(data['obs']),
                                                      ptr(idx), ptr(data['act']), ptr(data['adv']), ptr(data['logp_old']), ptr(data['v_s']),
                                                      ptr(data['returns']), idx.numel(), self._eps_clip, self._weight_vf, self._weight_ent,
@@ -338,11 +388,8 @@ class PPOPolicy(nn.Module):
                 if dp:                              # raw local gradients -> RCCL average -> global-norm clip + Adam
                     self.grad_sync(f.flat_g)
                     self._clip_adam(f, float(self._grad_norm or 0.0), lr, wd)
-                stats_all.append(stats)
-        st = torch.stack(stats_all).cpu().numpy()
-        for j, k in enumerate(('loss', 'loss/clip', 'loss/vf', 'loss/ent')):
-            losses[k] = st[:, j].tolist()
-        return losses
+            stats_all.append(stats_pass)
+        return LazyLosses(('loss', 'loss/clip', 'loss/vf', 'loss/ent'), stats_all)
 
     def bc_step(self, obs, act, ent_coef=0.1, train=True):
         """One behaviour-cloning step on a demonstration (utils/mansy_utils.py:60-69) or, with train=False, its validation

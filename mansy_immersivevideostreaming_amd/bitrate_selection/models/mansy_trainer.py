@@ -102,7 +102,7 @@ class OnpolicyTrainer:
                 print('==================== End Training identifier ====================')
             losses = self.policy.update(0, self.buffer, batch_size=self.batch_size, repeat=self.repeat_per_collect, is_train=True)
             self.buffer.reset()
-            self.gradient_step += max([1] + [len(v) for v in losses.values() if isinstance(v, list)])
+            self.gradient_step += max(1, getattr(losses, 'n_steps', 0))
         if self.save_checkpoint_fn:
             self.save_checkpoint_fn(self.epoch, self.env_step, self.gradient_step)
         if self.test_collector is not None:

@@ -17,7 +17,7 @@ import torch.nn as nn
 
 from ..._lib import MansyError, check, lib, ptr, stream_ptr
 from .mansy import MAXOUT, _Flat, _Seq0, _conv_as_linear_init
-from .mansy_ppo import _ActorCritic, _Result, split_indices
+from .mansy_ppo import LazyLosses, _ActorCritic, _Result, split_indices
 
 LD = 416
 SLICES = {'throughput': (0, 8, (1, 8)), 'chunk_sizes': (8, 328, (5, 64)), 'rebuffer': (328, 329, (1,)), 'last_bitrates': (329, 331, (2,)),
@@ -300,9 +300,14 @@ class A2CPolicy(nn.Module):
         stats_all = []
         dp = self.grad_sync is not None
         for _ in range(repeat):
-            for chunk in split_indices(n, batch_size):
-                idx = torch.from_numpy(chunk.astype(np.int32)).to(dev)
-                stats = torch.empty(4, dtype=torch.float32, device=dev)
+            chunks = list(split_indices(n, batch_size))
+            perm = torch.from_numpy(np.concatenate(chunks).astype(np.int32)).to(dev)      # one upload per pass; minibatches are views
+            stats_pass = torch.empty(len(chunks), 4, dtype=torch.float32, device=dev)
+            off = 0
+            for k, chunk in enumerate(chunks):
+                idx = perm[off:off + len(chunk)]
+                off += len(chunk)
+                stats = stats_pass[k]
                 arr, garr = f.pointers(grads=True)
                 check(lib().mansy_a2c_minibatch_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(sq), f.flat_p.numel(), ptr(data['obs']), ptr(idx),
                                                      ptr(data['act']), ptr(data['adv']), ptr(data['returns']), idx.numel(), self._weight_vf,
@@ -313,9 +318,8 @@ class A2CPolicy(nn.Module):
                     scratch = torch.empty(64, dtype=torch.float64, device=dev)
                     check(lib().mansy_clip_grad_rmsprop(ptr(f.flat_p), ptr(f.flat_g), ptr(sq), f.flat_p.numel(), float(self._grad_norm or 0.0), lr, alpha,
                                                         eps, ptr(scratch), stream_ptr(dev)), 'mansy_clip_grad_rmsprop')
-                stats_all.append(stats)
-        st = torch.stack(stats_all).cpu().numpy()
-        return {k: st[:, j].tolist() for j, k in enumerate(('loss', 'loss/actor', 'loss/vf', 'loss/ent'))}
+            stats_all.append(stats_pass)
+        return LazyLosses(('loss', 'loss/actor', 'loss/vf', 'loss/ent'), stats_all)
 
     def update(self, sample_size, buffer, batch_size=256, repeat=2, **kwargs):
         if buffer is None or len(buffer) == 0:

@@ -78,7 +78,7 @@ def train(args, config, policy, qoe_weights, models_dir, file_prefix):
             env_step += n
             losses = policy.update(0, buffer, batch_size=args.batch_size, repeat=args.repeat_per_collect)
             buffer.reset()
-            gradient_step += len(losses.get('loss', [])) or 1
+            gradient_step += max(1, getattr(losses, 'n_steps', 0))
         write_episode_log(train_log_path, t_train, qoe_weights, train_env.pop_episode_log())
         torch.save(policy.state_dict(), checkpoint_path)
         print('Checkpoint saved at ' + checkpoint_path)
