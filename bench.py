@@ -354,8 +354,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
             out['secondary']['cpu_baseline'] = cpu_baseline_ppo()
-        out['tertiary'] = bench_expert(dev, cpu=(world == 1 and not args.no_cpu_baseline))
-        out['inference'] = bench_vp_inference(model, h, c, f)
+        if world == 1:      # single-GPU extras (no collectives inside, but keep every rank's tail identical at N > 1)
+            out['tertiary'] = bench_expert(dev, cpu=not args.no_cpu_baseline)
+            out['inference'] = bench_vp_inference(model, h, c, f)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
