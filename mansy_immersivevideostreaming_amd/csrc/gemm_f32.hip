@@ -583,9 +583,9 @@ static long long tile_count(int M, int N, int tile) {
 // force_tile: 0 = heuristics; 64 / 96 / 128 = that tile; negative = that tile on the register-staged loop (A/B tests).
 int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb, int b_kmajor, float* C, int ldc,
                           int M, int N, int K, const GemmEpilogue& ep, int force_tile, int force_splitk, hipStream_t st) {
-  MANSY_REQUIRE(A && B && C, "gemm: null pointer");
   MANSY_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm: negative dimension");
-  if (M == 0 || N == 0) return MANSY_OK;
+  if (M == 0 || N == 0) return MANSY_OK;          // empty product (pointers of empty buffers may be null)
+  MANSY_REQUIRE(A && B && C, "gemm: null pointer");
   GemmParams p;
   p.A = A; p.B = B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.ep = ep;
   p.vec_ok = ((lda % 4) == 0) && ((ldb % 4) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&

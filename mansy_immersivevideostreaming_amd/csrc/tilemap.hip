@@ -94,8 +94,8 @@ __global__ __launch_bounds__(256) void tilemap_metrics_kernel(const unsigned lon
 }  // namespace
 
 int mansy_launch_tilemap_metrics(const unsigned long long* gt, const unsigned long long* pred, long long n, double* out, hipStream_t st) {
+  if (n <= 0) return MANSY_OK;                      // empty input: nothing to do (pointers of empty buffers may be null)
   MANSY_REQUIRE(gt && pred && out, "tilemap_metrics: null pointer");
-  if (n <= 0) return MANSY_OK;
   hipLaunchKernelGGL(tilemap_metrics_kernel, dim3(mansy_ceil_div(n, 256)), dim3(256), 0, st, gt, pred, n, out);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
@@ -103,24 +103,25 @@ int mansy_launch_tilemap_metrics(const unsigned long long* gt, const unsigned lo
 
 int mansy_launch_tilemap(const float* xy, long long n, int W, int H, int nw, int nh, int fov_w, int fov_h, unsigned long long* maps,
                          hipStream_t st) {
-  MANSY_REQUIRE(xy && maps, "tilemap: null pointer");
   MANSY_REQUIRE(nw >= 1 && nh >= 1 && nw * nh <= 64 && nw <= 32 && nh <= 32, "tilemap: grid %dx%d does not fit a uint64 map", nw, nh);
   MANSY_REQUIRE(fov_w < W && fov_h < H, "tilemap: FoV must be smaller than the frame");
   if (n <= 0) return MANSY_OK;
+  MANSY_REQUIRE(xy && maps, "tilemap: null pointer");
   hipLaunchKernelGGL(tilemap_kernel, dim3(mansy_ceil_div(n, 256)), dim3(256), 0, st, xy, n, W, H, nw, nh, fov_w, fov_h, maps);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }
 int mansy_launch_tilemap_iou(const unsigned long long* a, const unsigned long long* b, long long n, double* iou, hipStream_t st) {
-  MANSY_REQUIRE(a && b && iou, "tilemap_iou: null pointer");
   if (n <= 0) return MANSY_OK;
+  MANSY_REQUIRE(a && b && iou, "tilemap_iou: null pointer");
   hipLaunchKernelGGL(tilemap_iou_kernel, dim3(mansy_ceil_div(n, 256)), dim3(256), 0, st, a, b, n, iou);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }
 int mansy_launch_tilemap_or_groups(const unsigned long long* maps, long long ngroups, int group, unsigned long long* out, hipStream_t st) {
-  MANSY_REQUIRE(maps && out && group >= 1, "tilemap_or: bad arguments");
+  MANSY_REQUIRE(group >= 1, "tilemap_or: bad group size");
   if (ngroups <= 0) return MANSY_OK;
+  MANSY_REQUIRE(maps && out, "tilemap_or: null pointer");
   hipLaunchKernelGGL(tilemap_or_kernel, dim3(mansy_ceil_div(ngroups, 256)), dim3(256), 0, st, maps, ngroups, group, out);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;

@@ -261,3 +261,18 @@ def test_tilemap_bit_exact_vs_oracle_and_reference_goldens(K):
     xy[100:200] = 1.0
     got = K.tilemap(torch.from_numpy(xy).cuda()).cpu().numpy().view(np.uint64)
     np.testing.assert_array_equal(got, tm.tilemap_xy(xy))
+
+
+def test_empty_and_degenerate_inputs(K):
+    """Empty inputs are legal (the reference's loops simply do not run); degenerate 1x1x1 products and frame-edge pixels work."""
+    d = 'cuda'
+    assert K.tilemap(torch.zeros(0, 2, device=d)).shape == (0,)
+    e = torch.zeros(0, dtype=torch.int64, device=d)
+    assert K.tilemap_iou(e, e).shape == (0,) and K.tilemap_or_groups(e, 5).shape == (0,)
+    assert K.gemm(torch.zeros(0, 64, device=d), torch.zeros(32, 64, device=d)).shape == (0, 32)
+    assert K.gemm(torch.zeros(8, 64, device=d), torch.zeros(0, 64, device=d)).shape == (8, 0)
+    np.testing.assert_array_equal(K.gemm(torch.full((1, 1), 3.0, device=d), torch.full((1, 1), 2.0, device=d)).cpu().numpy(), [[6.0]])
+    from oracle import tilemap as otm
+    xy = np.array([[0.0, 0.0], [1.0, 1.0], [0.99999994, 0.5], [0.5, 0.99999994], [0.1171875, 0.2083333]], np.float32)
+    got = K.tilemap(torch.from_numpy(xy).to(d)).cpu().numpy().view(np.uint64)
+    np.testing.assert_array_equal(got, otm.tilemap_xy(xy).view(np.uint64))
