@@ -284,11 +284,9 @@ class A2CPolicy(nn.Module):
         check(lib().mansy_gae_returns(ptr(buffer.rew[:T]), ptr(v_s), ptr(v_next), ptr(buffer.done[:T]), T, N, self._gamma, self._lambda,
                                       int(self._rew_norm), ptr(rms_use), ptr(scratch), ptr(returns), ptr(adv), stream_ptr(dev)),
               'mansy_gae_returns')
-        if self.world > 1 and self._rew_norm:
-            from ...dist import merge_moments
-            x = scratch[:n]
-            merged = merge_moments(tuple(rms_local.tolist()), (x.mean().item(), x.var(unbiased=False).item(), float(n)))
-            rms_local.copy_(torch.tensor(merged, dtype=torch.float64, device=dev))
+        if self.world > 1 and self._rew_norm:      # accumulate only our own (un-normalised) returns locally; no host round trip
+            from ...dist import update_running_moments
+            update_running_moments(rms_local, scratch[:n])
         return dict(obs=obs, act=buffer.act[:T].reshape(n), returns=returns, adv=adv, n=n)
 
     def learn(self, data, batch_size, repeat):

@@ -75,14 +75,32 @@ def merge_moments(a, b):
     return am + delta * bc / tot, m2 / tot, tot
 
 
+def pooled_moments(triples):
+    """[k, 3] tensor of (mean, var, count) rows -> their pooled (mean, var, count) as a [3] tensor, computed where the data
+    lives (no host round trip): C = sum c_i, M = sum c_i m_i / C, var = sum c_i (v_i + (m_i - M)^2) / C -- the closed form of
+    chaining merge_moments over the rows.  All counts zero: the initial state (0, 1, 0)."""
+    m, v, c = triples[:, 0], triples[:, 1], triples[:, 2]
+    tot = c.sum()
+    safe = torch.where(tot > 0, tot, torch.ones_like(tot))
+    mean = (c * m).sum() / safe
+    var = (c * (v + (m - mean) ** 2)).sum() / safe
+    empty = tot <= 0
+    return torch.stack([torch.where(empty, torch.zeros_like(mean), mean), torch.where(empty, torch.ones_like(var), var), tot])
+
+
 def global_running_moments(rms_local, world):
     """rms_local: this rank's accumulated [mean, var, count] (float64 tensor, only its own returns).  Returns a NEW tensor
-    with the merge over all ranks (identical on every rank); rms_local is not modified.  With one process: a copy."""
+    with the merge over all ranks (identical on every rank); rms_local is not modified.  With one process: a copy.
+    Stays on the device: one all-gather of 3 doubles + a handful of tiny tensor ops, no host synchronisation."""
     if world <= 1:
         return rms_local.clone()
     gathered = [torch.zeros_like(rms_local) for _ in range(world)]
     dist.all_gather(gathered, rms_local)
-    acc = (0.0, 1.0, 0.0)
-    for g in gathered:
-        acc = merge_moments(acc, tuple(float(x) for x in g.tolist()))
-    return torch.tensor(acc, dtype=rms_local.dtype, device=rms_local.device)
+    return pooled_moments(torch.stack(gathered))
+
+
+def update_running_moments(rms_local, x):
+    """rms_local (+)= the statistics of the samples x, in place, on the device (tianshou RunningMeanStd.update)."""
+    batch = torch.stack([x.mean(), x.var(unbiased=False), torch.full((), float(x.numel()), dtype=x.dtype, device=x.device)]).to(rms_local.dtype)
+    rms_local.copy_(pooled_moments(torch.stack([rms_local, batch])))
+    return rms_local

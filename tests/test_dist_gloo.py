@@ -65,3 +65,28 @@ def test_single_process_helpers():
     assert mdist.shard_envs(256, 0, 1) == (0, 256)
     a = mdist.merge_moments((0.0, 1.0, 0.0), (2.0, 3.0, 10.0))
     assert a == (2.0, 3.0, 10.0)
+
+
+def test_pooled_moments_equals_chained_merges():
+    """The device-side closed form used by the data-parallel return normaliser equals chaining merge_moments (the
+    RunningMeanStd.update formula), including empty rows and the all-empty initial state."""
+    import numpy as np
+    import torch
+    from mansy_immersivevideostreaming_amd import dist as mdist
+    rs = np.random.RandomState(0)
+    rows, acc = [(0.0, 1.0, 0.0)], (0.0, 1.0, 0.0)
+    for k in range(5):
+        x = rs.randn(100 + 37 * k) * (1 + k) + k
+        rows.append((x.mean(), x.var(), float(len(x))))
+    rows.append((0.0, 1.0, 0.0))
+    for r in rows:
+        acc = mdist.merge_moments(acc, r)
+    got = mdist.pooled_moments(torch.tensor(rows, dtype=torch.float64)).numpy()
+    np.testing.assert_allclose(got, acc, rtol=1e-12)
+    np.testing.assert_array_equal(mdist.pooled_moments(torch.tensor([(0.0, 1.0, 0.0)] * 3, dtype=torch.float64)).numpy(), [0.0, 1.0, 0.0])
+    rms = torch.tensor([0.0, 1.0, 0.0], dtype=torch.float64)
+    xs = [torch.from_numpy(rs.randn(64)), torch.from_numpy(rs.randn(200) * 3 + 1)]
+    for x in xs:
+        mdist.update_running_moments(rms, x)
+    allx = torch.cat(xs).numpy()
+    np.testing.assert_allclose(rms.numpy(), [allx.mean(), allx.var(), len(allx)], rtol=1e-12)
