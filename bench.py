@@ -31,6 +31,17 @@ FLOP_PER_TRAJ = 0.522e9          # fwd+bwd algorithmic FLOPs per tr
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: FP32 matrix peak (spec)
 
 
+def synthetic_trajectories(B, S, T, seed=5):
+    """SURVEY 8(d) C2 inputs: smooth random walks on the unit torus, S + 1 + T samples (history, current, future), fp32."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    p0 = torch.rand(B, 1, 2, generator=g)
+    steps = torch.randn(B, S + T, 2, generator=g) * 0.02
+    traj = torch.cat([p0, p0 + torch.cumsum(steps, dim=1)], dim=1)
+    traj = traj - torch.floor(traj)
+    return traj[:, :S].contiguous(), traj[:, S:S + 1].contiguous(), traj[:, S + 1:].contiguous()
+
+
 def cpu_baseline(seconds=15.0):
     import torch
     from oracle import vp_oracle as vo
@@ -276,7 +287,6 @@ def main():
 
     from mansy_immersivevideostreaming_amd.viewport_prediction.models import ViewportTransformerMTIO, FusedAdamW
     from mansy_immersivevideostreaming_amd._lib import lib, check
-    from oracle import vp_oracle as vo      # input generator only (synthetic_trajectories)
 
     B, S, T, d = args.batch, 10, 10, 512
     torch.manual_seed(5)
@@ -287,7 +297,7 @@ def main():
     if world > 1:
         model.set_data_parallel(world)      # SyncBN for the DistillLayer: batch statistics over the GLOBAL mini-batch
     opt = FusedAdamW(model, lr=1e-4)
-    h, c, f = (t.to(dev) for t in vo.synthetic_trajectories(B, S, T, seed=5 + rank))
+    h, c, f = (t.to(dev) for t in synthetic_trajectories(B, S, T, seed=5 + rank))
 
     grad_sync = mdist.make_grad_sync(world)
 
