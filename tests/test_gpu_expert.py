@@ -146,3 +146,47 @@ def test_expert_env_wrapper_and_cache_dicts(X, tmp_path):
                     assert v == ref[i, c - vstart[i], a]
     with pytest.raises(X.MansyError):
         X.ExpertVecEnv(T, 1, 7)
+
+
+@pytest.mark.parametrize('horizon', [2, 4])
+def test_ties_resolve_to_the_first_plan(X, horizon):
+    """Adversarial ties: constant tile quality and tiny chunk sizes make every plan score the same (no rebuffering, no quality
+    change), or tie in large groups -- the reference's strict `<` scan keeps the FIRST best plan, so must the atomicMax key."""
+    base = X.EnvTables.synthetic('cuda', n_video=2, n_user=2, n_trace=2, n_chunk=40, seed=2, n_sample=4, train_identifier_reward=False)
+    arrays = {k: base.host[k].copy() for k in FIELDS}
+    arrays['quality'][:] = 8.0
+    arrays['size'][:] = 10
+    T = X.EnvTables(arrays, base.host['qoe_w'], 'cuda', train_identifier_reward=False)
+    OT = oenv.EnvTables(arrays, base.host['qoe_w'], train_identifier_reward=False)
+    venv = X.ExpertVecEnv(T, 4, horizon, seed=0)
+    ex = oenv.Expert(OT, venv.cache.vp_video.cpu().numpy(), horizon)
+    oenvs = [oenv.Env(OT, seed=i, worker_num=4) for i in range(4)]
+    venv.reset()
+    for e in oenvs:
+        e.reset()
+    for t in range(6):
+        a = venv.choose_action().cpu().numpy()
+        bi, bv = venv.best_index.cpu().numpy(), venv.best_value.cpu().numpy()
+        for i, e in enumerate(oenvs):
+            oa, ov, oi = ex.choose_action(e, with_value=True)
+            assert (int(a[i]), int(bi[i])) == (oa, oi) == (0, 0) and u32(bv[i]) == u32(ov), (t, i, a[i], bi[i], oa, oi)
+            e.step(oa)
+        venv.step(venv.actions)
+    # ties in groups: quality depends only on the rate version, sizes stay tiny -> plans with the same rate pattern tie
+    arrays['quality'][:] = np.array([1, 5, 8, 16, 35], np.float32).reshape(1, 1, 5, 1)
+    T2 = X.EnvTables(arrays, base.host['qoe_w'], 'cuda', train_identifier_reward=False)
+    OT2 = oenv.EnvTables(arrays, base.host['qoe_w'], train_identifier_reward=False)
+    v2 = X.ExpertVecEnv(T2, 4, horizon, seed=0)
+    ex2 = oenv.Expert(OT2, v2.cache.vp_video.cpu().numpy(), horizon)
+    o2 = [oenv.Env(OT2, seed=i, worker_num=4) for i in range(4)]
+    v2.reset()
+    for e in o2:
+        e.reset()
+    for t in range(8):
+        a = v2.choose_action().cpu().numpy()
+        bi = v2.best_index.cpu().numpy()
+        for i, e in enumerate(o2):
+            oa, _, oi = ex2.choose_action(e, with_value=True)
+            assert (int(a[i]), int(bi[i])) == (oa, oi), (t, i)
+            e.step(oa)
+        v2.step(v2.actions)
