@@ -86,7 +86,7 @@ def _pmc_traffic():
         return None
 
 
-def bench_ppo(rank, world, dev, mdist, cycles=5, warmup=2, n_env=256, steps_per_env=16):
+def bench_ppo(rank, world, dev, mdist, cycles=5, warmup=2, n_env=256, steps_per_env=16, rollout_probe=True):
     """PPO env-steps/s (BASELINE configs[2]/[3]): 256 vectorised trace-sim envs per GPU on synthetic bench-shaped tables,
     one cycle = collect 16 steps/env (4096 transitions/GPU) -> train_identifier (2 rounds) -> relabel -> PPO update
     (minibatch 512, repeat 2), i.e. run_mansy.py --train --train-identifier --use-identifier with step_per_collect=4096."""
@@ -142,10 +142,10 @@ def bench_ppo(rank, world, dev, mdist, cycles=5, warmup=2, n_env=256, steps_per_
         dt = t.item()
     # rollout alone (outside the timed region): policy forward + sampling + environment step, hipGraph-replayed collects
     tc = time.perf_counter()
-    for _ in range(cycles):
+    for _ in range(cycles if rollout_probe else 0):
         col.collect(steps_per_env * n_env, buf)
     torch.cuda.synchronize()
-    t_collect = time.perf_counter() - tc
+    t_collect = max(time.perf_counter() - tc, 1e-9)
     steps = world * n_env * steps_per_env * cycles
     return {'metric': 'PPO env-steps/sec', 'value': round(steps / dt, 1), 'unit': 'env-steps/s', 'n_gpus': world, 'cycles': cycles,
             'ms_per_cycle': round(dt / cycles * 1e3, 3), 'rollout_only_env_steps_per_s': round(n_env * steps_per_env * cycles / t_collect, 1),

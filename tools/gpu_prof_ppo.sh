@@ -5,7 +5,7 @@ import sys, os, time
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 import torch, bench
 from mansy_immersivevideostreaming_amd import dist as mdist
-r = bench.bench_ppo(0, 1, torch.device('cuda', 0), mdist, cycles=int(sys.argv[1]), warmup=2)
+r = bench.bench_ppo(0, 1, torch.device('cuda', 0), mdist, cycles=int(sys.argv[1]), warmup=2, rollout_probe=False)
 print(r['ms_per_cycle'], r['rollout_step_latency_us'])
 PY
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_ppo -- python3 /tmp/ppo_only.py 10 > gpurun_out/prof_ppo.log 2>&1; echo "rc=$?"; tail -1 gpurun_out/prof_ppo.log
