@@ -4,6 +4,7 @@ runs for real -- SyncBN statistics hook, flat-gradient all-reduce, sharded envir
 barrier / max-over-ranks timing protocol and the rank-0 JSON line -- only the transport differs."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -15,8 +16,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 def test_bench_two_ranks_share_one_gpu_over_gloo():
     env = dict(os.environ, MANSY_DIST_BACKEND='gloo', MANSY_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    with socket.socket() as s:          # a free rendezvous port on this box
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', '29533', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--no-cpu-baseline',
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--no-cpu-baseline',
            '--batch', '256']
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
