@@ -10,6 +10,7 @@ Everything numerical happens in libmansy_hip.so; this file sequences engine call
 tianshou semantics are restated from the 0.4.8 release (T2, parity unpinned -- see oracle/ppo_oracle.py).
 """
 import ctypes
+from collections.abc import Mapping
 
 import numpy as np
 import torch
@@ -140,32 +141,24 @@ def split_indices(length, size, shuffle=True, merge_last=True):
         yield indices[idx:idx + size]
 
 
-class LazyLosses(dict):
+class LazyLosses(Mapping):
     """The per-minibatch loss statistics of an update ({'loss': [...], ...} like tianshou's learn()), fetched from the device
-    on first access: an update that nobody inspects (every collect but the logged ones) costs no device-to-host sync."""
+    on first access: an update that nobody inspects (every collect but the logged ones) costs no device-to-host sync.
+    A read-only Mapping (dict(x), x.items(), x['loss'], json all see the values)."""
 
     def __init__(self, names, stat_tensors):
-        super().__init__()
-        self._names, self._pending = names, stat_tensors
+        self._names, self._pending, self._data = tuple(names), stat_tensors, None
         self.n_steps = sum(int(t.shape[0]) for t in stat_tensors)        # gradient steps taken (known without touching the device)
 
     def _load(self):
-        if self._pending is not None:
-            st = torch.cat(self._pending).cpu().numpy()
+        if self._data is None:
+            st = torch.cat(self._pending).cpu().numpy() if self._pending else np.zeros((0, len(self._names)), np.float32)
             self._pending = None
-            for j, k in enumerate(self._names):
-                super().__setitem__(k, st[:, j].tolist())
+            self._data = {k: st[:, j].tolist() for j, k in enumerate(self._names)}
+        return self._data
 
     def __getitem__(self, k):
-        self._load()
-        return super().__getitem__(k)
-
-    def get(self, k, default=None):
-        self._load()
-        return super().get(k, default)
-
-    def __contains__(self, k):
-        return k in self._names
+        return self._load()[k]
 
     def __iter__(self):
         return iter(self._names)
@@ -173,16 +166,8 @@ class LazyLosses(dict):
     def __len__(self):
         return len(self._names)
 
-    def keys(self):
-        return list(self._names)
-
-    def items(self):
-        self._load()
-        return super().items()
-
-    def values(self):
-        self._load()
-        return super().values()
+    def __repr__(self):
+        return repr(self._load())
 
 
 class _ActorCritic(nn.Module):
