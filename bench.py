@@ -31,6 +31,21 @@ FLOP_PER_TRAJ = 0.522e9          # fwd+bwd algorithmic FLOPs per tr
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: FP32 matrix peak (spec)
 
 
+def replica_spread(flat, world):
+    """Data-parallel sanity figure (after the timed region): max over ranks minus min over ranks of a checksum of the
+    parameters.  Identical replicas (same initial weights, averaged gradients, synchronised BatchNorm statistics) give 0."""
+    import torch
+    import torch.distributed as dist
+    if world <= 1:
+        return 0.0
+    s = flat.double().sum().reshape(1)
+    a = flat.double().abs().sum().reshape(1)
+    hi, lo = torch.cat([s, a]), torch.cat([s, a])
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    return float((hi - lo).abs().max().item())
+
+
 def synthetic_trajectories(B, S, T, seed=5):
     """SURVEY 8(d) C2 inputs: smooth random walks on the unit torus, S + 1 + T samples (history, current, future), fp32."""
     import torch
@@ -147,7 +162,9 @@ def bench_ppo(rank, world, dev, mdist, cycles=5, warmup=2, n_env=256, steps_per_
     torch.cuda.synchronize()
     t_collect = max(time.perf_counter() - tc, 1e-9)
     steps = world * n_env * steps_per_env * cycles
+    spread = max(replica_spread(pol.engine.ac.flat_p, world), replica_spread(pol.engine.idn.flat_p, world))
     return {'metric': 'PPO env-steps/sec', 'value': round(steps / dt, 1), 'unit': 'env-steps/s', 'n_gpus': world, 'cycles': cycles,
+            'replica_param_spread': spread,
             'ms_per_cycle': round(dt / cycles * 1e3, 3), 'rollout_only_env_steps_per_s': round(n_env * steps_per_env * cycles / t_collect, 1),
             'rollout_step_latency_us': round(t_collect / (cycles * steps_per_env) * 1e6, 1), 'final_loss': float(np.mean(res['loss'])),
             'config': {'workload': f'{n_env} device-resident envs/GPU x {steps_per_env} steps per collect (4096 transitions/GPU), '
@@ -347,6 +364,7 @@ def main():
                 'algorithmic_flops_per_step': FLOP_PER_TRAJ * B,
                 'model_frac': round(value / world * FLOP_PER_TRAJ / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
 
+    vp_spread = replica_spread(model._flat_p, world)
     ppo = bench_ppo(rank, world, dev, mdist, cycles=max(2, min(args.steps, 6)), warmup=2)
 
     if rank == 0:
@@ -357,7 +375,7 @@ def main():
             'config': {'workload': f'VP Transformer train step (fwd+loss+bwd+AdamW), B={B}/GPU synthetic torus-walk '
                                    f'trajectories len 21 (hist 10 + cur 1 + pred 10), d=512, 8 heads, 2+2 layers, dropout on, '
                                    f'fp32 MFMA', 'global_batch': B * world, 'parallelism': f'dp{world}'},
-            'final_loss': loss_val,
+            'final_loss': loss_val, 'replica_param_spread': vp_spread,
             'roofline': roof,
             'secondary': ppo,
         }

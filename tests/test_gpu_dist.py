@@ -31,3 +31,5 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
     assert out['value'] > 0 and out['secondary']['value'] > 0 and out['secondary']['n_gpus'] == 2
     assert out['roofline']['launches_per_step'] > 0
     assert 0 < out['final_loss'] < 10
+    # replicas stay bit-identical: averaged gradients, synchronised BatchNorm statistics, merged return normaliser
+    assert out['replica_param_spread'] == 0.0 and out['secondary']['replica_param_spread'] == 0.0
