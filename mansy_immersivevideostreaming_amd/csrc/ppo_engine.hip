@@ -84,11 +84,34 @@ struct PackArgs {
   // riders on the same launch (independent prologue work of a PPO minibatch step): gather the minibatch's observation rows,
   // zero the flat gradient buffer
   const float* g_src; const int* g_idx; float* g_dst; int g_rows; float* zero_ptr; long long zero_n;
+  // one more rider (an extra workgroup at the end of the grid): mean / unbiased std of the minibatch's advantages -> adv_stats[0..1]
+  // (the fused loss in head_out_kernel normalises with them)
+  const float* adv; int adv_n; float* adv_stats;
 };
 // Wbd [FEAT, KP] (columns >= K and everything off the block diagonal zero), bbd [FEAT], and per 64-feature column tile of
 // the product the K range that holds its branch's weights (GemmEpilogue::tile_krange).
 __global__ __launch_bounds__(256) void pack_wbd_kernel(PackArgs a, int identifier, int K, float* __restrict__ Wbd, float* __restrict__ bbd,
                                                        int* __restrict__ krange) {
+  if (a.adv && blockIdx.x == gridDim.x - 1) {        // advantage statistics (two-pass, like torch: mean, then unbiased variance)
+    __shared__ float sh_adv[8];
+    const int n = a.adv_n;
+    float s1 = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s1 += a.adv[a.g_idx ? a.g_idx[i] : i];
+    s1 = wave_sum(s1);
+    if ((threadIdx.x & 63) == 0) sh_adv[threadIdx.x >> 6] = s1;
+    __syncthreads();
+    const float mean = (sh_adv[0] + sh_adv[1] + sh_adv[2] + sh_adv[3]) / (float)n;
+    float q = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) { const float d = a.adv[a.g_idx ? a.g_idx[i] : i] - mean; q += d * d; }
+    q = wave_sum(q);
+    if ((threadIdx.x & 63) == 0) sh_adv[4 + (threadIdx.x >> 6)] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      a.adv_stats[0] = mean;
+      a.adv_stats[1] = sqrtf((sh_adv[4] + sh_adv[5] + sh_adv[6] + sh_adv[7]) / (float)(n > 1 ? n - 1 : 1));
+    }
+    return;
+  }
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx < FEAT / 64) {
     const Branch g = branch_geom((int)idx * 64 / HID, identifier);
@@ -146,10 +169,20 @@ struct HeadOut {
   float* A1; const float* fc_b; const float* Wout; const float* bout; int n_out; int sigmoid; float* H; float* out; int pre_col;
   int* act; float* logp;
 };
+// PPO minibatch loss fused into the output-layer launch (T2: tianshou 0.4.8 PPOPolicy.learn): head 0 (actor) turns its row's
+// logits into the clipped-surrogate + entropy terms and their gradient wrt the logits, head 1 (critic) its value into the
+// (clipped) value loss and its gradient; per-row loss terms go to lossrows [rows, 4] = (clip, vf, ent, -) and are summed in a
+// fixed order by head_out_bwd_kernel.  adv_stats: minibatch mean / unbiased std of the advantages (pack_wbd_kernel rider).
+struct LossFuse {
+  int on;
+  const int* act; const float* adv; const float* logp_old; const float* v_old; const float* ret; const int* idx;
+  int n; float eps_clip, vf_coef, ent_coef; int norm_adv, value_clip; float adv_eps;
+  const float* adv_stats; float* dlogits; float* dvalue; int dvalue_ld; float* lossrows;
+};
 struct HeadOutArgs { HeadOut h[2]; };
 __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const float* __restrict__ A1pre, int nsplit, long long slab, int pre_ld,
                                                        const float* __restrict__ F, int out_ld, int rows, const float* __restrict__ u_ext,
-                                                       uint32_t seed, uint32_t site) {
+                                                       uint32_t seed, uint32_t site, LossFuse lf) {
   const HeadOut& d = args.h[blockIdx.y];
   float* __restrict__ A1 = d.A1; const float* __restrict__ Wout = d.Wout; const float* __restrict__ bout = d.bout;
   float* __restrict__ H = d.H; float* __restrict__ out = d.out; int* __restrict__ act = d.act; float* __restrict__ logp = d.logp;
@@ -189,6 +222,59 @@ __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const f
     for (int k = 0; k < MAXOUT; ++k) if (k == lane) mine = o[k];
     out[(size_t)row * out_ld + lane] = mine;
   }
+  if (lf.on && blockIdx.y == 0) {  // actor: clipped surrogate + entropy of this row, gradient wrt the logits (every lane computes the same scalars)
+    const int bi = lf.idx ? lf.idx[row] : row;
+    float adv = lf.adv[bi];
+    if (lf.norm_adv) adv = (adv - lf.adv_stats[0]) / (lf.adv_stats[1] + lf.adv_eps);
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < NACT; ++k) m = fmaxf(m, o[k]);
+    float e[NACT], se = 0.f;
+#pragma unroll
+    for (int k = 0; k < NACT; ++k) { e[k] = expf(o[k] - m); se += e[k]; }
+    const float lse = logf(se);
+    const int a = lf.act[bi];
+    float lg_act = 0.f;
+#pragma unroll
+    for (int k = 0; k < NACT; ++k) if (k == a) lg_act = o[k];
+    const float lp_a = (lg_act - m) - lse;
+    const float ratio = expf(lp_a - lf.logp_old[bi]);
+    const float surr1 = ratio * adv;
+    const float rc = fminf(fmaxf(ratio, 1.f - lf.eps_clip), 1.f + lf.eps_clip);
+    const float surr2 = rc * adv;
+    float dlogp;
+    if (surr1 <= surr2) dlogp = -ratio * adv;
+    else dlogp = (ratio > 1.f - lf.eps_clip && ratio < 1.f + lf.eps_clip) ? -ratio * adv : 0.f;
+    dlogp /= (float)lf.n;
+    float ent = 0.f;
+#pragma unroll
+    for (int k = 0; k < NACT; ++k) { const float p = e[k] / se; const float lp = (o[k] - m) - lse; ent -= p * lp; }
+    float mine = 0.f;
+#pragma unroll
+    for (int k = 0; k < NACT; ++k) {
+      const float p = e[k] / se, lp = (o[k] - m) - lse;
+      float g = dlogp * ((k == a ? 1.f : 0.f) - p);
+      g += -lf.ent_coef * (-p * (lp + ent)) / (float)lf.n;      // d(-ent_coef * mean H)/dlogit_k = ent_coef * p_k (log p_k + H) / n
+      if (k == lane) mine = g;
+    }
+    if (lane < MAXOUT) lf.dlogits[(size_t)row * MAXOUT + lane] = mine;       // column 15 (lane 15) is 0
+    if (lane == 0) { lf.lossrows[4 * (size_t)row + 0] = -fminf(surr1, surr2); lf.lossrows[4 * (size_t)row + 2] = ent; }
+  }
+  if (lf.on && blockIdx.y == 1 && lane == 0) {   // critic: (clipped) value loss of this row and its gradient
+    const int bi = lf.idx ? lf.idx[row] : row;
+    const float v = o[0], ret = lf.ret[bi];
+    float dv, lv;
+    if (lf.value_clip) {
+      const float vo = lf.v_old[bi];
+      const float diff = v - vo;
+      const float vc = vo + fminf(fmaxf(diff, -lf.eps_clip), lf.eps_clip);
+      const float vf1 = (ret - v) * (ret - v), vf2 = (ret - vc) * (ret - vc);
+      if (vf1 >= vf2) { lv = vf1; dv = -2.f * (ret - v); }
+      else { lv = vf2; dv = (diff > -lf.eps_clip && diff < lf.eps_clip) ? -2.f * (ret - vc) : 0.f; }
+    } else { lv = (ret - v) * (ret - v); dv = -2.f * (ret - v); }
+    lf.dvalue[(size_t)row * lf.dvalue_ld] = lf.vf_coef * dv / (float)lf.n;
+    lf.lossrows[4 * (size_t)row + 1] = lv;
+  }
   if (act) {                       // Categorical(logits).sample() by inverse CDF; log_prob of the sample
     float m = -INFINITY;
 #pragma unroll
@@ -219,7 +305,24 @@ struct HeadBwd {
   float* gbout;
 };
 struct HeadBwdArgs { HeadBwd h[2]; };
-__global__ __launch_bounds__(256) void head_out_bwd_kernel(HeadBwdArgs args, int rows) {
+// loss statistics of the fused PPO loss: stats = [loss, clip, vf, ent] from the per-row terms (fixed summation order)
+struct LossFinish { const float* lossrows; int n; float vf_coef, ent_coef; float* stats; };
+__global__ __launch_bounds__(256) void head_out_bwd_kernel(HeadBwdArgs args, int rows, LossFinish fin) {
+  if (fin.stats && blockIdx.x == 0 && blockIdx.y == 0) {
+    __shared__ float sh_fin[3][4];
+    float c = 0.f, v = 0.f, e = 0.f;
+    for (int i = threadIdx.x; i < fin.n; i += 256) { c += fin.lossrows[4 * i]; v += fin.lossrows[4 * i + 1]; e += fin.lossrows[4 * i + 2]; }
+    c = wave_sum(c); v = wave_sum(v); e = wave_sum(e);
+    if ((threadIdx.x & 63) == 0) { sh_fin[0][threadIdx.x >> 6] = c; sh_fin[1][threadIdx.x >> 6] = v; sh_fin[2][threadIdx.x >> 6] = e; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float cm = (sh_fin[0][0] + sh_fin[0][1] + sh_fin[0][2] + sh_fin[0][3]) / (float)fin.n;
+      const float vm = (sh_fin[1][0] + sh_fin[1][1] + sh_fin[1][2] + sh_fin[1][3]) / (float)fin.n;
+      const float em = (sh_fin[2][0] + sh_fin[2][1] + sh_fin[2][2] + sh_fin[2][3]) / (float)fin.n;
+      fin.stats[0] = cm + fin.vf_coef * vm - fin.ent_coef * em; fin.stats[1] = cm; fin.stats[2] = vm; fin.stats[3] = em;
+    }
+    __syncthreads();
+  }
   const HeadBwd& d = args.h[blockIdx.y];
   const float* __restrict__ g = d.g; const int g_ld = d.g_ld; const float* __restrict__ A1 = d.A1; const float* __restrict__ H = d.H;
   const float* __restrict__ Wout = d.Wout; const int n_out = d.n_out; float* __restrict__ dH = d.dH; float* __restrict__ dA1 = d.dA1;
@@ -280,15 +383,6 @@ __global__ __launch_bounds__(256) void featgrad_finish_kernel(float* __restrict_
 }
 
 
-// PPO minibatch loss + gradient wrt logits/value (T2: tianshou 0.4.8 PPOPolicy.learn).  One block, rows strided.
-// stats: [0] loss [1] clip [2] vf [3] ent ; adv normalised with the minibatch mean / unbiased std (two-pass).
-struct PPOLossArgs {
-  const float* logits; const float* value; const int* act; const float* adv; const float* logp_old; const float* v_old; const float* ret;
-  const int* idx;          // minibatch row -> buffer row for act/adv/logp_old/v_old/ret (logits/value are minibatch-local)
-  int n; float eps_clip, vf_coef, ent_coef; int norm_adv, value_clip; float adv_eps;
-  int value_ld, dvalue_ld;
-  float* dlogits; float* dvalue; float* stats;
-};
 __device__ float block_sum(float v, float* sh) {
   v = wave_sum(v);
   __syncthreads();
@@ -297,80 +391,6 @@ __device__ float block_sum(float v, float* sh) {
   float t = 0.f;
   for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
   return t;
-}
-__global__ __launch_bounds__(1024) void ppo_loss_kernel(PPOLossArgs a) {
-  __shared__ float sh[16];
-  const int n = a.n;
-  float s = 0.f;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) s += a.adv[a.idx ? a.idx[i] : i];
-  const float mean = block_sum(s, sh) / (float)n;
-  float q = 0.f;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) { const float d = a.adv[a.idx ? a.idx[i] : i] - mean; q += d * d; }
-  const float var = block_sum(q, sh) / (float)(n > 1 ? n - 1 : 1);
-  const float stdv = sqrtf(var);
-  float l_clip = 0.f, l_vf = 0.f, l_ent = 0.f;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const int bi = a.idx ? a.idx[i] : i;
-    float adv = a.adv[bi];
-    if (a.norm_adv) adv = (adv - mean) / (stdv + a.adv_eps);
-    float lg[MAXOUT];                                  // the row's logits in registers: four 16-byte loads, no dynamic global index
-#pragma unroll
-    for (int q4 = 0; q4 < MAXOUT / 4; ++q4)
-      *reinterpret_cast<float4*>(lg + 4 * q4) = *reinterpret_cast<const float4*>(a.logits + (size_t)i * MAXOUT + 4 * q4);
-    float m = -INFINITY;
-#pragma unroll
-    for (int k = 0; k < NACT; ++k) m = fmaxf(m, lg[k]);
-    float e[NACT], se = 0.f;
-#pragma unroll
-    for (int k = 0; k < NACT; ++k) { e[k] = expf(lg[k] - m); se += e[k]; }
-    const float lse = logf(se);
-    const int act = a.act[bi];
-    float lg_act = 0.f;
-#pragma unroll
-    for (int k = 0; k < NACT; ++k) if (k == act) lg_act = lg[k];
-    const float logp = (lg_act - m) - lse;
-    const float ratio = expf(logp - a.logp_old[bi]);
-    const float surr1 = ratio * adv;
-    const float rc = fminf(fmaxf(ratio, 1.f - a.eps_clip), 1.f + a.eps_clip);
-    const float surr2 = rc * adv;
-    l_clip += -fminf(surr1, surr2);
-    // d(-min(s1,s2))/dlogp: s1 branch -> -ratio*adv ; s2 branch -> -ratio*adv only while ratio is inside the clip range
-    float dlogp;
-    if (surr1 <= surr2) dlogp = -ratio * adv;
-    else dlogp = (ratio > 1.f - a.eps_clip && ratio < 1.f + a.eps_clip) ? -ratio * adv : 0.f;
-    dlogp /= (float)n;
-    float ent = 0.f;
-#pragma unroll
-    for (int k = 0; k < NACT; ++k) { const float p = e[k] / se; const float lp = (lg[k] - m) - lse; ent -= p * lp; }
-    l_ent += ent;
-    float gout[MAXOUT];
-#pragma unroll
-    for (int k = 0; k < NACT; ++k) {
-      const float p = e[k] / se, lp = (lg[k] - m) - lse;
-      float g = dlogp * ((k == act ? 1.f : 0.f) - p);
-      g += -a.ent_coef * (-p * (lp + ent)) / (float)n;        // d(-ent_coef * mean H)/dlogit_k = ent_coef * p_k (log p_k + H) / n
-      gout[k] = g;
-    }
-    gout[NACT] = 0.f;
-#pragma unroll
-    for (int q4 = 0; q4 < MAXOUT / 4; ++q4)
-      *reinterpret_cast<float4*>(a.dlogits + (size_t)i * MAXOUT + 4 * q4) = *reinterpret_cast<const float4*>(gout + 4 * q4);
-    const float v = a.value[(size_t)i * a.value_ld], ret = a.ret[bi];
-    float dv;
-    if (a.value_clip) {
-      const float vo = a.v_old[bi];
-      const float diff = v - vo;
-      const float vc = vo + fminf(fmaxf(diff, -a.eps_clip), a.eps_clip);
-      const float vf1 = (ret - v) * (ret - v), vf2 = (ret - vc) * (ret - vc);
-      if (vf1 >= vf2) { l_vf += vf1; dv = -2.f * (ret - v); }
-      else { l_vf += vf2; dv = (diff > -a.eps_clip && diff < a.eps_clip) ? -2.f * (ret - vc) : 0.f; }
-    } else { l_vf += (ret - v) * (ret - v); dv = -2.f * (ret - v); }
-    a.dvalue[(size_t)i * a.dvalue_ld] = a.vf_coef * dv / (float)n;
-  }
-  const float c = block_sum(l_clip, sh) / (float)n;
-  const float vfm = block_sum(l_vf, sh) / (float)n;
-  const float em = block_sum(l_ent, sh) / (float)n;
-  if (threadIdx.x == 0 && a.stats) { a.stats[0] = c + a.vf_coef * vfm - a.ent_coef * em; a.stats[1] = c; a.stats[2] = vfm; a.stats[3] = em; }
 }
 
 // Behaviour cloning: mean cross entropy of the expert actions minus ent_coef * mean entropy, and its gradient wrt the
@@ -564,6 +584,7 @@ struct PWork {
   float *Wfc2, *dA1p;   // [actor.fc | critic.fc] stacked [2*HID, FEAT]; their dA1 side by side [B, 2*HID]
   int* krange;     // per 64-feature tile K range of the packed block-diagonal image
   double* acc;
+  float *adv_stats, *lossrows;   // fused PPO loss: minibatch advantage mean / std; per-row (clip, vf, ent, -) terms
 };
 // The head's fc product is [B,1280] x [1280,128]: 2 column tiles however large K is, so for B <= 2048 it is split over K
 // into slabs (GemmEpilogue::split_slab) that head_out_kernel sums -- 16x fewer K-tiles on the critical path at B = 256.
@@ -592,6 +613,7 @@ size_t ppo_layout(int maxB, char* base, PWork& W) {
   W.A1s = f((size_t)head_slab_rows(maxB) * 2 * HID);
   W.Wfc2 = f((size_t)2 * HID * FEAT); W.dA1p = f((size_t)maxB * 2 * HID);
   W.acc = (double*)f(2 * 64);      // NORM_PARTS doubles (gradient-norm partial sums; also the identifier-loss accumulator)
+  W.adv_stats = f(8); W.lossrows = f((size_t)maxB * 4);
   return tot + 256;
 }
 
@@ -603,6 +625,7 @@ struct PEng {
   int pack(const NetP& n, int identifier, const NetP* pair = nullptr, const float* g_src = nullptr, const int* g_idx = nullptr, int g_rows = 0,
            float* zero_ptr = nullptr, long long zero_n = 0) {
     PackArgs a; for (int j = 0; j < NB; ++j) { a.bw[j] = n.bw[j]; a.bb[j] = n.bb[j]; }
+    a.adv = nullptr; a.adv_n = 0; a.adv_stats = nullptr;
     a.fc_a = n.fc_w; a.fc_c = pair ? pair->fc_w : nullptr; a.Wfc2 = pair ? W.Wfc2 : nullptr;
     a.g_src = g_src; a.g_idx = g_idx; a.g_dst = W.obs_mb; a.g_rows = g_src ? g_rows : 0;
     a.zero_ptr = zero_ptr; a.zero_n = zero_ptr ? zero_n : 0;
@@ -610,6 +633,19 @@ struct PEng {
     const int K = identifier ? K_IDENT : K_POLICY;
     const long long threads = (long long)FEAT * KP + (pair ? 2LL * HID * FEAT : 0) + (long long)a.g_rows * (OBS_LD / 4) + (a.zero_n + 3) / 4;
     hipLaunchKernelGGL(pack_wbd_kernel, dim3(mansy_ceil_div(threads, 256)), dim3(256), 0, st, a, identifier, K, W.Wbd, W.bbd, W.krange);
+    MANSY_LAUNCH_CHECK();
+    return MANSY_OK;
+  }
+  // PPO minibatch prologue: re-pack, gather rows (idx != null), zero gradients, advantage statistics
+  int pack_mb(const NetP& a, const NetP& c, const float* g_src, const int* idx, int mb, float* zero_ptr, long long zero_n, const float* adv) {
+    PackArgs pa; for (int j = 0; j < NB; ++j) { pa.bw[j] = a.bw[j]; pa.bb[j] = a.bb[j]; }
+    pa.fc_a = a.fc_w; pa.fc_c = c.fc_w; pa.Wfc2 = W.Wfc2;
+    pa.g_src = g_src; pa.g_idx = idx; pa.g_dst = W.obs_mb; pa.g_rows = g_src ? mb : 0;
+    pa.zero_ptr = zero_ptr; pa.zero_n = zero_ptr ? zero_n : 0;
+    pa.adv = adv; pa.adv_n = mb; pa.adv_stats = W.adv_stats;
+    MANSY_REQUIRE(!zero_ptr || (reinterpret_cast<uintptr_t>(zero_ptr) & 15) == 0, "pack: gradient buffer must be 16-byte aligned");
+    const long long threads = (long long)FEAT * KP + 2LL * HID * FEAT + (long long)pa.g_rows * (OBS_LD / 4) + (pa.zero_n + 3) / 4;
+    hipLaunchKernelGGL(pack_wbd_kernel, dim3(mansy_ceil_div(threads, 256) + 1), dim3(256), 0, st, pa, 0, K_POLICY, W.Wbd, W.bbd, W.krange);
     MANSY_LAUNCH_CHECK();
     return MANSY_OK;
   }
@@ -634,13 +670,14 @@ struct PEng {
     HeadOutArgs ha;
     ha.h[0] = {A1, n.fc_b, n.out_w, n.out_b, n_out, sigmoid, H, out, 0, act, logp};
     ha.h[1] = ha.h[0];
+    LossFuse none; memset(&none, 0, sizeof(none));
     hipLaunchKernelGGL(head_out_kernel, dim3(mansy_ceil_div(B, 4), 1), dim3(256), 0, st, ha, W.A1s, nsplit, (long long)B * HID, HID, W.F, MAXOUT, B, u,
-                       seed, site);
+                       seed, site, none);
     MANSY_LAUNCH_CHECK();
     return MANSY_OK;
   }
   // actor + critic on the shared features in one product ([B,1280] x [1280,256], K-split slabs) and one head_out launch
-  int head_pair(const NetP& a, const NetP& c, int B) {
+  int head_pair(const NetP& a, const NetP& c, int B, const LossFuse* fuse = nullptr) {
     const int req = head_split_request(B, 2 * HID);
     const int nsplit = mansy_gemm_effective_splits(FEAT, req);
     GemmEpilogue ep; ep.split_slab = (long long)B * 2 * HID;
@@ -648,8 +685,10 @@ struct PEng {
     HeadOutArgs ha;
     ha.h[0] = {W.A1a, a.fc_b, a.out_w, a.out_b, NACT, 0, W.Ha, W.outa, 0, nullptr, nullptr};
     ha.h[1] = {W.A1c, c.fc_b, c.out_w, c.out_b, 1, 0, W.Hc, W.outc, HID, nullptr, nullptr};
+    LossFuse lf; memset(&lf, 0, sizeof(lf));
+    if (fuse) lf = *fuse;
     hipLaunchKernelGGL(head_out_kernel, dim3(mansy_ceil_div(B, 4), 2), dim3(256), 0, st, ha, W.A1s, nsplit, (long long)B * 2 * HID, 2 * HID, W.F, MAXOUT,
-                       B, nullptr, 0u, 0u);
+                       B, nullptr, 0u, 0u, lf);
     MANSY_LAUNCH_CHECK();
     return MANSY_OK;
   }
@@ -658,7 +697,8 @@ struct PEng {
     HeadBwdArgs hb;
     hb.h[0] = {g, MAXOUT, A1, H, n.out_w, n_out, dH, dA1, HID, n.gout_w, n.gout_b};
     hb.h[1] = hb.h[0];
-    hipLaunchKernelGGL(head_out_bwd_kernel, dim3(min(mansy_ceil_div(B, 2), 128), 1), dim3(256), 0, st, hb, B);
+    LossFinish nofin; memset(&nofin, 0, sizeof(nofin));
+    hipLaunchKernelGGL(head_out_bwd_kernel, dim3(min(mansy_ceil_div(B, 2), 128), 1), dim3(256), 0, st, hb, B, nofin);
     MANSY_LAUNCH_CHECK();
     GemmEpilogue acc; acc.accumulate = 1; acc.a_rowsum = n.gfc_b;                                           // gfc_b += column sums of dA1
     RC(mansy_launch_gemm_f32(dA1, HID, 1, W.F, FEAT, 1, n.gfc_w, FEAT, HID, FEAT, B, acc, 0, 0, st));      // gfc_w += dA1^T F
@@ -666,11 +706,13 @@ struct PEng {
     return mansy_launch_gemm_f32(dA1, HID, 0, n.fc_w, FEAT, 1, W.dF, FEAT, B, FEAT, HID, ep, 0, 0, st);    // dF (+)= dA1 Wfc
   }
   // both heads' backward: one output-layer launch, the two fc weight gradients, ONE dF = [dA1a | dA1c] [Wfc_a ; Wfc_c] product
-  int head_bwd_pair(const NetP& a, const NetP& c, int B) {
+  int head_bwd_pair(const NetP& a, const NetP& c, int B, const LossFinish* finish = nullptr) {
     HeadBwdArgs hb;
     hb.h[0] = {W.gout, MAXOUT, W.A1a, W.Ha, a.out_w, NACT, W.dHa, W.dA1p, 2 * HID, a.gout_w, a.gout_b};
     hb.h[1] = {W.gout_c, MAXOUT, W.A1c, W.Hc, c.out_w, 1, W.dHc, W.dA1p + HID, 2 * HID, c.gout_w, c.gout_b};
-    hipLaunchKernelGGL(head_out_bwd_kernel, dim3(min(mansy_ceil_div(B, 2), 128), 2), dim3(256), 0, st, hb, B);
+    LossFinish fin; memset(&fin, 0, sizeof(fin));
+    if (finish) fin = *finish;
+    hipLaunchKernelGGL(head_out_bwd_kernel, dim3(min(mansy_ceil_div(B, 2), 128), 2), dim3(256), 0, st, hb, B, fin);
     MANSY_LAUNCH_CHECK();
     GemmEpilogue acc; acc.accumulate = 1;           // gfc_w_{a,c} += dA1_{a,c}^T F, gfc_b_{a,c} += column sums: two products, one launch
     acc.a_rowsum = a.gfc_b;
@@ -864,16 +906,17 @@ int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, fl
   NetP a, c; bind_net(params, grads, 20, a); bind_net(params, grads, 24, c);
   // one prologue launch: re-pack the block-diagonal / stacked weights, gather the minibatch rows, zero the gradient buffer
   const float* obs = idx ? e.W.obs_mb : obs_all;
-  RC(e.pack(a, 0, &c, idx ? obs_all : nullptr, idx, mb, flat_g, n_flat));
+  // loss fused into the output-layer launches: advantage statistics ride on the prologue, per-row terms come out of head_out,
+  // their sums out of head_out_bwd (13 -> 12 launches per minibatch step)
+  RC(e.pack_mb(a, c, idx ? obs_all : nullptr, idx, mb, flat_g, n_flat, adv_all));
   RC(e.featnet(obs, mb, 0));
-  RC(e.head_pair(a, c, mb));
-  PPOLossArgs la;
-  la.logits = e.W.outa; la.value = e.W.outc; la.value_ld = MAXOUT; la.act = act_all; la.adv = adv_all; la.logp_old = logp_old_all; la.v_old = v_old_all;
-  la.ret = ret_all; la.idx = idx; la.n = mb; la.eps_clip = eps_clip; la.vf_coef = vf_coef; la.ent_coef = ent_coef; la.norm_adv = norm_adv;
-  la.value_clip = value_clip; la.adv_eps = 1e-8f; la.dlogits = e.W.gout; la.dvalue = e.W.gout_c; la.dvalue_ld = MAXOUT; la.stats = stats;
-  hipLaunchKernelGGL(ppo_loss_kernel, dim3(1), dim3(1024), 0, e.st, la);
-  MANSY_LAUNCH_CHECK();
-  RC(e.head_bwd_pair(a, c, mb));
+  LossFuse lf;
+  lf.on = 1; lf.act = act_all; lf.adv = adv_all; lf.logp_old = logp_old_all; lf.v_old = v_old_all; lf.ret = ret_all; lf.idx = idx; lf.n = mb;
+  lf.eps_clip = eps_clip; lf.vf_coef = vf_coef; lf.ent_coef = ent_coef; lf.norm_adv = norm_adv; lf.value_clip = value_clip; lf.adv_eps = 1e-8f;
+  lf.adv_stats = e.W.adv_stats; lf.dlogits = e.W.gout; lf.dvalue = e.W.gout_c; lf.dvalue_ld = MAXOUT; lf.lossrows = e.W.lossrows;
+  RC(e.head_pair(a, c, mb, &lf));
+  LossFinish fin; fin.lossrows = e.W.lossrows; fin.n = mb; fin.vf_coef = vf_coef; fin.ent_coef = ent_coef; fin.stats = stats;
+  RC(e.head_bwd_pair(a, c, mb, &fin));
   RC(e.featnet_bwd(a, obs, mb, 0, e.W.dHa, e.W.dHc));
   return e.clip_and_adam(flat_p, flat_g, flat_m, flat_v, n_flat, max_grad_norm, lr, weight_decay, step, tail_from, tail_step);
 }
