@@ -29,7 +29,7 @@ print(f'tilemap_iou   n={n}: {t*1e6:8.1f} us  {n * 24 / t / 1e9:7.1f} GB/s (16 B
 # trajectory gather: B windows of 21 samples from a [traces, 300, 2] table
 traces, L, B, S, T = 4096, 300, 1 << 18, 10, 10
 table = torch.rand(traces, L, 2, device='cuda')
-sel = torch.stack([torch.randint(0, traces, (B,), device='cuda'), torch.randint(0, L - S - T - 1, (B,), device='cuda')], 1).int().contiguous()
+sel = torch.stack([torch.randint(0, traces, (B,), device='cuda'), torch.randint(S, L - T, (B,), device="cuda")], 1).int().contiguous()
 hist, cur, fut = (torch.empty(B, k, 2, device='cuda') for k in (S, 1, T))
 t = timeit(lambda: check(lib().mansy_traj_gather(ptr(table), L, 2, ptr(sel), B, S, T, ptr(hist), ptr(cur), ptr(fut), stream_ptr(table.device)), 'gather'))
 print(f'traj_gather   B={B}: {t*1e6:8.1f} us  {B * (21 * 8 * 2 + 8) / t / 1e9:7.1f} GB/s (168 B read + 168 B written + 8 B index per window)')
