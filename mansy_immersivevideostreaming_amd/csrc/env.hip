@@ -102,6 +102,34 @@ __device__ __forceinline__ float seq_sum64(float x) {      // ((..(0 + x0) + x1)
   for (int t = 0; t < NTL; ++t) s = s + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), t));
   return s;
 }
+// The same sequential sum restricted to the lanes of `mask` (tile order).  Every skipped term must be +0.0f: s + 0.0f == s
+// bit for bit for the non-negative partial sums that occur here, so skipping them changes nothing -- a viewport covers
+// 9..20 of the 64 tiles, which makes the dependent-add chain 3-7x shorter.
+__device__ __forceinline__ float seq_sum_masked(float x, unsigned long long mask) {
+  float s = 0.f;
+  while (mask) {
+    const int t = __builtin_ctzll(mask);
+    s = s + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), t));
+    mask &= mask - 1;
+  }
+  return s;
+}
+// Quality sums over the ground-truth viewport gv (tile-order float32 sums of the reference, qoe.py:23-24 / simulator.py:156):
+// returns s_v = sum(gv), s_vq = sum(gv * tq); var_sum(...) then gives sum(gv * |tq - vq|).  For 0/1 maps with finite
+// non-negative qualities (the data format) only the viewport's tiles are visited; anything else takes the full 64-term chain.
+struct ViewportSums { float s_v, s_vq; unsigned long long mask; bool fast; };
+__device__ __forceinline__ ViewportSums viewport_sums(float gv, float tq) {
+  ViewportSums r;
+  r.mask = __ballot(gv != 0.f);
+  r.fast = r.mask != 0ull && __ballot(!(gv == 0.f || gv == 1.f) || !(tq >= 0.f && tq < 3.0e38f)) == 0ull;   // (empty viewport: NaN path, keep it literal)
+  if (r.fast) { r.s_v = (float)__popcll(r.mask); r.s_vq = seq_sum_masked(gv * tq, r.mask); }
+  else { r.s_vq = seq_sum64(gv * tq); r.s_v = seq_sum64(gv); }
+  return r;
+}
+__device__ __forceinline__ float var_sum(const ViewportSums& r, float gv, float tq, float vq) {
+  const float term = gv * fabsf(tq - vq);
+  return r.fast ? seq_sum_masked(term, r.mask) : seq_sum64(term);
+}
 
 __device__ __forceinline__ int wave_isum(int v) {
 #pragma unroll
@@ -109,15 +137,26 @@ __device__ __forceinline__ int wave_isum(int v) {
   return v;
 }
 
-__device__ __forceinline__ void write_obs(const mansy_env_tables& T, const EnvRegs& s, int chunk, int action, int lane, float* __restrict__ obs) {
-  const size_t mrow = ((size_t)s.video * T.n_chunk_max + chunk) * NR * NTL;
+// The table rows an observation shows (next chunk's sizes / qualities for all five versions, predicted viewport), loaded
+// separately from their use so that the step kernel can issue them before its dependent chain of simulator loads.
+struct ObsRows { int size[NR]; float quality[NR]; unsigned char pred; };
+__device__ __forceinline__ ObsRows load_obs_rows(const mansy_env_tables& T, int video, int vp, int chunk, int lane) {
+  ObsRows o;
+  const size_t mrow = ((size_t)video * T.n_chunk_max + chunk) * NR * NTL;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) { o.size[r] = T.size[mrow + r * NTL + lane]; o.quality[r] = T.quality[mrow + r * NTL + lane]; }
+  o.pred = T.vp_pred[((size_t)vp * T.n_vpchunk_max + (chunk - T.vp_start[vp])) * NTL + lane];
+  return o;
+}
+__device__ __forceinline__ void store_obs(const mansy_env_tables& T, const EnvRegs& s, const ObsRows& rows, int action, int lane,
+                                          float* __restrict__ obs) {
   const float inv_rate = (float)T.video_rates[NR - 1];
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
-    obs[MANSY_O_SIZE + r * NTL + lane] = (float)T.size[mrow + r * NTL + lane] / (float)T.max_size;
-    obs[MANSY_O_QUALITY + r * NTL + lane] = T.quality[mrow + r * NTL + lane] / inv_rate;
+    obs[MANSY_O_SIZE + r * NTL + lane] = (float)rows.size[r] / (float)T.max_size;
+    obs[MANSY_O_QUALITY + r * NTL + lane] = rows.quality[r] / inv_rate;
   }
-  obs[MANSY_O_PRED_VP + lane] = (float)T.vp_pred[((size_t)s.vp * T.n_vpchunk_max + (chunk - T.vp_start[s.vp])) * NTL + lane];
+  obs[MANSY_O_PRED_VP + lane] = (float)rows.pred;
   // the 68 scalar slots: 0..7 throughput | 712..743 acc,q,var,rebuf | 744 buffer | 745..747 qoe_w | 748..762 one-hot |
   // 763..778 rates in/out | 779 pad
   if (lane < PAST_K) {
@@ -134,6 +173,9 @@ __device__ __forceinline__ void write_obs(const mansy_env_tables& T, const EnvRe
   if (lane < 3) obs[MANSY_O_QOE_W + lane] = w[lane] / wsum;
   if (lane < N_ACTION) obs[MANSY_O_ACT_1HOT + lane] = (lane == action) ? 1.f : 0.f;
   if (lane == 0) { obs[MANSY_O_BUFFER] = s.buffer0 / (float)T.startup_download; obs[MANSY_OBS_DIM] = 0.f; }
+}
+__device__ __forceinline__ void write_obs(const mansy_env_tables& T, const EnvRegs& s, int chunk, int action, int lane, float* __restrict__ obs) {
+  store_obs(T, s, load_obs_rows(T, s.video, s.vp, chunk, lane), action, lane, obs);
 }
 
 __device__ __forceinline__ void do_reset(const mansy_env_tables& T, EnvRegs& s) {
@@ -192,6 +234,9 @@ __global__ __launch_bounds__(256) void env_step_kernel(mansy_env_tables T, EnvSt
   const int rin = (action >= 0 && action < N_ACTION) ? A2R[action][0] : 0;
   const int rout = (action >= 0 && action < N_ACTION) ? A2R[action][1] : 0;
   const int chunk = s.next_chunk;
+  // the observation after this step shows chunk + 1 (or, when the episode ends, this chunk again): known now, so its rows are
+  // requested first and arrive while the simulator's dependent loads below are in flight
+  const ObsRows rows_next = load_obs_rows(T, s.video, s.vp, (chunk + 1 > s.end_chunk) ? chunk : chunk + 1, lane);
   const size_t vrow = ((size_t)s.vp * T.n_vpchunk_max + (chunk - T.vp_start[s.vp])) * NTL;
   const bool in_pred = T.vp_pred[vrow + lane] == 1;
   const float gv = (float)T.vp_gt[vrow + lane];
@@ -229,9 +274,10 @@ __global__ __launch_bounds__(256) void env_step_kernel(mansy_env_tables T, EnvSt
   s.next_chunk += 1;
   const bool over = s.next_chunk > s.end_chunk;
   // ---- QoE (sequential float32 sums in tile order)
-  const float s_vq = seq_sum64(gv * tq), s_v = seq_sum64(gv);
-  float vq = s_vq / s_v;
-  const float s_var = seq_sum64(gv * fabsf(tq - vq));
+  const ViewportSums vs = viewport_sums(gv, tq);
+  const float s_v = vs.s_v;
+  float vq = vs.s_vq / s_v;
+  const float s_var = var_sum(vs, gv, tq, vq);
   const float max_rate = (float)rates.r4;
   const float intra = (s_var / s_v) / max_rate;
   vq = vq / max_rate;
@@ -253,7 +299,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(mansy_env_tables T, EnvSt
   roll_push(s.past_rebuf, (float)(rebuf / (double)T.startup_download));
   roll_push(s.past_var, qoe3);
   if (!over) s.last_chunk_accuracy = T.vp_acc[(size_t)s.vp * T.n_vpchunk_max + (s.next_chunk - T.vp_start[s.vp])];
-  write_obs(T, s, over ? chunk : s.next_chunk, action, lane, obs_next + (size_t)e * OBS_LD);
+  store_obs(T, s, rows_next, action, lane, obs_next + (size_t)e * OBS_LD);
   if (lane == 0) {
     reward[e] = rew;
     done[e] = over ? 1 : 0;
@@ -273,7 +319,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(mansy_env_tables T, EnvSt
       write_obs(T, s, s.next_chunk, -1, lane, obs_cur + (size_t)e * OBS_LD);
     }
   } else if (obs_cur && obs_cur != obs_next) {
-    write_obs(T, s, s.next_chunk, action, lane, obs_cur + (size_t)e * OBS_LD);
+    store_obs(T, s, rows_next, action, lane, obs_cur + (size_t)e * OBS_LD);
   }
   if (lane == 0) copy_state(st[e], s);
 }
@@ -339,9 +385,10 @@ __global__ __launch_bounds__(256) void expert_profile_kernel(mansy_env_tables T,
   const size_t mrow = ((size_t)video * T.n_chunk_max + chunk) * NR * NTL;
   const int chunk_size = wave_isum(T.size[mrow + ver * NTL + lane]);
   const float tq = T.quality[mrow + ver * NTL + lane];
-  const float s_vq = seq_sum64(gv * tq), s_v = seq_sum64(gv);
-  const float vq = s_vq / s_v;
-  const float s_var = seq_sum64(gv * fabsf(tq - vq));
+  const ViewportSums vs = viewport_sums(gv, tq);
+  const float s_v = vs.s_v;
+  const float vq = vs.s_vq / s_v;
+  const float s_var = var_sum(vs, gv, tq, vq);
   if (lane == 0) { out_q[o] = vq; out_v[o] = s_var / s_v; out_s[o] = chunk_size; }
 }
 
