@@ -236,10 +236,21 @@ __global__ __launch_bounds__(256) void env_step_kernel(mansy_env_tables T, EnvSt
   const int chunk = s.next_chunk;
   // the observation after this step shows chunk + 1 (or, when the episode ends, this chunk again): known now, so its rows are
   // requested first and arrive while the simulator's dependent loads below are in flight
-  const ObsRows rows_next = load_obs_rows(T, s.video, s.vp, (chunk + 1 > s.end_chunk) ? chunk : chunk + 1, lane);
+  const bool over_pre = chunk + 1 > s.end_chunk;
+  const ObsRows rows_next = load_obs_rows(T, s.video, s.vp, over_pre ? chunk : chunk + 1, lane);
+  // everything else that depends on the state alone is requested up front too: this chunk's five versions (the allocated version
+  // is selected from registers instead of a load that waits for the allocation), the preference weights, the trace bin the
+  // download starts in, the next chunk's prediction accuracy
+  const ObsRows rows_cur = load_obs_rows(T, s.video, s.vp, chunk, lane);
   const size_t vrow = ((size_t)s.vp * T.n_vpchunk_max + (chunk - T.vp_start[s.vp])) * NTL;
-  const bool in_pred = T.vp_pred[vrow + lane] == 1;
   const float gv = (float)T.vp_gt[vrow + lane];
+  const float* w = T.qoe_w + 3 * s.qoe;
+  const float w0 = w[0], w1 = w[1], w2 = w[2];
+  const double* bw = T.trace_bw + (size_t)s.trace * T.trace_len_max;
+  const int tlen = T.trace_len[s.trace];
+  double bwc = bw[s.cur_idx];                               // always bw[s.cur_idx]
+  const double acc_next = over_pre ? 0.0 : T.vp_acc[(size_t)s.vp * T.n_vpchunk_max + (chunk + 1 - T.vp_start[s.vp])];
+  const bool in_pred = rows_cur.pred == 1;
   // ---- pyramid tile-rate allocation
   unsigned long long m = __ballot(in_pred);
   int dist = ((m >> lane) & 1ull) ? 0 : -1;
@@ -254,18 +265,17 @@ __global__ __launch_bounds__(256) void env_step_kernel(mansy_env_tables T, EnvSt
   const Rates rates = load_rates(T);
   const int ver = dist == 0 ? rin : closest_rate_version(rates, pick_rate(rates, rout) / (dist > 0 ? dist : 1));
   // ---- Simulator.simulate_download
-  const size_t mrow = ((size_t)s.video * T.n_chunk_max + chunk) * NR * NTL;
-  const int chunk_size = wave_isum(T.size[mrow + ver * NTL + lane]);
-  const float tq = T.quality[mrow + ver * NTL + lane];
-  const double* bw = T.trace_bw + (size_t)s.trace * T.trace_len_max;
-  const int tlen = T.trace_len[s.trace];
+  int my_size = rows_cur.size[0]; float tq = rows_cur.quality[0];
+#pragma unroll
+  for (int r = 1; r < NR; ++r) { my_size = ver == r ? rows_cur.size[r] : my_size; tq = ver == r ? rows_cur.quality[r] : tq; }
+  const int chunk_size = wave_isum(my_size);
   const double start = s.cur_time;
   double size = (double)chunk_size;
   while (size > 0) {
     const double fl = floor(s.cur_time + 1);
-    const double remain = (fl - s.cur_time) * bw[s.cur_idx];
-    if (size >= remain) { s.cur_idx = (s.cur_idx + 1) % tlen; s.cur_time = fl; size -= remain; }
-    else { s.cur_time += size / bw[s.cur_idx]; size = 0; }
+    const double remain = (fl - s.cur_time) * bwc;
+    if (size >= remain) { s.cur_idx = (s.cur_idx + 1) % tlen; bwc = bw[s.cur_idx]; s.cur_time = fl; size -= remain; }
+    else { s.cur_time += size / bwc; size = 0; }
   }
   const double download_time = s.cur_time - start;
   double rebuf = 0.0;
@@ -283,10 +293,9 @@ __global__ __launch_bounds__(256) void env_step_kernel(mansy_env_tables T, EnvSt
   vq = vq / max_rate;
   const float inter = s.has_prev ? fabsf(vq - s.prev_vq) : 0.f;
   s.prev_vq = vq; s.has_prev = 1;
-  const float* w = T.qoe_w + 3 * s.qoe;
   const float qoe1 = vq, qoe3 = intra + inter;
-  const float qoe = w[0] * qoe1 - w[1] * (float)rebuf - w[2] * qoe3;
-  const float wsum = (w[0] + w[1]) + w[2];
+  const float qoe = w0 * qoe1 - w1 * (float)rebuf - w2 * qoe3;
+  const float wsum = (w0 + w1) + w2;
   const float rew = T.train_identifier_reward ? qoe / wsum : qoe;
   s.log_qoe += (double)qoe; s.log_qoe1 += (double)qoe1; s.log_qoe2 += rebuf; s.log_qoe3 += (double)qoe3; s.log_n += 1;
   // ---- history rings
@@ -298,7 +307,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(mansy_env_tables T, EnvSt
   roll_push(s.past_q, qoe1);
   roll_push(s.past_rebuf, (float)(rebuf / (double)T.startup_download));
   roll_push(s.past_var, qoe3);
-  if (!over) s.last_chunk_accuracy = T.vp_acc[(size_t)s.vp * T.n_vpchunk_max + (s.next_chunk - T.vp_start[s.vp])];
+  if (!over) s.last_chunk_accuracy = acc_next;
   store_obs(T, s, rows_next, action, lane, obs_next + (size_t)e * OBS_LD);
   if (lane == 0) {
     reward[e] = rew;
