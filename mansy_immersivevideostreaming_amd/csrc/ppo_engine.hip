@@ -26,6 +26,7 @@ constexpr int K_POLICY = 748, K_IDENT = 764;
 constexpr int KP = 768;                     // K of the packed block-diagonal image: padded to whole 32-wide K-tiles (LDS-DMA GEMM loop)
 static_assert(KP <= MANSY_OBS_LD && KP % 32 == 0 && KP >= 764, "packed K must cover both nets and stay inside an observation row");
 constexpr int RESID_COL = FEAT - HID;      // 10th branch output is the residual of every head
+constexpr int MAX_SLABS = 16;              // K splits of a head's fc product (head_split_request)
 
 struct Branch { int off, len; };
 __host__ __device__ inline Branch branch_geom(int j, int identifier) {
@@ -190,11 +191,28 @@ __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const f
   const int lane = threadIdx.x & 63;
   const int row = (blockIdx.x * 256 + threadIdx.x) >> 6;
   if (row >= rows) return;
+  // fused-loss operands (a gather through idx): requested first, ahead of this kernel's stores, so the two dependent round
+  // trips overlap the slab sums
+  int l_bi = 0, l_act = 0; float l_adv = 0.f, l_logp_old = 0.f, l_ret = 0.f, l_vold = 0.f, l_mean = 0.f, l_std = 1.f;
+  if (lf.on) {
+    l_bi = lf.idx ? lf.idx[row] : row;
+    if (blockIdx.y == 0) { l_adv = lf.adv[l_bi]; l_act = lf.act[l_bi]; l_logp_old = lf.logp_old[l_bi]; l_mean = lf.adv_stats[0]; l_std = lf.adv_stats[1]; }
+    else { l_ret = lf.ret[l_bi]; l_vold = lf.value_clip ? lf.v_old[l_bi] : 0.f; }
+  }
   float a0, a1;
   if (nsplit > 0) {
     a0 = d.fc_b[lane]; a1 = d.fc_b[64 + lane];
     const float* pre = A1pre + (size_t)row * pre_ld + d.pre_col;
-    for (int z = 0; z < nsplit; ++z) { a0 += pre[z * slab + lane]; a1 += pre[z * slab + 64 + lane]; }
+    // all slabs requested up front at clamped indices (a run-time trip count made hipcc wait for every pair of loads: up to 16
+    // dependent L2 round trips); summed in slab order
+    float p0[MAX_SLABS], p1[MAX_SLABS];
+#pragma unroll
+    for (int z = 0; z < MAX_SLABS; ++z) {
+      const long long zz = (long long)min(z, nsplit - 1) * slab;
+      p0[z] = pre[zz + lane]; p1[z] = pre[zz + 64 + lane];
+    }
+#pragma unroll
+    for (int z = 0; z < MAX_SLABS; ++z) { a0 = z < nsplit ? a0 + p0[z] : a0; a1 = z < nsplit ? a1 + p1[z] : a1; }
     a0 = a0 > 0.f ? a0 : a0 * SLOPE; a1 = a1 > 0.f ? a1 : a1 * SLOPE;
     A1[(size_t)row * HID + lane] = a0; A1[(size_t)row * HID + 64 + lane] = a1;
   } else {
@@ -223,9 +241,8 @@ __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const f
     out[(size_t)row * out_ld + lane] = mine;
   }
   if (lf.on && blockIdx.y == 0) {  // actor: clipped surrogate + entropy of this row, gradient wrt the logits (every lane computes the same scalars)
-    const int bi = lf.idx ? lf.idx[row] : row;
-    float adv = lf.adv[bi];
-    if (lf.norm_adv) adv = (adv - lf.adv_stats[0]) / (lf.adv_stats[1] + lf.adv_eps);
+    float adv = l_adv;
+    if (lf.norm_adv) adv = (adv - l_mean) / (l_std + lf.adv_eps);
     float m = -INFINITY;
 #pragma unroll
     for (int k = 0; k < NACT; ++k) m = fmaxf(m, o[k]);
@@ -233,12 +250,12 @@ __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const f
 #pragma unroll
     for (int k = 0; k < NACT; ++k) { e[k] = expf(o[k] - m); se += e[k]; }
     const float lse = logf(se);
-    const int a = lf.act[bi];
+    const int a = l_act;
     float lg_act = 0.f;
 #pragma unroll
     for (int k = 0; k < NACT; ++k) if (k == a) lg_act = o[k];
     const float lp_a = (lg_act - m) - lse;
-    const float ratio = expf(lp_a - lf.logp_old[bi]);
+    const float ratio = expf(lp_a - l_logp_old);
     const float surr1 = ratio * adv;
     const float rc = fminf(fmaxf(ratio, 1.f - lf.eps_clip), 1.f + lf.eps_clip);
     const float surr2 = rc * adv;
@@ -261,11 +278,10 @@ __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const f
     if (lane == 0) { lf.lossrows[4 * (size_t)row + 0] = -fminf(surr1, surr2); lf.lossrows[4 * (size_t)row + 2] = ent; }
   }
   if (lf.on && blockIdx.y == 1 && lane == 0) {   // critic: (clipped) value loss of this row and its gradient
-    const int bi = lf.idx ? lf.idx[row] : row;
-    const float v = o[0], ret = lf.ret[bi];
+    const float v = o[0], ret = l_ret;
     float dv, lv;
     if (lf.value_clip) {
-      const float vo = lf.v_old[bi];
+      const float vo = l_vold;
       const float diff = v - vo;
       const float vc = vo + fminf(fmaxf(diff, -lf.eps_clip), lf.eps_clip);
       const float vf1 = (ret - v) * (ret - v), vf2 = (ret - vc) * (ret - vc);
@@ -661,6 +677,7 @@ struct PEng {
     int nsplit = 0;
     if (req > 1) {
       nsplit = mansy_gemm_effective_splits(FEAT, req);
+      MANSY_REQUIRE(nsplit <= MAX_SLABS, "head: %d K splits exceed the slab sum's unroll", nsplit);
       GemmEpilogue ep; ep.split_slab = (long long)B * HID;
       RC(mansy_launch_gemm_f32(W.F, FEAT, 0, n.fc_w, FEAT, 0, W.A1s, HID, B, HID, FEAT, ep, 0, req, st));
     } else {
@@ -680,6 +697,7 @@ struct PEng {
   int head_pair(const NetP& a, const NetP& c, int B, const LossFuse* fuse = nullptr) {
     const int req = head_split_request(B, 2 * HID);
     const int nsplit = mansy_gemm_effective_splits(FEAT, req);
+    MANSY_REQUIRE(nsplit <= MAX_SLABS, "head_pair: %d K splits exceed the slab sum's unroll", nsplit);
     GemmEpilogue ep; ep.split_slab = (long long)B * 2 * HID;
     RC(mansy_launch_gemm_f32(W.F, FEAT, 0, W.Wfc2, FEAT, 0, W.A1s, 2 * HID, B, 2 * HID, FEAT, ep, 0, req, st));
     HeadOutArgs ha;
