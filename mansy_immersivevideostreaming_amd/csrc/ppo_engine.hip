@@ -26,6 +26,7 @@ constexpr int K_POLICY = 748, K_IDENT = 764;
 constexpr int KP = 768;                     // K of the packed block-diagonal image: padded to whole 32-wide K-tiles (LDS-DMA GEMM loop)
 static_assert(KP <= MANSY_OBS_LD && KP % 32 == 0 && KP >= 764, "packed K must cover both nets and stay inside an observation row");
 constexpr int RESID_COL = FEAT - HID;      // 10th branch output is the residual of every head
+constexpr int HB_BLOCKS = 64;               // workgroups of the output-layer backward (each ends with n_out x 128 global atomics)
 constexpr int MAX_SLABS = 16;              // K splits of a head's fc product (head_split_request)
 
 struct Branch { int off, len; };
@@ -730,7 +731,7 @@ struct PEng {
     hb.h[1] = {W.gout_c, MAXOUT, W.A1c, W.Hc, c.out_w, 1, W.dHc, W.dA1p + HID, 2 * HID, c.gout_w, c.gout_b};
     LossFinish fin; memset(&fin, 0, sizeof(fin));
     if (finish) fin = *finish;
-    hipLaunchKernelGGL(head_out_bwd_kernel, dim3(min(mansy_ceil_div(B, 2), 128), 2), dim3(256), 0, st, hb, B, fin);
+    hipLaunchKernelGGL(head_out_bwd_kernel, dim3(min(mansy_ceil_div(B, 2), HB_BLOCKS), 2), dim3(256), 0, st, hb, B, fin);
     MANSY_LAUNCH_CHECK();
     GemmEpilogue acc; acc.accumulate = 1;           // gfc_w_{a,c} += dA1_{a,c}^T F, gfc_b_{a,c} += column sums: two products, one launch
     acc.a_rowsum = a.gfc_b;
