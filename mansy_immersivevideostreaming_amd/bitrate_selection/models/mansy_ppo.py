@@ -163,6 +163,9 @@ class LazyLosses(Mapping):
     def __iter__(self):
         return iter(self._names)
 
+    def __contains__(self, k):
+        return k in self._names
+
     def __len__(self):
         return len(self._names)
 
