@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(mansy_env_tables T, EnvSt
   while (size > 0) {
     const double fl = floor(s.cur_time + 1);
     const double remain = (fl - s.cur_time) * bwc;
-    if (size >= remain) { s.cur_idx = (s.cur_idx + 1) % tlen; bwc = bw[s.cur_idx]; s.cur_time = fl; size -= remain; }
+    if (size >= remain) { s.cur_idx = s.cur_idx + 1 == tlen ? 0 : s.cur_idx + 1; bwc = bw[s.cur_idx]; s.cur_time = fl; size -= remain; }
     else { s.cur_time += size / bwc; size = 0; }
   }
   const double download_time = s.cur_time - start;
@@ -423,7 +423,7 @@ __device__ __forceinline__ void plan_step(PlanState& ps, const double* __restric
   while (size > 0) {
     const double fl = floor(ps.cur_time + 1);
     const double remain = (fl - ps.cur_time) * bw[ps.cur_idx];
-    if (size >= remain) { ps.cur_idx = (ps.cur_idx + 1) % tlen; ps.cur_time = fl; size -= remain; }
+    if (size >= remain) { ps.cur_idx = ps.cur_idx + 1 == tlen ? 0 : ps.cur_idx + 1; ps.cur_time = fl; size -= remain; }
     else { ps.cur_time += size / bw[ps.cur_idx]; size = 0; }
   }
   const double download_time = ps.cur_time - start;
