@@ -26,6 +26,7 @@ constexpr int K_POLICY = 748, K_IDENT = 764;
 constexpr int KP = 768;                     // K of the packed block-diagonal image: padded to whole 32-wide K-tiles (LDS-DMA GEMM loop)
 static_assert(KP <= MANSY_OBS_LD && KP % 32 == 0 && KP >= 764, "packed K must cover both nets and stay inside an observation row");
 constexpr int RESID_COL = FEAT - HID;      // 10th branch output is the residual of every head
+constexpr int NORM_PARTS_C = MANSY_CLIP_SCRATCH_DOUBLES;   // gradient-norm partial sums
 constexpr int HB_BLOCKS = 64;               // workgroups of the output-layer backward (each ends with n_out x 128 global atomics)
 constexpr int MAX_SLABS = 16;              // K splits of a head's fc product (head_split_request)
 
@@ -150,15 +151,41 @@ __global__ __launch_bounds__(256) void pack_wbd_kernel(PackArgs a, int identifie
 // packed gradients -> the compact reference-layout parameter gradients: block-diagonal entries of dWbd [FEAT, K] and the
 // packed bias gradient dbbd [FEAT] (first FEAT threads) are added to the ten branches' weight / bias gradients.
 struct UnpackArgs { float* gbw[NB]; float* gbb[NB]; };
+// Optional rider (PPO minibatch step with clipping): the squared gradient norm.  The branch gradients are exactly the values
+// this kernel writes (the buffers were zeroed by the prologue), the head gradients [tail_g, tail_g + tail_n) were completed by
+// earlier launches and are scanned by extra workgroups at the end of the grid; per-workgroup sums are added into the
+// NORM_PARTS slots that clip_adam_kernel adds up (zeroed by featgrad_finish_kernel).
+struct NormRider { double* parts; const float* tail_g; long long tail_n; };
 __global__ __launch_bounds__(256) void unpack_dwbd_kernel(const float* __restrict__ dWbd, const float* __restrict__ dbbd, int identifier, int K,
-                                                          UnpackArgs a) {
+                                                          UnpackArgs a, NormRider nr) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx < FEAT) a.gbb[idx / HID][idx % HID] += dbbd[idx];
-  if (idx >= (long long)FEAT * K) return;
-  const int col = (int)(idx % K), row = (int)(idx / K);
-  const int j = row / HID, r = row % HID;
-  const Branch g = branch_geom(j, identifier);
-  if (col >= g.off && col < g.off + g.len) a.gbw[j][r * g.len + (col - g.off)] += dWbd[idx];
+  const long long n_main = (long long)FEAT * K;
+  double sq = 0.0;
+  if (idx < FEAT) { const float b = dbbd[idx]; a.gbb[idx / HID][idx % HID] += b; sq += (double)b * (double)b; }
+  if (idx < n_main) {
+    const int col = (int)(idx % K), row = (int)(idx / K);
+    const int j = row / HID, r = row % HID;
+    const Branch g = branch_geom(j, identifier);
+    if (col >= g.off && col < g.off + g.len) { const float v = dWbd[idx]; a.gbw[j][r * g.len + (col - g.off)] += v; sq += (double)v * (double)v; }
+  } else if (nr.parts) {
+    const long long t4 = (idx - (n_main + 255) / 256 * 256) * 4;          // tail workgroups start on a workgroup boundary
+    if (t4 >= 0 && t4 + 4 <= nr.tail_n) {
+      const float4 v = *reinterpret_cast<const float4*>(nr.tail_g + t4);
+      sq += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+    } else if (t4 >= 0) {
+      for (long long e = t4; e < nr.tail_n; ++e) sq += (double)nr.tail_g[e] * (double)nr.tail_g[e];
+    }
+  }
+  if (!nr.parts) return;
+  __shared__ double red[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double t = (red[0] + red[1]) + (red[2] + red[3]);
+    if (t != 0.0) atomicAdd(nr.parts + (blockIdx.x % NORM_PARTS_C), t);
+  }
 }
 
 // one wave per (row, head): H = A1 + F[:, resid] ; out[k] = H . Wout[k] + b[k] (k < n_out <= 16), optional sigmoid;
@@ -385,9 +412,11 @@ __global__ __launch_bounds__(256) void head_out_bwd_kernel(HeadBwdArgs args, int
 
 // dPre = (dF + [residual grads in the last 128 columns]) * leaky'(F)
 __global__ __launch_bounds__(256) void featgrad_finish_kernel(float* __restrict__ dF, const float* __restrict__ dH_a, const float* __restrict__ dH_b,
-                                                              const float* __restrict__ F, long long n, float* __restrict__ dbbd_zero) {
+                                                              const float* __restrict__ F, long long n, float* __restrict__ dbbd_zero,
+                                                              double* __restrict__ parts_zero) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx < FEAT) dbbd_zero[idx] = 0.f;        // the dWbd product that follows accumulates the packed bias gradient here
+  if (parts_zero && idx < NORM_PARTS_C) parts_zero[idx] = 0.0;      // squared-norm slots of the unpack kernel's rider
   if (idx >= n) return;
   const int col = (int)(idx % FEAT);
   const long long row = idx / FEAT;
@@ -740,14 +769,20 @@ struct PEng {
     GemmEpilogue ep;
     return mansy_launch_gemm_f32(W.dA1p, 2 * HID, 0, W.Wfc2, FEAT, 1, W.dF, FEAT, B, FEAT, 2 * HID, ep, 0, 0, st);
   }
-  int featnet_bwd(const NetP& n, const float* obs, int B, int identifier, const float* dHa, const float* dHb) {
+  // norm_tail != nullptr: also leave the squared norm of ALL gradients (branches + [norm_tail, norm_tail + norm_tail_n)) in W.acc
+  int featnet_bwd(const NetP& n, const float* obs, int B, int identifier, const float* dHa, const float* dHb, const float* norm_tail = nullptr,
+                  long long norm_tail_n = 0) {
     const int K = identifier ? K_IDENT : K_POLICY;
     hipLaunchKernelGGL(featgrad_finish_kernel, dim3(mansy_ceil_div((long long)B * FEAT, 256)), dim3(256), 0, st, W.dF, dHa, dHb, W.F, (long long)B * FEAT,
-                       W.dbbd);
+                       W.dbbd, norm_tail ? W.acc : nullptr);
     GemmEpilogue ep; ep.a_rowsum = W.dbbd;                                                                   // dbbd = column sums of dPre
     RC(mansy_launch_gemm_f32(W.dF, FEAT, 1, obs, OBS_LD, 1, W.dWbd, K, FEAT, K, B, ep, 0, 1, st));           // dWbd = dPre^T obs
     UnpackArgs u; for (int j = 0; j < NB; ++j) { u.gbw[j] = n.gbw[j]; u.gbb[j] = n.gbb[j]; }
-    hipLaunchKernelGGL(unpack_dwbd_kernel, dim3(mansy_ceil_div((long long)FEAT * K, 256)), dim3(256), 0, st, W.dWbd, W.dbbd, identifier, K, u);
+    NormRider nr; nr.parts = norm_tail ? W.acc : nullptr; nr.tail_g = norm_tail; nr.tail_n = norm_tail_n;
+    const long long main_blocks = mansy_ceil_div((long long)FEAT * K, 256);
+    const long long tail_blocks = norm_tail ? mansy_ceil_div(mansy_ceil_div(norm_tail_n, 4), 256) : 0;
+    MANSY_REQUIRE(!norm_tail || (reinterpret_cast<uintptr_t>(norm_tail) & 15) == 0, "featnet_bwd: gradient tail must be 16-byte aligned");
+    hipLaunchKernelGGL(unpack_dwbd_kernel, dim3(main_blocks + tail_blocks), dim3(256), 0, st, W.dWbd, W.dbbd, identifier, K, u, nr);
     MANSY_LAUNCH_CHECK();
     return MANSY_OK;
   }
@@ -755,9 +790,9 @@ struct PEng {
   // their first gradient later than the rest: torch keeps one step counter per parameter); tail_step <= 0 never happens
   // with gradients present, so it is rejected.  The clip coefficient is the global one for both ranges.
   int clip_and_adam(float* flat_p, float* flat_g, float* m, float* v, long long n, float max_norm, float lr, float wd, int step,
-                    long long tail_from = -1, int tail_step = 0) {
+                    long long tail_from = -1, int tail_step = 0, bool have_sumsq = false) {
     if (max_norm > 0.f) {
-      hipLaunchKernelGGL(sumsq_kernel, dim3(NORM_PARTS), dim3(256), 0, st, flat_g, n, W.acc);
+      if (!have_sumsq) hipLaunchKernelGGL(sumsq_kernel, dim3(NORM_PARTS), dim3(256), 0, st, flat_g, n, W.acc);
       if (step <= 0) hipLaunchKernelGGL(clip_scale_kernel, dim3(256), dim3(256), 0, st, flat_g, n, W.acc, max_norm);   // parity tests: clipped gradients
       MANSY_LAUNCH_CHECK();
     }
@@ -936,8 +971,14 @@ int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, fl
   RC(e.head_pair(a, c, mb, &lf));
   LossFinish fin; fin.lossrows = e.W.lossrows; fin.n = mb; fin.vf_coef = vf_coef; fin.ent_coef = ent_coef; fin.stats = stats;
   RC(e.head_bwd_pair(a, c, mb, &fin));
-  RC(e.featnet_bwd(a, obs, mb, 0, e.W.dHa, e.W.dHc));
-  return e.clip_and_adam(flat_p, flat_g, flat_m, flat_v, n_flat, max_grad_norm, lr, weight_decay, step, tail_from, tail_step);
+  // squared gradient norm as a rider on the last gradient-writing launch (12 -> 11 launches): the head gradients are the
+  // contiguous tail of the flat buffer, starting at actor.fc.0.weight
+  const bool ride = max_grad_norm > 0.f && step > 0;
+  const float* tail = grads[2 * NB];
+  const long long tail_n = (flat_g + n_flat) - tail;
+  MANSY_REQUIRE(!ride || (tail >= flat_g && tail_n > 0 && tail_n <= n_flat), "ppo_minibatch_step: grads[] must point into flat_g");
+  RC(e.featnet_bwd(a, obs, mb, 0, e.W.dHa, e.W.dHc, ride ? tail : nullptr, ride ? tail_n : 0));
+  return e.clip_and_adam(flat_p, flat_g, flat_m, flat_v, n_flat, max_grad_norm, lr, weight_decay, step, tail_from, tail_step, ride);
 }
 
 // Behaviour-cloning step (utils/mansy_utils.py:52-69): loss = CrossEntropy(actor logits, expert action) - ent_coef * mean
