@@ -182,6 +182,13 @@ size_t mansy_ppo_workspace_bytes(int max_batch);
 int mansy_policy_forward(const float* const* params, const float* obs, int B, float* logits, float* value, int* act, float* logp,
                          const float* u, uint32_t seed, uint32_t site, int reuse_packed /* 1: parameters unchanged since the
                          previous policy call on this workspace */, void* workspace, int max_batch, void* stream);
+/* One rollout step as ONE call and one launch fewer: mansy_policy_forward (actor only, sampling on) for the n_env observation rows,
+ * then mansy_env_step of every environment with the action just drawn, inside the same output-layer launch (the wave that sampled
+ * row e goes on to step environment e).  Same outputs as the two calls. */
+int mansy_policy_env_step(const float* const* params, const float* obs, int n_env, float* logits, int* act, float* logp, const float* u,
+                          uint32_t seed, uint32_t site, int reuse_packed, void* workspace, int max_batch, const mansy_env_tables* T,
+                          void* env_state, float* obs_next, float* obs_cur, float* reward, unsigned char* done, float* qoe_parts,
+                          const mansy_env_episode_log* elog, void* stream);
 int mansy_policy_evaluate(const float* const* params, const float* obs, int B, const int* act, float* logp, float* value,
                           void* workspace, int max_batch, void* stream);
 int mansy_identifier_forward(const float* const* params, const float* obs, int B, float* pred /* [B,16], 3 used */, void* workspace,

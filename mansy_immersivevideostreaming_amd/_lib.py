@@ -91,6 +91,7 @@ _PROTOS = {
     'mansy_net_param_info': [c_int, c_int, ctypes.c_char_p, c_int, P, P, P],
     'mansy_ppo_workspace_bytes': [c_int],
     'mansy_policy_forward': [P, P, c_int, P, P, P, P, P, c_u32, c_u32, c_int, P, c_int, P],
+    'mansy_policy_env_step': [P, P, c_int, P, P, P, P, c_u32, c_u32, c_int, P, c_int, P, P, P, P, P, P, P, P, P],
     'mansy_policy_evaluate': [P, P, c_int, P, P, P, P, c_int, P],
     'mansy_identifier_forward': [P, P, c_int, P, P, c_int, P],
     'mansy_identifier_train_step': [P, P, P, P, P, P, c_ll, P, c_int, c_float, c_float, c_int, P, P, c_int, P],

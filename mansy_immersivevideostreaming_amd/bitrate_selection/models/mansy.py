@@ -306,6 +306,19 @@ class NetEngine:
             return logits[:, :15], value, act, logp
         return logits[:, :15], value
 
+    def policy_env_step(self, venv, obs, u, act, logp, obs_out, obs_next_out, reward_out, done_out, reuse_packed=False, seed=0, site=0):
+        """One rollout step in one engine call: sample actions for the observation rows `obs` [N, 780] (N = venv.n_env) and step
+        every environment with its action inside the same launch (`mansy_policy_env_step`).  Writes act / logp, the post-action
+        observations (obs_next_out), the next policy input with auto-reset applied (obs_out), rewards and done flags."""
+        import ctypes
+        N, dev = venv.n_env, obs.device
+        if obs.shape[0] != N or N > self.max_batch:
+            raise MansyError(f'policy_env_step: {obs.shape[0]} observation rows for {N} environments (max_batch {self.max_batch})')
+        arr, _ = self.ac.pointers()
+        check(lib().mansy_policy_env_step(arr, ptr(obs), N, None, ptr(act), ptr(logp), ptr(u), seed, site, int(reuse_packed), ptr(self.workspace()),
+                                          self.max_batch, ctypes.byref(venv.tables.c), ptr(venv.state), ptr(obs_next_out), ptr(obs_out), ptr(reward_out),
+                                          ptr(done_out), ptr(venv.qoe_parts), ctypes.byref(venv._elog), stream_ptr(dev)), 'mansy_policy_env_step')
+
     def identifier_forward(self, obs):
         B, dev = obs.shape[0], obs.device
         outs = []

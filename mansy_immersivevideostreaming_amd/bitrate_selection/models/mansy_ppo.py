@@ -44,9 +44,10 @@ class RolloutBuffer:
 
 class VecCollector:
     """Collector counterpart: steps N device environments with the policy, filling a RolloutBuffer.  A collect of T vector
-    steps is 1 + 5 T kernel launches with no host round trip (pack once; per step: FeatureNet GEMM, head GEMM, fused
-    output-layer + Categorical sampling, env step writing observation / reward / done straight into the slabs); the whole
-    sequence is captured once into a hipGraph and replayed (sampling uniforms are drawn before each replay)."""
+    steps is 1 + 3 T kernel launches with no host round trip (pack once; per step: FeatureNet GEMM, head GEMM, and ONE launch
+    that forms the logits, samples the action and steps the environment with it, writing observation / reward / done
+    straight into the slabs); the whole sequence is captured once into a hipGraph and replayed (sampling uniforms are drawn
+    before each replay)."""
 
     def __init__(self, policy, venv, seed=0, use_graph=True):
         self.policy, self.venv = policy, venv
@@ -70,12 +71,10 @@ class VecCollector:
     def _body(self, buffer, T):
         eng = self.policy.engine
         buffer.obs[0].copy_(self.carry)
-        for t in range(T):
-            eng._policy_forward(buffer.obs[t], False, True, self._u[t], 0, 0, out={'logits': self._logits, 'act': buffer.act[t], 'logp': buffer.logp[t]},
-                                reuse_packed=t > 0)
+        for t in range(T):              # policy forward + sampling + environment step: 3 launches per vector step (4 unfused)
             nxt = buffer.obs[t + 1] if t + 1 < T else self.carry
-            self.venv.step(buffer.act[t], auto_reset=True, obs_out=nxt, obs_next_out=buffer.obs_next[t], reward_out=buffer.rew[t],
-                           done_out=buffer.done[t])
+            eng.policy_env_step(self.venv, buffer.obs[t], self._u[t], buffer.act[t], buffer.logp[t], nxt, buffer.obs_next[t], buffer.rew[t],
+                                buffer.done[t], reuse_packed=t > 0)
 
     def collect(self, n_step, buffer):
         """n_step environment steps in total (n_step / N per environment); returns {'n/st': ..}."""

@@ -20,6 +20,14 @@
 
 namespace {
 
+// the streaming environment's device code (bit-exact double / sequential-float arithmetic: contraction off), for the fused
+// policy + environment rollout launch
+namespace envdev {
+#pragma clang fp contract(off)
+#include "env_device.h"
+#pragma clang fp contract(fast)
+}  // namespace envdev
+
 constexpr int HID = 128, NB = 10, FEAT = HID * NB, OBS_LD = MANSY_OBS_LD, NACT = 15, MAXOUT = 16;
 constexpr float SLOPE = 0.01f;
 constexpr int K_POLICY = 748, K_IDENT = 764;
@@ -208,10 +216,16 @@ struct LossFuse {
   int n; float eps_clip, vf_coef, ent_coef; int norm_adv, value_clip; float adv_eps;
   const float* adv_stats; float* dlogits; float* dvalue; int dvalue_ld; float* lossrows;
 };
+// Rollout fusion: the wave that sampled row e's action goes on to step environment e (lane = tile) in the same launch --
+// MANSYEnv.step with the action it just drew; the observation rows it writes are the next policy input.
+struct EnvFuse {
+  int on; mansy_env_tables T; envdev::EnvState* st; float* obs_next; float* obs_cur; float* reward; unsigned char* done; float* qoe_parts;
+  mansy_env_episode_log elog;
+};
 struct HeadOutArgs { HeadOut h[2]; };
 __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const float* __restrict__ A1pre, int nsplit, long long slab, int pre_ld,
                                                        const float* __restrict__ F, int out_ld, int rows, const float* __restrict__ u_ext,
-                                                       uint32_t seed, uint32_t site, LossFuse lf) {
+                                                       uint32_t seed, uint32_t site, LossFuse lf, EnvFuse ef) {
   const HeadOut& d = args.h[blockIdx.y];
   float* __restrict__ A1 = d.A1; const float* __restrict__ Wout = d.Wout; const float* __restrict__ bout = d.bout;
   float* __restrict__ H = d.H; float* __restrict__ out = d.out; int* __restrict__ act = d.act; float* __restrict__ logp = d.logp;
@@ -339,6 +353,7 @@ __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const f
       for (int k = 0; k < MAXOUT; ++k) if (k == a) oa = o[k];
       if (logp) logp[row] = (oa - m) - logf(s);
     }
+    if (ef.on) envdev::env_step_wave(ef.T, ef.st, row, lane, a, ef.obs_next, ef.obs_cur, ef.reward, ef.done, ef.qoe_parts, ef.elog);
   }
 }
 
@@ -702,7 +717,7 @@ struct PEng {
     return mansy_launch_gemm_f32(obs, OBS_LD, 0, W.Wbd, KP, 0, W.F, FEAT, B, FEAT, KP, ep, 0, 0, st);
   }
   int head(const NetP& n, int B, int n_out, int sigmoid, float* A1, float* H, float* out, const float* u, uint32_t seed, uint32_t site, int* act,
-           float* logp) {
+           float* logp, const EnvFuse* env = nullptr) {
     const int req = head_split_request(B);
     int nsplit = 0;
     if (req > 1) {
@@ -718,8 +733,10 @@ struct PEng {
     ha.h[0] = {A1, n.fc_b, n.out_w, n.out_b, n_out, sigmoid, H, out, 0, act, logp};
     ha.h[1] = ha.h[0];
     LossFuse none; memset(&none, 0, sizeof(none));
+    EnvFuse ef; memset(&ef, 0, sizeof(ef));
+    if (env) ef = *env;
     hipLaunchKernelGGL(head_out_kernel, dim3(mansy_ceil_div(B, 4), 1), dim3(256), 0, st, ha, W.A1s, nsplit, (long long)B * HID, HID, W.F, MAXOUT, B, u,
-                       seed, site, none);
+                       seed, site, none, ef);
     MANSY_LAUNCH_CHECK();
     return MANSY_OK;
   }
@@ -735,8 +752,9 @@ struct PEng {
     ha.h[1] = {W.A1c, c.fc_b, c.out_w, c.out_b, 1, 0, W.Hc, W.outc, HID, nullptr, nullptr};
     LossFuse lf; memset(&lf, 0, sizeof(lf));
     if (fuse) lf = *fuse;
+    EnvFuse noenv; memset(&noenv, 0, sizeof(noenv));
     hipLaunchKernelGGL(head_out_kernel, dim3(mansy_ceil_div(B, 4), 2), dim3(256), 0, st, ha, W.A1s, nsplit, (long long)B * 2 * HID, 2 * HID, W.F, MAXOUT,
-                       B, nullptr, 0u, 0u, lf);
+                       B, nullptr, 0u, 0u, lf, noenv);
     MANSY_LAUNCH_CHECK();
     return MANSY_OK;
   }
@@ -855,6 +873,27 @@ int mansy_policy_forward(const float* const* params, const float* obs, int B, fl
     MANSY_HIP_CHECK(hipMemcpy2DAsync(value, sizeof(float), e.W.outc, sizeof(float) * MAXOUT, sizeof(float), B, hipMemcpyDeviceToDevice, e.st));
   }
   return MANSY_OK;
+}
+
+// Rollout step as one call: policy forward + Categorical sample for the B = n_env observation rows, then (inside the same
+// output-layer launch) the environment step of every environment with the action just drawn.
+int mansy_policy_env_step(const float* const* params, const float* obs, int n_env, float* logits, int* act, float* logp, const float* u,
+                          uint32_t seed, uint32_t site, int reuse_packed, void* workspace, int max_batch, const mansy_env_tables* T, void* env_state,
+                          float* obs_next, float* obs_cur, float* reward, unsigned char* done, float* qoe_parts, const mansy_env_episode_log* elog,
+                          void* stream) {
+  MANSY_REQUIRE(params && obs && act && n_env >= 1 && n_env <= max_batch, "policy_env_step: bad arguments (n_env=%d, max_batch=%d)", n_env, max_batch);
+  MANSY_REQUIRE(T && env_state && obs_next && reward && done, "policy_env_step: null environment pointer");
+  MANSY_REQUIRE(T->size && T->quality && T->video_len && T->vp_gt && T->vp_pred && T->vp_acc && T->vp_start && T->vp_end && T->trace_bw &&
+                    T->trace_len && T->samples && T->qoe_w && T->n_sample >= 1, "policy_env_step: incomplete tables");
+  PEng e; RC(setup(workspace, max_batch, (hipStream_t)stream, e));
+  NetP a; bind_net(params, nullptr, 20, a);
+  if (!reuse_packed) RC(e.pack(a, 0));
+  RC(e.featnet(obs, n_env, 0));
+  EnvFuse ef; memset(&ef, 0, sizeof(ef));
+  ef.on = 1; ef.T = *T; ef.st = (envdev::EnvState*)env_state; ef.obs_next = obs_next; ef.obs_cur = obs_cur; ef.reward = reward; ef.done = done;
+  ef.qoe_parts = qoe_parts;
+  if (elog) ef.elog = *elog;
+  return e.head(a, n_env, NACT, 0, e.W.A1a, e.W.Ha, logits ? logits : e.W.outa, u, seed, site, act, logp, &ef);
 }
 
 int mansy_identifier_forward(const float* const* params, const float* obs, int B, float* pred, void* workspace, int max_batch, void* stream) {

@@ -340,3 +340,35 @@ def test_behaviour_cloning_steps_then_ppo_with_per_parameter_adam_steps(M):
     k = names.index('critic.out.weight')
     moved = (f.params[k].detach().cpu() - sd['critic.out.weight']).abs().max().item()
     assert moved > 1e-3            # first Adam steps of a fresh parameter are ~lr each
+
+
+def test_fused_rollout_step_equals_policy_forward_plus_env_step(M):
+    """mansy_policy_env_step (sampling + environment step in the output-layer launch) against the two separate calls on the
+    same observations and uniforms, through episode ends: actions, log-probs, observations, rewards, done flags bit-identical."""
+    sd = po.make_policy_state_dict(int(Z['wseed']))
+    pol = build_policy(M, sd)
+    eng = pol.engine
+    T = M.env.EnvTables.synthetic('cuda', n_video=5, n_user=4, n_trace=6, n_chunk=60, seed=3, n_sample=37, train_identifier_reward=True)
+    N = 192
+    va, vb = M.env.MANSYVecEnv(T, N, seed=4), M.env.MANSYVecEnv(T, N, seed=4)
+    oa, ob = va.reset().clone(), vb.reset().clone()
+    assert torch.equal(oa, ob)
+    g = torch.Generator(device='cuda').manual_seed(1)
+    f32 = dict(dtype=torch.float32, device='cuda')
+    act_b, logp_b = torch.empty(N, dtype=torch.int32, device='cuda'), torch.empty(N, **f32)
+    nxt_b, on_b, rew_b = torch.empty(N, 780, **f32), torch.empty(N, 780, **f32), torch.empty(N, **f32)
+    done_b = torch.empty(N, dtype=torch.uint8, device='cuda')
+    n_done = 0
+    for t in range(70):
+        u = torch.rand(N, generator=g, **f32)
+        _, _, act_a, logp_a = eng.policy_forward(oa, want_value=False, sample=True, u=u)
+        cur_a, rew_a, done_a, _ = va.step(act_a)
+        eng.policy_env_step(vb, ob, u, act_b, logp_b, nxt_b, on_b, rew_b, done_b, reuse_packed=t > 0)
+        assert torch.equal(act_a, act_b) and torch.equal(logp_a, logp_b), t
+        assert torch.equal(rew_a, rew_b) and torch.equal(done_a, done_b), t
+        assert torch.equal(va.obs_next, on_b) and torch.equal(cur_a, nxt_b), t
+        assert torch.equal(va.state, vb.state), t
+        n_done += int(done_a.sum())
+        oa, ob = cur_a.clone(), nxt_b.clone()
+    assert n_done >= N
+    np.testing.assert_array_equal(va.pop_episode_log()[:, [0, 2, 7]].sum(0), vb.pop_episode_log()[:, [0, 2, 7]].sum(0))
