@@ -346,7 +346,12 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmParams p) {
 // One DMA wave-instruction writes 64 lanes x 16 B = 1 KiB of LDS *contiguously* (wave-uniform base in M0 + lane*16); only
 // the global source address is per lane.  LDS images are therefore unpadded:
 //   K-contiguous operand -> [R][32]: 128-B rows, 8 rows per instruction.  Bank conflicts of the ds_read_b128 fragment reads
-//                           are avoided by an XOR swizzle applied on the SOURCE side: slot c' of row holds k-chunk c' ^ (row & 7).
+//                           are avoided by an XOR swizzle applied on the SOURCE side: slot c' of row holds k-chunk
+//                           c' ^ ((row >> 1) & 7).  (A ds_read_b128 is served in four 16-lane groups -- {0-3,12-15,20-27},
+//                           {4-11,16-19,28-31}, ... -- and a 128-B row spans half of the 64 banks, so the 16-B slot of a lane is
+//                           (row & 1) * 8 + slot; with (row & 7) as the key rows 12 and 20, 13 and 21, ... of a group met on
+//                           one slot: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE was 0.48.  (row >> 1) & 7 is distinct over
+//                           the even and over the odd rows of every group.)
 //   K-major operand      -> [32][R]: fragment reads are ds_read_b32 along the row axis, conflict-free as is.
 // The DMA is issued through inline asm: hipcc would otherwise put s_waitcnt vmcnt(0) in front of every ds_read that
 // follows an LDS-DMA; completion is counted by hand (one vmcnt(0) + barrier per K-tile, the loads of tile t+1 having the
@@ -367,9 +372,9 @@ __device__ __forceinline__ void dma_offsets(int ld, int row0, int nrows, unsigne
   const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
   for (int i = 0; i < R / 32; ++i) {
-    if (!KMAJ) {            // image [R][32]: 8 rows x 128 B per piece, k-chunk c of a row in slot c ^ (row & 7)
+    if (!KMAJ) {            // image [R][32]: 8 rows x 128 B per piece, k-chunk c of a row in slot c ^ ((row >> 1) & 7)
       const int row = i * 32 + wave * 8 + (lane >> 3);
-      const int c = (lane & 7) ^ (row & 7);
+      const int c = (lane & 7) ^ ((row >> 1) & 7);
       voff[i] = (unsigned)((min(row0 + row, nrows - 1) - row0) * ld + c * 4) * 4u;
     } else {                // image [32][R], linear
       constexpr int C4 = R / 4;
@@ -384,8 +389,9 @@ template <int R, bool KMAJ>
 __device__ __forceinline__ void read_frag_dma(const float* __restrict__ lds, int rb, int r, int h, int chunk, float (&out)[8]) {
   if (!KMAJ) {
     const int row = rb + r, c0 = h * 4 + chunk * 2;
-    const float4 v0 = *reinterpret_cast<const float4*>(lds + row * BK + ((c0 + 0) ^ (row & 7)) * 4);
-    const float4 v1 = *reinterpret_cast<const float4*>(lds + row * BK + ((c0 + 1) ^ (row & 7)) * 4);
+    const int sw = (row >> 1) & 7;
+    const float4 v0 = *reinterpret_cast<const float4*>(lds + row * BK + ((c0 + 0) ^ sw) * 4);
+    const float4 v1 = *reinterpret_cast<const float4*>(lds + row * BK + ((c0 + 1) ^ sw) * 4);
     out[0] = v0.x; out[1] = v0.y; out[2] = v0.z; out[3] = v0.w;
     out[4] = v1.x; out[5] = v1.y; out[6] = v1.z; out[7] = v1.w;
   } else {
