@@ -18,7 +18,8 @@ pytestmark = pytest.mark.gpu
 from oracle import rng as orng  # noqa: E402
 from oracle import vp_oracle as vo  # noqa: E402
 
-GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'golden', 'vp_*.npz')))
+GOLD = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), 'golden', 'vp_*.npz')) if 'vp_loop_' not in os.path.basename(p))
+LOOPS = sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'golden', 'vp_loop_*.npz')))
 IDS = [os.path.basename(p)[:-4] for p in GOLD]
 
 
@@ -380,3 +381,64 @@ def test_errors_are_loud(MT):
         m.loss_function(pred, gt).backward()                                   # eval-mode backward is not on the path
     with pytest.raises(MansyError):
         m.train_step(h, c, f, MT.FusedAdamW(m))                                # train_step requires train mode
+
+
+@pytest.mark.parametrize('path', LOOPS, ids=[os.path.basename(p)[:-4] for p in LOOPS])
+@pytest.mark.parametrize('fused', [True, False])
+def test_training_loop_vs_reference_capture(MT, path, fused):
+    """four consecutive iterations of run_models.py:37-44 + the validation metric of :50-58 against a capture of the
+    imported reference (tools/gen_golden_vp_loop.py): the MTIO repeat / shuffle decisions come out of the same host RNG stream,
+    AdamW moments and BatchNorm running statistics evolve across the steps.  Both the one-call train_step and the module API."""
+    z = np.load(path)
+    m, _ = _build(MT, z)
+    seed, lr = int(z['seed']), float(z['lr'])
+    np.random.seed(seed); torch.manual_seed(seed); random.seed(seed)
+    opt = MT.FusedAdamW(m, lr=lr)
+    m.train()
+    losses = []
+    for i in range(len(z['losses'])):
+        h, c, f = (torch.from_numpy(z[f'b{i}/{k}']).cuda() for k in ('history', 'current', 'future'))
+        if fused:
+            losses.append(m.train_step(h, c, f, opt).item())
+        else:
+            pred, gt = m(h, c, f)
+            loss = m.loss_function(pred, gt)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+    np.testing.assert_allclose(losses, z['losses'], rtol=2e-4, atol=2e-6)
+    sd = m.state_dict()
+    bn = 'transformer.distill_layer.norm.'
+    assert int(sd[bn + 'num_batches_tracked'].item()) == int(z['final::' + bn + 'num_batches_tracked'])
+    # Trajectories of two fp32 implementations separate over optimiser steps: AdamW moves an element whose gradient is at
+    # rounding-noise level by a full +-lr in either direction (m / sqrt(v) = +-1), and those elements differ between any two
+    # implementations.  The separation scales with lr (measured: 10x smaller at lr 1e-4 than at 1e-3) and stays ~3 orders of
+    # magnitude below what a semantic error (momentum, MTIO decision order, step count) produces; tolerances are set accordingly.
+    np.testing.assert_allclose(sd[bn + 'running_mean'].cpu().numpy(), z['final::' + bn + 'running_mean'], atol=6e-4, rtol=0)
+    np.testing.assert_allclose(sd[bn + 'running_var'].cpu().numpy(), z['final::' + bn + 'running_var'], atol=6e-4, rtol=1e-3)
+    for key in z.files:
+        if not key.startswith('final::') or 'running_' in key or 'num_batches' in key:
+            continue
+        got, ref = sd[key[7:]].cpu().numpy(), z[key]
+        err = np.abs(got - ref)
+        # four AdamW steps of lr 1e-4 move a weight by up to 4e-4: the bulk must agree to a small fraction of that, no element
+        # may be off by more than the total possible movement in opposite directions
+        # parameters whose true gradient is identically zero -- the conv bias in front of the BatchNorm (the batch mean removes it)
+        # the final encoder LayerNorm bias (a per-channel constant through the circular conv, removed by the same batch mean) and the
+        # key third of the attention input biases (softmax is shift-invariant) -- see nothing but rounding noise, so in
+        # BOTH implementations they random-walk by +-lr per step: only the walk's bound applies to them
+        noise_driven = key.endswith('downConv.bias') or key.endswith('in_proj_bias') or key.endswith('transformer.encoder.norm.bias')
+        frac = float((err > 4e-5).mean())
+        assert (noise_driven or frac <= 0.02) and err.max() <= 8.5e-4, (key, frac, float(err.max()))
+    m.eval()
+    with torch.no_grad():
+        mse = []
+        for i in range(2):
+            h, c, f = (torch.from_numpy(z[f'v{i}/{k}']).cuda() for k in ('history', 'current', 'future'))
+            pred = m.sample(h, c)
+            e = torch.abs(pred - f)
+            e = torch.minimum(e, torch.abs(pred + 1 - f))
+            e = torch.minimum(e, torch.abs(pred - 1 - f))
+            mse.append(torch.mean(torch.sum(e * e, dim=-1) / 2).item())
+    np.testing.assert_allclose(np.sum(mse) / 2, float(z['valid_mse']), rtol=2e-3, atol=1e-6)
