@@ -45,7 +45,9 @@ class Results:
                 yield blk, i
 
     def _metric(self, blk, name, i, t):
-        return blk[name][i, t] if name in blk else None
+        if name not in blk:
+            return None
+        return float(blk[name][i, t]) if name == 'mse' else blk[name][i, t]      # the reference stores mse as `.item()` (results.py:81)
 
     def write(self, log=True, label=''):
         stem = os.path.join(self.output_dir, label)
@@ -57,7 +59,7 @@ class Results:
                 for t in range(self.fut_window):
                     g, p = blk['gt'][i, t], blk['pred'][i, t]
                     cells = [hz[t], g[0], g[1], *p, *(self._metric(blk, k, i, t) for k in ('mse', 'accuracy', 'recall', 'precision', 'f1'))]
-                    out.write(head + ','.join(str(c) for c in cells) + '\n')
+                    out.write(head + ','.join(f'{c}' for c in cells) + '\n')          # f-string formatting like results.py:103-110
         print('Results saved at', stem + 'results.csv')
         if log:
             with open(stem + 'results.log', 'w', encoding='utf-8') as out:
