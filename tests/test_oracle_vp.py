@@ -78,3 +78,70 @@ def test_train_forward_backward_adamw(path, branch):
             p, g = params[k].detach(), params[k].grad
             p1, _, _ = vo.adamw_step(p, g, torch.zeros_like(p), torch.zeros_like(p), step=1)
             np.testing.assert_allclose(p1.numpy(), z[key], atol=2e-7, rtol=1e-6, err_msg=k)
+
+
+LOOPS = sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'golden', 'vp_loop_*.npz')))
+
+
+@pytest.mark.parametrize('path', LOOPS, ids=[os.path.basename(p)[:-4] for p in LOOPS])
+def test_training_loop_vs_reference_capture(path):
+    """The oracle through four consecutive iterations of run_models.py:37-44 + the validation metric (:50-58) against the capture
+    of the imported reference (tools/gen_golden_vp_loop.py): MTIO decisions from the same host RNG stream (random.random(), then
+    two np.random.shuffle per shuffled step -- mtio.py:77-87), AdamW moments and BatchNorm running statistics carried over."""
+    import random
+    z = np.load(path)
+    d, T, B = int(z['d']), int(z['T']), int(z['B'])
+    sd = vo.make_state_dict(d, int(z['wseed']), bias=bool(z['bias']))
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()
+              if v.dtype.is_floating_point and 'running_' not in k and k != 'positional_embedding.pe'}
+    full = dict(sd)
+    full.update(params)
+    m = {k: torch.zeros_like(v) for k, v in params.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in params.items()}
+    seed, lr = int(z['seed']), float(z['lr'])
+    np.random.seed(seed); torch.manual_seed(seed); random.seed(seed)
+    losses = []
+    for i in range(len(z['losses'])):
+        h, c, f = (torch.from_numpy(z[f'b{i}/{k}']) for k in ('history', 'current', 'future'))
+        repeat = random.random() < 0.5
+        assert repeat == bool(z['repeat'][i])
+        perms = None
+        if not repeat:
+            perms = []
+            for _ in range(2):
+                idx = np.arange(B)
+                np.random.shuffle(idx)
+                perms.append(idx.copy())
+        src, cur, gt = vo.mtio_mix(h, c, f, 3, repeat, perms)
+        orc = vo.VPOracle(full, fut_window=T)
+        loss = orc.loss_function(orc.process_src_current(src, cur, train=True), gt)
+        for p in params.values():
+            p.grad = None
+        loss.backward()
+        losses.append(loss.item())
+        bn_mean, bn_var = orc.last_bn_stats
+        full['transformer.distill_layer.norm.running_mean'], full['transformer.distill_layer.norm.running_var'] = bn_mean, bn_var
+        with torch.no_grad():
+            for k, p in params.items():
+                p1, m[k], v2[k] = vo.adamw_step(p, p.grad, m[k], v2[k], step=i + 1, lr=lr)
+                p.copy_(p1)
+    np.testing.assert_allclose(losses, z['losses'], rtol=2e-4, atol=2e-6)
+    bn = 'final::transformer.distill_layer.norm.'
+    # (tolerances: see tests/test_gpu_vp_engine.py::test_training_loop_vs_reference_capture -- zero-gradient parameters random-walk)
+    np.testing.assert_allclose(full['transformer.distill_layer.norm.running_mean'].numpy(), z[bn + 'running_mean'], atol=6e-4, rtol=0)
+    np.testing.assert_allclose(full['transformer.distill_layer.norm.running_var'].numpy(), z[bn + 'running_var'], atol=6e-4, rtol=1e-3)
+    for k, p in params.items():
+        err = np.abs(p.detach().numpy() - z['final::' + k])
+        noise_driven = k.endswith('downConv.bias') or k.endswith('in_proj_bias') or k.endswith('transformer.encoder.norm.bias')
+        assert (noise_driven or float((err > 4e-5).mean()) <= 0.02) and err.max() <= 8.5e-4, (k, float((err > 4e-5).mean()), float(err.max()))
+    with torch.no_grad():
+        orc = vo.VPOracle({k: (v.detach() if torch.is_tensor(v) else v) for k, v in full.items()}, fut_window=T)
+        mse = []
+        for i in range(2):
+            h, c, f = (torch.from_numpy(z[f'v{i}/{k}']) for k in ('history', 'current', 'future'))
+            pred = orc.sample(h, c)
+            e = torch.abs(pred - f)
+            e = torch.minimum(e, torch.abs(pred + 1 - f))
+            e = torch.minimum(e, torch.abs(pred - 1 - f))
+            mse.append(torch.mean(torch.sum(e * e, dim=-1) / 2).item())
+    np.testing.assert_allclose(np.sum(mse) / 2, float(z['valid_mse']), rtol=2e-3, atol=1e-6)
