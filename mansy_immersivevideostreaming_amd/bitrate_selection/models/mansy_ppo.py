@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from ..._lib import MansyError, check, lib, ptr, stream_ptr
 from ..envs.mansy_env import OBS_LD
-from .mansy import MAXOUT, NetEngine
+from .mansy import NetEngine
 
 
 class RolloutBuffer:
@@ -59,7 +59,6 @@ class VecCollector:
         self._graph = None
         self._graph_key = None
         self._u = None
-        self._logits = None
 
     @property
     def obs(self):
@@ -87,7 +86,6 @@ class VecCollector:
         dev = self.carry.device
         if self._u is None or self._u.shape != (T, N):
             self._u = torch.empty(T, N, dtype=torch.float32, device=dev)
-            self._logits = torch.empty(N, MAXOUT, dtype=torch.float32, device=dev)
             self._graph = None
         buffer.reset()
         self._u.uniform_()                      # Categorical sampling uniforms (torch generator => reproducible with manual_seed)
