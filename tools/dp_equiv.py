@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Data-parallel equivalence probe for the VP train step (tests/test_gpu_dist.py): the same seeded model takes one train step on
+a batch of B trajectories either alone (WORLD_SIZE unset) or as one of `world` ranks holding B/world rows each (torchrun; SyncBN
+statistics hook + flat-gradient all-reduce, exactly what bench.py wires).  Dropout off and the MTIO `repeat` branch forced so the
+two runs compute the same function.  Rank 0 writes loss / synchronised gradient / BN running statistics to an .npz.
+
+  python tools/dp_equiv.py OUT.npz [B]            |  python -m torch.distributed.run --nproc-per-node 2 ... tools/dp_equiv.py OUT.npz [B]"""
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    out, B = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 64
+    from bench import synthetic_trajectories
+    from mansy_immersivevideostreaming_amd import dist as mdist
+    rank, world, local = mdist.init_process_group()
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    from mansy_immersivevideostreaming_amd.viewport_prediction.models import FusedAdamW, ViewportTransformerMTIO
+    torch.manual_seed(5)
+    random.seed(5)
+    np.random.seed(5)
+    m = ViewportTransformerMTIO(in_channel=2, fut_window=10, d_model=64, dim_feedforward=64, device=dev, repeat_prob=1.0).to(dev)
+    m.dropout_p = m.attn_dropout_p = 0.0
+    m.train()
+    if world > 1:
+        m.set_data_parallel(world)
+    opt = FusedAdamW(m, lr=1e-4)
+    h, c, f = (t.to(dev) for t in synthetic_trajectories(B, 10, 10, seed=11))
+    n = B // world
+    sl = slice(rank * n, (rank + 1) * n)
+    loss = m.train_step(h[sl].contiguous(), c[sl].contiguous(), f[sl].contiguous(), opt, grad_sync=mdist.make_grad_sync(world))
+    lv = torch.tensor([float(loss.item())], dtype=torch.float64, device=dev)
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(lv)                                  # mean of the shard losses = loss of the whole batch
+        lv /= world
+    _, rm, rv, _ = m._engine_buffers()
+    if rank == 0:
+        np.savez(out, loss=lv.cpu().numpy(), grad=m._flat_g.cpu().numpy(), rm=rm.cpu().numpy(), rv=rv.cpu().numpy(),
+                 param=m._flat_p.cpu().numpy(), world=world)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
