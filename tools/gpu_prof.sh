@@ -8,11 +8,11 @@ import sys, os, random
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 import numpy as np, torch
 from mansy_immersivevideostreaming_amd.viewport_prediction.models import ViewportTransformerMTIO, FusedAdamW
-from oracle import vp_oracle as vo
+from bench import synthetic_trajectories
 torch.manual_seed(5); random.seed(5); np.random.seed(5)
 m = ViewportTransformerMTIO(in_channel=2, fut_window=10, d_model=512, dim_feedforward=512, device='cuda').to('cuda'); m.train()
 opt = FusedAdamW(m, lr=1e-4)
-h, c, f = (t.cuda() for t in vo.synthetic_trajectories(4096, 10, 10, seed=5))
+h, c, f = (t.cuda() for t in synthetic_trajectories(4096, 10, 10, seed=5))
 for _ in range(int(sys.argv[1])): m.train_step(h, c, f, opt)
 torch.cuda.synchronize()
 PY
