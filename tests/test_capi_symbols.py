@@ -146,3 +146,36 @@ def test_lazy_losses_mapping_cpu():
     chunks = list(split_indices(1100, 512))
     assert [len(c) for c in chunks] == [512, 588] and sorted(np.concatenate(chunks).tolist()) == list(range(1100))
     assert [len(c) for c in split_indices(1024, 512, shuffle=False)] == [512, 512]
+
+
+def test_ctypes_structs_match_header_layout(tmp_path):
+    """Every ctypes.Structure of _lib.py against the struct of include/mansy_hip.h it mirrors: a C program compiled from the
+    header prints sizeof and the offset of every field; names, order, offsets and total size must agree."""
+    import ctypes
+    import re
+    import subprocess
+    from mansy_immersivevideostreaming_amd import _lib
+    pairs = {'mansy_vp_config': _lib.VPConfig, 'mansy_gemm_epilogue': _lib.GemmEpilogue, 'mansy_env_tables': _lib.EnvTables,
+             'mansy_env_episode_log': _lib.EpisodeLog, 'mansy_attn_shape': _lib.AttnShape}
+    hdr = os.path.join(ROOT, 'include', 'mansy_hip.h')
+    text = open(hdr).read()
+    assert set(re.findall(r'typedef struct (mansy_\w+)', text)) == set(pairs)      # no struct of the header is left unmirrored
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{hdr}"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src, exe = tmp_path / 'layout.c', tmp_path / 'layout'
+    src.write_text('\n'.join(lines))
+    subprocess.run(['gcc', '-std=c11', '-o', str(exe), str(src)], check=True, capture_output=True)   # an unknown field name fails here
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in pairs.items():
+        assert int(got[cname]) == ctypes.sizeof(cls), (cname, got[cname], ctypes.sizeof(cls))
+        for fname, _ in cls._fields_:
+            assert int(got[f'{cname}.{fname}']) == getattr(cls, fname).offset, (cname, fname)
+        # and the header has no field the mirror lacks: count the declarators of the struct body
+        body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (cname, cname), text, re.S).group(1)
+        body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+        n_fields = sum(len(decl.split(',')) for decl in body.split(';') if decl.strip())
+        assert n_fields == len(cls._fields_), (cname, n_fields, len(cls._fields_))
