@@ -179,3 +179,32 @@ def test_ctypes_structs_match_header_layout(tmp_path):
         body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
         n_fields = sum(len(decl.split(',')) for decl in body.split(';') if decl.strip())
         assert n_fields == len(cls._fields_), (cname, n_fields, len(cls._fields_))
+
+
+def test_ctypes_prototypes_match_header_signatures():
+    """Argument count and scalar-vs-pointer class of every prototype in _lib._PROTOS against the declaration in the header
+    (a short or mistyped argument list is undefined behaviour that no compute test would necessarily catch)."""
+    from mansy_immersivevideostreaming_amd import _lib
+    src = open(os.path.join(ROOT, 'include', 'mansy_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    decls = {m.group(2): (m.group(1).strip(), m.group(3)) for m in re.finditer(r'^([A-Za-z_][\w \*]*?)\b(mansy_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;', src, re.M | re.S)}
+    assert set(decls) == set(_lib._PROTOS), set(decls) ^ set(_lib._PROTOS)
+    for name, (ret, args) in decls.items():
+        args = [a.strip() for a in args.replace('\n', ' ').split(',')] if args.strip() not in ('', 'void') else []
+        proto = _lib._PROTOS[name]
+        assert len(args) == len(proto), (name, len(args), len(proto))
+        for a, t in zip(args, proto):
+            is_ptr_c = '*' in a or '[' in a or 'mansy_bn_sync_fn' in a
+            is_ptr_py = t in (ctypes.c_void_p, ctypes.c_char_p) or hasattr(t, '_type_') and isinstance(t._type_, type) or 'CFunctionType' in str(t.__mro__)
+            if is_ptr_c:
+                assert is_ptr_py, (name, a, t)
+            else:
+                assert t in (ctypes.c_int, ctypes.c_uint, ctypes.c_uint32, ctypes.c_float, ctypes.c_double, ctypes.c_longlong, ctypes.c_ulonglong,
+                             ctypes.c_size_t, ctypes.c_int64, ctypes.c_uint64), (name, a, t)
+                want = {'float': ctypes.c_float, 'double': ctypes.c_double}.get(a.split()[0] if a.split()[0] != 'const' else a.split()[1])
+                if want is not None:
+                    assert t is want, (name, a, t)
+                if a.split()[0] in ('int', 'uint32_t', 'unsigned'):
+                    assert ctypes.sizeof(t) == 4, (name, a, t)
+                if 'long long' in a or 'int64_t' in a or 'size_t' in a:
+                    assert ctypes.sizeof(t) == 8, (name, a, t)
