@@ -294,6 +294,16 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
+    # a fresh clone has no in-tree library (*.so is git-ignored): local rank 0 compiles it, the others wait for the file
+    from mansy_immersivevideostreaming_amd import build_ext
+    if int(os.environ.get('LOCAL_RANK', '0')) == 0:
+        build_ext.ensure_built()
+    else:
+        for _ in range(3600):
+            if os.path.exists(build_ext.LIB):
+                break
+            time.sleep(0.5)
+
     import numpy as np
     import torch
     import torch.distributed as dist

@@ -51,5 +51,11 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def ensure_built():
+    """The in-tree library, compiled first if this checkout has none (a fresh clone: *.so is git-ignored).  Not a fallback --
+    it builds the HIP path; without hipcc it raises."""
+    return LIB if os.path.exists(LIB) else build()
+
+
 if __name__ == '__main__':
     print(build(force='--force' in sys.argv, verbose=True))
