@@ -265,6 +265,16 @@ typedef struct mansy_gemm_epilogue {
 } mansy_gemm_epilogue;
 int mansy_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb, int b_kmajor, float* C, int ldc,
                    int M, int N, int K, const mansy_gemm_epilogue* ep, int force_tile, int force_splitk, void* stream);
+/* Precision mode of every dense product (torch.nn.Linear / Conv1d arithmetic behind mtio.py, customized_transformer.py and
+ * bitrate_selection/models/mansy.py) launched from now on, process-wide: 0 = exact fp32 on v_mfma_f32_32x32x2_f32 (default,
+ * the parity mode); 3 = bf16x3, 6 = bf16x6: operands split into bf16 terms on their way into LDS, 3 / 6 bf16 MFMA products
+ * accumulated in fp32 (BASELINE.json configs[4] "bf16 MFMA").  Products with K % 32 != 0 or unaligned operands stay fp32.
+ * A launch-time property: a captured hipGraph keeps the mode it was captured in.  set returns the previous mode (< 0: error). */
+#define MANSY_PREC_F32 0
+#define MANSY_PREC_BF16X3 3
+#define MANSY_PREC_BF16X6 6
+int mansy_set_gemm_precision(int mode);
+int mansy_get_gemm_precision(void);
 typedef struct mansy_attn_shape {
   int nb, H, Lq, Lk, dh;
   long long q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;

@@ -70,6 +70,8 @@ _PROTOS = {
     'mansy_tilemap_iou': [P, P, c_ll, P, P],
     'mansy_tilemap_or_groups': [P, c_ll, c_int, P, P],
     'mansy_gemm_f32': [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, P, c_int, c_int, P],
+    'mansy_set_gemm_precision': [c_int],
+    'mansy_get_gemm_precision': [],
     'mansy_attn_fwd': [P, P, P, P, P, P, c_float, c_u32, c_u32, P],
     'mansy_attn_bwd': [P, P, P, P, P, P, P, P, P, c_float, c_u32, c_u32, c_int, P],
     'mansy_layernorm_fwd': [P, P, P, P, P, P, P, P, c_int, c_int, c_float, P],
@@ -116,6 +118,10 @@ _PROTOS = {
 _RESTYPES = {'mansy_last_error': ctypes.c_char_p, 'mansy_vp_workspace_bytes': ctypes.c_size_t,
              'mansy_ppo_workspace_bytes': ctypes.c_size_t, 'mansy_a2c_workspace_bytes': ctypes.c_size_t}
 
+# bumped together with mansy_abi_version() (csrc/capi.hip) whenever a prototype or struct above changes: a stale in-tree
+# libmansy_hip.so then fails at load time instead of being called with a wrong argument list
+ABI_VERSION = 2
+
 _lib = None
 
 
@@ -138,6 +144,10 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = args
             fn.restype = _RESTYPES.get(name, c_int)
+        got = L.mansy_abi_version()
+        if got != ABI_VERSION:
+            raise MansyError(f'{LIB_PATH} has ABI version {got}, these bindings expect {ABI_VERSION}: rebuild it with '
+                             '`python -m mansy_immersivevideostreaming_amd.build_ext`')
         _lib = L
     return _lib
 
@@ -158,3 +168,39 @@ def ptr(t):
 def stream_ptr(device=None):
     import torch
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+# ---- precision mode of the dense products (mansy_set_gemm_precision)
+PRECISIONS = {'f32': 0, 'fp32': 0, 'bf16x3': 3, 'bf16x6': 6, 0: 0, 3: 3, 6: 6}
+
+
+def set_precision(mode):
+    """Process-wide precision mode of the dense products (mansy_set_gemm_precision): 'f32' (exact fp32 MFMA, default),
+    'bf16x3' or 'bf16x6' (split-bf16 MFMA).  Returns the previous mode as a name."""
+    if mode not in PRECISIONS:
+        raise MansyError(f'unknown precision {mode!r}: one of f32, bf16x3, bf16x6')
+    prev = lib().mansy_set_gemm_precision(PRECISIONS[mode])
+    if prev < 0:
+        check(prev, 'mansy_set_gemm_precision')
+    return {0: 'f32', 3: 'bf16x3', 6: 'bf16x6'}[prev]
+
+
+def get_precision():
+    return {0: 'f32', 3: 'bf16x3', 6: 'bf16x6'}[lib().mansy_get_gemm_precision()]
+
+
+class precision:
+    """with kernels.precision('bf16x3'): ...   -- every product launched (or hipGraph-captured) inside runs in that mode.
+    mode None: leave the process-wide mode as it is (what a model with `precision = None` does)."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = set_precision(self.mode) if self.mode is not None else None
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            set_precision(self.prev)
+        return False

@@ -140,6 +140,22 @@ class EnvTables:
             bw[i, :len(t)], tl[i] = t, len(t)
         smp = np.array([(used_v.index(videos[a]), used_vp.index((videos[a], users[b])), used_t.index(traces[c]), d)
                         for a, b, c, d in samples], np.int32)
+        # The device code indexes the viewport tables with `chunk - vp_start` and the manifest with `chunk`, unchecked; the
+        # reference fails loudly on the same inputs (simulator.py:45 `assert startup_download + 1 >= start_chunk`, list / dict
+        # lookups raising on chunks a prediction pickle or a manifest does not hold).  Check every catalogue entry here.
+        first = int(config.startup_download) + 1
+        for i, (v, u) in enumerate(used_vp):
+            vi = used_v.index(v)
+            end = min(int(vend[i]), int(vlen[vi]) - 1)
+            if first < int(vstart[i]):
+                raise MansyError(f'video{v}/user{u}.pkl starts at chunk {int(vstart[i])} but the session starts at chunk {first} '
+                                 f'(startup_download + 1): re-export the predictions with a smaller --trim-head (simulator.py:45)')
+            if len(pks[i]) != int(vend[i]) - int(vstart[i]) + 1 or any(int(p[0]) != int(vstart[i]) + j for j, p in enumerate(pks[i])):
+                raise MansyError(f'video{v}/user{u}.pkl does not hold consecutive chunks {int(vstart[i])}..{int(vend[i])}')
+            missing = [c for c in range(first, end + 1) if str(c) not in manifests[v]['Chunks']]
+            if missing:
+                raise MansyError(f'video{v}.json has no chunk {missing[0]} (needed up to chunk {end}: Video_Time '
+                                 f'{int(vlen[vi])}, predictions end at {int(vend[i])})')
         arrays = dict(size=size, quality=qual, video_len=vlen, vp_gt=gt, vp_pred=pr, vp_acc=acc, vp_start=vstart, vp_end=vend,
                       trace_bw=bw, trace_len=tl, samples=smp)
         return cls(arrays, qoe_weights, device, video_rates=config.video_rates, startup_download=config.startup_download,

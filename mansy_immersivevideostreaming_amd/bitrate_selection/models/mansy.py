@@ -114,13 +114,19 @@ def _conv_as_linear_init(cin, k, hidden):
 
 
 class _Seq0(nn.Module):
-    """Holds `0.weight` / `0.bias` like nn.Sequential(layer, activation, ...) does in the reference."""
+    """Holds `0.weight` / `0.bias` like nn.Sequential(layer, activation, ...) does in the reference.  A layer that is an
+    nn.Linear in the reference is kept as a real nn.Linear child (pass the module), so that the reference's initialisation loop
+    `for m in net.modules(): if isinstance(m, nn.Linear): orthogonal_ / zeros_` (run_mansy.py:205-226) reaches exactly the
+    layers it reaches there; the Conv1d layers (not touched by that loop) are plain holders of the flattened weight."""
 
-    def __init__(self, w, b):
+    def __init__(self, w, b=None):
         super().__init__()
-        holder = nn.Module()
-        holder.weight = nn.Parameter(w)
-        holder.bias = nn.Parameter(b)
+        if isinstance(w, nn.Linear):
+            holder = w
+        else:
+            holder = nn.Module()
+            holder.weight = nn.Parameter(w)
+            holder.bias = nn.Parameter(b)
         self.add_module('0', holder)
 
     @property
@@ -145,10 +151,8 @@ class FeatureNet(nn.Module):
                              ('conv1d4', 1, tile_total_num), ('conv1d5', 1, pask_k), ('conv1d6', 1, pask_k), ('conv1d7', 1, pask_k),
                              ('conv1d8', 1, pask_k)):
             setattr(self, name, _Seq0(*_conv_as_linear_init(cin, k, hidden_dim)))
-        l1 = nn.Linear(1, hidden_dim)
-        self.fc1 = _Seq0(l1.weight.detach().clone(), l1.bias.detach().clone())
-        l2 = nn.Linear(self._last_in(), hidden_dim)
-        self.fc2 = _Seq0(l2.weight.detach().clone(), l2.bias.detach().clone())
+        self.fc1 = _Seq0(nn.Linear(1, hidden_dim))
+        self.fc2 = _Seq0(nn.Linear(self._last_in(), hidden_dim))
 
     def _last_in(self):
         return 3
@@ -180,8 +184,7 @@ class _Head(nn.Module):
         super().__init__()
         self.feature_net = feature_net
         self.feature_dim = feature_dim
-        fc = nn.Linear(feature_dim, hidden_dim)
-        self.fc = _Seq0(fc.weight.detach().clone(), fc.bias.detach().clone())
+        self.fc = _Seq0(nn.Linear(feature_dim, hidden_dim))
         self.out = nn.Linear(hidden_dim, n_out)
         self.device = device
         self._engine = None

@@ -53,8 +53,7 @@ class FeatureNet(nn.Module):
         self.conv1d_1 = _Seq0(*_conv_as_linear_init(1, pask_k, 128))
         self.conv1d_2 = _Seq0(*_conv_as_linear_init(1, tile_total_num * num_rates, 128))
         for name, nin in (('fc1', 1), ('fc2', 2), ('fc3', 64)):
-            l = nn.Linear(nin, 128)
-            setattr(self, name, _Seq0(l.weight.detach().clone(), l.bias.detach().clone()))
+            setattr(self, name, _Seq0(nn.Linear(nin, 128)))       # a real nn.Linear: reached by run_simple_rl's orthogonal init loop
 
     def ordered_parameters(self):
         out = []
@@ -70,8 +69,7 @@ class _Head(nn.Module):
         if feature_dim != 640:
             raise MansyError('feature_dim must be 5 * 128 (run_simple_rl.py:185-186)')
         self.feature_net = feature_net
-        fc = nn.Linear(feature_dim, 128)
-        self.fc = _Seq0(fc.weight.detach().clone(), fc.bias.detach().clone())
+        self.fc = _Seq0(nn.Linear(feature_dim, 128))
         self.out = nn.Linear(128, n_out)
         self.device = device
         self._engine = None

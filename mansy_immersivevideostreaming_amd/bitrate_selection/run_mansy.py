@@ -20,6 +20,7 @@ import numpy as np
 import torch
 from torch.distributions import Categorical
 
+from .. import _lib
 from .envs.mansy_env import EnvTables, MANSYVecEnv
 from .models.mansy import Actor, Critic, FeatureNet, QoEIdentifier, QoEIdentifierFeatureNet
 from .models.mansy_ppo import PPOPolicy, VecCollector
@@ -122,6 +123,7 @@ def test(args, config, policy, qoe_weights, identifier, models_dir, results_dir)
 
 
 def run(args, config):
+    _lib.set_precision(getattr(args, 'precision', 'f32'))
     np.random.seed(args.seed)
     torch.manual_seed(args.seed)
     torch.cuda.manual_seed_all(args.seed)
@@ -206,6 +208,8 @@ _FLAGS = [
     ('--bc-identifier-max-steps', int, 150), ('--init-from-bc', _T, _F),
     # additions of this build
     ('--config', str, None), ('--test-envs', int, 256), ('--verbose-table', _T, _F),
+    # precision of the dense products: f32 (exact fp32 MFMA, the parity mode) | bf16x3 | bf16x6 (split-bf16 MFMA; BASELINE configs[4])
+    ('--precision', str, 'f32'),
 ]
 
 

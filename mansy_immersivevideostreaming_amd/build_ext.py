@@ -24,6 +24,23 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+STAMP = LIB + '.stamp'
+
+
+def source_digest():
+    """sha256 over every source / header the library is built from (+ the flags): what ensure_built() compares, because file
+    times do not survive the copy to the GPU box."""
+    import hashlib
+    h = hashlib.sha256(' '.join(FLAGS).encode())
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(('.hip', '.h'))]
+    files.append(os.path.join(os.path.dirname(HERE), 'include', 'mansy_hip.h'))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
@@ -48,13 +65,21 @@ def build(force=False, verbose=False):
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
         run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs)
+    with open(STAMP, 'w') as fh:
+        fh.write(source_digest())
     return LIB
 
 
 def ensure_built():
-    """The in-tree library, compiled first if this checkout has none (a fresh clone: *.so is git-ignored).  Not a fallback --
-    it builds the HIP path; without hipcc it raises."""
-    return LIB if os.path.exists(LIB) else build()
+    """The in-tree library, (re)compiled if this checkout has none or if it was built from other sources than the ones in the
+    tree now (a fresh clone: *.so is git-ignored; an edit of csrc/ or include/mansy_hip.h: the digest in the stamp file no
+    longer matches).  Not a fallback -- it builds the HIP path; without hipcc it raises.  _lib.lib() additionally checks
+    mansy_abi_version() against its prototypes."""
+    if os.path.exists(LIB) and os.path.exists(STAMP):
+        with open(STAMP) as fh:
+            if fh.read().strip() == source_digest():
+                return LIB
+    return build()
 
 
 if __name__ == '__main__':

@@ -1,0 +1,305 @@
+// Split-bf16 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x16_bf16): the opt-in precision modes of the dense products.
+// Operands stay fp32 in HBM; on their way into LDS every element is split into bf16 terms by round-to-nearest-even
+// (v_cvt_pk_bf16_f32):   a = a0 + a1 (+ a2),  a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1)
+// and the product is formed from bf16 x bf16 MFMAs accumulated in fp32:
+//   bf16x3 (NP = 2 planes):  a0 b0 + a0 b1 + a1 b0                          dropped terms ~2^-16 |a||b|
+//   bf16x6 (NP = 3 planes):  + a1 b1 + a0 b2 + a2 b0                        dropped terms ~2^-24 |a||b|  (fp32-equivalent)
+// at 1/16 of the fp32-matrix cycle cost per MFMA, i.e. 16/3 and 16/6 of the fp32-matrix peak.  Parity study of both variants
+// against the reference goldens: tools/bf16_split_study.py (bf16x6 is indistinguishable from fp32 on every output and gradient;
+// bf16x3 keeps outputs / loss within 1.3e-5 and all tile decisions, gradients of small-magnitude parameters to ~1e-2).
+//
+// Structure: 256 threads = 4 waves (2x2), tile 128x128 or 64x64, BK = 32 (two 16-k MFMA steps), register-staged: the fp32 tile
+// of K-tile t+1 is loaded into registers while the MFMAs of tile t run, then split and written to ONE set of LDS planes
+// (two barriers per K-tile; two workgroups per CU cover each other's staging phase -- LDS stays <= 68 KB).
+// LDS image per plane and operand, both global layouts: [rows][32 bf16], row stride 80 B (5 x 16 B: the 16 lanes of a
+// ds_read_b128 group read 16 different rows, 5*row mod 16 is a bijection -> conflict-free; the ds_write_b128 groups of 8 lanes
+// likewise).  Fragment of lane (r = lane & 31, h = lane >> 5) for MFMA step s: the 8 bf16 at k = 16 s + 8 h of row r -- A and
+// B agree, and the sum over k is order-free.
+//   K-contiguous operand: a thread stages 8 consecutive k of one row (2 x global_load_dwordx4)
+//   K-major operand:      a thread stages 8 k of one row with the 64 lanes of a wave on 64 consecutive rows
+//                         (8 x global_load_dword, 256 B contiguous per instruction)
+// Whole K-tiles only (K % 32 == 0, 16-byte aligned operands): the dispatcher (gemm_f32.hip) routes everything else to the
+// fp32 loops.  The epilogue is the shared one (gemm_tile.h): the 32x32 accumulator blocks have the fp32 kernels' layout.
+#ifndef MANSY_BF16S_SCHED
+#define MANSY_BF16S_SCHED 0
+#endif
+#include "gemm_tile.h"
+
+using namespace mansy_gemm;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+// LDS image per plane and operand: [rows][32 bf16], element offset of the 16-B chunk q of a row:
+//   compact (the two-stage loop): 64-B rows, chunk q at slot q ^ ((row >> 2) & 3) -- the 16 lanes of a ds_read_b128 group read
+//            four aligned row quadruples with four different keys: 16 different 16-B slots
+//   padded  (the one-stage loop): 80-B rows (5 slots: 5 * row mod 16 is a bijection), no swizzle; measured 7 % faster there
+template <bool PAD>
+__device__ __forceinline__ int lds_off(int row, int q) { return PAD ? row * 40 + q * 8 : row * 32 + ((q ^ ((row >> 2) & 3)) << 3); }
+
+template <int R>
+struct Stg { static constexpr int ITEMS = R / 64; };      // (row, 8-k chunk) items per thread and operand
+
+// Per-thread loop-invariant source offsets (floats, relative to the tile corner of the current K-tile).  Rows beyond the
+// matrix are clamped onto the last valid one (their accumulators are never stored).
+template <int R, bool KMAJ, bool PAD>
+__device__ __forceinline__ void stage_offsets(int ld, int row0, int nrows, unsigned (&off)[Stg<R>::ITEMS], int (&ldso)[Stg<R>::ITEMS],
+                                              int (&srow)[Stg<R>::ITEMS], int tid) {
+#pragma unroll
+  for (int i = 0; i < Stg<R>::ITEMS; ++i) {
+    int kc;
+    if (!KMAJ) {
+      const int idx = tid + i * NT;
+      srow[i] = idx >> 2; kc = idx & 3;
+      off[i] = (unsigned)((min(row0 + srow[i], nrows - 1) - row0) * ld + kc * 8);
+    } else {
+      srow[i] = (tid & 63) + 64 * i; kc = tid >> 6;
+      off[i] = (unsigned)(kc * 8 * ld + (min(row0 + srow[i], nrows - 1) - row0));
+    }
+    ldso[i] = lds_off<PAD>(srow[i], kc);
+  }
+}
+
+template <int R, bool KMAJ>
+__device__ __forceinline__ void stage_load(const float* __restrict__ corner, int ld, const unsigned (&off)[Stg<R>::ITEMS],
+                                           float (&v)[Stg<R>::ITEMS][8]) {
+#pragma unroll
+  for (int i = 0; i < Stg<R>::ITEMS; ++i) {
+    if (!KMAJ) {
+      const float4* s = reinterpret_cast<const float4*>(corner + off[i]);
+      const float4 a = s[0], b = s[1];
+      v[i][0] = a.x; v[i][1] = a.y; v[i][2] = a.z; v[i][3] = a.w; v[i][4] = b.x; v[i][5] = b.y; v[i][6] = b.z; v[i][7] = b.w;
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) v[i][kk] = (corner + (long long)kk * ld)[off[i]];
+    }
+  }
+}
+
+// Split 8 staged floats into NP bf16 planes and store them (one ds_write_b128 per plane).
+template <int NP>
+__device__ __forceinline__ void split_store(__bf16* __restrict__ dst, int plane_elems, const float (&v)[8]) {
+  bf16x8 p0, p1, p2;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const __bf16 t0 = (__bf16)v[e];
+    const float r1 = v[e] - (float)t0;
+    const __bf16 t1 = (__bf16)r1;
+    p0[e] = t0; p1[e] = t1;
+    if (NP == 3) { const float r2 = r1 - (float)t1; p2[e] = (__bf16)r2; }
+  }
+  *reinterpret_cast<bf16x8*>(dst) = p0;
+  *reinterpret_cast<bf16x8*>(dst + plane_elems) = p1;
+  if (NP == 3) *reinterpret_cast<bf16x8*>(dst + 2 * plane_elems) = p2;
+}
+
+// DB: two LDS stages -- the split + LDS store of K-tile t+1 is issued between the MFMAs of tile t (one barrier per K-tile, the
+// global loads of tile t+2 fly across a whole tile); !DB: one stage, two barriers per K-tile (less LDS: the 3-plane mode keeps
+// two workgroups per CU that way).
+template <int BM, int BN, bool AKM, bool BKM, int NP, bool DB>
+__global__ __launch_bounds__(NT, 2) void gemm_bf16s_kernel(GemmParams p) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int SROW = DB ? 32 : 40;
+  constexpr int A_PLANE = BM * SROW, B_PLANE = BN * SROW;                 // bf16 elements
+  constexpr int STAGE = NP * (A_PLANE + B_PLANE);                         // bf16 elements per stage
+  constexpr int STAGE_FLOATS = (DB ? 2 : 1) * STAGE / 2;
+  constexpr int C_FLOATS = BM * (BN + 4);
+  constexpr int SMEM_FLOATS = STAGE_FLOATS > C_FLOATS ? STAGE_FLOATS : C_FLOATS;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+  __bf16* const planes = reinterpret_cast<__bf16*>(smem);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  int tile_x, tile_y, split;
+  {   // XCD-aware bijective remap over the whole 3-D grid, K split slowest (see gemm_f32_dma_kernel)
+    const int per_split = gridDim.x * gridDim.y, nwg = per_split * gridDim.z;
+    const int orig = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const int q = nwg >> 3, rem = nwg & 7, xcd = orig & 7, local = orig >> 3;
+    int t = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + local;
+    split = t / per_split; t -= split * per_split;
+    tile_y = t / gridDim.x; tile_x = t - tile_y * gridDim.x;
+  }
+  const int m0 = tile_y * BM, n0 = tile_x * BN;
+  int k_begin = split * p.k_per_split;
+  int k_end = min(p.K, k_begin + p.k_per_split);
+  if (BN == 64 && p.ep.tile_krange) {             // block-diagonal weights: structurally-zero K-tiles of this column tile are skipped
+    k_begin = max(k_begin, p.ep.tile_krange[2 * tile_x]);
+    k_end = min(k_end, p.ep.tile_krange[2 * tile_x + 1]);
+  }
+  const int nk = max(0, (k_end - k_begin) / BK);
+
+  unsigned offa[Stg<BM>::ITEMS], offb[Stg<BN>::ITEMS];
+  int lda_[Stg<BM>::ITEMS], ldb_[Stg<BN>::ITEMS], rowa[Stg<BM>::ITEMS], rowb[Stg<BN>::ITEMS];
+  stage_offsets<BM, AKM, !DB>(p.lda, m0, p.M, offa, lda_, rowa, tid);
+  stage_offsets<BN, BKM, !DB>(p.ldb, n0, p.N, offb, ldb_, rowb, tid);
+  const float* ca = AKM ? p.A + (long long)k_begin * p.lda + m0 : p.A + (long long)m0 * p.lda + k_begin;
+  const float* cb = BKM ? p.B + (long long)k_begin * p.ldb + n0 : p.B + (long long)n0 * p.ldb + k_begin;
+  const long long step_a = AKM ? (long long)BK * p.lda : BK, step_b = BKM ? (long long)BK * p.ldb : BK;
+  // fragment offsets of this lane (bf16 elements inside a plane): MFMA step s reads chunk q = 2 s + h of row r
+  int fa[TM][2], fb[TN][2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[i][s] = lds_off<!DB>(wm * (BM / 2) + i * 32 + r, 2 * s + h);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[j][s] = lds_off<!DB>(wn * (BN / 2) + j * 32 + r, 2 * s + h);
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // bias gradient riding on a dW product (K-major A): row sums of the fp32 A tile, taken by the first n-tile from its staged
+  // registers (each thread owns 8 k of its rows; the 4 waves hold the 4 k-chunks of a row)
+  const bool do_rowsum = AKM && p.ep.a_rowsum && tile_x == 0;
+  float rowsum[Stg<BM>::ITEMS];
+#pragma unroll
+  for (int i = 0; i < Stg<BM>::ITEMS; ++i) rowsum[i] = 0.f;
+
+  float va[Stg<BM>::ITEMS][8], vb[Stg<BN>::ITEMS][8];
+  auto stage_store = [&](int stage) {          // staged registers -> bf16 planes of `stage`
+    if (do_rowsum) {
+#pragma unroll
+      for (int i = 0; i < Stg<BM>::ITEMS; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rowsum[i] += va[i][e];
+    }
+    __bf16* const a_pl = planes + stage * STAGE;
+    __bf16* const b_pl = a_pl + NP * A_PLANE;
+#pragma unroll
+    for (int i = 0; i < Stg<BM>::ITEMS; ++i) split_store<NP>(a_pl + lda_[i], A_PLANE, va[i]);
+#pragma unroll
+    for (int i = 0; i < Stg<BN>::ITEMS; ++i) split_store<NP>(b_pl + ldb_[i], B_PLANE, vb[i]);
+  };
+  auto mfma_step = [&](int stage, int s) {
+    const __bf16* const a_pl = planes + stage * STAGE;
+    const __bf16* const b_pl = a_pl + NP * A_PLANE;
+    bf16x8 af[TM][NP], bf[TN][NP];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) af[i][pl] = *reinterpret_cast<const bf16x8*>(a_pl + pl * A_PLANE + fa[i][s]);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) bf[j][pl] = *reinterpret_cast<const bf16x8*>(b_pl + pl * B_PLANE + fb[j][s]);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        // small terms first: they are added to each other before they meet the large partial sum of a0 b0
+        if (NP == 3) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+        }
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+      }
+  };
+
+  if (DB) {
+    if (nk > 0) {
+      stage_load<BM, AKM>(ca, p.lda, offa, va);
+      stage_load<BN, BKM>(cb, p.ldb, offb, vb);
+      stage_store(0);
+      ca += step_a; cb += step_b;
+      if (nk > 1) {
+        stage_load<BM, AKM>(ca, p.lda, offa, va);
+        stage_load<BN, BKM>(cb, p.ldb, offb, vb);
+      }
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      // Branch-free body (one basic block, so that the scheduler may place the split VALU work and the LDS stores between the
+      // MFMAs): the last iterations re-stage / re-load the final tile instead of skipping -- harmless, nobody reads it.
+      const int cur = kt & 1;
+      mfma_step(cur, 0);
+      stage_store(cur ^ 1);                                // tile kt+1: registers -> the other stage
+      mfma_step(cur, 1);
+      const bool more = kt + 2 < nk;                       // tile kt+2: in flight across the whole next iteration
+      ca += more ? step_a : 0; cb += more ? step_b : 0;
+      stage_load<BM, AKM>(ca, p.lda, offa, va);
+      stage_load<BN, BKM>(cb, p.ldb, offb, vb);
+#if MANSY_BF16S_SCHED
+#pragma unroll
+      for (int g = 0; g < 2 * TM * TN * (NP == 3 ? 6 : 3); ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, NP == 3 ? 4 : 4, 0);   // a few split VALU ops in its shadow
+      }
+#endif
+      __syncthreads();
+    }
+  } else {
+    if (nk > 0) {
+      stage_load<BM, AKM>(ca, p.lda, offa, va);
+      stage_load<BN, BKM>(cb, p.ldb, offb, vb);
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+      stage_store(0);
+      __syncthreads();
+      ca += step_a; cb += step_b;
+      if (kt + 1 < nk) {                                   // next tile's global loads fly during the MFMAs
+        stage_load<BM, AKM>(ca, p.lda, offa, va);
+        stage_load<BN, BKM>(cb, p.ldb, offb, vb);
+      }
+      mfma_step(0, 0);
+      mfma_step(0, 1);
+      __syncthreads();                                     // every wave is done reading the planes
+    }
+  }
+
+  if (do_rowsum) {
+#pragma unroll
+    for (int i = 0; i < Stg<BM>::ITEMS; ++i)
+      if (m0 + rowa[i] < p.M) atomicAdd(p.ep.a_rowsum + m0 + rowa[i], rowsum[i]);
+  }
+  gemm_epilogue<BM, BN, SMEM_FLOATS>(p, acc, smem, m0, n0, tid, split, p.C);
+}
+
+template <int BM, int BN, int NP, bool DB>
+int launch_layouts(const GemmParams& p, int a_kmajor, int b_kmajor, int splits, hipStream_t st) {
+  dim3 grid(mansy_ceil_div(p.N, BN), mansy_ceil_div(p.M, BM), splits);
+  dim3 block(NT);
+  if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_bf16s_kernel<BM, BN, false, false, NP, DB>), grid, block, 0, st, p);
+  else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_bf16s_kernel<BM, BN, false, true, NP, DB>), grid, block, 0, st, p);
+  else if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_bf16s_kernel<BM, BN, true, true, NP, DB>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL((gemm_bf16s_kernel<BM, BN, true, false, NP, DB>), grid, block, 0, st, p);
+  MANSY_LAUNCH_CHECK();
+  return MANSY_OK;
+}
+
+}  // namespace
+
+// tile: 128 -> 128x128, anything else -> 64x64; prec: 3 (bf16x3) or 6 (bf16x6).  Preconditions as the LDS-DMA loop's.
+// bf16x3 runs the two-stage loop (64 KB of planes, two workgroups per CU); bf16x6 the one-stage loop -- two stages of three
+// planes are 96 KB, i.e. one workgroup per CU, and measured 10-20 % slower than one stage with two (tools/bf16_lab.sh).
+int mansy_gemm_bf16s_dispatch(const GemmParams& p, int tile, int prec, int a_kmajor, int b_kmajor, int splits, hipStream_t st) {
+  if (prec == 3) {
+    if (tile == 128) return launch_layouts<128, 128, 2, true>(p, a_kmajor, b_kmajor, splits, st);
+    return launch_layouts<64, 64, 2, true>(p, a_kmajor, b_kmajor, splits, st);
+  }
+  if (tile == 128) return launch_layouts<128, 128, 3, false>(p, a_kmajor, b_kmajor, splits, st);
+  return launch_layouts<64, 64, 3, false>(p, a_kmajor, b_kmajor, splits, st);
+}
+
+// resident workgroups per CU (diagnostic)
+extern "C" int mansy_gemm_bf16s_occupancy(int prec, int tile) {
+  int n = -1;
+  hipError_t e;
+#define OCC(BMN, NPL, D) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_bf16s_kernel<BMN, BMN, false, false, NPL, D>, NT, 0)
+  if (prec == 3 && tile == 128) OCC(128, 2, true);
+  else if (prec == 3) OCC(64, 2, true);
+  else if (tile == 128) OCC(128, 3, false);
+  else OCC(64, 3, false);
+#undef OCC
+  return e == hipSuccess ? n : -1;
+}

@@ -16,27 +16,11 @@
 // of one LDS row.  Split-K: atomics (dW products) or per-split slabs (skinny products); workgroups are remapped so that
 // the tiles sharing an operand panel -- and whole K splits -- land on one XCD's L2.
 #include <vector>
-#include "mansy_kernels.h"
+#include "gemm_tile.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+using namespace mansy_gemm;
 
 namespace {
-
-constexpr int BK = 32;
-constexpr int KC_LD = BK + 4;   // K-contiguous LDS row stride (floats)
-constexpr int NT = 256;
-
-struct GemmParams {
-  const float* A; const float* B; float* C;
-  int lda, ldb, ldc;
-  int M, N, K;
-  int k_per_split;
-  int vec_ok;
-  int c_vec_ok;      // 16-byte epilogue legal: C, bias, mask, resid 16-B aligned, their lds and N multiples of 4
-  GemmEpilogue ep;
-  // optional second problem of identical shape in the same launch (LDS-DMA loop; grid.z = 2 x splits, problem slowest)
-  const float* A2 = nullptr; const float* B2 = nullptr; float* C2 = nullptr; float* a_rowsum2 = nullptr; int splits_pp = 1;
-};
 
 template <int R, bool KMAJ>
 struct TileGeom {
@@ -117,139 +101,6 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ lds, int rb,
   }
 }
 
-// Epilogue shared by both main loops.  C/D layout of the 32x32 MFMA block: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-// `smem` is the (now idle) staging LDS, at least BM*(BN+4) floats; SMEM_FLOATS is its size.
-template <int BM, int BN, int SMEM_FLOATS>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[BM / 64][BN / 64 > 0 ? BN / 64 : 1], float* smem, int m0, int n0,
-                                              int tid, int split, float* Cbase) {
-  constexpr int TM = BM / 64, TN = BN / 64;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int r = lane & 31, h = lane >> 5;
-  const GemmEpilogue& ep = p.ep;
-  const bool atomic = ep.accumulate || (gridDim.z > 1 && ep.split_slab == 0);
-  float* const Cz = Cbase + (long long)split * ep.split_slab;             // own slab per K split in slab mode
-  const float drop_scale = ep.drop.p > 0.f ? 1.f / (1.f - ep.drop.p) : 1.f;
-  if (!atomic && p.c_vec_ok) {
-    // Row-major 16-byte epilogue: the accumulators (one column per lane, 16 scattered rows) are transposed through the LDS
-    // staging buffers (free after the last barrier) so that bias / activation / mask / dropout / residual and the store all
-    // run on float4 rows: 16 global_store_dwordx4 per thread instead of 64 global_store_dword, coalesced 512-B row pieces.
-    constexpr int CLD = BN + 4;
-    static_assert(BM * CLD <= SMEM_FLOATS, "C tile must fit the staging LDS");
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e)
-          smem[(wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * CLD + wn * (BN / 2) + j * 32 + r] = acc[i][j][e];
-    __syncthreads();
-    constexpr int C4 = BN / 4;
-    constexpr int IT = BM * C4 / NT, GRP = IT < 4 ? IT : 4;
-    static_assert(BM * C4 % NT == 0 && IT % GRP == 0, "epilogue groups");
-    // Groups of GRP float4 per thread: the residual / mask loads of a whole group are issued before its first store (C may
-    // alias the residual, so the compiler will not move a load above a store by itself: one exposed L2/HBM round trip per
-    // float4 otherwise -- ~3 us on the [4096, 512] decoder products).
-#pragma unroll
-    for (int g0 = 0; g0 < IT; g0 += GRP) {
-      float4 rr[GRP], mk[GRP];
-      long long off_r[GRP], off_m[GRP];
-#pragma unroll
-      for (int u = 0; u < GRP; ++u) {
-        const int idx = tid + (g0 + u) * NT;
-        const int lr = idx / C4, c4 = idx % C4;
-        const int row = min(m0 + lr, p.M - 1), col = min(n0 + c4 * 4, p.N - 4);      // clamped: out-of-range float4 are not stored
-        off_r[u] = (long long)row * ep.resid_ld + col; off_m[u] = (long long)row * ep.mask_ld + col;
-        rr[u] = make_float4(0.f, 0.f, 0.f, 0.f); mk[u] = make_float4(1.f, 1.f, 1.f, 1.f);
-      }
-      if (ep.resid) {          // one uniform branch around the group's loads, not one per load
-#pragma unroll
-        for (int u = 0; u < GRP; ++u) rr[u] = *reinterpret_cast<const float4*>(ep.resid + off_r[u]);
-      }
-      if (ep.mask_src) {
-#pragma unroll
-        for (int u = 0; u < GRP; ++u) mk[u] = *reinterpret_cast<const float4*>(ep.mask_src + off_m[u]);
-      }
-#pragma unroll
-      for (int u = 0; u < GRP; ++u) {
-        const int idx = tid + (g0 + u) * NT;
-        const int lr = idx / C4, c4 = idx % C4;
-        const int row = m0 + lr, col = n0 + c4 * 4;
-        if (row >= p.M || col >= p.N) continue;           // N % 4 == 0 on this path: a float4 is entirely in or out
-        float4 v = *reinterpret_cast<const float4*>(smem + lr * CLD + c4 * 4);
-        if (ep.bias) { const float4 b = *reinterpret_cast<const float4*>(ep.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
-        if (ep.relu) {
-          v.x = v.x > 0.f ? v.x : v.x * ep.relu_slope; v.y = v.y > 0.f ? v.y : v.y * ep.relu_slope;
-          v.z = v.z > 0.f ? v.z : v.z * ep.relu_slope; v.w = v.w > 0.f ? v.w : v.w * ep.relu_slope;
-        }
-        if (ep.mask_src) {
-          v.x = mk[u].x > 0.f ? v.x * ep.mask_scale : v.x * ep.mask_neg; v.y = mk[u].y > 0.f ? v.y * ep.mask_scale : v.y * ep.mask_neg;
-          v.z = mk[u].z > 0.f ? v.z * ep.mask_scale : v.z * ep.mask_neg; v.w = mk[u].w > 0.f ? v.w * ep.mask_scale : v.w * ep.mask_neg;
-        }
-        if (ep.drop.p > 0.f) {
-          const uint32_t base = (uint32_t)row * (uint32_t)p.N + (uint32_t)col;
-          v.x = mansy_keep(ep.drop.seed, ep.drop.site, base + 0, ep.drop.p) ? v.x * drop_scale : 0.f;
-          v.y = mansy_keep(ep.drop.seed, ep.drop.site, base + 1, ep.drop.p) ? v.y * drop_scale : 0.f;
-          v.z = mansy_keep(ep.drop.seed, ep.drop.site, base + 2, ep.drop.p) ? v.z * drop_scale : 0.f;
-          v.w = mansy_keep(ep.drop.seed, ep.drop.site, base + 3, ep.drop.p) ? v.w * drop_scale : 0.f;
-        }
-        v.x += rr[u].x; v.y += rr[u].y; v.z += rr[u].z; v.w += rr[u].w;
-        *reinterpret_cast<float4*>(Cz + (long long)row * p.ldc + col) = v;
-      }
-    }
-    return;
-  }
-  // Scalar path (atomics / unaligned): loads (mask / residual) hoisted into unconditional clamped-address batches.
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = n0 + wn * (BN / 2) + j * 32 + r;
-      const int colc = min(col, p.N - 1);
-      const int row_base = m0 + wm * (BM / 2) + i * 32 + 4 * h;
-      const float bias = ep.bias ? ep.bias[colc] : 0.f;
-      float v[16];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        v[e] = acc[i][j][e] + bias;
-        if (ep.relu) v[e] = v[e] > 0.f ? v[e] : v[e] * ep.relu_slope;
-      }
-      if (ep.mask_src) {
-        float mk[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e)
-          mk[e] = ep.mask_src[(long long)min(row_base + (e & 3) + 8 * (e >> 2), p.M - 1) * ep.mask_ld + colc];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = mk[e] > 0.f ? v[e] * ep.mask_scale : v[e] * ep.mask_neg;
-      }
-      if (ep.drop.p > 0.f) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const uint32_t row = (uint32_t)(row_base + (e & 3) + 8 * (e >> 2));
-          v[e] = mansy_keep(ep.drop.seed, ep.drop.site, row * (uint32_t)p.N + (uint32_t)col, ep.drop.p) ? v[e] * drop_scale : 0.f;
-        }
-      }
-      if (ep.resid) {
-        float rr[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e)
-          rr[e] = ep.resid[(long long)min(row_base + (e & 3) + 8 * (e >> 2), p.M - 1) * ep.resid_ld + colc];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] += rr[e];
-      }
-      if (col < p.N) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = row_base + (e & 3) + 8 * (e >> 2);
-          if (row < p.M) {
-            float* dst = Cz + (long long)row * p.ldc + col;
-            if (atomic) atomicAdd(dst, v[e]); else *dst = v[e];
-          }
-        }
-      }
-    }
-  }
-}
 
 template <int BM, int BN, bool AK, bool BKM, bool VEC>
 __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmParams p) {
@@ -539,8 +390,20 @@ struct ProfState {
   double flops = 0.0;
 };
 ProfState g_prof;
+int g_gemm_prec = 0;   // process-wide default precision of the dense products: 0 fp32, 3 bf16x3, 6 bf16x6
 
 }  // namespace
+
+// Precision mode of every dense product launched from now on (a launch-time property: a captured hipGraph keeps the mode it
+// was captured in).  0: exact fp32 on v_mfma_f32_32x32x2_f32 (default); 3 / 6: split-bf16 products (gemm_bf16s.hip).
+// Products the split loop does not cover (K % 32 != 0, unaligned operands) stay fp32 in every mode.  Returns the previous mode.
+extern "C" int mansy_set_gemm_precision(int mode) {
+  if (mode != 0 && mode != 3 && mode != 6) { mansy_set_error("gemm precision must be 0 (fp32), 3 (bf16x3) or 6 (bf16x6), got %d", mode); return MANSY_EINVAL; }
+  const int prev = g_gemm_prec;
+  g_gemm_prec = mode;
+  return prev;
+}
+extern "C" int mansy_get_gemm_precision(void) { return g_gemm_prec; }
 
 extern "C" int mansy_prof_gemm_enable(int on) {
   g_prof.on = on != 0;
@@ -567,7 +430,8 @@ extern "C" int mansy_prof_gemm_collect(double* total_ms, long long* launches, do
 }
 
 // tile codes: 128 -> 128x128, 96 -> 128x64 (LDS-DMA loop only), 64 -> 64x64
-static int gemm_dispatch(const GemmParams& p, int tile, bool dma, int a_kmajor, int b_kmajor, int splits, hipStream_t st) {
+static int gemm_dispatch(const GemmParams& p, int tile, bool dma, int bf, int a_kmajor, int b_kmajor, int splits, hipStream_t st) {
+  if (bf) return mansy_gemm_bf16s_dispatch(p, tile, bf, a_kmajor, b_kmajor, splits, st);
   if (dma) {
     if (tile == 128) return launch_dma<128, 128>(p, a_kmajor, b_kmajor, splits, st);
     if (tile == 96) return launch_dma<128, 64>(p, a_kmajor, b_kmajor, splits, st);
@@ -603,6 +467,8 @@ int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B,
   const bool plain = !ep.bias && !ep.relu && !ep.mask_src && ep.drop.p == 0.f && !ep.resid;
   // LDS-DMA loop: whole 16-byte chunks and whole K-tiles only (it cannot zero-fill a K tail)
   const bool dma = p.vec_ok && K >= BK && K % BK == 0 && force_tile >= 0;
+  // split-bf16 modes: same preconditions as the LDS-DMA loop; everything else stays on the fp32 loops
+  const int bf = dma ? (ep.prec >= 0 ? ep.prec : g_gemm_prec) : 0;
   if (!dma && p.vec_ok && force_tile >= 0 && plain && K % BK != 0 && K >= 8 * BK && ep.split_slab == 0 && !ep.tile_krange) {
     // long reduce dimension that is not a multiple of the K-tile (e.g. a dW over 3 276 rows): whole K-tiles on the LDS-DMA
     // loop, the < 32 leftover as a second, accumulating launch of the register-staged loop (sums and row sums are additive)
@@ -617,7 +483,7 @@ int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B,
   if (ep.pair_A) {
     MANSY_REQUIRE(ep.pair_B && ep.pair_C && plain && ep.accumulate && ep.split_slab == 0, "gemm: a paired product needs a plain accumulating epilogue");
     auto al = [](const void* x) { return (reinterpret_cast<uintptr_t>(x) & 15) == 0; };
-    if (!dma || !al(ep.pair_A) || !al(ep.pair_B)) {        // no second-problem support off the LDS-DMA loop: two launches
+    if (!dma || bf || !al(ep.pair_A) || !al(ep.pair_B)) {  // no second-problem support off the fp32 LDS-DMA loop: two launches
       GemmEpilogue e1 = ep; e1.pair_A = e1.pair_B = nullptr; e1.pair_C = e1.pair_rowsum = nullptr;
       const int rc = mansy_launch_gemm_f32(A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, e1, force_tile, force_splitk, st);
       if (rc) return rc;
@@ -632,7 +498,10 @@ int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B,
   int tile;
   if (force_tile) {
     tile = force_tile < 0 ? -force_tile : force_tile;
-    if (!dma && tile == 96) tile = 64;
+    if ((!dma || bf) && tile == 96) tile = 64;
+  } else if (bf) {
+    // split-bf16 loop: 128x128 (least operand traffic and split work per MFMA) once it fills the chip, else 64x64
+    tile = (can_split || tile_count(M, N, 128) >= 256) ? 128 : 64;
   } else if (dma) {
     // LDS-DMA loop: 128x64 and 64x64 run the K loop at the same rate as 128x128 (tools/gemm_lab.hip) and quantise better
     // over 256 CUs.  cost ~ (workgroups per CU, rounded up) x tile area / relative efficiency; a lone workgroup per CU
@@ -659,7 +528,7 @@ int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B,
   else if (plain && ep.accumulate && tiles < 256) {
     // fill ONE round of resident workgroups, never spill a few into a second: 2 per CU for the 128x128 / 64x64 loops as
     // dispatched here, 3 per CU for the 128x64 LDS-DMA loop (48 KB LDS, 136 VGPRs) -- tools/dw_split_sweep.py
-    splits = (int)(((dma && tile == 96) ? 768 : 512) / tiles);
+    splits = (int)(((dma && !bf && tile == 96) ? 768 : 512) / tiles);
     if (splits < 1) splits = 1;
     const int max_splits = K / (BK * 8) > 0 ? K / (BK * 8) : 1;
     if (splits > max_splits) splits = max_splits;
@@ -672,12 +541,12 @@ int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B,
   p.k_per_split = kps;
   p.splits_pp = splits;
   splits *= n_prob;                                        // grid.z: problem-major
-  if (!g_prof.on) return gemm_dispatch(p, tile, dma, a_kmajor, b_kmajor, splits, st);
+  if (!g_prof.on) return gemm_dispatch(p, tile, dma, bf, a_kmajor, b_kmajor, splits, st);
   if (g_prof.used + 2 > g_prof.ev.size()) {
     for (int i = 0; i < 2; ++i) { hipEvent_t e; MANSY_HIP_CHECK(hipEventCreate(&e)); g_prof.ev.push_back(e); }
   }
   MANSY_HIP_CHECK(hipEventRecord(g_prof.ev[g_prof.used], st));
-  const int rc = gemm_dispatch(p, tile, dma, a_kmajor, b_kmajor, splits, st);
+  const int rc = gemm_dispatch(p, tile, dma, bf, a_kmajor, b_kmajor, splits, st);
   MANSY_HIP_CHECK(hipEventRecord(g_prof.ev[g_prof.used + 1], st));
   g_prof.used += 2;
   g_prof.flops += 2.0 * (double)M * (double)N * (double)K * n_prob;

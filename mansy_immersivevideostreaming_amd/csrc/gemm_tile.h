@@ -1,0 +1,163 @@
+// Pieces shared by the GEMM main loops (gemm_f32.hip: exact-fp32 MFMA; gemm_bf16s.hip: split-bf16 MFMA): launch parameters and
+// the fused epilogue.  Both loops end with 32x32 MFMA accumulator blocks in the same register layout.
+#pragma once
+#include "mansy_kernels.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace mansy_gemm {
+
+constexpr int BK = 32;
+constexpr int KC_LD = BK + 4;   // K-contiguous LDS row stride (floats)
+constexpr int NT = 256;
+
+struct GemmParams {
+  const float* A; const float* B; float* C;
+  int lda, ldb, ldc;
+  int M, N, K;
+  int k_per_split;
+  int vec_ok;
+  int c_vec_ok;      // 16-byte epilogue legal: C, bias, mask, resid 16-B aligned, their lds and N multiples of 4
+  GemmEpilogue ep;
+  // optional second problem of identical shape in the same launch (LDS-DMA loop; grid.z = 2 x splits, problem slowest)
+  const float* A2 = nullptr; const float* B2 = nullptr; float* C2 = nullptr; float* a_rowsum2 = nullptr; int splits_pp = 1;
+};
+
+// Epilogue shared by both main loops.  C/D layout of the 32x32 MFMA block: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+// `smem` is the (now idle) staging LDS, at least BM*(BN+4) floats; SMEM_FLOATS is its size.
+template <int BM, int BN, int SMEM_FLOATS>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[BM / 64][BN / 64 > 0 ? BN / 64 : 1], float* smem, int m0, int n0,
+                                              int tid, int split, float* Cbase) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const GemmEpilogue& ep = p.ep;
+  const bool atomic = ep.accumulate || (gridDim.z > 1 && ep.split_slab == 0);
+  float* const Cz = Cbase + (long long)split * ep.split_slab;             // own slab per K split in slab mode
+  const float drop_scale = ep.drop.p > 0.f ? 1.f / (1.f - ep.drop.p) : 1.f;
+  if (!atomic && p.c_vec_ok) {
+    // Row-major 16-byte epilogue: the accumulators (one column per lane, 16 scattered rows) are transposed through the LDS
+    // staging buffers (free after the last barrier) so that bias / activation / mask / dropout / residual and the store all
+    // run on float4 rows: 16 global_store_dwordx4 per thread instead of 64 global_store_dword, coalesced 512-B row pieces.
+    constexpr int CLD = BN + 4;
+    static_assert(BM * CLD <= SMEM_FLOATS, "C tile must fit the staging LDS");
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          smem[(wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * CLD + wn * (BN / 2) + j * 32 + r] = acc[i][j][e];
+    __syncthreads();
+    constexpr int C4 = BN / 4;
+    constexpr int IT = BM * C4 / NT, GRP = IT < 4 ? IT : 4;
+    static_assert(BM * C4 % NT == 0 && IT % GRP == 0, "epilogue groups");
+    // Groups of GRP float4 per thread: the residual / mask loads of a whole group are issued before its first store (C may
+    // alias the residual, so the compiler will not move a load above a store by itself: one exposed L2/HBM round trip per
+    // float4 otherwise -- ~3 us on the [4096, 512] decoder products).
+#pragma unroll
+    for (int g0 = 0; g0 < IT; g0 += GRP) {
+      float4 rr[GRP], mk[GRP];
+      long long off_r[GRP], off_m[GRP];
+#pragma unroll
+      for (int u = 0; u < GRP; ++u) {
+        const int idx = tid + (g0 + u) * NT;
+        const int lr = idx / C4, c4 = idx % C4;
+        const int row = min(m0 + lr, p.M - 1), col = min(n0 + c4 * 4, p.N - 4);      // clamped: out-of-range float4 are not stored
+        off_r[u] = (long long)row * ep.resid_ld + col; off_m[u] = (long long)row * ep.mask_ld + col;
+        rr[u] = make_float4(0.f, 0.f, 0.f, 0.f); mk[u] = make_float4(1.f, 1.f, 1.f, 1.f);
+      }
+      if (ep.resid) {          // one uniform branch around the group's loads, not one per load
+#pragma unroll
+        for (int u = 0; u < GRP; ++u) rr[u] = *reinterpret_cast<const float4*>(ep.resid + off_r[u]);
+      }
+      if (ep.mask_src) {
+#pragma unroll
+        for (int u = 0; u < GRP; ++u) mk[u] = *reinterpret_cast<const float4*>(ep.mask_src + off_m[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < GRP; ++u) {
+        const int idx = tid + (g0 + u) * NT;
+        const int lr = idx / C4, c4 = idx % C4;
+        const int row = m0 + lr, col = n0 + c4 * 4;
+        if (row >= p.M || col >= p.N) continue;           // N % 4 == 0 on this path: a float4 is entirely in or out
+        float4 v = *reinterpret_cast<const float4*>(smem + lr * CLD + c4 * 4);
+        if (ep.bias) { const float4 b = *reinterpret_cast<const float4*>(ep.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+        if (ep.relu) {
+          v.x = v.x > 0.f ? v.x : v.x * ep.relu_slope; v.y = v.y > 0.f ? v.y : v.y * ep.relu_slope;
+          v.z = v.z > 0.f ? v.z : v.z * ep.relu_slope; v.w = v.w > 0.f ? v.w : v.w * ep.relu_slope;
+        }
+        if (ep.mask_src) {
+          v.x = mk[u].x > 0.f ? v.x * ep.mask_scale : v.x * ep.mask_neg; v.y = mk[u].y > 0.f ? v.y * ep.mask_scale : v.y * ep.mask_neg;
+          v.z = mk[u].z > 0.f ? v.z * ep.mask_scale : v.z * ep.mask_neg; v.w = mk[u].w > 0.f ? v.w * ep.mask_scale : v.w * ep.mask_neg;
+        }
+        if (ep.drop.p > 0.f) {
+          const uint32_t base = (uint32_t)row * (uint32_t)p.N + (uint32_t)col;
+          v.x = mansy_keep(ep.drop.seed, ep.drop.site, base + 0, ep.drop.p) ? v.x * drop_scale : 0.f;
+          v.y = mansy_keep(ep.drop.seed, ep.drop.site, base + 1, ep.drop.p) ? v.y * drop_scale : 0.f;
+          v.z = mansy_keep(ep.drop.seed, ep.drop.site, base + 2, ep.drop.p) ? v.z * drop_scale : 0.f;
+          v.w = mansy_keep(ep.drop.seed, ep.drop.site, base + 3, ep.drop.p) ? v.w * drop_scale : 0.f;
+        }
+        v.x += rr[u].x; v.y += rr[u].y; v.z += rr[u].z; v.w += rr[u].w;
+        *reinterpret_cast<float4*>(Cz + (long long)row * p.ldc + col) = v;
+      }
+    }
+    return;
+  }
+  // Scalar path (atomics / unaligned): loads (mask / residual) hoisted into unconditional clamped-address batches.
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * (BN / 2) + j * 32 + r;
+      const int colc = min(col, p.N - 1);
+      const int row_base = m0 + wm * (BM / 2) + i * 32 + 4 * h;
+      const float bias = ep.bias ? ep.bias[colc] : 0.f;
+      float v[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        v[e] = acc[i][j][e] + bias;
+        if (ep.relu) v[e] = v[e] > 0.f ? v[e] : v[e] * ep.relu_slope;
+      }
+      if (ep.mask_src) {
+        float mk[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          mk[e] = ep.mask_src[(long long)min(row_base + (e & 3) + 8 * (e >> 2), p.M - 1) * ep.mask_ld + colc];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = mk[e] > 0.f ? v[e] * ep.mask_scale : v[e] * ep.mask_neg;
+      }
+      if (ep.drop.p > 0.f) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const uint32_t row = (uint32_t)(row_base + (e & 3) + 8 * (e >> 2));
+          v[e] = mansy_keep(ep.drop.seed, ep.drop.site, row * (uint32_t)p.N + (uint32_t)col, ep.drop.p) ? v[e] * drop_scale : 0.f;
+        }
+      }
+      if (ep.resid) {
+        float rr[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          rr[e] = ep.resid[(long long)min(row_base + (e & 3) + 8 * (e >> 2), p.M - 1) * ep.resid_ld + colc];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] += rr[e];
+      }
+      if (col < p.N) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = row_base + (e & 3) + 8 * (e >> 2);
+          if (row < p.M) {
+            float* dst = Cz + (long long)row * p.ldc + col;
+            if (atomic) atomicAdd(dst, v[e]); else *dst = v[e];
+          }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace mansy_gemm
+
+// split-bf16 main loop (gemm_bf16s.hip); tile 128 -> 128x128, else 64x64; prec 3 = bf16x3, 6 = bf16x6
+int mansy_gemm_bf16s_dispatch(const mansy_gemm::GemmParams& p, int tile, int prec, int a_kmajor, int b_kmajor, int splits, hipStream_t st);

@@ -36,6 +36,8 @@ struct GemmEpilogue {
   // epilogue only, e.g. two dW products sharing an operand): C2 += A2 * B2, a_rowsum2 like a_rowsum.  Falls back to two
   // launches off the LDS-DMA loop.
   const float* pair_A = nullptr; const float* pair_B = nullptr; float* pair_C = nullptr; float* pair_rowsum = nullptr;
+  // precision of THIS product: -1 = the process-wide mode (mansy_set_gemm_precision), 0 fp32, 3 bf16x3, 6 bf16x6
+  int prec = -1;
 };
 int mansy_gemm_effective_splits(int K, int requested);
 int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb, int b_kmajor,

@@ -5,7 +5,8 @@ import math
 
 import torch
 
-from ._lib import AttnShape, GemmEpilogue, MansyError, check, lib, ptr, stream_ptr
+from ._lib import (AttnShape, GemmEpilogue, MansyError, check, lib, ptr, stream_ptr,   # noqa: F401
+                   PRECISIONS, get_precision, precision, set_precision)
 
 
 def _gpu(*ts):

@@ -85,6 +85,10 @@ class ViewportTransformerMTIO(nn.Module):
         self.repeat_prob = repeat_prob
         self.seed = seed
         self.has_bias = bool(bias)
+        # precision of the dense products: None = the process-wide mode (kernels.set_precision; 'f32' unless changed), or
+        # 'f32' (exact fp32 MFMA, the parity mode) / 'bf16x3' / 'bf16x6' (split-bf16 MFMA, csrc/gemm_bf16s.hip) for this
+        # model's calls only; a run-time attribute, not part of the checkpoint
+        self.precision = None
         self._ws = {}
         self._flat_p = None
         self._flat_g = None
@@ -329,8 +333,9 @@ class ViewportTransformerMTIO(nn.Module):
         arr, _ = self._pointers()
         pe, rm, rv, _nbt = self._engine_buffers()
         out = torch.empty(B, self.fut_window, self.in_channel, dtype=torch.float32, device=history.device)
-        check(lib().mansy_vp_sample(ctypes.byref(cfg), arr, ptr(pe), ptr(rm), ptr(rv), ptr(history), ptr(current), ptr(out),
-                                    ptr(ws), stream_ptr(history.device)), 'mansy_vp_sample')
+        with _lib.precision(self.precision):
+            check(lib().mansy_vp_sample(ctypes.byref(cfg), arr, ptr(pe), ptr(rm), ptr(rv), ptr(history), ptr(current), ptr(out),
+                                        ptr(ws), stream_ptr(history.device)), 'mansy_vp_sample')
         return out
 
     # ------------------------------------------------------------------ fused fast path
@@ -356,11 +361,12 @@ class ViewportTransformerMTIO(nn.Module):
         g = optimizer.param_groups[0]
         engine_step = optimizer.step_count if grad_sync is None else 0
         loss = torch.empty((), dtype=torch.float32, device=history.device)
-        check(lib().mansy_vp_train_step(
-            ctypes.byref(cfg), arr, garr, ptr(self._flat_p), ptr(self._flat_g), ptr(optimizer.exp_avg), ptr(optimizer.exp_avg_sq),
-            self._flat_p.numel(), ptr(pe), ptr(rm), ptr(rv), ptr(nbt), ptr(history), ptr(current), ptr(future), ptr(p1), ptr(p2),
-            g['lr'], g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], engine_step, ptr(loss), ptr(ws),
-            self._next_seed(), stream_ptr(history.device)), 'mansy_vp_train_step')
+        with _lib.precision(self.precision):
+            check(lib().mansy_vp_train_step(
+                ctypes.byref(cfg), arr, garr, ptr(self._flat_p), ptr(self._flat_g), ptr(optimizer.exp_avg), ptr(optimizer.exp_avg_sq),
+                self._flat_p.numel(), ptr(pe), ptr(rm), ptr(rv), ptr(nbt), ptr(history), ptr(current), ptr(future), ptr(p1), ptr(p2),
+                g['lr'], g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], engine_step, ptr(loss), ptr(ws),
+                self._next_seed(), stream_ptr(history.device)), 'mansy_vp_train_step')
         if grad_sync is not None:
             grad_sync(self._flat_g)
             optimizer.apply_flat()
@@ -379,8 +385,9 @@ class _VPFunction(torch.autograd.Function):
         seed = model._next_seed() if model.training else 0
         model._arm_bn_sync(cfg)
         pred = torch.empty(B, model.fut_window, cfg.in_ch, dtype=torch.float32, device=src.device)
-        check(lib().mansy_vp_forward(ctypes.byref(cfg), arr, ptr(pe), ptr(rm), ptr(rv), ptr(nbt), ptr(src), ptr(cur.reshape(B, -1)),
-                                     ptr(pred), ptr(ws), int(model.training), seed, stream_ptr(src.device)), 'mansy_vp_forward')
+        with _lib.precision(model.precision):
+            check(lib().mansy_vp_forward(ctypes.byref(cfg), arr, ptr(pe), ptr(rm), ptr(rv), ptr(nbt), ptr(src), ptr(cur.reshape(B, -1)),
+                                         ptr(pred), ptr(ws), int(model.training), seed, stream_ptr(src.device)), 'mansy_vp_forward')
         ctx.model, ctx.cfg, ctx.seed, ctx.src, ctx.train = model, cfg, seed, src, model.training
         return pred
 
@@ -393,8 +400,9 @@ class _VPFunction(torch.autograd.Function):
         model._arm_bn_sync(ctx.cfg)
         arr, garr = model._pointers(gflat)
         ws = model._workspace(ctx.cfg)
-        check(lib().mansy_vp_backward(ctypes.byref(ctx.cfg), arr, garr, ptr(ctx.src), ptr(dpred.contiguous()), ptr(ws), ctx.seed,
-                                      stream_ptr(dpred.device)), 'mansy_vp_backward')
+        with _lib.precision(model.precision):
+            check(lib().mansy_vp_backward(ctypes.byref(ctx.cfg), arr, garr, ptr(ctx.src), ptr(dpred.contiguous()), ptr(ws), ctx.seed,
+                                          stream_ptr(dpred.device)), 'mansy_vp_backward')
         grads = tuple(gflat[o:o + p.numel()].view(p.shape) for p, o in zip(model._params, model._offsets))
         return (None, None, None) + grads
 

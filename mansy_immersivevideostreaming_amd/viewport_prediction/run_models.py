@@ -18,6 +18,7 @@ import sys
 import numpy as np
 import torch
 
+from .. import _lib
 from .models import FusedAdamW, ViewportTransformerMTIO
 from .utils.common import get_config_from_yml, mean_square_error
 from .utils.load_dataset import DeviceLoader, create_dataset
@@ -36,6 +37,8 @@ _FLAGS = [
     ('--lr', dict(type=float, default=1e-4)), ('--weight-decay', dict(type=float)),       # parsed, unused (reference :190)
     ('--bs', dict(type=int)), ('--seed', dict(type=int, default=5)),
     ('--config', dict(type=str, default=None)), ('--verbose-steps', dict(action='store_true')),
+    # addition of this build: precision of the dense products (f32 = exact fp32 MFMA, the parity mode; bf16x3 / bf16x6 = split-bf16 MFMA)
+    ('--precision', dict(choices=('f32', 'bf16x3', 'bf16x6'), default='f32')),
 ]
 _CONFIG_DEFAULTS = {'trim_head': 'trim_head', 'trim_tail': 'trim_tail', 'dataset_frequency': 'frequency', 'sample_step': 'sample_step'}
 
@@ -145,6 +148,7 @@ class Session:
 def run(args, config):
     for seeder in (np.random.seed, torch.manual_seed, torch.cuda.manual_seed_all, random.seed):
         seeder(args.seed)
+    _lib.set_precision(getattr(args, 'precision', 'f32'))
     session = Session(args, config)
     if args.train:
         log = open(os.path.join(session.results_dir, session.stem + 'console.log'), 'w')

@@ -10,7 +10,7 @@ import os
 import numpy as np
 import torch
 
-from ..._lib import check, lib, ptr, stream_ptr
+from ..._lib import MansyError, check, lib, ptr, stream_ptr
 
 
 class ViewportDataset:
@@ -41,6 +41,13 @@ class ViewportDataset:
         """Builds the HBM table once: [n_trace, Lmax, 2] + int32 [n_samples, 2] (slot, timestep)."""
         if self._device_table is not None and self._device_table[0].device == torch.device(device):
             return self._device_table
+        # The gather kernel reads table[slot, t - S .. t + T] unchecked.  A window that leaves its trace (trim_head <
+        # his_window or trim_tail < fut_window + 1) gives ragged items in the reference, which then fails in collate; fail here.
+        S, T = self.history_window, self.future_window
+        for v, u, t in self.trace_indices:
+            if t - S < 0 or t + T + 1 > len(self.total_traces[v][u]):
+                raise MansyError(f'sample (video {v}, user {u}, timestep {t}) needs samples {t - S}..{t + T} of a trace of '
+                                 f'{len(self.total_traces[v][u])}: trim_head must be >= his_window ({S}) and trim_tail >= fut_window ({T})')
         pairs = [(v, u) for v in self.videos for u in self.users]
         slot = {p: i for i, p in enumerate(pairs)}
         lmax = max(len(self.total_traces[v][u]) for v, u in pairs)

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Per-shape timing of the fp32 MFMA GEMM on the shapes the VP train step launches (B=4096)."""
+"""Per-shape timing of the MFMA GEMM on the shapes the VP train step launches (B=4096).
+    python tools/gemm_bench.py [tile ...] [--prec f32|bf16x3|bf16x6 ...] [--check]
+--check additionally reports the max error of every (shape, mode) against a float64 product, relative to max|C|."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,14 +15,33 @@ SHAPES = [  # (name, a_kmajor, b_kmajor, M, N, K, accumulate, count per step)
     ('dW 512x512 TN', 1, 1, 512, 512, 40960, 1, 16), ('dW 1536x512 TN', 1, 1, 1536, 512, 40960, 1, 4), ('dW conv 512x1536 TN', 1, 1, 512, 1536, 40960, 1, 1),
     ('dW kv 1024x512 TN', 1, 1, 1024, 512, 20480, 1, 2),
 ]
-tiles = [int(x) for x in sys.argv[1:]] or [0]
+args = sys.argv[1:]
+CHECK = '--check' in args
+precs = []
+while '--prec' in args:
+    i = args.index('--prec')
+    precs.append(args[i + 1])
+    del args[i:i + 2]
+precs = precs or ['f32']
+tiles = [int(x) for x in args if x != '--check'] or [0]
+tiles = [(t, pr) for pr in precs for t in tiles]
 tot = {t: 0.0 for t in tiles}
 for name, ak, bk, M, N, Kd, acc, cnt in SHAPES:
     A = torch.randn((Kd, M) if ak else (M, Kd), device='cuda')
     B = torch.randn((Kd, N) if bk else (N, Kd), device='cuda')
     out = torch.zeros(M, N, device='cuda')
     line = f'{name:22s} M={M:6d} N={N:5d} K={Kd:6d}'
-    for t in tiles:
+    ref = None
+    if CHECK:
+        Ad, Bd = A.double(), B.double()
+        ref = (Ad.t() if ak else Ad) @ (Bd if bk else Bd.t())
+    for tp in tiles:
+        t, pr = tp
+        K.set_precision(pr)
+        if CHECK:
+            out.zero_()
+            K.gemm(A, B, bool(ak), bool(bk), out=out, accumulate=bool(acc), force_tile=t)
+            err = ((out.double() - ref).abs().max() / ref.abs().max()).item()
         for _ in range(3):
             K.gemm(A, B, bool(ak), bool(bk), out=out, accumulate=bool(acc), force_tile=t)
         torch.cuda.synchronize()
@@ -33,7 +54,8 @@ for name, ak, bk, M, N, Kd, acc, cnt in SHAPES:
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / n * 1e3
         tf = 2.0 * M * N * Kd / us / 1e6
-        tot[t] += us * cnt
-        line += f' | tile {t:3d}: {us:8.1f} us {tf:6.1f} TF'
+        tot[tp] += us * cnt
+        line += f' | {pr} tile {t:3d}: {us:8.1f} us {tf:6.1f} TF' + (f' err {err:.1e}' if CHECK else '')
     print(line)
-print('per-step GEMM total (ms):', {t: round(v / 1e3, 2) for t, v in tot.items()})
+K.set_precision('f32')
+print('per-step GEMM total (ms):', {f'{pr}/{t}': round(v / 1e3, 2) for (t, pr), v in tot.items()})
