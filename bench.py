@@ -14,7 +14,11 @@ Prints ONE JSON line (rank 0).  Extra objects:
                the launch stream in a separate instrumented leg of the same workload.
                `model_frac` = trajectories/s x 0.522 GFLOP / peak (whole-step MFMA utilisation, north_star).
   cpu_baseline the oracle (CPU restatement, torch fp32, autograd) timed on the host cores on a bounded
-               sample (B=32 steps for ~15 s), kind "port".
+               sample (B=32 steps, thread counts 1/8/16/32/all swept inside a ~15 s budget, best reported), kind "port".
+  precision_modes  the same step with the dense products in the split-bf16 modes (bf16x3, bf16x6: csrc/gemm_bf16s.hip), each
+               with its own roofline object priced against the dense BF16 MFMA peak.  The fp32 line stays the headline.
+  secondary    PPO env-steps/s (configs[2]) with its own roofline object (MFMA fraction on 11.5 MFLOP, HBM fraction on 29 KB per
+               env-step, the dominant kernel's live launch timing, and the launch-latency floor of the cycle).
 """
 import argparse
 import ctypes
@@ -29,6 +33,13 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_TRAJ = 0.522e9          # fwd+bwd algorithmic FLOPs per trajectory (d=ff=512, S=T=10, 2+2 layers)
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: FP32 matrix peak (spec)
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense BF16 MFMA peak (spec; random-data loops hold ~1.25-1.5 PF: DVFS)
+PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E
+PPO_FLOP_PER_ENV_STEP = 11.5e6   # rollout 0.523 + update 10.95 MFLOP per env-step, as written
+PPO_BYTES_PER_ENV_STEP = 29e3    # 3 116 B observation written + ~8.2 reads of it across the update passes
+PPO_LAUNCHES_PER_CYCLE = 307     # kernels per collect + identifier + update cycle (rocprofv3 kernel trace)
+PPO_LAUNCHES_SOURCE = 'profiles/r01m_ppo_kernel_stats.csv'
+LAUNCH_FLOOR_US = 5.0            # dependent-launch floor on this chip (K -> 0 intercept of a [4096,512] product)
 
 
 def replica_spread(flat, world):
@@ -58,6 +69,9 @@ def synthetic_trajectories(B, S, T, seed=5):
 
 
 def cpu_baseline(seconds=15.0):
+    """The VP oracle (KV-cached restatement, torch fp32 autograd + AdamW) on the host cores: thread counts are swept inside the
+    budget and the best is reported (320-token GEMMs do not scale to every core of a 2-socket host; the round-1 line ran all
+    128 threads and understated the CPU)."""
     import torch
     from oracle import vp_oracle as vo
     B, S, T, d = 32, 10, 10, 512
@@ -70,35 +84,73 @@ def cpu_baseline(seconds=15.0):
     h, c, f = vo.synthetic_trajectories(B, S, T, seed=5)
     m = {k: torch.zeros_like(v) for k, v in params.items()}
     v2 = {k: torch.zeros_like(v) for k, v in params.items()}
-    n, t0 = 0, time.time()
-    while True:
+    step_no = [0]
+
+    def one_step():
         src, cur, gt = vo.mtio_mix(h, c, f, 3, True, None)
         loss = orc.loss_function(orc.process_src_current(src, cur, train=True), gt)
         for p in params.values():
             p.grad = None
         loss.backward()
+        step_no[0] += 1
         with torch.no_grad():
             for k, p in params.items():
-                p1, m[k], v2[k] = vo.adamw_step(p, p.grad, m[k], v2[k], step=n + 1)
+                p1, m[k], v2[k] = vo.adamw_step(p, p.grad, m[k], v2[k], step=step_no[0])
                 p.copy_(p1)
-        n += 1
-        if time.time() - t0 > seconds and n >= 2:
-            break
-    dt = time.time() - t0
-    return {'value': round(n * B / dt, 2), 'unit': 'trajectories/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'{n} train steps of B={B} (S=T=10, d=512, 2+2 layers, dropout off, KV-cached oracle) in {dt:.1f}s'}
+
+    all_threads = torch.get_num_threads()
+    counts = sorted({n for n in (1, 8, 16, 32, all_threads) if n <= all_threads})
+    one_step()                                            # warm-up (allocator, autograd graph caches)
+    sweep, best = {}, (0.0, all_threads, 0, 0.0)
+    per = seconds / len(counts)
+    for nt in counts:
+        torch.set_num_threads(nt)
+        n, t0 = 0, time.time()
+        while True:
+            one_step()
+            n += 1
+            if time.time() - t0 > per and n >= 2:
+                break
+        dt = time.time() - t0
+        sweep[str(nt)] = round(n * B / dt, 2)
+        if n * B / dt > best[0]:
+            best = (n * B / dt, nt, n, dt)
+    torch.set_num_threads(all_threads)
+    return {'value': round(best[0], 2), 'unit': 'trajectories/s', 'cores': best[1], 'kind': 'port',
+            'sample': f'{best[2]} train steps of B={B} (S=T=10, d=512, 2+2 layers, dropout off, KV-cached oracle) in {best[3]:.1f}s on '
+                      f'{best[1]} threads (best of the sweep)',
+            'thread_sweep_traj_per_s': sweep, 'host_threads': all_threads,
+            # the reference re-runs the decoder on the growing target (55 token-positions instead of 10) and re-projects the cross
+            # K/V at every step: 1.945 vs 0.522 GFLOP per trajectory fwd+bwd -- the port above does the minimal work
+            'reference_as_written_flop_factor': round(1.945 / 0.522, 2),
+            'survey_container_reference_traj_per_s': {'value': 84, 'cores': 8, 'note': 'imported reference, B=32, SURVEY section 6'}}
 
 
-def _pmc_traffic():
-    """HBM-side bytes per GEMM launch from the newest committed rocprofv3 PMC aggregate (profiles/r*_pmc_gemm.json, written by
-    tools/pmc_aggregate.py from separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 per the gfx950 correction); PMC cannot
-    be collected from inside this process."""
+def _pmc_traffic(pattern='r*_pmc_gemm.json'):
+    """HBM-side bytes per GEMM launch from the newest committed rocprofv3 PMC aggregate (profiles/<round tag>_pmc_gemm*.json,
+    written by tools/pmc_aggregate.py from separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 per the gfx950 correction);
+    PMC cannot be collected from inside this process.  Returns (bytes per launch, file name) -- the file is named in the bench
+    line so that a stale aggregate is visible."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_gemm.json')))
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', pattern)))
     try:
-        return json.load(open(files[-1]))['traffic_bytes_per_launch']
+        return json.load(open(files[-1]))['traffic_bytes_per_launch'], 'profiles/' + os.path.basename(files[-1])
     except Exception:
-        return None
+        return None, None
+
+
+def _gemm_prof(L, fn, reps):
+    """HIP events around every GEMM launch of `reps` calls of fn (rank 0's launch stream): (ms, launches, exact FLOPs)."""
+    from mansy_immersivevideostreaming_amd._lib import check
+    import torch
+    check(L.mansy_prof_gemm_enable(1), 'prof_enable')
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    ms, n, fl = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double()
+    check(L.mansy_prof_gemm_collect(ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), 'prof_collect')
+    check(L.mansy_prof_gemm_enable(0), 'prof_disable')
+    return ms.value, n.value, fl.value
 
 
 def bench_ppo(rank, world, dev, mdist, cycles=5, warmup=2, n_env=256, steps_per_env=16, rollout_probe=True):
@@ -161,7 +213,35 @@ def bench_ppo(rank, world, dev, mdist, cycles=5, warmup=2, n_env=256, steps_per_
         col.collect(steps_per_env * n_env, buf)
     torch.cuda.synchronize()
     t_collect = max(time.perf_counter() - tc, 1e-9)
+    # ---- roofline leg (after the timed region): HIP events around the directly launched GEMMs of the update half of a cycle (the
+    # rollout half replays a hipGraph: its 2 products per vector step are not seen by the recorder and are counted analytically)
+    roof = None
+    nprof = 2
+    from mansy_immersivevideostreaming_amd._lib import lib
+    if rank == 0:
+        ms_g, n_g, fl_g = _gemm_prof(lib(), cycle, nprof)
+    else:
+        for _ in range(nprof):
+            cycle()
+        torch.cuda.synchronize()
     steps = world * n_env * steps_per_env * cycles
+    if rank == 0:
+        eps = steps / dt / world                                      # env-steps/s of this GPU
+        gemm_tf = fl_g / (ms_g * 1e-3) / 1e12 if ms_g > 0 else 0.0
+        roof = {'bound': 'mfma', 'kernel': 'gemm_f32_dma_kernel (FeatureNet block-diagonal product, heads, dF / dW products of the update)',
+                'achieved': round(eps * PPO_FLOP_PER_ENV_STEP / 1e12, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(eps * PPO_FLOP_PER_ENV_STEP / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+                'note': 'whole cycle on the as-written 11.5 MFLOP per env-step; the cycle is launch- and dependency-bound, not MFMA-bound',
+                'hbm': {'achieved': round(eps * PPO_BYTES_PER_ENV_STEP / 1e9, 2), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                        'frac': round(eps * PPO_BYTES_PER_ENV_STEP / 1e9 / PEAK_HBM_GBS, 5)},
+                'dominant_kernel_live': {'gemm_launches_per_cycle_update_half': n_g // nprof, 'avg_launch_us': round(ms_g * 1e3 / max(n_g, 1), 2),
+                                         'gemm_ms_per_cycle': round(ms_g / nprof, 3), 'gemm_tflops': round(gemm_tf, 2),
+                                         'gemm_frac_of_peak': round(gemm_tf / PEAK_F32_MFMA_TFLOPS, 4),
+                                         'rollout_gemm_launches_per_cycle_in_graph': 2 * steps_per_env},
+                'launch_floor': {'us_per_dependent_launch': LAUNCH_FLOOR_US, 'launches_per_cycle': PPO_LAUNCHES_PER_CYCLE,
+                                 'source': PPO_LAUNCHES_SOURCE,
+                                 'floor_ms_per_cycle': round(PPO_LAUNCHES_PER_CYCLE * LAUNCH_FLOOR_US * 1e-3, 3),
+                                 'measured_ms_per_cycle': round(dt / cycles * 1e3, 3)}}
     spread = max(replica_spread(pol.engine.ac.flat_p, world), replica_spread(pol.engine.idn.flat_p, world))
     return {'metric': 'PPO env-steps/sec', 'value': round(steps / dt, 1), 'unit': 'env-steps/s', 'n_gpus': world, 'cycles': cycles,
             'replica_param_spread': spread,
@@ -170,7 +250,8 @@ def bench_ppo(rank, world, dev, mdist, cycles=5, warmup=2, n_env=256, steps_per_
             'config': {'workload': f'{n_env} device-resident envs/GPU x {steps_per_env} steps per collect (4096 transitions/GPU), '
                                    'identifier train (2 full-batch rounds) + relabel + PPO update (minibatch 512, repeat 2), synthetic '
                                    'Jin2022/4G-shaped tables, fp32', 'parallelism': f'dp{world}'},
-            'model_flops_per_env_step': 11.5e6, 'algorithmic_bytes_per_env_step': 29e3}
+            'model_flops_per_env_step': PPO_FLOP_PER_ENV_STEP, 'algorithmic_bytes_per_env_step': PPO_BYTES_PER_ENV_STEP, 'dtype': 'f32',
+            'roofline': roof}
 
 
 def bench_vp_inference(model, h, c, f, reps=5):
@@ -357,22 +438,61 @@ def main():
     nprof = max(1, min(args.steps, 3))
     L = lib()
     if rank == 0:
-        check(L.mansy_prof_gemm_enable(1), 'prof_enable')
-    for _ in range(nprof):
-        step()
-    torch.cuda.synchronize()
-    if rank == 0:
-        ms, n, fl = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double()
-        check(L.mansy_prof_gemm_collect(ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), 'prof_collect')
-        check(L.mansy_prof_gemm_enable(0), 'prof_disable')
-        achieved = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        ms, n, fl = _gemm_prof(L, step, nprof)
+        achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        traffic, traffic_src = _pmc_traffic('r*_pmc_gemm.json')
         roof = {'bound': 'mfma', 'kernel': 'gemm_f32_dma_kernel (v_mfma_f32_32x32x2_f32, LDS-DMA staged)', 'achieved': round(achieved, 2),
                 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                'traffic': _pmc_traffic(),
-                'launches_per_step': n.value // nprof, 'avg_launch_us': round(ms.value * 1e3 / max(n.value, 1), 2),
-                'gemm_flops_per_step': fl.value / nprof, 'gemm_ms_per_step': round(ms.value / nprof, 3),
+                'traffic': traffic, 'traffic_source': traffic_src,
+                'launches_per_step': n // nprof, 'avg_launch_us': round(ms * 1e3 / max(n, 1), 2),
+                'gemm_flops_per_step': fl / nprof, 'gemm_ms_per_step': round(ms / nprof, 3),
                 'algorithmic_flops_per_step': FLOP_PER_TRAJ * B,
                 'model_frac': round(value / world * FLOP_PER_TRAJ / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+    else:
+        for _ in range(nprof):
+            step()
+        torch.cuda.synchronize()
+
+    # ---- the same step in the split-bf16 precision modes (secondary lines; every rank runs them: collectives inside)
+    modes = []
+    for mode, nprod in (('bf16x3', 3), ('bf16x6', 6)):
+        model.precision = mode
+        for _ in range(2):
+            step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        tm = time.perf_counter()
+        for _ in range(args.steps):
+            mloss = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dtm = time.perf_counter() - tm
+        if world > 1:
+            t = torch.tensor([dtm], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtm = t.item()
+        if rank == 0:
+            ms, n, fl = _gemm_prof(L, step, nprof)
+            alg_tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            traffic, traffic_src = _pmc_traffic(f'r*_pmc_gemm_{mode}.json')
+            vm = world * B * args.steps / dtm
+            modes.append({'dtype': mode, 'metric': 'viewport-trajectories/sec (VP train)', 'value': round(vm, 1), 'unit': 'trajectories/s',
+                          'ms_per_step': round(dtm / args.steps * 1e3, 3), 'final_loss': float(mloss.item()), 'speedup_vs_f32': round(vm / value, 3),
+                          'roofline': {'bound': 'mfma', 'kernel': f'gemm_bf16s_kernel (v_mfma_f32_32x32x16_bf16, {nprod} bf16 products per fp32 product, '
+                                                                  'operands split in the staging pass)',
+                                       # executed bf16 MFMA FLOPs = nprod x the algorithmic (fp32-product) FLOPs
+                                       'achieved': round(alg_tf * nprod, 2), 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                                       'frac': round(alg_tf * nprod / PEAK_BF16_MFMA_TFLOPS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
+                                       'algorithmic_tflops': round(alg_tf, 2), 'launches_per_step': n // nprof,
+                                       'avg_launch_us': round(ms * 1e3 / max(n, 1), 2), 'gemm_ms_per_step': round(ms / nprof, 3),
+                                       'model_frac_of_f32_peak': round(vm / world * FLOP_PER_TRAJ / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}})
+        else:
+            for _ in range(nprof):
+                step()
+            torch.cuda.synchronize()
+    model.precision = None
 
     vp_spread = replica_spread(model._flat_p, world)
     ppo = bench_ppo(rank, world, dev, mdist, cycles=max(2, min(args.steps, 6)), warmup=2)
@@ -387,6 +507,7 @@ def main():
                                    f'fp32 MFMA', 'global_batch': B * world, 'parallelism': f'dp{world}'},
             'final_loss': loss_val, 'replica_param_spread': vp_spread,
             'roofline': roof,
+            'precision_modes': modes,
             'secondary': ppo,
         }
         if world == 1 and not args.no_cpu_baseline:

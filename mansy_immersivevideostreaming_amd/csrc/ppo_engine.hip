@@ -1005,7 +1005,8 @@ int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, fl
   RC(e.featnet(obs, mb, 0));
   LossFuse lf;
   lf.on = 1; lf.act = act_all; lf.adv = adv_all; lf.logp_old = logp_old_all; lf.v_old = v_old_all; lf.ret = ret_all; lf.idx = idx; lf.n = mb;
-  lf.eps_clip = eps_clip; lf.vf_coef = vf_coef; lf.ent_coef = ent_coef; lf.norm_adv = norm_adv; lf.value_clip = value_clip; lf.adv_eps = 1e-8f;
+  lf.eps_clip = eps_clip; lf.vf_coef = vf_coef; lf.ent_coef = ent_coef; lf.norm_adv = norm_adv; lf.value_clip = value_clip;
+  lf.adv_eps = 0.f;   // T2: tianshou 0.4.8 ppo.py divides by the bare unbiased std (`(adv - mean) / std  # per-batch norm`); `+ self._eps` is 0.5.0's
   lf.adv_stats = e.W.adv_stats; lf.dlogits = e.W.gout; lf.dvalue = e.W.gout_c; lf.dvalue_ld = MAXOUT; lf.lossrows = e.W.lossrows;
   RC(e.head_pair(a, c, mb, &lf));
   LossFinish fin; fin.lossrows = e.W.lossrows; fin.n = mb; fin.vf_coef = vf_coef; fin.ent_coef = ent_coef; fin.stats = stats;

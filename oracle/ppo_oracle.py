@@ -136,10 +136,13 @@ def compute_returns(rew, v_s, v_s_next, done, end_flag, ret_rms, gamma=0.95, lam
 
 
 def ppo_loss(logits, value, act, adv, logp_old, v_old, returns, eps_clip=0.2, vf_coef=0.5, ent_coef=0.02, norm_adv=True,
-             value_clip=True, eps=1e-8):
+             value_clip=True, eps=0.0):
     """T2: PPOPolicy.learn body for one minibatch -> (loss, clip_loss, vf_loss, ent_loss)."""
     if norm_adv:
-        adv = (adv - adv.mean()) / (adv.std() + eps)            # T2: unbiased std
+        # T2 (release 0.4.8, tianshou/policy/modelfree/ppo.py): `mean, std = b.adv.mean(), b.adv.std(); b.adv = (b.adv - mean) / std
+        # # per-batch norm` -- torch's unbiased std, NO epsilon (the `+ self._eps` form is release 0.5.0's); eps stays a parameter
+        # for callers restating the later release
+        adv = (adv - adv.mean()) / (adv.std() + eps)
     logp_all = torch.log_softmax(logits, dim=-1)
     logp = logp_all.gather(1, act.long()[:, None])[:, 0]
     ratio = (logp - logp_old).exp()

@@ -7,27 +7,32 @@ import csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+KERNEL = 'gemm_f32'
+
+
 def total(dirname, counter):
     files = sorted(glob.glob(os.path.join(ROOT, 'gpurun_out', dirname, '**', '*_counter_collection.csv'), recursive=True), key=os.path.getmtime)
     if not files:
         raise SystemExit(f'no counter_collection.csv under gpurun_out/{dirname}')
     s, n = 0.0, 0
     for r in csv.DictReader(open(files[-1])):
-        if r['Counter_Name'] == counter and 'gemm_f32' in r['Kernel_Name']:
+        if r['Counter_Name'] == counter and KERNEL in r['Kernel_Name']:
             s += float(r['Counter_Value']); n += 1
     return s * 1024.0, n
 
 
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
 alg = float(sys.argv[2]) if len(sys.argv) > 2 else 50011000.0
+KERNEL = sys.argv[3] if len(sys.argv) > 3 else 'gemm_f32'          # kernel-name substring: gemm_f32 | gemm_bf16s
+suffix = sys.argv[4] if len(sys.argv) > 4 else ''                   # file name suffix, e.g. _bf16x3
 fetch, n = total('pmc_r', 'FETCH_SIZE')
 write, n2 = total('pmc_w', 'WRITE_SIZE')
 assert n == n2 and n > 0, (n, n2)
-out = {'kernel': 'gemm_f32_dma_kernel / gemm_f32_kernel', 'launches': n, 'fetch_bytes_per_launch': 2.0 * fetch / n, 'write_bytes_per_launch': write / n,
+out = {'kernel': 'gemm_f32_dma_kernel / gemm_f32_kernel' if KERNEL == 'gemm_f32' else 'gemm_bf16s_kernel', 'launches': n, 'fetch_bytes_per_launch': 2.0 * fetch / n, 'write_bytes_per_launch': write / n,
        'traffic_bytes_per_launch': (2.0 * fetch + write) / n, 'algorithmic_bytes_per_launch': alg,
        'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over 2 train steps (B=4096, 285 GEMM launches per step); '
                'FETCH_SIZE x2 per the gfx950 correction (MI355X_MICROARCH.md, HBM); the counters sit at the L2<->fabric boundary, so '
                'Infinity-Cache hits are included'}
-path = os.path.join(ROOT, 'profiles', f'{tag}_pmc_gemm.json')
+path = os.path.join(ROOT, 'profiles', f'{tag}_pmc_gemm{suffix}.json')
 json.dump(out, open(path, 'w'), indent=1)
 print(path, json.dumps(out)[:300])
