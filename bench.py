@@ -171,10 +171,8 @@ def bench_ppo(rank, world, dev, mdist, cycles=5, warmup=2, n_env=256, steps_per_
     fn = mm.FeatureNet(8, 64, 5, 128, device=dev)
     actor, critic = mm.Actor(fn, 1280, 128, 15, dev), mm.Critic(fn, 1280, 128, dev)
     ident = mm.QoEIdentifier(mm.QoEIdentifierFeatureNet(8, 64, 5, 15, 128, device=dev), 1280, 128, dev)
-    for m in list(actor.modules()) + list(critic.modules()) + list(ident.modules()):
-        if isinstance(m, torch.nn.Linear):
-            torch.nn.init.orthogonal_(m.weight, gain=np.sqrt(2))
-            torch.nn.init.zeros_(m.bias)
+    mm.orthogonal_init(actor, critic)
+    mm.orthogonal_init(ident)
     optim = torch.optim.Adam(actor.parameters(), lr=5e-4, weight_decay=1e-2)
     ioptim = torch.optim.Adam(ident.parameters(), lr=1e-4, weight_decay=1e-2)
     pol = PPOPolicy(actor, critic, optim, None, discount_factor=0.95, max_grad_norm=1.0, eps_clip=0.2, vf_coef=0.5, ent_coef=0.02,

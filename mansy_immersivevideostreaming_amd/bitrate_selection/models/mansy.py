@@ -138,6 +138,18 @@ class _Seq0(nn.Module):
         return self._modules['0'].bias
 
 
+def orthogonal_init(*nets):
+    """The reference's initialisation loop (run_mansy.py:209-213, 218-222; run_simple_rl.py:182-186):
+        for m in model.modules(): if isinstance(m, nn.Linear): orthogonal_(m.weight, gain=sqrt(2)); zeros_(m.bias)
+    where `model` is tianshou's ActorCritic(actor, critic) -- ONE container, so modules() visits the feature net the two heads
+    share once (two separate traversals would re-draw it and shift the RNG stream).  Pass (actor, critic) or (identifier,)."""
+    seen = nn.ModuleList(list(nets))
+    for m in seen.modules():
+        if isinstance(m, nn.Linear):
+            nn.init.orthogonal_(m.weight, gain=np.sqrt(2))
+            nn.init.zeros_(m.bias)
+
+
 class FeatureNet(nn.Module):
     """mansy.py:5-51 (parameter container; evaluated inside the engine as one block-diagonal MFMA product)."""
     IDENTIFIER = False

@@ -22,7 +22,7 @@ from torch.distributions import Categorical
 
 from .. import _lib
 from .envs.mansy_env import EnvTables, MANSYVecEnv
-from .models.mansy import Actor, Critic, FeatureNet, QoEIdentifier, QoEIdentifierFeatureNet
+from .models.mansy import Actor, Critic, FeatureNet, QoEIdentifier, QoEIdentifierFeatureNet, orthogonal_init
 from .models.mansy_ppo import PPOPolicy, VecCollector
 from .models.mansy_trainer import OnpolicyTrainer, run_episodes, write_episode_log
 from .utils.common import get_config_from_yml, read_log_file
@@ -147,19 +147,13 @@ def run(args, config):
     feature_net = FeatureNet(config.past_k, config.tile_total_num, len(config.video_rates), args.hidden_dim, device=args.device)
     actor = Actor(feature_net, feature_dim=feature_dim, hidden_dim=args.hidden_dim, action_space=config.action_space, device=args.device)
     critic = Critic(feature_net, feature_dim=feature_dim, hidden_dim=args.hidden_dim, device=args.device)
-    for m in list(actor.modules()) + list(critic.modules()):
-        if isinstance(m, torch.nn.Linear):
-            torch.nn.init.orthogonal_(m.weight, gain=np.sqrt(2))
-            torch.nn.init.zeros_(m.bias)
+    orthogonal_init(actor, critic)
     ac_params = list(actor.parameters()) + [p for n, p in critic.named_parameters() if not n.startswith('feature_net.')]
     optimizer = torch.optim.Adam(ac_params, lr=args.lr, weight_decay=args.weight_decay)
     identifier_feature_net = QoEIdentifierFeatureNet(config.past_k, config.tile_total_num, len(config.video_rates), config.action_space,
                                                      args.hidden_dim, device=args.device)
     identifier = QoEIdentifier(identifier_feature_net, feature_dim=feature_dim, hidden_dim=args.hidden_dim, device=args.device)
-    for m in identifier.modules():
-        if isinstance(m, torch.nn.Linear):
-            torch.nn.init.orthogonal_(m.weight, gain=np.sqrt(2))
-            torch.nn.init.zeros_(m.bias)
+    orthogonal_init(identifier)
     identifier_optimizer = torch.optim.Adam(identifier.parameters(), lr=args.identifier_lr, weight_decay=args.weight_decay)
     policy = PPOPolicy(actor, critic, optimizer, lambda logits: Categorical(logits=logits), discount_factor=args.gamma,
                        max_grad_norm=args.max_grad_norm, eps_clip=args.eps_clip, vf_coef=args.vf_coef, ent_coef=args.ent_coef,

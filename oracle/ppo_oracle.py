@@ -160,6 +160,106 @@ def ppo_loss(logits, value, act, adv, logp_old, v_old, returns, eps_clip=0.2, vf
     return loss, clip_loss, vf_loss, ent
 
 
+def split_indices(length, size, shuffle=True, merge_last=True):
+    """T2: tianshou Batch.split(size, shuffle=True, merge_last=True): np.random.permutation, chunks of `size`, a last chunk
+    shorter than `size` is merged into the one before it."""
+    indices = np.random.permutation(length) if shuffle else np.arange(length)
+    merge_last = merge_last and length % size > 0
+    out = []
+    for idx in range(0, length, size):
+        if merge_last and idx + size + size >= length:
+            out.append(indices[idx:])
+            break
+        out.append(indices[idx:idx + size])
+    return out
+
+
+def unique_params(sd):
+    """The 28 unique actor-critic tensors of a 120-key policy state dict (the feature net is ONE module shared by actor and
+    critic, run_mansy.py:207-209) as leaf tensors, plus the full-key view the forward functions index."""
+    uniq, params = {}, {}
+    for k, v in sd.items():
+        if k.startswith('_actor_critic.') or k.startswith('identifier.'):
+            continue
+        key = k.replace('critic.feature_net.', 'actor.feature_net.')
+        if key not in uniq:
+            uniq[key] = v.clone().requires_grad_(True)
+        params[k] = uniq[key]
+    return uniq, params
+
+
+def update(sd, obs, obs_next, act, rew, done, ret_rms, opt_state, lamb=0.5, use_identifier=True, batch_size=512, repeat=2, gamma=0.95,
+           gae_lambda=0.95, rew_norm=True, eps_clip=0.2, vf_coef=0.5, ent_coef=0.02, max_grad_norm=1.0, lr=5e-4, wd=1e-2, eps=1e-8, on_step=None):
+    """One whole PPOPolicy.update(0, buffer, is_train=True, batch_size, repeat) -- the reference's order of operations
+    (bitrate_selection/models/mansy_ppo.py:36-59) over tianshou 0.4.8's process_fn / learn (T2):
+      1. relabel: rew <- (1 - lamb) rew + lamb (1 - MSE(identifier(obs, obs.action_one_hot), obs.qoe_weight))      (:41-48)
+      2. process_fn: v_s = critic(obs), v_s_ = critic(obs_next) (no grad), both x sqrt(ret_rms.var + eps); GAE per environment
+         (end flag = done or last collected step); returns = (adv + v_s) / sqrt(var + eps); ret_rms.update(un-normalised
+         returns of the whole buffer); logp_old = log_prob of the taken actions under the current actor
+      3. learn: `repeat` passes; each pass np.random.permutation -> minibatches (merge_last); per minibatch ppo_loss, backward,
+         clip_grad_norm_(actor_critic parameters, max_grad_norm), Adam with L2 weight decay (one step counter per parameter).
+    Inputs are [T][N] step-major numpy / torch arrays (the build's rollout slabs; tianshou's VectorReplayBuffer.sample(0) would
+    hand the same transitions environment-major -- the minibatch permutation is uniform either way).  `sd`: 120-key policy state
+    dict; `opt_state`: dict with 'uniq' (leaf tensors, from unique_params), 'params', 'm', 'v', 'step' (per tensor), created on
+    first use.  Returns (loss rows [n_minibatch_steps, 4], dict of intermediate arrays)."""
+    obs, obs_next = torch.as_tensor(obs), torch.as_tensor(obs_next)
+    T, N = obs.shape[0], obs.shape[1]
+    n = T * N
+    fo, fn_ = obs.reshape(n, -1), obs_next.reshape(n, -1)
+    fact = torch.as_tensor(act).reshape(n).long()
+    frew = torch.as_tensor(rew).reshape(n).float().clone()
+    fdone = np.asarray(done).reshape(T, N).astype(bool)
+    if 'uniq' not in opt_state:
+        opt_state['uniq'], opt_state['params'] = unique_params(sd)
+        opt_state['m'] = {k: torch.zeros_like(v) for k, v in opt_state['uniq'].items()}
+        opt_state['v'] = {k: torch.zeros_like(v) for k, v in opt_state['uniq'].items()}
+        opt_state['step'] = {k: 0 for k in opt_state['uniq']}
+    uniq, params = opt_state['uniq'], opt_state['params']
+    if use_identifier:
+        frew = relabel_rewards(sd, fo, frew, lamb)
+    with torch.no_grad():
+        v_s = critic_value(params, fo).flatten()
+        v_next = critic_value(params, fn_).flatten()
+        logp_old = torch.log_softmax(actor_logits(params, fo), -1).gather(1, fact[:, None])[:, 0]
+    scale = np.sqrt(ret_rms.var + eps) if rew_norm else 1.0
+    vs64 = v_s.numpy().astype(np.float64).reshape(T, N) * scale
+    vn64 = v_next.numpy().astype(np.float64).reshape(T, N) * scale
+    r2 = frew.numpy().reshape(T, N)
+    unn = np.zeros((T, N))
+    adv = np.zeros((T, N))
+    for e in range(N):
+        end = fdone[:, e].copy()
+        end[-1] = True                                     # T2: the last collected index of an unfinished episode ends the trace
+        unn[:, e], adv[:, e] = gae_returns(r2[:, e], vs64[:, e], vn64[:, e], fdone[:, e], end, gamma, gae_lambda)
+    returns = unn / scale
+    if rew_norm:
+        ret_rms.update(unn.reshape(-1))
+    returns_t = torch.from_numpy(returns.reshape(-1).astype(np.float32))
+    adv_t = torch.from_numpy(adv.reshape(-1).astype(np.float32))
+    rows = []
+    for _ in range(repeat):
+        for idx in split_indices(n, batch_size):
+            idx = torch.from_numpy(np.asarray(idx)).long()
+            for p in uniq.values():
+                p.grad = None
+            loss, clip, vf, ent = ppo_loss(actor_logits(params, fo[idx]), critic_value(params, fo[idx]), fact[idx], adv_t[idx], logp_old[idx],
+                                           v_s[idx], returns_t[idx], eps_clip, vf_coef, ent_coef)
+            loss.backward()
+            if max_grad_norm:
+                torch.nn.utils.clip_grad_norm_(list(uniq.values()), max_grad_norm)
+            with torch.no_grad():
+                for k, p in uniq.items():
+                    opt_state['step'][k] += 1
+                    p1, opt_state['m'][k], opt_state['v'][k] = adam_l2_step(p, p.grad, opt_state['m'][k], opt_state['v'][k], opt_state['step'][k],
+                                                                            lr, wd)
+                    p.copy_(p1)
+            rows.append([loss.item(), clip.item(), vf.item(), ent.item()])
+            if on_step is not None:
+                on_step(len(rows) - 1, uniq)
+    return np.array(rows), dict(rew=frew.numpy(), v_s=v_s.numpy(), v_next=v_next.numpy(), logp_old=logp_old.numpy(), returns=returns_t.numpy(),
+                                adv=adv_t.numpy())
+
+
 def bc_loss(logits, act, ent_coef=0.1):
     """utils/mansy_utils.py:60-66: CrossEntropyLoss(logits, expert action) - 0.1 * Categorical(logits).entropy().mean()
     -> (loss, cross entropy, mean entropy)."""

@@ -436,3 +436,96 @@ def test_behavior_cloning_pretraining_vs_reference(M, tmp_path):
         if key.startswith('norm::actor.'):
             np.testing.assert_allclose(after[key[6:]].double().norm().item(), float(G[key]), rtol=2e-4, err_msg=key)
     assert os.path.exists(ipath)
+
+
+def test_whole_update_vs_oracle_update(M):
+    """PPOPolicy.update(0, buffer, is_train=True, batch_size=512, repeat=2) end to end against oracle.ppo_oracle.update -- the
+    reference's order of operations (mansy_ppo.py:36-59: relabel -> process_fn -> learn) on a fixed buffer and a fixed np.random
+    seed, TWO consecutive updates (so the return normaliser and the Adam moments carry over): the relabelled rewards, the
+    minibatch split order (np.random.permutation, merge_last: 4096 = 8 x 512 per pass, and a ragged 1100 = 512 + 588 case), the
+    loss rows, every weight after the update and the ret_rms state.
+
+    The first pass of the first update agrees to rounding, and so does everything each update starts from (relabelled rewards,
+    return normaliser, first row); later rows and the final weights are compared loosely.  The clipped value loss max((R - v)^2, (R - v_clip)^2) has a DISCONTINUOUS gradient: once the
+    values have moved more than eps_clip from v_old (all 512 samples of most minibatches here), a sample contributes -2 (R - v)
+    or nothing depending on which square is larger, so a 1e-6 difference in v flips a sample at the boundary and moves the
+    gradient of a minibatch in which only ~35 samples contribute by several per cent -- in any two fp32 implementations
+    (tools/_bin probes: the engine's per-sample rule equals autograd's on every sample; the first flip appears at step 26)."""
+    sd = po.make_policy_state_dict(int(Z['wseed']))
+    for (T, N, bs) in ((16, 256, 512), (11, 100, 512)):
+        pol = build_policy(M, sd)
+        rs = np.random.RandomState(3)
+        n = T * N
+        src = Z['obs']
+        obs = src[rs.randint(0, len(src), size=n)].reshape(T, N, 780).copy()
+        obs_next = src[rs.randint(0, len(src), size=n)].reshape(T, N, 780).copy()
+        act = rs.randint(0, 15, size=(T, N)).astype(np.int32)
+        rew = rs.randn(T, N).astype(np.float32)
+        done = rs.rand(T, N) < 0.05
+        buf = M.ppo.RolloutBuffer(T, N, 'cuda')
+        rms_o, ost = po.RunningMeanStd(), {}
+        for it in range(2):
+            r_it = rew + 0.1 * it
+            buf.obs.copy_(torch.from_numpy(obs)); buf.obs_next.copy_(torch.from_numpy(obs_next)); buf.act.copy_(torch.from_numpy(act))
+            buf.rew.copy_(torch.from_numpy(r_it)); buf.done.copy_(torch.from_numpy(done.astype(np.uint8)))
+            buf.filled = T
+            np.random.seed(100 + it)
+            res = pol.update(0, buf, is_train=True, batch_size=bs, repeat=2)
+            got_rows = np.stack([res['loss'], res['loss/clip'], res['loss/vf'], res['loss/ent']], 1)
+            np.random.seed(100 + it)
+            sd_now = {k: v.clone() for k, v in sd.items()}                   # identifier weights are not touched by update()
+            want_rows, inter = po.update(sd_now, obs, obs_next, act, r_it, done, rms_o, ost, lamb=0.5, batch_size=bs, repeat=2)
+            assert got_rows.shape == want_rows.shape == ((16, 4) if n == 4096 else (4, 4))
+            np.testing.assert_allclose(buf.rew.cpu().numpy().reshape(-1), inter['rew'], atol=2e-6, rtol=0)          # relabel, in place
+            # ret_rms absorbs the un-normalised returns of the whole buffer: pins process_fn (values, GAE, normalisation order)
+            # (the second update starts from weights that may already differ by a flipped sample: 1e-2)
+            np.testing.assert_allclose(pol.ret_rms().cpu().numpy(), [rms_o.mean, rms_o.var, rms_o.count], rtol=2e-6 if it == 0 else 1e-2)
+            tight = dict(rtol=1e-5, atol=3e-6)
+            first_pass = len(got_rows) // 2
+            if it == 0:          # first pass of the first update: ratio == 1 and |v - v_old| small at its start -> no flips yet
+                np.testing.assert_allclose(got_rows[:2], want_rows[:2], **tight)
+                np.testing.assert_allclose(got_rows[:first_pass], want_rows[:first_pass], rtol=2e-4, atol=2e-5)
+            np.testing.assert_allclose(got_rows, want_rows, rtol=3e-2, atol=2e-3)
+            f = pol.engine.ac
+            for name, o, p in zip([t[0] for t in f.table], f.offsets, f.params):
+                got = f.flat_p[o:o + p.numel()].view(p.shape).cpu().numpy()
+                want = ost['uniq'][name].detach().numpy()
+                err = np.abs(got - want)
+                # Adam moves a weight by up to lr per step whatever the gradient's size: after a flipped sample the two trajectories
+                # differ by a fraction of lr per step on most weights and by up to 2 lr per step on a few
+                steps = len(got_rows) * (it + 1)
+                assert err.max() <= steps * 2 * 5e-4 and np.median(err) <= 1e-4, (T, N, it, name, float(np.median(err)), float(err.max()))
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16x6', 'bf16x3'])
+def test_shipped_trained_checkpoint_vs_reference(M, mode):
+    """The TRAINED weights the reference ships (best_policy.pth / best_identifier.pth; their arrays travel in
+    tests/golden/shipped_checkpoint_reference.npz, tools/gen_golden_shipped.py) through the HIP nets on real observations against
+    the imported reference: logits / values / identifier outputs within 1e-4, every argmax (bitrate) decision identical, the
+    un-batched identifier reward -- in the exact-fp32 mode and in both split-bf16 modes."""
+    from mansy_immersivevideostreaming_amd import kernels
+    G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'shipped_checkpoint_reference.npz'))
+    assert int(G['shared_feature_net_identical']) == 1
+    uniq = {k[3:]: torch.from_numpy(G[k]) for k in G.files if k.startswith('w::')}
+    sd = {}
+    for k in po.make_policy_state_dict(0):                      # the 120-key layout of the shipped checkpoint
+        src = k.replace('_actor_critic.', '')
+        src = src.replace('critic.feature_net.', 'actor.feature_net.')
+        sd[k] = uniq[src]
+    pol = build_policy(M, sd)
+    obs = torch.from_numpy(G['obs']).cuda()
+    with kernels.precision(mode):
+        logits, _ = pol.actor(obs)
+        value = pol.critic(obs)
+        pred = pol.identifier(obs)
+        buf = M.ppo.RolloutBuffer(8, 1, 'cuda')
+        buf.obs[:, 0] = obs[:8]
+        buf.rew[:, 0] = 0.0
+        buf.filled = 8
+        pol.relabel(buf, lamb=1.0)                               # rew <- identifier reward
+    tol = 2e-5 if mode != 'bf16x3' else 1e-4
+    np.testing.assert_allclose(logits.cpu().numpy(), G['logits'], atol=tol, rtol=0)
+    np.testing.assert_allclose(value.cpu().numpy(), G['value'], atol=tol, rtol=0)
+    np.testing.assert_allclose(pred.cpu().numpy(), G['ident'], atol=tol, rtol=0)
+    assert (logits.argmax(-1).cpu().numpy() == G['logits'].argmax(-1)).all()
+    np.testing.assert_allclose(buf.rew[:, 0].cpu().numpy(), G['ident_reward'], atol=tol, rtol=0)
