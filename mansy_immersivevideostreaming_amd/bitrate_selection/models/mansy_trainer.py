@@ -1,7 +1,12 @@
 """On-policy trainer counterpart of bitrate_selection/models/mansy_trainer.py (:18-95 `__next__`, :162-177
 `policy_update_fn`) on top of the vectorised collector: per epoch  collect step_per_collect -> [train identifier] ->
 relabel + PPO update -> reset buffer  until step_per_epoch, then checkpoint, validation episodes, best-model save.
-Order of operations and the callback signatures are the reference's (tianshou BaseTrainer semantics, T2)."""
+Order of operations and the callback signatures are the reference's (tianshou 0.4.8 BaseTrainer semantics, T2), including two
+things that decide which files exist after a run:
+  * iterating the trainer first calls reset() (tianshou BaseTrainer.__iter__ / reset): ONE test of the still-untrained policy
+    (epoch 0) seeds best_reward / best_epoch, and save_best_fn is called once -- best_policy.pth exists before epoch 1;
+  * the reference's own `__next__` (mansy_trainer.py:24-27) stops on `epoch >= max_epoch` from the second iteration on, so
+    `--epochs E` runs max(1, E - 1) epochs (E = 1 runs one: the shipped example `epochs_1_...`)."""
 import time
 
 import numpy as np
@@ -58,8 +63,8 @@ class OnpolicyTrainer:
         self.args, self.identifier, self.identifier_optimizer = args, identifier, identifier_optimizer
         self.test_log = test_log          # (log_path, tables, qoe_weights) for the validation CSV
         self.verbose = verbose
-        self.epoch, self.env_step, self.gradient_step = 0, 0, 0
-        self.best_reward, self.best_reward_std, self.best_epoch = -np.inf, 0.0, 0
+        self.epoch, self.iter_num, self.env_step, self.gradient_step = 0, 0, 0, 0
+        self.best_reward, self.best_reward_std, self.best_epoch = -np.inf, 0.0, -1
         self.stop_fn_flag = False
         N = train_collector.venv.n_env
         self.buffer = RolloutBuffer(max(1, step_per_collect // N), N, train_collector.venv.device)
@@ -67,18 +72,31 @@ class OnpolicyTrainer:
             policy.identifier_optim = identifier_optimizer
         self.start_time = time.time()
 
+    def reset(self):
+        """T2: tianshou 0.4.8 BaseTrainer.reset(): statistics cleared, an initial test at epoch 0 (best_epoch = 0, best_reward = its
+        reward), then save_best_fn(policy) unconditionally."""
+        self.epoch, self.iter_num, self.env_step = 0, 0, 0
+        self.stop_fn_flag = False
+        self.start_time = time.time()
+        if self.test_collector is not None:
+            self.best_epoch = -1
+            self.test_step(save=False)
+        if self.save_best_fn:
+            self.save_best_fn(self.policy)
+
     def __iter__(self):
+        self.reset()
         return self
 
-    def test_step(self):
+    def test_step(self, save=True):
         venv = self.test_collector.venv
         rets = run_episodes(self.policy, venv, self.episode_per_test, seed=self.test_collector.seed)
         if self.test_log is not None:
             write_episode_log(self.test_log[0], self.test_log[1], self.test_log[2], venv.pop_episode_log()[:self.episode_per_test])
         rew, rew_std = float(rets.mean()), float(rets.std())
-        if self.best_epoch == 0 or self.best_reward < rew:
+        if self.best_epoch < 0 or self.best_reward < rew:
             self.best_epoch, self.best_reward, self.best_reward_std = self.epoch, rew, rew_std
-            if self.save_best_fn:
+            if self.save_best_fn and save:
                 self.save_best_fn(self.policy)
         if self.verbose:
             print(f'Epoch #{self.epoch}: test_reward: {rew:.6f} ± {rew_std:.6f}, best_reward: {self.best_reward:.6f} ± '
@@ -88,7 +106,8 @@ class OnpolicyTrainer:
 
     def __next__(self):
         self.epoch += 1
-        if self.epoch > self.max_epoch or self.stop_fn_flag:
+        self.iter_num += 1
+        if self.iter_num > 1 and (self.epoch >= self.max_epoch or self.stop_fn_flag):      # mansy_trainer.py:24-31
             raise StopIteration
         self.policy.train()
         epoch_stat, n_done, losses = {}, 0, {}

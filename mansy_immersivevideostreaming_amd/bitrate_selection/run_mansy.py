@@ -26,7 +26,7 @@ from .models.mansy import Actor, Critic, FeatureNet, QoEIdentifier, QoEIdentifie
 from .models.mansy_ppo import PPOPolicy, VecCollector
 from .models.mansy_trainer import OnpolicyTrainer, run_episodes, write_episode_log
 from .utils.common import get_config_from_yml, read_log_file
-from .utils.mansy_utils import behavior_cloning_pretraining
+from .utils.mansy_utils import behavior_cloning_pretraining, load_demonstrations
 
 
 def train(args, config, policy, qoe_weights, identifier, identifier_optimizer, models_dir, policy_bc_path=None, identifier_bc_path=None):
@@ -170,8 +170,8 @@ def run(args, config):
             train_demos_path = os.path.join(demos_dir, 'train_demonstrations.pkl')
             valid_demos_path = os.path.join(demos_dir, 'valid_demonstrations.pkl')
             assert os.path.exists(train_demos_path) and os.path.exists(valid_demos_path)
-            train_demos = list(pickle.load(open(train_demos_path, 'rb')).values())
-            valid_demos = list(pickle.load(open(valid_demos_path, 'rb')).values())
+            train_demos = list(load_demonstrations(train_demos_path).values())       # this build's or the reference's file format
+            valid_demos = list(load_demonstrations(valid_demos_path).values())
             behavior_cloning_pretraining(args, policy, identifier, optimizer, identifier_optimizer, train_demos, valid_demos,
                                          max_steps=args.bc_max_steps, valid_per_step=args.bc_valid_per_step,
                                          identifier_max_steps=args.bc_identifier_max_steps,

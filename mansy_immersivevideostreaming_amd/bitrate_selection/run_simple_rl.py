@@ -70,6 +70,14 @@ def train(args, config, policy, qoe_weights, models_dir, file_prefix):
     collector = A2CCollector(policy, train_env, seed=args.seed)
     buffer = A2CBuffer(max(1, args.step_per_collect // args.train_num), args.train_num, args.device)
     best_reward, best_std, best_epoch, env_step, gradient_step, start = -np.inf, 0.0, 0, 0, 0, time.time()
+    # T2: tianshou 0.4.8 BaseTrainer.reset() (the stock OnpolicyTrainer the reference iterates, run_simple_rl.py:90-106): one test
+    # of the untrained policy at epoch 0 seeds best_reward, and save_best_fn is called once before epoch 1.  The stock trainer
+    # stops on `epoch > max_epoch`, i.e. --epochs E runs E epochs here (unlike mansy's customised trainer).
+    rets = run_episodes(policy, valid_env, args.episode_per_test)
+    write_episode_log(valid_log_path, t_valid, qoe_weights, valid_env.pop_episode_log()[:args.episode_per_test])
+    best_reward, best_std = float(rets.mean()), float(rets.std())
+    torch.save(policy.state_dict(), best_policy_path)
+    print('Best policy save at ' + best_policy_path)
     for epoch in range(1, args.epochs + 1):
         n_done, losses = 0, {}
         while n_done < args.step_per_epoch:
@@ -85,7 +93,7 @@ def train(args, config, policy, qoe_weights, models_dir, file_prefix):
         rets = run_episodes(policy, valid_env, args.episode_per_test)
         write_episode_log(valid_log_path, t_valid, qoe_weights, valid_env.pop_episode_log()[:args.episode_per_test])
         rew, rew_std = float(rets.mean()), float(rets.std())
-        if best_epoch == 0 or best_reward < rew:
+        if best_reward < rew:
             best_reward, best_std, best_epoch = rew, rew_std, epoch
             torch.save(policy.state_dict(), best_policy_path)
             print('Best policy save at ' + best_policy_path)

@@ -1,11 +1,74 @@
 """Host mirror of bitrate_selection/utils/mansy_utils.py: train_identifier (:9-39), calculate_indentifier_reward (:42-49),
 behavior_cloning_pretraining (:52-93)."""
+import io
+import pickle
 from random import choice
 
 import numpy as np
 import torch
 
+from ..envs.mansy_env import OBS_LD, OBS_SLICES
 from ..models.mansy import obs_to_tensor, _engine_of
+
+
+# ---------------------------------------------------------------------------------------------- demonstration files
+class _TsStub:
+    """Stand-in for any tianshou class met while unpickling a reference-written demonstration file: keeps the pickled state."""
+
+    def __init__(self, *a, **k):
+        self.__dict__.update(k)
+
+    def __setstate__(self, state):
+        self.__dict__.update(state if isinstance(state, dict) else {'_state': state})
+
+    def __getitem__(self, k):
+        return self.__dict__[k]
+
+    def keys(self):
+        return self.__dict__.keys()
+
+
+class _DemoUnpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        if module.split('.')[0] == 'tianshou':
+            return _TsStub
+        return super().find_class(module, name)
+
+
+def _field(node, key):
+    return node[key] if isinstance(node, dict) else getattr(node, key)
+
+
+def _as_demo(obj):
+    """One demonstration in this build's form {'obs' [len, 780] float32, 'act' [len] int32, 'done' [len] bool}.  Accepts that form
+    as is, or what the reference's run_expert.py:35-41 pickles: a tianshou ReplayBuffer filled by add(Batch(obs=<observation
+    dict>, act, rew, done, obs_next, info)) -- T2, release 0.4.8 layout: the transitions live in `_meta` (a Batch whose `obs` is a
+    Batch of stacked arrays, one per observation key), `_size` of them are valid."""
+    if isinstance(obj, dict) and 'obs' in obj and 'act' in obj and not isinstance(obj['obs'], (dict, _TsStub)):
+        return obj
+    meta = _field(obj, '_meta') if not isinstance(obj, dict) else obj
+    size = int(_field(obj, '_size')) if not isinstance(obj, dict) and '_size' in obj.__dict__ else len(np.asarray(_field(meta, 'act')))
+    obs = _field(meta, 'obs')
+    rows = np.zeros((size, OBS_LD), np.float32)
+    for k, (a, b, shape) in OBS_SLICES.items():
+        try:
+            v = _field(obs, k)
+        except (KeyError, AttributeError):
+            continue
+        rows[:, a:b] = np.asarray(v, np.float32)[:size].reshape(size, -1)
+    act = np.asarray(_field(meta, 'act'))[:size].astype(np.int32)
+    done = np.asarray(_field(meta, 'done'))[:size].astype(bool) if 'done' in (meta.keys() if hasattr(meta, 'keys') else ()) else np.zeros(size, bool)
+    return {'obs': rows, 'act': act, 'done': done}
+
+
+def load_demonstrations(path):
+    """{(video, user, trace, qoe_weight): demonstration} from a demonstration file written by this build's run_expert (plain
+    dicts) or by the reference's (tianshou ReplayBuffers; read without tianshou through stand-in classes).  The reference
+    layout is restated from the 0.4.8 release and could not be checked against a reference-written file here (tianshou is not
+    installable): PARITY UNPINNED for that branch; tests/test_host_demos.py exercises it on a file with the same class paths."""
+    with open(path, 'rb') as f:
+        raw = _DemoUnpickler(io.BytesIO(f.read())).load()
+    return {k: _as_demo(v) for k, v in raw.items()}
 
 
 def train_identifier(identifier, identifier_optim, tracjetory, update_round=2, policy=None):

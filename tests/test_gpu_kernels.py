@@ -276,3 +276,28 @@ def test_empty_and_degenerate_inputs(K):
     xy = np.array([[0.0, 0.0], [1.0, 1.0], [0.99999994, 0.5], [0.5, 0.99999994], [0.1171875, 0.2083333]], np.float32)
     got = K.tilemap(torch.from_numpy(xy).to(d)).cpu().numpy().view(np.uint64)
     np.testing.assert_array_equal(got, otm.tilemap_xy(xy).view(np.uint64))
+
+
+def test_find_tiles_covered_by_viewport_integer_pixel_edges():
+    """The drop-in integer-pixel entry point (viewport_prediction/utils/common.py:46-58) on the frame edges and tile multiples --
+    x in {0, 1, 319, 320, 321, 2559, 2560 = W, ...}, y in {0, 1, 179, 180, 181, 1439, 1440 = H, ...} -- against the imported
+    reference function's maps (tests/golden/tilemap_px.npz): the wrapper turns the integer pixel into (x + 0.5) / W for the
+    kernel's truncation, which must give the pixel back at both ends of the range."""
+    from mansy_immersivevideostreaming_amd.viewport_prediction.utils.common import find_tiles_covered_by_viewport
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'tilemap_px.npz'))
+    ex = {0, 1, 299, 300, 301, 319, 320, 321, 639, 640, 2259, 2260, 2261, 2559, 2560}
+    ey = {0, 1, 149, 150, 151, 179, 180, 181, 1289, 1290, 1291, 1439, 1440}
+    n = 0
+    for (x, y), want in zip(z['px'], z['maps']):
+        if int(x) not in ex and int(y) not in ey:
+            continue
+        if int(x) not in ex and n % 3:          # thin the pure-y-edge rows: one launch per call
+            n += 1
+            continue
+        n += 1
+        m = find_tiles_covered_by_viewport(int(x), int(y), 2560, 1440, 320, 180, 8, 8)
+        got = sum(int(b) << k for k, b in enumerate(m.reshape(-1)))
+        assert got == int(want), (int(x), int(y), hex(got), hex(int(want)))
+    assert n > 1000
+    for x, y in ((0, 0), (2560, 1440), (2560, 0), (0, 1440), (320, 180), (640, 180), (2560, 180)):     # corners / tile multiples are in the fixture
+        assert ((z['px'][:, 0] == x) & (z['px'][:, 1] == y)).any(), (x, y)

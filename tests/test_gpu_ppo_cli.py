@@ -120,7 +120,9 @@ def test_run_mansy_train_and_test_cli(tree):
     assert rows[0] == 'video,user,trace,qoe_w1,qoe_w2,qoe_w3,qoe,qoe1,qoe2,qoe3'
     assert len(rows) == 1 + 1 * 1 * 1 * 2                        # test split: 1 video x 1 user x 1 trace x 2 preferences
     vrows = open(os.path.join(mdir, 'valid_log.csv')).read().splitlines()
-    assert len(vrows) == 1 + 2 * 4                               # 2 epochs x episode_per_test (= 4 valid samples)
+    # the reference's trainer: an initial test at epoch 0 (tianshou reset()) + `--epochs 2` = ONE epoch (mansy_trainer.py:24-27
+    # stops on epoch >= max_epoch from the second iteration) -> 2 x episode_per_test (= 4 valid samples) rows
+    assert len(vrows) == 1 + 2 * 4
 
 
 def test_run_expert_cli_and_dropin_env(tree):
@@ -235,7 +237,7 @@ def test_run_simple_rl_cli(tree):
     rows = open(os.path.join(rdir, prefix + '_results.csv')).read().splitlines()
     assert rows[0] == 'video,user,trace,qoe_w1,qoe_w2,qoe_w3,qoe,qoe1,qoe2,qoe3' and len(rows) == 1 + 2
     vrows = open(os.path.join(mdir, prefix + '_valid_log.csv')).read().splitlines()
-    assert len(vrows) == 1 + 2 * 3          # 2 epochs x episode_per_test (= the 3 valid samples of one preference)
+    assert len(vrows) == 1 + 3 * 3          # (initial test + 2 epochs: the stock tianshou trainer) x episode_per_test (= 3 valid samples)
     # drop-in single environment
     config = get_config_from_yml(cfg)
     env = SimpleRLEnv(config, 'Toy', '4G', [config.qoe_split['train'][1]], os.path.join(root, 'simple_single.csv'), config.startup_download,
