@@ -46,7 +46,11 @@ typedef struct mansy_vp_config {
 
 /* SyncBN hook: with bn_sync_world > 1 the engine calls fn(which, user) after enqueuing the per-channel partial sums
  * (which = 0: forward [sum, sumsq]; 1: backward [sum g, sum g*xhat]); the hook must all-reduce (SUM) the 2*d_model doubles at
- * workspace slot "dis.stats" (+ 0 / + 2*d_model doubles) over the ranks, ordered on the same stream. */
+ * workspace slot "dis.stats" (+ 0 / + 2*d_model doubles) over the ranks, ordered on the same stream.
+ * which = 2 (mansy_vp_backward / _train_step, between the DistillLayer backward and the encoder backward): the gradients of every
+ * parameter from transformer.decoder.layers.0.* to the end of the table are final -- the hook may start their all-reduce on
+ * another stream while the encoder backward runs (it must not touch the stream's pending work); returning 0 without doing
+ * anything is fine. */
 typedef int (*mansy_bn_sync_fn)(int which, void* user);
 int mansy_set_bn_sync_hook(mansy_bn_sync_fn fn, void* user);
 

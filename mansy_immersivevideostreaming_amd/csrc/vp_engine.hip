@@ -477,6 +477,10 @@ struct Eng {
     RC(lin_dw(W.g_b, W.col, N, d, 3 * d, P.conv.gw, P.conv.gb));
     RC(lin_dx(W.g_b, N, d, P.conv.w, 3 * d, W.g_wide, nullptr, nullptr, 1.f));
     RC(mansy_launch_col2im3(W.g_wide, W.g_a, B, S, d, st));
+    // Data parallel: every gradient from the first decoder layer to the end of the parameter table (decoder layers, decoder
+    // norm, DistillLayer conv + BatchNorm, predictor -- two thirds of the flat buffer) is final here.  The host hook (which = 2)
+    // starts their all-reduce on its side stream / second communicator, under the encoder backward that follows.
+    if (c.bn_sync_world > 1) RC(mansy_bn_sync_invoke(2));
     // ---- encoder
     const float* last = W.enc[c.n_enc - 1].y2;
     RC(ln_bwd(W.g_a, last, W.me, W.re, P.enc_norm, W.g_b, nullptr, mansy_no_drop(), N));

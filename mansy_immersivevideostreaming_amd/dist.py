@@ -21,9 +21,11 @@ def local_device_index(local):
     return local
 
 
-def init_process_group(backend=None):
+def init_process_group(backend=None, force=False):
+    """force=True initialises the process group even with WORLD_SIZE=1 (the RCCL self-test on a one-GPU box:
+    tools/rccl_selftest.py)."""
     rank, world, local = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if backend is None:
             backend = os.environ.get('MANSY_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
@@ -35,10 +37,12 @@ def init_process_group(backend=None):
     return rank, world, local_device_index(local)
 
 
-def make_grad_sync(world):
-    """flat gradient buffer -> average over ranks, in place (None when single process)."""
-    if world <= 1:
+def make_grad_sync(world, force=False):
+    """flat gradient buffer -> average over ranks, in place (None when single process, unless force=True: the collective is
+    then issued over the one-rank group -- tools/rccl_selftest.py)."""
+    if world <= 1 and not force:
         return None
+    world = max(world, 1)
     inv = 1.0 / world
     # RCCL averages inside the collective (one launch instead of all-reduce + scale); gloo (CPU tests) has no AVG
     use_avg = dist.is_initialized() and dist.get_backend() == 'nccl'
@@ -55,6 +59,55 @@ def make_grad_sync(world):
         dist.all_reduce(flat_g)
         flat_g.mul_(inv)
     return grad_sync
+
+
+class OverlappedGradSync:
+    """Gradient averaging for the VP step with the big half of the all-reduce hidden under the encoder backward: the engine's
+    hook (which = 2) hands over the tail of the flat gradient buffer (decoder, DistillLayer, predictor: two thirds of the 36.8
+    MB) as soon as it is final; its all-reduce runs on a SIDE stream through a SECOND communicator (so it can never interleave
+    with the SyncBN statistics collectives of the default group), while the compute stream goes on with the encoder backward.
+    `finish(head)` reduces the rest on the compute stream and makes it wait for the tail.  Also callable like the plain
+    grad_sync (whole buffer, no overlap) -- what the PPO policy and non-engine callers use."""
+
+    def __init__(self, world, device=None, force=False):
+        self.world = max(int(world), 1)
+        self.inv = 1.0 / self.world
+        self.avg = dist.is_initialized() and dist.get_backend() == 'nccl'
+        self.group = dist.new_group() if (dist.is_initialized() and (self.world > 1 or force)) else None
+        self.stream = torch.cuda.Stream(device=device) if torch.cuda.is_available() else None
+        self.done = None
+
+    def _reduce(self, t, group):
+        if self.avg:
+            try:
+                dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)
+                return
+            except (RuntimeError, ValueError):
+                self.avg = False
+        dist.all_reduce(t, group=group)
+        t.mul_(self.inv)
+
+    def __call__(self, flat_g):
+        self._reduce(flat_g, None)
+
+    def start_tail(self, tail):
+        """Called from the engine hook while the step is being enqueued: everything enqueued so far on the current stream
+        produced `tail`; the side stream waits for exactly that point."""
+        cur = torch.cuda.current_stream(tail.device)
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        self.stream.wait_event(ready)
+        with torch.cuda.stream(self.stream):
+            self._reduce(tail, self.group)
+            self.done = torch.cuda.Event()
+            self.done.record(self.stream)
+
+    def finish(self, head):
+        if head.numel():
+            self._reduce(head, None)
+        if self.done is not None:
+            torch.cuda.current_stream(head.device).wait_event(self.done)
+            self.done = None
 
 
 def shard_envs(n_env_per_rank, rank, world):
@@ -88,13 +141,13 @@ def pooled_moments(triples):
     return torch.stack([torch.where(empty, torch.zeros_like(mean), mean), torch.where(empty, torch.ones_like(var), var), tot])
 
 
-def global_running_moments(rms_local, world):
+def global_running_moments(rms_local, world, force=False):
     """rms_local: this rank's accumulated [mean, var, count] (float64 tensor, only its own returns).  Returns a NEW tensor
     with the merge over all ranks (identical on every rank); rms_local is not modified.  With one process: a copy.
     Stays on the device: one all-gather of 3 doubles + a handful of tiny tensor ops, no host synchronisation."""
-    if world <= 1:
+    if world <= 1 and not force:
         return rms_local.clone()
-    gathered = [torch.zeros_like(rms_local) for _ in range(world)]
+    gathered = [torch.zeros_like(rms_local) for _ in range(max(world, 1))]
     dist.all_gather(gathered, rms_local)
     return pooled_moments(torch.stack(gathered))
 

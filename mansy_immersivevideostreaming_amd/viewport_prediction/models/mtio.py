@@ -33,6 +33,10 @@ def _bn_sync_callback(which, user):
     2*d_model doubles of the DistillLayer BatchNorm statistics over the data-parallel ranks."""
     try:
         m, cfg = _BN_SYNC['model'], _BN_SYNC['cfg']
+        if which == 2:              # decoder-side gradients are final: start their all-reduce under the encoder backward
+            if m._grad_ready is not None:
+                m._grad_ready()
+            return 0
         off = ctypes.c_longlong()
         check(lib().mansy_vp_ws_lookup(ctypes.byref(cfg), b'dis.stats', ctypes.byref(off), None), 'ws_lookup')
         d = m.d_model
@@ -94,6 +98,7 @@ class ViewportTransformerMTIO(nn.Module):
         self._flat_g = None
         self.bn_sync_world = 1
         self._bn_allreduce = None
+        self._grad_ready = None
         self._build_parameters()
         self._flatten()
 
@@ -361,6 +366,17 @@ class ViewportTransformerMTIO(nn.Module):
         g = optimizer.param_groups[0]
         engine_step = optimizer.step_count if grad_sync is None else 0
         loss = torch.empty((), dtype=torch.float32, device=history.device)
+        # overlapped gradient sync (dist.OverlappedGradSync): the engine calls back once the decoder-side gradients are final
+        tail_started, tail_off = False, 0
+        self._grad_ready = None
+        if grad_sync is not None and hasattr(grad_sync, 'start_tail') and self.bn_sync_world > 1:
+            tail_off = self.grad_tail_offset()
+
+            def _ready():
+                nonlocal tail_started
+                grad_sync.start_tail(self._flat_g[tail_off:])
+                tail_started = True
+            self._grad_ready = _ready
         with _lib.precision(self.precision):
             check(lib().mansy_vp_train_step(
                 ctypes.byref(cfg), arr, garr, ptr(self._flat_p), ptr(self._flat_g), ptr(optimizer.exp_avg), ptr(optimizer.exp_avg_sq),
@@ -368,9 +384,18 @@ class ViewportTransformerMTIO(nn.Module):
                 g['lr'], g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], engine_step, ptr(loss), ptr(ws),
                 self._next_seed(), stream_ptr(history.device)), 'mansy_vp_train_step')
         if grad_sync is not None:
-            grad_sync(self._flat_g)
+            if tail_started:
+                grad_sync.finish(self._flat_g[:tail_off])          # head (embedding + encoder) now; then wait for the tail
+            else:
+                grad_sync(self._flat_g)
             optimizer.apply_flat()
         return loss
+
+    def grad_tail_offset(self):
+        """First element of the flat gradient buffer whose gradient is final before the encoder backward starts: everything from
+        transformer.decoder.layers.0.* to the end of the parameter table (engine hook which = 2)."""
+        names = [n for n, _ in self._param_table()]
+        return self._offsets[next(i for i, n in enumerate(names) if n.startswith('transformer.decoder.layers.0.'))]
 
 
 class _VPFunction(torch.autograd.Function):

@@ -36,12 +36,15 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
 
 
 @pytest.mark.gpu
-def test_two_rank_train_step_equals_whole_batch(tmp_path):
+@pytest.mark.parametrize('overlap', ['0', '1'])
+def test_two_rank_train_step_equals_whole_batch(tmp_path, overlap):
     """a data-parallel VP step over 2 ranks x 32 rows (SyncBN statistics over the global mini-batch + averaged
     flat gradient) computes the gradient, loss and BatchNorm running statistics of ONE process on all 64 rows (dropout off,
     MTIO repeat branch: the same function either way).  fp32 tolerance: summation order over the batch differs."""
     import numpy as np
-    env = dict(os.environ, MANSY_DIST_BACKEND='gloo', MANSY_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    # overlap = 1: the gradient sync bench.py uses -- the engine hook starts the all-reduce of the decoder-side two thirds of the
+    # flat buffer on a side stream / second process group while the encoder backward is still being enqueued
+    env = dict(os.environ, MANSY_DIST_BACKEND='gloo', MANSY_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0', MANSY_OVERLAP=overlap)
     probe = os.path.join(ROOT, 'tools', 'dp_equiv.py')
     one, two = str(tmp_path / 'one.npz'), str(tmp_path / 'two.npz')
     single_env = {k: v for k, v in env.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
@@ -63,3 +66,28 @@ def test_two_rank_train_step_equals_whole_batch(tmp_path):
     assert np.abs(ga - gb).max() < 1e-4 * np.abs(ga).max()
     np.testing.assert_allclose(b['rm'], a['rm'], atol=1e-6, rtol=1e-5)
     np.testing.assert_allclose(b['rv'], a['rv'], atol=1e-6, rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_rccl_world1_collectives_of_the_dp_step():
+    """RCCL itself (backend "nccl", `device_id=` init) executed on the one GPU there is: WORLD_SIZE=1 in a fresh process, the exact
+    collectives of the data-parallel step -- fp32 AVG over the 36.8 MB / 1.7 MB / 1.05 MB flat gradients, the fp64 SUM of the
+    2 x 512 SyncBN statistics issued from inside the engine's hook, the 3-double all-gather of the return normaliser -- and a
+    whole data-parallel VP step through them that reproduces the plain step (tools/rccl_selftest.py)."""
+    env = {k: v for k, v in os.environ.items() if k not in ('MANSY_DIST_BACKEND', 'MANSY_SHARE_GPU')}
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'rccl_selftest.py')], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert out['backend'] == 'nccl' and out['world'] == 1
+    assert out['bn_hook_calls'] == 2 and out['bn_hook_shape'] == [2 * 64]          # forward [sum, sumsq] + backward [sum g, sum g xhat]
+    assert abs(out['loss_dp'] - out['loss_plain']) <= 2e-6 * abs(out['loss_plain'])
+    # after AdamW (lr 1e-3): identical except the parameters whose true gradient is zero (conv bias in front of the BatchNorm, key
+    # biases ...): their gradient is rounding noise, and Adam turns noise of either sign into a +-lr step in both runs
+    assert out['param_max_diff'] <= 2.1e-3 and out['param_frac_gt_1e-6'] <= 0.02 and out['bn_mean_max_diff'] <= 1e-6
+    assert 0 < out['allreduce_avg_1p7MB_us'] < 5000 and 0 < out['allreduce_avg_36MB_us'] < 50000
+    # the overlapped sync ran: the engine hook handed over the decoder-side tail (about two thirds of the buffer)
+    assert 0.5 * out['flat_elems'] < out['overlap_tail_elems'] < 0.8 * out['flat_elems']

@@ -36,7 +36,10 @@ def main():
     h, c, f = (t.to(dev) for t in synthetic_trajectories(B, 10, 10, seed=11))
     n = B // world
     sl = slice(rank * n, (rank + 1) * n)
-    loss = m.train_step(h[sl].contiguous(), c[sl].contiguous(), f[sl].contiguous(), opt, grad_sync=mdist.make_grad_sync(world))
+    # MANSY_OVERLAP=1: the overlapped form bench.py uses (tail of the flat gradient reduced on a side stream from the engine hook)
+    sync = mdist.OverlappedGradSync(world, dev) if (world > 1 and os.environ.get('MANSY_OVERLAP') == '1') else mdist.make_grad_sync(world)
+    loss = m.train_step(h[sl].contiguous(), c[sl].contiguous(), f[sl].contiguous(), opt, grad_sync=sync)
+    torch.cuda.synchronize()
     lv = torch.tensor([float(loss.item())], dtype=torch.float64, device=dev)
     if world > 1:
         import torch.distributed as dist
