@@ -448,12 +448,12 @@ def test_dropout_mask_policy_loss_curves(MT):
     """Bounds the one declared training-dynamics deviation: the reference re-runs the decoder on the growing
     target and draws FRESH dropout masks for every recomputed position at every decode step (mtio.py:158-164, torch RNG); the
     KV-cached engine draws ONE mask per position (counter hash).  Same marginal distribution, different sample path -- so the
-    comparison is statistical: tests/golden/vp_dropout_curves_d64.npz holds the loss curves of the IMPORTED reference trained with
+    comparison is statistical: tests/golden/dropout_curves_vp_d64.npz holds the loss curves of the IMPORTED reference trained with
     its dropout on (5 dropout seeds x 200 AdamW steps, d=64, eight fixed batches, identical MTIO decisions:
     tools/gen_golden_dropout_curves.py); the engine is trained the same way with 5 dropout seeds.  Per 40-step window the two
     seed-averaged curves must agree within 3 standard errors of the seed-to-seed spread (+ 5 % of the level): the mask policy
     moves the loss curve by less than changing the dropout seed does."""
-    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'vp_dropout_curves_d64.npz'))
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'dropout_curves_vp_d64.npz'))
     d, S, T, B, steps, nb = int(z['d']), int(z['S']), int(z['T']), int(z['B']), int(z['steps']), int(z['nb'])
     batches = [tuple(t.cuda() for t in vo.synthetic_trajectories(B, S, T, seed=int(z['batch_seed0']) + i)) for i in range(nb)]
     curves = []

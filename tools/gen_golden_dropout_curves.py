@@ -47,7 +47,7 @@ def main():
             losses.append(loss.item())
         curves.append(losses)
         print('seed', dseed, 'first', losses[0], 'last mean', np.mean(losses[-20:]))
-    path = os.path.join(OUT, 'vp_dropout_curves_d64.npz')
+    path = os.path.join(OUT, 'dropout_curves_vp_d64.npz')
     np.savez_compressed(path, curves=np.array(curves, np.float32), d=d, S=S, T=T, B=B, wseed=wseed, steps=steps, nb=nb, lr=lr, mixseed=mixseed,
                         bias=int(bias), batch_seed0=500)
     print('written', path, os.path.getsize(path) // 1024, 'KiB')
