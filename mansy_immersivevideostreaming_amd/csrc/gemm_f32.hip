@@ -463,8 +463,9 @@ int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B,
              (!b_kmajor || N % 4 == 0);
   auto al16 = [](const void* x) { return (reinterpret_cast<uintptr_t>(x) & 15) == 0; };
   p.c_vec_ok = al16(C) && (ldc % 4 == 0) && (N % 4 == 0) && (!ep.bias || al16(ep.bias)) &&
-               (!ep.mask_src || (al16(ep.mask_src) && ep.mask_ld % 4 == 0)) && (!ep.resid || (al16(ep.resid) && ep.resid_ld % 4 == 0));
-  const bool plain = !ep.bias && !ep.relu && !ep.mask_src && ep.drop.p == 0.f && !ep.resid;
+               (!ep.mask_src || (al16(ep.mask_src) && ep.mask_ld % 4 == 0)) && (!ep.resid || (al16(ep.resid) && ep.resid_ld % 4 == 0)) &&
+               (!ep.pre_a || (al16(ep.pre_a) && (!ep.pre_b || al16(ep.pre_b)) && ep.pre_ld % 4 == 0 && ep.pre_col0 % 4 == 0));
+  const bool plain = !ep.bias && !ep.relu && !ep.mask_src && ep.drop.p == 0.f && !ep.resid && !ep.pre_a;
   // LDS-DMA loop: whole 16-byte chunks and whole K-tiles only (it cannot zero-fill a K tail)
   const bool dma = p.vec_ok && K >= BK && K % BK == 0 && force_tile >= 0;
   // split-bf16 modes: same preconditions as the LDS-DMA loop; everything else stays on the fp32 loops

@@ -83,6 +83,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
         const int row = m0 + lr, col = n0 + c4 * 4;
         if (row >= p.M || col >= p.N) continue;           // N % 4 == 0 on this path: a float4 is entirely in or out
         float4 v = *reinterpret_cast<const float4*>(smem + lr * CLD + c4 * 4);
+        if (ep.pre_a && col >= ep.pre_col0) {        // pre_col0 % 4 == 0 on this path: a float4 is entirely in or out
+          const long long po = (long long)row * ep.pre_ld + (col - ep.pre_col0);
+          const float4 a = *reinterpret_cast<const float4*>(ep.pre_a + po);
+          v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+          if (ep.pre_b) { const float4 b2 = *reinterpret_cast<const float4*>(ep.pre_b + po); v.x += b2.x; v.y += b2.y; v.z += b2.z; v.w += b2.w; }
+        }
         if (ep.bias) { const float4 b = *reinterpret_cast<const float4*>(ep.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
         if (ep.relu) {
           v.x = v.x > 0.f ? v.x : v.x * ep.relu_slope; v.y = v.y > 0.f ? v.y : v.y * ep.relu_slope;
@@ -117,7 +123,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
       float v[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        v[e] = acc[i][j][e] + bias;
+        float pre = 0.f;
+        if (ep.pre_a && col >= ep.pre_col0 && col < p.N) {
+          const long long po = (long long)min(row_base + (e & 3) + 8 * (e >> 2), p.M - 1) * ep.pre_ld + (col - ep.pre_col0);
+          pre = ep.pre_a[po] + (ep.pre_b ? ep.pre_b[po] : 0.f);
+        }
+        v[e] = acc[i][j][e] + pre + bias;
         if (ep.relu) v[e] = v[e] > 0.f ? v[e] : v[e] * ep.relu_slope;
       }
       if (ep.mask_src) {

@@ -9,8 +9,9 @@
 //   a_kmajor == 1: A(m,k) at A[k*lda + m]      (row-major [K,M],  i.e. A^T stored)
 //   b_kmajor == 0: B(k,n) at B[n*ldb + k]      (row-major [N,K],  torch Linear weight)
 //   b_kmajor == 1: B(k,n) at B[k*ldb + n]      (row-major [K,N])
-// Epilogue order: +bias[n] -> (leaky) relu -> mask (mask_src[m,n] > 0 ? v*mask_scale : v*mask_neg)
-//                 -> dropout(site, idx = m*N+n) -> +resid[m,n] -> store / atomicAdd.
+// Epilogue order: +pre_a[m, n - pre_col0] (+pre_b) for n >= pre_col0 -> +bias[n] -> (leaky) relu
+//                 -> mask (mask_src[m,n] > 0 ? v*mask_scale : v*mask_neg) -> dropout(site, idx = m*N+n) -> +resid[m,n]
+//                 -> store / atomicAdd.
 struct GemmEpilogue {
   const float* bias = nullptr;
   int relu = 0;
@@ -38,6 +39,10 @@ struct GemmEpilogue {
   const float* pair_A = nullptr; const float* pair_B = nullptr; float* pair_C = nullptr; float* pair_rowsum = nullptr;
   // precision of THIS product: -1 = the process-wide mode (mansy_set_gemm_precision), 0 fp32, 3 bf16x3, 6 bf16x6
   int prec = -1;
+  // optional addend applied BEFORE the mask stage to the columns n >= pre_col0: v += pre_a[m*pre_ld + n - pre_col0] (+ pre_b[..]).
+  // (FeatureNet backward: the heads' residual gradients join the last 128 feature columns ahead of the LeakyReLU derivative,
+  // which is the mask stage -- the former featgrad_finish launch.)
+  const float* pre_a = nullptr; const float* pre_b = nullptr; int pre_ld = 0; int pre_col0 = 0;
 };
 int mansy_gemm_effective_splits(int K, int requested);
 int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb, int b_kmajor,

@@ -98,6 +98,9 @@ struct PackArgs {
   // one more rider (an extra workgroup at the end of the grid): mean / unbiased std of the minibatch's advantages -> adv_stats[0..1]
   // (the fused loss in head_out_kernel normalises with them)
   const float* adv; int adv_n; float* adv_stats;
+  // two small zero-fills riding on every pack launch: the packed bias-gradient accumulator dbbd [FEAT] (the dWbd product adds
+  // its row sums there) and the gradient-norm / barrier slots (doubles, zeroed as pairs of floats)
+  float* z2; int z2n; float* z3; int z3n;
 };
 // Wbd [FEAT, KP] (columns >= K and everything off the block diagonal zero), bbd [FEAT], and per 64-feature column tile of
 // the product the K range that holds its branch's weights (GemmEpilogue::tile_krange).
@@ -124,6 +127,8 @@ __global__ __launch_bounds__(256) void pack_wbd_kernel(PackArgs a, int identifie
     return;
   }
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx < a.z2n) a.z2[idx] = 0.f;
+  if (idx < a.z3n) a.z3[idx] = 0.f;
   if (idx < FEAT / 64) {
     const Branch g = branch_geom((int)idx * 64 / HID, identifier);
     krange[2 * idx] = g.off / 32 * 32;
@@ -162,7 +167,7 @@ struct UnpackArgs { float* gbw[NB]; float* gbb[NB]; };
 // Optional rider (PPO minibatch step with clipping): the squared gradient norm.  The branch gradients are exactly the values
 // this kernel writes (the buffers were zeroed by the prologue), the head gradients [tail_g, tail_g + tail_n) were completed by
 // earlier launches and are scanned by extra workgroups at the end of the grid; per-workgroup sums are added into the
-// NORM_PARTS slots that clip_adam_kernel adds up (zeroed by featgrad_finish_kernel).
+// NORM_PARTS slots that clip_adam_kernel adds up (zeroed by the pack launch's riders).
 struct NormRider { double* parts; const float* tail_g; long long tail_n; };
 __global__ __launch_bounds__(256) void unpack_dwbd_kernel(const float* __restrict__ dWbd, const float* __restrict__ dbbd, int identifier, int K,
                                                           UnpackArgs a, NormRider nr) {
@@ -205,6 +210,7 @@ __global__ __launch_bounds__(256) void unpack_dwbd_kernel(const float* __restric
 struct HeadOut {
   float* A1; const float* fc_b; const float* Wout; const float* bout; int n_out; int sigmoid; float* H; float* out; int pre_col;
   int* act; float* logp;
+  int out_ld;      // row stride of `out` for this head (0: the launch-wide out_ld); 1 writes a value head straight into a [B] vector
 };
 // PPO minibatch loss fused into the output-layer launch (T2: tianshou 0.4.8 PPOPolicy.learn): head 0 (actor) turns its row's
 // logits into the clipped-surrogate + entropy terms and their gradient wrt the logits, head 1 (critic) its value into the
@@ -280,7 +286,7 @@ __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const f
     float mine = 0.f;
 #pragma unroll
     for (int k = 0; k < MAXOUT; ++k) if (k == lane) mine = o[k];
-    out[(size_t)row * out_ld + lane] = mine;
+    out[(size_t)row * (d.out_ld ? d.out_ld : out_ld) + lane] = mine;
   }
   if (lf.on && blockIdx.y == 0) {  // actor: clipped surrogate + entropy of this row, gradient wrt the logits (every lane computes the same scalars)
     float adv = l_adv;
@@ -424,25 +430,6 @@ __global__ __launch_bounds__(256) void head_out_bwd_kernel(HeadBwdArgs args, int
   for (int i = threadIdx.x; i < n_out * HID; i += 256) atomicAdd(gWout + i, sw[i]);
   if (threadIdx.x < n_out) atomicAdd(gbout + threadIdx.x, sb[threadIdx.x]);
 }
-
-// dPre = (dF + [residual grads in the last 128 columns]) * leaky'(F)
-__global__ __launch_bounds__(256) void featgrad_finish_kernel(float* __restrict__ dF, const float* __restrict__ dH_a, const float* __restrict__ dH_b,
-                                                              const float* __restrict__ F, long long n, float* __restrict__ dbbd_zero,
-                                                              double* __restrict__ parts_zero) {
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx < FEAT) dbbd_zero[idx] = 0.f;        // the dWbd product that follows accumulates the packed bias gradient here
-  if (parts_zero && idx < NORM_PARTS_C) parts_zero[idx] = 0.0;      // squared-norm slots of the unpack kernel's rider
-  if (idx >= n) return;
-  const int col = (int)(idx % FEAT);
-  const long long row = idx / FEAT;
-  float v = dF[idx];
-  if (col >= RESID_COL) {
-    v += dH_a[row * HID + (col - RESID_COL)];
-    if (dH_b) v += dH_b[row * HID + (col - RESID_COL)];
-  }
-  dF[idx] = F[idx] > 0.f ? v : v * SLOPE;
-}
-
 
 __device__ float block_sum(float v, float* sh) {
   v = wave_sum(v);
@@ -690,6 +677,7 @@ struct PEng {
     a.fc_a = n.fc_w; a.fc_c = pair ? pair->fc_w : nullptr; a.Wfc2 = pair ? W.Wfc2 : nullptr;
     a.g_src = g_src; a.g_idx = g_idx; a.g_dst = W.obs_mb; a.g_rows = g_src ? g_rows : 0;
     a.zero_ptr = zero_ptr; a.zero_n = zero_ptr ? zero_n : 0;
+    a.z2 = W.dbbd; a.z2n = FEAT; a.z3 = reinterpret_cast<float*>(W.acc); a.z3n = 2 * NORM_PARTS_C;
     MANSY_REQUIRE(!zero_ptr || (reinterpret_cast<uintptr_t>(zero_ptr) & 15) == 0, "pack: gradient buffer must be 16-byte aligned");
     const int K = identifier ? K_IDENT : K_POLICY;
     const long long threads = (long long)FEAT * KP + (pair ? 2LL * HID * FEAT : 0) + (long long)a.g_rows * (OBS_LD / 4) + (a.zero_n + 3) / 4;
@@ -704,6 +692,7 @@ struct PEng {
     pa.g_src = g_src; pa.g_idx = idx; pa.g_dst = W.obs_mb; pa.g_rows = g_src ? mb : 0;
     pa.zero_ptr = zero_ptr; pa.zero_n = zero_ptr ? zero_n : 0;
     pa.adv = adv; pa.adv_n = mb; pa.adv_stats = W.adv_stats;
+    pa.z2 = W.dbbd; pa.z2n = FEAT; pa.z3 = reinterpret_cast<float*>(W.acc); pa.z3n = 2 * NORM_PARTS_C;
     MANSY_REQUIRE(!zero_ptr || (reinterpret_cast<uintptr_t>(zero_ptr) & 15) == 0, "pack: gradient buffer must be 16-byte aligned");
     const long long threads = (long long)FEAT * KP + 2LL * HID * FEAT + (long long)pa.g_rows * (OBS_LD / 4) + (pa.zero_n + 3) / 4;
     hipLaunchKernelGGL(pack_wbd_kernel, dim3(mansy_ceil_div(threads, 256) + 1), dim3(256), 0, st, pa, 0, K_POLICY, W.Wbd, W.bbd, W.krange);
@@ -717,7 +706,7 @@ struct PEng {
     return mansy_launch_gemm_f32(obs, OBS_LD, 0, W.Wbd, KP, 0, W.F, FEAT, B, FEAT, KP, ep, 0, 0, st);
   }
   int head(const NetP& n, int B, int n_out, int sigmoid, float* A1, float* H, float* out, const float* u, uint32_t seed, uint32_t site, int* act,
-           float* logp, const EnvFuse* env = nullptr) {
+           float* logp, const EnvFuse* env = nullptr, int out_ld = 0) {
     const int req = head_split_request(B);
     int nsplit = 0;
     if (req > 1) {
@@ -730,7 +719,7 @@ struct PEng {
       RC(mansy_launch_gemm_f32(W.F, FEAT, 0, n.fc_w, FEAT, 0, A1, HID, B, HID, FEAT, ep, 0, 0, st));
     }
     HeadOutArgs ha;
-    ha.h[0] = {A1, n.fc_b, n.out_w, n.out_b, n_out, sigmoid, H, out, 0, act, logp};
+    ha.h[0] = {A1, n.fc_b, n.out_w, n.out_b, n_out, sigmoid, H, out, 0, act, logp, out_ld};
     ha.h[1] = ha.h[0];
     LossFuse none; memset(&none, 0, sizeof(none));
     EnvFuse ef; memset(&ef, 0, sizeof(ef));
@@ -741,15 +730,16 @@ struct PEng {
     return MANSY_OK;
   }
   // actor + critic on the shared features in one product ([B,1280] x [1280,256], K-split slabs) and one head_out launch
-  int head_pair(const NetP& a, const NetP& c, int B, const LossFuse* fuse = nullptr) {
+  // value != nullptr: the critic's output goes straight into that [B] vector (no strided copy afterwards)
+  int head_pair(const NetP& a, const NetP& c, int B, const LossFuse* fuse = nullptr, float* value = nullptr) {
     const int req = head_split_request(B, 2 * HID);
     const int nsplit = mansy_gemm_effective_splits(FEAT, req);
     MANSY_REQUIRE(nsplit <= MAX_SLABS, "head_pair: %d K splits exceed the slab sum's unroll", nsplit);
     GemmEpilogue ep; ep.split_slab = (long long)B * 2 * HID;
     RC(mansy_launch_gemm_f32(W.F, FEAT, 0, W.Wfc2, FEAT, 0, W.A1s, 2 * HID, B, 2 * HID, FEAT, ep, 0, req, st));
     HeadOutArgs ha;
-    ha.h[0] = {W.A1a, a.fc_b, a.out_w, a.out_b, NACT, 0, W.Ha, W.outa, 0, nullptr, nullptr};
-    ha.h[1] = {W.A1c, c.fc_b, c.out_w, c.out_b, 1, 0, W.Hc, W.outc, HID, nullptr, nullptr};
+    ha.h[0] = {W.A1a, a.fc_b, a.out_w, a.out_b, NACT, 0, W.Ha, W.outa, 0, nullptr, nullptr, 0};
+    ha.h[1] = {W.A1c, c.fc_b, c.out_w, c.out_b, 1, 0, W.Hc, value ? value : W.outc, HID, nullptr, nullptr, value ? 1 : 0};
     LossFuse lf; memset(&lf, 0, sizeof(lf));
     if (fuse) lf = *fuse;
     EnvFuse noenv; memset(&noenv, 0, sizeof(noenv));
@@ -768,8 +758,10 @@ struct PEng {
     MANSY_LAUNCH_CHECK();
     GemmEpilogue acc; acc.accumulate = 1; acc.a_rowsum = n.gfc_b;                                           // gfc_b += column sums of dA1
     RC(mansy_launch_gemm_f32(dA1, HID, 1, W.F, FEAT, 1, n.gfc_w, FEAT, HID, FEAT, B, acc, 0, 0, st));      // gfc_w += dA1^T F
-    GemmEpilogue ep; if (accumulate_dF) { ep.resid = W.dF; ep.resid_ld = FEAT; }
-    return mansy_launch_gemm_f32(dA1, HID, 0, n.fc_w, FEAT, 1, W.dF, FEAT, B, FEAT, HID, ep, 0, 0, st);    // dF (+)= dA1 Wfc
+    MANSY_REQUIRE(!accumulate_dF, "head_bwd: accumulating dF is not supported with the fused LeakyReLU-derivative epilogue");
+    // dPre = (dA1 Wfc + [dH in the residual columns]) * leaky'(F): residual join + derivative in the product's epilogue
+    GemmEpilogue ep; ep.pre_a = dH; ep.pre_ld = HID; ep.pre_col0 = RESID_COL; ep.mask_src = W.F; ep.mask_ld = FEAT; ep.mask_scale = 1.f; ep.mask_neg = SLOPE;
+    return mansy_launch_gemm_f32(dA1, HID, 0, n.fc_w, FEAT, 1, W.dF, FEAT, B, FEAT, HID, ep, 0, 0, st);
   }
   // both heads' backward: one output-layer launch, the two fc weight gradients, ONE dF = [dA1a | dA1c] [Wfc_a ; Wfc_c] product
   int head_bwd_pair(const NetP& a, const NetP& c, int B, const LossFinish* finish = nullptr) {
@@ -784,15 +776,16 @@ struct PEng {
     acc.a_rowsum = a.gfc_b;
     acc.pair_A = W.dA1p + HID; acc.pair_B = W.F; acc.pair_C = c.gfc_w; acc.pair_rowsum = c.gfc_b;
     RC(mansy_launch_gemm_f32(W.dA1p, 2 * HID, 1, W.F, FEAT, 1, a.gfc_w, FEAT, HID, FEAT, B, acc, 0, 0, st));
-    GemmEpilogue ep;
+    // dPre = ([dA1a | dA1c] [Wfc_a ; Wfc_c] + [dHa + dHc in the residual columns]) * leaky'(F) -- the former featgrad_finish launch
+    GemmEpilogue ep; ep.pre_a = W.dHa; ep.pre_b = W.dHc; ep.pre_ld = HID; ep.pre_col0 = RESID_COL;
+    ep.mask_src = W.F; ep.mask_ld = FEAT; ep.mask_scale = 1.f; ep.mask_neg = SLOPE;
     return mansy_launch_gemm_f32(W.dA1p, 2 * HID, 0, W.Wfc2, FEAT, 1, W.dF, FEAT, B, FEAT, 2 * HID, ep, 0, 0, st);
   }
   // norm_tail != nullptr: also leave the squared norm of ALL gradients (branches + [norm_tail, norm_tail + norm_tail_n)) in W.acc
   int featnet_bwd(const NetP& n, const float* obs, int B, int identifier, const float* dHa, const float* dHb, const float* norm_tail = nullptr,
                   long long norm_tail_n = 0) {
     const int K = identifier ? K_IDENT : K_POLICY;
-    hipLaunchKernelGGL(featgrad_finish_kernel, dim3(mansy_ceil_div((long long)B * FEAT, 256)), dim3(256), 0, st, W.dF, dHa, dHb, W.F, (long long)B * FEAT,
-                       W.dbbd, norm_tail ? W.acc : nullptr);
+    (void)dHa; (void)dHb;      // joined inside the dF product's epilogue (head_bwd / head_bwd_pair); dbbd and the norm slots were zeroed by pack
     GemmEpilogue ep; ep.a_rowsum = W.dbbd;                                                                   // dbbd = column sums of dPre
     RC(mansy_launch_gemm_f32(W.dF, FEAT, 1, obs, OBS_LD, 1, W.dWbd, K, FEAT, K, B, ep, 0, 1, st));           // dWbd = dPre^T obs
     UnpackArgs u; for (int j = 0; j < NB; ++j) { u.gbw[j] = n.gbw[j]; u.gbb[j] = n.gbb[j]; }
@@ -868,10 +861,7 @@ int mansy_policy_forward(const float* const* params, const float* obs, int B, fl
   if (!reuse_packed) RC(e.pack(a, 0));      // rollouts: the block-diagonal image of the (unchanged) parameters is packed once per collect
   RC(e.featnet(obs, B, 0));
   RC(e.head(a, B, NACT, 0, e.W.A1a, e.W.Ha, logits ? logits : e.W.outa, u, seed, site, act, logp));
-  if (value) {
-    RC(e.head(c, B, 1, 0, e.W.A1c, e.W.Hc, e.W.outc, nullptr, 0, 0, nullptr, nullptr));
-    MANSY_HIP_CHECK(hipMemcpy2DAsync(value, sizeof(float), e.W.outc, sizeof(float) * MAXOUT, sizeof(float), B, hipMemcpyDeviceToDevice, e.st));
-  }
+  if (value) RC(e.head(c, B, 1, 0, e.W.A1c, e.W.Hc, value, nullptr, 0, 0, nullptr, nullptr, nullptr, 1));     // written as a [B] vector
   return MANSY_OK;
 }
 
@@ -916,8 +906,7 @@ int mansy_identifier_train_step(const float* const* params, float* const* grads,
   RC(e.pack(n, 1));
   RC(e.featnet(obs, B, 1));
   RC(e.head(n, B, 3, 1, e.W.A1a, e.W.Ha, e.W.outa, nullptr, 0, 0, nullptr, nullptr));
-  MANSY_HIP_CHECK(hipMemsetAsync(e.W.acc, 0, sizeof(double), e.st));
-  const bool train = step != 0;        // step < 0: gradients only (data-parallel callers all-reduce, then mansy_clip_grad_adam)
+  const bool train = step != 0;      // (W.acc[0], the loss accumulator, was zeroed by the pack launch's riders)        // step < 0: gradients only (data-parallel callers all-reduce, then mansy_clip_grad_adam)
   // (gout needs no zero-fill: head_out_bwd_kernel selects columns < n_out and never uses the rest)
   hipLaunchKernelGGL(ident_mse_kernel, dim3(min(mansy_ceil_div(B * 3, 256), 256)), dim3(256), 0, e.st, e.W.outa, obs, B, train ? e.W.gout : nullptr, e.W.acc);
   hipLaunchKernelGGL(ident_mse_finish, dim3(1), dim3(1), 0, e.st, e.W.acc, B, loss_out);
@@ -954,16 +943,13 @@ int mansy_policy_evaluate(const float* const* params, const float* obs, int B, c
   RC(e.pack(a, 0, both ? &c : nullptr));
   RC(e.featnet(obs, B, 0));
   if (logp) MANSY_REQUIRE(act, "policy_evaluate: logp needs actions");
-  if (both) RC(e.head_pair(a, c, B));                      // actor + critic in one stacked product
+  if (both) RC(e.head_pair(a, c, B, nullptr, value));      // actor + critic in one stacked product; the value lands in `value`
   if (logp) {
     if (!both) RC(e.head(a, B, NACT, 0, e.W.A1a, e.W.Ha, e.W.outa, nullptr, 0, 0, nullptr, nullptr));
     hipLaunchKernelGGL(logp_kernel, dim3(mansy_ceil_div(B, 256)), dim3(256), 0, e.st, e.W.outa, act, B, logp);
     MANSY_LAUNCH_CHECK();
   }
-  if (value) {
-    if (!both) RC(e.head(c, B, 1, 0, e.W.A1c, e.W.Hc, e.W.outc, nullptr, 0, 0, nullptr, nullptr));
-    MANSY_HIP_CHECK(hipMemcpy2DAsync(value, sizeof(float), e.W.outc, sizeof(float) * MAXOUT, sizeof(float), B, hipMemcpyDeviceToDevice, e.st));
-  }
+  if (value && !both) RC(e.head(c, B, 1, 0, e.W.A1c, e.W.Hc, value, nullptr, 0, 0, nullptr, nullptr, nullptr, 1));
   return MANSY_OK;
 }
 
@@ -1017,6 +1003,10 @@ int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, fl
   const float* tail = grads[2 * NB];
   const long long tail_n = (flat_g + n_flat) - tail;
   MANSY_REQUIRE(!ride || (tail >= flat_g && tail_n > 0 && tail_n <= n_flat), "ppo_minibatch_step: grads[] must point into flat_g");
+  // (Tried and dropped, round 2: unpack + norm + clip + Adam as ONE launch with a device-scope barrier between the norm and the
+  // update -- 64..256 resident workgroups, two returning atomics per workgroup, gradients kept in registers across the barrier.
+  // 22-32 us per launch against 12 us for the two launches it replaced: a kernel boundary is cheaper than a device-scope
+  // rendezvous on this chip, as tools/chain_lab.hip found for the GEMM chain.)
   RC(e.featnet_bwd(a, obs, mb, 0, e.W.dHa, e.W.dHc, ride ? tail : nullptr, ride ? tail_n : 0));
   return e.clip_and_adam(flat_p, flat_g, flat_m, flat_v, n_flat, max_grad_norm, lr, weight_decay, step, tail_from, tail_step, ride);
 }

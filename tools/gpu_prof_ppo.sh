@@ -13,7 +13,8 @@ f=$(ls -t gpurun_out/prof_ppo/*/*kernel_stats.csv | head -1); python3 - "$f" <<'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 tot = sum(int(r['TotalDurationNs']) for r in rows); n = sum(int(r['Calls']) for r in rows)
-print('total kernel ms per cycle', tot / 12 / 1e6, 'launches per cycle', n / 12)
+NC = 14  # 10 timed + 2 warm-up + 2 roofline-leg cycles
+print("total kernel ms per cycle", tot / NC / 1e6, "launches per cycle", n / NC)
 for r in rows[:30]:
-    print(f"{r['Name'][:70]:70s} calls/cyc={int(r['Calls'])/12:7.1f} avg_us={float(r['AverageNs'])/1e3:8.1f} ms/cyc={int(r['TotalDurationNs'])/12/1e6:7.3f}")
+    print(f"{r['Name'][:70]:70s} calls/cyc={int(r['Calls'])/NC:7.1f} avg_us={float(r['AverageNs'])/1e3:8.1f} ms/cyc={int(r['TotalDurationNs'])/NC/1e6:7.3f}")
 PY
