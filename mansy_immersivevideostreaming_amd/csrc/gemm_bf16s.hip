@@ -211,8 +211,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16s_kernel(GemmParams p) {
       stage_load<BM, AKM>(ca, p.lda, offa, va);
       stage_load<BN, BKM>(cb, p.ldb, offb, vb);
       stage_store(0);
-      ca += step_a; cb += step_b;
-      if (nk > 1) {
+      if (nk > 1) {                                        // (nk == 1: the corners stay on tile 0 -- the loop body's unconditional
+        ca += step_a; cb += step_b;                        //  re-load must never leave the operand)
         stage_load<BM, AKM>(ca, p.lda, offa, va);
         stage_load<BN, BKM>(cb, p.ldb, offb, vb);
       }

@@ -230,9 +230,17 @@ struct Eng {
   MansyDrop dr(uint32_t site, float p) const { MansyDrop x; x.p = train ? p : 0.f; x.seed = seed; x.site = site; return x; }
 
   // Y[rows,N] = X[rows,K] W[N,K]^T (+b) with epilogue
-  int lin_fwd(const float* X, int rows, int K, const float* w, const float* b, int Nout, float* Y, int relu, MansyDrop drop) {
-    GemmEpilogue ep; ep.bias = b; ep.relu = relu; ep.drop = drop;
+  // resid != nullptr: Y = resid + drop(X W^T + b) -- the sub-layer's residual sum z, written by the product's epilogue, so that
+  // the LayerNorm that follows reads ONE tensor and writes one (it used to read x and the product, and write z and y).
+  // Same fp32 operations in the same order as drop(product) stored and then added by the LayerNorm kernel: bit-identical.
+  int lin_fwd(const float* X, int rows, int K, const float* w, const float* b, int Nout, float* Y, int relu, MansyDrop drop,
+              const float* resid = nullptr) {
+    GemmEpilogue ep; ep.bias = b; ep.relu = relu; ep.drop = drop; ep.resid = resid; ep.resid_ld = Nout;
     return mansy_launch_gemm_f32(X, K, 0, w, K, 0, Y, Nout, rows, Nout, K, ep, 0, 0, st);
+  }
+  // y = LN(z) for a z already formed by lin_fwd(..., resid)
+  int ln_of(const float* z, const NormP& n, float* y, float* m, float* r, int rows) {
+    return mansy_launch_layernorm_fwd(z, nullptr, n.w, n.b, nullptr, y, m, r, rows, d, c.ln_eps, st);
   }
   // dX[rows,K] = dY[rows,N] W[N,K] (+resid) (mask)
   int lin_dx(const float* dY, int rows, int Nout, const float* w, int K, float* dX, const float* resid, const float* mask_src,
@@ -288,11 +296,11 @@ struct Eng {
       const EncLayerP& p = P.enc[l]; EncBuf& e = W.enc[l];
       RC(lin_fwd(x, N, d, p.in_proj.w, p.in_proj.b, 3 * d, e.qkv, 0, mansy_no_drop()));
       RC(mansy_launch_attn_fwd(e.qkv, e.qkv + d, e.qkv + 2 * d, e.ao, e.P, enc_shape(), dr(site_enc(l, 0), c.p_drop), st));
-      RC(lin_fwd(e.ao, N, d, p.out_proj.w, p.out_proj.b, d, W.t_enc, 0, dr(site_enc(l, 1), c.p_drop)));
-      RC(ln_fwd(x, W.t_enc, p.n1, e.z1, e.y1, e.m1, e.r1, N));
+      RC(lin_fwd(e.ao, N, d, p.out_proj.w, p.out_proj.b, d, e.z1, 0, dr(site_enc(l, 1), c.p_drop), x));          // z1 = x + drop(out_proj(ao))
+      RC(ln_of(e.z1, p.n1, e.y1, e.m1, e.r1, N));
       RC(lin_fwd(e.y1, N, d, p.lin1.w, p.lin1.b, f, e.h, 1, dr(site_enc(l, 2), c.p_drop)));
-      RC(lin_fwd(e.h, N, f, p.lin2.w, p.lin2.b, d, W.t_enc, 0, dr(site_enc(l, 3), c.p_drop)));
-      RC(ln_fwd(e.y1, W.t_enc, p.n2, e.z2, e.y2, e.m2, e.r2, N));
+      RC(lin_fwd(e.h, N, f, p.lin2.w, p.lin2.b, d, e.z2, 0, dr(site_enc(l, 3), c.p_drop), e.y1));                // z2 = y1 + drop(lin2(h))
+      RC(ln_of(e.z2, p.n2, e.y2, e.m2, e.r2, N));
       x = e.y2;
     }
     RC(ln_fwd(x, nullptr, P.enc_norm, nullptr, W.enc_out, W.me, W.re, N));
@@ -321,17 +329,20 @@ struct Eng {
         RC(lin_fwd(xi, B, d, p.sa_in.w, p.sa_in.b, 3 * d, qkv_i, 0, mansy_no_drop()));
         RC(mansy_launch_attn_fwd(qkv_i, e.qkv + d, e.qkv + 2 * d, e.ao1 + o * d, e.P1 + o * H * T, self_shape(i),
                                  dr(site_dec(l, i, 0), c.p_drop), st));
-        RC(lin_fwd(e.ao1 + o * d, B, d, p.sa_out.w, p.sa_out.b, d, W.t_dec, 0, dr(site_dec(l, i, 1), c.p_drop)));
-        RC(ln_fwd(xi, W.t_dec, p.n1, e.z1 + o * d, e.y1 + o * d, e.m1 + o, e.r1 + o, B));
+        RC(lin_fwd(e.ao1 + o * d, B, d, p.sa_out.w, p.sa_out.b, d, e.z1 + o * d, 0, dr(site_dec(l, i, 1), c.p_drop), xi));
+        RC(ln_of(e.z1 + o * d, p.n1, e.y1 + o * d, e.m1 + o, e.r1 + o, B));
         RC(lin_fwd(e.y1 + o * d, B, d, p.ca_in.w, p.ca_in.b, d, e.qc + o * d, 0, mansy_no_drop()));
         RC(mansy_launch_attn_fwd(e.qc + o * d, e.memkv, e.memkv + d, e.ao2 + o * d, e.P2 + o * H * M, cross_shape(),
                                  dr(site_dec(l, i, 2), c.p_drop), st));
-        RC(lin_fwd(e.ao2 + o * d, B, d, p.ca_out.w, p.ca_out.b, d, W.t_dec, 0, dr(site_dec(l, i, 3), c.p_drop)));
-        RC(ln_fwd(e.y1 + o * d, W.t_dec, p.n2, e.z2 + o * d, e.y2 + o * d, e.m2 + o, e.r2 + o, B));
+        RC(lin_fwd(e.ao2 + o * d, B, d, p.ca_out.w, p.ca_out.b, d, e.z2 + o * d, 0, dr(site_dec(l, i, 3), c.p_drop), e.y1 + o * d));
+        RC(ln_of(e.z2 + o * d, p.n2, e.y2 + o * d, e.m2 + o, e.r2 + o, B));
         RC(lin_fwd(e.y2 + o * d, B, d, p.lin1.w, p.lin1.b, f, e.h + o * f, 1, dr(site_dec(l, i, 4), c.p_drop)));
-        RC(lin_fwd(e.h + o * f, B, f, p.lin2.w, p.lin2.b, d, W.t_dec, 0, dr(site_dec(l, i, 5), c.p_drop)));
-        if (fuse_tail && l == c.n_dec - 1) break;             // LayerNorm3 of the last layer is the head of the fused tail
-        RC(ln_fwd(e.y2 + o * d, W.t_dec, p.n3, e.z3 + o * d, e.y3 + o * d, e.m3 + o, e.r3 + o, B));
+        if (fuse_tail && l == c.n_dec - 1) {                  // LayerNorm3 of the last layer is the head of the fused tail (a + b form)
+          RC(lin_fwd(e.h + o * f, B, f, p.lin2.w, p.lin2.b, d, W.t_dec, 0, dr(site_dec(l, i, 5), c.p_drop)));
+          break;
+        }
+        RC(lin_fwd(e.h + o * f, B, f, p.lin2.w, p.lin2.b, d, e.z3 + o * d, 0, dr(site_dec(l, i, 5), c.p_drop), e.y2 + o * d));
+        RC(ln_of(e.z3 + o * d, p.n3, e.y3 + o * d, e.m3 + o, e.r3 + o, B));
         xi = e.y3 + o * d;
       }
       const size_t o = (size_t)i * B;

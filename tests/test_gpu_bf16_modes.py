@@ -356,3 +356,25 @@ def test_c5_eight_preference_table_identifier_and_ppo_cycle(K, M, mode):
     np.testing.assert_allclose(got['ppo_losses'][:4], ref['ppo_losses'][:4], rtol={'bf16x6': 2e-3, 'bf16x3': 2e-2}[mode], atol=1e-4)
     assert np.isfinite(got['id_losses']).all() and np.isfinite(got['ppo_losses']).all() and torch.isfinite(got['flat']).all()
     assert got['id_losses'][-1] < got['id_losses'][0]
+
+
+@pytest.mark.parametrize('mode', MODES + ['f32'])
+def test_single_k_tile_products_at_the_end_of_an_allocation(K, mode):
+    """K == 32 (one K-tile per workgroup) with the operands placed at the very end of their own 64 MiB allocations: the pipelined
+    loops re-load their last tile instead of branching, and must never form an address beyond the operand (round-2 regression:
+    the two-stage split loop advanced its tile corners once too often when there was a single K-tile -- a read past the end
+    that only faults when the next page is unmapped)."""
+    g = torch.Generator().manual_seed(2)
+    n_big = 16 * 1024 * 1024                                   # 64 MiB of floats: a multiple of the allocator's 2 MiB segments
+    for akm, bkm, M, N in ((0, 0, 192, 64), (1, 1, 128, 192), (0, 1, 64, 128), (1, 0, 256, 64)):
+        bigA, bigB = torch.empty(n_big, device='cuda'), torch.empty(n_big, device='cuda')
+        A = bigA[n_big - M * 32:].view((32, M) if akm else (M, 32))
+        B = bigB[n_big - N * 32:].view((32, N) if bkm else (N, 32))
+        A.copy_(torch.randn(A.shape, generator=g)); B.copy_(torch.randn(B.shape, generator=g))
+        ref = (A.double().t() if akm else A.double()) @ (B.double() if bkm else B.double().t())
+        with K.precision(mode):
+            for tile in (0, 64, 128):
+                C = K.gemm(A, B, bool(akm), bool(bkm), force_tile=tile)
+                torch.cuda.synchronize()
+                assert ((C.double() - ref).abs().max() / ref.abs().max()).item() < GEMM_TOL[mode]
+        del bigA, bigB
