@@ -279,6 +279,14 @@ int mansy_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ld
 #define MANSY_PREC_BF16X6 6
 int mansy_set_gemm_precision(int mode);
 int mansy_get_gemm_precision(void);
+/* Split-bf16 modes, weights split ahead of the products (what the viewport engine does once per step for every Linear / Conv1d weight):
+ * mansy_weight_planes writes n_planes (2: bf16x3, 3: bf16x6) bf16 planes of W [N, K] (plane t at out + t * plane_stride, row-major [N, K])
+ * and of its transpose (out_t + t * plane_stride, row-major [K, N]); mansy_gemm_planes is mansy_gemm_f32 with a K-contiguous A and those
+ * planes as the B operand (planes of W for C = A W^T, planes of W^T -- planes_ld = N of W -- for C = A W): in the split modes B then
+ * reaches LDS by LDS-DMA, with no split work in the loop.  B / ldb / b_kmajor describe the same operand in fp32 (used in fp32 mode). */
+int mansy_weight_planes(const float* W, int N, int K, uint16_t* out, uint16_t* out_t, long long plane_stride, int n_planes, void* stream);
+int mansy_gemm_planes(const float* A, int lda, const float* B, int ldb, int b_kmajor, const uint16_t* planes, long long plane_stride,
+                      int planes_ld, float* C, int ldc, int M, int N, int K, const mansy_gemm_epilogue* ep, int force_tile, void* stream);
 typedef struct mansy_attn_shape {
   int nb, H, Lq, Lk, dh;
   long long q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;

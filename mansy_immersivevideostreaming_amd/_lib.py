@@ -72,6 +72,8 @@ _PROTOS = {
     'mansy_gemm_f32': [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, P, c_int, c_int, P],
     'mansy_set_gemm_precision': [c_int],
     'mansy_get_gemm_precision': [],
+    'mansy_weight_planes': [P, c_int, c_int, P, P, c_ll, c_int, P],
+    'mansy_gemm_planes': [P, c_int, P, c_int, c_int, P, c_ll, c_int, P, c_int, c_int, c_int, c_int, P, c_int, P],
     'mansy_attn_fwd': [P, P, P, P, P, P, c_float, c_u32, c_u32, P],
     'mansy_attn_bwd': [P, P, P, P, P, P, P, P, P, c_float, c_u32, c_u32, c_int, P],
     'mansy_layernorm_fwd': [P, P, P, P, P, P, P, P, c_int, c_int, c_float, P],
@@ -120,7 +122,7 @@ _RESTYPES = {'mansy_last_error': ctypes.c_char_p, 'mansy_vp_workspace_bytes': ct
 
 # bumped together with mansy_abi_version() (csrc/capi.hip) whenever a prototype or struct above changes: a stale in-tree
 # libmansy_hip.so then fails at load time instead of being called with a wrong argument list
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 

@@ -26,7 +26,7 @@ extern "C" {
 int mansy_set_bn_sync_hook(mansy_bn_sync_fn fn, void* user) { g_bn_hook = fn; g_bn_user = user; return MANSY_OK; }
 
 const char* mansy_last_error(void) { return g_err; }
-int mansy_abi_version(void) { return 2; }   // == _lib.py ABI_VERSION
+int mansy_abi_version(void) { return 3; }   // == _lib.py ABI_VERSION
 
 int mansy_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb, int b_kmajor, float* C, int ldc, int M, int N,
                    int K, const mansy_gemm_epilogue* ep, int force_tile, int force_splitk, void* stream) {
@@ -39,6 +39,24 @@ int mansy_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ld
   MANSY_REQUIRE(force_tile == 0 || force_tile == 64 || force_tile == 96 || force_tile == 128 || force_tile == -64 || force_tile == -128,
                 "gemm: force_tile must be 0, 64, 96 (128x64), 128, or -64 / -128 (register-staged loop)");
   return mansy_launch_gemm_f32(A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, e, force_tile, force_splitk, (hipStream_t)stream);
+}
+
+int mansy_weight_planes(const float* W, int N, int K, uint16_t* out, uint16_t* out_t, long long plane_stride, int n_planes, void* stream) {
+  MANSY_REQUIRE(W && N >= 1 && K >= 1 && plane_stride >= (long long)N * K, "weight_planes: bad arguments");
+  MansyWPlaneTab tab; tab.n = 1; tab.w[0] = W; tab.N[0] = N; tab.K[0] = K; tab.off[0] = 0;
+  return mansy_launch_weight_planes(tab, out, out_t, plane_stride, n_planes, (hipStream_t)stream);
+}
+
+int mansy_gemm_planes(const float* A, int lda, const float* B, int ldb, int b_kmajor, const uint16_t* planes, long long plane_stride, int planes_ld,
+                      float* C, int ldc, int M, int N, int K, const mansy_gemm_epilogue* ep, int force_tile, void* stream) {
+  GemmEpilogue e;
+  if (ep) {
+    e.bias = ep->bias; e.relu = ep->relu; e.mask_src = ep->mask_src; e.mask_ld = ep->mask_ld; e.mask_scale = ep->mask_scale;
+    e.drop.p = ep->drop_p; e.drop.seed = ep->drop_seed; e.drop.site = ep->drop_site;
+    e.resid = ep->resid; e.resid_ld = ep->resid_ld; e.accumulate = ep->accumulate;
+  }
+  e.b_planes = planes; e.b_plane_stride = plane_stride; e.b_planes_ld = planes_ld;
+  return mansy_launch_gemm_f32(A, lda, 0, B, ldb, b_kmajor, C, ldc, M, N, K, e, force_tile, 0, (hipStream_t)stream);
 }
 
 static AttnShape to_shape(const mansy_attn_shape* s) {

@@ -265,6 +265,171 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16s_kernel(GemmParams p) {
   gemm_epilogue<BM, BN, SMEM_FLOATS>(p, acc, smem, m0, n0, tid, split, p.C);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Pre-split B: the weights' bf16 planes exist in HBM (mansy_launch_weight_planes, once per step), so the B tiles go HBM/L2 -> LDS by
+// LDS-DMA -- no split VALU work, no staging registers and no ds_write for that operand (the ds_write path, ~80 B/clk/CU, is what
+// bounds the in-loop split: removing B's writes measured -17 % on the forward / dX shapes).  A (activations, K-contiguous) is
+// split in the loop as above.  Two LDS stages in the compact swizzled layout; the DMA of tile t+1 is issued first thing in
+// iteration t (its stage was released by the previous barrier) and has the whole iteration to land.
+template <int BM, int BN, int NP>
+__global__ __launch_bounds__(NT, 2) void gemm_bf16p_kernel(GemmParams p) {
+  constexpr int TM = BM / 64, TN = BN / 64, PB = BN / 16;                 // PB: 1-KiB DMA pieces (16 rows x 64 B) per B plane
+  constexpr int A_PLANE = BM * 32, B_PLANE = BN * 32;                     // bf16 elements
+  constexpr int STAGE = NP * (A_PLANE + B_PLANE);
+  constexpr int STAGE_FLOATS = 2 * STAGE / 2;
+  constexpr int C_FLOATS = BM * (BN + 4);
+  constexpr int SMEM_FLOATS = STAGE_FLOATS > C_FLOATS ? STAGE_FLOATS : C_FLOATS;
+  __shared__ __attribute__((aligned(1024))) float smem[SMEM_FLOATS];
+  __bf16* const planes = reinterpret_cast<__bf16*>(smem);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  int tile_x, tile_y;
+  {   // XCD-aware bijective remap (no split-K on this path: forward and dX products only)
+    const int nwg = gridDim.x * gridDim.y, orig = blockIdx.y * gridDim.x + blockIdx.x;
+    const int q = nwg >> 3, rem = nwg & 7, xcd = orig & 7, local = orig >> 3;
+    const int t = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + local;
+    tile_y = t / gridDim.x; tile_x = t - tile_y * gridDim.x;
+  }
+  const int m0 = tile_y * BM, n0 = tile_x * BN;
+  const int nk = p.K / BK;
+
+  unsigned offa[Stg<BM>::ITEMS];
+  int lda_[Stg<BM>::ITEMS], rowa[Stg<BM>::ITEMS];
+  stage_offsets<BM, false, false>(p.lda, m0, p.M, offa, lda_, rowa, tid);
+  const float* ca = p.A + (long long)m0 * p.lda;
+  // B planes: this wave's pieces wave, wave + 4, ... of every plane; lane -> (row, 16-byte slot), source chunk = slot ^ key(row)
+  const unsigned short* cb = p.ep.b_planes + (long long)n0 * p.ep.b_planes_ld;
+  unsigned vob[(PB + 3) / 4];
+#pragma unroll
+  for (int i = 0; i < (PB + 3) / 4; ++i) {
+    const int row = (wave + 4 * i) * 16 + (lane >> 2), slot = lane & 3;
+    const int q = slot ^ ((row >> 2) & 3);
+    vob[i] = (unsigned)(((min(n0 + row, p.N - 1) - n0) * p.ep.b_planes_ld + q * 8) * 2);
+  }
+  const unsigned lds_b0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem + (unsigned)(NP * A_PLANE * 2) + (unsigned)wave * 1024u);
+  auto dma_b = [&](int stage, const unsigned short* corner) {
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+      for (int i = 0; i < (PB + 3) / 4; ++i)
+        if (wave + 4 * i < PB)
+          glds16(vob[i], corner + (long long)pl * p.ep.b_plane_stride, lds_b0 + (unsigned)(stage * STAGE * 2) + (unsigned)(pl * B_PLANE * 2) + (unsigned)i * 4096u);
+  };
+  int fa[TM][2], fb[TN][2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[i][s] = lds_off<false>(wm * (BM / 2) + i * 32 + r, 2 * s + h);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[j][s] = lds_off<false>(wn * (BN / 2) + j * 32 + r, 2 * s + h);
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  float va[Stg<BM>::ITEMS][8];
+  auto stage_store_a = [&](int stage) {
+    __bf16* const a_pl = planes + stage * STAGE;
+#pragma unroll
+    for (int i = 0; i < Stg<BM>::ITEMS; ++i) split_store<NP>(a_pl + lda_[i], A_PLANE, va[i]);
+  };
+  auto mfma_step = [&](int stage, int s) {
+    const __bf16* const a_pl = planes + stage * STAGE;
+    const __bf16* const b_pl = a_pl + NP * A_PLANE;
+    bf16x8 af[TM][NP], bf[TN][NP];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) af[i][pl] = *reinterpret_cast<const bf16x8*>(a_pl + pl * A_PLANE + fa[i][s]);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) bf[j][pl] = *reinterpret_cast<const bf16x8*>(b_pl + pl * B_PLANE + fb[j][s]);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (NP == 3) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+        }
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+      }
+  };
+
+  if (nk > 0) {
+    dma_b(0, cb);
+    stage_load<BM, false>(ca, p.lda, offa, va);
+    stage_store_a(0);
+    if (nk > 1) { ca += BK; stage_load<BM, false>(ca, p.lda, offa, va); }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    cb += (kt + 1 < nk) ? BK : 0;                          // B tile kt+1 (the last iteration re-fetches its own tile: harmless)
+    dma_b(cur ^ 1, cb);
+    mfma_step(cur, 0);
+    stage_store_a(cur ^ 1);                                // A tile kt+1: registers -> the other stage, between the MFMAs
+    mfma_step(cur, 1);
+    ca += (kt + 2 < nk) ? BK : 0;                          // A tile kt+2: in flight across the whole next iteration
+    stage_load<BM, false>(ca, p.lda, offa, va);
+    // the DMA pieces are older than the A loads just issued (Stg<BM>::ITEMS x 2 dwordx4 per lane): wait for all but those
+    if (Stg<BM>::ITEMS == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    __syncthreads();
+  }
+  gemm_epilogue<BM, BN, SMEM_FLOATS>(p, acc, smem, m0, n0, tid, 0, p.C);
+}
+
+// ---- weights -> bf16 planes (and planes of the transpose), 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void weight_planes_kernel(MansyWPlaneTab tab, unsigned short* __restrict__ out, unsigned short* __restrict__ out_t,
+                                                           long long plane_stride, int n_planes) {
+  __shared__ float tile[32][33];
+  int t = 0, b = blockIdx.x;
+  for (; t < tab.n; ++t) {
+    const int tiles = ((tab.N[t] + 31) / 32) * ((tab.K[t] + 31) / 32);
+    if (b < tiles) break;
+    b -= tiles;
+  }
+  if (t >= tab.n) return;
+  const int N = tab.N[t], K = tab.K[t], tk = (K + 31) / 32;
+  const int n0 = (b / tk) * 32, k0 = (b % tk) * 32;
+  const float* W = tab.w[t];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;               // 32 x 8 threads, 4 rows each
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + ty + 8 * i, k = k0 + tx;
+    tile[ty + 8 * i][tx] = (n < N && k < K) ? W[(long long)n * K + k] : 0.f;
+  }
+  __syncthreads();
+  auto emit = [&](float x, unsigned short* dst) {
+    const __bf16 t0 = (__bf16)x;
+    const float r1 = x - (float)t0;
+    const __bf16 t1 = (__bf16)r1;
+    dst[0] = __builtin_bit_cast(unsigned short, t0);
+    dst[plane_stride] = __builtin_bit_cast(unsigned short, t1);
+    if (n_planes == 3) { const float r2 = r1 - (float)t1; dst[2 * plane_stride] = __builtin_bit_cast(unsigned short, (__bf16)r2); }
+  };
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + ty + 8 * i, k = k0 + tx;                           // W planes: row n, k contiguous across the 32 lanes
+    if (n < N && k < K) emit(tile[ty + 8 * i][tx], out + tab.off[t] + (long long)n * K + k);
+    const int kk = k0 + ty + 8 * i, nn = n0 + tx;                         // W^T planes: row k, n contiguous across the 32 lanes
+    if (kk < K && nn < N) emit(tile[tx][ty + 8 * i], out_t + tab.off[t] + (long long)kk * N + nn);
+  }
+}
+
 template <int BM, int BN, int NP, bool DB>
 int launch_layouts(const GemmParams& p, int a_kmajor, int b_kmajor, int splits, hipStream_t st) {
   dim3 grid(mansy_ceil_div(p.N, BN), mansy_ceil_div(p.M, BM), splits);
@@ -289,6 +454,32 @@ int mansy_gemm_bf16s_dispatch(const GemmParams& p, int tile, int prec, int a_kma
   }
   if (tile == 128) return launch_layouts<128, 128, 3, false>(p, a_kmajor, b_kmajor, splits, st);
   return launch_layouts<64, 64, 3, false>(p, a_kmajor, b_kmajor, splits, st);
+}
+
+// B pre-split into planes (weights): forward / dX products with a K-contiguous A
+int mansy_gemm_bf16p_dispatch(const GemmParams& p, int tile, int prec, hipStream_t st) {
+  const int BMN = tile == 128 ? 128 : 64;
+  dim3 grid(mansy_ceil_div(p.N, BMN), mansy_ceil_div(p.M, BMN), 1), block(NT);
+  if (prec == 3) {
+    if (tile == 128) hipLaunchKernelGGL((gemm_bf16p_kernel<128, 128, 2>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((gemm_bf16p_kernel<64, 64, 2>), grid, block, 0, st, p);
+  } else {
+    if (tile == 128) hipLaunchKernelGGL((gemm_bf16p_kernel<128, 128, 3>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((gemm_bf16p_kernel<64, 64, 3>), grid, block, 0, st, p);
+  }
+  MANSY_LAUNCH_CHECK();
+  return MANSY_OK;
+}
+
+int mansy_launch_weight_planes(const MansyWPlaneTab& tab, unsigned short* out, unsigned short* out_t, long long plane_stride, int n_planes,
+                               hipStream_t st) {
+  MANSY_REQUIRE(tab.n >= 0 && tab.n <= MANSY_WPLANE_MAX && out && out_t && (n_planes == 2 || n_planes == 3), "weight_planes: bad arguments");
+  long long tiles = 0;
+  for (int t = 0; t < tab.n; ++t) tiles += (long long)((tab.N[t] + 31) / 32) * ((tab.K[t] + 31) / 32);
+  if (tiles == 0) return MANSY_OK;
+  hipLaunchKernelGGL(weight_planes_kernel, dim3((unsigned)tiles), dim3(256), 0, st, tab, out, out_t, plane_stride, n_planes);
+  MANSY_LAUNCH_CHECK();
+  return MANSY_OK;
 }
 
 // resident workgroups per CU (diagnostic)

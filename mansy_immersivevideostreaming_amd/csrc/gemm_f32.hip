@@ -210,12 +210,6 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmParams p) {
 // One DMA piece: per-lane source = sbase (SGPR pair, wave-uniform) + voff (VGPR, bytes); destination = LDS byte address
 // lds_dst (wave-uniform, via M0) + lane*16.  Keeping the tile corner in SGPRs and the per-lane offsets loop-invariant makes a
 // piece 3 scalar instructions + the load (per-lane 64-bit address arithmetic in the K loop cost ~8 % of the MFMA rate).
-__device__ __forceinline__ void glds16(unsigned voff, const float* sbase, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
-}
-
 // Byte offsets of this lane's R/32 DMA pieces relative to the tile corner (row0, k0); piece i lands at LDS byte
 // (tile image) + i*4096 + wave*1024 + lane*16 for both layouts.
 template <int R, bool KMAJ>
@@ -431,6 +425,9 @@ extern "C" int mansy_prof_gemm_collect(double* total_ms, long long* launches, do
 
 // tile codes: 128 -> 128x128, 96 -> 128x64 (LDS-DMA loop only), 64 -> 64x64
 static int gemm_dispatch(const GemmParams& p, int tile, bool dma, int bf, int a_kmajor, int b_kmajor, int splits, hipStream_t st) {
+  if (bf && p.ep.b_planes && !a_kmajor && splits == 1 && !p.ep.tile_krange && (reinterpret_cast<uintptr_t>(p.ep.b_planes) & 15) == 0 &&
+      p.ep.b_planes_ld % 8 == 0 && p.ep.b_plane_stride % 8 == 0)
+    return mansy_gemm_bf16p_dispatch(p, tile, bf, st);            // weights pre-split into planes: B by LDS-DMA
   if (bf) return mansy_gemm_bf16s_dispatch(p, tile, bf, a_kmajor, b_kmajor, splits, st);
   if (dma) {
     if (tile == 128) return launch_dma<128, 128>(p, a_kmajor, b_kmajor, splits, st);

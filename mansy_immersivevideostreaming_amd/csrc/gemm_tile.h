@@ -168,7 +168,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
   }
 }
 
+// One LDS-DMA piece (global_load_lds_dwordx4): per-lane source = sbase (SGPR pair, wave-uniform) + voff (VGPR, bytes); destination = LDS
+// byte address lds_dst (wave-uniform, via M0) + lane * 16 -- 1 KiB of LDS written contiguously per wave instruction.  Issued through
+// inline asm (hipcc would put s_waitcnt vmcnt(0) in front of every ds_read that follows an LDS-DMA); completion is counted by hand.
+__device__ __forceinline__ void glds16(unsigned voff, const void* sbase, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
 }  // namespace mansy_gemm
 
 // split-bf16 main loop (gemm_bf16s.hip); tile 128 -> 128x128, else 64x64; prec 3 = bf16x3, 6 = bf16x6
 int mansy_gemm_bf16s_dispatch(const mansy_gemm::GemmParams& p, int tile, int prec, int a_kmajor, int b_kmajor, int splits, hipStream_t st);
+// B operand pre-split into bf16 planes (GemmEpilogue::b_planes), A K-contiguous, no split-K
+int mansy_gemm_bf16p_dispatch(const mansy_gemm::GemmParams& p, int tile, int prec, hipStream_t st);

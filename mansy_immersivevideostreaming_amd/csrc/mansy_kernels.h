@@ -43,7 +43,19 @@ struct GemmEpilogue {
   // (FeatureNet backward: the heads' residual gradients join the last 128 feature columns ahead of the LeakyReLU derivative,
   // which is the mask stage -- the former featgrad_finish launch.)
   const float* pre_a = nullptr; const float* pre_b = nullptr; int pre_ld = 0; int pre_col0 = 0;
+  // optional, split-bf16 modes only: the B operand already split into bf16 planes (weights, split once per step by
+  // mansy_launch_weight_planes): plane t of B(k, n) at b_planes[t * b_plane_stride + n * b_planes_ld + k] (K-contiguous rows, 16-byte
+  // aligned, b_planes_ld % 8 == 0).  With a K-contiguous A the product then stages B by LDS-DMA: no split work and no ds_write for it.
+  const unsigned short* b_planes = nullptr; long long b_plane_stride = 0; int b_planes_ld = 0;
 };
+
+// Weights -> bf16 planes for the split-bf16 products (gemm_bf16s.hip): for each listed [N, K] fp32 matrix W (leading dimension K)
+// n_planes planes of W (plane t at out + t * plane_stride + off + n * K + k) and of its transpose (at out_t + t * plane_stride + off +
+// k * N + n), a = a0 + a1 (+ a2) by round-to-nearest-even.  One launch for up to MANSY_WPLANE_MAX matrices.
+constexpr int MANSY_WPLANE_MAX = 32;
+struct MansyWPlaneTab { const float* w[MANSY_WPLANE_MAX]; int N[MANSY_WPLANE_MAX]; int K[MANSY_WPLANE_MAX]; long long off[MANSY_WPLANE_MAX]; int n; };
+int mansy_launch_weight_planes(const MansyWPlaneTab& tab, unsigned short* out, unsigned short* out_t, long long plane_stride, int n_planes,
+                               hipStream_t st);
 int mansy_gemm_effective_splits(int K, int requested);
 int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb, int b_kmajor,
                           float* C, int ldc, int M, int N, int K, const GemmEpilogue& ep, int force_tile,

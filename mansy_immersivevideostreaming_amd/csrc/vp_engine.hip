@@ -131,6 +131,8 @@ struct Work {
   float *dE_all, *dz_all, *dmem;
   float *lnp_dec, *lnp_enc;                                 // LayerNorm weight-gradient partial sums (norm.hip)
   double* loss_acc;
+  unsigned short *wpl, *wpl_t;                              // bf16 planes of the GEMM weights and of their transposes (split-bf16 modes)
+  long long wpl_stride;                                     // elements per plane (sum of the listed weights)
 };
 struct BufInfo { std::string name; size_t off; size_t bytes; };
 
@@ -196,6 +198,14 @@ void build_layout(const mansy_vp_config& c, Layout& L, Work& W) {
   W.lnp_dec = L.f("lnp.dec", (size_t)(3 * c.n_dec + 1) * mansy_ln_bwd_parts((int)B) * 2 * d);
   W.lnp_enc = L.f("lnp.enc", (size_t)mansy_ln_bwd_parts((int)N) * 2 * d);
   W.loss_acc = (double*)L.add("loss_acc", 64);
+  // split-bf16 modes: 3 planes x (W, W^T) of every GEMM weight, 2 bytes each (110 MB at d = 512; filled once per step)
+  size_t wtot = 0;
+  for (const ParamInfo& pi : param_table(c))
+    if (pi.ndim >= 2 && pi.shape[0] * (pi.numel / pi.shape[0]) == pi.numel && pi.numel / pi.shape[0] >= 32 && pi.shape[0] >= 32)
+      wtot += ((size_t)pi.numel + 63) / 64 * 64;
+  W.wpl_stride = (long long)wtot;
+  W.wpl = (unsigned short*)L.add("wplanes", wtot * 3 * sizeof(unsigned short));
+  W.wpl_t = (unsigned short*)L.add("wplanes_t", wtot * 3 * sizeof(unsigned short));
 }
 
 int check_cfg(const mansy_vp_config* c) {
@@ -223,9 +233,50 @@ struct Eng {
   float drop_scale;
 
   Eng(const mansy_vp_config& cfg, hipStream_t s, bool tr, uint32_t sd) : c(cfg), st(s), train(tr), seed(sd) {
+    wtab.n = 0;
     B = c.B; S = c.S; T = c.T; d = c.d_model; f = c.d_ff; H = c.n_head; dh = d / H; M = (S - 1) / 2 + 1;
     N = B * S; TB = T * B; C6 = c.in_ch;
     drop_scale = (train && c.p_drop > 0.f) ? 1.f / (1.f - c.p_drop) : 1.f;
+  }
+  // ---- split-bf16 modes: the GEMM weights' planes (gemm_bf16s.hip, pre-split B)
+  MansyWPlaneTab wtab; int prec = 0;
+  void wtab_add(const LinearP& L, int Nout, int K) {
+    if (!L.w || Nout < 32 || K < 32 || wtab.n >= MANSY_WPLANE_MAX) return;
+    long long off = 0;
+    for (int t = 0; t < wtab.n; ++t) off += ((long long)wtab.N[t] * wtab.K[t] + 63) / 64 * 64;
+    wtab.w[wtab.n] = L.w; wtab.N[wtab.n] = Nout; wtab.K[wtab.n] = K; wtab.off[wtab.n] = off; ++wtab.n;
+  }
+  // once per engine call that runs products: split every GEMM weight into planes (order == param_table order, so the offsets
+  // add up to the workspace size computed there)
+  int prepare_planes() {
+    prec = mansy_get_gemm_precision();
+    wtab.n = 0;
+    // bf16x3 only: measured +4 % on the forward / dX products (tools/gemm_bench.py --planes).  bf16x6 stays on the in-loop split:
+    // two LDS stages of three planes leave one workgroup per CU and ran 8-15 % SLOWER with pre-split weights.
+    if (prec != 3) return MANSY_OK;
+    for (int l = 0; l < c.n_enc; ++l) { const EncLayerP& p = P.enc[l]; wtab_add(p.in_proj, 3 * d, d); wtab_add(p.out_proj, d, d); wtab_add(p.lin1, f, d); wtab_add(p.lin2, d, f); }
+    for (int l = 0; l < c.n_dec; ++l) {
+      const DecLayerP& p = P.dec[l];
+      wtab_add(p.sa_in, 3 * d, d); wtab_add(p.sa_out, d, d); wtab_add(p.ca_in, 3 * d, d); wtab_add(p.ca_out, d, d); wtab_add(p.lin1, f, d); wtab_add(p.lin2, d, f);
+    }
+    wtab_add(P.conv, d, 3 * d);
+    long long tot = 0;
+    for (int t = 0; t < wtab.n; ++t) tot += ((long long)wtab.N[t] * wtab.K[t] + 63) / 64 * 64;
+    if (tot > W.wpl_stride) { wtab.n = 0; return MANSY_OK; }       // (cannot happen: same table as build_layout) -> in-loop split
+    return mansy_launch_weight_planes(wtab, W.wpl, W.wpl_t, W.wpl_stride, prec == 3 ? 2 : 3, st);
+  }
+  // planes of the sub-matrix starting at `w` (rows r0.. of a listed weight) for the forward (transposed = false: B = W [Nout, K]) or
+  // the dX product (transposed = true: B = W^T [K, Nout_total], columns r0..)
+  void attach_planes(GemmEpilogue& ep, const float* w, bool transposed) const {
+    for (int t = 0; t < wtab.n; ++t) {
+      const long long e = w - wtab.w[t];
+      if (e < 0 || e >= (long long)wtab.N[t] * wtab.K[t] || e % wtab.K[t]) continue;
+      const long long r0 = e / wtab.K[t];
+      ep.b_plane_stride = W.wpl_stride;
+      if (!transposed) { ep.b_planes = W.wpl + wtab.off[t] + r0 * wtab.K[t]; ep.b_planes_ld = wtab.K[t]; }
+      else { ep.b_planes = W.wpl_t + wtab.off[t] + r0; ep.b_planes_ld = wtab.N[t]; }
+      return;
+    }
   }
   MansyDrop dr(uint32_t site, float p) const { MansyDrop x; x.p = train ? p : 0.f; x.seed = seed; x.site = site; return x; }
 
@@ -236,6 +287,7 @@ struct Eng {
   int lin_fwd(const float* X, int rows, int K, const float* w, const float* b, int Nout, float* Y, int relu, MansyDrop drop,
               const float* resid = nullptr) {
     GemmEpilogue ep; ep.bias = b; ep.relu = relu; ep.drop = drop; ep.resid = resid; ep.resid_ld = Nout;
+    if (prec) attach_planes(ep, w, false);
     return mansy_launch_gemm_f32(X, K, 0, w, K, 0, Y, Nout, rows, Nout, K, ep, 0, 0, st);
   }
   // y = LN(z) for a z already formed by lin_fwd(..., resid)
@@ -246,6 +298,7 @@ struct Eng {
   int lin_dx(const float* dY, int rows, int Nout, const float* w, int K, float* dX, const float* resid, const float* mask_src,
              float mask_scale) {
     GemmEpilogue ep; ep.resid = resid; ep.resid_ld = K; ep.mask_src = mask_src; ep.mask_ld = K; ep.mask_scale = mask_scale;
+    if (prec) attach_planes(ep, w, true);
     return mansy_launch_gemm_f32(dY, Nout, 0, w, K, 1, dX, K, rows, K, Nout, ep, 0, 0, st);
   }
   // gw[N,K] += dY[rows,N]^T X[rows,K] ; gb[N] += colsum(dY)
@@ -290,6 +343,7 @@ struct Eng {
 
   // ------------------------------------------------------------------ forward
   int forward(const float* src, const float* cur, const float* pe, float* bn_rm, float* bn_rv, long long* bn_nbt, float* pred_bt) {
+    RC(prepare_planes());
     RC(mansy_launch_embed_fwd(src, C6, P.emb.w, P.emb.b, pe, W.x0, N, d, S, -1, dr(site_pe_src(), c.p_pe), st));
     const float* x = W.x0;
     for (int l = 0; l < c.n_enc; ++l) {
@@ -370,6 +424,7 @@ struct Eng {
 
   // ------------------------------------------------------------------ backward
   int backward(const float* src, const float* dpred_bt) {
+    if (wtab.n == 0) RC(prepare_planes());      // separate mansy_vp_backward call: the weights have not changed since the forward
     const float ms = drop_scale;
     // Cross-attention K/V gradients: every step attends to the same memory rows, so (where the 4-heads-per-wave kernels
     // apply) the steps only record their coefficients and ONE pass per layer forms dK/dV -- instead of T read-modify-write

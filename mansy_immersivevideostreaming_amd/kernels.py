@@ -44,6 +44,39 @@ def gemm(A, B, a_kmajor=False, b_kmajor=False, bias=None, relu=False, mask_src=N
     return out
 
 
+def weight_planes(W, n_planes):
+    """bf16 planes of a weight W [N, K] and of its transpose for the split-bf16 products: (planes [n_planes, N, K], planes_t
+    [n_planes, K, N]) as int16 tensors (mansy_weight_planes)."""
+    _gpu(W)
+    W = W.contiguous().float()
+    N, K = W.shape
+    out = torch.empty(n_planes, N, K, dtype=torch.int16, device=W.device)
+    out_t = torch.empty(n_planes, K, N, dtype=torch.int16, device=W.device)
+    check(lib().mansy_weight_planes(ptr(W), N, K, ptr(out), ptr(out_t), N * K, n_planes, stream_ptr(W.device)), 'mansy_weight_planes')
+    return out, out_t
+
+
+def gemm_planes(A, W, planes, transposed=False, bias=None, relu=False, resid=None, force_tile=0):
+    """A [M, K'] times a weight given in fp32 (W [N, K]) AND as bf16 planes (weight_planes): transposed=False -> A W^T with `planes`
+    of W; transposed=True -> A W with the planes of W^T.  In fp32 mode the planes are ignored."""
+    _gpu(A, W, planes)
+    A, W = A.contiguous(), W.contiguous()
+    M = A.shape[0]
+    Nw, Kw = W.shape
+    N, K = (Kw, Nw) if transposed else (Nw, Kw)
+    assert A.shape[1] == K and planes.shape[1:] == (N, K), (A.shape, W.shape, planes.shape)
+    out = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    ep = GemmEpilogue()
+    ep.bias = ptr(bias).value if bias is not None else None
+    ep.relu = int(relu)
+    ep.mask_scale = 1.0
+    if resid is not None:
+        ep.resid, ep.resid_ld = resid.data_ptr(), resid.stride(0)
+    check(lib().mansy_gemm_planes(ptr(A), A.stride(0), ptr(W), W.stride(0), int(transposed), ptr(planes), planes.stride(0), planes.stride(1),
+                                  ptr(out), out.stride(0), M, N, K, ctypes.byref(ep), force_tile, stream_ptr(A.device)), 'mansy_gemm_planes')
+    return out
+
+
 def _attn_shape(nb, H, Lq, Lk, dh, q, k, v, o):
     s = AttnShape(nb=nb, H=H, Lq=Lq, Lk=Lk, dh=dh, scale=1.0 / math.sqrt(dh))
     s.q_bs, s.q_rs = q

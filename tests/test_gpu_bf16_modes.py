@@ -378,3 +378,38 @@ def test_single_k_tile_products_at_the_end_of_an_allocation(K, mode):
                 torch.cuda.synchronize()
                 assert ((C.double() - ref).abs().max() / ref.abs().max()).item() < GEMM_TOL[mode]
         del bigA, bigB
+
+
+@pytest.mark.parametrize('mode', MODES)
+def test_weight_planes_and_presplit_product(K, mode):
+    """Weights split ahead of the product (what the viewport engine does once per step): the planes re-assemble the weight
+    (a0 + a1 (+ a2) == W to 2^-16 / 2^-24 relative), the transposed planes are the planes of W^T, and the LDS-DMA product on
+    them agrees with the float64 product like the in-loop split does -- forward (A W^T) and dX (A W) forms, ragged rows, one to
+    many K-tiles, both tiles, with a fused epilogue."""
+    npl = 2 if mode == 'bf16x3' else 3
+    g = torch.Generator().manual_seed(8)
+    for (M, N, Kd) in ((4096, 512, 512), (300, 1536, 512), (70, 64, 32), (257, 96, 1536), (2048, 512, 64)):
+        W = torch.randn(N, Kd, generator=g).cuda()
+        pl, pl_t = K.weight_planes(W, npl)
+        back = sum(pl[t].view(torch.bfloat16).float() for t in range(npl))
+        assert ((back - W).abs().max() / W.abs().max()).item() < (2.0 ** -15 if npl == 2 else 2.0 ** -22)
+        assert torch.equal(pl_t, pl.transpose(1, 2).contiguous())
+        A = torch.randn(M, Kd, generator=g).cuda()
+        G = torch.randn(M, N, generator=g).cuda()
+        bias, resid = torch.randn(N, generator=g).cuda(), torch.randn(M, N, generator=g).cuda()
+        ref_f = A.double() @ W.double().t()
+        ref_b = G.double() @ W.double()
+        for tile in (0, 64, 128):
+            with K.precision(mode):
+                Cf = K.gemm_planes(A, W, pl, transposed=False, force_tile=tile)
+                Cb = K.gemm_planes(G, W, pl_t, transposed=True, force_tile=tile)
+                Ce = K.gemm_planes(A, W, pl, transposed=False, bias=bias, relu=True, resid=resid, force_tile=tile)
+            assert ((Cf.double() - ref_f).abs().max() / ref_f.abs().max()).item() < GEMM_TOL[mode], (M, N, Kd, tile)
+            assert ((Cb.double() - ref_b).abs().max() / ref_b.abs().max()).item() < GEMM_TOL[mode], (M, N, Kd, tile)
+            want = torch.relu(ref_f + bias.double()) + resid.double()
+            assert (Ce.double() - want).abs().max().item() < GEMM_TOL[mode] * ref_f.abs().max().item(), (M, N, Kd, tile)
+    # fp32 mode ignores the planes: bit-identical to the plain product
+    W = torch.randn(512, 512, generator=g).cuda()
+    A = torch.randn(256, 512, generator=g).cuda()
+    pl, _ = K.weight_planes(W, npl)
+    assert torch.equal(K.gemm_planes(A, W, pl), K.gemm(A, W))

@@ -17,6 +17,8 @@ SHAPES = [  # (name, a_kmajor, b_kmajor, M, N, K, accumulate, count per step)
 ]
 args = sys.argv[1:]
 CHECK = '--check' in args
+PLANES = '--planes' in args          # forward / dX shapes with the weight pre-split into bf16 planes (LDS-DMA B)
+args = [a for a in args if a != '--planes']
 precs = []
 while '--prec' in args:
     i = args.index('--prec')
@@ -42,14 +44,21 @@ for name, ak, bk, M, N, Kd, acc, cnt in SHAPES:
             out.zero_()
             K.gemm(A, B, bool(ak), bool(bk), out=out, accumulate=bool(acc), force_tile=t)
             err = ((out.double() - ref).abs().max() / ref.abs().max()).item()
+        use_pl = PLANES and not ak and pr != 'f32'
+        if use_pl:
+            Wm = B                                          # the weight behind this operand: [N, K] (forward) or [K, N] (dX: C = A W)
+            pl, pl_t = K.weight_planes(Wm, 2 if pr == 'bf16x3' else 3)
+            run = (lambda: K.gemm_planes(A, Wm, pl_t if bk else pl, transposed=bool(bk), force_tile=t))
+        else:
+            run = (lambda: K.gemm(A, B, bool(ak), bool(bk), out=out, accumulate=bool(acc), force_tile=t))
         for _ in range(3):
-            K.gemm(A, B, bool(ak), bool(bk), out=out, accumulate=bool(acc), force_tile=t)
+            run()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         n = 20
         e0.record()
         for _ in range(n):
-            K.gemm(A, B, bool(ak), bool(bk), out=out, accumulate=bool(acc), force_tile=t)
+            run()
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / n * 1e3
