@@ -32,7 +32,7 @@ for mode in f32 bf16x3; do
   rm -rf gpurun_out/pmc_r gpurun_out/pmc_w; mkdir -p gpurun_out/pmc_r gpurun_out/pmc_w
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_r -- python3 /tmp/vp_only.py 2 $mode > $OUT/pmc_r_$mode.log 2>&1; echo "pmc fetch $mode rc=$?"
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_w -- python3 /tmp/vp_only.py 2 $mode > $OUT/pmc_w_$mode.log 2>&1; echo "pmc write $mode rc=$?"
-  if [ $mode = f32 ]; then python3 tools/pmc_aggregate.py $TAG 50011000 gemm_f32 ""; else python3 tools/pmc_aggregate.py $TAG 50011000 gemm_bf16s _$mode; fi
+  if [ $mode = f32 ]; then python3 tools/pmc_aggregate.py $TAG 50011000 gemm_f32 ""; else python3 tools/pmc_aggregate.py $TAG 50011000 gemm_bf16 _$mode; fi
 done
 cp profiles/${TAG}_pmc_gemm*.json $OUT/ 2>/dev/null
 # PPO cycle
