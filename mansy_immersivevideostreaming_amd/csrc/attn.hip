@@ -66,7 +66,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_fwd_kernel(AttnPtrs p, AttnSh
       float pv = p_l[i * (LMAX + 1) + j] * inv;
       const long long pidx = (bh * Lq + i) * Lk + j;
       if (p.P) p.P[pidx] = pv;
-      if (drop.p > 0.f) pv = mansy_keep(drop.seed, drop.site, (uint32_t)pidx, drop.p) ? pv * ds : 0.f;
+      if (drop.p > 0.f) pv = mansy_keep(drop.seed, drop.site, drop.base + (uint32_t)pidx, drop.p) ? pv * ds : 0.f;
       p_l[i * (LMAX + 1) + j] = pv;
     }
   }
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_kernel(AttnPtrs p, AttnSh
       const float pv = p.P[pidx];
       p_l[i * (LMAX + 1) + j] = pv;
       float keepf = 1.f;
-      if (drop.p > 0.f) keepf = mansy_keep(drop.seed, drop.site, (uint32_t)pidx, drop.p) ? ds : 0.f;
+      if (drop.p > 0.f) keepf = mansy_keep(drop.seed, drop.site, drop.base + (uint32_t)pidx, drop.p) ? ds : 0.f;
       d_l[i * (LMAX + 1) + j] = pv * keepf;    // dropped probabilities (for dV)
     }
   }
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_kernel(AttnPtrs p, AttnSh
       float acc = 0.f;
       for (int d = 0; d < dh; ++d) acc = fmaf(do_l[i * DH_LD + d], v_l[j * DH_LD + d], acc);
       float keepf = 1.f;
-      if (drop.p > 0.f) keepf = mansy_keep(drop.seed, drop.site, (uint32_t)((bh * Lq + i) * Lk + j), drop.p) ? ds : 0.f;
+      if (drop.p > 0.f) keepf = mansy_keep(drop.seed, drop.site, drop.base + (uint32_t)((bh * Lq + i) * Lk + j), drop.p) ? ds : 0.f;
       d_l[i * (LMAX + 1) + j] = acc * keepf;   // dP (wrt pre-dropout probabilities)
     }
   }
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_fwd_q1_kernel(AttnPtrs p, Att
       float pv = sc[j] * inv;
       const long long pidx = bh * Lk + j;
       if (p.P && lane == j) p.P[pidx] = pv;
-      if (drop.p > 0.f) pv = mansy_keep(drop.seed, drop.site, (uint32_t)pidx, drop.p) ? pv * ds : 0.f;
+      if (drop.p > 0.f) pv = mansy_keep(drop.seed, drop.site, drop.base + (uint32_t)pidx, drop.p) ? pv * ds : 0.f;
       o = fmaf(pv, v[j], o);
     }
   }
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_q1_kernel(AttnPtrs p, Att
     dP[j] = dO * vj;
     P[j] = j < Lk ? p.P[bh * Lk + j] : 0.f;
     keepf[j] = 1.f;
-    if (drop.p > 0.f && j < Lk) keepf[j] = mansy_keep(drop.seed, drop.site, (uint32_t)(bh * Lk + j), drop.p) ? ds : 0.f;
+    if (drop.p > 0.f && j < Lk) keepf[j] = mansy_keep(drop.seed, drop.site, drop.base + (uint32_t)(bh * Lk + j), drop.p) ? ds : 0.f;
   }
   float delta = 0.f;
 #pragma unroll
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_fwd_q1x4_kernel(AttnPtrs p, A
     float pv = sc[j] * inv;                      // 0 for j >= Lk
     const long long pidx = bh * Lk + j;
     if (p.P && c == j && j < Lk) p.P[pidx] = pv;
-    if (drop.p > 0.f) pv = mansy_keep(drop.seed, drop.site, (uint32_t)pidx, drop.p) ? pv * ds : 0.f;
+    if (drop.p > 0.f) pv = mansy_keep(drop.seed, drop.site, drop.base + (uint32_t)pidx, drop.p) ? pv * ds : 0.f;
     o.x = fmaf(pv, v[j].x, o.x); o.y = fmaf(pv, v[j].y, o.y); o.z = fmaf(pv, v[j].z, o.z); o.w = fmaf(pv, v[j].w, o.w);
   }
   *reinterpret_cast<float4*>(p.O + b * s.o_bs + col) = o;
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_q1x4_kernel(AttnPtrs p, A
 #pragma unroll
   for (int j = 0; j < LKT; ++j) {
     keepf[j] = 1.f;
-    if (drop.p > 0.f) keepf[j] = mansy_keep(drop.seed, drop.site, (uint32_t)(bh * Lk + j), drop.p) ? ds : 0.f;
+    if (drop.p > 0.f) keepf[j] = mansy_keep(drop.seed, drop.site, drop.base + (uint32_t)(bh * Lk + j), drop.p) ? ds : 0.f;
     if (j >= Lk) P[j] = 0.f;
     dP[j] = group16_sum(dot4(dO, vv[j])) * keepf[j];
     delta = fmaf(P[j], dP[j], delta);
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_selfpull_q1x4_kernel(Attn
 #pragma unroll
   for (int j = 0; j < LKT; ++j) {
     keepf[j] = 1.f;
-    if (drop.p > 0.f) keepf[j] = mansy_keep(drop.seed, drop.site, (uint32_t)(bh * Lk + j), drop.p) ? ds : 0.f;
+    if (drop.p > 0.f) keepf[j] = mansy_keep(drop.seed, drop.site, drop.base + (uint32_t)(bh * Lk + j), drop.p) ? ds : 0.f;
     if (j >= Lk) P[j] = 0.f;
     dP[j] = group16_sum(dot4(dO, vv[j])) * keepf[j];
     delta = fmaf(P[j], dP[j], delta);
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_fwd_sx4_kernel(AttnPtrs p, At
       for (int j = 0; j < ST; ++j) if (c == j) pc = sc[j] * inv;
       const long long prow = (bh * S + i) * S;
       if (c < S && p.P) p.P[prow + c] = pc;
-      if (drop.p > 0.f) pc = mansy_keep(drop.seed, drop.site, (uint32_t)(prow + c), drop.p) ? pc * ds : 0.f;
+      if (drop.p > 0.f) pc = mansy_keep(drop.seed, drop.site, drop.base + (uint32_t)(prow + c), drop.p) ? pc * ds : 0.f;
       float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int j = 0; j < ST; ++j) {
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_sx4_kernel(AttnPtrs p, At
         if (c == j) dpc = t;
       }
       float kc = 1.f;
-      if (drop.p > 0.f) kc = mansy_keep(drop.seed, drop.site, (uint32_t)((bh * S + i) * S + c), drop.p) ? ds : 0.f;
+      if (drop.p > 0.f) kc = mansy_keep(drop.seed, drop.site, drop.base + (uint32_t)((bh * S + i) * S + c), drop.p) ? ds : 0.f;
       const float Pc = c < S ? pc[i] : 0.f;
       const float dPk = dpc * kc;
       const float delta = group16_sum(Pc * dPk);

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void dec_tail_fwd_kernel(MansyDecTailFwd p) {
         for (int k = 0; k < C6; ++k) a = fmaf(tok[k], ew[j][k], a);
         a += ebv[j];
         a += pev[j];
-        if (p.edrop.p > 0.f) a = mansy_keep(p.edrop.seed, p.edrop.site, (uint32_t)((long long)row * C + c + j), p.edrop.p) ? a * dsc : 0.f;
+        if (p.edrop.p > 0.f) a = mansy_keep(p.edrop.seed, p.edrop.site, p.edrop.base + (uint32_t)((long long)row * C + c + j), p.edrop.p) ? a * dsc : 0.f;
         e[j] = a;
       }
       *reinterpret_cast<float4*>(p.emb_next + base + i * 256) = *reinterpret_cast<const float4*>(e);
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(64 * HEAD_WAVES) void dec_head_bwd_kernel(MansyDecH
         float g[4] = {gn[i].x, gn[i].y, gn[i].z, gn[i].w};
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          if (p.edrop.p > 0.f) g[j] = mansy_keep(p.edrop.seed, p.edrop.site, (uint32_t)((long long)row * C + c + j), p.edrop.p) ? g[j] * esc : 0.f;
+          if (p.edrop.p > 0.f) g[j] = mansy_keep(p.edrop.seed, p.edrop.site, p.edrop.base + (uint32_t)((long long)row * C + c + j), p.edrop.p) ? g[j] * esc : 0.f;
         *reinterpret_cast<float4*>(p.dE_next + base + i * 256) = *reinterpret_cast<const float4*>(g);
         float ew[4][C6];
 #pragma unroll
@@ -276,10 +276,10 @@ __global__ __launch_bounds__(64 * HEAD_WAVES) void dec_head_bwd_kernel(MansyDecH
       *reinterpret_cast<float4*>(p.gz + off) = o;
       float4 od = o;
       if (p.drop3.p > 0.f) {
-        od.x = mansy_keep(p.drop3.seed, p.drop3.site, (uint32_t)(off + 0), p.drop3.p) ? o.x * dsc : 0.f;
-        od.y = mansy_keep(p.drop3.seed, p.drop3.site, (uint32_t)(off + 1), p.drop3.p) ? o.y * dsc : 0.f;
-        od.z = mansy_keep(p.drop3.seed, p.drop3.site, (uint32_t)(off + 2), p.drop3.p) ? o.z * dsc : 0.f;
-        od.w = mansy_keep(p.drop3.seed, p.drop3.site, (uint32_t)(off + 3), p.drop3.p) ? o.w * dsc : 0.f;
+        od.x = mansy_keep(p.drop3.seed, p.drop3.site, p.drop3.base + (uint32_t)(off + 0), p.drop3.p) ? o.x * dsc : 0.f;
+        od.y = mansy_keep(p.drop3.seed, p.drop3.site, p.drop3.base + (uint32_t)(off + 1), p.drop3.p) ? o.y * dsc : 0.f;
+        od.z = mansy_keep(p.drop3.seed, p.drop3.site, p.drop3.base + (uint32_t)(off + 2), p.drop3.p) ? o.z * dsc : 0.f;
+        od.w = mansy_keep(p.drop3.seed, p.drop3.site, p.drop3.base + (uint32_t)(off + 3), p.drop3.p) ? o.w * dsc : 0.f;
       }
       *reinterpret_cast<float4*>(p.dbr3 + off) = od;
       adw_3[i].x += dy3[i].x * xh[i].x; adw_3[i].y += dy3[i].y * xh[i].y; adw_3[i].z += dy3[i].z * xh[i].z; adw_3[i].w += dy3[i].w * xh[i].w;

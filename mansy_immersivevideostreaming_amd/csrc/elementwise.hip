@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict_
     for (int k = 0; k < NK; ++k) a = fmaf(xin[k], W[(c + j) * in_ch + small_idx<NS>(k, in_ch)], a);
     a += bv[j];
     a += pev[j];
-    if (drop.p > 0.f) a = mansy_keep(drop.seed, drop.site, (uint32_t)(idx + j), drop.p) ? a * (1.f / (1.f - drop.p)) : 0.f;
+    if (drop.p > 0.f) a = mansy_keep(drop.seed, drop.site, drop.base + (uint32_t)(idx + j), drop.p) ? a * (1.f / (1.f - drop.p)) : 0.f;
     acc[j] = a;
   }
   if (V == 4) *reinterpret_cast<float4*>(out + idx) = *reinterpret_cast<const float4*>(acc);
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void embed_fwd_rows_kernel(const float* __rest
       for (int k = 0; k < NK; ++k) a = fmaf(xin[k], wv[j][k], a);
       a += bv[j];
       a += pev[j];
-      if (drop.p > 0.f) a = mansy_keep(drop.seed, drop.site, (uint32_t)(idx + j), drop.p) ? a * dsc : 0.f;
+      if (drop.p > 0.f) a = mansy_keep(drop.seed, drop.site, drop.base + (uint32_t)(idx + j), drop.p) ? a * dsc : 0.f;
       acc[j] = a;
     }
     *reinterpret_cast<float4*>(out + idx) = *reinterpret_cast<const float4*>(acc);
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
     else g[0] = dX[idx];
 #pragma unroll
     for (int j = 0; j < V; ++j)
-      if (drop.p > 0.f) g[j] = mansy_keep(drop.seed, drop.site, (uint32_t)(idx + j), drop.p) ? g[j] * dsc : 0.f;
+      if (drop.p > 0.f) g[j] = mansy_keep(drop.seed, drop.site, drop.base + (uint32_t)(idx + j), drop.p) ? g[j] * dsc : 0.f;
     if (dE) {
       if (V == 4) *reinterpret_cast<float4*>(dE + idx) = *reinterpret_cast<const float4*>(g);
       else dE[idx] = g[0];

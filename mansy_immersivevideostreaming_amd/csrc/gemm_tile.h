@@ -100,10 +100,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
         }
         if (ep.drop.p > 0.f) {
           const uint32_t base = (uint32_t)row * (uint32_t)p.N + (uint32_t)col;
-          v.x = mansy_keep(ep.drop.seed, ep.drop.site, base + 0, ep.drop.p) ? v.x * drop_scale : 0.f;
-          v.y = mansy_keep(ep.drop.seed, ep.drop.site, base + 1, ep.drop.p) ? v.y * drop_scale : 0.f;
-          v.z = mansy_keep(ep.drop.seed, ep.drop.site, base + 2, ep.drop.p) ? v.z * drop_scale : 0.f;
-          v.w = mansy_keep(ep.drop.seed, ep.drop.site, base + 3, ep.drop.p) ? v.w * drop_scale : 0.f;
+          v.x = mansy_keep(ep.drop.seed, ep.drop.site, ep.drop.base + base + 0, ep.drop.p) ? v.x * drop_scale : 0.f;
+          v.y = mansy_keep(ep.drop.seed, ep.drop.site, ep.drop.base + base + 1, ep.drop.p) ? v.y * drop_scale : 0.f;
+          v.z = mansy_keep(ep.drop.seed, ep.drop.site, ep.drop.base + base + 2, ep.drop.p) ? v.z * drop_scale : 0.f;
+          v.w = mansy_keep(ep.drop.seed, ep.drop.site, ep.drop.base + base + 3, ep.drop.p) ? v.w * drop_scale : 0.f;
         }
         v.x += rr[u].x; v.y += rr[u].y; v.z += rr[u].z; v.w += rr[u].w;
         *reinterpret_cast<float4*>(Cz + (long long)row * p.ldc + col) = v;
@@ -143,7 +143,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const uint32_t row = (uint32_t)(row_base + (e & 3) + 8 * (e >> 2));
-          v[e] = mansy_keep(ep.drop.seed, ep.drop.site, row * (uint32_t)p.N + (uint32_t)col, ep.drop.p) ? v[e] * drop_scale : 0.f;
+          v[e] = mansy_keep(ep.drop.seed, ep.drop.site, ep.drop.base + row * (uint32_t)p.N + (uint32_t)col, ep.drop.p) ? v[e] * drop_scale : 0.f;
         }
       }
       if (ep.resid) {

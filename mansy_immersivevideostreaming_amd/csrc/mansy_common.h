@@ -52,8 +52,10 @@ struct MansyDrop {   // a dropout site; p == 0 disables
   float p;
   uint32_t seed;
   uint32_t site;
+  uint32_t base;     // added to the kernel's element index: a launch over the rows [b0, b0 + n) of a tensor draws the mask the launch over
+                     // all rows would draw there (base = b0 x the kernel's elements per row)
 };
-static inline MansyDrop mansy_no_drop() { MansyDrop d; d.p = 0.f; d.seed = 0; d.site = 0; return d; }
+static inline MansyDrop mansy_no_drop() { MansyDrop d; d.p = 0.f; d.seed = 0; d.site = 0; d.base = 0; return d; }
 
 // Cross-lane reductions on the VALU (DPP row rotations inside each 16-lane row, v_readlane across the four rows) instead of
 // __shfl_xor, which hipcc lowers to ds_bpermute_b32 -- an LDS-pipe round trip per step.

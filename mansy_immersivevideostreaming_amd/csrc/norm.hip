@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       dz[base + c] = o;
       if (dz_drop) {
         float od = o;
-        if (drop.p > 0.f) od = mansy_keep(drop.seed, drop.site, (uint32_t)(base + c), drop.p) ? o * dsc : 0.f;
+        if (drop.p > 0.f) od = mansy_keep(drop.seed, drop.site, drop.base + (uint32_t)(base + c), drop.p) ? o * dsc : 0.f;
         dz_drop[base + c] = od;
       }
       my_dw[c] += d * xh;
@@ -211,10 +211,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
           if (dz_drop) {
             float4 od = o;
             if (drop.p > 0.f) {
-              od.x = mansy_keep(drop.seed, drop.site, (uint32_t)(off + 0), drop.p) ? o.x * dsc : 0.f;
-              od.y = mansy_keep(drop.seed, drop.site, (uint32_t)(off + 1), drop.p) ? o.y * dsc : 0.f;
-              od.z = mansy_keep(drop.seed, drop.site, (uint32_t)(off + 2), drop.p) ? o.z * dsc : 0.f;
-              od.w = mansy_keep(drop.seed, drop.site, (uint32_t)(off + 3), drop.p) ? o.w * dsc : 0.f;
+              od.x = mansy_keep(drop.seed, drop.site, drop.base + (uint32_t)(off + 0), drop.p) ? o.x * dsc : 0.f;
+              od.y = mansy_keep(drop.seed, drop.site, drop.base + (uint32_t)(off + 1), drop.p) ? o.y * dsc : 0.f;
+              od.z = mansy_keep(drop.seed, drop.site, drop.base + (uint32_t)(off + 2), drop.p) ? o.z * dsc : 0.f;
+              od.w = mansy_keep(drop.seed, drop.site, drop.base + (uint32_t)(off + 3), drop.p) ? o.w * dsc : 0.f;
             }
             *reinterpret_cast<float4*>(dz_drop + off) = od;
           }

@@ -12,6 +12,7 @@
 //     dW = dY^T X GEMM per weight over the stacked [T*B] rows (reduce dim 40 960 at B = 4096).
 //   * all dense products run on the fp32 MFMA kernel (gemm_f32.hip) with bias/ReLU/dropout/mask/
 //     residual fused in the epilogue; attention is the fused one-wave-per-(batch,head) kernel.
+#include <stdlib.h>
 #include <string>
 #include <vector>
 #include "mansy_kernels.h"
@@ -195,7 +196,8 @@ void build_layout(const mansy_vp_config& c, Layout& L, Work& W) {
   W.s_tok = L.f("tmp.s_tok", B * C6);
   W.dE_all = L.f("dec.dE", TB * d); W.dz_all = L.f("dec.dz", TB * C6); W.dmem = L.f("dmem", B * M * d);
   // decoder: one slot set per LayerNorm (3 per layer + the final norm), accumulated over the T steps; encoder: one scratch set
-  W.lnp_dec = L.f("lnp.dec", (size_t)(3 * c.n_dec + 1) * mansy_ln_bwd_parts((int)B) * 2 * d);
+  // (x 2: when the decoder runs as two half-batches on two streams each half accumulates into its own slot sets)
+  W.lnp_dec = L.f("lnp.dec", (size_t)2 * (3 * c.n_dec + 1) * mansy_ln_bwd_parts((int)B) * 2 * d);
   W.lnp_enc = L.f("lnp.enc", (size_t)mansy_ln_bwd_parts((int)N) * 2 * d);
   W.loss_acc = (double*)L.add("loss_acc", 64);
   // split-bf16 modes: 3 planes x (W, W^T) of every GEMM weight, 2 bytes each (110 MB at d = 512; filled once per step)
@@ -278,7 +280,10 @@ struct Eng {
       return;
     }
   }
-  MansyDrop dr(uint32_t site, float p) const { MansyDrop x; x.p = train ? p : 0.f; x.seed = seed; x.site = site; return x; }
+  // base: first element index of the launch inside the full tensor (a launch over the rows [b0, ..) of a [B, C] tensor passes b0 * C)
+  MansyDrop dr(uint32_t site, float p, size_t base = 0) const {
+    MansyDrop x; x.p = train ? p : 0.f; x.seed = seed; x.site = site; x.base = (uint32_t)base; return x;
+  }
 
   // Y[rows,N] = X[rows,K] W[N,K]^T (+b) with epilogue
   // resid != nullptr: Y = resid + drop(X W^T + b) -- the sub-layer's residual sum z, written by the product's epilogue, so that
@@ -328,14 +333,14 @@ struct Eng {
     s.o_bs = (long long)S * d; s.o_rs = d; s.scale = 1.f / sqrtf((float)dh);
     return s;
   }
-  AttnShape self_shape(int i) const {   // query = slab i, keys = slabs 0..i
-    AttnShape s; s.nb = B; s.H = H; s.Lq = 1; s.Lk = i + 1; s.dh = dh;
+  AttnShape self_shape(int i, int nb = -1) const {   // query = slab i, keys = slabs 0..i; nb rows of the batch (default: all)
+    AttnShape s; s.nb = nb < 0 ? B : nb; s.H = H; s.Lq = 1; s.Lk = i + 1; s.dh = dh;
     s.q_bs = 3 * d; s.q_rs = 0; s.k_bs = s.v_bs = 3 * d; s.k_rs = s.v_rs = (long long)B * 3 * d;
     s.o_bs = d; s.o_rs = 0; s.scale = 1.f / sqrtf((float)dh);
     return s;
   }
-  AttnShape cross_shape() const {
-    AttnShape s; s.nb = B; s.H = H; s.Lq = 1; s.Lk = M; s.dh = dh;
+  AttnShape cross_shape(int nb = -1) const {
+    AttnShape s; s.nb = nb < 0 ? B : nb; s.H = H; s.Lq = 1; s.Lk = M; s.dh = dh;
     s.q_bs = d; s.q_rs = 0; s.k_bs = s.v_bs = (long long)M * 2 * d; s.k_rs = s.v_rs = 2 * d;
     s.o_bs = d; s.o_rs = 0; s.scale = 1.f / sqrtf((float)dh);
     return s;
@@ -371,58 +376,184 @@ struct Eng {
     MANSY_HIP_CHECK(hipMemcpyAsync(W.tok_all, cur, sizeof(float) * B * C6, hipMemcpyDeviceToDevice, st));
     // the four row-wise ops between the last product of step i and the first of step i+1 run as one launch (dec_step.hip)
     const bool fuse_tail = mansy_dec_tail_ok(d, C6) != 0;
+    // Trajectories are independent through the whole recurrence, so the batch can run as two halves on two streams: the products
+    // of one half (MFMA-bound) execute under the attention / LayerNorm passes of the other (HBM-bound).  Submission is interleaved
+    // step by step; every launch indexes the full slabs at its row offset and draws the dropout masks of those rows.
+    const bool split = split_ok();
+    const int h0 = split ? B / 2 : B;
+    if (split) RC(fork());
     for (int i = 0; i < T; ++i) {
-      const float* tok = W.tok_all + (size_t)i * B * C6;
-      float* emb = W.emb_all + (size_t)i * B * d;
-      if (i == 0 || !fuse_tail) RC(mansy_launch_embed_fwd(tok, C6, P.emb.w, P.emb.b, pe, emb, B, d, 1, i, dr(site_pe_tgt(i), c.p_pe), st));
-      const float* xi = emb;
-      for (int l = 0; l < c.n_dec; ++l) {
-        const DecLayerP& p = P.dec[l]; DecBuf& e = W.dec[l];
-        const size_t o = (size_t)i * B;
-        float* qkv_i = e.qkv + o * 3 * d;
-        RC(lin_fwd(xi, B, d, p.sa_in.w, p.sa_in.b, 3 * d, qkv_i, 0, mansy_no_drop()));
-        RC(mansy_launch_attn_fwd(qkv_i, e.qkv + d, e.qkv + 2 * d, e.ao1 + o * d, e.P1 + o * H * T, self_shape(i),
-                                 dr(site_dec(l, i, 0), c.p_drop), st));
-        RC(lin_fwd(e.ao1 + o * d, B, d, p.sa_out.w, p.sa_out.b, d, e.z1 + o * d, 0, dr(site_dec(l, i, 1), c.p_drop), xi));
-        RC(ln_of(e.z1 + o * d, p.n1, e.y1 + o * d, e.m1 + o, e.r1 + o, B));
-        RC(lin_fwd(e.y1 + o * d, B, d, p.ca_in.w, p.ca_in.b, d, e.qc + o * d, 0, mansy_no_drop()));
-        RC(mansy_launch_attn_fwd(e.qc + o * d, e.memkv, e.memkv + d, e.ao2 + o * d, e.P2 + o * H * M, cross_shape(),
-                                 dr(site_dec(l, i, 2), c.p_drop), st));
-        RC(lin_fwd(e.ao2 + o * d, B, d, p.ca_out.w, p.ca_out.b, d, e.z2 + o * d, 0, dr(site_dec(l, i, 3), c.p_drop), e.y1 + o * d));
-        RC(ln_of(e.z2 + o * d, p.n2, e.y2 + o * d, e.m2 + o, e.r2 + o, B));
-        RC(lin_fwd(e.y2 + o * d, B, d, p.lin1.w, p.lin1.b, f, e.h + o * f, 1, dr(site_dec(l, i, 4), c.p_drop)));
-        if (fuse_tail && l == c.n_dec - 1) {                  // LayerNorm3 of the last layer is the head of the fused tail (a + b form)
-          RC(lin_fwd(e.h + o * f, B, f, p.lin2.w, p.lin2.b, d, W.t_dec, 0, dr(site_dec(l, i, 5), c.p_drop)));
-          break;
-        }
-        RC(lin_fwd(e.h + o * f, B, f, p.lin2.w, p.lin2.b, d, e.z3 + o * d, 0, dr(site_dec(l, i, 5), c.p_drop), e.y2 + o * d));
-        RC(ln_of(e.z3 + o * d, p.n3, e.y3 + o * d, e.m3 + o, e.r3 + o, B));
-        xi = e.y3 + o * d;
-      }
-      const size_t o = (size_t)i * B;
-      if (fuse_tail) {
-        const DecLayerP& p = P.dec[c.n_dec - 1]; DecBuf& e = W.dec[c.n_dec - 1];
-        MansyDecTailFwd tp;
-        tp.a = e.y2 + o * d; tp.b = W.t_dec; tp.n3_w = p.n3.w; tp.n3_b = p.n3.b; tp.z3 = e.z3 + o * d; tp.y3 = e.y3 + o * d;
-        tp.m3 = e.m3 + o; tp.r3 = e.r3 + o;
-        tp.dn_w = P.dec_norm.w; tp.dn_b = P.dec_norm.b; tp.dec_out = W.dec_out + o * d; tp.md = W.md + o; tp.rd = W.rd + o;
-        tp.pw = P.pred.w; tp.pb = P.pred.b; tp.tok_next = W.tok_all + (size_t)(i + 1) * B * C6;
-        tp.pred_bt = pred_bt ? pred_bt + (size_t)i * C6 : nullptr; tp.pred_stride = (long long)T * C6;
-        const bool more = i + 1 < T;
-        tp.ew = P.emb.w; tp.eb = P.emb.b; tp.pe_row = pe + (size_t)(i + 1) * d; tp.emb_next = more ? W.emb_all + (size_t)(i + 1) * B * d : nullptr;
-        tp.edrop = dr(site_pe_tgt(i + 1), c.p_pe);
-        tp.rows = B; tp.C = d; tp.C6 = C6; tp.eps = c.ln_eps;
-        RC(mansy_launch_dec_tail_fwd(tp, st));
-        continue;
-      }
-      RC(ln_fwd(xi, nullptr, P.dec_norm, nullptr, W.dec_out + o * d, W.md + o, W.rd + o, B));
-      RC(mansy_launch_predictor_fwd(W.dec_out + o * d, P.pred.w, P.pred.b, W.tok_all + (size_t)(i + 1) * B * C6, C6,
-                                    pred_bt ? pred_bt + (size_t)i * C6 : nullptr, (long long)T * C6, B, d, C6, st));
+      RC(dec_fwd_step(i, 0, h0, pe, pred_bt, fuse_tail));
+      if (split) { hipStream_t keep = st; st = st2; int rc = dec_fwd_step(i, h0, B - h0, pe, pred_bt, fuse_tail); st = keep; RC(rc); }
     }
+    if (split) RC(join());
     return MANSY_OK;
   }
 
+  // ---- two-stream plumbing (the second stream and its events are created once per process)
+  hipStream_t st2 = nullptr;
+  // Opt-in (MANSY_VP_SPLIT=1, read at every call).  Measured at B = 4096: train step 23.08 -> 22.67 ms (+1.8 %), sample() 507 -> 529 k
+  // trajectories/s (+4 %), identical losses.  Off by default: the gain is small, and concurrent kernels stretch each other's
+  // durations, so per-kernel timings (bench.py's roofline leg, rocprof kernel stats) stop describing the kernels themselves.
+  bool split_ok() {
+    const char* e = getenv("MANSY_VP_SPLIT");
+    return e && atoi(e) == 1 && B >= 256 && B % 2 == 0;
+  }
+  int fork() {
+    static hipStream_t s2 = nullptr; static hipEvent_t ev_f = nullptr;
+    if (!s2) { MANSY_HIP_CHECK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking)); MANSY_HIP_CHECK(hipEventCreateWithFlags(&ev_f, hipEventDisableTiming)); }
+    st2 = s2;
+    MANSY_HIP_CHECK(hipEventRecord(ev_f, st));
+    MANSY_HIP_CHECK(hipStreamWaitEvent(st2, ev_f, 0));
+    return MANSY_OK;
+  }
+  int join() {
+    static hipEvent_t ev_j = nullptr;
+    if (!ev_j) MANSY_HIP_CHECK(hipEventCreateWithFlags(&ev_j, hipEventDisableTiming));
+    MANSY_HIP_CHECK(hipEventRecord(ev_j, st2));
+    MANSY_HIP_CHECK(hipStreamWaitEvent(st, ev_j, 0));
+    return MANSY_OK;
+  }
+
+  // decoder step i for the rows [b0, b0 + nb) of the batch, on the current stream
+  int dec_fwd_step(int i, int b0, int nb, const float* pe, float* pred_bt, bool fuse_tail) {
+    const size_t o = (size_t)i * B + b0;                       // row of this launch inside the step-major [T][B][.] slabs
+    const float* tok = W.tok_all + o * C6;
+    float* emb = W.emb_all + o * d;
+    float* t_dec = W.t_dec + (size_t)b0 * d;
+    if (i == 0 || !fuse_tail) RC(mansy_launch_embed_fwd(tok, C6, P.emb.w, P.emb.b, pe, emb, nb, d, 1, i, dr(site_pe_tgt(i), c.p_pe, (size_t)b0 * d), st));
+    const float* xi = emb;
+    for (int l = 0; l < c.n_dec; ++l) {
+      const DecLayerP& p = P.dec[l]; DecBuf& e = W.dec[l];
+      float* qkv_i = e.qkv + o * 3 * d;
+      const float* kv0 = e.qkv + (size_t)b0 * 3 * d;           // keys / values of step 0 for these rows (step stride B * 3d)
+      const float* mkv = e.memkv + (size_t)b0 * M * 2 * d;
+      RC(lin_fwd(xi, nb, d, p.sa_in.w, p.sa_in.b, 3 * d, qkv_i, 0, mansy_no_drop()));
+      RC(mansy_launch_attn_fwd(qkv_i, kv0 + d, kv0 + 2 * d, e.ao1 + o * d, e.P1 + o * H * T, self_shape(i, nb),
+                               dr(site_dec(l, i, 0), c.p_drop, (size_t)b0 * H * (i + 1)), st));
+      RC(lin_fwd(e.ao1 + o * d, nb, d, p.sa_out.w, p.sa_out.b, d, e.z1 + o * d, 0, dr(site_dec(l, i, 1), c.p_drop, (size_t)b0 * d), xi));
+      RC(ln_of(e.z1 + o * d, p.n1, e.y1 + o * d, e.m1 + o, e.r1 + o, nb));
+      RC(lin_fwd(e.y1 + o * d, nb, d, p.ca_in.w, p.ca_in.b, d, e.qc + o * d, 0, mansy_no_drop()));
+      RC(mansy_launch_attn_fwd(e.qc + o * d, mkv, mkv + d, e.ao2 + o * d, e.P2 + o * H * M, cross_shape(nb),
+                               dr(site_dec(l, i, 2), c.p_drop, (size_t)b0 * H * M), st));
+      RC(lin_fwd(e.ao2 + o * d, nb, d, p.ca_out.w, p.ca_out.b, d, e.z2 + o * d, 0, dr(site_dec(l, i, 3), c.p_drop, (size_t)b0 * d), e.y1 + o * d));
+      RC(ln_of(e.z2 + o * d, p.n2, e.y2 + o * d, e.m2 + o, e.r2 + o, nb));
+      RC(lin_fwd(e.y2 + o * d, nb, d, p.lin1.w, p.lin1.b, f, e.h + o * f, 1, dr(site_dec(l, i, 4), c.p_drop, (size_t)b0 * f)));
+      if (fuse_tail && l == c.n_dec - 1) {                  // LayerNorm3 of the last layer is the head of the fused tail (a + b form)
+        RC(lin_fwd(e.h + o * f, nb, f, p.lin2.w, p.lin2.b, d, t_dec, 0, dr(site_dec(l, i, 5), c.p_drop, (size_t)b0 * d)));
+        break;
+      }
+      RC(lin_fwd(e.h + o * f, nb, f, p.lin2.w, p.lin2.b, d, e.z3 + o * d, 0, dr(site_dec(l, i, 5), c.p_drop, (size_t)b0 * d), e.y2 + o * d));
+      RC(ln_of(e.z3 + o * d, p.n3, e.y3 + o * d, e.m3 + o, e.r3 + o, nb));
+      xi = e.y3 + o * d;
+    }
+    if (fuse_tail) {
+      const DecLayerP& p = P.dec[c.n_dec - 1]; DecBuf& e = W.dec[c.n_dec - 1];
+      MansyDecTailFwd tp;
+      tp.a = e.y2 + o * d; tp.b = t_dec; tp.n3_w = p.n3.w; tp.n3_b = p.n3.b; tp.z3 = e.z3 + o * d; tp.y3 = e.y3 + o * d;
+      tp.m3 = e.m3 + o; tp.r3 = e.r3 + o;
+      tp.dn_w = P.dec_norm.w; tp.dn_b = P.dec_norm.b; tp.dec_out = W.dec_out + o * d; tp.md = W.md + o; tp.rd = W.rd + o;
+      tp.pw = P.pred.w; tp.pb = P.pred.b; tp.tok_next = W.tok_all + ((size_t)(i + 1) * B + b0) * C6;
+      tp.pred_bt = pred_bt ? pred_bt + ((size_t)b0 * T + i) * C6 : nullptr; tp.pred_stride = (long long)T * C6;
+      const bool more = i + 1 < T;
+      tp.ew = P.emb.w; tp.eb = P.emb.b; tp.pe_row = pe + (size_t)(i + 1) * d; tp.emb_next = more ? W.emb_all + ((size_t)(i + 1) * B + b0) * d : nullptr;
+      tp.edrop = dr(site_pe_tgt(i + 1), c.p_pe, (size_t)b0 * d);
+      tp.rows = nb; tp.C = d; tp.C6 = C6; tp.eps = c.ln_eps;
+      return mansy_launch_dec_tail_fwd(tp, st);
+    }
+    RC(ln_fwd(xi, nullptr, P.dec_norm, nullptr, W.dec_out + o * d, W.md + o, W.rd + o, nb));
+    return mansy_launch_predictor_fwd(W.dec_out + o * d, P.pred.w, P.pred.b, W.tok_all + ((size_t)(i + 1) * B + b0) * C6, C6,
+                                      pred_bt ? pred_bt + ((size_t)b0 * T + i) * C6 : nullptr, (long long)T * C6, nb, d, C6, st);
+  }
+
   // ------------------------------------------------------------------ backward
+  // backward of decoder step i for the rows [b0, b0 + nb) on the current stream; `half` selects the LayerNorm slot sets
+  int dec_bwd_step(int i, int b0, int nb, int half, const float* dpred_bt, bool defer_cross, bool pull_self, bool ln_parts, bool fuse_head) {
+    const float ms = drop_scale;
+    const size_t lnp_set = (size_t)mansy_ln_bwd_parts(B) * 2 * d;
+    float* const lnp = W.lnp_dec + (size_t)half * (3 * c.n_dec + 1) * lnp_set;
+    const size_t o = (size_t)i * B + b0;
+    const float* pred_tb = W.tok_all + (size_t)B * C6;
+    float* gx = W.s_b + (size_t)b0 * d;     // gradient wrt the current layer's output
+    float* gz = W.s_a + (size_t)b0 * d;     // scratch for residual-path gradients
+    float* gt = W.s_c + (size_t)b0 * d;
+    float* s_tok = W.s_tok + (size_t)b0 * C6;
+    const size_t bd = (size_t)b0 * d;        // dropout index base of a [.., d]-wide row kernel
+    auto ln_bwd_dec = [&](const float* dy, const float* z, const float* m, const float* r, const NormP& n, float* dz, float* dz_drop, MansyDrop drop,
+                          int slot) {
+      if (!ln_parts) return mansy_launch_layernorm_bwd(dy, z, m, r, n.w, dz, dz_drop, drop, n.gw, n.gb, nb, d, st);
+      return mansy_launch_layernorm_bwd_partial(dy, z, m, r, n.w, dz, dz_drop, drop, lnp + (size_t)slot * lnp_set, 1, nb, d, st);
+    };
+    if (fuse_head) {
+      const int L = c.n_dec - 1;
+      DecBuf& e = W.dec[L];
+      MansyDecHeadBwd hp;
+      const bool has_next = i < T - 1;           // gx still holds d/d(embedding input) of step i+1
+      hp.gx_next = has_next ? gx : nullptr; hp.ew = P.emb.w; hp.dE_next = has_next ? W.dE_all + (o + B) * d : nullptr;
+      hp.edrop = dr(site_pe_tgt(i + 1), c.p_pe, bd);
+      hp.dpred = dpred_bt + ((size_t)b0 * T + i) * C6; hp.dpred_stride = (long long)T * C6; hp.pred = pred_tb + o * C6; hp.pw = P.pred.w;
+      hp.dz = W.dz_all + o * C6;
+      hp.y3 = e.y3 + o * d; hp.md = W.md + o; hp.rd = W.rd + o; hp.dn_w = P.dec_norm.w; hp.part_dn = lnp + (size_t)(3 * c.n_dec) * lnp_set;
+      hp.z3 = e.z3 + o * d; hp.m3 = e.m3 + o; hp.r3 = e.r3 + o; hp.n3_w = P.dec[L].n3.w; hp.part_n3 = lnp + (size_t)(3 * L + 2) * lnp_set;
+      hp.gz = gz; hp.dbr3 = e.dbr3 + o * d; hp.drop3 = dr(site_dec(L, i, 5), c.p_drop, bd);
+      hp.rows = nb; hp.C = d; hp.C6 = C6;
+      RC(mansy_launch_dec_head_bwd(hp, mansy_ln_bwd_parts(nb), st));
+    } else {
+      // predictor + final decoder LayerNorm
+      RC(mansy_launch_predictor_bwd(dpred_bt + ((size_t)b0 * T + i) * C6, (long long)T * C6, i < T - 1 ? s_tok : nullptr, C6,
+                                    pred_tb + o * C6, C6, P.pred.w, W.dz_all + o * C6, gz, nb, d, C6, st));
+      const float* last_y = W.dec[c.n_dec - 1].y3 + o * d;
+      RC(ln_bwd_dec(gz, last_y, W.md + o, W.rd + o, P.dec_norm, gx, nullptr, mansy_no_drop(), 3 * c.n_dec));
+    }
+    for (int l = c.n_dec - 1; l >= 0; --l) {
+      const DecLayerP& p = P.dec[l]; DecBuf& e = W.dec[l];
+      const float* mkv = e.memkv + (size_t)b0 * M * 2 * d;
+      // norm3( y2 + drop(lin2(h)) )
+      if (!(fuse_head && l == c.n_dec - 1))
+        RC(ln_bwd_dec(gx, e.z3 + o * d, e.m3 + o, e.r3 + o, p.n3, gz, e.dbr3 + o * d, dr(site_dec(l, i, 5), c.p_drop, bd), 3 * l + 2));
+      RC(lin_dx(e.dbr3 + o * d, nb, d, p.lin2.w, f, e.da + o * f, nullptr, e.h + o * f, ms));
+      RC(lin_dx(e.da + o * f, nb, f, p.lin1.w, d, gt, gz, nullptr, 1.f));                 // gt = d/dy2
+      // norm2( y1 + drop(ca_out(ao2)) )
+      RC(ln_bwd_dec(gt, e.z2 + o * d, e.m2 + o, e.r2 + o, p.n2, gz, e.dbr2 + o * d, dr(site_dec(l, i, 3), c.p_drop, bd), 3 * l + 1));
+      if (defer_cross) {
+        float* dao2_i = e.dao2 + o * d;
+        RC(lin_dx(e.dbr2 + o * d, nb, d, p.ca_out.w, d, dao2_i, nullptr, nullptr, 1.f));   // d/dao2, kept for the deferred dV
+        RC(mansy_launch_attn_bwd_dq(e.qc + o * d, mkv, mkv + d, e.P2 + o * H * M, dao2_i, e.dqc + o * d, e.dS2 + o * H * M,
+                                    e.Pk2 + o * H * M, cross_shape(nb), dr(site_dec(l, i, 2), c.p_drop, (size_t)b0 * H * M), st));
+      } else {
+        float* dmkv = e.dmemkv + (size_t)b0 * M * 2 * d;
+        RC(lin_dx(e.dbr2 + o * d, nb, d, p.ca_out.w, d, gt, nullptr, nullptr, 1.f));       // gt = d/dao2
+        RC(mansy_launch_attn_bwd(e.qc + o * d, mkv, mkv + d, e.P2 + o * H * M, gt, e.dqc + o * d, dmkv, dmkv + d,
+                                 cross_shape(nb), dr(site_dec(l, i, 2), c.p_drop, (size_t)b0 * H * M), 1, st));
+      }
+      RC(lin_dx(e.dqc + o * d, nb, d, p.ca_in.w, d, gt, gz, nullptr, 1.f));                // gt = d/dy1
+      // norm1( x + drop(sa_out(ao1)) )
+      RC(ln_bwd_dec(gt, e.z1 + o * d, e.m1 + o, e.r1 + o, p.n1, gz, e.dbr1 + o * d, dr(site_dec(l, i, 1), c.p_drop, bd), 3 * l + 0));
+      float* dqkv_i = e.dqkv + o * 3 * d;
+      const float* kv0 = e.qkv + (size_t)b0 * 3 * d;
+      float* dkv0 = e.dqkv + (size_t)b0 * 3 * d;
+      if (pull_self) {
+        RC(lin_dx(e.dbr1 + o * d, nb, d, p.sa_out.w, d, e.dao1 + o * d, nullptr, nullptr, 1.f));   // d/dao1, kept: later rows of dV pull it
+        // coefficient rows of this half: [T][nb*H][T], its own region of the [T][B*H][T] buffers
+        const size_t co = (size_t)b0 * T * H * T;
+        RC(mansy_launch_attn_bwd_selfpull(kv0, (long long)B * 3 * d, kv0 + d, kv0 + 2 * d, e.P1 + o * H * T, e.dao1 + (size_t)b0 * d, (long long)B * d,
+                                          dqkv_i, dkv0 + d, dkv0 + 2 * d, e.dS1 + co, e.Pk1 + co, self_shape(i, nb), T, i,
+                                          dr(site_dec(l, i, 0), c.p_drop, (size_t)b0 * H * (i + 1)), st));
+      } else {
+        RC(lin_dx(e.dbr1 + o * d, nb, d, p.sa_out.w, d, gt, nullptr, nullptr, 1.f));       // gt = d/dao1
+        RC(mansy_launch_attn_bwd(qkv_at(e, o), kv0 + d, kv0 + 2 * d, e.P1 + o * H * T, gt, dqkv_i, dkv0 + d, dkv0 + 2 * d,
+                                 self_shape(i, nb), dr(site_dec(l, i, 0), c.p_drop, (size_t)b0 * H * (i + 1)), 1, st));
+      }
+      RC(lin_dx(dqkv_i, nb, 3 * d, p.sa_in.w, d, gx, gz, nullptr, 1.f));                   // gx = d/d(layer input)
+    }
+    // embedding of the fed-back token: dE slab (masked) + gradient wrt pred_{i-1}; fused into the head of step i-1, except
+    // for step 0 (its token is the observed current position: only the masked gradient for the deferred dW is needed)
+    if (!fuse_head) return mansy_launch_embed_bwd(gx, P.emb.w, W.dE_all + o * d, s_tok, C6, nb, d, dr(site_pe_tgt(i), c.p_pe, bd), st);
+    if (i == 0) return mansy_launch_embed_bwd(gx, P.emb.w, W.dE_all + o * d, nullptr, C6, nb, d, dr(site_pe_tgt(0), c.p_pe, bd), st);
+    return MANSY_OK;
+  }
+  const float* qkv_at(const DecBuf& e, size_t o) const { return e.qkv + o * 3 * d; }
+
   int backward(const float* src, const float* dpred_bt) {
     if (wtab.n == 0) RC(prepare_planes());      // separate mansy_vp_backward call: the weights have not changed since the forward
     const float ms = drop_scale;
@@ -439,85 +570,35 @@ struct Eng {
     }
     const bool ln_parts = mansy_ln_bwd_partial_ok(d);
     const size_t lnp_set = (size_t)mansy_ln_bwd_parts(B) * 2 * d;
-    if (ln_parts) MANSY_HIP_CHECK(hipMemsetAsync(W.lnp_dec, 0, sizeof(float) * (size_t)(3 * c.n_dec + 1) * lnp_set, st));
-    const float* pred_tb = W.tok_all + (size_t)B * C6;
+    const int n_ln = 3 * c.n_dec + 1;
+    // two halves on two streams (see forward): each half accumulates its LayerNorm weight-gradient sums in its own slot sets
+    const bool split = split_ok();
+    const int h0 = split ? B / 2 : B;
+    if (ln_parts) MANSY_HIP_CHECK(hipMemsetAsync(W.lnp_dec, 0, sizeof(float) * (size_t)(split ? 2 : 1) * n_ln * lnp_set, st));
     // fused head of a backward step (dec_step.hip): embedding backward of step i+1 + predictor backward + final norm backward
     // + LayerNorm3 backward of the last layer in one launch
     const bool fuse_head = ln_parts && mansy_dec_tail_ok(d, C6) != 0;
+    if (split) RC(fork());
     for (int i = T - 1; i >= 0; --i) {
-      const size_t o = (size_t)i * B;
-      float* gx = W.s_b;     // gradient wrt the current layer's output
-      float* gz = W.s_a;     // scratch for residual-path gradients
-      float* gt = W.s_c;
-      if (fuse_head) {
-        const int L = c.n_dec - 1;
-        DecBuf& e = W.dec[L];
-        MansyDecHeadBwd hp;
-        const bool has_next = i < T - 1;           // gx still holds d/d(embedding input) of step i+1
-        hp.gx_next = has_next ? gx : nullptr; hp.ew = P.emb.w; hp.dE_next = has_next ? W.dE_all + (o + B) * d : nullptr;
-        hp.edrop = dr(site_pe_tgt(i + 1), c.p_pe);
-        hp.dpred = dpred_bt + (size_t)i * C6; hp.dpred_stride = (long long)T * C6; hp.pred = pred_tb + o * C6; hp.pw = P.pred.w;
-        hp.dz = W.dz_all + o * C6;
-        hp.y3 = e.y3 + o * d; hp.md = W.md + o; hp.rd = W.rd + o; hp.dn_w = P.dec_norm.w; hp.part_dn = W.lnp_dec + (size_t)(3 * c.n_dec) * lnp_set;
-        hp.z3 = e.z3 + o * d; hp.m3 = e.m3 + o; hp.r3 = e.r3 + o; hp.n3_w = P.dec[L].n3.w; hp.part_n3 = W.lnp_dec + (size_t)(3 * L + 2) * lnp_set;
-        hp.gz = gz; hp.dbr3 = e.dbr3 + o * d; hp.drop3 = dr(site_dec(L, i, 5), c.p_drop);
-        hp.rows = B; hp.C = d; hp.C6 = C6;
-        RC(mansy_launch_dec_head_bwd(hp, mansy_ln_bwd_parts(B), st));
-      } else {
-        // predictor + final decoder LayerNorm
-        RC(mansy_launch_predictor_bwd(dpred_bt + (size_t)i * C6, (long long)T * C6, i < T - 1 ? W.s_tok : nullptr, C6,
-                                      pred_tb + o * C6, C6, P.pred.w, W.dz_all + o * C6, W.s_a, B, d, C6, st));
-        const float* last_y = W.dec[c.n_dec - 1].y3 + o * d;
-        RC(ln_bwd(W.s_a, last_y, W.md + o, W.rd + o, P.dec_norm, W.s_b, nullptr, mansy_no_drop(), B, 3 * c.n_dec));
+      RC(dec_bwd_step(i, 0, h0, 0, dpred_bt, defer_cross, pull_self, ln_parts, fuse_head));
+      if (split) {
+        hipStream_t keep = st; st = st2;
+        const int rc = dec_bwd_step(i, h0, B - h0, 1, dpred_bt, defer_cross, pull_self, ln_parts, fuse_head);
+        st = keep; RC(rc);
       }
-      for (int l = c.n_dec - 1; l >= 0; --l) {
-        const DecLayerP& p = P.dec[l]; DecBuf& e = W.dec[l];
-        // norm3( y2 + drop(lin2(h)) )
-        if (!(fuse_head && l == c.n_dec - 1))
-          RC(ln_bwd(gx, e.z3 + o * d, e.m3 + o, e.r3 + o, p.n3, gz, e.dbr3 + o * d, dr(site_dec(l, i, 5), c.p_drop), B, 3 * l + 2));
-        RC(lin_dx(e.dbr3 + o * d, B, d, p.lin2.w, f, e.da + o * f, nullptr, e.h + o * f, ms));
-        RC(lin_dx(e.da + o * f, B, f, p.lin1.w, d, gt, gz, nullptr, 1.f));                 // gt = d/dy2
-        // norm2( y1 + drop(ca_out(ao2)) )
-        RC(ln_bwd(gt, e.z2 + o * d, e.m2 + o, e.r2 + o, p.n2, gz, e.dbr2 + o * d, dr(site_dec(l, i, 3), c.p_drop), B, 3 * l + 1));
-        if (defer_cross) {
-          float* dao2_i = e.dao2 + o * d;
-          RC(lin_dx(e.dbr2 + o * d, B, d, p.ca_out.w, d, dao2_i, nullptr, nullptr, 1.f));   // d/dao2, kept for the deferred dV
-          RC(mansy_launch_attn_bwd_dq(e.qc + o * d, e.memkv, e.memkv + d, e.P2 + o * H * M, dao2_i, e.dqc + o * d, e.dS2 + o * H * M,
-                                      e.Pk2 + o * H * M, cross_shape(), dr(site_dec(l, i, 2), c.p_drop), st));
-        } else {
-          RC(lin_dx(e.dbr2 + o * d, B, d, p.ca_out.w, d, gt, nullptr, nullptr, 1.f));       // gt = d/dao2
-          RC(mansy_launch_attn_bwd(e.qc + o * d, e.memkv, e.memkv + d, e.P2 + o * H * M, gt, e.dqc + o * d, e.dmemkv, e.dmemkv + d,
-                                   cross_shape(), dr(site_dec(l, i, 2), c.p_drop), 1, st));
-        }
-        RC(lin_dx(e.dqc + o * d, B, d, p.ca_in.w, d, gt, gz, nullptr, 1.f));                // gt = d/dy1
-        // norm1( x + drop(sa_out(ao1)) )
-        RC(ln_bwd(gt, e.z1 + o * d, e.m1 + o, e.r1 + o, p.n1, gz, e.dbr1 + o * d, dr(site_dec(l, i, 1), c.p_drop), B, 3 * l + 0));
-        float* dqkv_i = e.dqkv + o * 3 * d;
-        if (pull_self) {
-          RC(lin_dx(e.dbr1 + o * d, B, d, p.sa_out.w, d, e.dao1 + o * d, nullptr, nullptr, 1.f));   // d/dao1, kept: later rows of dV pull it
-          RC(mansy_launch_attn_bwd_selfpull(e.qkv, (long long)B * 3 * d, e.qkv + d, e.qkv + 2 * d, e.P1 + o * H * T, e.dao1, (long long)B * d,
-                                            dqkv_i, e.dqkv + d, e.dqkv + 2 * d, e.dS1, e.Pk1, self_shape(i), T, i,
-                                            dr(site_dec(l, i, 0), c.p_drop), st));
-        } else {
-          RC(lin_dx(e.dbr1 + o * d, B, d, p.sa_out.w, d, gt, nullptr, nullptr, 1.f));       // gt = d/dao1
-          RC(mansy_launch_attn_bwd(e.qkv + o * 3 * d, e.qkv + d, e.qkv + 2 * d, e.P1 + o * H * T, gt, dqkv_i, e.dqkv + d, e.dqkv + 2 * d,
-                                   self_shape(i), dr(site_dec(l, i, 0), c.p_drop), 1, st));
-        }
-        RC(lin_dx(dqkv_i, B, 3 * d, p.sa_in.w, d, gx, gz, nullptr, 1.f));                   // gx = d/d(layer input)
-      }
-      // embedding of the fed-back token: dE slab (masked) + gradient wrt pred_{i-1}; fused into the head of step i-1, except
-      // for step 0 (its token is the observed current position: only the masked gradient for the deferred dW is needed)
-      if (!fuse_head) RC(mansy_launch_embed_bwd(gx, P.emb.w, W.dE_all + o * d, W.s_tok, C6, B, d, dr(site_pe_tgt(i), c.p_pe), st));
-      else if (i == 0) RC(mansy_launch_embed_bwd(gx, P.emb.w, W.dE_all, nullptr, C6, B, d, dr(site_pe_tgt(0), c.p_pe), st));
     }
-    if (ln_parts) {   // decoder LayerNorm weight gradients: slot sets -> gradients
-      const int np = mansy_ln_bwd_parts(B);
-      for (int l = 0; l < c.n_dec; ++l) {
-        RC(mansy_launch_ln_partials_reduce(W.lnp_dec + (size_t)(3 * l + 0) * lnp_set, np, d, P.dec[l].n1.gw, P.dec[l].n1.gb, st));
-        RC(mansy_launch_ln_partials_reduce(W.lnp_dec + (size_t)(3 * l + 1) * lnp_set, np, d, P.dec[l].n2.gw, P.dec[l].n2.gb, st));
-        RC(mansy_launch_ln_partials_reduce(W.lnp_dec + (size_t)(3 * l + 2) * lnp_set, np, d, P.dec[l].n3.gw, P.dec[l].n3.gb, st));
+    if (split) RC(join());
+    if (ln_parts) {   // decoder LayerNorm weight gradients: slot sets -> gradients (both halves' sets add into the same gradient)
+      for (int half = 0; half < (split ? 2 : 1); ++half) {
+        const int np = mansy_ln_bwd_parts(half ? B - h0 : h0);
+        const float* base = W.lnp_dec + (size_t)half * n_ln * lnp_set;
+        for (int l = 0; l < c.n_dec; ++l) {
+          RC(mansy_launch_ln_partials_reduce(base + (size_t)(3 * l + 0) * lnp_set, np, d, P.dec[l].n1.gw, P.dec[l].n1.gb, st));
+          RC(mansy_launch_ln_partials_reduce(base + (size_t)(3 * l + 1) * lnp_set, np, d, P.dec[l].n2.gw, P.dec[l].n2.gb, st));
+          RC(mansy_launch_ln_partials_reduce(base + (size_t)(3 * l + 2) * lnp_set, np, d, P.dec[l].n3.gw, P.dec[l].n3.gb, st));
+        }
+        RC(mansy_launch_ln_partials_reduce(base + (size_t)(3 * c.n_dec) * lnp_set, np, d, P.dec_norm.gw, P.dec_norm.gb, st));
       }
-      RC(mansy_launch_ln_partials_reduce(W.lnp_dec + (size_t)(3 * c.n_dec) * lnp_set, np, d, P.dec_norm.gw, P.dec_norm.gb, st));
     }
     // ---- deferred decoder weight gradients: one reduce-dim-(T*B) GEMM per weight
     RC(mansy_launch_outer_reduce(W.dz_all, C6, W.dec_out, TB, d, P.pred.gw, 0, nullptr, P.pred.gb, st));

@@ -474,3 +474,33 @@ def test_dropout_mask_policy_loss_curves(MT):
         e, r = eng[:, s:s + w].mean(1), ref[:, s:s + w].mean(1)                       # per-seed window means
         se = np.sqrt(e.var(ddof=1) / len(e) + r.var(ddof=1) / len(r))
         assert abs(e.mean() - r.mean()) <= 3 * se + 0.05 * r.mean(), (s, e.mean(), r.mean(), se)
+
+
+def test_two_stream_half_batch_decoder_equals_single_stream(MT):
+    """MANSY_VP_SPLIT=1 runs the decoder recurrence (forward and backward) as two half-batches on two streams -- every launch on
+    the rows [b0, b0 + n) of the full slabs, dropout masks drawn at the rows' own indices (MansyDrop::base).  Same function:
+    with dropout ON, sample(), the loss and the post-step weights must equal the single-stream run (forward bit for bit; the weight
+    gradients sum rows in a different grouping, so the updated weights agree to fp32 rounding / Adam noise)."""
+    B = 512
+    h, c, f = (t.cuda() for t in vo.synthetic_trajectories(B, 10, 10, seed=9))
+    out = {}
+    for split in ('0', '1'):
+        os.environ['MANSY_VP_SPLIT'] = split
+        try:
+            m = MT.ViewportTransformerMTIO(in_channel=2, fut_window=10, d_model=256, dim_feedforward=256, device='cuda', seed=11)
+            m.load_state_dict(vo.make_state_dict(256, 4, bias=True))
+            m = m.to('cuda')
+            m.eval()
+            with torch.no_grad():
+                samp = m.sample(h, c)
+            m.train()                                   # dropout on (p_pe 0.2, 0.1)
+            random.seed(1); np.random.seed(1); torch.manual_seed(1)      # MTIO decisions + the dropout seeds drawn from torch's generator
+            opt = MT.FusedAdamW(m, lr=1e-4)
+            losses = [m.train_step(h, c, f, opt).item() for _ in range(3)]
+            out[split] = (samp.clone(), losses, m._flat_p.clone())
+        finally:
+            os.environ.pop('MANSY_VP_SPLIT', None)
+    assert torch.equal(out['0'][0], out['1'][0])                              # forward: row-independent arithmetic, identical bits
+    np.testing.assert_allclose(out['1'][1], out['0'][1], rtol=2e-6)          # same dropout masks, same losses
+    err = (out['0'][2] - out['1'][2]).abs()
+    assert float((err > 2e-6).float().mean()) <= 0.02 and err.max().item() <= 3 * 2 * 1e-4      # Adam noise on zero-gradient parameters only
