@@ -266,6 +266,142 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16s_kernel(GemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// bf16x6, 128 x 128 tile, HALF K-tiles (16 k = one MFMA step) so that TWO stages of three planes fit beside a second workgroup:
+// 2 x 3 x (128 + 128) rows x 32 B = 48 KB (the 32-k two-stage image is 96 KB: one workgroup per CU, measured slower than one
+// stage with two).  Same pipeline as the two-stage loop above: split + ds_write of tile t+1 between the MFMAs of tile t, one
+// barrier per (half) K-tile, global loads of tile t+2 across a whole iteration.  LDS rows of 32 B, chunk q (0 / 1) at slot
+// q ^ ((row >> 3) & 1): the 16 lanes of a ds_read_b128 group then hit 16 different 16-B slots.
+__device__ __forceinline__ int lds_off16(int row, int q) { return row * 16 + ((q ^ ((row >> 3) & 1)) << 3); }
+
+template <bool AKM, bool BKM>
+__global__ __launch_bounds__(NT, 2) void gemm_bf16x6_k16_kernel(GemmParams p) {
+  constexpr int BM = 128, BN = 128, NP = 3, KT = 16, TM = 2, TN = 2;
+  constexpr int A_PLANE = BM * KT, B_PLANE = BN * KT;                     // bf16 elements
+  constexpr int STAGE = NP * (A_PLANE + B_PLANE);
+  constexpr int C_FLOATS = BM * (BN + 4);
+  constexpr int SMEM_FLOATS = (2 * STAGE / 2) > C_FLOATS ? (2 * STAGE / 2) : C_FLOATS;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+  __bf16* const planes = reinterpret_cast<__bf16*>(smem);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  int tile_x, tile_y, split;
+  {   // XCD-aware bijective remap over the whole 3-D grid, K split slowest (see gemm_f32_dma_kernel)
+    const int per_split = gridDim.x * gridDim.y, nwg = per_split * gridDim.z;
+    const int orig = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const int q = nwg >> 3, rem = nwg & 7, xcd = orig & 7, local = orig >> 3;
+    int t = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + local;
+    split = t / per_split; t -= split * per_split;
+    tile_y = t / gridDim.x; tile_x = t - tile_y * gridDim.x;
+  }
+  const int m0 = tile_y * BM, n0 = tile_x * BN;
+  const int k_begin = split * p.k_per_split;
+  const int k_end = min(p.K, k_begin + p.k_per_split);
+  const int nk = max(0, (k_end - k_begin) / KT);
+
+  // one (row, 8-k chunk) item per thread and operand
+  auto item = [&](bool kmaj, int ld, int row0, int nrows, unsigned& off, int& ldso, int& srow) {
+    int kc;
+    if (!kmaj) { srow = tid >> 1; kc = tid & 1; off = (unsigned)((min(row0 + srow, nrows - 1) - row0) * ld + kc * 8); }
+    else { srow = lane + 64 * (wave >> 1); kc = wave & 1; off = (unsigned)(kc * 8 * ld + (min(row0 + srow, nrows - 1) - row0)); }
+    ldso = lds_off16(srow, kc);
+  };
+  unsigned offa, offb; int lda_, ldb_, rowa, rowb;
+  item(AKM, p.lda, m0, p.M, offa, lda_, rowa);
+  item(BKM, p.ldb, n0, p.N, offb, ldb_, rowb);
+  const float* ca = AKM ? p.A + (long long)k_begin * p.lda + m0 : p.A + (long long)m0 * p.lda + k_begin;
+  const float* cb = BKM ? p.B + (long long)k_begin * p.ldb + n0 : p.B + (long long)n0 * p.ldb + k_begin;
+  const long long step_a = AKM ? (long long)KT * p.lda : KT, step_b = BKM ? (long long)KT * p.ldb : KT;
+  int fa[TM], fb[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) fa[i] = lds_off16(wm * (BM / 2) + i * 32 + r, h);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) fb[j] = lds_off16(wn * (BN / 2) + j * 32 + r, h);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const bool do_rowsum = AKM && p.ep.a_rowsum && tile_x == 0;
+  float rowsum = 0.f;
+  float va[8], vb[8];
+  auto load8 = [&](bool kmaj, const float* corner, int ld, unsigned off, float (&v)[8]) {
+    if (!kmaj) {
+      const float4* s = reinterpret_cast<const float4*>(corner + off);
+      const float4 a = s[0], b = s[1];
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) v[kk] = (corner + (long long)kk * ld)[off];
+    }
+  };
+  auto stage_store = [&](int stage) {
+    if (do_rowsum) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) rowsum += va[e];
+    }
+    __bf16* const a_pl = planes + stage * STAGE;
+    __bf16* const b_pl = a_pl + NP * A_PLANE;
+    split_store<NP>(a_pl + lda_, A_PLANE, va);
+    split_store<NP>(b_pl + ldb_, B_PLANE, vb);
+  };
+  auto mfma_step = [&](int stage) {
+    const __bf16* const a_pl = planes + stage * STAGE;
+    const __bf16* const b_pl = a_pl + NP * A_PLANE;
+    bf16x8 af[TM][NP], bf[TN][NP];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) af[i][pl] = *reinterpret_cast<const bf16x8*>(a_pl + pl * A_PLANE + fa[i]);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) bf[j][pl] = *reinterpret_cast<const bf16x8*>(b_pl + pl * B_PLANE + fb[j]);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+      }
+  };
+
+  if (nk > 0) {
+    load8(AKM, ca, p.lda, offa, va);
+    load8(BKM, cb, p.ldb, offb, vb);
+    stage_store(0);
+    if (nk > 1) {                                          // (nk == 1: the corners stay on tile 0)
+      ca += step_a; cb += step_b;
+      load8(AKM, ca, p.lda, offa, va);
+      load8(BKM, cb, p.ldb, offb, vb);
+    }
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {                        // branch-free body: the last iterations re-stage / re-load the final tile
+    const int cur = kt & 1;
+    mfma_step(cur);
+    stage_store(cur ^ 1);
+    const bool more = kt + 2 < nk;
+    ca += more ? step_a : 0; cb += more ? step_b : 0;
+    load8(AKM, ca, p.lda, offa, va);
+    load8(BKM, cb, p.ldb, offb, vb);
+    __syncthreads();
+  }
+  if (do_rowsum && m0 + rowa < p.M) atomicAdd(p.ep.a_rowsum + m0 + rowa, rowsum);
+  gemm_epilogue<BM, BN, SMEM_FLOATS>(p, acc, smem, m0, n0, tid, split, p.C);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Pre-split B: the weights' bf16 planes exist in HBM (mansy_launch_weight_planes, once per step), so the B tiles go HBM/L2 -> LDS by
 // LDS-DMA -- no split VALU work, no staging registers and no ds_write for that operand (the ds_write path, ~80 B/clk/CU, is what
 // bounds the in-loop split: removing B's writes measured -17 % on the forward / dX shapes).  A (activations, K-contiguous) is
@@ -445,14 +581,23 @@ int launch_layouts(const GemmParams& p, int a_kmajor, int b_kmajor, int splits, 
 }  // namespace
 
 // tile: 128 -> 128x128, anything else -> 64x64; prec: 3 (bf16x3) or 6 (bf16x6).  Preconditions as the LDS-DMA loop's.
-// bf16x3 runs the two-stage loop (64 KB of planes, two workgroups per CU); bf16x6 the one-stage loop -- two stages of three
-// planes are 96 KB, i.e. one workgroup per CU, and measured 10-20 % slower than one stage with two (tools/bf16_lab.sh).
+// bf16x3 runs the two-stage loop (64 KB of planes, two workgroups per CU); bf16x6: 128 x 128 tiles on the half-K-tile two-stage
+// loop (48 KB), 64 x 64 tiles on the one-stage loop (two 32-k stages of three planes are 96 KB, i.e. one workgroup per CU, and
+// measured 10-20 % slower than one stage with two).
 int mansy_gemm_bf16s_dispatch(const GemmParams& p, int tile, int prec, int a_kmajor, int b_kmajor, int splits, hipStream_t st) {
   if (prec == 3) {
     if (tile == 128) return launch_layouts<128, 128, 2, true>(p, a_kmajor, b_kmajor, splits, st);
     return launch_layouts<64, 64, 2, true>(p, a_kmajor, b_kmajor, splits, st);
   }
-  if (tile == 128) return launch_layouts<128, 128, 3, false>(p, a_kmajor, b_kmajor, splits, st);
+  if (tile == 128) {       // half K-tiles, two stages, two workgroups per CU: 3-14 % faster than one 32-k stage (tools/gemm_bench.py)
+    dim3 grid(mansy_ceil_div(p.N, 128), mansy_ceil_div(p.M, 128), splits), block(NT);
+    if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_bf16x6_k16_kernel<false, false>), grid, block, 0, st, p);
+    else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_bf16x6_k16_kernel<false, true>), grid, block, 0, st, p);
+    else if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_bf16x6_k16_kernel<true, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((gemm_bf16x6_k16_kernel<true, false>), grid, block, 0, st, p);
+    MANSY_LAUNCH_CHECK();
+    return MANSY_OK;
+  }
   return launch_layouts<64, 64, 3, false>(p, a_kmajor, b_kmajor, splits, st);
 }
 
