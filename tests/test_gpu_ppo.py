@@ -450,7 +450,7 @@ def test_whole_update_vs_oracle_update(M):
     values have moved more than eps_clip from v_old (all 512 samples of most minibatches here), a sample contributes -2 (R - v)
     or nothing depending on which square is larger, so a 1e-6 difference in v flips a sample at the boundary and moves the
     gradient of a minibatch in which only ~35 samples contribute by several per cent -- in any two fp32 implementations
-    (tools/_bin probes: the engine's per-sample rule equals autograd's on every sample; the first flip appears at step 26)."""
+    (tools/ppo_update_probe.py: the engine's per-sample rule equals autograd's on every sample; the first flip appears at step 26)."""
     sd = po.make_policy_state_dict(int(Z['wseed']))
     for (T, N, bs) in ((16, 256, 512), (11, 100, 512)):
         pol = build_policy(M, sd)
