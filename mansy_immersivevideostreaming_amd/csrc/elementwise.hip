@@ -304,37 +304,42 @@ __global__ __launch_bounds__(256) void mtio_loss_kernel(const float* __restrict_
 __global__ void mtio_loss_finish(const double* accum, float inv_2bt, float* loss_out) { *loss_out = (float)(*accum * (double)inv_2bt); }
 
 // decoupled (AdamW, torch single-tensor math) or L2-coupled (Adam weight_decay) update, float4 per thread
+// one Adam element (torch.optim.Adam / AdamW, foreach=False arithmetic order)
+__device__ __forceinline__ void adamw_elem(float& p, float g, float& m, float& v, float lr, float b1, float b2, float eps, float wd,
+                                           float step_size, float sqrt_bc2, int decoupled) {
+  if (decoupled) p = p * (1.f - lr * wd);
+  else g = g + wd * p;
+  m = m + (g - m) * (1.f - b1);               // torch: exp_avg.lerp_(grad, 1-beta1)
+  v = v * b2 + (1.f - b2) * g * g;            // torch: mul_(beta2).addcmul_(grad, grad, 1-beta2)
+  const float denom = sqrtf(v) / sqrt_bc2 + eps;
+  p = p - step_size * (m / denom);
+}
+// (four elements per lane in named registers: indexing small per-lane arrays with a runtime count made the compiler place them in
+//  LDS -- 16 KB per workgroup and a 29 us launch for 270 k elements, found in profiles/r02c_ppo_kernel_stats.csv)
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
                                                     float wd, float bc1, float sqrt_bc2, int decoupled) {
   const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i4 >= n) return;
-  const int cnt = (int)min((long long)4, n - i4);
-  float pp[4], gg[4], mm[4], vv[4];
-  if (cnt == 4) {
-    *reinterpret_cast<float4*>(pp) = *reinterpret_cast<const float4*>(p + i4);
-    *reinterpret_cast<float4*>(gg) = *reinterpret_cast<const float4*>(g + i4);
-    *reinterpret_cast<float4*>(mm) = *reinterpret_cast<const float4*>(m + i4);
-    *reinterpret_cast<float4*>(vv) = *reinterpret_cast<const float4*>(v + i4);
-  } else {
-    for (int e = 0; e < cnt; ++e) { pp[e] = p[i4 + e]; gg[e] = g[i4 + e]; mm[e] = m[i4 + e]; vv[e] = v[i4 + e]; }
-  }
   const float step_size = lr / bc1;
-  for (int e = 0; e < cnt; ++e) {
-    float grad = gg[e];
-    if (decoupled) pp[e] = pp[e] * (1.f - lr * wd);
-    else grad = grad + wd * pp[e];
-    mm[e] = mm[e] + (grad - mm[e]) * (1.f - b1);            // torch: exp_avg.lerp_(grad, 1-beta1)
-    vv[e] = vv[e] * b2 + (1.f - b2) * grad * grad;          // torch: mul_(beta2).addcmul_(grad, grad, 1-beta2)
-    const float denom = sqrtf(vv[e]) / sqrt_bc2 + eps;
-    pp[e] = pp[e] - step_size * (mm[e] / denom);
+  if (i4 + 4 <= n) {
+    float4 pp = *reinterpret_cast<const float4*>(p + i4);
+    const float4 gg = *reinterpret_cast<const float4*>(g + i4);
+    float4 mm = *reinterpret_cast<const float4*>(m + i4);
+    float4 vv = *reinterpret_cast<const float4*>(v + i4);
+    adamw_elem(pp.x, gg.x, mm.x, vv.x, lr, b1, b2, eps, wd, step_size, sqrt_bc2, decoupled);
+    adamw_elem(pp.y, gg.y, mm.y, vv.y, lr, b1, b2, eps, wd, step_size, sqrt_bc2, decoupled);
+    adamw_elem(pp.z, gg.z, mm.z, vv.z, lr, b1, b2, eps, wd, step_size, sqrt_bc2, decoupled);
+    adamw_elem(pp.w, gg.w, mm.w, vv.w, lr, b1, b2, eps, wd, step_size, sqrt_bc2, decoupled);
+    *reinterpret_cast<float4*>(p + i4) = pp;
+    *reinterpret_cast<float4*>(m + i4) = mm;
+    *reinterpret_cast<float4*>(v + i4) = vv;
+    return;
   }
-  if (cnt == 4) {
-    *reinterpret_cast<float4*>(p + i4) = *reinterpret_cast<float4*>(pp);
-    *reinterpret_cast<float4*>(m + i4) = *reinterpret_cast<float4*>(mm);
-    *reinterpret_cast<float4*>(v + i4) = *reinterpret_cast<float4*>(vv);
-  } else {
-    for (int e = 0; e < cnt; ++e) { p[i4 + e] = pp[e]; m[i4 + e] = mm[e]; v[i4 + e] = vv[e]; }
+  for (long long e = i4; e < n; ++e) {          // the last, partial group of four
+    float pe = p[e], me = m[e], ve = v[e];
+    adamw_elem(pe, g[e], me, ve, lr, b1, b2, eps, wd, step_size, sqrt_bc2, decoupled);
+    p[e] = pe; m[e] = me; v[e] = ve;
   }
 }
 
