@@ -38,7 +38,7 @@ PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E
 PPO_FLOP_PER_ENV_STEP = 11.5e6   # rollout 0.523 + update 10.95 MFLOP per env-step, as written
 PPO_BYTES_PER_ENV_STEP = 29e3    # 3 116 B observation written + ~8.2 reads of it across the update passes
 PPO_LAUNCHES_PER_CYCLE = 281     # kernels per collect + identifier + update cycle (rocprofv3 kernel trace; round 1: 307)
-PPO_LAUNCHES_SOURCE = 'profiles/r02c_ppo_kernel_stats.csv'
+PPO_LAUNCHES_SOURCE = 'profiles/r02d_ppo_kernel_stats.csv'
 LAUNCH_FLOOR_US = 5.0            # dependent-launch floor on this chip (K -> 0 intercept of a [4096,512] product)
 
 

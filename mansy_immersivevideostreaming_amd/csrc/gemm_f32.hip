@@ -125,7 +125,13 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmParams p) {
     tile_y = t / gridDim.x; tile_x = t - tile_y * gridDim.x;
   }
   const int m0 = tile_y * BM, n0 = tile_x * BN;
-  const bool first_n_tile = tile_x == 0;
+  int first_tile = 0;
+  if (BM == 64 && p.ep.tile_nrange) {             // only the column tiles that meet this row tile's wanted range run
+    const int lo = p.ep.tile_nrange[2 * tile_y], hi = p.ep.tile_nrange[2 * tile_y + 1];
+    if (n0 >= hi || n0 + BN <= lo) return;
+    first_tile = lo / BN;
+  }
+  const bool first_n_tile = tile_x == first_tile;
   const int k_begin = blockIdx.z * p.k_per_split;
   const int k_end = min(p.K, k_begin + p.k_per_split);
   const int nk = (k_end - k_begin + BK - 1) / BK;
@@ -277,6 +283,13 @@ __global__ __launch_bounds__(NT) void gemm_f32_dma_kernel(GemmParams p) {
     if (prob) { Ap = p.A2; Bp = p.B2; Cp = p.C2; rowsum_dst = p.a_rowsum2; }
   }
   const int m0 = tile_y * BM, n0 = tile_x * BN;
+  int rs_first = 0, rs_cnt = gridDim.x;             // the column tiles of this row panel that run (they share the row-sum work)
+  if (BM == 64 && p.ep.tile_nrange) {
+    const int lo = p.ep.tile_nrange[2 * tile_y], hi = p.ep.tile_nrange[2 * tile_y + 1];
+    if (n0 >= hi || n0 + BN <= lo) return;
+    rs_first = lo / BN;
+    rs_cnt = min((int)gridDim.x, (hi + BN - 1) / BN) - rs_first;
+  }
   int k_begin = split * p.k_per_split;
   int k_end = min(p.K, k_begin + p.k_per_split);
   if (BN == 64 && p.ep.tile_krange) {             // structurally-zero K-tiles of this column tile are skipped
@@ -327,7 +340,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_dma_kernel(GemmParams p) {
     if (AK && rowsum_dst && tid < BM) {          // bias gradient: row sums of the staged A tile.  Every n-tile of this
       // row panel stages the same A tile, so they share the BK rows (a single n-tile doing all of them ran ~1.3x longer
       // than its neighbours and set the kernel's tail)
-      for (int kk = tile_x; kk < BK; kk += gridDim.x) rowsum += a_l[kk * BM + tid];
+      for (int kk = tile_x - rs_first; kk < BK; kk += rs_cnt) rowsum += a_l[kk * BM + tid];
     }
 #pragma unroll
     for (int chunk = 0; chunk < 2; ++chunk) {
@@ -348,7 +361,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_dma_kernel(GemmParams p) {
   }
   __syncthreads();                                        // staging LDS idle: the epilogue reuses it
 
-  if (AK && rowsum_dst && tile_x < BK && tid < BM && m0 + tid < p.M) atomicAdd(rowsum_dst + m0 + tid, rowsum);
+  if (AK && rowsum_dst && tile_x - rs_first < BK && tid < BM && m0 + tid < p.M) atomicAdd(rowsum_dst + m0 + tid, rowsum);
   gemm_epilogue<BM, BN, SMEM_FLOATS>(p, acc, smem, m0, n0, tid, split, Cp);
 }
 
@@ -519,6 +532,7 @@ int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B,
     // register-staged loop: 128x128 when it alone gives two full rounds of resident workgroups, else 64x64
     tile = tile_count(M, N, 128) >= 512 ? 128 : 64;
   }
+  if (tile != 64) p.ep.tile_nrange = nullptr;              // (64-row tiles only; without it every tile is computed -- still correct)
   const long long tiles = tile_count(M, N, tile) * n_prob;
   // split-K only for plain accumulating products (dW = dY^T X): partial sums are atomically added
   int splits = 1;
@@ -547,7 +561,7 @@ int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B,
   const int rc = gemm_dispatch(p, tile, dma, bf, a_kmajor, b_kmajor, splits, st);
   MANSY_HIP_CHECK(hipEventRecord(g_prof.ev[g_prof.used + 1], st));
   g_prof.used += 2;
-  g_prof.flops += 2.0 * (double)M * (double)N * (double)K * n_prob;
+  g_prof.flops += 2.0 * (double)M * (double)N * (double)K * n_prob * (p.ep.tile_nrange ? (double)ep.flops_frac : 1.0);
   return rc;
 }
 

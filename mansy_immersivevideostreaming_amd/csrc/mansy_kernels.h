@@ -33,6 +33,11 @@ struct GemmEpilogue {
   // tile t the K range [tile_krange[2t], tile_krange[2t+1]) (multiples of 32) that holds all of B's non-zeros for those
   // columns -- block-diagonal weights (FeatureNet) skip the K-tiles that are structurally zero.
   const int* tile_krange = nullptr;
+  // optional, 64-row tiles only (force_tile 64 / -64; ignored otherwise and by the split-bf16 loops): per 64-row tile t of C the
+  // column range [tile_nrange[2t], tile_nrange[2t+1]) that the consumer reads; workgroups whose column tile lies outside it
+  // exit at once and leave their part of C UNWRITTEN (gradient of a block-diagonal weight: only the diagonal blocks are wanted).
+  const int* tile_nrange = nullptr;
+  float flops_frac = 1.f;       // with tile_nrange: the fraction of C's tiles that run (only for the launch profiler's flop count)
   // optional second product of identical shape / layout / leading dimensions in the SAME launch (plain accumulating
   // epilogue only, e.g. two dW products sharing an operand): C2 += A2 * B2, a_rowsum2 like a_rowsum.  Falls back to two
   // launches off the LDS-DMA loop.

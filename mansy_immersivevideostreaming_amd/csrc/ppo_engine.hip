@@ -13,6 +13,7 @@
 //     optimiser step (3.8 MB) and its gradient is un-packed from one dWbd = dPre^T obs product;
 //   * actor and critic share F inside a minibatch (the reference evaluates the shared FeatureNet twice);
 //   * 128->{15,1,3} output layers, residual add, softmax/sampling, PPO loss and its gradient are fused row-wise kernels.
+#include <algorithm>
 #include <string>
 #include <vector>
 #include "mansy_kernels.h"
@@ -37,6 +38,7 @@ constexpr int RESID_COL = FEAT - HID;      // 10th branch output is the residual
 constexpr int NORM_PARTS_C = MANSY_CLIP_SCRATCH_DOUBLES;   // gradient-norm partial sums
 constexpr int HB_BLOCKS = 64;               // workgroups of the output-layer backward (each ends with n_out x 128 global atomics)
 constexpr int MAX_SLABS = 16;              // K splits of a head's fc product (head_split_request)
+constexpr int DW_SLABS = 6;                // K (= batch) splits of the packed FeatureNet weight-gradient product (featnet_bwd)
 
 struct Branch { int off, len; };
 __host__ __device__ inline Branch branch_geom(int j, int identifier) {
@@ -169,8 +171,10 @@ struct UnpackArgs { float* gbw[NB]; float* gbb[NB]; };
 // earlier launches and are scanned by extra workgroups at the end of the grid; per-workgroup sums are added into the
 // NORM_PARTS slots that clip_adam_kernel adds up (zeroed by the pack launch's riders).
 struct NormRider { double* parts; const float* tail_g; long long tail_n; };
-__global__ __launch_bounds__(256) void unpack_dwbd_kernel(const float* __restrict__ dWbd, const float* __restrict__ dbbd, int identifier, int K,
-                                                          UnpackArgs a, NormRider nr) {
+// dWbd arrives as nsplit K-split slabs (stride `slab` floats) of which only the block-diagonal windows were written
+// (GemmEpilogue::tile_nrange): summed here in slab order.
+__global__ __launch_bounds__(256) void unpack_dwbd_kernel(const float* __restrict__ dWbd, int nsplit, long long slab, const float* __restrict__ dbbd,
+                                                          int identifier, int K, UnpackArgs a, NormRider nr) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long n_main = (long long)FEAT * K;
   double sq = 0.0;
@@ -179,7 +183,11 @@ __global__ __launch_bounds__(256) void unpack_dwbd_kernel(const float* __restric
     const int col = (int)(idx % K), row = (int)(idx / K);
     const int j = row / HID, r = row % HID;
     const Branch g = branch_geom(j, identifier);
-    if (col >= g.off && col < g.off + g.len) { const float v = dWbd[idx]; a.gbw[j][r * g.len + (col - g.off)] += v; sq += (double)v * (double)v; }
+    if (col >= g.off && col < g.off + g.len) {
+      float v = dWbd[idx];
+      for (int z = 1; z < nsplit; ++z) v += dWbd[(long long)z * slab + idx];
+      a.gbw[j][r * g.len + (col - g.off)] += v; sq += (double)v * (double)v;
+    }
   } else if (nr.parts) {
     const long long t4 = (idx - (n_main + 255) / 256 * 256) * 4;          // tail workgroups start on a workgroup boundary
     if (t4 >= 0 && t4 + 4 <= nr.tail_n) {
@@ -656,7 +664,7 @@ size_t ppo_layout(int maxB, char* base, PWork& W) {
   W.A1a = f((size_t)maxB * HID); W.Ha = f((size_t)maxB * HID); W.A1c = f((size_t)maxB * HID); W.Hc = f((size_t)maxB * HID);
   W.outa = f((size_t)maxB * MAXOUT); W.outc = f((size_t)maxB * MAXOUT);
   W.dHa = f((size_t)maxB * HID); W.dHc = f((size_t)maxB * HID); W.dA1a = f((size_t)maxB * HID); W.dA1c = f((size_t)maxB * HID);
-  W.dF = f((size_t)maxB * FEAT); W.dWbd = f((size_t)FEAT * K_IDENT); W.dbbd = f(FEAT); W.obs_mb = f((size_t)maxB * OBS_LD);
+  W.dF = f((size_t)maxB * FEAT); W.dWbd = f((size_t)DW_SLABS * FEAT * K_IDENT); W.dbbd = f(FEAT); W.obs_mb = f((size_t)maxB * OBS_LD);
   W.gout = f((size_t)maxB * MAXOUT); W.gout_c = f((size_t)maxB * MAXOUT);
   W.A1s = f((size_t)head_slab_rows(maxB) * 2 * HID);
   W.Wfc2 = f((size_t)2 * HID * FEAT); W.dA1p = f((size_t)maxB * 2 * HID);
@@ -786,14 +794,35 @@ struct PEng {
                   long long norm_tail_n = 0) {
     const int K = identifier ? K_IDENT : K_POLICY;
     (void)dHa; (void)dHb;      // joined inside the dF product's epilogue (head_bwd / head_bwd_pair); dbbd and the norm slots were zeroed by pack
-    GemmEpilogue ep; ep.a_rowsum = W.dbbd;                                                                   // dbbd = column sums of dPre
-    RC(mansy_launch_gemm_f32(W.dF, FEAT, 1, obs, OBS_LD, 1, W.dWbd, K, FEAT, K, B, ep, 0, 1, st));           // dWbd = dPre^T obs
+    // dWbd = dPre^T obs, wanted on the block diagonal only: per 64-feature row tile the column tiles outside the branch's window
+    // exit at once (tile_nrange = the krange table of the packed image: 42 of the 240 tiles run), and the batch (= K of this
+    // product) is split into slabs that the unpack launch sums -- 16 update launches 13 -> 7 us, the identifier's (K = 3 277,
+    // one workgroup per CU walking 102 K-tiles) 82 -> 15 us.  dbbd = column sums of dPre ride on the staged A tiles as before.
+    const int req = std::min(DW_SLABS, std::max(1, B / 128));
+    const int Bmain = (B % 32 != 0 && B >= 256) ? B / 32 * 32 : B;          // whole K-tiles on the LDS-DMA loop, the rest added below
+    const int nsplit = mansy_gemm_effective_splits(Bmain, req);
+    const long long slab = (long long)FEAT * K;
+    MANSY_REQUIRE(nsplit <= DW_SLABS, "featnet_bwd: %d slabs exceed the workspace", nsplit);
+    int active = 0;                                                         // tiles that run (host copy of the geometry pack_wbd_kernel writes)
+    for (int t = 0; t < FEAT / 64; ++t) {
+      const Branch g = branch_geom(t * 64 / HID, identifier);
+      const int lo = g.off / 32 * 32, hi = std::min(KP, (g.off + g.len + 31) / 32 * 32);
+      active += std::min(mansy_ceil_div(K, 64), mansy_ceil_div(hi, 64)) - lo / 64;
+    }
+    GemmEpilogue ep; ep.a_rowsum = W.dbbd; ep.tile_nrange = W.krange; ep.split_slab = nsplit > 1 ? slab : 0;
+    ep.flops_frac = (float)active / (float)(FEAT / 64 * mansy_ceil_div(K, 64));
+    RC(mansy_launch_gemm_f32(W.dF, FEAT, 1, obs, OBS_LD, 1, W.dWbd, K, FEAT, K, Bmain, ep, 64, nsplit > 1 ? req : 1, st));
+    if (Bmain < B) {                                                        // the < 32 leftover rows: added into slab 0
+      GemmEpilogue tail; tail.a_rowsum = W.dbbd; tail.tile_nrange = W.krange; tail.accumulate = 1; tail.flops_frac = ep.flops_frac;
+      RC(mansy_launch_gemm_f32(W.dF + (size_t)Bmain * FEAT, FEAT, 1, obs + (size_t)Bmain * OBS_LD, OBS_LD, 1, W.dWbd, K, FEAT, K, B - Bmain, tail,
+                               -64, 1, st));
+    }
     UnpackArgs u; for (int j = 0; j < NB; ++j) { u.gbw[j] = n.gbw[j]; u.gbb[j] = n.gbb[j]; }
     NormRider nr; nr.parts = norm_tail ? W.acc : nullptr; nr.tail_g = norm_tail; nr.tail_n = norm_tail_n;
     const long long main_blocks = mansy_ceil_div((long long)FEAT * K, 256);
     const long long tail_blocks = norm_tail ? mansy_ceil_div(mansy_ceil_div(norm_tail_n, 4), 256) : 0;
     MANSY_REQUIRE(!norm_tail || (reinterpret_cast<uintptr_t>(norm_tail) & 15) == 0, "featnet_bwd: gradient tail must be 16-byte aligned");
-    hipLaunchKernelGGL(unpack_dwbd_kernel, dim3(main_blocks + tail_blocks), dim3(256), 0, st, W.dWbd, W.dbbd, identifier, K, u, nr);
+    hipLaunchKernelGGL(unpack_dwbd_kernel, dim3(main_blocks + tail_blocks), dim3(256), 0, st, W.dWbd, nsplit, slab, W.dbbd, identifier, K, u, nr);
     MANSY_LAUNCH_CHECK();
     return MANSY_OK;
   }
