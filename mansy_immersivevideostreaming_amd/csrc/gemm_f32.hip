@@ -123,6 +123,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmParams p) {
     const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7, local = orig >> 3;
     const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
     tile_y = t / gridDim.x; tile_x = t - tile_y * gridDim.x;
+    if (BM == 64 && BN == 64 && p.ep.tile_list) { tile_x = p.ep.tile_list[2 * t]; tile_y = p.ep.tile_list[2 * t + 1]; }
   }
   const int m0 = tile_y * BM, n0 = tile_x * BN;
   int first_tile = 0;
@@ -275,6 +276,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_dma_kernel(GemmParams p) {
     int t = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + local;
     split = t / per_split; t -= split * per_split;
     tile_y = t / gridDim.x; tile_x = t - tile_y * gridDim.x;
+    if (BM == 64 && BN == 64 && p.ep.tile_list) { tile_x = p.ep.tile_list[2 * t]; tile_y = p.ep.tile_list[2 * t + 1]; }
   }
   const float* Ap = p.A; const float* Bp = p.B; float* Cp = p.C; float* rowsum_dst = p.ep.a_rowsum;
   if (p.A2) {                                       // two same-shape problems in one launch: the upper half of the splits is problem 2
@@ -368,6 +370,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_dma_kernel(GemmParams p) {
 template <int BM, int BN>
 int launch_dma(const GemmParams& p, int a_kmajor, int b_kmajor, int splits, hipStream_t st) {
   dim3 grid(mansy_ceil_div(p.N, BN), mansy_ceil_div(p.M, BM), splits);
+  if (BM == 64 && BN == 64 && p.ep.tile_list) grid = dim3(p.ep.tile_list_n, 1, splits);      // only the listed tiles
   dim3 block(NT);
   if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, false, false>), grid, block, 0, st, p);
   else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, false, true>), grid, block, 0, st, p);
@@ -380,6 +383,7 @@ int launch_dma(const GemmParams& p, int a_kmajor, int b_kmajor, int splits, hipS
 template <int BM, int BN, bool VEC>
 int launch_cfg(const GemmParams& p, int a_kmajor, int b_kmajor, int splits, hipStream_t st) {
   dim3 grid(mansy_ceil_div(p.N, BN), mansy_ceil_div(p.M, BM), splits);
+  if (BM == 64 && BN == 64 && p.ep.tile_list) grid = dim3(p.ep.tile_list_n, 1, splits);      // only the listed tiles
   dim3 block(NT);
   if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false, VEC>), grid, block, 0, st, p);
   else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true, VEC>), grid, block, 0, st, p);
@@ -532,7 +536,11 @@ int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B,
     // register-staged loop: 128x128 when it alone gives two full rounds of resident workgroups, else 64x64
     tile = tile_count(M, N, 128) >= 512 ? 128 : 64;
   }
+  // tile_krange is honoured by the 64-column tiles of the LDS-DMA / split-bf16 loops (ppo_engine.hip packs B only inside the ranges and
+  // makes sure its operands qualify for those loops)
+  if (ep.tile_krange && dma && tile == 128) tile = bf ? 64 : 96;
   if (tile != 64) p.ep.tile_nrange = nullptr;              // (64-row tiles only; without it every tile is computed -- still correct)
+  if (tile != 64 || !p.ep.tile_nrange || bf || ep.tile_list_n < 1) { p.ep.tile_list = nullptr; p.ep.tile_list_n = 0; }
   const long long tiles = tile_count(M, N, tile) * n_prob;
   // split-K only for plain accumulating products (dW = dY^T X): partial sums are atomically added
   int splits = 1;

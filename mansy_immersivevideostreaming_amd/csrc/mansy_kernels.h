@@ -38,6 +38,9 @@ struct GemmEpilogue {
   // exit at once and leave their part of C UNWRITTEN (gradient of a block-diagonal weight: only the diagonal blocks are wanted).
   const int* tile_nrange = nullptr;
   float flops_frac = 1.f;       // with tile_nrange: the fraction of C's tiles that run (only for the launch profiler's flop count)
+  // optional companion of tile_nrange (64 x 64 tiles): the tiles that run, as (column tile, row tile) pairs -- the launch then has
+  // tile_list_n workgroups per K split instead of one per tile of C (thousands of workgroups that exit at once cost ~1 ns each).
+  const int* tile_list = nullptr; int tile_list_n = 0;
   // optional second product of identical shape / layout / leading dimensions in the SAME launch (plain accumulating
   // epilogue only, e.g. two dW products sharing an operand): C2 += A2 * B2, a_rowsum2 like a_rowsum.  Falls back to two
   // launches off the LDS-DMA loop.

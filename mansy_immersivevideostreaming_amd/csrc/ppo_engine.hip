@@ -38,7 +38,8 @@ constexpr int RESID_COL = FEAT - HID;      // 10th branch output is the residual
 constexpr int NORM_PARTS_C = MANSY_CLIP_SCRATCH_DOUBLES;   // gradient-norm partial sums
 constexpr int HB_BLOCKS = 64;               // workgroups of the output-layer backward (each ends with n_out x 128 global atomics)
 constexpr int MAX_SLABS = 16;              // K splits of a head's fc product (head_split_request)
-constexpr int DW_SLABS = 6;                // K (= batch) splits of the packed FeatureNet weight-gradient product (featnet_bwd)
+constexpr int DW_SLABS = 24;               // K (= batch) splits of the packed FeatureNet weight-gradient product (featnet_bwd)
+constexpr int DW_TILES_MAX = 64;           // 64 x 64 tiles of that product that meet a branch's window (42 for both nets)
 
 struct Branch { int off, len; };
 __host__ __device__ inline Branch branch_geom(int j, int identifier) {
@@ -47,6 +48,26 @@ __host__ __device__ inline Branch branch_geom(int j, int identifier) {
   Branch b; b.off = off[j]; b.len = len[j];
   return b;
 }
+
+// K window of branch j in whole 32-wide K-tiles: what the FeatureNet product reads for that branch's 128 features (tile_krange)
+__host__ __device__ inline Branch window_geom(int j, int identifier) {
+  const Branch g = branch_geom(j, identifier);
+  Branch w; w.off = g.off / 32 * 32;
+  const int hi = (g.off + g.len + 31) / 32 * 32;
+  w.len = (hi < KP ? hi : KP) - w.off;
+  return w;
+}
+// the 64 x 64 tiles of dWbd [FEAT, K] that meet the block diagonal, as (column tile, row tile) pairs in row-tile order
+__host__ __device__ inline int active_tiles(int identifier, int K, int* list) {
+  int n = 0;
+  for (int t = 0; t < FEAT / 64; ++t) {
+    const Branch w = window_geom(t * 64 / HID, identifier);
+    const int c1 = (K + 63) / 64 < (w.off + w.len + 63) / 64 ? (K + 63) / 64 : (w.off + w.len + 63) / 64;
+    for (int c = w.off / 64; c < c1; ++c) { if (list) { list[2 * n] = c; list[2 * n + 1] = t; } ++n; }
+  }
+  return n;
+}
+inline int window_cols(int identifier) { int n = 0; for (int j = 0; j < NB; ++j) n += window_geom(j, identifier).len; return n; }
 
 struct NetP {                  // one network = feature net + head
   const float* bw[NB]; const float* bb[NB]; const float* fc_w; const float* fc_b; const float* out_w; const float* out_b;
@@ -104,10 +125,12 @@ struct PackArgs {
   // its row sums there) and the gradient-norm / barrier slots (doubles, zeroed as pairs of floats)
   float* z2; int z2n; float* z3; int z3n;
 };
-// Wbd [FEAT, KP] (columns >= K and everything off the block diagonal zero), bbd [FEAT], and per 64-feature column tile of
-// the product the K range that holds its branch's weights (GemmEpilogue::tile_krange).
-__global__ __launch_bounds__(256) void pack_wbd_kernel(PackArgs a, int identifier, int K, float* __restrict__ Wbd, float* __restrict__ bbd,
-                                                       int* __restrict__ krange) {
+// Wbd [FEAT, KP], bbd [FEAT], and per 64-feature column tile of the product the K range that holds its branch's weights
+// (GemmEpilogue::tile_krange).  Only the K windows are written (branch weights, zeros around them up to the 32-wide K-tile
+// borders): the product runs on the 64-column LDS-DMA / split-bf16 loops, which never read a row outside its window (featnet()
+// insists on that path), so 131 k of the image's 983 k floats are touched per pack.  n_win = HID * window_cols().
+__global__ __launch_bounds__(256) void pack_wbd_kernel(PackArgs a, int identifier, int K, long long n_win, float* __restrict__ Wbd,
+                                                       float* __restrict__ bbd, int* __restrict__ krange, int* __restrict__ tlist) {
   if (a.adv && blockIdx.x == gridDim.x - 1) {        // advantage statistics (two-pass, like torch: mean, then unbiased variance)
     __shared__ float sh_adv[8];
     const int n = a.adv_n;
@@ -136,8 +159,10 @@ __global__ __launch_bounds__(256) void pack_wbd_kernel(PackArgs a, int identifie
     krange[2 * idx] = g.off / 32 * 32;
     krange[2 * idx + 1] = min(KP, (g.off + g.len + 31) / 32 * 32);
   }
-  if (idx >= (long long)FEAT * KP) {            // tail of the grid: [actor.fc | critic.fc] stacked to one [2*HID, FEAT] operand, then the riders
-    long long i2 = idx - (long long)FEAT * KP;
+  if (idx < FEAT) bbd[idx] = a.bb[idx / HID][idx % HID];
+  if (idx == FEAT) active_tiles(identifier, K, tlist);          // tile list of the weight-gradient product (featnet_bwd)
+  if (idx >= n_win) {                           // tail of the grid: [actor.fc | critic.fc] stacked to one [2*HID, FEAT] operand, then the riders
+    long long i2 = idx - n_win;
     const long long n_fc = a.Wfc2 ? 2LL * HID * FEAT : 0;
     if (i2 < n_fc) { a.Wfc2[i2] = i2 < (long long)HID * FEAT ? a.fc_a[i2] : a.fc_c[i2 - (long long)HID * FEAT]; return; }
     i2 -= n_fc;
@@ -155,13 +180,14 @@ __global__ __launch_bounds__(256) void pack_wbd_kernel(PackArgs a, int identifie
     }
     return;
   }
-  const int col = (int)(idx % KP), row = (int)(idx / KP);
-  const int j = row / HID, r = row % HID;
+  int j = 0, rem = (int)idx;
+  Branch w = window_geom(0, identifier);
+  while (rem >= HID * w.len) { rem -= HID * w.len; w = window_geom(++j, identifier); }
+  const int r = rem / w.len, col = w.off + rem % w.len;
   const Branch g = branch_geom(j, identifier);
   float v = 0.f;
   if (col < K && col >= g.off && col < g.off + g.len) v = a.bw[j][r * g.len + (col - g.off)];
-  Wbd[idx] = v;
-  if (col == 0) bbd[row] = a.bb[j][r];
+  Wbd[(long long)(j * HID + r) * KP + col] = v;
 }
 // packed gradients -> the compact reference-layout parameter gradients: block-diagonal entries of dWbd [FEAT, K] and the
 // packed bias gradient dbbd [FEAT] (first FEAT threads) are added to the ten branches' weight / bias gradients.
@@ -175,19 +201,22 @@ struct NormRider { double* parts; const float* tail_g; long long tail_n; };
 // (GemmEpilogue::tile_nrange): summed here in slab order.
 __global__ __launch_bounds__(256) void unpack_dwbd_kernel(const float* __restrict__ dWbd, int nsplit, long long slab, const float* __restrict__ dbbd,
                                                           int identifier, int K, UnpackArgs a, NormRider nr) {
+  // one thread per element of the ten branch weights (HID x KC with KC = the branches' input widths added up: the index space of
+  // the compact gradients, 8 x smaller than the packed image's)
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  const long long n_main = (long long)FEAT * K;
+  const int KC = identifier ? K_IDENT - 4 : K_POLICY;           // 745 state columns + 15 (identifier) / 3 (policy)
+  const long long n_main = (long long)HID * KC;
   double sq = 0.0;
   if (idx < FEAT) { const float b = dbbd[idx]; a.gbb[idx / HID][idx % HID] += b; sq += (double)b * (double)b; }
   if (idx < n_main) {
-    const int col = (int)(idx % K), row = (int)(idx / K);
-    const int j = row / HID, r = row % HID;
-    const Branch g = branch_geom(j, identifier);
-    if (col >= g.off && col < g.off + g.len) {
-      float v = dWbd[idx];
-      for (int z = 1; z < nsplit; ++z) v += dWbd[(long long)z * slab + idx];
-      a.gbw[j][r * g.len + (col - g.off)] += v; sq += (double)v * (double)v;
-    }
+    const int r = (int)(idx / KC);
+    int c = (int)(idx % KC), j = 0;
+    Branch g = branch_geom(0, identifier);
+    while (c >= g.len) { c -= g.len; g = branch_geom(++j, identifier); }
+    const long long src = (long long)(j * HID + r) * K + g.off + c;
+    float v = dWbd[src];
+    for (int z = 1; z < nsplit; ++z) v += dWbd[(long long)z * slab + src];
+    a.gbw[j][r * g.len + c] += v; sq += (double)v * (double)v;
   } else if (nr.parts) {
     const long long t4 = (idx - (n_main + 255) / 256 * 256) * 4;          // tail workgroups start on a workgroup boundary
     if (t4 >= 0 && t4 + 4 <= nr.tail_n) {
@@ -639,6 +668,7 @@ struct PWork {
   float* A1s;      // split-K slabs of a head's fc product (head(), head_pair())
   float *Wfc2, *dA1p;   // [actor.fc | critic.fc] stacked [2*HID, FEAT]; their dA1 side by side [B, 2*HID]
   int* krange;     // per 64-feature tile K range of the packed block-diagonal image
+  int* tlist;      // (column tile, row tile) pairs of the weight-gradient product's tiles on the block diagonal
   double* acc;
   float *adv_stats, *lossrows;   // fused PPO loss: minibatch advantage mean / std; per-row (clip, vf, ent, -) terms
 };
@@ -660,7 +690,7 @@ inline int head_slab_rows(int maxB) {
 size_t ppo_layout(int maxB, char* base, PWork& W) {
   size_t tot = 0;
   auto f = [&](size_t n) { const size_t off = (tot + 255) & ~size_t(255); tot = off + n * sizeof(float); return (float*)(base ? base + off : nullptr); };
-  W.Wbd = f((size_t)FEAT * KP); W.bbd = f(FEAT); W.krange = (int*)f(2 * FEAT / 64); W.F = f((size_t)maxB * FEAT);
+  W.Wbd = f((size_t)FEAT * KP); W.bbd = f(FEAT); W.krange = (int*)f(2 * FEAT / 64); W.tlist = (int*)f(2 * DW_TILES_MAX); W.F = f((size_t)maxB * FEAT);
   W.A1a = f((size_t)maxB * HID); W.Ha = f((size_t)maxB * HID); W.A1c = f((size_t)maxB * HID); W.Hc = f((size_t)maxB * HID);
   W.outa = f((size_t)maxB * MAXOUT); W.outc = f((size_t)maxB * MAXOUT);
   W.dHa = f((size_t)maxB * HID); W.dHc = f((size_t)maxB * HID); W.dA1a = f((size_t)maxB * HID); W.dA1c = f((size_t)maxB * HID);
@@ -688,8 +718,9 @@ struct PEng {
     a.z2 = W.dbbd; a.z2n = FEAT; a.z3 = reinterpret_cast<float*>(W.acc); a.z3n = 2 * NORM_PARTS_C;
     MANSY_REQUIRE(!zero_ptr || (reinterpret_cast<uintptr_t>(zero_ptr) & 15) == 0, "pack: gradient buffer must be 16-byte aligned");
     const int K = identifier ? K_IDENT : K_POLICY;
-    const long long threads = (long long)FEAT * KP + (pair ? 2LL * HID * FEAT : 0) + (long long)a.g_rows * (OBS_LD / 4) + (a.zero_n + 3) / 4;
-    hipLaunchKernelGGL(pack_wbd_kernel, dim3(mansy_ceil_div(threads, 256)), dim3(256), 0, st, a, identifier, K, W.Wbd, W.bbd, W.krange);
+    const long long n_win = (long long)HID * window_cols(identifier);
+    const long long threads = n_win + (pair ? 2LL * HID * FEAT : 0) + (long long)a.g_rows * (OBS_LD / 4) + (a.zero_n + 3) / 4;
+    hipLaunchKernelGGL(pack_wbd_kernel, dim3(mansy_ceil_div(threads, 256)), dim3(256), 0, st, a, identifier, K, n_win, W.Wbd, W.bbd, W.krange, W.tlist);
     MANSY_LAUNCH_CHECK();
     return MANSY_OK;
   }
@@ -702,8 +733,9 @@ struct PEng {
     pa.adv = adv; pa.adv_n = mb; pa.adv_stats = W.adv_stats;
     pa.z2 = W.dbbd; pa.z2n = FEAT; pa.z3 = reinterpret_cast<float*>(W.acc); pa.z3n = 2 * NORM_PARTS_C;
     MANSY_REQUIRE(!zero_ptr || (reinterpret_cast<uintptr_t>(zero_ptr) & 15) == 0, "pack: gradient buffer must be 16-byte aligned");
-    const long long threads = (long long)FEAT * KP + 2LL * HID * FEAT + (long long)pa.g_rows * (OBS_LD / 4) + (pa.zero_n + 3) / 4;
-    hipLaunchKernelGGL(pack_wbd_kernel, dim3(mansy_ceil_div(threads, 256) + 1), dim3(256), 0, st, pa, 0, K_POLICY, W.Wbd, W.bbd, W.krange);
+    const long long n_win = (long long)HID * window_cols(0);
+    const long long threads = n_win + 2LL * HID * FEAT + (long long)pa.g_rows * (OBS_LD / 4) + (pa.zero_n + 3) / 4;
+    hipLaunchKernelGGL(pack_wbd_kernel, dim3(mansy_ceil_div(threads, 256) + 1), dim3(256), 0, st, pa, 0, K_POLICY, n_win, W.Wbd, W.bbd, W.krange, W.tlist);
     MANSY_LAUNCH_CHECK();
     return MANSY_OK;
   }
@@ -711,6 +743,11 @@ struct PEng {
     const int K = identifier ? K_IDENT : K_POLICY;
     (void)K;      // the packed image spans KP columns (zero beyond K); obs rows are OBS_LD >= KP floats
     GemmEpilogue ep; ep.bias = W.bbd; ep.relu = 1; ep.relu_slope = SLOPE; ep.tile_krange = W.krange;
+    // the packed image is only defined inside the K windows: the product must run on a loop that honours tile_krange -- the LDS-DMA
+    // loop or its split-bf16 twin, i.e. K a multiple of 32 (KP), leading dimensions multiples of 4, 16-byte aligned operands
+    static_assert(KP % 32 == 0 && OBS_LD % 4 == 0, "FeatureNet product must qualify for the LDS-DMA loop");
+    MANSY_REQUIRE((reinterpret_cast<uintptr_t>(obs) & 15) == 0 && (reinterpret_cast<uintptr_t>(W.Wbd) & 15) == 0,
+                  "featnet: observation rows and workspace must be 16-byte aligned");
     return mansy_launch_gemm_f32(obs, OBS_LD, 0, W.Wbd, KP, 0, W.F, FEAT, B, FEAT, KP, ep, 0, 0, st);
   }
   int head(const NetP& n, int B, int n_out, int sigmoid, float* A1, float* H, float* out, const float* u, uint32_t seed, uint32_t site, int* act,
@@ -794,32 +831,32 @@ struct PEng {
                   long long norm_tail_n = 0) {
     const int K = identifier ? K_IDENT : K_POLICY;
     (void)dHa; (void)dHb;      // joined inside the dF product's epilogue (head_bwd / head_bwd_pair); dbbd and the norm slots were zeroed by pack
-    // dWbd = dPre^T obs, wanted on the block diagonal only: per 64-feature row tile the column tiles outside the branch's window
-    // exit at once (tile_nrange = the krange table of the packed image: 42 of the 240 tiles run), and the batch (= K of this
-    // product) is split into slabs that the unpack launch sums -- 16 update launches 13 -> 7 us, the identifier's (K = 3 277,
-    // one workgroup per CU walking 102 K-tiles) 82 -> 15 us.  dbbd = column sums of dPre ride on the staged A tiles as before.
-    const int req = std::min(DW_SLABS, std::max(1, B / 128));
+    // dWbd = dPre^T obs, wanted on the block diagonal only: the launch runs the 42 of 240 output tiles that meet a branch's window
+    // (GemmEpilogue::tile_list / tile_nrange, tables written by the pack launch) and splits the batch (= K of this product) into
+    // slabs that the unpack launch sums.  dbbd = column sums of dPre ride on the staged A tiles as before.
     const int Bmain = (B % 32 != 0 && B >= 256) ? B / 32 * 32 : B;          // whole K-tiles on the LDS-DMA loop, the rest added below
+    // ~3 K-tiles per split: the 42 running tiles are one workgroup each, and a lone workgroup per CU waits a full memory round trip
+    // per K-tile (2 us at K = 3 264 from HBM), so the reduce dimension is what fills the chip
+    int req = std::min(DW_SLABS, std::max(1, (Bmain / 32 + 2) / 3));
+    if (mansy_get_gemm_precision() != 0) req = std::min(req, 6);            // the split-bf16 loops run (and store) every tile of every slab
     const int nsplit = mansy_gemm_effective_splits(Bmain, req);
     const long long slab = (long long)FEAT * K;
     MANSY_REQUIRE(nsplit <= DW_SLABS, "featnet_bwd: %d slabs exceed the workspace", nsplit);
-    int active = 0;                                                         // tiles that run (host copy of the geometry pack_wbd_kernel writes)
-    for (int t = 0; t < FEAT / 64; ++t) {
-      const Branch g = branch_geom(t * 64 / HID, identifier);
-      const int lo = g.off / 32 * 32, hi = std::min(KP, (g.off + g.len + 31) / 32 * 32);
-      active += std::min(mansy_ceil_div(K, 64), mansy_ceil_div(hi, 64)) - lo / 64;
-    }
+    const int active = active_tiles(identifier, K, nullptr);             // host copy of the geometry pack_wbd_kernel writes
+    MANSY_REQUIRE(active <= DW_TILES_MAX, "featnet_bwd: %d tiles exceed the list", active);
     GemmEpilogue ep; ep.a_rowsum = W.dbbd; ep.tile_nrange = W.krange; ep.split_slab = nsplit > 1 ? slab : 0;
+    ep.tile_list = W.tlist; ep.tile_list_n = active;
     ep.flops_frac = (float)active / (float)(FEAT / 64 * mansy_ceil_div(K, 64));
     RC(mansy_launch_gemm_f32(W.dF, FEAT, 1, obs, OBS_LD, 1, W.dWbd, K, FEAT, K, Bmain, ep, 64, nsplit > 1 ? req : 1, st));
     if (Bmain < B) {                                                        // the < 32 leftover rows: added into slab 0
       GemmEpilogue tail; tail.a_rowsum = W.dbbd; tail.tile_nrange = W.krange; tail.accumulate = 1; tail.flops_frac = ep.flops_frac;
+      tail.tile_list = W.tlist; tail.tile_list_n = active;
       RC(mansy_launch_gemm_f32(W.dF + (size_t)Bmain * FEAT, FEAT, 1, obs + (size_t)Bmain * OBS_LD, OBS_LD, 1, W.dWbd, K, FEAT, K, B - Bmain, tail,
                                -64, 1, st));
     }
     UnpackArgs u; for (int j = 0; j < NB; ++j) { u.gbw[j] = n.gbw[j]; u.gbb[j] = n.gbb[j]; }
     NormRider nr; nr.parts = norm_tail ? W.acc : nullptr; nr.tail_g = norm_tail; nr.tail_n = norm_tail_n;
-    const long long main_blocks = mansy_ceil_div((long long)FEAT * K, 256);
+    const long long main_blocks = mansy_ceil_div((long long)HID * (identifier ? K_IDENT - 4 : K_POLICY), 256);
     const long long tail_blocks = norm_tail ? mansy_ceil_div(mansy_ceil_div(norm_tail_n, 4), 256) : 0;
     MANSY_REQUIRE(!norm_tail || (reinterpret_cast<uintptr_t>(norm_tail) & 15) == 0, "featnet_bwd: gradient tail must be 16-byte aligned");
     hipLaunchKernelGGL(unpack_dwbd_kernel, dim3(main_blocks + tail_blocks), dim3(256), 0, st, W.dWbd, nsplit, slab, W.dbbd, identifier, K, u, nr);
