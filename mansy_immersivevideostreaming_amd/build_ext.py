@@ -75,11 +75,21 @@ def ensure_built():
     tree now (a fresh clone: *.so is git-ignored; an edit of csrc/ or include/mansy_hip.h: the digest in the stamp file no
     longer matches).  Not a fallback -- it builds the HIP path; without hipcc it raises.  _lib.lib() additionally checks
     mansy_abi_version() against its prototypes."""
-    if os.path.exists(LIB) and os.path.exists(STAMP):
-        with open(STAMP) as fh:
-            if fh.read().strip() == source_digest():
-                return LIB
-    return build()
+    def fresh():
+        if os.path.exists(LIB) and os.path.exists(STAMP):
+            with open(STAMP) as fh:
+                return fh.read().strip() == source_digest()
+        return False
+    if fresh():
+        return LIB
+    # several ranks of one node may get here at once (torchrun on a fresh clone): one builds, the others wait for it
+    import fcntl
+    with open(LIB + '.lock', 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return LIB if fresh() else build()
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
 
 
 if __name__ == '__main__':
