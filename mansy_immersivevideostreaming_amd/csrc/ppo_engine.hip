@@ -67,6 +67,8 @@ __host__ __device__ inline int active_tiles(int identifier, int K, int* list) {
   }
   return n;
 }
+// input widths of the ten branches added up = columns of the compact (reference-layout) weight gradients
+__host__ __device__ inline int compact_cols(int identifier) { int n = 0; for (int j = 0; j < NB; ++j) n += branch_geom(j, identifier).len; return n; }
 inline int window_cols(int identifier) { int n = 0; for (int j = 0; j < NB; ++j) n += window_geom(j, identifier).len; return n; }
 
 struct NetP {                  // one network = feature net + head
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(256) void unpack_dwbd_kernel(const float* __restric
   // one thread per element of the ten branch weights (HID x KC with KC = the branches' input widths added up: the index space of
   // the compact gradients, 8 x smaller than the packed image's)
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  const int KC = identifier ? K_IDENT - 4 : K_POLICY;           // 745 state columns + 15 (identifier) / 3 (policy)
+  const int KC = compact_cols(identifier);                      // 745 state columns + 15 (identifier) / 3 (policy)
   const long long n_main = (long long)HID * KC;
   double sq = 0.0;
   if (idx < FEAT) { const float b = dbbd[idx]; a.gbb[idx / HID][idx % HID] += b; sq += (double)b * (double)b; }
@@ -856,7 +858,7 @@ struct PEng {
     }
     UnpackArgs u; for (int j = 0; j < NB; ++j) { u.gbw[j] = n.gbw[j]; u.gbb[j] = n.gbb[j]; }
     NormRider nr; nr.parts = norm_tail ? W.acc : nullptr; nr.tail_g = norm_tail; nr.tail_n = norm_tail_n;
-    const long long main_blocks = mansy_ceil_div((long long)HID * (identifier ? K_IDENT - 4 : K_POLICY), 256);
+    const long long main_blocks = mansy_ceil_div((long long)HID * compact_cols(identifier), 256);
     const long long tail_blocks = norm_tail ? mansy_ceil_div(mansy_ceil_div(norm_tail_n, 4), 256) : 0;
     MANSY_REQUIRE(!norm_tail || (reinterpret_cast<uintptr_t>(norm_tail) & 15) == 0, "featnet_bwd: gradient tail must be 16-byte aligned");
     hipLaunchKernelGGL(unpack_dwbd_kernel, dim3(main_blocks + tail_blocks), dim3(256), 0, st, W.dWbd, nsplit, slab, W.dbbd, identifier, K, u, nr);
