@@ -539,7 +539,7 @@ int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B,
   // tile_krange is honoured by the 64-column tiles of the LDS-DMA / split-bf16 loops (ppo_engine.hip packs B only inside the ranges and
   // makes sure its operands qualify for those loops)
   if (ep.tile_krange && dma && tile == 128) tile = bf ? 64 : 96;
-  if (tile != 64) p.ep.tile_nrange = nullptr;              // (64-row tiles only; without it every tile is computed -- still correct)
+  if (tile != 64 || bf) p.ep.tile_nrange = nullptr;        // (fp32 loops with 64-row tiles only; without it every tile is computed -- still correct)
   if (tile != 64 || !p.ep.tile_nrange || bf || ep.tile_list_n < 1) { p.ep.tile_list = nullptr; p.ep.tile_list_n = 0; }
   const long long tiles = tile_count(M, N, tile) * n_prob;
   // split-K only for plain accumulating products (dW = dY^T X): partial sums are atomically added
