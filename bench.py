@@ -10,8 +10,8 @@ gradient buffer per step.
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline     dominant kernel = gemm_f32_dma_kernel (exact-fp32 MFMA, LDS-DMA staged).  achieved = exact GEMM FLOPs
                (sum 2MNK over launches; KV-cached decoder => this IS the algorithmic minimum of SURVEY
-               8d up to the attention/elementwise terms) / summed launch duration from HIP events recorded on
-               the launch stream in a separate instrumented leg of the same workload.
+               8d up to the attention/elementwise terms) / summed launch duration from HIP event pairs attached to
+               each dispatch on the launch stream (the kernel's own begin / end) in a separate instrumented leg of the same workload.
                `model_frac` = trajectories/s x 0.522 GFLOP / peak (whole-step MFMA utilisation, north_star).
   cpu_baseline the oracle (CPU restatement, torch fp32, autograd) timed on the host cores on a bounded
                sample (B=32 steps, thread counts 1/8/16/32/all swept inside a ~15 s budget, best reported), kind "port".
@@ -140,7 +140,8 @@ def _pmc_traffic(pattern='r*_pmc_gemm.json'):
 
 
 def _gemm_prof(L, fn, reps):
-    """HIP events around every GEMM launch of `reps` calls of fn (rank 0's launch stream): (ms, launches, exact FLOPs)."""
+    """A HIP event pair attached to every GEMM dispatch (hipExtLaunchKernelGGL: the kernel's own begin / end on rank 0's launch stream) of
+    `reps` calls of fn: (ms, launches, exact FLOPs)."""
     from mansy_immersivevideostreaming_amd._lib import check
     import torch
     check(L.mansy_prof_gemm_enable(1), 'prof_enable')
@@ -211,7 +212,7 @@ def bench_ppo(rank, world, dev, mdist, cycles=5, warmup=2, n_env=256, steps_per_
         col.collect(steps_per_env * n_env, buf)
     torch.cuda.synchronize()
     t_collect = max(time.perf_counter() - tc, 1e-9)
-    # ---- roofline leg (after the timed region): HIP events around the directly launched GEMMs of the update half of a cycle (the
+    # ---- roofline leg (after the timed region): HIP event pairs on the directly launched GEMMs of the update half of a cycle (the
     # rollout half replays a hipGraph: its 2 products per vector step are not seen by the recorder and are counted analytically)
     roof = None
     nprof = 2
@@ -430,7 +431,7 @@ def main():
     loss_val = float(loss.item())
     value = world * B * args.steps / dt
 
-    # ---- roofline leg (rank 0): HIP events around every GEMM launch of the same workload
+    # ---- roofline leg (rank 0): a HIP event pair on every GEMM dispatch of the same workload
     roof = None
     # every rank runs these steps (the data-parallel step holds collectives: SyncBN statistics, gradient all-reduce -- a
     # rank-0-only step would leave the other ranks in a different collective); only rank 0 records GEMM launch times

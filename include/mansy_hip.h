@@ -326,7 +326,7 @@ int mansy_attn_bwd_selfpull(const float* Q_all, long long q_ts, const float* K, 
                             const mansy_attn_shape* s, int T, int step, float drop_p, uint32_t seed, uint32_t site, void* stream);
 
 /* ------------------------------------------------------------------ measurement hooks (bench.py) */
-/* HIP events around every GEMM launch on its own stream; collect() = device sync + summed ms, count, FLOPs. */
+/* A HIP event pair attached to every GEMM dispatch on its own stream (the kernel's begin / end); collect() = device sync + summed ms, count, FLOPs. */
 int mansy_prof_gemm_enable(int on);
 int mansy_prof_gemm_collect(double* total_ms, long long* launches, double* flops);
 

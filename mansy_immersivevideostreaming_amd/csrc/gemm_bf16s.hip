@@ -570,10 +570,10 @@ template <int BM, int BN, int NP, bool DB>
 int launch_layouts(const GemmParams& p, int a_kmajor, int b_kmajor, int splits, hipStream_t st) {
   dim3 grid(mansy_ceil_div(p.N, BN), mansy_ceil_div(p.M, BM), splits);
   dim3 block(NT);
-  if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_bf16s_kernel<BM, BN, false, false, NP, DB>), grid, block, 0, st, p);
-  else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_bf16s_kernel<BM, BN, false, true, NP, DB>), grid, block, 0, st, p);
-  else if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_bf16s_kernel<BM, BN, true, true, NP, DB>), grid, block, 0, st, p);
-  else hipLaunchKernelGGL((gemm_bf16s_kernel<BM, BN, true, false, NP, DB>), grid, block, 0, st, p);
+  if (!a_kmajor && !b_kmajor) MANSY_GEMM_LAUNCH((gemm_bf16s_kernel<BM, BN, false, false, NP, DB>), grid, block, st, p);
+  else if (!a_kmajor && b_kmajor) MANSY_GEMM_LAUNCH((gemm_bf16s_kernel<BM, BN, false, true, NP, DB>), grid, block, st, p);
+  else if (a_kmajor && b_kmajor) MANSY_GEMM_LAUNCH((gemm_bf16s_kernel<BM, BN, true, true, NP, DB>), grid, block, st, p);
+  else MANSY_GEMM_LAUNCH((gemm_bf16s_kernel<BM, BN, true, false, NP, DB>), grid, block, st, p);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }
@@ -591,10 +591,10 @@ int mansy_gemm_bf16s_dispatch(const GemmParams& p, int tile, int prec, int a_kma
   }
   if (tile == 128) {       // half K-tiles, two stages, two workgroups per CU: 3-14 % faster than one 32-k stage (tools/gemm_bench.py)
     dim3 grid(mansy_ceil_div(p.N, 128), mansy_ceil_div(p.M, 128), splits), block(NT);
-    if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_bf16x6_k16_kernel<false, false>), grid, block, 0, st, p);
-    else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_bf16x6_k16_kernel<false, true>), grid, block, 0, st, p);
-    else if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_bf16x6_k16_kernel<true, true>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((gemm_bf16x6_k16_kernel<true, false>), grid, block, 0, st, p);
+    if (!a_kmajor && !b_kmajor) MANSY_GEMM_LAUNCH((gemm_bf16x6_k16_kernel<false, false>), grid, block, st, p);
+    else if (!a_kmajor && b_kmajor) MANSY_GEMM_LAUNCH((gemm_bf16x6_k16_kernel<false, true>), grid, block, st, p);
+    else if (a_kmajor && b_kmajor) MANSY_GEMM_LAUNCH((gemm_bf16x6_k16_kernel<true, true>), grid, block, st, p);
+    else MANSY_GEMM_LAUNCH((gemm_bf16x6_k16_kernel<true, false>), grid, block, st, p);
     MANSY_LAUNCH_CHECK();
     return MANSY_OK;
   }
@@ -606,11 +606,11 @@ int mansy_gemm_bf16p_dispatch(const GemmParams& p, int tile, int prec, hipStream
   const int BMN = tile == 128 ? 128 : 64;
   dim3 grid(mansy_ceil_div(p.N, BMN), mansy_ceil_div(p.M, BMN), 1), block(NT);
   if (prec == 3) {
-    if (tile == 128) hipLaunchKernelGGL((gemm_bf16p_kernel<128, 128, 2>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((gemm_bf16p_kernel<64, 64, 2>), grid, block, 0, st, p);
+    if (tile == 128) MANSY_GEMM_LAUNCH((gemm_bf16p_kernel<128, 128, 2>), grid, block, st, p);
+    else MANSY_GEMM_LAUNCH((gemm_bf16p_kernel<64, 64, 2>), grid, block, st, p);
   } else {
-    if (tile == 128) hipLaunchKernelGGL((gemm_bf16p_kernel<128, 128, 3>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((gemm_bf16p_kernel<64, 64, 3>), grid, block, 0, st, p);
+    if (tile == 128) MANSY_GEMM_LAUNCH((gemm_bf16p_kernel<128, 128, 3>), grid, block, st, p);
+    else MANSY_GEMM_LAUNCH((gemm_bf16p_kernel<64, 64, 3>), grid, block, st, p);
   }
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;

@@ -372,10 +372,10 @@ int launch_dma(const GemmParams& p, int a_kmajor, int b_kmajor, int splits, hipS
   dim3 grid(mansy_ceil_div(p.N, BN), mansy_ceil_div(p.M, BM), splits);
   if (BM == 64 && BN == 64 && p.ep.tile_list) grid = dim3(p.ep.tile_list_n, 1, splits);      // only the listed tiles
   dim3 block(NT);
-  if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, false, false>), grid, block, 0, st, p);
-  else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, false, true>), grid, block, 0, st, p);
-  else if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, true, true>), grid, block, 0, st, p);
-  else hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, true, false>), grid, block, 0, st, p);
+  if (!a_kmajor && !b_kmajor) MANSY_GEMM_LAUNCH((gemm_f32_dma_kernel<BM, BN, false, false>), grid, block, st, p);
+  else if (!a_kmajor && b_kmajor) MANSY_GEMM_LAUNCH((gemm_f32_dma_kernel<BM, BN, false, true>), grid, block, st, p);
+  else if (a_kmajor && b_kmajor) MANSY_GEMM_LAUNCH((gemm_f32_dma_kernel<BM, BN, true, true>), grid, block, st, p);
+  else MANSY_GEMM_LAUNCH((gemm_f32_dma_kernel<BM, BN, true, false>), grid, block, st, p);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }
@@ -385,15 +385,15 @@ int launch_cfg(const GemmParams& p, int a_kmajor, int b_kmajor, int splits, hipS
   dim3 grid(mansy_ceil_div(p.N, BN), mansy_ceil_div(p.M, BM), splits);
   if (BM == 64 && BN == 64 && p.ep.tile_list) grid = dim3(p.ep.tile_list_n, 1, splits);      // only the listed tiles
   dim3 block(NT);
-  if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false, VEC>), grid, block, 0, st, p);
-  else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true, VEC>), grid, block, 0, st, p);
-  else if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, true, VEC>), grid, block, 0, st, p);
-  else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false, VEC>), grid, block, 0, st, p);
+  if (!a_kmajor && !b_kmajor) MANSY_GEMM_LAUNCH((gemm_f32_kernel<BM, BN, false, false, VEC>), grid, block, st, p);
+  else if (!a_kmajor && b_kmajor) MANSY_GEMM_LAUNCH((gemm_f32_kernel<BM, BN, false, true, VEC>), grid, block, st, p);
+  else if (a_kmajor && b_kmajor) MANSY_GEMM_LAUNCH((gemm_f32_kernel<BM, BN, true, true, VEC>), grid, block, st, p);
+  else MANSY_GEMM_LAUNCH((gemm_f32_kernel<BM, BN, true, false, VEC>), grid, block, st, p);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }
 
-// ---- optional launch timing (bench.py roofline leg): HIP events around every GEMM launch
+// ---- optional launch timing (bench.py roofline leg): a HIP event pair attached to every GEMM dispatch (gemm_tile.h: MANSY_GEMM_LAUNCH)
 struct ProfState {
   bool on = false;
   std::vector<hipEvent_t> ev;     // pairs
@@ -401,6 +401,9 @@ struct ProfState {
   double flops = 0.0;
 };
 ProfState g_prof;
+}  // namespace
+namespace mansy_gemm { hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr; }
+namespace {
 int g_gemm_prec = 0;   // process-wide default precision of the dense products: 0 fp32, 3 bf16x3, 6 bf16x6
 
 }  // namespace
@@ -565,9 +568,9 @@ int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B,
   if (g_prof.used + 2 > g_prof.ev.size()) {
     for (int i = 0; i < 2; ++i) { hipEvent_t e; MANSY_HIP_CHECK(hipEventCreate(&e)); g_prof.ev.push_back(e); }
   }
-  MANSY_HIP_CHECK(hipEventRecord(g_prof.ev[g_prof.used], st));
+  mansy_gemm::g_ev_start = g_prof.ev[g_prof.used]; mansy_gemm::g_ev_stop = g_prof.ev[g_prof.used + 1];     // stamped by the dispatch itself
   const int rc = gemm_dispatch(p, tile, dma, bf, a_kmajor, b_kmajor, splits, st);
-  MANSY_HIP_CHECK(hipEventRecord(g_prof.ev[g_prof.used + 1], st));
+  mansy_gemm::g_ev_start = mansy_gemm::g_ev_stop = nullptr;
   g_prof.used += 2;
   g_prof.flops += 2.0 * (double)M * (double)N * (double)K * n_prob * (p.ep.tile_nrange ? (double)ep.flops_frac : 1.0);
   return rc;

@@ -1,6 +1,7 @@
 // Pieces shared by the GEMM main loops (gemm_f32.hip: exact-fp32 MFMA; gemm_bf16s.hip: split-bf16 MFMA): launch parameters and
 // the fused epilogue.  Both loops end with 32x32 MFMA accumulator blocks in the same register layout.
 #pragma once
+#include <hip/hip_ext.h>
 #include "mansy_kernels.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -10,6 +11,16 @@ namespace mansy_gemm {
 constexpr int BK = 32;
 constexpr int KC_LD = BK + 4;   // K-contiguous LDS row stride (floats)
 constexpr int NT = 256;
+
+// Launch timing for bench.py's roofline leg: when the launcher has set a start / stop event pair, the product's kernel is dispatched
+// with hipExtLaunchKernelGGL, which stamps the two events with the kernel's own begin / end (what rocprofv3 reports as its duration);
+// events recorded around the launch would add the queue's per-packet overhead (~1 us) to every one of the ~285 products of a step.
+extern hipEvent_t g_ev_start, g_ev_stop;
+#define MANSY_GEMM_LAUNCH(kern, grid, block, st, params)                                                                        \
+  do {                                                                                                                          \
+    if (mansy_gemm::g_ev_start) hipExtLaunchKernelGGL(kern, grid, block, 0, st, mansy_gemm::g_ev_start, mansy_gemm::g_ev_stop, 0, params); \
+    else hipLaunchKernelGGL(kern, grid, block, 0, st, params);                                                                  \
+  } while (0)
 
 struct GemmParams {
   const float* A; const float* B; float* C;
