@@ -5,7 +5,10 @@ A "step" = one pass of run_models.py:37-44 over one synthetic batch of B=4096 tr
 (MTIO mix, zero-grad, forward, MTIO loss, backward, AdamW), executed by libmansy_hip.so.
 Inputs are resident in HBM before the timed region.  N>1: one process per GPU (torch.distributed /
 RCCL), data parallel over trajectories ("weak" scaling: 4096 per GPU), ONE all-reduce of the flat
-gradient buffer per step.
+gradient buffer per step.  Both launch forms work: under `python -m torch.distributed.run --nproc-per-node N ... bench.py
+--gpus N` the ranks come from the environment; a plain `python bench.py --gpus N` starts its own N rank processes
+(spawn_ranks: fresh children, before this process has touched the GPU).  The line carries `dist` = what the process group
+itself reported (backend, world size, an all-reduce head count); a run whose world size is not --gpus refuses to print.
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline     dominant kernel = gemm_f32_dma_kernel (exact-fp32 MFMA, LDS-DMA staged).  achieved = exact GEMM FLOPs
@@ -365,6 +368,52 @@ def _synthetic_arrays():
     return captured
 
 
+def spawn_ranks(n, argv, script=None):
+    """`python bench.py --gpus N` without a launcher around it: this process (which has made no GPU call -- it has only
+    compiled the library if it was missing) starts N fresh children of this very script, one per GPU, with the
+    torch.distributed environment of a one-node job (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), relays rank 0's JSON line and
+    exits non-zero if any rank fails.  It never replaces itself (no exec): the children are ordinary subprocesses."""
+    import socket
+    import subprocess
+    with socket.socket() as s:                    # a free rendezvous port on this node
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                MANSY_BENCH_LAUNCHER='self-spawn')
+    base.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        # rank 0 inherits stdout (its JSON line IS this command's output); the other ranks print nothing there by contract, and
+        # whatever they do print goes to stderr so it can never be mistaken for the result line
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + argv, env=env, cwd=ROOT,
+                                      stdout=None if r == 0 else sys.stderr))
+    failed = None
+    alive = set(range(n))
+    while alive and failed is None:
+        for r in sorted(alive):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            alive.discard(r)
+            if rc != 0:
+                failed = (r, rc)
+                break
+        time.sleep(0.05)
+    if failed is not None:                        # one rank died: the others would wait in a collective for ever
+        for r in alive:
+            procs[r].terminate()
+        deadline = time.time() + 10
+        for r in alive:
+            try:
+                procs[r].wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+        print(f'bench.py: rank {failed[0]} of {n} exited with code {failed[1]}', file=sys.stderr, flush=True)
+        return failed[1] if failed[1] > 0 else 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -373,6 +422,8 @@ def main():
     ap.add_argument('--batch', type=int, default=4096, help='trajectories per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error('--gpus must be >= 1')
 
     # a fresh clone has no in-tree library (*.so is git-ignored): local rank 0 compiles it, the others wait for the file
     from mansy_immersivevideostreaming_amd import build_ext
@@ -384,13 +435,32 @@ def main():
                 break
             time.sleep(0.5)
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    env_world_size = int(os.environ.get('WORLD_SIZE', '1'))
+    if env_world_size != args.gpus:
+        # a line whose n_gpus is not what was asked for would be read as a measurement of the wrong job
+        sys.exit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={env_world_size} ranks; refusing to run')
+
     import numpy as np
     import torch
     import torch.distributed as dist
     from mansy_immersivevideostreaming_amd import dist as mdist
+    if env_world_size > 1 and os.environ.get('MANSY_SHARE_GPU') != '1' and torch.cuda.device_count() < env_world_size:
+        sys.exit(f'bench.py: {env_world_size} ranks need {env_world_size} GPUs, this node shows {torch.cuda.device_count()} '
+                 '(MANSY_SHARE_GPU=1 MANSY_DIST_BACKEND=gloo runs the functional test of the multi-rank path on fewer)')
     rank, world, local = mdist.init_process_group()
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
+    # proof that the collective library saw every rank: its own world size and an all-reduce of one 1 per rank
+    dist_info = {'backend': None, 'world_size': 1, 'ranks_reporting': 1,
+                 'launcher': os.environ.get('MANSY_BENCH_LAUNCHER', 'torchrun' if 'TORCHELASTIC_RUN_ID' in os.environ else 'env')}
+    if world > 1:
+        ones = torch.ones(1, device=dev, dtype=torch.int32)
+        dist.all_reduce(ones)
+        dist_info.update(backend=dist.get_backend(), world_size=dist.get_world_size(), ranks_reporting=int(ones.item()))
+        if dist_info['world_size'] != args.gpus or dist_info['ranks_reporting'] != args.gpus:
+            sys.exit(f'bench.py: asked for {args.gpus} ranks, the process group reports {dist_info}')
 
     from mansy_immersivevideostreaming_amd.viewport_prediction.models import ViewportTransformerMTIO, FusedAdamW
     from mansy_immersivevideostreaming_amd._lib import lib, check
@@ -505,7 +575,7 @@ def main():
             'config': {'workload': f'VP Transformer train step (fwd+loss+bwd+AdamW), B={B}/GPU synthetic torus-walk '
                                    f'trajectories len 21 (hist 10 + cur 1 + pred 10), d=512, 8 heads, 2+2 layers, dropout on, '
                                    f'fp32 MFMA', 'global_batch': B * world, 'parallelism': f'dp{world}'},
-            'final_loss': loss_val, 'replica_param_spread': vp_spread,
+            'final_loss': loss_val, 'replica_param_spread': vp_spread, 'dist': dist_info,
             'roofline': roof,
             'precision_modes': modes,
             'secondary': ppo,

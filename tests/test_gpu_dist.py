@@ -36,6 +36,37 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
 
 
 @pytest.mark.gpu
+def test_plain_bench_gpus_2_starts_two_ranks():
+    """`python bench.py --gpus 2` with NO launcher around it (the driver's form for its scaling runs): bench.py itself starts
+    the two rank processes; the line must say so -- n_gpus 2, the process group's own world size 2, an all-reduce head count
+    of 2 -- and the replicas must end bit-identical.  `--gpus 1` stays a single process with no process group."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(MANSY_DIST_BACKEND='gloo', MANSY_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '256', '--no-cpu-baseline']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['config']['global_batch'] == 512 and out['secondary']['n_gpus'] == 2
+    assert out['dist'] == {'backend': 'gloo', 'world_size': 2, 'ranks_reporting': 2, 'launcher': 'self-spawn'}
+    assert out['replica_param_spread'] == 0.0 and out['secondary']['replica_param_spread'] == 0.0
+    assert out['value'] > 0 and out['secondary']['value'] > 0
+    # one GPU, two RCCL ranks, no sharing flag: must refuse loudly instead of printing a line
+    env.pop('MANSY_SHARE_GPU')
+    env.pop('MANSY_DIST_BACKEND')
+    import torch
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode != 0 and '{"metric"' not in r.stdout and 'need 2 GPUs' in r.stderr
+    one = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1', '--batch', '256',
+                          '--no-cpu-baseline'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-4000:]
+    o1 = json.loads([l for l in one.stdout.splitlines() if l.startswith('{"metric"')][0])
+    assert o1['n_gpus'] == 1 and o1['dist']['world_size'] == 1 and o1['dist']['backend'] is None
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('overlap', ['0', '1'])
 def test_two_rank_train_step_equals_whole_batch(tmp_path, overlap):
     """a data-parallel VP step over 2 ranks x 32 rows (SyncBN statistics over the global mini-batch + averaged
