@@ -266,6 +266,9 @@ int mansy_clip_grad_rmsprop(float* flat_p, float* flat_g, float* flat_sq, long l
 typedef struct mansy_gemm_epilogue {
   const float* bias; int relu; const float* mask_src; int mask_ld; float mask_scale;
   float drop_p; uint32_t drop_seed; uint32_t drop_site; const float* resid; int resid_ld; int accumulate;
+  /* bias-gradient rider of a dW product (a_kmajor != 0): a_rowsum[m] += sum_k A[m][k], added atomically (zero it first); the
+   * `+= dy.sum(0)` of a Linear's bias gradient at mtio.py / mansy.py autograd.  prec: < 0 = the process-wide mode, else MANSY_PREC_*. */
+  float* a_rowsum; int prec;
 } mansy_gemm_epilogue;
 int mansy_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb, int b_kmajor, float* C, int ldc,
                    int M, int N, int K, const mansy_gemm_epilogue* ep, int force_tile, int force_splitk, void* stream);

@@ -24,7 +24,12 @@ BN_SYNC_FN = ctypes.CFUNCTYPE(c_int, c_int, c_void_p)
 class GemmEpilogue(ctypes.Structure):
     _fields_ = [('bias', c_void_p), ('relu', c_int), ('mask_src', c_void_p), ('mask_ld', c_int), ('mask_scale', c_float),
                 ('drop_p', c_float), ('drop_seed', c_u32), ('drop_site', c_u32), ('resid', c_void_p), ('resid_ld', c_int),
-                ('accumulate', c_int)]
+                ('accumulate', c_int), ('a_rowsum', c_void_p), ('prec', c_int)]
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        if 'prec' not in kw:
+            self.prec = -1          # the process-wide precision mode
 
 
 class EnvTables(ctypes.Structure):
@@ -122,7 +127,7 @@ _RESTYPES = {'mansy_last_error': ctypes.c_char_p, 'mansy_vp_workspace_bytes': ct
 
 # bumped together with mansy_abi_version() (csrc/capi.hip) whenever a prototype or struct above changes: a stale in-tree
 # libmansy_hip.so then fails at load time instead of being called with a wrong argument list
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 

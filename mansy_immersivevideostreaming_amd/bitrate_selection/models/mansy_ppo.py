@@ -22,7 +22,11 @@ from .mansy import NetEngine
 
 
 class RolloutBuffer:
-    """[T][N] step-major slabs on the device (what VectorReplayBuffer holds for one collect)."""
+    """[T][N] step-major slabs on the device (what VectorReplayBuffer holds for one collect).
+    # T2: tianshou's ReplayBuffer keeps `rew` as float64 (ReplayBuffer.add casts the environment's reward), so the reference's
+    # relabel (mansy_ppo.py:47) and the GAE input are float64 there; `rew` is float32 here (the environment's QoE reward is
+    # computed in float32 anyway, qoe.py:22-34) and mansy_gae_returns widens it to float64 inside the scan: one float32
+    # rounding of the relabelled reward, ~6e-8 relative."""
 
     def __init__(self, T, N, device):
         self.T, self.N, self.device = T, N, device

@@ -26,7 +26,7 @@ extern "C" {
 int mansy_set_bn_sync_hook(mansy_bn_sync_fn fn, void* user) { g_bn_hook = fn; g_bn_user = user; return MANSY_OK; }
 
 const char* mansy_last_error(void) { return g_err; }
-int mansy_abi_version(void) { return 3; }   // == _lib.py ABI_VERSION
+int mansy_abi_version(void) { return 4; }   // == _lib.py ABI_VERSION
 
 int mansy_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb, int b_kmajor, float* C, int ldc, int M, int N,
                    int K, const mansy_gemm_epilogue* ep, int force_tile, int force_splitk, void* stream) {
@@ -35,6 +35,9 @@ int mansy_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ld
     e.bias = ep->bias; e.relu = ep->relu; e.mask_src = ep->mask_src; e.mask_ld = ep->mask_ld; e.mask_scale = ep->mask_scale;
     e.drop.p = ep->drop_p; e.drop.seed = ep->drop_seed; e.drop.site = ep->drop_site;
     e.resid = ep->resid; e.resid_ld = ep->resid_ld; e.accumulate = ep->accumulate;
+    e.a_rowsum = ep->a_rowsum; e.prec = ep->prec;
+    MANSY_REQUIRE(!ep->a_rowsum || a_kmajor, "gemm: a_rowsum rides on a K-major A (dW = dY^T X)");
+    MANSY_REQUIRE(ep->prec < 0 || ep->prec == 0 || ep->prec == 3 || ep->prec == 6, "gemm: prec must be < 0, 0, 3 or 6");
   }
   MANSY_REQUIRE(force_tile == 0 || force_tile == 64 || force_tile == 96 || force_tile == 128 || force_tile == -64 || force_tile == -128,
                 "gemm: force_tile must be 0, 64, 96 (128x64), 128, or -64 / -128 (register-staged loop)");
@@ -53,7 +56,7 @@ int mansy_gemm_planes(const float* A, int lda, const float* B, int ldb, int b_km
   if (ep) {
     e.bias = ep->bias; e.relu = ep->relu; e.mask_src = ep->mask_src; e.mask_ld = ep->mask_ld; e.mask_scale = ep->mask_scale;
     e.drop.p = ep->drop_p; e.drop.seed = ep->drop_seed; e.drop.site = ep->drop_site;
-    e.resid = ep->resid; e.resid_ld = ep->resid_ld; e.accumulate = ep->accumulate;
+    e.resid = ep->resid; e.resid_ld = ep->resid_ld; e.accumulate = ep->accumulate; e.prec = ep->prec;
   }
   e.b_planes = planes; e.b_plane_stride = plane_stride; e.b_planes_ld = planes_ld;
   return mansy_launch_gemm_f32(A, lda, 0, B, ldb, b_kmajor, C, ldc, M, N, K, e, force_tile, 0, (hipStream_t)stream);

@@ -164,12 +164,17 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16s_kernel(GemmParams p) {
   for (int i = 0; i < Stg<BM>::ITEMS; ++i) rowsum[i] = 0.f;
 
   float va[Stg<BM>::ITEMS][8], vb[Stg<BN>::ITEMS][8];
-  auto stage_store = [&](int stage) {          // staged registers -> bf16 planes of `stage`
+  // `real`: the staged registers hold a K-tile that has not been staged before.  The branch-free two-stage loop re-stages the
+  // final tile in its last iteration (nobody reads those planes); the bias-gradient rider must count every tile exactly once.
+  auto stage_store = [&](int stage, bool real) {          // staged registers -> bf16 planes of `stage`
     if (do_rowsum) {
 #pragma unroll
-      for (int i = 0; i < Stg<BM>::ITEMS; ++i)
+      for (int i = 0; i < Stg<BM>::ITEMS; ++i) {
+        float t = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) rowsum[i] += va[i][e];
+        for (int e = 0; e < 8; ++e) t += va[i][e];
+        rowsum[i] += real ? t : 0.f;
+      }
     }
     __bf16* const a_pl = planes + stage * STAGE;
     __bf16* const b_pl = a_pl + NP * A_PLANE;
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16s_kernel(GemmParams p) {
     if (nk > 0) {
       stage_load<BM, AKM>(ca, p.lda, offa, va);
       stage_load<BN, BKM>(cb, p.ldb, offb, vb);
-      stage_store(0);
+      stage_store(0, true);
       if (nk > 1) {                                        // (nk == 1: the corners stay on tile 0 -- the loop body's unconditional
         ca += step_a; cb += step_b;                        //  re-load must never leave the operand)
         stage_load<BM, AKM>(ca, p.lda, offa, va);
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16s_kernel(GemmParams p) {
       // MFMAs): the last iterations re-stage / re-load the final tile instead of skipping -- harmless, nobody reads it.
       const int cur = kt & 1;
       mfma_step(cur, 0);
-      stage_store(cur ^ 1);                                // tile kt+1: registers -> the other stage
+      stage_store(cur ^ 1, kt + 1 < nk);                   // tile kt+1: registers -> the other stage
       mfma_step(cur, 1);
       const bool more = kt + 2 < nk;                       // tile kt+2: in flight across the whole next iteration
       ca += more ? step_a : 0; cb += more ? step_b : 0;
@@ -244,7 +249,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16s_kernel(GemmParams p) {
       stage_load<BN, BKM>(cb, p.ldb, offb, vb);
     }
     for (int kt = 0; kt < nk; ++kt) {
-      stage_store(0);
+      stage_store(0, true);
       __syncthreads();
       ca += step_a; cb += step_b;
       if (kt + 1 < nk) {                                   // next tile's global loads fly during the MFMAs
@@ -341,10 +346,12 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16x6_k16_kernel(GemmParams p) {
       for (int kk = 0; kk < 8; ++kk) v[kk] = (corner + (long long)kk * ld)[off];
     }
   };
-  auto stage_store = [&](int stage) {
+  auto stage_store = [&](int stage, bool real) {          // real: see gemm_bf16s_kernel (the last iteration re-stages the final tile)
     if (do_rowsum) {
+      float t = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) rowsum += va[e];
+      for (int e = 0; e < 8; ++e) t += va[e];
+      rowsum += real ? t : 0.f;
     }
     __bf16* const a_pl = planes + stage * STAGE;
     __bf16* const b_pl = a_pl + NP * A_PLANE;
@@ -379,7 +386,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16x6_k16_kernel(GemmParams p) {
   if (nk > 0) {
     load8(AKM, ca, p.lda, offa, va);
     load8(BKM, cb, p.ldb, offb, vb);
-    stage_store(0);
+    stage_store(0, true);
     if (nk > 1) {                                          // (nk == 1: the corners stay on tile 0)
       ca += step_a; cb += step_b;
       load8(AKM, ca, p.lda, offa, va);
@@ -390,7 +397,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16x6_k16_kernel(GemmParams p) {
   for (int kt = 0; kt < nk; ++kt) {                        // branch-free body: the last iterations re-stage / re-load the final tile
     const int cur = kt & 1;
     mfma_step(cur);
-    stage_store(cur ^ 1);
+    stage_store(cur ^ 1, kt + 1 < nk);
     const bool more = kt + 2 < nk;
     ca += more ? step_a : 0; cb += more ? step_b : 0;
     load8(AKM, ca, p.lda, offa, va);

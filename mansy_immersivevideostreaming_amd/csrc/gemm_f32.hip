@@ -285,12 +285,15 @@ __global__ __launch_bounds__(NT) void gemm_f32_dma_kernel(GemmParams p) {
     if (prob) { Ap = p.A2; Bp = p.B2; Cp = p.C2; rowsum_dst = p.a_rowsum2; }
   }
   const int m0 = tile_y * BM, n0 = tile_x * BN;
-  int rs_first = 0, rs_cnt = gridDim.x;             // the column tiles of this row panel that run (they share the row-sum work)
+  // the column tiles of this row panel that run (they share the row-sum work): counted from N, not from gridDim.x -- with a
+  // tile list the grid's x extent is the length of the list, not the number of column tiles of C
+  const int n_col_tiles = (p.N + BN - 1) / BN;
+  int rs_first = 0, rs_cnt = n_col_tiles;
   if (BM == 64 && p.ep.tile_nrange) {
     const int lo = p.ep.tile_nrange[2 * tile_y], hi = p.ep.tile_nrange[2 * tile_y + 1];
     if (n0 >= hi || n0 + BN <= lo) return;
     rs_first = lo / BN;
-    rs_cnt = min((int)gridDim.x, (hi + BN - 1) / BN) - rs_first;
+    rs_cnt = min(n_col_tiles, (hi + BN - 1) / BN) - rs_first;
   }
   int k_begin = split * p.k_per_split;
   int k_end = min(p.K, k_begin + p.k_per_split);

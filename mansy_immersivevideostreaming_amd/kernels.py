@@ -16,9 +16,11 @@ def _gpu(*ts):
 
 
 def gemm(A, B, a_kmajor=False, b_kmajor=False, bias=None, relu=False, mask_src=None, mask_scale=1.0, drop=None,
-         resid=None, out=None, accumulate=False, force_tile=0, force_splitk=0):
+         resid=None, out=None, accumulate=False, force_tile=0, force_splitk=0, a_rowsum=None, prec=None):
     """C = A·B with A logical [M,K] (stored [K,M] if a_kmajor) and B logical [K,N]
-    (stored [N,K] if not b_kmajor -- a torch Linear weight -- or [K,N] if b_kmajor)."""
+    (stored [N,K] if not b_kmajor -- a torch Linear weight -- or [K,N] if b_kmajor).
+    a_rowsum [M] (a_kmajor only): += the row sums of A over K, the bias-gradient rider of the dW products.
+    prec: None = the process-wide mode, else 0 / 3 / 6 for this product."""
     _gpu(A, B)
     A, B = A.contiguous(), B.contiguous()
     M, K = (A.shape[1], A.shape[0]) if a_kmajor else A.shape
@@ -39,6 +41,11 @@ def gemm(A, B, a_kmajor=False, b_kmajor=False, bias=None, relu=False, mask_src=N
     if resid is not None:
         ep.resid, ep.resid_ld = resid.data_ptr(), resid.stride(0)
     ep.accumulate = int(accumulate)
+    if a_rowsum is not None:
+        assert a_kmajor and a_rowsum.numel() == M and a_rowsum.dtype == torch.float32
+        ep.a_rowsum = a_rowsum.data_ptr()
+    if prec is not None:
+        ep.prec = int(prec)
     check(lib().mansy_gemm_f32(ptr(A), A.stride(0), int(a_kmajor), ptr(B), B.stride(0), int(b_kmajor), ptr(out), out.stride(0),
                                M, N, K, ctypes.byref(ep), force_tile, force_splitk, stream_ptr(A.device)), 'mansy_gemm_f32')
     return out

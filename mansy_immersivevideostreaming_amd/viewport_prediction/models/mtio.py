@@ -377,12 +377,17 @@ class ViewportTransformerMTIO(nn.Module):
                 grad_sync.start_tail(self._flat_g[tail_off:])
                 tail_started = True
             self._grad_ready = _ready
-        with _lib.precision(self.precision):
-            check(lib().mansy_vp_train_step(
-                ctypes.byref(cfg), arr, garr, ptr(self._flat_p), ptr(self._flat_g), ptr(optimizer.exp_avg), ptr(optimizer.exp_avg_sq),
-                self._flat_p.numel(), ptr(pe), ptr(rm), ptr(rv), ptr(nbt), ptr(history), ptr(current), ptr(future), ptr(p1), ptr(p2),
-                g['lr'], g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], engine_step, ptr(loss), ptr(ws),
-                self._next_seed(), stream_ptr(history.device)), 'mansy_vp_train_step')
+        try:
+            with _lib.precision(self.precision):
+                check(lib().mansy_vp_train_step(
+                    ctypes.byref(cfg), arr, garr, ptr(self._flat_p), ptr(self._flat_g), ptr(optimizer.exp_avg), ptr(optimizer.exp_avg_sq),
+                    self._flat_p.numel(), ptr(pe), ptr(rm), ptr(rv), ptr(nbt), ptr(history), ptr(current), ptr(future), ptr(p1), ptr(p2),
+                    g['lr'], g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], engine_step, ptr(loss), ptr(ws),
+                    self._next_seed(), stream_ptr(history.device)), 'mansy_vp_train_step')
+        finally:
+            # the closure belongs to THIS call: a later autograd backward on the same model (hook which = 2 fires there too when
+            # bn_sync_world > 1) must not start a tail all-reduce nobody finishes
+            self._grad_ready = None
         if grad_sync is not None:
             if tail_started:
                 grad_sync.finish(self._flat_g[:tail_off])          # head (embedding + encoder) now; then wait for the tail
@@ -422,6 +427,7 @@ class _VPFunction(torch.autograd.Function):
         if not ctx.train:
             raise _lib.MansyError('backward through an eval-mode forward is not supported (BatchNorm eval backward is not on the path)')
         gflat = torch.zeros_like(model._flat_p)
+        model._grad_ready = None            # this backward writes into its own buffer: no overlapped tail all-reduce belongs to it
         model._arm_bn_sync(ctx.cfg)
         arr, garr = model._pointers(gflat)
         ws = model._workspace(ctx.cfg)

