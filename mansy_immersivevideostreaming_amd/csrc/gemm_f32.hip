@@ -499,6 +499,10 @@ int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B,
     GemmEpilogue tail = ep; tail.accumulate = 1;
     const float* A2 = a_kmajor ? A + (long long)Kmain * lda : A + Kmain;
     const float* B2 = b_kmajor ? B + (long long)Kmain * ldb : B + Kmain;
+    if (tail.pair_A) {      // the second problem of a paired launch has the same layout: its leftover rows start at Kmain too
+      tail.pair_A = a_kmajor ? ep.pair_A + (long long)Kmain * lda : ep.pair_A + Kmain;
+      tail.pair_B = b_kmajor ? ep.pair_B + (long long)Kmain * ldb : ep.pair_B + Kmain;
+    }
     return mansy_launch_gemm_f32(A2, lda, a_kmajor, B2, ldb, b_kmajor, C, ldc, M, N, K - Kmain, tail, -64, 1, st);
   }
   if (ep.pair_A) {

@@ -312,6 +312,7 @@ def test_update_teacher_forced_every_minibatch_step(M):
                 assert sorted(len(s['idx']) for s in snaps) == [512, 512, 588, 588]          # merge_last on the ragged buffer
             data = {k: torch.from_numpy(np.ascontiguousarray(inter[k])).cuda() for k in ('adv', 'logp_old', 'v_s', 'returns')}
             worst = 0.0
+            edge_steps = []
             for k, (sn, post) in enumerate(zip(snaps, posts)):
                 steps = set(sn['step'].values())
                 assert len(steps) == 1
@@ -326,6 +327,7 @@ def test_update_teacher_forced_every_minibatch_step(M):
                 torch.cuda.synchronize()
                 np.testing.assert_allclose(stats.cpu().numpy(), rows[k], rtol=1e-5, atol=3e-6, err_msg=f'{(T, N, it, k)}')
                 n_el = n_bad = 0
+                per = {}
                 for name, o, p in zip([t[0] for t in f.table], f.offsets, f.params):
                     got = f.flat_p[o:o + p.numel()].cpu().numpy()
                     want = post[name].numpy().reshape(-1)
@@ -335,9 +337,41 @@ def test_update_teacher_forced_every_minibatch_step(M):
                     assert err.max() <= 2.0 * lr * 1.001, (T, N, it, k, name, float(err.max()))
                     n_el += err.size
                     n_bad += int((err > 0.05 * lr).sum())
+                    if (err > 0.05 * lr).any():
+                        per[name] = (int((err > 0.05 * lr).sum()), float(err.max()))
                     worst = max(worst, float(err.max()))
-                assert n_bad <= 1e-4 * n_el, (T, N, it, k, n_bad, n_el)
+                # The clipped value loss max((R - v)^2, (R - v_clip)^2) has a discontinuous gradient where the two squares meet
+                # (|R - v| = |R - v_clip| outside the clip range) and where v leaves the range (|v - v_old| = eps_clip): a sample
+                # within float32 rounding of either contributes -2 (R - v) / mb or nothing to the critic's gradient, in any two
+                # implementations.  Its distance from the discontinuity is computed here from the oracle's own values; a step
+                # with such a sample may differ on the critic tensors by that one sample's share (seen: 171 weights of
+                # critic.fc.0.weight at 0.06 - 0.26 lr, ragged case, step 1); every other step holds 99.99 %.
+                with torch.no_grad():
+                    full = {key: sn['w'][key.replace('critic.feature_net.', 'actor.feature_net.')] for key in sd
+                            if not key.startswith('_actor_critic.') and not key.startswith('identifier.')}
+                    ii = torch.from_numpy(sn['idx']).long()
+                    v = po.critic_value(full, torch.from_numpy(obs.reshape(n, 780))[ii]).flatten().double()
+                v_old = torch.from_numpy(sn['inter']['v_s'])[ii].double()
+                R = torch.from_numpy(sn['inter']['returns'])[ii].double()
+                v_clip = v_old + (v - v_old).clamp(-0.2, 0.2)
+                outside = (v - v_old).abs() > 0.2
+                margin = ((v - v_old).abs() - 0.2).abs()
+                margin = torch.minimum(margin, torch.where(outside, ((R - v).abs() - (R - v_clip).abs()).abs(), torch.full_like(v, 1e9)))
+                on_edge = bool((margin < 2e-6).any())
+                critic_bad = sum(c for nm, (c, _) in per.items() if nm.startswith('critic.') and '.feature_net.' not in nm)
+                if on_edge:
+                    edge_steps.append((T, N, it, k, float(margin.min())))
+                    assert n_bad - critic_bad <= 1e-4 * n_el and critic_bad <= 2e-3 * n_el, (T, N, it, k, n_bad, critic_bad, n_el, per)
+                else:
+                    if n_bad > 1e-4 * n_el:
+                        o = f.offsets[[t[0] for t in f.table].index('critic.fc.0.weight')]
+                        got = f.flat_p[o:o + 128 * 1280].cpu().numpy().reshape(128, 1280)
+                        e2 = np.abs(got - post['critic.fc.0.weight'].numpy())
+                        print('DIAG margin', float(margin.min()), 'sorted margins', np.sort(margin.numpy())[:5], 'rows', np.unique(np.where(e2 > 0.05 * lr)[0]),
+                              'cols', np.unique(np.where(e2 > 0.05 * lr)[1])[:20], 'stats', stats.cpu().numpy(), rows[k])
+                    assert n_bad <= 1e-4 * n_el, (T, N, it, k, n_bad, n_el)
             assert worst <= 2.0 * lr * 1.001
+            assert len(edge_steps) <= 2, edge_steps            # the exception must stay an exception
 
 
 def test_collect_train_update_cycle(M):

@@ -202,7 +202,7 @@ def test_dropout_statistics_and_determinism(MT):
 
 def test_fused_train_step_equals_unfused(MT):
     """mansy_vp_train_step (one call) == zero_grad/forward/loss/backward/AdamW through the drop-in API."""
-    z = np.load(GOLD[0])
+    z = np.load([p for p in GOLD if 'vp_d64_' in p][0])
     h, c, f = (torch.from_numpy(z[k]).cuda() for k in ('history', 'current', 'future'))
     outs = []
     for fused in (False, True):
