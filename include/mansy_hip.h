@@ -42,6 +42,10 @@ typedef struct mansy_vp_config {
   float ln_eps, bn_eps, bn_momentum;
   int max_len;                 /* rows of the positional table (5000) */
   int bn_sync_world;           /* data-parallel ranks sharing DistillLayer BatchNorm statistics (<= 1: local) */
+  int two_stream;              /* 1: the decoder recurrence runs as two half-batches on two streams (products of one half under the
+                                * attention / LayerNorm passes of the other; needs B >= 256 and even, else ignored).  Same function,
+                                * bit-identical forward.  The host mirror turns it on for sample() (+4 % at B = 4096) and leaves it
+                                * off for training (+1.8 %, and concurrent kernels blur per-kernel timings). */
 } mansy_vp_config;
 
 /* SyncBN hook: with bn_sync_world > 1 the engine calls fn(which, user) after enqueuing the per-channel partial sums
@@ -209,7 +213,13 @@ int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, fl
                              const float* adv_all, const float* logp_old_all, const float* v_old_all, const float* ret_all, int mb,
                              float eps_clip, float vf_coef, float ent_coef, int norm_adv, int value_clip, float max_grad_norm, float lr,
                              float weight_decay, int step, long long tail_from, int tail_step, float* stats, void* workspace,
-                             int max_batch, void* stream);
+                             int max_batch, int chain_in, const int* next_idx, int next_mb, void* stream);
+/* Chaining (the clipped single-process step only: max_grad_norm > 0, step > 0, no lagged tail): the step's last launch -- clip + Adam --
+ * also zeroes the gradient buffer, writes the updated parameters into the packed images the next forward reads and, when next_mb > 0,
+ * gathers the rows next_idx[0..next_mb) of obs_all and takes the statistics of their advantages; the NEXT call on the same workspace /
+ * stream / parameters for exactly that minibatch passes chain_in = 1 and skips its prologue launch (16 steps of PPOPolicy.learn:
+ * 1 + 16 x 9 launches instead of 16 x 10).  chain_in = 0, next_mb = 0: the self-contained step.  After a step with step > 0 flat_g is
+ * all zeros. */
 /* Behaviour cloning on expert demonstrations (behavior_cloning_pretraining, utils/mansy_utils.py:52-93): loss =
  * CrossEntropy(actor logits, act) - ent_coef * mean entropy; Adam(L2) over the first n_update elements of the flat buffers
  * (the critic head -- the tail -- has no gradient here and torch.optim.Adam skips it).  step <= 0: forward + loss only.
@@ -331,6 +341,10 @@ int mansy_attn_bwd_selfpull(const float* Q_all, long long q_ts, const float* K, 
 /* ------------------------------------------------------------------ measurement hooks (bench.py) */
 /* A HIP event pair attached to every GEMM dispatch on its own stream (the kernel's begin / end); collect() = device sync + summed ms, count, FLOPs. */
 int mansy_prof_gemm_enable(int on);
+/* A/B knob of the bf16x3 products with pre-split weights (diagnostic; tools/gemm_bench.py): 1 (default) = A staged in fp32 by LDS-DMA
+ * and split at fragment read (gemm_bf16f_kernel), 0 = the round-2 loop (A register-staged and split before its ds_write); v < 0 only
+ * queries.  Returns the previous value.  Results of the two loops are bit-identical (same products, same order). */
+int mansy_gemm_bf16_variant(int v);
 int mansy_prof_gemm_collect(double* total_ms, long long* launches, double* flops);
 
 #ifdef __cplusplus

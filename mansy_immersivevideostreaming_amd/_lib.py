@@ -15,7 +15,7 @@ class MansyError(RuntimeError):
 
 class VPConfig(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ('B', 'S', 'T', 'd_model', 'n_head', 'd_ff', 'n_enc', 'n_dec', 'in_ch', 'has_bias')] + \
-               [(n, c_float) for n in ('p_pe', 'p_drop', 'ln_eps', 'bn_eps', 'bn_momentum')] + [('max_len', c_int), ('bn_sync_world', c_int)]
+               [(n, c_float) for n in ('p_pe', 'p_drop', 'ln_eps', 'bn_eps', 'bn_momentum')] + [('max_len', c_int), ('bn_sync_world', c_int), ('two_stream', c_int)]
 
 
 BN_SYNC_FN = ctypes.CFUNCTYPE(c_int, c_int, c_void_p)
@@ -107,7 +107,7 @@ _PROTOS = {
     'mansy_identifier_relabel': [P, P, P, P, c_int, c_float, P, c_int, P],
     'mansy_gae_returns': [P, P, P, P, c_int, c_int, ctypes.c_double, ctypes.c_double, c_int, P, P, P, P, P],
     'mansy_ppo_minibatch_step': [P, P, P, P, P, P, c_ll, P, P, P, P, P, P, P, c_int, c_float, c_float, c_float, c_int, c_int, c_float,
-                                 c_float, c_float, c_int, c_ll, c_int, P, P, c_int, P],
+                                 c_float, c_float, c_int, c_ll, c_int, P, P, c_int, c_int, P, c_int, P],
     'mansy_bc_step': [P, P, P, P, P, P, c_ll, c_ll, P, P, c_int, c_float, c_float, c_float, c_int, P, P, c_int, P],
     'mansy_clip_grad_adam': [P, P, P, P, c_ll, c_float, c_float, c_float, c_int, c_ll, c_int, P, P],
     'mansy_a2c_num_params': [],
@@ -120,6 +120,7 @@ _PROTOS = {
     'mansy_clip_grad_rmsprop': [P, P, P, c_ll, c_float, c_float, c_float, c_float, P, P],
     'mansy_set_bn_sync_hook': [P, P],
     'mansy_prof_gemm_enable': [c_int],
+    'mansy_gemm_bf16_variant': [c_int],
     'mansy_prof_gemm_collect': [P, P, P],
 }
 _RESTYPES = {'mansy_last_error': ctypes.c_char_p, 'mansy_vp_workspace_bytes': ctypes.c_size_t,
@@ -127,7 +128,7 @@ _RESTYPES = {'mansy_last_error': ctypes.c_char_p, 'mansy_vp_workspace_bytes': ct
 
 # bumped together with mansy_abi_version() (csrc/capi.hip) whenever a prototype or struct above changes: a stale in-tree
 # libmansy_hip.so then fails at load time instead of being called with a wrong argument list
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 

@@ -213,6 +213,7 @@ class PPOPolicy(nn.Module):
         self._rms = None
         self._seed_ctr = 0
         self.world, self.grad_sync = 1, None
+        self.chain_steps = True       # learn(): each minibatch step's last launch prepares the next one (False: self-contained steps)
 
     def set_data_parallel(self, world, grad_sync):
         """One process per GPU: `grad_sync(flat_grad)` averages a flat gradient buffer over ranks (dist.make_grad_sync)."""
@@ -353,29 +354,32 @@ class PPOPolicy(nn.Module):
         lr, wd = self._hyper(self.optim, 5e-4)
         stats_all = []
         dp = self.grad_sync is not None
-        for _ in range(repeat):
-            chunks = list(split_indices(n, batch_size))
-            # one upload of the whole permutation per pass; the minibatch index arrays are views into it
-            perm = torch.from_numpy(np.concatenate(chunks).astype(np.int32)).to(dev)
-            stats_pass = torch.empty(len(chunks), 4, dtype=torch.float32, device=dev)
+        # every pass's permutation is drawn up front, in the order tianshou draws them (one np.random.permutation per pass, nothing
+        # else consumes the generator in between), so that each step's last launch can prepare the next step's minibatch
+        passes = [list(split_indices(n, batch_size)) for _ in range(repeat)]
+        chain = self.chain_steps and not dp and float(self._grad_norm or 0.0) > 0.0 and f.tail()[0] < 0   # the step form that ends in step_tail
+        perms = [torch.from_numpy(np.concatenate(chunks).astype(np.int32)).to(dev) for chunks in passes]      # one upload per pass
+        flat = []                                                            # (pass, k, idx view) of every minibatch step, in order
+        for pi, chunks in enumerate(passes):
             off = 0
             for k, chunk in enumerate(chunks):
-                idx = perm[off:off + len(chunk)]
+                flat.append((pi, k, perms[pi][off:off + len(chunk)]))
                 off += len(chunk)
-                f.step += 1
-                stats = stats_pass[k]
-                arr, garr = f.pointers(grads=True)
-                check(lib().mansy_ppo_minibatch_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(data['obs']),
-                                                     ptr(idx), ptr(data['act']), ptr(data['adv']), ptr(data['logp_old']), ptr(data['v_s']),
-                                                     ptr(data['returns']), idx.numel(), self._eps_clip, self._weight_vf, self._weight_ent,
-                                                     int(self._norm_adv), int(self._value_clip), 0.0 if dp else float(self._grad_norm or 0.0), lr, wd,
-                                                     0 if dp else f.step, *f.tail(), ptr(stats), ptr(eng.workspace()), eng.max_batch,
-                                                     stream_ptr(dev)),
-                      'mansy_ppo_minibatch_step')
-                if dp:                              # raw local gradients -> RCCL average -> global-norm clip + Adam
-                    self.grad_sync(f.flat_g)
-                    self._clip_adam(f, float(self._grad_norm or 0.0), lr, wd)
-            stats_all.append(stats_pass)
+        stats_all = [torch.empty(len(chunks), 4, dtype=torch.float32, device=dev) for chunks in passes]
+        for s, (pi, k, idx) in enumerate(flat):
+            f.step += 1
+            nxt = flat[s + 1][2] if (chain and s + 1 < len(flat)) else None
+            arr, garr = f.pointers(grads=True)
+            check(lib().mansy_ppo_minibatch_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(data['obs']),
+                                                 ptr(idx), ptr(data['act']), ptr(data['adv']), ptr(data['logp_old']), ptr(data['v_s']),
+                                                 ptr(data['returns']), idx.numel(), self._eps_clip, self._weight_vf, self._weight_ent,
+                                                 int(self._norm_adv), int(self._value_clip), 0.0 if dp else float(self._grad_norm or 0.0), lr, wd,
+                                                 0 if dp else f.step, *f.tail(), ptr(stats_all[pi][k]), ptr(eng.workspace()), eng.max_batch,
+                                                 int(chain and s > 0), ptr(nxt), nxt.numel() if nxt is not None else 0, stream_ptr(dev)),
+                  'mansy_ppo_minibatch_step')
+            if dp:                              # raw local gradients -> RCCL average -> global-norm clip + Adam
+                self.grad_sync(f.flat_g)
+                self._clip_adam(f, float(self._grad_norm or 0.0), lr, wd)
         return LazyLosses(('loss', 'loss/clip', 'loss/vf', 'loss/ent'), stats_all)
 
     def bc_step(self, obs, act, ent_coef=0.1, train=True):

@@ -535,6 +535,137 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16p_kernel(GemmParams p) {
   gemm_epilogue<BM, BN, SMEM_FLOATS>(p, acc, smem, m0, n0, tid, 0, p.C);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16x3, pre-split B, and A split AT FRAGMENT READ (round 3): the fp32 A tile goes HBM/L2 -> LDS by LDS-DMA exactly like the exact-fp32
+// loop's (gemm_f32.hip: [rows][32 floats] image, 128-B rows, XOR swizzle applied on the source address), so the loop has no staging
+// registers, no global_load -> VGPR -> ds_write pass and no cooperative split phase at all; each wave converts the 8 floats of a
+// fragment into its two bf16 planes in registers right before the MFMAs that consume them (v_cvt_pk_bf16_f32 + one subtraction per
+// element, issued in the shadow of the MFMAs).  The conversion is done once per wave that needs the fragment (2 x redundant over the
+// 2 x 2 wave grid) -- the price of removing the ds_write path (~80 B/clk/CU), which is what bounded the in-loop split.  One barrier
+// per K-tile; the DMA of tile t+1 is issued right after the barrier that retires tile t-1 and has the whole MFMA phase to land.
+// LAB (timing-only diagnostics behind mansy_gemm_bf16_variant 2 / 3, results wrong): 1 = staging only (DMA + barriers, no fragment reads,
+// no MFMAs): the LDS-fill floor of a shape; 2 = math only (fragment reads + split + MFMAs on whatever the LDS holds, no DMA): its
+// MFMA + LDS-read floor.
+template <int BM, int BN, int LAB = 0>
+__global__ __launch_bounds__(NT, 2) void gemm_bf16f_kernel(GemmParams p) {
+  constexpr int TM = BM / 64, TN = BN / 64, PA = BM / 32, PB = BN / 16, PBW = (PB + 3) / 4;
+  constexpr int A_BYTES = BM * BK * 4, B_PLANE = BN * 32, B_PLANE_BYTES = B_PLANE * 2;      // B_PLANE in bf16 elements
+  constexpr int STAGE_BYTES = A_BYTES + 2 * B_PLANE_BYTES;
+  constexpr int C_FLOATS = BM * (BN + 4);
+  constexpr int SMEM_FLOATS = (2 * STAGE_BYTES / 4) > C_FLOATS ? (2 * STAGE_BYTES / 4) : C_FLOATS;
+  __shared__ __attribute__((aligned(1024))) float smem[SMEM_FLOATS];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  int tile_x, tile_y;
+  {   // XCD-aware bijective remap (no split-K on this path: forward and dX products only)
+    const int nwg = gridDim.x * gridDim.y, orig = blockIdx.y * gridDim.x + blockIdx.x;
+    const int q = nwg >> 3, rem = nwg & 7, xcd = orig & 7, local = orig >> 3;
+    const int t = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + local;
+    tile_y = t / gridDim.x; tile_x = t - tile_y * gridDim.x;
+  }
+  const int m0 = tile_y * BM, n0 = tile_x * BN;
+  const int nk = p.K / BK;
+
+  // A: fp32 image [BM][32], piece i of this wave = rows i*32 + wave*8 .. +8 (128 B each); k-chunk c of a row sits in slot c ^ ((row >> 1) & 7)
+  unsigned voa[PA];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int row = i * 32 + wave * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    voa[i] = (unsigned)((min(m0 + row, p.M - 1) - m0) * p.lda + c * 4) * 4u;
+  }
+  // B planes: image [BN][32 bf16] per plane (64-B rows), piece = 16 rows; 16-byte chunk q of a row in slot q ^ ((row >> 2) & 3)
+  unsigned vob[PBW];
+#pragma unroll
+  for (int i = 0; i < PBW; ++i) {
+    const int row = (wave + 4 * i) * 16 + (lane >> 2), slot = lane & 3;
+    const int q = slot ^ ((row >> 2) & 3);
+    vob[i] = (unsigned)(((min(n0 + row, p.N - 1) - n0) * p.ep.b_planes_ld + q * 8) * 2);
+  }
+  const float* ca = p.A + (long long)m0 * p.lda;
+  const unsigned short* cb = p.ep.b_planes + (long long)n0 * p.ep.b_planes_ld;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem + (unsigned)wave * 1024u);
+  auto dma = [&](int stage, const float* a_corner, const unsigned short* b_corner) {
+    const unsigned base = lds0 + (unsigned)(stage * STAGE_BYTES);
+#pragma unroll
+    for (int i = 0; i < PA; ++i) glds16(voa[i], a_corner, base + (unsigned)i * 4096u);
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+      for (int i = 0; i < PBW; ++i)
+        if (PB % 4 == 0 || wave + 4 * i < PB)
+          glds16(vob[i], b_corner + (long long)pl * p.ep.b_plane_stride, base + (unsigned)(A_BYTES + pl * B_PLANE_BYTES) + (unsigned)i * 4096u);
+  };
+  // fragment addresses: A in floats inside the A image (two 16-byte slots per k-step), B in bf16 elements inside a plane
+  int fa[TM][2][2], fb[TN][2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row = wm * (BM / 2) + i * 32 + r, sw = (row >> 1) & 7, c0 = 4 * s + 2 * h;
+      fa[i][s][0] = row * BK + ((c0 + 0) ^ sw) * 4;
+      fa[i][s][1] = row * BK + ((c0 + 1) ^ sw) * 4;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[j][s] = lds_off<false>(wn * (BN / 2) + j * 32 + r, 2 * s + h);
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (nk > 0 && LAB != 2) dma(0, ca, cb);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of tile kt have landed ...
+    __builtin_amdgcn_s_barrier();                        // ... and everyone's; everyone is done reading tile kt-1
+    asm volatile("" ::: "memory");
+    ca += BK; cb += BK;
+    if (kt + 1 < nk && LAB != 2) dma(cur ^ 1, ca, cb);
+    const float* a_l = smem + cur * (STAGE_BYTES / 4);
+    const __bf16* b_l = reinterpret_cast<const __bf16*>(a_l) + A_BYTES / 2;
+#pragma unroll
+    for (int s = 0; s < (LAB == 1 ? 0 : 2); ++s) {
+      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = *reinterpret_cast<const bf16x8*>(b_l + fb[j][s]);
+        bl[j] = *reinterpret_cast<const bf16x8*>(b_l + B_PLANE + fb[j][s]);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const float4 v0 = *reinterpret_cast<const float4*>(a_l + fa[i][s][0]);
+        const float4 v1 = *reinterpret_cast<const float4*>(a_l + fa[i][s][1]);
+        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const __bf16 t0 = (__bf16)v[e];
+          ah[i][e] = t0;
+          al[i][e] = (__bf16)(v[e] - (float)t0);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // LDS reads retired before the barrier that frees this buffer
+  }
+  __syncthreads();                                        // staging LDS idle: the epilogue reuses it
+  gemm_epilogue<BM, BN, SMEM_FLOATS>(p, acc, smem, m0, n0, tid, 0, p.C);
+}
+
 // ---- weights -> bf16 planes (and planes of the transpose), 32 x 32 tiles through LDS
 __global__ __launch_bounds__(256) void weight_planes_kernel(MansyWPlaneTab tab, unsigned short* __restrict__ out, unsigned short* __restrict__ out_t,
                                                            long long plane_stride, int n_planes) {
@@ -609,7 +740,29 @@ int mansy_gemm_bf16s_dispatch(const GemmParams& p, int tile, int prec, int a_kma
 }
 
 // B pre-split into planes (weights): forward / dX products with a K-contiguous A
+static int g_bf16_variant = 1;      // 1: A by LDS-DMA, split at fragment read (gemm_bf16f_kernel); 0: the round-2 loop (A/B tests)
+extern "C" int mansy_gemm_bf16_variant(int v) { const int old = g_bf16_variant; if (v >= 0) g_bf16_variant = v; return old; }
+
 int mansy_gemm_bf16p_dispatch(const GemmParams& p, int tile, int prec, hipStream_t st) {
+  if (prec == 3 && g_bf16_variant >= 1 && (reinterpret_cast<uintptr_t>(p.A) & 15) == 0 && p.lda % 4 == 0) {
+    dim3 block(NT);
+    if (g_bf16_variant >= 2) {      // timing-only diagnostics (results wrong): the LDS-fill floor / the math floor of the shape
+      const int lab = g_bf16_variant - 1;
+      if (tile == 128) { dim3 grid(mansy_ceil_div(p.N, 128), mansy_ceil_div(p.M, 128), 1);
+        if (lab == 1) MANSY_GEMM_LAUNCH((gemm_bf16f_kernel<128, 128, 1>), grid, block, st, p); else MANSY_GEMM_LAUNCH((gemm_bf16f_kernel<128, 128, 2>), grid, block, st, p); }
+      else { dim3 grid(mansy_ceil_div(p.N, 64), mansy_ceil_div(p.M, 64), 1);
+        if (lab == 1) MANSY_GEMM_LAUNCH((gemm_bf16f_kernel<64, 64, 1>), grid, block, st, p); else MANSY_GEMM_LAUNCH((gemm_bf16f_kernel<64, 64, 2>), grid, block, st, p); }
+      MANSY_LAUNCH_CHECK();
+      return MANSY_OK;
+    }
+    // measured per shape (tools/gemm_bench.py --planes, profiles/r03_gemm_bench_bf16f.txt): 128 x 128 tiles 3-9 % faster than the
+    // round-2 loop on the [40 960-row] products; 64 x 64 tiles ([4 096-row] decoder products) 6 % slower (one K-tile of a 64 x 64
+    // tile is 6 MFMAs per wave: the second, redundant fragment conversion is no longer hidden), so those keep the round-2 loop;
+    // the 128 x 64 instance loses to both at every shape and is reachable only as force_tile 96
+    if (tile == 128) { dim3 grid(mansy_ceil_div(p.N, 128), mansy_ceil_div(p.M, 128), 1); MANSY_GEMM_LAUNCH((gemm_bf16f_kernel<128, 128>), grid, block, st, p); MANSY_LAUNCH_CHECK(); return MANSY_OK; }
+    if (tile == 96) { dim3 grid(mansy_ceil_div(p.N, 64), mansy_ceil_div(p.M, 128), 1); MANSY_GEMM_LAUNCH((gemm_bf16f_kernel<128, 64>), grid, block, st, p); MANSY_LAUNCH_CHECK(); return MANSY_OK; }
+  }
+  if (tile == 96) tile = 64;
   const int BMN = tile == 128 ? 128 : 64;
   dim3 grid(mansy_ceil_div(p.N, BMN), mansy_ceil_div(p.M, BMN), 1), block(NT);
   if (prec == 3) {

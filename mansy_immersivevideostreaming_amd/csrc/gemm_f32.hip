@@ -523,7 +523,8 @@ int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B,
   int tile;
   if (force_tile) {
     tile = force_tile < 0 ? -force_tile : force_tile;
-    if ((!dma || bf) && tile == 96) tile = 64;
+    const bool bf_planes = bf == 3 && ep.b_planes && !a_kmajor;      // the fragment-split loop has a 128x64 instance
+    if ((!dma || (bf && !bf_planes)) && tile == 96) tile = 64;
   } else if (bf) {
     // split-bf16 loop: 128x128 (least operand traffic and split work per MFMA) once it fills the chip, else 64x64
     tile = (can_split || tile_count(M, N, 128) >= 256) ? 128 : 64;

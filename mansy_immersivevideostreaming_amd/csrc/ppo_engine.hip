@@ -131,28 +131,28 @@ struct PackArgs {
 // (GemmEpilogue::tile_krange).  Only the K windows are written (branch weights, zeros around them up to the 32-wide K-tile
 // borders): the product runs on the 64-column LDS-DMA / split-bf16 loops, which never read a row outside its window (featnet()
 // insists on that path), so 131 k of the image's 983 k floats are touched per pack.  n_win = HID * window_cols().
+// one 256-thread workgroup: mean / unbiased std of the minibatch's advantages (two-pass, like torch: mean, then variance)
+__device__ __forceinline__ void adv_stats_block(const float* __restrict__ adv, const int* __restrict__ idx, int n, float* __restrict__ out) {
+  __shared__ float sh_adv[8];
+  float s1 = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s1 += adv[idx ? idx[i] : i];
+  s1 = wave_sum(s1);
+  if ((threadIdx.x & 63) == 0) sh_adv[threadIdx.x >> 6] = s1;
+  __syncthreads();
+  const float mean = (sh_adv[0] + sh_adv[1] + sh_adv[2] + sh_adv[3]) / (float)n;
+  float q = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) { const float d = adv[idx ? idx[i] : i] - mean; q += d * d; }
+  q = wave_sum(q);
+  if ((threadIdx.x & 63) == 0) sh_adv[4 + (threadIdx.x >> 6)] = q;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[0] = mean;
+    out[1] = sqrtf((sh_adv[4] + sh_adv[5] + sh_adv[6] + sh_adv[7]) / (float)(n > 1 ? n - 1 : 1));
+  }
+}
 __global__ __launch_bounds__(256) void pack_wbd_kernel(PackArgs a, int identifier, int K, long long n_win, float* __restrict__ Wbd,
                                                        float* __restrict__ bbd, int* __restrict__ krange, int* __restrict__ tlist) {
-  if (a.adv && blockIdx.x == gridDim.x - 1) {        // advantage statistics (two-pass, like torch: mean, then unbiased variance)
-    __shared__ float sh_adv[8];
-    const int n = a.adv_n;
-    float s1 = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) s1 += a.adv[a.g_idx ? a.g_idx[i] : i];
-    s1 = wave_sum(s1);
-    if ((threadIdx.x & 63) == 0) sh_adv[threadIdx.x >> 6] = s1;
-    __syncthreads();
-    const float mean = (sh_adv[0] + sh_adv[1] + sh_adv[2] + sh_adv[3]) / (float)n;
-    float q = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) { const float d = a.adv[a.g_idx ? a.g_idx[i] : i] - mean; q += d * d; }
-    q = wave_sum(q);
-    if ((threadIdx.x & 63) == 0) sh_adv[4 + (threadIdx.x >> 6)] = q;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      a.adv_stats[0] = mean;
-      a.adv_stats[1] = sqrtf((sh_adv[4] + sh_adv[5] + sh_adv[6] + sh_adv[7]) / (float)(n > 1 ? n - 1 : 1));
-    }
-    return;
-  }
+  if (a.adv && blockIdx.x == gridDim.x - 1) { adv_stats_block(a.adv, a.g_idx, a.adv_n, a.adv_stats); return; }
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx < a.z2n) a.z2[idx] = 0.f;
   if (idx < a.z3n) a.z3[idx] = 0.f;
@@ -653,6 +653,61 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, c
   p[i] = pp - (lr / bc1) * (mm / denom);
   m[i] = mm; v[i] = vv;
 }
+// Last launch of a PPO minibatch step and, at the same time, the prologue of the NEXT one (round 3: one launch fewer per step).
+//  * clip + Adam(L2) exactly as clip_adam_kernel, then the thread ZEROES its gradient element (the next step accumulates into it) and
+//    SCATTERS the parameter it has just written into the packed images the next forward reads: branch weights into the
+//    block-diagonal Wbd [FEAT, KP] (the zero columns around a branch inside its K window never change), branch biases into bbd, the
+//    two fc weights into the stacked [2 HID, FEAT] operand -- what pack_wbd_kernel rebuilt from scratch before every step;
+//  * rider workgroups at the end of the grid do the data-dependent part of that prologue for the next minibatch, when the caller
+//    names it: gather its observation rows, mean / unbiased std of its advantages, zero the packed bias-gradient accumulator and
+//    the OTHER set of gradient-norm slots (the sets alternate with the Adam step count, so this launch can still read its own).
+struct TailTab { long long off[28]; int numel[28]; };       // flat offsets / sizes of the 28 unique actor-critic tensors, table order
+struct TailNext { const float* g_src; const int* g_idx; float* g_dst; int g_rows; const float* adv; float* adv_stats; float* dbbd; double* parts_next; };
+__global__ __launch_bounds__(256) void step_tail_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                       long long n, float lr, float b1, float b2, float eps, float wd, float bc1, float sqrt_bc2,
+                                                       const double* __restrict__ parts, float max_norm, TailTab tab, float* __restrict__ Wbd,
+                                                       float* __restrict__ bbd, float* __restrict__ Wfc2, TailNext nx, int adam_blocks) {
+  if ((int)blockIdx.x >= adam_blocks) {
+    const int rb = blockIdx.x - adam_blocks;
+    if (rb == 0) {
+      for (int i = threadIdx.x; i < FEAT; i += 256) nx.dbbd[i] = 0.f;
+      if (threadIdx.x < NORM_PARTS_C) nx.parts_next[threadIdx.x] = 0.0;
+      if (nx.adv && nx.g_rows >= 1) adv_stats_block(nx.adv, nx.g_idx, nx.g_rows, nx.adv_stats);
+      return;
+    }
+    const long long i2 = (long long)(rb - 1) * 256 + threadIdx.x;
+    if (nx.g_src && i2 < (long long)nx.g_rows * (OBS_LD / 4)) {
+      const int r = (int)(i2 / (OBS_LD / 4)), c4 = (int)(i2 % (OBS_LD / 4));
+      reinterpret_cast<float4*>(nx.g_dst)[(size_t)r * (OBS_LD / 4) + c4] = reinterpret_cast<const float4*>(nx.g_src)[(size_t)nx.g_idx[r] * (OBS_LD / 4) + c4];
+    }
+    return;
+  }
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float coef = clip_coef(parts, max_norm);
+  const float pp = p[i];
+  const float grad = g[i] * coef + wd * pp;
+  const float mm = m[i] + (grad - m[i]) * (1.f - b1);
+  const float vv = v[i] * b2 + (1.f - b2) * grad * grad;
+  const float denom = sqrtf(vv) / sqrt_bc2 + eps;
+  const float pn = pp - (lr / bc1) * (mm / denom);
+  p[i] = pn; m[i] = mm; v[i] = vv;
+  g[i] = 0.f;
+  // which tensor? (offsets ascending; the 256-byte alignment gaps between tensors belong to none)
+  int lo = 0, hi = 27;
+#pragma unroll
+  for (int it = 0; it < 5; ++it) { const int mid = (lo + hi + 1) >> 1; if (tab.off[mid] <= i) lo = mid; else hi = mid - 1; }
+  const long long e = i - tab.off[lo];
+  if (e >= tab.numel[lo]) return;
+  if (lo < 2 * NB) {
+    const int j = lo >> 1;
+    if (lo & 1) { bbd[j * HID + (int)e] = pn; return; }
+    const Branch gm = branch_geom(j, 0);
+    const int r = (int)e / gm.len, c = (int)e % gm.len;
+    Wbd[(long long)(j * HID + r) * KP + gm.off + c] = pn;
+  } else if (lo == 2 * NB) Wfc2[e] = pn;
+  else if (lo == 2 * NB + 4) Wfc2[(long long)HID * FEAT + e] = pn;
+}
 __global__ __launch_bounds__(256) void logp_kernel(const float* __restrict__ logits, const int* __restrict__ act, int B, float* __restrict__ logp) {
   const int r = blockIdx.x * 256 + threadIdx.x;
   if (r >= B) return;
@@ -700,7 +755,8 @@ size_t ppo_layout(int maxB, char* base, PWork& W) {
   W.gout = f((size_t)maxB * MAXOUT); W.gout_c = f((size_t)maxB * MAXOUT);
   W.A1s = f((size_t)head_slab_rows(maxB) * 2 * HID);
   W.Wfc2 = f((size_t)2 * HID * FEAT); W.dA1p = f((size_t)maxB * 2 * HID);
-  W.acc = (double*)f(2 * 64);      // NORM_PARTS doubles (gradient-norm partial sums; also the identifier-loss accumulator)
+  W.acc = (double*)f(4 * 64);      // 2 x NORM_PARTS doubles (gradient-norm partial sums, the sets alternate with the Adam step count in a
+                                   // chained PPO update; set 0 is also the identifier-loss accumulator)
   W.adv_stats = f(8); W.lossrows = f((size_t)maxB * 4);
   return tot + 256;
 }
@@ -717,7 +773,7 @@ struct PEng {
     a.fc_a = n.fc_w; a.fc_c = pair ? pair->fc_w : nullptr; a.Wfc2 = pair ? W.Wfc2 : nullptr;
     a.g_src = g_src; a.g_idx = g_idx; a.g_dst = W.obs_mb; a.g_rows = g_src ? g_rows : 0;
     a.zero_ptr = zero_ptr; a.zero_n = zero_ptr ? zero_n : 0;
-    a.z2 = W.dbbd; a.z2n = FEAT; a.z3 = reinterpret_cast<float*>(W.acc); a.z3n = 2 * NORM_PARTS_C;
+    a.z2 = W.dbbd; a.z2n = FEAT; a.z3 = reinterpret_cast<float*>(W.acc); a.z3n = 4 * NORM_PARTS_C;
     MANSY_REQUIRE(!zero_ptr || (reinterpret_cast<uintptr_t>(zero_ptr) & 15) == 0, "pack: gradient buffer must be 16-byte aligned");
     const int K = identifier ? K_IDENT : K_POLICY;
     const long long n_win = (long long)HID * window_cols(identifier);
@@ -733,7 +789,7 @@ struct PEng {
     pa.g_src = g_src; pa.g_idx = idx; pa.g_dst = W.obs_mb; pa.g_rows = g_src ? mb : 0;
     pa.zero_ptr = zero_ptr; pa.zero_n = zero_ptr ? zero_n : 0;
     pa.adv = adv; pa.adv_n = mb; pa.adv_stats = W.adv_stats;
-    pa.z2 = W.dbbd; pa.z2n = FEAT; pa.z3 = reinterpret_cast<float*>(W.acc); pa.z3n = 2 * NORM_PARTS_C;
+    pa.z2 = W.dbbd; pa.z2n = FEAT; pa.z3 = reinterpret_cast<float*>(W.acc); pa.z3n = 4 * NORM_PARTS_C;
     MANSY_REQUIRE(!zero_ptr || (reinterpret_cast<uintptr_t>(zero_ptr) & 15) == 0, "pack: gradient buffer must be 16-byte aligned");
     const long long n_win = (long long)HID * window_cols(0);
     const long long threads = n_win + 2LL * HID * FEAT + (long long)pa.g_rows * (OBS_LD / 4) + (pa.zero_n + 3) / 4;
@@ -830,7 +886,7 @@ struct PEng {
   }
   // norm_tail != nullptr: also leave the squared norm of ALL gradients (branches + [norm_tail, norm_tail + norm_tail_n)) in W.acc
   int featnet_bwd(const NetP& n, const float* obs, int B, int identifier, const float* dHa, const float* dHb, const float* norm_tail = nullptr,
-                  long long norm_tail_n = 0) {
+                  long long norm_tail_n = 0, double* norm_parts = nullptr) {
     const int K = identifier ? K_IDENT : K_POLICY;
     (void)dHa; (void)dHb;      // joined inside the dF product's epilogue (head_bwd / head_bwd_pair); dbbd and the norm slots were zeroed by pack
     // dWbd = dPre^T obs, wanted on the block diagonal only: the launch runs the 42 of 240 output tiles that meet a branch's window
@@ -857,11 +913,32 @@ struct PEng {
                                -64, 1, st));
     }
     UnpackArgs u; for (int j = 0; j < NB; ++j) { u.gbw[j] = n.gbw[j]; u.gbb[j] = n.gbb[j]; }
-    NormRider nr; nr.parts = norm_tail ? W.acc : nullptr; nr.tail_g = norm_tail; nr.tail_n = norm_tail_n;
+    NormRider nr; nr.parts = norm_tail ? (norm_parts ? norm_parts : W.acc) : nullptr; nr.tail_g = norm_tail; nr.tail_n = norm_tail_n;
     const long long main_blocks = mansy_ceil_div((long long)HID * compact_cols(identifier), 256);
     const long long tail_blocks = norm_tail ? mansy_ceil_div(mansy_ceil_div(norm_tail_n, 4), 256) : 0;
     MANSY_REQUIRE(!norm_tail || (reinterpret_cast<uintptr_t>(norm_tail) & 15) == 0, "featnet_bwd: gradient tail must be 16-byte aligned");
     hipLaunchKernelGGL(unpack_dwbd_kernel, dim3(main_blocks + tail_blocks), dim3(256), 0, st, W.dWbd, nsplit, slab, W.dbbd, identifier, K, u, nr);
+    MANSY_LAUNCH_CHECK();
+    return MANSY_OK;
+  }
+  // clip + Adam + gradient zero-fill + re-pack of the updated parameters + (next != null) the next minibatch's gather / statistics
+  int step_tail(const float* const* params, float* flat_p, float* flat_g, float* m, float* v, long long n, float max_norm, float lr, float wd, int step,
+                double* parts_cur, double* parts_next, const float* obs_all, const int* next_idx, int next_mb, const float* adv_all) {
+    TailTab tab;
+    const std::vector<ParamInfo> t = net_table(0);
+    MANSY_REQUIRE(t.size() == 28, "step_tail: parameter table changed");
+    for (int k = 0; k < 28; ++k) {
+      tab.off[k] = params[k] - flat_p; tab.numel[k] = (int)t[k].numel;
+      MANSY_REQUIRE(tab.off[k] >= 0 && tab.off[k] + tab.numel[k] <= n && (k == 0 || tab.off[k] >= tab.off[k - 1] + tab.numel[k - 1]),
+                    "step_tail: params[] must be ascending views of flat_p");
+    }
+    TailNext nx; nx.g_src = next_idx ? obs_all : nullptr; nx.g_idx = next_idx; nx.g_dst = W.obs_mb; nx.g_rows = next_mb;
+    nx.adv = next_mb > 0 ? adv_all : nullptr; nx.adv_stats = W.adv_stats; nx.dbbd = W.dbbd; nx.parts_next = parts_next;
+    const int adam_blocks = (int)mansy_ceil_div(n, 256);
+    const int rider_blocks = 1 + (next_idx ? (int)mansy_ceil_div((long long)next_mb * (OBS_LD / 4), 256) : 0);
+    const double bc1 = 1.0 - pow(0.9, (double)step), bc2 = 1.0 - pow(0.999, (double)step);
+    hipLaunchKernelGGL(step_tail_kernel, dim3(adam_blocks + rider_blocks), dim3(256), 0, st, flat_p, flat_g, m, v, n, lr, 0.9f, 0.999f, 1e-8f, wd,
+                       (float)bc1, (float)sqrt(bc2), parts_cur, max_norm, tab, W.Wbd, W.bbd, W.Wfc2, nx, adam_blocks);
     MANSY_LAUNCH_CHECK();
     return MANSY_OK;
   }
@@ -1045,7 +1122,8 @@ int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, fl
                              long long n_flat, const float* obs_all, const int* idx, const int* act_all, const float* adv_all,
                              const float* logp_old_all, const float* v_old_all, const float* ret_all, int mb, float eps_clip, float vf_coef,
                              float ent_coef, int norm_adv, int value_clip, float max_grad_norm, float lr, float weight_decay, int step,
-                             long long tail_from, int tail_step, float* stats, void* workspace, int max_batch, void* stream) {
+                             long long tail_from, int tail_step, float* stats, void* workspace, int max_batch, int chain_in,
+                             const int* next_idx, int next_mb, void* stream) {
   MANSY_REQUIRE(params && grads && flat_p && flat_g && flat_m && flat_v && obs_all && act_all && adv_all && logp_old_all && v_old_all && ret_all,
                 "ppo_minibatch_step: null pointer");
   MANSY_REQUIRE(mb >= 2 && mb <= max_batch, "ppo_minibatch_step: bad minibatch size");
@@ -1055,7 +1133,15 @@ int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, fl
   const float* obs = idx ? e.W.obs_mb : obs_all;
   // loss fused into the output-layer launches: advantage statistics ride on the prologue, per-row terms come out of head_out,
   // their sums out of head_out_bwd (13 -> 12 launches per minibatch step)
-  RC(e.pack_mb(a, c, idx ? obs_all : nullptr, idx, mb, flat_g, n_flat, adv_all));
+  // chain_in: the previous call (same workspace, stream, parameters) already did all of that for exactly this minibatch in its
+  // last launch (step_tail) -- 16 minibatch steps of an update are then 1 + 16 x 9 launches instead of 16 x 10
+  MANSY_REQUIRE(next_mb >= 0 && next_mb <= max_batch && (next_mb == 0 || !idx == !next_idx), "ppo_minibatch_step: bad next minibatch");
+  const bool lagged = tail_from >= 0 && tail_from < n_flat && tail_step != step;
+  const bool chain_ok = max_grad_norm > 0.f && step > 0 && !lagged;       // the step that ends in step_tail
+  MANSY_REQUIRE(!(chain_in || next_mb > 0) || chain_ok, "ppo_minibatch_step: chaining needs the clipped single-process step (no lagged tail)");
+  double* const parts_cur = e.W.acc + (chain_ok && (step & 1) ? NORM_PARTS_C : 0);
+  double* const parts_next = e.W.acc + (chain_ok && (step & 1) ? 0 : NORM_PARTS_C);
+  if (!chain_in) RC(e.pack_mb(a, c, idx ? obs_all : nullptr, idx, mb, flat_g, n_flat, adv_all));
   RC(e.featnet(obs, mb, 0));
   LossFuse lf;
   lf.on = 1; lf.act = act_all; lf.adv = adv_all; lf.logp_old = logp_old_all; lf.v_old = v_old_all; lf.ret = ret_all; lf.idx = idx; lf.n = mb;
@@ -1075,7 +1161,10 @@ int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, fl
   // update -- 64..256 resident workgroups, two returning atomics per workgroup, gradients kept in registers across the barrier.
   // 22-32 us per launch against 12 us for the two launches it replaced: a kernel boundary is cheaper than a device-scope
   // rendezvous on this chip, as tools/chain_lab.hip found for the GEMM chain.)
-  RC(e.featnet_bwd(a, obs, mb, 0, e.W.dHa, e.W.dHc, ride ? tail : nullptr, ride ? tail_n : 0));
+  RC(e.featnet_bwd(a, obs, mb, 0, e.W.dHa, e.W.dHc, ride ? tail : nullptr, ride ? tail_n : 0, parts_cur));
+  if (chain_ok)
+    return e.step_tail(params, flat_p, flat_g, flat_m, flat_v, n_flat, max_grad_norm, lr, weight_decay, step, parts_cur, parts_next, obs_all,
+                       next_idx, next_mb, adv_all);
   return e.clip_and_adam(flat_p, flat_g, flat_m, flat_v, n_flat, max_grad_norm, lr, weight_decay, step, tail_from, tail_step, ride);
 }
 

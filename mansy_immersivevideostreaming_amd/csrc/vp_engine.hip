@@ -200,14 +200,16 @@ void build_layout(const mansy_vp_config& c, Layout& L, Work& W) {
   W.lnp_dec = L.f("lnp.dec", (size_t)2 * (3 * c.n_dec + 1) * mansy_ln_bwd_parts((int)B) * 2 * d);
   W.lnp_enc = L.f("lnp.enc", (size_t)mansy_ln_bwd_parts((int)N) * 2 * d);
   W.loss_acc = (double*)L.add("loss_acc", 64);
-  // split-bf16 modes: 3 planes x (W, W^T) of every GEMM weight, 2 bytes each (110 MB at d = 512; filled once per step)
+  // bf16x3 mode: 2 planes x (W, W^T) of every GEMM weight, 2 bytes each (73 MB at d = 512, 1 % of the B = 4096 workspace; filled
+  // once per step).  Only bf16x3 pre-splits its weights (prepare_planes), so the third plane round 2 reserved is gone; the region
+  // stays part of the one workspace in every mode so that a model may change its precision between calls without re-sizing it.
   size_t wtot = 0;
   for (const ParamInfo& pi : param_table(c))
     if (pi.ndim >= 2 && pi.shape[0] * (pi.numel / pi.shape[0]) == pi.numel && pi.numel / pi.shape[0] >= 32 && pi.shape[0] >= 32)
       wtot += ((size_t)pi.numel + 63) / 64 * 64;
   W.wpl_stride = (long long)wtot;
-  W.wpl = (unsigned short*)L.add("wplanes", wtot * 3 * sizeof(unsigned short));
-  W.wpl_t = (unsigned short*)L.add("wplanes_t", wtot * 3 * sizeof(unsigned short));
+  W.wpl = (unsigned short*)L.add("wplanes", wtot * 2 * sizeof(unsigned short));
+  W.wpl_t = (unsigned short*)L.add("wplanes_t", wtot * 2 * sizeof(unsigned short));
 }
 
 int check_cfg(const mansy_vp_config* c) {
@@ -265,7 +267,7 @@ struct Eng {
     long long tot = 0;
     for (int t = 0; t < wtab.n; ++t) tot += ((long long)wtab.N[t] * wtab.K[t] + 63) / 64 * 64;
     if (tot > W.wpl_stride) { wtab.n = 0; return MANSY_OK; }       // (cannot happen: same table as build_layout) -> in-loop split
-    return mansy_launch_weight_planes(wtab, W.wpl, W.wpl_t, W.wpl_stride, prec == 3 ? 2 : 3, st);
+    return mansy_launch_weight_planes(wtab, W.wpl, W.wpl_t, W.wpl_stride, 2, st);
   }
   // planes of the sub-matrix starting at `w` (rows r0.. of a listed weight) for the forward (transposed = false: B = W [Nout, K]) or
   // the dX product (transposed = true: B = W^T [K, Nout_total], columns r0..)
@@ -392,13 +394,11 @@ struct Eng {
 
   // ---- two-stream plumbing (the second stream and its events are created once per process)
   hipStream_t st2 = nullptr;
-  // Opt-in (MANSY_VP_SPLIT=1, read at every call).  Measured at B = 4096: train step 23.08 -> 22.67 ms (+1.8 %), sample() 507 -> 529 k
-  // trajectories/s (+4 %), identical losses.  Off by default: the gain is small, and concurrent kernels stretch each other's
-  // durations, so per-kernel timings (bench.py's roofline leg, rocprof kernel stats) stop describing the kernels themselves.
-  bool split_ok() {
-    const char* e = getenv("MANSY_VP_SPLIT");
-    return e && atoi(e) == 1 && B >= 256 && B % 2 == 0;
-  }
+  // mansy_vp_config::two_stream.  Measured at B = 4096: train step 23.08 -> 22.67 ms (+1.8 %), sample() 507 -> 529 k trajectories/s
+  // (+4 %), identical losses.  The host mirror sets it for sample() and not for training: the gain there is small, and concurrent
+  // kernels stretch each other's durations, so per-kernel timings (bench.py's roofline leg, rocprof kernel stats) stop describing
+  // the kernels themselves.
+  bool split_ok() const { return c.two_stream == 1 && B >= 256 && B % 2 == 0; }
   int fork() {
     static hipStream_t s2 = nullptr; static hipEvent_t ev_f = nullptr;
     if (!s2) { MANSY_HIP_CHECK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking)); MANSY_HIP_CHECK(hipEventCreateWithFlags(&ev_f, hipEventDisableTiming)); }

@@ -99,15 +99,18 @@ class ViewportTransformerMTIO(nn.Module):
         self.bn_sync_world = 1
         self._bn_allreduce = None
         self._grad_ready = None
+        self.two_stream = None
         self._build_parameters()
         self._flatten()
 
     # ------------------------------------------------------------------ construction
-    def _cfg(self, B, S):
+    def _cfg(self, B, S, inference=False):
+        # two_stream: None = the measured default (on for sample(), off for training); True / False force it
+        two = inference if self.two_stream is None else bool(self.two_stream)
         return VPConfig(B=B, S=S, T=self.fut_window, d_model=self.d_model, n_head=_N_HEAD, d_ff=self.dim_feedforward,
                         n_enc=self.num_encoder_layers, n_dec=self.num_decoder_layers, in_ch=self.in_channel * self.num_head,
                         has_bias=int(self.has_bias), p_pe=self.dropout_p, p_drop=self.attn_dropout_p, ln_eps=1e-5, bn_eps=1e-5,
-                        bn_momentum=0.1, max_len=_PE_MAX_LEN, bn_sync_world=int(self.bn_sync_world))
+                        bn_momentum=0.1, max_len=_PE_MAX_LEN, bn_sync_world=int(self.bn_sync_world), two_stream=int(two))
 
     def set_data_parallel(self, world, allreduce=None):
         """SyncBN for the DistillLayer under data parallelism: `world` ranks share batch statistics; `allreduce(t)` sums a
@@ -333,7 +336,7 @@ class ViewportTransformerMTIO(nn.Module):
         self._require_gpu(history)
         history, current = history.contiguous().float(), current.contiguous().float()
         B, S, _ = history.shape
-        cfg = self._cfg(B, S)
+        cfg = self._cfg(B, S, inference=True)
         ws = self._workspace(cfg)
         arr, _ = self._pointers()
         pe, rm, rv, _nbt = self._engine_buffers()

@@ -166,7 +166,7 @@ def test_ppo_minibatch_loss_grads_clip_adam_vs_oracle(M):
         arr, garr = f.pointers(grads=True)
         check(lib().mansy_ppo_minibatch_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(d['obs']), None,
                                              ptr(d['act']), ptr(d['adv']), ptr(d['logp']), ptr(d['v']), ptr(d['ret']), len(obs), 0.2, 0.5, 0.02, 1, 1,
-                                             max_norm, 5e-4, 1e-2, step, -1, 0, ptr(stats), ptr(eng.workspace()), eng.max_batch, stream_ptr()), 'ppo_mb')
+                                             max_norm, 5e-4, 1e-2, step, -1, 0, ptr(stats), ptr(eng.workspace()), eng.max_batch, 0, None, 0, stream_ptr()), 'ppo_mb')
     call(0, 0.0)                                  # gradients only, no clipping
     np.testing.assert_allclose(stats.cpu().numpy(), [loss, clip, vf, ent], rtol=2e-5, atol=2e-6)
     names = [n for n, _ in f.table]
@@ -323,7 +323,7 @@ def test_update_teacher_forced_every_minibatch_step(M):
                 check(lib().mansy_ppo_minibatch_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(obs_d), ptr(idx),
                                                      ptr(act_d), ptr(data['adv']), ptr(data['logp_old']), ptr(data['v_s']), ptr(data['returns']),
                                                      idx.numel(), 0.2, 0.5, 0.02, 1, 1, 1.0, lr, wd, f.step, *f.tail(), ptr(stats),
-                                                     ptr(eng.workspace()), eng.max_batch, stream_ptr()), 'mansy_ppo_minibatch_step')
+                                                     ptr(eng.workspace()), eng.max_batch, 0, None, 0, stream_ptr()), 'mansy_ppo_minibatch_step')
                 torch.cuda.synchronize()
                 np.testing.assert_allclose(stats.cpu().numpy(), rows[k], rtol=1e-5, atol=3e-6, err_msg=f'{(T, N, it, k)}')
                 n_el = n_bad = 0
@@ -475,7 +475,7 @@ def test_behaviour_cloning_steps_then_ppo_with_per_parameter_adam_steps(M):
         assert f.tail()[1] == k + 1
         check(lib().mansy_ppo_minibatch_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(d['obs']), None,
                                              ptr(d['act']), ptr(d['adv']), ptr(d['logp']), ptr(d['v']), ptr(d['ret']), len(obs), 0.2, 0.5, 0.02, 1, 1,
-                                             1.0, 5e-4, 1e-2, f.step, *f.tail(), ptr(stats), ptr(eng.workspace()), eng.max_batch, stream_ptr()),
+                                             1.0, 5e-4, 1e-2, f.step, *f.tail(), ptr(stats), ptr(eng.workspace()), eng.max_batch, 0, None, 0, stream_ptr()),
               'ppo_mb')
         np.testing.assert_allclose(stats[0].item(), loss.item(), rtol=5e-5, atol=5e-6)
     compare('after PPO steps', 6e-6)
@@ -638,6 +638,45 @@ def test_whole_update_vs_oracle_update(M):
                 # differ by a fraction of lr per step on most weights and by up to 2 lr per step on a few
                 steps = len(got_rows) * (it + 1)
                 assert err.max() <= steps * 2 * 5e-4 and np.median(err) <= 1e-4, (T, N, it, name, float(np.median(err)), float(err.max()))
+
+
+def test_chained_update_equals_self_contained_steps(M):
+    """learn() chains the minibatch steps: a step's last launch (clip + Adam) also zeroes the gradients, scatters the updated
+    parameters into the packed block-diagonal / stacked images and gathers the next minibatch; the next step skips its prologue
+    launch.  Same values in the same places: two updates (4096 transitions, and a ragged 1100 with merge_last) must leave every
+    weight, Adam moment and loss row where the self-contained steps leave them -- to float32 rounding, not bit for bit: the
+    output-layer backward adds its per-workgroup partial sums with float atomics, whose order varies from launch to launch
+    (measured: loss rows of two chained-vs-unchained runs differ by <= 2.4e-7, the first step is identical)."""
+    sd = po.make_policy_state_dict(int(Z['wseed']))
+    for (T, N, bs) in ((16, 256, 512), (11, 100, 512)):
+        rs = np.random.RandomState(7)
+        n = T * N
+        src = Z['obs']
+        obs = torch.from_numpy(src[rs.randint(0, len(src), size=n)].reshape(T, N, 780).copy())
+        obs_next = torch.from_numpy(src[rs.randint(0, len(src), size=n)].reshape(T, N, 780).copy())
+        act = torch.from_numpy(rs.randint(0, 15, size=(T, N)).astype(np.int32))
+        rew = torch.from_numpy(rs.randn(T, N).astype(np.float32))
+        done = torch.from_numpy((rs.rand(T, N) < 0.05).astype(np.uint8))
+        outs = []
+        for chained in (True, False):
+            pol = build_policy(M, sd)
+            pol.chain_steps = chained
+            buf = M.ppo.RolloutBuffer(T, N, 'cuda')
+            rows = []
+            for it in range(2):
+                buf.obs.copy_(obs); buf.obs_next.copy_(obs_next); buf.act.copy_(act); buf.rew.copy_(rew + 0.1 * it); buf.done.copy_(done)
+                buf.filled = T
+                np.random.seed(50 + it)
+                res = pol.update(0, buf, is_train=True, batch_size=bs, repeat=2)
+                rows.append(np.stack([res['loss'], res['loss/clip'], res['loss/vf'], res['loss/ent']], 1))
+            f = pol.engine.ac
+            outs.append((np.concatenate(rows), f.flat_p.clone(), f.m.clone(), f.v.clone()))
+        np.testing.assert_array_equal(outs[0][0][0], outs[1][0][0])              # first step: the same prologue launch either way
+        np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=2e-5, atol=2e-6)
+        for a, b in zip(outs[0][1:], outs[1][1:]):
+            err = (a - b).abs()
+            assert float((err > 0.02 * 5e-4).float().mean()) <= 1e-4 and err.max().item() <= 2 * 5e-4, (err.max().item(),)
+        assert np.isfinite(outs[0][0]).all() and len(outs[0][0]) == (32 if n == 4096 else 8)
 
 
 @pytest.mark.parametrize('mode', ['f32', 'bf16x6', 'bf16x3'])

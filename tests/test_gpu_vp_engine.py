@@ -477,29 +477,28 @@ def test_dropout_mask_policy_loss_curves(MT):
 
 
 def test_two_stream_half_batch_decoder_equals_single_stream(MT):
-    """MANSY_VP_SPLIT=1 runs the decoder recurrence (forward and backward) as two half-batches on two streams -- every launch on
-    the rows [b0, b0 + n) of the full slabs, dropout masks drawn at the rows' own indices (MansyDrop::base).  Same function:
-    with dropout ON, sample(), the loss and the post-step weights must equal the single-stream run (forward bit for bit; the weight
-    gradients sum rows in a different grouping, so the updated weights agree to fp32 rounding / Adam noise)."""
+    """mansy_vp_config.two_stream (model.two_stream) runs the decoder recurrence (forward and backward) as two half-batches on two
+    streams -- every launch on the rows [b0, b0 + n) of the full slabs, dropout masks drawn at the rows' own indices
+    (MansyDrop::base).  Same function: with dropout ON, sample(), the loss and the post-step weights must equal the single-stream
+    run (forward bit for bit; the weight gradients sum rows in a different grouping, so the updated weights agree to fp32 rounding /
+    Adam noise).  Default (None): on for sample(), off for training."""
     B = 512
     h, c, f = (t.cuda() for t in vo.synthetic_trajectories(B, 10, 10, seed=9))
     out = {}
     for split in ('0', '1'):
-        os.environ['MANSY_VP_SPLIT'] = split
-        try:
-            m = MT.ViewportTransformerMTIO(in_channel=2, fut_window=10, d_model=256, dim_feedforward=256, device='cuda', seed=11)
-            m.load_state_dict(vo.make_state_dict(256, 4, bias=True))
-            m = m.to('cuda')
-            m.eval()
-            with torch.no_grad():
-                samp = m.sample(h, c)
-            m.train()                                   # dropout on (p_pe 0.2, 0.1)
-            random.seed(1); np.random.seed(1); torch.manual_seed(1)      # MTIO decisions + the dropout seeds drawn from torch's generator
-            opt = MT.FusedAdamW(m, lr=1e-4)
-            losses = [m.train_step(h, c, f, opt).item() for _ in range(3)]
-            out[split] = (samp.clone(), losses, m._flat_p.clone())
-        finally:
-            os.environ.pop('MANSY_VP_SPLIT', None)
+        m = MT.ViewportTransformerMTIO(in_channel=2, fut_window=10, d_model=256, dim_feedforward=256, device='cuda', seed=11)
+        m.load_state_dict(vo.make_state_dict(256, 4, bias=True))
+        m = m.to('cuda')
+        assert m.two_stream is None and m._cfg(B, 10).two_stream == 0 and m._cfg(B, 10, inference=True).two_stream == 1
+        m.two_stream = split == '1'
+        m.eval()
+        with torch.no_grad():
+            samp = m.sample(h, c)
+        m.train()                                   # dropout on (p_pe 0.2, 0.1)
+        random.seed(1); np.random.seed(1); torch.manual_seed(1)      # MTIO decisions + the dropout seeds drawn from torch's generator
+        opt = MT.FusedAdamW(m, lr=1e-4)
+        losses = [m.train_step(h, c, f, opt).item() for _ in range(3)]
+        out[split] = (samp.clone(), losses, m._flat_p.clone())
     assert torch.equal(out['0'][0], out['1'][0])                              # forward: row-independent arithmetic, identical bits
     np.testing.assert_allclose(out['1'][1], out['0'][1], rtol=2e-6)          # same dropout masks, same losses
     err = (out['0'][2] - out['1'][2]).abs()

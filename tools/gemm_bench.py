@@ -17,6 +17,11 @@ SHAPES = [  # (name, a_kmajor, b_kmajor, M, N, K, accumulate, count per step)
 ]
 args = sys.argv[1:]
 CHECK = '--check' in args
+VARIANT = None
+if '--variant' in args:
+    i = args.index('--variant')
+    VARIANT = int(args[i + 1])
+    del args[i:i + 2]
 PLANES = '--planes' in args          # forward / dX shapes with the weight pre-split into bf16 planes (LDS-DMA B)
 args = [a for a in args if a != '--planes']
 precs = []
@@ -27,6 +32,9 @@ while '--prec' in args:
 precs = precs or ['f32']
 tiles = [int(x) for x in args if x != '--check'] or [0]
 tiles = [(t, pr) for pr in precs for t in tiles]
+if VARIANT is not None:
+    from mansy_immersivevideostreaming_amd._lib import lib
+    lib().mansy_gemm_bf16_variant(VARIANT)
 tot = {t: 0.0 for t in tiles}
 for name, ak, bk, M, N, Kd, acc, cnt in SHAPES:
     A = torch.randn((Kd, M) if ak else (M, Kd), device='cuda')

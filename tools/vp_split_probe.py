@@ -1,4 +1,4 @@
-"""Two-stream half-batch decoder (MANSY_VP_SPLIT=1) against the single-stream run, dropout ON: every named workspace slab of one
+"""Two-stream half-batch decoder (model.two_stream = True) against the single-stream run, dropout ON: every named workspace slab of one
 train step compared bit for bit (tests/test_gpu_vp_engine.py::test_two_stream_half_batch_decoder_equals_single_stream is the assertion form).
     python tools/vp_split_probe.py"""
 import os, sys, random
@@ -12,8 +12,8 @@ names = ['dec.emb', 'dec0.qkv', 'dec0.P1', 'dec0.ao1', 'dec0.z1', 'dec0.y1', 'de
          'dec1.qkv', 'dec1.ao1', 'dec1.z1', 'dec1.h', 'dec1.z3', 'dec.out', 'tok_all', 'dec1.dbr3', 'dec1.da', 'dec1.dbr2', 'dec1.dqc', 'dec1.dbr1', 'dec1.dqkv', 'dec0.dqkv', 'dec.dE']
 out = {}
 for split in ('0', '1'):
-    os.environ['MANSY_VP_SPLIT'] = split
     m = MT.ViewportTransformerMTIO(in_channel=2, fut_window=10, d_model=d, dim_feedforward=d, device='cuda', seed=11)
+    m.two_stream = split == '1'
     m.load_state_dict(vo.make_state_dict(d, 4, bias=True)); m = m.to('cuda').train()
     random.seed(1); np.random.seed(1); torch.manual_seed(1)
     opt = MT.FusedAdamW(m, lr=1e-4)
