@@ -32,6 +32,10 @@ class GemmEpilogue(ctypes.Structure):
             self.prec = -1          # the process-wide precision mode
 
 
+class XgHandle(ctypes.Structure):          # mansy_xg_handle: an opaque hipIpcMemHandle_t
+    _fields_ = [('bytes', ctypes.c_ubyte * 64)]
+
+
 class EnvTables(ctypes.Structure):
     _fields_ = [('size', c_void_p), ('quality', c_void_p), ('video_len', c_void_p), ('n_chunk_max', c_int),
                 ('vp_gt', c_void_p), ('vp_pred', c_void_p), ('vp_acc', c_void_p), ('vp_start', c_void_p), ('vp_end', c_void_p),
@@ -109,7 +113,14 @@ _PROTOS = {
     'mansy_ppo_minibatch_step': [P, P, P, P, P, P, c_ll, P, P, P, P, P, P, P, c_int, c_float, c_float, c_float, c_int, c_int, c_float,
                                  c_float, c_float, c_int, c_ll, c_int, P, P, c_int, c_int, P, c_int, P],
     'mansy_bc_step': [P, P, P, P, P, P, c_ll, c_ll, P, P, c_int, c_float, c_float, c_float, c_int, P, P, c_int, P],
-    'mansy_clip_grad_adam': [P, P, P, P, c_ll, c_float, c_float, c_float, c_int, c_ll, c_int, P, P],
+    'mansy_clip_grad_adam': [P, P, P, P, c_ll, c_float, c_float, c_float, c_int, c_ll, c_int, P, c_int, P],
+    'mansy_xg_create': [c_ll, c_int, c_int, P],
+    'mansy_xg_export': [P, P],
+    'mansy_xg_import': [P, P],
+    'mansy_xg_set_timeout_ms': [P, ctypes.c_double],
+    'mansy_xg_allreduce_avg': [P, P, c_ll, P, P],
+    'mansy_xg_status': [P],
+    'mansy_xg_destroy': [P],
     'mansy_a2c_num_params': [],
     'mansy_a2c_param_info': [c_int, ctypes.c_char_p, c_int, P, P, P],
     'mansy_a2c_workspace_bytes': [c_int],

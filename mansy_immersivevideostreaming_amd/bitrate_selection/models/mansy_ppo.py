@@ -215,14 +215,29 @@ class PPOPolicy(nn.Module):
         self.world, self.grad_sync = 1, None
         self.chain_steps = True       # learn(): each minibatch step's last launch prepares the next one (False: self-contained steps)
 
-    def set_data_parallel(self, world, grad_sync):
-        """One process per GPU: `grad_sync(flat_grad)` averages a flat gradient buffer over ranks (dist.make_grad_sync)."""
+    def set_data_parallel(self, world, grad_sync, peer=False):
+        """One process per GPU: `grad_sync(flat_grad)` averages a flat gradient buffer over ranks (dist.make_grad_sync).
+        peer=True: the hand-written one-shot all-reduce over peer-mapped memory (dist.PeerGradSync, csrc/xgmi.hip) for both flat
+        buffers instead -- one launch that also leaves the gradient's sums of squares for the clip."""
         self.world, self.grad_sync = int(world), grad_sync
+        self._peer = {}
+        if peer and self.world > 1:
+            import torch.distributed as tdist
+            from ...dist import PeerGradSync
+            for f in (self.engine.ac, self.engine.idn):
+                if f is not None:
+                    self._peer[id(f)] = PeerGradSync(f.flat_p.numel(), self.world, tdist.get_rank(), f.flat_p.device)
 
-    def _clip_adam(self, f, max_norm, lr, wd):
+    def _sync_clip_adam(self, f, max_norm, lr, wd):
+        """Data-parallel second half of a step: average the raw local gradients over the ranks, then global-norm clip + Adam."""
+        peer = self._peer.get(id(f)) if getattr(self, '_peer', None) else None
         scratch = torch.empty(64, dtype=torch.float64, device=f.flat_p.device)      # MANSY_CLIP_SCRATCH_DOUBLES
+        if peer is not None:
+            peer(f.flat_g, scratch)
+        else:
+            self.grad_sync(f.flat_g)
         check(lib().mansy_clip_grad_adam(ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), float(max_norm), lr, wd, f.step,
-                                         *f.tail(), ptr(scratch), stream_ptr(f.flat_p.device)), 'mansy_clip_grad_adam')
+                                         *f.tail(), ptr(scratch), int(peer is not None), stream_ptr(f.flat_p.device)), 'mansy_clip_grad_adam')
 
     # ---- plumbing ---------------------------------------------------------------------------------------------
     def _apply(self, fn, *a, **k):
@@ -295,8 +310,7 @@ class PPOPolicy(nn.Module):
                                                 -1 if dp else step, ptr(loss), ptr(eng.workspace()), eng.max_batch, stream_ptr(obs.device)),
               'mansy_identifier_train_step')
         if dp:
-            self.grad_sync(f.flat_g)
-            self._clip_adam(f, 0.0, lr, wd)
+            self._sync_clip_adam(f, 0.0, lr, wd)
         return loss
 
     def relabel(self, buffer, lamb):
@@ -377,9 +391,8 @@ class PPOPolicy(nn.Module):
                                                  0 if dp else f.step, *f.tail(), ptr(stats_all[pi][k]), ptr(eng.workspace()), eng.max_batch,
                                                  int(chain and s > 0), ptr(nxt), nxt.numel() if nxt is not None else 0, stream_ptr(dev)),
                   'mansy_ppo_minibatch_step')
-            if dp:                              # raw local gradients -> RCCL average -> global-norm clip + Adam
-                self.grad_sync(f.flat_g)
-                self._clip_adam(f, float(self._grad_norm or 0.0), lr, wd)
+            if dp:                              # raw local gradients -> average over the ranks -> global-norm clip + Adam
+                self._sync_clip_adam(f, float(self._grad_norm or 0.0), lr, wd)
         return LazyLosses(('loss', 'loss/clip', 'loss/vf', 'loss/ent'), stats_all)
 
     def bc_step(self, obs, act, ent_coef=0.1, train=True):

@@ -1195,10 +1195,10 @@ int mansy_bc_step(const float* const* params, float* const* grads, float* flat_p
 // flat buffers.  Data-parallel callers run the minibatch step with step = 0 and max_grad_norm = 0 (raw gradients),
 // all-reduce flat_g over RCCL, then call this.  scratch: MANSY_CLIP_SCRATCH_DOUBLES doubles.
 int mansy_clip_grad_adam(float* flat_p, float* flat_g, float* flat_m, float* flat_v, long long n_flat, float max_grad_norm, float lr,
-                         float weight_decay, int step, long long tail_from, int tail_step, double* scratch, void* stream) {
+                         float weight_decay, int step, long long tail_from, int tail_step, double* scratch, int have_sumsq, void* stream) {
   MANSY_REQUIRE(flat_p && flat_g && flat_m && flat_v && scratch && step >= 1, "clip_grad_adam: bad arguments");
   PEng e; e.st = (hipStream_t)stream; e.W.acc = scratch;
-  return e.clip_and_adam(flat_p, flat_g, flat_m, flat_v, n_flat, max_grad_norm, lr, weight_decay, step, tail_from, tail_step);
+  return e.clip_and_adam(flat_p, flat_g, flat_m, flat_v, n_flat, max_grad_norm, lr, weight_decay, step, tail_from, tail_step, have_sumsq != 0);
 }
 
 }  // extern "C"

@@ -1,0 +1,196 @@
+// One-shot gradient all-reduce over peer-mapped memory (hipIpc / xGMI) for the latency-bound collectives of the data-parallel PPO
+// update: 16 + 2 all-reduces of 1.7 MB / 1.05 MB per 2.6 ms cycle, each on the critical path
+//   minibatch gradients -> average over ranks -> global-norm clip + Adam -> next minibatch's forward.
+// A library all-reduce is its own launch (or several) plus a separate pass for the gradient norm; here ONE launch per rank
+//   1. copies the rank's flat gradient into its exchange slot (fine-grained device memory every peer has mapped through hipIpc),
+//      fences at system scope and -- the last workgroup to finish -- publishes the step's epoch in the rank's flag word;
+//   2. waits (bounded) until every peer's flag has reached the epoch, acquires at system scope;
+//   3. sums the world's exchange slots element-wise IN RANK ORDER (every rank computes bit-identical averages, so the replicas
+//      cannot drift), scales by 1 / world, writes the average back over the gradient and leaves the 64 partial sums of squares
+//      mansy_clip_grad_adam wants (have_sumsq = 1: the separate norm launch disappears).
+// Each rank reads (world - 1) x n floats straight from its peers' HBM over the point-to-point links -- no ring, no intermediate
+// hops: 7 x 1.7 MB at 8 ranks, the seven links in parallel.  Two slots alternate with the epoch: a rank overwrites slot e & 1 at
+// epoch e + 2 only after it has seen every peer at epoch e + 1, i.e. after every peer's launch of epoch e -- the last reader of
+// that slot -- has completed.
+// Placement-independent and bounded: the wait gives up after `timeout_ms`, poisons its output with NaN and raises the context's
+// sticky error (mansy_xg_status), it never hangs the queue.  Grid = 64 workgroups, so the launches of all ranks are co-resident
+// even when several ranks share one GPU (the functional test: two processes on one device).
+#include <vector>
+#include "mansy_kernels.h"
+#include "../../include/mansy_hip.h"
+
+namespace {
+
+constexpr int XG_BLOCKS = MANSY_CLIP_SCRATCH_DOUBLES;      // one partial sum of squares per workgroup
+constexpr int XG_MAX_WORLD = 16;
+constexpr long long XG_HEADER_FLOATS = 64;                // 256-byte header: word 0 = the published epoch
+
+struct XgPeers { const float* data[XG_MAX_WORLD]; const unsigned* flag[XG_MAX_WORLD]; };
+
+struct XgCtx {
+  int world = 0, rank = 0, imported = 0;
+  long long n = 0, n_pad = 0;
+  float* own = nullptr;                   // header + 2 slots
+  void* peer_base[XG_MAX_WORLD] = {};     // mapped peer allocations (own entry = own)
+  unsigned epoch = 0;
+  unsigned* counter = nullptr;            // workgroups of this rank that have published (monotonic)
+  int* err = nullptr;                     // sticky device-side error word
+  unsigned long long launches = 0;
+  double timeout_ms = 2000.0;
+};
+
+__global__ __launch_bounds__(256) void xg_allreduce_kernel(float* __restrict__ g, long long n4, XgPeers peers, float* __restrict__ own_slot,
+                                                          unsigned* __restrict__ own_flag, long long slot_off, int rank, int world, unsigned epoch,
+                                                          float inv_world, double* __restrict__ parts, unsigned* __restrict__ counter, unsigned target,
+                                                          int* __restrict__ err, long long timeout_ticks) {
+  const long long gtid = (long long)blockIdx.x * 256 + threadIdx.x, gsize = (long long)gridDim.x * 256;
+  // 1. publish this rank's gradient
+  for (long long i = gtid; i < n4; i += gsize) reinterpret_cast<float4*>(own_slot)[i] = reinterpret_cast<const float4*>(g)[i];
+  __threadfence_system();                                   // this thread's stores are visible to every agent ...
+  __syncthreads();                                          // ... and so are the workgroup's
+  __shared__ int timed_out;
+  if (threadIdx.x == 0) {
+    timed_out = 0;
+    const unsigned prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev + 1u == target) __hip_atomic_store(own_flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __syncthreads();
+  // 2. wait for every peer's epoch (one polling lane per peer)
+  if (threadIdx.x < world && (int)threadIdx.x != rank) {
+    const long long t0 = wall_clock64();
+    while ((int)(__hip_atomic_load(peers.flag[threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
+      if (wall_clock64() - t0 > timeout_ticks) { timed_out = 1; __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      __builtin_amdgcn_s_sleep(4);
+    }
+  }
+  __syncthreads();
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);                  // system scope: the peers' slots as published
+  const bool bad = timed_out != 0;
+  // 3. reduce in rank order, average, sum of squares
+  double sq = 0.0;
+  for (long long i = gtid; i < n4; i += gsize) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = 0; p < world; ++p) {
+      const float4 v = reinterpret_cast<const float4*>(peers.data[p] + slot_off)[i];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    s.x *= inv_world; s.y *= inv_world; s.z *= inv_world; s.w *= inv_world;
+    if (bad) s.x = s.y = s.z = s.w = __builtin_nanf("");
+    reinterpret_cast<float4*>(g)[i] = s;
+    sq += ((double)s.x * s.x + (double)s.y * s.y) + ((double)s.z * s.z + (double)s.w * s.w);
+  }
+  if (!parts) return;
+  __shared__ double red[256];
+  red[threadIdx.x] = sq;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) parts[blockIdx.x] = red[0];
+}
+
+}  // namespace
+
+extern "C" {
+
+int mansy_xg_create(long long n_floats, int world, int rank, void** ctx_out) {
+  MANSY_REQUIRE(ctx_out && n_floats >= 4 && n_floats % 4 == 0 && world >= 1 && world <= XG_MAX_WORLD && rank >= 0 && rank < world,
+                "xg_create: need n %% 4 == 0, 1 <= world <= %d, 0 <= rank < world", XG_MAX_WORLD);
+  static_assert(sizeof(mansy_xg_handle) == sizeof(hipIpcMemHandle_t), "mansy_xg_handle must hold a hipIpcMemHandle_t");
+  XgCtx* c = new XgCtx();
+  c->world = world; c->rank = rank; c->n = n_floats; c->n_pad = (n_floats + 63) / 64 * 64;
+  const size_t bytes = sizeof(float) * (size_t)(XG_HEADER_FLOATS + 2 * c->n_pad);
+  // fine-grained: stores and flag updates are visible to the peers while the kernels run (coarse-grained device memory is only
+  // coherent across agents at kernel boundaries)
+  hipError_t e = hipExtMallocWithFlags((void**)&c->own, bytes, hipDeviceMallocFinegrained);
+  if (e != hipSuccess) { delete c; mansy_set_error("xg_create: hipExtMallocWithFlags(fine-grained, %zu bytes) -> %s", bytes, hipGetErrorString(e)); return MANSY_EHIP; }
+  MANSY_HIP_CHECK(hipMemset(c->own, 0, bytes));
+  MANSY_HIP_CHECK(hipMalloc((void**)&c->counter, 256));
+  MANSY_HIP_CHECK(hipMemset(c->counter, 0, 256));
+  c->err = reinterpret_cast<int*>(c->counter) + 16;
+  MANSY_HIP_CHECK(hipDeviceSynchronize());
+  c->peer_base[rank] = c->own;
+  if (world == 1) c->imported = 1;
+  *ctx_out = c;
+  return MANSY_OK;
+}
+
+int mansy_xg_export(void* ctx, mansy_xg_handle* out) {
+  XgCtx* c = (XgCtx*)ctx;
+  MANSY_REQUIRE(c && out, "xg_export: null");
+  hipIpcMemHandle_t h;
+  MANSY_HIP_CHECK(hipIpcGetMemHandle(&h, c->own));
+  memcpy(out->bytes, &h, sizeof(h));
+  return MANSY_OK;
+}
+
+int mansy_xg_import(void* ctx, const mansy_xg_handle* all) {
+  XgCtx* c = (XgCtx*)ctx;
+  MANSY_REQUIRE(c && all && !c->imported, "xg_import: null or already imported");
+  for (int p = 0; p < c->world; ++p) {
+    if (p == c->rank) continue;
+    hipIpcMemHandle_t h;
+    memcpy(&h, all[p].bytes, sizeof(h));
+    MANSY_HIP_CHECK(hipIpcOpenMemHandle(&c->peer_base[p], h, hipIpcMemLazyEnablePeerAccess));
+  }
+  c->imported = 1;
+  return MANSY_OK;
+}
+
+int mansy_xg_set_timeout_ms(void* ctx, double ms) {
+  XgCtx* c = (XgCtx*)ctx;
+  MANSY_REQUIRE(c && ms > 0.0, "xg_set_timeout_ms: bad arguments");
+  c->timeout_ms = ms;
+  return MANSY_OK;
+}
+
+int mansy_xg_allreduce_avg(void* ctx, float* g, long long n, double* sumsq_parts, void* stream) {
+  XgCtx* c = (XgCtx*)ctx;
+  MANSY_REQUIRE(c && g && c->imported, "xg_allreduce_avg: context not ready (create -> export -> exchange handles -> import)");
+  MANSY_REQUIRE(n == c->n && (reinterpret_cast<uintptr_t>(g) & 15) == 0, "xg_allreduce_avg: n must be the context's %lld and g 16-byte aligned", c->n);
+  c->epoch += 1;
+  c->launches += 1;
+  XgPeers peers;
+  for (int p = 0; p < XG_MAX_WORLD; ++p) {
+    const float* base = (const float*)c->peer_base[p < c->world ? p : c->rank];
+    peers.data[p] = base + XG_HEADER_FLOATS;
+    peers.flag[p] = reinterpret_cast<const unsigned*>(base);
+  }
+  const long long slot_off = (long long)(c->epoch & 1u) * c->n_pad;
+  int wall_khz = 100000;                                    // wall_clock64 ticks at a constant rate (100 MHz on gfx9)
+  int dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, dev);
+  if (wall_khz <= 0) wall_khz = 100000;
+  const long long ticks = (long long)(c->timeout_ms * (double)wall_khz);
+  hipLaunchKernelGGL(xg_allreduce_kernel, dim3(XG_BLOCKS), dim3(256), 0, (hipStream_t)stream, g, n / 4, peers, c->own + XG_HEADER_FLOATS + slot_off,
+                     reinterpret_cast<unsigned*>(c->own), slot_off, c->rank, c->world, c->epoch, 1.0f / (float)c->world, sumsq_parts, c->counter,
+                     (unsigned)(c->launches * XG_BLOCKS), c->err, ticks);
+  MANSY_LAUNCH_CHECK();
+  return MANSY_OK;
+}
+
+// 0: every wait so far met its peers; MANSY_EHIP: a wait timed out (the outputs of that call are NaN).  Synchronises the device.
+int mansy_xg_status(void* ctx) {
+  XgCtx* c = (XgCtx*)ctx;
+  MANSY_REQUIRE(c, "xg_status: null");
+  int e = 0;
+  MANSY_HIP_CHECK(hipDeviceSynchronize());
+  MANSY_HIP_CHECK(hipMemcpy(&e, c->err, sizeof(int), hipMemcpyDeviceToHost));
+  if (e) { mansy_set_error("xg: a peer did not publish its gradient within %.0f ms", c->timeout_ms); return MANSY_EHIP; }
+  return MANSY_OK;
+}
+
+int mansy_xg_destroy(void* ctx) {
+  XgCtx* c = (XgCtx*)ctx;
+  if (!c) return MANSY_OK;
+  (void)hipDeviceSynchronize();
+  for (int p = 0; p < c->world; ++p)
+    if (p != c->rank && c->peer_base[p]) (void)hipIpcCloseMemHandle(c->peer_base[p]);
+  if (c->own) (void)hipFree(c->own);
+  if (c->counter) (void)hipFree(c->counter);
+  delete c;
+  return MANSY_OK;
+}
+
+}  // extern "C"

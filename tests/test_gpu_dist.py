@@ -8,6 +8,7 @@ import socket
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -122,3 +123,40 @@ def test_rccl_world1_collectives_of_the_dp_step():
     assert 0 < out['allreduce_avg_1p7MB_us'] < 5000 and 0 < out['allreduce_avg_36MB_us'] < 50000
     # the overlapped sync ran: the engine hook handed over the decoder-side tail (about two thirds of the buffer)
     assert 0.5 * out['flat_elems'] < out['overlap_tail_elems'] < 0.8 * out['flat_elems']
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('world', [2, 3])
+def test_peer_memory_allreduce_between_processes_sharing_the_gpu(world):
+    """csrc/xgmi.hip through dist.PeerGradSync: `world` processes on the one GPU map each other's fine-grained exchange buffers
+    through hipIpc and run 40 back-to-back one-shot all-reduces of the PPO flat-gradient size; every result must equal the
+    rank-ordered float32 average bit for bit on every rank, the partial sums of squares must add up to its squared norm, and no
+    wait may time out (tools/xg_selftest.py)."""
+    env = dict(os.environ, MANSY_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'tools', 'xg_selftest.py')]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"ranks"')][-1])
+    assert len(out['ranks']) == world
+    for rec in out['ranks']:
+        assert rec['world'] == world and rec['mismatched_elements'] == 0 and rec['plain_call_ok'], rec
+        assert rec['sumsq_rel_err'] < 1e-12, rec
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_with_the_peer_memory_allreduce():
+    """The data-parallel PPO update through the one-shot peer-memory all-reduce (MANSY_PEER_SYNC=1): two ranks share the GPU, the
+    averaged gradients are bit-identical on both, so the replicas must end bit-identical like they do over the library collective."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(MANSY_DIST_BACKEND='gloo', MANSY_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0', MANSY_PEER_SYNC='1')
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '256', '--no-cpu-baseline']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][0])
+    assert out['n_gpus'] == 2 and out['secondary']['n_gpus'] == 2 and out['secondary']['grad_sync'] == 'peer-memory one-shot (csrc/xgmi.hip)'
+    assert out['secondary']['replica_param_spread'] == 0.0 and out['secondary']['value'] > 0
+    assert np.isfinite(out['secondary']['final_loss'])
