@@ -40,8 +40,6 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense BF16 MFMA peak (sp
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E
 PPO_FLOP_PER_ENV_STEP = 11.5e6   # rollout 0.523 + update 10.95 MFLOP per env-step, as written
 PPO_BYTES_PER_ENV_STEP = 29e3    # 3 116 B observation written + ~8.2 reads of it across the update passes
-PPO_LAUNCHES_PER_CYCLE = 281     # kernels per collect + identifier + update cycle (rocprofv3 kernel trace; round 1: 307)
-PPO_LAUNCHES_SOURCE = 'profiles/r02d_ppo_kernel_stats.csv'
 LAUNCH_FLOOR_US = 5.0            # dependent-launch floor on this chip (K -> 0 intercept of a [4096,512] product)
 
 
@@ -132,12 +130,29 @@ def cpu_baseline(seconds=15.0):
 def _pmc_traffic(pattern='r*_pmc_gemm.json'):
     """HBM-side bytes per GEMM launch from the newest committed rocprofv3 PMC aggregate (profiles/<round tag>_pmc_gemm*.json,
     written by tools/pmc_aggregate.py from separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 per the gfx950 correction);
-    PMC cannot be collected from inside this process.  Returns (bytes per launch, file name) -- the file is named in the bench
-    line so that a stale aggregate is visible."""
+    PMC cannot be collected from inside this process.  Returns (bytes per launch, file name, stale): the file is named in the
+    bench line, and `stale` says whether the GEMM sources it was collected on (their digest is stamped into the file) are the
+    ones running now -- counters of an older kernel must not pass for this build's."""
     import glob
+    from mansy_immersivevideostreaming_amd import build_ext
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', pattern)))
     try:
-        return json.load(open(files[-1]))['traffic_bytes_per_launch'], 'profiles/' + os.path.basename(files[-1])
+        rec = json.load(open(files[-1]))
+        stale = rec.get('gemm_source_digest') != build_ext.gemm_source_digest()
+        return rec['traffic_bytes_per_launch'], 'profiles/' + os.path.basename(files[-1]), stale
+    except Exception:
+        return None, None, None
+
+
+def _ppo_launches_per_cycle():
+    """Kernel launches per PPO cycle from the newest committed rocprofv3 kernel-stats file of the cycle (profiles/r*_ppo_kernel_stats.csv
+    = tools/gpu_prof_ppo.sh: 10 timed + 2 warm-up + 2 roofline-leg cycles) -- a measured figure, not a literal."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_ppo_kernel_stats.csv')))
+    try:
+        calls = sum(int(r['Calls']) for r in csv.DictReader(open(files[-1])))
+        return round(calls / 14.0, 1), 'profiles/' + os.path.basename(files[-1])
     except Exception:
         return None, None
 
@@ -233,6 +248,7 @@ def bench_ppo(rank, world, dev, mdist, cycles=5, warmup=2, n_env=256, steps_per_
     steps = world * n_env * steps_per_env * cycles
     if rank == 0:
         eps = steps / dt / world                                      # env-steps/s of this GPU
+        n_launch, launch_src = _ppo_launches_per_cycle()
         gemm_tf = fl_g / (ms_g * 1e-3) / 1e12 if ms_g > 0 else 0.0
         roof = {'bound': 'mfma', 'kernel': 'gemm_f32_dma_kernel (FeatureNet block-diagonal product, heads, dF / dW products of the update)',
                 'achieved': round(eps * PPO_FLOP_PER_ENV_STEP / 1e12, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
@@ -244,9 +260,9 @@ def bench_ppo(rank, world, dev, mdist, cycles=5, warmup=2, n_env=256, steps_per_
                                          'gemm_ms_per_cycle': round(ms_g / nprof, 3), 'gemm_tflops': round(gemm_tf, 2),
                                          'gemm_frac_of_peak': round(gemm_tf / PEAK_F32_MFMA_TFLOPS, 4),
                                          'rollout_gemm_launches_per_cycle_in_graph': 2 * steps_per_env},
-                'launch_floor': {'us_per_dependent_launch': LAUNCH_FLOOR_US, 'launches_per_cycle': PPO_LAUNCHES_PER_CYCLE,
-                                 'source': PPO_LAUNCHES_SOURCE,
-                                 'floor_ms_per_cycle': round(PPO_LAUNCHES_PER_CYCLE * LAUNCH_FLOOR_US * 1e-3, 3),
+                'launch_floor': {'us_per_dependent_launch': LAUNCH_FLOOR_US, 'launches_per_cycle': n_launch,
+                                 'source': launch_src,
+                                 'floor_ms_per_cycle': round((n_launch or 0) * LAUNCH_FLOOR_US * 1e-3, 3),
                                  'measured_ms_per_cycle': round(dt / cycles * 1e3, 3)}}
     if peer:
         for ps in pol._peer.values():
@@ -515,13 +531,16 @@ def main():
     # rank-0-only step would leave the other ranks in a different collective); only rank 0 records GEMM launch times
     nprof = max(1, min(args.steps, 3))
     L = lib()
+    # (the decoder recurrence runs as two half-batches on two streams in the timed legs; the per-kernel timing legs run it on one
+    # stream, because concurrent kernels stretch each other's durations: a kernel's duration is then a property of the kernel)
+    model.two_stream = False
     if rank == 0:
         ms, n, fl = _gemm_prof(L, step, nprof)
         achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        traffic, traffic_src = _pmc_traffic('r*_pmc_gemm.json')
+        traffic, traffic_src, traffic_stale = _pmc_traffic('r*_pmc_gemm.json')
         roof = {'bound': 'mfma', 'kernel': 'gemm_f32_dma_kernel (v_mfma_f32_32x32x2_f32, LDS-DMA staged)', 'achieved': round(achieved, 2),
                 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                'traffic': traffic, 'traffic_source': traffic_src,
+                'traffic': traffic, 'traffic_source': traffic_src, 'traffic_stale': traffic_stale,
                 'launches_per_step': n // nprof, 'avg_launch_us': round(ms * 1e3 / max(n, 1), 2),
                 'gemm_flops_per_step': fl / nprof, 'gemm_ms_per_step': round(ms / nprof, 3),
                 'algorithmic_flops_per_step': FLOP_PER_TRAJ * B,
@@ -535,6 +554,7 @@ def main():
     modes = []
     for mode, nprod in (('bf16x3', 3), ('bf16x6', 6)):
         model.precision = mode
+        model.two_stream = None
         for _ in range(2):
             step()
         if world > 1:
@@ -551,18 +571,20 @@ def main():
             t = torch.tensor([dtm], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dtm = t.item()
+        model.two_stream = False
         if rank == 0:
             ms, n, fl = _gemm_prof(L, step, nprof)
             alg_tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            traffic, traffic_src = _pmc_traffic(f'r*_pmc_gemm_{mode}.json')
+            traffic, traffic_src, traffic_stale = _pmc_traffic(f'r*_pmc_gemm_{mode}.json')
             vm = world * B * args.steps / dtm
             modes.append({'dtype': mode, 'metric': 'viewport-trajectories/sec (VP train)', 'value': round(vm, 1), 'unit': 'trajectories/s',
                           'ms_per_step': round(dtm / args.steps * 1e3, 3), 'final_loss': float(mloss.item()), 'speedup_vs_f32': round(vm / value, 3),
-                          'roofline': {'bound': 'mfma', 'kernel': f'gemm_bf16s_kernel (v_mfma_f32_32x32x16_bf16, {nprod} bf16 products per fp32 product, '
-                                                                  'operands split in the staging pass)',
+                          'roofline': {'bound': 'mfma', 'kernel': f'gemm_bf16{{f,p,s}}_kernel (v_mfma_f32_32x32x16_bf16, {nprod} bf16 products per fp32 product; weights pre-split, '
+                                                                  'activations split at fragment read / in the staging pass)',
                                        # executed bf16 MFMA FLOPs = nprod x the algorithmic (fp32-product) FLOPs
                                        'achieved': round(alg_tf * nprod, 2), 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                                        'frac': round(alg_tf * nprod / PEAK_BF16_MFMA_TFLOPS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
+                                       'traffic_stale': traffic_stale,
                                        'algorithmic_tflops': round(alg_tf, 2), 'launches_per_step': n // nprof,
                                        'avg_launch_us': round(ms * 1e3 / max(n, 1), 2), 'gemm_ms_per_step': round(ms / nprof, 3),
                                        'model_frac_of_f32_peak': round(vm / world * FLOP_PER_TRAJ / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}})
@@ -571,6 +593,7 @@ def main():
                 step()
             torch.cuda.synchronize()
     model.precision = None
+    model.two_stream = None
 
     vp_spread = replica_spread(model._flat_p, world)
     ppo = bench_ppo(rank, world, dev, mdist, cycles=max(2, min(args.steps, 6)), warmup=2)
@@ -582,7 +605,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'VP Transformer train step (fwd+loss+bwd+AdamW), B={B}/GPU synthetic torus-walk '
                                    f'trajectories len 21 (hist 10 + cur 1 + pred 10), d=512, 8 heads, 2+2 layers, dropout on, '
-                                   f'fp32 MFMA', 'global_batch': B * world, 'parallelism': f'dp{world}'},
+                                   f'fp32 MFMA, decoder recurrence as two half-batches on two streams', 'two_stream': True, 'global_batch': B * world, 'parallelism': f'dp{world}'},
             'final_loss': loss_val, 'replica_param_spread': vp_spread, 'dist': dist_info,
             'roofline': roof,
             'precision_modes': modes,

@@ -44,8 +44,8 @@ typedef struct mansy_vp_config {
   int bn_sync_world;           /* data-parallel ranks sharing DistillLayer BatchNorm statistics (<= 1: local) */
   int two_stream;              /* 1: the decoder recurrence runs as two half-batches on two streams (products of one half under the
                                 * attention / LayerNorm passes of the other; needs B >= 256 and even, else ignored).  Same function,
-                                * bit-identical forward.  The host mirror turns it on for sample() (+4 % at B = 4096) and leaves it
-                                * off for training (+1.8 %, and concurrent kernels blur per-kernel timings). */
+                                * bit-identical forward.  The host mirror turns it on (sample() +4 %, train step +1.8 % at B = 4096);
+                                * per-kernel timings are taken with it off (concurrent kernels stretch each other's durations). */
 } mansy_vp_config;
 
 /* SyncBN hook: with bn_sync_world > 1 the engine calls fn(which, user) after enqueuing the per-channel partial sums

@@ -41,6 +41,22 @@ def source_digest():
     return h.hexdigest()
 
 
+GEMM_SOURCES = ('gemm_f32.hip', 'gemm_bf16s.hip', 'gemm_tile.h', 'mansy_kernels.h', 'mansy_common.h')
+
+
+def gemm_source_digest():
+    """sha256 over the sources of the GEMM kernels only (+ the flags): stamped into profiles/*_pmc_gemm*.json when the PMC passes
+    are aggregated (tools/pmc_aggregate.py) and compared by bench.py, so that a `roofline.traffic` taken from counters of an
+    older kernel is flagged (`traffic_stale`)."""
+    import hashlib
+    h = hashlib.sha256(' '.join(FLAGS).encode())
+    for f in GEMM_SOURCES:
+        h.update(f.encode())
+        with open(os.path.join(CSRC, f), 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]

@@ -395,9 +395,8 @@ struct Eng {
   // ---- two-stream plumbing (the second stream and its events are created once per process)
   hipStream_t st2 = nullptr;
   // mansy_vp_config::two_stream.  Measured at B = 4096: train step 23.08 -> 22.67 ms (+1.8 %), sample() 507 -> 529 k trajectories/s
-  // (+4 %), identical losses.  The host mirror sets it for sample() and not for training: the gain there is small, and concurrent
-  // kernels stretch each other's durations, so per-kernel timings (bench.py's roofline leg, rocprof kernel stats) stop describing
-  // the kernels themselves.
+  // (+4 %), identical losses.  The host mirror sets it by default; per-kernel timings (bench.py's roofline leg, rocprof kernel
+  // stats) are taken with it off, because concurrent kernels stretch each other's durations.
   bool split_ok() const { return c.two_stream == 1 && B >= 256 && B % 2 == 0; }
   int fork() {
     static hipStream_t s2 = nullptr; static hipEvent_t ev_f = nullptr;

@@ -105,8 +105,10 @@ class ViewportTransformerMTIO(nn.Module):
 
     # ------------------------------------------------------------------ construction
     def _cfg(self, B, S, inference=False):
-        # two_stream: None = the measured default (on for sample(), off for training); True / False force it
-        two = inference if self.two_stream is None else bool(self.two_stream)
+        # two_stream: None = on (the engine applies it for B >= 256, even: sample() +4 %, train step +1.8 % at B = 4096); True / False
+        # force it.  Per-kernel timings (bench.py's roofline leg, rocprof kernel stats) are taken with it off: concurrent kernels
+        # stretch each other's durations.
+        two = True if self.two_stream is None else bool(self.two_stream)
         return VPConfig(B=B, S=S, T=self.fut_window, d_model=self.d_model, n_head=_N_HEAD, d_ff=self.dim_feedforward,
                         n_enc=self.num_encoder_layers, n_dec=self.num_decoder_layers, in_ch=self.in_channel * self.num_head,
                         has_bias=int(self.has_bias), p_pe=self.dropout_p, p_drop=self.attn_dropout_p, ln_eps=1e-5, bn_eps=1e-5,

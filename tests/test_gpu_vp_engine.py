@@ -481,7 +481,7 @@ def test_two_stream_half_batch_decoder_equals_single_stream(MT):
     streams -- every launch on the rows [b0, b0 + n) of the full slabs, dropout masks drawn at the rows' own indices
     (MansyDrop::base).  Same function: with dropout ON, sample(), the loss and the post-step weights must equal the single-stream
     run (forward bit for bit; the weight gradients sum rows in a different grouping, so the updated weights agree to fp32 rounding /
-    Adam noise).  Default (None): on for sample(), off for training."""
+    Adam noise).  Default (None): on."""
     B = 512
     h, c, f = (t.cuda() for t in vo.synthetic_trajectories(B, 10, 10, seed=9))
     out = {}
@@ -489,7 +489,7 @@ def test_two_stream_half_batch_decoder_equals_single_stream(MT):
         m = MT.ViewportTransformerMTIO(in_channel=2, fut_window=10, d_model=256, dim_feedforward=256, device='cuda', seed=11)
         m.load_state_dict(vo.make_state_dict(256, 4, bias=True))
         m = m.to('cuda')
-        assert m.two_stream is None and m._cfg(B, 10).two_stream == 0 and m._cfg(B, 10, inference=True).two_stream == 1
+        assert m.two_stream is None and m._cfg(B, 10).two_stream == 1 and m._cfg(B, 10, inference=True).two_stream == 1
         m.two_stream = split == '1'
         m.eval()
         with torch.no_grad():

@@ -5,6 +5,8 @@ on gfx950 FETCH_SIZE reports half of a wide streaming read (MI355X_MICROARCH.md,
 import csv, glob, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mansy_immersivevideostreaming_amd import build_ext  # noqa: E402
 
 
 KERNEL = 'gemm_f32'
@@ -30,6 +32,7 @@ write, n2 = total('pmc_w', 'WRITE_SIZE')
 assert n == n2 and n > 0, (n, n2)
 out = {'kernel': 'gemm_f32_dma_kernel / gemm_f32_kernel' if KERNEL == 'gemm_f32' else 'gemm_bf16s_kernel / gemm_bf16p_kernel', 'launches': n, 'fetch_bytes_per_launch': 2.0 * fetch / n, 'write_bytes_per_launch': write / n,
        'traffic_bytes_per_launch': (2.0 * fetch + write) / n, 'algorithmic_bytes_per_launch': alg,
+       'gemm_source_digest': build_ext.gemm_source_digest(),      # bench.py flags the figure as stale when the kernels have changed since
        'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over 2 train steps (B=4096, 285 GEMM launches per step); '
                'FETCH_SIZE x2 per the gfx950 correction (MI355X_MICROARCH.md, HBM); the counters sit at the L2<->fabric boundary, so '
                'Infinity-Cache hits are included'}
