@@ -197,7 +197,9 @@ int mansy_policy_env_step(const float* const* params, const float* obs, int n_en
                           uint32_t seed, uint32_t site, int reuse_packed, void* workspace, int max_batch, const mansy_env_tables* T,
                           void* env_state, float* obs_next, float* obs_cur, float* reward, unsigned char* done, float* qoe_parts,
                           const mansy_env_episode_log* elog, void* stream);
-int mansy_policy_evaluate(const float* const* params, const float* obs, int B, const int* act, float* logp, float* value,
+/* logits' log-probabilities of the given actions for the first n_logp rows (logp != NULL) and / or the critic's value for all B rows.
+ * process_fn calls it once on the 2 x 4096 rows [obs ; obs_next] of one rollout buffer: v_s, v_s_ and logp_old in one pass. */
+int mansy_policy_evaluate(const float* const* params, const float* obs, int B, const int* act, int n_logp, float* logp, float* value,
                           void* workspace, int max_batch, void* stream);
 int mansy_identifier_forward(const float* const* params, const float* obs, int B, float* pred /* [B,16], 3 used */, void* workspace,
                              int max_batch, void* stream);

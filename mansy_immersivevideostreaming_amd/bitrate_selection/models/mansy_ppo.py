@@ -31,8 +31,9 @@ class RolloutBuffer:
     def __init__(self, T, N, device):
         self.T, self.N, self.device = T, N, device
         f32 = dict(dtype=torch.float32, device=device)
-        self.obs = torch.zeros(T, N, OBS_LD, **f32)
-        self.obs_next = torch.zeros(T, N, OBS_LD, **f32)
+        # obs and obs_next are the two halves of ONE slab: a full buffer is 2 T N contiguous rows, which process_fn evaluates in one pass
+        self.obs2 = torch.zeros(2, T, N, OBS_LD, **f32)
+        self.obs, self.obs_next = self.obs2[0], self.obs2[1]
         self.act = torch.zeros(T, N, dtype=torch.int32, device=device)
         self.logp = torch.zeros(T, N, **f32)
         self.rew = torch.zeros(T, N, **f32)
@@ -209,7 +210,7 @@ class PPOPolicy(nn.Module):
         self.cnt, self.observe_round = 0, 1000
         self.updating = False
         self.lr_scheduler = None
-        self.engine = NetEngine(actor=actor, critic=critic, identifier=identifier, max_batch=4096)
+        self.engine = NetEngine(actor=actor, critic=critic, identifier=identifier, max_batch=8192)
         self._rms = None
         self._seed_ctr = 0
         self.world, self.grad_sync = 1, None
@@ -339,12 +340,20 @@ class PPOPolicy(nn.Module):
         v_s = torch.empty(n, dtype=torch.float32, device=dev)
         v_next = torch.empty(n, dtype=torch.float32, device=dev)
         logp_old = torch.empty(n, dtype=torch.float32, device=dev)
-        for s in range(0, n, eng.max_batch):
-            e = min(n, s + eng.max_batch)
-            check(lib().mansy_policy_evaluate(arr, ptr(obs[s:e]), e - s, ptr(act[s:e]), ptr(logp_old[s:e]), ptr(v_s[s:e]), ptr(eng.workspace()),
-                                              eng.max_batch, stream_ptr(dev)), 'mansy_policy_evaluate')
-            check(lib().mansy_policy_evaluate(arr, ptr(obs_next[s:e]), e - s, None, None, ptr(v_next[s:e]), ptr(eng.workspace()), eng.max_batch,
+        joint = getattr(buffer, 'obs2', None)
+        if joint is not None and T == buffer.T and 2 * n <= eng.max_batch and obs.data_ptr() == joint.data_ptr():
+            # [obs ; obs_next] are 2 n contiguous rows: values of both halves and logp_old of the first in ONE pass (5 launches for 9)
+            v_all = torch.empty(2 * n, dtype=torch.float32, device=dev)
+            check(lib().mansy_policy_evaluate(arr, ptr(joint), 2 * n, ptr(act), n, ptr(logp_old), ptr(v_all), ptr(eng.workspace()), eng.max_batch,
                                               stream_ptr(dev)), 'mansy_policy_evaluate')
+            v_s, v_next = v_all[:n], v_all[n:]
+        else:
+            for s in range(0, n, eng.max_batch):
+                e = min(n, s + eng.max_batch)
+                check(lib().mansy_policy_evaluate(arr, ptr(obs[s:e]), e - s, ptr(act[s:e]), e - s, ptr(logp_old[s:e]), ptr(v_s[s:e]),
+                                                  ptr(eng.workspace()), eng.max_batch, stream_ptr(dev)), 'mansy_policy_evaluate')
+                check(lib().mansy_policy_evaluate(arr, ptr(obs_next[s:e]), e - s, None, 0, None, ptr(v_next[s:e]), ptr(eng.workspace()),
+                                                  eng.max_batch, stream_ptr(dev)), 'mansy_policy_evaluate')
         returns = torch.empty(n, dtype=torch.float32, device=dev)
         adv = torch.empty(n, dtype=torch.float32, device=dev)
         scratch = torch.empty(n + 2, dtype=torch.float64, device=dev)

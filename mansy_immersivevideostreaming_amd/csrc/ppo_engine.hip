@@ -527,7 +527,7 @@ __global__ __launch_bounds__(1024) void bc_loss_kernel(const float* __restrict__
 
 // MSE(pred[B,3], obs[:,745:748]) forward + gradient wrt the PRE-sigmoid output (pred = sigmoid(z))
 __global__ __launch_bounds__(256) void ident_mse_kernel(const float* __restrict__ pred, const float* __restrict__ obs, int B, float* __restrict__ dz,
-                                                        double* __restrict__ acc) {
+                                                        double* __restrict__ acc, float* __restrict__ loss) {
   double local = 0.0;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < B * 3; i += gridDim.x * 256) {
     const int r = i / 3, k = i % 3;
@@ -539,8 +539,18 @@ __global__ __launch_bounds__(256) void ident_mse_kernel(const float* __restrict_
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o, 64);
   if ((threadIdx.x & 63) == 0) atomicAdd(acc, local);
+  // the last workgroup to arrive turns the sum into the loss (was a second, one-thread launch): acc[1] is the arrival counter,
+  // zeroed with acc[0] by the pack launch's riders
+  __shared__ int last;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicAdd(reinterpret_cast<unsigned*>(acc + 1), 1u) + 1u == gridDim.x;
+  __syncthreads();
+  if (last && threadIdx.x == 0) {
+    const double tot = __hip_atomic_load(acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *loss = (float)(tot / (double)(B * 3));
+  }
 }
-__global__ void ident_mse_finish(const double* acc, int B, float* loss) { *loss = (float)(*acc / (double)(B * 3)); }
 
 // rew <- (1 - lamb) * rew + lamb * (1 - mean_k (pred_k - w_k)^2)     (mansy_ppo.py:43-48, mansy_utils.py:42-49)
 __global__ __launch_bounds__(256) void relabel_kernel(const float* __restrict__ pred, const float* __restrict__ obs, float* __restrict__ rew,
@@ -596,6 +606,52 @@ __global__ __launch_bounds__(256) void ret_finish_kernel(const double* __restric
   const double scale = rew_norm ? sqrt(rms[1] + eps) : 1.0;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i < n) ret_out[i] = (float)(ret_unnorm[i] / scale);
+}
+// The four kernels below as ONE single-workgroup launch for N <= 1024 environments (the rollout sizes of run_mansy.py: 256):
+// scan, statistics of the un-normalised returns, normalisation with the OLD variance, then the running-moment merge -- the
+// phases are separated by workgroup barriers instead of kernel boundaries (4 launches -> 1).  Same arithmetic, same order.
+__global__ __launch_bounds__(1024) void gae_fused_kernel(const float* __restrict__ rew, const float* __restrict__ v_s, const float* __restrict__ v_next,
+                                                        const unsigned char* __restrict__ done, int T, int N, double gamma, double lam,
+                                                        double* __restrict__ rms, int rew_norm, double eps, double* __restrict__ ret_unnorm,
+                                                        float* __restrict__ adv, float* __restrict__ ret_out) {
+  __shared__ double sh[2][16];
+  __shared__ double sh_scale;
+  const long long n = (long long)T * N;
+  const double v_scale = rew_norm ? sqrt(rms[1] + eps) : 1.0;        // every thread reads the OLD variance before anyone merges
+  const int e = threadIdx.x;
+  if (e < N) {
+    double gae = 0.0;
+    for (int t = T - 1; t >= 0; --t) {
+      const size_t i = (size_t)t * N + e;
+      const double vs = (double)v_s[i] * v_scale;
+      const double dn = done[i] ? 1.0 : 0.0;
+      const double vn = (double)v_next[i] * v_scale * (1.0 - dn);
+      const double end = (done[i] || t == T - 1) ? 1.0 : 0.0;
+      const double delta = (double)rew[i] + gamma * vn - vs;
+      gae = delta + (1.0 - end) * gamma * lam * gae;
+      adv[i] = (float)gae;
+      ret_unnorm[i] = gae + vs;
+    }
+  }
+  __syncthreads();
+  double s = 0.0, q = 0.0;
+  for (long long i = threadIdx.x; i < n; i += blockDim.x) { const double x = ret_unnorm[i]; s += x; q += x * x; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s; sh[1][threadIdx.x >> 6] = q; }
+  if (threadIdx.x == 0) sh_scale = v_scale;
+  __syncthreads();
+  for (long long i = threadIdx.x; i < n; i += blockDim.x) ret_out[i] = (float)(ret_unnorm[i] / sh_scale);
+  if (threadIdx.x == 0 && rew_norm) {
+    double ts = 0.0, tq = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { ts += sh[0][i]; tq += sh[1][i]; }
+    ret_unnorm[n] = ts; ret_unnorm[n + 1] = tq;                    // (the `part` slots of the four-launch form)
+    const double bm = ts / (double)n, bv = tq / (double)n - bm * bm;
+    const double delta = bm - rms[0], tot = rms[2] + (double)n;
+    const double new_mean = rms[0] + delta * (double)n / tot;
+    const double m2 = rms[1] * rms[2] + bv * (double)n + delta * delta * rms[2] * (double)n / tot;
+    rms[0] = new_mean; rms[1] = m2 / tot; rms[2] = tot;
+  }
 }
 __global__ void rms_merge_kernel(double* rms, const double* part, long long n) {
   const double bm = part[0] / (double)n, bv = part[1] / (double)n - bm * bm;
@@ -1053,8 +1109,8 @@ int mansy_identifier_train_step(const float* const* params, float* const* grads,
   RC(e.head(n, B, 3, 1, e.W.A1a, e.W.Ha, e.W.outa, nullptr, 0, 0, nullptr, nullptr));
   const bool train = step != 0;      // (W.acc[0], the loss accumulator, was zeroed by the pack launch's riders)        // step < 0: gradients only (data-parallel callers all-reduce, then mansy_clip_grad_adam)
   // (gout needs no zero-fill: head_out_bwd_kernel selects columns < n_out and never uses the rest)
-  hipLaunchKernelGGL(ident_mse_kernel, dim3(min(mansy_ceil_div(B * 3, 256), 256)), dim3(256), 0, e.st, e.W.outa, obs, B, train ? e.W.gout : nullptr, e.W.acc);
-  hipLaunchKernelGGL(ident_mse_finish, dim3(1), dim3(1), 0, e.st, e.W.acc, B, loss_out);
+  hipLaunchKernelGGL(ident_mse_kernel, dim3(min(mansy_ceil_div(B * 3, 256), 256)), dim3(256), 0, e.st, e.W.outa, obs, B, train ? e.W.gout : nullptr, e.W.acc,
+                     loss_out);
   MANSY_LAUNCH_CHECK();
   if (!train) return MANSY_OK;
   MANSY_REQUIRE(grads && flat_p && flat_g && flat_m && flat_v, "identifier_train_step: null optimiser buffers");
@@ -1079,9 +1135,12 @@ int mansy_identifier_relabel(const float* const* params, const float* obs, float
 }
 
 // log-prob of given actions under logits [B,16]
-int mansy_policy_evaluate(const float* const* params, const float* obs, int B, const int* act, float* logp, float* value, void* workspace,
+// n_logp: log-probabilities are wanted for the first n_logp rows only (process_fn evaluates obs and obs_next -- 2 x 4096 rows of
+// one buffer -- in ONE pass: values for all rows, log-probabilities of the taken actions for the obs half)
+int mansy_policy_evaluate(const float* const* params, const float* obs, int B, const int* act, int n_logp, float* logp, float* value, void* workspace,
                           int max_batch, void* stream) {
   MANSY_REQUIRE(params && obs && B >= 1 && B <= max_batch, "policy_evaluate: bad arguments");
+  MANSY_REQUIRE(!logp || (n_logp >= 1 && n_logp <= B), "policy_evaluate: n_logp must be in [1, B] when log-probabilities are wanted");
   PEng e; RC(setup(workspace, max_batch, (hipStream_t)stream, e));
   NetP a, c; bind_net(params, nullptr, 20, a); bind_net(params, nullptr, 24, c);
   const bool both = logp && value;
@@ -1091,7 +1150,7 @@ int mansy_policy_evaluate(const float* const* params, const float* obs, int B, c
   if (both) RC(e.head_pair(a, c, B, nullptr, value));      // actor + critic in one stacked product; the value lands in `value`
   if (logp) {
     if (!both) RC(e.head(a, B, NACT, 0, e.W.A1a, e.W.Ha, e.W.outa, nullptr, 0, 0, nullptr, nullptr));
-    hipLaunchKernelGGL(logp_kernel, dim3(mansy_ceil_div(B, 256)), dim3(256), 0, e.st, e.W.outa, act, B, logp);
+    hipLaunchKernelGGL(logp_kernel, dim3(mansy_ceil_div(n_logp, 256)), dim3(256), 0, e.st, e.W.outa, act, n_logp, logp);
     MANSY_LAUNCH_CHECK();
   }
   if (value && !both) RC(e.head(c, B, 1, 0, e.W.A1c, e.W.Hc, value, nullptr, 0, 0, nullptr, nullptr, nullptr, 1));
@@ -1107,6 +1166,12 @@ int mansy_gae_returns(const float* rew, const float* v_s, const float* v_next, c
   hipStream_t st = (hipStream_t)stream;
   const long long n = (long long)T * N;
   double* part = scratch + n;
+  if (N <= 1024) {
+    hipLaunchKernelGGL(gae_fused_kernel, dim3(1), dim3(1024), 0, st, rew, v_s, v_next, done, T, N, (double)gamma, (double)gae_lambda, rms, rew_norm, 1e-8,
+                       scratch, adv, returns);
+    MANSY_LAUNCH_CHECK();
+    return MANSY_OK;
+  }
   hipLaunchKernelGGL(gae_kernel, dim3(mansy_ceil_div(N, 256)), dim3(256), 0, st, rew, v_s, v_next, done, T, N, (double)gamma, (double)gae_lambda,
                      rms, rew_norm, 1e-8, scratch, adv);
   hipLaunchKernelGGL(ret_stats_kernel, dim3(1), dim3(1024), 0, st, scratch, n, part);

@@ -194,9 +194,9 @@ def test_ppo_minibatch_loss_grads_clip_adam_vs_oracle(M):
     assert (np.sign(delta[big]) == -np.sign(mm_[big])).all()
 
 
-def test_gae_and_return_normaliser_vs_oracle(M):
+@pytest.mark.parametrize('T,N', [(16, 40), (16, 256), (3, 1100)])       # N <= 1024: the single-launch form; above: four launches
+def test_gae_and_return_normaliser_vs_oracle(M, T, N):
     from mansy_immersivevideostreaming_amd._lib import check, lib, ptr, stream_ptr
-    T, N = 16, 40
     rs = np.random.RandomState(2)
     rms_o = po.RunningMeanStd()
     rms_d = torch.tensor([0.0, 1.0, 0.0], dtype=torch.float64, device='cuda')
