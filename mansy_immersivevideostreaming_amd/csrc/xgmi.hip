@@ -13,8 +13,8 @@
 // epoch e + 2 only after it has seen every peer at epoch e + 1, i.e. after every peer's launch of epoch e -- the last reader of
 // that slot -- has completed.
 // Placement-independent and bounded: the wait gives up after `timeout_ms`, poisons its output with NaN and raises the context's
-// sticky error (mansy_xg_status), it never hangs the queue.  Grid = 64 workgroups, so the launches of all ranks are co-resident
-// even when several ranks share one GPU (the functional test: two processes on one device).
+// sticky error (mansy_xg_status), it never hangs the queue.  Grid = 64 workgroups of 256 threads, so the launches of all ranks
+// are co-resident even when they share one GPU (the functional test: several processes on one device).
 #include <vector>
 #include "mansy_kernels.h"
 #include "../../include/mansy_hip.h"
@@ -39,18 +39,28 @@ struct XgCtx {
   double timeout_ms = 2000.0;
 };
 
-__global__ __launch_bounds__(256) void xg_allreduce_kernel(float* __restrict__ g, long long n4, XgPeers peers, float* __restrict__ own_slot,
+constexpr int XG_THREADS = 256;        // (1 024-thread workgroups measured 1.4-1.9x slower: profiles/r03_xg_timing.txt history)
+__global__ __launch_bounds__(XG_THREADS) void xg_allreduce_kernel(float* __restrict__ g, long long n4, XgPeers peers, float* __restrict__ own_slot,
                                                           unsigned* __restrict__ own_flag, long long slot_off, int rank, int world, unsigned epoch,
                                                           float inv_world, double* __restrict__ parts, unsigned* __restrict__ counter, unsigned target,
                                                           int* __restrict__ err, long long timeout_ticks) {
-  const long long gtid = (long long)blockIdx.x * 256 + threadIdx.x, gsize = (long long)gridDim.x * 256;
+  const long long gtid = (long long)blockIdx.x * XG_THREADS + threadIdx.x, gsize = (long long)gridDim.x * XG_THREADS;
   // 1. publish this rank's gradient
-  for (long long i = gtid; i < n4; i += gsize) reinterpret_cast<float4*>(own_slot)[i] = reinterpret_cast<const float4*>(g)[i];
-  __threadfence_system();                                   // this thread's stores are visible to every agent ...
-  __syncthreads();                                          // ... and so are the workgroup's
+  for (long long i0 = gtid; i0 < n4; i0 += gsize * 4) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const long long i = i0 + (long long)u * gsize; v[u] = reinterpret_cast<const float4*>(g)[i < n4 ? i : n4 - 1]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const long long i = i0 + (long long)u * gsize; if (i < n4) reinterpret_cast<float4*>(own_slot)[i] = v[u]; }
+  }
+  // every storing wave drains its stores, the workgroup meets, then ONE lane releases at system scope (the release is cumulative
+  // over the barrier's happens-before) -- a system-scope fence in every thread cost a cache write-back per wave
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   __shared__ int timed_out;
   if (threadIdx.x == 0) {
     timed_out = 0;
+    __atomic_thread_fence(__ATOMIC_RELEASE);                // system scope
     const unsigned prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     if (prev + 1u == target) __hip_atomic_store(own_flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
@@ -67,23 +77,38 @@ __global__ __launch_bounds__(256) void xg_allreduce_kernel(float* __restrict__ g
   __atomic_thread_fence(__ATOMIC_ACQUIRE);                  // system scope: the peers' slots as published
   const bool bad = timed_out != 0;
   // 3. reduce in rank order, average, sum of squares
+  // UN elements per thread and round, every load of a round requested before the first is used (a peer's HBM over a link is a
+  // microsecond away; with one element per round a thread paid that latency ceil(n4 / threads) times in sequence)
+  constexpr int UN = 4;
   double sq = 0.0;
-  for (long long i = gtid; i < n4; i += gsize) {
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (long long i0 = gtid; i0 < n4; i0 += gsize * UN) {
+    float4 acc[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int p = 0; p < world; ++p) {
-      const float4 v = reinterpret_cast<const float4*>(peers.data[p] + slot_off)[i];
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      const float4* src = reinterpret_cast<const float4*>(peers.data[p] + slot_off);
+      float4 v[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) { const long long i = i0 + (long long)u * gsize; v[u] = src[i < n4 ? i : n4 - 1]; }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) { acc[u].x += v[u].x; acc[u].y += v[u].y; acc[u].z += v[u].z; acc[u].w += v[u].w; }
     }
-    s.x *= inv_world; s.y *= inv_world; s.z *= inv_world; s.w *= inv_world;
-    if (bad) s.x = s.y = s.z = s.w = __builtin_nanf("");
-    reinterpret_cast<float4*>(g)[i] = s;
-    sq += ((double)s.x * s.x + (double)s.y * s.y) + ((double)s.z * s.z + (double)s.w * s.w);
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const long long i = i0 + (long long)u * gsize;
+      if (i >= n4) continue;
+      float4 s = acc[u];
+      s.x *= inv_world; s.y *= inv_world; s.z *= inv_world; s.w *= inv_world;
+      if (bad) s.x = s.y = s.z = s.w = __builtin_nanf("");
+      reinterpret_cast<float4*>(g)[i] = s;
+      sq += ((double)s.x * s.x + (double)s.y * s.y) + ((double)s.z * s.z + (double)s.w * s.w);
+    }
   }
   if (!parts) return;
-  __shared__ double red[256];
+  __shared__ double red[XG_THREADS];
   red[threadIdx.x] = sq;
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
+  for (int o = XG_THREADS / 2; o > 0; o >>= 1) {
     if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
@@ -163,7 +188,7 @@ int mansy_xg_allreduce_avg(void* ctx, float* g, long long n, double* sumsq_parts
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, dev);
   if (wall_khz <= 0) wall_khz = 100000;
   const long long ticks = (long long)(c->timeout_ms * (double)wall_khz);
-  hipLaunchKernelGGL(xg_allreduce_kernel, dim3(XG_BLOCKS), dim3(256), 0, (hipStream_t)stream, g, n / 4, peers, c->own + XG_HEADER_FLOATS + slot_off,
+  hipLaunchKernelGGL(xg_allreduce_kernel, dim3(XG_BLOCKS), dim3(XG_THREADS), 0, (hipStream_t)stream, g, n / 4, peers, c->own + XG_HEADER_FLOATS + slot_off,
                      reinterpret_cast<unsigned*>(c->own), slot_off, c->rank, c->world, c->epoch, 1.0f / (float)c->world, sumsq_parts, c->counter,
                      (unsigned)(c->launches * XG_BLOCKS), c->err, ticks);
   MANSY_LAUNCH_CHECK();

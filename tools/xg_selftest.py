@@ -34,13 +34,16 @@ def main():
         mine.append(gs[rank].to(dev))
     torch.cuda.synchronize()
     dist.barrier()
+    parts = [torch.empty(64, dtype=torch.float64, device=dev) for _ in range(iters)]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    e0.record()
     for it in range(iters):
-        sc = torch.empty(64, dtype=torch.float64, device=dev)
-        sync(mine[it], sc)                                                          # in place
-        parts.append(sc)
+        sync(mine[it], parts[it])                                                   # in place
+    e1.record()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    dev_us = e0.elapsed_time(e1) / iters * 1e3
     sync.check()
     bad, sq_err = 0, 0.0
     for it in range(iters):
@@ -55,7 +58,7 @@ def main():
     sync.check()
     mean_ok = bool((x == sum(range(1, world + 1)) / world).all())
     out = dict(rank=rank, world=world, n=n, iters=iters, mismatched_elements=bad, sumsq_rel_err=sq_err, plain_call_ok=mean_ok,
-               us_per_call=round(dt / iters * 1e6, 1))
+               us_per_call=round(dt / iters * 1e6, 1), device_us_per_call=round(dev_us, 1))
     gathered = [None] * world
     dist.all_gather_object(gathered, out)
     sync.close()
