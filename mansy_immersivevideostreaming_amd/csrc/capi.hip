@@ -58,6 +58,8 @@ int mansy_gemm_planes(const float* A, int lda, const float* B, int ldb, int b_km
     e.drop.p = ep->drop_p; e.drop.seed = ep->drop_seed; e.drop.site = ep->drop_site;
     e.resid = ep->resid; e.resid_ld = ep->resid_ld; e.accumulate = ep->accumulate; e.prec = ep->prec;
   }
+  MANSY_REQUIRE(force_tile == 0 || force_tile == 64 || force_tile == 96 || force_tile == 128 || force_tile == 256,
+                "gemm_planes: force_tile must be 0, 64, 96 (128x64), 128 or 256 (256x128, bf16x3)");
   e.b_planes = planes; e.b_plane_stride = plane_stride; e.b_planes_ld = planes_ld;
   return mansy_launch_gemm_f32(A, lda, 0, B, ldb, b_kmajor, C, ldc, M, N, K, e, force_tile, 0, (hipStream_t)stream);
 }

@@ -666,6 +666,130 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16f_kernel(GemmParams p) {
   gemm_epilogue<BM, BN, SMEM_FLOATS>(p, acc, smem, m0, n0, tid, 0, p.C);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16x3, 256 x 128 tile, EIGHT waves, THREE LDS stages (round 3).  The 128 x 128 loops above are bound by the LDS fill: with two
+// stages per workgroup one K-tile per workgroup is in flight (2 x 32 KB per CU), and in-flight bytes / loaded round trip is all the
+// fill rate there is.  This loop is two of those workgroups fused -- waves 0-3 own rows 0..127, waves 4-7 rows
+// 128..255 -- sharing ONE B tile (0.75 x the bytes per flop) on a three-stage ring with TWO K-tiles in flight (96 KB per CU):
+//   wait for this wave's pieces of tile t (s_waitcnt vmcnt(6): tile t+1's six pieces stay in flight) -> raw s_barrier (everyone's
+//   pieces of t have landed; everyone is done reading t-1) -> DMA of tile t+2 into the stage t-1 occupied -> fragments + MFMAs of t.
+// No __syncthreads() inside the loop (its fence would drain the DMA queue); 144 KB of LDS, one workgroup (2 waves per SIMD) per CU.
+// A is staged in fp32 and split at fragment read, B comes pre-split, as in gemm_bf16f_kernel.
+__global__ __launch_bounds__(512) void gemm_bf16g_kernel(GemmParams p) {
+  constexpr int BM = 256, BN = 128, TM = 2, TN = 2, NW = 8, PA = BM / (8 * NW), NS = 3;      // PA: A pieces (8 rows x 128 B) per wave and K-tile
+  constexpr int A_BYTES = BM * BK * 4, B_PLANE = BN * 32, B_PLANE_BYTES = B_PLANE * 2;
+  constexpr int STAGE_BYTES = A_BYTES + 2 * B_PLANE_BYTES;                                   // 48 KB
+  constexpr int C_HALF_FLOATS = 128 * (BN + 4);
+  constexpr int SMEM_FLOATS = NS * STAGE_BYTES / 4;
+  static_assert(2 * C_HALF_FLOATS <= SMEM_FLOATS && BN / 16 == NW, "two half-tile epilogues must fit the ring; one B piece per wave and plane");
+  __shared__ __attribute__((aligned(1024))) float smem[SMEM_FLOATS];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, half = wave >> 2, w4 = wave & 3;
+  const int wm = w4 >> 1, wn = w4 & 1;
+  const int r = lane & 31, h = lane >> 5;
+  int tile_x, tile_y;
+  {
+    const int nwg = gridDim.x * gridDim.y, orig = blockIdx.y * gridDim.x + blockIdx.x;
+    const int q = nwg >> 3, rem = nwg & 7, xcd = orig & 7, local = orig >> 3;
+    const int t = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + local;
+    tile_y = t / gridDim.x; tile_x = t - tile_y * gridDim.x;
+  }
+  const int m0 = tile_y * BM, n0 = tile_x * BN;
+  const int nk = p.K / BK;
+
+  unsigned voa[PA];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {          // piece q = i * 8 + wave: rows q * 8 .. + 8
+    const int row = (i * NW + wave) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    voa[i] = (unsigned)((min(m0 + row, p.M - 1) - m0) * p.lda + c * 4) * 4u;
+  }
+  unsigned vob;
+  {
+    const int row = wave * 16 + (lane >> 2), slot = lane & 3;
+    const int q = slot ^ ((row >> 2) & 3);
+    vob = (unsigned)(((min(n0 + row, p.N - 1) - n0) * p.ep.b_planes_ld + q * 8) * 2);
+  }
+  const float* ca = p.A + (long long)m0 * p.lda;
+  const unsigned short* cb = p.ep.b_planes + (long long)n0 * p.ep.b_planes_ld;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem + (unsigned)wave * 1024u);
+  auto dma = [&](int stage, const float* a_corner, const unsigned short* b_corner) {
+    const unsigned base = lds0 + (unsigned)(stage * STAGE_BYTES);
+#pragma unroll
+    for (int i = 0; i < PA; ++i) glds16(voa[i], a_corner, base + (unsigned)i * (NW * 1024u));
+    glds16(vob, b_corner, base + (unsigned)A_BYTES);
+    glds16(vob, b_corner + p.ep.b_plane_stride, base + (unsigned)(A_BYTES + B_PLANE_BYTES));
+  };
+  int fa[TM][2][2], fb[TN][2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row = half * 128 + wm * 64 + i * 32 + r, sw = (row >> 1) & 7, c0 = 4 * s + 2 * h;
+      fa[i][s][0] = row * BK + ((c0 + 0) ^ sw) * 4;
+      fa[i][s][1] = row * BK + ((c0 + 1) ^ sw) * 4;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[j][s] = lds_off<false>(wn * 64 + j * 32 + r, 2 * s + h);
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (nk > 0) dma(0, ca, cb);
+  if (nk > 1) dma(1, ca + BK, cb + BK);
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");       // tile kt landed (this wave's pieces); tile kt+1's 6 stay in flight
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + 2 < nk) dma(cur == 0 ? 2 : cur - 1, ca + (long long)(kt + 2) * BK, cb + (long long)(kt + 2) * BK);     // into the stage tile kt-1 occupied
+    const float* a_l = smem + cur * (STAGE_BYTES / 4);
+    const __bf16* b_l = reinterpret_cast<const __bf16*>(a_l) + A_BYTES / 2;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = *reinterpret_cast<const bf16x8*>(b_l + fb[j][s]);
+        bl[j] = *reinterpret_cast<const bf16x8*>(b_l + B_PLANE + fb[j][s]);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const float4 v0 = *reinterpret_cast<const float4*>(a_l + fa[i][s][0]);
+        const float4 v1 = *reinterpret_cast<const float4*>(a_l + fa[i][s][1]);
+        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const __bf16 t0 = (__bf16)v[e];
+          ah[i][e] = t0;
+          al[i][e] = (__bf16)(v[e] - (float)t0);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    cur = cur == 2 ? 0 : cur + 1;
+  }
+  __syncthreads();
+  // each half of the workgroup is a 128 x 128 tile of the shared epilogue, with its own piece of the (now idle) ring
+  gemm_epilogue<128, 128, C_HALF_FLOATS>(p, acc, smem + half * C_HALF_FLOATS, m0 + half * 128, n0, tid & 255, 0, p.C);
+}
+
 // ---- weights -> bf16 planes (and planes of the transpose), 32 x 32 tiles through LDS
 __global__ __launch_bounds__(256) void weight_planes_kernel(MansyWPlaneTab tab, unsigned short* __restrict__ out, unsigned short* __restrict__ out_t,
                                                            long long plane_stride, int n_planes) {
@@ -740,13 +864,15 @@ int mansy_gemm_bf16s_dispatch(const GemmParams& p, int tile, int prec, int a_kma
 }
 
 // B pre-split into planes (weights): forward / dX products with a K-contiguous A
-static int g_bf16_variant = 1;      // 1: A by LDS-DMA, split at fragment read (gemm_bf16f_kernel); 0: the round-2 loop (A/B tests)
+static int g_bf16_variant = 1;      // 1: A by LDS-DMA, split at fragment read (gemm_bf16g / gemm_bf16f kernels); 4: as 1 without the 256 x 128 loop;
+                                    // 0: the round-2 loop; 2 / 3: timing-only staging / math variants (A/B tests)
 extern "C" int mansy_gemm_bf16_variant(int v) { const int old = g_bf16_variant; if (v >= 0) g_bf16_variant = v; return old; }
 
 int mansy_gemm_bf16p_dispatch(const GemmParams& p, int tile, int prec, hipStream_t st) {
   if (prec == 3 && g_bf16_variant >= 1 && (reinterpret_cast<uintptr_t>(p.A) & 15) == 0 && p.lda % 4 == 0) {
+    if (tile == 256 && p.K < 3 * BK) tile = 128;
     dim3 block(NT);
-    if (g_bf16_variant >= 2) {      // timing-only diagnostics (results wrong): the LDS-fill floor / the math floor of the shape
+    if (g_bf16_variant == 2 || g_bf16_variant == 3) {      // timing-only diagnostics (results wrong): the LDS-fill floor / the math floor of the shape
       const int lab = g_bf16_variant - 1;
       if (tile == 128) { dim3 grid(mansy_ceil_div(p.N, 128), mansy_ceil_div(p.M, 128), 1);
         if (lab == 1) MANSY_GEMM_LAUNCH((gemm_bf16f_kernel<128, 128, 1>), grid, block, st, p); else MANSY_GEMM_LAUNCH((gemm_bf16f_kernel<128, 128, 2>), grid, block, st, p); }
@@ -759,6 +885,11 @@ int mansy_gemm_bf16p_dispatch(const GemmParams& p, int tile, int prec, hipStream
     // round-2 loop on the [40 960-row] products; 64 x 64 tiles ([4 096-row] decoder products) 6 % slower (one K-tile of a 64 x 64
     // tile is 6 MFMAs per wave: the second, redundant fragment conversion is no longer hidden), so those keep the round-2 loop;
     // the 128 x 64 instance loses to both at every shape and is reachable only as force_tile 96
+    if (tile == 256 || (tile == 128 && g_bf16_variant == 1 && (long long)mansy_ceil_div(p.M, 256) * mansy_ceil_div(p.N, 128) >= 256)) {
+      // enough 256 x 128 tiles for every CU: the eight-wave three-stage loop (one workgroup per CU, two K-tiles in flight)
+      dim3 grid(mansy_ceil_div(p.N, 128), mansy_ceil_div(p.M, 256), 1);
+      MANSY_GEMM_LAUNCH(gemm_bf16g_kernel, grid, dim3(512), st, p); MANSY_LAUNCH_CHECK(); return MANSY_OK;
+    }
     if (tile == 128) { dim3 grid(mansy_ceil_div(p.N, 128), mansy_ceil_div(p.M, 128), 1); MANSY_GEMM_LAUNCH((gemm_bf16f_kernel<128, 128>), grid, block, st, p); MANSY_LAUNCH_CHECK(); return MANSY_OK; }
     if (tile == 96) { dim3 grid(mansy_ceil_div(p.N, 64), mansy_ceil_div(p.M, 128), 1); MANSY_GEMM_LAUNCH((gemm_bf16f_kernel<128, 64>), grid, block, st, p); MANSY_LAUNCH_CHECK(); return MANSY_OK; }
   }

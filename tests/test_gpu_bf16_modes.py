@@ -484,7 +484,7 @@ def test_weight_planes_and_presplit_product(K, mode):
     many K-tiles, both tiles, with a fused epilogue."""
     npl = 2 if mode == 'bf16x3' else 3
     g = torch.Generator().manual_seed(8)
-    for (M, N, Kd) in ((4096, 512, 512), (300, 1536, 512), (70, 64, 32), (257, 96, 1536), (2048, 512, 64)):
+    for (M, N, Kd) in ((4096, 512, 512), (300, 1536, 512), (70, 64, 32), (257, 96, 1536), (2048, 512, 64), (40960, 512, 512), (1000, 260, 96)):
         W = torch.randn(N, Kd, generator=g).cuda()
         pl, pl_t = K.weight_planes(W, npl)
         back = sum(pl[t].view(torch.bfloat16).float() for t in range(npl))
@@ -495,7 +495,7 @@ def test_weight_planes_and_presplit_product(K, mode):
         bias, resid = torch.randn(N, generator=g).cuda(), torch.randn(M, N, generator=g).cuda()
         ref_f = A.double() @ W.double().t()
         ref_b = G.double() @ W.double()
-        for tile in (0, 64, 128):
+        for tile in (0, 64, 128, 256):        # 256: the eight-wave 256 x 128 three-stage loop (bf16x3); 0 at [40 960, 512] picks it by itself
             with K.precision(mode):
                 Cf = K.gemm_planes(A, W, pl, transposed=False, force_tile=tile)
                 Cb = K.gemm_planes(G, W, pl_t, transposed=True, force_tile=tile)
