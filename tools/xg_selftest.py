@@ -20,12 +20,13 @@ def main():
     rank, world, local = mdist.init_process_group(backend='gloo', force=True)
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
-    n, iters = 427024 // 4 * 4 + 64, 40
+    n, iters = 427024 // 4 * 4 + 64, int(os.environ.get('XG_ITERS', '40'))
     n = (n + 63) // 64 * 64
+    distinct = min(iters, 40)          # long runs (XG_ITERS=3000: a race screen) cycle through 40 distinct gradients
     sync = mdist.PeerGradSync(n, world, rank, dev, timeout_ms=5000)
     gens = [torch.Generator().manual_seed(100 + r) for r in range(world)]
     mine, want, got, parts = [], [], [], []
-    for it in range(iters):
+    for it in range(distinct):
         gs = [torch.randn(n, generator=g) * (1.0 + 0.1 * it) for g in gens]        # every rank can form every rank's gradient
         acc = torch.zeros(n)
         for r in range(world):
@@ -34,19 +35,27 @@ def main():
         mine.append(gs[rank].to(dev))
     torch.cuda.synchronize()
     dist.barrier()
-    parts = [torch.empty(64, dtype=torch.float64, device=dev) for _ in range(iters)]
+    parts = [torch.empty(64, dtype=torch.float64, device=dev) for _ in range(distinct)]
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
+    src = [m.clone() for m in mine]
+    bad_rounds = 0
     for it in range(iters):
-        sync(mine[it], parts[it])                                                   # in place
+        k = it % distinct
+        if it >= distinct:                      # restore the input of this slot (device copy, stream-ordered) and check the previous use
+            if it % distinct == 0:
+                torch.cuda.synchronize()
+                bad_rounds += sum(int((mine[j].cpu() != want[j]).sum() > 0) for j in range(distinct))
+            mine[k].copy_(src[k])
+        sync(mine[k], parts[k])                                                     # in place
     e1.record()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     dev_us = e0.elapsed_time(e1) / iters * 1e3
     sync.check()
     bad, sq_err = 0, 0.0
-    for it in range(iters):
+    for it in range(distinct):
         g = mine[it].cpu()
         bad += int((g != want[it]).sum())
         ref = float((want[it].double() ** 2).sum())
@@ -57,7 +66,7 @@ def main():
     torch.cuda.synchronize()
     sync.check()
     mean_ok = bool((x == sum(range(1, world + 1)) / world).all())
-    out = dict(rank=rank, world=world, n=n, iters=iters, mismatched_elements=bad, sumsq_rel_err=sq_err, plain_call_ok=mean_ok,
+    out = dict(rank=rank, world=world, n=n, iters=iters, mismatched_elements=bad, bad_rounds=bad_rounds, sumsq_rel_err=sq_err, plain_call_ok=mean_ok,
                us_per_call=round(dt / iters * 1e6, 1), device_us_per_call=round(dev_us, 1))
     gathered = [None] * world
     dist.all_gather_object(gathered, out)
