@@ -241,6 +241,13 @@ int mansy_bc_step(const float* const* params, float* const* grads, float* flat_p
 int mansy_clip_grad_adam(float* flat_p, float* flat_g, float* flat_m, float* flat_v, long long n_flat, float max_grad_norm, float lr,
                          float weight_decay, int step, long long tail_from, int tail_step, double* scratch, int have_sumsq, void* stream);
 
+/* Data-parallel form of the chained step's last launch (after the ranks averaged the raw gradients of a step = 0 call): clip by the
+ * global norm, Adam(L2), zero flat_g, re-pack the updated parameters into the workspace's packed images and prepare the next
+ * minibatch (next_mb > 0) -- the next mansy_ppo_minibatch_step(step = 0) then passes chain_in = 1.  Actor-critic buffers only. */
+int mansy_ppo_dp_tail(const float* const* params, float* flat_p, float* flat_g, float* flat_m, float* flat_v, long long n_flat,
+                      float max_grad_norm, float lr, float weight_decay, int step, double* scratch, int have_sumsq, const float* obs_all,
+                      const float* adv_all, const int* next_idx, int next_mb, void* workspace, int max_batch, void* stream);
+
 /* ------------------------------------------------------------------ one-shot gradient all-reduce over peer-mapped memory (xGMI)
  * The data-parallel PPO update averages a 1.7 MB / 1.05 MB flat gradient 16 + 2 times per 2.6 ms cycle, every time on
  * the critical path.  Instead of a library all-reduce launch + a separate gradient-norm launch, each rank runs ONE kernel that

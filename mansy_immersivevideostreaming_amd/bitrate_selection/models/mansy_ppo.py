@@ -229,14 +229,24 @@ class PPOPolicy(nn.Module):
                 if f is not None:
                     self._peer[id(f)] = PeerGradSync(f.flat_p.numel(), self.world, tdist.get_rank(), f.flat_p.device)
 
-    def _sync_clip_adam(self, f, max_norm, lr, wd):
-        """Data-parallel second half of a step: average the raw local gradients over the ranks, then global-norm clip + Adam."""
+    def _sync_clip_adam(self, f, max_norm, lr, wd, tail=None):
+        """Data-parallel second half of a step: average the raw local gradients over the ranks, then global-norm clip + Adam.
+        tail = (data, next_idx or None): the chained form (actor-critic, clipped): the clip + Adam launch also zeroes the
+        gradients, re-packs the updated parameters and prepares the next minibatch (mansy_ppo_dp_tail)."""
         peer = self._peer.get(id(f)) if getattr(self, '_peer', None) else None
         scratch = torch.empty(64, dtype=torch.float64, device=f.flat_p.device)      # MANSY_CLIP_SCRATCH_DOUBLES
         if peer is not None:
             peer(f.flat_g, scratch)
         else:
             self.grad_sync(f.flat_g)
+        if tail is not None:
+            data, nxt = tail
+            arr, _ = f.pointers()
+            check(lib().mansy_ppo_dp_tail(arr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), float(max_norm), lr, wd, f.step,
+                                          ptr(scratch), int(peer is not None), ptr(data['obs']), ptr(data['adv']), ptr(nxt),
+                                          nxt.numel() if nxt is not None else 0, ptr(self.engine.workspace()), self.engine.max_batch,
+                                          stream_ptr(f.flat_p.device)), 'mansy_ppo_dp_tail')
+            return
         check(lib().mansy_clip_grad_adam(ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), float(max_norm), lr, wd, f.step,
                                          *f.tail(), ptr(scratch), int(peer is not None), stream_ptr(f.flat_p.device)), 'mansy_clip_grad_adam')
 
@@ -380,7 +390,7 @@ class PPOPolicy(nn.Module):
         # every pass's permutation is drawn up front, in the order tianshou draws them (one np.random.permutation per pass, nothing
         # else consumes the generator in between), so that each step's last launch can prepare the next step's minibatch
         passes = [list(split_indices(n, batch_size)) for _ in range(repeat)]
-        chain = self.chain_steps and not dp and float(self._grad_norm or 0.0) > 0.0 and f.tail()[0] < 0   # the step form that ends in step_tail
+        chain = self.chain_steps and float(self._grad_norm or 0.0) > 0.0 and f.tail()[0] < 0   # the step forms that end in step_tail / dp_tail
         perms = [torch.from_numpy(np.concatenate(chunks).astype(np.int32)).to(dev) for chunks in passes]      # one upload per pass
         flat = []                                                            # (pass, k, idx view) of every minibatch step, in order
         for pi, chunks in enumerate(passes):
@@ -398,10 +408,11 @@ class PPOPolicy(nn.Module):
                                                  ptr(data['returns']), idx.numel(), self._eps_clip, self._weight_vf, self._weight_ent,
                                                  int(self._norm_adv), int(self._value_clip), 0.0 if dp else float(self._grad_norm or 0.0), lr, wd,
                                                  0 if dp else f.step, *f.tail(), ptr(stats_all[pi][k]), ptr(eng.workspace()), eng.max_batch,
-                                                 int(chain and s > 0), ptr(nxt), nxt.numel() if nxt is not None else 0, stream_ptr(dev)),
+                                                 int(chain and s > 0), ptr(None if dp else nxt), nxt.numel() if (nxt is not None and not dp) else 0,
+                                                 stream_ptr(dev)),
                   'mansy_ppo_minibatch_step')
-            if dp:                              # raw local gradients -> average over the ranks -> global-norm clip + Adam
-                self._sync_clip_adam(f, float(self._grad_norm or 0.0), lr, wd)
+            if dp:                              # raw local gradients -> average over the ranks -> global-norm clip + Adam (+ next prologue)
+                self._sync_clip_adam(f, float(self._grad_norm or 0.0), lr, wd, tail=(data, nxt) if chain else None)
         return LazyLosses(('loss', 'loss/clip', 'loss/vf', 'loss/ent'), stats_all)
 
     def bc_step(self, obs, act, ent_coef=0.1, train=True):

@@ -1203,7 +1203,10 @@ int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, fl
   MANSY_REQUIRE(next_mb >= 0 && next_mb <= max_batch && (next_mb == 0 || !idx == !next_idx), "ppo_minibatch_step: bad next minibatch");
   const bool lagged = tail_from >= 0 && tail_from < n_flat && tail_step != step;
   const bool chain_ok = max_grad_norm > 0.f && step > 0 && !lagged;       // the step that ends in step_tail
-  MANSY_REQUIRE(!(chain_in || next_mb > 0) || chain_ok, "ppo_minibatch_step: chaining needs the clipped single-process step (no lagged tail)");
+  // (step == 0 -- gradients only, the data-parallel form -- may be chained INTO: mansy_ppo_dp_tail, called after the gradient
+  // average, is then the launch that prepared this minibatch)
+  MANSY_REQUIRE(next_mb == 0 || chain_ok, "ppo_minibatch_step: preparing the next minibatch needs the clipped single-process step (no lagged tail)");
+  MANSY_REQUIRE(!chain_in || chain_ok || step == 0, "ppo_minibatch_step: chain_in needs the clipped step or the gradients-only form");
   double* const parts_cur = e.W.acc + (chain_ok && (step & 1) ? NORM_PARTS_C : 0);
   double* const parts_next = e.W.acc + (chain_ok && (step & 1) ? 0 : NORM_PARTS_C);
   if (!chain_in) RC(e.pack_mb(a, c, idx ? obs_all : nullptr, idx, mb, flat_g, n_flat, adv_all));
@@ -1254,6 +1257,21 @@ int mansy_bc_step(const float* const* params, float* const* grads, float* flat_p
   RC(e.head_bwd_pair(a, c, B));
   RC(e.featnet_bwd(a, obs, B, 0, e.W.dHa, e.W.dHc));
   return e.clip_and_adam(flat_p, flat_g, flat_m, flat_v, n_update, 0.f, lr, weight_decay, step);
+}
+
+// Data-parallel counterpart of the chained step's last launch: the ranks ran mansy_ppo_minibatch_step with step = 0 (raw local
+// gradients) and averaged flat_g; this call clips by the global norm (have_sumsq: `scratch` already holds the partial sums of squares
+// -- mansy_xg_allreduce_avg leaves them), applies Adam(L2), zeroes flat_g, re-packs the updated parameters and, with next_mb > 0,
+// gathers the next minibatch and takes its advantage statistics, so that the next mansy_ppo_minibatch_step passes chain_in = 1.
+int mansy_ppo_dp_tail(const float* const* params, float* flat_p, float* flat_g, float* flat_m, float* flat_v, long long n_flat, float max_grad_norm,
+                      float lr, float weight_decay, int step, double* scratch, int have_sumsq, const float* obs_all, const float* adv_all,
+                      const int* next_idx, int next_mb, void* workspace, int max_batch, void* stream) {
+  MANSY_REQUIRE(params && flat_p && flat_g && flat_m && flat_v && scratch && step >= 1 && max_grad_norm > 0.f, "ppo_dp_tail: bad arguments");
+  MANSY_REQUIRE(next_mb >= 0 && next_mb <= max_batch && (next_mb == 0 || (obs_all && adv_all)), "ppo_dp_tail: bad next minibatch");
+  PEng e; RC(setup(workspace, max_batch, (hipStream_t)stream, e));
+  if (!have_sumsq) { hipLaunchKernelGGL(sumsq_kernel, dim3(NORM_PARTS), dim3(256), 0, e.st, flat_g, n_flat, scratch); MANSY_LAUNCH_CHECK(); }
+  return e.step_tail(params, flat_p, flat_g, flat_m, flat_v, n_flat, max_grad_norm, lr, weight_decay, step, scratch, e.W.acc + NORM_PARTS_C, obs_all,
+                     next_idx, next_mb, adv_all);
 }
 
 // Global-norm clip (torch clip_grad_norm_ semantics; max_norm <= 0 disables) followed by Adam with L2 weight decay over

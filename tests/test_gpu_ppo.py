@@ -679,6 +679,43 @@ def test_chained_update_equals_self_contained_steps(M):
         assert np.isfinite(outs[0][0]).all() and len(outs[0][0]) == (32 if n == 4096 else 8)
 
 
+def test_data_parallel_step_form_equals_the_single_process_step(M):
+    """The data-parallel form of an update -- raw gradients (step = 0), average over the ranks, then mansy_ppo_dp_tail (clip + Adam +
+    gradient zero-fill + re-pack + next minibatch's gather) or, unchained, mansy_clip_grad_adam -- with an identity `grad_sync`
+    (one rank) must land where the single-process chained step lands: same gradients, same clip, same Adam, to float32 rounding."""
+    sd = po.make_policy_state_dict(int(Z['wseed']))
+    T, N, bs = 11, 100, 512                                         # ragged: 512 + 588 per pass
+    rs = np.random.RandomState(11)
+    n = T * N
+    src = Z['obs']
+    obs = torch.from_numpy(src[rs.randint(0, len(src), size=n)].reshape(T, N, 780).copy())
+    obs_next = torch.from_numpy(src[rs.randint(0, len(src), size=n)].reshape(T, N, 780).copy())
+    act = torch.from_numpy(rs.randint(0, 15, size=(T, N)).astype(np.int32))
+    rew = torch.from_numpy(rs.randn(T, N).astype(np.float32))
+    done = torch.from_numpy((rs.rand(T, N) < 0.05).astype(np.uint8))
+    outs = []
+    for form in ('single', 'dp-chained', 'dp-unchained'):
+        pol = build_policy(M, sd)
+        if form != 'single':
+            pol.set_data_parallel(1, lambda g: None)
+            pol.chain_steps = form == 'dp-chained'
+        buf = M.ppo.RolloutBuffer(T, N, 'cuda')
+        rows = []
+        for it in range(2):
+            buf.obs.copy_(obs); buf.obs_next.copy_(obs_next); buf.act.copy_(act); buf.rew.copy_(rew + 0.1 * it); buf.done.copy_(done)
+            buf.filled = T
+            np.random.seed(70 + it)
+            res = pol.update(0, buf, is_train=True, batch_size=bs, repeat=2)
+            rows.append(np.stack([res['loss'], res['loss/clip'], res['loss/vf'], res['loss/ent']], 1))
+        f = pol.engine.ac
+        outs.append((np.concatenate(rows), f.flat_p.clone(), f.m.clone(), f.v.clone()))
+    for o in outs[1:]:
+        np.testing.assert_allclose(o[0], outs[0][0], rtol=2e-5, atol=2e-6)
+        for a, b in zip(o[1:], outs[0][1:]):
+            err = (a - b).abs()
+            assert float((err > 0.02 * 5e-4).float().mean()) <= 1e-4 and err.max().item() <= 2 * 5e-4, (err.max().item(),)
+
+
 @pytest.mark.parametrize('mode', ['f32', 'bf16x6', 'bf16x3'])
 def test_shipped_trained_checkpoint_vs_reference(M, mode):
     """The TRAINED weights the reference ships (best_policy.pth / best_identifier.pth; their arrays travel in
