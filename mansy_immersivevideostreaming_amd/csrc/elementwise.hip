@@ -471,6 +471,21 @@ __global__ __launch_bounds__(256) void traj_gather_kernel(const float* __restric
   else fut[((long long)b * T + (w - S - 1)) * c + j] = v;
 }
 
+// c == 2 (the reference's (x, y) samples): one thread per SAMPLE, 8-byte loads and stores -- half the threads, twice the bytes per
+// access of the per-float form (2.6 -> see profiles/r03_hbm_kernels_bench*.txt)
+__global__ __launch_bounds__(256) void traj_gather2_kernel(const float2* __restrict__ table, int L, const int* __restrict__ idx, int B, int S, int T,
+                                                           float2* __restrict__ hist, float2* __restrict__ cur, float2* __restrict__ fut) {
+  const int W = S + 1 + T;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long long)B * W) return;
+  const int b = (int)(t / W), w = (int)(t - (long long)b * W);
+  const int slot = idx[2 * b], ts = idx[2 * b + 1];
+  const float2 v = table[(long long)slot * L + (ts - S + w)];
+  if (w < S) hist[(long long)b * S + w] = v;
+  else if (w == S) cur[b] = v;
+  else fut[(long long)b * T + (w - S - 1)] = v;
+}
+
 // utils/common.py:73-80 per row: sum_j min(|a-b|,|a+1-b|,|a-1-b|)^2 / c
 __global__ __launch_bounds__(256) void periodic_mse_kernel(const float* __restrict__ a, const float* __restrict__ b, long long rows, int c,
                                                            float* __restrict__ out) {
@@ -509,7 +524,12 @@ int mansy_launch_traj_gather(const float* table, int L, int c, const int* idx, i
                              hipStream_t st) {
   MANSY_REQUIRE(table && idx && hist && cur && fut && L >= S + 1 + T, "traj_gather: bad arguments");
   if (B <= 0) return MANSY_OK;
-  hipLaunchKernelGGL(traj_gather_kernel, g1((long long)B * (S + 1 + T) * c), dim3(256), 0, st, table, L, c, idx, B, S, T, hist, cur, fut);
+  auto al8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; };
+  if (c == 2 && al8(table) && al8(hist) && al8(cur) && al8(fut))
+    hipLaunchKernelGGL(traj_gather2_kernel, g1((long long)B * (S + 1 + T)), dim3(256), 0, st, reinterpret_cast<const float2*>(table), L, idx, B, S, T,
+                       reinterpret_cast<float2*>(hist), reinterpret_cast<float2*>(cur), reinterpret_cast<float2*>(fut));
+  else
+    hipLaunchKernelGGL(traj_gather_kernel, g1((long long)B * (S + 1 + T) * c), dim3(256), 0, st, table, L, c, idx, B, S, T, hist, cur, fut);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }

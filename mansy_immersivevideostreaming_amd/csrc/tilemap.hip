@@ -38,15 +38,21 @@ __device__ __forceinline__ unsigned long long tilemap_px(int x, int y, int W, in
   int xa[2], xb[2], ya[2], yb[2];
   const int nx = split_axis(x - hw, x + hw, W, xa, xb);
   const int ny = split_axis(y - hh, y + hh, H, ya, yb);
-  unsigned long long m = 0ull;
-  for (int j = 0; j < ny; ++j) {
-    const unsigned rows = range_mask(block_of(ya[j], th), block_of(yb[j], th), nh);
-    for (int i = 0; i < nx; ++i) {
-      const unsigned cols = range_mask(block_of(xa[i], tw), block_of(xb[i], tw), nw);
-      for (int r = 0; r < nh; ++r)
-        if ((rows >> r) & 1u) m |= (unsigned long long)cols << (r * nw);
-    }
+  // The covered regions are the cross product of the (<= 2) x intervals and the (<= 2) y intervals, so the union of their tile
+  // rectangles is (union of the row masks) x (union of the column masks): two small OR loops and one outer product instead of
+  // up to 2 x 2 x nh shift / OR steps (round 3: the kernel was ALU-bound at ~290 integer instructions per point).
+  unsigned rows = 0u, cols = 0u;
+  for (int j = 0; j < ny; ++j) rows |= range_mask(block_of(ya[j], th), block_of(yb[j], th), nh);
+  for (int i = 0; i < nx; ++i) cols |= range_mask(block_of(xa[i], tw), block_of(xb[i], tw), nw);
+  if (nw == 8 && nh == 8) {
+    // byte r of the map = cols if bit r of rows is set: replicate rows into every byte, keep bit r in byte r, turn "byte != 0" into 0xFF
+    const unsigned long long t = ((unsigned long long)(rows & 0xFFu) * 0x0101010101010101ull) & 0x8040201008040201ull;
+    const unsigned long long sel = (((t + 0x7F7F7F7F7F7F7F7Full) & 0x8080808080808080ull) >> 7) * 0xFFull;
+    return sel & ((unsigned long long)(cols & 0xFFu) * 0x0101010101010101ull);
   }
+  unsigned long long m = 0ull;
+  for (int r = 0; r < nh; ++r)
+    if ((rows >> r) & 1u) m |= (unsigned long long)cols << (r * nw);
   return m;
 }
 
