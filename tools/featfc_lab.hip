@@ -1,3 +1,6 @@
+// LAB (not part of the library; round-3 experiment): to try it, copy into mansy_immersivevideostreaming_amd/csrc/ and call
+// mansy_launch_featfc from PEng::head() / head_pair() in place of the FeatureNet + fc products for batches <= 1024 rows.  Measured: correct, and
+// slower than the two launches it replaces (rollout step 31 -> 35 us).
 // FeatureNet + head fc as ONE launch for the small batches of the PPO loop (rollout: 256 rows; minibatch: 512-588): the two dependent
 // products of every policy forward
 //     F   = LeakyReLU(obs[B, K] Wbd^T + b)          block-diagonal: ten branches of 128 features on disjoint column windows
