@@ -199,16 +199,83 @@ struct UnpackArgs { float* gbw[NB]; float* gbb[NB]; };
 // earlier launches and are scanned by extra workgroups at the end of the grid; per-workgroup sums are added into the
 // NORM_PARTS slots that clip_adam_kernel adds up (zeroed by the pack launch's riders).
 struct NormRider { double* parts; const float* tail_g; long long tail_n; };
+// Riders of the PPO minibatch step (round 3): the output layers' weight gradients gWout_h[k, c] = sum_r g_h[r, k] H_h[r, c] and
+// gbout_h[k] = sum_r g_h[r, k] from what head_out_kernel wrote (rows summed in index order: deterministic, no atomics), stored
+// into the (zeroed) flat gradient, their squares added to the norm; and the loss statistics from the per-row terms.  The norm
+// scan of the head gradients skips the two output-layer ranges [skip0, skip0 + skip0_n), [skip1, ...) these riders own.
+struct OutGradRider {
+  int on; int rows;
+  const float* g[2]; const float* H[2]; int n_out[2]; float* gW[2]; float* gb[2];
+  const float* lossrows; float vf_coef, ent_coef; float* stats;
+  const float* skip0; long long skip0_n; const float* skip1; long long skip1_n;
+};
+constexpr int OG_BLOCKS = 257;         // 16 logits (actor: 15 + the critic's one value) x 16 groups of 8 columns + 1 for biases / statistics
 // dWbd arrives as nsplit K-split slabs (stride `slab` floats) of which only the block-diagonal windows were written
 // (GemmEpilogue::tile_nrange): summed here in slab order.
 __global__ __launch_bounds__(256) void unpack_dwbd_kernel(const float* __restrict__ dWbd, int nsplit, long long slab, const float* __restrict__ dbbd,
-                                                          int identifier, int K, UnpackArgs a, NormRider nr) {
+                                                          int identifier, int K, UnpackArgs a, NormRider nr, OutGradRider og, int og_first) {
   // one thread per element of the ten branch weights (HID x KC with KC = the branches' input widths added up: the index space of
   // the compact gradients, 8 x smaller than the packed image's)
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   const int KC = compact_cols(identifier);                      // 745 state columns + 15 (identifier) / 3 (policy)
   const long long n_main = (long long)HID * KC;
   double sq = 0.0;
+  if (og.on && (int)blockIdx.x >= og_first) {                   // output-layer gradient riders (the last OG_BLOCKS workgroups)
+    const int ob = blockIdx.x - og_first;
+    if (ob < OG_BLOCKS - 1) {
+      // workgroup -> (logit k = ob / 16, 8 columns from 8 (ob % 16)); thread -> (column t % 8, row lane t / 8): 32 row lanes stride
+      // the rows (16 each at a 512-row minibatch, 8 loads in flight), then one LDS reduction.  k = 15 is the critic's value column.
+      __shared__ float sh_w[32][9];
+      const int k = ob >> 4, cl = threadIdx.x & 7, c = 8 * (ob & 15) + cl, rl = threadIdx.x >> 3;
+      const int hd = k < NACT ? 0 : 1, kk = hd ? 0 : k;
+      const float* __restrict__ g = og.g[hd]; const float* __restrict__ H = og.H[hd];
+      float acc = 0.f, gacc = 0.f;
+      for (int r0 = rl; r0 < og.rows; r0 += 32 * 8) {
+        float gv[8], hv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int r = min(r0 + 32 * u, og.rows - 1); gv[u] = g[(size_t)r * MAXOUT + kk]; hv[u] = H[(size_t)r * HID + c]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const bool live = r0 + 32 * u < og.rows;
+          acc = live ? fmaf(gv[u], hv[u], acc) : acc;
+          gacc = live ? gacc + gv[u] : gacc;
+        }
+      }
+      sh_w[rl][cl] = acc;
+      if (cl == 0) sh_w[rl][8] = gacc;                           // the logit's bias gradient: the row lanes' sums of g[:, k]
+      __syncthreads();
+      if (threadIdx.x < 8) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) t += sh_w[i][threadIdx.x];
+        og.gW[hd][kk * HID + 8 * (ob & 15) + threadIdx.x] = t;
+        sq = (double)t * (double)t;
+      } else if (threadIdx.x == 8 && (ob & 15) == 0) {           // one of the logit's 16 workgroups also stores its bias gradient
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) t += sh_w[i][8];
+        og.gb[hd][kk] = t;
+        sq = (double)t * (double)t;
+      }
+    } else {
+      // the loss statistics
+      __shared__ float sh_og[4][4];
+      const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+      if (og.stats) {
+        float c = 0.f, v = 0.f, e = 0.f;
+        for (int i = threadIdx.x; i < og.rows; i += 256) { c += og.lossrows[4 * i]; v += og.lossrows[4 * i + 1]; e += og.lossrows[4 * i + 2]; }
+        c = wave_sum(c); v = wave_sum(v); e = wave_sum(e);
+        if (lane == 0) { sh_og[0][wv] = c; sh_og[1][wv] = v; sh_og[2][wv] = e; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          const float cm = (sh_og[0][0] + sh_og[0][1] + sh_og[0][2] + sh_og[0][3]) / (float)og.rows;
+          const float vm = (sh_og[1][0] + sh_og[1][1] + sh_og[1][2] + sh_og[1][3]) / (float)og.rows;
+          const float em = (sh_og[2][0] + sh_og[2][1] + sh_og[2][2] + sh_og[2][3]) / (float)og.rows;
+          og.stats[0] = cm + og.vf_coef * vm - og.ent_coef * em; og.stats[1] = cm; og.stats[2] = vm; og.stats[3] = em;
+        }
+      }
+    }
+  } else {
   if (idx < FEAT) { const float b = dbbd[idx]; a.gbb[idx / HID][idx % HID] += b; sq += (double)b * (double)b; }
   if (idx < n_main) {
     const int r = (int)(idx / KC);
@@ -221,12 +288,17 @@ __global__ __launch_bounds__(256) void unpack_dwbd_kernel(const float* __restric
     a.gbw[j][r * g.len + c] += v; sq += (double)v * (double)v;
   } else if (nr.parts) {
     const long long t4 = (idx - (n_main + 255) / 256 * 256) * 4;          // tail workgroups start on a workgroup boundary
-    if (t4 >= 0 && t4 + 4 <= nr.tail_n) {
+    // (the output-layer ranges belong to the riders above when they run: whole 16-byte groups, every tensor is 256-byte aligned)
+    const float* q = nr.tail_g + t4;
+    const bool skip = og.on && ((q >= og.skip0 && q < og.skip0 + og.skip0_n) || (q >= og.skip1 && q < og.skip1 + og.skip1_n));
+    if (skip) {
+    } else if (t4 >= 0 && t4 + 4 <= nr.tail_n) {
       const float4 v = *reinterpret_cast<const float4*>(nr.tail_g + t4);
       sq += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
     } else if (t4 >= 0) {
       for (long long e = t4; e < nr.tail_n; ++e) sq += (double)nr.tail_g[e] * (double)nr.tail_g[e];
     }
+  }
   }
   if (!nr.parts) return;
   __shared__ double red[4];
@@ -260,6 +332,12 @@ struct LossFuse {
   const int* act; const float* adv; const float* logp_old; const float* v_old; const float* ret; const int* idx;
   int n; float eps_clip, vf_coef, ent_coef; int norm_adv, value_clip; float adv_eps;
   const float* adv_stats; float* dlogits; float* dvalue; int dvalue_ld; float* lossrows;
+  // round 3: the output layer's input-side backward in the same launch (was head_out_bwd_kernel's row loop): per head h,
+  //   dH_h[row, c] = sum_k g[k] Wout_h[k, c]      (residual branch of the head; joins dF in the dF product's epilogue)
+  //   dA1[row, h * HID + c] = dH * leaky'(A1)     (operand of the fc weight-gradient and dF products)
+  // The output layer's own weight gradients (a [<= 15, B] x [B, 128] reduction over the rows) are taken by riders of the
+  // unpack launch from the dlogits / dvalue and H this kernel writes -- fixed summation order, no atomics.  Null: off.
+  float* bwd_dH[2]; float* bwd_dA1; int bwd_dA1_ld;
 };
 // Rollout fusion: the wave that sampled row e's action goes on to step environment e (lane = tile) in the same launch --
 // MANSYEnv.step with the action it just drew; the observation rows it writes are the next policy input.
@@ -327,6 +405,9 @@ __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const f
     for (int k = 0; k < MAXOUT; ++k) if (k == lane) mine = o[k];
     out[(size_t)row * (d.out_ld ? d.out_ld : out_ld) + lane] = mine;
   }
+  float gk[MAXOUT];                // dL/d(output pre-activation) of this row and head (fused loss)
+#pragma unroll
+  for (int k = 0; k < MAXOUT; ++k) gk[k] = 0.f;
   if (lf.on && blockIdx.y == 0) {  // actor: clipped surrogate + entropy of this row, gradient wrt the logits (every lane computes the same scalars)
     float adv = l_adv;
     if (lf.norm_adv) adv = (adv - l_mean) / (l_std + lf.adv_eps);
@@ -360,11 +441,12 @@ __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const f
       float g = dlogp * ((k == a ? 1.f : 0.f) - p);
       g += -lf.ent_coef * (-p * (lp + ent)) / (float)lf.n;      // d(-ent_coef * mean H)/dlogit_k = ent_coef * p_k (log p_k + H) / n
       if (k == lane) mine = g;
+      gk[k] = g;
     }
     if (lane < MAXOUT) lf.dlogits[(size_t)row * MAXOUT + lane] = mine;       // column 15 (lane 15) is 0
     if (lane == 0) { lf.lossrows[4 * (size_t)row + 0] = -fminf(surr1, surr2); lf.lossrows[4 * (size_t)row + 2] = ent; }
   }
-  if (lf.on && blockIdx.y == 1 && lane == 0) {   // critic: (clipped) value loss of this row and its gradient
+  if (lf.on && blockIdx.y == 1) {   // critic: (clipped) value loss of this row and its gradient (every lane computes the same scalars)
     const float v = o[0], ret = l_ret;
     float dv, lv;
     if (lf.value_clip) {
@@ -375,8 +457,20 @@ __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const f
       if (vf1 >= vf2) { lv = vf1; dv = -2.f * (ret - v); }
       else { lv = vf2; dv = (diff > -lf.eps_clip && diff < lf.eps_clip) ? -2.f * (ret - vc) : 0.f; }
     } else { lv = (ret - v) * (ret - v); dv = -2.f * (ret - v); }
-    lf.dvalue[(size_t)row * lf.dvalue_ld] = lf.vf_coef * dv / (float)lf.n;
-    lf.lossrows[4 * (size_t)row + 1] = lv;
+    gk[0] = lf.vf_coef * dv / (float)lf.n;
+    if (lane == 0) { lf.dvalue[(size_t)row * lf.dvalue_ld] = gk[0]; lf.lossrows[4 * (size_t)row + 1] = lv; }
+  }
+  if (lf.on && lf.bwd_dA1) {        // the output layer's input-side backward for this row (see LossFuse)
+    float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXOUT; ++k) {
+      const float g = k < n_out ? gk[k] : 0.f;
+      d0 = fmaf(g, w0[k], d0); d1 = fmaf(g, w1[k], d1);
+    }
+    float* dH = lf.bwd_dH[blockIdx.y];
+    dH[(size_t)row * HID + lane] = d0; dH[(size_t)row * HID + 64 + lane] = d1;
+    float* dA = lf.bwd_dA1 + (size_t)row * lf.bwd_dA1_ld + blockIdx.y * HID;
+    dA[lane] = a0 > 0.f ? d0 : d0 * SLOPE; dA[64 + lane] = a1 > 0.f ? d1 : d1 * SLOPE;
   }
   if (act) {                       // Categorical(logits).sample() by inverse CDF; log_prob of the sample
     float m = -INFINITY;
@@ -940,9 +1034,20 @@ struct PEng {
     ep.mask_src = W.F; ep.mask_ld = FEAT; ep.mask_scale = 1.f; ep.mask_neg = SLOPE;
     return mansy_launch_gemm_f32(W.dA1p, 2 * HID, 0, W.Wfc2, FEAT, 1, W.dF, FEAT, B, FEAT, 2 * HID, ep, 0, 0, st);
   }
+  // head_bwd_pair without the output-layer launch: head_out_kernel wrote dH / dA1 itself (LossFuse::bwd_*), the output layers' weight
+  // gradients are riders of the unpack launch (OutGradRider) -- the PPO minibatch step's form
+  int fc_bwd_pair(const NetP& a, const NetP& c, int B) {
+    GemmEpilogue acc; acc.accumulate = 1;
+    acc.a_rowsum = a.gfc_b;
+    acc.pair_A = W.dA1p + HID; acc.pair_B = W.F; acc.pair_C = c.gfc_w; acc.pair_rowsum = c.gfc_b;
+    RC(mansy_launch_gemm_f32(W.dA1p, 2 * HID, 1, W.F, FEAT, 1, a.gfc_w, FEAT, HID, FEAT, B, acc, 0, 0, st));
+    GemmEpilogue ep; ep.pre_a = W.dHa; ep.pre_b = W.dHc; ep.pre_ld = HID; ep.pre_col0 = RESID_COL;
+    ep.mask_src = W.F; ep.mask_ld = FEAT; ep.mask_scale = 1.f; ep.mask_neg = SLOPE;
+    return mansy_launch_gemm_f32(W.dA1p, 2 * HID, 0, W.Wfc2, FEAT, 1, W.dF, FEAT, B, FEAT, 2 * HID, ep, 0, 0, st);
+  }
   // norm_tail != nullptr: also leave the squared norm of ALL gradients (branches + [norm_tail, norm_tail + norm_tail_n)) in W.acc
   int featnet_bwd(const NetP& n, const float* obs, int B, int identifier, const float* dHa, const float* dHb, const float* norm_tail = nullptr,
-                  long long norm_tail_n = 0, double* norm_parts = nullptr) {
+                  long long norm_tail_n = 0, double* norm_parts = nullptr, const OutGradRider* out_grad = nullptr) {
     const int K = identifier ? K_IDENT : K_POLICY;
     (void)dHa; (void)dHb;      // joined inside the dF product's epilogue (head_bwd / head_bwd_pair); dbbd and the norm slots were zeroed by pack
     // dWbd = dPre^T obs, wanted on the block diagonal only: the launch runs the 42 of 240 output tiles that meet a branch's window
@@ -973,7 +1078,10 @@ struct PEng {
     const long long main_blocks = mansy_ceil_div((long long)HID * compact_cols(identifier), 256);
     const long long tail_blocks = norm_tail ? mansy_ceil_div(mansy_ceil_div(norm_tail_n, 4), 256) : 0;
     MANSY_REQUIRE(!norm_tail || (reinterpret_cast<uintptr_t>(norm_tail) & 15) == 0, "featnet_bwd: gradient tail must be 16-byte aligned");
-    hipLaunchKernelGGL(unpack_dwbd_kernel, dim3(main_blocks + tail_blocks), dim3(256), 0, st, W.dWbd, nsplit, slab, W.dbbd, identifier, K, u, nr);
+    OutGradRider og; memset(&og, 0, sizeof(og));
+    if (out_grad) og = *out_grad;
+    hipLaunchKernelGGL(unpack_dwbd_kernel, dim3(main_blocks + tail_blocks + (og.on ? OG_BLOCKS : 0)), dim3(256), 0, st, W.dWbd, nsplit, slab, W.dbbd,
+                       identifier, K, u, nr, og, (int)(main_blocks + tail_blocks));
     MANSY_LAUNCH_CHECK();
     return MANSY_OK;
   }
@@ -1216,9 +1324,18 @@ int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, fl
   lf.eps_clip = eps_clip; lf.vf_coef = vf_coef; lf.ent_coef = ent_coef; lf.norm_adv = norm_adv; lf.value_clip = value_clip;
   lf.adv_eps = 0.f;   // T2: tianshou 0.4.8 ppo.py divides by the bare unbiased std (`(adv - mean) / std  # per-batch norm`); `+ self._eps` is 0.5.0's
   lf.adv_stats = e.W.adv_stats; lf.dlogits = e.W.gout; lf.dvalue = e.W.gout_c; lf.dvalue_ld = MAXOUT; lf.lossrows = e.W.lossrows;
+  // the output layers' backward rides on the launches around it (round 3: head_out_bwd_kernel's launch is gone from this step): the
+  // input side (dH, dA1) in head_out_kernel, the weight gradients and the loss statistics in the unpack launch
+  lf.bwd_dH[0] = e.W.dHa; lf.bwd_dH[1] = e.W.dHc; lf.bwd_dA1 = e.W.dA1p; lf.bwd_dA1_ld = 2 * HID;
   RC(e.head_pair(a, c, mb, &lf));
-  LossFinish fin; fin.lossrows = e.W.lossrows; fin.n = mb; fin.vf_coef = vf_coef; fin.ent_coef = ent_coef; fin.stats = stats;
-  RC(e.head_bwd_pair(a, c, mb, &fin));
+  RC(e.fc_bwd_pair(a, c, mb));
+  OutGradRider og; memset(&og, 0, sizeof(og));
+  og.on = 1; og.rows = mb; og.g[0] = e.W.gout; og.g[1] = e.W.gout_c; og.H[0] = e.W.Ha; og.H[1] = e.W.Hc; og.n_out[0] = NACT; og.n_out[1] = 1;
+  og.gW[0] = a.gout_w; og.gb[0] = a.gout_b; og.gW[1] = c.gout_w; og.gb[1] = c.gout_b;
+  og.lossrows = e.W.lossrows; og.vf_coef = vf_coef; og.ent_coef = ent_coef; og.stats = stats;
+  og.skip0 = a.gout_w; og.skip0_n = c.gfc_w - a.gout_w; og.skip1 = c.gout_w; og.skip1_n = (flat_g + n_flat) - c.gout_w;
+  MANSY_REQUIRE(og.skip0_n > 0 && og.skip0_n % 4 == 0 && og.skip1_n > 0 && a.gout_b > a.gout_w && a.gout_b < c.gfc_w && c.gout_b > c.gout_w,
+                "ppo_minibatch_step: unexpected order of the head gradients in flat_g");
   // squared gradient norm as a rider on the last gradient-writing launch (12 -> 11 launches): the head gradients are the
   // contiguous tail of the flat buffer, starting at actor.fc.0.weight
   const bool ride = max_grad_norm > 0.f && step > 0;
@@ -1229,7 +1346,7 @@ int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, fl
   // update -- 64..256 resident workgroups, two returning atomics per workgroup, gradients kept in registers across the barrier.
   // 22-32 us per launch against 12 us for the two launches it replaced: a kernel boundary is cheaper than a device-scope
   // rendezvous on this chip, as tools/chain_lab.hip found for the GEMM chain.)
-  RC(e.featnet_bwd(a, obs, mb, 0, e.W.dHa, e.W.dHc, ride ? tail : nullptr, ride ? tail_n : 0, parts_cur));
+  RC(e.featnet_bwd(a, obs, mb, 0, e.W.dHa, e.W.dHc, ride ? tail : nullptr, ride ? tail_n : 0, parts_cur, &og));
   if (chain_ok)
     return e.step_tail(params, flat_p, flat_g, flat_m, flat_v, n_flat, max_grad_norm, lr, weight_decay, step, parts_cur, parts_next, obs_all,
                        next_idx, next_mb, adv_all);
