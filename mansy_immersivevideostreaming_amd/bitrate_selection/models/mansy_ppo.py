@@ -215,6 +215,7 @@ class PPOPolicy(nn.Module):
         self._seed_ctr = 0
         self.world, self.grad_sync = 1, None
         self.chain_steps = True       # learn(): each minibatch step's last launch prepares the next one (False: self-contained steps)
+        self._pinned = {}
 
     def set_data_parallel(self, world, grad_sync, peer=False):
         """One process per GPU: `grad_sync(flat_grad)` averages a flat gradient buffer over ranks (dist.make_grad_sync).
@@ -228,6 +229,23 @@ class PPOPolicy(nn.Module):
             for f in (self.engine.ac, self.engine.idn):
                 if f is not None:
                     self._peer[id(f)] = PeerGradSync(f.flat_p.numel(), self.world, tdist.get_rank(), f.flat_p.device)
+
+    def _upload_i32(self, key, arr, dev):
+        """Host int array -> device int32 tensor through a persistent PINNED staging buffer and a non-blocking copy: the copy engine
+        moves it, no staging kernel runs on the compute queue (a pageable upload costs one or two `copyBuffer` launches each; a cycle
+        had eleven).  One staging buffer per call site (`key`); its previous upload is waited for before it is overwritten."""
+        arr = np.ascontiguousarray(arr, dtype=np.int32)
+        slot = self._pinned.get(key)
+        if slot is None or slot[0].numel() < arr.size:
+            slot = [torch.empty(max(arr.size, 1), dtype=torch.int32).pin_memory(), None]
+            self._pinned[key] = slot
+        if slot[1] is not None:
+            slot[1].synchronize()
+        slot[0][:arr.size].copy_(torch.from_numpy(arr))
+        out = slot[0][:arr.size].to(dev, non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record(torch.cuda.current_stream(dev))
+        return out
 
     def _sync_clip_adam(self, f, max_norm, lr, wd, tail=None):
         """Data-parallel second half of a step: average the raw local gradients over the ranks, then global-norm clip + Adam.
@@ -291,7 +309,7 @@ class PPOPolicy(nn.Module):
         obs = buffer.obs[:buffer.filled].reshape(n, OBS_LD)
         idx = np.arange(n)
         np.random.shuffle(idx)
-        idx_t = torch.from_numpy(idx).to(obs.device)
+        idx_t = self._upload_i32('ident', idx, obs.device)
         obs = obs.index_select(0, idx_t)
         ntr = int(n * 0.8)
         tr, va = obs[:ntr].contiguous(), obs[ntr:].contiguous()
@@ -391,12 +409,11 @@ class PPOPolicy(nn.Module):
         # else consumes the generator in between), so that each step's last launch can prepare the next step's minibatch
         passes = [list(split_indices(n, batch_size)) for _ in range(repeat)]
         chain = self.chain_steps and float(self._grad_norm or 0.0) > 0.0 and f.tail()[0] < 0   # the step forms that end in step_tail / dp_tail
-        perms = [torch.from_numpy(np.concatenate(chunks).astype(np.int32)).to(dev) for chunks in passes]      # one upload per pass
-        flat = []                                                            # (pass, k, idx view) of every minibatch step, in order
+        perm = self._upload_i32('perm', np.concatenate([c for chunks in passes for c in chunks]), dev)      # ONE upload for all passes
+        flat, off = [], 0                                                    # (pass, k, idx view) of every minibatch step, in order
         for pi, chunks in enumerate(passes):
-            off = 0
             for k, chunk in enumerate(chunks):
-                flat.append((pi, k, perms[pi][off:off + len(chunk)]))
+                flat.append((pi, k, perm[off:off + len(chunk)]))
                 off += len(chunk)
         stats_all = [torch.empty(len(chunks), 4, dtype=torch.float32, device=dev) for chunks in passes]
         for s, (pi, k, idx) in enumerate(flat):

@@ -206,7 +206,7 @@ struct NormRider { double* parts; const float* tail_g; long long tail_n; };
 struct OutGradRider {
   int on; int rows;
   const float* g[2]; const float* H[2]; int n_out[2]; float* gW[2]; float* gb[2];
-  const float* lossrows; float vf_coef, ent_coef; float* stats;
+  const float* lossrows; float vf_coef, ent_coef; float* stats; int mse;
   const float* skip0; long long skip0_n; const float* skip1; long long skip1_n;
 };
 constexpr int OG_BLOCKS = 257;         // 16 logits (actor: 15 + the critic's one value) x 16 groups of 8 columns + 1 for biases / statistics
@@ -227,7 +227,8 @@ __global__ __launch_bounds__(256) void unpack_dwbd_kernel(const float* __restric
       // the rows (16 each at a 512-row minibatch, 8 loads in flight), then one LDS reduction.  k = 15 is the critic's value column.
       __shared__ float sh_w[32][9];
       const int k = ob >> 4, cl = threadIdx.x & 7, c = 8 * (ob & 15) + cl, rl = threadIdx.x >> 3;
-      const int hd = k < NACT ? 0 : 1, kk = hd ? 0 : k;
+      if (!(k < og.n_out[0] || (k == MAXOUT - 1 && og.n_out[1] > 0))) return;       // (a head with fewer logits: the identifier's 3)
+      const int hd = k < og.n_out[0] ? 0 : 1, kk = hd ? 0 : k;
       const float* __restrict__ g = og.g[hd]; const float* __restrict__ H = og.H[hd];
       float acc = 0.f, gacc = 0.f;
       for (int r0 = rl; r0 < og.rows; r0 += 32 * 8) {
@@ -261,7 +262,16 @@ __global__ __launch_bounds__(256) void unpack_dwbd_kernel(const float* __restric
       // the loss statistics
       __shared__ float sh_og[4][4];
       const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-      if (og.stats) {
+      if (og.stats && og.mse) {             // identifier: loss = sum of the rows' squared errors / (3 rows), summed in double like ident_mse_kernel
+        __shared__ double sh_d[4];
+        double t = 0.0;
+        for (int i = threadIdx.x; i < og.rows; i += 256) t += (double)og.lossrows[4 * i];
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) t += __shfl_xor(t, o2, 64);
+        if (lane == 0) sh_d[wv] = t;
+        __syncthreads();
+        if (threadIdx.x == 0) og.stats[0] = (float)(((sh_d[0] + sh_d[1]) + (sh_d[2] + sh_d[3])) / (double)(og.rows * 3));
+      } else if (og.stats) {
         float c = 0.f, v = 0.f, e = 0.f;
         for (int i = threadIdx.x; i < og.rows; i += 256) { c += og.lossrows[4 * i]; v += og.lossrows[4 * i + 1]; e += og.lossrows[4 * i + 2]; }
         c = wave_sum(c); v = wave_sum(v); e = wave_sum(e);
@@ -322,6 +332,9 @@ struct HeadOut {
   float* A1; const float* fc_b; const float* Wout; const float* bout; int n_out; int sigmoid; float* H; float* out; int pre_col;
   int* act; float* logp;
   int out_ld;      // row stride of `out` for this head (0: the launch-wide out_ld); 1 writes a value head straight into a [B] vector
+  // riders that used to be launches of their own (round 3):
+  const int* act_given; int n_given;     // log-probability of GIVEN actions for the rows < n_given -> logp (process_fn's logp_old; was logp_kernel)
+  float* relabel_rew; float* relabel_idrew; const float* relabel_obs; float relabel_lamb;      // identifier reward + relabel (was relabel_kernel)
 };
 // PPO minibatch loss fused into the output-layer launch (T2: tianshou 0.4.8 PPOPolicy.learn): head 0 (actor) turns its row's
 // logits into the clipped-surrogate + entropy terms and their gradient wrt the logits, head 1 (critic) its value into the
@@ -338,6 +351,7 @@ struct LossFuse {
   // The output layer's own weight gradients (a [<= 15, B] x [B, 128] reduction over the rows) are taken by riders of the
   // unpack launch from the dlogits / dvalue and H this kernel writes -- fixed summation order, no atomics.  Null: off.
   float* bwd_dH[2]; float* bwd_dA1; int bwd_dA1_ld;
+  const float* mse_obs;      // on == 2 (identifier): observation rows holding the regression target at MANSY_O_QOE_W
 };
 // Rollout fusion: the wave that sampled row e's action goes on to step environment e (lane = tile) in the same launch --
 // MANSYEnv.step with the action it just drew; the observation rows it writes are the next policy input.
@@ -359,7 +373,7 @@ __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const f
   // fused-loss operands (a gather through idx): requested first, ahead of this kernel's stores, so the two dependent round
   // trips overlap the slab sums
   int l_bi = 0, l_act = 0; float l_adv = 0.f, l_logp_old = 0.f, l_ret = 0.f, l_vold = 0.f, l_mean = 0.f, l_std = 1.f;
-  if (lf.on) {
+  if (lf.on == 1) {
     l_bi = lf.idx ? lf.idx[row] : row;
     if (blockIdx.y == 0) { l_adv = lf.adv[l_bi]; l_act = lf.act[l_bi]; l_logp_old = lf.logp_old[l_bi]; l_mean = lf.adv_stats[0]; l_std = lf.adv_stats[1]; }
     else { l_ret = lf.ret[l_bi]; l_vold = lf.value_clip ? lf.v_old[l_bi] : 0.f; }
@@ -405,10 +419,31 @@ __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const f
     for (int k = 0; k < MAXOUT; ++k) if (k == lane) mine = o[k];
     out[(size_t)row * (d.out_ld ? d.out_ld : out_ld) + lane] = mine;
   }
+  if (d.act_given && row < d.n_given) {      // log pi(a | obs) of the given action (logp_kernel's arithmetic: max, sequential sum of exp, log)
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < NACT; ++k) m = fmaxf(m, o[k]);
+    float se = 0.f;
+#pragma unroll
+    for (int k = 0; k < NACT; ++k) se += expf(o[k] - m);
+    const int a = d.act_given[row];
+    float oa = 0.f;
+#pragma unroll
+    for (int k = 0; k < NACT; ++k) if (k == a) oa = o[k];
+    if (lane == 0) logp[row] = (oa - m) - logf(se);
+  }
+  if (d.relabel_rew && lane == 0) {          // rew <- (1 - lamb) rew + lamb (1 - mean_k (pred_k - w_k)^2)   (mansy_ppo.py:43-48)
+    float sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const float dd = o[k] - d.relabel_obs[(size_t)row * OBS_LD + MANSY_O_QOE_W + k]; sq += dd * dd; }
+    const float ir = 1.f - sq / 3.f;
+    if (d.relabel_idrew) d.relabel_idrew[row] = ir;
+    d.relabel_rew[row] = (1.f - d.relabel_lamb) * d.relabel_rew[row] + d.relabel_lamb * ir;
+  }
   float gk[MAXOUT];                // dL/d(output pre-activation) of this row and head (fused loss)
 #pragma unroll
   for (int k = 0; k < MAXOUT; ++k) gk[k] = 0.f;
-  if (lf.on && blockIdx.y == 0) {  // actor: clipped surrogate + entropy of this row, gradient wrt the logits (every lane computes the same scalars)
+  if (lf.on == 1 && blockIdx.y == 0) {  // actor: clipped surrogate + entropy of this row, gradient wrt the logits (every lane computes the same scalars)
     float adv = l_adv;
     if (lf.norm_adv) adv = (adv - l_mean) / (l_std + lf.adv_eps);
     float m = -INFINITY;
@@ -446,7 +481,7 @@ __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const f
     if (lane < MAXOUT) lf.dlogits[(size_t)row * MAXOUT + lane] = mine;       // column 15 (lane 15) is 0
     if (lane == 0) { lf.lossrows[4 * (size_t)row + 0] = -fminf(surr1, surr2); lf.lossrows[4 * (size_t)row + 2] = ent; }
   }
-  if (lf.on && blockIdx.y == 1) {   // critic: (clipped) value loss of this row and its gradient (every lane computes the same scalars)
+  if (lf.on == 1 && blockIdx.y == 1) {   // critic: (clipped) value loss of this row and its gradient (every lane computes the same scalars)
     const float v = o[0], ret = l_ret;
     float dv, lv;
     if (lf.value_clip) {
@@ -459,6 +494,19 @@ __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const f
     } else { lv = (ret - v) * (ret - v); dv = -2.f * (ret - v); }
     gk[0] = lf.vf_coef * dv / (float)lf.n;
     if (lane == 0) { lf.dvalue[(size_t)row * lf.dvalue_ld] = gk[0]; lf.lossrows[4 * (size_t)row + 1] = lv; }
+  }
+  if (lf.on == 2) {                 // identifier: MSE(sigmoid outputs, the observation's normalised QoE weights) of this row, gradient wrt the pre-sigmoid
+    float sq = 0.f, mine = 0.f;      // (train_identifier, mansy_utils.py:20-31; ident_mse_kernel's arithmetic per element)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float p = o[k];
+      const float dd = p - lf.mse_obs[(size_t)row * OBS_LD + MANSY_O_QOE_W + k];
+      sq += dd * dd;
+      gk[k] = (2.f * dd / (float)(lf.n * 3)) * p * (1.f - p);
+      if (k == lane) mine = gk[k];
+    }
+    if (lane < MAXOUT) lf.dlogits[(size_t)row * MAXOUT + lane] = mine;
+    if (lane == 0) lf.lossrows[4 * (size_t)row] = sq;
   }
   if (lf.on && lf.bwd_dA1) {        // the output layer's input-side backward for this row (see LossFuse)
     float d0 = 0.f, d1 = 0.f;
@@ -646,19 +694,6 @@ __global__ __launch_bounds__(256) void ident_mse_kernel(const float* __restrict_
   }
 }
 
-// rew <- (1 - lamb) * rew + lamb * (1 - mean_k (pred_k - w_k)^2)     (mansy_ppo.py:43-48, mansy_utils.py:42-49)
-__global__ __launch_bounds__(256) void relabel_kernel(const float* __restrict__ pred, const float* __restrict__ obs, float* __restrict__ rew,
-                                                      float* __restrict__ id_rew, int B, float lamb) {
-  const int r = blockIdx.x * 256 + threadIdx.x;
-  if (r >= B) return;
-  float s = 0.f;
-  for (int k = 0; k < 3; ++k) { const float d = pred[(size_t)r * MAXOUT + k] - obs[(size_t)r * OBS_LD + MANSY_O_QOE_W + k]; s += d * d; }
-  const float ir = 1.f - s / 3.f;
-  if (id_rew) id_rew[r] = ir;
-  rew[r] = (1.f - lamb) * rew[r] + lamb * ir;
-}
-
-// GAE over [T][N] step-major slabs, one thread per environment, float64 like tianshou's numpy/numba path (T2).
 __global__ __launch_bounds__(256) void gae_kernel(const float* __restrict__ rew, const float* __restrict__ v_s, const float* __restrict__ v_next,
                                                   const unsigned char* __restrict__ done, int T, int N, double gamma, double lam,
                                                   const double* __restrict__ rms, int rew_norm, double eps, double* __restrict__ ret_unnorm,
@@ -858,16 +893,6 @@ __global__ __launch_bounds__(256) void step_tail_kernel(float* __restrict__ p, f
   } else if (lo == 2 * NB) Wfc2[e] = pn;
   else if (lo == 2 * NB + 4) Wfc2[(long long)HID * FEAT + e] = pn;
 }
-__global__ __launch_bounds__(256) void logp_kernel(const float* __restrict__ logits, const int* __restrict__ act, int B, float* __restrict__ logp) {
-  const int r = blockIdx.x * 256 + threadIdx.x;
-  if (r >= B) return;
-  const float* lg = logits + (size_t)r * MAXOUT;
-  float m = -INFINITY;
-  for (int k = 0; k < NACT; ++k) m = fmaxf(m, lg[k]);
-  float se = 0.f;
-  for (int k = 0; k < NACT; ++k) se += expf(lg[k] - m);
-  logp[r] = (lg[act[r]] - m) - logf(se);
-}
 
 // ------------------------------------------------------------------------------------ workspace
 struct PWork {
@@ -958,8 +983,10 @@ struct PEng {
                   "featnet: observation rows and workspace must be 16-byte aligned");
     return mansy_launch_gemm_f32(obs, OBS_LD, 0, W.Wbd, KP, 0, W.F, FEAT, B, FEAT, KP, ep, 0, 0, st);
   }
+  struct HeadRiders { const int* act_given = nullptr; int n_given = 0; float* logp = nullptr;
+                      float* relabel_rew = nullptr; float* relabel_idrew = nullptr; const float* relabel_obs = nullptr; float relabel_lamb = 0.f; };
   int head(const NetP& n, int B, int n_out, int sigmoid, float* A1, float* H, float* out, const float* u, uint32_t seed, uint32_t site, int* act,
-           float* logp, const EnvFuse* env = nullptr, int out_ld = 0) {
+           float* logp, const EnvFuse* env = nullptr, int out_ld = 0, const HeadRiders* rd = nullptr, const LossFuse* fuse = nullptr) {
     const int req = head_split_request(B);
     int nsplit = 0;
     if (req > 1) {
@@ -973,8 +1000,13 @@ struct PEng {
     }
     HeadOutArgs ha;
     ha.h[0] = {A1, n.fc_b, n.out_w, n.out_b, n_out, sigmoid, H, out, 0, act, logp, out_ld};
+    if (rd) {
+      ha.h[0].act_given = rd->act_given; ha.h[0].n_given = rd->n_given; if (rd->logp) ha.h[0].logp = rd->logp;
+      ha.h[0].relabel_rew = rd->relabel_rew; ha.h[0].relabel_idrew = rd->relabel_idrew; ha.h[0].relabel_obs = rd->relabel_obs; ha.h[0].relabel_lamb = rd->relabel_lamb;
+    }
     ha.h[1] = ha.h[0];
     LossFuse none; memset(&none, 0, sizeof(none));
+    if (fuse) none = *fuse;
     EnvFuse ef; memset(&ef, 0, sizeof(ef));
     if (env) ef = *env;
     hipLaunchKernelGGL(head_out_kernel, dim3(mansy_ceil_div(B, 4), 1), dim3(256), 0, st, ha, W.A1s, nsplit, (long long)B * HID, HID, W.F, MAXOUT, B, u,
@@ -984,7 +1016,7 @@ struct PEng {
   }
   // actor + critic on the shared features in one product ([B,1280] x [1280,256], K-split slabs) and one head_out launch
   // value != nullptr: the critic's output goes straight into that [B] vector (no strided copy afterwards)
-  int head_pair(const NetP& a, const NetP& c, int B, const LossFuse* fuse = nullptr, float* value = nullptr) {
+  int head_pair(const NetP& a, const NetP& c, int B, const LossFuse* fuse = nullptr, float* value = nullptr, const HeadRiders* rd = nullptr) {
     const int req = head_split_request(B, 2 * HID);
     const int nsplit = mansy_gemm_effective_splits(FEAT, req);
     MANSY_REQUIRE(nsplit <= MAX_SLABS, "head_pair: %d K splits exceed the slab sum's unroll", nsplit);
@@ -993,6 +1025,7 @@ struct PEng {
     HeadOutArgs ha;
     ha.h[0] = {W.A1a, a.fc_b, a.out_w, a.out_b, NACT, 0, W.Ha, W.outa, 0, nullptr, nullptr, 0};
     ha.h[1] = {W.A1c, c.fc_b, c.out_w, c.out_b, 1, 0, W.Hc, value ? value : W.outc, HID, nullptr, nullptr, value ? 1 : 0};
+    if (rd) { ha.h[0].act_given = rd->act_given; ha.h[0].n_given = rd->n_given; ha.h[0].logp = rd->logp; }
     LossFuse lf; memset(&lf, 0, sizeof(lf));
     if (fuse) lf = *fuse;
     EnvFuse noenv; memset(&noenv, 0, sizeof(noenv));
@@ -1033,6 +1066,13 @@ struct PEng {
     GemmEpilogue ep; ep.pre_a = W.dHa; ep.pre_b = W.dHc; ep.pre_ld = HID; ep.pre_col0 = RESID_COL;
     ep.mask_src = W.F; ep.mask_ld = FEAT; ep.mask_scale = 1.f; ep.mask_neg = SLOPE;
     return mansy_launch_gemm_f32(W.dA1p, 2 * HID, 0, W.Wfc2, FEAT, 1, W.dF, FEAT, B, FEAT, 2 * HID, ep, 0, 0, st);
+  }
+  // head_bwd without the output-layer launch (the identifier's training step): dA1 / dH were written by head_out_kernel
+  int fc_bwd_single(const NetP& n, int B, const float* dA1, const float* dH) {
+    GemmEpilogue acc; acc.accumulate = 1; acc.a_rowsum = n.gfc_b;
+    RC(mansy_launch_gemm_f32(dA1, HID, 1, W.F, FEAT, 1, n.gfc_w, FEAT, HID, FEAT, B, acc, 0, 0, st));
+    GemmEpilogue ep; ep.pre_a = dH; ep.pre_ld = HID; ep.pre_col0 = RESID_COL; ep.mask_src = W.F; ep.mask_ld = FEAT; ep.mask_scale = 1.f; ep.mask_neg = SLOPE;
+    return mansy_launch_gemm_f32(dA1, HID, 0, n.fc_w, FEAT, 1, W.dF, FEAT, B, FEAT, HID, ep, 0, 0, st);
   }
   // head_bwd_pair without the output-layer launch: head_out_kernel wrote dH / dA1 itself (LossFuse::bwd_*), the output layers' weight
   // gradients are riders of the unpack launch (OutGradRider) -- the PPO minibatch step's form
@@ -1212,19 +1252,29 @@ int mansy_identifier_train_step(const float* const* params, float* const* grads,
   MANSY_REQUIRE(params && obs && loss_out && B >= 1 && B <= max_batch, "identifier_train_step: bad arguments");
   PEng e; RC(setup(workspace, max_batch, (hipStream_t)stream, e));
   NetP n; bind_net(params, grads, 20, n);
-  RC(e.pack(n, 1));
+  const bool train = step != 0;
+  MANSY_REQUIRE(!train || (grads && flat_p && flat_g && flat_m && flat_v), "identifier_train_step: null optimiser buffers");
+  RC(e.pack(n, 1, nullptr, nullptr, nullptr, 0, train ? flat_g : nullptr, n_flat));      // the gradient zero-fill rides on the pack launch
   RC(e.featnet(obs, B, 1));
-  RC(e.head(n, B, 3, 1, e.W.A1a, e.W.Ha, e.W.outa, nullptr, 0, 0, nullptr, nullptr));
-  const bool train = step != 0;      // (W.acc[0], the loss accumulator, was zeroed by the pack launch's riders)        // step < 0: gradients only (data-parallel callers all-reduce, then mansy_clip_grad_adam)
-  // (gout needs no zero-fill: head_out_bwd_kernel selects columns < n_out and never uses the rest)
-  hipLaunchKernelGGL(ident_mse_kernel, dim3(min(mansy_ceil_div(B * 3, 256), 256)), dim3(256), 0, e.st, e.W.outa, obs, B, train ? e.W.gout : nullptr, e.W.acc,
-                     loss_out);
-  MANSY_LAUNCH_CHECK();
-  if (!train) return MANSY_OK;
-  MANSY_REQUIRE(grads && flat_p && flat_g && flat_m && flat_v, "identifier_train_step: null optimiser buffers");
-  MANSY_HIP_CHECK(hipMemsetAsync(flat_g, 0, sizeof(float) * (size_t)n_flat, e.st));
-  RC(e.head_bwd(n, B, 3, e.W.gout, e.W.A1a, e.W.Ha, e.W.dHa, e.W.dA1a, false));
-  RC(e.featnet_bwd(n, obs, B, 1, e.W.dHa, nullptr));
+  if (!train) {          // validation: loss only (W.acc[0..1], the accumulator and the arrival counter, were zeroed by the pack launch's riders)
+    RC(e.head(n, B, 3, 1, e.W.A1a, e.W.Ha, e.W.outa, nullptr, 0, 0, nullptr, nullptr));
+    hipLaunchKernelGGL(ident_mse_kernel, dim3(min(mansy_ceil_div(B * 3, 256), 256)), dim3(256), 0, e.st, e.W.outa, obs, B, nullptr, e.W.acc, loss_out);
+    MANSY_LAUNCH_CHECK();
+    return MANSY_OK;
+  }
+  // training (step < 0: gradients only -- data-parallel callers all-reduce, then mansy_clip_grad_adam): the MSE, its gradient and the
+  // output layer's input-side backward ride on the output-layer launch, the output layer's weight gradients and the loss on the unpack
+  // launch (round 3: ident_mse_kernel and head_out_bwd_kernel are gone from this path, as from the PPO step)
+  LossFuse lf; memset(&lf, 0, sizeof(lf));
+  lf.on = 2; lf.n = B; lf.mse_obs = obs; lf.dlogits = e.W.gout; lf.lossrows = e.W.lossrows;
+  lf.bwd_dH[0] = e.W.dHa; lf.bwd_dH[1] = e.W.dHa; lf.bwd_dA1 = e.W.dA1a; lf.bwd_dA1_ld = HID;
+  RC(e.head(n, B, 3, 1, e.W.A1a, e.W.Ha, e.W.outa, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, nullptr, &lf));
+  RC(e.fc_bwd_single(n, B, e.W.dA1a, e.W.dHa));
+  OutGradRider og; memset(&og, 0, sizeof(og));
+  og.on = 1; og.rows = B; og.g[0] = e.W.gout; og.g[1] = e.W.gout; og.H[0] = e.W.Ha; og.H[1] = e.W.Ha; og.n_out[0] = 3; og.n_out[1] = 0;
+  og.gW[0] = n.gout_w; og.gb[0] = n.gout_b; og.gW[1] = n.gout_w; og.gb[1] = n.gout_b;
+  og.lossrows = e.W.lossrows; og.stats = loss_out; og.mse = 1;
+  RC(e.featnet_bwd(n, obs, B, 1, e.W.dHa, nullptr, nullptr, 0, nullptr, &og));
   if (step < 0) return MANSY_OK;
   return e.clip_and_adam(flat_p, flat_g, flat_m, flat_v, n_flat, 0.f, lr, weight_decay, step);
 }
@@ -1236,9 +1286,8 @@ int mansy_identifier_relabel(const float* const* params, const float* obs, float
   NetP n; bind_net(params, nullptr, 20, n);
   RC(e.pack(n, 1));
   RC(e.featnet(obs, B, 1));
-  RC(e.head(n, B, 3, 1, e.W.A1a, e.W.Ha, e.W.outa, nullptr, 0, 0, nullptr, nullptr));
-  hipLaunchKernelGGL(relabel_kernel, dim3(mansy_ceil_div(B, 256)), dim3(256), 0, e.st, e.W.outa, obs, rew, id_rew, B, lamb);
-  MANSY_LAUNCH_CHECK();
+  PEng::HeadRiders rd; rd.relabel_rew = rew; rd.relabel_idrew = id_rew; rd.relabel_obs = obs; rd.relabel_lamb = lamb;      // the relabel rides on the output-layer launch
+  RC(e.head(n, B, 3, 1, e.W.A1a, e.W.Ha, e.W.outa, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, &rd));
   return MANSY_OK;
 }
 
@@ -1255,12 +1304,9 @@ int mansy_policy_evaluate(const float* const* params, const float* obs, int B, c
   RC(e.pack(a, 0, both ? &c : nullptr));
   RC(e.featnet(obs, B, 0));
   if (logp) MANSY_REQUIRE(act, "policy_evaluate: logp needs actions");
-  if (both) RC(e.head_pair(a, c, B, nullptr, value));      // actor + critic in one stacked product; the value lands in `value`
-  if (logp) {
-    if (!both) RC(e.head(a, B, NACT, 0, e.W.A1a, e.W.Ha, e.W.outa, nullptr, 0, 0, nullptr, nullptr));
-    hipLaunchKernelGGL(logp_kernel, dim3(mansy_ceil_div(n_logp, 256)), dim3(256), 0, e.st, e.W.outa, act, n_logp, logp);
-    MANSY_LAUNCH_CHECK();
-  }
+  PEng::HeadRiders rd; rd.act_given = logp ? act : nullptr; rd.n_given = logp ? n_logp : 0; rd.logp = logp;      // logp_old rides on the output-layer launch
+  if (both) RC(e.head_pair(a, c, B, nullptr, value, &rd));      // actor + critic in one stacked product; the value lands in `value`
+  else if (logp) RC(e.head(a, B, NACT, 0, e.W.A1a, e.W.Ha, e.W.outa, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, &rd));
   if (value && !both) RC(e.head(c, B, 1, 0, e.W.A1c, e.W.Hc, value, nullptr, 0, 0, nullptr, nullptr, nullptr, 1));
   return MANSY_OK;
 }
