@@ -309,9 +309,27 @@ class ViewportTransformerMTIO(nn.Module):
         return out
 
     def _perms_to_device(self, perms, device):
+        """The MTIO row permutations of heads 2 and 3 -> device int32, through a small ring of PINNED staging buffers and ONE
+        non-blocking copy (a pageable `.to(device)` blocks the host until the copy has run, i.e. until the GPU has drained
+        everything enqueued before it: the host then cannot enqueue the step ahead of time)."""
         if perms is None:
             return None
-        return [torch.from_numpy(np.ascontiguousarray(p, dtype=np.int32)).to(device) for p in perms]
+        B = len(perms[0])
+        ring = getattr(self, '_perm_ring', None)
+        if ring is None or ring['buf'][0].numel() < 2 * B:
+            ring = {'buf': [torch.empty(2 * B, dtype=torch.int32).pin_memory() for _ in range(4)], 'ev': [None] * 4, 'i': 0}
+            self._perm_ring = ring
+        i = ring['i']
+        ring['i'] = (i + 1) % 4
+        if ring['ev'][i] is not None:
+            ring['ev'][i].synchronize()                      # the copy that last used this slot (four uploads ago) has run
+        host = ring['buf'][i][:2 * B]
+        host[:B].copy_(torch.from_numpy(np.ascontiguousarray(perms[0], dtype=np.int32)))
+        host[B:].copy_(torch.from_numpy(np.ascontiguousarray(perms[1], dtype=np.int32)))
+        dev = host.to(device, non_blocking=True)
+        ring['ev'][i] = torch.cuda.Event()
+        ring['ev'][i].record(torch.cuda.current_stream(device))
+        return [dev[:B], dev[B:]]
 
     # ------------------------------------------------------------------ reference API
     def forward(self, history, current, future):
