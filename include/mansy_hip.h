@@ -204,8 +204,8 @@ int mansy_policy_evaluate(const float* const* params, const float* obs, int B, c
 int mansy_identifier_forward(const float* const* params, const float* obs, int B, float* pred /* [B,16], 3 used */, void* workspace,
                              int max_batch, void* stream);
 int mansy_identifier_train_step(const float* const* params, float* const* grads, float* flat_p, float* flat_g, float* flat_m,
-                                float* flat_v, long long n_flat, const float* obs, int B, float lr, float weight_decay, int step,
-                                float* loss_out, void* workspace, int max_batch, void* stream);
+                                float* flat_v, long long n_flat, const float* obs, const int* idx /* NULL: rows 0..B of obs; else obs[idx[r]] */,
+                                int B, float lr, float weight_decay, int step, float* loss_out, void* workspace, int max_batch, void* stream);
 int mansy_identifier_relabel(const float* const* params, const float* obs, float* rew, float* id_rew, int B, float lamb,
                              void* workspace, int max_batch, void* stream);
 int mansy_gae_returns(const float* rew, const float* v_s, const float* v_next, const unsigned char* done, int T, int N, double gamma,

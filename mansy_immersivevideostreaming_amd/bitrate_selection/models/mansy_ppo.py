@@ -310,16 +310,17 @@ class PPOPolicy(nn.Module):
         idx = np.arange(n)
         np.random.shuffle(idx)
         idx_t = self._upload_i32('ident', idx, obs.device)
-        obs = obs.index_select(0, idx_t)
         ntr = int(n * 0.8)
-        tr, va = obs[:ntr].contiguous(), obs[ntr:].contiguous()
+        # the shuffled 80 / 20 split as row indices into the buffer: each call gathers its rows in its own prologue launch (no
+        # shuffled copy of the 12.8 MB of observations, no separate gather launch)
+        tr, va = idx_t[:ntr], idx_t[ntr:]
         lr, wd = self._hyper(self.identifier_optim, 1e-4)
         f = eng.idn
         losses = []
         for _ in range(update_round):
             f.step += 1
-            losses.append(self._identifier_step(tr, lr, wd, f.step))
-        vloss = self._identifier_step(va, lr, wd, 0) if len(va) else None
+            losses.append(self._identifier_step(obs, lr, wd, f.step, rows=tr))
+        vloss = self._identifier_step(obs, lr, wd, 0, rows=va) if len(va) else None
         if verbose:
             for l in losses:
                 print('identifier loss is: ', l.item())
@@ -327,15 +328,16 @@ class PPOPolicy(nn.Module):
                 print('identifier validation loss is: ', vloss.item())
         return losses, vloss
 
-    def _identifier_step(self, obs, lr, wd, step):
+    def _identifier_step(self, obs, lr, wd, step, rows=None):
+        """One train_identifier step on `obs` (rows=None) or on its rows `rows` (device int32 indices)."""
         eng, f = self.engine, self.engine.idn
-        B = obs.shape[0]
+        B = obs.shape[0] if rows is None else rows.numel()
         if B > eng.max_batch:
             raise MansyError(f'identifier batch {B} exceeds engine max_batch {eng.max_batch}')
         arr, garr = f.pointers(grads=True)
         loss = torch.empty((), dtype=torch.float32, device=obs.device)
         dp = self.grad_sync is not None and step > 0
-        check(lib().mansy_identifier_train_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(obs), B, lr, wd,
+        check(lib().mansy_identifier_train_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(obs), ptr(rows), B, lr, wd,
                                                 -1 if dp else step, ptr(loss), ptr(eng.workspace()), eng.max_batch, stream_ptr(obs.device)),
               'mansy_identifier_train_step')
         if dp:

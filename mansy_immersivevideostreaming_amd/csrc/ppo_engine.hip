@@ -1246,15 +1246,18 @@ int mansy_identifier_forward(const float* const* params, const float* obs, int B
 
 // one full-batch step of train_identifier (mansy_utils.py:20-31): MSE fwd + bwd + Adam(L2).
 // step == 0: loss only (validation); step < 0: loss + gradients into flat_g, no optimiser step.
+// idx != NULL: the B rows are obs[idx[0..B)] (train_identifier's shuffled 80 / 20 split: gathered by a rider of the pack launch, like
+// the PPO minibatch step gathers its rows -- no separate gather launch, no shuffled copy of the buffer)
 int mansy_identifier_train_step(const float* const* params, float* const* grads, float* flat_p, float* flat_g, float* flat_m, float* flat_v,
-                                long long n_flat, const float* obs, int B, float lr, float weight_decay, int step, float* loss_out,
+                                long long n_flat, const float* obs_all, const int* idx, int B, float lr, float weight_decay, int step, float* loss_out,
                                 void* workspace, int max_batch, void* stream) {
-  MANSY_REQUIRE(params && obs && loss_out && B >= 1 && B <= max_batch, "identifier_train_step: bad arguments");
+  MANSY_REQUIRE(params && obs_all && loss_out && B >= 1 && B <= max_batch, "identifier_train_step: bad arguments");
   PEng e; RC(setup(workspace, max_batch, (hipStream_t)stream, e));
   NetP n; bind_net(params, grads, 20, n);
   const bool train = step != 0;
   MANSY_REQUIRE(!train || (grads && flat_p && flat_g && flat_m && flat_v), "identifier_train_step: null optimiser buffers");
-  RC(e.pack(n, 1, nullptr, nullptr, nullptr, 0, train ? flat_g : nullptr, n_flat));      // the gradient zero-fill rides on the pack launch
+  RC(e.pack(n, 1, nullptr, idx ? obs_all : nullptr, idx, B, train ? flat_g : nullptr, n_flat));      // row gather + gradient zero-fill ride on the pack launch
+  const float* obs = idx ? e.W.obs_mb : obs_all;
   RC(e.featnet(obs, B, 1));
   if (!train) {          // validation: loss only (W.acc[0..1], the accumulator and the arrival counter, were zeroed by the pack launch's riders)
     RC(e.head(n, B, 3, 1, e.W.A1a, e.W.Ha, e.W.outa, nullptr, 0, 0, nullptr, nullptr));
