@@ -27,23 +27,25 @@ __global__ __launch_bounds__(256) void env_init_kernel(EnvState* st, int n_env, 
   EnvRegs s = {};
   s.worker_num = worker_num;
   s.worker_id = (seed + index_offset + e) % worker_num;      // tianshou venv.seed(seed): env i gets seed + i (mansy_env.py:253-256)
-  copy_state(st[e], s);
+  copy_scalars(st[e], s);
+#pragma unroll
+  for (int k = 0; k < PAST_K; ++k) store_state(st[e], s, k);  // (lane 0 repeats the scalars; the rings get their eight zeros)
 }
 
 __global__ __launch_bounds__(256) void env_reset_kernel(mansy_env_tables T, EnvState* st, int n_env, float* obs) {
-  const int e = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  const int e = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + threadIdx.x) >> 6), lane = threadIdx.x & 63;
   if (e >= n_env) return;
   EnvRegs s;
-  copy_state(s, st[e]);                  // every lane holds the (uniform) record; lane 0 writes it back
+  load_state(s, st[e], lane);            // every lane holds the (uniform) scalars, lanes 0..7 the ring elements
   do_reset(T, s);
   write_obs(T, s, s.next_chunk, -1, lane, obs + (size_t)e * OBS_LD);
-  if (lane == 0) copy_state(st[e], s);
+  store_state(st[e], s, lane);
 }
 
 __global__ __launch_bounds__(256) void env_step_kernel(mansy_env_tables T, EnvState* st, int n_env, const int* __restrict__ actions,
                                                        float* obs_next, float* obs_cur, float* reward, unsigned char* done,
                                                        float* qoe_parts, mansy_env_episode_log elog) {
-  const int e = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  const int e = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + threadIdx.x) >> 6), lane = threadIdx.x & 63;   // wave-uniform
   if (e >= n_env) return;
   env_step_wave(T, st, e, lane, actions[e], obs_next, obs_cur, reward, done, qoe_parts, elog);
 }

@@ -9,12 +9,12 @@ constexpr int OBS_LD = MANSY_OBS_LD;
 static __constant__ int A2R[N_ACTION][2] = {{1,0},{2,0},{3,0},{4,0},{2,1},{3,1},{4,1},{3,2},{4,2},{4,3},{0,0},{1,1},{2,2},{3,3},{4,4}};
 
 typedef float RingMem[PAST_K];
-typedef float RingReg __attribute__((ext_vector_type(PAST_K)));
 
-// Per-environment record. EnvState (rings as float[8], AoS, 256 bytes) is the layout in HBM; EnvRegs (rings as 8-wide vector
-// values) is the copy a kernel works on. hipcc keeps a local record with array members in scratch memory for the whole kernel
-// (a lane-indexed ring read becomes a dynamically indexed private load, which pins the stack object); vector members are SSA
-// values, so the record lives in registers and a lane-indexed read is a select chain.
+// Per-environment record. EnvState (history rings as float[8], AoS, 256 bytes) is the layout in HBM; EnvRegs is the copy a wave
+// works on: the scalars are held by every lane (uniform), each history ring is spread over lanes 0..7 (lane k holds element k),
+// so a ring costs one register instead of eight, pushing a value is one row-shift and the observation's history slots are
+// written straight from the lanes that hold them.  (A local record with array members would live in scratch memory: a
+// lane-indexed ring read becomes a dynamically indexed private load, which pins the stack object.)
 template <typename Ring>
 struct EnvRec {
   int worker_id, worker_num, sample_id;
@@ -27,10 +27,10 @@ struct EnvRec {
   Ring past_throughput, past_acc, past_in, past_out, past_q, past_var, past_rebuf;
 };
 using EnvState = EnvRec<RingMem>;
-using EnvRegs = EnvRec<RingReg>;
+using EnvRegs = EnvRec<float>;
 
 template <typename D, typename S>
-__device__ __forceinline__ void copy_state(D& d, const S& s) {   // member-wise: a whole-struct copy is a memcpy via the stack
+__device__ __forceinline__ void copy_scalars(D& d, const S& s) {   // member-wise: a whole-struct copy is a memcpy via the stack
   d.worker_id = s.worker_id; d.worker_num = s.worker_num; d.sample_id = s.sample_id;
   d.video = s.video; d.vp = s.vp; d.trace = s.trace; d.qoe = s.qoe;
   d.next_chunk = s.next_chunk; d.end_chunk = s.end_chunk;
@@ -38,10 +38,18 @@ __device__ __forceinline__ void copy_state(D& d, const S& s) {   // member-wise:
   d.cur_time = s.cur_time; d.buf_size = s.buf_size; d.last_chunk_accuracy = s.last_chunk_accuracy;
   d.log_qoe = s.log_qoe; d.log_qoe1 = s.log_qoe1; d.log_qoe2 = s.log_qoe2; d.log_qoe3 = s.log_qoe3;
   d.prev_vq = s.prev_vq; d.buffer0 = s.buffer0;
-#pragma unroll
-  for (int i = 0; i < PAST_K; ++i) {
-    d.past_throughput[i] = s.past_throughput[i]; d.past_acc[i] = s.past_acc[i]; d.past_in[i] = s.past_in[i]; d.past_out[i] = s.past_out[i];
-    d.past_q[i] = s.past_q[i]; d.past_var[i] = s.past_var[i]; d.past_rebuf[i] = s.past_rebuf[i];
+}
+__device__ __forceinline__ void load_state(EnvRegs& d, const EnvState& s, int lane) {   // every lane of the wave calls this
+  copy_scalars(d, s);
+  const int k = lane & (PAST_K - 1);
+  d.past_throughput = s.past_throughput[k]; d.past_acc = s.past_acc[k]; d.past_in = s.past_in[k]; d.past_out = s.past_out[k];
+  d.past_q = s.past_q[k]; d.past_var = s.past_var[k]; d.past_rebuf = s.past_rebuf[k];
+}
+__device__ __forceinline__ void store_state(EnvState& d, const EnvRegs& s, int lane) {  // every lane of the wave calls this
+  if (lane == 0) copy_scalars(d, s);
+  if (lane < PAST_K) {
+    d.past_throughput[lane] = s.past_throughput; d.past_acc[lane] = s.past_acc; d.past_in[lane] = s.past_in; d.past_out[lane] = s.past_out;
+    d.past_q[lane] = s.past_q; d.past_var[lane] = s.past_var; d.past_rebuf[lane] = s.past_rebuf;
   }
 }
 
@@ -61,12 +69,6 @@ __device__ __forceinline__ Rates load_rates(const mansy_env_tables& T) {
 }
 __device__ __forceinline__ int pick_rate(const Rates& r, int i) {
   return i == 4 ? r.r4 : i == 3 ? r.r3 : i == 2 ? r.r2 : i == 1 ? r.r1 : r.r0;
-}
-__device__ __forceinline__ float pick_past(const RingReg& ring, int i) {
-  float v = ring[0];
-#pragma unroll
-  for (int k = 1; k < PAST_K; ++k) v = i == k ? ring[k] : v;
-  return v;
 }
 __device__ __forceinline__ void closer(int cand, int cand_rate, int rate, int& ver, int& ver_rate, int& gap) {
   const int g = abs(cand_rate - rate);
@@ -145,13 +147,13 @@ __device__ __forceinline__ void store_obs(const mansy_env_tables& T, const EnvRe
   // the 68 scalar slots: 0..7 throughput | 712..743 acc,q,var,rebuf | 744 buffer | 745..747 qoe_w | 748..762 one-hot |
   // 763..778 rates in/out | 779 pad
   if (lane < PAST_K) {
-    obs[MANSY_O_THROUGHPUT + lane] = pick_past(s.past_throughput, lane);
-    obs[MANSY_O_VP_ACC + lane] = pick_past(s.past_acc, lane);
-    obs[MANSY_O_PAST_Q + lane] = pick_past(s.past_q, lane);
-    obs[MANSY_O_PAST_VAR + lane] = pick_past(s.past_var, lane);
-    obs[MANSY_O_PAST_REBUF + lane] = pick_past(s.past_rebuf, lane);
-    obs[MANSY_O_RATES_IN + lane] = pick_past(s.past_in, lane);
-    obs[MANSY_O_RATES_OUT + lane] = pick_past(s.past_out, lane);
+    obs[MANSY_O_THROUGHPUT + lane] = s.past_throughput;
+    obs[MANSY_O_VP_ACC + lane] = s.past_acc;
+    obs[MANSY_O_PAST_Q + lane] = s.past_q;
+    obs[MANSY_O_PAST_VAR + lane] = s.past_var;
+    obs[MANSY_O_PAST_REBUF + lane] = s.past_rebuf;
+    obs[MANSY_O_RATES_IN + lane] = s.past_in;
+    obs[MANSY_O_RATES_OUT + lane] = s.past_out;
   }
   const float* w = T.qoe_w + 3 * s.qoe;
   const float wsum = (w[0] + w[1]) + w[2];
@@ -175,18 +177,15 @@ __device__ __forceinline__ void do_reset(const mansy_env_tables& T, EnvRegs& s) 
   s.next_chunk = T.startup_download + 1;
   s.has_prev = 0; s.prev_vq = 0.f;
   s.last_chunk_accuracy = T.vp_acc[(size_t)s.vp * T.n_vpchunk_max + (s.next_chunk - T.vp_start[s.vp])];
-#pragma unroll
-  for (int i = 0; i < PAST_K; ++i) {
-    s.past_throughput[i] = 0.f; s.past_acc[i] = 0.f; s.past_in[i] = 0.f; s.past_out[i] = 0.f; s.past_q[i] = 0.f; s.past_var[i] = 0.f;
-    s.past_rebuf[i] = 0.f;
-  }
+  s.past_throughput = 0.f; s.past_acc = 0.f; s.past_in = 0.f; s.past_out = 0.f; s.past_q = 0.f; s.past_var = 0.f; s.past_rebuf = 0.f;
   s.buffer0 = (float)s.buf_size;
   s.log_qoe = s.log_qoe1 = s.log_qoe2 = s.log_qoe3 = 0.0; s.log_n = 0;
 }
 
-__device__ __forceinline__ void roll_push(RingReg& ring, float v) {
-  ring = __builtin_shufflevector(ring, ring, 0, 0, 1, 2, 3, 4, 5, 6);
-  ring[0] = v;
+// np.roll(ring, 1); ring[0] = v on a lane-distributed ring: lane k takes lane k-1's element (row shift right by one; lane 0, which
+// has no source lane, keeps the `old` operand = v).  v is uniform over the wave.
+__device__ __forceinline__ void roll_push(float& ring, float v) {
+  ring = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, ring), 0x111, 0xf, 0xf, false));
 }
 
 // One environment step by one wavefront (lane = tile): MANSYEnv.step (mansy_env.py:154-248).  obs_next: the post-action
@@ -195,7 +194,7 @@ __device__ __forceinline__ void roll_push(RingReg& ring, float v) {
 __device__ __forceinline__ void env_step_wave(const mansy_env_tables& T, EnvState* st, int e, int lane, int action, float* obs_next, float* obs_cur,
                                               float* reward, unsigned char* done, float* qoe_parts, const mansy_env_episode_log& elog) {
   EnvRegs s;
-  copy_state(s, st[e]);
+  load_state(s, st[e], lane);
   const int rin = (action >= 0 && action < N_ACTION) ? A2R[action][0] : 0;
   const int rout = (action >= 0 && action < N_ACTION) ? A2R[action][1] : 0;
   const int chunk = s.next_chunk;
@@ -295,6 +294,6 @@ __device__ __forceinline__ void env_step_wave(const mansy_env_tables& T, EnvStat
   } else if (obs_cur && obs_cur != obs_next) {
     store_obs(T, s, rows_next, action, lane, obs_cur + (size_t)e * OBS_LD);
   }
-  if (lane == 0) copy_state(st[e], s);
+  store_state(st[e], s, lane);
 }
 

@@ -540,7 +540,7 @@ __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const f
       for (int k = 0; k < MAXOUT; ++k) if (k == a) oa = o[k];
       if (logp) logp[row] = (oa - m) - logf(s);
     }
-    if (ef.on) envdev::env_step_wave(ef.T, ef.st, row, lane, a, ef.obs_next, ef.obs_cur, ef.reward, ef.done, ef.qoe_parts, ef.elog);
+    if (ef.on) envdev::env_step_wave(ef.T, ef.st, __builtin_amdgcn_readfirstlane(row), lane, a, ef.obs_next, ef.obs_cur, ef.reward, ef.done, ef.qoe_parts, ef.elog);
   }
 }
 
