@@ -12,38 +12,41 @@ namespace {
 
 __device__ __forceinline__ int pymod(int a, int m) { int r = a % m; return r < 0 ? r + m : r; }
 __device__ __forceinline__ int block_of(int x, int bw) {   // find_block_covered_by_point, x >= 0
-  int w = x / bw;
-  if (x > 0 && x % bw == 0) w -= 1;
-  return w;
+  return (x > 0 ? x - 1 : x) / bw;               // x / bw, minus one when x is a positive exact multiple: one division, no modulo
 }
-// 1-D interval split exactly as _find_regions_covered_by_fov does per axis:
-//   lo >= 0 && hi <= size : [lo,hi]
-//   lo <  0 && hi <= size : [0,hi] and [lo % size, size]
+// Tiles of one axis covered by the FoV interval [lo, hi] on a frame of `size` pixels, tiles `bw` wide, `n` of them.
+// _find_regions_covered_by_fov splits the interval per axis exactly like this:
+//   lo >= 0 && hi <= size : [lo, hi]
+//   lo <  0 && hi <= size : [0, hi] and [lo % size, size]
 //   lo >= 0 && hi >  size : [0, hi % size] and [lo, size]
-// returns the count (0 if neither, which the reference cannot reach for fov < size)
-__device__ __forceinline__ int split_axis(int lo, int hi, int size, int (&a)[2], int (&b)[2]) {
-  if (lo >= 0 && hi <= size) { a[0] = lo; b[0] = hi; return 1; }
-  if (lo < 0 && hi <= size) { a[0] = 0; b[0] = hi; a[1] = pymod(lo, size); b[1] = size; return 2; }
-  if (lo >= 0 && hi > size) { a[0] = 0; b[0] = pymod(hi, size); a[1] = lo; b[1] = size; return 2; }
-  return 0;
+// (neither -- lo < 0 && hi > size -- cannot happen for fov < size and yields nothing), and each interval [p, q] marks the numpy
+// slice [block_of(p) : block_of(q) + 1] clipped to [0, n).  With tA = block_of(lo or lo % size), tB = block_of(hi or hi % size),
+// tS = block_of(size) and block_of(0) = 0 that is
+//   one interval : bits [tA, tB]          = below(tB) & ~under(tA)
+//   two intervals: bits [0, tB] | [tA, tS] = below(tB) | (~under(tA) & below(tS))
+// -- two divisions per axis and selects instead of branches: neighbouring points fall into different cases, and a wave that takes
+// every branch pays for all of them (round 3: the kernel was ALU-bound at ~290 integer instructions per point, a third of them
+// executed for the other lanes' cases).
+__device__ __forceinline__ unsigned below(int t, int n) {      // bits [0, min(t + 1, n))
+  const int c = t + 1 > n ? n : t + 1;
+  return c <= 0 ? 0u : (c >= 32 ? 0xFFFFFFFFu : ((1u << (c & 31)) - 1u));
 }
-__device__ __forceinline__ unsigned range_mask(int t1, int t2, int n) {   // numpy slice [t1 : t2+1] clipped to [0,n)
-  const int a = t1 < 0 ? 0 : t1, b = t2 + 1 > n ? n : t2 + 1;
-  if (b <= a) return 0u;
-  return ((b >= 32 ? 0xFFFFFFFFu : ((1u << b) - 1u))) & ~((1u << a) - 1u);
+__device__ __forceinline__ unsigned under(int t) {             // bits [0, max(t, 0))
+  return t <= 0 ? 0u : (t >= 32 ? 0xFFFFFFFFu : ((1u << (t & 31)) - 1u));
+}
+__device__ __forceinline__ unsigned axis_mask(int lo, int hi, int size, int bw, int n) {
+  const bool neg = lo < 0, over = hi > size;
+  const int tA = block_of(neg ? pymod(lo, size) : lo, bw), tB = block_of(over ? pymod(hi, size) : hi, bw), tS = block_of(size, bw);
+  const unsigned L = below(tB, n), Hh = ~under(tA);
+  const unsigned m = (neg != over) ? (L | (Hh & below(tS, n))) : (L & Hh);
+  return (neg && over) ? 0u : m;
 }
 
 __device__ __forceinline__ unsigned long long tilemap_px(int x, int y, int W, int H, int tw, int th, int nw, int nh, int fov_w, int fov_h) {
   const int hw = fov_w / 2, hh = fov_h / 2;
-  int xa[2], xb[2], ya[2], yb[2];
-  const int nx = split_axis(x - hw, x + hw, W, xa, xb);
-  const int ny = split_axis(y - hh, y + hh, H, ya, yb);
-  // The covered regions are the cross product of the (<= 2) x intervals and the (<= 2) y intervals, so the union of their tile
-  // rectangles is (union of the row masks) x (union of the column masks): two small OR loops and one outer product instead of
-  // up to 2 x 2 x nh shift / OR steps (round 3: the kernel was ALU-bound at ~290 integer instructions per point).
-  unsigned rows = 0u, cols = 0u;
-  for (int j = 0; j < ny; ++j) rows |= range_mask(block_of(ya[j], th), block_of(yb[j], th), nh);
-  for (int i = 0; i < nx; ++i) cols |= range_mask(block_of(xa[i], tw), block_of(xb[i], tw), nw);
+  const unsigned rows = axis_mask(y - hh, y + hh, H, th, nh), cols = axis_mask(x - hw, x + hw, W, tw, nw);
+  // the covered regions are the cross product of the x intervals and the y intervals, so the union of their tile rectangles is
+  // (union of the row masks) x (union of the column masks): one outer product
   if (nw == 8 && nh == 8) {
     // byte r of the map = cols if bit r of rows is set: replicate rows into every byte, keep bit r in byte r, turn "byte != 0" into 0xFF
     const unsigned long long t = ((unsigned long long)(rows & 0xFFu) * 0x0101010101010101ull) & 0x8040201008040201ull;

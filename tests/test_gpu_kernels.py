@@ -263,6 +263,33 @@ def test_tilemap_bit_exact_vs_oracle_and_reference_goldens(K):
     np.testing.assert_array_equal(got, tm.tilemap_xy(xy))
 
 
+@pytest.mark.parametrize('geom', [(2560, 1440, 8, 8, 600, 300), (1920, 1080, 6, 4, 400, 200), (3840, 1920, 16, 4, 1000, 500),
+                                  (1280, 720, 4, 4, 600, 300), (2560, 1440, 32, 2, 90, 90)])
+def test_tilemap_other_geometries_and_every_wrap_case_vs_oracle(K, geom):
+    """The generic kernel (run-time frame / grid / FoV) and the constant-folded standard one against the C oracle: a dense sweep of the
+    frame borders, every tile boundary +-1 pixel, both axes, so that all nine region cases of _find_regions_covered_by_fov
+    (viewport_prediction/utils/common.py:83-127) and the "exact multiple belongs to the lower tile" rule occur."""
+    from oracle import tilemap as tm
+    W, H, nw, nh, fw, fh = geom
+    tw, th = W // nw, H // nh
+    xs = sorted({v for k in range(nw + 1) for v in (k * tw - 1, k * tw, k * tw + 1)} | {fw // 2 - 1, fw // 2, fw // 2 + 1, W - fw // 2 - 1,
+                 W - fw // 2, W - fw // 2 + 1} | set(range(0, W + 1, max(1, W // 97))))
+    ys = sorted({v for k in range(nh + 1) for v in (k * th - 1, k * th, k * th + 1)} | {fh // 2 - 1, fh // 2, fh // 2 + 1, H - fh // 2 - 1,
+                 H - fh // 2, H - fh // 2 + 1} | set(range(0, H + 1, max(1, H // 89))))
+    xs = [x for x in xs if 0 <= x <= W]
+    ys = [y for y in ys if 0 <= y <= H]
+    px = np.array([(x, y) for x in xs for y in ys], np.int64)
+    xy = np.stack([(px[:, 0] + 0.5) / W, (px[:, 1] + 0.5) / H], 1).astype(np.float32)
+    xy[px[:, 0] == W, 0] = 1.0
+    xy[px[:, 1] == H, 1] = 1.0
+    back = np.stack([(xy[:, 0] * np.float32(W)).astype(np.int32), (xy[:, 1] * np.float32(H)).astype(np.int32)], 1)
+    assert (back == px).mean() > 0.99
+    got = K.tilemap(torch.from_numpy(xy).cuda(), W, H, nw, nh, fw, fh).cpu().numpy().view(np.uint64)
+    want = tm.tilemap_xy(xy, W, H, nw, nh, fw, fh)
+    np.testing.assert_array_equal(got, want)
+    assert len(np.unique(want)) > 4 * max(nw, nh) // 2
+
+
 def test_empty_and_degenerate_inputs(K):
     """Empty inputs are legal (the reference's loops simply do not run); degenerate 1x1x1 products and frame-edge pixels work."""
     d = 'cuda'
