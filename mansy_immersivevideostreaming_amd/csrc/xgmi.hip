@@ -130,11 +130,18 @@ int mansy_xg_create(long long n_floats, int world, int rank, void** ctx_out) {
   // coherent across agents at kernel boundaries)
   hipError_t e = hipExtMallocWithFlags((void**)&c->own, bytes, hipDeviceMallocFinegrained);
   if (e != hipSuccess) { delete c; mansy_set_error("xg_create: hipExtMallocWithFlags(fine-grained, %zu bytes) -> %s", bytes, hipGetErrorString(e)); return MANSY_EHIP; }
-  MANSY_HIP_CHECK(hipMemset(c->own, 0, bytes));
-  MANSY_HIP_CHECK(hipMalloc((void**)&c->counter, 256));
-  MANSY_HIP_CHECK(hipMemset(c->counter, 0, 256));
+  e = hipMalloc((void**)&c->counter, 256);
+  if (e == hipSuccess) e = hipMemset(c->own, 0, bytes);
+  if (e == hipSuccess) e = hipMemset(c->counter, 0, 256);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) {                                    // nothing of a half-built context survives
+    mansy_set_error("xg_create: %s", hipGetErrorString(e));
+    (void)hipFree(c->own);
+    if (c->counter) (void)hipFree(c->counter);
+    delete c;
+    return MANSY_EHIP;
+  }
   c->err = reinterpret_cast<int*>(c->counter) + 16;
-  MANSY_HIP_CHECK(hipDeviceSynchronize());
   c->peer_base[rank] = c->own;
   if (world == 1) c->imported = 1;
   *ctx_out = c;
