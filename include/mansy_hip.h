@@ -98,6 +98,10 @@ int mansy_mtio_loss_fwd_bwd(const float* pred, const float* gt, int B, int T, in
 int mansy_adamw_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                      float eps, float weight_decay, int step, int decoupled, void* stream);
 int mansy_ensemble_wrap(const float* pred, float* out, long long rows, int heads, int c, void* stream);
+/* LinearRegression.sample (viewport_prediction/models/linear_regression.py:18-36; `run_models.py --model regression`, :101-102): the
+ * comparison baseline -- per trajectory and coordinate a least-squares line through history [B,S,c] + current [B,1,c] over
+ * t = 0..S (scikit-learn LinearRegression(fit_intercept=True), float64 arithmetic), extrapolated to t = S+1..S+T -> out [B,T,c]. */
+int mansy_linreg_sample(const float* history, const float* current, int B, int S, int T, int c, float* out, void* stream);
 
 /* ViewportDataset.__getitem__ batched (viewport_prediction/utils/load_dataset.py:43-52): table [n_trace, L, c] resident
  * in HBM, idx int32 [B,2] = (trace slot, timestep) -> history [B,S,c], current [B,1,c], future [B,T,c] */

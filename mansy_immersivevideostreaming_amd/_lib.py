@@ -72,6 +72,7 @@ _PROTOS = {
     'mansy_mtio_loss_fwd_bwd': [P, P, c_int, c_int, c_int, P, P, P, P],
     'mansy_adamw_step': [P, P, P, P, c_ll, c_float, c_float, c_float, c_float, c_float, c_int, c_int, P],
     'mansy_ensemble_wrap': [P, P, c_ll, c_int, c_int, P],
+    'mansy_linreg_sample': [P, P, c_int, c_int, c_int, c_int, P, P],
     'mansy_traj_gather': [P, c_int, c_int, P, c_int, c_int, c_int, P, P, P, P],
     'mansy_periodic_mse': [P, P, c_ll, c_int, P, P],
     'mansy_tilemap_metrics': [P, P, c_ll, P, P],

@@ -140,6 +140,9 @@ int mansy_adamw_step(float* p, const float* g, float* m, float* v, long long n, 
                      float weight_decay, int step, int decoupled, void* stream) {
   return mansy_launch_adamw(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, decoupled, (hipStream_t)stream);
 }
+int mansy_linreg_sample(const float* history, const float* current, int B, int S, int T, int c, float* out, void* stream) {
+  return mansy_launch_linreg_sample(history, current, B, S, T, c, out, (hipStream_t)stream);
+}
 int mansy_ensemble_wrap(const float* pred, float* out, long long rows, int heads, int c, void* stream) {
   return mansy_launch_ensemble_wrap(pred, out, rows, heads, c, (hipStream_t)stream);
 }

@@ -446,6 +446,34 @@ __global__ __launch_bounds__(256) void ensemble_wrap_kernel(const float* __restr
   out[idx] = v;
 }
 
+// LinearRegression.sample (viewport_prediction/models/linear_regression.py:18-36, `run_models.py --model regression`): one thread per
+// (trajectory, coordinate) fits the least-squares line through the S + 1 past samples over t = 0..S and extrapolates T steps.
+// scikit-learn's arithmetic, in float64 like it: centre t and y on their means, coef = <tc, yc> / <tc, tc>,
+// intercept = y_mean - t_mean * coef, prediction = t * coef + intercept, rounded to float32 on the store (the reference assigns the
+// float64 prediction into a float32 tensor).
+__global__ __launch_bounds__(256) void linreg_sample_kernel(const float* __restrict__ hist, const float* __restrict__ cur, int B, int S, int T,
+                                                            int c, float* __restrict__ out) {
+#pragma clang fp contract(off)
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;     // over [B, c]
+  if (idx >= (long long)B * c) return;
+  const int j = (int)(idx % c);
+  const long long b = idx / c;
+  const int L = S + 1;
+  const float* h = hist + b * S * c + j;
+  const double last = (double)cur[b * c + j];
+  double sy = 0.0;
+  for (int l = 0; l < S; ++l) sy += (double)h[(long long)l * c];
+  sy += last;
+  const double y_mean = sy / (double)L, t_mean = (double)(L - 1) * 0.5;
+  double sxy = 0.0, sxx = 0.0;
+  for (int l = 0; l < L; ++l) {
+    const double tc = (double)l - t_mean, yc = (l < S ? (double)h[(long long)l * c] : last) - y_mean;
+    sxy += tc * yc; sxx += tc * tc;
+  }
+  const double coef = sxy / sxx, intercept = y_mean - t_mean * coef;
+  for (int k = 0; k < T; ++k) out[(b * T + k) * c + j] = (float)((double)(L + k) * coef + intercept);
+}
+
 __global__ __launch_bounds__(256) void tb_to_bt_kernel(const float* __restrict__ src, float* __restrict__ dst, int T, int B, int C) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;     // dst index over [B,T,C]
   if (idx >= (long long)T * B * C) return;
@@ -676,6 +704,14 @@ int mansy_launch_ensemble_wrap(const float* pred, float* out, long long rows, in
   MANSY_REQUIRE(pred && out, "ensemble_wrap: null pointer");
   if (rows <= 0) return MANSY_OK;
   hipLaunchKernelGGL(ensemble_wrap_kernel, g1(rows * c), dim3(256), 0, st, pred, out, rows, heads, c);
+  MANSY_LAUNCH_CHECK();
+  return MANSY_OK;
+}
+int mansy_launch_linreg_sample(const float* hist, const float* cur, int B, int S, int T, int c, float* out, hipStream_t st) {
+  MANSY_REQUIRE(S >= 1 && T >= 0 && c >= 1, "linreg_sample: need S >= 1 (two points fix a line), T >= 0, c >= 1");
+  if (B <= 0 || T == 0) return MANSY_OK;
+  MANSY_REQUIRE(hist && cur && out, "linreg_sample: null pointer");
+  hipLaunchKernelGGL(linreg_sample_kernel, g1((long long)B * c), dim3(256), 0, st, hist, cur, B, S, T, c, out);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }

@@ -203,6 +203,7 @@ int mansy_launch_mtio_mix(const float* x, const int* perm1, const int* perm2, fl
                           hipStream_t st);
 // ensemble mean over heads + wrap to [0,1] (mtio.py:125-133, utils/common.py:61-70): pred [B,T,heads*c] -> [B,T,c]
 int mansy_launch_ensemble_wrap(const float* pred, float* out, long long rows, int heads, int c, hipStream_t st);
+int mansy_launch_linreg_sample(const float* hist, const float* cur, int B, int S, int T, int c, float* out, hipStream_t st);
 // transpose-copy [T,B,C] <-> [B,T,C]
 int mansy_launch_tb_to_bt(const float* src, float* dst, int T, int B, int C, hipStream_t st);
 

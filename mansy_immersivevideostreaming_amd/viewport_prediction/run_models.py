@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from .. import _lib
-from .models import FusedAdamW, ViewportTransformerMTIO
+from .models import FusedAdamW, LinearRegression, ViewportTransformerMTIO
 from .utils.common import get_config_from_yml, mean_square_error
 from .utils.load_dataset import DeviceLoader, create_dataset
 from .utils.results import Results
@@ -58,9 +58,12 @@ class _Tee:
 
 
 def create_model(model_name, fut_window, hidden_dim, block_num, device, seed):
-    """run_models.py:99-106 (only the Transformer is on this path; the sklearn regression baseline is out of scope)."""
+    """run_models.py:99-106: the MTIO Transformer, or the linear-regression comparison baseline (one device launch per batch instead
+    of scikit-learn per trajectory)."""
+    if model_name == 'regression':
+        return LinearRegression(fut_window=fut_window, device=device)
     if model_name != 'mtio':
-        raise ValueError(f"model '{model_name}' is not on the MI355X path; use --model mtio")
+        raise ValueError(f"unknown model '{model_name}': the reference knows 'mtio' and 'regression' (run_models.py:110)")
     return ViewportTransformerMTIO(in_channel=2, fut_window=fut_window, d_model=hidden_dim, dim_feedforward=hidden_dim,
                                    num_encoder_layers=block_num, num_decoder_layers=block_num, device=device, seed=seed)
 
@@ -130,8 +133,9 @@ class Session:
 
     def test(self):
         a, model = self.args, self.model
-        model.load_state_dict(torch.load(self.path('best_model'), map_location=a.device))
-        print('Load model from', self.path('best_model'))
+        if a.model != 'regression':          # linear regression has no weights to load (run_models.py:75)
+            model.load_state_dict(torch.load(self.path('best_model'), map_location=a.device))
+            print('Load model from', self.path('best_model'))
         print(f'Testing {a.model} on {a.test_dataset} - seed: {a.seed}')
         notebook = Results(a.model, dimension=2, fut_window=a.fut_window, dataset_frequency=a.dataset_frequency, output_dir=self.results_dir,
                            mse=True, accuracy=True, config=self.config)
@@ -171,6 +175,10 @@ def main(argv=None):
     for attr, key in _CONFIG_DEFAULTS.items():                 # config.yml supplies what the command line leaves out (:199-203)
         if getattr(args, attr) is None:
             setattr(args, attr, config[key])
+    if args.model == 'regression':          # run_models.py:205-209 (the reference also moves to the CPU; here the fit is a device kernel)
+        args.train = False
+        args.compile = False
+        print('Detect model: regression. Automatically disenable train and compile mode.')
     print(args)
     run(args, config)
 

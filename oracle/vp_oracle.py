@@ -11,6 +11,9 @@ reference viewport predictor:
   * `sample`                                     models/mtio.py:106-133
   * MTIO loss / periodic MSE                     models/mtio.py:94-104, utils/common.py:73-80
   * `to_position_normalized_cartesian`           utils/common.py:61-70
+  * LinearRegression.sample (the comparison baseline) models/linear_regression.py:18-36
+    (third-party scikit-learn LinearRegression(fit_intercept=True): published algorithm restated;
+    pinned by tests/golden/linreg_reference.npz = the imported class on real Jin2022 windows)
 
 The decoder is restated as a KV-cached incremental decoder.  In eval mode / with
 dropout disabled this computes the same function (and therefore the same
@@ -311,6 +314,25 @@ def to_position_normalized_cartesian(values):
     out[neg] = values[neg] - values[neg].to(dtype=torch.int) + 1
     out[gt1] = values[gt1] - values[gt1].to(dtype=torch.int)
     return out
+
+
+def linear_regression_sample(history, current, fut_window):
+    """LinearRegression.sample (viewport_prediction/models/linear_regression.py:18-36): per trajectory and coordinate an ordinary
+    least-squares line through the S + 1 past samples over t = 0..S, extrapolated to t = S+1..S+T.  scikit-learn's
+    LinearRegression(fit_intercept=True).fit works in float64 (the int64 abscissa is converted by _preprocess_data, y follows X's
+    dtype): centre X and y on their means, least squares on the centred data (one column: coef = <xc, yc> / <xc, xc>),
+    intercept = y_mean - x_mean * coef, predict = t * coef + intercept; the float64 prediction is rounded to float32 when it is
+    assigned into the float32 `samples` tensor (:23,35).  numpy arrays in, float32 [B, T, 2] out."""
+    merge = np.concatenate([np.asarray(history), np.asarray(current)], axis=1).astype(np.float64)      # [B, L, 2]
+    L = merge.shape[1]
+    t = np.arange(L, dtype=np.float64)
+    tc = t - np.average(t)
+    y_mean = np.average(merge, axis=1)                                                                # [B, 2]
+    yc = merge - y_mean[:, None, :]
+    coef = np.einsum('l,blc->bc', tc, yc) / np.dot(tc, tc)
+    intercept = y_mean - np.average(t) * coef
+    fut = np.arange(L, L + fut_window, dtype=np.float64)
+    return (fut[None, :, None] * coef[:, None, :] + intercept[:, None, :]).astype(np.float32)
 
 
 def mtio_mix(history, current, future, num_head, repeat, perms):

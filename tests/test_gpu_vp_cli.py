@@ -143,3 +143,77 @@ def test_results_files_vs_reference_golden(tmp_path):
             assert num.sub('#', lg) == num.sub('#', lr), (name, lg, lr)          # same text around the numbers
             vg, vr = [float(x) for x in num.findall(lg)], [float(x) for x in num.findall(lr)]
             np.testing.assert_allclose(vg, vr, rtol=2e-6, atol=1e-9, err_msg=f'{name}: {lg} | {lr}')
+
+
+@pytest.mark.parametrize('tag,T', [('s5_t15', 15), ('s10_t10', 10), ('syn', 12)])
+def test_linear_regression_baseline_kernel_vs_reference_and_oracle(tag, T):
+    """`--model regression` (viewport_prediction/models/linear_regression.py:18-36): one device launch against the imported
+    reference class (scikit-learn per trajectory, tools/gen_golden_linreg.py) on real Jin2022 windows and stress rows, through
+    the C ABI; then at the benchmark's batch size against the oracle."""
+    from mansy_immersivevideostreaming_amd.viewport_prediction.models import LinearRegression
+    from oracle import vp_oracle as vo
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'linreg_reference.npz'))
+    h, c, want = z[f'{tag}_history'], z[f'{tag}_current'], z[f'{tag}_pred']
+    model = LinearRegression(fut_window=T)
+    got = model.sample(torch.from_numpy(h).cuda(), torch.from_numpy(c).cuda()).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=2e-7, atol=1e-7)         # float64 fit, float32 result: at most one ulp apart
+    assert (got == want).mean() > 0.99
+    rs = np.random.RandomState(3)
+    B, S = 4096, 10
+    start = rs.rand(B, 1, 2)
+    walk = (start + np.cumsum(rs.randn(B, S + 1, 2) * 0.02, 1)).astype(np.float32)
+    got = LinearRegression(fut_window=T).sample(torch.from_numpy(walk[:, :S]).cuda(), torch.from_numpy(walk[:, S:]).cuda()).cpu().numpy()
+    ref = vo.linear_regression_sample(walk[:, :S], walk[:, S:], T)
+    np.testing.assert_allclose(got, ref, rtol=2e-7, atol=1e-7)
+    assert (got == ref).mean() > 0.99
+    # properties that hold at any size: an exact line is continued exactly, a constant stays constant
+    t = np.arange(S + 1, dtype=np.float32)[None, :, None]
+    line = (0.25 + 0.03125 * t) * np.ones((8, 1, 2), np.float32)
+    out = LinearRegression(fut_window=4).sample(torch.from_numpy(line[:, :S]).cuda(), torch.from_numpy(line[:, S:]).cuda()).cpu().numpy()
+    np.testing.assert_array_equal(out, np.broadcast_to((0.25 + 0.03125 * np.arange(S + 1, S + 5, dtype=np.float32))[None, :, None], out.shape))
+    assert LinearRegression(fut_window=0).sample(torch.zeros(3, 5, 2).cuda(), torch.zeros(3, 1, 2).cuda()).shape == (3, 0, 2)
+    assert LinearRegression(fut_window=4).sample(torch.zeros(0, 5, 2).cuda(), torch.zeros(0, 1, 2).cuda()).shape == (0, 4, 2)
+
+
+@pytest.mark.parametrize('tag,T', [('s5_t15', 15), ('s10_t10', 10)])
+def test_linear_regression_results_files_vs_reference_golden(tmp_path, tag, T):
+    """The test driver's notebook for the regression baseline (run_models.py:72-85): device fit -> Results.record / write against the
+    three files the imported reference wrote for the same real-trace batch (predictions leave [0, 1] at the 15-step horizon)."""
+    import re
+    from mansy_immersivevideostreaming_amd.viewport_prediction.models import LinearRegression
+    from mansy_immersivevideostreaming_amd.viewport_prediction.utils.common import Config
+    from mansy_immersivevideostreaming_amd.viewport_prediction.utils.results import Results
+    Z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'linreg_reference.npz'))
+    cfg = Config(dict(video_width=2560, video_height=1440, tile_num_width=8, tile_num_height=8, tile_total_num=64))
+    res = Results('regression', 2, T, str(tmp_path), 5, mse=True, nll=False, accuracy=True, config=cfg)
+    pred = LinearRegression(fut_window=T).sample(torch.from_numpy(Z[f'{tag}_history']).cuda(), torch.from_numpy(Z[f'{tag}_current']).cuda())
+    res.record(pred.shape[0], pred, torch.from_numpy(Z[f'{tag}_future']).cuda(), [str(v) for v in Z[f'{tag}_video']],
+               torch.from_numpy(Z[f'{tag}_user']), torch.from_numpy(Z[f'{tag}_timestep']))
+    res.write(log=True, label='t_')
+    num = re.compile(r'-?\d+\.?\d*(?:e-?\d+)?')
+    for name in ('t_results.csv', 't_results.log', 't_accuracy_result.csv'):
+        got = open(os.path.join(str(tmp_path), name)).read().splitlines()
+        ref = str(Z[f'{tag}_file::{name}']).splitlines()
+        assert len(got) == len(ref), name
+        for lg, lr in zip(got, ref):
+            if lg == lr:
+                continue
+            assert num.sub('#', lg) == num.sub('#', lr), (name, lg, lr)
+            vg, vr = [float(x) for x in num.findall(lg)], [float(x) for x in num.findall(lr)]
+            np.testing.assert_allclose(vg, vr, rtol=2e-6, atol=1e-9, err_msg=f'{name}: {lg} | {lr}')
+
+
+def test_run_models_regression_cli(tree):
+    """`run_models --model regression --test`: no training, no checkpoint, the reference's result file names under .../regression/."""
+    from mansy_immersivevideostreaming_amd.viewport_prediction import run_models
+    root, cfg = tree
+    run_models.main(['--model', 'regression', '--train', '--test', '--train-dataset', 'Toy', '--test-dataset', 'Toy', '--his-window', '5',
+                     '--fut-window', '15', '--bs', '32', '--seed', '5', '--device', 'cuda:0', '--config', cfg])
+    prefix = 'his_5_fut_15_hid_512_ss_5_epochs_200_bs_32_lr_0.0001_seed_5'
+    rdir = os.path.join(root, 'results', 'viewport_prediction', 'regression', 'Toy', '5Hz')
+    for tag in ('seen', 'unseen'):
+        lines = open(os.path.join(rdir, f'{prefix}_{tag}_results.csv')).read().splitlines()
+        assert lines[0] == 'video,user,timestamp,time,gt_1,gt_2,pred_1,pred_2,mse,accuracy,recall,precision,f1'
+        assert len(lines) > 1 + 15
+        assert os.path.exists(os.path.join(rdir, f'{prefix}_{tag}_accuracy_result.csv'))
+    assert not os.listdir(os.path.join(root, 'models', 'viewport_prediction', 'regression', 'Toy', '5Hz'))

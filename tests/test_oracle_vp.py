@@ -147,3 +147,18 @@ def test_training_loop_vs_reference_capture(path):
             e = torch.minimum(e, torch.abs(pred - 1 - f))
             mse.append(torch.mean(torch.sum(e * e, dim=-1) / 2).item())
     np.testing.assert_allclose(np.sum(mse) / 2, float(z['valid_mse']), rtol=2e-3, atol=1e-6)
+
+
+@pytest.mark.parametrize('tag,T', [('s5_t15', 15), ('s10_t10', 10), ('syn', 12)])
+def test_linear_regression_baseline_vs_imported_reference(tag, T):
+    """oracle.linear_regression_sample against the imported reference class (scikit-learn per trajectory; tools/gen_golden_linreg.py):
+    bit-equal on the real Jin2022 windows; on the synthetic stress rows the closed form and LAPACK's least squares may differ in
+    the last float64 bits, which survives the rounding to float32 for under 1 % of the values, by one ulp."""
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'linreg_reference.npz'))
+    got = vo.linear_regression_sample(z[f'{tag}_history'], z[f'{tag}_current'], T)
+    want = z[f'{tag}_pred']
+    assert got.dtype == np.float32 and got.shape == want.shape
+    np.testing.assert_allclose(got, want, rtol=2e-7, atol=1e-7)
+    assert (got == want).mean() > 0.99
+    if tag != 'syn':
+        np.testing.assert_array_equal(got, want)
