@@ -11,34 +11,34 @@
 namespace {
 
 __device__ __forceinline__ int pymod(int a, int m) { int r = a % m; return r < 0 ? r + m : r; }
-__device__ __forceinline__ int block_of(int x, int bw) {   // find_block_covered_by_point, x >= 0
-  return (x > 0 ? x - 1 : x) / bw;               // x / bw, minus one when x is a positive exact multiple: one division, no modulo
-}
+// find_block_covered_by_point: Python's x // bw (FLOOR division, also for the negative pixels of a centre left of / above the
+// frame), minus one when x is a positive exact multiple -- as one truncating division: (x - 1) / bw for x > 0,
+// (x - (bw - 1)) / bw for x <= 0.
+__device__ __forceinline__ int block_of(int x, int bw) { return (x > 0 ? x - 1 : x - (bw - 1)) / bw; }
 // Tiles of one axis covered by the FoV interval [lo, hi] on a frame of `size` pixels, tiles `bw` wide, `n` of them.
 // _find_regions_covered_by_fov splits the interval per axis exactly like this:
 //   lo >= 0 && hi <= size : [lo, hi]
 //   lo <  0 && hi <= size : [0, hi] and [lo % size, size]
 //   lo >= 0 && hi >  size : [0, hi % size] and [lo, size]
 // (neither -- lo < 0 && hi > size -- cannot happen for fov < size and yields nothing), and each interval [p, q] marks the numpy
-// slice [block_of(p) : block_of(q) + 1] clipped to [0, n).  With tA = block_of(lo or lo % size), tB = block_of(hi or hi % size),
-// tS = block_of(size) and block_of(0) = 0 that is
-//   one interval : bits [tA, tB]          = below(tB) & ~under(tA)
-//   two intervals: bits [0, tB] | [tA, tS] = below(tB) | (~under(tA) & below(tS))
+// slice [block_of(p) : block_of(q) + 1] of the axis: a negative bound counts from the END of the axis and only then clips to 0, a
+// bound past the end clips to n (tests/golden/tilemap_px_outside.npz: the imported function on centres outside the frame -- raw
+// predictions reach it, predict.py:40-45).  With tA = block_of(lo or lo % size), tB = block_of(hi or hi % size),
+// tS = block_of(size) and block_of(0) = 0:
+//   one interval : bits [bound(tA), bound(tB + 1))
+//   two intervals: bits [0, bound(tB + 1)) | [bound(tA), bound(tS + 1))
 // -- two divisions per axis and selects instead of branches: neighbouring points fall into different cases, and a wave that takes
 // every branch pays for all of them (round 3: the kernel was ALU-bound at ~290 integer instructions per point, a third of them
 // executed for the other lanes' cases).
-__device__ __forceinline__ unsigned below(int t, int n) {      // bits [0, min(t + 1, n))
-  const int c = t + 1 > n ? n : t + 1;
-  return c <= 0 ? 0u : (c >= 32 ? 0xFFFFFFFFu : ((1u << (c & 31)) - 1u));
-}
-__device__ __forceinline__ unsigned under(int t) {             // bits [0, max(t, 0))
-  return t <= 0 ? 0u : (t >= 32 ? 0xFFFFFFFFu : ((1u << (t & 31)) - 1u));
+__device__ __forceinline__ int slice_bound(int i, int n) { return i < 0 ? max(i + n, 0) : min(i, n); }
+__device__ __forceinline__ unsigned below(int k) { return k >= 32 ? 0xFFFFFFFFu : ((1u << (k & 31)) - 1u); }      // bits [0, k), 0 <= k <= 32
+__device__ __forceinline__ unsigned span(int t1, int t2, int n) {          // numpy slice [t1 : t2 + 1] of an axis of n tiles (empty when reversed)
+  return below(slice_bound(t2 + 1, n)) & ~below(slice_bound(t1, n));
 }
 __device__ __forceinline__ unsigned axis_mask(int lo, int hi, int size, int bw, int n) {
   const bool neg = lo < 0, over = hi > size;
   const int tA = block_of(neg ? pymod(lo, size) : lo, bw), tB = block_of(over ? pymod(hi, size) : hi, bw), tS = block_of(size, bw);
-  const unsigned L = below(tB, n), Hh = ~under(tA);
-  const unsigned m = (neg != over) ? (L | (Hh & below(tS, n))) : (L & Hh);
+  const unsigned m = (neg != over) ? (span(0, tB, n) | span(tA, tS, n)) : span(tA, tB, n);
   return (neg && over) ? 0u : m;
 }
 

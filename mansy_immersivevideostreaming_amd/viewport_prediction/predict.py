@@ -28,8 +28,9 @@ def chunk_maps(config, merge, freq):
 
 
 def predict(args, config, model, videos, users, loader, results_dir, model_path):
-    model.load_state_dict(torch.load(model_path, map_location=args.device))
-    print('Successfully loaded model from', model_path)
+    if args.model != 'regression':          # linear regression has no weights to load (predict.py:16)
+        model.load_state_dict(torch.load(model_path, map_location=args.device))
+        print('Successfully loaded model from', model_path)
     results = {(video, user): [] for video in videos for user in users}
     with torch.no_grad():
         model.eval()

@@ -66,7 +66,9 @@ def to_position_normalized_cartesian(values):
 def find_tiles_covered_by_viewport(x, y, video_width, video_height, tile_width, tile_height, tile_num_width, tile_num_height,
                                    fov_width=600, fov_height=300, device='cuda'):
     """Single pixel centre (ints) -> uint8 [tile_num_height, tile_num_width] like the reference (device round trip)."""
-    xy = torch.tensor([[(x + 0.5) / video_width, (y + 0.5) / video_height]], dtype=torch.float32, device=device)
+    # a normalised coordinate that the kernel's int() (truncation toward zero) turns back into exactly this pixel, negative ones included
+    half = lambda v: 0.5 if v >= 0 else -0.5
+    xy = torch.tensor([[(x + half(x)) / video_width, (y + half(y)) / video_height]], dtype=torch.float32, device=device)
     m = int(kernels.tilemap(xy, video_width, video_height, tile_num_width, tile_num_height, fov_width, fov_height).item())
     bits = [(m >> k) & 1 for k in range(tile_num_width * tile_num_height)]
     return np.array(bits, dtype=np.uint8).reshape(tile_num_height, tile_num_width)

@@ -27,6 +27,9 @@ static void block_of_point(int x, int y, int bw, int bh, int *w, int *h) {
     if (y > 0 && y % bh == 0) *h -= 1;
 }
 
+/* Python / numpy slice bound on an axis of length n */
+static int slice_bound(int i, int n) { if (i < 0) { i += n; if (i < 0) i = 0; } else if (i > n) i = n; return i; }
+
 typedef struct { int x1, y1, x2, y2; } region_t;
 
 /* returns number of regions (0 if no case matches: the reference would raise UnboundLocalError) */
@@ -92,9 +95,12 @@ uint64_t oracle_tilemap_px(int x, int y, int W, int H, int tw, int th, int nw, i
         int tx1, ty1, tx2, ty2;
         block_of_point(r[k].x1, r[k].y1, tw, th, &tx1, &ty1);
         block_of_point(r[k].x2, r[k].y2, tw, th, &tx2, &ty2);
-        /* numpy slice semantics viewport[ty1:ty2+1, tx1:tx2+1] = 1 : clip to the array, empty if reversed */
-        int ya = ty1 < 0 ? 0 : ty1, yb = ty2 + 1 > nh ? nh : ty2 + 1;
-        int xa = tx1 < 0 ? 0 : tx1, xb = tx2 + 1 > nw ? nw : tx2 + 1;
+        /* numpy slice semantics viewport[ty1:ty2+1, tx1:tx2+1] = 1: a negative bound counts from the END of the axis (only
+         * then is it clipped to 0), a bound past the end is clipped to the length, a reversed range is empty.  Negative bounds
+         * arise for viewport centres left of / above the frame by more than half a FoV (raw model output; the linear-regression
+         * baseline extrapolating across a wrap-around jump) -- pinned by tests/golden/tilemap_px_outside.npz. */
+        int ya = slice_bound(ty1, nh), yb = slice_bound(ty2 + 1, nh);
+        int xa = slice_bound(tx1, nw), xb = slice_bound(tx2 + 1, nw);
         for (int yy = ya; yy < yb; ++yy)
             for (int xx = xa; xx < xb; ++xx) m |= (uint64_t)1 << (yy * nw + xx);
     }

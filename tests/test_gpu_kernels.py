@@ -290,6 +290,32 @@ def test_tilemap_other_geometries_and_every_wrap_case_vs_oracle(K, geom):
     assert len(np.unique(want)) > 4 * max(nw, nh) // 2
 
 
+def test_tilemap_centres_outside_the_frame_vs_imported_reference(K):
+    """Raw predictions reach the tile map (predict.py:40-45, results.py:15-18), and the linear-regression baseline extrapolates across
+    wrap-around jumps, so centres far outside the frame occur: Python floor division on negative pixels and numpy's slice semantics
+    on negative tile indices (a negative stop counts from the end of the axis) are part of the reference's behaviour.  9 165 such
+    centres through the imported function (tools/gen_golden_tilemap_outside.py) against the kernel and the C oracle, bit-exact."""
+    from oracle import tilemap as tm
+    z = np.load(os.path.join(G, 'tilemap_px_outside.npz'))
+    assert not z['raised'].any()
+    px = z['px'].astype(np.float64)
+    # a normalised coordinate that truncates (toward zero, like int()) back to the pixel: centre of the pixel's unit interval
+    xy = np.stack([(px[:, 0] + np.where(px[:, 0] >= 0, 0.5, -0.5)) / 2560.0, (px[:, 1] + np.where(px[:, 1] >= 0, 0.5, -0.5)) / 1440.0], 1).astype(np.float32)
+    back = np.stack([(xy[:, 0] * np.float32(2560)).astype(np.int32), (xy[:, 1] * np.float32(1440)).astype(np.int32)], 1)
+    sel = (back == z['px']).all(1)
+    assert sel.mean() > 0.99
+    np.testing.assert_array_equal(tm.tilemap_px(z['px']), z['maps'])
+    got = K.tilemap(torch.from_numpy(xy).cuda()).cpu().numpy().view(np.uint64)
+    np.testing.assert_array_equal(got[sel], z['maps'][sel])
+    assert len(np.unique(z['maps'])) > 400
+    # the float path against the oracle on a wide random cloud (both truncate toward zero)
+    rs = np.random.RandomState(8)
+    cloud = (rs.rand(200000, 2) * 5.0 - 2.0).astype(np.float32)
+    np.testing.assert_array_equal(K.tilemap(torch.from_numpy(cloud).cuda()).cpu().numpy().view(np.uint64), tm.tilemap_xy(cloud))
+    for geom in ((1920, 1080, 6, 4, 400, 200), (2560, 1440, 32, 2, 90, 90)):
+        np.testing.assert_array_equal(K.tilemap(torch.from_numpy(cloud).cuda(), *geom).cpu().numpy().view(np.uint64), tm.tilemap_xy(cloud, *geom))
+
+
 def test_empty_and_degenerate_inputs(K):
     """Empty inputs are legal (the reference's loops simply do not run); degenerate 1x1x1 products and frame-edge pixels work."""
     d = 'cuda'
@@ -326,5 +352,10 @@ def test_find_tiles_covered_by_viewport_integer_pixel_edges():
         got = sum(int(b) << k for k, b in enumerate(m.reshape(-1)))
         assert got == int(want), (int(x), int(y), hex(got), hex(int(want)))
     assert n > 1000
+    zo = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'tilemap_px_outside.npz'))      # centres outside the frame, negative pixels included
+    for k in range(0, len(zo['px']), 97):
+        x, y = (int(v) for v in zo['px'][k])
+        m = find_tiles_covered_by_viewport(x, y, 2560, 1440, 320, 180, 8, 8)
+        assert sum(int(b) << i for i, b in enumerate(m.reshape(-1))) == int(zo['maps'][k]), (x, y)
     for x, y in ((0, 0), (2560, 1440), (2560, 0), (0, 1440), (320, 180), (640, 180), (2560, 180)):     # corners / tile multiples are in the fixture
         assert ((z['px'][:, 0] == x) & (z['px'][:, 1] == y)).any(), (x, y)

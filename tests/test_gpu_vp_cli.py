@@ -217,3 +217,21 @@ def test_run_models_regression_cli(tree):
         assert len(lines) > 1 + 15
         assert os.path.exists(os.path.join(rdir, f'{prefix}_{tag}_accuracy_result.csv'))
     assert not os.listdir(os.path.join(root, 'models', 'viewport_prediction', 'regression', 'Toy', '5Hz'))
+    # predict.py --model regression (predict.py:146): HMDTrace pickles from the baseline's predictions, no --model-path needed
+    from mansy_immersivevideostreaming_amd.viewport_prediction import predict
+    from oracle import vp_oracle as vo
+    out = os.path.join(root, 'pred_reg')
+    predict.main(['--model', 'regression', '--dataset', 'Toy', '--his-window', '5', '--fut-window', '15', '--bs', '64', '--device', 'cuda:0',
+                  '--config', cfg, '--output-dir', out])
+    pk = pickle.load(open(os.path.join(out, 'video2', 'user3.pkl'), 'rb'))
+    tr = np.load(os.path.join(root, 'datasets', 'Toy', 'viewports', 'video2', '5Hz', 'simple_5Hz_user3.npy'))[:, 1:]
+    chunks, maps = otm.chunk_maps_from_trace(tr, fut_window=15)
+    assert [p[0] for p in pk] == list(chunks)
+    np.testing.assert_array_equal(np.stack([p[1] for p in pk]), otm.bits_to_u8(maps))
+    # prediction side: the oracle's line through the same windows, first second of each, OR of its five tile maps
+    ts = list(range(15, len(tr) - 15, 5))
+    hist = np.stack([tr[t - 5:t] for t in ts]); cur = np.stack([tr[t:t + 1] for t in ts])
+    first = vo.linear_regression_sample(hist, cur, 15)[:, :5]
+    pm = otm.tilemap_xy(first.reshape(-1, 2)).reshape(len(ts), 5)
+    want = np.bitwise_or.reduce(pm, axis=1)
+    np.testing.assert_array_equal(np.stack([p[2] for p in pk]), otm.bits_to_u8(want))

@@ -24,3 +24,16 @@ def test_dataset_gt_maps_bit_exact():
         np.testing.assert_allclose(tm.iou(maps, pred_bits), z[f'iou_{v}_{u}'], rtol=0, atol=1e-12)
         total += len(chunks)
     assert total == 637  # 12 (video,user) files, 58-s videos have fewer chunks
+
+
+def test_px_outside_the_frame_bit_exact():
+    """Centres outside the frame (raw predictions; the linear-regression baseline across a wrap jump): Python floor division and
+    numpy's negative-slice-bound semantics, against the imported function (tools/gen_golden_tilemap_outside.py)."""
+    z = np.load(os.path.join(G, 'tilemap_px_outside.npz'))
+    assert not z['raised'].any() and len(z['px']) > 9000
+    np.testing.assert_array_equal(tm.tilemap_px(z['px']), z['maps'])
+    # the case that distinguishes numpy's semantics from clipping: a stop of -1 keeps all but the last tile of the axis
+    k = np.where((z['px'][:, 0] == -700) & (z['px'][:, 1] == 700))[0]
+    if len(k):
+        m = int(z['maps'][k[0]])
+        assert m & 0x7F and not ((m >> 0) & 0x80)
