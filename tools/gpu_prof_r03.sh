@@ -29,7 +29,7 @@ for mode in f32 bf16x3 bf16x6; do
   f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/vp_train_b4096_${mode}_kernel_stats.csv
   python3 tools/step_breakdown.py 45 > $OUT/vp_step_breakdown_$mode.txt 2>&1
 done
-for mode in f32 bf16x3; do
+for mode in f32 bf16x3 bf16x6; do
   rm -rf gpurun_out/pmc_r gpurun_out/pmc_w; mkdir -p gpurun_out/pmc_r gpurun_out/pmc_w
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_r -- python3 /tmp/vp_only.py 2 $mode > $OUT/pmc_r_$mode.log 2>&1; echo "pmc fetch $mode rc=$?"
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_w -- python3 /tmp/vp_only.py 2 $mode > $OUT/pmc_w_$mode.log 2>&1; echo "pmc write $mode rc=$?"
