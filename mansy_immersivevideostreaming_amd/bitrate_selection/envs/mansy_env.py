@@ -57,6 +57,14 @@ class EnvTables:
             raise MansyError('EnvTables live in HBM: a cuda (ROCm) device is required')
         self.host = {k: np.ascontiguousarray(arrays[k], dtype=self.DTYPES[k]) for k in self.FIELDS}
         self.host['qoe_w'] = np.ascontiguousarray(qoe_weights, dtype=np.float32).reshape(-1, 3)
+        # simulate_download (simulators/network.py) walks the trace bins until the chunk is through: a trace without one positive bin
+        # (or with a negative / non-finite one) never gets there -- an endless loop in the reference, a hung queue on the device
+        bw, tl = self.host['trace_bw'], self.host['trace_len']
+        if bw.ndim != 2 or len(tl) != bw.shape[0] or (tl < 1).any() or (tl > bw.shape[1]).any():
+            raise MansyError('EnvTables: trace_len must lie in [1, trace_bw.shape[1]] for every trace')
+        live = np.arange(bw.shape[1])[None, :] < tl[:, None]
+        if not np.isfinite(bw[live]).all() or (bw[live] < 0).any() or not ((bw * live) > 0).any(1).all():
+            raise MansyError('EnvTables: every network trace needs finite, non-negative bandwidth bins and at least one positive bin')
         if (self.host['samples'] < 0).any():
             bad = np.nonzero((self.host['samples'] < 0).any(1))[0]
             self.unvisitable = set(int(b) for b in bad)
