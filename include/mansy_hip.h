@@ -110,7 +110,12 @@ int mansy_traj_gather(const float* table, int L, int c, const int* idx, int B, i
 /* mean_square_error (viewport_prediction/utils/common.py:73-80): per row of c coordinates */
 int mansy_periodic_mse(const float* a, const float* b, long long rows, int c, float* out, void* stream);
 
-/* ------------------------------------------------------------------ tile hit map */
+/* ------------------------------------------------------------------ tile hit map
+ * find_tiles_covered_by_viewport / _find_regions_covered_by_fov / find_block_covered_by_point
+ * (viewport_prediction/utils/common.py:37-58, 83-127) for n points at once: xy [n,2] float32 normalised centres, pixel =
+ * (int)(x * W), (int)(y * H) (float32 product, truncation toward zero: utils/results.py:15-18, predict.py:40-43); one uint64 per
+ * point, bit row * tile_num_w + col.  Centres OUTSIDE the frame behave like the reference's Python: floor division on negative
+ * pixels, numpy slice semantics on negative tile indices (a negative bound counts from the end of the axis). */
 int mansy_tilemap(const float* xy, long long n, int W, int H, int tile_num_w, int tile_num_h, int fov_w, int fov_h,
                   uint64_t* maps, void* stream);
 int mansy_tilemap_iou(const uint64_t* a, const uint64_t* b, long long n, double* iou, void* stream);
