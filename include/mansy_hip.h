@@ -382,7 +382,8 @@ int mansy_attn_bwd_selfpull(const float* Q_all, long long q_ts, const float* K, 
 /* A HIP event pair attached to every GEMM dispatch on its own stream (the kernel's begin / end); collect() = device sync + summed ms, count, FLOPs. */
 int mansy_prof_gemm_enable(int on);
 /* A/B knob of the bf16x3 products with pre-split weights (diagnostic; tools/gemm_bench.py): 1 (default) = A staged in fp32 by LDS-DMA
- * and split at fragment read (gemm_bf16f_kernel), 0 = the round-2 loop (A register-staged and split before its ds_write); v < 0 only
+ * and split at fragment read (gemm_bf16f / gemm_bf16g kernels; on the 64 x 64 tiles gemm_bf16h_kernel's three-stage ring, 6 = four
+ * stages), 0 = the round-2 loop (A register-staged and split before its ds_write), 7 = the round-2 loop on the 64 x 64 tiles only; v < 0 only
  * queries.  Returns the previous value.  Results of the two loops are bit-identical (same products, same order). */
 int mansy_gemm_bf16_variant(int v);
 int mansy_prof_gemm_collect(double* total_ms, long long* launches, double* flops);

@@ -667,6 +667,148 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16f_kernel(GemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// bf16x3 / bf16x6 (NP = 2 / 3 planes), pre-split B, A split at fragment read, on an NS-stage ring (late round 3): gemm_bf16f_kernel's loop with NS - 1 K-tiles in
+// flight instead of one.  For the 64 x 64 tiles of the [4 096-row] decoder products: one K-tile of such a tile is 6 MFMAs per wave
+// (~200 cycles), a cold fetch (the activations were written by the previous launch, usually on another XCD) is ~2 000, so with one
+// tile in flight the loop runs at one fetch latency per K-tile (in the step: 20 us per product against 14 us with warm operands).
+// 16 KB (20 KB with three planes) per stage: three stages and two workgroups per CU fit the LDS.  Measured in the step (tools/bf16_ring_ab.py,
+// variants interleaved in one process): bf16x3 train step 15.87 -> 14.53 ms with three stages (14.69 with four); results bit-identical to
+// gemm_bf16p_kernel's.
+//   wait for this wave's pieces of tile t (counted vmcnt: the younger tiles' pieces stay in flight) -> raw s_barrier (everyone's pieces
+//   of t have landed, everyone is done reading t - 1) -> DMA of tile t + NS - 1 into the stage t - 1 occupied -> fragments + MFMAs of t.
+template <int BM, int BN, int NS, int NP>
+__global__ __launch_bounds__(NT, 2) void gemm_bf16h_kernel(GemmParams p) {
+  constexpr int TM = BM / 64, TN = BN / 64, PA = BM / 32, PB = BN / 16, PBW = (PB + 3) / 4, D = NS - 1;
+  constexpr int A_BYTES = BM * BK * 4, B_PLANE = BN * 32, B_PLANE_BYTES = B_PLANE * 2;      // B_PLANE in bf16 elements
+  constexpr int STAGE_BYTES = A_BYTES + NP * B_PLANE_BYTES;
+  constexpr int C_FLOATS = BM * (BN + 4);
+  constexpr int SMEM_FLOATS = (NS * STAGE_BYTES / 4) > C_FLOATS ? (NS * STAGE_BYTES / 4) : C_FLOATS;
+  constexpr int PPT = PA + NP * PBW;                                                         // DMA pieces per wave and K-tile
+  static_assert((NP == 2 || NP == 3) && PB % 4 == 0 && NS >= 2 && NS <= 4 && PPT * (D - 1 > 0 ? D - 1 : 0) <= 15, "piece counts must fit the counted waits");
+  __shared__ __attribute__((aligned(1024))) float smem[SMEM_FLOATS];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  int tile_x, tile_y;
+  {   // XCD-aware bijective remap (no split-K on this path: forward and dX products only)
+    const int nwg = gridDim.x * gridDim.y, orig = blockIdx.y * gridDim.x + blockIdx.x;
+    const int q = nwg >> 3, rem = nwg & 7, xcd = orig & 7, local = orig >> 3;
+    const int t = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + local;
+    tile_y = t / gridDim.x; tile_x = t - tile_y * gridDim.x;
+  }
+  const int m0 = tile_y * BM, n0 = tile_x * BN;
+  const int nk = p.K / BK;
+
+  unsigned voa[PA];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int row = i * 32 + wave * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    voa[i] = (unsigned)((min(m0 + row, p.M - 1) - m0) * p.lda + c * 4) * 4u;
+  }
+  unsigned vob[PBW];
+#pragma unroll
+  for (int i = 0; i < PBW; ++i) {
+    const int row = (wave + 4 * i) * 16 + (lane >> 2), slot = lane & 3;
+    const int q = slot ^ ((row >> 2) & 3);
+    vob[i] = (unsigned)(((min(n0 + row, p.N - 1) - n0) * p.ep.b_planes_ld + q * 8) * 2);
+  }
+  const float* const ca = p.A + (long long)m0 * p.lda;
+  const unsigned short* const cb = p.ep.b_planes + (long long)n0 * p.ep.b_planes_ld;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem + (unsigned)wave * 1024u);
+  auto dma = [&](int stage, int kt) {
+    const unsigned base = lds0 + (unsigned)(stage * STAGE_BYTES);
+    const float* a_corner = ca + (long long)kt * BK;
+    const unsigned short* b_corner = cb + (long long)kt * BK;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) glds16(voa[i], a_corner, base + (unsigned)i * 4096u);
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+      for (int i = 0; i < PBW; ++i)
+        glds16(vob[i], b_corner + (long long)pl * p.ep.b_plane_stride, base + (unsigned)(A_BYTES + pl * B_PLANE_BYTES) + (unsigned)i * 4096u);
+  };
+  int fa[TM][2][2], fb[TN][2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row = wm * (BM / 2) + i * 32 + r, sw = (row >> 1) & 7, c0 = 4 * s + 2 * h;
+      fa[i][s][0] = row * BK + ((c0 + 0) ^ sw) * 4;
+      fa[i][s][1] = row * BK + ((c0 + 1) ^ sw) * 4;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[j][s] = lds_off<false>(wn * (BN / 2) + j * 32 + r, 2 * s + h);
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (d < nk) dma(d, d);
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    // tiles still wanted in flight after tile kt has landed: min(D - 1, nk - 1 - kt) of them, PPT pieces each (the wait count is an immediate)
+    const int ahead = nk - 1 - kt;
+    if (D >= 3 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPT) : "memory");
+    else if (D >= 2 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + D < nk) dma(cur == 0 ? NS - 1 : cur - 1, kt + D);       // into the stage tile kt - 1 occupied
+    const float* a_l = smem + cur * (STAGE_BYTES / 4);
+    const __bf16* b_l = reinterpret_cast<const __bf16*>(a_l) + A_BYTES / 2;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 af[TM][NP], bf[TN][NP];                      // plane 0 = leading bf16 part, 1 / 2 = first / second remainder
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) bf[j][pl] = *reinterpret_cast<const bf16x8*>(b_l + pl * B_PLANE + fb[j][s]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const float4 v0 = *reinterpret_cast<const float4*>(a_l + fa[i][s][0]);
+        const float4 v1 = *reinterpret_cast<const float4*>(a_l + fa[i][s][1]);
+        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {                     // split_store's arithmetic, in registers
+          const __bf16 t0 = (__bf16)v[e];
+          const float r1 = v[e] - (float)t0;
+          const __bf16 t1 = (__bf16)r1;
+          af[i][0][e] = t0; af[i][1][e] = t1;
+          if (NP == 3) af[i][2][e] = (__bf16)(r1 - (float)t1);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {                    // smallest products first, the order of gemm_bf16p_kernel (results bit-identical to it)
+          if (NP == 3) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // LDS reads retired before the barrier that frees this buffer
+    cur = cur == NS - 1 ? 0 : cur + 1;
+  }
+  __syncthreads();                                        // staging LDS idle (every DMA was waited for): the epilogue reuses it
+  gemm_epilogue<BM, BN, SMEM_FLOATS>(p, acc, smem, m0, n0, tid, 0, p.C);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // bf16x3, 256 x 128 tile, EIGHT waves, THREE LDS stages (round 3).  The 128 x 128 loops above are bound by the LDS fill: with two
 // stages per workgroup one K-tile per workgroup is in flight (2 x 32 KB per CU), and in-flight bytes / loaded round trip is all the
 // fill rate there is.  This loop is two of those workgroups fused -- waves 0-3 own rows 0..127, waves 4-7 rows
@@ -864,8 +1006,9 @@ int mansy_gemm_bf16s_dispatch(const GemmParams& p, int tile, int prec, int a_kma
 }
 
 // B pre-split into planes (weights): forward / dX products with a K-contiguous A
-static int g_bf16_variant = 1;      // 1: A by LDS-DMA, split at fragment read (gemm_bf16g / gemm_bf16f kernels); 4: as 1 without the 256 x 128 loop;
-                                    // 0: the round-2 loop; 2 / 3: timing-only staging / math variants (A/B tests)
+static int g_bf16_variant = 1;      // 1: A by LDS-DMA, split at fragment read (gemm_bf16g / gemm_bf16f kernels; 64 x 64 tiles: gemm_bf16h_kernel's
+                                    // three-stage ring); 4: as 1 without the 256 x 128 loop; 6: as 1 with a four-stage ring; 7: as 1 with the
+                                    // round-2 loop on the 64 x 64 tiles; 0: the round-2 loop; 2 / 3: timing-only staging / math variants (A/B tests)
 extern "C" int mansy_gemm_bf16_variant(int v) { const int old = g_bf16_variant; if (v >= 0) g_bf16_variant = v; return old; }
 
 int mansy_gemm_bf16p_dispatch(const GemmParams& p, int tile, int prec, hipStream_t st) {
@@ -882,9 +1025,10 @@ int mansy_gemm_bf16p_dispatch(const GemmParams& p, int tile, int prec, hipStream
       return MANSY_OK;
     }
     // measured per shape (tools/gemm_bench.py --planes, profiles/r03_gemm_bench_bf16f.txt): 128 x 128 tiles 3-9 % faster than the
-    // round-2 loop on the [40 960-row] products; 64 x 64 tiles ([4 096-row] decoder products) 6 % slower (one K-tile of a 64 x 64
-    // tile is 6 MFMAs per wave: the second, redundant fragment conversion is no longer hidden), so those keep the round-2 loop;
-    // the 128 x 64 instance loses to both at every shape and is reachable only as force_tile 96
+    // round-2 loop on the [40 960-row] products; the two-stage 64 x 64 instance ([4 096-row] decoder products) 6 % slower IN ISOLATION
+    // (one K-tile of a 64 x 64 tile is 6 MFMAs per wave: the second, redundant fragment conversion is no longer hidden) -- but inside
+    // the step those products are bound by the latency of their cold operands, which the three-stage ring below (gemm_bf16h_kernel)
+    // covers; the 128 x 64 instance loses to both at every shape and is reachable only as force_tile 96
     if (tile == 256 || (tile == 128 && g_bf16_variant == 1 && (long long)mansy_ceil_div(p.M, 256) * mansy_ceil_div(p.N, 128) >= 256)) {
       // enough 256 x 128 tiles for every CU: the eight-wave three-stage loop (one workgroup per CU, two K-tiles in flight)
       dim3 grid(mansy_ceil_div(p.N, 128), mansy_ceil_div(p.M, 256), 1);
@@ -892,6 +1036,16 @@ int mansy_gemm_bf16p_dispatch(const GemmParams& p, int tile, int prec, hipStream
     }
     if (tile == 128) { dim3 grid(mansy_ceil_div(p.N, 128), mansy_ceil_div(p.M, 128), 1); MANSY_GEMM_LAUNCH((gemm_bf16f_kernel<128, 128>), grid, block, st, p); MANSY_LAUNCH_CHECK(); return MANSY_OK; }
     if (tile == 96) { dim3 grid(mansy_ceil_div(p.N, 64), mansy_ceil_div(p.M, 128), 1); MANSY_GEMM_LAUNCH((gemm_bf16f_kernel<128, 64>), grid, block, st, p); MANSY_LAUNCH_CHECK(); return MANSY_OK; }
+  }
+  // 64 x 64 tiles (the [4 096-row] decoder products): the ring loop, both modes (variant 0 / 7: the round-2 loop, for A/B runs)
+  if (tile == 64 && g_bf16_variant != 0 && g_bf16_variant != 7 && (reinterpret_cast<uintptr_t>(p.A) & 15) == 0 && p.lda % 4 == 0) {
+    dim3 grid(mansy_ceil_div(p.N, 64), mansy_ceil_div(p.M, 64), 1), block(NT);
+    if (prec == 3) {
+      if (g_bf16_variant == 6) MANSY_GEMM_LAUNCH((gemm_bf16h_kernel<64, 64, 4, 2>), grid, block, st, p);
+      else MANSY_GEMM_LAUNCH((gemm_bf16h_kernel<64, 64, 3, 2>), grid, block, st, p);
+    } else MANSY_GEMM_LAUNCH((gemm_bf16h_kernel<64, 64, 3, 3>), grid, block, st, p);
+    MANSY_LAUNCH_CHECK();
+    return MANSY_OK;
   }
   if (tile == 96) tile = 64;
   const int BMN = tile == 128 ? 128 : 64;

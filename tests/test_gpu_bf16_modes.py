@@ -509,3 +509,39 @@ def test_weight_planes_and_presplit_product(K, mode):
     A = torch.randn(256, 512, generator=g).cuda()
     pl, _ = K.weight_planes(W, npl)
     assert torch.equal(K.gemm_planes(A, W, pl), K.gemm(A, W))
+
+
+@pytest.mark.parametrize('mode', MODES)
+def test_ring_staged_decoder_tiles_equal_the_two_stage_loop_bit_for_bit(K, mode):
+    """The 64 x 64 tiles of the pre-split products run on a three-stage operand ring (gemm_bf16h_kernel: two K-tiles in flight under
+    counted vmcnt waits; variant 6: four stages).  Same products in the same order as the round-2 two-stage loop (variant 7), so the
+    results must be bit-identical -- over 1..6 K-tiles (prologue shorter than the ring, tail with no DMA left to issue), ragged rows /
+    columns, both forms (A W^T and A W), with a fused epilogue, many launches back to back (stage reuse across launches)."""
+    from mansy_immersivevideostreaming_amd._lib import lib
+    L = lib()
+    npl = 2 if mode == 'bf16x3' else 3
+    g = torch.Generator().manual_seed(21)
+    old = L.mansy_gemm_bf16_variant(-1)
+    try:
+        for (M, N, Kd) in ((4096, 512, 512), (70, 64, 32), (64, 130, 64), (257, 96, 96), (100, 72, 128), (33, 512, 160), (1000, 260, 192), (4000, 520, 1536)):
+            W = torch.randn(N, Kd, generator=g).cuda()
+            pl, pl_t = K.weight_planes(W, npl)
+            A = torch.randn(M, Kd, generator=g).cuda()
+            G = torch.randn(M, N, generator=g).cuda()
+            bias, resid = torch.randn(N, generator=g).cuda(), torch.randn(M, N, generator=g).cuda()
+            outs = {}
+            for v in (7, 1, 6):
+                L.mansy_gemm_bf16_variant(v)
+                with K.precision(mode):
+                    outs[v] = [K.gemm_planes(A, W, pl, force_tile=64), K.gemm_planes(G, W, pl_t, transposed=True, force_tile=64),
+                               K.gemm_planes(A, W, pl, bias=bias, relu=True, resid=resid, force_tile=64)]
+                    for _ in range(3):                       # back to back: nothing of one launch's ring may leak into the next
+                        again = K.gemm_planes(A, W, pl, force_tile=64)
+                    assert torch.equal(again, outs[v][0])
+            for v in (1, 6):
+                for got, want in zip(outs[v], outs[7]):
+                    assert torch.equal(got, want), (mode, v, M, N, Kd)
+            ref = A.double() @ W.double().t()
+            assert ((outs[1][0].double() - ref).abs().max() / ref.abs().max()).item() < GEMM_TOL[mode]
+    finally:
+        L.mansy_gemm_bf16_variant(old)
