@@ -579,7 +579,7 @@ def main():
             vm = world * B * args.steps / dtm
             modes.append({'dtype': mode, 'metric': 'viewport-trajectories/sec (VP train)', 'value': round(vm, 1), 'unit': 'trajectories/s',
                           'ms_per_step': round(dtm / args.steps * 1e3, 3), 'final_loss': float(mloss.item()), 'speedup_vs_f32': round(vm / value, 3),
-                          'roofline': {'bound': 'mfma', 'kernel': f'gemm_bf16{{f,p,s}}_kernel (v_mfma_f32_32x32x16_bf16, {nprod} bf16 products per fp32 product; weights pre-split, '
+                          'roofline': {'bound': 'mfma', 'kernel': f'gemm_bf16{{f,g,h,p,s}}_kernel (v_mfma_f32_32x32x16_bf16, {nprod} bf16 products per fp32 product; weights pre-split, '
                                                                   'activations split at fragment read / in the staging pass)',
                                        # executed bf16 MFMA FLOPs = nprod x the algorithmic (fp32-product) FLOPs
                                        'achieved': round(alg_tf * nprod, 2), 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
