@@ -222,9 +222,11 @@ int mansy_gae_returns(const float* rew, const float* v_s, const float* v_next, c
 int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, float* flat_p, float* flat_g, float* flat_m,
                              float* flat_v, long long n_flat, const float* obs_all, const int* idx, const int* act_all,
                              const float* adv_all, const float* logp_old_all, const float* v_old_all, const float* ret_all, int mb,
-                             float eps_clip, float vf_coef, float ent_coef, int norm_adv, int value_clip, float max_grad_norm, float lr,
-                             float weight_decay, int step, long long tail_from, int tail_step, float* stats, void* workspace,
-                             int max_batch, int chain_in, const int* next_idx, int next_mb, void* stream);
+                             float eps_clip, float vf_coef, float ent_coef, int norm_adv, int value_clip, float dual_clip,
+                             float max_grad_norm, float lr, float weight_decay, int step, long long tail_from, int tail_step, float* stats,
+                             void* workspace, int max_batch, int chain_in, const int* next_idx, int next_mb, void* stream);
+/* dual_clip: tianshou PPOPolicy's dual_clip (> 1; for negative advantages the clipped surrogate is bounded below by dual_clip * adv,
+ * run_mansy.py --dual-clip) or 0 = off (the reference's default None). */
 /* Chaining (the clipped single-process step only: max_grad_norm > 0, step > 0, no lagged tail): the step's last launch -- clip + Adam --
  * also zeroes the gradient buffer, writes the updated parameters into the packed images the next forward reads and, when next_mb > 0,
  * gathers the rows next_idx[0..next_mb) of obs_all and takes the statistics of their advantages; the NEXT call on the same workspace /

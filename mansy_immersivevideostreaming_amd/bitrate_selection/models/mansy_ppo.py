@@ -197,8 +197,10 @@ class PPOPolicy(nn.Module):
                  ent_coef=0.01, reward_normalization=False, gae_lambda=0.95, max_batchsize=256, action_space=None, action_scaling=False,
                  identifier_optim=None, **kwargs):
         super().__init__()
-        if dual_clip is not None or recompute_advantage:
-            raise MansyError('dual_clip / recompute_advantage are not on the reference run configuration (run_mansy.py:308-311)')
+        if dual_clip is not None and not dual_clip > 1.0:
+            raise MansyError('Dual-clip PPO parameter should greater than 1.0.')      # T2: PPOPolicy.__init__'s assertion
+        self._dual_clip = dual_clip
+        self._recompute_adv = bool(recompute_advantage)
         self.actor, self.critic = actor, critic
         self._actor_critic = _ActorCritic(actor, critic)
         self.identifier = identifier
@@ -386,6 +388,17 @@ class PPOPolicy(nn.Module):
                                                   eng.max_batch, stream_ptr(dev)), 'mansy_policy_evaluate')
         returns = torch.empty(n, dtype=torch.float32, device=dev)
         adv = torch.empty(n, dtype=torch.float32, device=dev)
+        data = dict(obs=obs, obs_next=obs_next, act=act, v_s=v_s, v_next=v_next, logp_old=logp_old, returns=returns, adv=adv, n=n, buffer=buffer)
+        self._returns_from_values(data)
+        return data
+
+    def _returns_from_values(self, data):
+        """T2: the second half of A2CPolicy._compute_returns -- GAE over data['v_s'] / data['v_next'] with the running return
+        statistics, normalised returns and advantages written IN PLACE into data['returns'] / data['adv'], then ret_rms.update."""
+        buffer = data['buffer']
+        T, N, n = buffer.filled, buffer.N, data['n']
+        dev = data['obs'].device
+        v_s, v_next, returns, adv = data['v_s'], data['v_next'], data['returns'], data['adv']
         scratch = torch.empty(n + 2, dtype=torch.float64, device=dev)
         rms_local = self.ret_rms()
         rms_use = rms_local
@@ -398,7 +411,19 @@ class PPOPolicy(nn.Module):
         if self.world > 1 and self._rew_norm:      # accumulate only our own (un-normalised) returns locally; no host round trip
             from ...dist import update_running_moments
             update_running_moments(rms_local, scratch[:n])
-        return dict(obs=obs, act=act, v_s=v_s, logp_old=logp_old, returns=returns, adv=adv, n=n)
+
+    def _recompute_returns(self, data):
+        """T2: PPOPolicy.learn with recompute_advantage, before every pass but the first: `batch = self._compute_returns(batch, buffer,
+        indices)` -- the CURRENT critic's values of obs / obs_next (they also become the value-clip reference v_s), GAE, returns and
+        the running return statistics again; logp_old stays the one process_fn took."""
+        eng, n, dev = self.engine, data['n'], data['obs'].device
+        arr, _ = eng.ac.pointers()
+        for src, dst in ((data['obs'], data['v_s']), (data['obs_next'], data['v_next'])):
+            for s in range(0, n, eng.max_batch):
+                e = min(n, s + eng.max_batch)
+                check(lib().mansy_policy_evaluate(arr, ptr(src[s:e]), e - s, None, 0, None, ptr(dst[s:e]), ptr(eng.workspace()), eng.max_batch,
+                                                  stream_ptr(dev)), 'mansy_policy_evaluate')
+        self._returns_from_values(data)
 
     def learn(self, data, batch_size, repeat):
         """T2: PPOPolicy.learn: `repeat` passes over shuffled minibatches (np.random.permutation, merge_last)."""
@@ -418,16 +443,21 @@ class PPOPolicy(nn.Module):
                 flat.append((pi, k, perm[off:off + len(chunk)]))
                 off += len(chunk)
         stats_all = [torch.empty(len(chunks), 4, dtype=torch.float32, device=dev) for chunks in passes]
+        recompute = self._recompute_adv and repeat > 1
         for s, (pi, k, idx) in enumerate(flat):
+            first_of_later_pass = recompute and pi > 0 and k == 0
+            if first_of_later_pass:
+                self._recompute_returns(data)      # new advantages: the previous step must not have prepared this minibatch from the old ones
             f.step += 1
-            nxt = flat[s + 1][2] if (chain and s + 1 < len(flat)) else None
+            last_of_pass = s + 1 < len(flat) and flat[s + 1][0] != pi
+            nxt = flat[s + 1][2] if (chain and s + 1 < len(flat) and not (recompute and last_of_pass)) else None
             arr, garr = f.pointers(grads=True)
             check(lib().mansy_ppo_minibatch_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(data['obs']),
                                                  ptr(idx), ptr(data['act']), ptr(data['adv']), ptr(data['logp_old']), ptr(data['v_s']),
                                                  ptr(data['returns']), idx.numel(), self._eps_clip, self._weight_vf, self._weight_ent,
-                                                 int(self._norm_adv), int(self._value_clip), 0.0 if dp else float(self._grad_norm or 0.0), lr, wd,
+                                                 int(self._norm_adv), int(self._value_clip), float(self._dual_clip or 0.0), 0.0 if dp else float(self._grad_norm or 0.0), lr, wd,
                                                  0 if dp else f.step, *f.tail(), ptr(stats_all[pi][k]), ptr(eng.workspace()), eng.max_batch,
-                                                 int(chain and s > 0), ptr(None if dp else nxt), nxt.numel() if (nxt is not None and not dp) else 0,
+                                                 int(chain and s > 0 and not first_of_later_pass), ptr(None if dp else nxt), nxt.numel() if (nxt is not None and not dp) else 0,
                                                  stream_ptr(dev)),
                   'mansy_ppo_minibatch_step')
             if dp:                              # raw local gradients -> average over the ranks -> global-norm clip + Adam (+ next prologue)

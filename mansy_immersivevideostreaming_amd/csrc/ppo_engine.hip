@@ -344,6 +344,7 @@ struct LossFuse {
   int on;
   const int* act; const float* adv; const float* logp_old; const float* v_old; const float* ret; const int* idx;
   int n; float eps_clip, vf_coef, ent_coef; int norm_adv, value_clip; float adv_eps;
+  float dual_clip;           // T2: PPOPolicy dual_clip (> 1) or 0: for negative advantages the surrogate is bounded below by dual_clip * adv
   const float* adv_stats; float* dlogits; float* dvalue; int dvalue_ld; float* lossrows;
   // round 3: the output layer's input-side backward in the same launch (was head_out_bwd_kernel's row loop): per head h,
   //   dH_h[row, c] = sum_k g[k] Wout_h[k, c]      (residual branch of the head; joins dF in the dF product's epilogue)
@@ -465,6 +466,11 @@ __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const f
     float dlogp;
     if (surr1 <= surr2) dlogp = -ratio * adv;
     else dlogp = (ratio > 1.f - lf.eps_clip && ratio < 1.f + lf.eps_clip) ? -ratio * adv : 0.f;
+    float clip_term = fminf(surr1, surr2);
+    if (lf.dual_clip > 0.f && adv < 0.f) {                  // T2 (ppo.py): clip2 = max(min(surr1, surr2), dual_clip * adv) where adv < 0
+      const float bound = lf.dual_clip * adv;
+      if (clip_term < bound) { clip_term = bound; dlogp = 0.f; }      // the bound does not depend on the logits
+    }
     dlogp /= (float)lf.n;
     float ent = 0.f;
 #pragma unroll
@@ -479,7 +485,7 @@ __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const f
       gk[k] = g;
     }
     if (lane < MAXOUT) lf.dlogits[(size_t)row * MAXOUT + lane] = mine;       // column 15 (lane 15) is 0
-    if (lane == 0) { lf.lossrows[4 * (size_t)row + 0] = -fminf(surr1, surr2); lf.lossrows[4 * (size_t)row + 2] = ent; }
+    if (lane == 0) { lf.lossrows[4 * (size_t)row + 0] = -clip_term; lf.lossrows[4 * (size_t)row + 2] = ent; }
   }
   if (lf.on == 1 && blockIdx.y == 1) {   // critic: (clipped) value loss of this row and its gradient (every lane computes the same scalars)
     const float v = o[0], ret = l_ret;
@@ -1343,12 +1349,13 @@ int mansy_gae_returns(const float* rew, const float* v_s, const float* v_next, c
 int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, float* flat_p, float* flat_g, float* flat_m, float* flat_v,
                              long long n_flat, const float* obs_all, const int* idx, const int* act_all, const float* adv_all,
                              const float* logp_old_all, const float* v_old_all, const float* ret_all, int mb, float eps_clip, float vf_coef,
-                             float ent_coef, int norm_adv, int value_clip, float max_grad_norm, float lr, float weight_decay, int step,
+                             float ent_coef, int norm_adv, int value_clip, float dual_clip, float max_grad_norm, float lr, float weight_decay, int step,
                              long long tail_from, int tail_step, float* stats, void* workspace, int max_batch, int chain_in,
                              const int* next_idx, int next_mb, void* stream) {
   MANSY_REQUIRE(params && grads && flat_p && flat_g && flat_m && flat_v && obs_all && act_all && adv_all && logp_old_all && v_old_all && ret_all,
                 "ppo_minibatch_step: null pointer");
   MANSY_REQUIRE(mb >= 2 && mb <= max_batch, "ppo_minibatch_step: bad minibatch size");
+  MANSY_REQUIRE(dual_clip == 0.f || dual_clip > 1.f, "ppo_minibatch_step: dual_clip must be 0 (off) or > 1 (tianshou asserts the same)");
   PEng e; RC(setup(workspace, max_batch, (hipStream_t)stream, e));
   NetP a, c; bind_net(params, grads, 20, a); bind_net(params, grads, 24, c);
   // one prologue launch: re-pack the block-diagonal / stacked weights, gather the minibatch rows, zero the gradient buffer
@@ -1368,9 +1375,9 @@ int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, fl
   double* const parts_next = e.W.acc + (chain_ok && (step & 1) ? 0 : NORM_PARTS_C);
   if (!chain_in) RC(e.pack_mb(a, c, idx ? obs_all : nullptr, idx, mb, flat_g, n_flat, adv_all));
   RC(e.featnet(obs, mb, 0));
-  LossFuse lf;
+  LossFuse lf; memset(&lf, 0, sizeof(lf));
   lf.on = 1; lf.act = act_all; lf.adv = adv_all; lf.logp_old = logp_old_all; lf.v_old = v_old_all; lf.ret = ret_all; lf.idx = idx; lf.n = mb;
-  lf.eps_clip = eps_clip; lf.vf_coef = vf_coef; lf.ent_coef = ent_coef; lf.norm_adv = norm_adv; lf.value_clip = value_clip;
+  lf.eps_clip = eps_clip; lf.vf_coef = vf_coef; lf.ent_coef = ent_coef; lf.norm_adv = norm_adv; lf.value_clip = value_clip; lf.dual_clip = dual_clip;
   lf.adv_eps = 0.f;   // T2: tianshou 0.4.8 ppo.py divides by the bare unbiased std (`(adv - mean) / std  # per-batch norm`); `+ self._eps` is 0.5.0's
   lf.adv_stats = e.W.adv_stats; lf.dlogits = e.W.gout; lf.dvalue = e.W.gout_c; lf.dvalue_ld = MAXOUT; lf.lossrows = e.W.lossrows;
   // the output layers' backward rides on the launches around it (round 3: head_out_bwd_kernel's launch is gone from this step): the

@@ -136,7 +136,7 @@ def compute_returns(rew, v_s, v_s_next, done, end_flag, ret_rms, gamma=0.95, lam
 
 
 def ppo_loss(logits, value, act, adv, logp_old, v_old, returns, eps_clip=0.2, vf_coef=0.5, ent_coef=0.02, norm_adv=True,
-             value_clip=True, eps=0.0):
+             value_clip=True, eps=0.0, dual_clip=None):
     """T2: PPOPolicy.learn body for one minibatch -> (loss, clip_loss, vf_loss, ent_loss)."""
     if norm_adv:
         # T2 (release 0.4.8, tianshou/policy/modelfree/ppo.py): `mean, std = b.adv.mean(), b.adv.std(); b.adv = (b.adv - mean) / std
@@ -148,7 +148,13 @@ def ppo_loss(logits, value, act, adv, logp_old, v_old, returns, eps_clip=0.2, vf
     ratio = (logp - logp_old).exp()
     surr1 = ratio * adv
     surr2 = ratio.clamp(1.0 - eps_clip, 1.0 + eps_clip) * adv
-    clip_loss = -torch.min(surr1, surr2).mean()
+    if dual_clip:
+        # T2 (ppo.py): clip1 = min(surr1, surr2); clip2 = max(clip1, dual_clip * adv); clip_loss = -where(adv < 0, clip2, clip1).mean()
+        clip1 = torch.min(surr1, surr2)
+        clip2 = torch.max(clip1, dual_clip * adv)
+        clip_loss = -torch.where(adv < 0, clip2, clip1).mean()
+    else:
+        clip_loss = -torch.min(surr1, surr2).mean()
     value = value.flatten()
     if value_clip:
         v_clip = v_old + (value - v_old).clamp(-eps_clip, eps_clip)
@@ -190,7 +196,7 @@ def unique_params(sd):
 
 def update(sd, obs, obs_next, act, rew, done, ret_rms, opt_state, lamb=0.5, use_identifier=True, batch_size=512, repeat=2, gamma=0.95,
            gae_lambda=0.95, rew_norm=True, eps_clip=0.2, vf_coef=0.5, ent_coef=0.02, max_grad_norm=1.0, lr=5e-4, wd=1e-2, eps=1e-8, on_step=None,
-           before_step=None):
+           before_step=None, norm_adv=True, value_clip=True, dual_clip=None, recompute_adv=False):
     """One whole PPOPolicy.update(0, buffer, is_train=True, batch_size, repeat) -- the reference's order of operations
     (bitrate_selection/models/mansy_ppo.py:36-59) over tianshou 0.4.8's process_fn / learn (T2):
       1. relabel: rew <- (1 - lamb) rew + lamb (1 - MSE(identifier(obs, obs.action_one_hot), obs.qoe_weight))      (:41-48)
@@ -199,6 +205,9 @@ def update(sd, obs, obs_next, act, rew, done, ret_rms, opt_state, lamb=0.5, use_
          returns of the whole buffer); logp_old = log_prob of the taken actions under the current actor
       3. learn: `repeat` passes; each pass np.random.permutation -> minibatches (merge_last); per minibatch ppo_loss, backward,
          clip_grad_norm_(actor_critic parameters, max_grad_norm), Adam with L2 weight decay (one step counter per parameter).
+         recompute_adv (T2: `if self._recompute_adv and step > 0: batch = self._compute_returns(batch, self._buffer, self._indices)`):
+         before every pass but the first, step 2's values / GAE / returns / ret_rms.update are redone with the current critic (the
+         new v_s is also the value-clip reference); logp_old is NOT recomputed.
     Inputs are [T][N] step-major numpy / torch arrays (the build's rollout slabs; tianshou's VectorReplayBuffer.sample(0) would
     hand the same transitions environment-major -- the minibatch permutation is uniform either way).  `sd`: 120-key policy state
     dict; `opt_state`: dict with 'uniq' (leaf tensors, from unique_params), 'params', 'm', 'v', 'step' (per tensor), created on
@@ -229,25 +238,33 @@ def update(sd, obs, obs_next, act, rew, done, ret_rms, opt_state, lamb=0.5, use_
         v_s = critic_value(params, fo).flatten()
         v_next = critic_value(params, fn_).flatten()
         logp_old = torch.log_softmax(actor_logits(params, fo), -1).gather(1, fact[:, None])[:, 0]
-    scale = np.sqrt(ret_rms.var + eps) if rew_norm else 1.0
-    vs64 = v_s.numpy().astype(np.float64).reshape(T, N) * scale
-    vn64 = v_next.numpy().astype(np.float64).reshape(T, N) * scale
-    r2 = frew.numpy().reshape(T, N)
-    unn = np.zeros((T, N))
-    adv = np.zeros((T, N))
-    for e in range(N):
-        end = fdone[:, e].copy()
-        end[-1] = True                                     # T2: the last collected index of an unfinished episode ends the trace
-        unn[:, e], adv[:, e] = gae_returns(r2[:, e], vs64[:, e], vn64[:, e], fdone[:, e], end, gamma, gae_lambda)
-    returns = unn / scale
-    if rew_norm:
-        ret_rms.update(unn.reshape(-1))
-    returns_t = torch.from_numpy(returns.reshape(-1).astype(np.float32))
-    adv_t = torch.from_numpy(adv.reshape(-1).astype(np.float32))
+    def compute_returns_now(v_s, v_next):
+        scale = np.sqrt(ret_rms.var + eps) if rew_norm else 1.0
+        vs64 = v_s.numpy().astype(np.float64).reshape(T, N) * scale
+        vn64 = v_next.numpy().astype(np.float64).reshape(T, N) * scale
+        r2 = frew.numpy().reshape(T, N)
+        unn = np.zeros((T, N))
+        adv = np.zeros((T, N))
+        for e in range(N):
+            end = fdone[:, e].copy()
+            end[-1] = True                                     # T2: the last collected index of an unfinished episode ends the trace
+            unn[:, e], adv[:, e] = gae_returns(r2[:, e], vs64[:, e], vn64[:, e], fdone[:, e], end, gamma, gae_lambda)
+        returns = unn / scale
+        if rew_norm:
+            ret_rms.update(unn.reshape(-1))
+        return torch.from_numpy(returns.reshape(-1).astype(np.float32)), torch.from_numpy(adv.reshape(-1).astype(np.float32))
+
+    returns_t, adv_t = compute_returns_now(v_s, v_next)
     rows = []
     inter = dict(rew=frew.numpy(), v_s=v_s.numpy(), v_next=v_next.numpy(), logp_old=logp_old.numpy(), returns=returns_t.numpy(),
                  adv=adv_t.numpy())
-    for _ in range(repeat):
+    for pass_no in range(repeat):
+        if recompute_adv and pass_no > 0:
+            with torch.no_grad():
+                v_s = critic_value(params, fo).flatten()
+                v_next = critic_value(params, fn_).flatten()
+            returns_t, adv_t = compute_returns_now(v_s, v_next)
+            inter.update(v_s=v_s.numpy(), v_next=v_next.numpy(), returns=returns_t.numpy(), adv=adv_t.numpy())
         for idx in split_indices(n, batch_size):
             if before_step is not None:
                 before_step(len(rows), np.asarray(idx), opt_state, inter)
@@ -255,7 +272,8 @@ def update(sd, obs, obs_next, act, rew, done, ret_rms, opt_state, lamb=0.5, use_
             for p in uniq.values():
                 p.grad = None
             loss, clip, vf, ent = ppo_loss(actor_logits(params, fo[idx]), critic_value(params, fo[idx]), fact[idx], adv_t[idx], logp_old[idx],
-                                           v_s[idx], returns_t[idx], eps_clip, vf_coef, ent_coef)
+                                           v_s[idx], returns_t[idx], eps_clip, vf_coef, ent_coef, norm_adv=norm_adv, value_clip=value_clip,
+                                           dual_clip=dual_clip)
             loss.backward()
             if max_grad_norm:
                 torch.nn.utils.clip_grad_norm_(list(uniq.values()), max_grad_norm)

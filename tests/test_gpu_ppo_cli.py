@@ -214,6 +214,11 @@ def test_run_mansy_bc_and_init_from_bc(tree):
     os.remove(os.path.join(mdir, 'checkpoint.pth'))
     run_mansy.main(common + ['--init-from-bc'])
     assert os.path.exists(os.path.join(mdir, 'checkpoint.pth'))
+    # the PPO switches the reference's defaults leave off are accepted end to end (run_mansy.py:307-311)
+    os.remove(os.path.join(mdir, 'checkpoint.pth'))
+    run_mansy.main(common + ['--init-from-bc', '--dual-clip', '3.0', '--recompute-adv', '1', '--value-clip', '0', '--norm-adv', '0', '--rew-norm', '0'])
+    sd_x = torch.load(os.path.join(mdir, 'checkpoint.pth'))
+    assert len(sd_x) == 120 and all(torch.isfinite(v).all() for v in sd_x.values())
 
 
 def test_run_simple_rl_cli(tree):
