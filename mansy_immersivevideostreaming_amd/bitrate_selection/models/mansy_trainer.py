@@ -133,5 +133,21 @@ class OnpolicyTrainer:
         return self.epoch, epoch_stat, info
 
 
+    def run(self):
+        """tianshou BaseTrainer.run: iterate to the end, return the last epoch's info dict (best_reward, duration, train_step)."""
+        info = {'best_reward': self.best_reward, 'train_step': self.env_step}
+        for _, _, info in self:
+            pass
+        return info
+
+
+def onpolicy_trainer(*args, **kwargs):
+    """mansy_trainer.py:180-187: `OnpolicyTrainer(...).run()`."""
+    return OnpolicyTrainer(*args, **kwargs).run()
+
+
+onpolicy_trainer_iter = OnpolicyTrainer      # mansy_trainer.py:190
+BaseTrainer = OnpolicyTrainer                # the reference's BaseTrainer override (:18-95) and its on-policy subclass are one class here
+
 # the vectorised collector doubles as the "test collector" handle (policy + venv)
 TestCollector = VecCollector

@@ -63,6 +63,17 @@ def to_position_normalized_cartesian(values):
     return out
 
 
+def find_block_covered_by_point(x, y, block_width, block_height):
+    """common.py:37-43 (host arithmetic, Python floor division): the tile a pixel falls into; an exact positive multiple belongs to
+    the lower tile."""
+    w, h = x // block_width, y // block_height
+    if x > 0 and x % block_width == 0:
+        w -= 1
+    if y > 0 and y % block_height == 0:
+        h -= 1
+    return w, h
+
+
 def find_tiles_covered_by_viewport(x, y, video_width, video_height, tile_width, tile_height, tile_num_width, tile_num_height,
                                    fov_width=600, fov_height=300, device='cuda'):
     """Single pixel centre (ints) -> uint8 [tile_num_height, tile_num_width] like the reference (device round trip)."""

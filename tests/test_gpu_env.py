@@ -153,3 +153,30 @@ def test_traces_that_would_never_finish_a_download_are_refused(E):
     build(one_left)
     def padding(a): a['trace_bw'][1, L:] = -5.0                      # bins past a trace's length are never read
     build(padding)
+
+
+def test_utils_common_entry_points_name_for_name(E):
+    """bitrate_selection/utils/common.py as a module: every public function of the reference's file is importable from the mirror under
+    the same name; allocate_tile_rates for ALL 25 (in, out) version pairs (the 15 actions cover only in >= out) on the golden
+    viewports, an empty and a full prediction, against the C oracle -- versions and bitrates."""
+    from mansy_immersivevideostreaming_amd.bitrate_selection.utils import common as C
+    for name in ('get_config_from_yml', 'normalize_quality', 'normalize_size', 'normalize_throughput', 'normalize_qoe_weight',
+                 'generate_environment_samples', 'generate_environment_test_samples', 'action2rates', 'rates2action', 'allocate_tile_rates',
+                 'read_log_file'):
+        assert callable(getattr(C, name)), name
+    table = [(1, 0), (2, 0), (3, 0), (4, 0), (2, 1), (3, 1), (4, 1), (3, 2), (4, 2), (4, 3), (0, 0), (1, 1), (2, 2), (3, 3), (4, 4)]
+    for a, (i, o) in enumerate(table):                     # utils/common.py:101-139
+        assert C.action2rates(a) == (i, o) and C.rates2action(i, o) == a
+    cfg = C.Config(video_rates=[1, 5, 8, 16, 35], max_size=500000, max_throughput=5000000)
+    assert C.normalize_quality(cfg, 7.0) == 7.0 / 35 and C.normalize_size(cfg, 250000) == 0.5 and C.normalize_throughput(cfg, 1e6) == 0.2
+    np.testing.assert_allclose(C.normalize_qoe_weight(np.array([1.0, 1.0, 2.0])), [0.25, 0.25, 0.5])
+    rates = (1, 5, 8, 16, 35)
+    G25 = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'alloc25_reference.npz'))      # the imported function, tools/gen_golden_alloc25.py
+    for k, pv in enumerate(G25['pred_viewport']):
+        for rin in range(5):
+            for rout in range(5):
+                ver, br = C.allocate_tile_rates(rin, rout, pv, rates, 8, 8)
+                np.testing.assert_array_equal(ver, G25['versions'][k, rin, rout], err_msg=f'{k} {rin} {rout}')
+                np.testing.assert_array_equal(br, G25['rates'][k, rin, rout])
+                np.testing.assert_array_equal(oenv.allocate_tile_rates(rin, rout, pv, rates), ver)
+                assert ver.dtype == np.int32 and br.dtype == np.int32 and ver.shape == (64,)

@@ -59,3 +59,21 @@ def test_epochs_flag_runs_e_minus_one_epochs_and_an_initial_test(monkeypatch, ep
     assert tr.best_epoch == best and tr.best_reward == tested[best]
     improved = [i for i in range(1, len(tested)) if tested[i] > max(tested[:i])]
     assert saved[1:] == [i + 1 for i in improved]              # later saves exactly at the improving epochs
+
+
+def test_trainer_module_exports_the_reference_names():
+    """models/mansy_trainer.py defines BaseTrainer, OnpolicyTrainer, onpolicy_trainer and onpolicy_trainer_iter (:18, :98, :180-190)."""
+    from mansy_immersivevideostreaming_amd.bitrate_selection.models import mansy_trainer as T
+    assert T.onpolicy_trainer_iter is T.OnpolicyTrainer and issubclass(T.OnpolicyTrainer, T.BaseTrainer)
+    assert callable(T.onpolicy_trainer) and callable(T.OnpolicyTrainer.run)
+
+
+def test_onpolicy_trainer_function_runs_to_the_end(monkeypatch):
+    """`onpolicy_trainer(...)` == `OnpolicyTrainer(...).run()` (mansy_trainer.py:180-187): iterates every epoch, returns the final info."""
+    from mansy_immersivevideostreaming_amd.bitrate_selection.models import mansy_trainer as mt
+    monkeypatch.setattr(mt, 'run_episodes', lambda policy, venv, n_episode, seed=0, reset=True: np.array([1.0, 2.0]))
+    pol, tc = _Policy(), _Collector()
+    info = mt.onpolicy_trainer(pol, tc, _Collector(), 4, step_per_epoch=8, repeat_per_collect=2, episode_per_test=2, batch_size=4,
+                               step_per_collect=4, verbose=False)
+    assert pol.updates == 2 * 3 and tc.calls == 6              # --epochs 4 -> 3 epochs of two collects each
+    assert info['best_reward'] == 1.5 and info['train_step'] == 24

@@ -50,3 +50,14 @@ def test_sample_enumeration():
         nv, nu, nt, nq = (int(x) for x in Z[f'enum/{mode}_lens'])
         fn = oenv.generate_environment_test_samples if mode == 'test' else oenv.generate_environment_samples
         np.testing.assert_array_equal(fn(nv, nu, nt, nq), Z[f'enum/{mode}'])
+
+
+def test_allocate_tile_rates_all_25_version_pairs_vs_imported_reference():
+    """The 15 actions only reach (in, out) pairs with in >= out; the function itself takes any pair (utils/common.py:142-193):
+    all 25 on six viewports (empty and full prediction included) through the imported reference, tools/gen_golden_alloc25.py."""
+    import os
+    G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'alloc25_reference.npz'))
+    for k, pv in enumerate(G['pred_viewport']):
+        for i in range(5):
+            for o in range(5):
+                np.testing.assert_array_equal(oenv.allocate_tile_rates(i, o, pv), G['versions'][k, i, o])
