@@ -126,6 +126,19 @@ class ExpertEnv:
         self.current_video = self.current_user = self.current_trace = self.current_qoe_weight = None
         self.state = None
 
+    def seed(self, seed):
+        """expert_env.py:318-321: seeds numpy; the expert walks its sample list in order whatever the seed."""
+        np.random.seed(seed)
+        self.random_seed = seed
+
+    def render(self, mode='human'):
+        """gym API (expert_env.py:323-330 opens an empty classic-control window): nothing to draw on the device path."""
+        return None
+
+    def close(self):
+        """gym API (expert_env.py:332-335)."""
+        return None
+
     def sample_count(self):
         return len(self.samples)
 

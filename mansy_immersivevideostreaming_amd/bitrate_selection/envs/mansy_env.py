@@ -293,6 +293,15 @@ class MANSYEnv:
         self.random_seed = seed
         self._venv = MANSYVecEnv(self.tables, 1, seed=seed, index_offset=0, worker_num=self.worker_num)
 
+
+    def render(self, mode='human'):
+        """gym API (mansy_env.py:258-264 opens an empty classic-control window): nothing to draw on the device path."""
+        return None
+
+    def close(self):
+        """gym API (mansy_env.py:266-269)."""
+        return None
+
     def sample_count(self):
         return len(self.samples)
 

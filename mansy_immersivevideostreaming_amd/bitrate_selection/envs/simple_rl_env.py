@@ -65,6 +65,14 @@ class SimpleRLEnv:
         np.random.seed(seed)
         self._venv = SimpleRLVecEnv(self.tables, 1, seed=seed, worker_num=self.worker_num)
 
+    def render(self, mode='human'):
+        """gym API (simple_rl_env.py opens an empty classic-control window): nothing to draw on the device path."""
+        return None
+
+    def close(self):
+        """gym API (simple_rl_env.py)."""
+        return None
+
     def sample_count(self):
         return len(self.samples)
 
