@@ -197,11 +197,23 @@ def bench_ppo(rank, world, dev, mdist, cycles=5, warmup=2, n_env=256, steps_per_
     pol = PPOPolicy(actor, critic, optim, None, discount_factor=0.95, max_grad_norm=1.0, eps_clip=0.2, vf_coef=0.5, ent_coef=0.02,
                     reward_normalization=1, advantage_normalization=1, value_clip=1, gae_lambda=0.95, action_space=15, args=A(),
                     identifier=ident, identifier_optim=ioptim).to(dev)
-    # MANSY_PEER_SYNC=1: the hand-written one-shot all-reduce over hipIpc-mapped peer memory (csrc/xgmi.hip) instead of the library
-    # collective for the 16 + 2 latency-bound gradient averages of a cycle.  Opt-in: it has only been exercised with ranks sharing
-    # one GPU (tests/test_gpu_dist.py); the default path is RCCL.
-    peer = world > 1 and os.environ.get('MANSY_PEER_SYNC') == '1'
+    # The 16 + 2 gradient averages of a cycle are latency-bound (1.7 MB / 1.05 MB, each on the critical path).  Two implementations: the
+    # library collective (RCCL) and the hand-written one-shot all-reduce over hipIpc-mapped peer memory (csrc/xgmi.hip).  Default: build
+    # the second, check it against the first on the same data, time both on THIS machine's links and keep the faster correct one
+    # (dist.probe_peer_grad_sync; any set-up failure, wrong result or timed-out wait on any rank -> the library collective on every rank).
+    # MANSY_PEER_SYNC=1 / 0 forces one or the other.
+    mode = os.environ.get('MANSY_PEER_SYNC', 'auto')
+    peer = False if world <= 1 or mode == '0' else (True if mode == '1' else 'auto')
     pol.set_data_parallel(world, mdist.make_grad_sync(world), peer=peer)
+    rep = pol.grad_sync_report
+    if world <= 1:
+        sync_desc = 'none'
+    elif rep.get('chosen') == 'peer':
+        sync_desc = 'peer-memory one-shot (csrc/xgmi.hip)' + ('' if peer is True else
+                                                             f"; probe: peer {rep.get('us_peer')} us vs library {rep.get('us_library')} us per {rep.get('floats')}-float average")
+    else:
+        sync_desc = 'torch.distributed all_reduce' + ('' if peer is False else f"; probe: {rep.get('reason')}" + (
+            f" (peer {rep.get('us_peer')} us vs library {rep.get('us_library')} us)" if 'us_peer' in rep else ''))
     tables = EnvTables.synthetic(dev, seed=5, train_identifier_reward=True, n_sample=max(240, n_env * world))
     off, wnum = mdist.shard_envs(n_env, rank, world)
     venv = MANSYVecEnv(tables, n_env, seed=5, index_offset=off, worker_num=wnum)
@@ -270,7 +282,7 @@ def bench_ppo(rank, world, dev, mdist, cycles=5, warmup=2, n_env=256, steps_per_
     spread = max(replica_spread(pol.engine.ac.flat_p, world), replica_spread(pol.engine.idn.flat_p, world))
     return {'metric': 'PPO env-steps/sec', 'value': round(steps / dt, 1), 'unit': 'env-steps/s', 'n_gpus': world, 'cycles': cycles,
             'replica_param_spread': spread,
-            'grad_sync': 'none' if world <= 1 else ('peer-memory one-shot (csrc/xgmi.hip)' if peer else 'torch.distributed all_reduce'),
+            'grad_sync': sync_desc,
             'ms_per_cycle': round(dt / cycles * 1e3, 3), 'rollout_only_env_steps_per_s': round(n_env * steps_per_env * cycles / t_collect, 1),
             'rollout_step_latency_us': round(t_collect / (cycles * steps_per_env) * 1e6, 1), 'final_loss': float(np.mean(res['loss'])),
             'config': {'workload': f'{n_env} device-resident envs/GPU x {steps_per_env} steps per collect (4096 transitions/GPU), '

@@ -222,15 +222,26 @@ class PPOPolicy(nn.Module):
     def set_data_parallel(self, world, grad_sync, peer=False):
         """One process per GPU: `grad_sync(flat_grad)` averages a flat gradient buffer over ranks (dist.make_grad_sync).
         peer=True: the hand-written one-shot all-reduce over peer-mapped memory (dist.PeerGradSync, csrc/xgmi.hip) for both flat
-        buffers instead -- one launch that also leaves the gradient's sums of squares for the clip."""
+        buffers instead -- one launch that also leaves the gradient's sums of squares for the clip.  peer='auto': build it, check it
+        against `grad_sync` on the same data, time both, and use it only if every rank finds it correct and faster
+        (dist.probe_peer_grad_sync; the decision and the two timings are kept in `self.grad_sync_report`)."""
         self.world, self.grad_sync = int(world), grad_sync
         self._peer = {}
+        self.grad_sync_report = {'chosen': 'library' if self.world > 1 else 'none'}
         if peer and self.world > 1:
             import torch.distributed as tdist
-            from ...dist import PeerGradSync
-            for f in (self.engine.ac, self.engine.idn):
-                if f is not None:
+            from ...dist import PeerGradSync, probe_peer_grad_sync
+            flats = [f for f in (self.engine.ac, self.engine.idn) if f is not None]
+            if peer == 'auto':
+                sizes = sorted({f.flat_p.numel() for f in flats})
+                peers, self.grad_sync_report = probe_peer_grad_sync(sizes, self.world, tdist.get_rank(), flats[0].flat_p.device, grad_sync)
+                for f in flats:
+                    if f.flat_p.numel() in peers:
+                        self._peer[id(f)] = peers[f.flat_p.numel()]
+            else:
+                for f in flats:
                     self._peer[id(f)] = PeerGradSync(f.flat_p.numel(), self.world, tdist.get_rank(), f.flat_p.device)
+                self.grad_sync_report = {'chosen': 'peer', 'reason': 'forced'}
 
     def _upload_i32(self, key, arr, dev):
         """Host int array -> device int32 tensor through a persistent PINNED staging buffer and a non-blocking copy: the copy engine

@@ -124,28 +124,74 @@ class PeerGradSync:
     fused_sumsq = True
 
     def __init__(self, n_floats, world, rank, device=None, timeout_ms=None):
+        err = self._setup(n_floats, world, rank, device, timeout_ms, tolerant=False)
+        if err is not None:                      # another rank failed its set-up
+            from ._lib import MansyError
+            self.close()
+            raise MansyError(err)
+
+    @classmethod
+    def try_create(cls, n_floats, world, rank, device=None, timeout_ms=None):
+        """-> (PeerGradSync, None) or (None, reason): the same set-up, but a failure on ANY rank (fine-grained allocation, hipIpc export /
+        import, peer access) is agreed on by all ranks -- every rank takes part in every exchange whatever happened locally -- so that
+        the caller can fall back to the library collective everywhere instead of leaving some ranks inside a collective."""
+        self = cls.__new__(cls)
+        err = self._setup(n_floats, world, rank, device, timeout_ms, tolerant=True)
+        if err is not None:
+            self.close()
+            return None, err
+        return self, None
+
+    def _setup(self, n_floats, world, rank, device, timeout_ms, tolerant):
         import ctypes
-        from ._lib import check, lib
+        from ._lib import XgHandle, check, lib
         self.world, self.rank, self.n = int(world), int(rank), int(n_floats)
         self._lib, self._check = lib(), check
+        self.ctx = None
         if device is not None:
             torch.cuda.set_device(device)
-        self.ctx = ctypes.c_void_p()
-        check(self._lib.mansy_xg_create(self.n, self.world, self.rank, ctypes.byref(self.ctx)), 'mansy_xg_create')
-        if timeout_ms is not None:
-            check(self._lib.mansy_xg_set_timeout_ms(self.ctx, float(timeout_ms)), 'mansy_xg_set_timeout_ms')
-        if self.world > 1:
-            from ._lib import XgHandle
-            own = XgHandle()
-            check(self._lib.mansy_xg_export(self.ctx, ctypes.byref(own)), 'mansy_xg_export')
-            gathered = [None] * self.world
-            dist.all_gather_object(gathered, bytes(own.bytes))
+
+        def guarded(fn):
+            try:
+                fn()
+                return None
+            except Exception as e:          # noqa: BLE001 -- reported to every rank below
+                if not tolerant:
+                    raise
+                return f'rank {self.rank}: {e}'
+
+        own = XgHandle()
+
+        def create_export():
+            if os.environ.get('MANSY_XG_TEST_FAIL_RANK') == str(self.rank):      # test hook: one rank's set-up fails (tests/test_gpu_dist.py)
+                raise RuntimeError('injected set-up failure')
+            ctx = ctypes.c_void_p()
+            check(self._lib.mansy_xg_create(self.n, self.world, self.rank, ctypes.byref(ctx)), 'mansy_xg_create')
+            self.ctx = ctx
+            if timeout_ms is not None:
+                check(self._lib.mansy_xg_set_timeout_ms(self.ctx, float(timeout_ms)), 'mansy_xg_set_timeout_ms')
+            if self.world > 1:
+                check(self._lib.mansy_xg_export(self.ctx, ctypes.byref(own)), 'mansy_xg_export')
+        err = guarded(create_export)
+        if self.world <= 1:
+            return err
+        gathered = [None] * self.world
+        dist.all_gather_object(gathered, (err, bytes(own.bytes)))
+        errs = [e for e, _ in gathered if e]
+        if errs:
+            return errs[0]
+
+        def do_import():
             allh = (XgHandle * self.world)()
-            for r, h in enumerate(gathered):
+            for r, (_, h) in enumerate(gathered):
                 assert len(h) == 64
                 allh[r].bytes[:] = list(h)
             check(self._lib.mansy_xg_import(self.ctx, allh), 'mansy_xg_import')
-            dist.barrier()                     # every rank has mapped every peer before the first flag is read
+        err = guarded(do_import)
+        flags = [None] * self.world
+        dist.all_gather_object(flags, err)       # doubles as the barrier: every rank has mapped every peer before the first flag is read
+        errs = [e for e in flags if e]
+        return errs[0] if errs else None
 
     def __call__(self, flat_g, scratch=None):
         from ._lib import ptr, stream_ptr
@@ -156,9 +202,90 @@ class PeerGradSync:
         self._check(self._lib.mansy_xg_status(self.ctx), 'mansy_xg_status')
 
     def close(self):
-        if self.ctx:
+        if getattr(self, 'ctx', None):
             self._lib.mansy_xg_destroy(self.ctx)
             self.ctx = None
+
+
+def probe_peer_grad_sync(sizes, world, rank, device, library_sync, iters=10, timeout_ms=60000):
+    """Measure, do not guess: build the peer-memory all-reduce for flat buffers of `sizes` floats, check it against the library collective
+    on the same data, time both (max over ranks), and keep it only if every rank agrees it is correct AND faster.  The wait of the
+    peer kernel stays bounded (timeout_ms: generous, so that a rank delayed by a first-call set-up does not poison a step; a library
+    collective would simply wait).
+    -> ({size: PeerGradSync} or {}, report dict for the bench line).  Every rank calls this; every rank returns the same decision."""
+    import time
+    report = {'probe': 'peer-memory one-shot vs library all_reduce', 'iters': iters}
+    agree_dev = device if dist.get_backend() == 'nccl' else 'cpu'
+
+    def all_min(x):
+        t = torch.tensor([float(x)], dtype=torch.float64, device=agree_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return float(t.item())
+
+    def all_max(x):
+        t = torch.tensor([float(x)], dtype=torch.float64, device=agree_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    peers = {}
+    for n in sizes:
+        p, err = PeerGradSync.try_create(n, world, rank, device, timeout_ms=timeout_ms)
+        if p is None:
+            for q in peers.values():
+                q.close()
+            report.update(chosen='library', reason=f'peer set-up failed: {err}')
+            return {}, report
+        peers[n] = p
+    n0 = max(sizes)
+    g = torch.Generator(device='cpu').manual_seed(4321 + rank)
+    src = torch.randn(n0, generator=g).to(device)
+    ref = src.clone()
+    library_sync(ref)
+    out, scratch = src.clone(), torch.zeros(64, dtype=torch.float64, device=device)
+    ok, why = 1.0, ''
+    try:
+        peers[n0](out, scratch)
+        torch.cuda.synchronize(device)
+        peers[n0].check()
+        if not torch.allclose(out, ref, rtol=1e-5, atol=1e-6):
+            ok, why = 0.0, f'rank {rank}: peer average differs from the library average by {float((out - ref).abs().max()):.3e}'
+        elif abs(float(scratch.sum()) - float((out.double() ** 2).sum())) > 1e-6 * max(float((out.double() ** 2).sum()), 1e-30):
+            ok, why = 0.0, f'rank {rank}: sums of squares differ'
+    except Exception as e:          # noqa: BLE001
+        ok, why = 0.0, f'rank {rank}: {e}'
+    if all_min(ok) < 1.0:
+        for q in peers.values():
+            q.close()
+        report.update(chosen='library', reason='peer self-test failed' + (': ' + why if why else ' on another rank'))
+        return {}, report
+
+    def timed(fn):
+        buf = src.clone()
+        for _ in range(3):
+            fn(buf)
+        torch.cuda.synchronize(device)
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn(buf)
+        torch.cuda.synchronize(device)
+        return all_max((time.perf_counter() - t0) / iters * 1e6)
+    t_lib = timed(library_sync)
+    t_peer = timed(lambda b: peers[n0](b, scratch))
+    try:
+        peers[n0].check()
+        timed_ok = 1.0
+    except Exception:               # noqa: BLE001
+        timed_ok = 0.0
+    report.update(us_library=round(t_lib, 1), us_peer=round(t_peer, 1), floats=n0)
+    all_timed_ok = all_min(timed_ok) >= 1.0
+    if not all_timed_ok or not t_peer < t_lib:
+        for q in peers.values():
+            q.close()
+        report.update(chosen='library', reason='library collective is not slower' if all_timed_ok else 'a timed peer launch missed its peers')
+        return {}, report
+    report.update(chosen='peer', reason='correct on every rank and faster')
+    return peers, report
 
 
 def shard_envs(n_env_per_rank, rank, world):

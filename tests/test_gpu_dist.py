@@ -160,3 +160,30 @@ def test_bench_two_ranks_with_the_peer_memory_allreduce():
     assert out['n_gpus'] == 2 and out['secondary']['n_gpus'] == 2 and out['secondary']['grad_sync'] == 'peer-memory one-shot (csrc/xgmi.hip)'
     assert out['secondary']['replica_param_spread'] == 0.0 and out['secondary']['value'] > 0
     assert np.isfinite(out['secondary']['final_loss'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', ['auto', 'off', 'one_rank_fails'])
+def test_bench_chooses_its_gradient_average_by_probe_and_falls_back_together(case):
+    """bench.py's default for the PPO gradient averages: build the peer-memory all-reduce, check it against the library collective on
+    the same data, time both, keep the faster correct one -- the decision is taken collectively, so a set-up failure on ONE rank (injected)
+    sends EVERY rank to the library collective instead of leaving the others inside an exchange; MANSY_PEER_SYNC=0 skips the probe.
+    Two ranks share the GPU over gloo; the replicas end bit-identical either way."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'MANSY_PEER_SYNC')}
+    env.update(MANSY_DIST_BACKEND='gloo', MANSY_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    if case == 'off':
+        env['MANSY_PEER_SYNC'] = '0'
+    if case == 'one_rank_fails':
+        env['MANSY_XG_TEST_FAIL_RANK'] = '1'
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '256', '--no-cpu-baseline']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    sec = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][0])['secondary']
+    assert sec['n_gpus'] == 2 and sec['replica_param_spread'] == 0.0 and sec['value'] > 0 and np.isfinite(sec['final_loss'])
+    gs = sec['grad_sync']
+    if case == 'off':
+        assert gs == 'torch.distributed all_reduce'
+    elif case == 'one_rank_fails':
+        assert gs.startswith('torch.distributed all_reduce; probe: peer set-up failed: rank 1: injected set-up failure'), gs
+    else:                      # either outcome is legitimate; the line must say which and why (gloo moves the buffer through the host: peer wins here)
+        assert 'probe' in gs and (gs.startswith('peer-memory one-shot (csrc/xgmi.hip); probe: peer ') or gs.startswith('torch.distributed all_reduce; probe: ')), gs
