@@ -207,11 +207,12 @@ class PeerGradSync:
             self.ctx = None
 
 
-def probe_peer_grad_sync(sizes, world, rank, device, library_sync, iters=10, timeout_ms=60000):
+def probe_peer_grad_sync(sizes, world, rank, device, library_sync, iters=10, probe_timeout_ms=5000, timeout_ms=60000):
     """Measure, do not guess: build the peer-memory all-reduce for flat buffers of `sizes` floats, check it against the library collective
     on the same data, time both (max over ranks), and keep it only if every rank agrees it is correct AND faster.  The wait of the
-    peer kernel stays bounded (timeout_ms: generous, so that a rank delayed by a first-call set-up does not poison a step; a library
-    collective would simply wait).
+    peer kernel stays bounded: probe_timeout_ms while it is on trial (a dead link costs the start-up 5 s, then everyone uses the library),
+    timeout_ms once it is chosen (generous, so that a rank delayed by a first-call set-up does not poison a step; a library collective
+    would simply wait).
     -> ({size: PeerGradSync} or {}, report dict for the bench line).  Every rank calls this; every rank returns the same decision."""
     import time
     report = {'probe': 'peer-memory one-shot vs library all_reduce', 'iters': iters}
@@ -229,7 +230,7 @@ def probe_peer_grad_sync(sizes, world, rank, device, library_sync, iters=10, tim
 
     peers = {}
     for n in sizes:
-        p, err = PeerGradSync.try_create(n, world, rank, device, timeout_ms=timeout_ms)
+        p, err = PeerGradSync.try_create(n, world, rank, device, timeout_ms=probe_timeout_ms)
         if p is None:
             for q in peers.values():
                 q.close()
@@ -284,6 +285,8 @@ def probe_peer_grad_sync(sizes, world, rank, device, library_sync, iters=10, tim
             q.close()
         report.update(chosen='library', reason='library collective is not slower' if all_timed_ok else 'a timed peer launch missed its peers')
         return {}, report
+    for q in peers.values():                     # in production a late peer is waited for (bounded), not declared dead after 5 s
+        q._check(q._lib.mansy_xg_set_timeout_ms(q.ctx, float(timeout_ms)), 'mansy_xg_set_timeout_ms')
     report.update(chosen='peer', reason='correct on every rank and faster')
     return peers, report
 
