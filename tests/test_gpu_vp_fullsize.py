@@ -1,0 +1,132 @@
+"""The train step AT THE SIZE THE BENCH TIMES (BASELINE configs[1]: B = 4096, S = T = 10, d = ff = 512, 2 + 2 layers) against the
+oracle's autograd on the host cores -- reference arithmetic: viewport_prediction/models/mtio.py:65-104,150-166 and the loop body
+run_models.py:37-44.
+
+Everything bench.py's timed region launches is chosen by size: the 128 x 64 tiles, the split-K dW products over K = B*S = 40 960 rows
+(768 workgroups adding 64 x 64 partial tiles with float atomics), the bias-gradient riders over 1 280 K-tiles, the two-stream half-batch
+decoder.  None of those configurations runs at the golden sizes (B = 4..32); here they meet an independent answer: one `train_step`
+(dropout off, both MTIO branches, both `two_stream` settings, fp32 and bf16x6) -> loss, pred, EVERY gradient, the BatchNorm running
+statistics and the post-AdamW weights vs oracle.vp_oracle (CPU autograd, about a minute per branch on the box's host cores).
+"""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import vp_oracle as vo  # noqa: E402
+
+B, S, T, D = 4096, 10, 10, 512
+LR = 1e-4
+WSEED = 23
+
+
+@pytest.fixture(scope='module')
+def MT():
+    if not torch.cuda.is_available():
+        pytest.fail('GPU tests need a ROCm device (no CPU fallback exists)')
+    from mansy_immersivevideostreaming_amd.viewport_prediction.models import mtio
+    return mtio
+
+
+_ORACLE = {}
+
+
+def _perms(seed):
+    """The two np.random.shuffle permutations mtio.py:81-86 draws after random.random() chose the mix branch."""
+    np.random.seed(seed)
+    out = []
+    for _ in range(2):
+        idx = np.arange(B)
+        np.random.shuffle(idx)
+        out.append(idx)
+    return out
+
+
+def _oracle(branch):
+    """loss, pred, every gradient, BN running statistics and the AdamW'd weights of ONE step, by CPU autograd (cached per branch)."""
+    if branch in _ORACLE:
+        return _ORACLE[branch]
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    sd = vo.make_state_dict(D, WSEED, bias=True)
+    h, c, f = vo.synthetic_trajectories(B, S, T, seed=5)            # the bench's batch (bench.py, SURVEY 8d C2 inputs)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()
+              if v.dtype.is_floating_point and 'running_' not in k and k != 'positional_embedding.pe'}
+    full = dict(sd)
+    full.update(params)
+    orc = vo.VPOracle(full, fut_window=T)
+    perms = None if branch == 'rep' else [torch.from_numpy(p) for p in _perms(77)]
+    src, cur, gt = vo.mtio_mix(h, c, f, 3, branch == 'rep', perms)
+    pred = orc.process_src_current(src, cur, train=True)
+    loss = orc.loss_function(pred, gt)
+    loss.backward()
+    grads = {k: p.grad.detach().clone() for k, p in params.items()}
+    stepped = {}
+    for k, p in params.items():
+        p1, _, _ = vo.adamw_step(p.detach(), grads[k], torch.zeros_like(p), torch.zeros_like(p), step=1, lr=LR)
+        stepped[k] = p1
+    out = dict(sd=sd, h=h, c=c, f=f, loss=loss.item(), pred=pred.detach().clone(), grads=grads, stepped=stepped,
+               bn=tuple(t.clone() for t in orc.last_bn_stats))
+    del orc, pred, loss, params, full
+    _ORACLE[branch] = out
+    return out
+
+
+@pytest.mark.parametrize('two_stream', [False, True], ids=['one_stream', 'two_stream'])
+@pytest.mark.parametrize('prec', ['f32', 'bf16x6'])
+@pytest.mark.parametrize('branch', ['rep', 'mix'])
+def test_bench_size_train_step_vs_oracle_autograd(MT, branch, prec, two_stream):
+    o = _oracle(branch)
+    m = MT.ViewportTransformerMTIO(in_channel=2, fut_window=T, d_model=D, dim_feedforward=D, device='cuda', bias=True)
+    m.load_state_dict(o['sd'])
+    m = m.to('cuda')
+    m.dropout_p = m.attn_dropout_p = 0.0
+    m.precision = prec
+    m.two_stream = two_stream
+    assert m._cfg(B, S).two_stream == int(two_stream)
+    m.train()
+    if branch == 'rep':
+        m.repeat_prob = 1.0                         # random.random() < 1: the replicate branch
+    else:
+        m.repeat_prob = 0.0                         # the shuffle branch; np.random.seed(77) gives _perms(77)
+    random.seed(77)
+    np.random.seed(77)
+    opt = MT.FusedAdamW(m, lr=LR)
+    loss = m.train_step(o['h'].cuda(), o['c'].cuda(), o['f'].cuda(), opt).item()       # the call bench.py times
+    torch.cuda.synchronize()
+    cfg = m._cfg(B, S)
+    # ---- loss and predictions
+    assert abs(loss - o['loss']) <= 1e-6 * max(1.0, abs(o['loss'])), (loss, o['loss'])
+    pred = m.ws_tensor(cfg, 'pred_bt')[:B * T * 6].reshape(B, T, 6).cpu()
+    np.testing.assert_allclose(pred.numpy(), o['pred'].numpy(), atol=1e-4, rtol=0)
+    # ---- every gradient (train_step leaves them in the flat buffer)
+    bad = []
+    tols = {}
+    for k, p, off in zip(m._engine_names, m._params, m._offsets):
+        ref = o['grads'][k].numpy()
+        got = m._flat_g[off:off + p.numel()].view(p.shape).cpu().numpy()
+        tol = 3e-4 * np.abs(ref).max() + 2e-6
+        tols[k] = tol
+        err = np.abs(got - ref).max()
+        if not err <= tol:
+            bad.append((k, float(err), float(tol)))
+    assert not bad, bad
+    # ---- BatchNorm running statistics (DistillLayer, customized_transformer.py:30-36)
+    bn = m.transformer.distill_layer.norm
+    np.testing.assert_allclose(bn.running_mean.cpu().numpy(), o['bn'][0].numpy(), atol=1e-6, rtol=1e-5)
+    np.testing.assert_allclose(bn.running_var.cpu().numpy(), o['bn'][1].numpy(), atol=1e-6, rtol=1e-5)
+    assert int(bn.num_batches_tracked.item()) == 1
+    # ---- post-AdamW weights.  First step: update = lr * g / (|g| + eps) = +-lr wherever |g| >> eps, so an element whose gradient is
+    # inside the gradient tolerance may legitimately step the other way (2 lr apart); everywhere else the weights must agree to
+    # fp32 rounding of the update.
+    sdn = m.state_dict()
+    for k in m._engine_names:
+        got, ref = sdn[k].cpu().numpy(), o['stepped'][k].numpy()
+        err = np.abs(got - ref)
+        assert err.max() <= 2.02 * LR, (k, float(err.max()))
+        sure = np.abs(o['grads'][k].numpy()) > 2 * tols[k]
+        if sure.any():
+            assert err[sure].max() <= 1e-6, (k, float(err[sure].max()))
+        assert sure.mean() > 0.2 or k.endswith('bias') or 'norm' in k, (k, float(sure.mean()))
