@@ -144,17 +144,24 @@ def _pmc_traffic(pattern='r*_pmc_gemm.json'):
         return None, None, None
 
 
-def _ppo_launches_per_cycle():
-    """Kernel launches per PPO cycle from the newest committed rocprofv3 kernel-stats file of the cycle (profiles/r*_ppo_kernel_stats.csv
-    = tools/gpu_prof_ppo.sh: 10 timed + 2 warm-up + 2 roofline-leg cycles) -- a measured figure, not a literal."""
+def _ppo_torch_kernels_per_cycle():
+    """Kernels per PPO cycle that are NOT this library's (torch's own: the uniforms of the Categorical sampling, slab copies, index
+    arithmetic of the host mirror), from the newest committed rocprofv3 kernel-stats file of the cycle next to its meta file
+    (profiles/r*_ppo_kernel_stats.csv + .meta.json = tools/gpu_prof_ppo.sh: the cycle count of that profile and the digest of the
+    sources it ran).  The library's own launches are counted LIVE (mansy_prof_launch_count); this is the only profile-derived part of
+    the launch count and it carries a stale flag."""
     import csv
     import glob
+    from mansy_immersivevideostreaming_amd import build_ext
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_ppo_kernel_stats.csv')))
     try:
-        calls = sum(int(r['Calls']) for r in csv.DictReader(open(files[-1])))
-        return round(calls / 14.0, 1), 'profiles/' + os.path.basename(files[-1])
+        meta = json.load(open(files[-1][:-4] + '.meta.json'))
+        rows = list(csv.DictReader(open(files[-1])))
+        theirs = ('at::', 'rocclr', 'rocprim', 'hipcub')            # torch's kernels + the HIP runtime's blit kernels (copy / fill)
+        other = sum(int(r['Calls']) for r in rows if any(t in r['Name'] for t in theirs))
+        return round(other / float(meta['cycles']), 1), 'profiles/' + os.path.basename(files[-1]), meta.get('source_digest') != build_ext.source_digest()
     except Exception:
-        return None, None
+        return None, None, None
 
 
 def _gemm_prof(L, fn, reps):
@@ -229,9 +236,12 @@ def bench_ppo(rank, world, dev, mdist, cycles=5, warmup=2, n_env=256, steps_per_
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    from mansy_immersivevideostreaming_amd._lib import lib
+    launches0 = lib().mansy_prof_launch_count()
     t0 = time.perf_counter()
     for _ in range(cycles):
         res = cycle()
+    launches1 = lib().mansy_prof_launch_count()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -260,7 +270,11 @@ def bench_ppo(rank, world, dev, mdist, cycles=5, warmup=2, n_env=256, steps_per_
     steps = world * n_env * steps_per_env * cycles
     if rank == 0:
         eps = steps / dt / world                                      # env-steps/s of this GPU
-        n_launch, launch_src = _ppo_launches_per_cycle()
+        # live: this library's launches per cycle = what the timed cycles enqueued directly + the captured rollout graph's kernels (one
+        # replay per cycle); torch's own few kernels per cycle (uniforms, slab copies) from the committed profile, flagged if stale
+        n_lib = (launches1 - launches0) / float(cycles) + (col.graph_launches if col.use_graph and col._graph is not None else 0)
+        n_torch, launch_src, launch_stale = _ppo_torch_kernels_per_cycle()
+        n_launch = round(n_lib + (n_torch or 0), 1)
         gemm_tf = fl_g / (ms_g * 1e-3) / 1e12 if ms_g > 0 else 0.0
         roof = {'bound': 'mfma', 'kernel': 'gemm_f32_dma_kernel (FeatureNet block-diagonal product, heads, dF / dW products of the update)',
                 'achieved': round(eps * PPO_FLOP_PER_ENV_STEP / 1e12, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
@@ -273,7 +287,8 @@ def bench_ppo(rank, world, dev, mdist, cycles=5, warmup=2, n_env=256, steps_per_
                                          'gemm_frac_of_peak': round(gemm_tf / PEAK_F32_MFMA_TFLOPS, 4),
                                          'rollout_gemm_launches_per_cycle_in_graph': 2 * steps_per_env},
                 'launch_floor': {'us_per_dependent_launch': LAUNCH_FLOOR_US, 'launches_per_cycle': n_launch,
-                                 'source': launch_src,
+                                 'library_launches_per_cycle_live': round(n_lib, 1), 'rollout_graph_kernels': col.graph_launches,
+                                 'torch_kernels_per_cycle': n_torch, 'torch_kernels_source': launch_src, 'torch_kernels_stale': launch_stale,
                                  'floor_ms_per_cycle': round((n_launch or 0) * LAUNCH_FLOOR_US * 1e-3, 3),
                                  'measured_ms_per_cycle': round(dt / cycles * 1e3, 3)}}
     if peer:
@@ -426,15 +441,23 @@ def spawn_ranks(n, argv, script=None):
                                       stdout=None if r == 0 else sys.stderr))
     failed = None
     alive = set(range(n))
+    grace = float(os.environ.get('MANSY_BENCH_EXIT_GRACE_S', '120'))
+    first_exit = None
     while alive and failed is None:
         for r in sorted(alive):
             rc = procs[r].poll()
             if rc is None:
                 continue
             alive.discard(r)
+            if first_exit is None:
+                first_exit = time.time()
             if rc != 0:
                 failed = (r, rc)
                 break
+        # every rank ends with the same barrier + destroy_process_group: once one has exited 0 the others are seconds behind.  A rank
+        # still running long after that is stuck (a hung destroy, a peer kernel that never met its peers): do not poll for ever.
+        if failed is None and alive and first_exit is not None and time.time() - first_exit > grace:
+            failed = (sorted(alive)[0], 124)
         time.sleep(0.05)
     if failed is not None:                        # one rank died: the others would wait in a collective for ever
         for r in alive:
@@ -478,6 +501,9 @@ def main():
         # a line whose n_gpus is not what was asked for would be read as a measurement of the wrong job
         sys.exit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={env_world_size} ranks; refusing to run')
 
+    # before ANY torch.cuda call (device_count() can initialise HSA): the host driver only supports dmabuf IPC, and a torchrun launch
+    # has no self-spawn parent that exported the variable
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     import numpy as np
     import torch
     import torch.distributed as dist

@@ -32,6 +32,26 @@ const char* mansy_last_error(void);
 int mansy_abi_version(void);
 
 /* ------------------------------------------------------------------ viewport predictor */
+/* Precision of the dense products (torch.nn.Linear / Conv1d arithmetic behind mtio.py, customized_transformer.py and
+ * bitrate_selection/models/mansy.py) of ONE call: MANSY_PREC_F32 = exact fp32 on v_mfma_f32_32x32x2_f32 (the parity mode);
+ * MANSY_PREC_BF16X3 / _BF16X6: operands split into bf16 terms, 3 / 6 bf16 MFMA products accumulated in fp32 (BASELINE.json configs[4]
+ * "bf16 MFMA").  Products with K % 32 != 0 or unaligned operands stay fp32.  A launch-time property: a captured hipGraph keeps the
+ * mode it was captured in.  Carried by mansy_vp_config::precision and by the `precision` argument of the PPO / A2C entry points --
+ * no process-wide state (ABI 7).  MANSY_PREC_DEFAULT (-1) = the value of the deprecated process-wide setter below (fp32 unless set). */
+#define MANSY_PREC_DEFAULT (-1)
+#define MANSY_PREC_F32 0
+#define MANSY_PREC_BF16X3 3
+#define MANSY_PREC_BF16X6 6
+
+/* SyncBN hook (mansy_vp_config::bn_sync_fn / bn_sync_user): with bn_sync_world > 1 the engine calls fn(which, user) after enqueuing
+ * the per-channel partial sums (which = 0: forward [sum, sumsq]; 1: backward [sum g, sum g*xhat]); the hook must all-reduce (SUM) the
+ * 2*d_model doubles at workspace slot "dis.stats" (+ 0 / + 2*d_model doubles) over the ranks, ordered on the same stream.
+ * which = 2 (mansy_vp_backward / _train_step, between the DistillLayer backward and the encoder backward): the gradients of every
+ * parameter from transformer.decoder.layers.0.* to the end of the table are final -- the hook may start their all-reduce on
+ * another stream while the encoder backward runs (it must not touch the stream's pending work); returning 0 without doing
+ * anything is fine. */
+typedef int (*mansy_bn_sync_fn)(int which, void* user);
+
 typedef struct mansy_vp_config {
   int B, S, T;                 /* batch, history window, future window */
   int d_model, n_head, d_ff;   /* 512, 8 (nn.Transformer default), 512 */
@@ -46,16 +66,12 @@ typedef struct mansy_vp_config {
                                 * attention / LayerNorm passes of the other; needs B >= 256 and even, else ignored).  Same function,
                                 * bit-identical forward.  The host mirror turns it on (sample() +4 %, train step +1.8 % at B = 4096);
                                 * per-kernel timings are taken with it off (concurrent kernels stretch each other's durations). */
+  int precision;               /* MANSY_PREC_* of this call's dense products (ABI 7; was process-wide) */
+  mansy_bn_sync_fn bn_sync_fn; /* SyncBN / gradient-ready hook of this call (ABI 7; was process-wide); NULL with bn_sync_world > 1 */
+  void* bn_sync_user;          /*   falls back to the deprecated mansy_set_bn_sync_hook registration */
 } mansy_vp_config;
 
-/* SyncBN hook: with bn_sync_world > 1 the engine calls fn(which, user) after enqueuing the per-channel partial sums
- * (which = 0: forward [sum, sumsq]; 1: backward [sum g, sum g*xhat]); the hook must all-reduce (SUM) the 2*d_model doubles at
- * workspace slot "dis.stats" (+ 0 / + 2*d_model doubles) over the ranks, ordered on the same stream.
- * which = 2 (mansy_vp_backward / _train_step, between the DistillLayer backward and the encoder backward): the gradients of every
- * parameter from transformer.decoder.layers.0.* to the end of the table are final -- the hook may start their all-reduce on
- * another stream while the encoder backward runs (it must not touch the stream's pending work); returning 0 without doing
- * anything is fine. */
-typedef int (*mansy_bn_sync_fn)(int which, void* user);
+/* DEPRECATED (kept for one round as shims): process-wide registration, used only by calls whose config leaves bn_sync_fn NULL. */
 int mansy_set_bn_sync_hook(mansy_bn_sync_fn fn, void* user);
 
 /* ordered parameter table (names are the reference state_dict keys) */
@@ -198,25 +214,25 @@ size_t mansy_ppo_workspace_bytes(int max_batch);
  * u [B] external uniforms in [0,1) or NULL => counter hash (seed, site, row) */
 int mansy_policy_forward(const float* const* params, const float* obs, int B, float* logits, float* value, int* act, float* logp,
                          const float* u, uint32_t seed, uint32_t site, int reuse_packed /* 1: parameters unchanged since the
-                         previous policy call on this workspace */, void* workspace, int max_batch, void* stream);
+                         previous policy call on this workspace */, void* workspace, int max_batch, int precision, void* stream);
 /* One rollout step as ONE call and one launch fewer: mansy_policy_forward (actor only, sampling on) for the n_env observation rows,
  * then mansy_env_step of every environment with the action just drawn, inside the same output-layer launch (the wave that sampled
  * row e goes on to step environment e).  Same outputs as the two calls. */
 int mansy_policy_env_step(const float* const* params, const float* obs, int n_env, float* logits, int* act, float* logp, const float* u,
                           uint32_t seed, uint32_t site, int reuse_packed, void* workspace, int max_batch, const mansy_env_tables* T,
                           void* env_state, float* obs_next, float* obs_cur, float* reward, unsigned char* done, float* qoe_parts,
-                          const mansy_env_episode_log* elog, void* stream);
+                          const mansy_env_episode_log* elog, int precision, void* stream);
 /* logits' log-probabilities of the given actions for the first n_logp rows (logp != NULL) and / or the critic's value for all B rows.
  * process_fn calls it once on the 2 x 4096 rows [obs ; obs_next] of one rollout buffer: v_s, v_s_ and logp_old in one pass. */
 int mansy_policy_evaluate(const float* const* params, const float* obs, int B, const int* act, int n_logp, float* logp, float* value,
-                          void* workspace, int max_batch, void* stream);
+                          void* workspace, int max_batch, int precision, void* stream);
 int mansy_identifier_forward(const float* const* params, const float* obs, int B, float* pred /* [B,16], 3 used */, void* workspace,
-                             int max_batch, void* stream);
+                             int max_batch, int precision, void* stream);
 int mansy_identifier_train_step(const float* const* params, float* const* grads, float* flat_p, float* flat_g, float* flat_m,
                                 float* flat_v, long long n_flat, const float* obs, const int* idx /* NULL: rows 0..B of obs; else obs[idx[r]] */,
-                                int B, float lr, float weight_decay, int step, float* loss_out, void* workspace, int max_batch, void* stream);
+                                int B, float lr, float weight_decay, int step, float* loss_out, void* workspace, int max_batch, int precision, void* stream);
 int mansy_identifier_relabel(const float* const* params, const float* obs, float* rew, float* id_rew, int B, float lamb,
-                             void* workspace, int max_batch, void* stream);
+                             void* workspace, int max_batch, int precision, void* stream);
 int mansy_gae_returns(const float* rew, const float* v_s, const float* v_next, const unsigned char* done, int T, int N, double gamma,
                       double gae_lambda, int rew_norm, double* rms, double* scratch, float* returns, float* adv, void* stream);
 int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, float* flat_p, float* flat_g, float* flat_m,
@@ -224,7 +240,7 @@ int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, fl
                              const float* adv_all, const float* logp_old_all, const float* v_old_all, const float* ret_all, int mb,
                              float eps_clip, float vf_coef, float ent_coef, int norm_adv, int value_clip, float dual_clip,
                              float max_grad_norm, float lr, float weight_decay, int step, long long tail_from, int tail_step, float* stats,
-                             void* workspace, int max_batch, int chain_in, const int* next_idx, int next_mb, void* stream);
+                             void* workspace, int max_batch, int chain_in, const int* next_idx, int next_mb, int precision, void* stream);
 /* dual_clip: tianshou PPOPolicy's dual_clip (> 1; for negative advantages the clipped surrogate is bounded below by dual_clip * adv,
  * run_mansy.py --dual-clip) or 0 = off (the reference's default None). */
 /* Chaining (the clipped single-process step only: max_grad_norm > 0, step > 0, no lagged tail): the step's last launch -- clip + Adam --
@@ -239,7 +255,7 @@ int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, fl
  * stats: [loss, cross entropy, mean entropy]. */
 int mansy_bc_step(const float* const* params, float* const* grads, float* flat_p, float* flat_g, float* flat_m, float* flat_v,
                   long long n_flat, long long n_update, const float* obs, const int* act, int B, float ent_coef, float lr,
-                  float weight_decay, int step, float* stats, void* workspace, int max_batch, void* stream);
+                  float weight_decay, int step, float* stats, void* workspace, int max_batch, int precision, void* stream);
 
 /* clip_grad_norm_ (max_norm <= 0: off) + Adam with L2 weight decay over flat buffers (data-parallel second half).
  * scratch: MANSY_CLIP_SCRATCH_DOUBLES doubles of device memory (gradient-norm partial sums; need not be zeroed).
@@ -257,7 +273,7 @@ int mansy_clip_grad_adam(float* flat_p, float* flat_g, float* flat_m, float* fla
  * minibatch (next_mb > 0) -- the next mansy_ppo_minibatch_step(step = 0) then passes chain_in = 1.  Actor-critic buffers only. */
 int mansy_ppo_dp_tail(const float* const* params, float* flat_p, float* flat_g, float* flat_m, float* flat_v, long long n_flat,
                       float max_grad_norm, float lr, float weight_decay, int step, double* scratch, int have_sumsq, const float* obs_all,
-                      const float* adv_all, const int* next_idx, int next_mb, void* workspace, int max_batch, void* stream);
+                      const float* adv_all, const int* next_idx, int next_mb, void* workspace, int max_batch, int precision, void* stream);
 
 /* ------------------------------------------------------------------ one-shot gradient all-reduce over peer-mapped memory (xGMI)
  * The data-parallel PPO update averages a 1.7 MB / 1.05 MB flat gradient 16 + 2 times per 2.6 ms cycle, every time on
@@ -303,13 +319,13 @@ int mansy_a2c_obs(const float* obs, const float* qoe_parts, const int* actions, 
 /* probs [B,16] (15 used: the reference's Actor returns softmax outputs as "logits"), value [B] (nullable), optional
  * Categorical(probs) sampling: act int32 [B], logp [B]; u [B] external uniforms or NULL => counter hash (seed, site, row) */
 int mansy_a2c_forward(const float* const* params, const float* obs, int B, float* probs, float* value, int* act, float* logp, const float* u,
-                      uint32_t seed, uint32_t site, int reuse_packed, void* workspace, int max_batch, void* stream);
+                      uint32_t seed, uint32_t site, int reuse_packed, void* workspace, int max_batch, int precision, void* stream);
 /* loss = -(log_prob * adv).mean() + vf_coef * mse(ret, value) - ent_coef * entropy.mean(); clip_grad_norm_; RMSprop(lr, alpha,
  * eps) over flat buffers.  apply == 0: gradients only.  stats: [loss, actor loss, value loss, entropy]. */
 int mansy_a2c_minibatch_step(const float* const* params, float* const* grads, float* flat_p, float* flat_g, float* flat_sq, long long n_flat,
                              const float* obs_all, const int* idx, const int* act_all, const float* adv_all, const float* ret_all, int mb,
                              float vf_coef, float ent_coef, float max_grad_norm, float lr, float alpha, float eps, int apply, float* stats,
-                             void* workspace, int max_batch, void* stream);
+                             void* workspace, int max_batch, int precision, void* stream);
 /* data-parallel second half: clip_grad_norm_ + RMSprop over (all-reduced) flat gradients; scratch as mansy_clip_grad_adam */
 int mansy_clip_grad_rmsprop(float* flat_p, float* flat_g, float* flat_sq, long long n_flat, float max_grad_norm, float lr, float alpha,
                             float eps, double* scratch, void* stream);
@@ -324,14 +340,8 @@ typedef struct mansy_gemm_epilogue {
 } mansy_gemm_epilogue;
 int mansy_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb, int b_kmajor, float* C, int ldc,
                    int M, int N, int K, const mansy_gemm_epilogue* ep, int force_tile, int force_splitk, void* stream);
-/* Precision mode of every dense product (torch.nn.Linear / Conv1d arithmetic behind mtio.py, customized_transformer.py and
- * bitrate_selection/models/mansy.py) launched from now on, process-wide: 0 = exact fp32 on v_mfma_f32_32x32x2_f32 (default,
- * the parity mode); 3 = bf16x3, 6 = bf16x6: operands split into bf16 terms on their way into LDS, 3 / 6 bf16 MFMA products
- * accumulated in fp32 (BASELINE.json configs[4] "bf16 MFMA").  Products with K % 32 != 0 or unaligned operands stay fp32.
- * A launch-time property: a captured hipGraph keeps the mode it was captured in.  set returns the previous mode (< 0: error). */
-#define MANSY_PREC_F32 0
-#define MANSY_PREC_BF16X3 3
-#define MANSY_PREC_BF16X6 6
+/* DEPRECATED (kept for one round as shims): the process-wide precision mode, read only by calls that pass MANSY_PREC_DEFAULT
+ * (mansy_vp_config::precision / the `precision` argument / mansy_gemm_epilogue::prec < 0).  set returns the previous mode (< 0: error). */
 int mansy_set_gemm_precision(int mode);
 int mansy_get_gemm_precision(void);
 /* Split-bf16 modes, weights split ahead of the products (what the viewport engine does once per step for every Linear / Conv1d weight):
@@ -389,6 +399,9 @@ int mansy_prof_gemm_enable(int on);
  * queries.  Returns the previous value.  Results of the two loops are bit-identical (same products, same order). */
 int mansy_gemm_bf16_variant(int v);
 int mansy_prof_gemm_collect(double* total_ms, long long* launches, double* flops);
+/* Kernel launches this library has enqueued since the process started (every launch site counts; a launch enqueued during a hipGraph
+ * capture counts once, at capture time -- a replay of the graph adds nothing).  bench.py reads the difference around a cycle. */
+unsigned long long mansy_prof_launch_count(void);
 
 #ifdef __cplusplus
 }

@@ -13,12 +13,18 @@ class MansyError(RuntimeError):
     pass
 
 
+BN_SYNC_FN = ctypes.CFUNCTYPE(c_int, c_int, c_void_p)
+
+
 class VPConfig(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ('B', 'S', 'T', 'd_model', 'n_head', 'd_ff', 'n_enc', 'n_dec', 'in_ch', 'has_bias')] + \
-               [(n, c_float) for n in ('p_pe', 'p_drop', 'ln_eps', 'bn_eps', 'bn_momentum')] + [('max_len', c_int), ('bn_sync_world', c_int), ('two_stream', c_int)]
+               [(n, c_float) for n in ('p_pe', 'p_drop', 'ln_eps', 'bn_eps', 'bn_momentum')] + \
+               [('max_len', c_int), ('bn_sync_world', c_int), ('two_stream', c_int), ('precision', c_int),
+                ('bn_sync_fn', BN_SYNC_FN), ('bn_sync_user', c_void_p)]
 
-
-BN_SYNC_FN = ctypes.CFUNCTYPE(c_int, c_int, c_void_p)
+    def __init__(self, *a, **kw):
+        kw.setdefault('precision', -1)          # MANSY_PREC_DEFAULT
+        super().__init__(*a, **kw)
 
 
 class GemmEpilogue(ctypes.Structure):
@@ -104,18 +110,18 @@ _PROTOS = {
     'mansy_net_num_params': [c_int],
     'mansy_net_param_info': [c_int, c_int, ctypes.c_char_p, c_int, P, P, P],
     'mansy_ppo_workspace_bytes': [c_int],
-    'mansy_policy_forward': [P, P, c_int, P, P, P, P, P, c_u32, c_u32, c_int, P, c_int, P],
-    'mansy_policy_env_step': [P, P, c_int, P, P, P, P, c_u32, c_u32, c_int, P, c_int, P, P, P, P, P, P, P, P, P],
-    'mansy_policy_evaluate': [P, P, c_int, P, c_int, P, P, P, c_int, P],
-    'mansy_identifier_forward': [P, P, c_int, P, P, c_int, P],
-    'mansy_identifier_train_step': [P, P, P, P, P, P, c_ll, P, P, c_int, c_float, c_float, c_int, P, P, c_int, P],
-    'mansy_identifier_relabel': [P, P, P, P, c_int, c_float, P, c_int, P],
+    'mansy_policy_forward': [P, P, c_int, P, P, P, P, P, c_u32, c_u32, c_int, P, c_int, c_int, P],
+    'mansy_policy_env_step': [P, P, c_int, P, P, P, P, c_u32, c_u32, c_int, P, c_int, P, P, P, P, P, P, P, P, c_int, P],
+    'mansy_policy_evaluate': [P, P, c_int, P, c_int, P, P, P, c_int, c_int, P],
+    'mansy_identifier_forward': [P, P, c_int, P, P, c_int, c_int, P],
+    'mansy_identifier_train_step': [P, P, P, P, P, P, c_ll, P, P, c_int, c_float, c_float, c_int, P, P, c_int, c_int, P],
+    'mansy_identifier_relabel': [P, P, P, P, c_int, c_float, P, c_int, c_int, P],
     'mansy_gae_returns': [P, P, P, P, c_int, c_int, ctypes.c_double, ctypes.c_double, c_int, P, P, P, P, P],
     'mansy_ppo_minibatch_step': [P, P, P, P, P, P, c_ll, P, P, P, P, P, P, P, c_int, c_float, c_float, c_float, c_int, c_int, c_float, c_float,
-                                 c_float, c_float, c_int, c_ll, c_int, P, P, c_int, c_int, P, c_int, P],
-    'mansy_bc_step': [P, P, P, P, P, P, c_ll, c_ll, P, P, c_int, c_float, c_float, c_float, c_int, P, P, c_int, P],
+                                 c_float, c_float, c_int, c_ll, c_int, P, P, c_int, c_int, P, c_int, c_int, P],
+    'mansy_bc_step': [P, P, P, P, P, P, c_ll, c_ll, P, P, c_int, c_float, c_float, c_float, c_int, P, P, c_int, c_int, P],
     'mansy_clip_grad_adam': [P, P, P, P, c_ll, c_float, c_float, c_float, c_int, c_ll, c_int, P, c_int, P],
-    'mansy_ppo_dp_tail': [P, P, P, P, P, c_ll, c_float, c_float, c_float, c_int, P, c_int, P, P, P, c_int, P, c_int, P],
+    'mansy_ppo_dp_tail': [P, P, P, P, P, c_ll, c_float, c_float, c_float, c_int, P, c_int, P, P, P, c_int, P, c_int, c_int, P],
     'mansy_xg_create': [c_ll, c_int, c_int, P],
     'mansy_xg_export': [P, P],
     'mansy_xg_import': [P, P],
@@ -127,21 +133,22 @@ _PROTOS = {
     'mansy_a2c_param_info': [c_int, ctypes.c_char_p, c_int, P, P, P],
     'mansy_a2c_workspace_bytes': [c_int],
     'mansy_a2c_obs': [P, P, P, P, c_int, P, P, P],
-    'mansy_a2c_forward': [P, P, c_int, P, P, P, P, P, c_u32, c_u32, c_int, P, c_int, P],
+    'mansy_a2c_forward': [P, P, c_int, P, P, P, P, P, c_u32, c_u32, c_int, P, c_int, c_int, P],
     'mansy_a2c_minibatch_step': [P, P, P, P, P, c_ll, P, P, P, P, P, c_int, c_float, c_float, c_float, c_float, c_float, c_float, c_int, P,
-                                 P, c_int, P],
+                                 P, c_int, c_int, P],
     'mansy_clip_grad_rmsprop': [P, P, P, c_ll, c_float, c_float, c_float, c_float, P, P],
     'mansy_set_bn_sync_hook': [P, P],
     'mansy_prof_gemm_enable': [c_int],
     'mansy_gemm_bf16_variant': [c_int],
     'mansy_prof_gemm_collect': [P, P, P],
+    'mansy_prof_launch_count': [],
 }
-_RESTYPES = {'mansy_last_error': ctypes.c_char_p, 'mansy_vp_workspace_bytes': ctypes.c_size_t,
+_RESTYPES = {'mansy_last_error': ctypes.c_char_p, 'mansy_prof_launch_count': ctypes.c_ulonglong, 'mansy_vp_workspace_bytes': ctypes.c_size_t,
              'mansy_ppo_workspace_bytes': ctypes.c_size_t, 'mansy_a2c_workspace_bytes': ctypes.c_size_t}
 
 # bumped together with mansy_abi_version() (csrc/capi.hip) whenever a prototype or struct above changes: a stale in-tree
 # libmansy_hip.so then fails at load time instead of being called with a wrong argument list
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _lib = None
 

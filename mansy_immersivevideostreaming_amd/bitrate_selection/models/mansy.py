@@ -10,6 +10,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from ... import _lib
 from ..._lib import MansyError, check, lib, ptr, stream_ptr
 from ..envs.mansy_env import OBS_LD, OBS_SLICES
 
@@ -253,10 +254,17 @@ class NetEngine:
         self.max_batch = max_batch
         self.ac = self.idn = None
         self._ws = None
+        # precision of this engine's dense products: None = MANSY_PREC_DEFAULT (the deprecated process-wide mode, fp32 unless set), or
+        # 'f32' / 'bf16x3' / 'bf16x6' -- passed with every call (the `precision` argument of the PPO entry points, ABI 7)
+        self.precision = None
         for m in (actor, critic, identifier):
             if m is not None:
                 m._engine = self
         self._bind()
+
+    @property
+    def prec(self):
+        return -1 if self.precision is None else _lib.PRECISIONS[self.precision]
 
     @property
     def device(self):
@@ -316,7 +324,7 @@ class NetEngine:
         if sample and logp is None:
             logp = torch.empty(B, dtype=torch.float32, device=dev)
         check(lib().mansy_policy_forward(arr, ptr(obs), B, ptr(logits), ptr(value), ptr(act), ptr(logp), ptr(u), seed, site, int(reuse_packed),
-                                         ptr(self.workspace()), self.max_batch, stream_ptr(dev)), 'mansy_policy_forward')
+                                         ptr(self.workspace()), self.max_batch, self.prec, stream_ptr(dev)), 'mansy_policy_forward')
         if sample:
             return logits[:, :15], value, act, logp
         return logits[:, :15], value
@@ -332,7 +340,7 @@ class NetEngine:
         arr, _ = self.ac.pointers()
         check(lib().mansy_policy_env_step(arr, ptr(obs), N, None, ptr(act), ptr(logp), ptr(u), seed, site, int(reuse_packed), ptr(self.workspace()),
                                           self.max_batch, ctypes.byref(venv.tables.c), ptr(venv.state), ptr(obs_next_out), ptr(obs_out), ptr(reward_out),
-                                          ptr(done_out), ptr(venv.qoe_parts), ctypes.byref(venv._elog), stream_ptr(dev)), 'mansy_policy_env_step')
+                                          ptr(done_out), ptr(venv.qoe_parts), ctypes.byref(venv._elog), self.prec, stream_ptr(dev)), 'mansy_policy_env_step')
 
     def identifier_forward(self, obs):
         B, dev = obs.shape[0], obs.device
@@ -341,7 +349,7 @@ class NetEngine:
         for s in range(0, B, self.max_batch):
             o = obs[s:s + self.max_batch]
             pred = torch.empty(o.shape[0], MAXOUT, dtype=torch.float32, device=dev)
-            check(lib().mansy_identifier_forward(arr, ptr(o), o.shape[0], ptr(pred), ptr(self.workspace()), self.max_batch, stream_ptr(dev)),
+            check(lib().mansy_identifier_forward(arr, ptr(o), o.shape[0], ptr(pred), ptr(self.workspace()), self.max_batch, self.prec, stream_ptr(dev)),
                   'mansy_identifier_forward')
             outs.append(pred[:, :3])
         return outs[0] if len(outs) == 1 else torch.cat(outs)

@@ -63,6 +63,7 @@ class VecCollector:
         self.use_graph = use_graph
         self._graph = None
         self._graph_key = None
+        self.graph_launches = 0
         self._u = None
 
     @property
@@ -109,8 +110,10 @@ class VecCollector:
                     self.venv.elog_count.zero_()
                 torch.cuda.current_stream(dev).wait_stream(s)
                 g = torch.cuda.CUDAGraph()
+                n0 = lib().mansy_prof_launch_count()
                 with torch.cuda.graph(g):
                     self._body(buffer, T)
+                self.graph_launches = int(lib().mansy_prof_launch_count() - n0)      # library kernels one replay re-runs (bench.py)
                 self._graph, self._graph_key = g, key
                 self.venv.state.copy_(state)
                 self.carry.copy_(carry)
@@ -226,6 +229,8 @@ class PPOPolicy(nn.Module):
         against `grad_sync` on the same data, time both, and use it only if every rank finds it correct and faster
         (dist.probe_peer_grad_sync; the decision and the two timings are kept in `self.grad_sync_report`)."""
         self.world, self.grad_sync = int(world), grad_sync
+        for old in (getattr(self, '_peer', None) or {}).values():      # a second call: release the previous hipIpc mappings / slots
+            old.close()
         self._peer = {}
         self.grad_sync_report = {'chosen': 'library' if self.world > 1 else 'none'}
         if peer and self.world > 1:
@@ -242,6 +247,14 @@ class PPOPolicy(nn.Module):
                 for f in flats:
                     self._peer[id(f)] = PeerGradSync(f.flat_p.numel(), self.world, tdist.get_rank(), f.flat_p.device)
                 self.grad_sync_report = {'chosen': 'peer', 'reason': 'forced'}
+
+    def _check_peers(self):
+        """A peer-memory all-reduce whose bounded wait gave up has overwritten the gradient with NaN and raised its context's sticky
+        flag (csrc/xgmi.hip); the clip + Adam launch behind it has already run.  Called at the end of every learn() /
+        train_identifier() that used a peer context: raises MansyError on the rank that timed out, so the job exits non-zero instead of
+        training on with replicas that no longer agree.  (mansy_xg_status synchronises the device: once per update, peer mode only.)"""
+        for p in (getattr(self, '_peer', None) or {}).values():
+            p.check()
 
     def _upload_i32(self, key, arr, dev):
         """Host int array -> device int32 tensor through a persistent PINNED staging buffer and a non-blocking copy: the copy engine
@@ -275,7 +288,7 @@ class PPOPolicy(nn.Module):
             arr, _ = f.pointers()
             check(lib().mansy_ppo_dp_tail(arr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), float(max_norm), lr, wd, f.step,
                                           ptr(scratch), int(peer is not None), ptr(data['obs']), ptr(data['adv']), ptr(nxt),
-                                          nxt.numel() if nxt is not None else 0, ptr(self.engine.workspace()), self.engine.max_batch,
+                                          nxt.numel() if nxt is not None else 0, ptr(self.engine.workspace()), self.engine.max_batch, self.engine.prec,
                                           stream_ptr(f.flat_p.device)), 'mansy_ppo_dp_tail')
             return
         check(lib().mansy_clip_grad_adam(ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), float(max_norm), lr, wd, f.step,
@@ -334,6 +347,8 @@ class PPOPolicy(nn.Module):
             f.step += 1
             losses.append(self._identifier_step(obs, lr, wd, f.step, rows=tr))
         vloss = self._identifier_step(obs, lr, wd, 0, rows=va) if len(va) else None
+        if self.grad_sync is not None and update_round > 0:
+            self._check_peers()
         if verbose:
             for l in losses:
                 print('identifier loss is: ', l.item())
@@ -351,7 +366,7 @@ class PPOPolicy(nn.Module):
         loss = torch.empty((), dtype=torch.float32, device=obs.device)
         dp = self.grad_sync is not None and step > 0
         check(lib().mansy_identifier_train_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(obs), ptr(rows), B, lr, wd,
-                                                -1 if dp else step, ptr(loss), ptr(eng.workspace()), eng.max_batch, stream_ptr(obs.device)),
+                                                -1 if dp else step, ptr(loss), ptr(eng.workspace()), eng.max_batch, eng.prec, stream_ptr(obs.device)),
               'mansy_identifier_train_step')
         if dp:
             self._sync_clip_adam(f, 0.0, lr, wd)
@@ -366,7 +381,7 @@ class PPOPolicy(nn.Module):
         arr, _ = eng.idn.pointers()
         for s in range(0, n, eng.max_batch):
             e = min(n, s + eng.max_batch)
-            check(lib().mansy_identifier_relabel(arr, ptr(obs[s:e]), ptr(rew[s:e]), None, e - s, float(lamb), ptr(eng.workspace()), eng.max_batch,
+            check(lib().mansy_identifier_relabel(arr, ptr(obs[s:e]), ptr(rew[s:e]), None, e - s, float(lamb), ptr(eng.workspace()), eng.max_batch, eng.prec,
                                                  stream_ptr(obs.device)), 'mansy_identifier_relabel')
         self.cnt += n
 
@@ -387,16 +402,16 @@ class PPOPolicy(nn.Module):
         if joint is not None and T == buffer.T and 2 * n <= eng.max_batch and obs.data_ptr() == joint.data_ptr():
             # [obs ; obs_next] are 2 n contiguous rows: values of both halves and logp_old of the first in ONE pass (5 launches for 9)
             v_all = torch.empty(2 * n, dtype=torch.float32, device=dev)
-            check(lib().mansy_policy_evaluate(arr, ptr(joint), 2 * n, ptr(act), n, ptr(logp_old), ptr(v_all), ptr(eng.workspace()), eng.max_batch,
+            check(lib().mansy_policy_evaluate(arr, ptr(joint), 2 * n, ptr(act), n, ptr(logp_old), ptr(v_all), ptr(eng.workspace()), eng.max_batch, eng.prec,
                                               stream_ptr(dev)), 'mansy_policy_evaluate')
             v_s, v_next = v_all[:n], v_all[n:]
         else:
             for s in range(0, n, eng.max_batch):
                 e = min(n, s + eng.max_batch)
                 check(lib().mansy_policy_evaluate(arr, ptr(obs[s:e]), e - s, ptr(act[s:e]), e - s, ptr(logp_old[s:e]), ptr(v_s[s:e]),
-                                                  ptr(eng.workspace()), eng.max_batch, stream_ptr(dev)), 'mansy_policy_evaluate')
+                                                  ptr(eng.workspace()), eng.max_batch, eng.prec, stream_ptr(dev)), 'mansy_policy_evaluate')
                 check(lib().mansy_policy_evaluate(arr, ptr(obs_next[s:e]), e - s, None, 0, None, ptr(v_next[s:e]), ptr(eng.workspace()),
-                                                  eng.max_batch, stream_ptr(dev)), 'mansy_policy_evaluate')
+                                                  eng.max_batch, eng.prec, stream_ptr(dev)), 'mansy_policy_evaluate')
         returns = torch.empty(n, dtype=torch.float32, device=dev)
         adv = torch.empty(n, dtype=torch.float32, device=dev)
         data = dict(obs=obs, obs_next=obs_next, act=act, v_s=v_s, v_next=v_next, logp_old=logp_old, returns=returns, adv=adv, n=n, buffer=buffer)
@@ -432,7 +447,7 @@ class PPOPolicy(nn.Module):
         for src, dst in ((data['obs'], data['v_s']), (data['obs_next'], data['v_next'])):
             for s in range(0, n, eng.max_batch):
                 e = min(n, s + eng.max_batch)
-                check(lib().mansy_policy_evaluate(arr, ptr(src[s:e]), e - s, None, 0, None, ptr(dst[s:e]), ptr(eng.workspace()), eng.max_batch,
+                check(lib().mansy_policy_evaluate(arr, ptr(src[s:e]), e - s, None, 0, None, ptr(dst[s:e]), ptr(eng.workspace()), eng.max_batch, eng.prec,
                                                   stream_ptr(dev)), 'mansy_policy_evaluate')
         self._returns_from_values(data)
 
@@ -468,11 +483,13 @@ class PPOPolicy(nn.Module):
                                                  ptr(data['returns']), idx.numel(), self._eps_clip, self._weight_vf, self._weight_ent,
                                                  int(self._norm_adv), int(self._value_clip), float(self._dual_clip or 0.0), 0.0 if dp else float(self._grad_norm or 0.0), lr, wd,
                                                  0 if dp else f.step, *f.tail(), ptr(stats_all[pi][k]), ptr(eng.workspace()), eng.max_batch,
-                                                 int(chain and s > 0 and not first_of_later_pass), ptr(None if dp else nxt), nxt.numel() if (nxt is not None and not dp) else 0,
+                                                 int(chain and s > 0 and not first_of_later_pass), ptr(None if dp else nxt), nxt.numel() if (nxt is not None and not dp) else 0, eng.prec,
                                                  stream_ptr(dev)),
                   'mansy_ppo_minibatch_step')
             if dp:                              # raw local gradients -> average over the ranks -> global-norm clip + Adam (+ next prologue)
                 self._sync_clip_adam(f, float(self._grad_norm or 0.0), lr, wd, tail=(data, nxt) if chain else None)
+        if dp:
+            self._check_peers()
         return LazyLosses(('loss', 'loss/clip', 'loss/vf', 'loss/ent'), stats_all)
 
     def bc_step(self, obs, act, ent_coef=0.1, train=True):
@@ -491,7 +508,7 @@ class PPOPolicy(nn.Module):
         dp = train and self.grad_sync is not None
         check(lib().mansy_bc_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), n_update, ptr(obs), ptr(act),
                                   obs.shape[0], float(ent_coef), lr, wd, (f.step if train else 0), ptr(stats), ptr(eng.workspace()),
-                                  eng.max_batch, stream_ptr(obs.device)), 'mansy_bc_step')
+                                  eng.max_batch, eng.prec, stream_ptr(obs.device)), 'mansy_bc_step')
         if dp:
             raise MansyError('behaviour cloning runs on one rank (the reference does it before training starts)')
         return stats

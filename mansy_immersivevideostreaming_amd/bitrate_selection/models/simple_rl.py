@@ -15,6 +15,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from ... import _lib
 from ..._lib import MansyError, check, lib, ptr, stream_ptr
 from .mansy import MAXOUT, _Flat, _Seq0, _conv_as_linear_init
 from .mansy_ppo import LazyLosses, _ActorCritic, _Result, split_indices
@@ -115,6 +116,11 @@ class SimpleEngine:
         self.f = _Flat(2)
         self.f.attach(actor.feature_net.ordered_parameters() + actor.head_parameters() + critic.head_parameters())
         self._ws = None
+        self.precision = None       # None = MANSY_PREC_DEFAULT, or 'f32' / 'bf16x3' / 'bf16x6': the `precision` argument of every call
+
+    @property
+    def prec(self):
+        return -1 if self.precision is None else _lib.PRECISIONS[self.precision]
 
     @property
     def device(self):
@@ -145,7 +151,7 @@ class SimpleEngine:
             act = out.get('act') if out.get('act') is not None else torch.empty(B, dtype=torch.int32, device=dev)
             logp = out.get('logp') if out.get('logp') is not None else torch.empty(B, dtype=torch.float32, device=dev)
         check(lib().mansy_a2c_forward(arr, ptr(obs), B, ptr(probs), ptr(value), ptr(act), ptr(logp), ptr(u), seed, site, int(reuse_packed),
-                                      ptr(self.workspace()), self.max_batch, stream_ptr(dev)), 'mansy_a2c_forward')
+                                      ptr(self.workspace()), self.max_batch, self.prec, stream_ptr(dev)), 'mansy_a2c_forward')
         return (probs[:, :15], value, act, logp) if sample else (probs[:, :15], value)
 
 
@@ -325,7 +331,7 @@ class A2CPolicy(nn.Module):
                 check(lib().mansy_a2c_minibatch_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(sq), f.flat_p.numel(), ptr(data['obs']), ptr(idx),
                                                      ptr(data['act']), ptr(data['adv']), ptr(data['returns']), idx.numel(), self._weight_vf,
                                                      self._weight_ent, 0.0 if dp else float(self._grad_norm or 0.0), lr, alpha, eps, 0 if dp else 1,
-                                                     ptr(stats), ptr(eng.workspace()), eng.max_batch, stream_ptr(dev)), 'mansy_a2c_minibatch_step')
+                                                     ptr(stats), ptr(eng.workspace()), eng.max_batch, eng.prec, stream_ptr(dev)), 'mansy_a2c_minibatch_step')
                 if dp:
                     self.grad_sync(f.flat_g)
                     scratch = torch.empty(64, dtype=torch.float64, device=dev)

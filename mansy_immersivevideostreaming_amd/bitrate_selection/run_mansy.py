@@ -123,7 +123,8 @@ def test(args, config, policy, qoe_weights, identifier, models_dir, results_dir)
 
 
 def run(args, config):
-    _lib.set_precision(getattr(args, 'precision', 'f32'))
+    if getattr(args, 'precision', 'f32') not in _lib.PRECISIONS:
+        raise _lib.MansyError(f'unknown --precision {args.precision!r}: one of f32, bf16x3, bf16x6')
     np.random.seed(args.seed)
     torch.manual_seed(args.seed)
     torch.cuda.manual_seed_all(args.seed)
@@ -160,6 +161,7 @@ def run(args, config):
                        reward_normalization=args.rew_norm, advantage_normalization=args.norm_adv, recompute_advantage=args.recompute_adv,
                        dual_clip=args.dual_clip, value_clip=args.value_clip, gae_lambda=args.gae_lambda, action_space=config.action_space,
                        action_scaling=False, args=args, identifier=identifier, identifier_optim=identifier_optimizer).to(args.device)
+    policy.engine.precision = getattr(args, 'precision', 'f32')      # carried into every engine call (no process-wide mode)
     if args.train:
         bc_file_prefix = f'bc_ms_{args.bc_max_steps}_ims_{args.bc_identifier_max_steps}_ilr_{args.identifier_lr}_iur_{args.identifier_update_round}'
         policy_bc_path = os.path.join(models_dir, bc_file_prefix + '_policy.pth')

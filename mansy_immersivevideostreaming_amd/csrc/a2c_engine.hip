@@ -345,6 +345,7 @@ size_t layout(int maxB, char* base, Work& W) {
 
 struct Eng {
   hipStream_t st; Work W;
+  int prec = 0;      // MANSY_PREC_* of this call's products (the entry point's `precision` argument)
   int pack(const Net& n, const float* g_src, const int* g_idx, int g_rows, float* zero_ptr, long long zero_n) {
     PackArgs a;
     for (int j = 0; j < NB; ++j) { a.bw[j] = n.bw[j]; a.bb[j] = n.bb[j]; }
@@ -352,52 +353,54 @@ struct Eng {
     a.g_src = g_src; a.g_idx = g_idx; a.g_dst = W.obs_mb; a.g_rows = g_src ? g_rows : 0; a.zero_ptr = zero_ptr; a.zero_n = zero_ptr ? zero_n : 0;
     MANSY_REQUIRE(!zero_ptr || (reinterpret_cast<uintptr_t>(zero_ptr) & 15) == 0, "a2c pack: gradient buffer must be 16-byte aligned");
     const long long threads = (long long)FEAT * LD + 2LL * HID * FEAT + (long long)a.g_rows * (LD / 4) + (a.zero_n + 3) / 4;
-    hipLaunchKernelGGL(a2c_pack_kernel, dim3(mansy_ceil_div(threads, 256)), dim3(256), 0, st, a, W.Wbd, W.bbd, W.krange, W.Wfc2, W.bfc2);
+    MANSY_LAUNCH(a2c_pack_kernel, dim3(mansy_ceil_div(threads, 256)), dim3(256), 0, st, a, W.Wbd, W.bbd, W.krange, W.Wfc2, W.bfc2);
     MANSY_LAUNCH_CHECK();
     return MANSY_OK;
   }
   int forward(const Net& n, const float* obs, int B, float* probs, float* value, const float* u, uint32_t seed, uint32_t site, int* act, float* logp) {
-    GemmEpilogue e1; e1.bias = W.bbd; e1.relu = 1; e1.relu_slope = SLOPE; e1.tile_krange = W.krange;
+    GemmEpilogue e1; e1.prec = prec; e1.bias = W.bbd; e1.relu = 1; e1.relu_slope = SLOPE; e1.tile_krange = W.krange;
     RC(mansy_launch_gemm_f32(obs, LD, 0, W.Wbd, LD, 0, W.F, FEAT, B, FEAT, LD, e1, 0, 0, st));
-    GemmEpilogue e2; e2.bias = W.bfc2; e2.relu = 1; e2.relu_slope = SLOPE;
+    GemmEpilogue e2; e2.prec = prec; e2.bias = W.bfc2; e2.relu = 1; e2.relu_slope = SLOPE;
     RC(mansy_launch_gemm_f32(W.F, FEAT, 0, W.Wfc2, FEAT, 0, W.H2, 2 * HID, B, 2 * HID, FEAT, e2, 0, 0, st));
-    hipLaunchKernelGGL(a2c_out_kernel, dim3(mansy_ceil_div(B, 4)), dim3(256), 0, st, W.H2, n.out_w[0], n.out_b[0], n.out_w[1], n.out_b[1], B, probs, value,
+    MANSY_LAUNCH(a2c_out_kernel, dim3(mansy_ceil_div(B, 4)), dim3(256), 0, st, W.H2, n.out_w[0], n.out_b[0], n.out_w[1], n.out_b[1], B, probs, value,
                        u, seed, site, act, logp);
     MANSY_LAUNCH_CHECK();
     return MANSY_OK;
   }
   // g [B,16] = dL/d(logits | value) -> all parameter gradients (accumulated into zeroed buffers)
   int backward(const Net& n, const float* obs, int B) {
-    hipLaunchKernelGGL(a2c_out_bwd_kernel, dim3(mansy_ceil_div((long long)B * 2 * HID, 256)), dim3(256), 0, st, W.g, W.H2, n.out_w[0], n.out_w[1], B, W.dH2);
+    MANSY_LAUNCH(a2c_out_bwd_kernel, dim3(mansy_ceil_div((long long)B * 2 * HID, 256)), dim3(256), 0, st, W.g, W.H2, n.out_w[0], n.out_w[1], B, W.dH2);
     MANSY_LAUNCH_CHECK();
     MANSY_HIP_CHECK(hipMemsetAsync(W.gsum, 0, sizeof(float) * MAXOUT, st));
-    GemmEpilogue eo; eo.a_rowsum = W.gsum;                                                                    // Gout = g^T H2, gsum = column sums of g
+    GemmEpilogue eo; eo.prec = prec; eo.a_rowsum = W.gsum;                                                                    // Gout = g^T H2, gsum = column sums of g
     RC(mansy_launch_gemm_f32(W.g, MAXOUT, 1, W.H2, 2 * HID, 1, W.Gout, 2 * HID, MAXOUT, 2 * HID, B, eo, 0, 1, st));
-    GemmEpilogue acc; acc.accumulate = 1; acc.a_rowsum = n.gfc_b[0];                                         // fc weight / bias gradients, both heads
+    GemmEpilogue acc; acc.prec = prec; acc.accumulate = 1; acc.a_rowsum = n.gfc_b[0];                                         // fc weight / bias gradients, both heads
     acc.pair_A = W.dH2 + HID; acc.pair_B = W.F; acc.pair_C = n.gfc_w[1]; acc.pair_rowsum = n.gfc_b[1];
     RC(mansy_launch_gemm_f32(W.dH2, 2 * HID, 1, W.F, FEAT, 1, n.gfc_w[0], FEAT, HID, FEAT, B, acc, 0, 0, st));
-    GemmEpilogue ef; ef.mask_src = W.F; ef.mask_ld = FEAT; ef.mask_scale = 1.f; ef.mask_neg = SLOPE;        // dPre = (dH2 Wfc2) * LeakyReLU'(F)
+    GemmEpilogue ef; ef.prec = prec; ef.mask_src = W.F; ef.mask_ld = FEAT; ef.mask_scale = 1.f; ef.mask_neg = SLOPE;        // dPre = (dH2 Wfc2) * LeakyReLU'(F)
     RC(mansy_launch_gemm_f32(W.dH2, 2 * HID, 0, W.Wfc2, FEAT, 1, W.dF, FEAT, B, FEAT, 2 * HID, ef, 0, 0, st));
     MANSY_HIP_CHECK(hipMemsetAsync(W.dbbd, 0, sizeof(float) * FEAT, st));
-    GemmEpilogue ew; ew.a_rowsum = W.dbbd;                                                                   // dWbd = dPre^T obs
+    GemmEpilogue ew; ew.prec = prec; ew.a_rowsum = W.dbbd;                                                                   // dWbd = dPre^T obs
     RC(mansy_launch_gemm_f32(W.dF, FEAT, 1, obs, LD, 1, W.dWbd, LD, FEAT, LD, B, ew, 0, 1, st));
     UnpackArgs u;
     for (int j = 0; j < NB; ++j) { u.gbw[j] = n.gbw[j]; u.gbb[j] = n.gbb[j]; }
     for (int h = 0; h < 2; ++h) { u.gout_w[h] = n.gout_w[h]; u.gout_b[h] = n.gout_b[h]; }
-    hipLaunchKernelGGL(a2c_unpack_kernel, dim3(mansy_ceil_div((long long)FEAT * LD, 256)), dim3(256), 0, st, W.dWbd, W.dbbd, W.Gout, W.gsum, u);
+    MANSY_LAUNCH(a2c_unpack_kernel, dim3(mansy_ceil_div((long long)FEAT * LD, 256)), dim3(256), 0, st, W.dWbd, W.dbbd, W.Gout, W.gsum, u);
     MANSY_LAUNCH_CHECK();
     return MANSY_OK;
   }
   int clip_rmsprop(float* p, float* g, float* sq, long long n, float max_norm, float lr, float alpha, float eps, int apply) {
-    if (max_norm > 0.f) hipLaunchKernelGGL(a2c_sumsq_kernel, dim3(NORM_PARTS), dim3(256), 0, st, g, n, W.acc);
+    if (max_norm > 0.f) MANSY_LAUNCH(a2c_sumsq_kernel, dim3(NORM_PARTS), dim3(256), 0, st, g, n, W.acc);
     if (!apply && max_norm <= 0.f) return MANSY_OK;
-    hipLaunchKernelGGL(a2c_clip_rmsprop_kernel, dim3(mansy_ceil_div(n, 256)), dim3(256), 0, st, p, g, sq, n, lr, alpha, eps, W.acc, max_norm, apply);
+    MANSY_LAUNCH(a2c_clip_rmsprop_kernel, dim3(mansy_ceil_div(n, 256)), dim3(256), 0, st, p, g, sq, n, lr, alpha, eps, W.acc, max_norm, apply);
     MANSY_LAUNCH_CHECK();
     return MANSY_OK;
   }
 };
 
-int setup(void* ws, int maxB, hipStream_t st, Eng& e) {
+int setup(void* ws, int maxB, int precision, hipStream_t st, Eng& e) {
+  MANSY_REQUIRE(precision < 0 || precision == 0 || precision == 3 || precision == 6, "precision must be MANSY_PREC_DEFAULT (-1), 0, 3 or 6 (got %d)", precision);
+  e.prec = precision >= 0 ? precision : mansy_get_gemm_precision();
   MANSY_REQUIRE(ws && maxB >= 1, "a2c: bad workspace / batch");
   e.st = st;
   layout(maxB, (char*)ws, e.W);
@@ -423,16 +426,16 @@ size_t mansy_a2c_workspace_bytes(int max_batch) { Work W; return max_batch >= 1 
 int mansy_a2c_obs(const float* obs, const float* qoe_parts, const int* actions, const unsigned char* fresh, int n, const int video_rates[5],
                   float* out, void* stream) {
   MANSY_REQUIRE(obs && out && video_rates && n >= 1 && (!actions || qoe_parts), "a2c_obs: bad arguments");
-  hipLaunchKernelGGL(a2c_obs_kernel, dim3(mansy_ceil_div((long long)n * LD, 256)), dim3(256), 0, (hipStream_t)stream, obs, qoe_parts, actions, fresh, n,
+  MANSY_LAUNCH(a2c_obs_kernel, dim3(mansy_ceil_div((long long)n * LD, 256)), dim3(256), 0, (hipStream_t)stream, obs, qoe_parts, actions, fresh, n,
                      video_rates[0], video_rates[1], video_rates[2], video_rates[3], video_rates[4], out);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }
 
 int mansy_a2c_forward(const float* const* params, const float* obs, int B, float* probs, float* value, int* act, float* logp, const float* u,
-                      uint32_t seed, uint32_t site, int reuse_packed, void* workspace, int max_batch, void* stream) {
+                      uint32_t seed, uint32_t site, int reuse_packed, void* workspace, int max_batch, int precision, void* stream) {
   MANSY_REQUIRE(params && obs && B >= 1 && B <= max_batch, "a2c_forward: bad arguments (B=%d, max_batch=%d)", B, max_batch);
-  Eng e; RC(setup(workspace, max_batch, (hipStream_t)stream, e));
+  Eng e; RC(setup(workspace, max_batch, precision, (hipStream_t)stream, e));
   Net n; bind(params, nullptr, n);
   if (!reuse_packed) RC(e.pack(n, nullptr, nullptr, 0, nullptr, 0));
   return e.forward(n, obs, B, probs ? probs : e.W.probs, value, u, seed, site, act, logp);
@@ -443,10 +446,10 @@ int mansy_a2c_forward(const float* const* params, const float* obs, int B, float
 int mansy_a2c_minibatch_step(const float* const* params, float* const* grads, float* flat_p, float* flat_g, float* flat_sq, long long n_flat,
                              const float* obs_all, const int* idx, const int* act_all, const float* adv_all, const float* ret_all, int mb,
                              float vf_coef, float ent_coef, float max_grad_norm, float lr, float alpha, float eps, int apply, float* stats,
-                             void* workspace, int max_batch, void* stream) {
+                             void* workspace, int max_batch, int precision, void* stream) {
   MANSY_REQUIRE(params && grads && flat_p && flat_g && flat_sq && obs_all && act_all && adv_all && ret_all, "a2c_minibatch_step: null pointer");
   MANSY_REQUIRE(mb >= 1 && mb <= max_batch, "a2c_minibatch_step: bad minibatch size");
-  Eng e; RC(setup(workspace, max_batch, (hipStream_t)stream, e));
+  Eng e; RC(setup(workspace, max_batch, precision, (hipStream_t)stream, e));
   Net n; bind(params, grads, n);
   const float* obs = idx ? e.W.obs_mb : obs_all;
   RC(e.pack(n, idx ? obs_all : nullptr, idx, mb, flat_g, n_flat));
@@ -454,7 +457,7 @@ int mansy_a2c_minibatch_step(const float* const* params, float* const* grads, fl
   LossArgs la;
   la.probs = e.W.probs; la.value = e.W.value; la.act = act_all; la.adv = adv_all; la.ret = ret_all; la.idx = idx; la.n = mb; la.vf_coef = vf_coef;
   la.ent_coef = ent_coef; la.g = e.W.g; la.stats = stats;
-  hipLaunchKernelGGL(a2c_loss_kernel, dim3(1), dim3(1024), 0, e.st, la);
+  MANSY_LAUNCH(a2c_loss_kernel, dim3(1), dim3(1024), 0, e.st, la);
   MANSY_LAUNCH_CHECK();
   RC(e.backward(n, obs, mb));
   return e.clip_rmsprop(flat_p, flat_g, flat_sq, n_flat, max_grad_norm, lr, alpha, eps, apply);

@@ -672,15 +672,15 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_sx4_kernel(AttnPtrs p, At
 constexpr int SX4_MAX = 10;     // 4 x S float4 row sets + coefficients fit the register file up to here
 #define MANSY_SX4_DISPATCH(KERNEL, S_, ...)                                                                \
   switch (S_) {                                                                                            \
-    case 2: hipLaunchKernelGGL(KERNEL<2>, __VA_ARGS__); break;                                             \
-    case 3: hipLaunchKernelGGL(KERNEL<3>, __VA_ARGS__); break;                                             \
-    case 4: hipLaunchKernelGGL(KERNEL<4>, __VA_ARGS__); break;                                             \
-    case 5: hipLaunchKernelGGL(KERNEL<5>, __VA_ARGS__); break;                                             \
-    case 6: hipLaunchKernelGGL(KERNEL<6>, __VA_ARGS__); break;                                             \
-    case 7: hipLaunchKernelGGL(KERNEL<7>, __VA_ARGS__); break;                                             \
-    case 8: hipLaunchKernelGGL(KERNEL<8>, __VA_ARGS__); break;                                             \
-    case 9: hipLaunchKernelGGL(KERNEL<9>, __VA_ARGS__); break;                                             \
-    default: hipLaunchKernelGGL(KERNEL<10>, __VA_ARGS__); break;                                           \
+    case 2: MANSY_LAUNCH(KERNEL<2>, __VA_ARGS__); break;                                             \
+    case 3: MANSY_LAUNCH(KERNEL<3>, __VA_ARGS__); break;                                             \
+    case 4: MANSY_LAUNCH(KERNEL<4>, __VA_ARGS__); break;                                             \
+    case 5: MANSY_LAUNCH(KERNEL<5>, __VA_ARGS__); break;                                             \
+    case 6: MANSY_LAUNCH(KERNEL<6>, __VA_ARGS__); break;                                             \
+    case 7: MANSY_LAUNCH(KERNEL<7>, __VA_ARGS__); break;                                             \
+    case 8: MANSY_LAUNCH(KERNEL<8>, __VA_ARGS__); break;                                             \
+    case 9: MANSY_LAUNCH(KERNEL<9>, __VA_ARGS__); break;                                             \
+    default: MANSY_LAUNCH(KERNEL<10>, __VA_ARGS__); break;                                           \
   }
 static bool sx4_ok(const AttnShape& s, const void* a, const void* b, const void* c, const void* d) {
   auto al = [](const void* x) { return (reinterpret_cast<uintptr_t>(x) & 15) == 0; };
@@ -692,18 +692,18 @@ static bool sx4_ok(const AttnShape& s, const void* a, const void* b, const void*
 // LKT buckets: exact for the decode lengths the engine produces (1..10), then 12 and 16
 #define MANSY_Q1X4_DISPATCH(KERNEL, Lk, ...)                                                               \
   switch (Lk) {                                                                                            \
-    case 1: hipLaunchKernelGGL(KERNEL<1>, __VA_ARGS__); break;                                             \
-    case 2: hipLaunchKernelGGL(KERNEL<2>, __VA_ARGS__); break;                                             \
-    case 3: hipLaunchKernelGGL(KERNEL<3>, __VA_ARGS__); break;                                             \
-    case 4: hipLaunchKernelGGL(KERNEL<4>, __VA_ARGS__); break;                                             \
-    case 5: hipLaunchKernelGGL(KERNEL<5>, __VA_ARGS__); break;                                             \
-    case 6: hipLaunchKernelGGL(KERNEL<6>, __VA_ARGS__); break;                                             \
-    case 7: hipLaunchKernelGGL(KERNEL<7>, __VA_ARGS__); break;                                             \
-    case 8: hipLaunchKernelGGL(KERNEL<8>, __VA_ARGS__); break;                                             \
-    case 9: hipLaunchKernelGGL(KERNEL<9>, __VA_ARGS__); break;                                             \
-    case 10: hipLaunchKernelGGL(KERNEL<10>, __VA_ARGS__); break;                                           \
-    case 11: case 12: hipLaunchKernelGGL(KERNEL<12>, __VA_ARGS__); break;                                  \
-    default: hipLaunchKernelGGL(KERNEL<16>, __VA_ARGS__); break;                                           \
+    case 1: MANSY_LAUNCH(KERNEL<1>, __VA_ARGS__); break;                                             \
+    case 2: MANSY_LAUNCH(KERNEL<2>, __VA_ARGS__); break;                                             \
+    case 3: MANSY_LAUNCH(KERNEL<3>, __VA_ARGS__); break;                                             \
+    case 4: MANSY_LAUNCH(KERNEL<4>, __VA_ARGS__); break;                                             \
+    case 5: MANSY_LAUNCH(KERNEL<5>, __VA_ARGS__); break;                                             \
+    case 6: MANSY_LAUNCH(KERNEL<6>, __VA_ARGS__); break;                                             \
+    case 7: MANSY_LAUNCH(KERNEL<7>, __VA_ARGS__); break;                                             \
+    case 8: MANSY_LAUNCH(KERNEL<8>, __VA_ARGS__); break;                                             \
+    case 9: MANSY_LAUNCH(KERNEL<9>, __VA_ARGS__); break;                                             \
+    case 10: MANSY_LAUNCH(KERNEL<10>, __VA_ARGS__); break;                                           \
+    case 11: case 12: MANSY_LAUNCH(KERNEL<12>, __VA_ARGS__); break;                                  \
+    default: MANSY_LAUNCH(KERNEL<16>, __VA_ARGS__); break;                                           \
   }
 
 static bool q1x4_ok(const AttnShape& s, const void* a, const void* b, const void* c, const void* d) {
@@ -732,8 +732,8 @@ int mansy_launch_attn_fwd(const float* Q, const float* K, const float* V, float*
     MANSY_Q1X4_DISPATCH(attn_fwd_q1x4_kernel, s.Lk, dim3(mansy_ceil_div(n / 4, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop)
   else if (sx4_ok(s, Q, K, V, O))
     MANSY_SX4_DISPATCH(attn_fwd_sx4_kernel, s.Lk, dim3(mansy_ceil_div(n / 4, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop)
-  else if (s.Lq == 1) hipLaunchKernelGGL(attn_fwd_q1_kernel, dim3(mansy_ceil_div(n, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop);
-  else hipLaunchKernelGGL(attn_fwd_kernel, dim3(mansy_ceil_div(n, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop);
+  else if (s.Lq == 1) MANSY_LAUNCH(attn_fwd_q1_kernel, dim3(mansy_ceil_div(n, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop);
+  else MANSY_LAUNCH(attn_fwd_kernel, dim3(mansy_ceil_div(n, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }
@@ -749,8 +749,8 @@ int mansy_launch_attn_bwd(const float* Q, const float* K, const float* V, const 
     MANSY_Q1X4_DISPATCH(attn_bwd_q1x4_kernel, s.Lk, dim3(mansy_ceil_div(n / 4, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop, accum_kv)
   else if (sx4_ok(s, Q, K, V, dO) && sx4_ok(s, dQ, dK, dV, dO))
     MANSY_SX4_DISPATCH(attn_bwd_sx4_kernel, s.Lk, dim3(mansy_ceil_div(n / 4, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop, accum_kv)
-  else if (s.Lq == 1) hipLaunchKernelGGL(attn_bwd_q1_kernel, dim3(mansy_ceil_div(n, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop, accum_kv);
-  else hipLaunchKernelGGL(attn_bwd_kernel, dim3(mansy_ceil_div(n, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop, accum_kv);
+  else if (s.Lq == 1) MANSY_LAUNCH(attn_bwd_q1_kernel, dim3(mansy_ceil_div(n, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop, accum_kv);
+  else MANSY_LAUNCH(attn_bwd_kernel, dim3(mansy_ceil_div(n, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop, accum_kv);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }

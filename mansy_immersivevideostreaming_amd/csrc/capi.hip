@@ -12,11 +12,15 @@ extern "C" void mansy_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+extern "C" { unsigned long long g_mansy_launch_count = 0; }
+extern "C" unsigned long long mansy_prof_launch_count(void) { return __atomic_load_n(&g_mansy_launch_count, __ATOMIC_RELAXED); }
+
 static mansy_bn_sync_fn g_bn_hook = nullptr;
 static void* g_bn_user = nullptr;
-int mansy_bn_sync_invoke(int which) {
-  MANSY_REQUIRE(g_bn_hook, "bn_sync_world > 1 but no hook registered (mansy_set_bn_sync_hook)");
-  const int rc = g_bn_hook(which, g_bn_user);
+int mansy_bn_sync_invoke(int which, int (*fn)(int, void*), void* user) {
+  if (!fn) { fn = g_bn_hook; user = g_bn_user; }       // deprecated process-wide registration (one round of grace)
+  MANSY_REQUIRE(fn, "bn_sync_world > 1 but the call carries no hook (mansy_vp_config::bn_sync_fn)");
+  const int rc = fn(which, user);
   MANSY_REQUIRE(rc == 0, "bn sync hook failed (%d)", rc);
   return MANSY_OK;
 }
@@ -26,7 +30,7 @@ extern "C" {
 int mansy_set_bn_sync_hook(mansy_bn_sync_fn fn, void* user) { g_bn_hook = fn; g_bn_user = user; return MANSY_OK; }
 
 const char* mansy_last_error(void) { return g_err; }
-int mansy_abi_version(void) { return 6; }   // == _lib.py ABI_VERSION
+int mansy_abi_version(void) { return 7; }   // == _lib.py ABI_VERSION
 
 int mansy_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb, int b_kmajor, float* C, int ldc, int M, int N,
                    int K, const mansy_gemm_epilogue* ep, int force_tile, int force_splitk, void* stream) {

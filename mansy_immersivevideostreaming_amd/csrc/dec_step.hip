@@ -318,10 +318,10 @@ int mansy_launch_dec_tail_fwd(const MansyDecTailFwd& p, hipStream_t st) {
   if (p.rows <= 0) return MANSY_OK;
   const dim3 grid(mansy_ceil_div(p.rows, 4));
   switch (p.C / 256) {
-    case 1: hipLaunchKernelGGL(dec_tail_fwd_kernel<1>, grid, dim3(256), 0, st, p); break;
-    case 2: hipLaunchKernelGGL(dec_tail_fwd_kernel<2>, grid, dim3(256), 0, st, p); break;
-    case 3: hipLaunchKernelGGL(dec_tail_fwd_kernel<3>, grid, dim3(256), 0, st, p); break;
-    default: hipLaunchKernelGGL(dec_tail_fwd_kernel<4>, grid, dim3(256), 0, st, p); break;
+    case 1: MANSY_LAUNCH(dec_tail_fwd_kernel<1>, grid, dim3(256), 0, st, p); break;
+    case 2: MANSY_LAUNCH(dec_tail_fwd_kernel<2>, grid, dim3(256), 0, st, p); break;
+    case 3: MANSY_LAUNCH(dec_tail_fwd_kernel<3>, grid, dim3(256), 0, st, p); break;
+    default: MANSY_LAUNCH(dec_tail_fwd_kernel<4>, grid, dim3(256), 0, st, p); break;
   }
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
@@ -335,10 +335,10 @@ int mansy_launch_dec_head_bwd(const MansyDecHeadBwd& p, int n_slots, hipStream_t
   const size_t lds = (size_t)HEAD_WAVES * 4 * p.C * sizeof(float);
   const dim3 block(64 * HEAD_WAVES);
   switch (p.C / 256) {
-    case 1: hipLaunchKernelGGL(dec_head_bwd_kernel<1>, dim3(n_slots), block, lds, st, p); break;
-    case 2: hipLaunchKernelGGL(dec_head_bwd_kernel<2>, dim3(n_slots), block, lds, st, p); break;
-    case 3: hipLaunchKernelGGL(dec_head_bwd_kernel<3>, dim3(n_slots), block, lds, st, p); break;
-    default: hipLaunchKernelGGL(dec_head_bwd_kernel<4>, dim3(n_slots), block, lds, st, p); break;
+    case 1: MANSY_LAUNCH(dec_head_bwd_kernel<1>, dim3(n_slots), block, lds, st, p); break;
+    case 2: MANSY_LAUNCH(dec_head_bwd_kernel<2>, dim3(n_slots), block, lds, st, p); break;
+    case 3: MANSY_LAUNCH(dec_head_bwd_kernel<3>, dim3(n_slots), block, lds, st, p); break;
+    default: MANSY_LAUNCH(dec_head_bwd_kernel<4>, dim3(n_slots), block, lds, st, p); break;
   }
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;

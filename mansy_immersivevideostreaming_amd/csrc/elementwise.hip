@@ -536,13 +536,13 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 #define MANSY_SMALL_DISPATCH(KERNEL, vec, ns, grid_v4, grid_v1, ...)                                                          \
   do {                                                                                                                        \
     if (vec) {                                                                                                                \
-      if ((ns) == 2) hipLaunchKernelGGL((KERNEL<4, 2>), grid_v4, dim3(256), 0, st, __VA_ARGS__);                              \
-      else if ((ns) == 6) hipLaunchKernelGGL((KERNEL<4, 6>), grid_v4, dim3(256), 0, st, __VA_ARGS__);                         \
-      else hipLaunchKernelGGL((KERNEL<4, 0>), grid_v4, dim3(256), 0, st, __VA_ARGS__);                                        \
+      if ((ns) == 2) MANSY_LAUNCH((KERNEL<4, 2>), grid_v4, dim3(256), 0, st, __VA_ARGS__);                              \
+      else if ((ns) == 6) MANSY_LAUNCH((KERNEL<4, 6>), grid_v4, dim3(256), 0, st, __VA_ARGS__);                         \
+      else MANSY_LAUNCH((KERNEL<4, 0>), grid_v4, dim3(256), 0, st, __VA_ARGS__);                                        \
     } else {                                                                                                                  \
-      if ((ns) == 2) hipLaunchKernelGGL((KERNEL<1, 2>), grid_v1, dim3(256), 0, st, __VA_ARGS__);                              \
-      else if ((ns) == 6) hipLaunchKernelGGL((KERNEL<1, 6>), grid_v1, dim3(256), 0, st, __VA_ARGS__);                         \
-      else hipLaunchKernelGGL((KERNEL<1, 0>), grid_v1, dim3(256), 0, st, __VA_ARGS__);                                        \
+      if ((ns) == 2) MANSY_LAUNCH((KERNEL<1, 2>), grid_v1, dim3(256), 0, st, __VA_ARGS__);                              \
+      else if ((ns) == 6) MANSY_LAUNCH((KERNEL<1, 6>), grid_v1, dim3(256), 0, st, __VA_ARGS__);                         \
+      else MANSY_LAUNCH((KERNEL<1, 0>), grid_v1, dim3(256), 0, st, __VA_ARGS__);                                        \
     }                                                                                                                         \
   } while (0)
 
@@ -554,17 +554,17 @@ int mansy_launch_traj_gather(const float* table, int L, int c, const int* idx, i
   if (B <= 0) return MANSY_OK;
   auto al8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; };
   if (c == 2 && al8(table) && al8(hist) && al8(cur) && al8(fut))
-    hipLaunchKernelGGL(traj_gather2_kernel, g1((long long)B * (S + 1 + T)), dim3(256), 0, st, reinterpret_cast<const float2*>(table), L, idx, B, S, T,
+    MANSY_LAUNCH(traj_gather2_kernel, g1((long long)B * (S + 1 + T)), dim3(256), 0, st, reinterpret_cast<const float2*>(table), L, idx, B, S, T,
                        reinterpret_cast<float2*>(hist), reinterpret_cast<float2*>(cur), reinterpret_cast<float2*>(fut));
   else
-    hipLaunchKernelGGL(traj_gather_kernel, g1((long long)B * (S + 1 + T) * c), dim3(256), 0, st, table, L, c, idx, B, S, T, hist, cur, fut);
+    MANSY_LAUNCH(traj_gather_kernel, g1((long long)B * (S + 1 + T) * c), dim3(256), 0, st, table, L, c, idx, B, S, T, hist, cur, fut);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }
 int mansy_launch_periodic_mse(const float* a, const float* b, long long rows, int c, float* out, hipStream_t st) {
   MANSY_REQUIRE(a && b && out && c >= 1, "periodic_mse: bad arguments");
   if (rows <= 0) return MANSY_OK;
-  hipLaunchKernelGGL(periodic_mse_kernel, g1(rows), dim3(256), 0, st, a, b, rows, c, out);
+  MANSY_LAUNCH(periodic_mse_kernel, g1(rows), dim3(256), 0, st, a, b, rows, c, out);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }
@@ -578,9 +578,9 @@ int mansy_launch_embed_fwd(const float* x, int in_ch, const float* W, const floa
   if (vec && rows >= 8192 && 256 % (C / 4) == 0) {
     const int rpw = 8 * (256 / (C / 4));                 // 8 iterations per workgroup
     const dim3 grid(mansy_ceil_div(rows, rpw));
-    if (in_ch == 2) hipLaunchKernelGGL(embed_fwd_rows_kernel<2>, grid, dim3(256), 0, st, x, in_ch, W, b, pe, out, rows, C, S, pos_fixed, drop, rpw);
-    else if (in_ch == 6) hipLaunchKernelGGL(embed_fwd_rows_kernel<6>, grid, dim3(256), 0, st, x, in_ch, W, b, pe, out, rows, C, S, pos_fixed, drop, rpw);
-    else hipLaunchKernelGGL(embed_fwd_rows_kernel<0>, grid, dim3(256), 0, st, x, in_ch, W, b, pe, out, rows, C, S, pos_fixed, drop, rpw);
+    if (in_ch == 2) MANSY_LAUNCH(embed_fwd_rows_kernel<2>, grid, dim3(256), 0, st, x, in_ch, W, b, pe, out, rows, C, S, pos_fixed, drop, rpw);
+    else if (in_ch == 6) MANSY_LAUNCH(embed_fwd_rows_kernel<6>, grid, dim3(256), 0, st, x, in_ch, W, b, pe, out, rows, C, S, pos_fixed, drop, rpw);
+    else MANSY_LAUNCH(embed_fwd_rows_kernel<0>, grid, dim3(256), 0, st, x, in_ch, W, b, pe, out, rows, C, S, pos_fixed, drop, rpw);
   } else {
     MANSY_SMALL_DISPATCH(embed_fwd_kernel, vec, in_ch, g1((long long)rows * C / 4), g1((long long)rows * C),
                          x, in_ch, W, b, pe, out, rows, C, S, pos_fixed, drop);
@@ -640,9 +640,9 @@ int mansy_launch_mtio_loss(const float* pred, const float* gt, long long n, floa
   MANSY_HIP_CHECK(hipMemsetAsync(loss_accum, 0, sizeof(double), st));
   if (n > 0) {
     const int grid = min(mansy_ceil_div(n, 256), 1024);
-    hipLaunchKernelGGL(mtio_loss_kernel, dim3(grid), dim3(256), 0, st, pred, gt, n, inv_2bt, loss_accum, dpred);
+    MANSY_LAUNCH(mtio_loss_kernel, dim3(grid), dim3(256), 0, st, pred, gt, n, inv_2bt, loss_accum, dpred);
   }
-  hipLaunchKernelGGL(mtio_loss_finish, dim3(1), dim3(1), 0, st, loss_accum, inv_2bt, loss_out);
+  MANSY_LAUNCH(mtio_loss_finish, dim3(1), dim3(1), 0, st, loss_accum, inv_2bt, loss_out);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }
@@ -654,7 +654,7 @@ int mansy_launch_adamw(float* p, const float* g, float* m, float* v, long long n
   if (n <= 0) return MANSY_OK;
   const double bc1 = 1.0 - pow((double)b1, (double)step);
   const double bc2 = 1.0 - pow((double)b2, (double)step);
-  hipLaunchKernelGGL(adamw_kernel, g1((n + 3) / 4), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, wd, (float)bc1,
+  MANSY_LAUNCH(adamw_kernel, g1((n + 3) / 4), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, wd, (float)bc1,
                      (float)sqrt(bc2), decoupled);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
@@ -663,8 +663,8 @@ int mansy_launch_adamw(float* p, const float* g, float* m, float* v, long long n
 int mansy_launch_im2col3(const float* x, float* col, int B, int S, int C, hipStream_t st) {
   MANSY_REQUIRE(x && col, "im2col3: null pointer");
   if ((long long)B * S * C <= 0) return MANSY_OK;
-  if (C % 4 == 0 && al16(x) && al16(col)) hipLaunchKernelGGL(im2col3_kernel<4>, g1((long long)B * S * C / 4), dim3(256), 0, st, x, col, B, S, C);
-  else hipLaunchKernelGGL(im2col3_kernel<1>, g1((long long)B * S * C), dim3(256), 0, st, x, col, B, S, C);
+  if (C % 4 == 0 && al16(x) && al16(col)) MANSY_LAUNCH(im2col3_kernel<4>, g1((long long)B * S * C / 4), dim3(256), 0, st, x, col, B, S, C);
+  else MANSY_LAUNCH(im2col3_kernel<1>, g1((long long)B * S * C), dim3(256), 0, st, x, col, B, S, C);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }
@@ -672,8 +672,8 @@ int mansy_launch_col2im3(const float* dcol, float* dx, int B, int S, int C, hipS
   MANSY_REQUIRE(dcol && dx, "col2im3: null pointer");
   const long long total = (long long)B * S * C;
   if (total <= 0) return MANSY_OK;
-  if (C % 4 == 0 && al16(dcol) && al16(dx)) hipLaunchKernelGGL(col2im3_kernel<4>, g1(total / 4), dim3(256), 0, st, dcol, dx, B, S, C);
-  else hipLaunchKernelGGL(col2im3_kernel<1>, g1(total), dim3(256), 0, st, dcol, dx, B, S, C);
+  if (C % 4 == 0 && al16(dcol) && al16(dx)) MANSY_LAUNCH(col2im3_kernel<4>, g1(total / 4), dim3(256), 0, st, dcol, dx, B, S, C);
+  else MANSY_LAUNCH(col2im3_kernel<1>, g1(total), dim3(256), 0, st, dcol, dx, B, S, C);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }
@@ -681,14 +681,14 @@ int mansy_launch_colsum(const float* x, int ld, int rows, int C, float* out, hip
   MANSY_REQUIRE(x && out, "colsum: null pointer");
   if (rows <= 0) return MANSY_OK;
   dim3 grid(mansy_ceil_div(C, 256), min(rows, 256));
-  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, st, x, ld, rows, C, out);
+  MANSY_LAUNCH(colsum_kernel, grid, dim3(256), 0, st, x, ld, rows, C, out);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }
 int mansy_launch_add(const float* a, const float* b, float* y, long long n, hipStream_t st) {
   MANSY_REQUIRE(a && b && y, "add: null pointer");
   if (n <= 0) return MANSY_OK;
-  hipLaunchKernelGGL(add_kernel, g1(n), dim3(256), 0, st, a, b, y, n);
+  MANSY_LAUNCH(add_kernel, g1(n), dim3(256), 0, st, a, b, y, n);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }
@@ -696,14 +696,14 @@ int mansy_launch_mtio_mix(const float* x, const int* perm1, const int* perm2, fl
   MANSY_REQUIRE(x && out, "mtio_mix: null pointer");
   const long long total = (long long)B * L * 3 * c;
   if (total <= 0) return MANSY_OK;
-  hipLaunchKernelGGL(mtio_mix_kernel, g1(total), dim3(256), 0, st, x, perm1, perm2, out, B, L, c);
+  MANSY_LAUNCH(mtio_mix_kernel, g1(total), dim3(256), 0, st, x, perm1, perm2, out, B, L, c);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }
 int mansy_launch_ensemble_wrap(const float* pred, float* out, long long rows, int heads, int c, hipStream_t st) {
   MANSY_REQUIRE(pred && out, "ensemble_wrap: null pointer");
   if (rows <= 0) return MANSY_OK;
-  hipLaunchKernelGGL(ensemble_wrap_kernel, g1(rows * c), dim3(256), 0, st, pred, out, rows, heads, c);
+  MANSY_LAUNCH(ensemble_wrap_kernel, g1(rows * c), dim3(256), 0, st, pred, out, rows, heads, c);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }
@@ -711,7 +711,7 @@ int mansy_launch_linreg_sample(const float* hist, const float* cur, int B, int S
   MANSY_REQUIRE(S >= 1 && T >= 0 && c >= 1, "linreg_sample: need S >= 1 (two points fix a line), T >= 0, c >= 1");
   if (B <= 0 || T == 0) return MANSY_OK;
   MANSY_REQUIRE(hist && cur && out, "linreg_sample: null pointer");
-  hipLaunchKernelGGL(linreg_sample_kernel, g1((long long)B * c), dim3(256), 0, st, hist, cur, B, S, T, c, out);
+  MANSY_LAUNCH(linreg_sample_kernel, g1((long long)B * c), dim3(256), 0, st, hist, cur, B, S, T, c, out);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }
@@ -719,7 +719,7 @@ int mansy_launch_tb_to_bt(const float* src, float* dst, int T, int B, int C, hip
   MANSY_REQUIRE(src && dst, "tb_to_bt: null pointer");
   const long long total = (long long)T * B * C;
   if (total <= 0) return MANSY_OK;
-  hipLaunchKernelGGL(tb_to_bt_kernel, g1(total), dim3(256), 0, st, src, dst, T, B, C);
+  MANSY_LAUNCH(tb_to_bt_kernel, g1(total), dim3(256), 0, st, src, dst, T, B, C);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }

@@ -235,7 +235,7 @@ int mansy_env_state_bytes(void) { return (int)sizeof(EnvState); }
 
 int mansy_env_init(void* state, int n_env, int index_offset, int worker_num, int seed, void* stream) {
   MANSY_REQUIRE(state && n_env >= 1 && worker_num >= 1, "env_init: bad arguments");
-  hipLaunchKernelGGL(env_init_kernel, dim3(mansy_ceil_div(n_env, 256)), dim3(256), 0, (hipStream_t)stream, (EnvState*)state, n_env,
+  MANSY_LAUNCH(env_init_kernel, dim3(mansy_ceil_div(n_env, 256)), dim3(256), 0, (hipStream_t)stream, (EnvState*)state, n_env,
                      index_offset, worker_num, seed);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
@@ -244,7 +244,7 @@ int mansy_env_init(void* state, int n_env, int index_offset, int worker_num, int
 int mansy_env_reset(const mansy_env_tables* T, void* state, int n_env, float* obs, void* stream) {
   int rc = check_tables(T); if (rc) return rc;
   MANSY_REQUIRE(state && obs && n_env >= 1, "env_reset: bad arguments");
-  hipLaunchKernelGGL(env_reset_kernel, dim3(mansy_ceil_div((long long)n_env * 64, 256)), dim3(256), 0, (hipStream_t)stream, *T,
+  MANSY_LAUNCH(env_reset_kernel, dim3(mansy_ceil_div((long long)n_env * 64, 256)), dim3(256), 0, (hipStream_t)stream, *T,
                      (EnvState*)state, n_env, obs);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
@@ -256,7 +256,7 @@ int mansy_env_step(const mansy_env_tables* T, void* state, int n_env, const int*
   MANSY_REQUIRE(state && actions && obs_next && reward && done && n_env >= 1, "env_step: bad arguments");
   mansy_env_episode_log el = {nullptr, nullptr, 0};
   if (elog) el = *elog;
-  hipLaunchKernelGGL(env_step_kernel, dim3(mansy_ceil_div((long long)n_env * 64, 256)), dim3(256), 0, (hipStream_t)stream, *T,
+  MANSY_LAUNCH(env_step_kernel, dim3(mansy_ceil_div((long long)n_env * 64, 256)), dim3(256), 0, (hipStream_t)stream, *T,
                      (EnvState*)state, n_env, actions, obs_next, obs_cur, reward, done, qoe_parts, el);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
@@ -268,7 +268,7 @@ int mansy_allocate_tile_rates(const float* pred_viewport, const int* actions, in
   mansy_env_tables T;
   memset(&T, 0, sizeof(T));
   for (int i = 0; i < 5; ++i) T.video_rates[i] = video_rates[i];
-  hipLaunchKernelGGL(alloc_rates_kernel, dim3(mansy_ceil_div((long long)n * 64, 256)), dim3(256), 0, (hipStream_t)stream, pred_viewport,
+  MANSY_LAUNCH(alloc_rates_kernel, dim3(mansy_ceil_div((long long)n * 64, 256)), dim3(256), 0, (hipStream_t)stream, pred_viewport,
                      actions, n, T, versions);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
@@ -280,7 +280,7 @@ int mansy_expert_profile(const mansy_env_tables* T, const int* vp_video, int n_v
   MANSY_REQUIRE(vp_video && n_vp >= 1 && gt_quality && pred_quality && gt_var && pred_var && gt_size && pred_size,
                 "expert_profile: bad arguments");
   const long long waves = (long long)n_vp * T->n_vpchunk_max * N_ACTION * 2;
-  hipLaunchKernelGGL(expert_profile_kernel, dim3((unsigned)mansy_ceil_div(waves * 64, 256)), dim3(256), 0, (hipStream_t)stream, *T,
+  MANSY_LAUNCH(expert_profile_kernel, dim3((unsigned)mansy_ceil_div(waves * 64, 256)), dim3(256), 0, (hipStream_t)stream, *T,
                      vp_video, n_vp, gt_quality, pred_quality, gt_var, pred_var, gt_size, pred_size);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
@@ -296,10 +296,10 @@ int mansy_expert_choose_action(const mansy_env_tables* T, const void* state, int
   unsigned n_prefix = 1;
   for (int t = 0; t < horizon - 1; ++t) n_prefix *= N_ACTION;
   const dim3 eb(mansy_ceil_div(n_env, 256));
-  hipLaunchKernelGGL(expert_keys_init_kernel, eb, dim3(256), 0, (hipStream_t)stream, keys, n_env);
-  hipLaunchKernelGGL(expert_search_kernel, dim3(mansy_ceil_div(n_prefix, 256u), n_env), dim3(256), 0, (hipStream_t)stream, *T,
+  MANSY_LAUNCH(expert_keys_init_kernel, eb, dim3(256), 0, (hipStream_t)stream, keys, n_env);
+  MANSY_LAUNCH(expert_search_kernel, dim3(mansy_ceil_div(n_prefix, 256u), n_env), dim3(256), 0, (hipStream_t)stream, *T,
                      (const EnvState*)state, horizon, pred_quality, pred_var, pred_size, keys);
-  hipLaunchKernelGGL(expert_pick_kernel, eb, dim3(256), 0, (hipStream_t)stream, keys, n_env, actions, best_value, best_index);
+  MANSY_LAUNCH(expert_pick_kernel, eb, dim3(256), 0, (hipStream_t)stream, keys, n_env, actions, best_value, best_index);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }

@@ -1067,7 +1067,7 @@ int mansy_launch_weight_planes(const MansyWPlaneTab& tab, unsigned short* out, u
   long long tiles = 0;
   for (int t = 0; t < tab.n; ++t) tiles += (long long)((tab.N[t] + 31) / 32) * ((tab.K[t] + 31) / 32);
   if (tiles == 0) return MANSY_OK;
-  hipLaunchKernelGGL(weight_planes_kernel, dim3((unsigned)tiles), dim3(256), 0, st, tab, out, out_t, plane_stride, n_planes);
+  MANSY_LAUNCH(weight_planes_kernel, dim3((unsigned)tiles), dim3(256), 0, st, tab, out, out_t, plane_stride, n_planes);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }

@@ -18,6 +18,7 @@ constexpr int NT = 256;
 extern hipEvent_t g_ev_start, g_ev_stop;
 #define MANSY_GEMM_LAUNCH(kern, grid, block, st, params)                                                                        \
   do {                                                                                                                          \
+    __atomic_fetch_add(&g_mansy_launch_count, 1ull, __ATOMIC_RELAXED);                                                          \
     if (mansy_gemm::g_ev_start) hipExtLaunchKernelGGL(kern, grid, block, 0, st, mansy_gemm::g_ev_start, mansy_gemm::g_ev_stop, 0, params); \
     else hipLaunchKernelGGL(kern, grid, block, 0, st, params);                                                                  \
   } while (0)

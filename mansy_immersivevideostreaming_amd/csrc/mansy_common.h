@@ -23,6 +23,16 @@ extern "C" void mansy_set_error(const char* fmt, ...);
 
 #define MANSY_LAUNCH_CHECK() MANSY_HIP_CHECK(hipGetLastError())
 
+// Every kernel launch of the library goes through MANSY_LAUNCH (or MANSY_GEMM_LAUNCH, gemm_tile.h): it counts the launch in a process
+// counter that bench.py reads live (mansy_prof_launch_count; launches enqueued during a hipGraph capture count once, at capture).
+// A measurement hook only: nothing in the library reads it.
+extern "C" unsigned long long g_mansy_launch_count;
+#define MANSY_LAUNCH(kern, grid, block, shmem, st, ...)               \
+  do {                                                                \
+    __atomic_fetch_add(&g_mansy_launch_count, 1ull, __ATOMIC_RELAXED); \
+    hipLaunchKernelGGL(kern, grid, block, shmem, st, __VA_ARGS__);    \
+  } while (0)
+
 #define MANSY_REQUIRE(cond, ...)        \
   do {                                  \
     if (!(cond)) {                      \

@@ -127,9 +127,10 @@ int mansy_launch_layernorm_bwd_partial(const float* dy, const float* z, const fl
 int mansy_launch_ln_partials_reduce(const float* partials, int nparts, int C, float* dw, float* dbias, hipStream_t st);
 
 // BatchNorm1d(train) + ELU + MaxPool1d(3,2,1) of the DistillLayer on conv output [B*S, C].
-struct DistillShape { int B, S, M, C; int sync_world = 1; };
-// Invokes the registered data-parallel hook (capi.hip: mansy_set_bn_sync_hook); which = 0 forward stats, 1 backward stats.
-int mansy_bn_sync_invoke(int which);
+struct DistillShape { int B, S, M, C; int sync_world = 1; int (*hook)(int, void*) = nullptr; void* hook_user = nullptr; };
+// Invokes the call's data-parallel hook (mansy_vp_config::bn_sync_fn; fn == nullptr: the deprecated process-wide registration of
+// capi.hip: mansy_set_bn_sync_hook); which = 0 forward stats, 1 backward stats, 2 decoder-side gradients final.
+int mansy_bn_sync_invoke(int which, int (*fn)(int, void*), void* user);
 // stats_d: device scratch of 6*C doubles ([sum, sumsq] forward, [sum g, sum g*xhat] backward global + local copy).
 int mansy_launch_distill_fwd(const float* conv, const float* bn_w, const float* bn_b, float* run_mean, float* run_var,
                              long long* num_batches, float* mean_out, float* rstd_out, float* mem, unsigned char* argmax,

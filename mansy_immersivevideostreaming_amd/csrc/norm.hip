@@ -413,13 +413,13 @@ int mansy_launch_layernorm_fwd(const float* a, const float* b, const float* w, c
   const int grid = min(mansy_ceil_div(rows, 4), 2048);
   if ((C % 256) == 0 && C <= 256 * LN_MAXV) {
     switch (C / 256) {
-      case 1: hipLaunchKernelGGL(layernorm_fwd_kernel<1>, dim3(grid), dim3(256), 0, st, a, b, w, bias, z_out, y, mean, rstd, rows, C, eps); break;
-      case 2: hipLaunchKernelGGL(layernorm_fwd_kernel<2>, dim3(grid), dim3(256), 0, st, a, b, w, bias, z_out, y, mean, rstd, rows, C, eps); break;
-      case 3: hipLaunchKernelGGL(layernorm_fwd_kernel<3>, dim3(grid), dim3(256), 0, st, a, b, w, bias, z_out, y, mean, rstd, rows, C, eps); break;
-      default: hipLaunchKernelGGL(layernorm_fwd_kernel<4>, dim3(grid), dim3(256), 0, st, a, b, w, bias, z_out, y, mean, rstd, rows, C, eps); break;
+      case 1: MANSY_LAUNCH(layernorm_fwd_kernel<1>, dim3(grid), dim3(256), 0, st, a, b, w, bias, z_out, y, mean, rstd, rows, C, eps); break;
+      case 2: MANSY_LAUNCH(layernorm_fwd_kernel<2>, dim3(grid), dim3(256), 0, st, a, b, w, bias, z_out, y, mean, rstd, rows, C, eps); break;
+      case 3: MANSY_LAUNCH(layernorm_fwd_kernel<3>, dim3(grid), dim3(256), 0, st, a, b, w, bias, z_out, y, mean, rstd, rows, C, eps); break;
+      default: MANSY_LAUNCH(layernorm_fwd_kernel<4>, dim3(grid), dim3(256), 0, st, a, b, w, bias, z_out, y, mean, rstd, rows, C, eps); break;
     }
   } else
-    hipLaunchKernelGGL(layernorm_fwd_generic, dim3(grid), dim3(256), 0, st, a, b, w, bias, z_out, y, mean, rstd, rows, C, eps);
+    MANSY_LAUNCH(layernorm_fwd_generic, dim3(grid), dim3(256), 0, st, a, b, w, bias, z_out, y, mean, rstd, rows, C, eps);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }
@@ -434,13 +434,13 @@ int mansy_launch_layernorm_bwd(const float* dy, const float* z, const float* mea
   MANSY_REQUIRE(lds <= 64 * 1024, "layernorm_bwd: C=%d too large", C);
   if ((C % 256) == 0 && C <= 256 * LN_MAXV) {
     switch (C / 256) {
-      case 1: hipLaunchKernelGGL((layernorm_bwd_vec_kernel<1, false, 4>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C); break;
-      case 2: hipLaunchKernelGGL((layernorm_bwd_vec_kernel<2, false, 4>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C); break;
-      case 3: hipLaunchKernelGGL((layernorm_bwd_vec_kernel<3, false, 4>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C); break;
-      default: hipLaunchKernelGGL((layernorm_bwd_vec_kernel<4, false, 4>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C); break;
+      case 1: MANSY_LAUNCH((layernorm_bwd_vec_kernel<1, false, 4>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C); break;
+      case 2: MANSY_LAUNCH((layernorm_bwd_vec_kernel<2, false, 4>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C); break;
+      case 3: MANSY_LAUNCH((layernorm_bwd_vec_kernel<3, false, 4>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C); break;
+      default: MANSY_LAUNCH((layernorm_bwd_vec_kernel<4, false, 4>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C); break;
     }
   } else
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias,
+    MANSY_LAUNCH(layernorm_bwd_kernel, dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias,
                        rows, C);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
@@ -456,14 +456,14 @@ int mansy_launch_distill_fwd(const float* conv, const float* bn_w, const float* 
   if (train) {
     MANSY_HIP_CHECK(hipMemsetAsync(stats_d, 0, sizeof(double) * 6 * s.C, st));
     dim3 grid(mansy_ceil_div(s.C, 256), min(rows, 512));
-    hipLaunchKernelGGL(colstats_kernel, grid, dim3(256), 0, st, conv, rows, s.C, stats_d);
-    if (s.sync_world > 1) RC_HOOK(mansy_bn_sync_invoke(0));     // SyncBN: all-reduce [sum, sumsq] (2C doubles) over the data-parallel ranks
+    MANSY_LAUNCH(colstats_kernel, grid, dim3(256), 0, st, conv, rows, s.C, stats_d);
+    if (s.sync_world > 1) RC_HOOK(mansy_bn_sync_invoke(0, s.hook, s.hook_user));     // SyncBN: all-reduce [sum, sumsq] (2C doubles) over the data-parallel ranks
   }
   const int n_glob = rows * (train && s.sync_world > 1 ? s.sync_world : 1);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(mansy_ceil_div(s.C, 256)), dim3(256), 0, st, stats_d, n_glob, s.C, run_mean, run_var,
+  MANSY_LAUNCH(bn_finalize_kernel, dim3(mansy_ceil_div(s.C, 256)), dim3(256), 0, st, stats_d, n_glob, s.C, run_mean, run_var,
                      num_batches, mean_out, rstd_out, train, eps, momentum);
   const long long total = (long long)s.B * s.M * s.C;
-  hipLaunchKernelGGL(bn_elu_pool_kernel, dim3(mansy_ceil_div(total, 256)), dim3(256), 0, st, conv, bn_w, bn_b, mean_out, rstd_out,
+  MANSY_LAUNCH(bn_elu_pool_kernel, dim3(mansy_ceil_div(total, 256)), dim3(256), 0, st, conv, bn_w, bn_b, mean_out, rstd_out,
                      mem, argmax, s);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
@@ -481,16 +481,16 @@ int mansy_launch_distill_bwd(const float* conv, const float* dmem, const unsigne
   if (s.C % 4 == 0 && (cv % 256 == 0 || 256 % cv == 0) && al(conv) && al(dmem) && al(g_tmp) && (reinterpret_cast<uintptr_t>(argmax) & 3) == 0) {
     const int tpr = cv < 256 ? cv : 256;
     dim3 grid1(mansy_ceil_div(cv, tpr), min(mansy_ceil_div(rows, 256 / tpr), 256));
-    hipLaunchKernelGGL(distill_bwd_stage1<4>, grid1, dim3(256), 0, st, conv, dmem, argmax, bn_w, bn_b, mean, rstd, g_tmp, stats_d, s);
+    MANSY_LAUNCH(distill_bwd_stage1<4>, grid1, dim3(256), 0, st, conv, dmem, argmax, bn_w, bn_b, mean, rstd, g_tmp, stats_d, s);
   } else {
     dim3 grid1(mansy_ceil_div(s.C, 256), min(rows, 512));
-    hipLaunchKernelGGL(distill_bwd_stage1<1>, grid1, dim3(256), 0, st, conv, dmem, argmax, bn_w, bn_b, mean, rstd, g_tmp, stats_d, s);
+    MANSY_LAUNCH(distill_bwd_stage1<1>, grid1, dim3(256), 0, st, conv, dmem, argmax, bn_w, bn_b, mean, rstd, g_tmp, stats_d, s);
   }
   // parameter gradients use THIS rank's sums (the gradient all-reduce averages them); the input gradient needs the global ones
   MANSY_HIP_CHECK(hipMemcpyAsync(stats_d + 4 * s.C, stats_d + 2 * s.C, sizeof(double) * 2 * s.C, hipMemcpyDeviceToDevice, st));
-  if (s.sync_world > 1) RC_HOOK(mansy_bn_sync_invoke(1));       // SyncBN backward: all-reduce [sum g, sum g*xhat]
+  if (s.sync_world > 1) RC_HOOK(mansy_bn_sync_invoke(1, s.hook, s.hook_user));       // SyncBN backward: all-reduce [sum g, sum g*xhat]
   const long long total = (long long)rows * s.C;
-  hipLaunchKernelGGL(distill_bwd_stage2, dim3(mansy_ceil_div(total, 256)), dim3(256), 0, st, conv, g_tmp, bn_w, mean, rstd, stats_d,
+  MANSY_LAUNCH(distill_bwd_stage2, dim3(mansy_ceil_div(total, 256)), dim3(256), 0, st, conv, g_tmp, bn_w, mean, rstd, stats_d,
                      dconv, dbn_w, dbn_b, s);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
@@ -510,7 +510,7 @@ int mansy_launch_layernorm_bwd_partial(const float* dy, const float* z, const fl
   const int grid = mansy_ln_bwd_parts(rows);
   const size_t lds = (size_t)4 * 2 * C * sizeof(float);
   float* flag = accumulate ? partials : nullptr;      // the kernel only tests it for null
-#define LNB(NV, RBV) hipLaunchKernelGGL((layernorm_bwd_vec_kernel<NV, true, RBV>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, partials, flag, rows, C)
+#define LNB(NV, RBV) MANSY_LAUNCH((layernorm_bwd_vec_kernel<NV, true, RBV>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, partials, flag, rows, C)
   if (C / 256 == 2) LNB(2, 4);
   else if (C / 256 == 1) LNB(1, 4);
   else if (C / 256 == 3) LNB(3, 4);
@@ -521,7 +521,7 @@ int mansy_launch_layernorm_bwd_partial(const float* dy, const float* z, const fl
 }
 int mansy_launch_ln_partials_reduce(const float* partials, int nparts, int C, float* dw, float* dbias, hipStream_t st) {
   MANSY_REQUIRE(partials && nparts >= 1, "ln_partials_reduce: bad arguments");
-  hipLaunchKernelGGL(ln_partials_reduce_kernel, dim3(mansy_ceil_div(C, 64), 2, mansy_ceil_div(nparts, 64)), dim3(256), 0, st, partials, nparts, C, dw, dbias);
+  MANSY_LAUNCH(ln_partials_reduce_kernel, dim3(mansy_ceil_div(C, 64), 2, mansy_ceil_div(nparts, 64)), dim3(256), 0, st, partials, nparts, C, dw, dbias);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }

@@ -946,6 +946,7 @@ size_t ppo_layout(int maxB, char* base, PWork& W) {
 
 struct PEng {
   hipStream_t st; PWork W;
+  int prec = 0;      // MANSY_PREC_* of this call's products (the entry point's `precision` argument)
   // pair != nullptr: also stack the fc weights of (n, *pair) for head_pair()
   int pack(const NetP& n, int identifier, const NetP* pair = nullptr, const float* g_src = nullptr, const int* g_idx = nullptr, int g_rows = 0,
            float* zero_ptr = nullptr, long long zero_n = 0) {
@@ -959,7 +960,7 @@ struct PEng {
     const int K = identifier ? K_IDENT : K_POLICY;
     const long long n_win = (long long)HID * window_cols(identifier);
     const long long threads = n_win + (pair ? 2LL * HID * FEAT : 0) + (long long)a.g_rows * (OBS_LD / 4) + (a.zero_n + 3) / 4;
-    hipLaunchKernelGGL(pack_wbd_kernel, dim3(mansy_ceil_div(threads, 256)), dim3(256), 0, st, a, identifier, K, n_win, W.Wbd, W.bbd, W.krange, W.tlist);
+    MANSY_LAUNCH(pack_wbd_kernel, dim3(mansy_ceil_div(threads, 256)), dim3(256), 0, st, a, identifier, K, n_win, W.Wbd, W.bbd, W.krange, W.tlist);
     MANSY_LAUNCH_CHECK();
     return MANSY_OK;
   }
@@ -974,14 +975,14 @@ struct PEng {
     MANSY_REQUIRE(!zero_ptr || (reinterpret_cast<uintptr_t>(zero_ptr) & 15) == 0, "pack: gradient buffer must be 16-byte aligned");
     const long long n_win = (long long)HID * window_cols(0);
     const long long threads = n_win + 2LL * HID * FEAT + (long long)pa.g_rows * (OBS_LD / 4) + (pa.zero_n + 3) / 4;
-    hipLaunchKernelGGL(pack_wbd_kernel, dim3(mansy_ceil_div(threads, 256) + 1), dim3(256), 0, st, pa, 0, K_POLICY, n_win, W.Wbd, W.bbd, W.krange, W.tlist);
+    MANSY_LAUNCH(pack_wbd_kernel, dim3(mansy_ceil_div(threads, 256) + 1), dim3(256), 0, st, pa, 0, K_POLICY, n_win, W.Wbd, W.bbd, W.krange, W.tlist);
     MANSY_LAUNCH_CHECK();
     return MANSY_OK;
   }
   int featnet(const float* obs, int B, int identifier) {
     const int K = identifier ? K_IDENT : K_POLICY;
     (void)K;      // the packed image spans KP columns (zero beyond K); obs rows are OBS_LD >= KP floats
-    GemmEpilogue ep; ep.bias = W.bbd; ep.relu = 1; ep.relu_slope = SLOPE; ep.tile_krange = W.krange;
+    GemmEpilogue ep; ep.prec = prec; ep.bias = W.bbd; ep.relu = 1; ep.relu_slope = SLOPE; ep.tile_krange = W.krange;
     // the packed image is only defined inside the K windows: the product must run on a loop that honours tile_krange -- the LDS-DMA
     // loop or its split-bf16 twin, i.e. K a multiple of 32 (KP), leading dimensions multiples of 4, 16-byte aligned operands
     static_assert(KP % 32 == 0 && OBS_LD % 4 == 0, "FeatureNet product must qualify for the LDS-DMA loop");
@@ -998,10 +999,10 @@ struct PEng {
     if (req > 1) {
       nsplit = mansy_gemm_effective_splits(FEAT, req);
       MANSY_REQUIRE(nsplit <= MAX_SLABS, "head: %d K splits exceed the slab sum's unroll", nsplit);
-      GemmEpilogue ep; ep.split_slab = (long long)B * HID;
+      GemmEpilogue ep; ep.prec = prec; ep.split_slab = (long long)B * HID;
       RC(mansy_launch_gemm_f32(W.F, FEAT, 0, n.fc_w, FEAT, 0, W.A1s, HID, B, HID, FEAT, ep, 0, req, st));
     } else {
-      GemmEpilogue ep; ep.bias = n.fc_b; ep.relu = 1; ep.relu_slope = SLOPE;
+      GemmEpilogue ep; ep.prec = prec; ep.bias = n.fc_b; ep.relu = 1; ep.relu_slope = SLOPE;
       RC(mansy_launch_gemm_f32(W.F, FEAT, 0, n.fc_w, FEAT, 0, A1, HID, B, HID, FEAT, ep, 0, 0, st));
     }
     HeadOutArgs ha;
@@ -1015,7 +1016,7 @@ struct PEng {
     if (fuse) none = *fuse;
     EnvFuse ef; memset(&ef, 0, sizeof(ef));
     if (env) ef = *env;
-    hipLaunchKernelGGL(head_out_kernel, dim3(mansy_ceil_div(B, 4), 1), dim3(256), 0, st, ha, W.A1s, nsplit, (long long)B * HID, HID, W.F, MAXOUT, B, u,
+    MANSY_LAUNCH(head_out_kernel, dim3(mansy_ceil_div(B, 4), 1), dim3(256), 0, st, ha, W.A1s, nsplit, (long long)B * HID, HID, W.F, MAXOUT, B, u,
                        seed, site, none, ef);
     MANSY_LAUNCH_CHECK();
     return MANSY_OK;
@@ -1026,7 +1027,7 @@ struct PEng {
     const int req = head_split_request(B, 2 * HID);
     const int nsplit = mansy_gemm_effective_splits(FEAT, req);
     MANSY_REQUIRE(nsplit <= MAX_SLABS, "head_pair: %d K splits exceed the slab sum's unroll", nsplit);
-    GemmEpilogue ep; ep.split_slab = (long long)B * 2 * HID;
+    GemmEpilogue ep; ep.prec = prec; ep.split_slab = (long long)B * 2 * HID;
     RC(mansy_launch_gemm_f32(W.F, FEAT, 0, W.Wfc2, FEAT, 0, W.A1s, 2 * HID, B, 2 * HID, FEAT, ep, 0, req, st));
     HeadOutArgs ha;
     ha.h[0] = {W.A1a, a.fc_b, a.out_w, a.out_b, NACT, 0, W.Ha, W.outa, 0, nullptr, nullptr, 0};
@@ -1035,7 +1036,7 @@ struct PEng {
     LossFuse lf; memset(&lf, 0, sizeof(lf));
     if (fuse) lf = *fuse;
     EnvFuse noenv; memset(&noenv, 0, sizeof(noenv));
-    hipLaunchKernelGGL(head_out_kernel, dim3(mansy_ceil_div(B, 4), 2), dim3(256), 0, st, ha, W.A1s, nsplit, (long long)B * 2 * HID, 2 * HID, W.F, MAXOUT,
+    MANSY_LAUNCH(head_out_kernel, dim3(mansy_ceil_div(B, 4), 2), dim3(256), 0, st, ha, W.A1s, nsplit, (long long)B * 2 * HID, 2 * HID, W.F, MAXOUT,
                        B, nullptr, 0u, 0u, lf, noenv);
     MANSY_LAUNCH_CHECK();
     return MANSY_OK;
@@ -1046,13 +1047,13 @@ struct PEng {
     hb.h[0] = {g, MAXOUT, A1, H, n.out_w, n_out, dH, dA1, HID, n.gout_w, n.gout_b};
     hb.h[1] = hb.h[0];
     LossFinish nofin; memset(&nofin, 0, sizeof(nofin));
-    hipLaunchKernelGGL(head_out_bwd_kernel, dim3(min(mansy_ceil_div(B, 2), 128), 1), dim3(256), 0, st, hb, B, nofin);
+    MANSY_LAUNCH(head_out_bwd_kernel, dim3(min(mansy_ceil_div(B, 2), 128), 1), dim3(256), 0, st, hb, B, nofin);
     MANSY_LAUNCH_CHECK();
-    GemmEpilogue acc; acc.accumulate = 1; acc.a_rowsum = n.gfc_b;                                           // gfc_b += column sums of dA1
+    GemmEpilogue acc; acc.prec = prec; acc.accumulate = 1; acc.a_rowsum = n.gfc_b;                                           // gfc_b += column sums of dA1
     RC(mansy_launch_gemm_f32(dA1, HID, 1, W.F, FEAT, 1, n.gfc_w, FEAT, HID, FEAT, B, acc, 0, 0, st));      // gfc_w += dA1^T F
     MANSY_REQUIRE(!accumulate_dF, "head_bwd: accumulating dF is not supported with the fused LeakyReLU-derivative epilogue");
     // dPre = (dA1 Wfc + [dH in the residual columns]) * leaky'(F): residual join + derivative in the product's epilogue
-    GemmEpilogue ep; ep.pre_a = dH; ep.pre_ld = HID; ep.pre_col0 = RESID_COL; ep.mask_src = W.F; ep.mask_ld = FEAT; ep.mask_scale = 1.f; ep.mask_neg = SLOPE;
+    GemmEpilogue ep; ep.prec = prec; ep.pre_a = dH; ep.pre_ld = HID; ep.pre_col0 = RESID_COL; ep.mask_src = W.F; ep.mask_ld = FEAT; ep.mask_scale = 1.f; ep.mask_neg = SLOPE;
     return mansy_launch_gemm_f32(dA1, HID, 0, n.fc_w, FEAT, 1, W.dF, FEAT, B, FEAT, HID, ep, 0, 0, st);
   }
   // both heads' backward: one output-layer launch, the two fc weight gradients, ONE dF = [dA1a | dA1c] [Wfc_a ; Wfc_c] product
@@ -1062,32 +1063,32 @@ struct PEng {
     hb.h[1] = {W.gout_c, MAXOUT, W.A1c, W.Hc, c.out_w, 1, W.dHc, W.dA1p + HID, 2 * HID, c.gout_w, c.gout_b};
     LossFinish fin; memset(&fin, 0, sizeof(fin));
     if (finish) fin = *finish;
-    hipLaunchKernelGGL(head_out_bwd_kernel, dim3(min(mansy_ceil_div(B, 2), HB_BLOCKS), 2), dim3(256), 0, st, hb, B, fin);
+    MANSY_LAUNCH(head_out_bwd_kernel, dim3(min(mansy_ceil_div(B, 2), HB_BLOCKS), 2), dim3(256), 0, st, hb, B, fin);
     MANSY_LAUNCH_CHECK();
-    GemmEpilogue acc; acc.accumulate = 1;           // gfc_w_{a,c} += dA1_{a,c}^T F, gfc_b_{a,c} += column sums: two products, one launch
+    GemmEpilogue acc; acc.prec = prec; acc.accumulate = 1;           // gfc_w_{a,c} += dA1_{a,c}^T F, gfc_b_{a,c} += column sums: two products, one launch
     acc.a_rowsum = a.gfc_b;
     acc.pair_A = W.dA1p + HID; acc.pair_B = W.F; acc.pair_C = c.gfc_w; acc.pair_rowsum = c.gfc_b;
     RC(mansy_launch_gemm_f32(W.dA1p, 2 * HID, 1, W.F, FEAT, 1, a.gfc_w, FEAT, HID, FEAT, B, acc, 0, 0, st));
     // dPre = ([dA1a | dA1c] [Wfc_a ; Wfc_c] + [dHa + dHc in the residual columns]) * leaky'(F) -- the former featgrad_finish launch
-    GemmEpilogue ep; ep.pre_a = W.dHa; ep.pre_b = W.dHc; ep.pre_ld = HID; ep.pre_col0 = RESID_COL;
+    GemmEpilogue ep; ep.prec = prec; ep.pre_a = W.dHa; ep.pre_b = W.dHc; ep.pre_ld = HID; ep.pre_col0 = RESID_COL;
     ep.mask_src = W.F; ep.mask_ld = FEAT; ep.mask_scale = 1.f; ep.mask_neg = SLOPE;
     return mansy_launch_gemm_f32(W.dA1p, 2 * HID, 0, W.Wfc2, FEAT, 1, W.dF, FEAT, B, FEAT, 2 * HID, ep, 0, 0, st);
   }
   // head_bwd without the output-layer launch (the identifier's training step): dA1 / dH were written by head_out_kernel
   int fc_bwd_single(const NetP& n, int B, const float* dA1, const float* dH) {
-    GemmEpilogue acc; acc.accumulate = 1; acc.a_rowsum = n.gfc_b;
+    GemmEpilogue acc; acc.prec = prec; acc.accumulate = 1; acc.a_rowsum = n.gfc_b;
     RC(mansy_launch_gemm_f32(dA1, HID, 1, W.F, FEAT, 1, n.gfc_w, FEAT, HID, FEAT, B, acc, 0, 0, st));
-    GemmEpilogue ep; ep.pre_a = dH; ep.pre_ld = HID; ep.pre_col0 = RESID_COL; ep.mask_src = W.F; ep.mask_ld = FEAT; ep.mask_scale = 1.f; ep.mask_neg = SLOPE;
+    GemmEpilogue ep; ep.prec = prec; ep.pre_a = dH; ep.pre_ld = HID; ep.pre_col0 = RESID_COL; ep.mask_src = W.F; ep.mask_ld = FEAT; ep.mask_scale = 1.f; ep.mask_neg = SLOPE;
     return mansy_launch_gemm_f32(dA1, HID, 0, n.fc_w, FEAT, 1, W.dF, FEAT, B, FEAT, HID, ep, 0, 0, st);
   }
   // head_bwd_pair without the output-layer launch: head_out_kernel wrote dH / dA1 itself (LossFuse::bwd_*), the output layers' weight
   // gradients are riders of the unpack launch (OutGradRider) -- the PPO minibatch step's form
   int fc_bwd_pair(const NetP& a, const NetP& c, int B) {
-    GemmEpilogue acc; acc.accumulate = 1;
+    GemmEpilogue acc; acc.prec = prec; acc.accumulate = 1;
     acc.a_rowsum = a.gfc_b;
     acc.pair_A = W.dA1p + HID; acc.pair_B = W.F; acc.pair_C = c.gfc_w; acc.pair_rowsum = c.gfc_b;
     RC(mansy_launch_gemm_f32(W.dA1p, 2 * HID, 1, W.F, FEAT, 1, a.gfc_w, FEAT, HID, FEAT, B, acc, 0, 0, st));
-    GemmEpilogue ep; ep.pre_a = W.dHa; ep.pre_b = W.dHc; ep.pre_ld = HID; ep.pre_col0 = RESID_COL;
+    GemmEpilogue ep; ep.prec = prec; ep.pre_a = W.dHa; ep.pre_b = W.dHc; ep.pre_ld = HID; ep.pre_col0 = RESID_COL;
     ep.mask_src = W.F; ep.mask_ld = FEAT; ep.mask_scale = 1.f; ep.mask_neg = SLOPE;
     return mansy_launch_gemm_f32(W.dA1p, 2 * HID, 0, W.Wfc2, FEAT, 1, W.dF, FEAT, B, FEAT, 2 * HID, ep, 0, 0, st);
   }
@@ -1103,18 +1104,18 @@ struct PEng {
     // ~3 K-tiles per split: the 42 running tiles are one workgroup each, and a lone workgroup per CU waits a full memory round trip
     // per K-tile (2 us at K = 3 264 from HBM), so the reduce dimension is what fills the chip
     int req = std::min(DW_SLABS, std::max(1, (Bmain / 32 + 2) / 3));
-    if (mansy_get_gemm_precision() != 0) req = std::min(req, 6);            // the split-bf16 loops run (and store) every tile of every slab
+    if (prec != 0) req = std::min(req, 6);            // the split-bf16 loops run (and store) every tile of every slab
     const int nsplit = mansy_gemm_effective_splits(Bmain, req);
     const long long slab = (long long)FEAT * K;
     MANSY_REQUIRE(nsplit <= DW_SLABS, "featnet_bwd: %d slabs exceed the workspace", nsplit);
     const int active = active_tiles(identifier, K, nullptr);             // host copy of the geometry pack_wbd_kernel writes
     MANSY_REQUIRE(active <= DW_TILES_MAX, "featnet_bwd: %d tiles exceed the list", active);
-    GemmEpilogue ep; ep.a_rowsum = W.dbbd; ep.tile_nrange = W.krange; ep.split_slab = nsplit > 1 ? slab : 0;
+    GemmEpilogue ep; ep.prec = prec; ep.a_rowsum = W.dbbd; ep.tile_nrange = W.krange; ep.split_slab = nsplit > 1 ? slab : 0;
     ep.tile_list = W.tlist; ep.tile_list_n = active;
     ep.flops_frac = (float)active / (float)(FEAT / 64 * mansy_ceil_div(K, 64));
     RC(mansy_launch_gemm_f32(W.dF, FEAT, 1, obs, OBS_LD, 1, W.dWbd, K, FEAT, K, Bmain, ep, 64, nsplit > 1 ? req : 1, st));
     if (Bmain < B) {                                                        // the < 32 leftover rows: added into slab 0
-      GemmEpilogue tail; tail.a_rowsum = W.dbbd; tail.tile_nrange = W.krange; tail.accumulate = 1; tail.flops_frac = ep.flops_frac;
+      GemmEpilogue tail; tail.prec = prec; tail.a_rowsum = W.dbbd; tail.tile_nrange = W.krange; tail.accumulate = 1; tail.flops_frac = ep.flops_frac;
       tail.tile_list = W.tlist; tail.tile_list_n = active;
       RC(mansy_launch_gemm_f32(W.dF + (size_t)Bmain * FEAT, FEAT, 1, obs + (size_t)Bmain * OBS_LD, OBS_LD, 1, W.dWbd, K, FEAT, K, B - Bmain, tail,
                                -64, 1, st));
@@ -1126,7 +1127,7 @@ struct PEng {
     MANSY_REQUIRE(!norm_tail || (reinterpret_cast<uintptr_t>(norm_tail) & 15) == 0, "featnet_bwd: gradient tail must be 16-byte aligned");
     OutGradRider og; memset(&og, 0, sizeof(og));
     if (out_grad) og = *out_grad;
-    hipLaunchKernelGGL(unpack_dwbd_kernel, dim3(main_blocks + tail_blocks + (og.on ? OG_BLOCKS : 0)), dim3(256), 0, st, W.dWbd, nsplit, slab, W.dbbd,
+    MANSY_LAUNCH(unpack_dwbd_kernel, dim3(main_blocks + tail_blocks + (og.on ? OG_BLOCKS : 0)), dim3(256), 0, st, W.dWbd, nsplit, slab, W.dbbd,
                        identifier, K, u, nr, og, (int)(main_blocks + tail_blocks));
     MANSY_LAUNCH_CHECK();
     return MANSY_OK;
@@ -1147,7 +1148,7 @@ struct PEng {
     const int adam_blocks = (int)mansy_ceil_div(n, 256);
     const int rider_blocks = 1 + (next_idx ? (int)mansy_ceil_div((long long)next_mb * (OBS_LD / 4), 256) : 0);
     const double bc1 = 1.0 - pow(0.9, (double)step), bc2 = 1.0 - pow(0.999, (double)step);
-    hipLaunchKernelGGL(step_tail_kernel, dim3(adam_blocks + rider_blocks), dim3(256), 0, st, flat_p, flat_g, m, v, n, lr, 0.9f, 0.999f, 1e-8f, wd,
+    MANSY_LAUNCH(step_tail_kernel, dim3(adam_blocks + rider_blocks), dim3(256), 0, st, flat_p, flat_g, m, v, n, lr, 0.9f, 0.999f, 1e-8f, wd,
                        (float)bc1, (float)sqrt(bc2), parts_cur, max_norm, tab, W.Wbd, W.bbd, W.Wfc2, nx, adam_blocks);
     MANSY_LAUNCH_CHECK();
     return MANSY_OK;
@@ -1158,8 +1159,8 @@ struct PEng {
   int clip_and_adam(float* flat_p, float* flat_g, float* m, float* v, long long n, float max_norm, float lr, float wd, int step,
                     long long tail_from = -1, int tail_step = 0, bool have_sumsq = false) {
     if (max_norm > 0.f) {
-      if (!have_sumsq) hipLaunchKernelGGL(sumsq_kernel, dim3(NORM_PARTS), dim3(256), 0, st, flat_g, n, W.acc);
-      if (step <= 0) hipLaunchKernelGGL(clip_scale_kernel, dim3(256), dim3(256), 0, st, flat_g, n, W.acc, max_norm);   // parity tests: clipped gradients
+      if (!have_sumsq) MANSY_LAUNCH(sumsq_kernel, dim3(NORM_PARTS), dim3(256), 0, st, flat_g, n, W.acc);
+      if (step <= 0) MANSY_LAUNCH(clip_scale_kernel, dim3(256), dim3(256), 0, st, flat_g, n, W.acc, max_norm);   // parity tests: clipped gradients
       MANSY_LAUNCH_CHECK();
     }
     if (step <= 0) return MANSY_OK;
@@ -1176,7 +1177,7 @@ struct PEng {
         continue;
       }
       const double bc1 = 1.0 - pow(0.9, (double)stp), bc2 = 1.0 - pow(0.999, (double)stp);
-      hipLaunchKernelGGL(clip_adam_kernel, dim3(mansy_ceil_div(cnt, 256)), dim3(256), 0, st, flat_p + o, flat_g + o, m + o, v + o, cnt, lr, 0.9f,
+      MANSY_LAUNCH(clip_adam_kernel, dim3(mansy_ceil_div(cnt, 256)), dim3(256), 0, st, flat_p + o, flat_g + o, m + o, v + o, cnt, lr, 0.9f,
                          0.999f, 1e-8f, wd, (float)bc1, (float)sqrt(bc2), W.acc, max_norm);
     }
     MANSY_LAUNCH_CHECK();
@@ -1184,7 +1185,9 @@ struct PEng {
   }
 };
 
-int setup(void* ws, int maxB, hipStream_t st, PEng& e) {
+int setup(void* ws, int maxB, int precision, hipStream_t st, PEng& e) {
+  MANSY_REQUIRE(precision < 0 || precision == 0 || precision == 3 || precision == 6, "precision must be MANSY_PREC_DEFAULT (-1), 0, 3 or 6 (got %d)", precision);
+  e.prec = precision >= 0 ? precision : mansy_get_gemm_precision();
   MANSY_REQUIRE(ws && maxB >= 1, "ppo: bad workspace / batch");
   e.st = st;
   ppo_layout(maxB, (char*)ws, e.W);
@@ -1209,9 +1212,9 @@ size_t mansy_ppo_workspace_bytes(int max_batch) { PWork W; return max_batch >= 1
 
 // logits [B,16] (15 used), value [B] (nullable => actor only), optional sampling (act/logp; u nullable => hash RNG)
 int mansy_policy_forward(const float* const* params, const float* obs, int B, float* logits, float* value, int* act, float* logp,
-                         const float* u, uint32_t seed, uint32_t site, int reuse_packed, void* workspace, int max_batch, void* stream) {
+                         const float* u, uint32_t seed, uint32_t site, int reuse_packed, void* workspace, int max_batch, int precision, void* stream) {
   MANSY_REQUIRE(params && obs && B >= 1 && B <= max_batch, "policy_forward: bad arguments (B=%d, max_batch=%d)", B, max_batch);
-  PEng e; RC(setup(workspace, max_batch, (hipStream_t)stream, e));
+  PEng e; RC(setup(workspace, max_batch, precision, (hipStream_t)stream, e));
   NetP a, c; bind_net(params, nullptr, 20, a); bind_net(params, nullptr, 24, c);
   if (!reuse_packed) RC(e.pack(a, 0));      // rollouts: the block-diagonal image of the (unchanged) parameters is packed once per collect
   RC(e.featnet(obs, B, 0));
@@ -1225,12 +1228,12 @@ int mansy_policy_forward(const float* const* params, const float* obs, int B, fl
 int mansy_policy_env_step(const float* const* params, const float* obs, int n_env, float* logits, int* act, float* logp, const float* u,
                           uint32_t seed, uint32_t site, int reuse_packed, void* workspace, int max_batch, const mansy_env_tables* T, void* env_state,
                           float* obs_next, float* obs_cur, float* reward, unsigned char* done, float* qoe_parts, const mansy_env_episode_log* elog,
-                          void* stream) {
+                          int precision, void* stream) {
   MANSY_REQUIRE(params && obs && act && n_env >= 1 && n_env <= max_batch, "policy_env_step: bad arguments (n_env=%d, max_batch=%d)", n_env, max_batch);
   MANSY_REQUIRE(T && env_state && obs_next && reward && done, "policy_env_step: null environment pointer");
   MANSY_REQUIRE(T->size && T->quality && T->video_len && T->vp_gt && T->vp_pred && T->vp_acc && T->vp_start && T->vp_end && T->trace_bw &&
                     T->trace_len && T->samples && T->qoe_w && T->n_sample >= 1, "policy_env_step: incomplete tables");
-  PEng e; RC(setup(workspace, max_batch, (hipStream_t)stream, e));
+  PEng e; RC(setup(workspace, max_batch, precision, (hipStream_t)stream, e));
   NetP a; bind_net(params, nullptr, 20, a);
   if (!reuse_packed) RC(e.pack(a, 0));
   RC(e.featnet(obs, n_env, 0));
@@ -1241,9 +1244,9 @@ int mansy_policy_env_step(const float* const* params, const float* obs, int n_en
   return e.head(a, n_env, NACT, 0, e.W.A1a, e.W.Ha, logits ? logits : e.W.outa, u, seed, site, act, logp, &ef);
 }
 
-int mansy_identifier_forward(const float* const* params, const float* obs, int B, float* pred, void* workspace, int max_batch, void* stream) {
+int mansy_identifier_forward(const float* const* params, const float* obs, int B, float* pred, void* workspace, int max_batch, int precision, void* stream) {
   MANSY_REQUIRE(params && obs && pred && B >= 1 && B <= max_batch, "identifier_forward: bad arguments");
-  PEng e; RC(setup(workspace, max_batch, (hipStream_t)stream, e));
+  PEng e; RC(setup(workspace, max_batch, precision, (hipStream_t)stream, e));
   NetP n; bind_net(params, nullptr, 20, n);
   RC(e.pack(n, 1));
   RC(e.featnet(obs, B, 1));
@@ -1256,9 +1259,9 @@ int mansy_identifier_forward(const float* const* params, const float* obs, int B
 // the PPO minibatch step gathers its rows -- no separate gather launch, no shuffled copy of the buffer)
 int mansy_identifier_train_step(const float* const* params, float* const* grads, float* flat_p, float* flat_g, float* flat_m, float* flat_v,
                                 long long n_flat, const float* obs_all, const int* idx, int B, float lr, float weight_decay, int step, float* loss_out,
-                                void* workspace, int max_batch, void* stream) {
+                                void* workspace, int max_batch, int precision, void* stream) {
   MANSY_REQUIRE(params && obs_all && loss_out && B >= 1 && B <= max_batch, "identifier_train_step: bad arguments");
-  PEng e; RC(setup(workspace, max_batch, (hipStream_t)stream, e));
+  PEng e; RC(setup(workspace, max_batch, precision, (hipStream_t)stream, e));
   NetP n; bind_net(params, grads, 20, n);
   const bool train = step != 0;
   MANSY_REQUIRE(!train || (grads && flat_p && flat_g && flat_m && flat_v), "identifier_train_step: null optimiser buffers");
@@ -1267,7 +1270,7 @@ int mansy_identifier_train_step(const float* const* params, float* const* grads,
   RC(e.featnet(obs, B, 1));
   if (!train) {          // validation: loss only (W.acc[0..1], the accumulator and the arrival counter, were zeroed by the pack launch's riders)
     RC(e.head(n, B, 3, 1, e.W.A1a, e.W.Ha, e.W.outa, nullptr, 0, 0, nullptr, nullptr));
-    hipLaunchKernelGGL(ident_mse_kernel, dim3(min(mansy_ceil_div(B * 3, 256), 256)), dim3(256), 0, e.st, e.W.outa, obs, B, nullptr, e.W.acc, loss_out);
+    MANSY_LAUNCH(ident_mse_kernel, dim3(min(mansy_ceil_div(B * 3, 256), 256)), dim3(256), 0, e.st, e.W.outa, obs, B, nullptr, e.W.acc, loss_out);
     MANSY_LAUNCH_CHECK();
     return MANSY_OK;
   }
@@ -1289,9 +1292,9 @@ int mansy_identifier_train_step(const float* const* params, float* const* grads,
 }
 
 int mansy_identifier_relabel(const float* const* params, const float* obs, float* rew, float* id_rew, int B, float lamb, void* workspace,
-                             int max_batch, void* stream) {
+                             int max_batch, int precision, void* stream) {
   MANSY_REQUIRE(params && obs && rew && B >= 1 && B <= max_batch, "identifier_relabel: bad arguments");
-  PEng e; RC(setup(workspace, max_batch, (hipStream_t)stream, e));
+  PEng e; RC(setup(workspace, max_batch, precision, (hipStream_t)stream, e));
   NetP n; bind_net(params, nullptr, 20, n);
   RC(e.pack(n, 1));
   RC(e.featnet(obs, B, 1));
@@ -1304,10 +1307,10 @@ int mansy_identifier_relabel(const float* const* params, const float* obs, float
 // n_logp: log-probabilities are wanted for the first n_logp rows only (process_fn evaluates obs and obs_next -- 2 x 4096 rows of
 // one buffer -- in ONE pass: values for all rows, log-probabilities of the taken actions for the obs half)
 int mansy_policy_evaluate(const float* const* params, const float* obs, int B, const int* act, int n_logp, float* logp, float* value, void* workspace,
-                          int max_batch, void* stream) {
+                          int max_batch, int precision, void* stream) {
   MANSY_REQUIRE(params && obs && B >= 1 && B <= max_batch, "policy_evaluate: bad arguments");
   MANSY_REQUIRE(!logp || (n_logp >= 1 && n_logp <= B), "policy_evaluate: n_logp must be in [1, B] when log-probabilities are wanted");
-  PEng e; RC(setup(workspace, max_batch, (hipStream_t)stream, e));
+  PEng e; RC(setup(workspace, max_batch, precision, (hipStream_t)stream, e));
   NetP a, c; bind_net(params, nullptr, 20, a); bind_net(params, nullptr, 24, c);
   const bool both = logp && value;
   RC(e.pack(a, 0, both ? &c : nullptr));
@@ -1330,16 +1333,16 @@ int mansy_gae_returns(const float* rew, const float* v_s, const float* v_next, c
   const long long n = (long long)T * N;
   double* part = scratch + n;
   if (N <= 1024) {
-    hipLaunchKernelGGL(gae_fused_kernel, dim3(1), dim3(1024), 0, st, rew, v_s, v_next, done, T, N, (double)gamma, (double)gae_lambda, rms, rew_norm, 1e-8,
+    MANSY_LAUNCH(gae_fused_kernel, dim3(1), dim3(1024), 0, st, rew, v_s, v_next, done, T, N, (double)gamma, (double)gae_lambda, rms, rew_norm, 1e-8,
                        scratch, adv, returns);
     MANSY_LAUNCH_CHECK();
     return MANSY_OK;
   }
-  hipLaunchKernelGGL(gae_kernel, dim3(mansy_ceil_div(N, 256)), dim3(256), 0, st, rew, v_s, v_next, done, T, N, (double)gamma, (double)gae_lambda,
+  MANSY_LAUNCH(gae_kernel, dim3(mansy_ceil_div(N, 256)), dim3(256), 0, st, rew, v_s, v_next, done, T, N, (double)gamma, (double)gae_lambda,
                      rms, rew_norm, 1e-8, scratch, adv);
-  hipLaunchKernelGGL(ret_stats_kernel, dim3(1), dim3(1024), 0, st, scratch, n, part);
-  hipLaunchKernelGGL(ret_finish_kernel, dim3(mansy_ceil_div(n, 256)), dim3(256), 0, st, scratch, n, rms, rew_norm, 1e-8, returns);
-  if (rew_norm) hipLaunchKernelGGL(rms_merge_kernel, dim3(1), dim3(1), 0, st, rms, part, n);
+  MANSY_LAUNCH(ret_stats_kernel, dim3(1), dim3(1024), 0, st, scratch, n, part);
+  MANSY_LAUNCH(ret_finish_kernel, dim3(mansy_ceil_div(n, 256)), dim3(256), 0, st, scratch, n, rms, rew_norm, 1e-8, returns);
+  if (rew_norm) MANSY_LAUNCH(rms_merge_kernel, dim3(1), dim3(1), 0, st, rms, part, n);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }
@@ -1351,12 +1354,12 @@ int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, fl
                              const float* logp_old_all, const float* v_old_all, const float* ret_all, int mb, float eps_clip, float vf_coef,
                              float ent_coef, int norm_adv, int value_clip, float dual_clip, float max_grad_norm, float lr, float weight_decay, int step,
                              long long tail_from, int tail_step, float* stats, void* workspace, int max_batch, int chain_in,
-                             const int* next_idx, int next_mb, void* stream) {
+                             const int* next_idx, int next_mb, int precision, void* stream) {
   MANSY_REQUIRE(params && grads && flat_p && flat_g && flat_m && flat_v && obs_all && act_all && adv_all && logp_old_all && v_old_all && ret_all,
                 "ppo_minibatch_step: null pointer");
   MANSY_REQUIRE(mb >= 2 && mb <= max_batch, "ppo_minibatch_step: bad minibatch size");
   MANSY_REQUIRE(dual_clip == 0.f || dual_clip > 1.f, "ppo_minibatch_step: dual_clip must be 0 (off) or > 1 (tianshou asserts the same)");
-  PEng e; RC(setup(workspace, max_batch, (hipStream_t)stream, e));
+  PEng e; RC(setup(workspace, max_batch, precision, (hipStream_t)stream, e));
   NetP a, c; bind_net(params, grads, 20, a); bind_net(params, grads, 24, c);
   // one prologue launch: re-pack the block-diagonal / stacked weights, gather the minibatch rows, zero the gradient buffer
   const float* obs = idx ? e.W.obs_mb : obs_all;
@@ -1416,15 +1419,15 @@ int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, fl
 // :71-78; stats[1] is the plain cross entropy).  stats: [loss, cross entropy, mean entropy].
 int mansy_bc_step(const float* const* params, float* const* grads, float* flat_p, float* flat_g, float* flat_m, float* flat_v,
                   long long n_flat, long long n_update, const float* obs, const int* act, int B, float ent_coef, float lr,
-                  float weight_decay, int step, float* stats, void* workspace, int max_batch, void* stream) {
+                  float weight_decay, int step, float* stats, void* workspace, int max_batch, int precision, void* stream) {
   MANSY_REQUIRE(params && obs && act && stats && B >= 1 && B <= max_batch, "bc_step: bad arguments");
   MANSY_REQUIRE(step <= 0 || (grads && flat_p && flat_g && flat_m && flat_v && n_update >= 1 && n_update <= n_flat), "bc_step: bad buffers");
-  PEng e; RC(setup(workspace, max_batch, (hipStream_t)stream, e));
+  PEng e; RC(setup(workspace, max_batch, precision, (hipStream_t)stream, e));
   NetP a, c; bind_net(params, grads, 20, a); bind_net(params, grads, 24, c);
   RC(e.pack(a, 0, &c, nullptr, nullptr, B, step > 0 ? flat_g : nullptr, step > 0 ? n_flat : 0));
   RC(e.featnet(obs, B, 0));
   RC(e.head_pair(a, c, B));
-  hipLaunchKernelGGL(bc_loss_kernel, dim3(1), dim3(1024), 0, e.st, e.W.outa, act, B, ent_coef, e.W.gout, e.W.gout_c, stats);
+  MANSY_LAUNCH(bc_loss_kernel, dim3(1), dim3(1024), 0, e.st, e.W.outa, act, B, ent_coef, e.W.gout, e.W.gout_c, stats);
   MANSY_LAUNCH_CHECK();
   if (step <= 0) return MANSY_OK;
   RC(e.head_bwd_pair(a, c, B));
@@ -1438,11 +1441,11 @@ int mansy_bc_step(const float* const* params, float* const* grads, float* flat_p
 // gathers the next minibatch and takes its advantage statistics, so that the next mansy_ppo_minibatch_step passes chain_in = 1.
 int mansy_ppo_dp_tail(const float* const* params, float* flat_p, float* flat_g, float* flat_m, float* flat_v, long long n_flat, float max_grad_norm,
                       float lr, float weight_decay, int step, double* scratch, int have_sumsq, const float* obs_all, const float* adv_all,
-                      const int* next_idx, int next_mb, void* workspace, int max_batch, void* stream) {
+                      const int* next_idx, int next_mb, void* workspace, int max_batch, int precision, void* stream) {
   MANSY_REQUIRE(params && flat_p && flat_g && flat_m && flat_v && scratch && step >= 1 && max_grad_norm > 0.f, "ppo_dp_tail: bad arguments");
   MANSY_REQUIRE(next_mb >= 0 && next_mb <= max_batch && (next_mb == 0 || (obs_all && adv_all)), "ppo_dp_tail: bad next minibatch");
-  PEng e; RC(setup(workspace, max_batch, (hipStream_t)stream, e));
-  if (!have_sumsq) { hipLaunchKernelGGL(sumsq_kernel, dim3(NORM_PARTS), dim3(256), 0, e.st, flat_g, n_flat, scratch); MANSY_LAUNCH_CHECK(); }
+  PEng e; RC(setup(workspace, max_batch, precision, (hipStream_t)stream, e));
+  if (!have_sumsq) { MANSY_LAUNCH(sumsq_kernel, dim3(NORM_PARTS), dim3(256), 0, e.st, flat_g, n_flat, scratch); MANSY_LAUNCH_CHECK(); }
   return e.step_tail(params, flat_p, flat_g, flat_m, flat_v, n_flat, max_grad_norm, lr, weight_decay, step, scratch, e.W.acc + NORM_PARTS_C, obs_all,
                      next_idx, next_mb, adv_all);
 }

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void tilemap_metrics_kernel(const unsigned lon
 int mansy_launch_tilemap_metrics(const unsigned long long* gt, const unsigned long long* pred, long long n, double* out, hipStream_t st) {
   if (n <= 0) return MANSY_OK;                      // empty input: nothing to do (pointers of empty buffers may be null)
   MANSY_REQUIRE(gt && pred && out, "tilemap_metrics: null pointer");
-  hipLaunchKernelGGL(tilemap_metrics_kernel, dim3(mansy_ceil_div(n, 256)), dim3(256), 0, st, gt, pred, n, out);
+  MANSY_LAUNCH(tilemap_metrics_kernel, dim3(mansy_ceil_div(n, 256)), dim3(256), 0, st, gt, pred, n, out);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }
@@ -122,16 +122,16 @@ int mansy_launch_tilemap(const float* xy, long long n, int W, int H, int nw, int
   if (n <= 0) return MANSY_OK;
   MANSY_REQUIRE(xy && maps, "tilemap: null pointer");
   if (W == 2560 && H == 1440 && nw == 8 && nh == 8 && fov_w == 600 && fov_h == 300)
-    hipLaunchKernelGGL(tilemap_kernel<true>, dim3(mansy_ceil_div(n, 256)), dim3(256), 0, st, xy, n, W, H, nw, nh, fov_w, fov_h, maps);
+    MANSY_LAUNCH(tilemap_kernel<true>, dim3(mansy_ceil_div(n, 256)), dim3(256), 0, st, xy, n, W, H, nw, nh, fov_w, fov_h, maps);
   else
-    hipLaunchKernelGGL(tilemap_kernel<false>, dim3(mansy_ceil_div(n, 256)), dim3(256), 0, st, xy, n, W, H, nw, nh, fov_w, fov_h, maps);
+    MANSY_LAUNCH(tilemap_kernel<false>, dim3(mansy_ceil_div(n, 256)), dim3(256), 0, st, xy, n, W, H, nw, nh, fov_w, fov_h, maps);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }
 int mansy_launch_tilemap_iou(const unsigned long long* a, const unsigned long long* b, long long n, double* iou, hipStream_t st) {
   if (n <= 0) return MANSY_OK;
   MANSY_REQUIRE(a && b && iou, "tilemap_iou: null pointer");
-  hipLaunchKernelGGL(tilemap_iou_kernel, dim3(mansy_ceil_div(n, 256)), dim3(256), 0, st, a, b, n, iou);
+  MANSY_LAUNCH(tilemap_iou_kernel, dim3(mansy_ceil_div(n, 256)), dim3(256), 0, st, a, b, n, iou);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }
@@ -139,7 +139,7 @@ int mansy_launch_tilemap_or_groups(const unsigned long long* maps, long long ngr
   MANSY_REQUIRE(group >= 1, "tilemap_or: bad group size");
   if (ngroups <= 0) return MANSY_OK;
   MANSY_REQUIRE(maps && out, "tilemap_or: null pointer");
-  hipLaunchKernelGGL(tilemap_or_kernel, dim3(mansy_ceil_div(ngroups, 256)), dim3(256), 0, st, maps, ngroups, group, out);
+  MANSY_LAUNCH(tilemap_or_kernel, dim3(mansy_ceil_div(ngroups, 256)), dim3(256), 0, st, maps, ngroups, group, out);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }

@@ -221,6 +221,7 @@ int check_cfg(const mansy_vp_config* c) {
   MANSY_REQUIRE(c->in_ch >= 1 && c->in_ch <= 8 && c->in_ch % 3 == 0, "vp: in_ch must be 3*in_channel <= 8");
   MANSY_REQUIRE(c->max_len >= c->S && c->max_len >= c->T, "vp: positional table too short");
   MANSY_REQUIRE(c->p_pe >= 0.f && c->p_pe < 1.f && c->p_drop >= 0.f && c->p_drop < 1.f, "vp: dropout p outside [0,1)");
+  MANSY_REQUIRE(c->precision < 0 || c->precision == 0 || c->precision == 3 || c->precision == 6, "vp: precision must be MANSY_PREC_DEFAULT (-1), 0, 3 or 6 (got %d)", c->precision);
   return MANSY_OK;
 }
 
@@ -238,6 +239,7 @@ struct Eng {
 
   Eng(const mansy_vp_config& cfg, hipStream_t s, bool tr, uint32_t sd) : c(cfg), st(s), train(tr), seed(sd) {
     wtab.n = 0;
+    prec = c.precision >= 0 ? c.precision : mansy_get_gemm_precision();      // MANSY_PREC_DEFAULT: the deprecated process-wide mode
     B = c.B; S = c.S; T = c.T; d = c.d_model; f = c.d_ff; H = c.n_head; dh = d / H; M = (S - 1) / 2 + 1;
     N = B * S; TB = T * B; C6 = c.in_ch;
     drop_scale = (train && c.p_drop > 0.f) ? 1.f / (1.f - c.p_drop) : 1.f;
@@ -253,7 +255,6 @@ struct Eng {
   // once per engine call that runs products: split every GEMM weight into planes (order == param_table order, so the offsets
   // add up to the workspace size computed there)
   int prepare_planes() {
-    prec = mansy_get_gemm_precision();
     wtab.n = 0;
     // bf16x3 only: measured +4 % on the forward / dX products (tools/gemm_bench.py --planes).  bf16x6 stays on the in-loop split:
     // two LDS stages of three planes leave one workgroup per CU and ran 8-15 % SLOWER with pre-split weights.
@@ -293,7 +294,7 @@ struct Eng {
   // Same fp32 operations in the same order as drop(product) stored and then added by the LayerNorm kernel: bit-identical.
   int lin_fwd(const float* X, int rows, int K, const float* w, const float* b, int Nout, float* Y, int relu, MansyDrop drop,
               const float* resid = nullptr) {
-    GemmEpilogue ep; ep.bias = b; ep.relu = relu; ep.drop = drop; ep.resid = resid; ep.resid_ld = Nout;
+    GemmEpilogue ep; ep.prec = prec; ep.bias = b; ep.relu = relu; ep.drop = drop; ep.resid = resid; ep.resid_ld = Nout;
     if (prec) attach_planes(ep, w, false);
     return mansy_launch_gemm_f32(X, K, 0, w, K, 0, Y, Nout, rows, Nout, K, ep, 0, 0, st);
   }
@@ -304,13 +305,13 @@ struct Eng {
   // dX[rows,K] = dY[rows,N] W[N,K] (+resid) (mask)
   int lin_dx(const float* dY, int rows, int Nout, const float* w, int K, float* dX, const float* resid, const float* mask_src,
              float mask_scale) {
-    GemmEpilogue ep; ep.resid = resid; ep.resid_ld = K; ep.mask_src = mask_src; ep.mask_ld = K; ep.mask_scale = mask_scale;
+    GemmEpilogue ep; ep.prec = prec; ep.resid = resid; ep.resid_ld = K; ep.mask_src = mask_src; ep.mask_ld = K; ep.mask_scale = mask_scale;
     if (prec) attach_planes(ep, w, true);
     return mansy_launch_gemm_f32(dY, Nout, 0, w, K, 1, dX, K, rows, K, Nout, ep, 0, 0, st);
   }
   // gw[N,K] += dY[rows,N]^T X[rows,K] ; gb[N] += colsum(dY)
   int lin_dw(const float* dY, const float* X, int rows, int Nout, int K, float* gw, float* gb) {
-    GemmEpilogue ep; ep.accumulate = 1; ep.a_rowsum = gb;      // bias gradient = row sums of dY^T, taken from the staged A tiles
+    GemmEpilogue ep; ep.prec = prec; ep.accumulate = 1; ep.a_rowsum = gb;      // bias gradient = row sums of dY^T, taken from the staged A tiles
     return mansy_launch_gemm_f32(dY, Nout, 1, X, K, 1, gw, K, Nout, K, rows, ep, 0, 0, st);
   }
   int ln_fwd(const float* a, const float* b, const NormP& n, float* z, float* y, float* m, float* r, int rows) {
@@ -368,7 +369,7 @@ struct Eng {
     // DistillLayer: circular conv k=3 as one K=3d GEMM on the im2col image, then BN+ELU+maxpool
     RC(mansy_launch_im2col3(W.enc_out, W.col, B, S, d, st));
     RC(lin_fwd(W.col, N, 3 * d, P.conv.w, P.conv.b, d, W.conv, 0, mansy_no_drop()));
-    DistillShape ds = {B, S, M, d, c.bn_sync_world > 1 ? c.bn_sync_world : 1};
+    DistillShape ds = {B, S, M, d, c.bn_sync_world > 1 ? c.bn_sync_world : 1, c.bn_sync_fn, c.bn_sync_user};
     RC(mansy_launch_distill_fwd(W.conv, P.bn.w, P.bn.b, bn_rm, bn_rv, bn_nbt, W.bn_mean, W.bn_rstd, W.mem, W.argmax, W.stats, ds,
                                 train ? 1 : 0, c.bn_eps, c.bn_momentum, st));
     for (int l = 0; l < c.n_dec; ++l) {
@@ -617,7 +618,7 @@ struct Eng {
       RC(lin_dx(e.dmemkv, B * M, 2 * d, p.ca_in.w + (size_t)d * d, d, W.dmem, l == 0 ? nullptr : W.dmem, nullptr, 1.f));
     }
     // ---- DistillLayer
-    DistillShape ds = {B, S, M, d, c.bn_sync_world > 1 ? c.bn_sync_world : 1};
+    DistillShape ds = {B, S, M, d, c.bn_sync_world > 1 ? c.bn_sync_world : 1, c.bn_sync_fn, c.bn_sync_user};
     RC(mansy_launch_distill_bwd(W.conv, W.dmem, W.argmax, P.bn.w, P.bn.b, W.bn_mean, W.bn_rstd, W.g_a, W.g_b, P.bn.gw, P.bn.gb, W.stats,
                                 ds, st));
     RC(lin_dw(W.g_b, W.col, N, d, 3 * d, P.conv.gw, P.conv.gb));
@@ -626,7 +627,7 @@ struct Eng {
     // Data parallel: every gradient from the first decoder layer to the end of the parameter table (decoder layers, decoder
     // norm, DistillLayer conv + BatchNorm, predictor -- two thirds of the flat buffer) is final here.  The host hook (which = 2)
     // starts their all-reduce on its side stream / second communicator, under the encoder backward that follows.
-    if (c.bn_sync_world > 1) RC(mansy_bn_sync_invoke(2));
+    if (c.bn_sync_world > 1) RC(mansy_bn_sync_invoke(2, c.bn_sync_fn, c.bn_sync_user));
     // ---- encoder
     const float* last = W.enc[c.n_enc - 1].y2;
     RC(ln_bwd(W.g_a, last, W.me, W.re, P.enc_norm, W.g_b, nullptr, mansy_no_drop(), N));

@@ -195,7 +195,7 @@ int mansy_xg_allreduce_avg(void* ctx, float* g, long long n, double* sumsq_parts
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, dev);
   if (wall_khz <= 0) wall_khz = 100000;
   const long long ticks = (long long)(c->timeout_ms * (double)wall_khz);
-  hipLaunchKernelGGL(xg_allreduce_kernel, dim3(XG_BLOCKS), dim3(XG_THREADS), 0, (hipStream_t)stream, g, n / 4, peers, c->own + XG_HEADER_FLOATS + slot_off,
+  MANSY_LAUNCH(xg_allreduce_kernel, dim3(XG_BLOCKS), dim3(XG_THREADS), 0, (hipStream_t)stream, g, n / 4, peers, c->own + XG_HEADER_FLOATS + slot_off,
                      reinterpret_cast<unsigned*>(c->own), slot_off, c->rank, c->world, c->epoch, 1.0f / (float)c->world, sumsq_parts, c->counter,
                      (unsigned)(c->launches * XG_BLOCKS), c->err, ticks);
   MANSY_LAUNCH_CHECK();

@@ -124,8 +124,10 @@ class PeerGradSync:
     fused_sumsq = True
 
     def __init__(self, n_floats, world, rank, device=None, timeout_ms=None):
-        err = self._setup(n_floats, world, rank, device, timeout_ms, tolerant=False)
-        if err is not None:                      # another rank failed its set-up
+        # tolerant set-up here too: a rank whose local set-up fails still takes part in both host exchanges, so that EVERY rank gets
+        # the error and raises together (a rank raising before all_gather_object would leave the others inside the collective)
+        err = self._setup(n_floats, world, rank, device, timeout_ms, tolerant=True)
+        if err is not None:                      # this or another rank failed its set-up
             from ._lib import MansyError
             self.close()
             raise MansyError(err)
@@ -240,20 +242,26 @@ def probe_peer_grad_sync(sizes, world, rank, device, library_sync, iters=10, pro
     n0 = max(sizes)
     g = torch.Generator(device='cpu').manual_seed(4321 + rank)
     src = torch.randn(n0, generator=g).to(device)
-    ref = src.clone()
-    library_sync(ref)
-    out, scratch = src.clone(), torch.zeros(64, dtype=torch.float64, device=device)
+    scratch = torch.zeros(64, dtype=torch.float64, device=device)
     ok, why = 1.0, ''
-    try:
-        peers[n0](out, scratch)
-        torch.cuda.synchronize(device)
-        peers[n0].check()
-        if not torch.allclose(out, ref, rtol=1e-5, atol=1e-6):
-            ok, why = 0.0, f'rank {rank}: peer average differs from the library average by {float((out - ref).abs().max()):.3e}'
-        elif abs(float(scratch.sum()) - float((out.double() ** 2).sum())) > 1e-6 * max(float((out.double() ** 2).sum()), 1e-30):
-            ok, why = 0.0, f'rank {rank}: sums of squares differ'
-    except Exception as e:          # noqa: BLE001
-        ok, why = 0.0, f'rank {rank}: {e}'
+    # correctness on EVERY context (each has its own IPC mappings, flags and epochs: the identifier's 1.05 MB one used to go into
+    # production without ever having been launched), speed on the largest
+    for n in sorted(sizes):
+        ref = src[:n].clone()
+        library_sync(ref)
+        out = src[:n].clone()
+        try:
+            peers[n](out, scratch)
+            torch.cuda.synchronize(device)
+            peers[n].check()
+            if not torch.allclose(out, ref, rtol=1e-5, atol=1e-6):
+                ok, why = 0.0, f'rank {rank}: peer average ({n} floats) differs from the library average by {float((out - ref).abs().max()):.3e}'
+            elif abs(float(scratch.sum()) - float((out.double() ** 2).sum())) > 1e-6 * max(float((out.double() ** 2).sum()), 1e-30):
+                ok, why = 0.0, f'rank {rank}: sums of squares differ ({n} floats)'
+        except Exception as e:          # noqa: BLE001
+            ok, why = 0.0, f'rank {rank}: {e}'
+        if ok < 1.0:
+            break
     if all_min(ok) < 1.0:
         for q in peers.values():
             q.close()

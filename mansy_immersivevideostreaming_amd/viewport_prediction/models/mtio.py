@@ -12,6 +12,7 @@ C-ABI call that enqueues the whole kernel sequence on the current HIP stream.
 """
 import ctypes
 import random
+import weakref
 
 import numpy as np
 import torch
@@ -25,14 +26,17 @@ _N_HEAD = 8          # nn.Transformer default; mtio.py:56-58 never passes nhead
 _ATTN_DROPOUT = 0.1  # nn.Transformer default dropout
 
 
-_BN_SYNC = {'model': None, 'cfg': None}
+# models with SyncBN armed, by the integer that travels as mansy_vp_config::bn_sync_user (weak: a model that is dropped un-registers itself)
+_BN_MODELS = weakref.WeakValueDictionary()
 
 
 def _bn_sync_callback(which, user):
-    """Called by the engine (mansy_set_bn_sync_hook) between the partial-sum kernel and its consumer: all-reduce the
-    2*d_model doubles of the DistillLayer BatchNorm statistics over the data-parallel ranks."""
+    """mansy_vp_config::bn_sync_fn of this model's calls (per call, no process-wide registration): called by the engine between the
+    partial-sum kernel and its consumer: all-reduce the 2*d_model doubles of the DistillLayer BatchNorm statistics over the
+    data-parallel ranks."""
     try:
-        m, cfg = _BN_SYNC['model'], _BN_SYNC['cfg']
+        m = _BN_MODELS[int(user or 0)]
+        cfg = m._bn_cfg
         if which == 2:              # decoder-side gradients are final: start their all-reduce under the encoder backward
             if m._grad_ready is not None:
                 m._grad_ready()
@@ -89,9 +93,9 @@ class ViewportTransformerMTIO(nn.Module):
         self.repeat_prob = repeat_prob
         self.seed = seed
         self.has_bias = bool(bias)
-        # precision of the dense products: None = the process-wide mode (kernels.set_precision; 'f32' unless changed), or
-        # 'f32' (exact fp32 MFMA, the parity mode) / 'bf16x3' / 'bf16x6' (split-bf16 MFMA, csrc/gemm_bf16s.hip) for this
-        # model's calls only; a run-time attribute, not part of the checkpoint
+        # precision of the dense products, carried in every call's mansy_vp_config (ABI 7: no process-wide mode): 'f32' (exact fp32
+        # MFMA, the parity mode) / 'bf16x3' / 'bf16x6' (split-bf16 MFMA, csrc/gemm_bf16s.hip); None = MANSY_PREC_DEFAULT (whatever the
+        # deprecated kernels.set_precision shim holds: 'f32' unless changed).  A run-time attribute, not part of the checkpoint
         self.precision = None
         self._ws = {}
         self._flat_p = None
@@ -109,10 +113,17 @@ class ViewportTransformerMTIO(nn.Module):
         # force it.  Per-kernel timings (bench.py's roofline leg, rocprof kernel stats) are taken with it off: concurrent kernels
         # stretch each other's durations.
         two = True if self.two_stream is None else bool(self.two_stream)
-        return VPConfig(B=B, S=S, T=self.fut_window, d_model=self.d_model, n_head=_N_HEAD, d_ff=self.dim_feedforward,
-                        n_enc=self.num_encoder_layers, n_dec=self.num_decoder_layers, in_ch=self.in_channel * self.num_head,
-                        has_bias=int(self.has_bias), p_pe=self.dropout_p, p_drop=self.attn_dropout_p, ln_eps=1e-5, bn_eps=1e-5,
-                        bn_momentum=0.1, max_len=_PE_MAX_LEN, bn_sync_world=int(self.bn_sync_world), two_stream=int(two))
+        if self.precision is not None and self.precision not in _lib.PRECISIONS:
+            raise _lib.MansyError(f'unknown precision {self.precision!r}: one of f32, bf16x3, bf16x6')
+        cfg = VPConfig(B=B, S=S, T=self.fut_window, d_model=self.d_model, n_head=_N_HEAD, d_ff=self.dim_feedforward,
+                       n_enc=self.num_encoder_layers, n_dec=self.num_decoder_layers, in_ch=self.in_channel * self.num_head,
+                       has_bias=int(self.has_bias), p_pe=self.dropout_p, p_drop=self.attn_dropout_p, ln_eps=1e-5, bn_eps=1e-5,
+                       bn_momentum=0.1, max_len=_PE_MAX_LEN, bn_sync_world=int(self.bn_sync_world), two_stream=int(two),
+                       precision=-1 if self.precision is None else _lib.PRECISIONS[self.precision])
+        if self.bn_sync_world > 1:              # the call's own SyncBN / gradient-ready hook + the key that finds this model again
+            cfg.bn_sync_fn = _BN_SYNC_CFUNC
+            cfg.bn_sync_user = id(self)
+        return cfg
 
     def set_data_parallel(self, world, allreduce=None):
         """SyncBN for the DistillLayer under data parallelism: `world` ranks share batch statistics; `allreduce(t)` sums a
@@ -122,11 +133,14 @@ class ViewportTransformerMTIO(nn.Module):
             import torch.distributed as dist
             allreduce = dist.all_reduce
         self._bn_allreduce = allreduce
-        check(lib().mansy_set_bn_sync_hook(_BN_SYNC_CFUNC, None), 'mansy_set_bn_sync_hook')
+        if self.bn_sync_world > 1:
+            _BN_MODELS[id(self)] = self
+        else:
+            _BN_MODELS.pop(id(self), None)
 
     def _arm_bn_sync(self, cfg):
         if self.bn_sync_world > 1:
-            _BN_SYNC['model'], _BN_SYNC['cfg'] = self, cfg
+            self._bn_cfg = cfg
 
     def _param_table(self):
         L = lib()
@@ -361,9 +375,8 @@ class ViewportTransformerMTIO(nn.Module):
         arr, _ = self._pointers()
         pe, rm, rv, _nbt = self._engine_buffers()
         out = torch.empty(B, self.fut_window, self.in_channel, dtype=torch.float32, device=history.device)
-        with _lib.precision(self.precision):
-            check(lib().mansy_vp_sample(ctypes.byref(cfg), arr, ptr(pe), ptr(rm), ptr(rv), ptr(history), ptr(current), ptr(out),
-                                        ptr(ws), stream_ptr(history.device)), 'mansy_vp_sample')
+        check(lib().mansy_vp_sample(ctypes.byref(cfg), arr, ptr(pe), ptr(rm), ptr(rv), ptr(history), ptr(current), ptr(out),
+                                    ptr(ws), stream_ptr(history.device)), 'mansy_vp_sample')
         return out
 
     # ------------------------------------------------------------------ fused fast path
@@ -401,12 +414,11 @@ class ViewportTransformerMTIO(nn.Module):
                 tail_started = True
             self._grad_ready = _ready
         try:
-            with _lib.precision(self.precision):
-                check(lib().mansy_vp_train_step(
-                    ctypes.byref(cfg), arr, garr, ptr(self._flat_p), ptr(self._flat_g), ptr(optimizer.exp_avg), ptr(optimizer.exp_avg_sq),
-                    self._flat_p.numel(), ptr(pe), ptr(rm), ptr(rv), ptr(nbt), ptr(history), ptr(current), ptr(future), ptr(p1), ptr(p2),
-                    g['lr'], g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], engine_step, ptr(loss), ptr(ws),
-                    self._next_seed(), stream_ptr(history.device)), 'mansy_vp_train_step')
+            check(lib().mansy_vp_train_step(
+                ctypes.byref(cfg), arr, garr, ptr(self._flat_p), ptr(self._flat_g), ptr(optimizer.exp_avg), ptr(optimizer.exp_avg_sq),
+                self._flat_p.numel(), ptr(pe), ptr(rm), ptr(rv), ptr(nbt), ptr(history), ptr(current), ptr(future), ptr(p1), ptr(p2),
+                g['lr'], g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], engine_step, ptr(loss), ptr(ws),
+                self._next_seed(), stream_ptr(history.device)), 'mansy_vp_train_step')
         finally:
             # the closure belongs to THIS call: a later autograd backward on the same model (hook which = 2 fires there too when
             # bn_sync_world > 1) must not start a tail all-reduce nobody finishes
@@ -438,9 +450,8 @@ class _VPFunction(torch.autograd.Function):
         seed = model._next_seed() if model.training else 0
         model._arm_bn_sync(cfg)
         pred = torch.empty(B, model.fut_window, cfg.in_ch, dtype=torch.float32, device=src.device)
-        with _lib.precision(model.precision):
-            check(lib().mansy_vp_forward(ctypes.byref(cfg), arr, ptr(pe), ptr(rm), ptr(rv), ptr(nbt), ptr(src), ptr(cur.reshape(B, -1)),
-                                         ptr(pred), ptr(ws), int(model.training), seed, stream_ptr(src.device)), 'mansy_vp_forward')
+        check(lib().mansy_vp_forward(ctypes.byref(cfg), arr, ptr(pe), ptr(rm), ptr(rv), ptr(nbt), ptr(src), ptr(cur.reshape(B, -1)),
+                                     ptr(pred), ptr(ws), int(model.training), seed, stream_ptr(src.device)), 'mansy_vp_forward')
         ctx.model, ctx.cfg, ctx.seed, ctx.src, ctx.train = model, cfg, seed, src, model.training
         return pred
 
@@ -454,9 +465,8 @@ class _VPFunction(torch.autograd.Function):
         model._arm_bn_sync(ctx.cfg)
         arr, garr = model._pointers(gflat)
         ws = model._workspace(ctx.cfg)
-        with _lib.precision(model.precision):
-            check(lib().mansy_vp_backward(ctypes.byref(ctx.cfg), arr, garr, ptr(ctx.src), ptr(dpred.contiguous()), ptr(ws), ctx.seed,
-                                          stream_ptr(dpred.device)), 'mansy_vp_backward')
+        check(lib().mansy_vp_backward(ctypes.byref(ctx.cfg), arr, garr, ptr(ctx.src), ptr(dpred.contiguous()), ptr(ws), ctx.seed,
+                                      stream_ptr(dpred.device)), 'mansy_vp_backward')
         grads = tuple(gflat[o:o + p.numel()].view(p.shape) for p, o in zip(model._params, model._offsets))
         return (None, None, None) + grads
 

@@ -81,6 +81,8 @@ class Session:
         self.stem = (f'his_{a.his_window}_fut_{a.fut_window}_hid_{a.hidden_dim}_ss_{a.sample_step}_epochs_{a.epochs}_bs_{a.bs}'
                      f'_lr_{a.lr}_seed_{a.seed}')
         self.model = create_model(a.model, a.fut_window, a.hidden_dim, a.block_num, a.device, a.seed).to(a.device)
+        if hasattr(self.model, 'precision'):                      # the model carries its precision into every engine call (no process-wide mode)
+            self.model.precision = getattr(a, 'precision', 'f32')
         self.window = dict(his_window=a.his_window, fut_window=a.fut_window, frequency=a.dataset_frequency, sample_step=a.sample_step,
                            trim_head=a.trim_head, trim_tail=a.trim_tail)
 
@@ -152,7 +154,6 @@ class Session:
 def run(args, config):
     for seeder in (np.random.seed, torch.manual_seed, torch.cuda.manual_seed_all, random.seed):
         seeder(args.seed)
-    _lib.set_precision(getattr(args, 'precision', 'f32'))
     session = Session(args, config)
     if args.train:
         log = open(os.path.join(session.results_dir, session.stem + 'console.log'), 'w')
