@@ -223,6 +223,10 @@ def bench_ppo(rank, world, dev, mdist, cycles=5, warmup=2, n_env=256, steps_per_
             f" (peer {rep.get('us_peer')} us vs library {rep.get('us_library')} us)" if 'us_peer' in rep else ''))
     tables = EnvTables.synthetic(dev, seed=5, train_identifier_reward=True, n_sample=max(240, n_env * world))
     off, wnum = mdist.shard_envs(n_env, rank, world)
+    shards = [[off, wnum]]
+    if world > 1:                               # every rank's (first global environment, global worker count): the line shows the partition
+        shards = [None] * world
+        dist.all_gather_object(shards, [off, wnum])
     venv = MANSYVecEnv(tables, n_env, seed=5, index_offset=off, worker_num=wnum)
     col = VecCollector(pol, venv, seed=5 + rank)
     buf = RolloutBuffer(steps_per_env, n_env, dev)
@@ -296,7 +300,7 @@ def bench_ppo(rank, world, dev, mdist, cycles=5, warmup=2, n_env=256, steps_per_
             ps.check()                       # a timed-out wait would have poisoned the gradients with NaN: fail loudly
     spread = max(replica_spread(pol.engine.ac.flat_p, world), replica_spread(pol.engine.idn.flat_p, world))
     return {'metric': 'PPO env-steps/sec', 'value': round(steps / dt, 1), 'unit': 'env-steps/s', 'n_gpus': world, 'cycles': cycles,
-            'replica_param_spread': spread,
+            'replica_param_spread': spread, 'env_shards': shards, 'envs_per_gpu': n_env,
             'grad_sync': sync_desc,
             'ms_per_cycle': round(dt / cycles * 1e3, 3), 'rollout_only_env_steps_per_s': round(n_env * steps_per_env * cycles / t_collect, 1),
             'rollout_step_latency_us': round(t_collect / (cycles * steps_per_env) * 1e6, 1), 'final_loss': float(np.mean(res['loss'])),

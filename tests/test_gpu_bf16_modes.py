@@ -545,3 +545,43 @@ def test_ring_staged_decoder_tiles_equal_the_two_stage_loop_bit_for_bit(K, mode)
             assert ((outs[1][0].double() - ref).abs().max() / ref.abs().max()).item() < GEMM_TOL[mode]
     finally:
         L.mansy_gemm_bf16_variant(old)
+
+
+def test_role_split_256x128_loop_equals_the_other_loops_bit_for_bit(K):
+    """Round 4: the 256 x 128 tiles of the pre-split bf16x3 products run on twelve waves with fixed roles (gemm_bf16k_kernel: 8 consumer
+    waves that only read fragments / split / MFMA, 4 loader waves that only issue LDS-DMA; the default, variant 1).  Same products in the
+    same order per output element as the eight-wave loop (variant 8, force_tile 256) and the 128 x 128 loop (variant 4, force_tile 128),
+    and the same row-major epilogue: bit-identical results -- over 3..48 K-tiles (prologue shorter than the ring, tails with nothing left
+    to issue), ragged rows / columns, both forms (A W^T and A W), a fused epilogue, launches back to back (ring reuse across launches)."""
+    from mansy_immersivevideostreaming_amd._lib import lib
+    L = lib()
+    g = torch.Generator().manual_seed(33)
+    old = L.mansy_gemm_bf16_variant(-1)
+    try:
+        for (M, N, Kd) in ((40960, 512, 512), (1000, 260, 96), (257, 128, 128), (4096, 1536, 512), (300, 132, 160), (2048, 512, 1536), (256, 128, 192)):
+            W = torch.randn(N, Kd, generator=g).cuda()
+            pl, pl_t = K.weight_planes(W, 2)
+            A = torch.randn(M, Kd, generator=g).cuda()
+            G = torch.randn(M, N, generator=g).cuda()
+            bias, resid = torch.randn(N, generator=g).cuda(), torch.randn(M, N, generator=g).cuda()
+
+            def run(tile):
+                with K.precision('bf16x3'):
+                    return [K.gemm_planes(A, W, pl, force_tile=tile), K.gemm_planes(G, W, pl_t, transposed=True, force_tile=tile),
+                            K.gemm_planes(A, W, pl, bias=bias, relu=True, resid=resid, force_tile=tile)]
+            L.mansy_gemm_bf16_variant(4)
+            want = run(128)                                   # gemm_bf16f_kernel<128, 128>
+            L.mansy_gemm_bf16_variant(8)
+            for got, w in zip(run(256), want):                # gemm_bf16g_kernel
+                assert torch.equal(got, w)
+            L.mansy_gemm_bf16_variant(1)
+            outs = run(256)                                   # gemm_bf16k_kernel
+            for got, w in zip(outs, want):
+                assert torch.equal(got, w), (M, N, Kd, float((got - w).abs().max()))
+            with K.precision('bf16x3'):
+                for _ in range(3):
+                    assert torch.equal(K.gemm_planes(A, W, pl, force_tile=256), want[0])
+            ref = A.double() @ W.double().t()
+            assert ((want[0].double() - ref).abs().max() / ref.abs().max()).item() < GEMM_TOL['bf16x3']
+    finally:
+        L.mansy_gemm_bf16_variant(old)

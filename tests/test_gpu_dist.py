@@ -187,3 +187,27 @@ def test_bench_chooses_its_gradient_average_by_probe_and_falls_back_together(cas
         assert gs.startswith('torch.distributed all_reduce; probe: peer set-up failed: rank 1: injected set-up failure'), gs
     else:                      # either outcome is legitimate; the line must say which and why (gloo moves the buffer through the host: peer wins here)
         assert 'probe' in gs and (gs.startswith('peer-memory one-shot (csrc/xgmi.hip); probe: peer ') or gs.startswith('torch.distributed all_reduce; probe: ')), gs
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_functional_on_the_shared_gpu():
+    """The real entry point at the world size the driver's scaling run uses: `bench.py --gpus 8` starts eight rank processes (here they
+    share the one GPU over gloo: MANSY_SHARE_GPU=1), tiny VP batch, one cycle.  What must hold at world 8 before a node ever sees it:
+    the process group reports eight ranks, the environment partition is 8 x 256 disjoint consecutive blocks of the 2 048 global workers
+    (the reference's worker_id / worker_num stride, mansy_env.py:55-56,100-101), the hand-written peer-memory all-reduce imports seven
+    peers' buffers (MANSY_PEER_SYNC=1) and leaves the PPO replicas bit-identical, SyncBN + the overlapped gradient all-reduce leave the
+    VP replicas identical."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(MANSY_DIST_BACKEND='gloo', MANSY_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0', MANSY_PEER_SYNC='1')
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '1', '--warmup', '1', '--batch', '64', '--no-cpu-baseline']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][0])
+    assert out['n_gpus'] == 8 and out['dist']['world_size'] == 8 and out['dist']['ranks_reporting'] == 8
+    assert out['config']['global_batch'] == 8 * 64 and out['config']['parallelism'] == 'dp8'
+    assert out['replica_param_spread'] <= 1e-6 and np.isfinite(out['final_loss'])
+    sec = out['secondary']
+    assert sec['n_gpus'] == 8 and sec['config']['parallelism'] == 'dp8' and sec['grad_sync'] == 'peer-memory one-shot (csrc/xgmi.hip)'
+    assert sec['replica_param_spread'] == 0.0 and sec['value'] > 0 and np.isfinite(sec['final_loss'])
+    n = sec['envs_per_gpu']
+    assert sec['env_shards'] == [[r_ * n, 8 * n] for r_ in range(8)]

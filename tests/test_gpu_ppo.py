@@ -795,6 +795,55 @@ def test_data_parallel_step_form_equals_the_single_process_step(M):
             assert float((err > 0.02 * 5e-4).float().mean()) <= 1e-4 and err.max().item() <= 2 * 5e-4, (err.max().item(),)
 
 
+def test_identifier_gradient_averages_hidden_under_process_fn_passes(M):
+    """Data parallel: the two gradient averages of train_identifier run on a side stream while the two
+    evaluation passes of the following process_fn (v_s + logp_old on obs; v_s_ on obs_next -- they depend on the actor-critic only)
+    run on the caller's stream; process_fn then takes those values instead of recomputing them.  With an identity `grad_sync` (one
+    rank) the whole collect-less cycle train_identifier -> update must land where the un-overlapped order lands: same identifier
+    losses and parameters, same PPO losses and parameters, to float32 rounding (the two halves are evaluated as two passes instead
+    of one joint pass: a different split of the fc product's batch, nothing else); a stale cache (other buffer, changed policy) is
+    never used."""
+    sd = po.make_policy_state_dict(int(Z['wseed']))
+    T, N, bs = 16, 64, 256
+    rs = np.random.RandomState(5)
+    n = T * N
+    src = Z['obs']
+    obs2 = torch.from_numpy(src[rs.randint(0, len(src), size=2 * n)].reshape(2, T, N, 780).copy())
+    act = torch.from_numpy(rs.randint(0, 15, size=(T, N)).astype(np.int32))
+    rew = torch.from_numpy(rs.randn(T, N).astype(np.float32))
+    done = torch.from_numpy((rs.rand(T, N) < 0.05).astype(np.uint8))
+    outs = []
+    for hide in (False, True):
+        pol = build_policy(M, sd)
+        calls = []
+        pol.set_data_parallel(1, lambda g: calls.append(g.numel()))
+        pol.overlap_identifier_sync = hide
+        buf = M.ppo.RolloutBuffer(T, N, 'cuda')
+        rows, ilosses = [], []
+        for it in range(2):
+            buf.obs.copy_(obs2[0]); buf.obs_next.copy_(obs2[1]); buf.act.copy_(act); buf.rew.copy_(rew + 0.1 * it); buf.done.copy_(done)
+            buf.filled = T
+            np.random.seed(90 + it)
+            il, vl = pol.train_identifier(buf, 2, verbose=False)
+            assert (pol._pre_eval is not None and pol._pre_eval['done'] == {0, 1}) == hide
+            ilosses += [x.item() for x in il] + [vl.item()]
+            res = pol.update(0, buf, is_train=True, batch_size=bs, repeat=2)
+            assert pol._pre_eval is None                                  # consumed (or never there)
+            rows.append(np.stack([res['loss'], res['loss/clip'], res['loss/vf'], res['loss/ent']], 1))
+        assert calls.count(pol.engine.idn.flat_p.numel()) == 4          # the identifier's 2 x 2 averages went through grad_sync either way
+        outs.append((np.array(ilosses), np.concatenate(rows), pol.engine.idn.flat_p.clone(), pol.engine.ac.flat_p.clone()))
+        if hide:      # a cache taken for another buffer state must not be used: process_fn recomputes
+            pol._pre_evaluate(buf, 0)
+            buf.filled = T - 1
+            data = pol.process_fn(buf)
+            assert data['n'] == (T - 1) * N and pol._pre_eval is None
+    np.testing.assert_allclose(outs[1][0], outs[0][0], rtol=1e-6)
+    np.testing.assert_allclose(outs[1][1], outs[0][1], rtol=2e-5, atol=2e-6)
+    assert torch.equal(outs[1][2], outs[0][2])                           # identifier: identical launches, identical order per stream
+    err = (outs[1][3] - outs[0][3]).abs()
+    assert float((err > 0.02 * 5e-4).float().mean()) <= 1e-4 and err.max().item() <= 2 * 5e-4, err.max().item()
+
+
 @pytest.mark.parametrize('mode', ['f32', 'bf16x6', 'bf16x3'])
 def test_shipped_trained_checkpoint_vs_reference(M, mode):
     """The TRAINED weights the reference ships (best_policy.pth / best_identifier.pth; their arrays travel in

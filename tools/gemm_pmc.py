@@ -12,9 +12,13 @@ planes = len(sys.argv) > 8 and sys.argv[8] == '1'
 A = torch.randn((Kd, M) if ak else (M, Kd), device='cuda'); B = torch.randn((Kd, N) if bk else (N, Kd), device='cuda')
 out = torch.zeros(M, N, device='cuda')
 K.set_precision(prec)
+if os.environ.get('MANSY_BF16_VARIANT'):
+    from mansy_immersivevideostreaming_amd._lib import lib
+    lib().mansy_gemm_bf16_variant(int(os.environ['MANSY_BF16_VARIANT']))
+FT = int(os.environ.get('MANSY_FORCE_TILE', '0'))
 if planes and not ak and prec != 'f32':
     pl, pl_t = K.weight_planes(B, 2 if prec == 'bf16x3' else 3)
-    run = lambda: K.gemm_planes(A, B, pl_t if bk else pl, transposed=bool(bk))
+    run = lambda: K.gemm_planes(A, B, pl_t if bk else pl, transposed=bool(bk), force_tile=FT)
 else:
     run = lambda: K.gemm(A, B, bool(ak), bool(bk), out=out, accumulate=acc)
 for _ in range(6):
