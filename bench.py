@@ -164,6 +164,20 @@ def _ppo_torch_kernels_per_cycle():
         return None, None, None
 
 
+def _ppo_pmc_traffic():
+    """HBM-side bytes per env-step of the whole PPO cycle from the newest committed PMC aggregate (profiles/r*_ppo_pmc.json, written by
+    tools/gpu_prof_ppo.sh from separate FETCH_SIZE / WRITE_SIZE passes over every kernel of the cycle, FETCH_SIZE x2 per the gfx950
+    correction) -> (bytes per env-step, file, stale): stale = the library sources have changed since the counters were taken."""
+    import glob
+    from mansy_immersivevideostreaming_amd import build_ext
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_ppo_pmc.json')))
+    try:
+        rec = json.load(open(files[-1]))
+        return rec['traffic_bytes_per_env_step'], 'profiles/' + os.path.basename(files[-1]), rec.get('source_digest') != build_ext.source_digest()
+    except Exception:
+        return None, None, None
+
+
 def _gemm_prof(L, fn, reps):
     """A HIP event pair attached to every GEMM dispatch (hipExtLaunchKernelGGL: the kernel's own begin / end on rank 0's launch stream) of
     `reps` calls of fn: (ms, launches, exact FLOPs)."""
@@ -279,10 +293,13 @@ def bench_ppo(rank, world, dev, mdist, cycles=5, warmup=2, n_env=256, steps_per_
         n_lib = (launches1 - launches0) / float(cycles) + (col.graph_launches if col.use_graph and col._graph is not None else 0)
         n_torch, launch_src, launch_stale = _ppo_torch_kernels_per_cycle()
         n_launch = round(n_lib + (n_torch or 0), 1)
+        ppo_traffic, ppo_traffic_src, ppo_traffic_stale = _ppo_pmc_traffic()
         gemm_tf = fl_g / (ms_g * 1e-3) / 1e12 if ms_g > 0 else 0.0
         roof = {'bound': 'mfma', 'kernel': 'gemm_f32_dma_kernel (FeatureNet block-diagonal product, heads, dF / dW products of the update)',
                 'achieved': round(eps * PPO_FLOP_PER_ENV_STEP / 1e12, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(eps * PPO_FLOP_PER_ENV_STEP / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+                'frac': round(eps * PPO_FLOP_PER_ENV_STEP / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                'traffic': ppo_traffic, 'traffic_unit': 'HBM-side bytes per env-step (whole cycle, PMC)', 'traffic_source': ppo_traffic_src,
+                'traffic_stale': ppo_traffic_stale,
                 'note': 'whole cycle on the as-written 11.5 MFLOP per env-step; the cycle is launch- and dependency-bound, not MFMA-bound',
                 'hbm': {'achieved': round(eps * PPO_BYTES_PER_ENV_STEP / 1e9, 2), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                         'frac': round(eps * PPO_BYTES_PER_ENV_STEP / 1e9 / PEAK_HBM_GBS, 5)},

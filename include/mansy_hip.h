@@ -401,6 +401,9 @@ int mansy_prof_gemm_enable(int on);
  * real loops are bit-identical (same products, same order). */
 int mansy_gemm_bf16_variant(int v);
 int mansy_prof_gemm_collect(double* total_ms, long long* launches, double* flops);
+/* A/B knob (diagnostic): column-group width of the XCD-aware tile order of the fp32 LDS-DMA loop for products with more column tiles than
+ * that (default 12; 0 = plain row-panel-major order); v < 0 only queries.  Returns the previous value.  Never changes a result (tile ORDER only). */
+int mansy_gemm_col_group(int v);
 /* Kernel launches this library has enqueued since the process started (every launch site counts; a launch enqueued during a hipGraph
  * capture counts once, at capture time -- a replay of the graph adds nothing).  bench.py reads the difference around a cycle. */
 unsigned long long mansy_prof_launch_count(void);

@@ -276,6 +276,11 @@ __global__ __launch_bounds__(NT) void gemm_f32_dma_kernel(GemmParams p) {
     int t = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + local;
     split = t / per_split; t -= split * per_split;
     tile_y = t / gridDim.x; tile_x = t - tile_y * gridDim.x;
+    if (p.col_group > 0 && (int)gridDim.x > p.col_group) {      // column-group order (bijective for any grid): see GemmParams::col_group
+      const int G = p.col_group, gy = gridDim.y, full = ((int)gridDim.x / G) * G;
+      if (t < full * gy) { const int g = t / (G * gy), rr = t - g * G * gy; tile_y = rr / G; tile_x = g * G + (rr - tile_y * G); }
+      else { const int W = gridDim.x - full, rr = t - full * gy; tile_y = rr / W; tile_x = full + (rr - tile_y * W); }
+    }
     if (BM == 64 && BN == 64 && p.ep.tile_list) { tile_x = p.ep.tile_list[2 * t]; tile_y = p.ep.tile_list[2 * t + 1]; }
   }
   const float* Ap = p.A; const float* Bp = p.B; float* Cp = p.C; float* rowsum_dst = p.ep.a_rowsum;
@@ -422,6 +427,11 @@ extern "C" int mansy_set_gemm_precision(int mode) {
 }
 extern "C" int mansy_get_gemm_precision(void) { return g_gemm_prec; }
 
+// A/B knob (diagnostic, tools/gpu_gemm_colgroup.sh; default 12): column-group width of the XCD-aware tile order of the LDS-DMA loop for products with more
+// column tiles than that (0 = plain row-panel-major order); v < 0 only queries.  Returns the previous value.  Never changes a result.
+static int g_col_group = 12;      // measured (profiles/r04_gemm_colgroup.txt): [40 960, 1 536, 512] fetch 578 -> 211 MB per launch, same duration
+extern "C" int mansy_gemm_col_group(int v) { const int old = g_col_group; if (v >= 0) g_col_group = v; return old; }
+
 extern "C" int mansy_prof_gemm_enable(int on) {
   g_prof.on = on != 0;
   g_prof.used = 0;
@@ -478,6 +488,7 @@ int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B,
   MANSY_REQUIRE(A && B && C, "gemm: null pointer");
   GemmParams p;
   p.A = A; p.B = B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.ep = ep;
+  p.col_group = (ep.tile_nrange || ep.tile_list || ep.tile_krange) ? 0 : g_col_group;
   p.vec_ok = ((lda % 4) == 0) && ((ldb % 4) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
              ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (K % 4 == 0) && (!a_kmajor || M % 4 == 0) &&
              (!b_kmajor || N % 4 == 0);

@@ -33,6 +33,9 @@ struct GemmParams {
   GemmEpilogue ep;
   // optional second problem of identical shape in the same launch (LDS-DMA loop; grid.z = 2 x splits, problem slowest)
   const float* A2 = nullptr; const float* B2 = nullptr; float* C2 = nullptr; float* a_rowsum2 = nullptr; int splits_pp = 1;
+  // > 0: the XCD-aware tile order walks the column tiles in groups of col_group (all row panels of a group before the next group), so that an
+  // XCD's L2 holds ONE group's slice of B next to the A panels it streams (wide-N products: B alone is 3 MB of the 4 MB L2 at N = 1536)
+  int col_group = 0;
 };
 
 // Row-major pass of the fused epilogue: the C tile sits in LDS as [BM][BN + 4] floats (`smem`, written by the caller, who has also

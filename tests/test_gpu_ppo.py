@@ -839,7 +839,8 @@ def test_identifier_gradient_averages_hidden_under_process_fn_passes(M):
             assert data['n'] == (T - 1) * N and pol._pre_eval is None
     np.testing.assert_allclose(outs[1][0], outs[0][0], rtol=1e-6)
     np.testing.assert_allclose(outs[1][1], outs[0][1], rtol=2e-5, atol=2e-6)
-    assert torch.equal(outs[1][2], outs[0][2])                           # identifier: identical launches, identical order per stream
+    ierr = (outs[1][2] - outs[0][2]).abs()                               # identifier: the same launches (bias-gradient row sums are float atomics: rounding noise, which Adam turns into +-lr on zero-gradient elements)
+    assert float((ierr > 0.02 * 1e-4).float().mean()) <= 1e-3 and ierr.max().item() <= 4 * 1e-4, ierr.max().item()
     err = (outs[1][3] - outs[0][3]).abs()
     assert float((err > 0.02 * 5e-4).float().mean()) <= 1e-4 and err.max().item() <= 2 * 5e-4, err.max().item()
 

@@ -16,6 +16,9 @@ if os.environ.get('MANSY_BF16_VARIANT'):
     from mansy_immersivevideostreaming_amd._lib import lib
     lib().mansy_gemm_bf16_variant(int(os.environ['MANSY_BF16_VARIANT']))
 FT = int(os.environ.get('MANSY_FORCE_TILE', '0'))
+if os.environ.get('MANSY_COL_GROUP'):
+    from mansy_immersivevideostreaming_amd._lib import lib
+    lib().mansy_gemm_col_group(int(os.environ['MANSY_COL_GROUP']))
 if planes and not ak and prec != 'f32':
     pl, pl_t = K.weight_planes(B, 2 if prec == 'bf16x3' else 3)
     run = lambda: K.gemm_planes(A, B, pl_t if bk else pl, transposed=bool(bk), force_tile=FT)
