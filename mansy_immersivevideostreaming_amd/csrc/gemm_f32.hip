@@ -253,12 +253,17 @@ __device__ __forceinline__ void read_frag_dma(const float* __restrict__ lds, int
   }
 }
 
-template <int BM, int BN, bool AK, bool BKM>
+// NS = LDS stages of the operand ring: NS - 1 K-tiles in flight under counted `s_waitcnt vmcnt` (round 4; NS = 2 is the round-1 loop: one tile
+// in flight, vmcnt(0) per K-tile).  A launch with ONE workgroup per CU -- the PPO cycle's ~130 small products, 80-160 workgroups each -- runs its K
+// loop at one L2 / HBM round trip per K-tile with one tile in flight (0.7-1 us against 0.45 us of MFMA for a 64 x 64 tile); with three in flight the
+// round trips overlap.  Same MFMAs in the same order: results bit-identical for every NS.
+template <int BM, int BN, bool AK, bool BKM, int NS = 2>
 __global__ __launch_bounds__(NT) void gemm_f32_dma_kernel(GemmParams p) {
-  constexpr int TM = BM / 64, TN = BN / 64, PA = BM / 32, PB = BN / 32;
+  constexpr int TM = BM / 64, TN = BN / 64, PA = BM / 32, PB = BN / 32, D = NS - 1, PPT = PA + PB;      // PPT: DMA pieces per wave and K-tile
   constexpr int A_FLOATS = BM * BK, B_FLOATS = BN * BK, STAGE = A_FLOATS + B_FLOATS;
   constexpr int C_FLOATS = BM * (BN + 4);
-  constexpr int SMEM_FLOATS = 2 * STAGE > C_FLOATS ? 2 * STAGE : C_FLOATS;
+  constexpr int SMEM_FLOATS = NS * STAGE > C_FLOATS ? NS * STAGE : C_FLOATS;
+  static_assert(NS >= 2 && NS <= 4 && PPT * (D - 1 > 0 ? D - 1 : 0) <= 15, "piece counts must fit the counted waits");
   __shared__ __attribute__((aligned(1024))) float smem[SMEM_FLOATS];
 
   const int tid = threadIdx.x;
@@ -326,25 +331,28 @@ __global__ __launch_bounds__(NT) void gemm_f32_dma_kernel(GemmParams p) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   float rowsum = 0.f;
-  if (nk > 0) {
+  auto dma = [&](int stage, int kt) {           // tile kt of this workgroup's K range -> ring stage `stage`
+    const float* ca = sa + (long long)kt * step_a;
+    const float* cb = sb + (long long)kt * step_b;
+    const unsigned base = lds_wave + (unsigned)stage * (STAGE * 4u);
 #pragma unroll
-    for (int i = 0; i < PA; ++i) glds16(voa[i], sa, lds_wave + i * 4096u);
+    for (int i = 0; i < PA; ++i) glds16(voa[i], ca, base + i * 4096u);
 #pragma unroll
-    for (int i = 0; i < PB; ++i) glds16(vob[i], sb, lds_wave + A_FLOATS * 4u + i * 4096u);
-  }
+    for (int i = 0; i < PB; ++i) glds16(vob[i], cb, base + A_FLOATS * 4u + i * 4096u);
+  };
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (d < nk) dma(d, d);
+  int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of tile kt have landed ...
+    // this wave's pieces of tile kt have landed; the younger tiles' pieces (min(D - 1, nk - 1 - kt) tiles, PPT each) stay in flight
+    const int ahead = nk - 1 - kt;
+    if (D >= 3 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPT) : "memory");
+    else if (D >= 2 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                        // ... and everyone's; everyone is done reading tile kt-1
     asm volatile("" ::: "memory");
-    sa += step_a; sb += step_b;                          // corners of tile kt+1
-    const unsigned lds_next = lds_wave + (unsigned)(cur ^ 1) * (STAGE * 4u);
-    if (kt + 1 < nk) {
-#pragma unroll
-      for (int i = 0; i < PA; ++i) glds16(voa[i], sa, lds_next + i * 4096u);
-#pragma unroll
-      for (int i = 0; i < PB; ++i) glds16(vob[i], sb, lds_next + A_FLOATS * 4u + i * 4096u);
-    }
+    if (kt + D < nk) dma(cur == 0 ? NS - 1 : cur - 1, kt + D);       // into the stage tile kt - 1 occupied
     const float* a_l = smem + cur * STAGE;
     const float* b_l = a_l + A_FLOATS;
     if (AK && rowsum_dst && tid < BM) {          // bias gradient: row sums of the staged A tile.  Every n-tile of this
@@ -368,6 +376,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_dma_kernel(GemmParams p) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // LDS reads retired before the barrier that frees this buffer
+    cur = cur == NS - 1 ? 0 : cur + 1;
   }
   __syncthreads();                                        // staging LDS idle: the epilogue reuses it
 
@@ -375,15 +384,115 @@ __global__ __launch_bounds__(NT) void gemm_f32_dma_kernel(GemmParams p) {
   gemm_epilogue<BM, BN, SMEM_FLOATS>(p, acc, smem, m0, n0, tid, split, Cp);
 }
 
-template <int BM, int BN>
+// ---------------------------------------------------------------------------------------------------------------------
+// Wave-split-K loop for SMALL products (round 4): a launch that cannot fill the chip -- the PPO cycle's FeatureNet / head / dF products, 80-160
+// tiles of 64 x 64 -- runs as long as ONE workgroup's K chain: measured 3.8 us + 0.62 us per K-tile (tools/gemm_small_ksweep.py; a lone wave per
+// SIMD hides neither its fragment-read latency nor the 64-cycle dependent MFMA chain).  Here a workgroup owns a 32 x 32 output block and its four
+// waves SPLIT THE K-TILES between them (wave w takes tiles w, w + 4, ...): the chain is a quarter as long and four times as many workgroups fill the
+// chip.  Each wave stages its own tiles into its own LDS stage (A and B by LDS-DMA, the images and fragment reads of the loop above; no workgroup
+// barrier inside the loop: a wave only reads what it staged itself, ordered by its own vmcnt; the next tile is requested as soon as the current one
+// sits in registers and flies under its MFMAs; 32 KB of LDS per workgroup, so five fit a CU), the four partial blocks are summed
+// through LDS in wave order (deterministic), then the shared row-major epilogue runs.  A K-contiguous; B K-contiguous or K-major.
+template <bool BKM>
+__global__ __launch_bounds__(NT) void gemm_f32_wsk_kernel(GemmParams p) {
+  constexpr int T = 32, TILE_FLOATS = T * BK, WAVE_FLOATS = 2 * TILE_FLOATS, CLD = T + 4;       // ONE stage per wave: 8 KB (32 KB per workgroup, five per CU)
+  static_assert(T * CLD <= WAVE_FLOATS, "a partial block must fit a wave's stage");
+  __shared__ __attribute__((aligned(1024))) float smem[4 * WAVE_FLOATS];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  int tile_x, tile_y, split;
+  {   // XCD-aware bijective remap over the whole 3-D grid, K split slowest (see gemm_f32_dma_kernel)
+    const int per_split = gridDim.x * gridDim.y, nwg = per_split * gridDim.z;
+    const int orig = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const int q = nwg >> 3, rem = nwg & 7, xcd = orig & 7, local = orig >> 3;
+    int t = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + local;
+    split = t / per_split; t -= split * per_split;
+    tile_y = t / gridDim.x; tile_x = t - tile_y * gridDim.x;
+  }
+  const int m0 = tile_y * T, n0 = tile_x * T;
+  int k_begin = split * p.k_per_split;
+  int k_end = min(p.K, k_begin + p.k_per_split);
+  if (p.ep.tile_krange) {                          // block-diagonal weights: the table is per 64-column tile
+    k_begin = max(k_begin, p.ep.tile_krange[2 * (n0 / 64)]);
+    k_end = min(k_end, p.ep.tile_krange[2 * (n0 / 64) + 1]);
+  }
+  const int nk = max(0, (k_end - k_begin) / BK);
+
+  // this WAVE's pieces of a tile: A image [32][32] (128-B rows, k-chunk c of a row in slot c ^ ((row >> 1) & 7)), B likewise or, K-major, [32 k][32 n] linear
+  unsigned voa[4], vob[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = i * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    voa[i] = (unsigned)((min(m0 + row, p.M - 1) - m0) * p.lda + c * 4) * 4u;
+    if (!BKM) vob[i] = (unsigned)((min(n0 + row, p.N - 1) - n0) * p.ldb + c * 4) * 4u;
+    else vob[i] = (unsigned)(row * p.ldb + (min(n0 + (lane & 7) * 4, p.N - 4) - n0)) * 4u;       // row = k index of the tile here
+  }
+  const float* const sa = p.A + (long long)m0 * p.lda + k_begin;
+  const float* const sb = BKM ? p.B + (long long)k_begin * p.ldb + n0 : p.B + (long long)n0 * p.ldb + k_begin;
+  const long long step_b = BKM ? (long long)BK * p.ldb : BK;
+  const unsigned lds_w = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem + (unsigned)wave * (WAVE_FLOATS * 4u));
+  auto dma = [&](int kt) {
+    const float* ca = sa + (long long)kt * BK;
+    const float* cb = sb + (long long)kt * step_b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(voa[i], ca, lds_w + i * 1024u);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(vob[i], cb, lds_w + TILE_FLOATS * 4u + i * 1024u);
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  float* const mine = smem + wave * WAVE_FLOATS;
+  const float* const a_l = mine;
+  const float* const b_l = mine + TILE_FLOATS;
+  int kt = wave;
+  if (kt < nk) dma(kt);
+  for (; kt < nk; kt += 4) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's tile has landed (it staged it itself: no barrier)
+    float af[2][8], bf[2][8];
+#pragma unroll
+    for (int chunk = 0; chunk < 2; ++chunk) {
+      read_frag_dma<T, false>(a_l, 0, r, h, chunk, af[chunk]);
+      read_frag_dma<T, BKM>(b_l, 0, r, h, chunk, bf[chunk]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the whole tile is in registers: the stage may be staged again ...
+    if (kt + 4 < nk) dma(kt + 4);                        // ... and the wave's next tile flies under this tile's 16 MFMAs
+#pragma unroll
+    for (int chunk = 0; chunk < 2; ++chunk)
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[chunk][kk], bf[chunk][kk], acc, 0, 0, 0);
+  }
+  // partial block of this wave -> its own (now idle) stage, [32][36]
+#pragma unroll
+  for (int e = 0; e < 16; ++e) mine[((e & 3) + 8 * (e >> 2) + 4 * h) * CLD + r] = acc[e];
+  __syncthreads();
+  {   // sum the four partial blocks in wave order; thread -> (row tid / 8, float4 tid % 8): the mapping of gemm_epilogue_rows<32, 32, 256>
+    const int off = (tid >> 3) * CLD + (tid & 7) * 4;
+    float4 v = *reinterpret_cast<const float4*>(smem + off);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float4 q = *reinterpret_cast<const float4*>(smem + w * WAVE_FLOATS + off);
+      v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+    }
+    *reinterpret_cast<float4*>(smem + off) = v;           // read back by the same thread below
+  }
+  __syncthreads();
+  gemm_epilogue_rows<T, T, NT>(p, smem, m0, n0, tid, p.C + (long long)split * p.ep.split_slab);
+}
+
+template <int BM, int BN, int NS = 2>
 int launch_dma(const GemmParams& p, int a_kmajor, int b_kmajor, int splits, hipStream_t st) {
   dim3 grid(mansy_ceil_div(p.N, BN), mansy_ceil_div(p.M, BM), splits);
   if (BM == 64 && BN == 64 && p.ep.tile_list) grid = dim3(p.ep.tile_list_n, 1, splits);      // only the listed tiles
   dim3 block(NT);
-  if (!a_kmajor && !b_kmajor) MANSY_GEMM_LAUNCH((gemm_f32_dma_kernel<BM, BN, false, false>), grid, block, st, p);
-  else if (!a_kmajor && b_kmajor) MANSY_GEMM_LAUNCH((gemm_f32_dma_kernel<BM, BN, false, true>), grid, block, st, p);
-  else if (a_kmajor && b_kmajor) MANSY_GEMM_LAUNCH((gemm_f32_dma_kernel<BM, BN, true, true>), grid, block, st, p);
-  else MANSY_GEMM_LAUNCH((gemm_f32_dma_kernel<BM, BN, true, false>), grid, block, st, p);
+  if (!a_kmajor && !b_kmajor) MANSY_GEMM_LAUNCH((gemm_f32_dma_kernel<BM, BN, false, false, NS>), grid, block, st, p);
+  else if (!a_kmajor && b_kmajor) MANSY_GEMM_LAUNCH((gemm_f32_dma_kernel<BM, BN, false, true, NS>), grid, block, st, p);
+  else if (a_kmajor && b_kmajor) MANSY_GEMM_LAUNCH((gemm_f32_dma_kernel<BM, BN, true, true, NS>), grid, block, st, p);
+  else MANSY_GEMM_LAUNCH((gemm_f32_dma_kernel<BM, BN, true, false, NS>), grid, block, st, p);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }
@@ -456,15 +565,32 @@ extern "C" int mansy_prof_gemm_collect(double* total_ms, long long* launches, do
   return MANSY_OK;
 }
 
+// A/B knob (diagnostic): LDS stages of the 64 x 64 fp32 LDS-DMA loop's operand ring (2 = one K-tile in flight, 3 / 4 = two / three); v < 2 only queries
+static int g_f32_wsk = 1;        // A/B knob (diagnostic): 1 = small products run on the wave-split-K loop (gemm_f32_wsk_kernel), 0 = on the 64 x 64 loop
+extern "C" int mansy_gemm_f32_wsk(int v) { const int old = g_f32_wsk; if (v == 0 || v == 1) g_f32_wsk = v; return old; }
+static int g_f32_ring = 2;
+extern "C" int mansy_gemm_f32_ring(int v) { const int old = g_f32_ring; if (v >= 2 && v <= 4) g_f32_ring = v; return old; }
+
 // tile codes: 128 -> 128x128, 96 -> 128x64 (LDS-DMA loop only), 64 -> 64x64
 static int gemm_dispatch(const GemmParams& p, int tile, bool dma, int bf, int a_kmajor, int b_kmajor, int splits, hipStream_t st) {
   if (bf && p.ep.b_planes && !a_kmajor && splits == 1 && !p.ep.tile_krange && (reinterpret_cast<uintptr_t>(p.ep.b_planes) & 15) == 0 &&
       p.ep.b_planes_ld % 8 == 0 && p.ep.b_plane_stride % 8 == 0)
     return mansy_gemm_bf16p_dispatch(p, tile, bf, st);            // weights pre-split into planes: B by LDS-DMA
   if (bf) return mansy_gemm_bf16s_dispatch(p, tile, bf, a_kmajor, b_kmajor, splits, st);
+  if (dma && g_f32_wsk && tile == 64 && !a_kmajor && p.c_vec_ok && !p.ep.accumulate && (splits == 1 || p.ep.split_slab != 0) && !p.ep.tile_list &&
+      !p.ep.tile_nrange && !p.ep.a_rowsum && !p.A2 && (long long)mansy_ceil_div(p.M, 64) * mansy_ceil_div(p.N, 64) * splits <= 256) {
+    // a launch that cannot fill the chip: 32 x 32 blocks, the K-tiles split over the workgroup's four waves
+    dim3 grid(mansy_ceil_div(p.N, 32), mansy_ceil_div(p.M, 32), splits);
+    if (b_kmajor) MANSY_GEMM_LAUNCH((gemm_f32_wsk_kernel<true>), grid, dim3(NT), st, p);
+    else MANSY_GEMM_LAUNCH((gemm_f32_wsk_kernel<false>), grid, dim3(NT), st, p);
+    MANSY_LAUNCH_CHECK();
+    return MANSY_OK;
+  }
   if (dma) {
     if (tile == 128) return launch_dma<128, 128>(p, a_kmajor, b_kmajor, splits, st);
     if (tile == 96) return launch_dma<128, 64>(p, a_kmajor, b_kmajor, splits, st);
+    if (g_f32_ring == 4) return launch_dma<64, 64, 4>(p, a_kmajor, b_kmajor, splits, st);
+    if (g_f32_ring == 3) return launch_dma<64, 64, 3>(p, a_kmajor, b_kmajor, splits, st);
     return launch_dma<64, 64>(p, a_kmajor, b_kmajor, splits, st);
   }
   if (p.vec_ok) {

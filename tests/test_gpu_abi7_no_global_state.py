@@ -74,7 +74,7 @@ def test_two_vp_models_with_different_precisions_interleaved_on_two_streams(MT):
         for g, want in zip(got, (alone[pa], alone[pb])):
             assert g[0][0] == want[0][0]
             np.testing.assert_allclose(g[0], want[0], rtol=5e-5)       # steps 2..: weights differ by the float-atomics noise of step 1
-            torch.testing.assert_close(g[1], want[1], rtol=0, atol=2e-5)
+            torch.testing.assert_close(g[1], want[1], rtol=0, atol=5e-4)      # after 3 Adam steps: +-lr walks of noise-driven parameters
             assert float(((g[2] - want[2]).abs() > 1e-6).float().mean()) < 0.02 and float((g[2] - want[2]).abs().max()) <= 6.1e-4
     assert K.get_precision() == 'f32'                 # the deprecated process-wide mode was never touched
 

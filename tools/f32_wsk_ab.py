@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""A/B of the wave-split-K loop for small fp32 products (mansy_gemm_f32_wsk: 0 = the 64 x 64 loop, 1 = 32 x 32 blocks with the K-tiles split over the
+workgroup's waves), variants interleaved in ONE process: the small product shapes of the PPO cycle alone (with a check against a float64 product),
+then the whole cycle (bench.bench_ppo, 256 envs x 16 steps)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from mansy_immersivevideostreaming_amd import dist as mdist, kernels as K
+from mansy_immersivevideostreaming_amd._lib import lib
+L = lib()
+dev = torch.device('cuda', 0)
+g = torch.Generator().manual_seed(1)
+for (M, N, Kd, bk) in ((256, 1280, 320, 0), (512, 1280, 320, 0), (512, 1280, 256, 1), (256, 128, 96, 0), (512, 256, 96, 0), (300, 132, 64, 1), (33, 36, 32, 0)):
+    A = torch.randn(M, Kd, generator=g).to(dev); B = torch.randn((Kd, N) if bk else (N, Kd), generator=g).to(dev); out = torch.zeros(M, N, device=dev)
+    ref = A.double() @ (B.double() if bk else B.double().t())
+    line = f'gemm M={M} N={N} K={Kd} {"NN" if bk else "NT"}:'
+    for v in (0, 1):
+        L.mansy_gemm_f32_wsk(v)
+        out.zero_()
+        K.gemm(A, B, False, bool(bk), out=out, force_tile=64)
+        err = ((out.double() - ref).abs().max() / ref.abs().max()).item()
+        for _ in range(5): K.gemm(A, B, False, bool(bk), out=out, force_tile=64)
+        torch.cuda.synchronize()
+        gph = torch.cuda.CUDAGraph()                     # graph replay: the device-side duration, not the host's launch rate
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            K.gemm(A, B, False, bool(bk), out=out, force_tile=64)
+            torch.cuda.synchronize()
+            with torch.cuda.graph(gph, stream=s):
+                for _ in range(50): K.gemm(A, B, False, bool(bk), out=out, force_tile=64)
+        gph.replay(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(4): gph.replay()
+        e1.record(); torch.cuda.synchronize()
+        line += f'  wsk {v}: {e0.elapsed_time(e1) / 200 * 1e3:6.2f} us (err {err:.1e})'
+    print(line, flush=True)
+for rnd in range(3):
+    for v in (0, 1):
+        L.mansy_gemm_f32_wsk(v)
+        r = bench.bench_ppo(0, 1, dev, mdist, cycles=20, warmup=3, rollout_probe=True)
+        print(f'ppo wsk {v}: {r["ms_per_cycle"]:.3f} ms/cycle, {r["value"]:.0f} env-steps/s, rollout step {r["rollout_step_latency_us"]} us, loss {r["final_loss"]:.6f}', flush=True)
+L.mansy_gemm_f32_wsk(1)
