@@ -393,7 +393,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_dma_kernel(GemmParams p) {
 // barrier inside the loop: a wave only reads what it staged itself, ordered by its own vmcnt; the next tile is requested as soon as the current one
 // sits in registers and flies under its MFMAs; 32 KB of LDS per workgroup, so five fit a CU), the four partial blocks are summed
 // through LDS in wave order (deterministic), then the shared row-major epilogue runs.  A K-contiguous; B K-contiguous or K-major.
-template <bool BKM>
+template <bool AK, bool BKM>
 __global__ __launch_bounds__(NT) void gemm_f32_wsk_kernel(GemmParams p) {
   constexpr int T = 32, TILE_FLOATS = T * BK, WAVE_FLOATS = 2 * TILE_FLOATS, CLD = T + 4;       // ONE stage per wave: 8 KB (32 KB per workgroup, five per CU)
   static_assert(T * CLD <= WAVE_FLOATS, "a partial block must fit a wave's stage");
@@ -410,8 +410,26 @@ __global__ __launch_bounds__(NT) void gemm_f32_wsk_kernel(GemmParams p) {
     int t = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + local;
     split = t / per_split; t -= split * per_split;
     tile_y = t / gridDim.x; tile_x = t - tile_y * gridDim.x;
+    if (AK && p.ep.tile_list) {          // the list names 64 x 64 tiles (column tile, row tile): four 32 x 32 blocks each
+      const int e = t >> 2, sub = t & 3;
+      tile_x = 2 * p.ep.tile_list[2 * e] + (sub & 1); tile_y = 2 * p.ep.tile_list[2 * e + 1] + (sub >> 1);
+    }
+  }
+  const float* Ap = p.A; const float* Bp = p.B; float* Cp = p.C; float* rowsum_dst = p.ep.a_rowsum;
+  if (AK && p.A2) {                                 // two same-shape problems in one launch: the upper half of the splits is problem 2
+    const int prob = split / p.splits_pp;
+    split -= prob * p.splits_pp;
+    if (prob) { Ap = p.A2; Bp = p.B2; Cp = p.C2; rowsum_dst = p.a_rowsum2; }
   }
   const int m0 = tile_y * T, n0 = tile_x * T;
+  // the column blocks of this row panel that run share the row-sum work (see gemm_f32_dma_kernel)
+  int rs_first = 0, rs_cnt = (p.N + T - 1) / T;
+  if (AK && p.ep.tile_nrange) {                     // the table is per 64-row tile of C
+    const int lo = p.ep.tile_nrange[2 * (m0 / 64)], hi = p.ep.tile_nrange[2 * (m0 / 64) + 1];
+    if (n0 >= hi || n0 + T <= lo) return;
+    rs_first = lo / T;
+    rs_cnt = min(rs_cnt, (hi + T - 1) / T) - rs_first;
+  }
   int k_begin = split * p.k_per_split;
   int k_end = min(p.K, k_begin + p.k_per_split);
   if (p.ep.tile_krange) {                          // block-diagonal weights: the table is per 64-column tile
@@ -420,22 +438,24 @@ __global__ __launch_bounds__(NT) void gemm_f32_wsk_kernel(GemmParams p) {
   }
   const int nk = max(0, (k_end - k_begin) / BK);
 
-  // this WAVE's pieces of a tile: A image [32][32] (128-B rows, k-chunk c of a row in slot c ^ ((row >> 1) & 7)), B likewise or, K-major, [32 k][32 n] linear
+  // this WAVE's pieces of a tile.  K-contiguous operand: image [32][32] (128-B rows, k-chunk c of a row in slot c ^ ((row >> 1) & 7));
+  // K-major operand: image [32 k][32 rows] linear
   unsigned voa[4], vob[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = i * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((row >> 1) & 7);
-    voa[i] = (unsigned)((min(m0 + row, p.M - 1) - m0) * p.lda + c * 4) * 4u;
+    if (!AK) voa[i] = (unsigned)((min(m0 + row, p.M - 1) - m0) * p.lda + c * 4) * 4u;
+    else voa[i] = (unsigned)(row * p.lda + (min(m0 + (lane & 7) * 4, p.M - 4) - m0)) * 4u;       // row = k index of the tile here
     if (!BKM) vob[i] = (unsigned)((min(n0 + row, p.N - 1) - n0) * p.ldb + c * 4) * 4u;
-    else vob[i] = (unsigned)(row * p.ldb + (min(n0 + (lane & 7) * 4, p.N - 4) - n0)) * 4u;       // row = k index of the tile here
+    else vob[i] = (unsigned)(row * p.ldb + (min(n0 + (lane & 7) * 4, p.N - 4) - n0)) * 4u;
   }
-  const float* const sa = p.A + (long long)m0 * p.lda + k_begin;
-  const float* const sb = BKM ? p.B + (long long)k_begin * p.ldb + n0 : p.B + (long long)n0 * p.ldb + k_begin;
-  const long long step_b = BKM ? (long long)BK * p.ldb : BK;
+  const float* const sa = AK ? Ap + (long long)k_begin * p.lda + m0 : Ap + (long long)m0 * p.lda + k_begin;
+  const float* const sb = BKM ? Bp + (long long)k_begin * p.ldb + n0 : Bp + (long long)n0 * p.ldb + k_begin;
+  const long long step_a = AK ? (long long)BK * p.lda : BK, step_b = BKM ? (long long)BK * p.ldb : BK;
   const unsigned lds_w = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem + (unsigned)wave * (WAVE_FLOATS * 4u));
   auto dma = [&](int kt) {
-    const float* ca = sa + (long long)kt * BK;
+    const float* ca = sa + (long long)kt * step_a;
     const float* cb = sb + (long long)kt * step_b;
 #pragma unroll
     for (int i = 0; i < 4; ++i) glds16(voa[i], ca, lds_w + i * 1024u);
@@ -449,6 +469,8 @@ __global__ __launch_bounds__(NT) void gemm_f32_wsk_kernel(GemmParams p) {
   float* const mine = smem + wave * WAVE_FLOATS;
   const float* const a_l = mine;
   const float* const b_l = mine + TILE_FLOATS;
+  const bool do_rowsum = AK && rowsum_dst != nullptr && tile_x - rs_first < BK;
+  float rowsum = 0.f;
   int kt = wave;
   if (kt < nk) dma(kt);
   for (; kt < nk; kt += 4) {
@@ -456,8 +478,11 @@ __global__ __launch_bounds__(NT) void gemm_f32_wsk_kernel(GemmParams p) {
     float af[2][8], bf[2][8];
 #pragma unroll
     for (int chunk = 0; chunk < 2; ++chunk) {
-      read_frag_dma<T, false>(a_l, 0, r, h, chunk, af[chunk]);
+      read_frag_dma<T, AK>(a_l, 0, r, h, chunk, af[chunk]);
       read_frag_dma<T, BKM>(b_l, 0, r, h, chunk, bf[chunk]);
+    }
+    if (do_rowsum && lane < T) {                         // bias gradient: this block's share of the k-rows of the staged (K-major) A tile
+      for (int kk = tile_x - rs_first; kk < BK; kk += rs_cnt) rowsum += a_l[kk * T + lane];
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the whole tile is in registers: the stage may be staged again ...
     if (kt + 4 < nk) dma(kt + 4);                        // ... and the wave's next tile flies under this tile's 16 MFMAs
@@ -466,22 +491,44 @@ __global__ __launch_bounds__(NT) void gemm_f32_wsk_kernel(GemmParams p) {
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[chunk][kk], bf[chunk][kk], acc, 0, 0, 0);
   }
+  if (do_rowsum && lane < T && m0 + lane < p.M) atomicAdd(rowsum_dst + m0 + lane, rowsum);
   // partial block of this wave -> its own (now idle) stage, [32][36]
 #pragma unroll
   for (int e = 0; e < 16; ++e) mine[((e & 3) + 8 * (e >> 2) + 4 * h) * CLD + r] = acc[e];
   __syncthreads();
-  {   // sum the four partial blocks in wave order; thread -> (row tid / 8, float4 tid % 8): the mapping of gemm_epilogue_rows<32, 32, 256>
-    const int off = (tid >> 3) * CLD + (tid & 7) * 4;
-    float4 v = *reinterpret_cast<const float4*>(smem + off);
+  const int off = (tid >> 3) * CLD + (tid & 7) * 4;      // thread -> (row tid / 8, float4 tid % 8): the mapping of gemm_epilogue_rows<32, 32, 256>
+  float4 v = *reinterpret_cast<const float4*>(smem + off);
 #pragma unroll
-    for (int w = 1; w < 4; ++w) {
-      const float4 q = *reinterpret_cast<const float4*>(smem + w * WAVE_FLOATS + off);
-      v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
-    }
-    *reinterpret_cast<float4*>(smem + off) = v;           // read back by the same thread below
+  for (int w = 1; w < 4; ++w) {                          // the four partial blocks, in wave order
+    const float4 q = *reinterpret_cast<const float4*>(smem + w * WAVE_FLOATS + off);
+    v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
   }
+  float* const Cz = Cp + (long long)split * p.ep.split_slab;
+  if (p.ep.accumulate && p.splits_pp == 1 && p.c_rmw_ok) {
+    // accumulating product (dW) with no K split over workgroups: this workgroup is the only owner of its block -- plain read-add-write
+    const int row = m0 + (tid >> 3), col = n0 + (tid & 7) * 4;
+    if (row < p.M && col < p.N) {                        // N % 4 == 0 on this path: a float4 is entirely in or out
+      float4* dst = reinterpret_cast<float4*>(Cz + (long long)row * p.ldc + col);
+      const float4 c = *dst;
+      *dst = make_float4(c.x + v.x, c.y + v.y, c.z + v.z, c.w + v.w);
+    }
+    return;
+  }
+  if (p.ep.accumulate || (p.splits_pp > 1 && p.ep.split_slab == 0)) {
+    // accumulating product with a K split over workgroups / K split without slabs: plain epilogue by construction, partial sums added atomically
+    const int row = m0 + (tid >> 3), col = n0 + (tid & 7) * 4;
+    if (row < p.M) {
+      float* dst = Cz + (long long)row * p.ldc + col;
+      if (col + 0 < p.N) atomicAdd(dst + 0, v.x);
+      if (col + 1 < p.N) atomicAdd(dst + 1, v.y);
+      if (col + 2 < p.N) atomicAdd(dst + 2, v.z);
+      if (col + 3 < p.N) atomicAdd(dst + 3, v.w);
+    }
+    return;
+  }
+  *reinterpret_cast<float4*>(smem + off) = v;             // read back by the same thread below
   __syncthreads();
-  gemm_epilogue_rows<T, T, NT>(p, smem, m0, n0, tid, p.C + (long long)split * p.ep.split_slab);
+  gemm_epilogue_rows<T, T, NT>(p, smem, m0, n0, tid, Cz);
 }
 
 template <int BM, int BN, int NS = 2>
@@ -567,8 +614,18 @@ extern "C" int mansy_prof_gemm_collect(double* total_ms, long long* launches, do
 
 // A/B knob (diagnostic): LDS stages of the 64 x 64 fp32 LDS-DMA loop's operand ring (2 = one K-tile in flight, 3 / 4 = two / three); v < 2 only queries
 static int g_f32_wsk = 1;        // A/B knob (diagnostic): 1 = small products run on the wave-split-K loop (gemm_f32_wsk_kernel), 0 = on the 64 x 64 loop
-extern "C" int mansy_gemm_f32_wsk(int v) { const int old = g_f32_wsk; if (v == 0 || v == 1) g_f32_wsk = v; return old; }
+extern "C" int mansy_gemm_f32_wsk(int v);
+static int g_f32_wsk_max_tiles = 256;      // products with at most this many 64 x 64 tiles (x K splits) count as small; mansy_gemm_f32_wsk(v >= 16) sets it
+static int g_f32_wsk_tn = 1;     // the same for the weight-gradient (TN) products; mansy_gemm_f32_wsk(2) / (3) turn it off / on
 static int g_f32_ring = 2;
+int mansy_gemm_wsk_tn_enabled() { return g_f32_wsk && g_f32_wsk_tn; }
+extern "C" int mansy_gemm_f32_wsk(int v) {
+  const int old = g_f32_wsk;
+  if (v == 0 || v == 1) g_f32_wsk = v;
+  if (v == 2 || v == 3) g_f32_wsk_tn = v - 2;
+  if (v >= 16) g_f32_wsk_max_tiles = v;
+  return old;
+}
 extern "C" int mansy_gemm_f32_ring(int v) { const int old = g_f32_ring; if (v >= 2 && v <= 4) g_f32_ring = v; return old; }
 
 // tile codes: 128 -> 128x128, 96 -> 128x64 (LDS-DMA loop only), 64 -> 64x64
@@ -577,14 +634,27 @@ static int gemm_dispatch(const GemmParams& p, int tile, bool dma, int bf, int a_
       p.ep.b_planes_ld % 8 == 0 && p.ep.b_plane_stride % 8 == 0)
     return mansy_gemm_bf16p_dispatch(p, tile, bf, st);            // weights pre-split into planes: B by LDS-DMA
   if (bf) return mansy_gemm_bf16s_dispatch(p, tile, bf, a_kmajor, b_kmajor, splits, st);
-  if (dma && g_f32_wsk && tile == 64 && !a_kmajor && p.c_vec_ok && !p.ep.accumulate && (splits == 1 || p.ep.split_slab != 0) && !p.ep.tile_list &&
-      !p.ep.tile_nrange && !p.ep.a_rowsum && !p.A2 && (long long)mansy_ceil_div(p.M, 64) * mansy_ceil_div(p.N, 64) * splits <= 256) {
-    // a launch that cannot fill the chip: 32 x 32 blocks, the K-tiles split over the workgroup's four waves
-    dim3 grid(mansy_ceil_div(p.N, 32), mansy_ceil_div(p.M, 32), splits);
-    if (b_kmajor) MANSY_GEMM_LAUNCH((gemm_f32_wsk_kernel<true>), grid, dim3(NT), st, p);
-    else MANSY_GEMM_LAUNCH((gemm_f32_wsk_kernel<false>), grid, dim3(NT), st, p);
-    MANSY_LAUNCH_CHECK();
-    return MANSY_OK;
+  if (dma && g_f32_wsk && tile == 64 && (p.c_vec_ok || p.ep.accumulate)) {
+    // a launch that cannot fill the chip: 32 x 32 blocks, the K-tiles split over the workgroup's four waves.  NT / NN: plain or slab-split stores,
+    // any fused epilogue; TN (the weight-gradient products): accumulating (atomics) or slab-split, row-sum rider, tile list / ranges, paired problems
+    const long long tiles64 = p.ep.tile_list ? (long long)p.ep.tile_list_n : (long long)mansy_ceil_div(p.M, 64) * mansy_ceil_div(p.N, 64);
+    const bool small = tiles64 * splits <= g_f32_wsk_max_tiles;
+    const bool store_ok = !p.ep.accumulate && (splits == 1 || p.ep.split_slab != 0);
+    if (small && !a_kmajor && p.c_vec_ok && store_ok && !p.ep.tile_list && !p.ep.tile_nrange && !p.ep.a_rowsum && !p.A2) {
+      dim3 grid(mansy_ceil_div(p.N, 32), mansy_ceil_div(p.M, 32), splits);
+      if (b_kmajor) MANSY_GEMM_LAUNCH((gemm_f32_wsk_kernel<false, true>), grid, dim3(NT), st, p);
+      else MANSY_GEMM_LAUNCH((gemm_f32_wsk_kernel<false, false>), grid, dim3(NT), st, p);
+      MANSY_LAUNCH_CHECK();
+      return MANSY_OK;
+    }
+    if (small && g_f32_wsk_tn && a_kmajor && b_kmajor && !p.ep.tile_krange && (p.ep.accumulate || splits == p.splits_pp * (p.A2 ? 2 : 1)) &&
+        (p.ep.accumulate || ((p.splits_pp == 1 || p.ep.split_slab != 0) && p.c_vec_ok)) && (!p.ep.tile_list || p.ep.tile_nrange)) {
+      dim3 grid(mansy_ceil_div(p.N, 32), mansy_ceil_div(p.M, 32), splits);
+      if (p.ep.tile_list) grid = dim3(4 * p.ep.tile_list_n, 1, splits);
+      MANSY_GEMM_LAUNCH((gemm_f32_wsk_kernel<true, true>), grid, dim3(NT), st, p);
+      MANSY_LAUNCH_CHECK();
+      return MANSY_OK;
+    }
   }
   if (dma) {
     if (tile == 128) return launch_dma<128, 128>(p, a_kmajor, b_kmajor, splits, st);
@@ -615,6 +685,7 @@ int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B,
   GemmParams p;
   p.A = A; p.B = B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.ep = ep;
   p.col_group = (ep.tile_nrange || ep.tile_list || ep.tile_krange) ? 0 : g_col_group;
+  p.c_rmw_ok = (reinterpret_cast<uintptr_t>(C) & 15) == 0 && (!ep.pair_C || (reinterpret_cast<uintptr_t>(ep.pair_C) & 15) == 0) && ldc % 4 == 0 && N % 4 == 0;
   p.vec_ok = ((lda % 4) == 0) && ((ldb % 4) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
              ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (K % 4 == 0) && (!a_kmajor || M % 4 == 0) &&
              (!b_kmajor || N % 4 == 0);
@@ -692,7 +763,12 @@ int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B,
   const long long tiles = tile_count(M, N, tile) * n_prob;
   // split-K only for plain accumulating products (dW = dY^T X): partial sums are atomically added
   int splits = 1;
+  // small accumulating weight-gradient product on the wave-split-K loop: the K-tiles are split inside the workgroup, so no split over workgroups
+  // (every element of C then has ONE owner: a plain read-add-write instead of float atomics)
+  const bool wsk_tn = dma && !bf && g_f32_wsk && g_f32_wsk_tn && tile == 64 && a_kmajor && b_kmajor && plain && ep.accumulate && !p.ep.tile_list &&
+                      tiles <= g_f32_wsk_max_tiles && ep.split_slab == 0;
   if (force_splitk > 0) splits = force_splitk;
+  else if (wsk_tn) splits = 1;
   else if (plain && ep.accumulate && tiles < 256) {
     // fill ONE round of resident workgroups, never spill a few into a second: 2 per CU for the 128x128 / 64x64 loops as
     // dispatched here, 3 per CU for the 128x64 LDS-DMA loop (48 KB LDS, 136 VGPRs) -- tools/dw_split_sweep.py

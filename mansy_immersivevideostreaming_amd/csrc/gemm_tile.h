@@ -36,6 +36,7 @@ struct GemmParams {
   // > 0: the XCD-aware tile order walks the column tiles in groups of col_group (all row panels of a group before the next group), so that an
   // XCD's L2 holds ONE group's slice of B next to the A panels it streams (wide-N products: B alone is 3 MB of the 4 MB L2 at N = 1536)
   int col_group = 0;
+  int c_rmw_ok = 0;  // C (and C2) 16-byte aligned, ldc % 4 == 0, N % 4 == 0: an accumulating product whose blocks have one owner may read-add-write float4
 };
 
 // Row-major pass of the fused epilogue: the C tile sits in LDS as [BM][BN + 4] floats (`smem`, written by the caller, who has also

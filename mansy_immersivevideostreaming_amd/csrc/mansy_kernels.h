@@ -131,6 +131,8 @@ struct DistillShape { int B, S, M, C; int sync_world = 1; int (*hook)(int, void*
 // Invokes the call's data-parallel hook (mansy_vp_config::bn_sync_fn; fn == nullptr: the deprecated process-wide registration of
 // capi.hip: mansy_set_bn_sync_hook); which = 0 forward stats, 1 backward stats, 2 decoder-side gradients final.
 int mansy_bn_sync_invoke(int which, int (*fn)(int, void*), void* user);
+// the wave-split-K loop serves small fp32 weight-gradient (TN) products (gemm_f32.hip; callers that pick a K split for such a product ask first)
+int mansy_gemm_wsk_tn_enabled();
 // stats_d: device scratch of 6*C doubles ([sum, sumsq] forward, [sum g, sum g*xhat] backward global + local copy).
 int mansy_launch_distill_fwd(const float* conv, const float* bn_w, const float* bn_b, float* run_mean, float* run_var,
                              long long* num_batches, float* mean_out, float* rstd_out, float* mem, unsigned char* argmax,

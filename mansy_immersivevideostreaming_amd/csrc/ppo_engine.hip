@@ -1105,6 +1105,12 @@ struct PEng {
     // per K-tile (2 us at K = 3 264 from HBM), so the reduce dimension is what fills the chip
     int req = std::min(DW_SLABS, std::max(1, (Bmain / 32 + 2) / 3));
     if (prec != 0) req = std::min(req, 6);            // the split-bf16 loops run (and store) every tile of every slab
+    else if (mansy_gemm_wsk_tn_enabled()) {
+      // minibatch-sized products run on the wave-split-K loop, which splits the K-tiles over a workgroup's four waves itself: ~12 K-tiles per slab
+      // there (3 per wave) -- fewer, larger workgroups and fewer slabs for the unpack launch to add
+      const int req_w = std::max(1, (Bmain / 32 + 8) / 12);
+      if ((long long)active_tiles(identifier, K, nullptr) * req_w <= 256) req = req_w;
+    }
     const int nsplit = mansy_gemm_effective_splits(Bmain, req);
     const long long slab = (long long)FEAT * K;
     MANSY_REQUIRE(nsplit <= DW_SLABS, "featnet_bwd: %d slabs exceed the workspace", nsplit);

@@ -36,9 +36,39 @@ for (M, N, Kd, bk) in ((256, 1280, 320, 0), (512, 1280, 320, 0), (512, 1280, 256
         e1.record(); torch.cuda.synchronize()
         line += f'  wsk {v}: {e0.elapsed_time(e1) / 200 * 1e3:6.2f} us (err {err:.1e})'
     print(line, flush=True)
-for rnd in range(3):
-    for v in (0, 1):
+# weight-gradient (TN) form: C += A^T B with the bias-gradient rider, knob 2 / 3 = off / on
+L.mansy_gemm_f32_wsk(1); L.mansy_gemm_f32_wsk(3)
+for (M, N, Kd) in ((128, 1280, 512), (256, 1280, 512), (128, 1280, 3264), (36, 132, 96)):
+    A = torch.randn(Kd, M, generator=g).to(dev); B = torch.randn(Kd, N, generator=g).to(dev)
+    ref = A.double().t() @ B.double() + 1.0
+    line = f'gemm TN M={M} N={N} K={Kd}:'
+    for v in (2, 3):
         L.mansy_gemm_f32_wsk(v)
+        out = torch.ones(M, N, device=dev); rs = torch.zeros(M, device=dev)
+        K.gemm(A, B, True, True, out=out, accumulate=True, a_rowsum=rs, force_tile=64)
+        err = ((out.double() - ref).abs().max() / ref.abs().max()).item()
+        rerr = ((rs.double() - A.double().sum(0)).abs().max() / A.double().sum(0).abs().max()).item()
+        scratch = torch.zeros(M, N, device=dev)
+        for _ in range(5): K.gemm(A, B, True, True, out=scratch, accumulate=True, force_tile=64)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        gph = torch.cuda.CUDAGraph(); s_ = torch.cuda.Stream()
+        with torch.cuda.stream(s_):
+            torch.cuda.synchronize()
+            with torch.cuda.graph(gph, stream=s_):
+                for _ in range(50): K.gemm(A, B, True, True, out=scratch, accumulate=True, force_tile=64)
+        gph.replay(); torch.cuda.synchronize()
+        e0.record()
+        for _ in range(4): gph.replay()
+        e1.record(); torch.cuda.synchronize()
+        line += f'  tn {v - 2}: {e0.elapsed_time(e1) / 200 * 1e3:6.2f} us (err {err:.1e}, rowsum err {rerr:.1e})'
+    print(line, flush=True)
+for rnd in range(3):
+    for v in (0, 1, 3):
+        if v == 3:
+            L.mansy_gemm_f32_wsk(1); L.mansy_gemm_f32_wsk(3)
+        else:
+            L.mansy_gemm_f32_wsk(v); L.mansy_gemm_f32_wsk(2)
         r = bench.bench_ppo(0, 1, dev, mdist, cycles=20, warmup=3, rollout_probe=True)
         print(f'ppo wsk {v}: {r["ms_per_cycle"]:.3f} ms/cycle, {r["value"]:.0f} env-steps/s, rollout step {r["rollout_step_latency_us"]} us, loss {r["final_loss"]:.6f}', flush=True)
-L.mansy_gemm_f32_wsk(1)
+L.mansy_gemm_f32_wsk(1); L.mansy_gemm_f32_wsk(3)
