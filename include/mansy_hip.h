@@ -404,10 +404,7 @@ int mansy_prof_gemm_collect(double* total_ms, long long* launches, double* flops
 /* A/B knob (diagnostic): column-group width of the XCD-aware tile order of the fp32 LDS-DMA loop for products with more column tiles than
  * that (default 12; 0 = plain row-panel-major order); v < 0 only queries.  Returns the previous value.  Never changes a result (tile ORDER only). */
 int mansy_gemm_col_group(int v);
-/* A/B knob (diagnostic): LDS stages of the operand ring of the 64 x 64 fp32 LDS-DMA loop: 2 = one K-tile in flight, 3 / 4 = two / three under counted
- * waits; v < 2 only queries.  Returns the previous value.  Never changes a result (same MFMAs, same order). */
-int mansy_gemm_f32_ring(int v);
-/* A/B knob (diagnostic): 1 (default) = fp32 products too small to fill the chip (<= 256 tiles of 64 x 64 incl. K splits, K-contiguous A, plain or
+/* A/B knob (diagnostic): 1 (default) = fp32 products too small to fill the chip (<= 200 tiles of 64 x 64 incl. K splits, K-contiguous A, plain or
  * slab-split store) run on the wave-split-K loop (32 x 32 blocks, the four waves of a workgroup split the K-tiles; partial sums added in wave order:
  * deterministic, but a different summation order than the 64 x 64 loop's), 0 = on the 64 x 64 loop; other values only query.  Returns the previous value. */
 int mansy_gemm_f32_wsk(int v);

@@ -142,7 +142,6 @@ _PROTOS = {
     'mansy_gemm_bf16_variant': [c_int],
     'mansy_prof_gemm_collect': [P, P, P],
     'mansy_gemm_col_group': [c_int],
-    'mansy_gemm_f32_ring': [c_int],
     'mansy_gemm_f32_wsk': [c_int],
     'mansy_prof_launch_count': [],
 }

@@ -253,17 +253,12 @@ __device__ __forceinline__ void read_frag_dma(const float* __restrict__ lds, int
   }
 }
 
-// NS = LDS stages of the operand ring: NS - 1 K-tiles in flight under counted `s_waitcnt vmcnt` (round 4; NS = 2 is the round-1 loop: one tile
-// in flight, vmcnt(0) per K-tile).  A launch with ONE workgroup per CU -- the PPO cycle's ~130 small products, 80-160 workgroups each -- runs its K
-// loop at one L2 / HBM round trip per K-tile with one tile in flight (0.7-1 us against 0.45 us of MFMA for a 64 x 64 tile); with three in flight the
-// round trips overlap.  Same MFMAs in the same order: results bit-identical for every NS.
-template <int BM, int BN, bool AK, bool BKM, int NS = 2>
+template <int BM, int BN, bool AK, bool BKM>
 __global__ __launch_bounds__(NT) void gemm_f32_dma_kernel(GemmParams p) {
-  constexpr int TM = BM / 64, TN = BN / 64, PA = BM / 32, PB = BN / 32, D = NS - 1, PPT = PA + PB;      // PPT: DMA pieces per wave and K-tile
+  constexpr int TM = BM / 64, TN = BN / 64, PA = BM / 32, PB = BN / 32;
   constexpr int A_FLOATS = BM * BK, B_FLOATS = BN * BK, STAGE = A_FLOATS + B_FLOATS;
   constexpr int C_FLOATS = BM * (BN + 4);
-  constexpr int SMEM_FLOATS = NS * STAGE > C_FLOATS ? NS * STAGE : C_FLOATS;
-  static_assert(NS >= 2 && NS <= 4 && PPT * (D - 1 > 0 ? D - 1 : 0) <= 15, "piece counts must fit the counted waits");
+  constexpr int SMEM_FLOATS = 2 * STAGE > C_FLOATS ? 2 * STAGE : C_FLOATS;
   __shared__ __attribute__((aligned(1024))) float smem[SMEM_FLOATS];
 
   const int tid = threadIdx.x;
@@ -331,28 +326,25 @@ __global__ __launch_bounds__(NT) void gemm_f32_dma_kernel(GemmParams p) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   float rowsum = 0.f;
-  auto dma = [&](int stage, int kt) {           // tile kt of this workgroup's K range -> ring stage `stage`
-    const float* ca = sa + (long long)kt * step_a;
-    const float* cb = sb + (long long)kt * step_b;
-    const unsigned base = lds_wave + (unsigned)stage * (STAGE * 4u);
+  if (nk > 0) {
 #pragma unroll
-    for (int i = 0; i < PA; ++i) glds16(voa[i], ca, base + i * 4096u);
+    for (int i = 0; i < PA; ++i) glds16(voa[i], sa, lds_wave + i * 4096u);
 #pragma unroll
-    for (int i = 0; i < PB; ++i) glds16(vob[i], cb, base + A_FLOATS * 4u + i * 4096u);
-  };
-#pragma unroll
-  for (int d = 0; d < D; ++d)
-    if (d < nk) dma(d, d);
-  int cur = 0;
+    for (int i = 0; i < PB; ++i) glds16(vob[i], sb, lds_wave + A_FLOATS * 4u + i * 4096u);
+  }
   for (int kt = 0; kt < nk; ++kt) {
-    // this wave's pieces of tile kt have landed; the younger tiles' pieces (min(D - 1, nk - 1 - kt) tiles, PPT each) stay in flight
-    const int ahead = nk - 1 - kt;
-    if (D >= 3 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPT) : "memory");
-    else if (D >= 2 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPT) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int cur = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of tile kt have landed ...
     __builtin_amdgcn_s_barrier();                        // ... and everyone's; everyone is done reading tile kt-1
     asm volatile("" ::: "memory");
-    if (kt + D < nk) dma(cur == 0 ? NS - 1 : cur - 1, kt + D);       // into the stage tile kt - 1 occupied
+    sa += step_a; sb += step_b;                          // corners of tile kt+1
+    const unsigned lds_next = lds_wave + (unsigned)(cur ^ 1) * (STAGE * 4u);
+    if (kt + 1 < nk) {
+#pragma unroll
+      for (int i = 0; i < PA; ++i) glds16(voa[i], sa, lds_next + i * 4096u);
+#pragma unroll
+      for (int i = 0; i < PB; ++i) glds16(vob[i], sb, lds_next + A_FLOATS * 4u + i * 4096u);
+    }
     const float* a_l = smem + cur * STAGE;
     const float* b_l = a_l + A_FLOATS;
     if (AK && rowsum_dst && tid < BM) {          // bias gradient: row sums of the staged A tile.  Every n-tile of this
@@ -376,7 +368,6 @@ __global__ __launch_bounds__(NT) void gemm_f32_dma_kernel(GemmParams p) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // LDS reads retired before the barrier that frees this buffer
-    cur = cur == NS - 1 ? 0 : cur + 1;
   }
   __syncthreads();                                        // staging LDS idle: the epilogue reuses it
 
@@ -531,15 +522,15 @@ __global__ __launch_bounds__(NT) void gemm_f32_wsk_kernel(GemmParams p) {
   gemm_epilogue_rows<T, T, NT>(p, smem, m0, n0, tid, Cz);
 }
 
-template <int BM, int BN, int NS = 2>
+template <int BM, int BN>
 int launch_dma(const GemmParams& p, int a_kmajor, int b_kmajor, int splits, hipStream_t st) {
   dim3 grid(mansy_ceil_div(p.N, BN), mansy_ceil_div(p.M, BM), splits);
   if (BM == 64 && BN == 64 && p.ep.tile_list) grid = dim3(p.ep.tile_list_n, 1, splits);      // only the listed tiles
   dim3 block(NT);
-  if (!a_kmajor && !b_kmajor) MANSY_GEMM_LAUNCH((gemm_f32_dma_kernel<BM, BN, false, false, NS>), grid, block, st, p);
-  else if (!a_kmajor && b_kmajor) MANSY_GEMM_LAUNCH((gemm_f32_dma_kernel<BM, BN, false, true, NS>), grid, block, st, p);
-  else if (a_kmajor && b_kmajor) MANSY_GEMM_LAUNCH((gemm_f32_dma_kernel<BM, BN, true, true, NS>), grid, block, st, p);
-  else MANSY_GEMM_LAUNCH((gemm_f32_dma_kernel<BM, BN, true, false, NS>), grid, block, st, p);
+  if (!a_kmajor && !b_kmajor) MANSY_GEMM_LAUNCH((gemm_f32_dma_kernel<BM, BN, false, false>), grid, block, st, p);
+  else if (!a_kmajor && b_kmajor) MANSY_GEMM_LAUNCH((gemm_f32_dma_kernel<BM, BN, false, true>), grid, block, st, p);
+  else if (a_kmajor && b_kmajor) MANSY_GEMM_LAUNCH((gemm_f32_dma_kernel<BM, BN, true, true>), grid, block, st, p);
+  else MANSY_GEMM_LAUNCH((gemm_f32_dma_kernel<BM, BN, true, false>), grid, block, st, p);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }
@@ -612,12 +603,12 @@ extern "C" int mansy_prof_gemm_collect(double* total_ms, long long* launches, do
   return MANSY_OK;
 }
 
-// A/B knob (diagnostic): LDS stages of the 64 x 64 fp32 LDS-DMA loop's operand ring (2 = one K-tile in flight, 3 / 4 = two / three); v < 2 only queries
 static int g_f32_wsk = 1;        // A/B knob (diagnostic): 1 = small products run on the wave-split-K loop (gemm_f32_wsk_kernel), 0 = on the 64 x 64 loop
 extern "C" int mansy_gemm_f32_wsk(int v);
-static int g_f32_wsk_max_tiles = 256;      // products with at most this many 64 x 64 tiles (x K splits) count as small; mansy_gemm_f32_wsk(v >= 16) sets it
+static int g_f32_wsk_max_tiles = 200;      // products with at most this many 64 x 64 tiles (x K splits) count as small (mansy_gemm_f32_wsk(v >= 16) sets it): the PPO
+                                            // cycle's products have 80-160; at 256 -- the half-batch decoder products of the VP step, two of them in flight on two streams -- the 64 x 64
+                                            // loop wins inside the step (profiles/r04_f32_wsk_threshold.txt)
 static int g_f32_wsk_tn = 1;     // the same for the weight-gradient (TN) products; mansy_gemm_f32_wsk(2) / (3) turn it off / on
-static int g_f32_ring = 2;
 int mansy_gemm_wsk_tn_enabled() { return g_f32_wsk && g_f32_wsk_tn; }
 extern "C" int mansy_gemm_f32_wsk(int v) {
   const int old = g_f32_wsk;
@@ -626,7 +617,6 @@ extern "C" int mansy_gemm_f32_wsk(int v) {
   if (v >= 16) g_f32_wsk_max_tiles = v;
   return old;
 }
-extern "C" int mansy_gemm_f32_ring(int v) { const int old = g_f32_ring; if (v >= 2 && v <= 4) g_f32_ring = v; return old; }
 
 // tile codes: 128 -> 128x128, 96 -> 128x64 (LDS-DMA loop only), 64 -> 64x64
 static int gemm_dispatch(const GemmParams& p, int tile, bool dma, int bf, int a_kmajor, int b_kmajor, int splits, hipStream_t st) {
@@ -659,8 +649,6 @@ static int gemm_dispatch(const GemmParams& p, int tile, bool dma, int bf, int a_
   if (dma) {
     if (tile == 128) return launch_dma<128, 128>(p, a_kmajor, b_kmajor, splits, st);
     if (tile == 96) return launch_dma<128, 64>(p, a_kmajor, b_kmajor, splits, st);
-    if (g_f32_ring == 4) return launch_dma<64, 64, 4>(p, a_kmajor, b_kmajor, splits, st);
-    if (g_f32_ring == 3) return launch_dma<64, 64, 3>(p, a_kmajor, b_kmajor, splits, st);
     return launch_dma<64, 64>(p, a_kmajor, b_kmajor, splits, st);
   }
   if (p.vec_ok) {

@@ -77,7 +77,7 @@ def test_gemm_epilogue_dropout_matches_shared_hash(K):
 
 @pytest.mark.parametrize('M,N,Kd,bk', [(256, 1280, 320, 0), (512, 1280, 256, 1), (300, 132, 64, 1), (33, 36, 32, 0), (512, 256, 1280, 0), (100, 64, 96, 0)])
 def test_wave_split_k_loop_vs_the_64x64_loop(K, M, N, Kd, bk):
-    """Round 4: fp32 products too small to fill the chip (<= 256 tiles of 64 x 64) run on gemm_f32_wsk_kernel -- 32 x 32 blocks, the four waves of a
+    """Round 4: fp32 products too small to fill the chip (<= 200 tiles of 64 x 64) run on gemm_f32_wsk_kernel -- 32 x 32 blocks, the four waves of a
     workgroup split the K-tiles, partial blocks added in wave order.  Same product, another (deterministic) summation order: against the 64 x 64
     loop (knob off) to fp32 rounding, against float64 within the exact-fp32 bound, with every fused epilogue, ragged rows / columns, K-major B,
     1..40 K-tiles (waves with no tile at all), run to run bit-identical."""
