@@ -457,6 +457,18 @@ __global__ __launch_bounds__(NT) void gemm_f32_wsk_kernel(GemmParams p) {
   f32x16 acc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  // accumulating product whose blocks have one owner (no K split over workgroups): the old values of C are requested NOW, so that their round
+  // trip (the gradient buffer was zero-filled by another launch: cold) runs under the K loop instead of behind it
+  const bool rmw = AK && p.ep.accumulate && p.splits_pp == 1 && p.c_rmw_ok;
+  float4 c_old = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4* c_dst = nullptr;
+  if (rmw) {
+    const int row = m0 + (tid >> 3), col = n0 + (tid & 7) * 4;
+    if (row < p.M && col < p.N) {                        // N % 4 == 0 on this path: a float4 is entirely in or out
+      c_dst = reinterpret_cast<float4*>(Cp + (long long)row * p.ldc + col);
+      c_old = *c_dst;
+    }
+  }
   float* const mine = smem + wave * WAVE_FLOATS;
   const float* const a_l = mine;
   const float* const b_l = mine + TILE_FLOATS;
@@ -495,14 +507,8 @@ __global__ __launch_bounds__(NT) void gemm_f32_wsk_kernel(GemmParams p) {
     v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
   }
   float* const Cz = Cp + (long long)split * p.ep.split_slab;
-  if (p.ep.accumulate && p.splits_pp == 1 && p.c_rmw_ok) {
-    // accumulating product (dW) with no K split over workgroups: this workgroup is the only owner of its block -- plain read-add-write
-    const int row = m0 + (tid >> 3), col = n0 + (tid & 7) * 4;
-    if (row < p.M && col < p.N) {                        // N % 4 == 0 on this path: a float4 is entirely in or out
-      float4* dst = reinterpret_cast<float4*>(Cz + (long long)row * p.ldc + col);
-      const float4 c = *dst;
-      *dst = make_float4(c.x + v.x, c.y + v.y, c.z + v.z, c.w + v.w);
-    }
+  if (rmw) {                                             // this workgroup is the only owner of its block: plain read-add-write (the read was issued up front)
+    if (c_dst) *c_dst = make_float4(c_old.x + v.x, c_old.y + v.y, c_old.z + v.z, c_old.w + v.w);
     return;
   }
   if (p.ep.accumulate || (p.splits_pp > 1 && p.ep.split_slab == 0)) {
