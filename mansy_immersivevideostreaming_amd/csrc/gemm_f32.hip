@@ -611,7 +611,7 @@ extern "C" int mansy_prof_gemm_collect(double* total_ms, long long* launches, do
 
 static int g_f32_wsk = 1;        // A/B knob (diagnostic): 1 = small products run on the wave-split-K loop (gemm_f32_wsk_kernel), 0 = on the 64 x 64 loop
 extern "C" int mansy_gemm_f32_wsk(int v);
-static int g_f32_wsk_max_tiles = 200;      // products with at most this many 64 x 64 tiles (x K splits) count as small (mansy_gemm_f32_wsk(v >= 16) sets it): the PPO
+static int g_f32_wsk_max_tiles = 200;      // products with at most this many 64 x 64 output tiles (and <= 256 workgroups incl. K splits) count as small (mansy_gemm_f32_wsk(v >= 16) sets it): the PPO
                                             // cycle's products have 80-160; at 256 -- the half-batch decoder products of the VP step, two of them in flight on two streams -- the 64 x 64
                                             // loop wins inside the step (profiles/r04_f32_wsk_threshold.txt)
 static int g_f32_wsk_tn = 1;     // the same for the weight-gradient (TN) products; mansy_gemm_f32_wsk(2) / (3) turn it off / on
@@ -634,7 +634,7 @@ static int gemm_dispatch(const GemmParams& p, int tile, bool dma, int bf, int a_
     // a launch that cannot fill the chip: 32 x 32 blocks, the K-tiles split over the workgroup's four waves.  NT / NN: plain or slab-split stores,
     // any fused epilogue; TN (the weight-gradient products): accumulating (atomics) or slab-split, row-sum rider, tile list / ranges, paired problems
     const long long tiles64 = p.ep.tile_list ? (long long)p.ep.tile_list_n : (long long)mansy_ceil_div(p.M, 64) * mansy_ceil_div(p.N, 64);
-    const bool small = tiles64 * splits <= g_f32_wsk_max_tiles;
+    const bool small = tiles64 <= g_f32_wsk_max_tiles && tiles64 * splits <= 256;      // few output tiles, and the K splits do not fill the chip either
     const bool store_ok = !p.ep.accumulate && (splits == 1 || p.ep.split_slab != 0);
     if (small && !a_kmajor && p.c_vec_ok && store_ok && !p.ep.tile_list && !p.ep.tile_nrange && !p.ep.a_rowsum && !p.A2) {
       dim3 grid(mansy_ceil_div(p.N, 32), mansy_ceil_div(p.M, 32), splits);
