@@ -191,29 +191,45 @@ __device__ __forceinline__ void roll_push(float& ring, float v) {
 // One environment step by one wavefront (lane = tile): MANSYEnv.step (mansy_env.py:154-248).  obs_next: the post-action
 // observation row (terminal one when the episode ends); obs_cur (optional): the same, except that a finished environment is reset and
 // shows the first observation of its next episode.  Used by env_step_kernel and by the fused policy + environment rollout launch.
-__device__ __forceinline__ void env_step_wave(const mansy_env_tables& T, EnvState* st, int e, int lane, int action, float* obs_next, float* obs_cur,
-                                              float* reward, unsigned char* done, float* qoe_parts, const mansy_env_episode_log& elog) {
-  EnvRegs s;
-  load_state(s, st[e], lane);
-  const int rin = (action >= 0 && action < N_ACTION) ? A2R[action][0] : 0;
-  const int rout = (action >= 0 && action < N_ACTION) ? A2R[action][1] : 0;
+//
+// The step is split where the ACTION enters: env_step_requests() issues every load that depends on the state alone, env_step_finish()
+// does the rest.  env_step_kernel calls them back to back; the fused rollout launch (ppo_engine.hip head_out_kernel) loads the state and
+// issues the requests BEFORE the policy's output layer, so that the two dependent round trips (state -> table rows) fly under the
+// logits / softmax / sampling arithmetic instead of behind it.
+struct EnvPre {
+  ObsRows rows_next, rows_cur; float gv, w0, w1, w2; const double* bw; int tlen; double bwc, acc_next; Rates rates;
+};
+__device__ __forceinline__ EnvPre env_step_requests(const mansy_env_tables& T, const EnvRegs& s, int lane) {
+  EnvPre q;
   const int chunk = s.next_chunk;
   // the observation after this step shows chunk + 1 (or, when the episode ends, this chunk again): known now, so its rows are
-  // requested first and arrive while the simulator's dependent loads below are in flight
+  // requested first and arrive while the simulator's dependent loads are in flight
   const bool over_pre = chunk + 1 > s.end_chunk;
-  const ObsRows rows_next = load_obs_rows(T, s.video, s.vp, over_pre ? chunk : chunk + 1, lane);
+  q.rows_next = load_obs_rows(T, s.video, s.vp, over_pre ? chunk : chunk + 1, lane);
   // everything else that depends on the state alone is requested up front too: this chunk's five versions (the allocated version
   // is selected from registers instead of a load that waits for the allocation), the preference weights, the trace bin the
   // download starts in, the next chunk's prediction accuracy
-  const ObsRows rows_cur = load_obs_rows(T, s.video, s.vp, chunk, lane);
+  q.rows_cur = load_obs_rows(T, s.video, s.vp, chunk, lane);
   const size_t vrow = ((size_t)s.vp * T.n_vpchunk_max + (chunk - T.vp_start[s.vp])) * NTL;
-  const float gv = (float)T.vp_gt[vrow + lane];
+  q.gv = (float)T.vp_gt[vrow + lane];
   const float* w = T.qoe_w + 3 * s.qoe;
-  const float w0 = w[0], w1 = w[1], w2 = w[2];
-  const double* bw = T.trace_bw + (size_t)s.trace * T.trace_len_max;
-  const int tlen = T.trace_len[s.trace];
-  double bwc = bw[s.cur_idx];                               // always bw[s.cur_idx]
-  const double acc_next = over_pre ? 0.0 : T.vp_acc[(size_t)s.vp * T.n_vpchunk_max + (chunk + 1 - T.vp_start[s.vp])];
+  q.w0 = w[0]; q.w1 = w[1]; q.w2 = w[2];
+  q.bw = T.trace_bw + (size_t)s.trace * T.trace_len_max;
+  q.tlen = T.trace_len[s.trace];
+  q.bwc = q.bw[s.cur_idx];                                  // always bw[s.cur_idx]
+  q.acc_next = over_pre ? 0.0 : T.vp_acc[(size_t)s.vp * T.n_vpchunk_max + (chunk + 1 - T.vp_start[s.vp])];
+  q.rates = load_rates(T);
+  return q;
+}
+__device__ __forceinline__ void env_step_finish(const mansy_env_tables& T, EnvState* st, int e, int lane, int action, EnvRegs& s, const EnvPre& q,
+                                                float* obs_next, float* obs_cur, float* reward, unsigned char* done, float* qoe_parts,
+                                                const mansy_env_episode_log& elog) {
+  const int rin = (action >= 0 && action < N_ACTION) ? A2R[action][0] : 0;
+  const int rout = (action >= 0 && action < N_ACTION) ? A2R[action][1] : 0;
+  const int chunk = s.next_chunk;
+  const ObsRows& rows_next = q.rows_next; const ObsRows& rows_cur = q.rows_cur;
+  const float gv = q.gv, w0 = q.w0, w1 = q.w1, w2 = q.w2;
+  const double* bw = q.bw; const int tlen = q.tlen; double bwc = q.bwc; const double acc_next = q.acc_next;
   const bool in_pred = rows_cur.pred == 1;
   // ---- pyramid tile-rate allocation
   unsigned long long m = __ballot(in_pred);
@@ -226,7 +242,7 @@ __device__ __forceinline__ void env_step_wave(const mansy_env_tables& T, EnvStat
       if (dist < 0 && ((m >> lane) & 1ull)) dist = sidx;
     }
   }
-  const Rates rates = load_rates(T);
+  const Rates rates = q.rates;
   const int ver = dist == 0 ? rin : closest_rate_version(rates, pick_rate(rates, rout) / (dist > 0 ? dist : 1));
   // ---- Simulator.simulate_download
   int my_size = rows_cur.size[0]; float tq = rows_cur.quality[0];
@@ -295,5 +311,12 @@ __device__ __forceinline__ void env_step_wave(const mansy_env_tables& T, EnvStat
     store_obs(T, s, rows_next, action, lane, obs_cur + (size_t)e * OBS_LD);
   }
   store_state(st[e], s, lane);
+}
+__device__ __forceinline__ void env_step_wave(const mansy_env_tables& T, EnvState* st, int e, int lane, int action, float* obs_next, float* obs_cur,
+                                              float* reward, unsigned char* done, float* qoe_parts, const mansy_env_episode_log& elog) {
+  EnvRegs s;
+  load_state(s, st[e], lane);
+  const EnvPre q = env_step_requests(T, s, lane);
+  env_step_finish(T, st, e, lane, action, s, q, obs_next, obs_cur, reward, done, qoe_parts, elog);
 }
 

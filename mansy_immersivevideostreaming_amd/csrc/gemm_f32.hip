@@ -387,7 +387,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_dma_kernel(GemmParams p) {
 template <bool AK, bool BKM>
 __global__ __launch_bounds__(NT) void gemm_f32_wsk_kernel(GemmParams p) {
   constexpr int T = 32, TILE_FLOATS = T * BK, WAVE_FLOATS = 2 * TILE_FLOATS, CLD = T + 4;       // ONE stage per wave: 8 KB (32 KB per workgroup, five per CU)
-  static_assert(T * CLD <= WAVE_FLOATS, "a partial block must fit a wave's stage");
+  static_assert(T * CLD + 64 <= WAVE_FLOATS, "a partial block and its row sums must fit a wave's stage");
   __shared__ __attribute__((aligned(1024))) float smem[4 * WAVE_FLOATS];
 
   const int tid = threadIdx.x;
@@ -413,13 +413,11 @@ __global__ __launch_bounds__(NT) void gemm_f32_wsk_kernel(GemmParams p) {
     if (prob) { Ap = p.A2; Bp = p.B2; Cp = p.C2; rowsum_dst = p.a_rowsum2; }
   }
   const int m0 = tile_y * T, n0 = tile_x * T;
-  // the column blocks of this row panel that run share the row-sum work (see gemm_f32_dma_kernel)
-  int rs_first = 0, rs_cnt = (p.N + T - 1) / T;
+  int rs_first = 0;                                 // first column block of this row panel that runs
   if (AK && p.ep.tile_nrange) {                     // the table is per 64-row tile of C
     const int lo = p.ep.tile_nrange[2 * (m0 / 64)], hi = p.ep.tile_nrange[2 * (m0 / 64) + 1];
     if (n0 >= hi || n0 + T <= lo) return;
     rs_first = lo / T;
-    rs_cnt = min(rs_cnt, (hi + T - 1) / T) - rs_first;
   }
   int k_begin = split * p.k_per_split;
   int k_end = min(p.K, k_begin + p.k_per_split);
@@ -472,7 +470,10 @@ __global__ __launch_bounds__(NT) void gemm_f32_wsk_kernel(GemmParams p) {
   float* const mine = smem + wave * WAVE_FLOATS;
   const float* const a_l = mine;
   const float* const b_l = mine + TILE_FLOATS;
-  const bool do_rowsum = AK && rowsum_dst != nullptr && tile_x - rs_first < BK;
+  // bias-gradient rider: ONE column block per row panel (the first that runs) sums the k-rows of the staged (K-major) A tiles -- every column block
+  // stages the same tiles.  (Round 4, first form: the panel's column blocks shared the k-rows and each added its 32 sums atomically -- up to 32
+  // workgroups x 4 waves on the same 32 addresses at the end of a 10 us launch.)
+  const bool do_rowsum = AK && rowsum_dst != nullptr && tile_x == rs_first;
   float rowsum = 0.f;
   int kt = wave;
   if (kt < nk) dma(kt);
@@ -484,8 +485,9 @@ __global__ __launch_bounds__(NT) void gemm_f32_wsk_kernel(GemmParams p) {
       read_frag_dma<T, AK>(a_l, 0, r, h, chunk, af[chunk]);
       read_frag_dma<T, BKM>(b_l, 0, r, h, chunk, bf[chunk]);
     }
-    if (do_rowsum && lane < T) {                         // bias gradient: this block's share of the k-rows of the staged (K-major) A tile
-      for (int kk = tile_x - rs_first; kk < BK; kk += rs_cnt) rowsum += a_l[kk * T + lane];
+    if (do_rowsum) {                                     // lane (r, h): row r of the block, k-rows 16 h .. 16 h + 15 of the tile
+#pragma unroll
+      for (int kk = 0; kk < BK / 2; ++kk) rowsum += a_l[(h * (BK / 2) + kk) * T + r];
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the whole tile is in registers: the stage may be staged again ...
     if (kt + 4 < nk) dma(kt + 4);                        // ... and the wave's next tile flies under this tile's 16 MFMAs
@@ -494,11 +496,18 @@ __global__ __launch_bounds__(NT) void gemm_f32_wsk_kernel(GemmParams p) {
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[chunk][kk], bf[chunk][kk], acc, 0, 0, 0);
   }
-  if (do_rowsum && lane < T && m0 + lane < p.M) atomicAdd(rowsum_dst + m0 + lane, rowsum);
-  // partial block of this wave -> its own (now idle) stage, [32][36]
+  // partial block of this wave -> its own (now idle) stage, [32][36]; its row sums behind it
 #pragma unroll
   for (int e = 0; e < 16; ++e) mine[((e & 3) + 8 * (e >> 2) + 4 * h) * CLD + r] = acc[e];
+  if (do_rowsum) mine[T * CLD + lane] = rowsum;
   __syncthreads();
+  if (do_rowsum && tid < T && m0 + tid < p.M) {            // the four waves' sums in wave order, the two k-halves of each; then one add per row
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) t += smem[w * WAVE_FLOATS + T * CLD + tid] + smem[w * WAVE_FLOATS + T * CLD + 32 + tid];
+    if (p.splits_pp == 1) rowsum_dst[m0 + tid] += t;      // the only workgroup of the launch that owns these rows' sums
+    else atomicAdd(rowsum_dst + m0 + tid, t);             // K split over workgroups: one add per split
+  }
   const int off = (tid >> 3) * CLD + (tid & 7) * 4;      // thread -> (row tid / 8, float4 tid % 8): the mapping of gemm_epilogue_rows<32, 32, 256>
   float4 v = *reinterpret_cast<const float4*>(smem + off);
 #pragma unroll

@@ -379,35 +379,48 @@ __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const f
     if (blockIdx.y == 0) { l_adv = lf.adv[l_bi]; l_act = lf.act[l_bi]; l_logp_old = lf.logp_old[l_bi]; l_mean = lf.adv_stats[0]; l_std = lf.adv_stats[1]; }
     else { l_ret = lf.ret[l_bi]; l_vold = lf.value_clip ? lf.v_old[l_bi] : 0.f; }
   }
-  float a0, a1;
-  if (nsplit > 0) {
-    a0 = d.fc_b[lane]; a1 = d.fc_b[64 + lane];
-    const float* pre = A1pre + (size_t)row * pre_ld + d.pre_col;
-    // all slabs requested up front at clamped indices (a run-time trip count made hipcc wait for every pair of loads: up to 16
-    // dependent L2 round trips); summed in slab order
-    float p0[MAX_SLABS], p1[MAX_SLABS];
-#pragma unroll
-    for (int z = 0; z < MAX_SLABS; ++z) {
-      const long long zz = (long long)min(z, nsplit - 1) * slab;
-      p0[z] = pre[zz + lane]; p1[z] = pre[zz + 64 + lane];
-    }
-#pragma unroll
-    for (int z = 0; z < MAX_SLABS; ++z) { a0 = z < nsplit ? a0 + p0[z] : a0; a1 = z < nsplit ? a1 + p1[z] : a1; }
-    a0 = a0 > 0.f ? a0 : a0 * SLOPE; a1 = a1 > 0.f ? a1 : a1 * SLOPE;
-    A1[(size_t)row * HID + lane] = a0; A1[(size_t)row * HID + 64 + lane] = a1;
-  } else {
-    a0 = A1[(size_t)row * HID + lane]; a1 = A1[(size_t)row * HID + 64 + lane];
-  }
-  const float h0 = a0 + F[(size_t)row * FEAT + RESID_COL + lane];
-  const float h1 = a1 + F[(size_t)row * FEAT + RESID_COL + 64 + lane];
-  if (H) { H[(size_t)row * HID + lane] = h0; H[(size_t)row * HID + 64 + lane] = h1; }
-  float o[MAXOUT];
-  float w0[MAXOUT], w1[MAXOUT], bo[MAXOUT];     // loads first, at clamped indices: a predicate around each would serialise them
+  // Every load that does not depend on this kernel's own arithmetic is requested here, before the first wait: the residual branch of F, the
+  // output layer's weights (at clamped indices: a predicate around each would serialise them), the sampling uniform, the fc slabs -- and, in
+  // the rollout launch, the environment's state record, whose table rows (env_step_requests below) then fly under the output layer.
+  const float f0 = F[(size_t)row * FEAT + RESID_COL + lane];
+  const float f1 = F[(size_t)row * FEAT + RESID_COL + 64 + lane];
+  float w0[MAXOUT], w1[MAXOUT], bo[MAXOUT];
 #pragma unroll
   for (int k = 0; k < MAXOUT; ++k) {
     const int kc = min(k, n_out - 1);
     w0[k] = Wout[kc * HID + lane]; w1[k] = Wout[kc * HID + 64 + lane]; bo[k] = bout[kc];
   }
+  const float u_row = (act && u_ext) ? u_ext[row] : 0.f;
+  float a0, a1;
+  float p0[MAX_SLABS], p1[MAX_SLABS];
+  if (nsplit > 0) {
+    a0 = d.fc_b[lane]; a1 = d.fc_b[64 + lane];
+    const float* pre = A1pre + (size_t)row * pre_ld + d.pre_col;
+    // all slabs requested up front at clamped indices (a run-time trip count made hipcc wait for every pair of loads: up to 16
+    // dependent L2 round trips); summed in slab order
+#pragma unroll
+    for (int z = 0; z < MAX_SLABS; ++z) {
+      const long long zz = (long long)min(z, nsplit - 1) * slab;
+      p0[z] = pre[zz + lane]; p1[z] = pre[zz + 64 + lane];
+    }
+  } else {
+    a0 = A1[(size_t)row * HID + lane]; a1 = A1[(size_t)row * HID + 64 + lane];
+  }
+  const int erow = __builtin_amdgcn_readfirstlane(row);
+  envdev::EnvRegs es = {};
+  if (ef.on && act) envdev::load_state(es, ef.st[erow], lane);
+  if (nsplit > 0) {
+#pragma unroll
+    for (int z = 0; z < MAX_SLABS; ++z) { a0 = z < nsplit ? a0 + p0[z] : a0; a1 = z < nsplit ? a1 + p1[z] : a1; }
+    a0 = a0 > 0.f ? a0 : a0 * SLOPE; a1 = a1 > 0.f ? a1 : a1 * SLOPE;
+    A1[(size_t)row * HID + lane] = a0; A1[(size_t)row * HID + 64 + lane] = a1;
+  }
+  envdev::EnvPre eq = {};
+  if (ef.on && act) eq = envdev::env_step_requests(ef.T, es, lane);
+  const float h0 = a0 + f0;
+  const float h1 = a1 + f1;
+  if (H) { H[(size_t)row * HID + lane] = h0; H[(size_t)row * HID + 64 + lane] = h1; }
+  float o[MAXOUT];
 #pragma unroll
   for (int k = 0; k < MAXOUT; ++k) {
     float p = wave_sum(h0 * w0[k] + h1 * w1[k]) + bo[k];
@@ -533,7 +546,7 @@ __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const f
     float e[MAXOUT], s = 0.f;
 #pragma unroll
     for (int k = 0; k < MAXOUT; ++k) { e[k] = k < n_out ? expf(o[k] - m) : 0.f; s += e[k]; }
-    const float u = u_ext ? u_ext[row] : mansy_uniform01(seed, site, (uint32_t)row);
+    const float u = u_ext ? u_row : mansy_uniform01(seed, site, (uint32_t)row);
     float c = 0.f; int a = n_out - 1; bool found = false;
 #pragma unroll
     for (int k = 0; k < MAXOUT; ++k) {
@@ -546,7 +559,7 @@ __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const f
       for (int k = 0; k < MAXOUT; ++k) if (k == a) oa = o[k];
       if (logp) logp[row] = (oa - m) - logf(s);
     }
-    if (ef.on) envdev::env_step_wave(ef.T, ef.st, __builtin_amdgcn_readfirstlane(row), lane, a, ef.obs_next, ef.obs_cur, ef.reward, ef.done, ef.qoe_parts, ef.elog);
+    if (ef.on) envdev::env_step_finish(ef.T, ef.st, erow, lane, a, es, eq, ef.obs_next, ef.obs_cur, ef.reward, ef.done, ef.qoe_parts, ef.elog);
   }
 }
 
@@ -873,31 +886,61 @@ __global__ __launch_bounds__(256) void step_tail_kernel(float* __restrict__ p, f
     }
     return;
   }
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  // four consecutive elements per thread (16-byte accesses; the tensors start on 256-byte boundaries, so the four share one tensor's slot)
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= n) return;
   const float coef = clip_coef(parts, max_norm);
-  const float pp = p[i];
-  const float grad = g[i] * coef + wd * pp;
-  const float mm = m[i] + (grad - m[i]) * (1.f - b1);
-  const float vv = v[i] * b2 + (1.f - b2) * grad * grad;
-  const float denom = sqrtf(vv) / sqrt_bc2 + eps;
-  const float pn = pp - (lr / bc1) * (mm / denom);
-  p[i] = pn; m[i] = mm; v[i] = vv;
-  g[i] = 0.f;
+  float pp[4], gg[4], mo[4], vo[4], pn[4];
+  const bool full = i + 4 <= n;
+  if (full) {
+    *reinterpret_cast<float4*>(pp) = *reinterpret_cast<const float4*>(p + i); *reinterpret_cast<float4*>(gg) = *reinterpret_cast<const float4*>(g + i);
+    *reinterpret_cast<float4*>(mo) = *reinterpret_cast<const float4*>(m + i); *reinterpret_cast<float4*>(vo) = *reinterpret_cast<const float4*>(v + i);
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const bool in = i + q < n; pp[q] = in ? p[i + q] : 0.f; gg[q] = in ? g[i + q] : 0.f; mo[q] = in ? m[i + q] : 0.f; vo[q] = in ? v[i + q] : 0.f; }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float grad = gg[q] * coef + wd * pp[q];
+    const float mm = mo[q] + (grad - mo[q]) * (1.f - b1);
+    const float vv = vo[q] * b2 + (1.f - b2) * grad * grad;
+    const float denom = sqrtf(vv) / sqrt_bc2 + eps;
+    pn[q] = pp[q] - (lr / bc1) * (mm / denom);
+    mo[q] = mm; vo[q] = vv;
+  }
+  if (full) {
+    *reinterpret_cast<float4*>(p + i) = *reinterpret_cast<const float4*>(pn); *reinterpret_cast<float4*>(m + i) = *reinterpret_cast<const float4*>(mo);
+    *reinterpret_cast<float4*>(v + i) = *reinterpret_cast<const float4*>(vo); *reinterpret_cast<float4*>(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) if (i + q < n) { p[i + q] = pn[q]; m[i + q] = mo[q]; v[i + q] = vo[q]; g[i + q] = 0.f; }
+  }
   // which tensor? (offsets ascending; the 256-byte alignment gaps between tensors belong to none)
   int lo = 0, hi = 27;
 #pragma unroll
   for (int it = 0; it < 5; ++it) { const int mid = (lo + hi + 1) >> 1; if (tab.off[mid] <= i) lo = mid; else hi = mid - 1; }
-  const long long e = i - tab.off[lo];
-  if (e >= tab.numel[lo]) return;
+  const long long e0 = i - tab.off[lo];
+  const int numel = tab.numel[lo];
+  if (e0 >= numel) return;
   if (lo < 2 * NB) {
     const int j = lo >> 1;
-    if (lo & 1) { bbd[j * HID + (int)e] = pn; return; }
+    if (lo & 1) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) if (e0 + q < numel) bbd[j * HID + (int)e0 + q] = pn[q];
+      return;
+    }
     const Branch gm = branch_geom(j, 0);
-    const int r = (int)e / gm.len, c = (int)e % gm.len;
-    Wbd[(long long)(j * HID + r) * KP + gm.off + c] = pn;
-  } else if (lo == 2 * NB) Wfc2[e] = pn;
-  else if (lo == 2 * NB + 4) Wfc2[(long long)HID * FEAT + e] = pn;
+    int r = (int)e0 / gm.len, c = (int)e0 % gm.len;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (e0 + q < numel) Wbd[(long long)(j * HID + r) * KP + gm.off + c] = pn[q];
+      if (++c == gm.len) { c = 0; ++r; }
+    }
+  } else if (lo == 2 * NB || lo == 2 * NB + 4) {          // the two fc weights: [HID, FEAT] each, numel % 4 == 0
+    float* dst = Wfc2 + (lo == 2 * NB ? 0 : (long long)HID * FEAT) + e0;
+    if (e0 + 4 <= numel) *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(pn);
+    else for (int q = 0; q < 4 && e0 + q < numel; ++q) dst[q] = pn[q];
+  }
 }
 
 // ------------------------------------------------------------------------------------ workspace
@@ -1149,9 +1192,12 @@ struct PEng {
       MANSY_REQUIRE(tab.off[k] >= 0 && tab.off[k] + tab.numel[k] <= n && (k == 0 || tab.off[k] >= tab.off[k - 1] + tab.numel[k - 1]),
                     "step_tail: params[] must be ascending views of flat_p");
     }
+    for (int k = 0; k < 28; ++k) MANSY_REQUIRE(tab.off[k] % 4 == 0, "step_tail: tensor %d does not start on a 16-byte boundary of flat_p", k);
+    MANSY_REQUIRE(((reinterpret_cast<uintptr_t>(flat_p) | reinterpret_cast<uintptr_t>(flat_g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0,
+                  "step_tail: flat buffers must be 16-byte aligned");
     TailNext nx; nx.g_src = next_idx ? obs_all : nullptr; nx.g_idx = next_idx; nx.g_dst = W.obs_mb; nx.g_rows = next_mb;
     nx.adv = next_mb > 0 ? adv_all : nullptr; nx.adv_stats = W.adv_stats; nx.dbbd = W.dbbd; nx.parts_next = parts_next;
-    const int adam_blocks = (int)mansy_ceil_div(n, 256);
+    const int adam_blocks = (int)mansy_ceil_div(mansy_ceil_div(n, 4), 256);       // four elements per thread
     const int rider_blocks = 1 + (next_idx ? (int)mansy_ceil_div((long long)next_mb * (OBS_LD / 4), 256) : 0);
     const double bc1 = 1.0 - pow(0.9, (double)step), bc2 = 1.0 - pow(0.999, (double)step);
     MANSY_LAUNCH(step_tail_kernel, dim3(adam_blocks + rider_blocks), dim3(256), 0, st, flat_p, flat_g, m, v, n, lr, 0.9f, 0.999f, 1e-8f, wd,
