@@ -408,11 +408,6 @@ int mansy_gemm_col_group(int v);
  * slab-split store) run on the wave-split-K loop (32 x 32 blocks, the four waves of a workgroup split the K-tiles; partial sums added in wave order:
  * deterministic, but a different summation order than the 64 x 64 loop's), 0 = on the 64 x 64 loop; other values only query.  Returns the previous value. */
 int mansy_gemm_f32_wsk(int v);
-/* A/B knob (diagnostic): 1 (default) = in mansy_vp_backward / _train_step the decoder's deferred weight-gradient products over the rows of the later
- * half of the steps run on a low-priority side stream under the rest of the backward recurrence (the recurrence is launch-latency-bound, those products
- * MFMA-bound), 0 = every row after the recurrence; v < 0 only queries.  Returns the previous value.  The gradients accumulate either way (a row split
- * of the reduce dimension: same products, different summation order). */
-int mansy_vp_dw_overlap(int v);
 /* Kernel launches this library has enqueued since the process started (every launch site counts; a launch enqueued during a hipGraph
  * capture counts once, at capture time -- a replay of the graph adds nothing).  bench.py reads the difference around a cycle. */
 unsigned long long mansy_prof_launch_count(void);

@@ -143,7 +143,6 @@ _PROTOS = {
     'mansy_prof_gemm_collect': [P, P, P],
     'mansy_gemm_col_group': [c_int],
     'mansy_gemm_f32_wsk': [c_int],
-    'mansy_vp_dw_overlap': [c_int],
     'mansy_prof_launch_count': [],
 }
 _RESTYPES = {'mansy_last_error': ctypes.c_char_p, 'mansy_prof_launch_count': ctypes.c_ulonglong, 'mansy_vp_workspace_bytes': ctypes.c_size_t,

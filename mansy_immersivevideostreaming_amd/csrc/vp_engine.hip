@@ -18,11 +18,6 @@
 #include "mansy_kernels.h"
 #include "../../include/mansy_hip.h"
 
-// A/B knob (diagnostic; v < 0 only queries, returns the previous value): 1 = the decoder's deferred weight-gradient products of the later steps run on a
-// low-priority side stream under the rest of the backward recurrence (Eng::dw_fork), 0 = all of them after it.
-static int g_vp_dw_overlap = 1;
-extern "C" int mansy_vp_dw_overlap(int v) { const int old = g_vp_dw_overlap; if (v >= 0) g_vp_dw_overlap = v != 0; return old; }
-
 namespace {
 
 constexpr int MAXL = 8;
@@ -420,41 +415,6 @@ struct Eng {
     return MANSY_OK;
   }
 
-  // ---- deferred decoder weight gradients under the recurrence (round 4).  The backward recurrence is a chain of launch-latency-bound
-  // [B, 512, 512] products (0.5-0.6 of the MFMA rate), the deferred dW products are MFMA-bound and need nothing but finished slab rows:
-  // once the steps T-1 .. i_split are done on both halves, their rows' share of every decoder dW runs on a third, LOW-priority stream
-  // while the chain goes on with the earlier steps; the rest of the rows follow after the loop.  Same products over a row split of the
-  // reduce dimension (the gradients accumulate either way).
-  hipStream_t st3 = nullptr;
-  hipEvent_t ev_dw = nullptr;
-  int dw_fork(bool split) {
-    static hipStream_t s3 = nullptr; static hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_d = nullptr;
-    if (!s3) {
-      int lo = 0, hi = 0;
-      MANSY_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));          // lo = the numerically greatest = LOWEST priority
-      MANSY_HIP_CHECK(hipStreamCreateWithPriority(&s3, hipStreamNonBlocking, lo));
-      MANSY_HIP_CHECK(hipEventCreateWithFlags(&ev_a, hipEventDisableTiming));
-      MANSY_HIP_CHECK(hipEventCreateWithFlags(&ev_b, hipEventDisableTiming));
-      MANSY_HIP_CHECK(hipEventCreateWithFlags(&ev_d, hipEventDisableTiming));
-    }
-    st3 = s3; ev_dw = ev_d;
-    MANSY_HIP_CHECK(hipEventRecord(ev_a, st));
-    MANSY_HIP_CHECK(hipStreamWaitEvent(st3, ev_a, 0));
-    if (split) { MANSY_HIP_CHECK(hipEventRecord(ev_b, st2)); MANSY_HIP_CHECK(hipStreamWaitEvent(st3, ev_b, 0)); }
-    return MANSY_OK;
-  }
-  // the six row-separable weight gradients of decoder layer l over the slab rows [r0, r0 + rows), on the current stream
-  int dec_dw_rows(int l, size_t r0, int rows) {
-    const DecLayerP& p = P.dec[l]; DecBuf& e = W.dec[l];
-    const float* x_all = l == 0 ? W.emb_all : W.dec[l - 1].y3;
-    RC(lin_dw(e.dqkv + r0 * 3 * d, x_all + r0 * d, rows, 3 * d, d, p.sa_in.gw, p.sa_in.gb));
-    RC(lin_dw(e.dbr1 + r0 * d, e.ao1 + r0 * d, rows, d, d, p.sa_out.gw, p.sa_out.gb));
-    RC(lin_dw(e.dqc + r0 * d, e.y1 + r0 * d, rows, d, d, p.ca_in.gw, p.ca_in.gb));
-    RC(lin_dw(e.dbr2 + r0 * d, e.ao2 + r0 * d, rows, d, d, p.ca_out.gw, p.ca_out.gb));
-    RC(lin_dw(e.da + r0 * f, e.y2 + r0 * d, rows, f, d, p.lin1.gw, p.lin1.gb));
-    return lin_dw(e.dbr3 + r0 * d, e.h + r0 * f, rows, d, f, p.lin2.gw, p.lin2.gb);
-  }
-
   // decoder step i for the rows [b0, b0 + nb) of the batch, on the current stream
   int dec_fwd_step(int i, int b0, int nb, const float* pe, float* pred_bt, bool fuse_tail) {
     const size_t o = (size_t)i * B + b0;                       // row of this launch inside the step-major [T][B][.] slabs
@@ -619,22 +579,12 @@ struct Eng {
     // + LayerNorm3 backward of the last layer in one launch
     const bool fuse_head = ln_parts && mansy_dec_tail_ok(d, C6) != 0;
     if (split) RC(fork());
-    // steps [i_split, T) give their rows to the overlapped dW launches (0: off -- every row after the loop)
-    const int i_split = (mansy_vp_dw_overlap(-1) && T >= 4 && B >= 256) ? T / 2 : 0;
     for (int i = T - 1; i >= 0; --i) {
       RC(dec_bwd_step(i, 0, h0, 0, dpred_bt, defer_cross, pull_self, ln_parts, fuse_head));
       if (split) {
         hipStream_t keep = st; st = st2;
         const int rc = dec_bwd_step(i, h0, B - h0, 1, dpred_bt, defer_cross, pull_self, ln_parts, fuse_head);
         st = keep; RC(rc);
-      }
-      if (i_split > 0 && i == i_split) {
-        RC(dw_fork(split));
-        hipStream_t keep = st; st = st3;
-        int rc = MANSY_OK;
-        for (int l = 0; l < c.n_dec && rc == MANSY_OK; ++l) rc = dec_dw_rows(l, (size_t)i_split * B, (T - i_split) * B);
-        st = keep; RC(rc);
-        MANSY_HIP_CHECK(hipEventRecord(ev_dw, st3));
       }
     }
     if (split) RC(join());
@@ -650,17 +600,21 @@ struct Eng {
         RC(mansy_launch_ln_partials_reduce(base + (size_t)(3 * c.n_dec) * lnp_set, np, d, P.dec_norm.gw, P.dec_norm.gb, st));
       }
     }
-    // ---- deferred decoder weight gradients: one reduce-dim-(T*B) GEMM per weight (two over a row split with the overlap on: the
-    // overlapped launches accumulate into the same gradients, so this stream waits for them first)
+    // ---- deferred decoder weight gradients: one reduce-dim-(T*B) GEMM per weight
     RC(mansy_launch_outer_reduce(W.dz_all, C6, W.dec_out, TB, d, P.pred.gw, 0, nullptr, P.pred.gb, st));
     RC(mansy_launch_outer_reduce(W.tok_all, C6, W.dE_all, TB, d, P.emb.gw, 1, P.emb.gb, nullptr, st));
     for (int l = 0; l < c.n_dec; ++l) {
       const DecLayerP& p = P.dec[l]; DecBuf& e = W.dec[l];
+      const float* x_all = l == 0 ? W.emb_all : W.dec[l - 1].y3;
+      RC(lin_dw(e.dqkv, x_all, TB, 3 * d, d, p.sa_in.gw, p.sa_in.gb));
+      RC(lin_dw(e.dbr1, e.ao1, TB, d, d, p.sa_out.gw, p.sa_out.gb));
+      RC(lin_dw(e.dqc, e.y1, TB, d, d, p.ca_in.gw, p.ca_in.gb));
       if (defer_cross)
         RC(mansy_launch_attn_kvgrad(e.qc, (long long)B * d, e.dao2, (long long)B * d, e.dS2, e.Pk2, e.dmemkv, e.dmemkv + d, cross_shape(), T, 0, st));
       RC(lin_dw(e.dmemkv, W.mem, B * M, 2 * d, d, p.ca_in.gw + (size_t)d * d, p.ca_in.gb ? p.ca_in.gb + d : nullptr));
-      if (i_split > 0 && l == 0) MANSY_HIP_CHECK(hipStreamWaitEvent(st, ev_dw, 0));
-      RC(dec_dw_rows(l, 0, i_split > 0 ? i_split * B : TB));        // (the rows of the steps >= i_split went to the overlapped launches)
+      RC(lin_dw(e.dbr2, e.ao2, TB, d, d, p.ca_out.gw, p.ca_out.gb));
+      RC(lin_dw(e.da, e.y2, TB, f, d, p.lin1.gw, p.lin1.gb));
+      RC(lin_dw(e.dbr3, e.h, TB, d, f, p.lin2.gw, p.lin2.gb));
       RC(lin_dx(e.dmemkv, B * M, 2 * d, p.ca_in.w + (size_t)d * d, d, W.dmem, l == 0 ? nullptr : W.dmem, nullptr, 1.f));
     }
     // ---- DistillLayer

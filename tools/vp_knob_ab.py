@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of tile-order / loop knobs on the VP train step (B = 4096, fp32), variants interleaved in ONE process:
-python tools/vp_knob_ab.py col_group 0 12   |   python tools/vp_knob_ab.py f32_wsk 0 1"""
+python tools/vp_knob_ab.py col_group 0 12   |   python tools/vp_knob_ab.py f32_wsk 0 1   |   python tools/vp_knob_ab.py mansy_vp_dw_overlap 0 1"""
 import os, sys, time, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -8,7 +8,7 @@ import bench
 from mansy_immersivevideostreaming_amd._lib import lib
 from mansy_immersivevideostreaming_amd.viewport_prediction.models import ViewportTransformerMTIO, FusedAdamW
 L = lib()
-knob = getattr(L, 'mansy_gemm_' + sys.argv[1])
+knob = getattr(L, sys.argv[1] if sys.argv[1].startswith('mansy_') else 'mansy_gemm_' + sys.argv[1])
 vals = [int(x) for x in sys.argv[2:]]
 torch.manual_seed(5); random.seed(5); np.random.seed(5)
 m = ViewportTransformerMTIO(in_channel=2, fut_window=10, d_model=512, dim_feedforward=512, device='cuda').to('cuda'); m.train()
