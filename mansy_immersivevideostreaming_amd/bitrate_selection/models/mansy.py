@@ -288,16 +288,10 @@ class NetEngine:
             self.idn = _Flat(1)
             self.idn.attach(self.identifier.feature_net.ordered_parameters() + self.identifier.head_parameters())
 
-    def workspace(self, which=0):
-        """which = 1: a second workspace of the same size, for a call that runs on another stream while the first is in use
-        (PPOPolicy: process_fn's evaluation pass under train_identifier)."""
+    def workspace(self):
         dev = self.device
         if dev.type != 'cuda':
             raise MansyError('the bitrate-selection networks run on the HIP engine only: move the modules to a cuda (ROCm) device')
-        if which:
-            if getattr(self, '_ws2', None) is None or self._ws2.device != dev:
-                self._ws2 = torch.empty(lib().mansy_ppo_workspace_bytes(self.max_batch), dtype=torch.uint8, device=dev)
-            return self._ws2
         if self._ws is None or self._ws.device != dev:
             nbytes = lib().mansy_ppo_workspace_bytes(self.max_batch)
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)

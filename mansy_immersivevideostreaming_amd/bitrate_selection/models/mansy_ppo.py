@@ -94,8 +94,6 @@ class VecCollector:
             self._u = torch.empty(T, N, dtype=torch.float32, device=dev)
             self._graph = None
         buffer.reset()
-        if hasattr(self.policy, '_join_eval'):
-            self.policy._join_eval()            # a forked evaluation pass that nobody consumed still reads the slabs this collect overwrites
         self._u.uniform_()                      # Categorical sampling uniforms (torch generator => reproducible with manual_seed)
         key = (id(buffer), T, self.policy.engine.ac.flat_p.data_ptr())
         if self.use_graph and (self._graph is None or self._graph_key != key):
@@ -197,8 +195,6 @@ class PPOPolicy(nn.Module):
     """Reference signature (mansy_ppo.py:14-33 + the tianshou keyword arguments used at run_mansy.py:231-251).  `optim` is
     accepted for signature compatibility; its lr / weight_decay are read from it and the fused Adam(L2) kernel does the step."""
 
-    OVERLAP_EVAL = True          # default of the instances' `overlap_eval` (tools/ppo_cycle_ab.py flips it for an A/B)
-
     def __init__(self, actor, critic, optim, dist_fn, eps_clip=0.2, dual_clip=None, value_clip=False, advantage_normalization=True,
                  recompute_advantage=False, args=None, identifier=None, discount_factor=0.99, max_grad_norm=None, vf_coef=0.5,
                  ent_coef=0.01, reward_normalization=False, gae_lambda=0.95, max_batchsize=256, action_space=None, action_scaling=False,
@@ -225,11 +221,6 @@ class PPOPolicy(nn.Module):
         self.world, self.grad_sync = 1, None
         self.chain_steps = True       # learn(): each minibatch step's last launch prepares the next one (False: self-contained steps)
         self.overlap_identifier_sync = True   # data parallel: the identifier's gradient averages fly under process_fn's evaluation passes
-        # one process: process_fn's evaluation pass (actor-critic on obs / obs_next: 4 launches, two of them [8192-row] products) runs on a side
-        # stream with its own workspace UNDER train_identifier + relabel (identifier only; ~25 small dependent launches) -- neither reads what
-        # the other writes; process_fn waits for it before the GAE
-        self.overlap_eval = type(self).OVERLAP_EVAL
-        self._eval_stream = None
         self._pre_eval = None
         self._pinned = {}
 
@@ -379,8 +370,6 @@ class PPOPolicy(nn.Module):
         # which this function does not touch: round r's average flies on a side stream while pass r runs here; process_fn then finds
         # the values it needs (self._pre_eval) instead of recomputing them.
         hide = self.grad_sync is not None and self.overlap_identifier_sync
-        if self.grad_sync is None and self.overlap_eval:
-            self._fork_eval(buffer)
         for r in range(update_round):
             f.step += 1
             ov = (lambda part=r: self._pre_evaluate(buffer, part)) if hide and r < 2 else None
@@ -424,43 +413,6 @@ class PPOPolicy(nn.Module):
                                                  stream_ptr(obs.device)), 'mansy_identifier_relabel')
         self.cnt += n
 
-    def _fork_eval(self, buffer):
-        """process_fn's joint evaluation pass ([obs ; obs_next]: values of both halves, logp_old of the first) enqueued NOW on a side stream
-        with the second workspace; process_fn finds it in self._pre_eval and waits for its event.  No-op when the buffer does not qualify
-        for the one-pass form (process_fn then evaluates as before)."""
-        self._join_eval()
-        eng = self.engine
-        T, N = buffer.filled, buffer.N
-        n = T * N
-        joint = getattr(buffer, 'obs2', None)
-        if joint is None or n == 0 or T != buffer.T or 2 * n > eng.max_batch or buffer.obs.data_ptr() != joint.data_ptr():
-            return
-        dev = buffer.obs.device
-        main = torch.cuda.current_stream(dev)
-        if self._eval_stream is None or self._eval_stream.device != dev:
-            self._eval_stream = torch.cuda.Stream(device=dev)
-        v_all = torch.empty(2 * n, dtype=torch.float32, device=dev)
-        logp_old = torch.empty(n, dtype=torch.float32, device=dev)
-        act = buffer.act[:T].reshape(n)
-        arr, _ = eng.ac.pointers()
-        ws = eng.workspace(1)
-        side = self._eval_stream
-        side.wait_stream(main)                      # the rollout that filled the buffer
-        with torch.cuda.stream(side):
-            check(lib().mansy_policy_evaluate(arr, ptr(joint), 2 * n, ptr(act), n, ptr(logp_old), ptr(v_all), ptr(ws), eng.max_batch, eng.prec,
-                                              stream_ptr(dev)), 'mansy_policy_evaluate')
-            ev = torch.cuda.Event()
-            ev.record(side)
-        self._pre_eval = dict(key=self._pre_eval_key(buffer), done={0, 1}, v_s=v_all[:n], v_next=v_all[n:], logp_old=logp_old, event=ev, keep=(v_all, act))
-
-    def _join_eval(self):
-        """The caller's stream waits for a forked evaluation pass (if any is pending): before its results are used, before another is
-        forked, and before the buffer it reads is overwritten (VecCollector.collect)."""
-        pe = self._pre_eval
-        if pe is not None and pe.get('event') is not None:
-            torch.cuda.current_stream(pe['logp_old'].device).wait_event(pe['event'])
-            pe['event'] = None
-
     def _pre_eval_key(self, buffer):
         return (id(buffer), buffer.filled, buffer.N, self.engine.ac.step, buffer.obs.data_ptr())
 
@@ -503,7 +455,6 @@ class PPOPolicy(nn.Module):
         v_next = torch.empty(n, dtype=torch.float32, device=dev)
         logp_old = torch.empty(n, dtype=torch.float32, device=dev)
         joint = getattr(buffer, 'obs2', None)
-        self._join_eval()
         pe, self._pre_eval = self._pre_eval, None
         if pe is not None and pe['key'] == self._pre_eval_key(buffer) and pe['done']:
             # (some of) the passes ran under the identifier's gradient averages (train_identifier): take them, compute the rest
