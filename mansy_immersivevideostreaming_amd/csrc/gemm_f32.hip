@@ -332,13 +332,6 @@ __global__ __launch_bounds__(NT) void gemm_f32_dma_kernel(GemmParams p) {
 #pragma unroll
     for (int i = 0; i < PB; ++i) glds16(vob[i], sb, lds_wave + A_FLOATS * 4u + i * 4096u);
   }
-  // the epilogue's residual / mask operands, requested behind the first tile: they land under the K loop (gemm_tile.h)
-  // (64 x 64 tiles only: the launches that run as ONE round of workgroups, the decoder-step products; larger tiles would hold 64-128 registers
-  // across the loop, and their launches have several rounds whose epilogues and K loops overlap anyway)
-  constexpr bool PRE = BM == 64 && BN == 64;
-  EpiloguePre<PRE ? BM : 4, PRE ? BN : 4, PRE ? NT : 4> pre_regs;
-  if (PRE) gemm_epilogue_prefetch<BM, BN, NT>(p, m0, n0, tid, p.ep_prefetch && gemm_epilogue_is_rows(p) && (p.ep.resid || p.ep.mask_src),
-                                              reinterpret_cast<EpiloguePre<BM, BN, NT>&>(pre_regs));
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of tile kt have landed ...
@@ -379,7 +372,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_dma_kernel(GemmParams p) {
   __syncthreads();                                        // staging LDS idle: the epilogue reuses it
 
   if (AK && rowsum_dst && tile_x - rs_first < BK && tid < BM && m0 + tid < p.M) atomicAdd(rowsum_dst + m0 + tid, rowsum);
-  gemm_epilogue<BM, BN, SMEM_FLOATS>(p, acc, smem, m0, n0, tid, split, Cp, PRE ? reinterpret_cast<const EpiloguePre<BM, BN, NT>*>(&pre_regs) : nullptr);
+  gemm_epilogue<BM, BN, SMEM_FLOATS>(p, acc, smem, m0, n0, tid, split, Cp);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -630,14 +623,12 @@ extern "C" int mansy_gemm_f32_wsk(int v);
 static int g_f32_wsk_max_tiles = 200;      // products with at most this many 64 x 64 output tiles (and <= 256 workgroups incl. K splits) count as small (mansy_gemm_f32_wsk(v >= 16) sets it): the PPO
                                             // cycle's products have 80-160; at 256 -- the half-batch decoder products of the VP step, two of them in flight on two streams -- the 64 x 64
                                             // loop wins inside the step (profiles/r04_f32_wsk_threshold.txt)
-static int g_f32_ep_prefetch = 1;   // GemmParams::ep_prefetch; mansy_gemm_f32_wsk(6) / (7) turn it off / on
 static int g_f32_wsk_tn = 1;     // the same for the weight-gradient (TN) products; mansy_gemm_f32_wsk(2) / (3) turn it off / on
 int mansy_gemm_wsk_tn_enabled() { return g_f32_wsk && g_f32_wsk_tn; }
 extern "C" int mansy_gemm_f32_wsk(int v) {
   const int old = g_f32_wsk;
   if (v == 0 || v == 1) g_f32_wsk = v;
   if (v == 2 || v == 3) g_f32_wsk_tn = v - 2;
-  if (v == 6 || v == 7) g_f32_ep_prefetch = v - 6;
   if (v >= 16) g_f32_wsk_max_tiles = v;
   return old;
 }
@@ -697,7 +688,6 @@ int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B,
   GemmParams p;
   p.A = A; p.B = B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.ep = ep;
   p.col_group = (ep.tile_nrange || ep.tile_list || ep.tile_krange) ? 0 : g_col_group;
-  p.ep_prefetch = g_f32_ep_prefetch;
   p.c_rmw_ok = (reinterpret_cast<uintptr_t>(C) & 15) == 0 && (!ep.pair_C || (reinterpret_cast<uintptr_t>(ep.pair_C) & 15) == 0) && ldc % 4 == 0 && N % 4 == 0;
   p.vec_ok = ((lda % 4) == 0) && ((ldb % 4) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
              ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (K % 4 == 0) && (!a_kmajor || M % 4 == 0) &&

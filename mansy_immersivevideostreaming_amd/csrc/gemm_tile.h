@@ -36,46 +36,15 @@ struct GemmParams {
   // > 0: the XCD-aware tile order walks the column tiles in groups of col_group (all row panels of a group before the next group), so that an
   // XCD's L2 holds ONE group's slice of B next to the A panels it streams (wide-N products: B alone is 3 MB of the 4 MB L2 at N = 1536)
   int col_group = 0;
-  int ep_prefetch = 1;   // the fp32 LDS-DMA loop requests the epilogue's residual / mask operands before its K loop (A/B: mansy_gemm_f32_wsk(6) / (7))
+  int bk_full = 0, bk_cols = 1;   // gemm_bf16k_kernel's tile list: the first bk_full entries are whole 256 x 128 tiles (bk_cols per row panel), the rest halves
   int c_rmw_ok = 0;  // C (and C2) 16-byte aligned, ldc % 4 == 0, N % 4 == 0: an accumulating product whose blocks have one owner may read-add-write float4
 };
 
 // Row-major pass of the fused epilogue: the C tile sits in LDS as [BM][BN + 4] floats (`smem`, written by the caller, who has also
 // synchronised the workgroup); bias / activation / mask / dropout / residual and the store run on float4 rows, NTHR threads (tid in
 // [0, NTHR)).  Shared by every main loop, whatever its wave layout, so that a product's value does not depend on the loop it ran on.
-// Residual / mask operands of the row-major pass, requested BEFORE the K loop (round 4): thread tid's float4 number i of the pass is element
-// idx = tid + i * NTHR of the tile -- exactly what gemm_epilogue_rows reads -- so a launch whose workgroups all reach the epilogue together does not
-// add one more cold read of [M, N] floats (and its round trip) behind the MFMA body.  Each element is read by the thread that later stores it, so C
-// may alias the residual as before.
 template <int BM, int BN, int NTHR>
-struct EpiloguePre { float4 rr[BM * (BN / 4) / NTHR], mk[BM * (BN / 4) / NTHR]; bool have; };
-template <int BM, int BN, int NTHR>
-__device__ __forceinline__ void gemm_epilogue_prefetch(const GemmParams& p, int m0, int n0, int tid, bool on, EpiloguePre<BM, BN, NTHR>& q) {
-  constexpr int C4 = BN / 4, IT = BM * C4 / NTHR;
-  const GemmEpilogue& ep = p.ep;
-  q.have = on;
-#pragma unroll
-  for (int i = 0; i < IT; ++i) { q.rr[i] = make_float4(0.f, 0.f, 0.f, 0.f); q.mk[i] = make_float4(1.f, 1.f, 1.f, 1.f); }
-  if (!on) return;
-  if (ep.resid) {
-#pragma unroll
-    for (int i = 0; i < IT; ++i) {
-      const int idx = tid + i * NTHR, lr = idx / C4, c4 = idx % C4;
-      q.rr[i] = *reinterpret_cast<const float4*>(ep.resid + (long long)min(m0 + lr, p.M - 1) * ep.resid_ld + min(n0 + c4 * 4, p.N - 4));
-    }
-  }
-  if (ep.mask_src) {
-#pragma unroll
-    for (int i = 0; i < IT; ++i) {
-      const int idx = tid + i * NTHR, lr = idx / C4, c4 = idx % C4;
-      q.mk[i] = *reinterpret_cast<const float4*>(ep.mask_src + (long long)min(m0 + lr, p.M - 1) * ep.mask_ld + min(n0 + c4 * 4, p.N - 4));
-    }
-  }
-}
-
-template <int BM, int BN, int NTHR>
-__device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, const float* smem, int m0, int n0, int tid, float* Cz,
-                                                   const EpiloguePre<BM, BN, NTHR>* pre = nullptr) {
+__device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, const float* smem, int m0, int n0, int tid, float* Cz) {
   constexpr int CLD = BN + 4;
   const GemmEpilogue& ep = p.ep;
   const float drop_scale = ep.drop.p > 0.f ? 1.f / (1.f - ep.drop.p) : 1.f;
@@ -97,18 +66,13 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, const fl
       off_r[u] = (long long)row * ep.resid_ld + col; off_m[u] = (long long)row * ep.mask_ld + col;
       rr[u] = make_float4(0.f, 0.f, 0.f, 0.f); mk[u] = make_float4(1.f, 1.f, 1.f, 1.f);
     }
-    if (pre && pre->have) {  // requested before the K loop (gemm_epilogue_prefetch)
+    if (ep.resid) {          // one uniform branch around the group's loads, not one per load
 #pragma unroll
-      for (int u = 0; u < GRP; ++u) { rr[u] = pre->rr[g0 + u]; mk[u] = pre->mk[g0 + u]; }
-    } else {
-      if (ep.resid) {          // one uniform branch around the group's loads, not one per load
+      for (int u = 0; u < GRP; ++u) rr[u] = *reinterpret_cast<const float4*>(ep.resid + off_r[u]);
+    }
+    if (ep.mask_src) {
 #pragma unroll
-        for (int u = 0; u < GRP; ++u) rr[u] = *reinterpret_cast<const float4*>(ep.resid + off_r[u]);
-      }
-      if (ep.mask_src) {
-#pragma unroll
-        for (int u = 0; u < GRP; ++u) mk[u] = *reinterpret_cast<const float4*>(ep.mask_src + off_m[u]);
-      }
+      for (int u = 0; u < GRP; ++u) mk[u] = *reinterpret_cast<const float4*>(ep.mask_src + off_m[u]);
     }
 #pragma unroll
     for (int u = 0; u < GRP; ++u) {
@@ -145,16 +109,11 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, const fl
   }
 }
 
-// true when gemm_epilogue() will run the row-major pass for this launch (what gemm_epilogue_prefetch may serve)
-__device__ __forceinline__ bool gemm_epilogue_is_rows(const GemmParams& p) {
-  return !(p.ep.accumulate || (gridDim.z > 1 && p.ep.split_slab == 0)) && p.c_vec_ok;
-}
-
 // Epilogue shared by both main loops.  C/D layout of the 32x32 MFMA block: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 // `smem` is the (now idle) staging LDS, at least BM*(BN+4) floats; SMEM_FLOATS is its size.
 template <int BM, int BN, int SMEM_FLOATS>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[BM / 64][BN / 64 > 0 ? BN / 64 : 1], float* smem, int m0, int n0,
-                                              int tid, int split, float* Cbase, const EpiloguePre<BM, BN, NT>* pre = nullptr) {
+                                              int tid, int split, float* Cbase) {
   constexpr int TM = BM / 64, TN = BN / 64;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -177,7 +136,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
         for (int e = 0; e < 16; ++e)
           smem[(wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * CLD + wn * (BN / 2) + j * 32 + r] = acc[i][j][e];
     __syncthreads();
-    gemm_epilogue_rows<BM, BN, NT>(p, smem, m0, n0, tid, Cz, pre);
+    gemm_epilogue_rows<BM, BN, NT>(p, smem, m0, n0, tid, Cz);
     return;
   }
   // Scalar path (atomics / unaligned): loads (mask / residual) hoisted into unconditional clamped-address batches.
