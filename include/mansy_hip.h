@@ -395,8 +395,7 @@ int mansy_attn_bwd_selfpull(const float* Q_all, long long q_ts, const float* K, 
 int mansy_prof_gemm_enable(int on);
 /* A/B knob of the bf16x3 products with pre-split weights (diagnostic; tools/gemm_bench.py): 1 (default) = A staged in fp32 by LDS-DMA
  * and split at fragment read (256 x 128 tiles: gemm_bf16k_kernel, twelve waves with fixed loader / consumer roles; 128 x 128: gemm_bf16f; 64 x 64:
- * gemm_bf16h_kernel's three-stage ring, 6 = four stages), 8 = as 1 with the round-3 eight-wave loop on the 256 x 128 tiles, 9 = as 1 without the half-tile
- * last round of the 256 x 128 loop, 4 = as 1 without
+ * gemm_bf16h_kernel's three-stage ring, 6 = four stages), 8 = as 1 with the round-3 eight-wave loop on the 256 x 128 tiles, 4 = as 1 without
  * a 256 x 128 loop, 0 = the round-2 loop (A register-staged and split before its ds_write), 7 = the round-2 loop on the 64 x 64 tiles only,
  * 2 / 3 / 11 / 12 = timing-only staging / math forms (results wrong); v < 0 only queries.  Returns the previous value.  Results of all the
  * real loops are bit-identical (same products, same order). */

@@ -23,7 +23,6 @@
 #ifndef MANSY_BF16S_SCHED
 #define MANSY_BF16S_SCHED 0
 #endif
-#include <type_traits>
 #include "gemm_tile.h"
 
 using namespace mansy_gemm;
@@ -968,19 +967,14 @@ __global__ __launch_bounds__(768) void gemm_bf16k_kernel(GemmParams p) {
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  // Tiles: a 1-D grid over the logical tile list (XCD-aware: XCD x takes a contiguous range).  The first p.bk_full entries are 256 x 128 tiles in
-  // row-panel-major order; every later entry is one 256 x 64 HALF of a remaining tile (round 4: one workgroup per CU means whole rounds of 256 --
-  // 640 tiles of the [40 960, 512] products ran as 3 rounds for 2.5 rounds of work; the last 128 tiles now run as 256 halves: a round of half the
-  // duration).  nb = 32-column blocks of this workgroup's tile (4 or 2); same products in the same order per output element either way.
-  int tile_x, tile_y, nb = 4, n_half = 0;
+  int tile_x, tile_y;
   {
-    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int nwg = gridDim.x * gridDim.y, orig = blockIdx.y * gridDim.x + blockIdx.x;
     const int q = nwg >> 3, rem = nwg & 7, xcd = orig & 7, local = orig >> 3;
-    int t = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + local;
-    if (t >= p.bk_full) { const int hh = t - p.bk_full; t = p.bk_full + (hh >> 1); n_half = hh & 1; nb = 2; }
-    tile_y = t / p.bk_cols; tile_x = t - tile_y * p.bk_cols;
+    const int t = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + local;
+    tile_y = t / gridDim.x; tile_x = t - tile_y * gridDim.x;
   }
-  const int m0 = tile_y * BM, n0 = tile_x * BN + n_half * 64;
+  const int m0 = tile_y * BM, n0 = tile_x * BN;
   const int nk = p.K / BK;
   const float* const ca = p.A + (long long)m0 * p.lda;
   const unsigned short* const cb = p.ep.b_planes + (long long)n0 * p.ep.b_planes_ld;
@@ -1019,15 +1013,13 @@ __global__ __launch_bounds__(768) void gemm_bf16k_kernel(GemmParams p) {
       for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-          if (i == 0 || nb == 4)                                    // half tile: rows 0 .. 63 of each plane only (pieces 0 .. 3)
-            glds16(vob[i], b_corner + (long long)pl * p.ep.b_plane_stride, base + (unsigned)(A_BYTES + pl * B_PLANE_BYTES) + (unsigned)i * 4096u);
+          glds16(vob[i], b_corner + (long long)pl * p.ep.b_plane_stride, base + (unsigned)(A_BYTES + pl * B_PLANE_BYTES) + (unsigned)i * 4096u);
     };
     if (nk > 0 && LAB != 2) dma(0, 0);
     if (nk > 1 && LAB != 2) dma(1, 1);
     int st = 2;                                                     // stage of tile t + 2
     for (int kt = 0; kt < nk; ++kt) {
-      // this wave's pieces of tile kt have landed; tile kt+1's (12, or 10 of a half tile) stay in flight
-      if (kt + 1 < nk) { if (nb == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
+      if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");    // this wave's pieces of tile kt have landed; tile kt+1's 12 stay in flight
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                                 // barrier kt: tile kt readable; tile kt-1 no longer read
       asm volatile("" ::: "memory");
@@ -1046,63 +1038,52 @@ __global__ __launch_bounds__(768) void gemm_bf16k_kernel(GemmParams p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) fb[j][s] = lds_off<false>(j * 32 + r, 2 * s + h);
     }
-    // the K loop for a tile of NB 32-column blocks (a compile-time constant inside: one straight-line body per K-tile either way)
-    auto k_loop = [&](auto nb_c) {
-      constexpr int NB = decltype(nb_c)::value;
-      int cur = 0;
-      for (int kt = 0; kt < nk; ++kt) {
-        __builtin_amdgcn_s_barrier();                                 // barrier kt
-        asm volatile("" ::: "memory");
-        const float* a_l = smem + cur * (STAGE_BYTES / 4);
-        const __bf16* b_l = reinterpret_cast<const __bf16*>(a_l) + A_BYTES / 2;
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      __builtin_amdgcn_s_barrier();                                 // barrier kt
+      asm volatile("" ::: "memory");
+      const float* a_l = smem + cur * (STAGE_BYTES / 4);
+      const __bf16* b_l = reinterpret_cast<const __bf16*>(a_l) + A_BYTES / 2;
 #pragma unroll
-        for (int s = 0; s < (LAB == 1 ? 0 : 2); ++s) {
-          bf16x8 ah, al, bh[NB], bl[NB];
-          const float4 v0 = *reinterpret_cast<const float4*>(a_l + fa[s][0]);
-          const float4 v1 = *reinterpret_cast<const float4*>(a_l + fa[s][1]);
+      for (int s = 0; s < (LAB == 1 ? 0 : 2); ++s) {
+        bf16x8 ah, al, bh[4], bl[4];
+        const float4 v0 = *reinterpret_cast<const float4*>(a_l + fa[s][0]);
+        const float4 v1 = *reinterpret_cast<const float4*>(a_l + fa[s][1]);
 #pragma unroll
-          for (int j = 0; j < NB; ++j) {
-            bh[j] = *reinterpret_cast<const bf16x8*>(b_l + fb[j][s]);
-            bl[j] = *reinterpret_cast<const bf16x8*>(b_l + B_PLANE + fb[j][s]);
-          }
-          const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const __bf16 t0 = (__bf16)v[e];
-            ah[e] = t0;
-            al[e] = (__bf16)(v[e] - (float)t0);
-          }
-#pragma unroll
-          for (int j = 0; j < NB; ++j) {
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[j], 0, 0, 0);
-          }
+        for (int j = 0; j < 4; ++j) {
+          bh[j] = *reinterpret_cast<const bf16x8*>(b_l + fb[j][s]);
+          bl[j] = *reinterpret_cast<const bf16x8*>(b_l + B_PLANE + fb[j][s]);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // LDS reads retired before the barrier that frees this stage
-        cur = cur == 2 ? 0 : cur + 1;
+        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const __bf16 t0 = (__bf16)v[e];
+          ah[e] = t0;
+          al[e] = (__bf16)(v[e] - (float)t0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[j], 0, 0, 0);
+        }
       }
-    };
-    if (nb == 4) k_loop(std::integral_constant<int, 4>{});
-    else k_loop(std::integral_constant<int, 2>{});
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // LDS reads retired before the barrier that frees this stage
+      cur = cur == 2 ? 0 : cur + 1;
+    }
   }
   __syncthreads();                                                  // ring idle (every DMA waited for, every fragment read)
-  constexpr int CLD_H = BN / 2 + 4;                                 // row stride of a half tile's C image
   if (wave < NCW) {
     const int r = lane & 31, h = lane >> 5;
-    const int cld = nb == 4 ? CLD : CLD_H;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      if (j < 2 || nb == 4) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e)
-          smem[(wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * cld + j * 32 + r] = acc[j][e];
-      }
+      for (int e = 0; e < 16; ++e)
+        smem[(wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * CLD + j * 32 + r] = acc[j][e];
   }
   __syncthreads();
   if (wave >= NCW) return;
-  if (nb == 4) gemm_epilogue_rows<BM, BN, NCW * 64>(p, smem, m0, n0, (int)threadIdx.x, p.C);
-  else gemm_epilogue_rows<BM, BN / 2, NCW * 64>(p, smem, m0, n0, (int)threadIdx.x, p.C);
+  gemm_epilogue_rows<BM, BN, NCW * 64>(p, smem, m0, n0, (int)threadIdx.x, p.C);
 }
 
 // ---- weights -> bf16 planes (and planes of the transpose), 32 x 32 tiles through LDS
@@ -1208,17 +1189,10 @@ int mansy_gemm_bf16p_dispatch(const GemmParams& p, int tile, int prec, hipStream
     if (big && g_bf16_variant != 8 && p.c_vec_ok && !p.ep.accumulate && p.ep.split_slab == 0) {
       // round 4: twelve waves with fixed roles (8 consumers + 4 loaders); variant 8 = the eight-wave loop below (A/B runs), 11 / 12 = this
       // loop's staging-only / math-only timing forms (results wrong)
-      // one workgroup per CU: whole rounds of `cus` tiles.  When the last round would be at most half full, its tiles run as 256 x 64 halves
-      // (twice as many workgroups, half the duration): [40 960, 512]: 640 tiles = 512 + 128 -> 512 full + 256 halves (variant 9: off, for A/B runs)
-      GemmParams pk = p;
-      pk.bk_cols = mansy_ceil_div(p.N, 128);
-      const int tiles = pk.bk_cols * mansy_ceil_div(p.M, 256), cus = 256, tail = tiles % cus;
-      const bool halves = g_bf16_variant != 9 && tiles > cus && tail > 0 && 2 * tail <= cus && p.N % 128 == 0;
-      pk.bk_full = halves ? tiles - tail : tiles;
-      dim3 grid(pk.bk_full + 2 * (tiles - pk.bk_full), 1, 1);
-      if (g_bf16_variant == 11) MANSY_GEMM_LAUNCH((gemm_bf16k_kernel<1>), grid, dim3(768), st, pk);
-      else if (g_bf16_variant == 12) MANSY_GEMM_LAUNCH((gemm_bf16k_kernel<2>), grid, dim3(768), st, pk);
-      else MANSY_GEMM_LAUNCH((gemm_bf16k_kernel<0>), grid, dim3(768), st, pk);
+      dim3 grid(mansy_ceil_div(p.N, 128), mansy_ceil_div(p.M, 256), 1);
+      if (g_bf16_variant == 11) MANSY_GEMM_LAUNCH((gemm_bf16k_kernel<1>), grid, dim3(768), st, p);
+      else if (g_bf16_variant == 12) MANSY_GEMM_LAUNCH((gemm_bf16k_kernel<2>), grid, dim3(768), st, p);
+      else MANSY_GEMM_LAUNCH((gemm_bf16k_kernel<0>), grid, dim3(768), st, p);
       MANSY_LAUNCH_CHECK(); return MANSY_OK;
     }
     if (big) {

@@ -384,23 +384,24 @@ __global__ __launch_bounds__(NT) void gemm_f32_dma_kernel(GemmParams p) {
 // barrier inside the loop: a wave only reads what it staged itself, ordered by its own vmcnt; the next tile is requested as soon as the current one
 // sits in registers and flies under its MFMAs; 32 KB of LDS per workgroup, so five fit a CU), the four partial blocks are summed
 // through LDS in wave order (deterministic), then the shared row-major epilogue runs.  A K-contiguous; B K-contiguous or K-major.
+constexpr int WSK_T = 32, WSK_WAVE_FLOATS = 2 * WSK_T * BK, WSK_SMEM_FLOATS = 4 * WSK_WAVE_FLOATS;
+// The loop as a device function of (problem, workgroup index `orig` inside the problem's gx x gy x gz grid, the workgroup's LDS): one problem per
+// launch (gemm_f32_wsk_kernel) or two independent problems side by side in one launch (gemm_f32_wsk_dual_kernel).
 template <bool AK, bool BKM>
-__global__ __launch_bounds__(NT) void gemm_f32_wsk_kernel(GemmParams p) {
-  constexpr int T = 32, TILE_FLOATS = T * BK, WAVE_FLOATS = 2 * TILE_FLOATS, CLD = T + 4;       // ONE stage per wave: 8 KB (32 KB per workgroup, five per CU)
+__device__ __forceinline__ void gemm_f32_wsk_body(const GemmParams& p, int orig, int gx, int gy, int gz, float* smem) {
+  constexpr int T = WSK_T, TILE_FLOATS = T * BK, WAVE_FLOATS = WSK_WAVE_FLOATS, CLD = T + 4;       // ONE stage per wave: 8 KB (32 KB per workgroup, five per CU)
   static_assert(T * CLD + 64 <= WAVE_FLOATS, "a partial block and its row sums must fit a wave's stage");
-  __shared__ __attribute__((aligned(1024))) float smem[4 * WAVE_FLOATS];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   int tile_x, tile_y, split;
   {   // XCD-aware bijective remap over the whole 3-D grid, K split slowest (see gemm_f32_dma_kernel)
-    const int per_split = gridDim.x * gridDim.y, nwg = per_split * gridDim.z;
-    const int orig = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const int per_split = gx * gy, nwg = per_split * gz;
     const int q = nwg >> 3, rem = nwg & 7, xcd = orig & 7, local = orig >> 3;
     int t = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + local;
     split = t / per_split; t -= split * per_split;
-    tile_y = t / gridDim.x; tile_x = t - tile_y * gridDim.x;
+    tile_y = t / gx; tile_x = t - tile_y * gx;
     if (AK && p.ep.tile_list) {          // the list names 64 x 64 tiles (column tile, row tile): four 32 x 32 blocks each
       const int e = t >> 2, sub = t & 3;
       tile_x = 2 * p.ep.tile_list[2 * e] + (sub & 1); tile_y = 2 * p.ep.tile_list[2 * e + 1] + (sub >> 1);
@@ -537,6 +538,22 @@ __global__ __launch_bounds__(NT) void gemm_f32_wsk_kernel(GemmParams p) {
   gemm_epilogue_rows<T, T, NT>(p, smem, m0, n0, tid, Cz);
 }
 
+template <bool AK, bool BKM>
+__global__ __launch_bounds__(NT) void gemm_f32_wsk_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(1024))) float smem[WSK_SMEM_FLOATS];
+  gemm_f32_wsk_body<AK, BKM>(p, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, gridDim.z, smem);
+}
+// Two INDEPENDENT small products in one launch (round 4): the workgroups [0, n1) run problem 1 (weight-gradient form, both operands K-major), the rest
+// problem 2 (A K-contiguous, B K-major).  The PPO minibatch step's fc weight-gradient pair and its dF product both read dA1 and feed different
+// consumers; as two dependent launches each cost its own ~8 us of launch / fill / drain in a cycle that is a chain of such launches.
+struct WskGrid { int x, y, z; };
+__global__ __launch_bounds__(NT) void gemm_f32_wsk_dual_kernel(GemmParams p1, WskGrid g1, GemmParams p2, WskGrid g2) {
+  __shared__ __attribute__((aligned(1024))) float smem[WSK_SMEM_FLOATS];
+  const int n1 = g1.x * g1.y * g1.z, orig = blockIdx.x;
+  if (orig < n1) gemm_f32_wsk_body<true, true>(p1, orig, g1.x, g1.y, g1.z, smem);
+  else gemm_f32_wsk_body<false, true>(p2, orig - n1, g2.x, g2.y, g2.z, smem);
+}
+
 template <int BM, int BN>
 int launch_dma(const GemmParams& p, int a_kmajor, int b_kmajor, int splits, hipStream_t st) {
   dim3 grid(mansy_ceil_div(p.N, BN), mansy_ceil_div(p.M, BM), splits);
@@ -618,6 +635,7 @@ extern "C" int mansy_prof_gemm_collect(double* total_ms, long long* launches, do
   return MANSY_OK;
 }
 
+static int g_f32_wsk_dual = 1;   // two independent small products as one launch (mansy_gemm_pair_begin / _end); mansy_gemm_f32_wsk(8) / (9) turn it off / on
 static int g_f32_wsk = 1;        // A/B knob (diagnostic): 1 = small products run on the wave-split-K loop (gemm_f32_wsk_kernel), 0 = on the 64 x 64 loop
 extern "C" int mansy_gemm_f32_wsk(int v);
 static int g_f32_wsk_max_tiles = 200;      // products with at most this many 64 x 64 output tiles (and <= 256 workgroups incl. K splits) count as small (mansy_gemm_f32_wsk(v >= 16) sets it): the PPO
@@ -629,8 +647,50 @@ extern "C" int mansy_gemm_f32_wsk(int v) {
   const int old = g_f32_wsk;
   if (v == 0 || v == 1) g_f32_wsk = v;
   if (v == 2 || v == 3) g_f32_wsk_tn = v - 2;
+  if (v == 8 || v == 9) g_f32_wsk_dual = v - 8;
   if (v >= 16) g_f32_wsk_max_tiles = v;
   return old;
+}
+
+// ---- two independent small products as ONE launch (gemm_f32_wsk_dual_kernel).  Between mansy_gemm_pair_begin() and mansy_gemm_pair_end() the products
+// that resolve to the wave-split-K loop are collected instead of launched (everything else launches at once: the caller states that the products
+// between the two calls do not depend on each other); pair_end launches a (TN, NN) couple as one grid, anything else one by one.
+struct WskPending { GemmParams p; int variant; dim3 grid; };       // variant: 0 = <false, false>, 1 = <false, true>, 2 = <true, true>
+static thread_local bool g_pair_open = false;
+static thread_local std::vector<WskPending> g_pair;
+static int wsk_launch_one(const WskPending& w, hipStream_t st) {
+  if (w.variant == 0) MANSY_GEMM_LAUNCH((gemm_f32_wsk_kernel<false, false>), w.grid, dim3(NT), st, w.p);
+  else if (w.variant == 1) MANSY_GEMM_LAUNCH((gemm_f32_wsk_kernel<false, true>), w.grid, dim3(NT), st, w.p);
+  else MANSY_GEMM_LAUNCH((gemm_f32_wsk_kernel<true, true>), w.grid, dim3(NT), st, w.p);
+  MANSY_LAUNCH_CHECK();
+  return MANSY_OK;
+}
+static int wsk_launch(const GemmParams& p, int variant, dim3 grid, hipStream_t st) {
+  WskPending w{p, variant, grid};
+  if (g_pair_open) { g_pair.push_back(w); return MANSY_OK; }
+  return wsk_launch_one(w, st);
+}
+int mansy_gemm_pair_begin() {
+  if (!g_f32_wsk_dual || g_prof.on || g_pair_open) return 0;      // (the launch recorder stamps one event pair per product: no pairing while it runs)
+  g_pair_open = true; g_pair.clear();
+  return 1;
+}
+int mansy_gemm_pair_end(hipStream_t st) {
+  g_pair_open = false;
+  std::vector<WskPending> w;
+  w.swap(g_pair);
+  if (w.size() == 2 && w[0].variant + w[1].variant == 3 && (w[0].variant == 2 || w[1].variant == 2)) {
+    const WskPending& tn = w[0].variant == 2 ? w[0] : w[1];
+    const WskPending& nn = w[0].variant == 2 ? w[1] : w[0];
+    const WskGrid g1{(int)tn.grid.x, (int)tn.grid.y, (int)tn.grid.z}, g2{(int)nn.grid.x, (int)nn.grid.y, (int)nn.grid.z};
+    const dim3 grid(g1.x * g1.y * g1.z + g2.x * g2.y * g2.z);
+    __atomic_fetch_add(&g_mansy_launch_count, 1ull, __ATOMIC_RELAXED);
+    hipLaunchKernelGGL(gemm_f32_wsk_dual_kernel, grid, dim3(NT), 0, st, tn.p, g1, nn.p, g2);
+    MANSY_LAUNCH_CHECK();
+    return MANSY_OK;
+  }
+  for (const WskPending& x : w) { const int rc = wsk_launch_one(x, st); if (rc) return rc; }
+  return MANSY_OK;
 }
 
 // tile codes: 128 -> 128x128, 96 -> 128x64 (LDS-DMA loop only), 64 -> 64x64
@@ -647,18 +707,13 @@ static int gemm_dispatch(const GemmParams& p, int tile, bool dma, int bf, int a_
     const bool store_ok = !p.ep.accumulate && (splits == 1 || p.ep.split_slab != 0);
     if (small && !a_kmajor && p.c_vec_ok && store_ok && !p.ep.tile_list && !p.ep.tile_nrange && !p.ep.a_rowsum && !p.A2) {
       dim3 grid(mansy_ceil_div(p.N, 32), mansy_ceil_div(p.M, 32), splits);
-      if (b_kmajor) MANSY_GEMM_LAUNCH((gemm_f32_wsk_kernel<false, true>), grid, dim3(NT), st, p);
-      else MANSY_GEMM_LAUNCH((gemm_f32_wsk_kernel<false, false>), grid, dim3(NT), st, p);
-      MANSY_LAUNCH_CHECK();
-      return MANSY_OK;
+      return wsk_launch(p, b_kmajor ? 1 : 0, grid, st);
     }
     if (small && g_f32_wsk_tn && a_kmajor && b_kmajor && !p.ep.tile_krange && (p.ep.accumulate || splits == p.splits_pp * (p.A2 ? 2 : 1)) &&
         (p.ep.accumulate || ((p.splits_pp == 1 || p.ep.split_slab != 0) && p.c_vec_ok)) && (!p.ep.tile_list || p.ep.tile_nrange)) {
       dim3 grid(mansy_ceil_div(p.N, 32), mansy_ceil_div(p.M, 32), splits);
       if (p.ep.tile_list) grid = dim3(4 * p.ep.tile_list_n, 1, splits);
-      MANSY_GEMM_LAUNCH((gemm_f32_wsk_kernel<true, true>), grid, dim3(NT), st, p);
-      MANSY_LAUNCH_CHECK();
-      return MANSY_OK;
+      return wsk_launch(p, 2, grid, st);
     }
   }
   if (dma) {

@@ -36,7 +36,6 @@ struct GemmParams {
   // > 0: the XCD-aware tile order walks the column tiles in groups of col_group (all row panels of a group before the next group), so that an
   // XCD's L2 holds ONE group's slice of B next to the A panels it streams (wide-N products: B alone is 3 MB of the 4 MB L2 at N = 1536)
   int col_group = 0;
-  int bk_full = 0, bk_cols = 1;   // gemm_bf16k_kernel's tile list: the first bk_full entries are whole 256 x 128 tiles (bk_cols per row panel), the rest halves
   int c_rmw_ok = 0;  // C (and C2) 16-byte aligned, ldc % 4 == 0, N % 4 == 0: an accumulating product whose blocks have one owner may read-add-write float4
 };
 

@@ -133,6 +133,10 @@ struct DistillShape { int B, S, M, C; int sync_world = 1; int (*hook)(int, void*
 int mansy_bn_sync_invoke(int which, int (*fn)(int, void*), void* user);
 // the wave-split-K loop serves small fp32 weight-gradient (TN) products (gemm_f32.hip; callers that pick a K split for such a product ask first)
 int mansy_gemm_wsk_tn_enabled();
+// Two INDEPENDENT products as one launch where both resolve to the wave-split-K loop (gemm_f32.hip: gemm_f32_wsk_dual_kernel): the products launched
+// between begin (returns 1 if pairing is on) and end must not depend on each other; end launches what was collected (as one grid if it can, else one by one).
+int mansy_gemm_pair_begin();
+int mansy_gemm_pair_end(hipStream_t st);
 // stats_d: device scratch of 6*C doubles ([sum, sumsq] forward, [sum g, sum g*xhat] backward global + local copy).
 int mansy_launch_distill_fwd(const float* conv, const float* bn_w, const float* bn_b, float* run_mean, float* run_var,
                              long long* num_batches, float* mean_out, float* rstd_out, float* mem, unsigned char* argmax,

@@ -1119,21 +1119,28 @@ struct PEng {
   }
   // head_bwd without the output-layer launch (the identifier's training step): dA1 / dH were written by head_out_kernel
   int fc_bwd_single(const NetP& n, int B, const float* dA1, const float* dH) {
+    // the fc weight gradient and the dF product both read dA1 and feed different consumers: one launch where both are small (mansy_gemm_pair_*)
+    const int paired = mansy_gemm_pair_begin();
     GemmEpilogue acc; acc.prec = prec; acc.accumulate = 1; acc.a_rowsum = n.gfc_b;
-    RC(mansy_launch_gemm_f32(dA1, HID, 1, W.F, FEAT, 1, n.gfc_w, FEAT, HID, FEAT, B, acc, 0, 0, st));
+    int rc = mansy_launch_gemm_f32(dA1, HID, 1, W.F, FEAT, 1, n.gfc_w, FEAT, HID, FEAT, B, acc, 0, 0, st);
     GemmEpilogue ep; ep.prec = prec; ep.pre_a = dH; ep.pre_ld = HID; ep.pre_col0 = RESID_COL; ep.mask_src = W.F; ep.mask_ld = FEAT; ep.mask_scale = 1.f; ep.mask_neg = SLOPE;
-    return mansy_launch_gemm_f32(dA1, HID, 0, n.fc_w, FEAT, 1, W.dF, FEAT, B, FEAT, HID, ep, 0, 0, st);
+    if (!rc) rc = mansy_launch_gemm_f32(dA1, HID, 0, n.fc_w, FEAT, 1, W.dF, FEAT, B, FEAT, HID, ep, 0, 0, st);
+    if (paired) { const int rc2 = mansy_gemm_pair_end(st); if (!rc) rc = rc2; }
+    return rc;
   }
   // head_bwd_pair without the output-layer launch: head_out_kernel wrote dH / dA1 itself (LossFuse::bwd_*), the output layers' weight
   // gradients are riders of the unpack launch (OutGradRider) -- the PPO minibatch step's form
   int fc_bwd_pair(const NetP& a, const NetP& c, int B) {
+    const int paired = mansy_gemm_pair_begin();      // the two fc weight gradients and the dF product: independent readers of dA1 (see fc_bwd_single)
     GemmEpilogue acc; acc.prec = prec; acc.accumulate = 1;
     acc.a_rowsum = a.gfc_b;
     acc.pair_A = W.dA1p + HID; acc.pair_B = W.F; acc.pair_C = c.gfc_w; acc.pair_rowsum = c.gfc_b;
-    RC(mansy_launch_gemm_f32(W.dA1p, 2 * HID, 1, W.F, FEAT, 1, a.gfc_w, FEAT, HID, FEAT, B, acc, 0, 0, st));
+    int rc = mansy_launch_gemm_f32(W.dA1p, 2 * HID, 1, W.F, FEAT, 1, a.gfc_w, FEAT, HID, FEAT, B, acc, 0, 0, st);
     GemmEpilogue ep; ep.prec = prec; ep.pre_a = W.dHa; ep.pre_b = W.dHc; ep.pre_ld = HID; ep.pre_col0 = RESID_COL;
     ep.mask_src = W.F; ep.mask_ld = FEAT; ep.mask_scale = 1.f; ep.mask_neg = SLOPE;
-    return mansy_launch_gemm_f32(W.dA1p, 2 * HID, 0, W.Wfc2, FEAT, 1, W.dF, FEAT, B, FEAT, 2 * HID, ep, 0, 0, st);
+    if (!rc) rc = mansy_launch_gemm_f32(W.dA1p, 2 * HID, 0, W.Wfc2, FEAT, 1, W.dF, FEAT, B, FEAT, 2 * HID, ep, 0, 0, st);
+    if (paired) { const int rc2 = mansy_gemm_pair_end(st); if (!rc) rc = rc2; }
+    return rc;
   }
   // norm_tail != nullptr: also leave the squared norm of ALL gradients (branches + [norm_tail, norm_tail + norm_tail_n)) in W.acc
   int featnet_bwd(const NetP& n, const float* obs, int B, int identifier, const float* dHa, const float* dHb, const float* norm_tail = nullptr,
