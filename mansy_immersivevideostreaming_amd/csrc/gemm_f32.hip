@@ -387,14 +387,8 @@ __global__ __launch_bounds__(NT) void gemm_f32_dma_kernel(GemmParams p) {
 constexpr int WSK_T = 32, WSK_WAVE_FLOATS = 2 * WSK_T * BK, WSK_SMEM_FLOATS = 4 * WSK_WAVE_FLOATS;
 // The loop as a device function of (problem, workgroup index `orig` inside the problem's gx x gy x gz grid, the workgroup's LDS): one problem per
 // launch (gemm_f32_wsk_kernel) or two independent problems side by side in one launch (gemm_f32_wsk_dual_kernel).
-// FCN > 0 (NT form only): a second product rides on the launch -- the PPO networks' fc layer on top of the FeatureNet product.  The workgroup's finished
-// 32 x 32 block of F = act(A B^T + bias) (bias + leaky ReLU: the only epilogue this form takes) is written to C as usual AND kept in LDS as the A operand
-// of F_block [32 x 32] x fc_w[:, n0 .. n0 + 31]^T [32 x FCN]: wave w forms the outputs w FCN/4 .. (w + 1) FCN/4 - 1 (its rows of fc_w were requested by
-// LDS-DMA at the start of the kernel) and stores them as slab tile_x of fc_slab; the head kernel adds the N/32 slabs in slab order.  One launch instead
-// of two dependent ones in a cycle that is a chain of ~8 us launches; LDS 52 KB (FCN = 128) / 68 KB (256).
-template <bool AK, bool BKM, int FCN = 0>
+template <bool AK, bool BKM>
 __device__ __forceinline__ void gemm_f32_wsk_body(const GemmParams& p, int orig, int gx, int gy, int gz, float* smem) {
-  static_assert(FCN == 0 || (!AK && !BKM && FCN % 128 == 0), "the second-stage product rides on the NT form");
   constexpr int T = WSK_T, TILE_FLOATS = T * BK, WAVE_FLOATS = WSK_WAVE_FLOATS, CLD = T + 4;       // ONE stage per wave: 8 KB (32 KB per workgroup, five per CU)
   static_assert(T * CLD + 64 <= WAVE_FLOATS, "a partial block and its row sums must fit a wave's stage");
 
@@ -458,19 +452,6 @@ __device__ __forceinline__ void gemm_f32_wsk_body(const GemmParams& p, int orig,
 #pragma unroll
     for (int i = 0; i < 4; ++i) glds16(vob[i], cb, lds_w + TILE_FLOATS * 4u + i * 1024u);
   };
-
-  float* const f_img = smem + WSK_SMEM_FLOATS;           // [32][32]: the activated block, K-contiguous image (second-stage A operand)
-  float* const fc_img = f_img + T * BK;                  // [FCN][32]: rows of fc_w, columns n0 .. n0 + 31 (second-stage B operand)
-  if constexpr (FCN > 0) {                               // this wave's FCN / 4 rows of the slice: 8 rows x 128 B per piece, swizzled like every K-contiguous image
-    constexpr int RW = FCN / 4;
-    const float* const src = p.fc_w + (long long)(wave * RW) * p.fc_ld + n0;
-    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)fc_img + (unsigned)wave * (RW * 128u));
-#pragma unroll
-    for (int i = 0; i < RW / 8; ++i) {
-      const int row = i * 8 + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
-      glds16((unsigned)(row * p.fc_ld + c * 4) * 4u, src, dst + (unsigned)i * 1024u);
-    }
-  }
 
   f32x16 acc;
 #pragma unroll
@@ -552,46 +533,6 @@ __device__ __forceinline__ void gemm_f32_wsk_body(const GemmParams& p, int orig,
     }
     return;
   }
-  if constexpr (FCN > 0) {
-    // bias + leaky ReLU as gemm_epilogue_rows applies them (same operations: F is bit-identical to the unfused product), F stored, the block kept
-    const int lr = tid >> 3, c4 = tid & 7, row = m0 + lr, col = n0 + c4 * 4;
-    if (p.ep.bias) { const float4 b = *reinterpret_cast<const float4*>(p.ep.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
-    if (p.ep.relu) {
-      v.x = v.x > 0.f ? v.x : v.x * p.ep.relu_slope; v.y = v.y > 0.f ? v.y : v.y * p.ep.relu_slope;
-      v.z = v.z > 0.f ? v.z : v.z * p.ep.relu_slope; v.w = v.w > 0.f ? v.w : v.w * p.ep.relu_slope;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's rows of the fc slice have landed (a wave without K-tiles never waited)
-    if (row < p.M) *reinterpret_cast<float4*>(Cz + (long long)row * p.ldc + col) = v;
-    *reinterpret_cast<float4*>(f_img + lr * BK + ((c4 ^ ((lr >> 1) & 7)) * 4)) = v;
-    __syncthreads();
-    constexpr int NBK = FCN / 128;                         // 32-output blocks per wave
-    f32x16 acc2[NBK];
-#pragma unroll
-    for (int jb = 0; jb < NBK; ++jb)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc2[jb][e] = 0.f;
-#pragma unroll
-    for (int chunk = 0; chunk < 2; ++chunk) {
-      float af[8];
-      read_frag_dma<T, false>(f_img, 0, r, h, chunk, af);
-#pragma unroll
-      for (int jb = 0; jb < NBK; ++jb) {
-        float bf[8];
-        read_frag_dma<T, false>(fc_img, wave * (FCN / 4) + jb * 32, r, h, chunk, bf);
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) acc2[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk], bf[kk], acc2[jb], 0, 0, 0);
-      }
-    }
-    float* const slab = p.fc_slab + (long long)tile_x * p.fc_slab_stride;
-#pragma unroll
-    for (int jb = 0; jb < NBK; ++jb)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int orow = m0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (orow < p.M) slab[(long long)orow * FCN + wave * (FCN / 4) + jb * 32 + r] = acc2[jb][e];
-      }
-    return;
-  }
   *reinterpret_cast<float4*>(smem + off) = v;             // read back by the same thread below
   __syncthreads();
   gemm_epilogue_rows<T, T, NT>(p, smem, m0, n0, tid, Cz);
@@ -601,11 +542,6 @@ template <bool AK, bool BKM>
 __global__ __launch_bounds__(NT) void gemm_f32_wsk_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(1024))) float smem[WSK_SMEM_FLOATS];
   gemm_f32_wsk_body<AK, BKM>(p, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, gridDim.z, smem);
-}
-template <int FCN>
-__global__ __launch_bounds__(NT) void gemm_f32_wsk_fc_kernel(GemmParams p) {
-  __shared__ __attribute__((aligned(1024))) float smem[WSK_SMEM_FLOATS + WSK_T * BK + FCN * BK];
-  gemm_f32_wsk_body<false, false, FCN>(p, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, gridDim.z, smem);
 }
 // Two INDEPENDENT small products in one launch (round 4): the workgroups [0, n1) run problem 1 (weight-gradient form, both operands K-major), the rest
 // problem 2 (A K-contiguous, B K-major).  The PPO minibatch step's fc weight-gradient pair and its dF product both read dA1 and feed different
@@ -700,7 +636,6 @@ extern "C" int mansy_prof_gemm_collect(double* total_ms, long long* launches, do
 }
 
 static int g_f32_wsk_dual = 1;   // two independent small products as one launch (mansy_gemm_pair_begin / _end); mansy_gemm_f32_wsk(8) / (9) turn it off / on
-static int g_f32_wsk_fc = 1;     // the second-stage (fc) product riding on the FeatureNet launch (mansy_gemm_f32_fc2_try); mansy_gemm_f32_wsk(10) / (11) turn it off / on
 static int g_f32_wsk = 1;        // A/B knob (diagnostic): 1 = small products run on the wave-split-K loop (gemm_f32_wsk_kernel), 0 = on the 64 x 64 loop
 extern "C" int mansy_gemm_f32_wsk(int v);
 static int g_f32_wsk_max_tiles = 200;      // products with at most this many 64 x 64 output tiles (and <= 256 workgroups incl. K splits) count as small (mansy_gemm_f32_wsk(v >= 16) sets it): the PPO
@@ -713,7 +648,6 @@ extern "C" int mansy_gemm_f32_wsk(int v) {
   if (v == 0 || v == 1) g_f32_wsk = v;
   if (v == 2 || v == 3) g_f32_wsk_tn = v - 2;
   if (v == 8 || v == 9) g_f32_wsk_dual = v - 8;
-  if (v == 10 || v == 11) g_f32_wsk_fc = v - 10;
   if (v >= 16) g_f32_wsk_max_tiles = v;
   return old;
 }
@@ -921,41 +855,6 @@ int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B,
   return rc;
 }
 
-
-// C = act(A B^T + bias) [M, N] AND its second-stage product with fc_w [fc_n, N] as N / 32 slabs of [M, fc_n] (see gemm_f32_wsk_body<.., FCN>), in one
-// launch -- when the first product is a small exact-fp32 NT product with a bias / leaky-ReLU epilogue.  Returns 1 = launched, 0 = not eligible (the caller
-// runs the two products as two launches), < 0 = error.
-int mansy_gemm_f32_fc2_try(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, const GemmEpilogue& ep,
-                           const float* fc_w, int fc_ld, int fc_n, float* slab, long long slab_stride, hipStream_t st) {
-  auto al16 = [](const void* x) { return (reinterpret_cast<uintptr_t>(x) & 15) == 0; };
-  const int prec = ep.prec >= 0 ? ep.prec : g_gemm_prec;
-  const bool plain_act = !ep.mask_src && ep.drop.p == 0.f && !ep.resid && !ep.pre_a && !ep.accumulate && ep.split_slab == 0 && !ep.tile_list && !ep.tile_nrange &&
-                         !ep.a_rowsum && !ep.pair_A;
-  if (!g_f32_wsk || !g_f32_wsk_fc || prec != 0 || !plain_act || M < 1 || (fc_n != 128 && fc_n != 256) || N % 32 != 0 || K < BK || K % BK != 0) return 0;
-  if (!A || !B || !C || !fc_w || !slab) return 0;
-  if (!(al16(A) && al16(B) && al16(C) && al16(fc_w) && al16(slab) && lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && fc_ld % 4 == 0 && (!ep.bias || al16(ep.bias)))) return 0;
-  if ((long long)mansy_ceil_div(M, 64) * mansy_ceil_div(N, 64) > g_f32_wsk_max_tiles) return 0;        // the launches the wave-split-K loop takes
-  GemmParams p;
-  p.A = A; p.B = B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.ep = ep;
-  p.vec_ok = 1; p.c_vec_ok = 1; p.col_group = 0; p.k_per_split = K; p.splits_pp = 1;
-  p.fc_w = fc_w; p.fc_ld = fc_ld; p.fc_slab = slab; p.fc_slab_stride = slab_stride;
-  const dim3 grid(N / 32, mansy_ceil_div(M, 32), 1);
-  if (g_prof.on) {
-    if (g_prof.used + 2 > g_prof.ev.size()) {
-      for (int i = 0; i < 2; ++i) { hipEvent_t e; MANSY_HIP_CHECK(hipEventCreate(&e)); g_prof.ev.push_back(e); }
-    }
-    mansy_gemm::g_ev_start = g_prof.ev[g_prof.used]; mansy_gemm::g_ev_stop = g_prof.ev[g_prof.used + 1];
-  }
-  if (fc_n == 128) MANSY_GEMM_LAUNCH((gemm_f32_wsk_fc_kernel<128>), grid, dim3(NT), st, p);
-  else MANSY_GEMM_LAUNCH((gemm_f32_wsk_fc_kernel<256>), grid, dim3(NT), st, p);
-  if (g_prof.on) {
-    mansy_gemm::g_ev_start = mansy_gemm::g_ev_stop = nullptr;
-    g_prof.used += 2;
-    g_prof.flops += 2.0 * (double)M * (double)N * (double)K * (ep.tile_krange ? (double)ep.flops_frac : 1.0) + 2.0 * (double)M * (double)fc_n * (double)N;
-  }
-  MANSY_LAUNCH_CHECK();
-  return 1;
-}
 
 int mansy_gemm_effective_splits(int K, int requested) {
   if (requested <= 1 || K <= 0) return 1;

@@ -36,9 +36,6 @@ struct GemmParams {
   // > 0: the XCD-aware tile order walks the column tiles in groups of col_group (all row panels of a group before the next group), so that an
   // XCD's L2 holds ONE group's slice of B next to the A panels it streams (wide-N products: B alone is 3 MB of the 4 MB L2 at N = 1536)
   int col_group = 0;
-  // second-stage product of the wave-split-K loop (gemm_f32_wsk_body<.., FCN>): each 32 x 32 block of C = act(A B^T + bias), still in LDS, is multiplied
-  // by the FCN x 32 slice fc_w[:, n0 .. n0 + 31] of a second weight and stored as slab number tile_x of fc_slab ([M, FCN] floats each, fc_slab_stride apart)
-  const float* fc_w = nullptr; int fc_ld = 0; float* fc_slab = nullptr; long long fc_slab_stride = 0;
   int c_rmw_ok = 0;  // C (and C2) 16-byte aligned, ldc % 4 == 0, N % 4 == 0: an accumulating product whose blocks have one owner may read-add-write float4
 };
 

@@ -133,10 +133,6 @@ struct DistillShape { int B, S, M, C; int sync_world = 1; int (*hook)(int, void*
 int mansy_bn_sync_invoke(int which, int (*fn)(int, void*), void* user);
 // the wave-split-K loop serves small fp32 weight-gradient (TN) products (gemm_f32.hip; callers that pick a K split for such a product ask first)
 int mansy_gemm_wsk_tn_enabled();
-// C = act(A B^T + bias) and, in the same launch, its product with fc_w [fc_n, N] (fc_n = 128 / 256) as N / 32 slabs of [M, fc_n] floats (slab_stride apart).
-// 1 = launched, 0 = not eligible (run the two products separately), < 0 = error.  gemm_f32.hip.
-int mansy_gemm_f32_fc2_try(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, const GemmEpilogue& ep,
-                           const float* fc_w, int fc_ld, int fc_n, float* slab, long long slab_stride, hipStream_t st);
 // Two INDEPENDENT products as one launch where both resolve to the wave-split-K loop (gemm_f32.hip: gemm_f32_wsk_dual_kernel): the products launched
 // between begin (returns 1 if pairing is on) and end must not depend on each other; end launches what was collected (as one grid if it can, else one by one).
 int mansy_gemm_pair_begin();

@@ -38,8 +38,6 @@ constexpr int RESID_COL = FEAT - HID;      // 10th branch output is the residual
 constexpr int NORM_PARTS_C = MANSY_CLIP_SCRATCH_DOUBLES;   // gradient-norm partial sums
 constexpr int HB_BLOCKS = 64;               // workgroups of the output-layer backward (each ends with n_out x 128 global atomics)
 constexpr int MAX_SLABS = 16;              // K splits of a head's fc product (head_split_request)
-constexpr int FC_SLABS = FEAT / 32;        // slabs of the fc product when it rides on the FeatureNet launch (one per 32-feature block: mansy_gemm_f32_fc2_try)
-constexpr int FC_FUSE_MAX_B = 512;         // batches up to this size take that form (rollout steps, PPO minibatches); larger ones run the two products as two launches
 constexpr int DW_SLABS = 24;               // K (= batch) splits of the packed FeatureNet weight-gradient product (featnet_bwd)
 constexpr int DW_TILES_MAX = 64;           // 64 x 64 tiles of that product that meet a branch's window (42 for both nets)
 
@@ -394,8 +392,7 @@ __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const f
   }
   const float u_row = (act && u_ext) ? u_ext[row] : 0.f;
   float a0, a1;
-  float p0[FC_SLABS], p1[FC_SLABS];
-  const bool many = nsplit > MAX_SLABS;          // the fc product rode on the FeatureNet launch: FC_SLABS slabs
+  float p0[MAX_SLABS], p1[MAX_SLABS];
   if (nsplit > 0) {
     a0 = d.fc_b[lane]; a1 = d.fc_b[64 + lane];
     const float* pre = A1pre + (size_t)row * pre_ld + d.pre_col;
@@ -406,13 +403,6 @@ __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const f
       const long long zz = (long long)min(z, nsplit - 1) * slab;
       p0[z] = pre[zz + lane]; p1[z] = pre[zz + 64 + lane];
     }
-    if (many) {
-#pragma unroll
-      for (int z = MAX_SLABS; z < FC_SLABS; ++z) {
-        const long long zz = (long long)min(z, nsplit - 1) * slab;
-        p0[z] = pre[zz + lane]; p1[z] = pre[zz + 64 + lane];
-      }
-    }
   } else {
     a0 = A1[(size_t)row * HID + lane]; a1 = A1[(size_t)row * HID + 64 + lane];
   }
@@ -422,10 +412,6 @@ __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const f
   if (nsplit > 0) {
 #pragma unroll
     for (int z = 0; z < MAX_SLABS; ++z) { a0 = z < nsplit ? a0 + p0[z] : a0; a1 = z < nsplit ? a1 + p1[z] : a1; }
-    if (many) {
-#pragma unroll
-      for (int z = MAX_SLABS; z < FC_SLABS; ++z) { a0 = z < nsplit ? a0 + p0[z] : a0; a1 = z < nsplit ? a1 + p1[z] : a1; }
-    }
     a0 = a0 > 0.f ? a0 : a0 * SLOPE; a1 = a1 > 0.f ? a1 : a1 * SLOPE;
     A1[(size_t)row * HID + lane] = a0; A1[(size_t)row * HID + 64 + lane] = a1;
   }
@@ -975,7 +961,7 @@ inline int head_split_request(int B, int n_cols = HID) {
   return req < 2 ? 1 : (req > 16 ? 16 : req);
 }
 inline int head_slab_rows(int maxB) {
-  int rows = std::max(maxB, FC_SLABS * std::min(maxB, FC_FUSE_MAX_B));      // the fused form: FC_SLABS slabs of up to FC_FUSE_MAX_B rows
+  int rows = maxB;
   for (int B = 1; B <= maxB; B = B < 64 ? 64 : B + 64) {
     const int r = mansy_gemm_effective_splits(FEAT, head_split_request(B)) * B;
     if (r > rows) rows = r;
@@ -1036,19 +1022,10 @@ struct PEng {
     MANSY_LAUNCH_CHECK();
     return MANSY_OK;
   }
-  int fused_slabs = 0;      // > 0: the fc product of the head(s) that follow rode on the FeatureNet launch (its slabs are in W.A1s); consumed by head() / head_pair()
-  // fc_w != nullptr: the [fcn, FEAT] fc weight of the head(s) evaluated next (fcn = HID: one head, 2 HID: the stacked actor / critic operand): where the
-  // batch is small enough for the wave-split-K loop the fc product rides on this launch (one launch fewer per rollout step / minibatch step)
-  int featnet(const float* obs, int B, int identifier, const float* fc_w = nullptr, int fcn = 0) {
+  int featnet(const float* obs, int B, int identifier) {
     const int K = identifier ? K_IDENT : K_POLICY;
     (void)K;      // the packed image spans KP columns (zero beyond K); obs rows are OBS_LD >= KP floats
     GemmEpilogue ep; ep.prec = prec; ep.bias = W.bbd; ep.relu = 1; ep.relu_slope = SLOPE; ep.tile_krange = W.krange;
-    fused_slabs = 0;
-    if (fc_w && prec == 0 && B <= FC_FUSE_MAX_B && (reinterpret_cast<uintptr_t>(obs) & 15) == 0) {
-      const int rc = mansy_gemm_f32_fc2_try(obs, OBS_LD, W.Wbd, KP, W.F, FEAT, B, FEAT, KP, ep, fc_w, FEAT, fcn, W.A1s, (long long)B * fcn, st);
-      if (rc < 0) return rc;
-      if (rc == 1) { fused_slabs = FC_SLABS; return MANSY_OK; }
-    }
     // the packed image is only defined inside the K windows: the product must run on a loop that honours tile_krange -- the LDS-DMA
     // loop or its split-bf16 twin, i.e. K a multiple of 32 (KP), leading dimensions multiples of 4, 16-byte aligned operands
     static_assert(KP % 32 == 0 && OBS_LD % 4 == 0, "FeatureNet product must qualify for the LDS-DMA loop");
@@ -1062,8 +1039,7 @@ struct PEng {
            float* logp, const EnvFuse* env = nullptr, int out_ld = 0, const HeadRiders* rd = nullptr, const LossFuse* fuse = nullptr) {
     const int req = head_split_request(B);
     int nsplit = 0;
-    if (fused_slabs) { nsplit = fused_slabs; fused_slabs = 0; }      // the slabs are there already (featnet)
-    else if (req > 1) {
+    if (req > 1) {
       nsplit = mansy_gemm_effective_splits(FEAT, req);
       MANSY_REQUIRE(nsplit <= MAX_SLABS, "head: %d K splits exceed the slab sum's unroll", nsplit);
       GemmEpilogue ep; ep.prec = prec; ep.split_slab = (long long)B * HID;
@@ -1092,14 +1068,10 @@ struct PEng {
   // value != nullptr: the critic's output goes straight into that [B] vector (no strided copy afterwards)
   int head_pair(const NetP& a, const NetP& c, int B, const LossFuse* fuse = nullptr, float* value = nullptr, const HeadRiders* rd = nullptr) {
     const int req = head_split_request(B, 2 * HID);
-    int nsplit;
-    if (fused_slabs) { nsplit = fused_slabs; fused_slabs = 0; }      // the slabs are there already (featnet)
-    else {
-      nsplit = mansy_gemm_effective_splits(FEAT, req);
-      MANSY_REQUIRE(nsplit <= MAX_SLABS, "head_pair: %d K splits exceed the slab sum's unroll", nsplit);
-      GemmEpilogue ep; ep.prec = prec; ep.split_slab = (long long)B * 2 * HID;
-      RC(mansy_launch_gemm_f32(W.F, FEAT, 0, W.Wfc2, FEAT, 0, W.A1s, 2 * HID, B, 2 * HID, FEAT, ep, 0, req, st));
-    }
+    const int nsplit = mansy_gemm_effective_splits(FEAT, req);
+    MANSY_REQUIRE(nsplit <= MAX_SLABS, "head_pair: %d K splits exceed the slab sum's unroll", nsplit);
+    GemmEpilogue ep; ep.prec = prec; ep.split_slab = (long long)B * 2 * HID;
+    RC(mansy_launch_gemm_f32(W.F, FEAT, 0, W.Wfc2, FEAT, 0, W.A1s, 2 * HID, B, 2 * HID, FEAT, ep, 0, req, st));
     HeadOutArgs ha;
     ha.h[0] = {W.A1a, a.fc_b, a.out_w, a.out_b, NACT, 0, W.Ha, W.outa, 0, nullptr, nullptr, 0};
     ha.h[1] = {W.A1c, c.fc_b, c.out_w, c.out_b, 1, 0, W.Hc, value ? value : W.outc, HID, nullptr, nullptr, value ? 1 : 0};
@@ -1323,7 +1295,7 @@ int mansy_policy_env_step(const float* const* params, const float* obs, int n_en
   PEng e; RC(setup(workspace, max_batch, precision, (hipStream_t)stream, e));
   NetP a; bind_net(params, nullptr, 20, a);
   if (!reuse_packed) RC(e.pack(a, 0));
-  RC(e.featnet(obs, n_env, 0, a.fc_w, HID));
+  RC(e.featnet(obs, n_env, 0));
   EnvFuse ef; memset(&ef, 0, sizeof(ef));
   ef.on = 1; ef.T = *T; ef.st = (envdev::EnvState*)env_state; ef.obs_next = obs_next; ef.obs_cur = obs_cur; ef.reward = reward; ef.done = done;
   ef.qoe_parts = qoe_parts;
@@ -1336,7 +1308,7 @@ int mansy_identifier_forward(const float* const* params, const float* obs, int B
   PEng e; RC(setup(workspace, max_batch, precision, (hipStream_t)stream, e));
   NetP n; bind_net(params, nullptr, 20, n);
   RC(e.pack(n, 1));
-  RC(e.featnet(obs, B, 1, n.fc_w, HID));
+  RC(e.featnet(obs, B, 1));
   return e.head(n, B, 3, 1, e.W.A1a, e.W.Ha, pred, nullptr, 0, 0, nullptr, nullptr);
 }
 
@@ -1354,7 +1326,7 @@ int mansy_identifier_train_step(const float* const* params, float* const* grads,
   MANSY_REQUIRE(!train || (grads && flat_p && flat_g && flat_m && flat_v), "identifier_train_step: null optimiser buffers");
   RC(e.pack(n, 1, nullptr, idx ? obs_all : nullptr, idx, B, train ? flat_g : nullptr, n_flat));      // row gather + gradient zero-fill ride on the pack launch
   const float* obs = idx ? e.W.obs_mb : obs_all;
-  RC(e.featnet(obs, B, 1, n.fc_w, HID));
+  RC(e.featnet(obs, B, 1));
   if (!train) {          // validation: loss only (W.acc[0..1], the accumulator and the arrival counter, were zeroed by the pack launch's riders)
     RC(e.head(n, B, 3, 1, e.W.A1a, e.W.Ha, e.W.outa, nullptr, 0, 0, nullptr, nullptr));
     MANSY_LAUNCH(ident_mse_kernel, dim3(min(mansy_ceil_div(B * 3, 256), 256)), dim3(256), 0, e.st, e.W.outa, obs, B, nullptr, e.W.acc, loss_out);
@@ -1384,7 +1356,7 @@ int mansy_identifier_relabel(const float* const* params, const float* obs, float
   PEng e; RC(setup(workspace, max_batch, precision, (hipStream_t)stream, e));
   NetP n; bind_net(params, nullptr, 20, n);
   RC(e.pack(n, 1));
-  RC(e.featnet(obs, B, 1, n.fc_w, HID));
+  RC(e.featnet(obs, B, 1));
   PEng::HeadRiders rd; rd.relabel_rew = rew; rd.relabel_idrew = id_rew; rd.relabel_obs = obs; rd.relabel_lamb = lamb;      // the relabel rides on the output-layer launch
   RC(e.head(n, B, 3, 1, e.W.A1a, e.W.Ha, e.W.outa, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, &rd));
   return MANSY_OK;
@@ -1401,7 +1373,7 @@ int mansy_policy_evaluate(const float* const* params, const float* obs, int B, c
   NetP a, c; bind_net(params, nullptr, 20, a); bind_net(params, nullptr, 24, c);
   const bool both = logp && value;
   RC(e.pack(a, 0, both ? &c : nullptr));
-  RC(e.featnet(obs, B, 0, both ? e.W.Wfc2 : (logp ? a.fc_w : c.fc_w), both ? 2 * HID : HID));
+  RC(e.featnet(obs, B, 0));
   if (logp) MANSY_REQUIRE(act, "policy_evaluate: logp needs actions");
   PEng::HeadRiders rd; rd.act_given = logp ? act : nullptr; rd.n_given = logp ? n_logp : 0; rd.logp = logp;      // logp_old rides on the output-layer launch
   if (both) RC(e.head_pair(a, c, B, nullptr, value, &rd));      // actor + critic in one stacked product; the value lands in `value`
@@ -1464,7 +1436,7 @@ int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, fl
   double* const parts_cur = e.W.acc + (chain_ok && (step & 1) ? NORM_PARTS_C : 0);
   double* const parts_next = e.W.acc + (chain_ok && (step & 1) ? 0 : NORM_PARTS_C);
   if (!chain_in) RC(e.pack_mb(a, c, idx ? obs_all : nullptr, idx, mb, flat_g, n_flat, adv_all));
-  RC(e.featnet(obs, mb, 0, e.W.Wfc2, 2 * HID));
+  RC(e.featnet(obs, mb, 0));
   LossFuse lf; memset(&lf, 0, sizeof(lf));
   lf.on = 1; lf.act = act_all; lf.adv = adv_all; lf.logp_old = logp_old_all; lf.v_old = v_old_all; lf.ret = ret_all; lf.idx = idx; lf.n = mb;
   lf.eps_clip = eps_clip; lf.vf_coef = vf_coef; lf.ent_coef = ent_coef; lf.norm_adv = norm_adv; lf.value_clip = value_clip; lf.dual_clip = dual_clip;
@@ -1512,7 +1484,7 @@ int mansy_bc_step(const float* const* params, float* const* grads, float* flat_p
   PEng e; RC(setup(workspace, max_batch, precision, (hipStream_t)stream, e));
   NetP a, c; bind_net(params, grads, 20, a); bind_net(params, grads, 24, c);
   RC(e.pack(a, 0, &c, nullptr, nullptr, B, step > 0 ? flat_g : nullptr, step > 0 ? n_flat : 0));
-  RC(e.featnet(obs, B, 0, e.W.Wfc2, 2 * HID));
+  RC(e.featnet(obs, B, 0));
   RC(e.head_pair(a, c, B));
   MANSY_LAUNCH(bc_loss_kernel, dim3(1), dim3(1024), 0, e.st, e.W.outa, act, B, ent_coef, e.W.gout, e.W.gout_c, stats);
   MANSY_LAUNCH_CHECK();

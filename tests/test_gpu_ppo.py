@@ -596,45 +596,6 @@ def test_fused_rollout_step_equals_policy_forward_plus_env_step(M):
     np.testing.assert_array_equal(va.pop_episode_log()[:, [0, 2, 7]].sum(0), vb.pop_episode_log()[:, [0, 2, 7]].sum(0))
 
 
-@pytest.mark.parametrize('B', [1, 33, 192, 500])
-def test_fc_product_riding_on_the_featurenet_launch_equals_the_two_launch_form(M, B):
-    """Round 4: for batches up to 512 rows the heads' fc product [B, 1280] x [1280, 128 | 256] rides on the FeatureNet launch (each 32 x 32 block of F,
-    still in LDS, times its 32-column slice of the fc weight -> 40 slabs that the output-layer launch adds; gemm_f32_wsk_body<.., FCN>,
-    mansy_gemm_f32_wsk(10) / (11) = off / on).  Same products, another (deterministic) summation order for the fc layer: logits, values and the
-    identifier's predictions agree with the two-launch form to fp32 rounding, ragged row counts included; run to run bit-identical."""
-    from mansy_immersivevideostreaming_amd._lib import check, lib, ptr, stream_ptr
-    L = lib()
-    sd = po.make_policy_state_dict(int(Z['wseed']))
-    pol = build_policy(M, sd)
-    eng = pol.engine
-    g = torch.Generator().manual_seed(100 + B)
-    obs = torch.rand(B, 780, generator=g).cuda()
-    u = torch.rand(B, generator=g).cuda()
-    act_given = torch.randint(0, 15, (B,), generator=g).int().cuda()
-    arr, _ = eng.ac.pointers()
-
-    def run():
-        logits, value, act, logp = eng.policy_forward(obs, want_value=True, sample=True, u=u)       # actor head fused, critic head on its own product
-        pred = eng.identifier_forward(obs)
-        lp, v2 = torch.empty(B, device='cuda'), torch.empty(B, device='cuda')
-        check(L.mansy_policy_evaluate(arr, ptr(obs), B, ptr(act_given), B, ptr(lp), ptr(v2), ptr(eng.workspace()), eng.max_batch, eng.prec, stream_ptr(obs.device)),
-              'mansy_policy_evaluate')                                                                # both heads on the stacked [256, 1280] operand
-        return logits.clone(), value.clone(), logp.clone(), pred.clone(), lp, v2, act.clone()
-    try:
-        L.mansy_gemm_f32_wsk(10)
-        ref = run()
-        L.mansy_gemm_f32_wsk(11)
-        got = run()
-        again = run()
-    finally:
-        L.mansy_gemm_f32_wsk(11)
-    for a, b in zip(got, again):
-        assert torch.equal(a, b)
-    for k, (a, b) in enumerate(zip(ref[:6], got[:6])):
-        assert (a - b).abs().max().item() <= 3e-6 * max(1.0, float(a.abs().max())), k
-    assert (ref[6] != got[6]).sum().item() <= max(1, B // 100)      # a sampling threshold may sit inside the rounding difference
-
-
 def test_behavior_cloning_pretraining_vs_reference(M, tmp_path):
     """The whole behavior_cloning_pretraining() loop (utils/mansy_utils.py:52-93) against the capture of the IMPORTED reference
     function (tools/gen_golden_bc.py: duck-typed policy around the reference Actor, duck-typed demonstrations): same host RNG
