@@ -155,11 +155,12 @@ __global__ __launch_bounds__(256) void outer_reduce_kernel(const float* __restri
     for (int j = 0; j < V; ++j) acc[k][j] = 0.f;
 #pragma unroll
   for (int j = 0; j < V; ++j) sb[j] = 0.f;
+  constexpr int U = 4;                                   // rows in flight per wave (8: 57 -> 65 us on the [40 960-row] calls)
   const int rstep = gridDim.y * 4;
-  for (int r0 = blockIdx.y * 4 + wave; r0 < rows; r0 += 4 * rstep) {
-    float v[4][V];
+  for (int r0 = blockIdx.y * 4 + wave; r0 < rows; r0 += U * rstep) {
+    float v[U][V];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int r = r0 + u * rstep;
       if (live && r < rows) {
         if (V == 4) *reinterpret_cast<float4*>(v[u]) = *reinterpret_cast<const float4*>(big + (long long)r * C + c);
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(256) void outer_reduce_kernel(const float* __restri
       }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int r = min(r0 + u * rstep, rows - 1);      // v[u] is zero beyond the last row
 #pragma unroll
       for (int k = 0; k < NK; ++k) {
@@ -605,6 +606,8 @@ int mansy_launch_outer_reduce(const float* small_, int small_n, const float* big
   MANSY_REQUIRE(small_ && big && out, "outer_reduce: null pointer");
   MANSY_REQUIRE(small_n >= 1 && small_n <= MAX_IN, "outer_reduce: small_n %d unsupported", small_n);
   if (rows <= 0) return MANSY_OK;
+  // (measured, round 4: 64 chunks instead of 256 -- a quarter of the atomics per output element -- DOUBLED the [40 960-row] calls of the VP step,
+  // 57 -> 116 us: the streaming, not the tail of float atomics, sets this kernel's time)
   const int chunks = max(1, min(mansy_ceil_div(rows, 16), 256));
   MANSY_SMALL_DISPATCH(outer_reduce_kernel, C % 4 == 0 && al16(big), small_n, dim3(mansy_ceil_div(C, 256), chunks),
                        dim3(mansy_ceil_div(C, 64), chunks), small_, small_n, big, rows, C, out, c_major, bsum_big, bsum_small);

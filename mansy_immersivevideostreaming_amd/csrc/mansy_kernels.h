@@ -138,14 +138,17 @@ int mansy_gemm_wsk_tn_enabled();
 int mansy_gemm_pair_begin();
 int mansy_gemm_pair_end(hipStream_t st);
 // stats_d: device scratch of 6*C doubles ([sum, sumsq] forward, [sum g, sum g*xhat] backward global + local copy).
+// part (optional): scratch of MANSY_DISTILL_PARTS * 2 * C doubles -- the column sums then go through one partial per workgroup and a small reduce
+// launch (deterministic, in order) instead of double atomics on 2 C addresses from every workgroup.
+constexpr int MANSY_DISTILL_PARTS = 512;
 int mansy_launch_distill_fwd(const float* conv, const float* bn_w, const float* bn_b, float* run_mean, float* run_var,
                              long long* num_batches, float* mean_out, float* rstd_out, float* mem, unsigned char* argmax,
                              double* stats_d, const DistillShape& s, int train, float eps, float momentum,
-                             hipStream_t st);
+                             hipStream_t st, double* part = nullptr);
 // dconv [B*S,C] from dmem [B*M,C]; dbn_w/dbn_b accumulated (+=).  g_tmp: [B*S,C] scratch.
 int mansy_launch_distill_bwd(const float* conv, const float* dmem, const unsigned char* argmax, const float* bn_w,
                              const float* bn_b, const float* mean, const float* rstd, float* g_tmp, float* dconv,
-                             float* dbn_w, float* dbn_b, double* stats_d, const DistillShape& s, hipStream_t st);
+                             float* dbn_w, float* dbn_b, double* stats_d, const DistillShape& s, hipStream_t st, double* part = nullptr);
 
 // ---------------------------------------------------------------- fused decoder-step tail (dec_step.hip)
 // One launch for the four row-wise ops between the last product of decoder step i and the first of step i+1:

@@ -271,14 +271,42 @@ __global__ __launch_bounds__(256) void ln_partials_reduce_kernel(const float* __
 
 // ------------------------------------------------------------------ DistillLayer tail
 // column sums of x and x^2 over rows -> doubles
-__global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__ x, int rows, int C, double* __restrict__ stats) {
+__global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__ x, int rows, int C, double* __restrict__ stats, double* __restrict__ part) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   const int r0 = blockIdx.y, rstep = gridDim.y;
   double s = 0.0, q = 0.0;
-  for (int r = r0; r < rows; r += rstep) { const double v = x[(long long)r * C + c]; s += v; q += v * v; }
+  constexpr int U = 8;                                    // loads of U rows issued before their sums (double adds are sequential per thread)
+  for (int r = r0; r < rows; r += U * rstep) {
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = x[(long long)min(r + u * rstep, rows - 1) * C + c];
+#pragma unroll
+    for (int u = 0; u < U; ++u) if (r + u * rstep < rows) { const double d = v[u]; s += d; q += d * d; }
+  }
+  if (part) {                                             // per-workgroup partial sums, added up in order by col_parts_reduce_kernel
+    part[((long long)blockIdx.y * 2 + 0) * C + c] = s;
+    part[((long long)blockIdx.y * 2 + 1) * C + c] = q;
+    return;
+  }
   atomicAdd(stats + c, s);
   atomicAdd(stats + C + c, q);
+}
+// dst[i] = sum_p part[p][i], i < n (= 2 C), p in order: the second half of a column reduction whose first half left one partial per workgroup.
+// (Round 4: the first half used to add its sums with double atomics -- 512 to 1024 workgroups on the same 2 C addresses, resolved at the memory side
+// across the eight XCDs: ~80 us of a 125 us kernel.)
+__global__ __launch_bounds__(256) void col_parts_reduce_kernel(const double* __restrict__ part, int nparts, int n, double* __restrict__ dst) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double t = 0.0;
+  for (int p0 = 0; p0 < nparts; p0 += 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[(long long)min(p0 + u, nparts - 1) * n + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) if (p0 + u < nparts) t += v[u];
+  }
+  dst[i] = t;
 }
 
 __global__ void bn_finalize_kernel(const double* __restrict__ stats, int n, int C, float* run_mean, float* run_var,
@@ -334,48 +362,78 @@ __global__ __launch_bounds__(256) void distill_bwd_stage1(const float* __restric
                                                           const unsigned char* __restrict__ argmax, const float* __restrict__ bn_w,
                                                           const float* __restrict__ bn_b, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, float* __restrict__ g, double* __restrict__ stats,
-                                                          DistillShape s) {
+                                                          DistillShape s, double* __restrict__ part) {
   const int CV = s.C / V;
   const int tpr = CV < 256 ? CV : 256;                  // threads per row (CV a multiple of 256, or a divisor of it)
   const int rsub = threadIdx.x / tpr, rpw = 256 / tpr;  // row sub-stream of this thread, row streams per workgroup
   const int c = (blockIdx.x * tpr + threadIdx.x % tpr) * V;
-  if (c >= s.C || rsub >= rpw) return;
+  __shared__ double sh_part[256][2 * V + 1];
+  if (c >= s.C || rsub >= rpw) return;                  // (never true on the partial-sum path: CV is a multiple or a divisor of 256 there)
   float mu[V], rs[V], w[V], sh[V];
   double sg[V], sgx[V];
 #pragma unroll
   for (int j = 0; j < V; ++j) { mu[j] = mean[c + j]; rs[j] = rstd[c + j]; w[j] = bn_w[c + j]; sh[j] = bn_b[c + j]; sg[j] = 0.0; sgx[j] = 0.0; }
   const int rows = s.B * s.S;
-  for (int r = blockIdx.y * rpw + rsub; r < rows; r += gridDim.y * rpw) {
-    const int b = r / s.S, sp = r % s.S;
-    // pooling windows containing sp: 2m-1 <= sp <= 2m+1  <=>  m in {sp/2, (sp+1)/2} (the same window twice when sp is even)
-    const int m0 = min(sp / 2, s.M - 1), m1 = min((sp + 1) / 2, s.M - 1);
-    const bool two = (sp + 1) / 2 != sp / 2 && (sp + 1) / 2 < s.M;
-    const bool one = sp / 2 < s.M;
-    const long long i0 = ((long long)b * s.M + m0) * s.C + c, i1 = ((long long)b * s.M + m1) * s.C + c;
-    float d0[V], d1[V], xv[V];
-    unsigned char a0[V], a1[V];
-    if (V == 4) {
-      *reinterpret_cast<float4*>(d0) = *reinterpret_cast<const float4*>(dmem + i0);
-      *reinterpret_cast<float4*>(d1) = *reinterpret_cast<const float4*>(dmem + i1);
-      *reinterpret_cast<float4*>(xv) = *reinterpret_cast<const float4*>(conv + (long long)r * s.C + c);
-      *reinterpret_cast<uchar4*>(a0) = *reinterpret_cast<const uchar4*>(argmax + i0);
-      *reinterpret_cast<uchar4*>(a1) = *reinterpret_cast<const uchar4*>(argmax + i1);
-    } else {
-      d0[0] = dmem[i0]; d1[0] = dmem[i1]; xv[0] = conv[(long long)r * s.C + c]; a0[0] = argmax[i0]; a1[0] = argmax[i1];
-    }
-    float gg[V];
+  constexpr int U = 4;                                    // rows in flight per thread: every load of the U rows is issued before the first use (one row at a
+                                                          // time made the [40 960-row] call 80 dependent round trips per thread: 129 us for 220 MB)
+  const int rstep = gridDim.y * rpw;
+  for (int r0 = blockIdx.y * rpw + rsub; r0 < rows; r0 += U * rstep) {
+    float d0[U][V], d1[U][V], xv[U][V];
+    unsigned char a0[U][V], a1[U][V];
 #pragma unroll
-    for (int j = 0; j < V; ++j) {
-      float up = 0.f;
-      if (one && a0[j] == (unsigned char)sp) up += d0[j];
-      if (two && a1[j] == (unsigned char)sp) up += d1[j];
-      const float xh = (xv[j] - mu[j]) * rs[j];
-      const float ypre = xh * w[j] + sh[j];
-      gg[j] = up * (ypre > 0.f ? 1.f : expf(ypre));
-      sg[j] += gg[j]; sgx[j] += (double)gg[j] * xh;
+    for (int u = 0; u < U; ++u) {
+      const int r = min(r0 + u * rstep, rows - 1);        // clamped: rows beyond the end are recomputed and dropped
+      const int b = r / s.S, sp = r % s.S;
+      // pooling windows containing sp: 2m-1 <= sp <= 2m+1  <=>  m in {sp/2, (sp+1)/2} (the same window twice when sp is even)
+      const int m0 = min(sp / 2, s.M - 1), m1 = min((sp + 1) / 2, s.M - 1);
+      const long long i0 = ((long long)b * s.M + m0) * s.C + c, i1 = ((long long)b * s.M + m1) * s.C + c;
+      if (V == 4) {
+        *reinterpret_cast<float4*>(d0[u]) = *reinterpret_cast<const float4*>(dmem + i0);
+        *reinterpret_cast<float4*>(d1[u]) = *reinterpret_cast<const float4*>(dmem + i1);
+        *reinterpret_cast<float4*>(xv[u]) = *reinterpret_cast<const float4*>(conv + (long long)r * s.C + c);
+        *reinterpret_cast<uchar4*>(a0[u]) = *reinterpret_cast<const uchar4*>(argmax + i0);
+        *reinterpret_cast<uchar4*>(a1[u]) = *reinterpret_cast<const uchar4*>(argmax + i1);
+      } else {
+        d0[u][0] = dmem[i0]; d1[u][0] = dmem[i1]; xv[u][0] = conv[(long long)r * s.C + c]; a0[u][0] = argmax[i0]; a1[u][0] = argmax[i1];
+      }
     }
-    if (V == 4) *reinterpret_cast<float4*>(g + (long long)r * s.C + c) = *reinterpret_cast<const float4*>(gg);
-    else g[(long long)r * s.C + c] = gg[0];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int r = r0 + u * rstep;
+      if (r >= rows) break;
+      const int sp = r % s.S;
+      const bool two = (sp + 1) / 2 != sp / 2 && (sp + 1) / 2 < s.M;
+      const bool one = sp / 2 < s.M;
+      float gg[V];
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        float up = 0.f;
+        if (one && a0[u][j] == (unsigned char)sp) up += d0[u][j];
+        if (two && a1[u][j] == (unsigned char)sp) up += d1[u][j];
+        const float xh = (xv[u][j] - mu[j]) * rs[j];
+        const float ypre = xh * w[j] + sh[j];
+        gg[j] = up * (ypre > 0.f ? 1.f : expf(ypre));
+        sg[j] += gg[j]; sgx[j] += (double)gg[j] * xh;
+      }
+      if (V == 4) *reinterpret_cast<float4*>(g + (long long)r * s.C + c) = *reinterpret_cast<const float4*>(gg);
+      else g[(long long)r * s.C + c] = gg[0];
+    }
+  }
+  if (part) {                                             // the workgroup's row streams combined through LDS, one partial per workgroup and column
+#pragma unroll
+    for (int j = 0; j < V; ++j) { sh_part[threadIdx.x][j] = sg[j]; sh_part[threadIdx.x][V + j] = sgx[j]; }
+    __syncthreads();
+    if (rsub == 0) {
+      for (int q = 1; q < rpw; ++q)
+#pragma unroll
+        for (int j = 0; j < V; ++j) { sg[j] += sh_part[q * tpr + threadIdx.x][j]; sgx[j] += sh_part[q * tpr + threadIdx.x][V + j]; }
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        part[((long long)blockIdx.y * 2 + 0) * s.C + c + j] = sg[j];
+        part[((long long)blockIdx.y * 2 + 1) * s.C + c + j] = sgx[j];
+      }
+    }
+    return;
   }
 #pragma unroll
   for (int j = 0; j < V; ++j) {
@@ -448,15 +506,16 @@ int mansy_launch_layernorm_bwd(const float* dy, const float* z, const float* mea
 
 int mansy_launch_distill_fwd(const float* conv, const float* bn_w, const float* bn_b, float* run_mean, float* run_var,
                              long long* num_batches, float* mean_out, float* rstd_out, float* mem, unsigned char* argmax,
-                             double* stats_d, const DistillShape& s, int train, float eps, float momentum, hipStream_t st) {
+                             double* stats_d, const DistillShape& s, int train, float eps, float momentum, hipStream_t st, double* part) {
   MANSY_REQUIRE(conv && bn_w && bn_b && run_mean && run_var && mean_out && rstd_out && mem && stats_d, "distill_fwd: null pointer");
   MANSY_REQUIRE(s.M == (s.S - 1) / 2 + 1, "distill_fwd: M must be floor((S-1)/2)+1");
   MANSY_REQUIRE(s.S <= 255, "distill_fwd: S too large");
   const int rows = s.B * s.S;
   if (train) {
     MANSY_HIP_CHECK(hipMemsetAsync(stats_d, 0, sizeof(double) * 6 * s.C, st));
-    dim3 grid(mansy_ceil_div(s.C, 256), min(rows, 512));
-    MANSY_LAUNCH(colstats_kernel, grid, dim3(256), 0, st, conv, rows, s.C, stats_d);
+    dim3 grid(mansy_ceil_div(s.C, 256), min(rows, MANSY_DISTILL_PARTS));
+    MANSY_LAUNCH(colstats_kernel, grid, dim3(256), 0, st, conv, rows, s.C, stats_d, part);
+    if (part) MANSY_LAUNCH(col_parts_reduce_kernel, dim3(mansy_ceil_div(2 * s.C, 256)), dim3(256), 0, st, part, (int)grid.y, 2 * s.C, stats_d);
     if (s.sync_world > 1) RC_HOOK(mansy_bn_sync_invoke(0, s.hook, s.hook_user));     // SyncBN: all-reduce [sum, sumsq] (2C doubles) over the data-parallel ranks
   }
   const int n_glob = rows * (train && s.sync_world > 1 ? s.sync_world : 1);
@@ -471,7 +530,7 @@ int mansy_launch_distill_fwd(const float* conv, const float* bn_w, const float* 
 
 int mansy_launch_distill_bwd(const float* conv, const float* dmem, const unsigned char* argmax, const float* bn_w,
                              const float* bn_b, const float* mean, const float* rstd, float* g_tmp, float* dconv, float* dbn_w,
-                             float* dbn_b, double* stats_d, const DistillShape& s, hipStream_t st) {
+                             float* dbn_b, double* stats_d, const DistillShape& s, hipStream_t st, double* part) {
   MANSY_REQUIRE(conv && dmem && argmax && bn_w && bn_b && mean && rstd && g_tmp && dconv && dbn_w && dbn_b && stats_d,
                 "distill_bwd: null pointer");
   const int rows = s.B * s.S;
@@ -480,11 +539,12 @@ int mansy_launch_distill_bwd(const float* conv, const float* dmem, const unsigne
   const int cv = s.C / 4;
   if (s.C % 4 == 0 && (cv % 256 == 0 || 256 % cv == 0) && al(conv) && al(dmem) && al(g_tmp) && (reinterpret_cast<uintptr_t>(argmax) & 3) == 0) {
     const int tpr = cv < 256 ? cv : 256;
-    dim3 grid1(mansy_ceil_div(cv, tpr), min(mansy_ceil_div(rows, 256 / tpr), 256));
-    MANSY_LAUNCH(distill_bwd_stage1<4>, grid1, dim3(256), 0, st, conv, dmem, argmax, bn_w, bn_b, mean, rstd, g_tmp, stats_d, s);
+    dim3 grid1(mansy_ceil_div(cv, tpr), min(mansy_ceil_div(rows, 4 * (256 / tpr)), MANSY_DISTILL_PARTS));
+    MANSY_LAUNCH(distill_bwd_stage1<4>, grid1, dim3(256), 0, st, conv, dmem, argmax, bn_w, bn_b, mean, rstd, g_tmp, stats_d, s, part);
+    if (part) MANSY_LAUNCH(col_parts_reduce_kernel, dim3(mansy_ceil_div(2 * s.C, 256)), dim3(256), 0, st, part, (int)grid1.y, 2 * s.C, stats_d + 2 * s.C);
   } else {
     dim3 grid1(mansy_ceil_div(s.C, 256), min(rows, 512));
-    MANSY_LAUNCH(distill_bwd_stage1<1>, grid1, dim3(256), 0, st, conv, dmem, argmax, bn_w, bn_b, mean, rstd, g_tmp, stats_d, s);
+    MANSY_LAUNCH(distill_bwd_stage1<1>, grid1, dim3(256), 0, st, conv, dmem, argmax, bn_w, bn_b, mean, rstd, g_tmp, stats_d, s, nullptr);
   }
   // parameter gradients use THIS rank's sums (the gradient all-reduce averages them); the input gradient needs the global ones
   MANSY_HIP_CHECK(hipMemcpyAsync(stats_d + 4 * s.C, stats_d + 2 * s.C, sizeof(double) * 2 * s.C, hipMemcpyDeviceToDevice, st));

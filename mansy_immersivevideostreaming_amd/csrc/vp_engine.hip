@@ -124,7 +124,7 @@ struct DecBuf {
 struct Work {
   float *src6, *cur6, *fut6, *pred_bt, *dpred_bt;           // train_step staging
   float *x0; EncBuf enc[MAXL]; float *enc_out, *me, *re;
-  float *col, *conv, *bn_mean, *bn_rstd, *mem; unsigned char* argmax; double* stats;
+  float *col, *conv, *bn_mean, *bn_rstd, *mem; unsigned char* argmax; double* stats; double* dis_part;
   float *tok_all, *emb_all; DecBuf dec[MAXL]; float *dec_out, *md, *rd;
   float *t_enc, *t_dec;                                     // GEMM-out temporaries
   float *g_a, *g_b, *g_c, *g_wide, *g_ff;                   // encoder backward temporaries [N, .]
@@ -170,6 +170,7 @@ void build_layout(const mansy_vp_config& c, Layout& L, Work& W) {
   W.mem = L.f("mem", B * M * d);
   W.argmax = (unsigned char*)L.add("dis.argmax", B * M * d);
   W.stats = (double*)L.add("dis.stats", 6 * d * sizeof(double));
+  W.dis_part = (double*)L.add("dis.part", (size_t)MANSY_DISTILL_PARTS * 2 * d * sizeof(double));      // per-workgroup partial column sums (norm.hip)
   W.tok_all = L.f("tok_all", (T + 1) * B * C6);
   W.emb_all = L.f("dec.emb", TB * d);
   for (int l = 0; l < c.n_dec; ++l) {
@@ -371,7 +372,7 @@ struct Eng {
     RC(lin_fwd(W.col, N, 3 * d, P.conv.w, P.conv.b, d, W.conv, 0, mansy_no_drop()));
     DistillShape ds = {B, S, M, d, c.bn_sync_world > 1 ? c.bn_sync_world : 1, c.bn_sync_fn, c.bn_sync_user};
     RC(mansy_launch_distill_fwd(W.conv, P.bn.w, P.bn.b, bn_rm, bn_rv, bn_nbt, W.bn_mean, W.bn_rstd, W.mem, W.argmax, W.stats, ds,
-                                train ? 1 : 0, c.bn_eps, c.bn_momentum, st));
+                                train ? 1 : 0, c.bn_eps, c.bn_momentum, st, W.dis_part));
     for (int l = 0; l < c.n_dec; ++l) {
       const DecLayerP& p = P.dec[l];
       RC(lin_fwd(W.mem, B * M, d, p.ca_in.w + (size_t)d * d, p.ca_in.b ? p.ca_in.b + d : nullptr, 2 * d, W.dec[l].memkv, 0, mansy_no_drop()));
@@ -620,7 +621,7 @@ struct Eng {
     // ---- DistillLayer
     DistillShape ds = {B, S, M, d, c.bn_sync_world > 1 ? c.bn_sync_world : 1, c.bn_sync_fn, c.bn_sync_user};
     RC(mansy_launch_distill_bwd(W.conv, W.dmem, W.argmax, P.bn.w, P.bn.b, W.bn_mean, W.bn_rstd, W.g_a, W.g_b, P.bn.gw, P.bn.gb, W.stats,
-                                ds, st));
+                                ds, st, W.dis_part));
     RC(lin_dw(W.g_b, W.col, N, d, 3 * d, P.conv.gw, P.conv.gb));
     RC(lin_dx(W.g_b, N, d, P.conv.w, 3 * d, W.g_wide, nullptr, nullptr, 1.f));
     RC(mansy_launch_col2im3(W.g_wide, W.g_a, B, S, d, st));
