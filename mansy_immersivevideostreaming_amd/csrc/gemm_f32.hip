@@ -824,8 +824,8 @@ int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B,
   // small accumulating weight-gradient product on the wave-split-K loop: the K-tiles are split inside the workgroup, so no split over workgroups
   // (every element of C then has ONE owner: a plain read-add-write instead of float atomics)
   const bool wsk_tn = dma && !bf && g_f32_wsk && g_f32_wsk_tn && tile == 64 && a_kmajor && b_kmajor && plain && ep.accumulate && !p.ep.tile_list &&
-                      tiles <= g_f32_wsk_max_tiles && ep.split_slab == 0 && K <= 2048;      // (long K: the split-K 64 x 64 loop fills the chip and wins --
-                                                                                              // [128, 1280]^T over K = 3264: 17.5 vs 20.6 us, profiles/r04_f32_wsk_ab.txt)
+                      tiles <= g_f32_wsk_max_tiles && ep.split_slab == 0;      // (any K: at K = 3264 the split-K 64 x 64 loop is 3 us faster WITHOUT the bias-gradient
+                                                                               // rider -- 17.5 vs 20.6 us -- but its rider adds (column tiles x splits)-way atomics per row)
   if (force_splitk > 0) splits = force_splitk;
   else if (wsk_tn) splits = 1;
   else if (plain && ep.accumulate && tiles < 256) {
