@@ -642,7 +642,7 @@ int mansy_launch_mtio_loss(const float* pred, const float* gt, long long n, floa
   MANSY_REQUIRE(pred && gt && loss_accum && loss_out, "mtio_loss: null pointer");
   MANSY_HIP_CHECK(hipMemsetAsync(loss_accum, 0, sizeof(double), st));
   if (n > 0) {
-    const int grid = min(mansy_ceil_div(n, 256), 1024);
+    const int grid = min(mansy_ceil_div(n, 256), 128);      // every workgroup ends with ONE double atomic on the same address: 128-way, not 1024-way (14 -> ~6 us)
     MANSY_LAUNCH(mtio_loss_kernel, dim3(grid), dim3(256), 0, st, pred, gt, n, inv_2bt, loss_accum, dpred);
   }
   MANSY_LAUNCH(mtio_loss_finish, dim3(1), dim3(1), 0, st, loss_accum, inv_2bt, loss_out);
