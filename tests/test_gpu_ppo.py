@@ -195,6 +195,43 @@ def test_ppo_minibatch_loss_grads_clip_adam_vs_oracle(M):
     assert (np.sign(delta[big]) == -np.sign(mm_[big])).all()
 
 
+def test_paired_launch_of_the_fc_weight_gradients_and_dF_is_bit_identical_to_two_launches(M):
+    """Round 4: the minibatch step's fc weight-gradient pair and its dF product are independent readers of dA1 and run as ONE launch
+    (gemm_f32_wsk_dual_kernel: the same two loop bodies on disjoint workgroup ranges of one grid; mansy_gemm_f32_wsk(8) / (9) = off / on).
+    Every gradient, the loss statistics and the identifier's training step (fc_bwd_single's pair) are bit-identical either way."""
+    from mansy_immersivevideostreaming_amd._lib import check, lib, ptr, stream_ptr
+    L = lib()
+    sd = po.make_policy_state_dict(int(Z['wseed']))
+    obs, act, adv, v_old, ret, g = _minibatch_data()
+    logp_old = torch.log_softmax(po.actor_logits(sd, obs), -1).gather(1, act[:, None])[:, 0] + 0.3 * torch.randn(len(obs), generator=g)
+    dev = 'cuda'
+    d = dict(obs=obs.to(dev), act=act.int().to(dev), adv=adv.to(dev), logp=logp_old.to(dev), v=v_old.to(dev), ret=ret.to(dev))
+    outs = {}
+    try:
+        for knob in (8, 9):
+            L.mansy_gemm_f32_wsk(knob)
+            pol = build_policy(M, sd)
+            eng, f, fi = pol.engine, pol.engine.ac, pol.engine.idn
+            stats = torch.zeros(4, device=dev)
+            arr, garr = f.pointers(grads=True)
+            check(L.mansy_ppo_minibatch_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(d['obs']), None,
+                                             ptr(d['act']), ptr(d['adv']), ptr(d['logp']), ptr(d['v']), ptr(d['ret']), len(obs), 0.2, 0.5, 0.02, 1, 1, 0.0,
+                                             0.0, 5e-4, 1e-2, 0, -1, 0, ptr(stats), ptr(eng.workspace()), eng.max_batch, 0, None, 0, -1, stream_ptr()), 'ppo_mb')
+            iloss = torch.zeros((), device=dev)
+            iarr, igarr = fi.pointers(grads=True)
+            check(L.mansy_identifier_train_step(iarr, igarr, ptr(fi.flat_p), ptr(fi.flat_g), ptr(fi.m), ptr(fi.v), fi.flat_p.numel(), ptr(d['obs']), None,
+                                                len(obs), 1e-4, 1e-2, -1, ptr(iloss), ptr(eng.workspace()), eng.max_batch, -1, stream_ptr()), 'ident')
+            outs[knob] = (f.flat_g.clone(), stats.clone(), fi.flat_g.clone(), iloss.clone())
+    finally:
+        L.mansy_gemm_f32_wsk(9)
+    assert float(outs[9][0].abs().max()) > 0 and float(outs[9][2].abs().max()) > 0
+    for a, b in zip(outs[8][:2], outs[9][:2]):
+        assert torch.equal(a, b)
+    # the identifier's dbbd / fc bias row sums are float atomics on the 64 x 64 loop for batches of this size: compare to rounding there
+    assert torch.equal(outs[8][3], outs[9][3])
+    assert (outs[8][2] - outs[9][2]).abs().max().item() <= 1e-6 * float(outs[9][2].abs().max())
+
+
 @pytest.mark.parametrize('flags', [dict(dual_clip=3.0), dict(dual_clip=1.5, value_clip=False), dict(norm_adv=False, dual_clip=2.0),
                                    dict(norm_adv=False, value_clip=False)])
 def test_ppo_minibatch_flag_combinations_incl_dual_clip_vs_oracle(M, flags):
