@@ -14,6 +14,7 @@
 //   * actor and critic share F inside a minibatch (the reference evaluates the shared FeatureNet twice);
 //   * 128->{15,1,3} output layers, residual add, softmax/sampling, PPO loss and its gradient are fused row-wise kernels.
 #include <algorithm>
+#include <cstdlib>
 #include <string>
 #include <vector>
 #include "mansy_kernels.h"
@@ -361,20 +362,28 @@ struct EnvFuse {
   mansy_env_episode_log elog;
 };
 struct HeadOutArgs { HeadOut h[2]; };
-__global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const float* __restrict__ A1pre, int nsplit, long long slab, int pre_ld,
+// MODE 0: every path by its run-time flag.  The two launches that make up most of a PPO cycle have their flags fixed at compile time, so that the
+// paths they never take -- and the scalar loads of their arguments -- are not in their instruction stream: MODE 1 = the rollout launch (one head, fc
+// slabs, sampling + environment step; no loss, no riders, no sigmoid), MODE 2 = the minibatch step (two heads, fc slabs, fused PPO loss + input-side
+// backward; no sampling, no environment, no riders).
+template <int MODE>
+__global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const float* __restrict__ A1pre, int nsplit_rt, long long slab, int pre_ld,
                                                        const float* __restrict__ F, int out_ld, int rows, const float* __restrict__ u_ext,
                                                        uint32_t seed, uint32_t site, LossFuse lf, EnvFuse ef) {
   const HeadOut& d = args.h[blockIdx.y];
   float* __restrict__ A1 = d.A1; const float* __restrict__ Wout = d.Wout; const float* __restrict__ bout = d.bout;
-  float* __restrict__ H = d.H; float* __restrict__ out = d.out; int* __restrict__ act = d.act; float* __restrict__ logp = d.logp;
-  const int n_out = d.n_out, sigmoid = d.sigmoid;
+  float* __restrict__ H = d.H; float* __restrict__ out = d.out; int* __restrict__ act = MODE == 2 ? nullptr : d.act; float* __restrict__ logp = d.logp;
+  const int n_out = d.n_out, sigmoid = MODE == 0 ? d.sigmoid : 0;
+  const int lf_on = MODE == 1 ? 0 : (MODE == 2 ? 1 : lf.on);
+  const bool env_on = MODE == 1 ? true : (MODE == 2 ? false : ef.on != 0);
+  const int nsplit = MODE == 0 ? nsplit_rt : max(nsplit_rt, 1);          // (modes 1 / 2 always sum slabs)
   const int lane = threadIdx.x & 63;
   const int row = (blockIdx.x * 256 + threadIdx.x) >> 6;
   if (row >= rows) return;
   // fused-loss operands (a gather through idx): requested first, ahead of this kernel's stores, so the two dependent round
   // trips overlap the slab sums
   int l_bi = 0, l_act = 0; float l_adv = 0.f, l_logp_old = 0.f, l_ret = 0.f, l_vold = 0.f, l_mean = 0.f, l_std = 1.f;
-  if (lf.on == 1) {
+  if (lf_on == 1) {
     l_bi = lf.idx ? lf.idx[row] : row;
     if (blockIdx.y == 0) { l_adv = lf.adv[l_bi]; l_act = lf.act[l_bi]; l_logp_old = lf.logp_old[l_bi]; l_mean = lf.adv_stats[0]; l_std = lf.adv_stats[1]; }
     else { l_ret = lf.ret[l_bi]; l_vold = lf.value_clip ? lf.v_old[l_bi] : 0.f; }
@@ -408,7 +417,7 @@ __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const f
   }
   const int erow = __builtin_amdgcn_readfirstlane(row);
   envdev::EnvRegs es = {};
-  if (ef.on && act) envdev::load_state(es, ef.st[erow], lane);
+  if (env_on && act) envdev::load_state(es, ef.st[erow], lane);
   if (nsplit > 0) {
 #pragma unroll
     for (int z = 0; z < MAX_SLABS; ++z) { a0 = z < nsplit ? a0 + p0[z] : a0; a1 = z < nsplit ? a1 + p1[z] : a1; }
@@ -416,7 +425,7 @@ __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const f
     A1[(size_t)row * HID + lane] = a0; A1[(size_t)row * HID + 64 + lane] = a1;
   }
   envdev::EnvPre eq = {};
-  if (ef.on && act) eq = envdev::env_step_requests(ef.T, es, lane);
+  if (env_on && act) eq = envdev::env_step_requests(ef.T, es, lane);
   const float h0 = a0 + f0;
   const float h1 = a1 + f1;
   if (H) { H[(size_t)row * HID + lane] = h0; H[(size_t)row * HID + 64 + lane] = h1; }
@@ -433,7 +442,7 @@ __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const f
     for (int k = 0; k < MAXOUT; ++k) if (k == lane) mine = o[k];
     out[(size_t)row * (d.out_ld ? d.out_ld : out_ld) + lane] = mine;
   }
-  if (d.act_given && row < d.n_given) {      // log pi(a | obs) of the given action (logp_kernel's arithmetic: max, sequential sum of exp, log)
+  if (MODE == 0 && d.act_given && row < d.n_given) {      // log pi(a | obs) of the given action (logp_kernel's arithmetic: max, sequential sum of exp, log)
     float m = -INFINITY;
 #pragma unroll
     for (int k = 0; k < NACT; ++k) m = fmaxf(m, o[k]);
@@ -446,7 +455,7 @@ __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const f
     for (int k = 0; k < NACT; ++k) if (k == a) oa = o[k];
     if (lane == 0) logp[row] = (oa - m) - logf(se);
   }
-  if (d.relabel_rew && lane == 0) {          // rew <- (1 - lamb) rew + lamb (1 - mean_k (pred_k - w_k)^2)   (mansy_ppo.py:43-48)
+  if (MODE == 0 && d.relabel_rew && lane == 0) {          // rew <- (1 - lamb) rew + lamb (1 - mean_k (pred_k - w_k)^2)   (mansy_ppo.py:43-48)
     float sq = 0.f;
 #pragma unroll
     for (int k = 0; k < 3; ++k) { const float dd = o[k] - d.relabel_obs[(size_t)row * OBS_LD + MANSY_O_QOE_W + k]; sq += dd * dd; }
@@ -457,7 +466,7 @@ __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const f
   float gk[MAXOUT];                // dL/d(output pre-activation) of this row and head (fused loss)
 #pragma unroll
   for (int k = 0; k < MAXOUT; ++k) gk[k] = 0.f;
-  if (lf.on == 1 && blockIdx.y == 0) {  // actor: clipped surrogate + entropy of this row, gradient wrt the logits (every lane computes the same scalars)
+  if (lf_on == 1 && blockIdx.y == 0) {  // actor: clipped surrogate + entropy of this row, gradient wrt the logits (every lane computes the same scalars)
     float adv = l_adv;
     if (lf.norm_adv) adv = (adv - l_mean) / (l_std + lf.adv_eps);
     float m = -INFINITY;
@@ -500,7 +509,7 @@ __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const f
     if (lane < MAXOUT) lf.dlogits[(size_t)row * MAXOUT + lane] = mine;       // column 15 (lane 15) is 0
     if (lane == 0) { lf.lossrows[4 * (size_t)row + 0] = -clip_term; lf.lossrows[4 * (size_t)row + 2] = ent; }
   }
-  if (lf.on == 1 && blockIdx.y == 1) {   // critic: (clipped) value loss of this row and its gradient (every lane computes the same scalars)
+  if (lf_on == 1 && blockIdx.y == 1) {   // critic: (clipped) value loss of this row and its gradient (every lane computes the same scalars)
     const float v = o[0], ret = l_ret;
     float dv, lv;
     if (lf.value_clip) {
@@ -514,7 +523,7 @@ __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const f
     gk[0] = lf.vf_coef * dv / (float)lf.n;
     if (lane == 0) { lf.dvalue[(size_t)row * lf.dvalue_ld] = gk[0]; lf.lossrows[4 * (size_t)row + 1] = lv; }
   }
-  if (lf.on == 2) {                 // identifier: MSE(sigmoid outputs, the observation's normalised QoE weights) of this row, gradient wrt the pre-sigmoid
+  if (lf_on == 2) {                 // identifier: MSE(sigmoid outputs, the observation's normalised QoE weights) of this row, gradient wrt the pre-sigmoid
     float sq = 0.f, mine = 0.f;      // (train_identifier, mansy_utils.py:20-31; ident_mse_kernel's arithmetic per element)
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -527,7 +536,7 @@ __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const f
     if (lane < MAXOUT) lf.dlogits[(size_t)row * MAXOUT + lane] = mine;
     if (lane == 0) lf.lossrows[4 * (size_t)row] = sq;
   }
-  if (lf.on && lf.bwd_dA1) {        // the output layer's input-side backward for this row (see LossFuse)
+  if (lf_on && lf.bwd_dA1) {        // the output layer's input-side backward for this row (see LossFuse)
     float d0 = 0.f, d1 = 0.f;
 #pragma unroll
     for (int k = 0; k < MAXOUT; ++k) {
@@ -559,7 +568,7 @@ __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const f
       for (int k = 0; k < MAXOUT; ++k) if (k == a) oa = o[k];
       if (logp) logp[row] = (oa - m) - logf(s);
     }
-    if (ef.on) envdev::env_step_finish(ef.T, ef.st, erow, lane, a, es, eq, ef.obs_next, ef.obs_cur, ef.reward, ef.done, ef.qoe_parts, ef.elog);
+    if (env_on) envdev::env_step_finish(ef.T, ef.st, erow, lane, a, es, eq, ef.obs_next, ef.obs_cur, ef.reward, ef.done, ef.qoe_parts, ef.elog);
   }
 }
 
@@ -987,6 +996,12 @@ size_t ppo_layout(int maxB, char* base, PWork& W) {
 
 #define RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
+// A/B switch, read once: MANSY_HEAD_OUT_GENERIC=1 runs every output-layer launch on the generic instance of head_out_kernel (tools/ppo_cycle_ab.py)
+static bool head_out_modes() {
+  static const bool on = !(getenv("MANSY_HEAD_OUT_GENERIC") && getenv("MANSY_HEAD_OUT_GENERIC")[0] == '1');
+  return on;
+}
+
 struct PEng {
   hipStream_t st; PWork W;
   int prec = 0;      // MANSY_PREC_* of this call's products (the entry point's `precision` argument)
@@ -1059,8 +1074,11 @@ struct PEng {
     if (fuse) none = *fuse;
     EnvFuse ef; memset(&ef, 0, sizeof(ef));
     if (env) ef = *env;
-    MANSY_LAUNCH(head_out_kernel, dim3(mansy_ceil_div(B, 4), 1), dim3(256), 0, st, ha, W.A1s, nsplit, (long long)B * HID, HID, W.F, MAXOUT, B, u,
-                       seed, site, none, ef);
+    // the rollout launch has its own instance of the kernel (MODE 1)
+    if (head_out_modes() && env && ef.on && act && nsplit > 0 && !sigmoid && !rd && !fuse)
+      MANSY_LAUNCH(head_out_kernel<1>, dim3(mansy_ceil_div(B, 4), 1), dim3(256), 0, st, ha, W.A1s, nsplit, (long long)B * HID, HID, W.F, MAXOUT, B, u, seed, site, none, ef);
+    else
+      MANSY_LAUNCH(head_out_kernel<0>, dim3(mansy_ceil_div(B, 4), 1), dim3(256), 0, st, ha, W.A1s, nsplit, (long long)B * HID, HID, W.F, MAXOUT, B, u, seed, site, none, ef);
     MANSY_LAUNCH_CHECK();
     return MANSY_OK;
   }
@@ -1079,8 +1097,11 @@ struct PEng {
     LossFuse lf; memset(&lf, 0, sizeof(lf));
     if (fuse) lf = *fuse;
     EnvFuse noenv; memset(&noenv, 0, sizeof(noenv));
-    MANSY_LAUNCH(head_out_kernel, dim3(mansy_ceil_div(B, 4), 2), dim3(256), 0, st, ha, W.A1s, nsplit, (long long)B * 2 * HID, 2 * HID, W.F, MAXOUT,
-                       B, nullptr, 0u, 0u, lf, noenv);
+    // the minibatch step's launch has its own instance of the kernel (MODE 2)
+    if (head_out_modes() && fuse && lf.on == 1 && !rd)
+      MANSY_LAUNCH(head_out_kernel<2>, dim3(mansy_ceil_div(B, 4), 2), dim3(256), 0, st, ha, W.A1s, nsplit, (long long)B * 2 * HID, 2 * HID, W.F, MAXOUT, B, nullptr, 0u, 0u, lf, noenv);
+    else
+      MANSY_LAUNCH(head_out_kernel<0>, dim3(mansy_ceil_div(B, 4), 2), dim3(256), 0, st, ha, W.A1s, nsplit, (long long)B * 2 * HID, 2 * HID, W.F, MAXOUT, B, nullptr, 0u, 0u, lf, noenv);
     MANSY_LAUNCH_CHECK();
     return MANSY_OK;
   }
