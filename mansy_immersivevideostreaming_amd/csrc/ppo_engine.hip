@@ -365,18 +365,19 @@ struct HeadOutArgs { HeadOut h[2]; };
 // MODE 0: every path by its run-time flag.  The two launches that make up most of a PPO cycle have their flags fixed at compile time, so that the
 // paths they never take -- and the scalar loads of their arguments -- are not in their instruction stream: MODE 1 = the rollout launch (one head, fc
 // slabs, sampling + environment step; no loss, no riders, no sigmoid), MODE 2 = the minibatch step (two heads, fc slabs, fused PPO loss + input-side
-// backward; no sampling, no environment, no riders).
+// backward; no sampling, no environment, no riders), MODE 3 = forward-only launches (process_fn's evaluation pass over 2 x 4096 rows, the identifier's
+// validation / relabel passes: no loss, no sampling, no environment; the log-probability / relabel riders and the sigmoid stay run-time flags).
 template <int MODE>
 __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const float* __restrict__ A1pre, int nsplit_rt, long long slab, int pre_ld,
                                                        const float* __restrict__ F, int out_ld, int rows, const float* __restrict__ u_ext,
                                                        uint32_t seed, uint32_t site, LossFuse lf, EnvFuse ef) {
   const HeadOut& d = args.h[blockIdx.y];
   float* __restrict__ A1 = d.A1; const float* __restrict__ Wout = d.Wout; const float* __restrict__ bout = d.bout;
-  float* __restrict__ H = d.H; float* __restrict__ out = d.out; int* __restrict__ act = MODE == 2 ? nullptr : d.act; float* __restrict__ logp = d.logp;
-  const int n_out = d.n_out, sigmoid = MODE == 0 ? d.sigmoid : 0;
-  const int lf_on = MODE == 1 ? 0 : (MODE == 2 ? 1 : lf.on);
-  const bool env_on = MODE == 1 ? true : (MODE == 2 ? false : ef.on != 0);
-  const int nsplit = MODE == 0 ? nsplit_rt : max(nsplit_rt, 1);          // (modes 1 / 2 always sum slabs)
+  float* __restrict__ H = d.H; float* __restrict__ out = d.out; int* __restrict__ act = (MODE == 2 || MODE == 3) ? nullptr : d.act; float* __restrict__ logp = d.logp;
+  const int n_out = d.n_out, sigmoid = (MODE == 0 || MODE == 3) ? d.sigmoid : 0;
+  const int lf_on = (MODE == 1 || MODE == 3) ? 0 : (MODE == 2 ? 1 : lf.on);
+  const bool env_on = MODE == 1 ? true : ((MODE == 2 || MODE == 3) ? false : ef.on != 0);
+  const int nsplit = (MODE == 0 || MODE == 3) ? nsplit_rt : max(nsplit_rt, 1);          // (modes 1 / 2 always sum slabs)
   const int lane = threadIdx.x & 63;
   const int row = (blockIdx.x * 256 + threadIdx.x) >> 6;
   if (row >= rows) return;
@@ -442,7 +443,7 @@ __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const f
     for (int k = 0; k < MAXOUT; ++k) if (k == lane) mine = o[k];
     out[(size_t)row * (d.out_ld ? d.out_ld : out_ld) + lane] = mine;
   }
-  if (MODE == 0 && d.act_given && row < d.n_given) {      // log pi(a | obs) of the given action (logp_kernel's arithmetic: max, sequential sum of exp, log)
+  if ((MODE == 0 || MODE == 3) && d.act_given && row < d.n_given) {      // log pi(a | obs) of the given action (logp_kernel's arithmetic: max, sequential sum of exp, log)
     float m = -INFINITY;
 #pragma unroll
     for (int k = 0; k < NACT; ++k) m = fmaxf(m, o[k]);
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const f
     for (int k = 0; k < NACT; ++k) if (k == a) oa = o[k];
     if (lane == 0) logp[row] = (oa - m) - logf(se);
   }
-  if (MODE == 0 && d.relabel_rew && lane == 0) {          // rew <- (1 - lamb) rew + lamb (1 - mean_k (pred_k - w_k)^2)   (mansy_ppo.py:43-48)
+  if ((MODE == 0 || MODE == 3) && d.relabel_rew && lane == 0) {          // rew <- (1 - lamb) rew + lamb (1 - mean_k (pred_k - w_k)^2)   (mansy_ppo.py:43-48)
     float sq = 0.f;
 #pragma unroll
     for (int k = 0; k < 3; ++k) { const float dd = o[k] - d.relabel_obs[(size_t)row * OBS_LD + MANSY_O_QOE_W + k]; sq += dd * dd; }
@@ -1077,6 +1078,8 @@ struct PEng {
     // the rollout launch has its own instance of the kernel (MODE 1)
     if (head_out_modes() && env && ef.on && act && nsplit > 0 && !sigmoid && !rd && !fuse)
       MANSY_LAUNCH(head_out_kernel<1>, dim3(mansy_ceil_div(B, 4), 1), dim3(256), 0, st, ha, W.A1s, nsplit, (long long)B * HID, HID, W.F, MAXOUT, B, u, seed, site, none, ef);
+    else if (head_out_modes() && !env && !act && !fuse)      // forward only (+ riders): MODE 3
+      MANSY_LAUNCH(head_out_kernel<3>, dim3(mansy_ceil_div(B, 4), 1), dim3(256), 0, st, ha, W.A1s, nsplit, (long long)B * HID, HID, W.F, MAXOUT, B, u, seed, site, none, ef);
     else
       MANSY_LAUNCH(head_out_kernel<0>, dim3(mansy_ceil_div(B, 4), 1), dim3(256), 0, st, ha, W.A1s, nsplit, (long long)B * HID, HID, W.F, MAXOUT, B, u, seed, site, none, ef);
     MANSY_LAUNCH_CHECK();
@@ -1100,6 +1103,8 @@ struct PEng {
     // the minibatch step's launch has its own instance of the kernel (MODE 2)
     if (head_out_modes() && fuse && lf.on == 1 && !rd)
       MANSY_LAUNCH(head_out_kernel<2>, dim3(mansy_ceil_div(B, 4), 2), dim3(256), 0, st, ha, W.A1s, nsplit, (long long)B * 2 * HID, 2 * HID, W.F, MAXOUT, B, nullptr, 0u, 0u, lf, noenv);
+    else if (head_out_modes() && !fuse)                       // forward only (+ the log-probability rider): MODE 3
+      MANSY_LAUNCH(head_out_kernel<3>, dim3(mansy_ceil_div(B, 4), 2), dim3(256), 0, st, ha, W.A1s, nsplit, (long long)B * 2 * HID, 2 * HID, W.F, MAXOUT, B, nullptr, 0u, 0u, lf, noenv);
     else
       MANSY_LAUNCH(head_out_kernel<0>, dim3(mansy_ceil_div(B, 4), 2), dim3(256), 0, st, ha, W.A1s, nsplit, (long long)B * 2 * HID, 2 * HID, W.F, MAXOUT, B, nullptr, 0u, 0u, lf, noenv);
     MANSY_LAUNCH_CHECK();
