@@ -535,6 +535,15 @@ class PPOPolicy(nn.Module):
                 off += len(chunk)
         stats_all = [torch.empty(len(chunks), 4, dtype=torch.float32, device=dev) for chunks in passes]
         recompute = self._recompute_adv and repeat > 1
+        # everything that does not change from step to step is converted for ctypes ONCE: the cycle is a chain of ~8 us launches and this loop's
+        # host time per step (pointer tables of 28 tensors, ~35 argument conversions) must stay below the step's GPU time (tools/ppo_host_enqueue_probe.py)
+        step_fn = lib().mansy_ppo_minibatch_step
+        arr, garr = f.pointers(grads=True)
+        fixed_head = (arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(data['obs']))
+        fixed_mid = (ptr(data['act']), ptr(data['adv']), ptr(data['logp_old']), ptr(data['v_s']), ptr(data['returns']))
+        hyper = (self._eps_clip, self._weight_vf, self._weight_ent, int(self._norm_adv), int(self._value_clip), float(self._dual_clip or 0.0),
+                 0.0 if dp else float(self._grad_norm or 0.0), lr, wd)
+        ws_ptr, st_ptr = ptr(eng.workspace()), stream_ptr(dev)
         for s, (pi, k, idx) in enumerate(flat):
             first_of_later_pass = recompute and pi > 0 and k == 0
             if first_of_later_pass:
@@ -542,14 +551,10 @@ class PPOPolicy(nn.Module):
             f.step += 1
             last_of_pass = s + 1 < len(flat) and flat[s + 1][0] != pi
             nxt = flat[s + 1][2] if (chain and s + 1 < len(flat) and not (recompute and last_of_pass)) else None
-            arr, garr = f.pointers(grads=True)
-            check(lib().mansy_ppo_minibatch_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(data['obs']),
-                                                 ptr(idx), ptr(data['act']), ptr(data['adv']), ptr(data['logp_old']), ptr(data['v_s']),
-                                                 ptr(data['returns']), idx.numel(), self._eps_clip, self._weight_vf, self._weight_ent,
-                                                 int(self._norm_adv), int(self._value_clip), float(self._dual_clip or 0.0), 0.0 if dp else float(self._grad_norm or 0.0), lr, wd,
-                                                 0 if dp else f.step, *f.tail(), ptr(stats_all[pi][k]), ptr(eng.workspace()), eng.max_batch,
-                                                 int(chain and s > 0 and not first_of_later_pass), ptr(None if dp else nxt), nxt.numel() if (nxt is not None and not dp) else 0, eng.prec,
-                                                 stream_ptr(dev)),
+            # (_recompute_returns rewrites data['v_s'] / ['returns'] / ['adv'] IN PLACE: the pointers converted above still hold)
+            check(step_fn(*fixed_head, ptr(idx), *fixed_mid, idx.numel(), *hyper, 0 if dp else f.step, *f.tail(), ptr(stats_all[pi][k]), ws_ptr, eng.max_batch,
+                          int(chain and s > 0 and not first_of_later_pass), ptr(None if dp else nxt), nxt.numel() if (nxt is not None and not dp) else 0, eng.prec,
+                          st_ptr),
                   'mansy_ppo_minibatch_step')
             if dp:                              # raw local gradients -> average over the ranks -> global-norm clip + Adam (+ next prologue)
                 self._sync_clip_adam(f, float(self._grad_norm or 0.0), lr, wd, tail=(data, nxt) if chain else None)

@@ -1218,7 +1218,7 @@ struct PEng {
   int step_tail(const float* const* params, float* flat_p, float* flat_g, float* m, float* v, long long n, float max_norm, float lr, float wd, int step,
                 double* parts_cur, double* parts_next, const float* obs_all, const int* next_idx, int next_mb, const float* adv_all) {
     TailTab tab;
-    const std::vector<ParamInfo> t = net_table(0);
+    static const std::vector<ParamInfo> t = net_table(0);       // (built once: 28 entries with std::string names -- this runs in every minibatch step)
     MANSY_REQUIRE(t.size() == 28, "step_tail: parameter table changed");
     for (int k = 0; k < 28; ++k) {
       tab.off[k] = params[k] - flat_p; tab.numel[k] = (int)t[k].numel;
