@@ -611,7 +611,7 @@ def main():
 
     # ---- the same step in the split-bf16 precision modes (secondary lines; every rank runs them: collectives inside)
     modes = []
-    for mode, nprod in (('bf16x3', 3), ('bf16x6', 6)):
+    for mode, nprod in (('bf16x3', 3), ('bf16x6', 6), ('bf16', 1)):      # bf16: ONE product (a perf mode: errors ~1e-3, the class of the reference's TF32 setting)
         model.precision = mode
         model.two_stream = None
         for _ in range(2):

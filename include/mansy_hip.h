@@ -40,6 +40,8 @@ int mansy_abi_version(void);
  * no process-wide state (ABI 7).  MANSY_PREC_DEFAULT (-1) = the value of the deprecated process-wide setter below (fp32 unless set). */
 #define MANSY_PREC_DEFAULT (-1)
 #define MANSY_PREC_F32 0
+#define MANSY_PREC_BF16 1      /* plain bf16: ONE bf16 MFMA product per fp32 product, fp32 accumulate (errors ~1e-3 of the operands' scale: the class of the
+                                * reference's own GPU setting, torch.set_float32_matmul_precision('high'); a perf mode, never the parity mode) */
 #define MANSY_PREC_BF16X3 3
 #define MANSY_PREC_BF16X6 6
 

@@ -201,22 +201,22 @@ def stream_ptr(device=None):
 
 
 # ---- precision mode of the dense products (mansy_set_gemm_precision)
-PRECISIONS = {'f32': 0, 'fp32': 0, 'bf16x3': 3, 'bf16x6': 6, 0: 0, 3: 3, 6: 6}
+PRECISIONS = {'f32': 0, 'fp32': 0, 'bf16': 1, 'bf16x3': 3, 'bf16x6': 6, 0: 0, 1: 1, 3: 3, 6: 6}
 
 
 def set_precision(mode):
     """Process-wide precision mode of the dense products (mansy_set_gemm_precision): 'f32' (exact fp32 MFMA, default),
     'bf16x3' or 'bf16x6' (split-bf16 MFMA).  Returns the previous mode as a name."""
     if mode not in PRECISIONS:
-        raise MansyError(f'unknown precision {mode!r}: one of f32, bf16x3, bf16x6')
+        raise MansyError(f'unknown precision {mode!r}: one of f32, bf16, bf16x3, bf16x6')
     prev = lib().mansy_set_gemm_precision(PRECISIONS[mode])
     if prev < 0:
         check(prev, 'mansy_set_gemm_precision')
-    return {0: 'f32', 3: 'bf16x3', 6: 'bf16x6'}[prev]
+    return {0: 'f32', 1: 'bf16', 3: 'bf16x3', 6: 'bf16x6'}[prev]
 
 
 def get_precision():
-    return {0: 'f32', 3: 'bf16x3', 6: 'bf16x6'}[lib().mansy_get_gemm_precision()]
+    return {0: 'f32', 1: 'bf16', 3: 'bf16x3', 6: 'bf16x6'}[lib().mansy_get_gemm_precision()]
 
 
 class precision:

@@ -124,7 +124,7 @@ def test(args, config, policy, qoe_weights, identifier, models_dir, results_dir)
 
 def run(args, config):
     if getattr(args, 'precision', 'f32') not in _lib.PRECISIONS:
-        raise _lib.MansyError(f'unknown --precision {args.precision!r}: one of f32, bf16x3, bf16x6')
+        raise _lib.MansyError(f'unknown --precision {args.precision!r}: one of f32, bf16, bf16x3, bf16x6')
     np.random.seed(args.seed)
     torch.manual_seed(args.seed)
     torch.cuda.manual_seed_all(args.seed)
@@ -204,7 +204,7 @@ _FLAGS = [
     ('--bc-identifier-max-steps', int, 150), ('--init-from-bc', _T, _F),
     # additions of this build
     ('--config', str, None), ('--test-envs', int, 256), ('--verbose-table', _T, _F),
-    # precision of the dense products: f32 (exact fp32 MFMA, the parity mode) | bf16x3 | bf16x6 (split-bf16 MFMA; BASELINE configs[4])
+    # precision of the dense products: f32 (exact fp32 MFMA, the parity mode) | bf16x3 | bf16x6 (split-bf16 MFMA; BASELINE configs[4]) | bf16 (one product: perf mode)
     ('--precision', str, 'f32'),
 ]
 

@@ -41,7 +41,7 @@ int mansy_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ld
     e.resid = ep->resid; e.resid_ld = ep->resid_ld; e.accumulate = ep->accumulate;
     e.a_rowsum = ep->a_rowsum; e.prec = ep->prec;
     MANSY_REQUIRE(!ep->a_rowsum || a_kmajor, "gemm: a_rowsum rides on a K-major A (dW = dY^T X)");
-    MANSY_REQUIRE(ep->prec < 0 || ep->prec == 0 || ep->prec == 3 || ep->prec == 6, "gemm: prec must be < 0, 0, 3 or 6");
+    MANSY_REQUIRE(ep->prec < 0 || ep->prec == 0 || ep->prec == 1 || ep->prec == 3 || ep->prec == 6, "gemm: prec must be < 0, 0, 1, 3 or 6");
   }
   MANSY_REQUIRE(force_tile == 0 || force_tile == 64 || force_tile == 96 || force_tile == 128 || force_tile == -64 || force_tile == -128,
                 "gemm: force_tile must be 0, 64, 96 (128x64), 128, or -64 / -128 (register-staged loop)");

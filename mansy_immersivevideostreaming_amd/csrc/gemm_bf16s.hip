@@ -84,13 +84,16 @@ __device__ __forceinline__ void split_store(__bf16* __restrict__ dst, int plane_
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const __bf16 t0 = (__bf16)v[e];
-    const float r1 = v[e] - (float)t0;
-    const __bf16 t1 = (__bf16)r1;
-    p0[e] = t0; p1[e] = t1;
-    if (NP == 3) { const float r2 = r1 - (float)t1; p2[e] = (__bf16)r2; }
+    p0[e] = t0;
+    if (NP >= 2) {
+      const float r1 = v[e] - (float)t0;
+      const __bf16 t1 = (__bf16)r1;
+      p1[e] = t1;
+      if (NP == 3) { const float r2 = r1 - (float)t1; p2[e] = (__bf16)r2; }
+    }
   }
   *reinterpret_cast<bf16x8*>(dst) = p0;
-  *reinterpret_cast<bf16x8*>(dst + plane_elems) = p1;
+  if (NP >= 2) *reinterpret_cast<bf16x8*>(dst + plane_elems) = p1;
   if (NP == 3) *reinterpret_cast<bf16x8*>(dst + 2 * plane_elems) = p2;
 }
 
@@ -201,13 +204,15 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16s_kernel(GemmParams p) {
       for (int j = 0; j < TN; ++j) {
         // small terms first: they are added to each other before they meet the large partial sum of a0 b0
         if (NP == 3) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][NP - 1], bf[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][NP - 1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][NP >= 2 ? 1 : 0], bf[j][NP >= 2 ? 1 : 0], acc[i][j], 0, 0, 0);
         }
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+        if (NP >= 2) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][NP >= 2 ? 1 : 0], bf[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][NP >= 2 ? 1 : 0], acc[i][j], 0, 0, 0);
+        }
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);      // (NP == 1, plain bf16: this product alone)
       }
   };
 
@@ -236,7 +241,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16s_kernel(GemmParams p) {
       stage_load<BN, BKM>(cb, p.ldb, offb, vb);
 #if MANSY_BF16S_SCHED
 #pragma unroll
-      for (int g = 0; g < 2 * TM * TN * (NP == 3 ? 6 : 3); ++g) {
+      for (int g = 0; g < 2 * TM * TN * (NP == 3 ? 6 : (NP == 2 ? 3 : 1)); ++g) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
         __builtin_amdgcn_sched_group_barrier(0x002, NP == 3 ? 4 : 4, 0);   // a few split VALU ops in its shadow
       }
@@ -1138,11 +1143,15 @@ int launch_layouts(const GemmParams& p, int a_kmajor, int b_kmajor, int splits, 
 
 }  // namespace
 
-// tile: 128 -> 128x128, anything else -> 64x64; prec: 3 (bf16x3) or 6 (bf16x6).  Preconditions as the LDS-DMA loop's.
+// tile: 128 -> 128x128, anything else -> 64x64; prec: 1 (plain bf16), 3 (bf16x3) or 6 (bf16x6).  Preconditions as the LDS-DMA loop's.
 // bf16x3 runs the two-stage loop (64 KB of planes, two workgroups per CU); bf16x6: 128 x 128 tiles on the half-K-tile two-stage
 // loop (48 KB), 64 x 64 tiles on the one-stage loop (two 32-k stages of three planes are 96 KB, i.e. one workgroup per CU, and
 // measured 10-20 % slower than one stage with two).
 int mansy_gemm_bf16s_dispatch(const GemmParams& p, int tile, int prec, int a_kmajor, int b_kmajor, int splits, hipStream_t st) {
+  if (prec == 1) {         // plain bf16 (MANSY_PREC_BF16): one plane per operand, one product -- the two-stage loop with half the LDS of bf16x3
+    if (tile == 128) return launch_layouts<128, 128, 1, true>(p, a_kmajor, b_kmajor, splits, st);
+    return launch_layouts<64, 64, 1, true>(p, a_kmajor, b_kmajor, splits, st);
+  }
   if (prec == 3) {
     if (tile == 128) return launch_layouts<128, 128, 2, true>(p, a_kmajor, b_kmajor, splits, st);
     return launch_layouts<64, 64, 2, true>(p, a_kmajor, b_kmajor, splits, st);

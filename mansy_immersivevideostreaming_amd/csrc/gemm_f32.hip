@@ -599,7 +599,7 @@ int g_gemm_prec = 0;   // process-wide default precision of the dense products: 
 // was captured in).  0: exact fp32 on v_mfma_f32_32x32x2_f32 (default); 3 / 6: split-bf16 products (gemm_bf16s.hip).
 // Products the split loop does not cover (K % 32 != 0, unaligned operands) stay fp32 in every mode.  Returns the previous mode.
 extern "C" int mansy_set_gemm_precision(int mode) {
-  if (mode != 0 && mode != 3 && mode != 6) { mansy_set_error("gemm precision must be 0 (fp32), 3 (bf16x3) or 6 (bf16x6), got %d", mode); return MANSY_EINVAL; }
+  if (mode != 0 && mode != 1 && mode != 3 && mode != 6) { mansy_set_error("gemm precision must be 0 (fp32), 1 (bf16), 3 (bf16x3) or 6 (bf16x6), got %d", mode); return MANSY_EINVAL; }
   const int prev = g_gemm_prec;
   g_gemm_prec = mode;
   return prev;

@@ -1271,7 +1271,7 @@ struct PEng {
 };
 
 int setup(void* ws, int maxB, int precision, hipStream_t st, PEng& e) {
-  MANSY_REQUIRE(precision < 0 || precision == 0 || precision == 3 || precision == 6, "precision must be MANSY_PREC_DEFAULT (-1), 0, 3 or 6 (got %d)", precision);
+  MANSY_REQUIRE(precision < 0 || precision == 0 || precision == 1 || precision == 3 || precision == 6, "precision must be MANSY_PREC_DEFAULT (-1), 0, 1, 3 or 6 (got %d)", precision);
   e.prec = precision >= 0 ? precision : mansy_get_gemm_precision();
   MANSY_REQUIRE(ws && maxB >= 1, "ppo: bad workspace / batch");
   e.st = st;

@@ -222,7 +222,7 @@ int check_cfg(const mansy_vp_config* c) {
   MANSY_REQUIRE(c->in_ch >= 1 && c->in_ch <= 8 && c->in_ch % 3 == 0, "vp: in_ch must be 3*in_channel <= 8");
   MANSY_REQUIRE(c->max_len >= c->S && c->max_len >= c->T, "vp: positional table too short");
   MANSY_REQUIRE(c->p_pe >= 0.f && c->p_pe < 1.f && c->p_drop >= 0.f && c->p_drop < 1.f, "vp: dropout p outside [0,1)");
-  MANSY_REQUIRE(c->precision < 0 || c->precision == 0 || c->precision == 3 || c->precision == 6, "vp: precision must be MANSY_PREC_DEFAULT (-1), 0, 3 or 6 (got %d)", c->precision);
+  MANSY_REQUIRE(c->precision < 0 || c->precision == 0 || c->precision == 1 || c->precision == 3 || c->precision == 6, "vp: precision must be MANSY_PREC_DEFAULT (-1), 0, 1, 3 or 6 (got %d)", c->precision);
   return MANSY_OK;
 }
 

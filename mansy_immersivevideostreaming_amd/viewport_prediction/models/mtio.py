@@ -114,7 +114,7 @@ class ViewportTransformerMTIO(nn.Module):
         # stretch each other's durations.
         two = True if self.two_stream is None else bool(self.two_stream)
         if self.precision is not None and self.precision not in _lib.PRECISIONS:
-            raise _lib.MansyError(f'unknown precision {self.precision!r}: one of f32, bf16x3, bf16x6')
+            raise _lib.MansyError(f'unknown precision {self.precision!r}: one of f32, bf16, bf16x3, bf16x6')
         cfg = VPConfig(B=B, S=S, T=self.fut_window, d_model=self.d_model, n_head=_N_HEAD, d_ff=self.dim_feedforward,
                        n_enc=self.num_encoder_layers, n_dec=self.num_decoder_layers, in_ch=self.in_channel * self.num_head,
                        has_bias=int(self.has_bias), p_pe=self.dropout_p, p_drop=self.attn_dropout_p, ln_eps=1e-5, bn_eps=1e-5,

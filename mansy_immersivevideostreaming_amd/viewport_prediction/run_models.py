@@ -38,7 +38,7 @@ _FLAGS = [
     ('--bs', dict(type=int)), ('--seed', dict(type=int, default=5)),
     ('--config', dict(type=str, default=None)), ('--verbose-steps', dict(action='store_true')),
     # addition of this build: precision of the dense products (f32 = exact fp32 MFMA, the parity mode; bf16x3 / bf16x6 = split-bf16 MFMA)
-    ('--precision', dict(choices=('f32', 'bf16x3', 'bf16x6'), default='f32')),
+    ('--precision', dict(choices=('f32', 'bf16', 'bf16x3', 'bf16x6'), default='f32')),
 ]
 _CONFIG_DEFAULTS = {'trim_head': 'trim_head', 'trim_tail': 'trim_tail', 'dataset_frequency': 'frequency', 'sample_step': 'sample_step'}
 

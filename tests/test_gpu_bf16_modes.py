@@ -331,6 +331,61 @@ def test_vp_fused_train_step_tracks_fp32_at_bench_width(K, mode):
     np.testing.assert_allclose(curves[mode], curves['f32'], rtol={'bf16x6': 2e-3, 'bf16x3': 1e-2}[mode])
 
 
+# ------------------------------------------------------------------ plain bf16 (MANSY_PREC_BF16 = 1): one product, a perf mode
+@pytest.mark.parametrize('akm,bkm', [(0, 0), (0, 1), (1, 1), (1, 0)])
+def test_plain_bf16_product_all_layouts(K, akm, bkm):
+    """precision 'bf16' (round 4): ONE bf16 MFMA product per fp32 product, operands rounded to bf16 on their way into LDS, fp32 accumulate --
+    the class of the reference's own GPU setting (torch.set_float32_matmul_precision('high'), run_models.py:135).  Against float64 within the
+    bf16 rounding bound (2^-9 per operand: ~1e-3 of max |C| on N(0,1) operands), clearly looser than bf16x3 (so the mode is really a
+    different arithmetic), every layout / tile / ragged shape, fused epilogue included."""
+    g = torch.Generator().manual_seed(3)
+    worst = 0.0
+    for M, N, Kd in SHAPES:
+        if (akm and M % 4) or (bkm and N % 4):
+            continue
+        A = torch.randn((Kd, M) if akm else (M, Kd), generator=g).cuda()
+        B = torch.randn((Kd, N) if bkm else (N, Kd), generator=g).cuda()
+        ref = (A.double().t() if akm else A.double()) @ (B.double() if bkm else B.double().t())
+        for tile in (0, 64, 128):
+            with K.precision('bf16'):
+                C = K.gemm(A, B, bool(akm), bool(bkm), force_tile=tile)
+            err = ((C.double() - ref).abs().max() / ref.abs().max()).item()
+            assert err < 6e-3, (akm, bkm, M, N, Kd, tile, err)
+            worst = max(worst, err)
+    assert worst > 10 * GEMM_TOL['bf16x3']
+    if not akm and not bkm:
+        A = torch.randn(300, 256, generator=g).cuda(); W = torch.randn(132, 256, generator=g).cuda()
+        bias, R = torch.randn(132, generator=g).cuda(), torch.randn(300, 132, generator=g).cuda()
+        with K.precision('bf16'):
+            C = K.gemm(A, W, bias=bias, relu=True, resid=R)
+        want = torch.relu(A.double() @ W.double().t() + bias.double().cuda()) + R.double()
+        assert (C.double() - want).abs().max().item() < 6e-3 * (A.double() @ W.double().t()).abs().max().item()
+
+
+def test_plain_bf16_vp_train_step_and_sample_track_fp32(K):
+    """The VP model in precision 'bf16': the fused train step's loss trajectory stays within a few per cent of the fp32 one (d = 512, dropout
+    on, same seeds) and sample() stays within 2e-2 of the fp32 predictions -- a perf mode, held to a perf mode's bar."""
+    from mansy_immersivevideostreaming_amd.viewport_prediction.models import mtio
+    h, c, f = (t.cuda() for t in vo.synthetic_trajectories(256, 10, 10, seed=3))
+    curves, preds = {}, {}
+    for md in ('f32', 'bf16'):
+        torch.manual_seed(0); random.seed(0); np.random.seed(0)
+        m = mtio.ViewportTransformerMTIO(in_channel=2, fut_window=10, d_model=512, dim_feedforward=512, device='cuda', seed=1)
+        m.load_state_dict(vo.make_state_dict(512, 3, bias=True))
+        m = m.to('cuda').train()
+        m.precision = md
+        opt = mtio.FusedAdamW(m, lr=1e-4)
+        curves[md] = [m.train_step(h, c, f, opt).item() for _ in range(6)]
+        m.eval()
+        preds[md] = m.sample(h, c).cpu()
+    assert curves['bf16'][0] != curves['f32'][0]
+    np.testing.assert_allclose(curves['bf16'], curves['f32'], rtol=5e-2)
+    assert all(np.isfinite(curves['bf16'])) and curves['bf16'][-1] < curves['bf16'][0]
+    d = (preds['bf16'] - preds['f32']).abs()
+    d = torch.minimum(d, 1 - d)                        # coordinates live on the unit torus
+    assert d.max().item() < 2e-2
+
+
 # ------------------------------------------------------------------ bitrate-selection nets against the reference goldens
 @pytest.fixture(scope='module')
 def M():
@@ -425,6 +480,27 @@ def _cycle(M, K, mode, cycles=2):
             out['ppo_losses'] += list(res['loss'])
         out['flat'] = pol.engine.ac.flat_p.clone()
     return out
+
+
+def test_plain_bf16_ppo_nets_and_cycle(K, M):
+    """precision 'bf16' on the bitrate-selection path: logits / values / identifier predictions of the reference golden within 2e-2 (a perf
+    mode's bar), and two collect -> train_identifier -> relabel -> update cycles on the eight-preference table run through every product of the
+    engine (block-diagonal FeatureNet with K windows, slab-split heads, weight-gradient products with tile lists) with finite, falling losses."""
+    sd = po.make_policy_state_dict(int(ZP['wseed']))
+    pol = _policy(M, sd)
+    obs = torch.from_numpy(ZP['obs'][:64]).cuda()
+    with K.precision('bf16'):
+        logits, _ = pol.actor(obs)
+        value = pol.critic(obs)
+        pred = pol.identifier(obs)
+    np.testing.assert_allclose(logits.cpu().numpy(), ZP['logits'], atol=2e-2, rtol=0)
+    np.testing.assert_allclose(value.cpu().numpy(), ZP['value'], atol=2e-2, rtol=0)
+    np.testing.assert_allclose(pred.cpu().numpy(), ZP['ident'], atol=2e-2, rtol=0)
+    assert float(np.abs(logits.cpu().numpy() - ZP['logits']).max()) > 1e-5          # (really another arithmetic)
+    got, ref = _cycle(M, K, 'bf16'), _cycle(M, K, 'f32')
+    assert np.isfinite(got['id_losses']).all() and np.isfinite(got['ppo_losses']).all() and torch.isfinite(got['flat']).all()
+    np.testing.assert_allclose(got['id_losses'][:3], ref['id_losses'][:3], rtol=5e-2)
+    assert got['id_losses'][1] < got['id_losses'][0]
 
 
 @pytest.mark.parametrize('mode', MODES)
