@@ -689,7 +689,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16h_kernel(GemmParams p) {
   constexpr int C_FLOATS = BM * (BN + 4);
   constexpr int SMEM_FLOATS = (NS * STAGE_BYTES / 4) > C_FLOATS ? (NS * STAGE_BYTES / 4) : C_FLOATS;
   constexpr int PPT = PA + NP * PBW;                                                         // DMA pieces per wave and K-tile
-  static_assert((NP == 2 || NP == 3) && PB % 4 == 0 && NS >= 2 && NS <= 4 && PPT * (D - 1 > 0 ? D - 1 : 0) <= 15, "piece counts must fit the counted waits");
+  static_assert(NP >= 1 && NP <= 3 && PB % 4 == 0 && NS >= 2 && NS <= 4 && PPT * (D - 1 > 0 ? D - 1 : 0) <= 15, "piece counts must fit the counted waits");
   __shared__ __attribute__((aligned(1024))) float smem[SMEM_FLOATS];
 
   const int tid = threadIdx.x;
@@ -786,10 +786,13 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16h_kernel(GemmParams p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {                     // split_store's arithmetic, in registers
           const __bf16 t0 = (__bf16)v[e];
-          const float r1 = v[e] - (float)t0;
-          const __bf16 t1 = (__bf16)r1;
-          af[i][0][e] = t0; af[i][1][e] = t1;
-          if (NP == 3) af[i][2][e] = (__bf16)(r1 - (float)t1);
+          af[i][0][e] = t0;
+          if (NP >= 2) {
+            const float r1 = v[e] - (float)t0;
+            const __bf16 t1 = (__bf16)r1;
+            af[i][NP >= 2 ? 1 : 0][e] = t1;
+            if (NP == 3) af[i][NP - 1][e] = (__bf16)(r1 - (float)t1);
+          }
         }
       }
 #pragma unroll
@@ -797,13 +800,15 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16h_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {                    // smallest products first, the order of gemm_bf16p_kernel (results bit-identical to it)
           if (NP == 3) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][NP - 1], bf[j][0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][NP - 1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][NP >= 2 ? 1 : 0], bf[j][NP >= 2 ? 1 : 0], acc[i][j], 0, 0, 0);
           }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+          if (NP >= 2) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][NP >= 2 ? 1 : 0], bf[j][0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][NP >= 2 ? 1 : 0], acc[i][j], 0, 0, 0);
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);      // (NP == 1, plain bf16: this product alone)
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // LDS reads retired before the barrier that frees this buffer
@@ -1177,6 +1182,16 @@ static int g_bf16_variant = 1;      // 1: A by LDS-DMA, split at fragment read (
 extern "C" int mansy_gemm_bf16_variant(int v) { const int old = g_bf16_variant; if (v >= 0) g_bf16_variant = v; return old; }
 
 int mansy_gemm_bf16p_dispatch(const GemmParams& p, int tile, int prec, hipStream_t st) {
+  if (prec == 1) {
+    // plain bf16 with the weight's leading plane pre-converted: the ring loop (A staged in fp32 by LDS-DMA and rounded at fragment read, B's ONE plane by
+    // LDS-DMA), 128 x 128 or 64 x 64 tiles (gemm_dispatch sends operands it cannot take to the general staging loop)
+    MANSY_REQUIRE((reinterpret_cast<uintptr_t>(p.A) & 15) == 0 && p.lda % 4 == 0, "bf16 planes path: A must be 16-byte aligned with lda %% 4 == 0 (the dispatcher checks)");
+    dim3 block(NT);
+    if (tile >= 128) { dim3 grid(mansy_ceil_div(p.N, 128), mansy_ceil_div(p.M, 128), 1); MANSY_GEMM_LAUNCH((gemm_bf16h_kernel<128, 128, 3, 1>), grid, block, st, p); }
+    else { dim3 grid(mansy_ceil_div(p.N, 64), mansy_ceil_div(p.M, 64), 1); MANSY_GEMM_LAUNCH((gemm_bf16h_kernel<64, 64, 3, 1>), grid, block, st, p); }
+    MANSY_LAUNCH_CHECK();
+    return MANSY_OK;
+  }
   if (prec == 3 && g_bf16_variant >= 1 && (reinterpret_cast<uintptr_t>(p.A) & 15) == 0 && p.lda % 4 == 0) {
     if (tile == 256 && p.K < 3 * BK) tile = 128;
     dim3 block(NT);

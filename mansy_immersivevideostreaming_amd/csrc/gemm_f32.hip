@@ -696,7 +696,7 @@ int mansy_gemm_pair_end(hipStream_t st) {
 // tile codes: 128 -> 128x128, 96 -> 128x64 (LDS-DMA loop only), 64 -> 64x64
 static int gemm_dispatch(const GemmParams& p, int tile, bool dma, int bf, int a_kmajor, int b_kmajor, int splits, hipStream_t st) {
   if (bf && p.ep.b_planes && !a_kmajor && splits == 1 && !p.ep.tile_krange && (reinterpret_cast<uintptr_t>(p.ep.b_planes) & 15) == 0 &&
-      p.ep.b_planes_ld % 8 == 0 && p.ep.b_plane_stride % 8 == 0)
+      p.ep.b_planes_ld % 8 == 0 && p.ep.b_plane_stride % 8 == 0 && (bf != 1 || ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0 && p.lda % 4 == 0)))
     return mansy_gemm_bf16p_dispatch(p, tile, bf, st);            // weights pre-split into planes: B by LDS-DMA
   if (bf) return mansy_gemm_bf16s_dispatch(p, tile, bf, a_kmajor, b_kmajor, splits, st);
   if (dma && g_f32_wsk && tile == 64 && (p.c_vec_ok || p.ep.accumulate)) {

@@ -259,7 +259,7 @@ struct Eng {
     wtab.n = 0;
     // bf16x3 only: measured +4 % on the forward / dX products (tools/gemm_bench.py --planes).  bf16x6 stays on the in-loop split:
     // two LDS stages of three planes leave one workgroup per CU and ran 8-15 % SLOWER with pre-split weights.
-    if (prec != 3) return MANSY_OK;
+    if (prec != 3 && prec != 1) return MANSY_OK;      // (plain bf16 reads the leading plane only)
     for (int l = 0; l < c.n_enc; ++l) { const EncLayerP& p = P.enc[l]; wtab_add(p.in_proj, 3 * d, d); wtab_add(p.out_proj, d, d); wtab_add(p.lin1, f, d); wtab_add(p.lin2, d, f); }
     for (int l = 0; l < c.n_dec; ++l) {
       const DecLayerP& p = P.dec[l];
