@@ -410,7 +410,8 @@ int mansy_gemm_col_group(int v);
  * slab-split store) run on the wave-split-K loop (32 x 32 blocks, the four waves of a workgroup split the K-tiles; partial sums added in wave order:
  * deterministic, but a different summation order than the 64 x 64 loop's), 0 = on the 64 x 64 loop; 2 / 3 = the same for the small weight-gradient (TN)
  * products off / on; 8 / 9 = two independent small products of one engine call as ONE launch off / on (default on; bit-identical results);
- * v >= 16 = the tile-count threshold of "small" (default 200); other values only query.  Returns the previous value of the 0 / 1 setting. */
+ * 14 / 15 = the compile-time "plain" instances of the LDS-DMA loop (no optional form in the launch: none of their scalar loads / branches in its
+ * prologue) off / on (default on; bit-identical); v >= 16 = the tile-count threshold of "small" (default 200); other values only query.  Returns the previous value of the 0 / 1 setting. */
 int mansy_gemm_f32_wsk(int v);
 /* Kernel launches this library has enqueued since the process started (every launch site counts; a launch enqueued during a hipGraph
  * capture counts once, at capture time -- a replay of the graph adds nothing).  bench.py reads the difference around a cycle. */

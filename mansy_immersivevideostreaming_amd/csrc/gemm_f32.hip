@@ -253,7 +253,10 @@ __device__ __forceinline__ void read_frag_dma(const float* __restrict__ lds, int
   }
 }
 
-template <int BM, int BN, bool AK, bool BKM>
+// PLAIN (compile time): the launch has none of the optional forms -- one problem, no K split over workgroups, no tile list / ranges, no row-sum rider, no
+// column-group order, the row-major epilogue.  The decoder recurrence is a chain of ~240 such launches whose fixed cost (prologue, first-tile latency,
+// epilogue) is a quarter of their time: their instance carries none of the other forms' scalar loads and branches in front of the first LDS-DMA.
+template <int BM, int BN, bool AK, bool BKM, bool PLAIN = false>
 __global__ __launch_bounds__(NT) void gemm_f32_dma_kernel(GemmParams p) {
   constexpr int TM = BM / 64, TN = BN / 64, PA = BM / 32, PB = BN / 32;
   constexpr int A_FLOATS = BM * BK, B_FLOATS = BN * BK, STAGE = A_FLOATS + B_FLOATS;
@@ -274,17 +277,18 @@ __global__ __launch_bounds__(NT) void gemm_f32_dma_kernel(GemmParams p) {
     const int orig = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     const int q = nwg >> 3, rem = nwg & 7, xcd = orig & 7, local = orig >> 3;
     int t = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + local;
-    split = t / per_split; t -= split * per_split;
+    if (PLAIN) split = 0;
+    else { split = t / per_split; t -= split * per_split; }
     tile_y = t / gridDim.x; tile_x = t - tile_y * gridDim.x;
-    if (p.col_group > 0 && (int)gridDim.x > p.col_group) {      // column-group order (bijective for any grid): see GemmParams::col_group
+    if (!PLAIN && p.col_group > 0 && (int)gridDim.x > p.col_group) {      // column-group order (bijective for any grid): see GemmParams::col_group
       const int G = p.col_group, gy = gridDim.y, full = ((int)gridDim.x / G) * G;
       if (t < full * gy) { const int g = t / (G * gy), rr = t - g * G * gy; tile_y = rr / G; tile_x = g * G + (rr - tile_y * G); }
       else { const int W = gridDim.x - full, rr = t - full * gy; tile_y = rr / W; tile_x = full + (rr - tile_y * W); }
     }
-    if (BM == 64 && BN == 64 && p.ep.tile_list) { tile_x = p.ep.tile_list[2 * t]; tile_y = p.ep.tile_list[2 * t + 1]; }
+    if (!PLAIN && BM == 64 && BN == 64 && p.ep.tile_list) { tile_x = p.ep.tile_list[2 * t]; tile_y = p.ep.tile_list[2 * t + 1]; }
   }
-  const float* Ap = p.A; const float* Bp = p.B; float* Cp = p.C; float* rowsum_dst = p.ep.a_rowsum;
-  if (p.A2) {                                       // two same-shape problems in one launch: the upper half of the splits is problem 2
+  const float* Ap = p.A; const float* Bp = p.B; float* Cp = p.C; float* rowsum_dst = PLAIN ? nullptr : p.ep.a_rowsum;
+  if (!PLAIN && p.A2) {                                       // two same-shape problems in one launch: the upper half of the splits is problem 2
     const int prob = split / p.splits_pp;
     split -= prob * p.splits_pp;
     if (prob) { Ap = p.A2; Bp = p.B2; Cp = p.C2; rowsum_dst = p.a_rowsum2; }
@@ -294,15 +298,15 @@ __global__ __launch_bounds__(NT) void gemm_f32_dma_kernel(GemmParams p) {
   // tile list the grid's x extent is the length of the list, not the number of column tiles of C
   const int n_col_tiles = (p.N + BN - 1) / BN;
   int rs_first = 0, rs_cnt = n_col_tiles;
-  if (BM == 64 && p.ep.tile_nrange) {
+  if (!PLAIN && BM == 64 && p.ep.tile_nrange) {
     const int lo = p.ep.tile_nrange[2 * tile_y], hi = p.ep.tile_nrange[2 * tile_y + 1];
     if (n0 >= hi || n0 + BN <= lo) return;
     rs_first = lo / BN;
     rs_cnt = min(n_col_tiles, (hi + BN - 1) / BN) - rs_first;
   }
-  int k_begin = split * p.k_per_split;
-  int k_end = min(p.K, k_begin + p.k_per_split);
-  if (BN == 64 && p.ep.tile_krange) {             // structurally-zero K-tiles of this column tile are skipped
+  int k_begin = PLAIN ? 0 : split * p.k_per_split;
+  int k_end = PLAIN ? p.K : min(p.K, k_begin + p.k_per_split);
+  if (!PLAIN && BN == 64 && p.ep.tile_krange) {             // structurally-zero K-tiles of this column tile are skipped
     k_begin = max(k_begin, p.ep.tile_krange[2 * tile_x]);
     k_end = min(k_end, p.ep.tile_krange[2 * tile_x + 1]);
   }
@@ -372,6 +376,19 @@ __global__ __launch_bounds__(NT) void gemm_f32_dma_kernel(GemmParams p) {
   __syncthreads();                                        // staging LDS idle: the epilogue reuses it
 
   if (AK && rowsum_dst && tile_x - rs_first < BK && tid < BM && m0 + tid < p.M) atomicAdd(rowsum_dst + m0 + tid, rowsum);
+  if (PLAIN) {      // the row-major pass by construction (the dispatcher checked): gemm_epilogue's first branch, without its tests
+    constexpr int CLD = BN + 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          smem[(wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * CLD + wn * (BN / 2) + j * 32 + r] = acc[i][j][e];
+    __syncthreads();
+    gemm_epilogue_rows<BM, BN, NT>(p, smem, m0, n0, tid, Cp);
+    return;
+  }
   gemm_epilogue<BM, BN, SMEM_FLOATS>(p, acc, smem, m0, n0, tid, split, Cp);
 }
 
@@ -554,11 +571,23 @@ __global__ __launch_bounds__(NT) void gemm_f32_wsk_dual_kernel(GemmParams p1, Ws
   else gemm_f32_wsk_body<false, true>(p2, orig - n1, g2.x, g2.y, g2.z, smem);
 }
 
+int g_f32_plain = 1;      // A/B: mansy_gemm_f32_wsk(14) / (15) = the plain instances (64 x 64 and 128 x 64 tiles) off / on
 template <int BM, int BN>
 int launch_dma(const GemmParams& p, int a_kmajor, int b_kmajor, int splits, hipStream_t st) {
   dim3 grid(mansy_ceil_div(p.N, BN), mansy_ceil_div(p.M, BM), splits);
   if (BM == 64 && BN == 64 && p.ep.tile_list) grid = dim3(p.ep.tile_list_n, 1, splits);      // only the listed tiles
   dim3 block(NT);
+  // the plain form (the decoder-step products on 64 x 64 tiles, the [40 960-row] forward / dX products on 128 x 64): its own instance (see the kernel).
+  // Measured on the VP step (tools/vp_knob_ab.py f32_wsk 14 15): 22.49 -> 22.34 ms with the 64 x 64 instance, -0.05 ms more with the 128 x 64 one
+  const bool plain_form = ((BM == 64 && BN == 64) || (BM == 128 && BN == 64)) && g_f32_plain && !a_kmajor && splits == 1 && !p.A2 && !p.ep.tile_list && !p.ep.tile_nrange && !p.ep.tile_krange &&
+                          !p.ep.a_rowsum && !p.ep.accumulate && p.ep.split_slab == 0 && p.c_vec_ok && !(p.col_group > 0 && (int)grid.x > p.col_group);
+  if (plain_form) {
+    constexpr int PBM = (BM == 128 && BN == 64) ? 128 : 64;      // (instantiated for the two tile shapes that have a plain form)
+    if (b_kmajor) MANSY_GEMM_LAUNCH((gemm_f32_dma_kernel<PBM, 64, false, true, true>), grid, block, st, p);
+    else MANSY_GEMM_LAUNCH((gemm_f32_dma_kernel<PBM, 64, false, false, true>), grid, block, st, p);
+    MANSY_LAUNCH_CHECK();
+    return MANSY_OK;
+  }
   if (!a_kmajor && !b_kmajor) MANSY_GEMM_LAUNCH((gemm_f32_dma_kernel<BM, BN, false, false>), grid, block, st, p);
   else if (!a_kmajor && b_kmajor) MANSY_GEMM_LAUNCH((gemm_f32_dma_kernel<BM, BN, false, true>), grid, block, st, p);
   else if (a_kmajor && b_kmajor) MANSY_GEMM_LAUNCH((gemm_f32_dma_kernel<BM, BN, true, true>), grid, block, st, p);
@@ -648,6 +677,7 @@ extern "C" int mansy_gemm_f32_wsk(int v) {
   if (v == 0 || v == 1) g_f32_wsk = v;
   if (v == 2 || v == 3) g_f32_wsk_tn = v - 2;
   if (v == 8 || v == 9) g_f32_wsk_dual = v - 8;
+  if (v == 14 || v == 15) g_f32_plain = v - 14;
   if (v >= 16) g_f32_wsk_max_tiles = v;
   return old;
 }
