@@ -4,6 +4,7 @@
 // DistillLayer: viewport_prediction/models/customized_transformer.py:13-36.
 // All HBM-bound: one wavefront per row with 16-byte accesses, column sums reduced in registers
 // -> LDS -> one atomic per column per workgroup.
+#include <cstdlib>
 #include "mansy_kernels.h"
 
 #define RC_HOOK(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
@@ -482,6 +483,9 @@ int mansy_launch_layernorm_fwd(const float* a, const float* b, const float* w, c
   return MANSY_OK;
 }
 
+// rows per wave of the partial-sum backward: 2 for the decoder-step calls (<= 8192 rows: one wave per SIMD carries the whole ~1500-instruction body of its
+// rows, so half the rows per wave is a shorter launch: VP step 22.32 -> 22.20 ms; 1 row per wave gives it back), 4 for the [40 960-row] encoder calls
+static int ln_rows_per_wave(int rows) { return rows <= 8192 ? 2 : 4; }
 int mansy_launch_layernorm_bwd(const float* dy, const float* z, const float* mean, const float* rstd, const float* w,
                                float* dz, float* dz_drop, MansyDrop drop, float* dw, float* dbias, int rows, int C,
                                hipStream_t st) {
@@ -493,7 +497,10 @@ int mansy_launch_layernorm_bwd(const float* dy, const float* z, const float* mea
   if ((C % 256) == 0 && C <= 256 * LN_MAXV) {
     switch (C / 256) {
       case 1: MANSY_LAUNCH((layernorm_bwd_vec_kernel<1, false, 4>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C); break;
-      case 2: MANSY_LAUNCH((layernorm_bwd_vec_kernel<2, false, 4>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C); break;
+      case 2:      // (the same rows-per-wave rule as the partial-sum form: the two forms stay bit-identical per row)
+        if (ln_rows_per_wave(rows) == 2) MANSY_LAUNCH((layernorm_bwd_vec_kernel<2, false, 2>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C);
+        else MANSY_LAUNCH((layernorm_bwd_vec_kernel<2, false, 4>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C);
+        break;
       case 3: MANSY_LAUNCH((layernorm_bwd_vec_kernel<3, false, 4>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C); break;
       default: MANSY_LAUNCH((layernorm_bwd_vec_kernel<4, false, 4>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C); break;
     }
@@ -557,7 +564,7 @@ int mansy_launch_distill_bwd(const float* conv, const float* dmem, const unsigne
 }
 
 // ---- LayerNorm backward with per-workgroup partial weight-gradient sums (no atomics): the engine's form.
-int mansy_ln_bwd_parts(int rows) { return min(mansy_ceil_div(rows, 16), 1024); }
+int mansy_ln_bwd_parts(int rows) { return min(mansy_ceil_div(rows, 4 * ln_rows_per_wave(rows)), 1024); }
 bool mansy_ln_bwd_partial_ok(int C) { return (C % 256) == 0 && C <= 256 * LN_MAXV; }
 // partials: [mansy_ln_bwd_parts(rows)][2][C]; accumulate != 0 adds to what the slots hold (decoder: one LayerNorm
 // applied at T steps), else the slots are overwritten.
@@ -571,7 +578,7 @@ int mansy_launch_layernorm_bwd_partial(const float* dy, const float* z, const fl
   const size_t lds = (size_t)4 * 2 * C * sizeof(float);
   float* flag = accumulate ? partials : nullptr;      // the kernel only tests it for null
 #define LNB(NV, RBV) MANSY_LAUNCH((layernorm_bwd_vec_kernel<NV, true, RBV>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, partials, flag, rows, C)
-  if (C / 256 == 2) LNB(2, 4);
+  if (C / 256 == 2) { if (ln_rows_per_wave(rows) == 2) LNB(2, 2); else LNB(2, 4); }
   else if (C / 256 == 1) LNB(1, 4);
   else if (C / 256 == 3) LNB(3, 4);
   else LNB(4, 4);
