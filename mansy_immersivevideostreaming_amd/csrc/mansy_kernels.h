@@ -139,7 +139,7 @@ int mansy_gemm_pair_begin();
 int mansy_gemm_pair_end(hipStream_t st);
 // stats_d: device scratch of 6*C doubles ([sum, sumsq] forward, [sum g, sum g*xhat] backward global + local copy).
 // part (optional): scratch of MANSY_DISTILL_PARTS * 2 * C doubles -- the column sums then go through one partial per workgroup and a small reduce
-// launch (deterministic, in order) instead of double atomics on 2 C addresses from every workgroup.
+// launch (32 partials per thread, <= 16 adds per address) instead of double atomics on 2 C addresses from every workgroup.
 constexpr int MANSY_DISTILL_PARTS = 512;
 int mansy_launch_distill_fwd(const float* conv, const float* bn_w, const float* bn_b, float* run_mean, float* run_var,
                              long long* num_batches, float* mean_out, float* rstd_out, float* mem, unsigned char* argmax,

@@ -297,17 +297,18 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
 // (Round 4: the first half used to add its sums with double atomics -- 512 to 1024 workgroups on the same 2 C addresses, resolved at the memory side
 // across the eight XCDs: ~80 us of a 125 us kernel.)
 __global__ __launch_bounds__(256) void col_parts_reduce_kernel(const double* __restrict__ part, int nparts, int n, double* __restrict__ dst) {
+  // grid (ceil(n / 256), ceil(nparts / 32)): a thread sums up to 32 partials of its column and adds the sum to the (zeroed) destination -- at most
+  // 16 adds per address.  (First form: one thread per column over all 512 partials: 30 us for 4 MB.)
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  const int p0 = blockIdx.y * 32, p1 = min(p0 + 32, nparts);
+  double v[32];
+#pragma unroll
+  for (int u = 0; u < 32; ++u) v[u] = part[(long long)min(p0 + u, nparts - 1) * n + i];
   double t = 0.0;
-  for (int p0 = 0; p0 < nparts; p0 += 8) {
-    double v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = part[(long long)min(p0 + u, nparts - 1) * n + i];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) if (p0 + u < nparts) t += v[u];
-  }
-  dst[i] = t;
+  for (int u = 0; u < 32; ++u) if (p0 + u < p1) t += v[u];
+  atomicAdd(dst + i, t);
 }
 
 __global__ void bn_finalize_kernel(const double* __restrict__ stats, int n, int C, float* run_mean, float* run_var,
@@ -522,7 +523,7 @@ int mansy_launch_distill_fwd(const float* conv, const float* bn_w, const float* 
     MANSY_HIP_CHECK(hipMemsetAsync(stats_d, 0, sizeof(double) * 6 * s.C, st));
     dim3 grid(mansy_ceil_div(s.C, 256), min(rows, MANSY_DISTILL_PARTS));
     MANSY_LAUNCH(colstats_kernel, grid, dim3(256), 0, st, conv, rows, s.C, stats_d, part);
-    if (part) MANSY_LAUNCH(col_parts_reduce_kernel, dim3(mansy_ceil_div(2 * s.C, 256)), dim3(256), 0, st, part, (int)grid.y, 2 * s.C, stats_d);
+    if (part) MANSY_LAUNCH(col_parts_reduce_kernel, dim3(mansy_ceil_div(2 * s.C, 256), mansy_ceil_div((int)grid.y, 32)), dim3(256), 0, st, part, (int)grid.y, 2 * s.C, stats_d);
     if (s.sync_world > 1) RC_HOOK(mansy_bn_sync_invoke(0, s.hook, s.hook_user));     // SyncBN: all-reduce [sum, sumsq] (2C doubles) over the data-parallel ranks
   }
   const int n_glob = rows * (train && s.sync_world > 1 ? s.sync_world : 1);
@@ -548,7 +549,7 @@ int mansy_launch_distill_bwd(const float* conv, const float* dmem, const unsigne
     const int tpr = cv < 256 ? cv : 256;
     dim3 grid1(mansy_ceil_div(cv, tpr), min(mansy_ceil_div(rows, 4 * (256 / tpr)), MANSY_DISTILL_PARTS));
     MANSY_LAUNCH(distill_bwd_stage1<4>, grid1, dim3(256), 0, st, conv, dmem, argmax, bn_w, bn_b, mean, rstd, g_tmp, stats_d, s, part);
-    if (part) MANSY_LAUNCH(col_parts_reduce_kernel, dim3(mansy_ceil_div(2 * s.C, 256)), dim3(256), 0, st, part, (int)grid1.y, 2 * s.C, stats_d + 2 * s.C);
+    if (part) MANSY_LAUNCH(col_parts_reduce_kernel, dim3(mansy_ceil_div(2 * s.C, 256), mansy_ceil_div((int)grid1.y, 32)), dim3(256), 0, st, part, (int)grid1.y, 2 * s.C, stats_d + 2 * s.C);
   } else {
     dim3 grid1(mansy_ceil_div(s.C, 256), min(rows, 512));
     MANSY_LAUNCH(distill_bwd_stage1<1>, grid1, dim3(256), 0, st, conv, dmem, argmax, bn_w, bn_b, mean, rstd, g_tmp, stats_d, s, nullptr);

@@ -13,6 +13,7 @@
 //   * all dense products run on the fp32 MFMA kernel (gemm_f32.hip) with bias/ReLU/dropout/mask/
 //     residual fused in the epilogue; attention is the fused one-wave-per-(batch,head) kernel.
 #include <stdlib.h>
+#include <algorithm>
 #include <string>
 #include <vector>
 #include "mansy_kernels.h"
@@ -498,7 +499,9 @@ struct Eng {
       hp.z3 = e.z3 + o * d; hp.m3 = e.m3 + o; hp.r3 = e.r3 + o; hp.n3_w = P.dec[L].n3.w; hp.part_n3 = lnp + (size_t)(3 * L + 2) * lnp_set;
       hp.gz = gz; hp.dbr3 = e.dbr3 + o * d; hp.drop3 = dr(site_dec(L, i, 5), c.p_drop, bd);
       hp.rows = nb; hp.C = d; hp.C6 = C6;
-      RC(mansy_launch_dec_head_bwd(hp, mansy_ln_bwd_parts(nb), st));
+      // (its own grid rule: 16 rows per workgroup as before -- 8 made this fused kernel 17.9 -> 22 us; it fills the first slots of its sets, the rest stay
+      // zero from the memset and the reduce launches add them as such)
+      RC(mansy_launch_dec_head_bwd(hp, std::min(mansy_ln_bwd_parts(nb), (nb + 15) / 16), st));
     } else {
       // predictor + final decoder LayerNorm
       RC(mansy_launch_predictor_bwd(dpred_bt + ((size_t)b0 * T + i) * C6, (long long)T * C6, i < T - 1 ? s_tok : nullptr, C6,
