@@ -36,9 +36,10 @@ int mansy_abi_version(void);
  * bitrate_selection/models/mansy.py) of ONE call: MANSY_PREC_F32 = exact fp32 on v_mfma_f32_32x32x2_f32 (the parity mode);
  * MANSY_PREC_BF16X3 / _BF16X6: operands split into bf16 terms, 3 / 6 bf16 MFMA products accumulated in fp32 (BASELINE.json configs[4]
  * "bf16 MFMA").  Products with K % 32 != 0 or unaligned operands stay fp32.  A launch-time property: a captured hipGraph keeps the
- * mode it was captured in.  Carried by mansy_vp_config::precision and by the `precision` argument of the PPO / A2C entry points --
- * no process-wide state (ABI 7).  MANSY_PREC_DEFAULT (-1) = the value of the deprecated process-wide setter below (fp32 unless set). */
-#define MANSY_PREC_DEFAULT (-1)
+ * mode it was captured in.  Carried by mansy_vp_config::precision, by the `precision` argument of the PPO / A2C entry points and by
+ * mansy_gemm_epilogue::prec.  ABI 8: the library holds NO process-wide mutable state -- no precision setter, no hook registration, no
+ * kernel-selection knob, no environment variable; any other value than the four below is MANSY_EINVAL.  (What is process-wide and
+ * read-only after first use: the error string of the calling thread, the launch counter and launch recorder of the measurement hooks.) */
 #define MANSY_PREC_F32 0
 #define MANSY_PREC_BF16 1      /* plain bf16: ONE bf16 MFMA product per fp32 product, fp32 accumulate (errors ~1e-3 of the operands' scale: the class of the
                                 * reference's own GPU setting, torch.set_float32_matmul_precision('high'); a perf mode, never the parity mode) */
@@ -68,13 +69,10 @@ typedef struct mansy_vp_config {
                                 * attention / LayerNorm passes of the other; needs B >= 256 and even, else ignored).  Same function,
                                 * bit-identical forward.  The host mirror turns it on (sample() +4 %, train step +1.8 % at B = 4096);
                                 * per-kernel timings are taken with it off (concurrent kernels stretch each other's durations). */
-  int precision;               /* MANSY_PREC_* of this call's dense products (ABI 7; was process-wide) */
-  mansy_bn_sync_fn bn_sync_fn; /* SyncBN / gradient-ready hook of this call (ABI 7; was process-wide); NULL with bn_sync_world > 1 */
-  void* bn_sync_user;          /*   falls back to the deprecated mansy_set_bn_sync_hook registration */
+  int precision;               /* MANSY_PREC_* of this call's dense products */
+  mansy_bn_sync_fn bn_sync_fn; /* SyncBN / gradient-ready hook of this call; NULL with bn_sync_world > 1 is MANSY_EINVAL (ABI 8: there is */
+  void* bn_sync_user;          /*   no process-wide registration to fall back to) */
 } mansy_vp_config;
-
-/* DEPRECATED (kept for one round as shims): process-wide registration, used only by calls whose config leaves bn_sync_fn NULL. */
-int mansy_set_bn_sync_hook(mansy_bn_sync_fn fn, void* user);
 
 /* ordered parameter table (names are the reference state_dict keys) */
 int mansy_vp_num_params(const mansy_vp_config* cfg);
@@ -243,6 +241,10 @@ int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, fl
                              float eps_clip, float vf_coef, float ent_coef, int norm_adv, int value_clip, float dual_clip,
                              float max_grad_norm, float lr, float weight_decay, int step, long long tail_from, int tail_step, float* stats,
                              void* workspace, int max_batch, int chain_in, const int* next_idx, int next_mb, int precision, void* stream);
+/* Layout contract of the chained forms (step > 0 with max_grad_norm > 0, and mansy_ppo_dp_tail): their last launch updates four consecutive
+ * elements per thread and scatters them into the packed images, so flat_p / flat_g / flat_m / flat_v must be 16-byte aligned and every
+ * params[k] must be an ascending view of flat_p that starts at a multiple of 4 floats (the host mirror aligns tensors to 256 bytes);
+ * anything else is MANSY_EINVAL. */
 /* dual_clip: tianshou PPOPolicy's dual_clip (> 1; for negative advantages the clipped surrogate is bounded below by dual_clip * adv,
  * run_mansy.py --dual-clip) or 0 = off (the reference's default None). */
 /* Chaining (the clipped single-process step only: max_grad_norm > 0, step > 0, no lagged tail): the step's last launch -- clip + Adam --
@@ -336,16 +338,24 @@ int mansy_clip_grad_rmsprop(float* flat_p, float* flat_g, float* flat_sq, long l
 typedef struct mansy_gemm_epilogue {
   const float* bias; int relu; const float* mask_src; int mask_ld; float mask_scale;
   float drop_p; uint32_t drop_seed; uint32_t drop_site; const float* resid; int resid_ld; int accumulate;
-  /* bias-gradient rider of a dW product (a_kmajor != 0): a_rowsum[m] += sum_k A[m][k], added atomically (zero it first); the
-   * `+= dy.sum(0)` of a Linear's bias gradient at mtio.py / mansy.py autograd.  prec: < 0 = the process-wide mode, else MANSY_PREC_*. */
+  /* bias-gradient rider of a dW product (a_kmajor != 0): a_rowsum[m] += sum_k A[m][k] (zero it first); the `+= dy.sum(0)` of a
+   * Linear's bias gradient at mtio.py / mansy.py autograd.  prec: MANSY_PREC_* of this product.
+   * SINGLE WRITER: `accumulate` and `a_rowsum` update C / a_rowsum with plain read-add-write on the small-product
+   * loops (one owner per block, no atomics): two accumulating products into the SAME C or a_rowsum must be ordered on one stream. */
   float* a_rowsum; int prec;
+  /* kernel-selection override of THIS call (0 = defaults; diagnostics / parity tests: the same product on two loops).  OR of
+   * MANSY_VARIANT_* below.  Per call, thread-safe: nothing about it is remembered. */
+  int variant;
 } mansy_gemm_epilogue;
+#define MANSY_VARIANT_BF16(v) (((v) + 1) & 0xFF) /* loop variant v of the bf16x3 products with pre-split weights (0, 1 default, 4, 6, 7, 8: bit-identical
+                                                  * real loops; 2, 3, 11, 12: timing-only forms, results wrong -- csrc/gemm_bf16s.hip) */
+#define MANSY_VARIANT_NO_WSK 0x100               /* fp32 products too small to fill the chip: the 64 x 64 LDS-DMA loop instead of the wave-split-K loop
+                                                  * (same products, different summation order) */
+#define MANSY_VARIANT_NO_WSK_TN 0x200            /* the same for the small weight-gradient (TN) products only */
+#define MANSY_VARIANT_NO_PLAIN 0x400             /* no compile-time "plain" instance of the LDS-DMA loop (bit-identical) */
+#define MANSY_VARIANT_COL_GROUP(g) ((((g) + 1) & 0xFF) << 16) /* column-group width g of the XCD-aware tile order (default 12; 0 = row-panel-major); tile ORDER only */
 int mansy_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb, int b_kmajor, float* C, int ldc,
                    int M, int N, int K, const mansy_gemm_epilogue* ep, int force_tile, int force_splitk, void* stream);
-/* DEPRECATED (kept for one round as shims): the process-wide precision mode, read only by calls that pass MANSY_PREC_DEFAULT
- * (mansy_vp_config::precision / the `precision` argument / mansy_gemm_epilogue::prec < 0).  set returns the previous mode (< 0: error). */
-int mansy_set_gemm_precision(int mode);
-int mansy_get_gemm_precision(void);
 /* Split-bf16 modes, weights split ahead of the products (what the viewport engine does once per step for every Linear / Conv1d weight):
  * mansy_weight_planes writes n_planes (2: bf16x3, 3: bf16x6) bf16 planes of W [N, K] (plane t at out + t * plane_stride, row-major [N, K])
  * and of its transpose (out_t + t * plane_stride, row-major [K, N]); mansy_gemm_planes is mansy_gemm_f32 with a K-contiguous A and those
@@ -395,24 +405,10 @@ int mansy_attn_bwd_selfpull(const float* Q_all, long long q_ts, const float* K, 
 /* ------------------------------------------------------------------ measurement hooks (bench.py) */
 /* A HIP event pair attached to every GEMM dispatch on its own stream (the kernel's begin / end); collect() = device sync + summed ms, count, FLOPs. */
 int mansy_prof_gemm_enable(int on);
-/* A/B knob of the bf16x3 products with pre-split weights (diagnostic; tools/gemm_bench.py): 1 (default) = A staged in fp32 by LDS-DMA
- * and split at fragment read (256 x 128 tiles: gemm_bf16k_kernel, twelve waves with fixed loader / consumer roles; 128 x 128: gemm_bf16f; 64 x 64:
- * gemm_bf16h_kernel's three-stage ring, 6 = four stages), 8 = as 1 with the round-3 eight-wave loop on the 256 x 128 tiles, 4 = as 1 without
- * a 256 x 128 loop, 0 = the round-2 loop (A register-staged and split before its ds_write), 7 = the round-2 loop on the 64 x 64 tiles only,
- * 2 / 3 / 11 / 12 = timing-only staging / math forms (results wrong); v < 0 only queries.  Returns the previous value.  Results of all the
- * real loops are bit-identical (same products, same order). */
-int mansy_gemm_bf16_variant(int v);
 int mansy_prof_gemm_collect(double* total_ms, long long* launches, double* flops);
-/* A/B knob (diagnostic): column-group width of the XCD-aware tile order of the fp32 LDS-DMA loop for products with more column tiles than
- * that (default 12; 0 = plain row-panel-major order); v < 0 only queries.  Returns the previous value.  Never changes a result (tile ORDER only). */
-int mansy_gemm_col_group(int v);
-/* A/B knob (diagnostic): 1 (default) = fp32 products too small to fill the chip (<= 200 tiles of 64 x 64 incl. K splits, K-contiguous A, plain or
- * slab-split store) run on the wave-split-K loop (32 x 32 blocks, the four waves of a workgroup split the K-tiles; partial sums added in wave order:
- * deterministic, but a different summation order than the 64 x 64 loop's), 0 = on the 64 x 64 loop; 2 / 3 = the same for the small weight-gradient (TN)
- * products off / on; 8 / 9 = two independent small products of one engine call as ONE launch off / on (default on; bit-identical results);
- * 14 / 15 = the compile-time "plain" instances of the LDS-DMA loop (no optional form in the launch: none of their scalar loads / branches in its
- * prologue) off / on (default on; bit-identical); v >= 16 = the tile-count threshold of "small" (default 200); other values only query.  Returns the previous value of the 0 / 1 setting. */
-int mansy_gemm_f32_wsk(int v);
+/* (ABI 8: the round-4 A/B knobs mansy_gemm_bf16_variant / mansy_gemm_col_group / mansy_gemm_f32_wsk are gone from the library.  One product's
+ * loop can be chosen per call through mansy_gemm_epilogue::variant; whole-engine A/B timings use a -DMANSY_LAB build of the same sources
+ * (libmansy_hip_lab.so, tools/ only), which alone exports mansy_lab_set_variant.) */
 /* Kernel launches this library has enqueued since the process started (every launch site counts; a launch enqueued during a hipGraph
  * capture counts once, at capture time -- a replay of the graph adds nothing).  bench.py reads the difference around a cycle. */
 unsigned long long mansy_prof_launch_count(void);

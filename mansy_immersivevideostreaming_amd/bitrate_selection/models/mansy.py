@@ -254,8 +254,8 @@ class NetEngine:
         self.max_batch = max_batch
         self.ac = self.idn = None
         self._ws = None
-        # precision of this engine's dense products: None = MANSY_PREC_DEFAULT (the deprecated process-wide mode, fp32 unless set), or
-        # 'f32' / 'bf16x3' / 'bf16x6' -- passed with every call (the `precision` argument of the PPO entry points, ABI 7)
+        # precision of this engine's dense products: 'f32' / 'bf16' / 'bf16x3' / 'bf16x6', passed with every call (the `precision` argument of
+        # the PPO entry points); None = the calling thread's host-side default (_lib.current_precision(), 'f32' unless changed)
         self.precision = None
         for m in (actor, critic, identifier):
             if m is not None:
@@ -264,7 +264,7 @@ class NetEngine:
 
     @property
     def prec(self):
-        return -1 if self.precision is None else _lib.PRECISIONS[self.precision]
+        return _lib.resolve_precision(self.precision)
 
     @property
     def device(self):

@@ -116,11 +116,11 @@ class SimpleEngine:
         self.f = _Flat(2)
         self.f.attach(actor.feature_net.ordered_parameters() + actor.head_parameters() + critic.head_parameters())
         self._ws = None
-        self.precision = None       # None = MANSY_PREC_DEFAULT, or 'f32' / 'bf16x3' / 'bf16x6': the `precision` argument of every call
+        self.precision = None       # 'f32' / 'bf16' / 'bf16x3' / 'bf16x6' (the `precision` argument of every call); None = the thread's host-side default
 
     @property
     def prec(self):
-        return -1 if self.precision is None else _lib.PRECISIONS[self.precision]
+        return _lib.resolve_precision(self.precision)
 
     @property
     def device(self):

@@ -57,7 +57,19 @@ def gemm_source_digest():
     return h.hexdigest()
 
 
-def build(force=False, verbose=False):
+LAB_LIB = os.path.join(HERE, 'libmansy_hip_lab.so')
+
+
+def build(force=False, verbose=False, lab=False):
+    """lab=True: the same sources with -DMANSY_LAB -> libmansy_hip_lab.so, the only build that has a settable default kernel-selection
+    variant (mansy_lab_set_variant) for whole-engine A/B timings (tools/) and the paired-launch equivalence test.  The release library
+    (lab=False) holds no process-wide mutable state."""
+    if lab:
+        return _build(os.path.join(CSRC, '_obj_lab'), LAB_LIB, FLAGS + ['-DMANSY_LAB'], force, verbose, stamp=None)
+    return _build(OBJ, LIB, FLAGS, force, verbose, stamp=STAMP)
+
+
+def _build(OBJ, LIB, FLAGS, force, verbose, stamp):
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
     headers.append(os.path.join(os.path.dirname(HERE), 'include', 'mansy_hip.h'))
@@ -81,8 +93,9 @@ def build(force=False, verbose=False):
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
         run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs)
-    with open(STAMP, 'w') as fh:
-        fh.write(source_digest())
+    if stamp:
+        with open(stamp, 'w') as fh:
+            fh.write(source_digest())
     return LIB
 
 
@@ -109,4 +122,4 @@ def ensure_built():
 
 
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv, verbose=True))
+    print(build(force='--force' in sys.argv, verbose=True, lab='--lab' in sys.argv))

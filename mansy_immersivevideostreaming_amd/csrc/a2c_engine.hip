@@ -399,8 +399,8 @@ struct Eng {
 };
 
 int setup(void* ws, int maxB, int precision, hipStream_t st, Eng& e) {
-  MANSY_REQUIRE(precision < 0 || precision == 0 || precision == 1 || precision == 3 || precision == 6, "precision must be MANSY_PREC_DEFAULT (-1), 0, 1, 3 or 6 (got %d)", precision);
-  e.prec = precision >= 0 ? precision : mansy_get_gemm_precision();
+  MANSY_REQUIRE(precision == 0 || precision == 1 || precision == 3 || precision == 6, "precision must be MANSY_PREC_F32 (0), _BF16 (1), _BF16X3 (3) or _BF16X6 (6), got %d", precision);
+  e.prec = precision;
   MANSY_REQUIRE(ws && maxB >= 1, "a2c: bad workspace / batch");
   e.st = st;
   layout(maxB, (char*)ws, e.W);

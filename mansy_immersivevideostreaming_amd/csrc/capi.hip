@@ -15,10 +15,7 @@ extern "C" void mansy_set_error(const char* fmt, ...) {
 extern "C" { unsigned long long g_mansy_launch_count = 0; }
 extern "C" unsigned long long mansy_prof_launch_count(void) { return __atomic_load_n(&g_mansy_launch_count, __ATOMIC_RELAXED); }
 
-static mansy_bn_sync_fn g_bn_hook = nullptr;
-static void* g_bn_user = nullptr;
 int mansy_bn_sync_invoke(int which, int (*fn)(int, void*), void* user) {
-  if (!fn) { fn = g_bn_hook; user = g_bn_user; }       // deprecated process-wide registration (one round of grace)
   MANSY_REQUIRE(fn, "bn_sync_world > 1 but the call carries no hook (mansy_vp_config::bn_sync_fn)");
   const int rc = fn(which, user);
   MANSY_REQUIRE(rc == 0, "bn sync hook failed (%d)", rc);
@@ -27,10 +24,9 @@ int mansy_bn_sync_invoke(int which, int (*fn)(int, void*), void* user) {
 
 extern "C" {
 
-int mansy_set_bn_sync_hook(mansy_bn_sync_fn fn, void* user) { g_bn_hook = fn; g_bn_user = user; return MANSY_OK; }
 
 const char* mansy_last_error(void) { return g_err; }
-int mansy_abi_version(void) { return 7; }   // == _lib.py ABI_VERSION
+int mansy_abi_version(void) { return 8; }   // == _lib.py ABI_VERSION
 
 int mansy_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb, int b_kmajor, float* C, int ldc, int M, int N,
                    int K, const mansy_gemm_epilogue* ep, int force_tile, int force_splitk, void* stream) {
@@ -39,9 +35,9 @@ int mansy_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ld
     e.bias = ep->bias; e.relu = ep->relu; e.mask_src = ep->mask_src; e.mask_ld = ep->mask_ld; e.mask_scale = ep->mask_scale;
     e.drop.p = ep->drop_p; e.drop.seed = ep->drop_seed; e.drop.site = ep->drop_site;
     e.resid = ep->resid; e.resid_ld = ep->resid_ld; e.accumulate = ep->accumulate;
-    e.a_rowsum = ep->a_rowsum; e.prec = ep->prec;
+    e.a_rowsum = ep->a_rowsum; e.prec = ep->prec; e.variant = ep->variant;
     MANSY_REQUIRE(!ep->a_rowsum || a_kmajor, "gemm: a_rowsum rides on a K-major A (dW = dY^T X)");
-    MANSY_REQUIRE(ep->prec < 0 || ep->prec == 0 || ep->prec == 1 || ep->prec == 3 || ep->prec == 6, "gemm: prec must be < 0, 0, 1, 3 or 6");
+    MANSY_REQUIRE(ep->prec == 0 || ep->prec == 1 || ep->prec == 3 || ep->prec == 6, "gemm: prec must be MANSY_PREC_F32 (0), _BF16 (1), _BF16X3 (3) or _BF16X6 (6), got %d", ep->prec);
   }
   MANSY_REQUIRE(force_tile == 0 || force_tile == 64 || force_tile == 96 || force_tile == 128 || force_tile == -64 || force_tile == -128,
                 "gemm: force_tile must be 0, 64, 96 (128x64), 128, or -64 / -128 (register-staged loop)");
@@ -60,7 +56,8 @@ int mansy_gemm_planes(const float* A, int lda, const float* B, int ldb, int b_km
   if (ep) {
     e.bias = ep->bias; e.relu = ep->relu; e.mask_src = ep->mask_src; e.mask_ld = ep->mask_ld; e.mask_scale = ep->mask_scale;
     e.drop.p = ep->drop_p; e.drop.seed = ep->drop_seed; e.drop.site = ep->drop_site;
-    e.resid = ep->resid; e.resid_ld = ep->resid_ld; e.accumulate = ep->accumulate; e.prec = ep->prec;
+    e.resid = ep->resid; e.resid_ld = ep->resid_ld; e.accumulate = ep->accumulate; e.prec = ep->prec; e.variant = ep->variant;
+    MANSY_REQUIRE(ep->prec == 0 || ep->prec == 1 || ep->prec == 3 || ep->prec == 6, "gemm_planes: prec must be MANSY_PREC_F32 (0), _BF16 (1), _BF16X3 (3) or _BF16X6 (6), got %d", ep->prec);
   }
   MANSY_REQUIRE(force_tile == 0 || force_tile == 64 || force_tile == 96 || force_tile == 128 || force_tile == 256,
                 "gemm_planes: force_tile must be 0, 64, 96 (128x64), 128 or 256 (256x128, bf16x3)");

@@ -1174,14 +1174,14 @@ int mansy_gemm_bf16s_dispatch(const GemmParams& p, int tile, int prec, int a_kma
 }
 
 // B pre-split into planes (weights): forward / dX products with a K-contiguous A
-static int g_bf16_variant = 1;      // 1: A by LDS-DMA, split at fragment read (256 x 128 tiles: gemm_bf16k_kernel's twelve waves with fixed roles; 128 x 128:
-                                    // gemm_bf16f; 64 x 64 tiles: gemm_bf16h_kernel's three-stage ring); 8: as 1 with the round-3 eight-wave loop (gemm_bf16g)
-                                    // on the 256 x 128 tiles; 4: as 1 without any 256 x 128 loop; 6: as 1 with a four-stage ring; 7: as 1 with the
-                                    // round-2 loop on the 64 x 64 tiles; 0: the round-2 loop; 2 / 3 (128 x 128, 64 x 64) and 11 / 12 (256 x 128):
-                                    // timing-only staging / math forms (A/B tests, results wrong)
-extern "C" int mansy_gemm_bf16_variant(int v) { const int old = g_bf16_variant; if (v >= 0) g_bf16_variant = v; return old; }
+// Loop variant of the bf16x3 products with pre-split weights (GemmEpilogue::variant low byte, MANSY_VARIANT_BF16(v); default 1):
+//   1: A by LDS-DMA, split at fragment read (256 x 128 tiles: gemm_bf16k_kernel's twelve waves with fixed roles; 128 x 128: gemm_bf16f; 64 x 64 tiles:
+//      gemm_bf16h_kernel's three-stage ring); 8: as 1 with the round-3 eight-wave loop (gemm_bf16g) on the 256 x 128 tiles; 4: as 1 without any 256 x 128
+//      loop; 6: as 1 with a four-stage ring; 7: as 1 with the round-2 loop on the 64 x 64 tiles; 0: the round-2 loop; 2 / 3 (128 x 128, 64 x 64) and
+//      11 / 12 (256 x 128): timing-only staging / math forms (results wrong).  The real loops are bit-identical (same products, same order).
 
 int mansy_gemm_bf16p_dispatch(const GemmParams& p, int tile, int prec, hipStream_t st) {
+  const int bvar = mansy_var_bf16(p.ep.variant);
   if (prec == 1) {
     // plain bf16 with the weight's leading plane pre-converted: the ring loop (A staged in fp32 by LDS-DMA and rounded at fragment read, B's ONE plane by
     // LDS-DMA), 128 x 128 or 64 x 64 tiles (gemm_dispatch sends operands it cannot take to the general staging loop)
@@ -1192,11 +1192,11 @@ int mansy_gemm_bf16p_dispatch(const GemmParams& p, int tile, int prec, hipStream
     MANSY_LAUNCH_CHECK();
     return MANSY_OK;
   }
-  if (prec == 3 && g_bf16_variant >= 1 && (reinterpret_cast<uintptr_t>(p.A) & 15) == 0 && p.lda % 4 == 0) {
+  if (prec == 3 && bvar >= 1 && (reinterpret_cast<uintptr_t>(p.A) & 15) == 0 && p.lda % 4 == 0) {
     if (tile == 256 && p.K < 3 * BK) tile = 128;
     dim3 block(NT);
-    if (g_bf16_variant == 2 || g_bf16_variant == 3) {      // timing-only diagnostics (results wrong): the LDS-fill floor / the math floor of the shape
-      const int lab = g_bf16_variant - 1;
+    if (bvar == 2 || bvar == 3) {      // timing-only diagnostics (results wrong): the LDS-fill floor / the math floor of the shape
+      const int lab = bvar - 1;
       if (tile == 128) { dim3 grid(mansy_ceil_div(p.N, 128), mansy_ceil_div(p.M, 128), 1);
         if (lab == 1) MANSY_GEMM_LAUNCH((gemm_bf16f_kernel<128, 128, 1>), grid, block, st, p); else MANSY_GEMM_LAUNCH((gemm_bf16f_kernel<128, 128, 2>), grid, block, st, p); }
       else { dim3 grid(mansy_ceil_div(p.N, 64), mansy_ceil_div(p.M, 64), 1);
@@ -1209,13 +1209,13 @@ int mansy_gemm_bf16p_dispatch(const GemmParams& p, int tile, int prec, hipStream
     // (one K-tile of a 64 x 64 tile is 6 MFMAs per wave: the second, redundant fragment conversion is no longer hidden) -- but inside
     // the step those products are bound by the latency of their cold operands, which the three-stage ring below (gemm_bf16h_kernel)
     // covers; the 128 x 64 instance loses to both at every shape and is reachable only as force_tile 96
-    const bool big = tile == 256 || (tile == 128 && (g_bf16_variant == 1 || g_bf16_variant >= 8) && (long long)mansy_ceil_div(p.M, 256) * mansy_ceil_div(p.N, 128) >= 256);
-    if (big && g_bf16_variant != 8 && p.c_vec_ok && !p.ep.accumulate && p.ep.split_slab == 0) {
+    const bool big = tile == 256 || (tile == 128 && (bvar == 1 || bvar >= 8) && (long long)mansy_ceil_div(p.M, 256) * mansy_ceil_div(p.N, 128) >= 256);
+    if (big && bvar != 8 && p.c_vec_ok && !p.ep.accumulate && p.ep.split_slab == 0) {
       // round 4: twelve waves with fixed roles (8 consumers + 4 loaders); variant 8 = the eight-wave loop below (A/B runs), 11 / 12 = this
       // loop's staging-only / math-only timing forms (results wrong)
       dim3 grid(mansy_ceil_div(p.N, 128), mansy_ceil_div(p.M, 256), 1);
-      if (g_bf16_variant == 11) MANSY_GEMM_LAUNCH((gemm_bf16k_kernel<1>), grid, dim3(768), st, p);
-      else if (g_bf16_variant == 12) MANSY_GEMM_LAUNCH((gemm_bf16k_kernel<2>), grid, dim3(768), st, p);
+      if (bvar == 11) MANSY_GEMM_LAUNCH((gemm_bf16k_kernel<1>), grid, dim3(768), st, p);
+      else if (bvar == 12) MANSY_GEMM_LAUNCH((gemm_bf16k_kernel<2>), grid, dim3(768), st, p);
       else MANSY_GEMM_LAUNCH((gemm_bf16k_kernel<0>), grid, dim3(768), st, p);
       MANSY_LAUNCH_CHECK(); return MANSY_OK;
     }
@@ -1228,10 +1228,10 @@ int mansy_gemm_bf16p_dispatch(const GemmParams& p, int tile, int prec, hipStream
     if (tile == 96) { dim3 grid(mansy_ceil_div(p.N, 64), mansy_ceil_div(p.M, 128), 1); MANSY_GEMM_LAUNCH((gemm_bf16f_kernel<128, 64>), grid, block, st, p); MANSY_LAUNCH_CHECK(); return MANSY_OK; }
   }
   // 64 x 64 tiles (the [4 096-row] decoder products): the ring loop, both modes (variant 0 / 7: the round-2 loop, for A/B runs)
-  if (tile == 64 && g_bf16_variant != 0 && g_bf16_variant != 7 && (reinterpret_cast<uintptr_t>(p.A) & 15) == 0 && p.lda % 4 == 0) {
+  if (tile == 64 && bvar != 0 && bvar != 7 && (reinterpret_cast<uintptr_t>(p.A) & 15) == 0 && p.lda % 4 == 0) {
     dim3 grid(mansy_ceil_div(p.N, 64), mansy_ceil_div(p.M, 64), 1), block(NT);
     if (prec == 3) {
-      if (g_bf16_variant == 6) MANSY_GEMM_LAUNCH((gemm_bf16h_kernel<64, 64, 4, 2>), grid, block, st, p);
+      if (bvar == 6) MANSY_GEMM_LAUNCH((gemm_bf16h_kernel<64, 64, 4, 2>), grid, block, st, p);
       else MANSY_GEMM_LAUNCH((gemm_bf16h_kernel<64, 64, 3, 2>), grid, block, st, p);
     } else MANSY_GEMM_LAUNCH((gemm_bf16h_kernel<64, 64, 3, 3>), grid, block, st, p);
     MANSY_LAUNCH_CHECK();

@@ -571,7 +571,6 @@ __global__ __launch_bounds__(NT) void gemm_f32_wsk_dual_kernel(GemmParams p1, Ws
   else gemm_f32_wsk_body<false, true>(p2, orig - n1, g2.x, g2.y, g2.z, smem);
 }
 
-int g_f32_plain = 1;      // A/B: mansy_gemm_f32_wsk(14) / (15) = the plain instances (64 x 64 and 128 x 64 tiles) off / on
 template <int BM, int BN>
 int launch_dma(const GemmParams& p, int a_kmajor, int b_kmajor, int splits, hipStream_t st) {
   dim3 grid(mansy_ceil_div(p.N, BN), mansy_ceil_div(p.M, BM), splits);
@@ -579,7 +578,7 @@ int launch_dma(const GemmParams& p, int a_kmajor, int b_kmajor, int splits, hipS
   dim3 block(NT);
   // the plain form (the decoder-step products on 64 x 64 tiles, the [40 960-row] forward / dX products on 128 x 64): its own instance (see the kernel).
   // Measured on the VP step (tools/vp_knob_ab.py f32_wsk 14 15): 22.49 -> 22.34 ms with the 64 x 64 instance, -0.05 ms more with the 128 x 64 one
-  const bool plain_form = ((BM == 64 && BN == 64) || (BM == 128 && BN == 64)) && g_f32_plain && !a_kmajor && splits == 1 && !p.A2 && !p.ep.tile_list && !p.ep.tile_nrange && !p.ep.tile_krange &&
+  const bool plain_form = ((BM == 64 && BN == 64) || (BM == 128 && BN == 64)) && !mansy_var_no_plain(p.ep.variant) && !a_kmajor && splits == 1 && !p.A2 && !p.ep.tile_list && !p.ep.tile_nrange && !p.ep.tile_krange &&
                           !p.ep.a_rowsum && !p.ep.accumulate && p.ep.split_slab == 0 && p.c_vec_ok && !(p.col_group > 0 && (int)grid.x > p.col_group);
   if (plain_form) {
     constexpr int PBM = (BM == 128 && BN == 64) ? 128 : 64;      // (instantiated for the two tile shapes that have a plain form)
@@ -619,26 +618,13 @@ struct ProfState {
 ProfState g_prof;
 }  // namespace
 namespace mansy_gemm { hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr; }
-namespace {
-int g_gemm_prec = 0;   // process-wide default precision of the dense products: 0 fp32, 3 bf16x3, 6 bf16x6
-
-}  // namespace
-
-// Precision mode of every dense product launched from now on (a launch-time property: a captured hipGraph keeps the mode it
-// was captured in).  0: exact fp32 on v_mfma_f32_32x32x2_f32 (default); 3 / 6: split-bf16 products (gemm_bf16s.hip).
-// Products the split loop does not cover (K % 32 != 0, unaligned operands) stay fp32 in every mode.  Returns the previous mode.
-extern "C" int mansy_set_gemm_precision(int mode) {
-  if (mode != 0 && mode != 1 && mode != 3 && mode != 6) { mansy_set_error("gemm precision must be 0 (fp32), 1 (bf16), 3 (bf16x3) or 6 (bf16x6), got %d", mode); return MANSY_EINVAL; }
-  const int prev = g_gemm_prec;
-  g_gemm_prec = mode;
-  return prev;
-}
-extern "C" int mansy_get_gemm_precision(void) { return g_gemm_prec; }
-
-// A/B knob (diagnostic, tools/gpu_gemm_colgroup.sh; default 12): column-group width of the XCD-aware tile order of the LDS-DMA loop for products with more
-// column tiles than that (0 = plain row-panel-major order); v < 0 only queries.  Returns the previous value.  Never changes a result.
-static int g_col_group = 12;      // measured (profiles/r04_gemm_colgroup.txt): [40 960, 1 536, 512] fetch 578 -> 211 MB per launch, same duration
-extern "C" int mansy_gemm_col_group(int v) { const int old = g_col_group; if (v >= 0) g_col_group = v; return old; }
+// (ABI 8: no process-wide precision, no kernel-selection knobs.  The precision travels with the call; the loop a product runs on follows from
+// its shape and from GemmEpilogue::variant -- mansy_kernels.h, MANSY_VARIANT_* in include/mansy_hip.h.  The column-group width of the XCD-aware
+// tile order defaults to 12: profiles/r04_gemm_colgroup.txt, [40 960, 1 536, 512] fetch 578 -> 211 MB per launch at the same duration.)
+#ifdef MANSY_LAB
+int g_mansy_lab_variant = 0;
+extern "C" int mansy_lab_set_variant(int v) { const int old = g_mansy_lab_variant; if (v >= 0) g_mansy_lab_variant = v; return old; }
+#endif
 
 extern "C" int mansy_prof_gemm_enable(int on) {
   g_prof.on = on != 0;
@@ -664,23 +650,11 @@ extern "C" int mansy_prof_gemm_collect(double* total_ms, long long* launches, do
   return MANSY_OK;
 }
 
-static int g_f32_wsk_dual = 1;   // two independent small products as one launch (mansy_gemm_pair_begin / _end); mansy_gemm_f32_wsk(8) / (9) turn it off / on
-static int g_f32_wsk = 1;        // A/B knob (diagnostic): 1 = small products run on the wave-split-K loop (gemm_f32_wsk_kernel), 0 = on the 64 x 64 loop
-extern "C" int mansy_gemm_f32_wsk(int v);
-static int g_f32_wsk_max_tiles = 200;      // products with at most this many 64 x 64 output tiles (and <= 256 workgroups incl. K splits) count as small (mansy_gemm_f32_wsk(v >= 16) sets it): the PPO
-                                            // cycle's products have 80-160; at 256 -- the half-batch decoder products of the VP step, two of them in flight on two streams -- the 64 x 64
-                                            // loop wins inside the step (profiles/r04_f32_wsk_threshold.txt)
-static int g_f32_wsk_tn = 1;     // the same for the weight-gradient (TN) products; mansy_gemm_f32_wsk(2) / (3) turn it off / on
-int mansy_gemm_wsk_tn_enabled() { return g_f32_wsk && g_f32_wsk_tn; }
-extern "C" int mansy_gemm_f32_wsk(int v) {
-  const int old = g_f32_wsk;
-  if (v == 0 || v == 1) g_f32_wsk = v;
-  if (v == 2 || v == 3) g_f32_wsk_tn = v - 2;
-  if (v == 8 || v == 9) g_f32_wsk_dual = v - 8;
-  if (v == 14 || v == 15) g_f32_plain = v - 14;
-  if (v >= 16) g_f32_wsk_max_tiles = v;
-  return old;
-}
+// Small products (at most WSK_MAX_TILES output tiles of 64 x 64 and <= 256 workgroups incl. K splits) run on the wave-split-K loop: the PPO cycle's
+// products have 80-160 tiles; at 256 -- the half-batch decoder products of the VP step, two of them in flight on two streams -- the 64 x 64 loop
+// wins inside the step (profiles/r04_f32_wsk_threshold.txt).  MANSY_VARIANT_NO_WSK / _NO_WSK_TN (per call) put one product back on the 64 x 64 loop.
+constexpr int WSK_MAX_TILES = 200;
+int mansy_gemm_wsk_tn_enabled() { return !mansy_var_no_wsk_tn(0); }
 
 // ---- two independent small products as ONE launch (gemm_f32_wsk_dual_kernel).  Between mansy_gemm_pair_begin() and mansy_gemm_pair_end() the products
 // that resolve to the wave-split-K loop are collected instead of launched (everything else launches at once: the caller states that the products
@@ -701,7 +675,7 @@ static int wsk_launch(const GemmParams& p, int variant, dim3 grid, hipStream_t s
   return wsk_launch_one(w, st);
 }
 int mansy_gemm_pair_begin() {
-  if (!g_f32_wsk_dual || g_prof.on || g_pair_open) return 0;      // (the launch recorder stamps one event pair per product: no pairing while it runs)
+  if (mansy_var_no_pair(0) || g_prof.on || g_pair_open) return 0;      // (the launch recorder stamps one event pair per product: no pairing while it runs)
   g_pair_open = true; g_pair.clear();
   return 1;
 }
@@ -729,17 +703,17 @@ static int gemm_dispatch(const GemmParams& p, int tile, bool dma, int bf, int a_
       p.ep.b_planes_ld % 8 == 0 && p.ep.b_plane_stride % 8 == 0 && (bf != 1 || ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0 && p.lda % 4 == 0)))
     return mansy_gemm_bf16p_dispatch(p, tile, bf, st);            // weights pre-split into planes: B by LDS-DMA
   if (bf) return mansy_gemm_bf16s_dispatch(p, tile, bf, a_kmajor, b_kmajor, splits, st);
-  if (dma && g_f32_wsk && tile == 64 && (p.c_vec_ok || p.ep.accumulate)) {
+  if (dma && !mansy_var_no_wsk(p.ep.variant) && tile == 64 && (p.c_vec_ok || p.ep.accumulate)) {
     // a launch that cannot fill the chip: 32 x 32 blocks, the K-tiles split over the workgroup's four waves.  NT / NN: plain or slab-split stores,
     // any fused epilogue; TN (the weight-gradient products): accumulating (atomics) or slab-split, row-sum rider, tile list / ranges, paired problems
     const long long tiles64 = p.ep.tile_list ? (long long)p.ep.tile_list_n : (long long)mansy_ceil_div(p.M, 64) * mansy_ceil_div(p.N, 64);
-    const bool small = tiles64 <= g_f32_wsk_max_tiles && tiles64 * splits <= 256;      // few output tiles, and the K splits do not fill the chip either
+    const bool small = tiles64 <= WSK_MAX_TILES && tiles64 * splits <= 256;      // few output tiles, and the K splits do not fill the chip either
     const bool store_ok = !p.ep.accumulate && (splits == 1 || p.ep.split_slab != 0);
     if (small && !a_kmajor && p.c_vec_ok && store_ok && !p.ep.tile_list && !p.ep.tile_nrange && !p.ep.a_rowsum && !p.A2) {
       dim3 grid(mansy_ceil_div(p.N, 32), mansy_ceil_div(p.M, 32), splits);
       return wsk_launch(p, b_kmajor ? 1 : 0, grid, st);
     }
-    if (small && g_f32_wsk_tn && a_kmajor && b_kmajor && !p.ep.tile_krange && (p.ep.accumulate || splits == p.splits_pp * (p.A2 ? 2 : 1)) &&
+    if (small && !mansy_var_no_wsk_tn(p.ep.variant) && a_kmajor && b_kmajor && !p.ep.tile_krange && (p.ep.accumulate || splits == p.splits_pp * (p.A2 ? 2 : 1)) &&
         (p.ep.accumulate || ((p.splits_pp == 1 || p.ep.split_slab != 0) && p.c_vec_ok)) && (!p.ep.tile_list || p.ep.tile_nrange)) {
       dim3 grid(mansy_ceil_div(p.N, 32), mansy_ceil_div(p.M, 32), splits);
       if (p.ep.tile_list) grid = dim3(4 * p.ep.tile_list_n, 1, splits);
@@ -772,7 +746,7 @@ int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B,
   MANSY_REQUIRE(A && B && C, "gemm: null pointer");
   GemmParams p;
   p.A = A; p.B = B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.ep = ep;
-  p.col_group = (ep.tile_nrange || ep.tile_list || ep.tile_krange) ? 0 : g_col_group;
+  p.col_group = (ep.tile_nrange || ep.tile_list || ep.tile_krange) ? 0 : mansy_var_col_group(ep.variant);
   p.c_rmw_ok = (reinterpret_cast<uintptr_t>(C) & 15) == 0 && (!ep.pair_C || (reinterpret_cast<uintptr_t>(ep.pair_C) & 15) == 0) && ldc % 4 == 0 && N % 4 == 0;
   p.vec_ok = ((lda % 4) == 0) && ((ldb % 4) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
              ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (K % 4 == 0) && (!a_kmajor || M % 4 == 0) &&
@@ -785,7 +759,7 @@ int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B,
   // LDS-DMA loop: whole 16-byte chunks and whole K-tiles only (it cannot zero-fill a K tail)
   const bool dma = p.vec_ok && K >= BK && K % BK == 0 && force_tile >= 0;
   // split-bf16 modes: same preconditions as the LDS-DMA loop; everything else stays on the fp32 loops
-  const int bf = dma ? (ep.prec >= 0 ? ep.prec : g_gemm_prec) : 0;
+  const int bf = dma ? ep.prec : 0;
   if (!dma && p.vec_ok && force_tile >= 0 && plain && K % BK != 0 && K >= 8 * BK && ep.split_slab == 0 && !ep.tile_krange) {
     // long reduce dimension that is not a multiple of the K-tile (e.g. a dW over 3 276 rows): whole K-tiles on the LDS-DMA
     // loop, the < 32 leftover as a second, accumulating launch of the register-staged loop (sums and row sums are additive)
@@ -853,8 +827,8 @@ int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B,
   int splits = 1;
   // small accumulating weight-gradient product on the wave-split-K loop: the K-tiles are split inside the workgroup, so no split over workgroups
   // (every element of C then has ONE owner: a plain read-add-write instead of float atomics)
-  const bool wsk_tn = dma && !bf && g_f32_wsk && g_f32_wsk_tn && tile == 64 && a_kmajor && b_kmajor && plain && ep.accumulate && !p.ep.tile_list &&
-                      tiles <= g_f32_wsk_max_tiles && ep.split_slab == 0;      // (any K: at K = 3264 the split-K 64 x 64 loop is 3 us faster WITHOUT the bias-gradient
+  const bool wsk_tn = dma && !bf && !mansy_var_no_wsk_tn(ep.variant) && tile == 64 && a_kmajor && b_kmajor && plain && ep.accumulate && !p.ep.tile_list &&
+                      tiles <= WSK_MAX_TILES && ep.split_slab == 0;      // (any K: at K = 3264 the split-K 64 x 64 loop is 3 us faster WITHOUT the bias-gradient
                                                                                // rider -- 17.5 vs 20.6 us -- but its rider adds (column tiles x splits)-way atomics per row)
   if (force_splitk > 0) splits = force_splitk;
   else if (wsk_tn) splits = 1;

@@ -45,8 +45,11 @@ struct GemmEpilogue {
   // epilogue only, e.g. two dW products sharing an operand): C2 += A2 * B2, a_rowsum2 like a_rowsum.  Falls back to two
   // launches off the LDS-DMA loop.
   const float* pair_A = nullptr; const float* pair_B = nullptr; float* pair_C = nullptr; float* pair_rowsum = nullptr;
-  // precision of THIS product: -1 = the process-wide mode (mansy_set_gemm_precision), 0 fp32, 3 bf16x3, 6 bf16x6
-  int prec = -1;
+  // precision of THIS product (MANSY_PREC_*): 0 fp32, 1 bf16, 3 bf16x3, 6 bf16x6 -- there is no process-wide mode (ABI 8)
+  int prec = 0;
+  // kernel-selection override of THIS product (mansy_gemm_epilogue::variant, MANSY_VARIANT_*; 0 = the defaults).  The engines never
+  // set it; the parity tests use it to run the same product on two loops, tools/ for A/B timings.
+  int variant = 0;
   // optional addend applied BEFORE the mask stage to the columns n >= pre_col0: v += pre_a[m*pre_ld + n - pre_col0] (+ pre_b[..]).
   // (FeatureNet backward: the heads' residual gradients join the last 128 feature columns ahead of the LeakyReLU derivative,
   // which is the mask stage -- the former featgrad_finish launch.)
@@ -56,6 +59,22 @@ struct GemmEpilogue {
   // aligned, b_planes_ld % 8 == 0).  With a K-contiguous A the product then stages B by LDS-DMA: no split work and no ds_write for it.
   const unsigned short* b_planes = nullptr; long long b_plane_stride = 0; int b_planes_ld = 0;
 };
+
+// ---- decoding of GemmEpilogue::variant (bit layout: include/mansy_hip.h, MANSY_VARIANT_*).  A release build has NO process-wide knob: a call
+// that passes 0 gets the compiled-in defaults.  Only a -DMANSY_LAB build (tools/: build_ext.build(lab=True) -> libmansy_hip_lab.so) has a
+// settable default for calls that pass 0 (mansy_lab_set_variant), so that whole engine steps can be A/B-timed.
+#ifdef MANSY_LAB
+extern int g_mansy_lab_variant;
+inline int mansy_variant_of(int v) { return v ? v : g_mansy_lab_variant; }
+#else
+inline int mansy_variant_of(int v) { return v; }
+#endif
+inline int mansy_var_bf16(int v) { const int b = mansy_variant_of(v) & 0xFF; return b ? b - 1 : 1; }                 // bf16x3 loop variant (default 1)
+inline bool mansy_var_no_wsk(int v) { return (mansy_variant_of(v) & 0x100) != 0; }                                 // small products on the 64 x 64 loop
+inline bool mansy_var_no_wsk_tn(int v) { return (mansy_variant_of(v) & 0x300) != 0; }                              // small weight-gradient products likewise
+inline bool mansy_var_no_plain(int v) { return (mansy_variant_of(v) & 0x400) != 0; }                               // no compile-time plain instance
+inline bool mansy_var_no_pair(int v) { return (mansy_variant_of(v) & 0x800) != 0; }                                // (lab default only) no paired launch
+inline int mansy_var_col_group(int v) { const int g = (mansy_variant_of(v) >> 16) & 0xFF; return g ? g - 1 : 12; }   // column-group width (default 12)
 
 // Weights -> bf16 planes for the split-bf16 products (gemm_bf16s.hip): for each listed [N, K] fp32 matrix W (leading dimension K)
 // n_planes planes of W (plane t at out + t * plane_stride + off + n * K + k) and of its transpose (at out_t + t * plane_stride + off +

@@ -997,11 +997,9 @@ size_t ppo_layout(int maxB, char* base, PWork& W) {
 
 #define RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
-// A/B switch, read once: MANSY_HEAD_OUT_GENERIC=1 runs every output-layer launch on the generic instance of head_out_kernel (tools/ppo_cycle_ab.py)
-static bool head_out_modes() {
-  static const bool on = !(getenv("MANSY_HEAD_OUT_GENERIC") && getenv("MANSY_HEAD_OUT_GENERIC")[0] == '1');
-  return on;
-}
+// the launches that make up most of a cycle run compile-time instances of head_out_kernel (MODE 1 / 2 / 3); a -DMANSY_LAB build can send
+// them all to the generic instance (variant bit 0x1000) for A/B timing -- a release build reads no switch
+static bool head_out_modes() { return (mansy_variant_of(0) & 0x1000) == 0; }
 
 struct PEng {
   hipStream_t st; PWork W;
@@ -1271,8 +1269,8 @@ struct PEng {
 };
 
 int setup(void* ws, int maxB, int precision, hipStream_t st, PEng& e) {
-  MANSY_REQUIRE(precision < 0 || precision == 0 || precision == 1 || precision == 3 || precision == 6, "precision must be MANSY_PREC_DEFAULT (-1), 0, 1, 3 or 6 (got %d)", precision);
-  e.prec = precision >= 0 ? precision : mansy_get_gemm_precision();
+  MANSY_REQUIRE(precision == 0 || precision == 1 || precision == 3 || precision == 6, "precision must be MANSY_PREC_F32 (0), _BF16 (1), _BF16X3 (3) or _BF16X6 (6), got %d", precision);
+  e.prec = precision;
   MANSY_REQUIRE(ws && maxB >= 1, "ppo: bad workspace / batch");
   e.st = st;
   ppo_layout(maxB, (char*)ws, e.W);

@@ -223,7 +223,7 @@ int check_cfg(const mansy_vp_config* c) {
   MANSY_REQUIRE(c->in_ch >= 1 && c->in_ch <= 8 && c->in_ch % 3 == 0, "vp: in_ch must be 3*in_channel <= 8");
   MANSY_REQUIRE(c->max_len >= c->S && c->max_len >= c->T, "vp: positional table too short");
   MANSY_REQUIRE(c->p_pe >= 0.f && c->p_pe < 1.f && c->p_drop >= 0.f && c->p_drop < 1.f, "vp: dropout p outside [0,1)");
-  MANSY_REQUIRE(c->precision < 0 || c->precision == 0 || c->precision == 1 || c->precision == 3 || c->precision == 6, "vp: precision must be MANSY_PREC_DEFAULT (-1), 0, 1, 3 or 6 (got %d)", c->precision);
+  MANSY_REQUIRE(c->precision == 0 || c->precision == 1 || c->precision == 3 || c->precision == 6, "vp: precision must be MANSY_PREC_F32 (0), _BF16 (1), _BF16X3 (3) or _BF16X6 (6), got %d", c->precision);
   return MANSY_OK;
 }
 
@@ -241,7 +241,7 @@ struct Eng {
 
   Eng(const mansy_vp_config& cfg, hipStream_t s, bool tr, uint32_t sd) : c(cfg), st(s), train(tr), seed(sd) {
     wtab.n = 0;
-    prec = c.precision >= 0 ? c.precision : mansy_get_gemm_precision();      // MANSY_PREC_DEFAULT: the deprecated process-wide mode
+    prec = c.precision;
     B = c.B; S = c.S; T = c.T; d = c.d_model; f = c.d_ff; H = c.n_head; dh = d / H; M = (S - 1) / 2 + 1;
     N = B * S; TB = T * B; C6 = c.in_ch;
     drop_scale = (train && c.p_drop > 0.f) ? 1.f / (1.f - c.p_drop) : 1.f;
@@ -402,7 +402,7 @@ struct Eng {
   // stats) are taken with it off, because concurrent kernels stretch each other's durations.
   bool split_ok() const { return c.two_stream == 1 && B >= 256 && B % 2 == 0; }
   int fork() {
-    static hipStream_t s2 = nullptr; static hipEvent_t ev_f = nullptr;
+    static thread_local hipStream_t s2 = nullptr; static thread_local hipEvent_t ev_f = nullptr;      // one side stream per host thread
     if (!s2) { MANSY_HIP_CHECK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking)); MANSY_HIP_CHECK(hipEventCreateWithFlags(&ev_f, hipEventDisableTiming)); }
     st2 = s2;
     MANSY_HIP_CHECK(hipEventRecord(ev_f, st));
@@ -410,7 +410,7 @@ struct Eng {
     return MANSY_OK;
   }
   int join() {
-    static hipEvent_t ev_j = nullptr;
+    static thread_local hipEvent_t ev_j = nullptr;
     if (!ev_j) MANSY_HIP_CHECK(hipEventCreateWithFlags(&ev_j, hipEventDisableTiming));
     MANSY_HIP_CHECK(hipEventRecord(ev_j, st2));
     MANSY_HIP_CHECK(hipStreamWaitEvent(st, ev_j, 0));

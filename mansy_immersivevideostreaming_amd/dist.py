@@ -243,7 +243,7 @@ def probe_peer_grad_sync(sizes, world, rank, device, library_sync, iters=10, pro
     g = torch.Generator(device='cpu').manual_seed(4321 + rank)
     src = torch.randn(n0, generator=g).to(device)
     scratch = torch.zeros(64, dtype=torch.float64, device=device)
-    ok, why = 1.0, ''
+    ok, why, agreed = 1.0, '', 1.0
     # correctness on EVERY context (each has its own IPC mappings, flags and epochs: the identifier's 1.05 MB one used to go into
     # production without ever having been launched), speed on the largest
     for n in sorted(sizes):
@@ -260,9 +260,13 @@ def probe_peer_grad_sync(sizes, world, rank, device, library_sync, iters=10, pro
                 ok, why = 0.0, f'rank {rank}: sums of squares differ ({n} floats)'
         except Exception as e:          # noqa: BLE001
             ok, why = 0.0, f'rank {rank}: {e}'
-        if ok < 1.0:
+        # agree AFTER EVERY SIZE: every iteration starts with a collective (library_sync), so a rank-local `break`
+        # would leave the failed rank in all_min() while the healthy ones enter the next size's all_reduce + a peer launch that waits
+        # for the missing rank -- mismatched collectives.  The agreed value is what every rank leaves the loop on.
+        agreed = all_min(ok)
+        if agreed < 1.0:
             break
-    if all_min(ok) < 1.0:
+    if agreed < 1.0:
         for q in peers.values():
             q.close()
         report.update(chosen='library', reason='peer self-test failed' + (': ' + why if why else ' on another rank'))

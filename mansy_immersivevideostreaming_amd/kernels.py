@@ -9,6 +9,18 @@ from ._lib import (AttnShape, GemmEpilogue, MansyError, check, lib, ptr, stream_
                    PRECISIONS, get_precision, precision, set_precision)
 
 
+# mansy_gemm_epilogue::variant (include/mansy_hip.h MANSY_VARIANT_*): per call, nothing is remembered by the library
+VARIANT_NO_WSK, VARIANT_NO_WSK_TN, VARIANT_NO_PLAIN = 0x100, 0x200, 0x400
+
+
+def VARIANT_BF16(v):
+    return (v + 1) & 0xFF
+
+
+def VARIANT_COL_GROUP(g):
+    return ((g + 1) & 0xFF) << 16
+
+
 def _gpu(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -16,11 +28,12 @@ def _gpu(*ts):
 
 
 def gemm(A, B, a_kmajor=False, b_kmajor=False, bias=None, relu=False, mask_src=None, mask_scale=1.0, drop=None,
-         resid=None, out=None, accumulate=False, force_tile=0, force_splitk=0, a_rowsum=None, prec=None):
+         resid=None, out=None, accumulate=False, force_tile=0, force_splitk=0, a_rowsum=None, prec=None, variant=0):
     """C = A·B with A logical [M,K] (stored [K,M] if a_kmajor) and B logical [K,N]
     (stored [N,K] if not b_kmajor -- a torch Linear weight -- or [K,N] if b_kmajor).
     a_rowsum [M] (a_kmajor only): += the row sums of A over K, the bias-gradient rider of the dW products.
-    prec: None = the process-wide mode, else 0 / 3 / 6 for this product."""
+    prec: None = the calling thread's default (kernels.precision), else 0 / 1 / 3 / 6 for this product.
+    variant: mansy_gemm_epilogue::variant (VARIANT_* below) -- which loop this one product runs on."""
     _gpu(A, B)
     A, B = A.contiguous(), B.contiguous()
     M, K = (A.shape[1], A.shape[0]) if a_kmajor else A.shape
@@ -46,6 +59,7 @@ def gemm(A, B, a_kmajor=False, b_kmajor=False, bias=None, relu=False, mask_src=N
         ep.a_rowsum = a_rowsum.data_ptr()
     if prec is not None:
         ep.prec = int(prec)
+    ep.variant = int(variant)
     check(lib().mansy_gemm_f32(ptr(A), A.stride(0), int(a_kmajor), ptr(B), B.stride(0), int(b_kmajor), ptr(out), out.stride(0),
                                M, N, K, ctypes.byref(ep), force_tile, force_splitk, stream_ptr(A.device)), 'mansy_gemm_f32')
     return out
@@ -63,7 +77,7 @@ def weight_planes(W, n_planes):
     return out, out_t
 
 
-def gemm_planes(A, W, planes, transposed=False, bias=None, relu=False, resid=None, force_tile=0):
+def gemm_planes(A, W, planes, transposed=False, bias=None, relu=False, resid=None, force_tile=0, variant=0):
     """A [M, K'] times a weight given in fp32 (W [N, K]) AND as bf16 planes (weight_planes): transposed=False -> A W^T with `planes`
     of W; transposed=True -> A W with the planes of W^T.  In fp32 mode the planes are ignored."""
     _gpu(A, W, planes)
@@ -79,6 +93,7 @@ def gemm_planes(A, W, planes, transposed=False, bias=None, relu=False, resid=Non
     ep.mask_scale = 1.0
     if resid is not None:
         ep.resid, ep.resid_ld = resid.data_ptr(), resid.stride(0)
+    ep.variant = int(variant)
     check(lib().mansy_gemm_planes(ptr(A), A.stride(0), ptr(W), W.stride(0), int(transposed), ptr(planes), planes.stride(0), planes.stride(1),
                                   ptr(out), out.stride(0), M, N, K, ctypes.byref(ep), force_tile, stream_ptr(A.device)), 'mansy_gemm_planes')
     return out

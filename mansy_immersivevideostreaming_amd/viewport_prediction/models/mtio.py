@@ -93,9 +93,9 @@ class ViewportTransformerMTIO(nn.Module):
         self.repeat_prob = repeat_prob
         self.seed = seed
         self.has_bias = bool(bias)
-        # precision of the dense products, carried in every call's mansy_vp_config (ABI 7: no process-wide mode): 'f32' (exact fp32
-        # MFMA, the parity mode) / 'bf16x3' / 'bf16x6' (split-bf16 MFMA, csrc/gemm_bf16s.hip); None = MANSY_PREC_DEFAULT (whatever the
-        # deprecated kernels.set_precision shim holds: 'f32' unless changed).  A run-time attribute, not part of the checkpoint
+        # precision of the dense products, carried in every call's mansy_vp_config (the library has no process-wide mode): 'f32' (exact
+        # fp32 MFMA, the parity mode) / 'bf16' / 'bf16x3' / 'bf16x6' (csrc/gemm_bf16s.hip); None = the calling thread's host-side default
+        # (_lib.current_precision(): 'f32' unless a `with kernels.precision(..)` block is open).  A run-time attribute, not part of the checkpoint
         self.precision = None
         self._ws = {}
         self._flat_p = None
@@ -119,7 +119,7 @@ class ViewportTransformerMTIO(nn.Module):
                        n_enc=self.num_encoder_layers, n_dec=self.num_decoder_layers, in_ch=self.in_channel * self.num_head,
                        has_bias=int(self.has_bias), p_pe=self.dropout_p, p_drop=self.attn_dropout_p, ln_eps=1e-5, bn_eps=1e-5,
                        bn_momentum=0.1, max_len=_PE_MAX_LEN, bn_sync_world=int(self.bn_sync_world), two_stream=int(two),
-                       precision=-1 if self.precision is None else _lib.PRECISIONS[self.precision])
+                       precision=_lib.resolve_precision(self.precision))
         if self.bn_sync_world > 1:              # the call's own SyncBN / gradient-ready hook + the key that finds this model again
             cfg.bn_sync_fn = _BN_SYNC_CFUNC
             cfg.bn_sync_user = id(self)

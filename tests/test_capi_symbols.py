@@ -30,6 +30,23 @@ def test_header_symbols_exported(built):
         assert hasattr(L, n), n
 
 
+def test_release_library_has_no_process_wide_state_entry_points(built):
+    """ABI 8 ("no global state except an opaque ctx"): no setter, no hook registration, no kernel-selection knob is exported,
+    and the sources read no environment variable."""
+    import subprocess
+    out = subprocess.run(['nm', '-D', '--defined-only', built], check=True, capture_output=True, text=True).stdout
+    names = sorted({l.split()[-1] for l in out.splitlines() if ' T ' in l and 'mansy_' in l.split()[-1]})
+    assert len(names) >= 90
+    bad = [n for n in names if n != 'mansy_set_error' and      # (the thread-local error string's internal writer)
+           re.search(r'^mansy_(set_|get_gemm|lab_)|_variant$|mansy_gemm_col_group|mansy_gemm_f32_wsk|bn_sync_hook', n)]
+    assert bad == ['mansy_xg_set_timeout_ms'] or bad == [], bad          # (a per-context setting of an opaque ctx is not process-wide state)
+    assert ctypes.CDLL(built).mansy_abi_version() == 8
+    csrc = os.path.join(ROOT, 'mansy_immersivevideostreaming_amd', 'csrc')
+    for f in os.listdir(csrc):
+        if f.endswith(('.hip', '.h')):
+            assert 'getenv' not in open(os.path.join(csrc, f)).read(), f
+
+
 def test_ctypes_table_matches_header(built):
     from mansy_immersivevideostreaming_amd import _lib
     assert _lib.declared_symbols() == _declared()

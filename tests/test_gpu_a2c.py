@@ -158,7 +158,7 @@ def test_minibatch_loss_grads_clip_rmsprop_vs_oracle(S, n):
         arr, garr = f.pointers(grads=True)
         check(lib().mansy_a2c_minibatch_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(sq), f.flat_p.numel(), ptr(d['obs']), None, ptr(d['act']),
                                              ptr(d['adv']), ptr(d['ret']), n, 0.5, 0.1, max_norm, 1e-3, 0.99, 1e-8, apply, ptr(stats),
-                                             ptr(eng.workspace()), eng.max_batch, -1, stream_ptr()), 'a2c_mb')
+                                             ptr(eng.workspace()), eng.max_batch, eng.prec, stream_ptr()), 'a2c_mb')
 
     def oracle_step(max_norm, apply):
         opt.zero_grad(set_to_none=True)

@@ -76,20 +76,27 @@ def test_two_vp_models_with_different_precisions_interleaved_on_two_streams(MT):
             np.testing.assert_allclose(g[0], want[0], rtol=5e-5)       # steps 2..: weights differ by the float-atomics noise of step 1
             torch.testing.assert_close(g[1], want[1], rtol=0, atol=5e-4)      # after 3 Adam steps: +-lr walks of noise-driven parameters
             assert float(((g[2] - want[2]).abs() > 1e-6).float().mean()) < 0.02 and float((g[2] - want[2]).abs().max()) <= 6.1e-4
-    assert K.get_precision() == 'f32'                 # the deprecated process-wide mode was never touched
+    assert K.get_precision() == 'f32'                 # the thread's host-side default was never touched
 
 
-def test_config_precision_overrides_the_deprecated_process_wide_mode(MT):
+def test_config_precision_overrides_the_host_side_default(MT):
+    """ABI 8: the library has no mode of its own; `precision = None` resolves on the HOST to the calling thread's default and is passed
+    with the call like any other value."""
     from mansy_immersivevideostreaming_amd import kernels as K
     batch = tuple(t.cuda() for t in vo.synthetic_trajectories(64, 10, 10, seed=4))
     m = _vp(MT, 'f32').eval()
     with torch.no_grad():
         ref = m.sample(batch[0], batch[1]).clone()
         try:
-            K.set_precision('bf16x3')                 # the shim: only calls that pass MANSY_PREC_DEFAULT look at it
+            K.set_precision('bf16x3')                 # host-side default: a model that names its precision does not look at it
             assert torch.equal(m.sample(batch[0], batch[1]), ref)
-            m.precision = None                        # MANSY_PREC_DEFAULT -> the shim's mode
+            m.precision = None                        # -> the thread's default
             other = m.sample(batch[0], batch[1]).clone()
+            import threading
+            seen = []
+            th = threading.Thread(target=lambda: seen.append(K.get_precision()))      # per thread: another thread still sees 'f32'
+            th.start(); th.join()
+            assert seen == ['f32']
         finally:
             K.set_precision('f32')
         m.precision = 'bf16x3'

@@ -58,8 +58,15 @@ def test_mode_switch_api(K):
     K.set_precision('f32')
     with pytest.raises(Exception):
         K.set_precision('fp8')
+    # ABI 8: the mode is host-side state of the calling thread; the library has no setter and rejects codes it does not know per call
     from mansy_immersivevideostreaming_amd._lib import lib
-    assert lib().mansy_set_gemm_precision(5) < 0 and K.get_precision() == 'f32'
+    assert not hasattr(lib(), 'mansy_set_gemm_precision') and not hasattr(lib(), 'mansy_get_gemm_precision')
+    A = torch.randn(64, 32).cuda()
+    with pytest.raises(Exception):
+        K.gemm(A, A, prec=5)
+    with pytest.raises(Exception):
+        K.gemm(A, A, prec=-1)
+    assert K.get_precision() == 'f32'
 
 
 SHAPES = [  # (M, N, K) -- ragged rows / columns, one-tile and many-tile cases, the VP and PPO shapes
@@ -593,34 +600,28 @@ def test_ring_staged_decoder_tiles_equal_the_two_stage_loop_bit_for_bit(K, mode)
     counted vmcnt waits; variant 6: four stages).  Same products in the same order as the round-2 two-stage loop (variant 7), so the
     results must be bit-identical -- over 1..6 K-tiles (prologue shorter than the ring, tail with no DMA left to issue), ragged rows /
     columns, both forms (A W^T and A W), with a fused epilogue, many launches back to back (stage reuse across launches)."""
-    from mansy_immersivevideostreaming_amd._lib import lib
-    L = lib()
     npl = 2 if mode == 'bf16x3' else 3
     g = torch.Generator().manual_seed(21)
-    old = L.mansy_gemm_bf16_variant(-1)
-    try:
-        for (M, N, Kd) in ((4096, 512, 512), (70, 64, 32), (64, 130, 64), (257, 96, 96), (100, 72, 128), (33, 512, 160), (1000, 260, 192), (4000, 520, 1536)):
-            W = torch.randn(N, Kd, generator=g).cuda()
-            pl, pl_t = K.weight_planes(W, npl)
-            A = torch.randn(M, Kd, generator=g).cuda()
-            G = torch.randn(M, N, generator=g).cuda()
-            bias, resid = torch.randn(N, generator=g).cuda(), torch.randn(M, N, generator=g).cuda()
-            outs = {}
-            for v in (7, 1, 6):
-                L.mansy_gemm_bf16_variant(v)
-                with K.precision(mode):
-                    outs[v] = [K.gemm_planes(A, W, pl, force_tile=64), K.gemm_planes(G, W, pl_t, transposed=True, force_tile=64),
-                               K.gemm_planes(A, W, pl, bias=bias, relu=True, resid=resid, force_tile=64)]
-                    for _ in range(3):                       # back to back: nothing of one launch's ring may leak into the next
-                        again = K.gemm_planes(A, W, pl, force_tile=64)
-                    assert torch.equal(again, outs[v][0])
-            for v in (1, 6):
-                for got, want in zip(outs[v], outs[7]):
-                    assert torch.equal(got, want), (mode, v, M, N, Kd)
-            ref = A.double() @ W.double().t()
-            assert ((outs[1][0].double() - ref).abs().max() / ref.abs().max()).item() < GEMM_TOL[mode]
-    finally:
-        L.mansy_gemm_bf16_variant(old)
+    for (M, N, Kd) in ((4096, 512, 512), (70, 64, 32), (64, 130, 64), (257, 96, 96), (100, 72, 128), (33, 512, 160), (1000, 260, 192), (4000, 520, 1536)):
+        W = torch.randn(N, Kd, generator=g).cuda()
+        pl, pl_t = K.weight_planes(W, npl)
+        A = torch.randn(M, Kd, generator=g).cuda()
+        G = torch.randn(M, N, generator=g).cuda()
+        bias, resid = torch.randn(N, generator=g).cuda(), torch.randn(M, N, generator=g).cuda()
+        outs = {}
+        for v in (7, 1, 6):
+            var = K.VARIANT_BF16(v)                      # per call (ABI 8): nothing is remembered by the library
+            with K.precision(mode):
+                outs[v] = [K.gemm_planes(A, W, pl, force_tile=64, variant=var), K.gemm_planes(G, W, pl_t, transposed=True, force_tile=64, variant=var),
+                           K.gemm_planes(A, W, pl, bias=bias, relu=True, resid=resid, force_tile=64, variant=var)]
+                for _ in range(3):                       # back to back: nothing of one launch's ring may leak into the next
+                    again = K.gemm_planes(A, W, pl, force_tile=64, variant=var)
+                assert torch.equal(again, outs[v][0])
+        for v in (1, 6):
+            for got, want in zip(outs[v], outs[7]):
+                assert torch.equal(got, want), (mode, v, M, N, Kd)
+        ref = A.double() @ W.double().t()
+        assert ((outs[1][0].double() - ref).abs().max() / ref.abs().max()).item() < GEMM_TOL[mode]
 
 
 def test_role_split_256x128_loop_equals_the_other_loops_bit_for_bit(K):
@@ -629,35 +630,27 @@ def test_role_split_256x128_loop_equals_the_other_loops_bit_for_bit(K):
     same order per output element as the eight-wave loop (variant 8, force_tile 256) and the 128 x 128 loop (variant 4, force_tile 128),
     and the same row-major epilogue: bit-identical results -- over 3..48 K-tiles (prologue shorter than the ring, tails with nothing left
     to issue), ragged rows / columns, both forms (A W^T and A W), a fused epilogue, launches back to back (ring reuse across launches)."""
-    from mansy_immersivevideostreaming_amd._lib import lib
-    L = lib()
     g = torch.Generator().manual_seed(33)
-    old = L.mansy_gemm_bf16_variant(-1)
-    try:
-        for (M, N, Kd) in ((40960, 512, 512), (1000, 260, 96), (257, 128, 128), (4096, 1536, 512), (300, 132, 160), (2048, 512, 1536), (256, 128, 192)):
-            W = torch.randn(N, Kd, generator=g).cuda()
-            pl, pl_t = K.weight_planes(W, 2)
-            A = torch.randn(M, Kd, generator=g).cuda()
-            G = torch.randn(M, N, generator=g).cuda()
-            bias, resid = torch.randn(N, generator=g).cuda(), torch.randn(M, N, generator=g).cuda()
+    for (M, N, Kd) in ((40960, 512, 512), (1000, 260, 96), (257, 128, 128), (4096, 1536, 512), (300, 132, 160), (2048, 512, 1536), (256, 128, 192)):
+        W = torch.randn(N, Kd, generator=g).cuda()
+        pl, pl_t = K.weight_planes(W, 2)
+        A = torch.randn(M, Kd, generator=g).cuda()
+        G = torch.randn(M, N, generator=g).cuda()
+        bias, resid = torch.randn(N, generator=g).cuda(), torch.randn(M, N, generator=g).cuda()
 
-            def run(tile):
-                with K.precision('bf16x3'):
-                    return [K.gemm_planes(A, W, pl, force_tile=tile), K.gemm_planes(G, W, pl_t, transposed=True, force_tile=tile),
-                            K.gemm_planes(A, W, pl, bias=bias, relu=True, resid=resid, force_tile=tile)]
-            L.mansy_gemm_bf16_variant(4)
-            want = run(128)                                   # gemm_bf16f_kernel<128, 128>
-            L.mansy_gemm_bf16_variant(8)
-            for got, w in zip(run(256), want):                # gemm_bf16g_kernel
-                assert torch.equal(got, w)
-            L.mansy_gemm_bf16_variant(1)
-            outs = run(256)                                   # gemm_bf16k_kernel
-            for got, w in zip(outs, want):
-                assert torch.equal(got, w), (M, N, Kd, float((got - w).abs().max()))
+        def run(tile, v):
+            var = K.VARIANT_BF16(v)
             with K.precision('bf16x3'):
-                for _ in range(3):
-                    assert torch.equal(K.gemm_planes(A, W, pl, force_tile=256), want[0])
-            ref = A.double() @ W.double().t()
-            assert ((want[0].double() - ref).abs().max() / ref.abs().max()).item() < GEMM_TOL['bf16x3']
-    finally:
-        L.mansy_gemm_bf16_variant(old)
+                return [K.gemm_planes(A, W, pl, force_tile=tile, variant=var), K.gemm_planes(G, W, pl_t, transposed=True, force_tile=tile, variant=var),
+                        K.gemm_planes(A, W, pl, bias=bias, relu=True, resid=resid, force_tile=tile, variant=var)]
+        want = run(128, 4)                                # gemm_bf16f_kernel<128, 128>
+        for got, w in zip(run(256, 8), want):             # gemm_bf16g_kernel
+            assert torch.equal(got, w)
+        outs = run(256, 1)                                # gemm_bf16k_kernel
+        for got, w in zip(outs, want):
+            assert torch.equal(got, w), (M, N, Kd, float((got - w).abs().max()))
+        with K.precision('bf16x3'):
+            for _ in range(3):
+                assert torch.equal(K.gemm_planes(A, W, pl, force_tile=256), want[0])
+        ref = A.double() @ W.double().t()
+        assert ((want[0].double() - ref).abs().max() / ref.abs().max()).item() < GEMM_TOL['bf16x3']

@@ -167,7 +167,7 @@ def test_ppo_minibatch_loss_grads_clip_adam_vs_oracle(M):
         arr, garr = f.pointers(grads=True)
         check(lib().mansy_ppo_minibatch_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(d['obs']), None,
                                              ptr(d['act']), ptr(d['adv']), ptr(d['logp']), ptr(d['v']), ptr(d['ret']), len(obs), 0.2, 0.5, 0.02, 1, 1, 0.0,
-                                             max_norm, 5e-4, 1e-2, step, -1, 0, ptr(stats), ptr(eng.workspace()), eng.max_batch, 0, None, 0, -1, stream_ptr()), 'ppo_mb')
+                                             max_norm, 5e-4, 1e-2, step, -1, 0, ptr(stats), ptr(eng.workspace()), eng.max_batch, 0, None, 0, eng.prec, stream_ptr()), 'ppo_mb')
     call(0, 0.0)                                  # gradients only, no clipping
     np.testing.assert_allclose(stats.cpu().numpy(), [loss, clip, vf, ent], rtol=2e-5, atol=2e-6)
     names = [n for n, _ in f.table]
@@ -197,33 +197,39 @@ def test_ppo_minibatch_loss_grads_clip_adam_vs_oracle(M):
 
 def test_paired_launch_of_the_fc_weight_gradients_and_dF_is_bit_identical_to_two_launches(M):
     """Round 4: the minibatch step's fc weight-gradient pair and its dF product are independent readers of dA1 and run as ONE launch
-    (gemm_f32_wsk_dual_kernel: the same two loop bodies on disjoint workgroup ranges of one grid; mansy_gemm_f32_wsk(8) / (9) = off / on).
-    Every gradient, the loss statistics and the identifier's training step (fc_bwd_single's pair) are bit-identical either way."""
-    from mansy_immersivevideostreaming_amd._lib import check, lib, ptr, stream_ptr
-    L = lib()
+    (gemm_f32_wsk_dual_kernel: the same two loop bodies on disjoint workgroup ranges of one grid).  ABI 8: the release library has no switch
+    for it; the -DMANSY_LAB build of the same sources has (default variant 0x800 = no paired launch).  Every gradient, the loss statistics and
+    the identifier's training step (fc_bwd_single's pair) are bit-identical either way -- and the release library agrees with both."""
+    from mansy_immersivevideostreaming_amd import _lib as LB, build_ext
+    from mansy_immersivevideostreaming_amd._lib import check, ptr, stream_ptr
+    build_ext.build(lab=True)
     sd = po.make_policy_state_dict(int(Z['wseed']))
     obs, act, adv, v_old, ret, g = _minibatch_data()
     logp_old = torch.log_softmax(po.actor_logits(sd, obs), -1).gather(1, act[:, None])[:, 0] + 0.3 * torch.randn(len(obs), generator=g)
     dev = 'cuda'
     d = dict(obs=obs.to(dev), act=act.int().to(dev), adv=adv.to(dev), logp=logp_old.to(dev), v=v_old.to(dev), ret=ret.to(dev))
     outs = {}
-    try:
-        for knob in (8, 9):
-            L.mansy_gemm_f32_wsk(knob)
-            pol = build_policy(M, sd)
-            eng, f, fi = pol.engine, pol.engine.ac, pol.engine.idn
-            stats = torch.zeros(4, device=dev)
-            arr, garr = f.pointers(grads=True)
-            check(L.mansy_ppo_minibatch_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(d['obs']), None,
-                                             ptr(d['act']), ptr(d['adv']), ptr(d['logp']), ptr(d['v']), ptr(d['ret']), len(obs), 0.2, 0.5, 0.02, 1, 1, 0.0,
-                                             0.0, 5e-4, 1e-2, 0, -1, 0, ptr(stats), ptr(eng.workspace()), eng.max_batch, 0, None, 0, -1, stream_ptr()), 'ppo_mb')
-            iloss = torch.zeros((), device=dev)
-            iarr, igarr = fi.pointers(grads=True)
-            check(L.mansy_identifier_train_step(iarr, igarr, ptr(fi.flat_p), ptr(fi.flat_g), ptr(fi.m), ptr(fi.v), fi.flat_p.numel(), ptr(d['obs']), None,
-                                                len(obs), 1e-4, 1e-2, -1, ptr(iloss), ptr(eng.workspace()), eng.max_batch, -1, stream_ptr()), 'ident')
-            outs[knob] = (f.flat_g.clone(), stats.clone(), fi.flat_g.clone(), iloss.clone())
-    finally:
-        L.mansy_gemm_f32_wsk(9)
+
+    def run(L):
+        pol = build_policy(M, sd)
+        eng, f, fi = pol.engine, pol.engine.ac, pol.engine.idn
+        stats = torch.zeros(4, device=dev)
+        arr, garr = f.pointers(grads=True)
+        check(L.mansy_ppo_minibatch_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(d['obs']), None,
+                                         ptr(d['act']), ptr(d['adv']), ptr(d['logp']), ptr(d['v']), ptr(d['ret']), len(obs), 0.2, 0.5, 0.02, 1, 1, 0.0,
+                                         0.0, 5e-4, 1e-2, 0, -1, 0, ptr(stats), ptr(eng.workspace()), eng.max_batch, 0, None, 0, eng.prec, stream_ptr()), 'ppo_mb')
+        iloss = torch.zeros((), device=dev)
+        iarr, igarr = fi.pointers(grads=True)
+        check(L.mansy_identifier_train_step(iarr, igarr, ptr(fi.flat_p), ptr(fi.flat_g), ptr(fi.m), ptr(fi.v), fi.flat_p.numel(), ptr(d['obs']), None,
+                                            len(obs), 1e-4, 1e-2, -1, ptr(iloss), ptr(eng.workspace()), eng.max_batch, eng.prec, stream_ptr()), 'ident')
+        torch.cuda.synchronize()
+        return (f.flat_g.clone(), stats.clone(), fi.flat_g.clone(), iloss.clone())
+    for knob, variant in ((8, 0x800), (9, 0)):
+        with LB.lab_library(variant) as L:
+            outs[knob] = run(L)
+    rel = run(LB.lib())
+    for a, b in zip(rel, outs[9]):
+        assert torch.equal(a, b)
     assert float(outs[9][0].abs().max()) > 0 and float(outs[9][2].abs().max()) > 0
     for a, b in zip(outs[8][:2], outs[9][:2]):
         assert torch.equal(a, b)
@@ -257,7 +263,7 @@ def test_ppo_minibatch_flag_combinations_incl_dual_clip_vs_oracle(M, flags):
     check(lib().mansy_ppo_minibatch_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(d['obs']), None,
                                          ptr(d['act']), ptr(d['adv']), ptr(d['logp']), ptr(d['v']), ptr(d['ret']), len(obs), 0.2, 0.5, 0.02,
                                          int(okw['norm_adv']), int(okw['value_clip']), float(okw['dual_clip'] or 0.0), 0.0, 5e-4, 1e-2, 0, -1, 0,
-                                         ptr(stats), ptr(eng.workspace()), eng.max_batch, 0, None, 0, -1, stream_ptr()), 'ppo_mb')
+                                         ptr(stats), ptr(eng.workspace()), eng.max_batch, 0, None, 0, eng.prec, stream_ptr()), 'ppo_mb')
     np.testing.assert_allclose(stats.cpu().numpy(), [loss, clip, vf, ent], rtol=2e-5, atol=2e-6)
     for n_, o, p in zip([n for n, _ in f.table], f.offsets, f.params):
         got = f.flat_g[o:o + p.numel()].view(p.shape).cpu().numpy()
@@ -439,7 +445,7 @@ def test_update_teacher_forced_every_minibatch_step(M):
                 check(lib().mansy_ppo_minibatch_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(obs_d), ptr(idx),
                                                      ptr(act_d), ptr(data['adv']), ptr(data['logp_old']), ptr(data['v_s']), ptr(data['returns']),
                                                      idx.numel(), 0.2, 0.5, 0.02, 1, 1, 0.0, 1.0, lr, wd, f.step, *f.tail(), ptr(stats),
-                                                     ptr(eng.workspace()), eng.max_batch, 0, None, 0, -1, stream_ptr()), 'mansy_ppo_minibatch_step')
+                                                     ptr(eng.workspace()), eng.max_batch, 0, None, 0, eng.prec, stream_ptr()), 'mansy_ppo_minibatch_step')
                 torch.cuda.synchronize()
                 np.testing.assert_allclose(stats.cpu().numpy(), rows[k], rtol=1e-5, atol=3e-6, err_msg=f'{(T, N, it, k)}')
                 n_el = n_bad = 0
@@ -591,7 +597,7 @@ def test_behaviour_cloning_steps_then_ppo_with_per_parameter_adam_steps(M):
         assert f.tail()[1] == k + 1
         check(lib().mansy_ppo_minibatch_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(d['obs']), None,
                                              ptr(d['act']), ptr(d['adv']), ptr(d['logp']), ptr(d['v']), ptr(d['ret']), len(obs), 0.2, 0.5, 0.02, 1, 1, 0.0,
-                                             1.0, 5e-4, 1e-2, f.step, *f.tail(), ptr(stats), ptr(eng.workspace()), eng.max_batch, 0, None, 0, -1, stream_ptr()),
+                                             1.0, 5e-4, 1e-2, f.step, *f.tail(), ptr(stats), ptr(eng.workspace()), eng.max_batch, 0, None, 0, eng.prec, stream_ptr()),
               'ppo_mb')
         np.testing.assert_allclose(stats[0].item(), loss.item(), rtol=5e-5, atol=5e-6)
     compare('after PPO steps', 6e-6)
