@@ -193,16 +193,16 @@ def _gemm_prof(L, fn, reps):
     return ms.value, n.value, fl.value
 
 
-def bench_ppo(rank, world, dev, mdist, cycles=5, warmup=2, n_env=256, steps_per_env=16, rollout_probe=True):
-    """PPO env-steps/s (BASELINE configs[2]/[3]): 256 vectorised trace-sim envs per GPU on synthetic bench-shaped tables,
-    one cycle = collect 16 steps/env (4096 transitions/GPU) -> train_identifier (2 rounds) -> relabel -> PPO update
-    (minibatch 512, repeat 2), i.e. run_mansy.py --train --train-identifier --use-identifier with step_per_collect=4096."""
+QOE_TRAIN = ((7, 1, 1), (1, 7, 1), (1, 1, 7), (3, 3, 3))          # bitrate_selection/config.yml:142 (train / valid preferences)
+QOE_TEST = ((5, 1, 3), (2, 4, 3), (1, 3, 5), (4, 4, 1))           # config.yml:144 (test preferences)
+
+
+def _ppo_policy(dev, rank=0, precision=None):
+    """run_mansy.py:205-251's nets + PPOPolicy with the reference's hyper-parameters, random-init (orthogonal, as the reference)."""
     import numpy as np
     import torch
-    import torch.distributed as dist
-    from mansy_immersivevideostreaming_amd.bitrate_selection.envs.mansy_env import EnvTables, MANSYVecEnv
     from mansy_immersivevideostreaming_amd.bitrate_selection.models import mansy as mm
-    from mansy_immersivevideostreaming_amd.bitrate_selection.models.mansy_ppo import PPOPolicy, RolloutBuffer, VecCollector
+    from mansy_immersivevideostreaming_amd.bitrate_selection.models.mansy_ppo import PPOPolicy
 
     class A:
         use_identifier, lamb = True, 0.5
@@ -218,6 +218,156 @@ def bench_ppo(rank, world, dev, mdist, cycles=5, warmup=2, n_env=256, steps_per_
     pol = PPOPolicy(actor, critic, optim, None, discount_factor=0.95, max_grad_norm=1.0, eps_clip=0.2, vf_coef=0.5, ent_coef=0.02,
                     reward_normalization=1, advantage_normalization=1, value_clip=1, gae_lambda=0.95, action_space=15, args=A(),
                     identifier=ident, identifier_optim=ioptim).to(dev)
+    if precision is not None:
+        pol.engine.precision = precision
+    return pol
+
+
+def _ppo_cycle_time(pol, dev, cycles, warmup, n_env=256, steps_per_env=16, qoe_weights=QOE_TRAIN, seed=5):
+    """(ms per cycle, library launches per cycle incl. the rollout graph's) of collect -> train_identifier (2 rounds) -> relabel + PPO update."""
+    import torch
+    from mansy_immersivevideostreaming_amd._lib import lib
+    from mansy_immersivevideostreaming_amd.bitrate_selection.envs.mansy_env import EnvTables, MANSYVecEnv
+    from mansy_immersivevideostreaming_amd.bitrate_selection.models.mansy_ppo import RolloutBuffer, VecCollector
+    tables = EnvTables.synthetic(dev, seed=5, qoe_weights=qoe_weights, train_identifier_reward=True, n_sample=max(240, n_env))
+    venv = MANSYVecEnv(tables, n_env, seed=seed, index_offset=0, worker_num=n_env)
+    col = VecCollector(pol, venv, seed=seed)
+    buf = RolloutBuffer(steps_per_env, n_env, dev)
+
+    def cycle():
+        col.collect(steps_per_env * n_env, buf)
+        pol.train_identifier(buf, 2, verbose=False)
+        return pol.update(0, buf, is_train=True, batch_size=512, repeat=2)
+    for _ in range(warmup):
+        cycle()
+    torch.cuda.synchronize()
+    n0 = lib().mansy_prof_launch_count()
+    t0 = time.perf_counter()
+    for _ in range(cycles):
+        res = cycle()
+    n1 = lib().mansy_prof_launch_count()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    import numpy as np
+    loss = float(np.mean(res['loss']))
+    return dt / cycles * 1e3, (n1 - n0) / float(cycles) + (col.graph_launches if col.use_graph and col._graph is not None else 0), loss
+
+
+def bench_ppo_dp_form(dev, mdist, cycles=6, warmup=2):
+    """VERDICT r04 #1a: what data parallelism costs a rank BEFORE any wire time, measured on one MI355X.  The same PPO cycle three ways:
+    fused (single process: gradient norm, clip and Adam ride on the step's own launches), and the data-parallel FORM at world 1 with the
+    average really issued -- the hand-written peer kernel on a one-rank context (csrc/xgmi.hip) and the library collective (RCCL AVG over a
+    one-rank process group).  `implied_ceiling_8gpu` = 8 x fused / dp: the best 1 -> 8 scaling this form allows if the wire were free."""
+    import torch
+    import torch.distributed as dist
+    out = {'workload': '256 envs x 16 steps, identifier 2 rounds + relabel + PPO update (minibatch 512, repeat 2): 16 + 2 gradient averages per cycle',
+           'cycles': cycles}
+    ms, nl, _ = _ppo_cycle_time(_ppo_policy(dev), dev, cycles, warmup)
+    out['fused'] = {'ms_per_cycle': round(ms, 3), 'library_launches_per_cycle': round(nl, 1)}
+    for key, in_slot in (('dp_peer_kernel', True), ('dp_peer_kernel_copy_form_r04', False)):
+        pol = _ppo_policy(dev)
+        pol.peer_in_slot = in_slot      # True (round 5): gradients produced straight in the exchange slot; False: copied into it by the collective launch
+        pol.set_data_parallel(1, None, peer=True, force=True)
+        ms_x, nl_x, _ = _ppo_cycle_time(pol, dev, cycles, warmup)
+        pol._check_peers()
+        out[key] = {'ms_per_cycle': round(ms_x, 3), 'library_launches_per_cycle': round(nl_x, 1), 'vs_fused': round(ms_x / ms, 3),
+                    'us_per_average': round((ms_x - ms) * 1e3 / 18, 2), 'implied_ceiling_8gpu': round(8 * ms / ms_x, 2)}
+    try:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if 'MASTER_PORT' not in os.environ:
+            import socket
+            with socket.socket() as s:
+                s.bind(('127.0.0.1', 0))
+                os.environ['MASTER_PORT'] = str(s.getsockname()[1])
+        os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1'); os.environ.setdefault('LOCAL_RANK', '0')
+        mdist.init_process_group(backend='nccl', force=True)
+        pol = _ppo_policy(dev)
+        pol.set_data_parallel(1, mdist.make_grad_sync(1, force=True), peer=False, force=True)
+        ms_r, nl_r, _ = _ppo_cycle_time(pol, dev, cycles, warmup)
+        out['dp_rccl'] = {'ms_per_cycle': round(ms_r, 3), 'library_launches_per_cycle': round(nl_r, 1), 'vs_fused': round(ms_r / ms, 3),
+                          'us_per_average': round((ms_r - ms) * 1e3 / 18, 2), 'implied_ceiling_8gpu': round(8 * ms / ms_r, 2),
+                          'note': 'launch counts exclude RCCL\'s own kernels'}
+        dist.destroy_process_group()
+    except Exception as e:          # noqa: BLE001 -- a box without a usable RCCL: say so instead of losing the line
+        out['dp_rccl'] = {'error': str(e)[:200]}
+    return out
+
+
+def bench_ppo_c5(dev, cycles=5, warmup=2):
+    """BASELINE configs[4] on one GPU (its per-GPU share): the PPO cycle over the 8-preference table (config.yml:141-144: 4 train + 4 test
+    vectors in one vectorised environment), identifier training on, dense products in the bf16 modes ("bf16 MFMA")."""
+    out = []
+    for mode in ('f32', 'bf16x3', 'bf16'):
+        ms, nl, loss = _ppo_cycle_time(_ppo_policy(dev, precision=mode), dev, cycles, warmup, qoe_weights=QOE_TRAIN + QOE_TEST)
+        eps = 256 * 16 / ms * 1e3
+        nprod = {'f32': 1, 'bf16x3': 3, 'bf16': 1}[mode]
+        peak = PEAK_F32_MFMA_TFLOPS if mode == 'f32' else PEAK_BF16_MFMA_TFLOPS
+        out.append({'dtype': mode, 'metric': 'PPO env-steps/sec', 'value': round(eps, 1), 'unit': 'env-steps/s', 'ms_per_cycle': round(ms, 3),
+                    'library_launches_per_cycle': round(nl, 1), 'final_loss': loss,
+                    'roofline': {'bound': 'mfma', 'achieved': round(eps * PPO_FLOP_PER_ENV_STEP * nprod / 1e12, 3), 'peak': peak, 'unit': 'TFLOP/s',
+                                 'frac': round(eps * PPO_FLOP_PER_ENV_STEP * nprod / 1e12 / peak, 5),
+                                 'launch_floor_ms': round(nl * LAUNCH_FLOOR_US * 1e-3, 3),
+                                 'note': 'the cycle is a chain of ~200 dependent launches of 5-12 us: precision changes the arithmetic of its products, not its time'}})
+    return {'config': {'workload': 'BASELINE configs[4], per-GPU share: 256 envs over the 8-preference table (4 train + 4 test QoE vectors), identifier '
+                                   'training (2 rounds) + relabel + PPO update, 16 steps per env per collect, synthetic Jin2022/4G-shaped tables'},
+            'modes': out}
+
+
+def bench_vp_small(dev, steps=30, warmup=5):
+    """The reference's REAL batch sizes: BASELINE configs[0] on the GPU (B = 32, hist 10, pred 10) and the README's training
+    command (B = 512, hist 5, pred 15: README.md:139, run_models.py:143,196).  Launch-bound: ms per step, library launches per step."""
+    import numpy as np
+    import torch
+    from mansy_immersivevideostreaming_amd._lib import lib
+    from mansy_immersivevideostreaming_amd.viewport_prediction.models import ViewportTransformerMTIO, FusedAdamW
+    out = []
+    for name, B, S, T in (('configs[0] on the GPU', 32, 10, 10), ('README training command', 512, 5, 15)):
+        torch.manual_seed(5); random.seed(5); np.random.seed(5)
+        m = ViewportTransformerMTIO(in_channel=2, fut_window=T, d_model=512, dim_feedforward=512, device=dev).to(dev)
+        m.train()
+        opt = FusedAdamW(m, lr=1e-4)
+        h, c, f = (t.to(dev) for t in synthetic_trajectories(B, S, T, seed=5))
+        for _ in range(warmup):
+            m.train_step(h, c, f, opt)
+        torch.cuda.synchronize()
+        n0 = lib().mansy_prof_launch_count()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = m.train_step(h, c, f, opt)
+        n1 = lib().mansy_prof_launch_count()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        m.eval()
+        with torch.no_grad():
+            for _ in range(3):
+                m.sample(h, c)
+            torch.cuda.synchronize()
+            s0 = lib().mansy_prof_launch_count()
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                m.sample(h, c)
+            s1 = lib().mansy_prof_launch_count()
+            torch.cuda.synchronize()
+            ms_s = (time.perf_counter() - t1) / steps * 1e3
+        out.append({'name': name, 'B': B, 'S': S, 'T': T, 'ms_per_step': round(ms, 3), 'trajectories_per_s': round(B / ms * 1e3, 1),
+                    'library_launches_per_step': round((n1 - n0) / steps, 1), 'final_loss': float(loss.item()),
+                    'sample_ms': round(ms_s, 3), 'sample_trajectories_per_s': round(B / ms_s * 1e3, 1),
+                    'sample_launches': round((s1 - s0) / steps, 1),
+                    'model_frac_of_f32_peak': round(B / ms * 1e3 * (FLOP_PER_TRAJ if (S, T) == (10, 10) else float('nan')) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+                    if (S, T) == (10, 10) else None})
+    return out
+
+
+def bench_ppo(rank, world, dev, mdist, cycles=5, warmup=2, n_env=256, steps_per_env=16, rollout_probe=True):
+    """PPO env-steps/s (BASELINE configs[2]/[3]): 256 vectorised trace-sim envs per GPU on synthetic bench-shaped tables,
+    one cycle = collect 16 steps/env (4096 transitions/GPU) -> train_identifier (2 rounds) -> relabel -> PPO update
+    (minibatch 512, repeat 2), i.e. run_mansy.py --train --train-identifier --use-identifier with step_per_collect=4096."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from mansy_immersivevideostreaming_amd.bitrate_selection.envs.mansy_env import EnvTables, MANSYVecEnv
+    from mansy_immersivevideostreaming_amd.bitrate_selection.models.mansy_ppo import RolloutBuffer, VecCollector
+    pol = _ppo_policy(dev, rank)
     # The 16 + 2 gradient averages of a cycle are latency-bound (1.7 MB / 1.05 MB, each on the critical path).  Two implementations: the
     # library collective (RCCL) and the hand-written one-shot all-reduce over hipIpc-mapped peer memory (csrc/xgmi.hip).  Default: build
     # the second, check it against the first on the same data, time both on THIS machine's links and keep the faster correct one
@@ -676,6 +826,9 @@ def main():
         if world == 1:      # single-GPU extras (no collectives inside, but keep every rank's tail identical at N > 1)
             out['tertiary'] = bench_expert(dev, cpu=not args.no_cpu_baseline)
             out['inference'] = bench_vp_inference(model, h, c, f)
+            out['small_batch'] = bench_vp_small(dev)
+            out['configs4'] = bench_ppo_c5(dev)
+            out['secondary']['dp_form'] = bench_ppo_dp_form(dev, mdist)      # (last: it brings up a one-rank RCCL group)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

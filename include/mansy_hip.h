@@ -65,10 +65,11 @@ typedef struct mansy_vp_config {
   float ln_eps, bn_eps, bn_momentum;
   int max_len;                 /* rows of the positional table (5000) */
   int bn_sync_world;           /* data-parallel ranks sharing DistillLayer BatchNorm statistics (<= 1: local) */
-  int two_stream;              /* 1: the decoder recurrence runs as two half-batches on two streams (products of one half under the
-                                * attention / LayerNorm passes of the other; needs B >= 256 and even, else ignored).  Same function,
-                                * bit-identical forward.  The host mirror turns it on (sample() +4 %, train step +1.8 % at B = 4096);
-                                * per-kernel timings are taken with it off (concurrent kernels stretch each other's durations). */
+  int two_stream;              /* the decoder recurrence as two half-batches on two streams (products of one half under the attention /
+                                * LayerNorm passes of the other): 0 = never, 1 = where it pays (even B >= 2048: sample() +4 %, train step
+                                * +2 % at B = 4096; below that the step is a chain of latency-bound launches and the split only doubles
+                                * them), 2 = wherever the halves are whole (even B >= 256).  Same function, bit-identical forward.
+                                * Per-kernel timings are taken with it off (concurrent kernels stretch each other's durations). */
   int precision;               /* MANSY_PREC_* of this call's dense products */
   mansy_bn_sync_fn bn_sync_fn; /* SyncBN / gradient-ready hook of this call; NULL with bn_sync_world > 1 is MANSY_EINVAL (ABI 8: there is */
   void* bn_sync_user;          /*   no process-wide registration to fall back to) */
@@ -275,9 +276,13 @@ int mansy_clip_grad_adam(float* flat_p, float* flat_g, float* flat_m, float* fla
 /* Data-parallel form of the chained step's last launch (after the ranks averaged the raw gradients of a step = 0 call): clip by the
  * global norm, Adam(L2), zero flat_g, re-pack the updated parameters into the workspace's packed images and prepare the next
  * minibatch (next_mb > 0) -- the next mansy_ppo_minibatch_step(step = 0) then passes chain_in = 1.  Actor-critic buffers only. */
+/* next_flat_g (ABI 8; nullable = flat_g): the buffer the NEXT mansy_ppo_minibatch_step(step = 0) will use as its flat_g / grads[] -- zero-filled
+ * here instead of flat_g.  The peer-memory form (mansy_xg_reduce_avg) produces each step's gradients in one of the rank's two exchange slots and
+ * averages them into flat_g; the next step's gradients go into the other slot. */
 int mansy_ppo_dp_tail(const float* const* params, float* flat_p, float* flat_g, float* flat_m, float* flat_v, long long n_flat,
                       float max_grad_norm, float lr, float weight_decay, int step, double* scratch, int have_sumsq, const float* obs_all,
-                      const float* adv_all, const int* next_idx, int next_mb, void* workspace, int max_batch, int precision, void* stream);
+                      const float* adv_all, const int* next_idx, int next_mb, float* next_flat_g, void* workspace, int max_batch, int precision,
+                      void* stream);
 
 /* ------------------------------------------------------------------ one-shot gradient all-reduce over peer-mapped memory (xGMI)
  * The data-parallel PPO update averages a 1.7 MB / 1.05 MB flat gradient 16 + 2 times per 2.6 ms cycle, every time on
@@ -296,6 +301,14 @@ int mansy_xg_import(void* ctx, const mansy_xg_handle* all /* [world], rank order
 int mansy_xg_set_timeout_ms(void* ctx, double ms);
 int mansy_xg_allreduce_avg(void* ctx, float* g /* in place */, long long n, double* sumsq_parts /* [MANSY_CLIP_SCRATCH_DOUBLES] or NULL */,
                            void* stream);
+/* Round-5 form, no copy in front of the flag: the rank's two exchange slots ARE its flat gradient buffers.  The gradient kernels of a step use
+ * slot mansy_xg_next_slot(ctx) (0 / 1; pointers from mansy_xg_slot_ptrs, n floats each, 16-byte aligned, fine-grained device memory) as flat_g /
+ * grads[]; mansy_xg_reduce_avg then publishes that slot, waits (bounded) for every peer's, sums all ranks' slots in rank order and writes the
+ * average to g_out (ordinary device memory) + the partial sums of squares; the slots alternate with every call.  Measured on one MI355X at
+ * world 1 (everything but wire time): DESIGN.md section 6. */
+int mansy_xg_slot_ptrs(void* ctx, float** slot0, float** slot1);
+int mansy_xg_next_slot(void* ctx);
+int mansy_xg_reduce_avg(void* ctx, float* g_out, long long n, double* sumsq_parts /* [MANSY_CLIP_SCRATCH_DOUBLES] or NULL */, void* stream);
 int mansy_xg_status(void* ctx);
 int mansy_xg_destroy(void* ctx);
 

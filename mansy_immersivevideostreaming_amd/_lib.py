@@ -120,12 +120,15 @@ _PROTOS = {
                                  c_float, c_float, c_int, c_ll, c_int, P, P, c_int, c_int, P, c_int, c_int, P],
     'mansy_bc_step': [P, P, P, P, P, P, c_ll, c_ll, P, P, c_int, c_float, c_float, c_float, c_int, P, P, c_int, c_int, P],
     'mansy_clip_grad_adam': [P, P, P, P, c_ll, c_float, c_float, c_float, c_int, c_ll, c_int, P, c_int, P],
-    'mansy_ppo_dp_tail': [P, P, P, P, P, c_ll, c_float, c_float, c_float, c_int, P, c_int, P, P, P, c_int, P, c_int, c_int, P],
+    'mansy_ppo_dp_tail': [P, P, P, P, P, c_ll, c_float, c_float, c_float, c_int, P, c_int, P, P, P, c_int, P, P, c_int, c_int, P],
     'mansy_xg_create': [c_ll, c_int, c_int, P],
     'mansy_xg_export': [P, P],
     'mansy_xg_import': [P, P],
     'mansy_xg_set_timeout_ms': [P, ctypes.c_double],
     'mansy_xg_allreduce_avg': [P, P, c_ll, P, P],
+    'mansy_xg_slot_ptrs': [P, P, P],
+    'mansy_xg_next_slot': [P],
+    'mansy_xg_reduce_avg': [P, P, c_ll, P, P],
     'mansy_xg_status': [P],
     'mansy_xg_destroy': [P],
     'mansy_a2c_num_params': [],

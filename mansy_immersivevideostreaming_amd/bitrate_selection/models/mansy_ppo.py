@@ -223,19 +223,27 @@ class PPOPolicy(nn.Module):
         self.overlap_identifier_sync = True   # data parallel: the identifier's gradient averages fly under process_fn's evaluation passes
         self._pre_eval = None
         self._pinned = {}
+        self.peer_in_slot = True      # peer-memory averages: gradients are produced straight in the exchange slot (no copy in front of the flag)
+        self._slot_tabs = {}
 
-    def set_data_parallel(self, world, grad_sync, peer=False):
+    def set_data_parallel(self, world, grad_sync, peer=False, force=False):
         """One process per GPU: `grad_sync(flat_grad)` averages a flat gradient buffer over ranks (dist.make_grad_sync).
         peer=True: the hand-written one-shot all-reduce over peer-mapped memory (dist.PeerGradSync, csrc/xgmi.hip) for both flat
         buffers instead -- one launch that also leaves the gradient's sums of squares for the clip.  peer='auto': build it, check it
         against `grad_sync` on the same data, time both, and use it only if every rank finds it correct and faster
-        (dist.probe_peer_grad_sync; the decision and the two timings are kept in `self.grad_sync_report`)."""
+        (dist.probe_peer_grad_sync; the decision and the two timings are kept in `self.grad_sync_report`).
+        force=True (bench.py's `dp_form` leg): take the data-parallel FORM of the update at world 1 too -- raw gradients, the average really
+        issued (grad_sync over a one-rank group, or the peer kernel on a one-rank context), then clip + Adam as a launch of its own --
+        i.e. everything a rank pays for data parallelism except the wire time."""
         self.world, self.grad_sync = int(world), grad_sync
+        if force and grad_sync is None:
+            self.grad_sync = lambda flat_g: None          # the peer kernel does the work; a library sync was not asked for
         for old in (getattr(self, '_peer', None) or {}).values():      # a second call: release the previous hipIpc mappings / slots
             old.close()
         self._peer = {}
+        self._slot_tabs = {}
         self.grad_sync_report = {'chosen': 'library' if self.world > 1 else 'none'}
-        if peer and self.world > 1:
+        if peer and (self.world > 1 or force):
             import torch.distributed as tdist
             from ...dist import PeerGradSync, probe_peer_grad_sync
             flats = [f for f in (self.engine.ac, self.engine.idn) if f is not None]
@@ -246,8 +254,9 @@ class PPOPolicy(nn.Module):
                     if f.flat_p.numel() in peers:
                         self._peer[id(f)] = peers[f.flat_p.numel()]
             else:
+                rank = tdist.get_rank() if tdist.is_initialized() else 0
                 for f in flats:
-                    self._peer[id(f)] = PeerGradSync(f.flat_p.numel(), self.world, tdist.get_rank(), f.flat_p.device)
+                    self._peer[id(f)] = PeerGradSync(f.flat_p.numel(), self.world, rank, f.flat_p.device)
                 self.grad_sync_report = {'chosen': 'peer', 'reason': 'forced'}
 
     def _check_peers(self):
@@ -275,6 +284,22 @@ class PPOPolicy(nn.Module):
         slot[1].record(torch.cuda.current_stream(dev))
         return out
 
+    def _grad_target(self, f):
+        """(flat_g pointer, grads[] pointer table) the gradient kernels of the NEXT step on `f` must use.  Single process, library collective,
+        or peer_in_slot off: the flat gradient buffer.  Peer-memory averages (round 5): the exchange slot the next reduce publishes, so that
+        the collective launch has nothing to copy -- it publishes, waits and sums (dist.PeerGradSync.reduce_into)."""
+        peer = self._peer.get(id(f)) if getattr(self, '_peer', None) else None
+        if peer is None or not self.peer_in_slot:
+            _, garr = f.pointers(grads=True)
+            return ptr(f.flat_g), garr
+        s = peer.next_slot()
+        tab = self._slot_tabs.get((id(f), s))
+        if tab is None:
+            base = peer.slot_ptrs()[s]
+            garr = (ctypes.c_void_p * len(f.offsets))(*[base + 4 * o for o in f.offsets])
+            tab = self._slot_tabs[(id(f), s)] = (ctypes.c_void_p(base), garr)
+        return tab
+
     def _sync_clip_adam(self, f, max_norm, lr, wd, tail=None, overlap=None):
         """Data-parallel second half of a step: average the raw local gradients over the ranks, then global-norm clip + Adam.
         tail = (data, next_idx or None): the chained form (actor-critic, clipped): the clip + Adam launch also zeroes the
@@ -285,8 +310,12 @@ class PPOPolicy(nn.Module):
         dev = f.flat_p.device
         scratch = torch.empty(64, dtype=torch.float64, device=dev)      # MANSY_CLIP_SCRATCH_DOUBLES
 
+        in_slot = peer is not None and self.peer_in_slot
+
         def average():
-            if peer is not None:
+            if in_slot:
+                peer.reduce_into(f.flat_g, scratch)      # the step's gradients are in the slot already: publish, wait, sum -> f.flat_g
+            elif peer is not None:
                 peer(f.flat_g, scratch)
             else:
                 self.grad_sync(f.flat_g)
@@ -308,10 +337,11 @@ class PPOPolicy(nn.Module):
         if tail is not None:
             data, nxt = tail
             arr, _ = f.pointers()
+            next_g = self._grad_target(f)[0] if in_slot else None      # the slot the next step accumulates into: zeroed by this launch
             check(lib().mansy_ppo_dp_tail(arr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), float(max_norm), lr, wd, f.step,
                                           ptr(scratch), int(peer is not None), ptr(data['obs']), ptr(data['adv']), ptr(nxt),
-                                          nxt.numel() if nxt is not None else 0, ptr(self.engine.workspace()), self.engine.max_batch, self.engine.prec,
-                                          stream_ptr(f.flat_p.device)), 'mansy_ppo_dp_tail')
+                                          nxt.numel() if nxt is not None else 0, next_g, ptr(self.engine.workspace()), self.engine.max_batch,
+                                          self.engine.prec, stream_ptr(f.flat_p.device)), 'mansy_ppo_dp_tail')
             return
         check(lib().mansy_clip_grad_adam(ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), float(max_norm), lr, wd, f.step,
                                          *f.tail(), ptr(scratch), int(peer is not None), stream_ptr(f.flat_p.device)), 'mansy_clip_grad_adam')
@@ -393,7 +423,10 @@ class PPOPolicy(nn.Module):
         arr, garr = f.pointers(grads=True)
         loss = torch.empty((), dtype=torch.float32, device=obs.device)
         dp = self.grad_sync is not None and step > 0
-        check(lib().mansy_identifier_train_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(obs), ptr(rows), B, lr, wd,
+        gptr = ptr(f.flat_g)
+        if dp:
+            gptr, garr = self._grad_target(f)
+        check(lib().mansy_identifier_train_step(arr, garr, ptr(f.flat_p), gptr, ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(obs), ptr(rows), B, lr, wd,
                                                 -1 if dp else step, ptr(loss), ptr(eng.workspace()), eng.max_batch, eng.prec, stream_ptr(obs.device)),
               'mansy_identifier_train_step')
         if dp:
@@ -552,6 +585,9 @@ class PPOPolicy(nn.Module):
             last_of_pass = s + 1 < len(flat) and flat[s + 1][0] != pi
             nxt = flat[s + 1][2] if (chain and s + 1 < len(flat) and not (recompute and last_of_pass)) else None
             # (_recompute_returns rewrites data['v_s'] / ['returns'] / ['adv'] IN PLACE: the pointers converted above still hold)
+            if dp:                              # (peer-memory averages: this step's gradient buffer is the exchange slot the next reduce publishes)
+                gptr, garr_s = self._grad_target(f)
+                fixed_head = (arr, garr_s, fixed_head[2], gptr) + fixed_head[4:]
             check(step_fn(*fixed_head, ptr(idx), *fixed_mid, idx.numel(), *hyper, 0 if dp else f.step, *f.tail(), ptr(stats_all[pi][k]), ws_ptr, eng.max_batch,
                           int(chain and s > 0 and not first_of_later_pass), ptr(None if dp else nxt), nxt.numel() if (nxt is not None and not dp) else 0, eng.prec,
                           st_ptr),

@@ -877,7 +877,7 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, c
 //    the OTHER set of gradient-norm slots (the sets alternate with the Adam step count, so this launch can still read its own).
 struct TailTab { long long off[28]; int numel[28]; };       // flat offsets / sizes of the 28 unique actor-critic tensors, table order
 struct TailNext { const float* g_src; const int* g_idx; float* g_dst; int g_rows; const float* adv; float* adv_stats; float* dbbd; double* parts_next; };
-__global__ __launch_bounds__(256) void step_tail_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+__global__ __launch_bounds__(256) void step_tail_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ gz, float* __restrict__ m, float* __restrict__ v,
                                                        long long n, float lr, float b1, float b2, float eps, float wd, float bc1, float sqrt_bc2,
                                                        const double* __restrict__ parts, float max_norm, TailTab tab, float* __restrict__ Wbd,
                                                        float* __restrict__ bbd, float* __restrict__ Wfc2, TailNext nx, int adam_blocks) {
@@ -920,10 +920,10 @@ __global__ __launch_bounds__(256) void step_tail_kernel(float* __restrict__ p, f
   }
   if (full) {
     *reinterpret_cast<float4*>(p + i) = *reinterpret_cast<const float4*>(pn); *reinterpret_cast<float4*>(m + i) = *reinterpret_cast<const float4*>(mo);
-    *reinterpret_cast<float4*>(v + i) = *reinterpret_cast<const float4*>(vo); *reinterpret_cast<float4*>(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(v + i) = *reinterpret_cast<const float4*>(vo); *reinterpret_cast<float4*>(gz + i) = make_float4(0.f, 0.f, 0.f, 0.f);
   } else {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) if (i + q < n) { p[i + q] = pn[q]; m[i + q] = mo[q]; v[i + q] = vo[q]; g[i + q] = 0.f; }
+    for (int q = 0; q < 4; ++q) if (i + q < n) { p[i + q] = pn[q]; m[i + q] = mo[q]; v[i + q] = vo[q]; gz[i + q] = 0.f; }
   }
   // which tensor? (offsets ascending; the 256-byte alignment gaps between tensors belong to none)
   int lo = 0, hi = 27;
@@ -1213,8 +1213,10 @@ struct PEng {
     return MANSY_OK;
   }
   // clip + Adam + gradient zero-fill + re-pack of the updated parameters + (next != null) the next minibatch's gather / statistics
+  // g_zero: the buffer the NEXT step accumulates its gradients into (zero-filled here); null = flat_g itself.  The data-parallel peer form hands over
+  // the other exchange slot: this step's gradients were produced in one slot and averaged into flat_g, the next step's go into the other slot.
   int step_tail(const float* const* params, float* flat_p, float* flat_g, float* m, float* v, long long n, float max_norm, float lr, float wd, int step,
-                double* parts_cur, double* parts_next, const float* obs_all, const int* next_idx, int next_mb, const float* adv_all) {
+                double* parts_cur, double* parts_next, const float* obs_all, const int* next_idx, int next_mb, const float* adv_all, float* g_zero = nullptr) {
     TailTab tab;
     static const std::vector<ParamInfo> t = net_table(0);       // (built once: 28 entries with std::string names -- this runs in every minibatch step)
     MANSY_REQUIRE(t.size() == 28, "step_tail: parameter table changed");
@@ -1231,7 +1233,8 @@ struct PEng {
     const int adam_blocks = (int)mansy_ceil_div(mansy_ceil_div(n, 4), 256);       // four elements per thread
     const int rider_blocks = 1 + (next_idx ? (int)mansy_ceil_div((long long)next_mb * (OBS_LD / 4), 256) : 0);
     const double bc1 = 1.0 - pow(0.9, (double)step), bc2 = 1.0 - pow(0.999, (double)step);
-    MANSY_LAUNCH(step_tail_kernel, dim3(adam_blocks + rider_blocks), dim3(256), 0, st, flat_p, flat_g, m, v, n, lr, 0.9f, 0.999f, 1e-8f, wd,
+    MANSY_REQUIRE(!g_zero || (reinterpret_cast<uintptr_t>(g_zero) & 15) == 0, "step_tail: the next gradient buffer must be 16-byte aligned");
+    MANSY_LAUNCH(step_tail_kernel, dim3(adam_blocks + rider_blocks), dim3(256), 0, st, flat_p, (const float*)flat_g, g_zero ? g_zero : flat_g, m, v, n, lr, 0.9f, 0.999f, 1e-8f, wd,
                        (float)bc1, (float)sqrt(bc2), parts_cur, max_norm, tab, W.Wbd, W.bbd, W.Wfc2, nx, adam_blocks);
     MANSY_LAUNCH_CHECK();
     return MANSY_OK;
@@ -1524,13 +1527,13 @@ int mansy_bc_step(const float* const* params, float* const* grads, float* flat_p
 // gathers the next minibatch and takes its advantage statistics, so that the next mansy_ppo_minibatch_step passes chain_in = 1.
 int mansy_ppo_dp_tail(const float* const* params, float* flat_p, float* flat_g, float* flat_m, float* flat_v, long long n_flat, float max_grad_norm,
                       float lr, float weight_decay, int step, double* scratch, int have_sumsq, const float* obs_all, const float* adv_all,
-                      const int* next_idx, int next_mb, void* workspace, int max_batch, int precision, void* stream) {
+                      const int* next_idx, int next_mb, float* next_flat_g, void* workspace, int max_batch, int precision, void* stream) {
   MANSY_REQUIRE(params && flat_p && flat_g && flat_m && flat_v && scratch && step >= 1 && max_grad_norm > 0.f, "ppo_dp_tail: bad arguments");
   MANSY_REQUIRE(next_mb >= 0 && next_mb <= max_batch && (next_mb == 0 || (obs_all && adv_all)), "ppo_dp_tail: bad next minibatch");
   PEng e; RC(setup(workspace, max_batch, precision, (hipStream_t)stream, e));
   if (!have_sumsq) { MANSY_LAUNCH(sumsq_kernel, dim3(NORM_PARTS), dim3(256), 0, e.st, flat_g, n_flat, scratch); MANSY_LAUNCH_CHECK(); }
   return e.step_tail(params, flat_p, flat_g, flat_m, flat_v, n_flat, max_grad_norm, lr, weight_decay, step, scratch, e.W.acc + NORM_PARTS_C, obs_all,
-                     next_idx, next_mb, adv_all);
+                     next_idx, next_mb, adv_all, next_flat_g);
 }
 
 // Global-norm clip (torch clip_grad_norm_ semantics; max_norm <= 0 disables) followed by Adam with L2 weight decay over

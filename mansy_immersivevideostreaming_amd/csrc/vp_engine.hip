@@ -400,7 +400,10 @@ struct Eng {
   // mansy_vp_config::two_stream.  Measured at B = 4096: train step 23.08 -> 22.67 ms (+1.8 %), sample() 507 -> 529 k trajectories/s
   // (+4 %), identical losses.  The host mirror sets it by default; per-kernel timings (bench.py's roofline leg, rocprof kernel
   // stats) are taken with it off, because concurrent kernels stretch each other's durations.
-  bool split_ok() const { return c.two_stream == 1 && B >= 256 && B % 2 == 0; }
+  // Round 5 (profiles/r05_two_stream_sweep.txt): below B = 2048 the step is a latency-bound chain of ~5 us launches whatever the row count, and a second
+  // stream only doubles the launches (B = 512, hist 5 / pred 15: 7.07 ms with the split, 6.11 without; sample() 3.0 vs 2.2 ms); at 1024 it is even; from
+  // 2048 it pays (+4 %).  two_stream = 1: the engine decides (B >= 2048); 2: forced wherever the halves are whole (B >= 256, even: the equivalence test).
+  bool split_ok() const { return B % 2 == 0 && ((c.two_stream == 1 && B >= 2048) || (c.two_stream == 2 && B >= 256)); }
   int fork() {
     static thread_local hipStream_t s2 = nullptr; static thread_local hipEvent_t ev_f = nullptr;      // one side stream per host thread
     if (!s2) { MANSY_HIP_CHECK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking)); MANSY_HIP_CHECK(hipEventCreateWithFlags(&ev_f, hipEventDisableTiming)); }

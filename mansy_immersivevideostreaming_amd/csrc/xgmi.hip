@@ -40,18 +40,24 @@ struct XgCtx {
 };
 
 constexpr int XG_THREADS = 256;        // (1 024-thread workgroups measured 1.4-1.9x slower: profiles/r03_xg_timing.txt history)
+// COPY = true (mansy_xg_allreduce_avg): the gradient arrives in ordinary device memory `g` and is copied into the rank's exchange slot first.
+// COPY = false (mansy_xg_reduce_avg, round 5): the step's gradient kernels wrote straight INTO the slot (the slot IS the flat gradient buffer of
+// that step: mansy_xg_slot_ptrs), so this launch only publishes, waits and sums -- no 1.7 MB copy in front of the flag.
+template <bool COPY>
 __global__ __launch_bounds__(XG_THREADS) void xg_allreduce_kernel(float* __restrict__ g, long long n4, XgPeers peers, float* __restrict__ own_slot,
                                                           unsigned* __restrict__ own_flag, long long slot_off, int rank, int world, unsigned epoch,
                                                           float inv_world, double* __restrict__ parts, unsigned* __restrict__ counter, unsigned target,
                                                           int* __restrict__ err, long long timeout_ticks) {
   const long long gtid = (long long)blockIdx.x * XG_THREADS + threadIdx.x, gsize = (long long)gridDim.x * XG_THREADS;
   // 1. publish this rank's gradient
-  for (long long i0 = gtid; i0 < n4; i0 += gsize * 4) {
-    float4 v[4];
+  if (COPY) {
+    for (long long i0 = gtid; i0 < n4; i0 += gsize * 4) {
+      float4 v[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { const long long i = i0 + (long long)u * gsize; v[u] = reinterpret_cast<const float4*>(g)[i < n4 ? i : n4 - 1]; }
+      for (int u = 0; u < 4; ++u) { const long long i = i0 + (long long)u * gsize; v[u] = reinterpret_cast<const float4*>(g)[i < n4 ? i : n4 - 1]; }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { const long long i = i0 + (long long)u * gsize; if (i < n4) reinterpret_cast<float4*>(own_slot)[i] = v[u]; }
+      for (int u = 0; u < 4; ++u) { const long long i = i0 + (long long)u * gsize; if (i < n4) reinterpret_cast<float4*>(own_slot)[i] = v[u]; }
+    }
   }
   // every storing wave drains its stores, the workgroup meets, then ONE lane releases at system scope (the release is cumulative
   // over the barrier's happens-before) -- a system-scope fence in every thread cost a cache write-back per wave
@@ -65,16 +71,21 @@ __global__ __launch_bounds__(XG_THREADS) void xg_allreduce_kernel(float* __restr
     if (prev + 1u == target) __hip_atomic_store(own_flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   __syncthreads();
-  // 2. wait for every peer's epoch (one polling lane per peer)
-  if (threadIdx.x < world && (int)threadIdx.x != rank) {
-    const long long t0 = wall_clock64();
-    while ((int)(__hip_atomic_load(peers.flag[threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
-      if (wall_clock64() - t0 > timeout_ticks) { timed_out = 1; __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-      __builtin_amdgcn_s_sleep(4);
+  // 2. wait for every peer's epoch: wave 0 polls (one lane per peer, RELAXED loads: an acquire per poll is a cache invalidate per poll), then that
+  // ONE wave acquires at system scope and drains it; the workgroup's barrier orders every other wave's loads behind it (round 5: was an acquire in
+  // every poll and a fence in every wave)
+  if (threadIdx.x < 64) {
+    if ((int)threadIdx.x < world && (int)threadIdx.x != rank) {
+      const long long t0 = wall_clock64();
+      while ((int)(__hip_atomic_load(peers.flag[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
+        if (wall_clock64() - t0 > timeout_ticks) { timed_out = 1; __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
     }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);                // system scope: the peers' slots as published
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
-  __atomic_thread_fence(__ATOMIC_ACQUIRE);                  // system scope: the peers' slots as published
   const bool bad = timed_out != 0;
   // 3. reduce in rank order, average, sum of squares
   // UN elements per thread and round, every load of a round requested before the first is used (a peer's HBM over a link is a
@@ -177,10 +188,34 @@ int mansy_xg_set_timeout_ms(void* ctx, double ms) {
   return MANSY_OK;
 }
 
+// The rank's two exchange slots (n_pad floats each, fine-grained device memory the peers have mapped).  Round-5 form of a data-parallel step:
+// the step's gradient kernels use slot (epoch + 1) & 1 as their flat gradient buffer (mansy_xg_next_slot), then mansy_xg_reduce_avg publishes
+// it, waits for the peers and leaves the average in ordinary device memory; the clip + Adam launch zeroes the OTHER slot for the next step.
+int mansy_xg_slot_ptrs(void* ctx, float** slot0, float** slot1) {
+  XgCtx* c = (XgCtx*)ctx;
+  MANSY_REQUIRE(c && slot0 && slot1, "xg_slot_ptrs: null");
+  *slot0 = c->own + XG_HEADER_FLOATS; *slot1 = c->own + XG_HEADER_FLOATS + c->n_pad;
+  return MANSY_OK;
+}
+int mansy_xg_next_slot(void* ctx) { XgCtx* c = (XgCtx*)ctx; return c ? (int)((c->epoch + 1u) & 1u) : -1; }
+
+static int xg_launch(XgCtx* c, float* g, long long n, double* sumsq_parts, hipStream_t stream, bool copy);
+
+int mansy_xg_reduce_avg(void* ctx, float* g_out, long long n, double* sumsq_parts, void* stream) {
+  XgCtx* c = (XgCtx*)ctx;
+  MANSY_REQUIRE(c && g_out && c->imported, "xg_reduce_avg: context not ready (create -> export -> exchange handles -> import)");
+  MANSY_REQUIRE(n == c->n && (reinterpret_cast<uintptr_t>(g_out) & 15) == 0, "xg_reduce_avg: n must be the context's %lld and g_out 16-byte aligned", c->n);
+  return xg_launch(c, g_out, n, sumsq_parts, (hipStream_t)stream, false);
+}
+
 int mansy_xg_allreduce_avg(void* ctx, float* g, long long n, double* sumsq_parts, void* stream) {
   XgCtx* c = (XgCtx*)ctx;
   MANSY_REQUIRE(c && g && c->imported, "xg_allreduce_avg: context not ready (create -> export -> exchange handles -> import)");
   MANSY_REQUIRE(n == c->n && (reinterpret_cast<uintptr_t>(g) & 15) == 0, "xg_allreduce_avg: n must be the context's %lld and g 16-byte aligned", c->n);
+  return xg_launch(c, g, n, sumsq_parts, (hipStream_t)stream, true);
+}
+
+static int xg_launch(XgCtx* c, float* g, long long n, double* sumsq_parts, hipStream_t stream, bool copy) {
   c->epoch += 1;
   c->launches += 1;
   XgPeers peers;
@@ -195,9 +230,14 @@ int mansy_xg_allreduce_avg(void* ctx, float* g, long long n, double* sumsq_parts
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, dev);
   if (wall_khz <= 0) wall_khz = 100000;
   const long long ticks = (long long)(c->timeout_ms * (double)wall_khz);
-  MANSY_LAUNCH(xg_allreduce_kernel, dim3(XG_BLOCKS), dim3(XG_THREADS), 0, (hipStream_t)stream, g, n / 4, peers, c->own + XG_HEADER_FLOATS + slot_off,
-                     reinterpret_cast<unsigned*>(c->own), slot_off, c->rank, c->world, c->epoch, 1.0f / (float)c->world, sumsq_parts, c->counter,
-                     (unsigned)(c->launches * XG_BLOCKS), c->err, ticks);
+  if (copy)
+    MANSY_LAUNCH(xg_allreduce_kernel<true>, dim3(XG_BLOCKS), dim3(XG_THREADS), 0, stream, g, n / 4, peers, c->own + XG_HEADER_FLOATS + slot_off,
+                       reinterpret_cast<unsigned*>(c->own), slot_off, c->rank, c->world, c->epoch, 1.0f / (float)c->world, sumsq_parts, c->counter,
+                       (unsigned)(c->launches * XG_BLOCKS), c->err, ticks);
+  else
+    MANSY_LAUNCH(xg_allreduce_kernel<false>, dim3(XG_BLOCKS), dim3(XG_THREADS), 0, stream, g, n / 4, peers, c->own + XG_HEADER_FLOATS + slot_off,
+                       reinterpret_cast<unsigned*>(c->own), slot_off, c->rank, c->world, c->epoch, 1.0f / (float)c->world, sumsq_parts, c->counter,
+                       (unsigned)(c->launches * XG_BLOCKS), c->err, ticks);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }

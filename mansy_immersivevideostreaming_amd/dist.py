@@ -200,6 +200,34 @@ class PeerGradSync:
         assert flat_g.is_cuda and flat_g.dtype == torch.float32 and flat_g.numel() == self.n
         self._check(self._lib.mansy_xg_allreduce_avg(self.ctx, ptr(flat_g), self.n, ptr(scratch), stream_ptr(flat_g.device)), 'mansy_xg_allreduce_avg')
 
+    # ---- round 5: no copy in front of the flag.  The two exchange slots ARE the flat gradient buffers of alternate steps: the step's gradient kernels
+    # write into slot `next_slot()`, `reduce_into(out)` publishes it, waits for the peers and leaves the average in `out` (ordinary device memory).
+    def slot_ptrs(self):
+        """(address of slot 0, address of slot 1): n floats each, fine-grained device memory."""
+        import ctypes
+        if getattr(self, '_slots', None) is None:
+            a, b = ctypes.c_void_p(), ctypes.c_void_p()
+            self._check(self._lib.mansy_xg_slot_ptrs(self.ctx, ctypes.byref(a), ctypes.byref(b)), 'mansy_xg_slot_ptrs')
+            self._slots = (int(a.value), int(b.value))
+        return self._slots
+
+    def slot_tensor(self, i):
+        """Slot i as a float32 tensor ALIASING the exchange memory (tests / tools: fill a slot, inspect a raw gradient)."""
+        class _Mem:
+            pass
+        m = _Mem()
+        m.__cuda_array_interface__ = {'shape': (self.n,), 'typestr': '<f4', 'data': (self.slot_ptrs()[i], False), 'version': 2}
+        return torch.as_tensor(m, device=torch.device('cuda', torch.cuda.current_device()))
+
+    def next_slot(self):
+        """Index (0 / 1) of the slot the NEXT reduce_into() publishes: where this step's gradients must be produced."""
+        return int(self._lib.mansy_xg_next_slot(self.ctx))
+
+    def reduce_into(self, out, scratch=None):
+        from ._lib import ptr, stream_ptr
+        assert out.is_cuda and out.dtype == torch.float32 and out.numel() == self.n
+        self._check(self._lib.mansy_xg_reduce_avg(self.ctx, ptr(out), self.n, ptr(scratch), stream_ptr(out.device)), 'mansy_xg_reduce_avg')
+
     def check(self):
         self._check(self._lib.mansy_xg_status(self.ctx), 'mansy_xg_status')
 

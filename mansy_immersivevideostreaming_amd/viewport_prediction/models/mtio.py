@@ -109,10 +109,11 @@ class ViewportTransformerMTIO(nn.Module):
 
     # ------------------------------------------------------------------ construction
     def _cfg(self, B, S, inference=False):
-        # two_stream: None = on (the engine applies it for B >= 256, even: sample() +4 %, train step +1.8 % at B = 4096); True / False
-        # force it.  Per-kernel timings (bench.py's roofline leg, rocprof kernel stats) are taken with it off: concurrent kernels
-        # stretch each other's durations.
-        two = True if self.two_stream is None else bool(self.two_stream)
+        # two_stream: None = where it pays (the engine applies it for even B >= 2048: sample() +4 %, train step +2 % at B = 4096; below that the
+        # step is a chain of latency-bound launches and a second stream only doubles them); True = wherever the halves are whole (even
+        # B >= 256); False = never.  Per-kernel timings (bench.py's roofline leg, rocprof kernel stats) are taken with it off: concurrent
+        # kernels stretch each other's durations.
+        two = 1 if self.two_stream is None else (2 if self.two_stream else 0)
         if self.precision is not None and self.precision not in _lib.PRECISIONS:
             raise _lib.MansyError(f'unknown precision {self.precision!r}: one of f32, bf16, bf16x3, bf16x6')
         cfg = VPConfig(B=B, S=S, T=self.fut_window, d_model=self.d_model, n_head=_N_HEAD, d_ff=self.dim_feedforward,

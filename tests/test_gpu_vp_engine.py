@@ -476,6 +476,37 @@ def test_dropout_mask_policy_loss_curves(MT):
         assert abs(e.mean() - r.mean()) <= 3 * se + 0.05 * r.mean(), (s, e.mean(), r.mean(), se)
 
 
+def test_dropout_mask_policy_loss_curves_d512(MT):
+    """The same bound at the REAL width and on REAL data (the bench times dropout ON, parity is shown with it OFF):
+    tests/golden/dropout_curves_vp_d512.npz holds the loss curves of the IMPORTED reference at d = 512, B = 32 real Jin2022 windows
+    (BASELINE configs[0]), dropout on, 3 dropout seeds x 60 AdamW steps (lr 1e-4) over six fixed batches
+    (tools/gen_golden_dropout_curves_d512.py).  The engine -- one mask per position instead of a fresh mask per recompute -- is
+    trained the same way with 3 seeds of its own; per 20-step window the seed-averaged curves agree within 3 standard errors of the
+    seed-to-seed spread + 5 % of the level, the start is the same and the loss falls as far."""
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'dropout_curves_vp_d512.npz'))
+    d, T, steps, nb = int(z['d']), int(z['T']), int(z['steps']), int(z['nb'])
+    batches = [tuple(torch.from_numpy(z[k][i]).cuda() for k in ('history', 'current', 'future')) for i in range(nb)]
+    ref = z['curves']
+    curves = []
+    for dseed in range(ref.shape[0]):
+        m = MT.ViewportTransformerMTIO(in_channel=2, fut_window=T, d_model=d, dim_feedforward=d, device='cuda', bias=bool(z['bias']),
+                                       seed=7919 * (dseed + 1))
+        m.load_state_dict(vo.make_state_dict(d, int(z['wseed']), bias=bool(z['bias'])))
+        m = m.to('cuda').train()                          # dropout ON: p_pe 0.2, transformer 0.1 (reference defaults)
+        random.seed(int(z['mixseed'])); np.random.seed(int(z['mixseed']))
+        opt = MT.FusedAdamW(m, lr=float(z['lr']))
+        losses = [m.train_step(*batches[i % nb], opt) for i in range(steps)]
+        curves.append(torch.stack(losses).cpu().numpy())
+    eng = np.array(curves)
+    np.testing.assert_allclose(eng[:, 0].mean(), ref[:, 0].mean(), rtol=0.1)         # same start (same weights, same batch)
+    assert eng[:, -10:].mean() <= 1.15 * ref[:, -10:].mean()                          # and it trains as far as the reference does
+    w = 20
+    for s in range(0, steps, w):
+        e, r = eng[:, s:s + w].mean(1), ref[:, s:s + w].mean(1)                       # per-seed window means
+        se = np.sqrt(e.var(ddof=1) / len(e) + r.var(ddof=1) / len(r))
+        assert abs(e.mean() - r.mean()) <= 3 * se + 0.05 * r.mean(), (s, e.mean(), r.mean(), se)
+
+
 def test_two_stream_half_batch_decoder_equals_single_stream(MT):
     """mansy_vp_config.two_stream (model.two_stream) runs the decoder recurrence (forward and backward) as two half-batches on two
     streams -- every launch on the rows [b0, b0 + n) of the full slabs, dropout masks drawn at the rows' own indices

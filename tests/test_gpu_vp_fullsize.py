@@ -85,7 +85,7 @@ def test_bench_size_train_step_vs_oracle_autograd(MT, branch, prec, two_stream):
     m.dropout_p = m.attn_dropout_p = 0.0
     m.precision = prec
     m.two_stream = two_stream
-    assert m._cfg(B, S).two_stream == int(two_stream)
+    assert m._cfg(B, S).two_stream == (2 if two_stream else 0)
     m.train()
     if branch == 'rep':
         m.repeat_prob = 1.0                         # random.random() < 1: the replicate branch

@@ -36,6 +36,9 @@ CASES = [
     ('vp_d64_s5_t15_bias', 64, 5, 15, 6, True, 12, True),
     ('vp_d512_s10_t10_bias', 512, 10, 10, 4, True, 13, False),
     ('vp_d512_s10_t10_nobias', 512, 10, 10, 4, False, 14, False),
+    # the README's own training shape (his 5, fut 15, hid 512: README.md:139, .MISSING_LARGE_BLOBS): Lk = 11..15 self-attention instances and an
+    # M = 3 memory meet the imported model at d = 512 (round 5; `python tools/gen_golden_vp.py vp_d512_s5_t15_bias` writes only this case)
+    ('vp_d512_s5_t15_bias', 512, 5, 15, 4, True, 15, False),
 ]
 
 
@@ -59,7 +62,10 @@ def zero_dropout(model):
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    only = set(sys.argv[1:])
     for name, d, S, T, B, bias, wseed, full in CASES:
+        if only and name not in only:
+            continue
         sd = vo.make_state_dict(d, wseed, bias=bias)
         model = build_reference(d, T, bias, sd)
         assert set(model.state_dict().keys()) == set(sd.keys()), (

@@ -33,6 +33,8 @@ def main():
             acc = acc + gs[r]                                                       # rank order, float32
         want.append(acc * (1.0 / world))
         mine.append(gs[rank].to(dev))
+    SLOT = os.environ.get('XG_SLOT') == '1'
+    slots = [sync.slot_tensor(0), sync.slot_tensor(1)] if SLOT else None
     torch.cuda.synchronize()
     dist.barrier()
     parts = [torch.empty(64, dtype=torch.float64, device=dev) for _ in range(distinct)]
@@ -48,7 +50,11 @@ def main():
                 torch.cuda.synchronize()
                 bad_rounds += sum(int((mine[j].cpu() != want[j]).sum() > 0) for j in range(distinct))
             mine[k].copy_(src[k])
-        sync(mine[k], parts[k])                                                     # in place
+        if SLOT:        # round-5 form: the gradient is produced IN the exchange slot, the collective publishes / waits / sums into mine[k]
+            slots[sync.next_slot()].copy_(mine[k])
+            sync.reduce_into(mine[k], parts[k])
+        else:
+            sync(mine[k], parts[k])                                                 # in place
     e1.record()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -66,7 +72,7 @@ def main():
     torch.cuda.synchronize()
     sync.check()
     mean_ok = bool((x == sum(range(1, world + 1)) / world).all())
-    out = dict(rank=rank, world=world, n=n, iters=iters, mismatched_elements=bad, bad_rounds=bad_rounds, sumsq_rel_err=sq_err, plain_call_ok=mean_ok,
+    out = dict(rank=rank, world=world, n=n, form='slot (+ a device copy into the slot per call)' if SLOT else 'copy', iters=iters, mismatched_elements=bad, bad_rounds=bad_rounds, sumsq_rel_err=sq_err, plain_call_ok=mean_ok,
                us_per_call=round(dt / iters * 1e6, 1), device_us_per_call=round(dev_us, 1))
     gathered = [None] * world
     dist.all_gather_object(gathered, out)
