@@ -246,10 +246,12 @@ def _ppo_cycle_time(pol, dev, cycles, warmup, n_env=256, steps_per_env=16, qoe_w
     for _ in range(cycles):
         res = cycle()
     n1 = lib().mansy_prof_launch_count()
+    t_host = time.perf_counter() - t0           # the host has enqueued everything (it runs ahead of the GPU unless the cycle is host-bound)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     import numpy as np
     loss = float(np.mean(res['loss']))
+    _ppo_cycle_time.host_ms = t_host / cycles * 1e3
     return dt / cycles * 1e3, (n1 - n0) / float(cycles) + (col.graph_launches if col.use_graph and col._graph is not None else 0), loss
 
 
@@ -263,14 +265,14 @@ def bench_ppo_dp_form(dev, mdist, cycles=6, warmup=2):
     out = {'workload': '256 envs x 16 steps, identifier 2 rounds + relabel + PPO update (minibatch 512, repeat 2): 16 + 2 gradient averages per cycle',
            'cycles': cycles}
     ms, nl, _ = _ppo_cycle_time(_ppo_policy(dev), dev, cycles, warmup)
-    out['fused'] = {'ms_per_cycle': round(ms, 3), 'library_launches_per_cycle': round(nl, 1)}
-    for key, in_slot in (('dp_peer_kernel', True), ('dp_peer_kernel_copy_form_r04', False)):
+    out['fused'] = {'ms_per_cycle': round(ms, 3), 'library_launches_per_cycle': round(nl, 1), 'host_enqueue_ms_per_cycle': round(_ppo_cycle_time.host_ms, 3)}
+    for key, in_slot in (('dp_peer_kernel', True), ('dp_peer_kernel_copy_form_r04', False)):      # slot form: one library call per step, as the fused step
         pol = _ppo_policy(dev)
         pol.peer_in_slot = in_slot      # True (round 5): gradients produced straight in the exchange slot; False: copied into it by the collective launch
         pol.set_data_parallel(1, None, peer=True, force=True)
         ms_x, nl_x, _ = _ppo_cycle_time(pol, dev, cycles, warmup)
         pol._check_peers()
-        out[key] = {'ms_per_cycle': round(ms_x, 3), 'library_launches_per_cycle': round(nl_x, 1), 'vs_fused': round(ms_x / ms, 3),
+        out[key] = {'ms_per_cycle': round(ms_x, 3), 'library_launches_per_cycle': round(nl_x, 1), 'host_enqueue_ms_per_cycle': round(_ppo_cycle_time.host_ms, 3), 'vs_fused': round(ms_x / ms, 3),
                     'us_per_average': round((ms_x - ms) * 1e3 / 18, 2), 'implied_ceiling_8gpu': round(8 * ms / ms_x, 2)}
     try:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -284,7 +286,7 @@ def bench_ppo_dp_form(dev, mdist, cycles=6, warmup=2):
         pol = _ppo_policy(dev)
         pol.set_data_parallel(1, mdist.make_grad_sync(1, force=True), peer=False, force=True)
         ms_r, nl_r, _ = _ppo_cycle_time(pol, dev, cycles, warmup)
-        out['dp_rccl'] = {'ms_per_cycle': round(ms_r, 3), 'library_launches_per_cycle': round(nl_r, 1), 'vs_fused': round(ms_r / ms, 3),
+        out['dp_rccl'] = {'ms_per_cycle': round(ms_r, 3), 'library_launches_per_cycle': round(nl_r, 1), 'host_enqueue_ms_per_cycle': round(_ppo_cycle_time.host_ms, 3), 'vs_fused': round(ms_r / ms, 3),
                           'us_per_average': round((ms_r - ms) * 1e3 / 18, 2), 'implied_ceiling_8gpu': round(8 * ms / ms_r, 2),
                           'note': 'launch counts exclude RCCL\'s own kernels'}
         dist.destroy_process_group()

@@ -231,7 +231,8 @@ int mansy_identifier_forward(const float* const* params, const float* obs, int B
                              int max_batch, int precision, void* stream);
 int mansy_identifier_train_step(const float* const* params, float* const* grads, float* flat_p, float* flat_g, float* flat_m,
                                 float* flat_v, long long n_flat, const float* obs, const int* idx /* NULL: rows 0..B of obs; else obs[idx[r]] */,
-                                int B, float lr, float weight_decay, int step, float* loss_out, void* workspace, int max_batch, int precision, void* stream);
+                                int B, float lr, float weight_decay, int step, float* loss_out, void* workspace, int max_batch,
+                                void* xg_ctx /* NULL, or (step > 0) a mansy_xg context: see mansy_ppo_minibatch_step */, int precision, void* stream);
 int mansy_identifier_relabel(const float* const* params, const float* obs, float* rew, float* id_rew, int B, float lamb,
                              void* workspace, int max_batch, int precision, void* stream);
 int mansy_gae_returns(const float* rew, const float* v_s, const float* v_next, const unsigned char* done, int T, int N, double gamma,
@@ -241,7 +242,13 @@ int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, fl
                              const float* adv_all, const float* logp_old_all, const float* v_old_all, const float* ret_all, int mb,
                              float eps_clip, float vf_coef, float ent_coef, int norm_adv, int value_clip, float dual_clip,
                              float max_grad_norm, float lr, float weight_decay, int step, long long tail_from, int tail_step, float* stats,
-                             void* workspace, int max_batch, int chain_in, const int* next_idx, int next_mb, int precision, void* stream);
+                             void* workspace, int max_batch, int chain_in, const int* next_idx, int next_mb, void* xg_ctx, int precision, void* stream);
+/* xg_ctx (ABI 8; NULL = single process): a mansy_xg context of n_flat floats (below) -- the DATA-PARALLEL step as one call: the rank's raw
+ * gradients are produced straight in its exchange slot, ONE more launch than the single-process step publishes the slot, waits (bounded) for
+ * every peer's, sums all ranks' slots in rank order into flat_g and leaves the sums of squares of the average; clip + Adam + the chained
+ * prologue follow as in the single-process step.  Needs the clipped chained form (max_grad_norm > 0, step > 0, no lagged tail).  Every rank
+ * makes the same sequence of calls on its context.  (The library-collective form stays: step = 0 here, the caller's all-reduce,
+ * mansy_ppo_dp_tail.) */
 /* Layout contract of the chained forms (step > 0 with max_grad_norm > 0, and mansy_ppo_dp_tail): their last launch updates four consecutive
  * elements per thread and scatters them into the packed images, so flat_p / flat_g / flat_m / flat_v must be 16-byte aligned and every
  * params[k] must be an ascending view of flat_p that starts at a multiple of 4 floats (the host mirror aligns tensors to 256 bytes);

@@ -113,11 +113,11 @@ _PROTOS = {
     'mansy_policy_env_step': [P, P, c_int, P, P, P, P, c_u32, c_u32, c_int, P, c_int, P, P, P, P, P, P, P, P, c_int, P],
     'mansy_policy_evaluate': [P, P, c_int, P, c_int, P, P, P, c_int, c_int, P],
     'mansy_identifier_forward': [P, P, c_int, P, P, c_int, c_int, P],
-    'mansy_identifier_train_step': [P, P, P, P, P, P, c_ll, P, P, c_int, c_float, c_float, c_int, P, P, c_int, c_int, P],
+    'mansy_identifier_train_step': [P, P, P, P, P, P, c_ll, P, P, c_int, c_float, c_float, c_int, P, P, c_int, P, c_int, P],
     'mansy_identifier_relabel': [P, P, P, P, c_int, c_float, P, c_int, c_int, P],
     'mansy_gae_returns': [P, P, P, P, c_int, c_int, ctypes.c_double, ctypes.c_double, c_int, P, P, P, P, P],
     'mansy_ppo_minibatch_step': [P, P, P, P, P, P, c_ll, P, P, P, P, P, P, P, c_int, c_float, c_float, c_float, c_int, c_int, c_float, c_float,
-                                 c_float, c_float, c_int, c_ll, c_int, P, P, c_int, c_int, P, c_int, c_int, P],
+                                 c_float, c_float, c_int, c_ll, c_int, P, P, c_int, c_int, P, c_int, P, c_int, P],
     'mansy_bc_step': [P, P, P, P, P, P, c_ll, c_ll, P, P, c_int, c_float, c_float, c_float, c_int, P, P, c_int, c_int, P],
     'mansy_clip_grad_adam': [P, P, P, P, c_ll, c_float, c_float, c_float, c_int, c_ll, c_int, P, c_int, P],
     'mansy_ppo_dp_tail': [P, P, P, P, P, c_ll, c_float, c_float, c_float, c_int, P, c_int, P, P, P, c_int, P, P, c_int, c_int, P],

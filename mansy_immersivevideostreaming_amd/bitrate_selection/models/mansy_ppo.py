@@ -224,7 +224,6 @@ class PPOPolicy(nn.Module):
         self._pre_eval = None
         self._pinned = {}
         self.peer_in_slot = True      # peer-memory averages: gradients are produced straight in the exchange slot (no copy in front of the flag)
-        self._slot_tabs = {}
 
     def set_data_parallel(self, world, grad_sync, peer=False, force=False):
         """One process per GPU: `grad_sync(flat_grad)` averages a flat gradient buffer over ranks (dist.make_grad_sync).
@@ -241,7 +240,6 @@ class PPOPolicy(nn.Module):
         for old in (getattr(self, '_peer', None) or {}).values():      # a second call: release the previous hipIpc mappings / slots
             old.close()
         self._peer = {}
-        self._slot_tabs = {}
         self.grad_sync_report = {'chosen': 'library' if self.world > 1 else 'none'}
         if peer and (self.world > 1 or force):
             import torch.distributed as tdist
@@ -263,7 +261,8 @@ class PPOPolicy(nn.Module):
         """A peer-memory all-reduce whose bounded wait gave up has overwritten the gradient with NaN and raised its context's sticky
         flag (csrc/xgmi.hip); the clip + Adam launch behind it has already run.  Called at the end of every learn() /
         train_identifier() that used a peer context: raises MansyError on the rank that timed out, so the job exits non-zero instead of
-        training on with replicas that no longer agree.  (mansy_xg_status synchronises the device: once per update, peer mode only.)"""
+        training on with replicas that no longer agree.  mansy_xg_status does NOT synchronise (round 5: it reads a host-mapped sticky word), so
+        a time-out of a launch still in flight surfaces at the next check -- the poisoned (NaN) parameters cannot un-poison themselves meanwhile."""
         for p in (getattr(self, '_peer', None) or {}).values():
             p.check()
 
@@ -284,21 +283,13 @@ class PPOPolicy(nn.Module):
         slot[1].record(torch.cuda.current_stream(dev))
         return out
 
-    def _grad_target(self, f):
-        """(flat_g pointer, grads[] pointer table) the gradient kernels of the NEXT step on `f` must use.  Single process, library collective,
-        or peer_in_slot off: the flat gradient buffer.  Peer-memory averages (round 5): the exchange slot the next reduce publishes, so that
-        the collective launch has nothing to copy -- it publishes, waits and sums (dist.PeerGradSync.reduce_into)."""
+    def _xg_ctx(self, f):
+        """The peer-memory context of flat buffer `f` when its data-parallel steps run in the exchange-slot form (round 5): the engine call
+        produces the raw gradients straight in the rank's exchange slot, one more launch averages them over the ranks, clip + Adam follow --
+        ONE library call per step, like the single-process step (mansy_ppo_minibatch_step / mansy_identifier_train_step, `xg_ctx`).  None:
+        single process, a library collective, or the round-4 copy form (peer_in_slot = False)."""
         peer = self._peer.get(id(f)) if getattr(self, '_peer', None) else None
-        if peer is None or not self.peer_in_slot:
-            _, garr = f.pointers(grads=True)
-            return ptr(f.flat_g), garr
-        s = peer.next_slot()
-        tab = self._slot_tabs.get((id(f), s))
-        if tab is None:
-            base = peer.slot_ptrs()[s]
-            garr = (ctypes.c_void_p * len(f.offsets))(*[base + 4 * o for o in f.offsets])
-            tab = self._slot_tabs[(id(f), s)] = (ctypes.c_void_p(base), garr)
-        return tab
+        return peer.ctx if (peer is not None and self.peer_in_slot) else None
 
     def _sync_clip_adam(self, f, max_norm, lr, wd, tail=None, overlap=None):
         """Data-parallel second half of a step: average the raw local gradients over the ranks, then global-norm clip + Adam.
@@ -308,14 +299,12 @@ class PPOPolicy(nn.Module):
         flight on a side stream (the identifier's two all-reduces hide under the critic / log-prob passes of process_fn)."""
         peer = self._peer.get(id(f)) if getattr(self, '_peer', None) else None
         dev = f.flat_p.device
-        scratch = torch.empty(64, dtype=torch.float64, device=dev)      # MANSY_CLIP_SCRATCH_DOUBLES
-
-        in_slot = peer is not None and self.peer_in_slot
+        scratch = self._pinned.get(('clip_scratch', dev))               # MANSY_CLIP_SCRATCH_DOUBLES, one per device (stream-ordered reuse)
+        if scratch is None:
+            scratch = self._pinned[('clip_scratch', dev)] = torch.empty(64, dtype=torch.float64, device=dev)
 
         def average():
-            if in_slot:
-                peer.reduce_into(f.flat_g, scratch)      # the step's gradients are in the slot already: publish, wait, sum -> f.flat_g
-            elif peer is not None:
+            if peer is not None:
                 peer(f.flat_g, scratch)
             else:
                 self.grad_sync(f.flat_g)
@@ -337,10 +326,9 @@ class PPOPolicy(nn.Module):
         if tail is not None:
             data, nxt = tail
             arr, _ = f.pointers()
-            next_g = self._grad_target(f)[0] if in_slot else None      # the slot the next step accumulates into: zeroed by this launch
             check(lib().mansy_ppo_dp_tail(arr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), float(max_norm), lr, wd, f.step,
                                           ptr(scratch), int(peer is not None), ptr(data['obs']), ptr(data['adv']), ptr(nxt),
-                                          nxt.numel() if nxt is not None else 0, next_g, ptr(self.engine.workspace()), self.engine.max_batch,
+                                          nxt.numel() if nxt is not None else 0, None, ptr(self.engine.workspace()), self.engine.max_batch,
                                           self.engine.prec, stream_ptr(f.flat_p.device)), 'mansy_ppo_dp_tail')
             return
         check(lib().mansy_clip_grad_adam(ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), float(max_norm), lr, wd, f.step,
@@ -399,7 +387,8 @@ class PPOPolicy(nn.Module):
         # of the process_fn that follows (mansy_ppo.py:53: v_s + logp_old on obs, v_s_ on obs_next) depend on the actor-critic only,
         # which this function does not touch: round r's average flies on a side stream while pass r runs here; process_fn then finds
         # the values it needs (self._pre_eval) instead of recomputing them.
-        hide = self.grad_sync is not None and self.overlap_identifier_sync
+        # (peer-memory averages in the exchange-slot form are one ~5 us launch inside the step's own call: nothing worth hiding)
+        hide = self.grad_sync is not None and self.overlap_identifier_sync and self._xg_ctx(f) is None
         for r in range(update_round):
             f.step += 1
             ov = (lambda part=r: self._pre_evaluate(buffer, part)) if hide and r < 2 else None
@@ -423,11 +412,14 @@ class PPOPolicy(nn.Module):
         arr, garr = f.pointers(grads=True)
         loss = torch.empty((), dtype=torch.float32, device=obs.device)
         dp = self.grad_sync is not None and step > 0
-        gptr = ptr(f.flat_g)
-        if dp:
-            gptr, garr = self._grad_target(f)
-        check(lib().mansy_identifier_train_step(arr, garr, ptr(f.flat_p), gptr, ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(obs), ptr(rows), B, lr, wd,
-                                                -1 if dp else step, ptr(loss), ptr(eng.workspace()), eng.max_batch, eng.prec, stream_ptr(obs.device)),
+        xg = self._xg_ctx(f) if dp else None
+        if xg is not None:          # the data-parallel step as ONE call: gradients into the exchange slot, one launch averages them, Adam
+            check(lib().mansy_identifier_train_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(obs), ptr(rows), B, lr, wd,
+                                                    step, ptr(loss), ptr(eng.workspace()), eng.max_batch, xg, eng.prec, stream_ptr(obs.device)),
+                  'mansy_identifier_train_step')
+            return loss
+        check(lib().mansy_identifier_train_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(obs), ptr(rows), B, lr, wd,
+                                                -1 if dp else step, ptr(loss), ptr(eng.workspace()), eng.max_batch, None, eng.prec, stream_ptr(obs.device)),
               'mansy_identifier_train_step')
         if dp:
             self._sync_clip_adam(f, 0.0, lr, wd, overlap=overlap)
@@ -574,8 +566,12 @@ class PPOPolicy(nn.Module):
         arr, garr = f.pointers(grads=True)
         fixed_head = (arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(data['obs']))
         fixed_mid = (ptr(data['act']), ptr(data['adv']), ptr(data['logp_old']), ptr(data['v_s']), ptr(data['returns']))
+        # data parallel, two forms: peer-memory averages in the exchange-slot form (xg) are part of the step's own call, exactly like the
+        # single-process step; a library collective (or the round-4 copy form) splits the step: raw gradients (step = 0) -> average -> mansy_ppo_dp_tail
+        xg = self._xg_ctx(f) if (dp and chain) else None
+        split = dp and xg is None
         hyper = (self._eps_clip, self._weight_vf, self._weight_ent, int(self._norm_adv), int(self._value_clip), float(self._dual_clip or 0.0),
-                 0.0 if dp else float(self._grad_norm or 0.0), lr, wd)
+                 0.0 if split else float(self._grad_norm or 0.0), lr, wd)
         ws_ptr, st_ptr = ptr(eng.workspace()), stream_ptr(dev)
         for s, (pi, k, idx) in enumerate(flat):
             first_of_later_pass = recompute and pi > 0 and k == 0
@@ -585,14 +581,11 @@ class PPOPolicy(nn.Module):
             last_of_pass = s + 1 < len(flat) and flat[s + 1][0] != pi
             nxt = flat[s + 1][2] if (chain and s + 1 < len(flat) and not (recompute and last_of_pass)) else None
             # (_recompute_returns rewrites data['v_s'] / ['returns'] / ['adv'] IN PLACE: the pointers converted above still hold)
-            if dp:                              # (peer-memory averages: this step's gradient buffer is the exchange slot the next reduce publishes)
-                gptr, garr_s = self._grad_target(f)
-                fixed_head = (arr, garr_s, fixed_head[2], gptr) + fixed_head[4:]
-            check(step_fn(*fixed_head, ptr(idx), *fixed_mid, idx.numel(), *hyper, 0 if dp else f.step, *f.tail(), ptr(stats_all[pi][k]), ws_ptr, eng.max_batch,
-                          int(chain and s > 0 and not first_of_later_pass), ptr(None if dp else nxt), nxt.numel() if (nxt is not None and not dp) else 0, eng.prec,
-                          st_ptr),
+            check(step_fn(*fixed_head, ptr(idx), *fixed_mid, idx.numel(), *hyper, 0 if split else f.step, *f.tail(), ptr(stats_all[pi][k]), ws_ptr, eng.max_batch,
+                          int(chain and s > 0 and not first_of_later_pass), ptr(None if split else nxt), nxt.numel() if (nxt is not None and not split) else 0, xg,
+                          eng.prec, st_ptr),
                   'mansy_ppo_minibatch_step')
-            if dp:                              # raw local gradients -> average over the ranks -> global-norm clip + Adam (+ next prologue)
+            if split:                           # raw local gradients -> average over the ranks -> global-norm clip + Adam (+ next prologue)
                 self._sync_clip_adam(f, float(self._grad_norm or 0.0), lr, wd, tail=(data, nxt) if chain else None)
         if dp:
             self._check_peers()

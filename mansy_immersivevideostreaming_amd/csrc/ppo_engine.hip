@@ -1345,12 +1345,30 @@ int mansy_identifier_forward(const float* const* params, const float* obs, int B
 // the PPO minibatch step gathers its rows -- no separate gather launch, no shuffled copy of the buffer)
 int mansy_identifier_train_step(const float* const* params, float* const* grads, float* flat_p, float* flat_g, float* flat_m, float* flat_v,
                                 long long n_flat, const float* obs_all, const int* idx, int B, float lr, float weight_decay, int step, float* loss_out,
-                                void* workspace, int max_batch, int precision, void* stream) {
+                                void* workspace, int max_batch, void* xg_ctx, int precision, void* stream) {
   MANSY_REQUIRE(params && obs_all && loss_out && B >= 1 && B <= max_batch, "identifier_train_step: bad arguments");
   PEng e; RC(setup(workspace, max_batch, precision, (hipStream_t)stream, e));
-  NetP n; bind_net(params, grads, 20, n);
   const bool train = step != 0;
   MANSY_REQUIRE(!train || (grads && flat_p && flat_g && flat_m && flat_v), "identifier_train_step: null optimiser buffers");
+  // xg_ctx != NULL (step > 0): the data-parallel step as one call -- gradients into the exchange slot, one launch averages them into flat_g, Adam
+  std::vector<float*> slot_grads;
+  float* const g_avg = flat_g;
+  if (xg_ctx) {
+    MANSY_REQUIRE(step > 0, "identifier_train_step: the peer-averaged form is a training step (step > 0)");
+    float* s0 = nullptr; float* s1 = nullptr;
+    RC(mansy_xg_slot_ptrs(xg_ctx, &s0, &s1));
+    const int cur = mansy_xg_next_slot(xg_ctx);
+    MANSY_REQUIRE(cur == 0 || cur == 1, "identifier_train_step: bad exchange context");
+    float* slot = cur ? s1 : s0;
+    const int np = mansy_net_num_params(1);
+    slot_grads.resize(np);
+    for (int k = 0; k < np; ++k) {
+      MANSY_REQUIRE(grads[k] >= flat_g && grads[k] < flat_g + n_flat, "identifier_train_step: grads[] must point into flat_g");
+      slot_grads[k] = slot + (grads[k] - flat_g);
+    }
+    grads = slot_grads.data(); flat_g = slot;
+  }
+  NetP n; bind_net(params, grads, 20, n);
   RC(e.pack(n, 1, nullptr, idx ? obs_all : nullptr, idx, B, train ? flat_g : nullptr, n_flat));      // row gather + gradient zero-fill ride on the pack launch
   const float* obs = idx ? e.W.obs_mb : obs_all;
   RC(e.featnet(obs, B, 1));
@@ -1374,7 +1392,8 @@ int mansy_identifier_train_step(const float* const* params, float* const* grads,
   og.lossrows = e.W.lossrows; og.stats = loss_out; og.mse = 1;
   RC(e.featnet_bwd(n, obs, B, 1, e.W.dHa, nullptr, nullptr, 0, nullptr, &og));
   if (step < 0) return MANSY_OK;
-  return e.clip_and_adam(flat_p, flat_g, flat_m, flat_v, n_flat, 0.f, lr, weight_decay, step);
+  if (xg_ctx) RC(mansy_xg_reduce_avg(xg_ctx, g_avg, n_flat, nullptr, stream));
+  return e.clip_and_adam(flat_p, g_avg, flat_m, flat_v, n_flat, 0.f, lr, weight_decay, step);
 }
 
 int mansy_identifier_relabel(const float* const* params, const float* obs, float* rew, float* id_rew, int B, float lamb, void* workspace,
@@ -1440,9 +1459,31 @@ int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, fl
                              const float* logp_old_all, const float* v_old_all, const float* ret_all, int mb, float eps_clip, float vf_coef,
                              float ent_coef, int norm_adv, int value_clip, float dual_clip, float max_grad_norm, float lr, float weight_decay, int step,
                              long long tail_from, int tail_step, float* stats, void* workspace, int max_batch, int chain_in,
-                             const int* next_idx, int next_mb, int precision, void* stream) {
+                             const int* next_idx, int next_mb, void* xg_ctx, int precision, void* stream) {
   MANSY_REQUIRE(params && grads && flat_p && flat_g && flat_m && flat_v && obs_all && act_all && adv_all && logp_old_all && v_old_all && ret_all,
                 "ppo_minibatch_step: null pointer");
+  // xg_ctx != NULL (round 5): the data-parallel step as ONE call -- this rank's raw gradients are produced straight in its exchange slot
+  // (csrc/xgmi.hip), one launch publishes it / waits for the peers / sums all ranks' slots in rank order into flat_g (+ the partial sums of
+  // squares), then the chained tail (clip + Adam + re-pack + next prologue) runs on the average and zeroes the OTHER slot for the next step.
+  // Same launches as the single-process step with one more (the average) and without the norm rider; the host does nothing per step that the
+  // single-process form does not do.  Needs the chained form: step > 0, max_grad_norm > 0, no lagged tail.
+  float* slot_g[2] = {nullptr, nullptr};
+  int slot_cur = 0;
+  std::vector<float*> slot_grads;
+  if (xg_ctx) {
+    MANSY_REQUIRE(max_grad_norm > 0.f && step > 0 && !(tail_from >= 0 && tail_from < n_flat && tail_step != step), "ppo_minibatch_step: the peer-averaged form needs the clipped step without a lagged tail");
+    RC(mansy_xg_slot_ptrs(xg_ctx, &slot_g[0], &slot_g[1]));
+    slot_cur = mansy_xg_next_slot(xg_ctx);
+    MANSY_REQUIRE(slot_cur == 0 || slot_cur == 1, "ppo_minibatch_step: bad exchange context");
+    const int np = mansy_net_num_params(0);
+    slot_grads.resize(np);
+    for (int k = 0; k < np; ++k) {
+      MANSY_REQUIRE(grads[k] >= flat_g && grads[k] < flat_g + n_flat, "ppo_minibatch_step: grads[] must point into flat_g");
+      slot_grads[k] = slot_g[slot_cur] + (grads[k] - flat_g);
+    }
+  }
+  float* const g_avg = flat_g;                               // where the (averaged) gradient ends up for the tail
+  if (xg_ctx) { grads = slot_grads.data(); flat_g = slot_g[slot_cur]; }
   MANSY_REQUIRE(mb >= 2 && mb <= max_batch, "ppo_minibatch_step: bad minibatch size");
   MANSY_REQUIRE(dual_clip == 0.f || dual_clip > 1.f, "ppo_minibatch_step: dual_clip must be 0 (off) or > 1 (tianshou asserts the same)");
   PEng e; RC(setup(workspace, max_batch, precision, (hipStream_t)stream, e));
@@ -1483,7 +1524,7 @@ int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, fl
                 "ppo_minibatch_step: unexpected order of the head gradients in flat_g");
   // squared gradient norm as a rider on the last gradient-writing launch (12 -> 11 launches): the head gradients are the
   // contiguous tail of the flat buffer, starting at actor.fc.0.weight
-  const bool ride = max_grad_norm > 0.f && step > 0;
+  const bool ride = max_grad_norm > 0.f && step > 0 && !xg_ctx;      // (peer-averaged form: the norm is the AVERAGE's, left by the collective launch)
   const float* tail = grads[2 * NB];
   const long long tail_n = (flat_g + n_flat) - tail;
   MANSY_REQUIRE(!ride || (tail >= flat_g && tail_n > 0 && tail_n <= n_flat), "ppo_minibatch_step: grads[] must point into flat_g");
@@ -1492,6 +1533,11 @@ int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, fl
   // 22-32 us per launch against 12 us for the two launches it replaced: a kernel boundary is cheaper than a device-scope
   // rendezvous on this chip, as tools/chain_lab.hip found for the GEMM chain.)
   RC(e.featnet_bwd(a, obs, mb, 0, e.W.dHa, e.W.dHc, ride ? tail : nullptr, ride ? tail_n : 0, parts_cur, &og));
+  if (xg_ctx) {
+    RC(mansy_xg_reduce_avg(xg_ctx, g_avg, n_flat, parts_cur, stream));      // slot -> average in flat_g, sums of squares in this step's norm slots
+    return e.step_tail(params, flat_p, g_avg, flat_m, flat_v, n_flat, max_grad_norm, lr, weight_decay, step, parts_cur, parts_next, obs_all,
+                       next_idx, next_mb, adv_all, slot_g[slot_cur ^ 1]);
+  }
   if (chain_ok)
     return e.step_tail(params, flat_p, flat_g, flat_m, flat_v, n_flat, max_grad_norm, lr, weight_decay, step, parts_cur, parts_next, obs_all,
                        next_idx, next_mb, adv_all);

@@ -34,9 +34,11 @@ struct XgCtx {
   void* peer_base[XG_MAX_WORLD] = {};     // mapped peer allocations (own entry = own)
   unsigned epoch = 0;
   unsigned* counter = nullptr;            // workgroups of this rank that have published (monotonic)
-  int* err = nullptr;                     // sticky device-side error word
-  unsigned long long launches = 0;
+  int* err = nullptr;                     // sticky error word: pinned HOST memory the kernels write (system-scope store) and the host reads without a sync
+  int* err_dev = nullptr;                 // its device address
+  unsigned long long launches = 0;        // copy-form launches only: the ticket counter advances XG_BLOCKS per such launch (the two forms may alternate on one context)
   double timeout_ms = 2000.0;
+  int wall_khz = 100000;                  // wall_clock64 ticks at a constant rate (100 MHz on gfx9), read once at create
 };
 
 constexpr int XG_THREADS = 256;        // (1 024-thread workgroups measured 1.4-1.9x slower: profiles/r03_xg_timing.txt history)
@@ -59,16 +61,31 @@ __global__ __launch_bounds__(XG_THREADS) void xg_allreduce_kernel(float* __restr
       for (int u = 0; u < 4; ++u) { const long long i = i0 + (long long)u * gsize; if (i < n4) reinterpret_cast<float4*>(own_slot)[i] = v[u]; }
     }
   }
-  // every storing wave drains its stores, the workgroup meets, then ONE lane releases at system scope (the release is cumulative
-  // over the barrier's happens-before) -- a system-scope fence in every thread cost a cache write-back per wave
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
   __shared__ int timed_out;
-  if (threadIdx.x == 0) {
-    timed_out = 0;
-    __atomic_thread_fence(__ATOMIC_RELEASE);                // system scope
-    const unsigned prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (prev + 1u == target) __hip_atomic_store(own_flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (COPY) {
+    // every storing wave drains its stores, the workgroup meets, then ONE lane releases at system scope (the release is cumulative
+    // over the barrier's happens-before) -- a system-scope fence in every thread cost a cache write-back per wave
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      timed_out = 0;
+      __atomic_thread_fence(__ATOMIC_RELEASE);                // system scope
+      const unsigned prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      if (prev + 1u == target) __hip_atomic_store(own_flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  } else {
+    // The slot was written by EARLIER launches of this stream: the kernel boundary in front of this launch has already written their stores back
+    // to the memory side (what makes them visible to this launch's workgroups on the other XCDs is what makes them visible to a peer reading the
+    // home memory over a link).  So the publish is ONE flag store -- no copy, no per-workgroup release, no ticket (tools/xg_lab.hip: 8.2 -> 4.4 us
+    // per launch at world 1); the publishing lane still releases at system scope first (its own XCD's L2: belt and braces, off the other
+    // workgroups' path).
+    if (threadIdx.x == 0) {
+      timed_out = 0;
+      if (blockIdx.x == 0) {
+        __atomic_thread_fence(__ATOMIC_RELEASE);              // system scope
+        __hip_atomic_store(own_flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
   }
   __syncthreads();
   // 2. wait for every peer's epoch: wave 0 polls (one lane per peer, RELAXED loads: an acquire per poll is a cache invalidate per poll), then that
@@ -78,7 +95,7 @@ __global__ __launch_bounds__(XG_THREADS) void xg_allreduce_kernel(float* __restr
     if ((int)threadIdx.x < world && (int)threadIdx.x != rank) {
       const long long t0 = wall_clock64();
       while ((int)(__hip_atomic_load(peers.flag[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
-        if (wall_clock64() - t0 > timeout_ticks) { timed_out = 1; __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        if (wall_clock64() - t0 > timeout_ticks) { timed_out = 1; __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
         __builtin_amdgcn_s_sleep(2);
       }
     }
@@ -152,7 +169,17 @@ int mansy_xg_create(long long n_floats, int world, int rank, void** ctx_out) {
     delete c;
     return MANSY_EHIP;
   }
-  c->err = reinterpret_cast<int*>(c->counter) + 16;
+  // the error word lives in mapped host memory: mansy_xg_status() reads it WITHOUT synchronising the device (round 5: a device sync at the end
+  // of every learn() / train_identifier() drained the queue twice per cycle)
+  if (hipHostMalloc((void**)&c->err, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer((void**)&c->err_dev, c->err, 0) != hipSuccess) {
+    mansy_set_error("xg_create: cannot allocate the mapped error word");
+    if (c->err) (void)hipHostFree(c->err);
+    (void)hipFree(c->own); (void)hipFree(c->counter);
+    delete c;
+    return MANSY_EHIP;
+  }
+  *c->err = 0;
+  { int dev = 0, khz = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess && khz > 0) c->wall_khz = khz; }
   c->peer_base[rank] = c->own;
   if (world == 1) c->imported = 1;
   *ctx_out = c;
@@ -217,7 +244,7 @@ int mansy_xg_allreduce_avg(void* ctx, float* g, long long n, double* sumsq_parts
 
 static int xg_launch(XgCtx* c, float* g, long long n, double* sumsq_parts, hipStream_t stream, bool copy) {
   c->epoch += 1;
-  c->launches += 1;
+  if (copy) c->launches += 1;
   XgPeers peers;
   for (int p = 0; p < XG_MAX_WORLD; ++p) {
     const float* base = (const float*)c->peer_base[p < c->world ? p : c->rank];
@@ -225,30 +252,26 @@ static int xg_launch(XgCtx* c, float* g, long long n, double* sumsq_parts, hipSt
     peers.flag[p] = reinterpret_cast<const unsigned*>(base);
   }
   const long long slot_off = (long long)(c->epoch & 1u) * c->n_pad;
-  int wall_khz = 100000;                                    // wall_clock64 ticks at a constant rate (100 MHz on gfx9)
-  int dev = 0;
-  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, dev);
-  if (wall_khz <= 0) wall_khz = 100000;
-  const long long ticks = (long long)(c->timeout_ms * (double)wall_khz);
+  const long long ticks = (long long)(c->timeout_ms * (double)c->wall_khz);      // (the rate is read once at create: two runtime calls per average were host time on a latency-bound cycle)
   if (copy)
     MANSY_LAUNCH(xg_allreduce_kernel<true>, dim3(XG_BLOCKS), dim3(XG_THREADS), 0, stream, g, n / 4, peers, c->own + XG_HEADER_FLOATS + slot_off,
                        reinterpret_cast<unsigned*>(c->own), slot_off, c->rank, c->world, c->epoch, 1.0f / (float)c->world, sumsq_parts, c->counter,
-                       (unsigned)(c->launches * XG_BLOCKS), c->err, ticks);
+                       (unsigned)(c->launches * XG_BLOCKS), c->err_dev, ticks);
   else
     MANSY_LAUNCH(xg_allreduce_kernel<false>, dim3(XG_BLOCKS), dim3(XG_THREADS), 0, stream, g, n / 4, peers, c->own + XG_HEADER_FLOATS + slot_off,
                        reinterpret_cast<unsigned*>(c->own), slot_off, c->rank, c->world, c->epoch, 1.0f / (float)c->world, sumsq_parts, c->counter,
-                       (unsigned)(c->launches * XG_BLOCKS), c->err, ticks);
+                       (unsigned)(c->launches * XG_BLOCKS), c->err_dev, ticks);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }
 
-// 0: every wait so far met its peers; MANSY_EHIP: a wait timed out (the outputs of that call are NaN).  Synchronises the device.
+// 0: every wait of the launches that have COMPLETED so far met its peers; MANSY_EHIP: one timed out (the outputs of that call are NaN and stay
+// NaN through the optimiser: nothing trains on silently).  Does not synchronise: launches still in flight are covered by the next call (the
+// word is sticky) -- call it after a synchronisation point of your own for a final verdict.
 int mansy_xg_status(void* ctx) {
   XgCtx* c = (XgCtx*)ctx;
   MANSY_REQUIRE(c, "xg_status: null");
-  int e = 0;
-  MANSY_HIP_CHECK(hipDeviceSynchronize());
-  MANSY_HIP_CHECK(hipMemcpy(&e, c->err, sizeof(int), hipMemcpyDeviceToHost));
+  const int e = __atomic_load_n(c->err, __ATOMIC_ACQUIRE);
   if (e) { mansy_set_error("xg: a peer did not publish its gradient within %.0f ms", c->timeout_ms); return MANSY_EHIP; }
   return MANSY_OK;
 }
@@ -261,6 +284,7 @@ int mansy_xg_destroy(void* ctx) {
     if (p != c->rank && c->peer_base[p]) (void)hipIpcCloseMemHandle(c->peer_base[p]);
   if (c->own) (void)hipFree(c->own);
   if (c->counter) (void)hipFree(c->counter);
+  if (c->err) (void)hipHostFree(c->err);
   delete c;
   return MANSY_OK;
 }

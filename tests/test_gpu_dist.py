@@ -126,13 +126,16 @@ def test_rccl_world1_collectives_of_the_dp_step():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('form', ['copy', 'slot'])
 @pytest.mark.parametrize('world', [2, 3])
-def test_peer_memory_allreduce_between_processes_sharing_the_gpu(world):
+def test_peer_memory_allreduce_between_processes_sharing_the_gpu(world, form):
     """csrc/xgmi.hip through dist.PeerGradSync: `world` processes on the one GPU map each other's fine-grained exchange buffers
     through hipIpc and run 40 back-to-back one-shot all-reduces of the PPO flat-gradient size; every result must equal the
     rank-ordered float32 average bit for bit on every rank, the partial sums of squares must add up to its squared norm, and no
-    wait may time out (tools/xg_selftest.py)."""
-    env = dict(os.environ, MANSY_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    wait may time out (tools/xg_selftest.py).  form 'copy': the gradient is copied into the exchange slot by the collective launch
+    (mansy_xg_allreduce_avg); 'slot' (round 5): it is produced IN the slot by an earlier launch and the collective only publishes,
+    waits and sums (mansy_xg_reduce_avg) -- followed by a copy-form call on the same context (the two forms may alternate)."""
+    env = dict(os.environ, MANSY_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0', XG_SLOT='1' if form == 'slot' else '0')
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]

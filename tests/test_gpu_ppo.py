@@ -167,7 +167,7 @@ def test_ppo_minibatch_loss_grads_clip_adam_vs_oracle(M):
         arr, garr = f.pointers(grads=True)
         check(lib().mansy_ppo_minibatch_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(d['obs']), None,
                                              ptr(d['act']), ptr(d['adv']), ptr(d['logp']), ptr(d['v']), ptr(d['ret']), len(obs), 0.2, 0.5, 0.02, 1, 1, 0.0,
-                                             max_norm, 5e-4, 1e-2, step, -1, 0, ptr(stats), ptr(eng.workspace()), eng.max_batch, 0, None, 0, eng.prec, stream_ptr()), 'ppo_mb')
+                                             max_norm, 5e-4, 1e-2, step, -1, 0, ptr(stats), ptr(eng.workspace()), eng.max_batch, 0, None, 0, None, eng.prec, stream_ptr()), 'ppo_mb')
     call(0, 0.0)                                  # gradients only, no clipping
     np.testing.assert_allclose(stats.cpu().numpy(), [loss, clip, vf, ent], rtol=2e-5, atol=2e-6)
     names = [n for n, _ in f.table]
@@ -217,11 +217,11 @@ def test_paired_launch_of_the_fc_weight_gradients_and_dF_is_bit_identical_to_two
         arr, garr = f.pointers(grads=True)
         check(L.mansy_ppo_minibatch_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(d['obs']), None,
                                          ptr(d['act']), ptr(d['adv']), ptr(d['logp']), ptr(d['v']), ptr(d['ret']), len(obs), 0.2, 0.5, 0.02, 1, 1, 0.0,
-                                         0.0, 5e-4, 1e-2, 0, -1, 0, ptr(stats), ptr(eng.workspace()), eng.max_batch, 0, None, 0, eng.prec, stream_ptr()), 'ppo_mb')
+                                         0.0, 5e-4, 1e-2, 0, -1, 0, ptr(stats), ptr(eng.workspace()), eng.max_batch, 0, None, 0, None, eng.prec, stream_ptr()), 'ppo_mb')
         iloss = torch.zeros((), device=dev)
         iarr, igarr = fi.pointers(grads=True)
         check(L.mansy_identifier_train_step(iarr, igarr, ptr(fi.flat_p), ptr(fi.flat_g), ptr(fi.m), ptr(fi.v), fi.flat_p.numel(), ptr(d['obs']), None,
-                                            len(obs), 1e-4, 1e-2, -1, ptr(iloss), ptr(eng.workspace()), eng.max_batch, eng.prec, stream_ptr()), 'ident')
+                                            len(obs), 1e-4, 1e-2, -1, ptr(iloss), ptr(eng.workspace()), eng.max_batch, None, eng.prec, stream_ptr()), 'ident')
         torch.cuda.synchronize()
         return (f.flat_g.clone(), stats.clone(), fi.flat_g.clone(), iloss.clone())
     for knob, variant in ((8, 0x800), (9, 0)):
@@ -263,7 +263,7 @@ def test_ppo_minibatch_flag_combinations_incl_dual_clip_vs_oracle(M, flags):
     check(lib().mansy_ppo_minibatch_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(d['obs']), None,
                                          ptr(d['act']), ptr(d['adv']), ptr(d['logp']), ptr(d['v']), ptr(d['ret']), len(obs), 0.2, 0.5, 0.02,
                                          int(okw['norm_adv']), int(okw['value_clip']), float(okw['dual_clip'] or 0.0), 0.0, 5e-4, 1e-2, 0, -1, 0,
-                                         ptr(stats), ptr(eng.workspace()), eng.max_batch, 0, None, 0, eng.prec, stream_ptr()), 'ppo_mb')
+                                         ptr(stats), ptr(eng.workspace()), eng.max_batch, 0, None, 0, None, eng.prec, stream_ptr()), 'ppo_mb')
     np.testing.assert_allclose(stats.cpu().numpy(), [loss, clip, vf, ent], rtol=2e-5, atol=2e-6)
     for n_, o, p in zip([n for n, _ in f.table], f.offsets, f.params):
         got = f.flat_g[o:o + p.numel()].view(p.shape).cpu().numpy()
@@ -445,7 +445,7 @@ def test_update_teacher_forced_every_minibatch_step(M):
                 check(lib().mansy_ppo_minibatch_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(obs_d), ptr(idx),
                                                      ptr(act_d), ptr(data['adv']), ptr(data['logp_old']), ptr(data['v_s']), ptr(data['returns']),
                                                      idx.numel(), 0.2, 0.5, 0.02, 1, 1, 0.0, 1.0, lr, wd, f.step, *f.tail(), ptr(stats),
-                                                     ptr(eng.workspace()), eng.max_batch, 0, None, 0, eng.prec, stream_ptr()), 'mansy_ppo_minibatch_step')
+                                                     ptr(eng.workspace()), eng.max_batch, 0, None, 0, None, eng.prec, stream_ptr()), 'mansy_ppo_minibatch_step')
                 torch.cuda.synchronize()
                 np.testing.assert_allclose(stats.cpu().numpy(), rows[k], rtol=1e-5, atol=3e-6, err_msg=f'{(T, N, it, k)}')
                 n_el = n_bad = 0
@@ -597,7 +597,7 @@ def test_behaviour_cloning_steps_then_ppo_with_per_parameter_adam_steps(M):
         assert f.tail()[1] == k + 1
         check(lib().mansy_ppo_minibatch_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(d['obs']), None,
                                              ptr(d['act']), ptr(d['adv']), ptr(d['logp']), ptr(d['v']), ptr(d['ret']), len(obs), 0.2, 0.5, 0.02, 1, 1, 0.0,
-                                             1.0, 5e-4, 1e-2, f.step, *f.tail(), ptr(stats), ptr(eng.workspace()), eng.max_batch, 0, None, 0, eng.prec, stream_ptr()),
+                                             1.0, 5e-4, 1e-2, f.step, *f.tail(), ptr(stats), ptr(eng.workspace()), eng.max_batch, 0, None, 0, None, eng.prec, stream_ptr()),
               'ppo_mb')
         np.testing.assert_allclose(stats[0].item(), loss.item(), rtol=5e-5, atol=5e-6)
     compare('after PPO steps', 6e-6)
