@@ -39,12 +39,14 @@ class RolloutBuffer:
         self.rew = torch.zeros(T, N, **f32)
         self.done = torch.zeros(T, N, dtype=torch.uint8, device=device)
         self.filled = 0
+        self.generation = 0        # bumped whenever the contents change (reset / collect): keys caches of values computed FROM the contents
 
     def __len__(self):
         return self.filled * self.N
 
     def reset(self):
         self.filled = 0
+        self.generation += 1
 
 
 class VecCollector:
@@ -129,6 +131,7 @@ class VecCollector:
             self._body(buffer, T)
         self.step_count += T
         buffer.filled = T
+        buffer.generation = getattr(buffer, 'generation', 0) + 1      # new contents: values evaluated on the old ones (PPOPolicy._pre_eval) are stale
         self.env_step += T * N
         return {'n/st': T * N}
 
@@ -439,7 +442,7 @@ class PPOPolicy(nn.Module):
         self.cnt += n
 
     def _pre_eval_key(self, buffer):
-        return (id(buffer), buffer.filled, buffer.N, self.engine.ac.step, buffer.obs.data_ptr())
+        return (id(buffer), getattr(buffer, 'generation', None), buffer.filled, buffer.N, self.engine.ac.step, buffer.obs.data_ptr())
 
     def _pre_evaluate(self, buffer, part):
         """One of process_fn's two evaluation passes ahead of time (part 0: v_s + logp_old on obs, part 1: v_s_ on obs_next), kept for the

@@ -245,7 +245,7 @@ def probe_peer_grad_sync(sizes, world, rank, device, library_sync, iters=10, pro
     would simply wait).
     -> ({size: PeerGradSync} or {}, report dict for the bench line).  Every rank calls this; every rank returns the same decision."""
     import time
-    report = {'probe': 'peer-memory one-shot vs library all_reduce', 'iters': iters}
+    report = {'probe': 'peer-memory one-shot (exchange-slot form) vs library all_reduce', 'iters': iters}
     agree_dev = device if dist.get_backend() == 'nccl' else 'cpu'
 
     def all_min(x):
@@ -286,6 +286,14 @@ def probe_peer_grad_sync(sizes, world, rank, device, library_sync, iters=10, pro
                 ok, why = 0.0, f'rank {rank}: peer average ({n} floats) differs from the library average by {float((out - ref).abs().max()):.3e}'
             elif abs(float(scratch.sum()) - float((out.double() ** 2).sum())) > 1e-6 * max(float((out.double() ** 2).sum()), 1e-30):
                 ok, why = 0.0, f'rank {rank}: sums of squares differ ({n} floats)'
+            else:      # the exchange-slot form (what the engine steps use): the same gradient produced IN the slot, then publish / wait / sum
+                peers[n].slot_tensor(peers[n].next_slot()).copy_(src[:n])
+                out2 = torch.empty_like(out)
+                peers[n].reduce_into(out2, scratch)
+                torch.cuda.synchronize(device)
+                peers[n].check()
+                if not torch.equal(out2, out):
+                    ok, why = 0.0, f'rank {rank}: the exchange-slot form differs from the copy form ({n} floats) by {float((out2 - out).abs().max()):.3e}'
         except Exception as e:          # noqa: BLE001
             ok, why = 0.0, f'rank {rank}: {e}'
         # agree AFTER EVERY SIZE: every iteration starts with a collective (library_sync), so a rank-local `break`
@@ -312,7 +320,9 @@ def probe_peer_grad_sync(sizes, world, rank, device, library_sync, iters=10, pro
         torch.cuda.synchronize(device)
         return all_max((time.perf_counter() - t0) / iters * 1e6)
     t_lib = timed(library_sync)
-    t_peer = timed(lambda b: peers[n0](b, scratch))
+    # the form the engine steps use: the gradient is already in the slot, the launch publishes / waits / sums (the library side additionally
+    # pays a gradient-norm launch and a second library call per step, which this comparison leaves out: it errs towards the library)
+    t_peer = timed(lambda b: peers[n0].reduce_into(b, scratch))
     try:
         peers[n0].check()
         timed_ok = 1.0

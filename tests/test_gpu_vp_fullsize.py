@@ -34,7 +34,7 @@ def MT():
 _ORACLE = {}
 
 
-def _perms(seed):
+def _perms(seed, B=B):
     """The two np.random.shuffle permutations mtio.py:81-86 draws after random.random() chose the mix branch."""
     np.random.seed(seed)
     out = []
@@ -45,10 +45,10 @@ def _perms(seed):
     return out
 
 
-def _oracle(branch):
-    """loss, pred, every gradient, BN running statistics and the AdamW'd weights of ONE step, by CPU autograd (cached per branch)."""
-    if branch in _ORACLE:
-        return _ORACLE[branch]
+def _oracle(branch, B=B, S=S, T=T):
+    """loss, pred, every gradient, BN running statistics and the AdamW'd weights of ONE step, by CPU autograd (cached per branch and shape)."""
+    if (branch, B, S, T) in _ORACLE:
+        return _ORACLE[(branch, B, S, T)]
     torch.set_num_threads(max(1, torch.get_num_threads()))
     sd = vo.make_state_dict(D, WSEED, bias=True)
     h, c, f = vo.synthetic_trajectories(B, S, T, seed=5)            # the bench's batch (bench.py, SURVEY 8d C2 inputs)
@@ -57,7 +57,7 @@ def _oracle(branch):
     full = dict(sd)
     full.update(params)
     orc = vo.VPOracle(full, fut_window=T)
-    perms = None if branch == 'rep' else [torch.from_numpy(p) for p in _perms(77)]
+    perms = None if branch == 'rep' else [torch.from_numpy(p) for p in _perms(77, B)]
     src, cur, gt = vo.mtio_mix(h, c, f, 3, branch == 'rep', perms)
     pred = orc.process_src_current(src, cur, train=True)
     loss = orc.loss_function(pred, gt)
@@ -70,7 +70,7 @@ def _oracle(branch):
     out = dict(sd=sd, h=h, c=c, f=f, loss=loss.item(), pred=pred.detach().clone(), grads=grads, stepped=stepped,
                bn=tuple(t.clone() for t in orc.last_bn_stats))
     del orc, pred, loss, params, full
-    _ORACLE[branch] = out
+    _ORACLE[(branch, B, S, T)] = out
     return out
 
 
@@ -78,7 +78,25 @@ def _oracle(branch):
 @pytest.mark.parametrize('prec', ['f32', 'bf16x6'])
 @pytest.mark.parametrize('branch', ['rep', 'mix'])
 def test_bench_size_train_step_vs_oracle_autograd(MT, branch, prec, two_stream):
-    o = _oracle(branch)
+    _train_step_vs_oracle(MT, branch, prec, two_stream, B, S, T)
+
+
+@pytest.mark.parametrize('two_stream', [False, True], ids=['one_stream', 'two_stream'])
+@pytest.mark.parametrize('branch', ['rep', 'mix'])
+def test_readme_shape_train_step_vs_oracle_autograd(MT, branch, two_stream):
+    """Round 5: the README's own training shape -- B = 512, hist 5, pred 15, d = 512 (README.md:139, run_models.py:143,196) -- where
+    the step is a latency-bound chain of small launches (wave-split-K products, M = 3 memory rows, Lk up to 15 in the self-attention) instead of the
+    chip-filling ones of B = 4096: one train_step vs the oracle's CPU autograd, every gradient, on one stream (what the engine picks below B = 2048)
+    and with the two half-batch streams forced."""
+    # MaxPool1d (DistillLayer) routes each gradient element to the arg-max of its window -- a discontinuity: a window whose two largest values are closer
+    # than the fp32 rounding of the conv / BatchNorm chain (786 k windows here: some always are) may route differently in two correct fp32
+    # implementations, and ONE flipped window carries ~1 / (B M) of an encoder-side gradient's scale: 6.5e-4 at B = 512, M = 3 (8e-5 at the bench size,
+    # inside its 3e-4).  The encoder-side tensors therefore get 1.5e-3 of their maximum here; everything behind the memory keeps 3e-4.
+    _train_step_vs_oracle(MT, branch, 'f32', two_stream, 512, 5, 15, enc_tol=1.5e-3)
+
+
+def _train_step_vs_oracle(MT, branch, prec, two_stream, B, S, T, enc_tol=3e-4):
+    o = _oracle(branch, B, S, T)
     m = MT.ViewportTransformerMTIO(in_channel=2, fut_window=T, d_model=D, dim_feedforward=D, device='cuda', bias=True)
     m.load_state_dict(o['sd'])
     m = m.to('cuda')
@@ -107,7 +125,8 @@ def test_bench_size_train_step_vs_oracle_autograd(MT, branch, prec, two_stream):
     for k, p, off in zip(m._engine_names, m._params, m._offsets):
         ref = o['grads'][k].numpy()
         got = m._flat_g[off:off + p.numel()].view(p.shape).cpu().numpy()
-        tol = 3e-4 * np.abs(ref).max() + 2e-6
+        enc_side = k.startswith(('transformer.encoder.', 'transformer.distill_layer.', 'embedding.'))
+        tol = (enc_tol if enc_side else 3e-4) * np.abs(ref).max() + 2e-6
         tols[k] = tol
         err = np.abs(got - ref).max()
         if not err <= tol:

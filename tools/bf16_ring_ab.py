@@ -5,6 +5,9 @@ step in bf16x3 mode, variants interleaved in ONE process."""
 import os, sys, time, random
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import lab_knobs as KN  # noqa: E402  (ABI 8: the A/B knobs live in the -DMANSY_LAB build only)
+KN.enter()
 import numpy as np, torch
 from mansy_immersivevideostreaming_amd import kernels as K
 from mansy_immersivevideostreaming_amd._lib import lib
@@ -21,7 +24,7 @@ for (M, N, Kd) in [(4096, 512, 512), (4000, 520, 512), (64, 64, 32), (100, 72, 6
     ref = A.double() @ W.double().t()
     outs = {}
     for v in (7, 1, 6):
-        L.mansy_gemm_bf16_variant(v)
+        KN.bf16_variant(v)
         outs[v] = K.gemm_planes(A, W, pl, force_tile=64)
     for v in (1, 6):
         same = torch.equal(outs[v], outs[7])
@@ -32,14 +35,14 @@ for (M, N, Kd) in [(4096, 512, 512), (4000, 520, 512), (64, 64, 32), (100, 72, 6
     A2 = torch.randn(M, N, device='cuda')
     ref2 = A2.double() @ W.double()
     for v in (7, 1, 6):
-        L.mansy_gemm_bf16_variant(v)
+        KN.bf16_variant(v)
         outs[v] = K.gemm_planes(A2, W, pl_t, transposed=True, force_tile=64)
     for v in (1, 6):
         err = ((outs[v].double() - ref2).abs().max() / ref2.abs().max()).item()
         worst = max(worst, err)
         print(f'   dX form variant {v}: bit-equal {torch.equal(outs[v], outs[7])}, err {err:.2e}')
 print('worst err', worst)
-L.mansy_gemm_bf16_variant(1)
+KN.bf16_variant(1)
 
 torch.manual_seed(5); random.seed(5); np.random.seed(5)
 m = ViewportTransformerMTIO(in_channel=2, fut_window=10, d_model=512, dim_feedforward=512, device='cuda').to('cuda'); m.train()
@@ -50,11 +53,11 @@ for _ in range(5): m.train_step(h, c, f, opt)
 res = {7: [], 1: [], 6: []}
 for rep in range(4):
     for v in (7, 1, 6):
-        L.mansy_gemm_bf16_variant(v)
+        KN.bf16_variant(v)
         for _ in range(2): m.train_step(h, c, f, opt)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(10): loss = m.train_step(h, c, f, opt)
         torch.cuda.synchronize(); res[v].append((time.perf_counter() - t0) / 10 * 1e3)
-L.mansy_gemm_bf16_variant(1)
+KN.bf16_variant(1)
 for v in (7, 1, 6):
     print(f'variant {v}: bf16x3 train step ms {[round(x, 3) for x in res[v]]} min {min(res[v]):.3f}', 'loss', float(loss))

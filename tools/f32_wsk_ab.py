@@ -4,6 +4,9 @@ workgroup's waves), variants interleaved in ONE process: the small product shape
 then the whole cycle (bench.bench_ppo, 256 envs x 16 steps)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import lab_knobs as KN  # noqa: E402  (ABI 8: the A/B knobs live in the -DMANSY_LAB build only)
+KN.enter()
 import torch
 import bench
 from mansy_immersivevideostreaming_amd import dist as mdist, kernels as K
@@ -16,7 +19,7 @@ for (M, N, Kd, bk) in ((256, 1280, 320, 0), (512, 1280, 320, 0), (512, 1280, 256
     ref = A.double() @ (B.double() if bk else B.double().t())
     line = f'gemm M={M} N={N} K={Kd} {"NN" if bk else "NT"}:'
     for v in (0, 1):
-        L.mansy_gemm_f32_wsk(v)
+        KN.f32_wsk(v)
         out.zero_()
         K.gemm(A, B, False, bool(bk), out=out, force_tile=64)
         err = ((out.double() - ref).abs().max() / ref.abs().max()).item()
@@ -37,13 +40,13 @@ for (M, N, Kd, bk) in ((256, 1280, 320, 0), (512, 1280, 320, 0), (512, 1280, 256
         line += f'  wsk {v}: {e0.elapsed_time(e1) / 200 * 1e3:6.2f} us (err {err:.1e})'
     print(line, flush=True)
 # weight-gradient (TN) form: C += A^T B with the bias-gradient rider, knob 2 / 3 = off / on
-L.mansy_gemm_f32_wsk(1); L.mansy_gemm_f32_wsk(3)
+KN.f32_wsk(1); KN.f32_wsk(3)
 for (M, N, Kd) in ((128, 1280, 512), (256, 1280, 512), (128, 1280, 3264), (36, 132, 96)):
     A = torch.randn(Kd, M, generator=g).to(dev); B = torch.randn(Kd, N, generator=g).to(dev)
     ref = A.double().t() @ B.double() + 1.0
     line = f'gemm TN M={M} N={N} K={Kd}:'
     for v in (2, 3):
-        L.mansy_gemm_f32_wsk(v)
+        KN.f32_wsk(v)
         out = torch.ones(M, N, device=dev); rs = torch.zeros(M, device=dev)
         K.gemm(A, B, True, True, out=out, accumulate=True, a_rowsum=rs, force_tile=64)
         err = ((out.double() - ref).abs().max() / ref.abs().max()).item()
@@ -66,9 +69,9 @@ for (M, N, Kd) in ((128, 1280, 512), (256, 1280, 512), (128, 1280, 3264), (36, 1
 for rnd in range(3):
     for v in (0, 1, 3):
         if v == 3:
-            L.mansy_gemm_f32_wsk(1); L.mansy_gemm_f32_wsk(3)
+            KN.f32_wsk(1); KN.f32_wsk(3)
         else:
-            L.mansy_gemm_f32_wsk(v); L.mansy_gemm_f32_wsk(2)
+            KN.f32_wsk(v); KN.f32_wsk(2)
         r = bench.bench_ppo(0, 1, dev, mdist, cycles=20, warmup=3, rollout_probe=True)
         print(f'ppo wsk {v}: {r["ms_per_cycle"]:.3f} ms/cycle, {r["value"]:.0f} env-steps/s, rollout step {r["rollout_step_latency_us"]} us, loss {r["final_loss"]:.6f}', flush=True)
-L.mansy_gemm_f32_wsk(1); L.mansy_gemm_f32_wsk(3)
+KN.f32_wsk(1); KN.f32_wsk(3)

@@ -3,6 +3,9 @@
 <= 512 workgroups), variants interleaved in ONE process: the small product shapes of the PPO cycle alone, then the whole cycle."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import lab_knobs as KN  # noqa: E402  (ABI 8: the A/B knobs live in the -DMANSY_LAB build only)
+KN.enter()
 import torch
 import bench
 from mansy_immersivevideostreaming_amd import dist as mdist, kernels as K
@@ -29,7 +32,7 @@ for (M, N, Kd, bk) in ((256, 1280, 320, 0), (512, 1280, 320, 0), (512, 1280, 256
     ref = A.double() @ (B.double() if bk else B.double().t())
     line = f'gemm M={M} N={N} K={Kd} {"NN" if bk else "NT"}:'
     for v in (4, 5):
-        L.mansy_gemm_f32_wsk(v); out.zero_()
+        KN.f32_wsk(v); out.zero_()
         K.gemm(A, B, False, bool(bk), out=out, force_tile=64)
         err = ((out.double() - ref).abs().max() / ref.abs().max()).item()
         line += f'  stages {v - 3}: {timed(lambda: K.gemm(A, B, False, bool(bk), out=out, force_tile=64)):6.2f} us (err {err:.1e})'
@@ -39,7 +42,7 @@ for (M, N, Kd) in ((128, 1280, 512), (256, 1280, 512), (36, 132, 96)):
     ref = A.double().t() @ B.double() + 1.0
     line = f'gemm TN M={M} N={N} K={Kd}:'
     for v in (4, 5):
-        L.mansy_gemm_f32_wsk(v)
+        KN.f32_wsk(v)
         out = torch.ones(M, N, device=dev); rs = torch.zeros(M, device=dev)
         K.gemm(A, B, True, True, out=out, accumulate=True, a_rowsum=rs, force_tile=64)
         err = ((out.double() - ref).abs().max() / ref.abs().max()).item()
@@ -49,7 +52,7 @@ for (M, N, Kd) in ((128, 1280, 512), (256, 1280, 512), (36, 132, 96)):
     print(line, flush=True)
 for rnd in range(3):
     for v in (4, 5):
-        L.mansy_gemm_f32_wsk(v)
+        KN.f32_wsk(v)
         r = bench.bench_ppo(0, 1, dev, mdist, cycles=20, warmup=3, rollout_probe=True)
         print(f'ppo stages {v - 3}: {r["ms_per_cycle"]:.3f} ms/cycle, {r["value"]:.0f} env-steps/s, rollout step {r["rollout_step_latency_us"]} us, loss {r["final_loss"]:.6f}', flush=True)
-L.mansy_gemm_f32_wsk(5)
+KN.f32_wsk(5)

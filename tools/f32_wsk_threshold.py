@@ -3,6 +3,9 @@
 loop) and the VP train step with the 'small product' threshold at 256 (default) / 512 / 2048 tiles."""
 import os, sys, time, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import lab_knobs as KN  # noqa: E402  (ABI 8: the A/B knobs live in the -DMANSY_LAB build only)
+KN.enter()
 import numpy as np, torch
 import bench
 from mansy_immersivevideostreaming_amd import kernels as K
@@ -29,7 +32,7 @@ for (M, N, Kd, bk) in ((4096, 512, 512, 0), (4096, 512, 512, 1), (2048, 512, 512
     A = torch.randn(M, Kd, device=dev); B = torch.randn((Kd, N) if bk else (N, Kd), device=dev); out = torch.zeros(M, N, device=dev)
     line = f'gemm M={M} N={N} K={Kd} {"NN" if bk else "NT"}:'
     for thr in THR:
-        L.mansy_gemm_f32_wsk(thr)
+        KN.f32_wsk(thr)
         line += f'  threshold {thr}: {timed(lambda: K.gemm(A, B, False, bool(bk), out=out, force_tile=64)):6.2f} us'
     print(line, flush=True)
 torch.manual_seed(5); random.seed(5); np.random.seed(5)
@@ -38,10 +41,10 @@ opt = FusedAdamW(m, lr=1e-4)
 h, c, f = (t.cuda() for t in bench.synthetic_trajectories(4096, 10, 10, seed=5))
 for rnd in range(3):
     for thr in THR:
-        L.mansy_gemm_f32_wsk(thr)
+        KN.f32_wsk(thr)
         for _ in range(3): m.train_step(h, c, f, opt)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(10): m.train_step(h, c, f, opt)
         torch.cuda.synchronize()
         print(f'vp threshold {thr}: {(time.perf_counter() - t0) / 10 * 1e3:.3f} ms/step', flush=True)
-L.mansy_gemm_f32_wsk(256)
+KN.f32_wsk(256)

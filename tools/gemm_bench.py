@@ -4,6 +4,8 @@
 --check additionally reports the max error of every (shape, mode) against a float64 product, relative to max|C|."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import lab_knobs as KN  # noqa: E402  (ABI 8: the A/B knobs live in the -DMANSY_LAB build only; entered lazily, by the first knob that is set)
 import torch
 from mansy_immersivevideostreaming_amd import kernels as K
 
@@ -34,7 +36,7 @@ tiles = [int(x) for x in args if x != '--check'] or [0]
 tiles = [(t, pr) for pr in precs for t in tiles]
 if VARIANT is not None:
     from mansy_immersivevideostreaming_amd._lib import lib
-    lib().mansy_gemm_bf16_variant(VARIANT)
+    KN.bf16_variant(VARIANT)
 tot = {t: 0.0 for t in tiles}
 for name, ak, bk, M, N, Kd, acc, cnt in SHAPES:
     A = torch.randn((Kd, M) if ak else (M, Kd), device='cuda')

@@ -3,6 +3,8 @@
 precision: f32 | bf16x3 | bf16x6; planes = 1: the weight operand pre-split into bf16 planes (the engine's forward / dX form)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import lab_knobs as KN  # noqa: E402  (ABI 8: the A/B knobs live in the -DMANSY_LAB build only; entered lazily, by the first knob that is set)
 import torch
 from mansy_immersivevideostreaming_amd import kernels as K
 M, N, Kd, ak, bk = (int(x) for x in sys.argv[1:6])
@@ -14,11 +16,11 @@ out = torch.zeros(M, N, device='cuda')
 K.set_precision(prec)
 if os.environ.get('MANSY_BF16_VARIANT'):
     from mansy_immersivevideostreaming_amd._lib import lib
-    lib().mansy_gemm_bf16_variant(int(os.environ['MANSY_BF16_VARIANT']))
+    KN.bf16_variant(int(os.environ['MANSY_BF16_VARIANT']))
 FT = int(os.environ.get('MANSY_FORCE_TILE', '0'))
 if os.environ.get('MANSY_COL_GROUP'):
     from mansy_immersivevideostreaming_amd._lib import lib
-    lib().mansy_gemm_col_group(int(os.environ['MANSY_COL_GROUP']))
+    KN.col_group(int(os.environ['MANSY_COL_GROUP']))
 if planes and not ak and prec != 'f32':
     pl, pl_t = K.weight_planes(B, 2 if prec == 'bf16x3' else 3)
     run = lambda: K.gemm_planes(A, B, pl_t if bk else pl, transposed=bool(bk), force_tile=FT)
