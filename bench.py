@@ -255,7 +255,7 @@ def _ppo_cycle_time(pol, dev, cycles, warmup, n_env=256, steps_per_env=16, qoe_w
     return dt / cycles * 1e3, (n1 - n0) / float(cycles) + (col.graph_launches if col.use_graph and col._graph is not None else 0), loss
 
 
-def bench_ppo_dp_form(dev, mdist, cycles=6, warmup=2):
+def bench_ppo_dp_form(dev, mdist, cycles=6, warmup=2, vp_leg=None):
     """VERDICT r04 #1a: what data parallelism costs a rank BEFORE any wire time, measured on one MI355X.  The same PPO cycle three ways:
     fused (single process: gradient norm, clip and Adam ride on the step's own launches), and the data-parallel FORM at world 1 with the
     average really issued -- the hand-written peer kernel on a one-rank context (csrc/xgmi.hip) and the library collective (RCCL AVG over a
@@ -289,10 +289,44 @@ def bench_ppo_dp_form(dev, mdist, cycles=6, warmup=2):
         out['dp_rccl'] = {'ms_per_cycle': round(ms_r, 3), 'library_launches_per_cycle': round(nl_r, 1), 'host_enqueue_ms_per_cycle': round(_ppo_cycle_time.host_ms, 3), 'vs_fused': round(ms_r / ms, 3),
                           'us_per_average': round((ms_r - ms) * 1e3 / 18, 2), 'implied_ceiling_8gpu': round(8 * ms / ms_r, 2),
                           'note': 'launch counts exclude RCCL\'s own kernels'}
+        if vp_leg is not None:          # the VP step in ITS data-parallel form over the same one-rank RCCL group
+            out['vp_step'] = vp_leg()
         dist.destroy_process_group()
     except Exception as e:          # noqa: BLE001 -- a box without a usable RCCL: say so instead of losing the line
         out['dp_rccl'] = {'error': str(e)[:200]}
     return out
+
+
+def vp_dp_form_leg(model, opt, h, c, f, dev, mdist, steps=8, warmup=3):
+    """The VP train step (B = 4096) in its data-parallel form at world 1 over a one-rank RCCL group, everything issued: the two SyncBN statistics
+    all-reduces from inside the engine's hook, the flat-gradient AVG with its decoder-side two thirds on the side stream under the encoder backward
+    (dist.OverlappedGradSync), AdamW as a launch of its own behind the collective.  The one real rank stands for two identical ones (the hook doubles
+    the reduced sums: tools/rccl_selftest.py), so the arithmetic equals the single-process step."""
+    import torch
+    import torch.distributed as dist
+
+    def timed(step):
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
+    ms_plain = timed(lambda: model.train_step(h, c, f, opt))
+
+    def bn_allreduce(t):
+        dist.all_reduce(t)
+        t.mul_(2.0)
+    model.set_data_parallel(2, allreduce=bn_allreduce)
+    osync = mdist.OverlappedGradSync(1, dev, force=True)
+    try:
+        ms_dp = timed(lambda: model.train_step(h, c, f, opt, grad_sync=osync))
+    finally:
+        model.set_data_parallel(1)
+    return {'workload': 'VP train step B=4096 fp32: SyncBN hook (2 x 1024 doubles) + 36.8 MB flat-gradient AVG (tail overlapped) + AdamW behind the collective, one-rank RCCL group',
+            'ms_per_step_single_process': round(ms_plain, 3), 'ms_per_step_dp_form': round(ms_dp, 3), 'vs_single_process': round(ms_dp / ms_plain, 4)}
 
 
 def bench_ppo_c5(dev, cycles=5, warmup=2):
@@ -830,7 +864,7 @@ def main():
             out['inference'] = bench_vp_inference(model, h, c, f)
             out['small_batch'] = bench_vp_small(dev)
             out['configs4'] = bench_ppo_c5(dev)
-            out['secondary']['dp_form'] = bench_ppo_dp_form(dev, mdist)      # (last: it brings up a one-rank RCCL group)
+            out['secondary']['dp_form'] = bench_ppo_dp_form(dev, mdist, vp_leg=lambda: vp_dp_form_leg(model, opt, h, c, f, dev, mdist))      # (last: it brings up a one-rank RCCL group)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
