@@ -804,7 +804,10 @@ def test_chained_update_equals_self_contained_steps(M):
 def test_data_parallel_step_form_equals_the_single_process_step(M):
     """The data-parallel form of an update -- raw gradients (step = 0), average over the ranks, then mansy_ppo_dp_tail (clip + Adam +
     gradient zero-fill + re-pack + next minibatch's gather) or, unchained, mansy_clip_grad_adam -- with an identity `grad_sync`
-    (one rank) must land where the single-process chained step lands: same gradients, same clip, same Adam, to float32 rounding."""
+    (one rank) must land where the single-process chained step lands: same gradients, same clip, same Adam, to float32 rounding.
+    Round 5: also the peer-memory forms on a one-rank context with the average REALLY issued -- 'peer-slot' (the default: the whole
+    data-parallel step is one mansy_ppo_minibatch_step(..., xg_ctx) call, gradients produced in the exchange slot, one launch publishes /
+    waits / sums) and 'peer-copy' (the round-4 three-call form) -- and the identifier's training rounds in the same two forms."""
     sd = po.make_policy_state_dict(int(Z['wseed']))
     T, N, bs = 11, 100, 512                                         # ragged: 512 + 588 per pass
     rs = np.random.RandomState(11)
@@ -816,9 +819,15 @@ def test_data_parallel_step_form_equals_the_single_process_step(M):
     rew = torch.from_numpy(rs.randn(T, N).astype(np.float32))
     done = torch.from_numpy((rs.rand(T, N) < 0.05).astype(np.uint8))
     outs = []
-    for form in ('single', 'dp-chained', 'dp-unchained'):
+    ident = []
+    for form in ('single', 'dp-chained', 'dp-unchained', 'peer-slot', 'peer-copy', 'peer-slot-unchained'):
         pol = build_policy(M, sd)
-        if form != 'single':
+        if form.startswith('peer'):
+            pol.peer_in_slot = form != 'peer-copy'
+            pol.set_data_parallel(1, None, peer=True, force=True)
+            pol.chain_steps = form != 'peer-slot-unchained'            # unchained: the slot form is not available, the copy form takes over on the same context
+            assert (pol._xg_ctx(pol.engine.ac) is not None) == (form != 'peer-copy')
+        elif form != 'single':
             pol.set_data_parallel(1, lambda g: None)
             pol.chain_steps = form == 'dp-chained'
         buf = M.ppo.RolloutBuffer(T, N, 'cuda')
@@ -831,6 +840,16 @@ def test_data_parallel_step_form_equals_the_single_process_step(M):
             rows.append(np.stack([res['loss'], res['loss/clip'], res['loss/vf'], res['loss/ent']], 1))
         f = pol.engine.ac
         outs.append((np.concatenate(rows), f.flat_p.clone(), f.m.clone(), f.v.clone()))
+        if form in ('single', 'peer-slot', 'peer-copy'):            # train_identifier: two full-batch rounds + validation, same shuffle
+            np.random.seed(5)
+            losses, vloss = pol.train_identifier(buf, 2, verbose=False)
+            torch.cuda.synchronize()
+            pol._check_peers()
+            ident.append((np.array([l.item() for l in losses] + [vloss.item()]), pol.engine.idn.flat_p.clone()))
+    for losses, flat in ident[1:]:
+        np.testing.assert_allclose(losses, ident[0][0], rtol=1e-6, atol=1e-7)
+        assert (flat - ident[0][1]).abs().max().item() <= 2.1 * 1e-4          # Adam(lr 1e-4): +-lr steps of zero-gradient parameters at most
+        assert float(((flat - ident[0][1]).abs() > 1e-6).float().mean()) <= 2e-3
     for o in outs[1:]:
         np.testing.assert_allclose(o[0], outs[0][0], rtol=2e-5, atol=2e-6)
         for a, b in zip(o[1:], outs[0][1:]):
