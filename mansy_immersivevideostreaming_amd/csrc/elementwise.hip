@@ -433,6 +433,24 @@ __global__ __launch_bounds__(256) void mtio_mix_kernel(const float* __restrict__
   out[idx] = x[((long long)src * L + l) * c + j];
 }
 
+// the three MTIO mixes of a train step (history, current, future: mtio.py:77-87) as ONE launch: segment s covers [B, L_s, 3c]
+struct MtioMix3 { const float* x[3]; float* out[3]; int L[3]; long long end[3]; };
+__global__ __launch_bounds__(256) void mtio_mix3_kernel(MtioMix3 a, const int* __restrict__ perm1, const int* __restrict__ perm2, int B, int c) {
+  long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= a.end[2]) return;
+  const int s = idx < a.end[0] ? 0 : (idx < a.end[1] ? 1 : 2);
+  if (s) idx -= a.end[s - 1];
+  const int L = a.L[s];
+  const int ch = (int)(idx % (3 * c));
+  const int l = (int)((idx / (3 * c)) % L);
+  const int b = (int)(idx / ((long long)3 * c * L));
+  const int k = ch / c, j = ch % c;
+  int src = b;
+  if (k == 1 && perm1) src = perm1[b];
+  if (k == 2 && perm2) src = perm2[b];
+  a.out[s][idx] = a.x[s][((long long)src * L + l) * c + j];
+}
+
 __global__ __launch_bounds__(256) void ensemble_wrap_kernel(const float* __restrict__ pred, float* __restrict__ out, long long rows,
                                                             int heads, int c) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;     // over [rows, c]
@@ -700,6 +718,17 @@ int mansy_launch_mtio_mix(const float* x, const int* perm1, const int* perm2, fl
   const long long total = (long long)B * L * 3 * c;
   if (total <= 0) return MANSY_OK;
   MANSY_LAUNCH(mtio_mix_kernel, g1(total), dim3(256), 0, st, x, perm1, perm2, out, B, L, c);
+  MANSY_LAUNCH_CHECK();
+  return MANSY_OK;
+}
+int mansy_launch_mtio_mix3(const float* hist, const float* cur, const float* fut, const int* perm1, const int* perm2, float* src6, float* cur6, float* fut6,
+                           int B, int S, int T, int c, hipStream_t st) {
+  MANSY_REQUIRE(hist && cur && fut && src6 && cur6 && fut6, "mtio_mix3: null pointer");
+  MtioMix3 a;
+  a.x[0] = hist; a.x[1] = cur; a.x[2] = fut; a.out[0] = src6; a.out[1] = cur6; a.out[2] = fut6; a.L[0] = S; a.L[1] = 1; a.L[2] = T;
+  a.end[0] = (long long)B * S * 3 * c; a.end[1] = a.end[0] + (long long)B * 3 * c; a.end[2] = a.end[1] + (long long)B * T * 3 * c;
+  if (a.end[2] <= 0) return MANSY_OK;
+  MANSY_LAUNCH(mtio_mix3_kernel, g1(a.end[2]), dim3(256), 0, st, a, perm1, perm2, B, c);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }

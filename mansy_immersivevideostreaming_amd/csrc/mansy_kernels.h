@@ -144,6 +144,10 @@ int mansy_launch_layernorm_bwd_partial(const float* dy, const float* z, const fl
                                        float* dz, float* dz_drop, MansyDrop drop, float* partials, int accumulate, int rows, int C,
                                        hipStream_t st);
 int mansy_launch_ln_partials_reduce(const float* partials, int nparts, int C, float* dw, float* dbias, hipStream_t st);
+// several slot sets in one launch (the end of a VP backward: every LayerNorm's weight / bias gradient)
+constexpr int LN_MULTI_MAX = 64;      // >= 2 halves x (3 x 8 layers + 1)
+struct MansyLnReduce { const float* partials; int nparts; float* dw; float* dbias; };
+int mansy_launch_ln_partials_reduce_multi(const MansyLnReduce* sets, int n, int C, hipStream_t st);
 
 // BatchNorm1d(train) + ELU + MaxPool1d(3,2,1) of the DistillLayer on conv output [B*S, C].
 struct DistillShape { int B, S, M, C; int sync_world = 1; int (*hook)(int, void*) = nullptr; void* hook_user = nullptr; };
@@ -230,6 +234,8 @@ int mansy_launch_add(const float* a, const float* b, float* y, long long n, hipS
 // MTIO channel mix (mtio.py:72-90): out[b, l, k*c + j] = x[perm_k[b], l, j] ; perm null => identity
 int mansy_launch_mtio_mix(const float* x, const int* perm1, const int* perm2, float* out, int B, int L, int c,
                           hipStream_t st);
+int mansy_launch_mtio_mix3(const float* hist, const float* cur, const float* fut, const int* perm1, const int* perm2, float* src6, float* cur6, float* fut6,
+                           int B, int S, int T, int c, hipStream_t st);
 // ensemble mean over heads + wrap to [0,1] (mtio.py:125-133, utils/common.py:61-70): pred [B,T,heads*c] -> [B,T,c]
 int mansy_launch_ensemble_wrap(const float* pred, float* out, long long rows, int heads, int c, hipStream_t st);
 int mansy_launch_linreg_sample(const float* hist, const float* cur, int B, int S, int T, int c, float* out, hipStream_t st);

@@ -270,6 +270,31 @@ __global__ __launch_bounds__(256) void ln_partials_reduce_kernel(const float* __
   if (grp == 0 && c < C) atomicAdd(dst + c, (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
 }
 
+// the same for up to LN_MULTI_MAX slot sets in ONE launch (round 5: the decoder's 7 / 14 sets and the encoder's 5 at the end of a backward were
+// twelve launches of ~4 us each at the reference's batch sizes): blockIdx.y = 2 * set + which
+struct LnMulti { const float* partials[LN_MULTI_MAX]; int nparts[LN_MULTI_MAX]; float* dw[LN_MULTI_MAX]; float* dbias[LN_MULTI_MAX]; };
+__global__ __launch_bounds__(256) void ln_partials_reduce_multi_kernel(LnMulti t, int C) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane, set = blockIdx.y >> 1, which = blockIdx.y & 1;
+  float* dst = which == 0 ? t.dw[set] : t.dbias[set];
+  const int nparts = t.nparts[set];
+  if (!dst || (int)blockIdx.z * 64 >= nparts) return;
+  float acc = 0.f;
+  if (c < C) {
+    const float* src = t.partials[set] + (size_t)which * C + c;
+    const int p0 = blockIdx.z * 64 + grp * 16;
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = src[(size_t)min(p0 + u, nparts - 1) * 2 * C];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc += p0 + u < nparts ? v[u] : 0.f;
+  }
+  red[grp][lane] = acc;
+  __syncthreads();
+  if (grp == 0 && c < C) atomicAdd(dst + c, (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
+}
+
 // ------------------------------------------------------------------ DistillLayer tail
 // column sums of x and x^2 over rows -> doubles
 __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__ x, int rows, int C, double* __restrict__ stats, double* __restrict__ part) {
@@ -584,6 +609,18 @@ int mansy_launch_layernorm_bwd_partial(const float* dy, const float* z, const fl
   else if (C / 256 == 3) LNB(3, 4);
   else LNB(4, 4);
 #undef LNB
+  MANSY_LAUNCH_CHECK();
+  return MANSY_OK;
+}
+int mansy_launch_ln_partials_reduce_multi(const MansyLnReduce* sets, int n, int C, hipStream_t st) {
+  MANSY_REQUIRE(sets && n >= 1 && n <= LN_MULTI_MAX, "ln_partials_reduce_multi: 1..%d sets", LN_MULTI_MAX);
+  LnMulti t; int maxp = 1;
+  for (int i = 0; i < LN_MULTI_MAX; ++i) {
+    const MansyLnReduce& s = sets[i < n ? i : 0];
+    t.partials[i] = s.partials; t.nparts[i] = i < n ? s.nparts : 0; t.dw[i] = i < n ? s.dw : nullptr; t.dbias[i] = i < n ? s.dbias : nullptr;
+    if (i < n) { MANSY_REQUIRE(s.partials && s.nparts >= 1, "ln_partials_reduce_multi: bad set %d", i); maxp = s.nparts > maxp ? s.nparts : maxp; }
+  }
+  MANSY_LAUNCH(ln_partials_reduce_multi_kernel, dim3(mansy_ceil_div(C, 64), 2 * n, mansy_ceil_div(maxp, 64)), dim3(256), 0, st, t, C);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }

@@ -200,7 +200,7 @@ void build_layout(const mansy_vp_config& c, Layout& L, Work& W) {
   // decoder: one slot set per LayerNorm (3 per layer + the final norm), accumulated over the T steps; encoder: one scratch set
   // (x 2: when the decoder runs as two half-batches on two streams each half accumulates into its own slot sets)
   W.lnp_dec = L.f("lnp.dec", (size_t)2 * (3 * c.n_dec + 1) * mansy_ln_bwd_parts((int)B) * 2 * d);
-  W.lnp_enc = L.f("lnp.enc", (size_t)mansy_ln_bwd_parts((int)N) * 2 * d);
+  W.lnp_enc = L.f("lnp.enc", (size_t)(2 * c.n_enc + 1) * mansy_ln_bwd_parts((int)N) * 2 * d);      // one set per encoder LayerNorm (round 5: reduced together at the end)
   W.loss_acc = (double*)L.add("loss_acc", 64);
   // bf16x3 mode: 2 planes x (W, W^T) of every GEMM weight, 2 bytes each (73 MB at d = 512, 1 % of the B = 4096 workspace; filled
   // once per step).  Only bf16x3 pre-splits its weights (prepare_planes), so the third plane round 2 reserved is gone; the region
@@ -248,6 +248,12 @@ struct Eng {
   }
   // ---- split-bf16 modes: the GEMM weights' planes (gemm_bf16s.hip, pre-split B)
   MansyWPlaneTab wtab; int prec = 0;
+  MansyLnReduce ln_pending[LN_MULTI_MAX]; int ln_n_pending = 0;      // LayerNorm weight-gradient slot sets waiting for their reduce launch
+  int flush_ln() {
+    if (!ln_n_pending) return MANSY_OK;
+    const int n = ln_n_pending; ln_n_pending = 0;
+    return mansy_launch_ln_partials_reduce_multi(ln_pending, n, d, st);
+  }
   void wtab_add(const LinearP& L, int Nout, int K) {
     if (!L.w || Nout < 32 || K < 32 || wtab.n >= MANSY_WPLANE_MAX) return;
     long long off = 0;
@@ -324,9 +330,12 @@ struct Eng {
   int ln_bwd(const float* dy, const float* z, const float* m, const float* r, const NormP& n, float* dz, float* dz_drop,
              MansyDrop drop, int rows, int part_slot = -1) {
     if (!mansy_ln_bwd_partial_ok(d)) return mansy_launch_layernorm_bwd(dy, z, m, r, n.w, dz, dz_drop, drop, n.gw, n.gb, rows, d, st);
-    if (part_slot < 0) {
-      RC(mansy_launch_layernorm_bwd_partial(dy, z, m, r, n.w, dz, dz_drop, drop, W.lnp_enc, 0, rows, d, st));
-      return mansy_launch_ln_partials_reduce(W.lnp_enc, mansy_ln_bwd_parts(rows), d, n.gw, n.gb, st);
+    if (part_slot < 0) {          // encoder LayerNorm -(part_slot + 1): its own scratch set, overwritten; added into the gradient by the one reduce launch at the end
+      const int e = -(part_slot + 1);
+      float* set = W.lnp_enc + (size_t)e * mansy_ln_bwd_parts(rows) * 2 * d;
+      RC(mansy_launch_layernorm_bwd_partial(dy, z, m, r, n.w, dz, dz_drop, drop, set, 0, rows, d, st));
+      ln_pending[ln_n_pending++] = MansyLnReduce{set, mansy_ln_bwd_parts(rows), n.gw, n.gb};
+      return MANSY_OK;
     }
     float* slots = W.lnp_dec + (size_t)part_slot * mansy_ln_bwd_parts(B) * 2 * d;
     return mansy_launch_layernorm_bwd_partial(dy, z, m, r, n.w, dz, dz_drop, drop, slots, 1, rows, d, st);
@@ -595,17 +604,19 @@ struct Eng {
       }
     }
     if (split) RC(join());
-    if (ln_parts) {   // decoder LayerNorm weight gradients: slot sets -> gradients (both halves' sets add into the same gradient)
+    if (ln_parts) {   // decoder LayerNorm weight gradients: slot sets -> gradients (both halves' sets add into the same gradient); queued for the ONE
+      // reduce launch at the end of the backward (with the encoder's sets: round 5, was 7 / 14 + 5 launches)
       for (int half = 0; half < (split ? 2 : 1); ++half) {
         const int np = mansy_ln_bwd_parts(half ? B - h0 : h0);
-        const float* base = W.lnp_dec + (size_t)half * n_ln * lnp_set;
+        float* base = W.lnp_dec + (size_t)half * n_ln * lnp_set;
         for (int l = 0; l < c.n_dec; ++l) {
-          RC(mansy_launch_ln_partials_reduce(base + (size_t)(3 * l + 0) * lnp_set, np, d, P.dec[l].n1.gw, P.dec[l].n1.gb, st));
-          RC(mansy_launch_ln_partials_reduce(base + (size_t)(3 * l + 1) * lnp_set, np, d, P.dec[l].n2.gw, P.dec[l].n2.gb, st));
-          RC(mansy_launch_ln_partials_reduce(base + (size_t)(3 * l + 2) * lnp_set, np, d, P.dec[l].n3.gw, P.dec[l].n3.gb, st));
+          ln_pending[ln_n_pending++] = MansyLnReduce{base + (size_t)(3 * l + 0) * lnp_set, np, P.dec[l].n1.gw, P.dec[l].n1.gb};
+          ln_pending[ln_n_pending++] = MansyLnReduce{base + (size_t)(3 * l + 1) * lnp_set, np, P.dec[l].n2.gw, P.dec[l].n2.gb};
+          ln_pending[ln_n_pending++] = MansyLnReduce{base + (size_t)(3 * l + 2) * lnp_set, np, P.dec[l].n3.gw, P.dec[l].n3.gb};
         }
-        RC(mansy_launch_ln_partials_reduce(base + (size_t)(3 * c.n_dec) * lnp_set, np, d, P.dec_norm.gw, P.dec_norm.gb, st));
+        ln_pending[ln_n_pending++] = MansyLnReduce{base + (size_t)(3 * c.n_dec) * lnp_set, np, P.dec_norm.gw, P.dec_norm.gb};
       }
+      RC(flush_ln());      // here: the decoder-side gradients must be final before the hook below (which = 2) hands them to the all-reduce
     }
     // ---- deferred decoder weight gradients: one reduce-dim-(T*B) GEMM per weight
     RC(mansy_launch_outer_reduce(W.dz_all, C6, W.dec_out, TB, d, P.pred.gw, 0, nullptr, P.pred.gb, st));
@@ -637,17 +648,17 @@ struct Eng {
     if (c.bn_sync_world > 1) RC(mansy_bn_sync_invoke(2, c.bn_sync_fn, c.bn_sync_user));
     // ---- encoder
     const float* last = W.enc[c.n_enc - 1].y2;
-    RC(ln_bwd(W.g_a, last, W.me, W.re, P.enc_norm, W.g_b, nullptr, mansy_no_drop(), N));
+    RC(ln_bwd(W.g_a, last, W.me, W.re, P.enc_norm, W.g_b, nullptr, mansy_no_drop(), N, -1));
     float* gx = W.g_b; float* gz = W.g_a; float* gt = W.g_c;
     for (int l = c.n_enc - 1; l >= 0; --l) {
       const EncLayerP& p = P.enc[l]; EncBuf& e = W.enc[l];
       const float* x_in = l == 0 ? W.x0 : W.enc[l - 1].y2;
-      RC(ln_bwd(gx, e.z2, e.m2, e.r2, p.n2, gz, gt, dr(site_enc(l, 3), c.p_drop), N));        // gt = d/d(lin2 out)
+      RC(ln_bwd(gx, e.z2, e.m2, e.r2, p.n2, gz, gt, dr(site_enc(l, 3), c.p_drop), N, -(2 + 2 * l)));        // gt = d/d(lin2 out)
       RC(lin_dw(gt, e.h, N, d, f, p.lin2.gw, p.lin2.gb));
       RC(lin_dx(gt, N, d, p.lin2.w, f, W.g_ff, nullptr, e.h, ms));                             // g_ff = d/d(lin1 pre-act)
       RC(lin_dw(W.g_ff, e.y1, N, f, d, p.lin1.gw, p.lin1.gb));
       RC(lin_dx(W.g_ff, N, f, p.lin1.w, d, gt, gz, nullptr, 1.f));                             // gt = d/dy1
-      RC(ln_bwd(gt, e.z1, e.m1, e.r1, p.n1, gz, gx, dr(site_enc(l, 1), c.p_drop), N));         // gx = d/d(out_proj out)
+      RC(ln_bwd(gt, e.z1, e.m1, e.r1, p.n1, gz, gx, dr(site_enc(l, 1), c.p_drop), N, -(3 + 2 * l)));         // gx = d/d(out_proj out)
       RC(lin_dw(gx, e.ao, N, d, d, p.out_proj.gw, p.out_proj.gb));
       RC(lin_dx(gx, N, d, p.out_proj.w, d, gt, nullptr, nullptr, 1.f));                        // gt = d/dao
       RC(mansy_launch_attn_bwd(e.qkv, e.qkv + d, e.qkv + 2 * d, e.P, gt, W.g_wide, W.g_wide + d, W.g_wide + 2 * d, enc_shape(),
@@ -657,7 +668,7 @@ struct Eng {
     }
     RC(mansy_launch_embed_bwd(gx, P.emb.w, gt, nullptr, C6, N, d, dr(site_pe_src(), c.p_pe), st));
     RC(mansy_launch_outer_reduce(src, C6, gt, N, d, P.emb.gw, 1, P.emb.gb, nullptr, st));
-    return MANSY_OK;
+    return flush_ln();      // the encoder's five LayerNorm weight / bias gradients: one launch
   }
 };
 
@@ -757,9 +768,7 @@ int mansy_vp_train_step(const mansy_vp_config* cfg, const float* const* params, 
   e.W = W;
   bind_params(*cfg, params, grads, e.P);
   const int c = cfg->in_ch / 3;
-  RC(mansy_launch_mtio_mix(history, perm1, perm2, W.src6, cfg->B, cfg->S, c, st));
-  RC(mansy_launch_mtio_mix(current, perm1, perm2, W.cur6, cfg->B, 1, c, st));
-  RC(mansy_launch_mtio_mix(future, perm1, perm2, W.fut6, cfg->B, cfg->T, c, st));
+  RC(mansy_launch_mtio_mix3(history, current, future, perm1, perm2, W.src6, W.cur6, W.fut6, cfg->B, cfg->S, cfg->T, c, st));      // one launch (was three)
   MANSY_HIP_CHECK(hipMemsetAsync(flat_g, 0, sizeof(float) * (size_t)n_flat, st));
   RC(e.forward(W.src6, W.cur6, pe, bn_running_mean, bn_running_var, bn_num_batches, W.pred_bt));
   const long long n = (long long)cfg->B * cfg->T * cfg->in_ch;
