@@ -323,9 +323,26 @@ def probe_peer_grad_sync(sizes, world, rank, device, library_sync, iters=10, pro
     # the form the engine steps use: the gradient is already in the slot, the launch publishes / waits / sums (the library side additionally
     # pays a gradient-norm launch and a second library call per step, which this comparison leaves out: it errs towards the library)
     t_peer = timed(lambda b: peers[n0].reduce_into(b, scratch))
+    # once more with NEW data after the timed loops: both slots have been used many times by now, so a reader that kept a stale copy of a
+    # peer's slot from an earlier epoch (a cache the acquire did not drop) shows here and nowhere above (the timed loops repeat one buffer).
+    # (The library collective of this check runs OUTSIDE the try block: every rank issues it whatever happened to its peer launches.)
+    fresh = (src * 0.5 + float(rank + 1)).contiguous()
+    ref2 = fresh.clone()
+    library_sync(ref2)
     try:
         peers[n0].check()
         timed_ok = 1.0
+        for form in ('slot', 'copy'):
+            out3 = fresh.clone()
+            if form == 'slot':
+                peers[n0].slot_tensor(peers[n0].next_slot()).copy_(fresh)
+                peers[n0].reduce_into(out3, scratch)
+            else:
+                peers[n0](out3, scratch)
+            torch.cuda.synchronize(device)
+            peers[n0].check()
+            if not torch.allclose(out3, ref2, rtol=1e-5, atol=1e-6):
+                timed_ok = 0.0
     except Exception:               # noqa: BLE001
         timed_ok = 0.0
     report.update(us_library=round(t_lib, 1), us_peer=round(t_peer, 1), floats=n0)
@@ -333,7 +350,7 @@ def probe_peer_grad_sync(sizes, world, rank, device, library_sync, iters=10, pro
     if not all_timed_ok or not t_peer < t_lib:
         for q in peers.values():
             q.close()
-        report.update(chosen='library', reason='library collective is not slower' if all_timed_ok else 'a timed peer launch missed its peers')
+        report.update(chosen='library', reason='library collective is not slower' if all_timed_ok else 'a timed peer launch missed its peers or a later average came out wrong')
         return {}, report
     for q in peers.values():                     # in production a late peer is waited for (bounded), not declared dead after 5 s
         q._check(q._lib.mansy_xg_set_timeout_ms(q.ctx, float(timeout_ms)), 'mansy_xg_set_timeout_ms')
