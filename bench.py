@@ -289,6 +289,15 @@ def bench_ppo_dp_form(dev, mdist, cycles=6, warmup=2, vp_leg=None):
         out['dp_rccl'] = {'ms_per_cycle': round(ms_r, 3), 'library_launches_per_cycle': round(nl_r, 1), 'host_enqueue_ms_per_cycle': round(_ppo_cycle_time.host_ms, 3), 'vs_fused': round(ms_r / ms, 3),
                           'us_per_average': round((ms_r - ms) * 1e3 / 18, 2), 'implied_ceiling_8gpu': round(8 * ms / ms_r, 2),
                           'note': 'launch counts exclude RCCL\'s own kernels'}
+        # the same library collective through the library's OWN communicator wrapper (mansy_comm_* / mansy_allreduce_*): the step is one call again
+        comm = mdist.RcclComm(1, 0, dev)
+        pol = _ppo_policy(dev)
+        pol.set_data_parallel(1, None, peer=False, force=True, comm=comm)
+        ms_c, nl_c, _ = _ppo_cycle_time(pol, dev, cycles, warmup)
+        out['dp_rccl_one_call'] = {'ms_per_cycle': round(ms_c, 3), 'library_launches_per_cycle': round(nl_c, 1), 'host_enqueue_ms_per_cycle': round(_ppo_cycle_time.host_ms, 3),
+                                   'vs_fused': round(ms_c / ms, 3), 'us_per_average': round((ms_c - ms) * 1e3 / 18, 2), 'implied_ceiling_8gpu': round(8 * ms / ms_c, 2),
+                                   'note': 'mansy_ppo_minibatch_step(..., sync = mansy_comm context): ncclAllReduce(avg) + norm launch inside the step call'}
+        comm.close()
         if vp_leg is not None:          # the VP step in ITS data-parallel form over the same one-rank RCCL group
             out['vp_step'] = vp_leg()
         dist.destroy_process_group()

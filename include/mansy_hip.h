@@ -243,12 +243,14 @@ int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, fl
                              float eps_clip, float vf_coef, float ent_coef, int norm_adv, int value_clip, float dual_clip,
                              float max_grad_norm, float lr, float weight_decay, int step, long long tail_from, int tail_step, float* stats,
                              void* workspace, int max_batch, int chain_in, const int* next_idx, int next_mb, void* xg_ctx, int precision, void* stream);
-/* xg_ctx (ABI 8; NULL = single process): a mansy_xg context of n_flat floats (below) -- the DATA-PARALLEL step as one call: the rank's raw
- * gradients are produced straight in its exchange slot, ONE more launch than the single-process step publishes the slot, waits (bounded) for
- * every peer's, sums all ranks' slots in rank order into flat_g and leaves the sums of squares of the average; clip + Adam + the chained
- * prologue follow as in the single-process step.  Needs the clipped chained form (max_grad_norm > 0, step > 0, no lagged tail).  Every rank
- * makes the same sequence of calls on its context.  (The library-collective form stays: step = 0 here, the caller's all-reduce,
- * mansy_ppo_dp_tail.) */
+/* xg_ctx = the step's `sync` context (ABI 8; NULL = single process) -- the DATA-PARALLEL step as ONE call.  Needs the clipped chained form
+ * (max_grad_norm > 0, step > 0, no lagged tail); every rank makes the same sequence of calls on its context.
+ *  - a mansy_xg context of n_flat floats (MANSY_SYNC_XG): the rank's raw gradients are produced straight in its exchange slot, ONE more launch
+ *    than the single-process step publishes the slot, waits (bounded) for every peer's, sums all ranks' slots in rank order into flat_g and
+ *    leaves the sums of squares of the average; clip + Adam + the chained prologue follow as in the single-process step;
+ *  - a communicator context (MANSY_SYNC_RCCL, mansy_comm_create): raw gradients in flat_g, ncclAllReduce(avg) on the stream, a gradient-norm
+ *    launch, then the same tail.
+ * (The three-call form stays for callers with a collective of their own: step = 0 here, their all-reduce, mansy_ppo_dp_tail.) */
 /* Layout contract of the chained forms (step > 0 with max_grad_norm > 0, and mansy_ppo_dp_tail): their last launch updates four consecutive
  * elements per thread and scatters them into the packed images, so flat_p / flat_g / flat_m / flat_v must be 16-byte aligned and every
  * params[k] must be an ascending view of flat_p that starts at a multiple of 4 floats (the host mirror aligns tensors to 256 bytes);
@@ -290,6 +292,23 @@ int mansy_ppo_dp_tail(const float* const* params, float* flat_p, float* flat_g, 
                       float max_grad_norm, float lr, float weight_decay, int step, double* scratch, int have_sumsq, const float* obs_all,
                       const float* adv_all, const int* next_idx, int next_mb, float* next_flat_g, void* workspace, int max_batch, int precision,
                       void* stream);
+
+/* ------------------------------------------------------------------ thin wrappers over RCCL communicators (round 5)
+ * The three collectives of the data-parallel hot path as C-ABI calls: explicit communicator, explicit stream, device pointers.  RCCL is bound at
+ * run time (dlopen of librccl.so -- torch's copy when the process already holds one), so the library has no link-time dependency on it.
+ * mansy_comm_unique_id on rank 0 -> the host moves the 128 bytes to every rank -> mansy_comm_create on every rank (collective) -> any number of
+ * collectives, the same sequence on every rank -> mansy_comm_destroy.  A communicator context is also a `sync` context of
+ * mansy_ppo_minibatch_step / mansy_identifier_train_step (below), like the peer-memory context of the next section. */
+typedef struct mansy_comm_id { unsigned char bytes[128]; } mansy_comm_id;
+int mansy_comm_unique_id(mansy_comm_id* out);
+int mansy_comm_create(const mansy_comm_id* id, int world, int rank, void** comm_out);
+int mansy_comm_destroy(void* comm);
+int mansy_allreduce_avg_f32(void* comm, float* buf /* in place */, long long n, void* stream);      /* flat gradient buffers (ncclAvg) */
+int mansy_allreduce_sum_f64(void* comm, double* buf /* in place */, long long n, void* stream);     /* SyncBN statistics (the hook of mansy_vp_config) */
+int mansy_allgather_f64(void* comm, const double* send, double* recv /* [world][n_per_rank] */, long long n_per_rank, void* stream);   /* return normaliser */
+/* first int of every sync context (what the engine entry points dispatch on) */
+#define MANSY_SYNC_XG 0x5847      /* peer-memory context (mansy_xg_create) */
+#define MANSY_SYNC_RCCL 0x5243    /* RCCL communicator context (mansy_comm_create) */
 
 /* ------------------------------------------------------------------ one-shot gradient all-reduce over peer-mapped memory (xGMI)
  * The data-parallel PPO update averages a 1.7 MB / 1.05 MB flat gradient 16 + 2 times per 2.6 ms cycle, every time on

@@ -39,6 +39,10 @@ class GemmEpilogue(ctypes.Structure):
             self.prec = PRECISIONS[current_precision()]      # the calling thread's default (host-side; the library has no default)
 
 
+class CommId(ctypes.Structure):            # mansy_comm_id: an opaque ncclUniqueId
+    _fields_ = [('bytes', ctypes.c_ubyte * 128)]
+
+
 class XgHandle(ctypes.Structure):          # mansy_xg_handle: an opaque hipIpcMemHandle_t
     _fields_ = [('bytes', ctypes.c_ubyte * 64)]
 
@@ -121,6 +125,12 @@ _PROTOS = {
     'mansy_bc_step': [P, P, P, P, P, P, c_ll, c_ll, P, P, c_int, c_float, c_float, c_float, c_int, P, P, c_int, c_int, P],
     'mansy_clip_grad_adam': [P, P, P, P, c_ll, c_float, c_float, c_float, c_int, c_ll, c_int, P, c_int, P],
     'mansy_ppo_dp_tail': [P, P, P, P, P, c_ll, c_float, c_float, c_float, c_int, P, c_int, P, P, P, c_int, P, P, c_int, c_int, P],
+    'mansy_comm_unique_id': [P],
+    'mansy_comm_create': [P, c_int, c_int, P],
+    'mansy_comm_destroy': [P],
+    'mansy_allreduce_avg_f32': [P, P, c_ll, P],
+    'mansy_allreduce_sum_f64': [P, P, c_ll, P],
+    'mansy_allgather_f64': [P, P, P, c_ll, P],
     'mansy_xg_create': [c_ll, c_int, c_int, P],
     'mansy_xg_export': [P, P],
     'mansy_xg_import': [P, P],

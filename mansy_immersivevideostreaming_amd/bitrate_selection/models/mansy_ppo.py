@@ -228,7 +228,7 @@ class PPOPolicy(nn.Module):
         self._pinned = {}
         self.peer_in_slot = True      # peer-memory averages: gradients are produced straight in the exchange slot (no copy in front of the flag)
 
-    def set_data_parallel(self, world, grad_sync, peer=False, force=False):
+    def set_data_parallel(self, world, grad_sync, peer=False, force=False, comm=None):
         """One process per GPU: `grad_sync(flat_grad)` averages a flat gradient buffer over ranks (dist.make_grad_sync).
         peer=True: the hand-written one-shot all-reduce over peer-mapped memory (dist.PeerGradSync, csrc/xgmi.hip) for both flat
         buffers instead -- one launch that also leaves the gradient's sums of squares for the clip.  peer='auto': build it, check it
@@ -238,7 +238,13 @@ class PPOPolicy(nn.Module):
         issued (grad_sync over a one-rank group, or the peer kernel on a one-rank context), then clip + Adam as a launch of its own --
         i.e. everything a rank pays for data parallelism except the wire time."""
         self.world, self.grad_sync = int(world), grad_sync
-        if force and grad_sync is None:
+        # comm: a dist.RcclComm (the library's own RCCL communicator): the library-collective form of the step also becomes ONE call per step
+        # (gradients, ncclAllReduce(avg), norm, clip + Adam inside mansy_ppo_minibatch_step); it doubles as grad_sync where the one-call form
+        # does not apply (unchained steps)
+        self._comm = comm
+        if comm is not None and grad_sync is None:
+            self.grad_sync = comm
+        if force and self.grad_sync is None:
             self.grad_sync = lambda flat_g: None          # the peer kernel does the work; a library sync was not asked for
         for old in (getattr(self, '_peer', None) or {}).values():      # a second call: release the previous hipIpc mappings / slots
             old.close()
@@ -292,7 +298,10 @@ class PPOPolicy(nn.Module):
         ONE library call per step, like the single-process step (mansy_ppo_minibatch_step / mansy_identifier_train_step, `xg_ctx`).  None:
         single process, a library collective, or the round-4 copy form (peer_in_slot = False)."""
         peer = self._peer.get(id(f)) if getattr(self, '_peer', None) else None
-        return peer.ctx if (peer is not None and self.peer_in_slot) else None
+        if peer is not None:
+            return peer.ctx if self.peer_in_slot else None
+        comm = getattr(self, '_comm', None)          # no peer kernel: the library's own RCCL communicator, if one was handed over
+        return comm.ctx if comm is not None else None
 
     def _sync_clip_adam(self, f, max_norm, lr, wd, tail=None, overlap=None):
         """Data-parallel second half of a step: average the raw local gradients over the ranks, then global-norm clip + Adam.

@@ -1353,6 +1353,10 @@ int mansy_identifier_train_step(const float* const* params, float* const* grads,
   // xg_ctx != NULL (step > 0): the data-parallel step as one call -- gradients into the exchange slot, one launch averages them into flat_g, Adam
   std::vector<float*> slot_grads;
   float* const g_avg = flat_g;
+  const int sync_kind = xg_ctx ? *reinterpret_cast<const int*>(xg_ctx) : 0;
+  MANSY_REQUIRE(!xg_ctx || sync_kind == MANSY_SYNC_XG || sync_kind == MANSY_SYNC_RCCL, "identifier_train_step: the sync context is neither a peer-memory nor a communicator context");
+  void* const comm = sync_kind == MANSY_SYNC_RCCL ? xg_ctx : nullptr;
+  if (comm) { MANSY_REQUIRE(step > 0, "identifier_train_step: the averaged form is a training step (step > 0)"); xg_ctx = nullptr; }
   if (xg_ctx) {
     MANSY_REQUIRE(step > 0, "identifier_train_step: the peer-averaged form is a training step (step > 0)");
     float* s0 = nullptr; float* s1 = nullptr;
@@ -1393,6 +1397,7 @@ int mansy_identifier_train_step(const float* const* params, float* const* grads,
   RC(e.featnet_bwd(n, obs, B, 1, e.W.dHa, nullptr, nullptr, 0, nullptr, &og));
   if (step < 0) return MANSY_OK;
   if (xg_ctx) RC(mansy_xg_reduce_avg(xg_ctx, g_avg, n_flat, nullptr, stream));
+  if (comm) RC(mansy_allreduce_avg_f32(comm, g_avg, n_flat, stream));
   return e.clip_and_adam(flat_p, g_avg, flat_m, flat_v, n_flat, 0.f, lr, weight_decay, step);
 }
 
@@ -1470,6 +1475,15 @@ int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, fl
   float* slot_g[2] = {nullptr, nullptr};
   int slot_cur = 0;
   std::vector<float*> slot_grads;
+  // a communicator context instead (MANSY_SYNC_RCCL): raw gradients in flat_g, ncclAllReduce(avg) on the stream, a norm launch, the same tail
+  void* const sync = xg_ctx;
+  const int sync_kind = sync ? *reinterpret_cast<const int*>(sync) : 0;
+  MANSY_REQUIRE(!sync || sync_kind == MANSY_SYNC_XG || sync_kind == MANSY_SYNC_RCCL, "ppo_minibatch_step: the sync context is neither a peer-memory nor a communicator context");
+  void* const comm = sync_kind == MANSY_SYNC_RCCL ? sync : nullptr;
+  if (comm) {
+    MANSY_REQUIRE(max_grad_norm > 0.f && step > 0 && !(tail_from >= 0 && tail_from < n_flat && tail_step != step), "ppo_minibatch_step: the averaged form needs the clipped step without a lagged tail");
+    xg_ctx = nullptr;
+  }
   if (xg_ctx) {
     MANSY_REQUIRE(max_grad_norm > 0.f && step > 0 && !(tail_from >= 0 && tail_from < n_flat && tail_step != step), "ppo_minibatch_step: the peer-averaged form needs the clipped step without a lagged tail");
     RC(mansy_xg_slot_ptrs(xg_ctx, &slot_g[0], &slot_g[1]));
@@ -1524,7 +1538,7 @@ int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, fl
                 "ppo_minibatch_step: unexpected order of the head gradients in flat_g");
   // squared gradient norm as a rider on the last gradient-writing launch (12 -> 11 launches): the head gradients are the
   // contiguous tail of the flat buffer, starting at actor.fc.0.weight
-  const bool ride = max_grad_norm > 0.f && step > 0 && !xg_ctx;      // (peer-averaged form: the norm is the AVERAGE's, left by the collective launch)
+  const bool ride = max_grad_norm > 0.f && step > 0 && !xg_ctx && !comm;      // (averaged forms: the norm is the AVERAGE's)
   const float* tail = grads[2 * NB];
   const long long tail_n = (flat_g + n_flat) - tail;
   MANSY_REQUIRE(!ride || (tail >= flat_g && tail_n > 0 && tail_n <= n_flat), "ppo_minibatch_step: grads[] must point into flat_g");
@@ -1533,6 +1547,13 @@ int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, fl
   // 22-32 us per launch against 12 us for the two launches it replaced: a kernel boundary is cheaper than a device-scope
   // rendezvous on this chip, as tools/chain_lab.hip found for the GEMM chain.)
   RC(e.featnet_bwd(a, obs, mb, 0, e.W.dHa, e.W.dHc, ride ? tail : nullptr, ride ? tail_n : 0, parts_cur, &og));
+  if (comm) {
+    RC(mansy_allreduce_avg_f32(comm, flat_g, n_flat, stream));
+    MANSY_LAUNCH(sumsq_kernel, dim3(NORM_PARTS), dim3(256), 0, e.st, flat_g, n_flat, parts_cur);
+    MANSY_LAUNCH_CHECK();
+    return e.step_tail(params, flat_p, flat_g, flat_m, flat_v, n_flat, max_grad_norm, lr, weight_decay, step, parts_cur, parts_next, obs_all,
+                       next_idx, next_mb, adv_all);
+  }
   if (xg_ctx) {
     RC(mansy_xg_reduce_avg(xg_ctx, g_avg, n_flat, parts_cur, stream));      // slot -> average in flat_g, sums of squares in this step's norm slots
     return e.step_tail(params, flat_p, g_avg, flat_m, flat_v, n_flat, max_grad_norm, lr, weight_decay, step, parts_cur, parts_next, obs_all,

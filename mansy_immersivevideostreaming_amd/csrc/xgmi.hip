@@ -28,6 +28,7 @@ constexpr long long XG_HEADER_FLOATS = 64;                // 256-byte header: wo
 struct XgPeers { const float* data[XG_MAX_WORLD]; const unsigned* flag[XG_MAX_WORLD]; };
 
 struct XgCtx {
+  int kind = MANSY_SYNC_XG;               // first field of every sync context (include/mansy_hip.h)
   int world = 0, rank = 0, imported = 0;
   long long n = 0, n_pad = 0;
   float* own = nullptr;                   // header + 2 slots

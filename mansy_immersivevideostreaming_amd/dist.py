@@ -237,6 +237,52 @@ class PeerGradSync:
             self.ctx = None
 
 
+class RcclComm:
+    """A communicator of the library's own (include/mansy_hip.h: mansy_comm_* / mansy_allreduce_*, thin wrappers over RCCL bound at run time) --
+    SURVEY 8b's `mansy_allreduce_*`.  Used as the `sync` context of the one-call data-parallel PPO step in its library-collective form
+    (PPOPolicy.set_data_parallel(..., comm=RcclComm(...))): gradients, ncclAllReduce(avg), norm, clip + Adam are then ONE library call per step,
+    like the peer-memory form; also callable like a grad_sync (`comm(flat_g)`).  Rank 0 draws the 128-byte id, torch.distributed (any backend:
+    it is host data) carries it to the others."""
+
+    def __init__(self, world, rank, device=None):
+        import ctypes
+        from ._lib import CommId, check, lib
+        self.world, self.rank = int(world), int(rank)
+        self._lib, self._check = lib(), check
+        if device is not None:
+            torch.cuda.set_device(device)
+        cid = CommId()
+        if self.rank == 0:
+            check(self._lib.mansy_comm_unique_id(ctypes.byref(cid)), 'mansy_comm_unique_id')
+        if self.world > 1:
+            box = [bytes(cid.bytes)]
+            dist.broadcast_object_list(box, src=0)
+            cid.bytes[:] = list(box[0])
+        ctx = ctypes.c_void_p()
+        check(self._lib.mansy_comm_create(ctypes.byref(cid), self.world, self.rank, ctypes.byref(ctx)), 'mansy_comm_create')
+        self.ctx = ctx
+
+    def __call__(self, flat_g):
+        from ._lib import ptr, stream_ptr
+        self._check(self._lib.mansy_allreduce_avg_f32(self.ctx, ptr(flat_g), flat_g.numel(), stream_ptr(flat_g.device)), 'mansy_allreduce_avg_f32')
+
+    def sum_f64(self, t):
+        from ._lib import ptr, stream_ptr
+        assert t.dtype == torch.float64
+        self._check(self._lib.mansy_allreduce_sum_f64(self.ctx, ptr(t), t.numel(), stream_ptr(t.device)), 'mansy_allreduce_sum_f64')
+
+    def allgather_f64(self, t):
+        from ._lib import ptr, stream_ptr
+        out = torch.empty(self.world, t.numel(), dtype=torch.float64, device=t.device)
+        self._check(self._lib.mansy_allgather_f64(self.ctx, ptr(t), ptr(out), t.numel(), stream_ptr(t.device)), 'mansy_allgather_f64')
+        return out
+
+    def close(self):
+        if getattr(self, 'ctx', None):
+            self._lib.mansy_comm_destroy(self.ctx)
+            self.ctx = None
+
+
 def probe_peer_grad_sync(sizes, world, rank, device, library_sync, iters=10, probe_timeout_ms=5000, timeout_ms=60000):
     """Measure, do not guess: build the peer-memory all-reduce for flat buffers of `sizes` floats, check it against the library collective
     on the same data, time both (max over ranks), and keep it only if every rank agrees it is correct AND faster.  The wait of the

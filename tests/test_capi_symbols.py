@@ -173,7 +173,8 @@ def test_ctypes_structs_match_header_layout(tmp_path):
     import subprocess
     from mansy_immersivevideostreaming_amd import _lib
     pairs = {'mansy_vp_config': _lib.VPConfig, 'mansy_gemm_epilogue': _lib.GemmEpilogue, 'mansy_env_tables': _lib.EnvTables,
-             'mansy_env_episode_log': _lib.EpisodeLog, 'mansy_attn_shape': _lib.AttnShape, 'mansy_xg_handle': _lib.XgHandle}
+             'mansy_env_episode_log': _lib.EpisodeLog, 'mansy_attn_shape': _lib.AttnShape, 'mansy_xg_handle': _lib.XgHandle,
+             'mansy_comm_id': _lib.CommId}
     hdr = os.path.join(ROOT, 'include', 'mansy_hip.h')
     text = open(hdr).read()
     assert set(re.findall(r'typedef struct (mansy_\w+)', text)) == set(pairs)      # no struct of the header is left unmirrored
