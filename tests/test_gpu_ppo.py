@@ -825,7 +825,7 @@ def test_data_parallel_step_form_equals_the_single_process_step(M):
     for form in ('single', 'dp-chained', 'dp-unchained', 'peer-slot', 'peer-copy', 'peer-slot-unchained', 'rccl-comm'):
         pol = build_policy(M, sd)
         if form == 'rccl-comm':      # the library's own RCCL communicator (mansy_comm_* / mansy_allreduce_avg_f32) as the step's sync context: one call per step
-            comms.append(mdist.RcclComm(1, 0, 'cuda'))
+            comms.append(mdist.RcclComm(1, 0, torch.device('cuda', torch.cuda.current_device())))
             pol.set_data_parallel(1, None, force=True, comm=comms[-1])
             assert pol._xg_ctx(pol.engine.ac) is not None
         elif form.startswith('peer'):
