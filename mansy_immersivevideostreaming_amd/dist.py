@@ -262,6 +262,41 @@ class RcclComm:
         check(self._lib.mansy_comm_create(ctypes.byref(cid), self.world, self.rank, ctypes.byref(ctx)), 'mansy_comm_create')
         self.ctx = ctx
 
+    @classmethod
+    def try_create(cls, world, rank, device=None):
+        """-> (RcclComm, None) or (None, reason), the SAME answer on every rank: before anyone enters the collective communicator set-up, the ranks
+        agree (through torch.distributed) that EVERY rank can bind RCCL -- a rank that cannot must not leave the others inside ncclCommInitRank --
+        and afterwards that every rank joined and that an average over the new communicator is the average."""
+        import ctypes
+        from ._lib import CommId, lib
+        agree_dev = device if (dist.is_initialized() and dist.get_backend() == 'nccl') else 'cpu'
+
+        def all_min(x):
+            if world <= 1 or not dist.is_initialized():
+                return float(x)
+            t = torch.tensor([float(x)], dtype=torch.float64, device=agree_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return float(t.item())
+        probe = CommId()
+        can = 1.0 if lib().mansy_comm_unique_id(ctypes.byref(probe)) == 0 else 0.0      # binds librccl.so on this rank (dlopen)
+        if all_min(can) < 1.0:
+            return None, 'RCCL cannot be bound on every rank (' + (lib().mansy_last_error() or b'').decode() + ')'
+        self, ok, why = None, 1.0, ''
+        try:
+            self = cls(world, rank, device)
+            x = torch.full((1024,), float(rank + 1), device=device)
+            self(x)
+            torch.cuda.synchronize(device)
+            if abs(float(x[0]) - (world + 1) / 2.0) > 1e-6:
+                ok, why = 0.0, f'rank {rank}: average over the new communicator is {float(x[0])}, expected {(world + 1) / 2.0}'
+        except Exception as e:          # noqa: BLE001
+            ok, why = 0.0, f'rank {rank}: {e}'
+        if all_min(ok) < 1.0:
+            if self is not None:
+                self.close()
+            return None, why or 'another rank failed to join the communicator'
+        return self, None
+
     def __call__(self, flat_g):
         from ._lib import ptr, stream_ptr
         self._check(self._lib.mansy_allreduce_avg_f32(self.ctx, ptr(flat_g), flat_g.numel(), stream_ptr(flat_g.device)), 'mansy_allreduce_avg_f32')

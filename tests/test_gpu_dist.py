@@ -214,3 +214,32 @@ def test_bench_eight_ranks_functional_on_the_shared_gpu():
     assert sec['replica_param_spread'] == 0.0 and sec['value'] > 0 and np.isfinite(sec['final_loss'])
     n = sec['envs_per_gpu']
     assert sec['env_shards'] == [[r_ * n, 8 * n] for r_ in range(8)]
+
+
+@pytest.mark.gpu
+def test_library_rccl_communicator_wrappers_world1():
+    """mansy_comm_* / mansy_allreduce_* (SURVEY 8b's thin wrappers over RCCL communicators, round 5) on a one-rank communicator: RCCL is bound at run
+    time, the agreed set-up (RcclComm.try_create) returns a communicator, and the three collectives of the data-parallel hot path -- flat-gradient
+    average (fp32, ncclAvg), SyncBN statistics (fp64 sum), return normaliser (fp64 all-gather) -- are the identity over one rank, at the sizes the
+    step uses.  (Two ranks on one GPU are refused by RCCL itself; beyond world 1 the wrappers are correct by construction only.)"""
+    import torch
+    from mansy_immersivevideostreaming_amd import dist as mdist
+    dev = torch.device('cuda', torch.cuda.current_device())
+    comm, why = mdist.RcclComm.try_create(1, 0, dev)
+    assert comm is not None, why
+    try:
+        for n in (9_212_000, 427_072, 262_144):
+            g = torch.randn(n, device=dev)
+            ref = g.clone()
+            comm(g)
+            torch.cuda.synchronize()
+            assert torch.equal(g, ref)
+        s = torch.randn(2 * 512, dtype=torch.float64, device=dev)
+        ref = s.clone()
+        comm.sum_f64(s)
+        rms = torch.tensor([0.25, 2.0, 4096.0], dtype=torch.float64, device=dev)
+        got = comm.allgather_f64(rms)
+        torch.cuda.synchronize()
+        assert torch.equal(s, ref) and got.shape == (1, 3) and torch.equal(got[0], rms)
+    finally:
+        comm.close()
