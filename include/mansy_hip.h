@@ -223,6 +223,19 @@ int mansy_policy_env_step(const float* const* params, const float* obs, int n_en
                           uint32_t seed, uint32_t site, int reuse_packed, void* workspace, int max_batch, const mansy_env_tables* T,
                           void* env_state, float* obs_next, float* obs_cur, float* reward, unsigned char* done, float* qoe_parts,
                           const mansy_env_episode_log* elog, int precision, void* stream);
+/* A whole collect -- T vector steps of mansy_policy_env_step -- as ONE persistent launch (round 5): the three launches of a step become three phases of a
+ * kernel whose workgroups (one per CU) form one team per XCD and synchronise through that XCD's L2; the environments are dealt to the teams in chunks of
+ * 32 and never leave them.  obs_slab [T][n_env][MANSY_OBS_LD]: block 0 = the observations the collect starts from, block t + 1 <- step t's auto-reset
+ * observation, `carry` <- the last one; u / act / logp / reward / done: [T][n_env]; obs_next_slab [T][n_env][MANSY_OBS_LD].  Bit-identical to T calls of
+ * mansy_policy_env_step.  ctl: MANSY_ROLLOUT_CTL_BYTES of device memory (zeroed by the call); err_host: a host-MAPPED int (hipHostMalloc) that the kernel
+ * sets to 1 if a workgroup or team-mate never showed up within 2 s (a shared device): the outputs are then garbage and the caller must raise.
+ * Returns MANSY_EINVAL ("rollout_team: ...") where the form does not apply (precision != fp32, n_env whose products do not run on the wave-split-K loop,
+ * launch recorder on): take the per-step call then. */
+#define MANSY_ROLLOUT_CTL_BYTES 1024
+int mansy_policy_rollout(const float* const* params, float* obs_slab, int n_env, int T, const float* u, int* act, float* logp, float* obs_next_slab,
+                         float* carry, float* reward, unsigned char* done, float* qoe_parts, const mansy_env_tables* tables, void* env_state,
+                         const mansy_env_episode_log* elog, int reuse_packed, void* ctl, int* err_host, void* workspace, int max_batch, int precision,
+                         void* stream);
 /* logits' log-probabilities of the given actions for the first n_logp rows (logp != NULL) and / or the critic's value for all B rows.
  * process_fn calls it once on the 2 x 4096 rows [obs ; obs_next] of one rollout buffer: v_s, v_s_ and logp_old in one pass. */
 int mansy_policy_evaluate(const float* const* params, const float* obs, int B, const int* act, int n_logp, float* logp, float* value,

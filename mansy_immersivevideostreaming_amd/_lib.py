@@ -116,6 +116,7 @@ _PROTOS = {
     'mansy_policy_forward': [P, P, c_int, P, P, P, P, P, c_u32, c_u32, c_int, P, c_int, c_int, P],
     'mansy_policy_env_step': [P, P, c_int, P, P, P, P, c_u32, c_u32, c_int, P, c_int, P, P, P, P, P, P, P, P, c_int, P],
     'mansy_policy_evaluate': [P, P, c_int, P, c_int, P, P, P, c_int, c_int, P],
+    'mansy_policy_rollout': [P, P, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, c_int, P, P, P, c_int, c_int, P],
     'mansy_identifier_forward': [P, P, c_int, P, P, c_int, c_int, P],
     'mansy_identifier_train_step': [P, P, P, P, P, P, c_ll, P, P, c_int, c_float, c_float, c_int, P, P, c_int, P, c_int, P],
     'mansy_identifier_relabel': [P, P, P, P, c_int, c_float, P, c_int, c_int, P],

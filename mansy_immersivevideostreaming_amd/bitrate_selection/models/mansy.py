@@ -342,6 +342,33 @@ class NetEngine:
                                           self.max_batch, ctypes.byref(venv.tables.c), ptr(venv.state), ptr(obs_next_out), ptr(obs_out), ptr(reward_out),
                                           ptr(done_out), ptr(venv.qoe_parts), ctypes.byref(venv._elog), self.prec, stream_ptr(dev)), 'mansy_policy_env_step')
 
+    def policy_rollout(self, venv, T, obs_slab, u, act, logp, obs_next_slab, carry, reward_out, done_out, reuse_packed=False):
+        """A whole collect of T vector steps as ONE persistent launch on XCD teams (`mansy_policy_rollout`, csrc/ppo_engine.hip): block 0 of
+        `obs_slab` [T][N][780] holds the starting observations, the call fills the rest like T calls of policy_env_step would (bit-identical).
+        -> True, or False where the library says the form does not apply (another precision than fp32, a batch outside the wave-split-K range,
+        launch recorder on): the caller then takes the per-step path.  A launch that gave up (a workgroup never became resident within 2 s: the
+        device is shared) has raised its host-mapped word; the NEXT call raises."""
+        import ctypes
+        N, dev = venv.n_env, obs_slab.device
+        if getattr(self, '_rollout_ctl', None) is None or self._rollout_ctl.device != dev:
+            self._rollout_ctl = torch.zeros(1024, dtype=torch.uint8, device=dev)          # MANSY_ROLLOUT_CTL_BYTES
+            self._rollout_err = torch.zeros(16, dtype=torch.int32).pin_memory()            # host-mapped: the kernel's give-up word
+        if int(self._rollout_err[0]) != 0:
+            raise MansyError('a persistent rollout launch gave up waiting for its workgroups (is the device shared?): its outputs were garbage')
+        if N > self.max_batch:
+            raise MansyError(f'policy_rollout: {N} environments exceed max_batch {self.max_batch}')
+        arr, _ = self.ac.pointers()
+        rc = lib().mansy_policy_rollout(arr, ptr(obs_slab), N, int(T), ptr(u), ptr(act), ptr(logp), ptr(obs_next_slab), ptr(carry), ptr(reward_out),
+                                        ptr(done_out), ptr(venv.qoe_parts), ctypes.byref(venv.tables.c), ptr(venv.state), ctypes.byref(venv._elog),
+                                        int(reuse_packed), ptr(self._rollout_ctl), ctypes.c_void_p(self._rollout_err.data_ptr()), ptr(self.workspace()),
+                                        self.max_batch, self.prec, stream_ptr(dev))
+        if rc != 0:
+            msg = lib().mansy_last_error() or b''
+            if b'rollout_team' in msg:
+                return False
+            check(rc, 'mansy_policy_rollout')
+        return True
+
     def identifier_forward(self, obs):
         B, dev = obs.shape[0], obs.device
         outs = []

@@ -63,6 +63,12 @@ class VecCollector:
         self.step_count = 0
         self.env_step = 0
         self.use_graph = use_graph
+        # round 5: the whole collect as ONE persistent launch on XCD teams (mansy_policy_rollout) where the library takes it (fp32, batch in the
+        # wave-split-K range).  Bit-identical to the per-step launches and 49 launches fewer, but NOT faster (24.0 against 22.5 us per vector
+        # step: profiles/r05_rollout_team_ab.txt), so it is opt-in (`collector.use_team = True` / MANSY_ROLLOUT_TEAM=1); never on a device
+        # shared between ranks (the kernel wants one resident workgroup per CU)
+        import os
+        self.use_team = os.environ.get('MANSY_ROLLOUT_TEAM', '0') == '1' and os.environ.get('MANSY_SHARE_GPU') != '1'
         self._graph = None
         self._graph_key = None
         self.graph_launches = 0
@@ -97,6 +103,17 @@ class VecCollector:
             self._graph = None
         buffer.reset()
         self._u.uniform_()                      # Categorical sampling uniforms (torch generator => reproducible with manual_seed)
+        if self.use_team and buffer.obs.is_contiguous() and buffer.obs.shape[1] == N:
+            buffer.obs[0].copy_(self.carry)
+            took = self.policy.engine.policy_rollout(self.venv, T, buffer.obs, self._u, buffer.act, buffer.logp, buffer.obs_next, self.carry, buffer.rew,
+                                                     buffer.done)
+            if took:
+                self.step_count += T
+                buffer.filled = T
+                buffer.generation = getattr(buffer, 'generation', 0) + 1
+                self.env_step += T * N
+                return {'n/st': T * N}
+            self.use_team = False               # the library said the form does not apply here: per-step launches from now on
         key = (id(buffer), T, self.policy.engine.ac.flat_p.data_ptr())
         if self.use_graph and (self._graph is None or self._graph_key != key):
             try:

@@ -206,6 +206,9 @@ __device__ __forceinline__ void glds16(unsigned voff, const void* sbase, unsigne
 
 }  // namespace mansy_gemm
 
+// capture of wave-split-K launches (gemm_f32.hip): see there
+int mansy_gemm_capture_begin();
+int mansy_gemm_capture_end(mansy_gemm::GemmParams* out, int* variant, int* gx, int* gy, int* gz, int max_n);
 // split-bf16 main loop (gemm_bf16s.hip); tile 128 -> 128x128, else 64x64; prec 3 = bf16x3, 6 = bf16x6
 int mansy_gemm_bf16s_dispatch(const mansy_gemm::GemmParams& p, int tile, int prec, int a_kmajor, int b_kmajor, int splits, hipStream_t st);
 // B operand pre-split into bf16 planes (GemmEpilogue::b_planes), A K-contiguous, no split-K

@@ -18,7 +18,10 @@
 #include <string>
 #include <vector>
 #include "mansy_kernels.h"
+#include "gemm_wsk.h"
 #include "../../include/mansy_hip.h"
+
+using mansy_gemm::GemmParams;
 
 namespace {
 
@@ -571,6 +574,191 @@ __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const f
     }
     if (env_on) envdev::env_step_finish(ef.T, ef.st, erow, lane, a, es, eq, ef.obs_next, ef.obs_cur, ef.reward, ef.done, ef.qoe_parts, ef.elog);
   }
+}
+
+
+// ------------------------------------------------------------------------------------ persistent rollout on XCD teams (round 5)
+// A collect of T vector steps as ONE launch.  The three launches of a rollout step (FeatureNet product, heads' fc product in K-split slabs, output layer +
+// sampling + environment step) become three PHASES of a persistent kernel; what separates them is not a kernel boundary (1.5 us + each launch's fill and
+// drain) but a barrier among the workgroups of ONE XCD through that XCD's L2: 0.77 us (tools/team_lab.hip, profiles/r05_team_seam_lab.txt).  One workgroup
+// per CU reads the XCD it runs on (HW_REG_XCC_ID -- placement is READ, never assumed) and joins that XCD's team; the environments are dealt to the teams in
+// chunks of 32 rows, and a chunk never leaves its team: trajectories are independent, so no byte ever crosses an XCD inside the launch.  Per step and chunk:
+//   A  the members share the 40 column blocks of F = LeakyReLU(obs Wbd^T + b)   (gemm_f32_wsk_body, the SAME body, blocks and K order as the launch it replaces)
+//   B  ... and the 4 x nsplit blocks of the fc product's K-split slabs
+//   C  row r's owner sums the slabs, forms the logits, samples and steps environment r (the row logic of head_out_kernel<1>); the observation it writes
+//      is phase A's operand of the next step.
+// Operands written by another workgroup of the launch are read past this CU's L1 (sc1 LDS-DMA / sc1 loads; the L2 is the team's coherence point: plain
+// stores, drained before the barrier); weights, tables and uniforms do not change inside the launch.  Results are bit-identical to the three-launch path.
+struct RolloutCtl { unsigned claim[8]; unsigned started; unsigned err; unsigned pad[6]; unsigned bar[8][16]; unsigned long long prof[8]; };      // prof: lab builds only (phase clocks of one workgroup)
+static_assert(sizeof(RolloutCtl) <= MANSY_ROLLOUT_CTL_BYTES, "rollout control block");
+struct RolloutArgs {
+  GemmParams p1, p2; int g1x, g2x, g2z;
+  const float* fc_b; const float* Wout; const float* bout;
+  const float* F; const float* A1s; long long slab; int nsplit;
+  int n_env, T;
+  float* obs; long long obs_ts; float* obs_next; long long obsn_ts; float* carry;
+  const float* u; int* act; float* logp; float* rew; unsigned char* done;
+  mansy_env_tables Tb; envdev::EnvState* st; float* qoe_parts; mansy_env_episode_log elog;
+  long long timeout_ticks; int* err_host;
+};
+__device__ __forceinline__ float ld_sc1_f(const float* p) { return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+__device__ __forceinline__ bool spin_until(const unsigned* p, unsigned target, long long ticks) {
+  const long long t0 = wall_clock64();
+  while ((int)(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+    if (wall_clock64() - t0 > ticks) return false;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return true;
+}
+__global__ __launch_bounds__(256) void rollout_team_kernel(RolloutArgs a, RolloutCtl* __restrict__ ctl) {
+  __shared__ __attribute__((aligned(1024))) float smem[mansy_gemm::WSK_SMEM_FLOATS];
+  __shared__ unsigned sh[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+    xcc &= 7u;
+    sh[0] = xcc;
+    sh[1] = __hip_atomic_fetch_add(&ctl->claim[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(&ctl->started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sh[2] = spin_until(&ctl->started, gridDim.x, a.timeout_ticks) ? 1u : 0u;      // every workgroup of the launch is resident and has joined its team
+    for (int i = 0; i < 8; ++i) sh[4 + i] = __hip_atomic_load(&ctl->claim[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  const int xcc = sh[0], m = sh[1], s = sh[4 + xcc];
+  int nteams = 0, ti = 0;
+  for (int i = 0; i < 8; ++i) { if (sh[4 + i]) { if (i < xcc) ++ti; ++nteams; } }
+  if (!sh[2]) { if (tid == 0) { ctl->err = 1u; __hip_atomic_store(a.err_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } return; }
+  unsigned nbar = 0;
+  unsigned* const bar = &ctl->bar[xcc][0];
+  // a barrier in two halves, so that loads which do not depend on the phase just finished can be REQUESTED between the arrival and the wait and fly
+  // under it (the wait's own poll returns behind them: loads return in order)
+  auto barrier_arrive = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's stores have left for L2
+    __syncthreads();
+    nbar += (unsigned)s;
+    if (tid == 0) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto barrier_wait = [&]() -> bool {
+    if (tid == 0) sh[3] = spin_until(bar, nbar, a.timeout_ticks) ? 1u : 0u;
+    __syncthreads();
+    return sh[3] != 0u;
+  };
+#ifdef MANSY_LAB
+  long long tp_ = wall_clock64();
+#define PROF_(k) do { if (tid == 0 && m == 0 && ti == 0) { const long long n_ = wall_clock64(); ctl->prof[k] += (unsigned long long)(n_ - tp_); tp_ = n_; } } while (0)
+#else
+#define PROF_(k) do { } while (0)
+#endif
+  const int chunks = (a.n_env + 31) / 32;
+  bool ok = true;
+  for (int chunk = ti; chunk < chunks && ok; chunk += nteams) {
+    const int row0 = chunk * 32, rows = min(32, a.n_env - row0);
+    // phase C: member m's wave w owns the rows m + s (w + 4 j) of the chunk (with a full team of 32: row m, wave 0)
+    for (int t = 0; t < a.T && ok; ++t) {
+      // ---- A: FeatureNet blocks of this chunk's rows
+      {
+        GemmParams p = a.p1;
+        p.A = a.obs + (long long)t * a.obs_ts + (long long)row0 * p.lda; p.C = a.p1.C + (long long)row0 * p.ldc; p.M = rows;
+        bool first = true;
+        for (int blk = m; blk < a.g1x; blk += s) {
+          if (!first) __syncthreads();
+          first = false;
+          mansy_gemm::gemm_f32_wsk_body<false, false, true, true>(p, blk, a.g1x, 1, 1, smem);
+        }
+      }
+      PROF_(0);
+      barrier_arrive();
+      ok = barrier_wait();
+      PROF_(1);
+      if (!ok) break;
+      // ---- B: the fc product's slabs
+      {
+        GemmParams p = a.p2;
+        p.A = a.p2.A + (long long)row0 * p.lda; p.C = a.p2.C + (long long)row0 * p.ldc; p.M = rows;
+        bool first = true;
+        for (int blk = m; blk < a.g2x * a.g2z; blk += s) {
+          if (!first) __syncthreads();
+          first = false;
+          mansy_gemm::gemm_f32_wsk_body<false, false, true, true>(p, blk, a.g2x, 1, a.g2z, smem);
+        }
+      }
+      PROF_(2);
+      barrier_arrive();
+      // ---- C: one wave per row: slab sums, output layer, sampling, environment step.  Everything that does not depend on phase B -- the output
+      // layer's weights, the uniform, the environment's record and the table rows it names -- is requested HERE, between arrival and wait.
+      const int rr0 = m + s * wave;                          // this wave's first row of the chunk
+      const bool have0 = rr0 < rows;
+      const int row_c = row0 + (have0 ? rr0 : 0);
+      float w0[MAXOUT], w1[MAXOUT], bo[MAXOUT];
+#pragma unroll
+      for (int k = 0; k < MAXOUT; ++k) { const int kc = min(k, NACT - 1); w0[k] = a.Wout[kc * HID + lane]; w1[k] = a.Wout[kc * HID + 64 + lane]; bo[k] = a.bout[kc]; }
+      const float fcb0 = a.fc_b[lane], fcb1 = a.fc_b[64 + lane];
+      float u_pre = 0.f;
+      envdev::EnvRegs es_pre = {};
+      envdev::EnvPre eq_pre = {};
+      if (have0) {
+        u_pre = a.u[(size_t)t * a.n_env + row_c];
+        envdev::load_state(es_pre, a.st[__builtin_amdgcn_readfirstlane(row_c)], lane);
+        eq_pre = envdev::env_step_requests(a.Tb, es_pre, lane);
+      }
+      ok = barrier_wait();
+      PROF_(3);
+      if (!ok) break;
+      for (int j = wave; ; j += 4) {
+        const int rr = m + s * j;
+        if (rr >= rows) break;
+        const int row = row0 + rr;
+        const float f0 = ld_sc1_f(a.F + (size_t)row * FEAT + RESID_COL + lane);
+        const float f1 = ld_sc1_f(a.F + (size_t)row * FEAT + RESID_COL + 64 + lane);
+        float a0 = fcb0, a1 = fcb1;
+        float p0[MAX_SLABS], p1[MAX_SLABS];
+        const float* pre = a.A1s + (size_t)row * HID;
+#pragma unroll
+        for (int z = 0; z < MAX_SLABS; ++z) { const long long zz = (long long)min(z, a.nsplit - 1) * a.slab; p0[z] = ld_sc1_f(pre + zz + lane); p1[z] = ld_sc1_f(pre + zz + 64 + lane); }
+        const int erow = __builtin_amdgcn_readfirstlane(row);
+        envdev::EnvRegs es = es_pre;
+        envdev::EnvPre eq = eq_pre;
+        float u_row = u_pre;
+        if (j != wave) {                                     // (a team smaller than the chunk: further rows of this wave, nothing requested ahead)
+          u_row = a.u[(size_t)t * a.n_env + row];
+          envdev::load_state(es, a.st[erow], lane);
+          eq = envdev::env_step_requests(a.Tb, es, lane);
+        }
+#pragma unroll
+        for (int z = 0; z < MAX_SLABS; ++z) { a0 = z < a.nsplit ? a0 + p0[z] : a0; a1 = z < a.nsplit ? a1 + p1[z] : a1; }
+        a0 = a0 > 0.f ? a0 : a0 * SLOPE; a1 = a1 > 0.f ? a1 : a1 * SLOPE;
+        const float h0 = a0 + f0, h1 = a1 + f1;
+        float o[MAXOUT];
+#pragma unroll
+        for (int k = 0; k < MAXOUT; ++k) { const float pk = wave_sum(h0 * w0[k] + h1 * w1[k]) + bo[k]; o[k] = k < NACT ? pk : 0.f; }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < MAXOUT; ++k) if (k < NACT) mx = fmaxf(mx, o[k]);
+        float e[MAXOUT], se = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXOUT; ++k) { e[k] = k < NACT ? expf(o[k] - mx) : 0.f; se += e[k]; }
+        float c = 0.f; int act = NACT - 1; bool found = false;
+#pragma unroll
+        for (int k = 0; k < MAXOUT; ++k) { if (k < NACT) { c += e[k] / se; if (!found && c > u_row) { act = k; found = true; } } }
+        if (lane == 0) {
+          a.act[(size_t)t * a.n_env + row] = act;
+          float oa = 0.f;
+#pragma unroll
+          for (int k = 0; k < MAXOUT; ++k) if (k == act) oa = o[k];
+          a.logp[(size_t)t * a.n_env + row] = (oa - mx) - logf(se);
+        }
+        float* obs_cur = t + 1 < a.T ? a.obs + (long long)(t + 1) * a.obs_ts : a.carry;
+        envdev::env_step_finish(a.Tb, a.st, erow, lane, act, es, eq, a.obs_next + (long long)t * a.obsn_ts, obs_cur, a.rew + (size_t)t * a.n_env,
+                                a.done + (size_t)t * a.n_env, a.qoe_parts, a.elog);
+      }
+      PROF_(4);
+      barrier_arrive();
+      ok = barrier_wait();
+      PROF_(5);
+    }
+  }
+  if (!ok && tid == 0) { ctl->err = 1u; __hip_atomic_store(a.err_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 }
 
 // backward of the output layer + residual: dH[r,c] = sum_k g[r,k] Wout[k,c] ; dA1 = dH * leaky'(A1) ;
@@ -1328,6 +1516,55 @@ int mansy_policy_env_step(const float* const* params, const float* obs, int n_en
   ef.qoe_parts = qoe_parts;
   if (elog) ef.elog = *elog;
   return e.head(a, n_env, NACT, 0, e.W.A1a, e.W.Ha, logits ? logits : e.W.outa, u, seed, site, act, logp, &ef);
+}
+
+// A whole collect -- T vector steps of policy forward + Categorical sample + environment step for n_env environments -- as ONE persistent launch on XCD
+// teams (rollout_team_kernel above).  obs_slab [T][n_env][OBS_LD]: row block 0 holds the observations the collect starts from (the caller copied its
+// carry there), block t + 1 receives step t's auto-reset observation, `carry` the last one; obs_next_slab / reward / done / act / logp as the per-step
+// call writes them.  Same values, bit for bit, as T calls of mansy_policy_env_step.  MANSY_EINVAL (message: "rollout_team: ...") where the form does not
+// apply -- another precision than fp32, a batch whose two products do not resolve to the wave-split-K loop, the launch recorder running -- so that the
+// caller can take the per-step path.
+int mansy_policy_rollout(const float* const* params, float* obs_slab, int n_env, int T, const float* u, int* act, float* logp, float* obs_next_slab,
+                         float* carry, float* reward, unsigned char* done, float* qoe_parts, const mansy_env_tables* Tb, void* env_state,
+                         const mansy_env_episode_log* elog, int reuse_packed, void* ctl, int* err_host, void* workspace, int max_batch, int precision,
+                         void* stream) {
+  MANSY_REQUIRE(params && obs_slab && u && act && logp && obs_next_slab && carry && reward && done && Tb && env_state && ctl && err_host && n_env >= 1 &&
+                    n_env <= max_batch && T >= 1, "policy_rollout: bad arguments");
+  MANSY_REQUIRE(precision == 0, "rollout_team: fp32 only (precision %d)", precision);
+  PEng e; RC(setup(workspace, max_batch, precision, (hipStream_t)stream, e));
+  NetP a; bind_net(params, nullptr, 20, a);
+  const int req = head_split_request(n_env);
+  MANSY_REQUIRE(req > 1, "rollout_team: the heads' fc product is not K-split at this batch");
+  const int nsplit = mansy_gemm_effective_splits(FEAT, req);
+  MANSY_REQUIRE(nsplit <= MAX_SLABS, "rollout_team: %d K splits exceed the slab sum's unroll", nsplit);
+  if (!reuse_packed) RC(e.pack(a, 0));
+  MANSY_REQUIRE(mansy_gemm_capture_begin(), "rollout_team: products cannot be captured now (launch recorder or a paired launch open)");
+  int rc = e.featnet(obs_slab, n_env, 0);
+  if (!rc) { GemmEpilogue ep; ep.prec = 0; ep.split_slab = (long long)n_env * HID; rc = mansy_launch_gemm_f32(e.W.F, FEAT, 0, a.fc_w, FEAT, 0, e.W.A1s, HID, n_env, HID, FEAT, ep, 0, req, e.st); }
+  GemmParams gp[2]; int var[2], gx[2], gy[2], gz[2];
+  const int ncap = mansy_gemm_capture_end(gp, var, gx, gy, gz, 2);
+  RC(rc);
+  MANSY_REQUIRE(ncap == 2 && var[0] == 0 && var[1] == 0 && gz[0] == 1 && gz[1] == nsplit && gx[0] == FEAT / 32 && gx[1] == HID / 32,
+                "rollout_team: the two products of a step do not both resolve to the wave-split-K loop at n_env = %d", n_env);
+  RolloutArgs ra;
+  ra.p1 = gp[0]; ra.p2 = gp[1]; ra.g1x = gx[0]; ra.g2x = gx[1]; ra.g2z = gz[1];
+  ra.fc_b = a.fc_b; ra.Wout = a.out_w; ra.bout = a.out_b;
+  ra.F = e.W.F; ra.A1s = e.W.A1s; ra.slab = (long long)n_env * HID; ra.nsplit = nsplit;
+  ra.n_env = n_env; ra.T = T;
+  ra.obs = obs_slab; ra.obs_ts = (long long)n_env * OBS_LD; ra.obs_next = obs_next_slab; ra.obsn_ts = (long long)n_env * OBS_LD; ra.carry = carry;
+  ra.u = u; ra.act = act; ra.logp = logp; ra.rew = reward; ra.done = done;
+  ra.Tb = *Tb; ra.st = (envdev::EnvState*)env_state; ra.qoe_parts = qoe_parts;
+  memset(&ra.elog, 0, sizeof(ra.elog));
+  if (elog) ra.elog = *elog;
+  static const int wall_khz = [] { int dev = 0, khz = 0; return (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess && khz > 0) ? khz : 100000; }();
+  static const int n_cu = [] { int dev = 0, n = 0; return (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256; }();
+  ra.timeout_ticks = 2000LL * wall_khz;          // 2 s: a workgroup that never became resident (the device is shared) gives up loudly
+  ra.err_host = err_host;
+  MANSY_HIP_CHECK(hipMemsetAsync(ctl, 0, MANSY_ROLLOUT_CTL_BYTES, e.st));
+  // one workgroup per CU (241 VGPRs + 16 AGPRs: a second one per CU does not fit; forced to fit it spills and the step takes 43 us: profiles/r05_rollout_team_ab.txt)
+  MANSY_LAUNCH(rollout_team_kernel, dim3(n_cu < 256 ? n_cu : 256), dim3(256), 0, e.st, ra, (RolloutCtl*)ctl);
+  MANSY_LAUNCH_CHECK();
+  return MANSY_OK;
 }
 
 int mansy_identifier_forward(const float* const* params, const float* obs, int B, float* pred, void* workspace, int max_batch, int precision, void* stream) {

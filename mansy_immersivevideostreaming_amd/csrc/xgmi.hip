@@ -221,24 +221,24 @@ int mansy_xg_set_timeout_ms(void* ctx, double ms) {
 // it, waits for the peers and leaves the average in ordinary device memory; the clip + Adam launch zeroes the OTHER slot for the next step.
 int mansy_xg_slot_ptrs(void* ctx, float** slot0, float** slot1) {
   XgCtx* c = (XgCtx*)ctx;
-  MANSY_REQUIRE(c && slot0 && slot1, "xg_slot_ptrs: null");
+  MANSY_REQUIRE(c && c->kind == MANSY_SYNC_XG && slot0 && slot1, "xg_slot_ptrs: null or not a peer-memory context");
   *slot0 = c->own + XG_HEADER_FLOATS; *slot1 = c->own + XG_HEADER_FLOATS + c->n_pad;
   return MANSY_OK;
 }
-int mansy_xg_next_slot(void* ctx) { XgCtx* c = (XgCtx*)ctx; return c ? (int)((c->epoch + 1u) & 1u) : -1; }
+int mansy_xg_next_slot(void* ctx) { XgCtx* c = (XgCtx*)ctx; return (c && c->kind == MANSY_SYNC_XG) ? (int)((c->epoch + 1u) & 1u) : -1; }
 
 static int xg_launch(XgCtx* c, float* g, long long n, double* sumsq_parts, hipStream_t stream, bool copy);
 
 int mansy_xg_reduce_avg(void* ctx, float* g_out, long long n, double* sumsq_parts, void* stream) {
   XgCtx* c = (XgCtx*)ctx;
-  MANSY_REQUIRE(c && g_out && c->imported, "xg_reduce_avg: context not ready (create -> export -> exchange handles -> import)");
+  MANSY_REQUIRE(c && c->kind == MANSY_SYNC_XG && g_out && c->imported, "xg_reduce_avg: not a ready peer-memory context (create -> export -> exchange handles -> import)");
   MANSY_REQUIRE(n == c->n && (reinterpret_cast<uintptr_t>(g_out) & 15) == 0, "xg_reduce_avg: n must be the context's %lld and g_out 16-byte aligned", c->n);
   return xg_launch(c, g_out, n, sumsq_parts, (hipStream_t)stream, false);
 }
 
 int mansy_xg_allreduce_avg(void* ctx, float* g, long long n, double* sumsq_parts, void* stream) {
   XgCtx* c = (XgCtx*)ctx;
-  MANSY_REQUIRE(c && g && c->imported, "xg_allreduce_avg: context not ready (create -> export -> exchange handles -> import)");
+  MANSY_REQUIRE(c && c->kind == MANSY_SYNC_XG && g && c->imported, "xg_allreduce_avg: not a ready peer-memory context (create -> export -> exchange handles -> import)");
   MANSY_REQUIRE(n == c->n && (reinterpret_cast<uintptr_t>(g) & 15) == 0, "xg_allreduce_avg: n must be the context's %lld and g 16-byte aligned", c->n);
   return xg_launch(c, g, n, sumsq_parts, (hipStream_t)stream, true);
 }

@@ -639,6 +639,44 @@ def test_fused_rollout_step_equals_policy_forward_plus_env_step(M):
     np.testing.assert_array_equal(va.pop_episode_log()[:, [0, 2, 7]].sum(0), vb.pop_episode_log()[:, [0, 2, 7]].sum(0))
 
 
+@pytest.mark.parametrize('N,Tsteps', [(256, 16), (100, 7), (32, 3)])
+def test_persistent_rollout_on_xcd_teams_equals_the_per_step_launches(M, N, Tsteps):
+    """Round 5: a whole collect as ONE persistent launch (mansy_policy_rollout: one workgroup per CU, a team per XCD read from HW_REG_XCC_ID, the three
+    launches of a step as three phases separated by barriers through the XCD's L2; the chunks of 32 environments never leave their team) against the
+    per-step launches on the same uniforms, through episode ends and auto-resets, several collects in a row (the control block is re-zeroed, the packed
+    weights re-built, the carry handed over): every slab of the rollout buffer, the carry, the environment records and the episode log bit-identical.
+    Ragged sizes: a last chunk of 4 rows, fewer chunks than teams."""
+    sd = po.make_policy_state_dict(int(Z['wseed']))
+    tables = M.env.EnvTables.synthetic('cuda', n_video=5, n_user=4, n_trace=6, n_chunk=30, seed=3, n_sample=max(37, N), train_identifier_reward=True)
+    out = {}
+    for form in ('team', 'steps'):
+        pol = build_policy(M, sd)
+        venv = M.env.MANSYVecEnv(tables, N, seed=4)
+        col = M.ppo.VecCollector(pol, venv, seed=5, use_graph=False)
+        col.use_team = form == 'team'
+        buf = M.ppo.RolloutBuffer(Tsteps, N, 'cuda')
+        torch.manual_seed(11)
+        snaps = []
+        for it in range(4):
+            col.collect(Tsteps * N, buf)
+            torch.cuda.synchronize()
+            snaps.append([t.clone() for t in (buf.obs, buf.obs_next, buf.act, buf.logp, buf.rew, buf.done, col.carry, venv.state)])
+        assert col.use_team == (form == 'team')                       # the library took the persistent form (no silent per-step path)
+        if form == 'team':
+            assert int(pol.engine._rollout_err[0]) == 0
+        out[form] = (snaps, venv.pop_episode_log())
+    n_done = 0
+    for a, b in zip(out['team'][0], out['steps'][0]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+        n_done += int(a[5].sum())
+    if 4 * Tsteps >= 28:
+        assert n_done >= N // 2                                       # episodes did end (30-chunk videos): auto-resets were exercised
+    la, lb = out['team'][1], out['steps'][1]
+    assert la.shape == lb.shape and len(la) == n_done
+    np.testing.assert_array_equal(la[np.lexsort(la.T[::-1])], lb[np.lexsort(lb.T[::-1])])      # (records are appended in completion order: compare as sets)
+
+
 def test_behavior_cloning_pretraining_vs_reference(M, tmp_path):
     """The whole behavior_cloning_pretraining() loop (utils/mansy_utils.py:52-93) against the capture of the IMPORTED reference
     function (tools/gen_golden_bc.py: duck-typed policy around the reference Actor, duck-typed demonstrations): same host RNG
