@@ -447,6 +447,8 @@ namespace mansy_gemm { hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr; }
 #ifdef MANSY_LAB
 int g_mansy_lab_variant = 0;
 extern "C" int mansy_lab_set_variant(int v) { const int old = g_mansy_lab_variant; if (v >= 0) g_mansy_lab_variant = v; return old; }
+static unsigned long long* g_mansy_lab_stamps = nullptr;     // device buffer [64] for the phase stamps of the wave-split-K loop (gemm_wsk.h WSK_STAMP)
+extern "C" void mansy_lab_set_stamps(void* dev) { g_mansy_lab_stamps = (unsigned long long*)dev; }
 #endif
 
 extern "C" int mansy_prof_gemm_enable(int on) {
@@ -590,6 +592,9 @@ int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B,
   GemmParams p;
   p.A = A; p.B = B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.ep = ep;
   p.col_group = (ep.tile_nrange || ep.tile_list || ep.tile_krange) ? 0 : mansy_var_col_group(ep.variant);
+#ifdef MANSY_LAB
+  p.lab_stamps = g_mansy_lab_stamps;
+#endif
   p.c_rmw_ok = (reinterpret_cast<uintptr_t>(C) & 15) == 0 && (!ep.pair_C || (reinterpret_cast<uintptr_t>(ep.pair_C) & 15) == 0) && ldc % 4 == 0 && N % 4 == 0;
   p.vec_ok = ((lda % 4) == 0) && ((ldb % 4) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
              ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (K % 4 == 0) && (!a_kmajor || M % 4 == 0) &&
