@@ -355,7 +355,8 @@ def test_gae_and_return_normaliser_vs_oracle(M, T, N):
 
 def test_gae_kernel_reproduces_tianshou_published_known_answers(M):
     """P5 pin on the HIP path: mansy_gae_returns on the vectors tianshou's own repository publishes for compute_episodic_return
-    (v0.4.8 test/base/test_returns.py; tests/golden/tianshou_known_answers.npz, tools/gen_golden_tianshou_ka.py): one
+    (v0.4.8 test/base/test_returns.py; tests/golden/tianshou_known_answers.npz, tools/gen_golden_tianshou_ka.py -- TYPED IN from that published test, tianshou is
+    not installable here: the vectors are authentic to the best of the builder's knowledge, they were not generated by running tianshou): one
     environment (N = 1), each case alone and all four side by side as the columns of one padded [T][N] launch."""
     from mansy_immersivevideostreaming_amd._lib import check, lib, ptr, stream_ptr
     KA = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'tianshou_known_answers.npz'))

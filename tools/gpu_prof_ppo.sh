@@ -47,3 +47,4 @@ out = {'fetch_bytes_per_cycle': fe, 'write_bytes_per_cycle': wr, 'traffic_bytes_
 json.dump(out, open('gpurun_out/prof_ppo/ppo_pmc.json', 'w'), indent=1)
 print(json.dumps(out))
 PY
+python3 tools/ppo_traffic_by_kernel.py > gpurun_out/prof_ppo/ppo_traffic_by_kernel.txt 2>&1; head -12 gpurun_out/prof_ppo/ppo_traffic_by_kernel.txt

@@ -41,6 +41,7 @@ bash tools/gpu_prof_ppo.sh > $OUT/ppo_prof_summary.txt 2>&1
 f=$(ls -t gpurun_out/prof_ppo/*/*kernel_stats.csv | head -1); [ -n "$f" ] && cp "$f" $OUT/ppo_kernel_stats.csv
 cp gpurun_out/prof_ppo/ppo_kernel_stats.meta.json $OUT/ppo_kernel_stats.meta.json 2>/dev/null
 cp gpurun_out/prof_ppo/ppo_pmc.json $OUT/ppo_pmc.json 2>/dev/null
+cp gpurun_out/prof_ppo/ppo_traffic_by_kernel.txt $OUT/ppo_traffic_by_kernel.txt 2>/dev/null
 # per-shape HBM-side traffic of the fp32 GEMM launches
 bash tools/gpu_gemm_traffic.sh > $OUT/gemm_traffic_by_shape.txt 2>&1
 # byte / integer kernels
