@@ -756,11 +756,24 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16h_kernel(GemmParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+#ifdef MANSY_LAB
+  // (lab build only) phase stamps of ONE workgroup (p.lab_stamps[63] names it), lane 0 of each wave: as gemm_f32_dma_kernel's (tools/dma_phase_lab.py)
+  const bool lab_on = p.lab_stamps && (int)(blockIdx.y * gridDim.x + blockIdx.x) == (int)p.lab_stamps[63] && lane == 0;
+  long long lab_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (lab_on) lab_t[0] = wall_clock64();
+#endif
 #pragma unroll
   for (int d = 0; d < D; ++d)
     if (d < nk) dma(d, d);
+#ifdef MANSY_LAB
+  if (lab_on) lab_t[1] = wall_clock64();
+#endif
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
+#ifdef MANSY_LAB
+    long long lab_w0 = 0;
+    if (lab_on) lab_w0 = wall_clock64();
+#endif
     // tiles still wanted in flight after tile kt has landed: min(D - 1, nk - 1 - kt) of them, PPT pieces each (the wait count is an immediate)
     const int ahead = nk - 1 - kt;
     if (D >= 3 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPT) : "memory");
@@ -768,6 +781,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16h_kernel(GemmParams p) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+#ifdef MANSY_LAB
+    if (lab_on) { const long long n_ = wall_clock64(); lab_t[5] += n_ - lab_w0; if (kt == 0) lab_t[2] = n_; }
+#endif
     if (kt + D < nk) dma(cur == 0 ? NS - 1 : cur - 1, kt + D);       // into the stage tile kt - 1 occupied
     const float* a_l = smem + cur * (STAGE_BYTES / 4);
     const __bf16* b_l = reinterpret_cast<const __bf16*>(a_l) + A_BYTES / 2;
@@ -814,8 +830,18 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16h_kernel(GemmParams p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // LDS reads retired before the barrier that frees this buffer
     cur = cur == NS - 1 ? 0 : cur + 1;
   }
+#ifdef MANSY_LAB
+  if (lab_on) { lab_t[3] = wall_clock64(); lab_t[6] = nk; }
+#endif
   __syncthreads();                                        // staging LDS idle (every DMA was waited for): the epilogue reuses it
   gemm_epilogue<BM, BN, SMEM_FLOATS>(p, acc, smem, m0, n0, tid, 0, p.C);
+#ifdef MANSY_LAB
+  if (lab_on) {
+    lab_t[4] = wall_clock64();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) p.lab_stamps[wave * 8 + i] = (unsigned long long)lab_t[i];
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
