@@ -328,7 +328,8 @@ def test_syncbn_hook_two_identical_ranks_equal_single(MT):
 
 @pytest.mark.parametrize('B,S,T,d,bias', [(1, 10, 10, 64, True), (3, 1, 1, 64, False), (2, 16, 16, 64, True), (5, 5, 15, 256, False),
                                           (130, 7, 3, 128, True), (33, 2, 16, 64, True),
-                                          (4, 5, 15, 512, True), (3, 16, 16, 512, False), (6, 3, 12, 512, True)])   # dh = 64: 4-heads-per-wave kernels at every length bucket
+                                          (4, 5, 15, 512, True), (3, 16, 16, 512, False), (6, 3, 12, 512, True),   # dh = 64: 4-heads-per-wave kernels at every length bucket
+                                          (77, 10, 10, 512, True), (40, 5, 15, 512, False)])   # the real width at ragged batches: clamped rows in the 32-row blocks of the small-product loop, dW over 770 / 600 rows (K % 32 != 0)
 def test_edge_shapes_forward_loss_grads_vs_oracle(MT, B, S, T, d, bias):
     """Ragged / extreme shapes: single trajectory, window length 1, the maximum window 16, head dims 8/16/32, row counts that
     are not multiples of any tile -- forward, loss and every gradient against the oracle's autograd."""
@@ -364,7 +365,15 @@ def test_edge_shapes_forward_loss_grads_vs_oracle(MT, B, S, T, d, bias):
         np.testing.assert_allclose(loss.item(), oloss.item(), rtol=1e-4, atol=1e-7)
         for k, p in m.named_parameters():
             ref = params[k].grad.numpy()
-            np.testing.assert_allclose(p.grad.cpu().numpy(), ref, atol=3e-4 * np.abs(ref).max() + 2e-6, rtol=0, err_msg=k)
+            tol = 3e-4 * np.abs(ref).max() + 2e-6
+            if B * d >= 40 * 512:
+                # the real width at tens of trajectories: a ReLU gate / MaxPool route that the fp32 oracle and the kernels decide differently on a near-tie moves single
+                # gradient elements (measured: 1-2 of 262 144 of an encoder linear1.weight, 15 % past the band) -- the criterion of tests/test_gpu_vp_fullsize.py at
+                # B = 512: at most max(8, 0.5 %) of a tensor's elements outside the 3e-4 band, none beyond 1e-2
+                err = np.abs(p.grad.cpu().numpy() - ref)
+                assert (err > tol).sum() <= max(8, 5e-3 * err.size) and err.max() <= 1e-2 * np.abs(ref).max() + 2e-6, (k, float(err.max()), float(tol), int((err > tol).sum()))
+            else:
+                np.testing.assert_allclose(p.grad.cpu().numpy(), ref, atol=tol, rtol=0, err_msg=k)
 
 
 def test_errors_are_loud(MT):
