@@ -223,13 +223,14 @@ def _ppo_policy(dev, rank=0, precision=None):
     return pol
 
 
-def _ppo_cycle_time(pol, dev, cycles, warmup, n_env=256, steps_per_env=16, qoe_weights=QOE_TRAIN, seed=5):
+def _ppo_cycle_time(pol, dev, cycles, warmup, n_env=256, steps_per_env=16, qoe_weights=QOE_TRAIN, seed=5, tables=None):
     """(ms per cycle, library launches per cycle incl. the rollout graph's) of collect -> train_identifier (2 rounds) -> relabel + PPO update."""
     import torch
     from mansy_immersivevideostreaming_amd._lib import lib
     from mansy_immersivevideostreaming_amd.bitrate_selection.envs.mansy_env import EnvTables, MANSYVecEnv
     from mansy_immersivevideostreaming_amd.bitrate_selection.models.mansy_ppo import RolloutBuffer, VecCollector
-    tables = EnvTables.synthetic(dev, seed=5, qoe_weights=qoe_weights, train_identifier_reward=True, n_sample=max(240, n_env))
+    if tables is None:
+        tables = EnvTables.synthetic(dev, seed=5, qoe_weights=qoe_weights, train_identifier_reward=True, n_sample=max(240, n_env))
     venv = MANSYVecEnv(tables, n_env, seed=seed, index_offset=0, worker_num=n_env)
     col = VecCollector(pol, venv, seed=seed)
     buf = RolloutBuffer(steps_per_env, n_env, dev)
@@ -409,10 +410,24 @@ def bench_vp_small(dev, steps=30, warmup=5):
     return out
 
 
-def bench_ppo(rank, world, dev, mdist, cycles=5, warmup=2, n_env=256, steps_per_env=16, rollout_probe=True):
-    """PPO env-steps/s (BASELINE configs[2]/[3]): 256 vectorised trace-sim envs per GPU on synthetic bench-shaped tables,
-    one cycle = collect 16 steps/env (4096 transitions/GPU) -> train_identifier (2 rounds) -> relabel -> PPO update
-    (minibatch 512, repeat 2), i.e. run_mansy.py --train --train-identifier --use-identifier with step_per_collect=4096."""
+REAL_TABLES = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tests', 'golden', 'env_tables_jin2022_4g.npz')
+
+
+def _ppo_tables(dev, kind, n_env_total):
+    """'real': the reference's Jin2022 x 4G TRAIN split (18 videos x 45 users x 24 traces x 4 preferences = the 72-episode catalogue of
+    generate_environment_samples, utils/common.py:60-84), packed by tools/gen_golden_tables_full.py out of the reference's own loaders --
+    BASELINE configs[2] "Jin2022 tiles x 4G bandwidth traces".  'synthetic': same-shape random tables."""
+    from mansy_immersivevideostreaming_amd.bitrate_selection.envs.mansy_env import EnvTables
+    if kind == 'real':
+        return EnvTables.from_file(REAL_TABLES, 'train', dev, use_identifier=True)
+    return EnvTables.synthetic(dev, seed=5, train_identifier_reward=True, n_sample=max(240, n_env_total))
+
+
+def bench_ppo(rank, world, dev, mdist, cycles=5, warmup=2, n_env=256, steps_per_env=16, rollout_probe=True, tables_kind='real'):
+    """PPO env-steps/s (BASELINE configs[2]/[3]): 256 vectorised trace-sim envs per GPU on the reference's real Jin2022 x 4G train tables
+    (`tables_kind='synthetic'`: bench-shaped random tables), one cycle = collect 16 steps/env (4096 transitions/GPU) -> train_identifier
+    (2 rounds) -> relabel -> PPO update (minibatch 512, repeat 2), i.e. run_mansy.py --train --train-identifier --use-identifier with
+    step_per_collect=4096."""
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -447,7 +462,9 @@ def bench_ppo(rank, world, dev, mdist, cycles=5, warmup=2, n_env=256, steps_per_
     else:
         sync_desc = ('RCCL all-reduce via ' + rccl_direct if rccl_direct else 'torch.distributed all_reduce') + ('' if peer is False else f"; probe: {rep.get('reason')}" + (
             f" (peer {rep.get('us_peer')} us vs library {rep.get('us_library')} us)" if 'us_peer' in rep else ''))
-    tables = EnvTables.synthetic(dev, seed=5, train_identifier_reward=True, n_sample=max(240, n_env * world))
+    if tables_kind == 'real' and not os.path.exists(REAL_TABLES):
+        tables_kind = 'synthetic'
+    tables = _ppo_tables(dev, tables_kind, n_env * world)
     off, wnum = mdist.shard_envs(n_env, rank, world)
     shards = [[off, wnum]]
     if world > 1:                               # every rank's (first global environment, global worker count): the line shows the partition
@@ -534,8 +551,11 @@ def bench_ppo(rank, world, dev, mdist, cycles=5, warmup=2, n_env=256, steps_per_
             'ms_per_cycle': round(dt / cycles * 1e3, 3), 'rollout_only_env_steps_per_s': round(n_env * steps_per_env * cycles / t_collect, 1),
             'rollout_step_latency_us': round(t_collect / (cycles * steps_per_env) * 1e6, 1), 'final_loss': float(np.mean(res['loss'])),
             'config': {'workload': f'{n_env} device-resident envs/GPU x {steps_per_env} steps per collect (4096 transitions/GPU), '
-                                   'identifier train (2 full-batch rounds) + relabel + PPO update (minibatch 512, repeat 2), synthetic '
-                                   'Jin2022/4G-shaped tables, fp32', 'parallelism': f'dp{world}'},
+                                   'identifier train (2 full-batch rounds) + relabel + PPO update (minibatch 512, repeat 2), ' + (
+                                       'REAL Jin2022 x 4G train tables of the reference (72-episode catalogue: 18 videos x 45 users x 24 traces x 4 preferences; '
+                                       'tests/golden/env_tables_jin2022_4g.npz)' if tables_kind == 'real' else 'synthetic Jin2022/4G-shaped tables') + ', fp32',
+                       'parallelism': f'dp{world}', 'tables': tables_kind},
+            'data': 'real' if tables_kind == 'real' else 'synthetic',
             'model_flops_per_env_step': PPO_FLOP_PER_ENV_STEP, 'algorithmic_bytes_per_env_step': PPO_BYTES_PER_ENV_STEP, 'dtype': 'f32',
             'roofline': roof}
 
@@ -617,7 +637,12 @@ def cpu_baseline_ppo(seconds=6.0):
     nthreads = torch.get_num_threads()
     torch.set_num_threads(1)
     rs = np.random.RandomState(0)
-    arrays = _synthetic_arrays()          # same synthetic tables as the GPU leg, host copy
+    if os.path.exists(REAL_TABLES):       # the same tables as the GPU leg, host copy: the reference's Jin2022 x 4G train split
+        z = np.load(REAL_TABLES)
+        arrays = {k: z['train/' + k] for k in ('size', 'quality', 'video_len', 'vp_gt', 'vp_pred', 'vp_acc', 'vp_start', 'vp_end', 'trace_bw', 'trace_len', 'samples')}
+        tables_desc = 'real Jin2022 x 4G train tables'
+    else:
+        arrays, tables_desc = _synthetic_arrays(), 'synthetic tables'
     OT = oenv.EnvTables(arrays, np.array([[7, 1, 1], [1, 7, 1], [1, 1, 7], [3, 3, 3]], np.float32), train_identifier_reward=True)
     env = oenv.Env(OT, seed=5, worker_num=1)
     sd = po.make_policy_state_dict(5)
@@ -636,7 +661,7 @@ def cpu_baseline_ppo(seconds=6.0):
     dt = time.time() - t0
     torch.set_num_threads(nthreads)
     return {'value': round(n / dt, 1), 'unit': 'env-steps/s', 'cores': 1, 'kind': 'port',
-            'sample': f'{n} sequential env steps (C oracle env + B=1 oracle actor forward + sampling) in {dt:.1f}s'}
+            'sample': f'{n} sequential env steps (C oracle env + B=1 oracle actor forward + sampling) in {dt:.1f}s on the {tables_desc}'}
 
 
 def _synthetic_arrays():
@@ -890,6 +915,11 @@ def main():
             out['inference'] = bench_vp_inference(model, h, c, f)
             out['small_batch'] = bench_vp_small(dev)
             out['configs4'] = bench_ppo_c5(dev)
+            # the same cycle on the synthetic bench-shaped tables every earlier round's line was measured on (the real-table line above should sit within a few % of it)
+            ms_syn, nl_syn, _ = _ppo_cycle_time(_ppo_policy(dev), dev, max(2, min(args.steps, 6)), 2)
+            out['secondary']['synthetic_tables'] = {'value': round(256 * 16 / ms_syn * 1e3, 1), 'unit': 'env-steps/s', 'ms_per_cycle': round(ms_syn, 3),
+                                                    'library_launches_per_cycle': round(nl_syn, 1), 'data': 'synthetic',
+                                                    'real_over_synthetic': round(out['secondary']['value'] / (256 * 16 / ms_syn * 1e3), 4)}
             out['secondary']['dp_form'] = bench_ppo_dp_form(dev, mdist, vp_leg=lambda: vp_dp_form_leg(model, opt, h, c, f, dev, mdist))      # (last: it brings up a one-rank RCCL group)
         print(json.dumps(out), flush=True)
     if world > 1:

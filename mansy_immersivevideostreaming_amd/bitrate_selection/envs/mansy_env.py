@@ -93,11 +93,11 @@ class EnvTables:
         return self.c.n_sample
 
     # ---- builders ------------------------------------------------------------------------------
-    @classmethod
-    def from_dataset(cls, config, dataset, network_dataset, mode, qoe_weights, device, seed=0, use_identifier=False, samples=None,
-                     lists=None):
-        """Reads the files Simulator.__init__ reads (simulator.py:30-45): prediction pickles, manifests, traces.
-        `samples`: explicit episode catalogue of (video, user, trace, qoe) list positions (ExpertEnv takes one);
+    @staticmethod
+    def arrays_from_dataset(config, dataset, network_dataset, mode, qoe_weights, seed=0, samples=None, lists=None):
+        """Host half of `from_dataset`: reads the files Simulator.__init__ reads (simulator.py:30-45: prediction pickles, manifests,
+        traces) for the episode catalogue MANSYEnv.__init__ enumerates (mansy_env.py:44-52) and returns (arrays, ids) -- numpy only, no
+        device.  `samples`: explicit episode catalogue of (video, user, trace, qoe) list positions (ExpertEnv takes one);
         `lists`: explicit (videos, users, traces) id lists instead of the split of `mode`."""
         videos, users, traces = lists if lists is not None else (
             config.video_split[dataset][mode], config.user_split[dataset][mode], config.network_split[network_dataset][mode])
@@ -166,10 +166,31 @@ class EnvTables:
                                  f'{int(vlen[vi])}, predictions end at {int(vend[i])})')
         arrays = dict(size=size, quality=qual, video_len=vlen, vp_gt=gt, vp_pred=pr, vp_acc=acc, vp_start=vstart, vp_end=vend,
                       trace_bw=bw, trace_len=tl, samples=smp)
+        return arrays, (used_v, used_vp, used_t, [(videos[a], users[b], traces[c]) for a, b, c, _ in samples])
+
+    @classmethod
+    def from_dataset(cls, config, dataset, network_dataset, mode, qoe_weights, device, seed=0, use_identifier=False, samples=None,
+                     lists=None):
+        """The tables of one split read from the dataset tree (`arrays_from_dataset`), uploaded."""
+        arrays, ids = cls.arrays_from_dataset(config, dataset, network_dataset, mode, qoe_weights, seed=seed, samples=samples, lists=lists)
         return cls(arrays, qoe_weights, device, video_rates=config.video_rates, startup_download=config.startup_download,
                    chunk_length=config.chunk_length, max_size=config.max_size, max_throughput=config.max_throughput,
-                   train_identifier_reward=(mode == 'train' and use_identifier),
-                   ids=(used_v, used_vp, used_t, [(videos[a], users[b], traces[c]) for a, b, c, _ in samples]))
+                   train_identifier_reward=(mode == 'train' and use_identifier), ids=ids)
+
+    @classmethod
+    def from_file(cls, path, split, device, qoe_weights=None, use_identifier=False):
+        """The tables of one split from a packed table file (`.npz` with `<split>/<field>` arrays, `<split>/qoe_w`, `<split>/ids_*` and
+        `const/*`: the layout tools/gen_golden_tables_full.py writes for the reference's Jin2022 x 4G splits) -- one file read instead of
+        the split's ~100 pickles / JSON manifests.  bench.py's real-table PPO leg and the shipped-run tests load the reference's tables this way."""
+        z = np.load(path)
+        arrays = {k: z[f'{split}/{k}'] for k in cls.FIELDS}
+        qw = z[f'{split}/qoe_w'] if qoe_weights is None else qoe_weights
+        misc = z['const/misc']
+        ids = ([int(v) for v in z[f'{split}/ids_v']], [tuple(int(x) for x in r) for r in z[f'{split}/ids_vp']],
+               [int(t) for t in z[f'{split}/ids_t']], [tuple(int(x) for x in r) for r in z[f'{split}/ids_samples']])
+        return cls(arrays, qw, device, video_rates=tuple(int(r) for r in z['const/video_rates']), startup_download=int(misc[0]),
+                   chunk_length=int(misc[1]), max_size=float(misc[2]), max_throughput=float(misc[3]),
+                   train_identifier_reward=(split == 'train' and use_identifier), ids=ids)
 
     @classmethod
     def synthetic(cls, device, n_video=27, n_user=60, n_trace=40, n_chunk=60, seed=5, qoe_weights=((7, 1, 1), (1, 7, 1), (1, 1, 7), (3, 3, 3)),

@@ -31,9 +31,12 @@ def write_episode_log(log_path, tables, qoe_weights, records):
                     f'{round(s3 / n, 5)}\n')
 
 
-def run_episodes(policy, venv, n_episode, seed=0, reset=True):
+def run_episodes(policy, venv, n_episode, seed=0, reset=True, log=None):
     """Test collector: step `venv` with sampled actions until n_episode episodes have finished; returns their returns.
-    reset=False continues from the environments' current state."""
+    reset=False continues from the environments' current state.
+    log: a list that receives the finished episodes' device records in the order the reference's CSV rows appear -- by vector step, and
+    within a step by environment index (tianshou's DummyVectorEnv steps its workers in order and each MANSYEnv appends its row when its
+    episode ends, mansy_env.py:230-232,271-290); the device appends records of ONE step in arbitrary order."""
     eng = policy.engine
     N = venv.n_env
     obs = venv.reset() if reset else venv.obs
@@ -48,6 +51,9 @@ def run_episodes(policy, venv, n_episode, seed=0, reset=True):
         if d.any():
             done_returns += ret[d].cpu().tolist()
             ret[d] = 0
+            if log is not None:
+                rec = venv.pop_episode_log()
+                log.extend(rec[np.argsort(rec[:, 1], kind='stable')])
         step += 1
     return np.array(done_returns[:n_episode])
 
@@ -55,13 +61,15 @@ def run_episodes(policy, venv, n_episode, seed=0, reset=True):
 class OnpolicyTrainer:
     def __init__(self, policy, train_collector, test_collector, max_epoch, step_per_epoch, repeat_per_collect, episode_per_test, batch_size,
                  step_per_collect=None, stop_fn=None, save_best_fn=None, save_checkpoint_fn=None, logger=None, args=None, identifier=None,
-                 identifier_optimizer=None, test_log=None, verbose=True, **kwargs):
+                 identifier_optimizer=None, test_log=None, train_log=None, verbose=True, **kwargs):
         self.policy, self.train_collector, self.test_collector = policy, train_collector, test_collector
         self.max_epoch, self.step_per_epoch, self.repeat_per_collect = max_epoch, step_per_epoch, repeat_per_collect
         self.episode_per_test, self.batch_size, self.step_per_collect = episode_per_test, batch_size, step_per_collect
         self.stop_fn, self.save_best_fn, self.save_checkpoint_fn = stop_fn, save_best_fn, save_checkpoint_fn
         self.args, self.identifier, self.identifier_optimizer = args, identifier, identifier_optimizer
         self.test_log = test_log          # (log_path, tables, qoe_weights) for the validation CSV
+        self.train_log = train_log        # the same for the training CSV (rows appended after every collect)
+        self.history = []                 # per collect: env_step, n/ep, len -- what tianshou's logger writes as train/episode, train/length
         self.verbose = verbose
         self.epoch, self.iter_num, self.env_step, self.gradient_step = 0, 0, 0, 0
         self.best_reward, self.best_reward_std, self.best_epoch = -np.inf, 0.0, -1
@@ -70,6 +78,14 @@ class OnpolicyTrainer:
         self.buffer = RolloutBuffer(max(1, step_per_collect // N), N, train_collector.venv.device)
         if identifier_optimizer is not None:
             policy.identifier_optim = identifier_optimizer
+        # T2: tianshou's Collector.__init__ ends in reset() -> reset_env(): every environment has been reset ONCE before the trainer touches
+        # it.  For the training collector that reset is the start of the first collect (VecCollector.reset_env at the first collect); for
+        # the test collector it moves each environment one entry along its catalogue walk (worker_id += worker_num, mansy_env.py:100-101)
+        # before test_episode resets again -- the shipped valid_log.csv starts at catalogue entries 5, 6, 7, 4, not 1, 2, 3, 0.
+        tv = getattr(test_collector, 'venv', None)
+        if tv is not None and hasattr(tv, 'reset') and not getattr(test_collector, '_constructed_reset', False):
+            tv.reset()
+            test_collector._constructed_reset = True
         self.start_time = time.time()
 
     def reset(self):
@@ -89,10 +105,21 @@ class OnpolicyTrainer:
         return self
 
     def test_step(self, save=True):
+        # T2: tianshou test_episode = collector.reset_env() -> collect(n_episode) -- which resets every finished environment and, having
+        # collected by episodes, ends in ANOTHER reset_env() (Collector.collect's closing `if n_episode: self.reset_env()`).  Each test thus moves an
+        # environment 2 + episodes-played entries along its catalogue walk; the shipped valid_log.csv (second test starts at entries
+        # 13, 14, 15, 12) holds exactly that.
         venv = self.test_collector.venv
-        rets = run_episodes(self.policy, venv, self.episode_per_test, seed=self.test_collector.seed)
         if self.test_log is not None:
-            write_episode_log(self.test_log[0], self.test_log[1], self.test_log[2], venv.pop_episode_log()[:self.episode_per_test])
+            venv.pop_episode_log()
+            records = []
+            rets = run_episodes(self.policy, venv, self.episode_per_test, seed=self.test_collector.seed, log=records)
+            write_episode_log(self.test_log[0], self.test_log[1], self.test_log[2], records[:self.episode_per_test])
+            self.last_test_lengths = [int(r[2]) for r in records[:self.episode_per_test]]
+        else:
+            rets = run_episodes(self.policy, venv, self.episode_per_test, seed=self.test_collector.seed)
+        if hasattr(venv, 'reset'):
+            venv.reset()
         rew, rew_std = float(rets.mean()), float(rets.std())
         if self.best_epoch < 0 or self.best_reward < rew:
             self.best_epoch, self.best_reward, self.best_reward_std = self.epoch, rew, rew_std
@@ -115,6 +142,10 @@ class OnpolicyTrainer:
             result = self.train_collector.collect(self.step_per_collect, self.buffer)
             n_done += result['n/st']
             self.env_step += result['n/st']
+            if self.train_log is not None:       # the training environments' finished episodes: CSV rows + the collect's n/ep and mean length
+                rec = self.train_collector.venv.pop_episode_log()
+                write_episode_log(self.train_log[0], self.train_log[1], self.train_log[2], rec)
+                self.history.append({'env_step': self.env_step, 'n/ep': len(rec), 'len': float(np.mean(rec[:, 2])) if len(rec) else 0.0})
             if self.args is not None and getattr(self.args, 'train_identifier', False):
                 print('==================== Start Training QOE identifier ====================')
                 self.policy.train_identifier(self.buffer, update_round=self.args.identifier_update_round)

@@ -87,12 +87,12 @@ def train(args, config, policy, qoe_weights, identifier, identifier_optimizer, m
                               args.epochs, args.step_per_epoch, args.repeat_per_collect, episode_per_test=args.episode_per_test,
                               batch_size=args.batch_size, step_per_collect=args.step_per_collect, stop_fn=stop_fn, save_best_fn=save_best_fn,
                               save_checkpoint_fn=save_checkpoint_fn, args=args, identifier=identifier,
-                              identifier_optimizer=identifier_optimizer, test_log=(valid_log_path, t_valid, qoe_weights))
+                              identifier_optimizer=identifier_optimizer, test_log=(valid_log_path, t_valid, qoe_weights),
+                              train_log=(train_log_path, t_train, qoe_weights))
     for epoch, epoch_stat, info in trainer:
         print(f'Epoch: {epoch}')
         print('loss:', epoch_stat.get('loss'), ' --- ', 'loss/clip:', epoch_stat.get('loss/clip'), ' --- ', 'loss/vf:', epoch_stat.get('loss/vf'),
               ' --- ', 'loss/ent:', epoch_stat.get('loss/ent'))
-        write_episode_log(train_log_path, t_train, qoe_weights, train_env.pop_episode_log())
     return trainer
 
 
@@ -120,6 +120,7 @@ def test(args, config, policy, qoe_weights, identifier, models_dir, results_dir)
     write_episode_log(test_log_path, tables, qoe_weights, ordered)
     read_log_file(test_log_path, verbose=args.verbose_table)
     print('Results saved at:', test_log_path)
+    return ordered
 
 
 def run(args, config):
@@ -162,6 +163,7 @@ def run(args, config):
                        dual_clip=args.dual_clip, value_clip=args.value_clip, gae_lambda=args.gae_lambda, action_space=config.action_space,
                        action_scaling=False, args=args, identifier=identifier, identifier_optim=identifier_optimizer).to(args.device)
     policy.engine.precision = getattr(args, 'precision', 'f32')      # carried into every engine call (no process-wide mode)
+    out = {'policy': policy, 'models_dir': models_dir, 'results_dir': results_dir}      # (the reference's run() returns nothing: extra, for callers / tests)
     if args.train:
         bc_file_prefix = f'bc_ms_{args.bc_max_steps}_ims_{args.bc_identifier_max_steps}_ilr_{args.identifier_lr}_iur_{args.identifier_update_round}'
         policy_bc_path = os.path.join(models_dir, bc_file_prefix + '_policy.pth')
@@ -180,10 +182,11 @@ def run(args, config):
                                          identifier_update_round=args.identifier_update_round, policy_save_path=policy_bc_path,
                                          identifier_save_path=identifier_bc_path)
         qoe_weights = [config.qoe_split['train'][i] for i in args.qoe_train_ids]
-        train(args, config, policy, qoe_weights, identifier, identifier_optimizer, models_dir, policy_bc_path, identifier_bc_path)
+        out['trainer'] = train(args, config, policy, qoe_weights, identifier, identifier_optimizer, models_dir, policy_bc_path, identifier_bc_path)
     if args.test:
         qoe_weights = [config.qoe_split[split][i] for i in args.qoe_test_ids]
-        test(args, config, policy, qoe_weights, identifier, models_dir, results_dir)
+        out['test_records'] = test(args, config, policy, qoe_weights, identifier, models_dir, results_dir)
+    return out
 
 
 # the reference's command line (run_mansy.py:284-337) as data: (flag, type-or-None for store_true, default)
@@ -225,7 +228,7 @@ def main(argv=None):
     args = build_parser().parse_known_args(argv)[0]          # unknown flags are ignored, as in the reference (:340)
     print(args)
     config = get_config_from_yml(args.config)
-    run(args, config)
+    return run(args, config)
 
 
 if __name__ == '__main__':
