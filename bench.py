@@ -242,17 +242,18 @@ def _ppo_cycle_time(pol, dev, cycles, warmup, n_env=256, steps_per_env=16, qoe_w
     for _ in range(warmup):
         cycle()
     torch.cuda.synchronize()
-    n0 = lib().mansy_prof_launch_count()
+    n0 = lib().mansy_prof_launch_count() + pol.graph_launches
     t0 = time.perf_counter()
     for _ in range(cycles):
         res = cycle()
-    n1 = lib().mansy_prof_launch_count()
+    n1 = lib().mansy_prof_launch_count() + pol.graph_launches      # direct launches + the ones the update half's graph replays re-ran
     t_host = time.perf_counter() - t0           # the host has enqueued everything (it runs ahead of the GPU unless the cycle is host-bound)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     import numpy as np
     loss = float(np.mean(res['loss']))
     _ppo_cycle_time.host_ms = t_host / cycles * 1e3
+    _ppo_cycle_time.graph_replays = pol.graph_replays
     return dt / cycles * 1e3, (n1 - n0) / float(cycles) + (col.graph_launches if col.use_graph and col._graph is not None else 0), loss
 
 
@@ -439,9 +440,11 @@ def bench_ppo(rank, world, dev, mdist, cycles=5, warmup=2, n_env=256, steps_per_
     # the second, check it against the first on the same data, time both on THIS machine's links and keep the faster correct one
     # (dist.probe_peer_grad_sync; any set-up failure, wrong result or timed-out wait on any rank -> the library collective on every rank).
     # MANSY_PEER_SYNC=1 / 0 forces one or the other.
+    # 'slot': forced peer kernel in the exchange-slot form (the form 'auto' takes once its probe has agreed: the functional 8-rank test uses it);
+    # '1': forced peer kernel, un-probed, hence the copy form (PPOPolicy.set_data_parallel).
     mode = os.environ.get('MANSY_PEER_SYNC', 'auto')
-    peer = False if world <= 1 or mode == '0' else (True if mode == '1' else 'auto')
-    pol.set_data_parallel(world, mdist.make_grad_sync(world), peer=peer)
+    peer = False if world <= 1 or mode == '0' else (True if mode in ('1', 'slot') else 'auto')
+    pol.set_data_parallel(world, mdist.make_grad_sync(world), peer=peer, in_slot=True if mode == 'slot' else None)
     rep = pol.grad_sync_report
     rccl_direct = None
     if world > 1 and rep.get('chosen') != 'peer' and dist.get_backend() == 'nccl' and os.environ.get('MANSY_RCCL_DIRECT', '1') != '0':
@@ -484,19 +487,44 @@ def bench_ppo(rank, world, dev, mdist, cycles=5, warmup=2, n_env=256, steps_per_
         dist.barrier()
     torch.cuda.synchronize()
     from mansy_immersivevideostreaming_amd._lib import lib
-    launches0 = lib().mansy_prof_launch_count()
+    launches0 = lib().mansy_prof_launch_count() + pol.graph_launches
     t0 = time.perf_counter()
     for _ in range(cycles):
         res = cycle()
-    launches1 = lib().mansy_prof_launch_count()
+    launches1 = lib().mansy_prof_launch_count() + pol.graph_launches      # (the update half replays captured graphs from the third cycle on)
+    t_host = time.perf_counter() - t0
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    per_rank = None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        # every rank's own view: cycle time to its last sync and the time its host needed to ENQUEUE the cycles (a straggling enqueue thread
+        # is what every other rank's peer kernel then waits for)
+        mine = torch.tensor([dt / cycles * 1e3, t_host / cycles * 1e3], device=dev, dtype=torch.float64)
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        per_rank = {'ms_per_cycle': [round(float(v[0]), 3) for v in allv], 'host_enqueue_ms_per_cycle': [round(float(v[1]), 3) for v in allv]}
         dt = t.item()
+    # the cycle in its data-parallel FORM on a ONE-rank peer context, on every rank at once (no wire, no waiting for anyone): what is left of the
+    # N-rank cycle after subtracting it is the wire + skew term w of DESIGN section 6, per average
+    wire = None
+    if world > 1:
+        try:
+            pol1 = _ppo_policy(dev, rank)
+            pol1.set_data_parallel(1, None, peer=True, force=True, in_slot=True)
+            ms1, _, _ = _ppo_cycle_time(pol1, dev, cycles, 3, n_env=n_env, steps_per_env=steps_per_env, tables=tables)
+            pol1._check_peers()
+            t1 = torch.tensor([ms1], device=dev, dtype=torch.float64)
+            dist.all_reduce(t1, op=dist.ReduceOp.MAX)
+            wire = {'dp_form_world1_ms_per_cycle_max_over_ranks': round(float(t1.item()), 3),
+                    'us_per_average_wire_and_skew': round((dt / cycles * 1e3 - float(t1.item())) * 1e3 / 18, 2),
+                    'design_budget': 'DESIGN section 6: 7.8x at w = 0, ~6.8x at w = 16 us, 6.0x at w = 30 us'}
+        except Exception as e:          # noqa: BLE001
+            wire = {'error': str(e)[:200]}
+        dist.barrier()
     # rollout alone (outside the timed region): policy forward + sampling + environment step, hipGraph-replayed collects
     tc = time.perf_counter()
     for _ in range(cycles if rollout_probe else 0):
@@ -508,12 +536,15 @@ def bench_ppo(rank, world, dev, mdist, cycles=5, warmup=2, n_env=256, steps_per_
     roof = None
     nprof = 2
     from mansy_immersivevideostreaming_amd._lib import lib
+    graph_mode = pol.graph_update
+    pol.graph_update = False              # (the event pairs ride on direct launches: the profiled cycles run the update half un-captured)
     if rank == 0:
         ms_g, n_g, fl_g = _gemm_prof(lib(), cycle, nprof)
     else:
         for _ in range(nprof):
             cycle()
         torch.cuda.synchronize()
+    pol.graph_update = graph_mode
     steps = world * n_env * steps_per_env * cycles
     if rank == 0:
         eps = steps / dt / world                                      # env-steps/s of this GPU
@@ -547,8 +578,10 @@ def bench_ppo(rank, world, dev, mdist, cycles=5, warmup=2, n_env=256, steps_per_
     spread = max(replica_spread(pol.engine.ac.flat_p, world), replica_spread(pol.engine.idn.flat_p, world))
     return {'metric': 'PPO env-steps/sec', 'value': round(steps / dt, 1), 'unit': 'env-steps/s', 'n_gpus': world, 'cycles': cycles,
             'replica_param_spread': spread, 'env_shards': shards, 'envs_per_gpu': n_env,
-            'grad_sync': sync_desc,
-            'ms_per_cycle': round(dt / cycles * 1e3, 3), 'rollout_only_env_steps_per_s': round(n_env * steps_per_env * cycles / t_collect, 1),
+            'grad_sync': sync_desc, 'grad_sync_report': rep, 'per_rank': per_rank, 'wire_term': wire,
+            'update_half': ('hipGraph replay' if pol.graph_replays else 'direct launches') + f' ({pol.graph_replays} replays so far)',
+            'ms_per_cycle': round(dt / cycles * 1e3, 3), 'host_enqueue_ms_per_cycle': round(t_host / cycles * 1e3, 3),
+            'update_graph_replays': pol.graph_replays, 'rollout_only_env_steps_per_s': round(n_env * steps_per_env * cycles / t_collect, 1),
             'rollout_step_latency_us': round(t_collect / (cycles * steps_per_env) * 1e6, 1), 'final_loss': float(np.mean(res['loss'])),
             'config': {'workload': f'{n_env} device-resident envs/GPU x {steps_per_env} steps per collect (4096 transitions/GPU), '
                                    'identifier train (2 full-batch rounds) + relabel + PPO update (minibatch 512, repeat 2), ' + (
@@ -766,6 +799,11 @@ def main():
     import torch
     import torch.distributed as dist
     from mansy_immersivevideostreaming_amd import dist as mdist
+    # each rank's threads on a core set of their own (LOCAL_RANK-th slice of the allowed cores), before anything touches the GPU: at 8 ranks every
+    # gradient average waits for the slowest rank's enqueue thread, and eight of them on one socket otherwise share whatever the scheduler gives
+    host_cores = mdist.pin_host_cores() if env_world_size > 1 else None
+    if os.environ.get('MANSY_XG_TEST_FAIL_RANK'):       # tests/test_gpu_dist.py: one rank's peer set-up fails (the package reads no environment: the harness injects)
+        mdist.PeerGradSync._fail_setup_on_rank = int(os.environ['MANSY_XG_TEST_FAIL_RANK'])
     if env_world_size > 1 and os.environ.get('MANSY_SHARE_GPU') != '1' and torch.cuda.device_count() < env_world_size:
         sys.exit(f'bench.py: {env_world_size} ranks need {env_world_size} GPUs, this node shows {torch.cuda.device_count()} '
                  '(MANSY_SHARE_GPU=1 MANSY_DIST_BACKEND=gloo runs the functional test of the multi-rank path on fewer)')
@@ -781,6 +819,10 @@ def main():
         dist_info.update(backend=dist.get_backend(), world_size=dist.get_world_size(), ranks_reporting=int(ones.item()))
         if dist_info['world_size'] != args.gpus or dist_info['ranks_reporting'] != args.gpus:
             sys.exit(f'bench.py: asked for {args.gpus} ranks, the process group reports {dist_info}')
+        # self-diagnosis before any timed leg: devices, peer-access matrix, hipIpc open of a fine-grained allocation from every
+        # peer + one peer-memory average in both forms, the library all-reduce, each rank's core set -- gathered on every rank, printed by rank 0
+        dist_info['preflight'] = mdist.preflight(world, rank, dev, sizes=(1024, 435200))
+        dist_info['preflight']['pinned_cores_this_rank'] = host_cores
 
     from mansy_immersivevideostreaming_amd.viewport_prediction.models import ViewportTransformerMTIO, FusedAdamW
     from mansy_immersivevideostreaming_amd._lib import lib, check
@@ -892,7 +934,7 @@ def main():
     model.two_stream = None
 
     vp_spread = replica_spread(model._flat_p, world)
-    ppo = bench_ppo(rank, world, dev, mdist, cycles=max(2, min(args.steps, 6)), warmup=2)
+    ppo = bench_ppo(rank, world, dev, mdist, cycles=max(2, min(args.steps, 6)), warmup=3)      # warm-up: direct, capture + replay, replay
 
     if rank == 0:
         out = {

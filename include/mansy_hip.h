@@ -245,7 +245,8 @@ int mansy_identifier_forward(const float* const* params, const float* obs, int B
 int mansy_identifier_train_step(const float* const* params, float* const* grads, float* flat_p, float* flat_g, float* flat_m,
                                 float* flat_v, long long n_flat, const float* obs, const int* idx /* NULL: rows 0..B of obs; else obs[idx[r]] */,
                                 int B, float lr, float weight_decay, int step, float* loss_out, void* workspace, int max_batch,
-                                void* xg_ctx /* NULL, or (step > 0) a mansy_xg context: see mansy_ppo_minibatch_step */, int precision, void* stream);
+                                void* xg_ctx /* NULL, or (step > 0) a mansy_xg context: see mansy_ppo_minibatch_step */,
+                                const float* adam_bias /* NULL, or device [2]: see mansy_ppo_minibatch_step */, int precision, void* stream);
 int mansy_identifier_relabel(const float* const* params, const float* obs, float* rew, float* id_rew, int B, float lamb,
                              void* workspace, int max_batch, int precision, void* stream);
 int mansy_gae_returns(const float* rew, const float* v_s, const float* v_next, const unsigned char* done, int T, int N, double gamma,
@@ -255,7 +256,13 @@ int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, fl
                              const float* adv_all, const float* logp_old_all, const float* v_old_all, const float* ret_all, int mb,
                              float eps_clip, float vf_coef, float ent_coef, int norm_adv, int value_clip, float dual_clip,
                              float max_grad_norm, float lr, float weight_decay, int step, long long tail_from, int tail_step, float* stats,
-                             void* workspace, int max_batch, int chain_in, const int* next_idx, int next_mb, void* xg_ctx, int precision, void* stream);
+                             void* workspace, int max_batch, int chain_in, const int* next_idx, int next_mb, void* xg_ctx, const float* adam_bias,
+                             int precision, void* stream);
+/* adam_bias (ABI 9; nullable): device pointer to two floats [1 - 0.9^t, sqrt(1 - 0.999^t)] that the Adam launch READS instead of the values the
+ * host derives from `step` -- what makes the call replayable from a captured hipGraph: the kernel arguments of a replay are frozen, the caller
+ * rewrites the two floats (stream-ordered) before every replay.  `step` still selects the step's form and its scratch parity: a graph must hold
+ * an EVEN number of steps per flat buffer.  Not with a lagged tail.  Accepted by mansy_identifier_train_step, mansy_ppo_dp_tail and
+ * mansy_clip_grad_adam as well. */
 /* xg_ctx = the step's `sync` context (ABI 8; NULL = single process) -- the DATA-PARALLEL step as ONE call.  Needs the clipped chained form
  * (max_grad_norm > 0, step > 0, no lagged tail); every rank makes the same sequence of calls on its context.
  *  - a mansy_xg context of n_flat floats (MANSY_SYNC_XG): the rank's raw gradients are produced straight in its exchange slot, ONE more launch
@@ -293,7 +300,8 @@ int mansy_bc_step(const float* const* params, float* const* grads, float* flat_p
 /* have_sumsq != 0: scratch already holds the MANSY_CLIP_SCRATCH_DOUBLES partial sums of squares of flat_g (mansy_xg_allreduce_avg
  * leaves them there) -- the norm launch is skipped. */
 int mansy_clip_grad_adam(float* flat_p, float* flat_g, float* flat_m, float* flat_v, long long n_flat, float max_grad_norm, float lr,
-                         float weight_decay, int step, long long tail_from, int tail_step, double* scratch, int have_sumsq, void* stream);
+                         float weight_decay, int step, long long tail_from, int tail_step, double* scratch, int have_sumsq,
+                         const float* adam_bias /* nullable: see mansy_ppo_minibatch_step */, void* stream);
 
 /* Data-parallel form of the chained step's last launch (after the ranks averaged the raw gradients of a step = 0 call): clip by the
  * global norm, Adam(L2), zero flat_g, re-pack the updated parameters into the workspace's packed images and prepare the next
@@ -303,8 +311,8 @@ int mansy_clip_grad_adam(float* flat_p, float* flat_g, float* flat_m, float* fla
  * averages them into flat_g; the next step's gradients go into the other slot. */
 int mansy_ppo_dp_tail(const float* const* params, float* flat_p, float* flat_g, float* flat_m, float* flat_v, long long n_flat,
                       float max_grad_norm, float lr, float weight_decay, int step, double* scratch, int have_sumsq, const float* obs_all,
-                      const float* adv_all, const int* next_idx, int next_mb, float* next_flat_g, void* workspace, int max_batch, int precision,
-                      void* stream);
+                      const float* adv_all, const int* next_idx, int next_mb, float* next_flat_g, const float* adam_bias /* nullable */, void* workspace,
+                      int max_batch, int precision, void* stream);
 
 /* ------------------------------------------------------------------ thin wrappers over RCCL communicators (round 5)
  * The three collectives of the data-parallel hot path as C-ABI calls: explicit communicator, explicit stream, device pointers.  RCCL is bound at
@@ -399,8 +407,9 @@ typedef struct mansy_gemm_epilogue {
    * MANSY_VARIANT_* below.  Per call, thread-safe: nothing about it is remembered. */
   int variant;
 } mansy_gemm_epilogue;
-#define MANSY_VARIANT_BF16(v) (((v) + 1) & 0xFF) /* loop variant v of the bf16x3 products with pre-split weights (0, 1 default, 4, 6, 7, 8: bit-identical
-                                                  * real loops; 2, 3, 11, 12: timing-only forms, results wrong -- csrc/gemm_bf16s.hip) */
+#define MANSY_VARIANT_BF16(v) (((v) + 1) & 0xFF) /* loop variant v of the bf16x3 products with pre-split weights (0, 1 default, 4, 7, 8: real loops with
+                                                  * bit-identical results -- csrc/gemm_bf16s.hip; any other code runs the default.  Round 6: the timing-only
+                                                  * forms 2 / 3 / 11 / 12, whose results were wrong, no longer exist) */
 #define MANSY_VARIANT_NO_WSK 0x100               /* fp32 products too small to fill the chip: the 64 x 64 LDS-DMA loop instead of the wave-split-K loop
                                                   * (same products, different summation order) */
 #define MANSY_VARIANT_NO_WSK_TN 0x200            /* the same for the small weight-gradient (TN) products only */

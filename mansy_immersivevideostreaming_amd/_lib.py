@@ -118,14 +118,14 @@ _PROTOS = {
     'mansy_policy_evaluate': [P, P, c_int, P, c_int, P, P, P, c_int, c_int, P],
     'mansy_policy_rollout': [P, P, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, c_int, P, P, P, c_int, c_int, P],
     'mansy_identifier_forward': [P, P, c_int, P, P, c_int, c_int, P],
-    'mansy_identifier_train_step': [P, P, P, P, P, P, c_ll, P, P, c_int, c_float, c_float, c_int, P, P, c_int, P, c_int, P],
+    'mansy_identifier_train_step': [P, P, P, P, P, P, c_ll, P, P, c_int, c_float, c_float, c_int, P, P, c_int, P, P, c_int, P],
     'mansy_identifier_relabel': [P, P, P, P, c_int, c_float, P, c_int, c_int, P],
     'mansy_gae_returns': [P, P, P, P, c_int, c_int, ctypes.c_double, ctypes.c_double, c_int, P, P, P, P, P],
     'mansy_ppo_minibatch_step': [P, P, P, P, P, P, c_ll, P, P, P, P, P, P, P, c_int, c_float, c_float, c_float, c_int, c_int, c_float, c_float,
-                                 c_float, c_float, c_int, c_ll, c_int, P, P, c_int, c_int, P, c_int, P, c_int, P],
+                                 c_float, c_float, c_int, c_ll, c_int, P, P, c_int, c_int, P, c_int, P, P, c_int, P],
     'mansy_bc_step': [P, P, P, P, P, P, c_ll, c_ll, P, P, c_int, c_float, c_float, c_float, c_int, P, P, c_int, c_int, P],
-    'mansy_clip_grad_adam': [P, P, P, P, c_ll, c_float, c_float, c_float, c_int, c_ll, c_int, P, c_int, P],
-    'mansy_ppo_dp_tail': [P, P, P, P, P, c_ll, c_float, c_float, c_float, c_int, P, c_int, P, P, P, c_int, P, P, c_int, c_int, P],
+    'mansy_clip_grad_adam': [P, P, P, P, c_ll, c_float, c_float, c_float, c_int, c_ll, c_int, P, c_int, P, P],
+    'mansy_ppo_dp_tail': [P, P, P, P, P, c_ll, c_float, c_float, c_float, c_int, P, c_int, P, P, P, c_int, P, P, P, c_int, c_int, P],
     'mansy_comm_unique_id': [P],
     'mansy_comm_create': [P, c_int, c_int, P],
     'mansy_comm_destroy': [P],
@@ -159,7 +159,7 @@ _RESTYPES = {'mansy_last_error': ctypes.c_char_p, 'mansy_prof_launch_count': cty
 
 # bumped together with mansy_abi_version() (csrc/capi.hip) whenever a prototype or struct above changes: a stale in-tree
 # libmansy_hip.so then fails at load time instead of being called with a wrong argument list
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _lib = None
 
@@ -193,37 +193,6 @@ def lib():
     if _lib is None:
         _lib = _load(LIB_PATH)
     return _lib
-
-
-LAB_LIB_PATH = os.path.join(_HERE, 'libmansy_hip_lab.so')
-_lab = None
-
-
-class lab_library:
-    """Test / tools harness only: inside the block every host mirror of THIS process talks to the -DMANSY_LAB build of the same sources
-    (libmansy_hip_lab.so: `python -m mansy_immersivevideostreaming_amd.build_ext --lab`), the only build that exports
-    mansy_lab_set_variant(v) -- a default kernel-selection variant for calls that pass 0, so that whole engine steps can be run on two
-    loops.  `variant` is set on entry and reset to 0 on exit.  The release library has no such entry point."""
-
-    def __init__(self, variant=0):
-        self.variant = int(variant)
-
-    def __enter__(self):
-        global _lib, _lab
-        if _lab is None:
-            _lab = _load(LAB_LIB_PATH)
-            _lab.mansy_lab_set_variant.argtypes = [c_int]
-            _lab.mansy_lab_set_variant.restype = c_int
-        self.prev_lib = lib()
-        _lab.mansy_lab_set_variant(self.variant)
-        _lib = _lab
-        return _lab
-
-    def __exit__(self, *exc):
-        global _lib
-        _lab.mansy_lab_set_variant(0)
-        _lib = self.prev_lib
-        return False
 
 
 def check(rc, what=''):

@@ -347,7 +347,7 @@ class NetEngine:
         `obs_slab` [T][N][780] holds the starting observations, the call fills the rest like T calls of policy_env_step would (bit-identical).
         -> True, or False where the library says the form does not apply (another precision than fp32, a batch outside the wave-split-K range,
         launch recorder on): the caller then takes the per-step path.  A launch that gave up (a workgroup never became resident within 2 s: the
-        device is shared) has raised its host-mapped word; the NEXT call raises."""
+        device is shared) has raised its host-mapped word: `check_rollout()` -- called by the policy before it trains on the buffer -- raises."""
         import ctypes
         N, dev = venv.n_env, obs_slab.device
         if getattr(self, '_rollout_ctl', None) is None or self._rollout_ctl.device != dev:
@@ -368,6 +368,18 @@ class NetEngine:
                 return False
             check(rc, 'mansy_policy_rollout')
         return True
+
+    def check_rollout(self, sync=False):
+        """Verdict on the persistent rollout launches issued so far: a launch that gave up left partial / garbage slabs behind.  The
+        policy calls it at the top of train_identifier() / process_fn() with sync=True when the team form is in use, i.e. BEFORE the buffer is
+        trained on (the word is host-mapped: without the sync it covers completed launches only)."""
+        err = getattr(self, '_rollout_err', None)
+        if err is None:
+            return
+        if sync:
+            torch.cuda.synchronize(self.device)
+        if int(err[0]) != 0:
+            raise MansyError('a persistent rollout launch gave up waiting for its workgroups (is the device shared?): its outputs were garbage')
 
     def identifier_forward(self, obs):
         B, dev = obs.shape[0], obs.device

@@ -56,7 +56,7 @@ class VecCollector:
     straight into the slabs); the whole sequence is captured once into a hipGraph and replayed (sampling uniforms are drawn
     before each replay)."""
 
-    def __init__(self, policy, venv, seed=0, use_graph=True):
+    def __init__(self, policy, venv, seed=0, use_graph=True, use_team=False):
         self.policy, self.venv = policy, venv
         self.carry = None                       # observation the next collect starts from
         self.seed = int(seed) & 0x7FFFFFFF
@@ -65,10 +65,9 @@ class VecCollector:
         self.use_graph = use_graph
         # round 5: the whole collect as ONE persistent launch on XCD teams (mansy_policy_rollout) where the library takes it (fp32, batch in the
         # wave-split-K range).  Bit-identical to the per-step launches and 49 launches fewer, but NOT faster (24.0 against 22.5 us per vector
-        # step: profiles/r05_rollout_team_ab.txt), so it is opt-in (`collector.use_team = True` / MANSY_ROLLOUT_TEAM=1); never on a device
-        # shared between ranks (the kernel wants one resident workgroup per CU)
-        import os
-        self.use_team = os.environ.get('MANSY_ROLLOUT_TEAM', '0') == '1' and os.environ.get('MANSY_SHARE_GPU') != '1'
+        # step: profiles/r05_rollout_team_ab.txt), so it is opt-in (the `use_team` argument / attribute); never on a device shared between
+        # ranks (the kernel wants one resident workgroup per CU)
+        self.use_team = bool(use_team)
         self._graph = None
         self._graph_key = None
         self.graph_launches = 0
@@ -244,8 +243,17 @@ class PPOPolicy(nn.Module):
         self._pre_eval = None
         self._pinned = {}
         self.peer_in_slot = True      # peer-memory averages: gradients are produced straight in the exchange slot (no copy in front of the flag)
+        # round 6: train_identifier() and update() replayed from captured hipGraphs (the rollout half has been one since round 2): a cycle's host
+        # work is then three replays + one staged upload each (the host-drawn shuffles and the Adam bias corrections of the replay's step counts)
+        # instead of ~150 engine calls -- the host leaves the critical path (1.42 of a 1.75 ms cycle before).  'auto': wherever the captured
+        # sequence is made of this library's own launches only (single process, or peer-memory averages in the exchange-slot form); library
+        # collectives (RCCL / torch.distributed) are captured only when forced with True.  False: direct launches.
+        self.graph_update = 'auto'
+        self._graphs, self._graph_seen = {}, set()
+        self.graph_replays = 0
+        self.graph_launches = 0       # library launches re-run by the replays so far (mansy_prof_launch_count only sees direct launches)
 
-    def set_data_parallel(self, world, grad_sync, peer=False, force=False, comm=None):
+    def set_data_parallel(self, world, grad_sync, peer=False, force=False, comm=None, in_slot=None):
         """One process per GPU: `grad_sync(flat_grad)` averages a flat gradient buffer over ranks (dist.make_grad_sync).
         peer=True: the hand-written one-shot all-reduce over peer-mapped memory (dist.PeerGradSync, csrc/xgmi.hip) for both flat
         buffers instead -- one launch that also leaves the gradient's sums of squares for the clip.  peer='auto': build it, check it
@@ -255,6 +263,18 @@ class PPOPolicy(nn.Module):
         issued (grad_sync over a one-rank group, or the peer kernel on a one-rank context), then clip + Adam as a launch of its own --
         i.e. everything a rank pays for data parallelism except the wire time."""
         self.world, self.grad_sync = int(world), grad_sync
+        self._graphs, self._graph_seen = {}, set()          # captured sequences hold the previous form's launches
+        # in_slot (ADVICE r05): the exchange-slot form publishes with ONE flag store and relies on the kernel boundary in front of it having
+        # written the gradient kernels' stores back to the memory side.  That is validated on THIS machine's links by the start-up probe
+        # (peer='auto': fresh data written by many workgroups right before every average, both forms against the library's average); a forced
+        # peer=True skips the probe, so it takes the copy form (every workgroup releases its own copy at system scope) unless in_slot=True is
+        # asked for explicitly (bench.py's world-1 legs; tests).
+        if in_slot is not None:
+            self.peer_in_slot = bool(in_slot)
+        elif peer is True and int(world) > 1:
+            self.peer_in_slot = False
+        elif peer == 'auto':
+            self.peer_in_slot = True
         # comm: a dist.RcclComm (the library's own RCCL communicator): the library-collective form of the step also becomes ONE call per step
         # (gradients, ncclAllReduce(avg), norm, clip + Adam inside mansy_ppo_minibatch_step); it doubles as grad_sync where the one-call form
         # does not apply (unchained steps)
@@ -286,11 +306,24 @@ class PPOPolicy(nn.Module):
     def _check_peers(self):
         """A peer-memory all-reduce whose bounded wait gave up has overwritten the gradient with NaN and raised its context's sticky
         flag (csrc/xgmi.hip); the clip + Adam launch behind it has already run.  Called at the end of every learn() /
-        train_identifier() that used a peer context: raises MansyError on the rank that timed out, so the job exits non-zero instead of
-        training on with replicas that no longer agree.  mansy_xg_status does NOT synchronise (round 5: it reads a host-mapped sticky word), so
-        a time-out of a launch still in flight surfaces at the next check -- the poisoned (NaN) parameters cannot un-poison themselves meanwhile."""
+        train_identifier() that used a peer context: raises MansyError on the rank that timed out.  mansy_xg_status does NOT synchronise
+        (it reads a host-mapped sticky word), so here it only covers launches that have COMPLETED -- a cheap early warning on the hot path.
+        The definitive verdict is `sync_check()`, taken wherever parameters leave the process (state_dict(): checkpoints, best-model saves,
+        the end of training)."""
         for p in (getattr(self, '_peer', None) or {}).values():
             p.check()
+
+    def sync_check(self):
+        """Definitive verdict on the peer-memory averages issued so far: wait for the device, then read the sticky words (a
+        time-out in the update that has just been enqueued would otherwise be saved into checkpoint.pth before the next learn() raises, and the
+        last update of a run was never checked).  No-op without peer contexts."""
+        if getattr(self, '_peer', None):
+            torch.cuda.synchronize(self.engine.device)
+            self._check_peers()
+
+    def state_dict(self, *args, **kwargs):
+        self.sync_check()            # parameters are about to leave the process (torch.save in save_checkpoint_fn / save_best_fn, run_mansy.py:70-84)
+        return super().state_dict(*args, **kwargs)
 
     def _upload_i32(self, key, arr, dev):
         """Host int array -> device int32 tensor through a persistent PINNED staging buffer and a non-blocking copy: the copy engine
@@ -320,7 +353,7 @@ class PPOPolicy(nn.Module):
         comm = getattr(self, '_comm', None)          # no peer kernel: the library's own RCCL communicator, if one was handed over
         return comm.ctx if comm is not None else None
 
-    def _sync_clip_adam(self, f, max_norm, lr, wd, tail=None, overlap=None):
+    def _sync_clip_adam(self, f, max_norm, lr, wd, tail=None, overlap=None, bias=None):
         """Data-parallel second half of a step: average the raw local gradients over the ranks, then global-norm clip + Adam.
         tail = (data, next_idx or None): the chained form (actor-critic, clipped): the clip + Adam launch also zeroes the
         gradients, re-packs the updated parameters and prepares the next minibatch (mansy_ppo_dp_tail).
@@ -357,11 +390,11 @@ class PPOPolicy(nn.Module):
             arr, _ = f.pointers()
             check(lib().mansy_ppo_dp_tail(arr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), float(max_norm), lr, wd, f.step,
                                           ptr(scratch), int(peer is not None), ptr(data['obs']), ptr(data['adv']), ptr(nxt),
-                                          nxt.numel() if nxt is not None else 0, None, ptr(self.engine.workspace()), self.engine.max_batch,
+                                          nxt.numel() if nxt is not None else 0, None, ptr(bias), ptr(self.engine.workspace()), self.engine.max_batch,
                                           self.engine.prec, stream_ptr(f.flat_p.device)), 'mansy_ppo_dp_tail')
             return
         check(lib().mansy_clip_grad_adam(ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), float(max_norm), lr, wd, f.step,
-                                         *f.tail(), ptr(scratch), int(peer is not None), stream_ptr(f.flat_p.device)), 'mansy_clip_grad_adam')
+                                         *f.tail(), ptr(scratch), int(peer is not None), ptr(bias), stream_ptr(f.flat_p.device)), 'mansy_clip_grad_adam')
 
     # ---- plumbing ---------------------------------------------------------------------------------------------
     def _apply(self, fn, *a, **k):
@@ -396,33 +429,83 @@ class PPOPolicy(nn.Module):
         logits, _, act, _ = self.engine.policy_forward(t, want_value=False, sample=True, seed=seed, site=self._seed_ctr)
         return _Result(logits=logits, act=act.long(), state=state, dist=self.dist_fn(logits) if self.dist_fn else None)
 
+    # ---- hipGraph replay of the update half (round 6) ---------------------------------------------------------------
+    def _graph_ok(self, n_steps_per_flat):
+        """May this sequence be captured?  Needs an even number of Adam steps per flat buffer (the norm-slot sets and the peer exchange slots
+        alternate with the step count: a replay must start on the parity the capture started on), no lagged tail, and -- unless forced --
+        no library collective inside (see `graph_update`)."""
+        if not self.graph_update or n_steps_per_flat % 2 or self.engine.ac.tail()[0] >= 0:
+            return False
+        if self.graph_update is True:
+            return True
+        if self.grad_sync is None:
+            return True
+        return bool(getattr(self, '_peer', None)) and self.peer_in_slot and self.world >= 1 and getattr(self, '_comm', None) is None and \
+            all(self._xg_ctx(f) is not None for f in (self.engine.ac, self.engine.idn) if f is not None)
+
+    @staticmethod
+    def _adam_bias(step0, k):
+        """[k, 2] float32: (1 - 0.9^t, sqrt(1 - 0.999^t)) for t = step0 + 1 .. step0 + k, in the host arithmetic of csrc/ppo_engine.hip
+        (double pow, then float)."""
+        t = np.arange(step0 + 1, step0 + k + 1, dtype=np.float64)
+        return np.stack([1.0 - np.power(0.9, t), np.sqrt(1.0 - np.power(0.999, t))], 1).astype(np.float32)
+
+    def _stage(self, key, host_i32, dst):
+        """Host int32 array -> the persistent device buffer `dst` a captured graph reads, through a pinned staging buffer (stream-ordered,
+        no staging kernel).  The previous upload of the same buffer is waited for before the staging memory is overwritten."""
+        n = host_i32.size
+        ring = self._pinned.get(key)
+        if ring is None or ring['buf'].shape[1] < n:
+            # FOUR staging buffers used in turn: the host may run up to three cycles ahead of the device before it has to wait for an upload to
+            # have been consumed (with one buffer every cycle's staging waited for the previous cycle's copy, i.e. for the device: the host's
+            # enqueue time then read as the device's cycle time)
+            ring = self._pinned[key] = dict(buf=torch.empty(4, max(n, 1), dtype=torch.int32).pin_memory(), ev=[None] * 4, i=0)
+        i = ring['i']
+        ring['i'] = (i + 1) % 4
+        if ring['ev'][i] is not None:
+            ring['ev'][i].synchronize()
+        ring['buf'][i, :n].copy_(torch.from_numpy(host_i32))
+        dst[:n].copy_(ring['buf'][i, :n], non_blocking=True)
+        ring['ev'][i] = torch.cuda.Event()
+        ring['ev'][i].record(torch.cuda.current_stream(dst.device))
+
+    def _capture(self, dev, body):
+        """Capture `body()` (engine calls only, fixed shapes / addresses) on a side stream into a CUDAGraph; returns (graph, body's value,
+        library launches one replay re-runs).  Tensors `body` allocates live in the graph's pool for as long as the graph does."""
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        n0 = lib().mansy_prof_launch_count()
+        with torch.cuda.graph(g):
+            out = body()
+        return g, out, int(lib().mansy_prof_launch_count() - n0)
+
     def train_identifier(self, buffer, update_round=2, verbose=True):
         """utils/mansy_utils.py:9-39 on the collected buffer: np.random.shuffle, 80/20 split, `update_round` full-batch
         MSE steps with Adam(lr, L2), then the validation loss."""
-        eng = self.engine
+        self.engine.check_rollout(sync=True)       # (no-op unless the persistent-rollout form filled the buffer: its verdict before the data is used)
         n = len(buffer)
-        obs = buffer.obs[:buffer.filled].reshape(n, OBS_LD)
         idx = np.arange(n)
         np.random.shuffle(idx)
-        idx_t = self._upload_i32('ident', idx, obs.device)
-        ntr = int(n * 0.8)
-        # the shuffled 80 / 20 split as row indices into the buffer: each call gathers its rows in its own prologue launch (no
-        # shuffled copy of the 12.8 MB of observations, no separate gather launch)
-        tr, va = idx_t[:ntr], idx_t[ntr:]
-        lr, wd = self._hyper(self.identifier_optim, 1e-4)
-        f = eng.idn
-        losses = []
-        # data parallel: each round's gradient average is on the critical path (1.05 MB, latency-bound).  The critic / log-prob passes
-        # of the process_fn that follows (mansy_ppo.py:53: v_s + logp_old on obs, v_s_ on obs_next) depend on the actor-critic only,
-        # which this function does not touch: round r's average flies on a side stream while pass r runs here; process_fn then finds
-        # the values it needs (self._pre_eval) instead of recomputing them.
-        # (peer-memory averages in the exchange-slot form are one ~5 us launch inside the step's own call: nothing worth hiding)
-        hide = self.grad_sync is not None and self.overlap_identifier_sync and self._xg_ctx(f) is None
-        for r in range(update_round):
-            f.step += 1
-            ov = (lambda part=r: self._pre_evaluate(buffer, part)) if hide and r < 2 else None
-            losses.append(self._identifier_step(obs, lr, wd, f.step, rows=tr, overlap=ov))
-        vloss = self._identifier_step(obs, lr, wd, 0, rows=va) if len(va) else None
+        f = self.engine.idn
+        losses = vloss = None
+        fixed = isinstance(buffer, RolloutBuffer)          # (behaviour cloning hands over duck-typed demonstration buffers of varying length: direct launches)
+        key = ('ident', id(buffer), buffer.filled, buffer.N, buffer.obs.data_ptr(), int(update_round), f.flat_p.data_ptr(), self.engine.prec) if fixed else None
+        if fixed and update_round > 0 and self._graph_ok(update_round):
+            G = self._graphs.get(key)
+            if G is None and key in self._graph_seen:          # second call with this shape: capture (the first ran direct = the warm-up)
+                G = self._capture_identifier(key, buffer, n, update_round)
+            if G is not None:
+                host = np.concatenate([idx.astype(np.int32), self._adam_bias(f.step, update_round).reshape(-1).view(np.int32)])
+                self._stage(('ident_in', key), host, G['inp'])
+                f.step += update_round
+                G['graph'].replay()
+                self.graph_replays += 1
+                self.graph_launches += G['launches']
+                losses, vloss = [l.clone() for l in G['losses']], (G['vloss'].clone() if G['vloss'] is not None else None)
+            else:
+                self._graph_seen.add(key)
+        if losses is None:
+            losses, vloss = self._train_identifier_body(buffer, n, self._upload_i32('ident', idx, buffer.obs.device), update_round)
         if self.grad_sync is not None and update_round > 0:
             self._check_peers()
         if verbose:
@@ -432,8 +515,51 @@ class PPOPolicy(nn.Module):
                 print('identifier validation loss is: ', vloss.item())
         return losses, vloss
 
-    def _identifier_step(self, obs, lr, wd, step, rows=None, overlap=None):
-        """One train_identifier step on `obs` (rows=None) or on its rows `rows` (device int32 indices)."""
+    def _capture_identifier(self, key, buffer, n, update_round):
+        dev = buffer.obs.device
+        inp = torch.zeros(n + 2 * update_round, dtype=torch.int32, device=dev)
+        bias = inp[n:].view(torch.float32).view(update_round, 2)
+        f = self.engine.idn
+        step0, pre = f.step, self._pre_eval
+        try:
+            g, (losses, vloss), nl = self._capture(dev, lambda: self._train_identifier_body(buffer, n, inp[:n], update_round, bias=bias))
+        except Exception as e:                      # capture unsupported for this form: direct launches from now on
+            import warnings
+            warnings.warn(f'hipGraph capture of train_identifier failed ({e}); using direct launches')
+            self.graph_update = False
+            f.step = step0
+            return None
+        f.step, self._pre_eval = step0, pre         # the capture executed nothing: the replay that follows takes these steps
+        G = self._graphs[key] = dict(graph=g, inp=inp, losses=losses, vloss=vloss, launches=nl)
+        return G
+
+    def _train_identifier_body(self, buffer, n, idx_t, update_round, bias=None):
+        """The engine calls of train_identifier on shuffled row indices `idx_t` (device int32 [n])."""
+        eng = self.engine
+        obs = buffer.obs[:buffer.filled].reshape(n, OBS_LD)
+        ntr = int(n * 0.8)
+        # the shuffled 80 / 20 split as row indices into the buffer: each call gathers its rows in its own prologue launch (no
+        # shuffled copy of the 12.8 MB of observations, no separate gather launch)
+        tr, va = idx_t[:ntr], idx_t[ntr:n]
+        lr, wd = self._hyper(self.identifier_optim, 1e-4)
+        f = eng.idn
+        losses = []
+        # data parallel: each round's gradient average is on the critical path (1.05 MB, latency-bound).  The critic / log-prob passes
+        # of the process_fn that follows (mansy_ppo.py:53: v_s + logp_old on obs, v_s_ on obs_next) depend on the actor-critic only,
+        # which this function does not touch: round r's average flies on a side stream while pass r runs here; process_fn then finds
+        # the values it needs (self._pre_eval) instead of recomputing them.
+        # (peer-memory averages in the exchange-slot form are one ~5 us launch inside the step's own call: nothing worth hiding)
+        hide = self.grad_sync is not None and self.overlap_identifier_sync and self._xg_ctx(f) is None and bias is None
+        for r in range(update_round):
+            f.step += 1
+            ov = (lambda part=r: self._pre_evaluate(buffer, part)) if hide and r < 2 else None
+            losses.append(self._identifier_step(obs, lr, wd, f.step, rows=tr, overlap=ov, bias=None if bias is None else bias[r]))
+        vloss = self._identifier_step(obs, lr, wd, 0, rows=va) if len(va) else None
+        return losses, vloss
+
+    def _identifier_step(self, obs, lr, wd, step, rows=None, overlap=None, bias=None):
+        """One train_identifier step on `obs` (rows=None) or on its rows `rows` (device int32 indices).  bias: device [2] floats the Adam
+        launch reads instead of deriving them from `step` (graph replays)."""
         eng, f = self.engine, self.engine.idn
         B = obs.shape[0] if rows is None else rows.numel()
         if B > eng.max_batch:
@@ -444,14 +570,14 @@ class PPOPolicy(nn.Module):
         xg = self._xg_ctx(f) if dp else None
         if xg is not None:          # the data-parallel step as ONE call: gradients into the exchange slot, one launch averages them, Adam
             check(lib().mansy_identifier_train_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(obs), ptr(rows), B, lr, wd,
-                                                    step, ptr(loss), ptr(eng.workspace()), eng.max_batch, xg, eng.prec, stream_ptr(obs.device)),
+                                                    step, ptr(loss), ptr(eng.workspace()), eng.max_batch, xg, ptr(bias), eng.prec, stream_ptr(obs.device)),
                   'mansy_identifier_train_step')
             return loss
         check(lib().mansy_identifier_train_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(obs), ptr(rows), B, lr, wd,
-                                                -1 if dp else step, ptr(loss), ptr(eng.workspace()), eng.max_batch, None, eng.prec, stream_ptr(obs.device)),
+                                                -1 if dp else step, ptr(loss), ptr(eng.workspace()), eng.max_batch, None, ptr(bias), eng.prec, stream_ptr(obs.device)),
               'mansy_identifier_train_step')
         if dp:
-            self._sync_clip_adam(f, 0.0, lr, wd, overlap=overlap)
+            self._sync_clip_adam(f, 0.0, lr, wd, overlap=overlap, bias=bias)
         return loss
 
     def relabel(self, buffer, lamb):
@@ -495,8 +621,9 @@ class PPOPolicy(nn.Module):
                                                   eng.max_batch, eng.prec, stream_ptr(dev)), 'mansy_policy_evaluate')
         pe['done'].add(part)
 
-    def process_fn(self, buffer):
-        """T2: A2CPolicy._compute_returns + PPOPolicy.process_fn: v_s, v_s_, GAE, normalised returns, logp_old."""
+    def process_fn(self, buffer, out=None):
+        """T2: A2CPolicy._compute_returns + PPOPolicy.process_fn: v_s, v_s_, GAE, normalised returns, logp_old.
+        out: a previous call's result whose tensors are to be REUSED (same addresses: the captured learn graph reads them)."""
         eng = self.engine
         T, N = buffer.filled, buffer.N
         n = T * N
@@ -531,6 +658,11 @@ class PPOPolicy(nn.Module):
                                                   ptr(eng.workspace()), eng.max_batch, eng.prec, stream_ptr(dev)), 'mansy_policy_evaluate')
                 check(lib().mansy_policy_evaluate(arr, ptr(obs_next[s:e]), e - s, None, 0, None, ptr(v_next[s:e]), ptr(eng.workspace()),
                                                   eng.max_batch, eng.prec, stream_ptr(dev)), 'mansy_policy_evaluate')
+        if out is not None:          # persistent outputs: the values land where the captured graph reads them
+            for k, t in (('v_s', v_s), ('v_next', v_next), ('logp_old', logp_old)):
+                out[k].copy_(t)
+            self._returns_from_values(out)
+            return out
         returns = torch.empty(n, dtype=torch.float32, device=dev)
         adv = torch.empty(n, dtype=torch.float32, device=dev)
         data = dict(obs=obs, obs_next=obs_next, act=act, v_s=v_s, v_next=v_next, logp_old=logp_old, returns=returns, adv=adv, n=n, buffer=buffer)
@@ -570,8 +702,10 @@ class PPOPolicy(nn.Module):
                                                   stream_ptr(dev)), 'mansy_policy_evaluate')
         self._returns_from_values(data)
 
-    def learn(self, data, batch_size, repeat):
-        """T2: PPOPolicy.learn: `repeat` passes over shuffled minibatches (np.random.permutation, merge_last)."""
+    def learn(self, data, batch_size, repeat, passes=None, perm=None, bias=None):
+        """T2: PPOPolicy.learn: `repeat` passes over shuffled minibatches (np.random.permutation, merge_last).
+        passes / perm: the passes' index chunks drawn by the caller and their concatenation as a device int32 tensor (graph capture / replay:
+        update() draws and stages them); bias: device [n_steps, 2] Adam bias corrections read by the step's last launch (graph replays)."""
         eng, f = self.engine, self.engine.ac
         n, dev = data['n'], data['obs'].device
         lr, wd = self._hyper(self.optim, 5e-4)
@@ -579,9 +713,11 @@ class PPOPolicy(nn.Module):
         dp = self.grad_sync is not None
         # every pass's permutation is drawn up front, in the order tianshou draws them (one np.random.permutation per pass, nothing
         # else consumes the generator in between), so that each step's last launch can prepare the next step's minibatch
-        passes = [list(split_indices(n, batch_size)) for _ in range(repeat)]
+        if passes is None:
+            passes = [list(split_indices(n, batch_size)) for _ in range(repeat)]
         chain = self.chain_steps and float(self._grad_norm or 0.0) > 0.0 and f.tail()[0] < 0   # the step forms that end in step_tail / dp_tail
-        perm = self._upload_i32('perm', np.concatenate([c for chunks in passes for c in chunks]), dev)      # ONE upload for all passes
+        if perm is None:
+            perm = self._upload_i32('perm', np.concatenate([c for chunks in passes for c in chunks]), dev)      # ONE upload for all passes
         flat, off = [], 0                                                    # (pass, k, idx view) of every minibatch step, in order
         for pi, chunks in enumerate(passes):
             for k, chunk in enumerate(chunks):
@@ -609,14 +745,15 @@ class PPOPolicy(nn.Module):
             f.step += 1
             last_of_pass = s + 1 < len(flat) and flat[s + 1][0] != pi
             nxt = flat[s + 1][2] if (chain and s + 1 < len(flat) and not (recompute and last_of_pass)) else None
+            b_s = None if bias is None else bias[s]
             # (_recompute_returns rewrites data['v_s'] / ['returns'] / ['adv'] IN PLACE: the pointers converted above still hold)
             check(step_fn(*fixed_head, ptr(idx), *fixed_mid, idx.numel(), *hyper, 0 if split else f.step, *f.tail(), ptr(stats_all[pi][k]), ws_ptr, eng.max_batch,
                           int(chain and s > 0 and not first_of_later_pass), ptr(None if split else nxt), nxt.numel() if (nxt is not None and not split) else 0, xg,
-                          eng.prec, st_ptr),
+                          ptr(b_s), eng.prec, st_ptr),
                   'mansy_ppo_minibatch_step')
             if split:                           # raw local gradients -> average over the ranks -> global-norm clip + Adam (+ next prologue)
-                self._sync_clip_adam(f, float(self._grad_norm or 0.0), lr, wd, tail=(data, nxt) if chain else None)
-        if dp:
+                self._sync_clip_adam(f, float(self._grad_norm or 0.0), lr, wd, tail=(data, nxt) if chain else None, bias=b_s)
+        if dp and bias is None:
             self._check_peers()
         return LazyLosses(('loss', 'loss/clip', 'loss/vf', 'loss/ent'), stats_all)
 
@@ -642,13 +779,93 @@ class PPOPolicy(nn.Module):
         return stats
 
     def update(self, sample_size, buffer, is_train=False, batch_size=512, repeat=2, **kwargs):
-        """mansy_ppo.py:36-59."""
+        """mansy_ppo.py:36-59.  From the second call with the same buffer / batch_size / repeat on, the whole sequence (relabel, the
+        evaluation passes, GAE, every minibatch step) is one hipGraph replay (`graph_update`); the host draws the permutations (same numpy
+        calls in the same order), stages them together with the replay's Adam bias corrections in ONE upload, and replays."""
         if buffer is None or len(buffer) == 0:
             return {}
-        if self.args is not None and getattr(self.args, 'use_identifier', False) and is_train:
-            self.relabel(buffer, self.args.lamb)
-        self.updating = True
-        data = self.process_fn(buffer)
-        result = self.learn(data, batch_size, repeat)
+        self.engine.check_rollout(sync=True)
+        relabel = self.args is not None and getattr(self.args, 'use_identifier', False) and is_train
+        n = len(buffer)
+        f = self.engine.ac
+        sizes = [len(c) for c in split_indices(n, batch_size, shuffle=False)]
+        n_steps = len(sizes) * repeat
+        fixed = isinstance(buffer, RolloutBuffer)
+        key = ('update', id(buffer), buffer.filled, buffer.N, buffer.obs.data_ptr(), int(batch_size), int(repeat), bool(relabel),
+               float(getattr(self.args, 'lamb', 0.0)) if relabel else 0.0, f.flat_p.data_ptr(), self.engine.prec, self._recompute_adv,
+               self.chain_steps) if fixed else None
+        if fixed and self._graph_ok(n_steps) and self.chain_steps and float(self._grad_norm or 0.0) > 0.0:
+            G = self._graphs.get(key)
+            capture = G is None and key in self._graph_seen          # second call with this shape: capture (the first ran direct = the warm-up)
+            if G is not None or capture:
+                passes = [list(split_indices(n, batch_size)) for _ in range(repeat)]          # the host RNG is consumed exactly as learn() does
+                if capture:
+                    G = self._capture_update(key, buffer, n, passes, batch_size, repeat, relabel)
+                if G is not None:
+                    host = np.concatenate([np.concatenate([c for chunks in passes for c in chunks]).astype(np.int32),
+                                           self._adam_bias(f.step, n_steps).reshape(-1).view(np.int32)])
+                    self._stage(('update_in', key), host, G['inp'])
+                    self.updating = True
+                    if G['data'] is not None:      # learn-only graph (more than one rank): relabel + process_fn hold a library collective, they run direct
+                        if G.pop('fresh', False):
+                            pass                   # (the capturing call has just run them)
+                        else:
+                            if relabel:
+                                self.relabel(buffer, self.args.lamb)
+                            self.process_fn(buffer, out=G['data'])
+                    elif relabel:
+                        self.cnt += n
+                    f.step += n_steps
+                    G['graph'].replay()
+                    self.graph_replays += 1
+                    self.graph_launches += G['launches']
+                    self.updating = False
+                    if self.grad_sync is not None:
+                        self._check_peers()
+                    return LazyLosses(('loss', 'loss/clip', 'loss/vf', 'loss/ent'), [t.clone() for t in G['stats']])
+                # capture failed: the permutations are drawn -- run them directly
+                return self._update_body(buffer, batch_size, repeat, relabel, passes=passes)
+            self._graph_seen.add(key)
+        return self._update_body(buffer, batch_size, repeat, relabel)
+
+    def _update_body(self, buffer, batch_size, repeat, relabel, passes=None, perm=None, bias=None, data=None):
+        if data is None:
+            if relabel:
+                self.relabel(buffer, self.args.lamb)
+            self.updating = True
+            data = self.process_fn(buffer)
+        result = self.learn(data, batch_size, repeat, passes=passes, perm=perm, bias=bias)
         self.updating = False
         return result
+
+    def _capture_update(self, key, buffer, n, passes, batch_size, repeat, relabel):
+        dev = buffer.obs.device
+        n_perm = sum(len(c) for chunks in passes for c in chunks)
+        n_steps = sum(len(chunks) for chunks in passes)
+        inp = torch.zeros(n_perm + 2 * n_steps, dtype=torch.int32, device=dev)
+        bias = inp[n_perm:].view(torch.float32).view(n_steps, 2)
+        f = self.engine.ac
+        step0, cnt0, pre = f.step, self.cnt, self._pre_eval
+        # more than one rank: process_fn gathers the return statistics with a library collective (dist.global_running_moments).  Unless library
+        # collectives in graphs were asked for (graph_update = True), only learn() -- the 16 dependent steps, 90 % of the launches -- is captured;
+        # relabel + process_fn run direct into PERSISTENT output tensors the graph reads.
+        data = None
+        if self.world > 1 and self.graph_update is not True:
+            if relabel:
+                self.relabel(buffer, self.args.lamb)          # (real work: the replay below must not repeat it)
+            data = self.process_fn(buffer)
+            data = {k: (v.clone() if torch.is_tensor(v) and k in ('v_s', 'v_next', 'logp_old', 'returns', 'adv') else v) for k, v in data.items()}
+            cnt0 = self.cnt
+        self._pre_eval = None                      # values evaluated ahead of time belong to one buffer state: a replay recomputes them
+        try:
+            g, res, nl = self._capture(dev, lambda: self._update_body(buffer, batch_size, repeat, relabel, passes=passes, perm=inp[:n_perm], bias=bias,
+                                                                      data=data))
+        except Exception as e:                      # capture unsupported for this form: direct launches from now on
+            import warnings
+            warnings.warn(f'hipGraph capture of the PPO update failed ({e}); using direct launches')
+            self.graph_update = False
+            f.step, self.cnt, self._pre_eval, self.updating = step0, cnt0, pre, False
+            return None
+        f.step, self.cnt = step0, cnt0             # the capture executed nothing: the replay that follows takes these steps
+        G = self._graphs[key] = dict(graph=g, inp=inp, stats=res._pending, launches=nl, data=data, fresh=data is not None)
+        return G

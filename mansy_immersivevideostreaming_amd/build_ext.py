@@ -13,8 +13,12 @@ HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-result']
 
 
-def sources():
-    return sorted(f for f in os.listdir(CSRC) if f.endswith('.hip'))
+def sources(lab=False):
+    """The library's translation units; lab=True adds csrc/lab/*.hip (the -DMANSY_LAB twin's settable default variant: never in the release build)."""
+    out = sorted(f for f in os.listdir(CSRC) if f.endswith('.hip'))
+    if lab:
+        out += sorted(os.path.join('lab', f) for f in os.listdir(os.path.join(CSRC, 'lab')) if f.endswith('.hip'))
+    return out
 
 
 def _stale(target, deps):
@@ -65,19 +69,19 @@ def build(force=False, verbose=False, lab=False):
     variant (mansy_lab_set_variant) for whole-engine A/B timings (tools/) and the paired-launch equivalence test.  The release library
     (lab=False) holds no process-wide mutable state."""
     if lab:
-        return _build(os.path.join(CSRC, '_obj_lab'), LAB_LIB, FLAGS + ['-DMANSY_LAB'], force, verbose, stamp=None)
+        return _build(os.path.join(CSRC, '_obj_lab'), LAB_LIB, FLAGS + ['-DMANSY_LAB'], force, verbose, stamp=None, lab=True)
     return _build(OBJ, LIB, FLAGS, force, verbose, stamp=STAMP)
 
 
-def _build(OBJ, LIB, FLAGS, force, verbose, stamp):
+def _build(OBJ, LIB, FLAGS, force, verbose, stamp, lab=False):
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
     headers.append(os.path.join(os.path.dirname(HERE), 'include', 'mansy_hip.h'))
     jobs = []
     objs = []
-    for s in sources():
+    for s in sources(lab):
         src = os.path.join(CSRC, s)
-        obj = os.path.join(OBJ, s[:-4] + '.o')
+        obj = os.path.join(OBJ, os.path.basename(s)[:-4] + '.o')
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
             jobs.append([HIPCC] + FLAGS + ['-c', src, '-o', obj])

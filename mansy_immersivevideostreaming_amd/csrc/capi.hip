@@ -26,7 +26,7 @@ extern "C" {
 
 
 const char* mansy_last_error(void) { return g_err; }
-int mansy_abi_version(void) { return 8; }   // == _lib.py ABI_VERSION
+int mansy_abi_version(void) { return 9; }   // == _lib.py ABI_VERSION
 
 int mansy_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb, int b_kmajor, float* C, int ldc, int M, int N,
                    int K, const mansy_gemm_epilogue* ep, int force_tile, int force_splitk, void* stream) {

@@ -319,9 +319,10 @@ __device__ __forceinline__ void adamw_elem(float& p, float g, float& m, float& v
 //  LDS -- 16 KB per workgroup and a 29 us launch for 270 k elements, found in profiles/r02c_ppo_kernel_stats.csv)
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
-                                                    float wd, float bc1, float sqrt_bc2, int decoupled) {
+                                                    float wd, float bc1, float sqrt_bc2, int decoupled, const float* __restrict__ bias) {
   const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i4 >= n) return;
+  if (bias) { bc1 = bias[0]; sqrt_bc2 = bias[1]; }      // graph-replayed steps: the bias corrections of THIS replay's step count, written by the host before the replay
   const float step_size = lr / bc1;
   if (i4 + 4 <= n) {
     float4 pp = *reinterpret_cast<const float4*>(p + i4);
@@ -669,14 +670,14 @@ int mansy_launch_mtio_loss(const float* pred, const float* gt, long long n, floa
 }
 
 int mansy_launch_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
-                       float wd, int step, int decoupled, hipStream_t st) {
+                       float wd, int step, int decoupled, hipStream_t st, const float* bias_dev) {
   MANSY_REQUIRE(p && g && m && v, "adamw: null pointer");
   MANSY_REQUIRE(step >= 1, "adamw: step must be >= 1");
   if (n <= 0) return MANSY_OK;
   const double bc1 = 1.0 - pow((double)b1, (double)step);
   const double bc2 = 1.0 - pow((double)b2, (double)step);
   MANSY_LAUNCH(adamw_kernel, g1((n + 3) / 4), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, wd, (float)bc1,
-                     (float)sqrt(bc2), decoupled);
+                     (float)sqrt(bc2), decoupled, bias_dev);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }

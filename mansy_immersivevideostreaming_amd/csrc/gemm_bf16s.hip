@@ -548,10 +548,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16p_kernel(GemmParams p) {
 // element, issued in the shadow of the MFMAs).  The conversion is done once per wave that needs the fragment (2 x redundant over the
 // 2 x 2 wave grid) -- the price of removing the ds_write path (~80 B/clk/CU), which is what bounded the in-loop split.  One barrier
 // per K-tile; the DMA of tile t+1 is issued right after the barrier that retires tile t-1 and has the whole MFMA phase to land.
-// LAB (timing-only diagnostics behind mansy_gemm_bf16_variant 2 / 3, results wrong): 1 = staging only (DMA + barriers, no fragment reads,
-// no MFMAs): the LDS-fill floor of a shape; 2 = math only (fragment reads + split + MFMAs on whatever the LDS holds, no DMA): its
-// MFMA + LDS-read floor.
-template <int BM, int BN, int LAB = 0>
+template <int BM, int BN>
 __global__ __launch_bounds__(NT, 2) void gemm_bf16f_kernel(GemmParams p) {
   constexpr int TM = BM / 64, TN = BN / 64, PA = BM / 32, PB = BN / 16, PBW = (PB + 3) / 4;
   constexpr int A_BYTES = BM * BK * 4, B_PLANE = BN * 32, B_PLANE_BYTES = B_PLANE * 2;      // B_PLANE in bf16 elements
@@ -626,18 +623,18 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16f_kernel(GemmParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  if (nk > 0 && LAB != 2) dma(0, ca, cb);
+  if (nk > 0) dma(0, ca, cb);
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of tile kt have landed ...
     __builtin_amdgcn_s_barrier();                        // ... and everyone's; everyone is done reading tile kt-1
     asm volatile("" ::: "memory");
     ca += BK; cb += BK;
-    if (kt + 1 < nk && LAB != 2) dma(cur ^ 1, ca, cb);
+    if (kt + 1 < nk) dma(cur ^ 1, ca, cb);
     const float* a_l = smem + cur * (STAGE_BYTES / 4);
     const __bf16* b_l = reinterpret_cast<const __bf16*>(a_l) + A_BYTES / 2;
 #pragma unroll
-    for (int s = 0; s < (LAB == 1 ? 0 : 2); ++s) {
+    for (int s = 0; s < 2; ++s) {
       bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
@@ -756,24 +753,11 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16h_kernel(GemmParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-#ifdef MANSY_LAB
-  // (lab build only) phase stamps of ONE workgroup (p.lab_stamps[63] names it), lane 0 of each wave: as gemm_f32_dma_kernel's (tools/dma_phase_lab.py)
-  const bool lab_on = p.lab_stamps && (int)(blockIdx.y * gridDim.x + blockIdx.x) == (int)p.lab_stamps[63] && lane == 0;
-  long long lab_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (lab_on) lab_t[0] = wall_clock64();
-#endif
 #pragma unroll
   for (int d = 0; d < D; ++d)
     if (d < nk) dma(d, d);
-#ifdef MANSY_LAB
-  if (lab_on) lab_t[1] = wall_clock64();
-#endif
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
-#ifdef MANSY_LAB
-    long long lab_w0 = 0;
-    if (lab_on) lab_w0 = wall_clock64();
-#endif
     // tiles still wanted in flight after tile kt has landed: min(D - 1, nk - 1 - kt) of them, PPT pieces each (the wait count is an immediate)
     const int ahead = nk - 1 - kt;
     if (D >= 3 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPT) : "memory");
@@ -781,9 +765,6 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16h_kernel(GemmParams p) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-#ifdef MANSY_LAB
-    if (lab_on) { const long long n_ = wall_clock64(); lab_t[5] += n_ - lab_w0; if (kt == 0) lab_t[2] = n_; }
-#endif
     if (kt + D < nk) dma(cur == 0 ? NS - 1 : cur - 1, kt + D);       // into the stage tile kt - 1 occupied
     const float* a_l = smem + cur * (STAGE_BYTES / 4);
     const __bf16* b_l = reinterpret_cast<const __bf16*>(a_l) + A_BYTES / 2;
@@ -830,18 +811,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16h_kernel(GemmParams p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // LDS reads retired before the barrier that frees this buffer
     cur = cur == NS - 1 ? 0 : cur + 1;
   }
-#ifdef MANSY_LAB
-  if (lab_on) { lab_t[3] = wall_clock64(); lab_t[6] = nk; }
-#endif
   __syncthreads();                                        // staging LDS idle (every DMA was waited for): the epilogue reuses it
   gemm_epilogue<BM, BN, SMEM_FLOATS>(p, acc, smem, m0, n0, tid, 0, p.C);
-#ifdef MANSY_LAB
-  if (lab_on) {
-    lab_t[4] = wall_clock64();
-#pragma unroll
-    for (int i = 0; i < 8; ++i) p.lab_stamps[wave * 8 + i] = (unsigned long long)lab_t[i];
-  }
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -989,9 +960,6 @@ __global__ __launch_bounds__(512) void gemm_bf16g_kernel(GemmParams p) {
 // Tried and dropped (same files): an L2 prefetch stream of the A lines 4 / 6 K-tiles ahead (one LDS-DMA dword per consumer wave and
 // K-tile into a scratch pad): 3-8 % SLOWER -- the staging-only form of this loop already fills at 70 GB/s per CU at K = 512, the fill is
 // not the bound; starting half of the first round's workgroups half a tile late (to de-phase the epilogue store bursts): no effect.
-// LAB (timing-only diagnostics, results wrong; variants 11 / 12): 1 = staging only (the loaders run, the consumers only meet the barriers): the LDS-fill
-// floor of the ring; 2 = math only (the consumers run on whatever the LDS holds, the loaders only meet the barriers): the fragment-read + MFMA floor.
-template <int LAB = 0>
 __global__ __launch_bounds__(768) void gemm_bf16k_kernel(GemmParams p) {
   constexpr int BM = 256, BN = 128, NCW = 8, NS = 3;
   constexpr int A_BYTES = BM * BK * 4, B_PLANE = BN * 32, B_PLANE_BYTES = B_PLANE * 2;
@@ -1051,15 +1019,15 @@ __global__ __launch_bounds__(768) void gemm_bf16k_kernel(GemmParams p) {
         for (int i = 0; i < 2; ++i)
           glds16(vob[i], b_corner + (long long)pl * p.ep.b_plane_stride, base + (unsigned)(A_BYTES + pl * B_PLANE_BYTES) + (unsigned)i * 4096u);
     };
-    if (nk > 0 && LAB != 2) dma(0, 0);
-    if (nk > 1 && LAB != 2) dma(1, 1);
+    if (nk > 0) dma(0, 0);
+    if (nk > 1) dma(1, 1);
     int st = 2;                                                     // stage of tile t + 2
     for (int kt = 0; kt < nk; ++kt) {
       if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");    // this wave's pieces of tile kt have landed; tile kt+1's 12 stay in flight
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                                 // barrier kt: tile kt readable; tile kt-1 no longer read
       asm volatile("" ::: "memory");
-      if (kt + 2 < nk && LAB != 2) dma(st, kt + 2);
+      if (kt + 2 < nk) dma(st, kt + 2);
       st = st == 2 ? 0 : st + 1;
     }
   } else {
@@ -1081,7 +1049,7 @@ __global__ __launch_bounds__(768) void gemm_bf16k_kernel(GemmParams p) {
       const float* a_l = smem + cur * (STAGE_BYTES / 4);
       const __bf16* b_l = reinterpret_cast<const __bf16*>(a_l) + A_BYTES / 2;
 #pragma unroll
-      for (int s = 0; s < (LAB == 1 ? 0 : 2); ++s) {
+      for (int s = 0; s < 2; ++s) {
         bf16x8 ah, al, bh[4], bl[4];
         const float4 v0 = *reinterpret_cast<const float4*>(a_l + fa[s][0]);
         const float4 v1 = *reinterpret_cast<const float4*>(a_l + fa[s][1]);
@@ -1203,8 +1171,9 @@ int mansy_gemm_bf16s_dispatch(const GemmParams& p, int tile, int prec, int a_kma
 // Loop variant of the bf16x3 products with pre-split weights (GemmEpilogue::variant low byte, MANSY_VARIANT_BF16(v); default 1):
 //   1: A by LDS-DMA, split at fragment read (256 x 128 tiles: gemm_bf16k_kernel's twelve waves with fixed roles; 128 x 128: gemm_bf16f; 64 x 64 tiles:
 //      gemm_bf16h_kernel's three-stage ring); 8: as 1 with the round-3 eight-wave loop (gemm_bf16g) on the 256 x 128 tiles; 4: as 1 without any 256 x 128
-//      loop; 6: as 1 with a four-stage ring; 7: as 1 with the round-2 loop on the 64 x 64 tiles; 0: the round-2 loop; 2 / 3 (128 x 128, 64 x 64) and
-//      11 / 12 (256 x 128): timing-only staging / math forms (results wrong).  The real loops are bit-identical (same products, same order).
+//      loop; 7: as 1 with the round-2 loop on the 64 x 64 tiles; 0: the round-2 loop.  Every selectable loop computes the same products in the same
+//      order (bit-identical results); the timing-only staging / math forms of rounds 3-4 (variants 2 / 3 / 11 / 12, results wrong) and the four-stage
+//      ring (6) are gone from the sources (round 6: nothing in the release library may produce a wrong product).
 
 int mansy_gemm_bf16p_dispatch(const GemmParams& p, int tile, int prec, hipStream_t st) {
   const int bvar = mansy_var_bf16(p.ep.variant);
@@ -1221,15 +1190,6 @@ int mansy_gemm_bf16p_dispatch(const GemmParams& p, int tile, int prec, hipStream
   if (prec == 3 && bvar >= 1 && (reinterpret_cast<uintptr_t>(p.A) & 15) == 0 && p.lda % 4 == 0) {
     if (tile == 256 && p.K < 3 * BK) tile = 128;
     dim3 block(NT);
-    if (bvar == 2 || bvar == 3) {      // timing-only diagnostics (results wrong): the LDS-fill floor / the math floor of the shape
-      const int lab = bvar - 1;
-      if (tile == 128) { dim3 grid(mansy_ceil_div(p.N, 128), mansy_ceil_div(p.M, 128), 1);
-        if (lab == 1) MANSY_GEMM_LAUNCH((gemm_bf16f_kernel<128, 128, 1>), grid, block, st, p); else MANSY_GEMM_LAUNCH((gemm_bf16f_kernel<128, 128, 2>), grid, block, st, p); }
-      else { dim3 grid(mansy_ceil_div(p.N, 64), mansy_ceil_div(p.M, 64), 1);
-        if (lab == 1) MANSY_GEMM_LAUNCH((gemm_bf16f_kernel<64, 64, 1>), grid, block, st, p); else MANSY_GEMM_LAUNCH((gemm_bf16f_kernel<64, 64, 2>), grid, block, st, p); }
-      MANSY_LAUNCH_CHECK();
-      return MANSY_OK;
-    }
     // measured per shape (tools/gemm_bench.py --planes, profiles/r03_gemm_bench_bf16f.txt): 128 x 128 tiles 3-9 % faster than the
     // round-2 loop on the [40 960-row] products; the two-stage 64 x 64 instance ([4 096-row] decoder products) 6 % slower IN ISOLATION
     // (one K-tile of a 64 x 64 tile is 6 MFMAs per wave: the second, redundant fragment conversion is no longer hidden) -- but inside
@@ -1237,12 +1197,9 @@ int mansy_gemm_bf16p_dispatch(const GemmParams& p, int tile, int prec, hipStream
     // covers; the 128 x 64 instance loses to both at every shape and is reachable only as force_tile 96
     const bool big = tile == 256 || (tile == 128 && (bvar == 1 || bvar >= 8) && (long long)mansy_ceil_div(p.M, 256) * mansy_ceil_div(p.N, 128) >= 256);
     if (big && bvar != 8 && p.c_vec_ok && !p.ep.accumulate && p.ep.split_slab == 0) {
-      // round 4: twelve waves with fixed roles (8 consumers + 4 loaders); variant 8 = the eight-wave loop below (A/B runs), 11 / 12 = this
-      // loop's staging-only / math-only timing forms (results wrong)
+      // round 4: twelve waves with fixed roles (8 consumers + 4 loaders); variant 8 = the eight-wave loop below (A/B runs)
       dim3 grid(mansy_ceil_div(p.N, 128), mansy_ceil_div(p.M, 256), 1);
-      if (bvar == 11) MANSY_GEMM_LAUNCH((gemm_bf16k_kernel<1>), grid, dim3(768), st, p);
-      else if (bvar == 12) MANSY_GEMM_LAUNCH((gemm_bf16k_kernel<2>), grid, dim3(768), st, p);
-      else MANSY_GEMM_LAUNCH((gemm_bf16k_kernel<0>), grid, dim3(768), st, p);
+      MANSY_GEMM_LAUNCH(gemm_bf16k_kernel, grid, dim3(768), st, p);
       MANSY_LAUNCH_CHECK(); return MANSY_OK;
     }
     if (big) {
@@ -1257,8 +1214,7 @@ int mansy_gemm_bf16p_dispatch(const GemmParams& p, int tile, int prec, hipStream
   if (tile == 64 && bvar != 0 && bvar != 7 && (reinterpret_cast<uintptr_t>(p.A) & 15) == 0 && p.lda % 4 == 0) {
     dim3 grid(mansy_ceil_div(p.N, 64), mansy_ceil_div(p.M, 64), 1), block(NT);
     if (prec == 3) {
-      if (bvar == 6) MANSY_GEMM_LAUNCH((gemm_bf16h_kernel<64, 64, 4, 2>), grid, block, st, p);
-      else MANSY_GEMM_LAUNCH((gemm_bf16h_kernel<64, 64, 3, 2>), grid, block, st, p);
+      MANSY_GEMM_LAUNCH((gemm_bf16h_kernel<64, 64, 3, 2>), grid, block, st, p);
     } else MANSY_GEMM_LAUNCH((gemm_bf16h_kernel<64, 64, 3, 3>), grid, block, st, p);
     MANSY_LAUNCH_CHECK();
     return MANSY_OK;

@@ -315,35 +315,17 @@ __global__ __launch_bounds__(NT) void gemm_f32_dma_kernel(GemmParams p) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   float rowsum = 0.f;
-#ifdef MANSY_LAB
-  // (lab build only) phase stamps of ONE workgroup (p.lab_stamps[63] names it), lane 0 of each wave: 0 start, 1 first DMA out, 2 tile 0 ready, 3 K loop done,
-  // 4 epilogue done, 5 = summed time between the top of a K-tile and its barrier (DMA latency still exposed + waiting for the other waves), 6 = K-tiles
-  // (tools/dma_phase_lab.py, profiles/r05_dma_phase_lab.txt)
-  const bool lab_on = p.lab_stamps && ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) == (int)p.lab_stamps[63] && lane == 0;
-  long long lab_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (lab_on) lab_t[0] = wall_clock64();
-#endif
   if (nk > 0) {
 #pragma unroll
     for (int i = 0; i < PA; ++i) glds16(voa[i], sa, lds_wave + i * 4096u);
 #pragma unroll
     for (int i = 0; i < PB; ++i) glds16(vob[i], sb, lds_wave + A_FLOATS * 4u + i * 4096u);
   }
-#ifdef MANSY_LAB
-  if (lab_on) lab_t[1] = wall_clock64();
-#endif
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-#ifdef MANSY_LAB
-    long long lab_w0 = 0;
-    if (lab_on) lab_w0 = wall_clock64();
-#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of tile kt have landed ...
     __builtin_amdgcn_s_barrier();                        // ... and everyone's; everyone is done reading tile kt-1
     asm volatile("" ::: "memory");
-#ifdef MANSY_LAB
-    if (lab_on) { const long long n_ = wall_clock64(); lab_t[5] += n_ - lab_w0; if (kt == 0) lab_t[2] = n_; }
-#endif
     sa += step_a; sb += step_b;                          // corners of tile kt+1
     const unsigned lds_next = lds_wave + (unsigned)(cur ^ 1) * (STAGE * 4u);
     if (kt + 1 < nk) {
@@ -376,9 +358,6 @@ __global__ __launch_bounds__(NT) void gemm_f32_dma_kernel(GemmParams p) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // LDS reads retired before the barrier that frees this buffer
   }
-#ifdef MANSY_LAB
-  if (lab_on) { lab_t[3] = wall_clock64(); lab_t[6] = nk; }
-#endif
   __syncthreads();                                        // staging LDS idle: the epilogue reuses it
 
   if (AK && rowsum_dst && tile_x - rs_first < BK && tid < BM && m0 + tid < p.M) atomicAdd(rowsum_dst + m0 + tid, rowsum);
@@ -393,23 +372,9 @@ __global__ __launch_bounds__(NT) void gemm_f32_dma_kernel(GemmParams p) {
           smem[(wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * CLD + wn * (BN / 2) + j * 32 + r] = acc[i][j][e];
     __syncthreads();
     gemm_epilogue_rows<BM, BN, NT>(p, smem, m0, n0, tid, Cp);
-#ifdef MANSY_LAB
-    if (lab_on) {
-      lab_t[4] = wall_clock64();
-#pragma unroll
-      for (int i = 0; i < 8; ++i) p.lab_stamps[wave * 8 + i] = (unsigned long long)lab_t[i];
-    }
-#endif
     return;
   }
   gemm_epilogue<BM, BN, SMEM_FLOATS>(p, acc, smem, m0, n0, tid, split, Cp);
-#ifdef MANSY_LAB
-  if (lab_on) {
-    lab_t[4] = wall_clock64();
-#pragma unroll
-    for (int i = 0; i < 8; ++i) p.lab_stamps[wave * 8 + i] = (unsigned long long)lab_t[i];
-  }
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -479,12 +444,6 @@ namespace mansy_gemm { hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr; }
 // (ABI 8: no process-wide precision, no kernel-selection knobs.  The precision travels with the call; the loop a product runs on follows from
 // its shape and from GemmEpilogue::variant -- mansy_kernels.h, MANSY_VARIANT_* in include/mansy_hip.h.  The column-group width of the XCD-aware
 // tile order defaults to 12: profiles/r04_gemm_colgroup.txt, [40 960, 1 536, 512] fetch 578 -> 211 MB per launch at the same duration.)
-#ifdef MANSY_LAB
-int g_mansy_lab_variant = 0;
-extern "C" int mansy_lab_set_variant(int v) { const int old = g_mansy_lab_variant; if (v >= 0) g_mansy_lab_variant = v; return old; }
-static unsigned long long* g_mansy_lab_stamps = nullptr;     // device buffer [64] for the phase stamps of the wave-split-K loop (gemm_wsk.h WSK_STAMP)
-extern "C" void mansy_lab_set_stamps(void* dev) { g_mansy_lab_stamps = (unsigned long long*)dev; }
-#endif
 
 extern "C" int mansy_prof_gemm_enable(int on) {
   g_prof.on = on != 0;
@@ -627,9 +586,6 @@ int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B,
   GemmParams p;
   p.A = A; p.B = B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.ep = ep;
   p.col_group = (ep.tile_nrange || ep.tile_list || ep.tile_krange) ? 0 : mansy_var_col_group(ep.variant);
-#ifdef MANSY_LAB
-  p.lab_stamps = g_mansy_lab_stamps;
-#endif
   p.c_rmw_ok = (reinterpret_cast<uintptr_t>(C) & 15) == 0 && (!ep.pair_C || (reinterpret_cast<uintptr_t>(ep.pair_C) & 15) == 0) && ldc % 4 == 0 && N % 4 == 0;
   p.vec_ok = ((lda % 4) == 0) && ((ldb % 4) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
              ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (K % 4 == 0) && (!a_kmajor || M % 4 == 0) &&

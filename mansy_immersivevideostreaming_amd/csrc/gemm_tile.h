@@ -37,9 +37,6 @@ struct GemmParams {
   // XCD's L2 holds ONE group's slice of B next to the A panels it streams (wide-N products: B alone is 3 MB of the 4 MB L2 at N = 1536)
   int col_group = 0;
   int c_rmw_ok = 0;  // C (and C2) 16-byte aligned, ldc % 4 == 0, N % 4 == 0: an accumulating product whose blocks have one owner may read-add-write float4
-#ifdef MANSY_LAB
-  unsigned long long* lab_stamps = nullptr;     // (lab build only) [4 waves][16] wall-clock stamps of workgroup 0 of a wave-split-K launch (tools/wsk_phase_lab.py)
-#endif
 };
 
 // Row-major pass of the fused epilogue: the C tile sits in LDS as [BM][BN + 4] floats (`smem`, written by the caller, who has also

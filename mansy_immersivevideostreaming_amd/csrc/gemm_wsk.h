@@ -43,16 +43,6 @@ __device__ __forceinline__ void read_frag_dma(const float* __restrict__ lds, int
 // and the preamble 0.3 us longer; requesting the row epilogue's residual / mask / bias float4 under the K loop and handing the summed block over in registers
 // changed nothing inside the launch and cost 0.8 us per launch in the B = 512 step (rocprofv3 averages): all removed again.
 constexpr int WSK_T = 32, WSK_WAVE_FLOATS = 2 * WSK_T * BK, WSK_SMEM_FLOATS = 4 * WSK_WAVE_FLOATS;
-#ifdef MANSY_LAB
-// (lab build only) phase stamps of workgroup 0: lane 0 of every wave notes the 100 MHz wall clock at the phase boundaries in registers and writes them out at the end
-#define WSK_STAMP(i) do { if (p.lab_stamps && orig == 0) lab_t[(i)] = wall_clock64(); } while (0)
-// stamp base + 3 x min(it, 3) (constant indices only: the stamps stay in registers)
-#define WSK_STAMP_IT(base, it) do { if (p.lab_stamps && orig == 0) { const long long c_ = wall_clock64(); const int j_ = (it); \
-  if (j_ == 0) lab_t[(base)] = c_; else if (j_ == 1) lab_t[(base) + 3] = c_; else if (j_ == 2) lab_t[(base) + 6] = c_; else lab_t[(base) + 9] = c_; } } while (0)
-#else
-#define WSK_STAMP(i) do {} while (0)
-#define WSK_STAMP_IT(base, it) do {} while (0)
-#endif
 // The loop as a device function of (problem, workgroup index `orig` inside the problem's gx x gy x gz grid, the workgroup's LDS): one problem per
 // launch (gemm_f32_wsk_kernel) or two independent problems side by side in one launch (gemm_f32_wsk_dual_kernel).
 // A_SC1: the A operand was written by OTHER workgroups of the SAME launch (the persistent rollout of ppo_engine.hip): its LDS-DMA loads carry sc1
@@ -62,9 +52,6 @@ template <bool AK, bool BKM, bool A_SC1 = false, bool DIRECT = false>
 __device__ __forceinline__ void gemm_f32_wsk_body(const GemmParams& p, int orig, int gx, int gy, int gz, float* smem) {
   constexpr int T = WSK_T, TILE_FLOATS = T * BK, WAVE_FLOATS = WSK_WAVE_FLOATS, CLD = T + 4;       // ONE stage per wave: 8 KB (32 KB per workgroup, five per CU)
   static_assert(T * CLD + 64 <= WAVE_FLOATS, "a partial block and its row sums must fit a wave's stage");
-#ifdef MANSY_LAB
-  long long lab_t[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#endif
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -152,14 +139,10 @@ __device__ __forceinline__ void gemm_f32_wsk_body(const GemmParams& p, int orig,
   // workgroups x 4 waves on the same 32 addresses at the end of a 10 us launch.)
   const bool do_rowsum = AK && rowsum_dst != nullptr && tile_x == rs_first;
   float rowsum = 0.f;
-  WSK_STAMP(0);
   int kt = wave;
   if (kt < nk) dma(kt);
-  WSK_STAMP(1);
-  int lab_it = 0;
   for (; kt < nk; kt += 4) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's tile has landed (it staged it itself: no barrier)
-    WSK_STAMP_IT(2, lab_it);
     float af[2][8], bf[2][8];
 #pragma unroll
     for (int chunk = 0; chunk < 2; ++chunk) {
@@ -167,7 +150,6 @@ __device__ __forceinline__ void gemm_f32_wsk_body(const GemmParams& p, int orig,
       read_frag_dma<T, BKM>(b_l, 0, r, h, chunk, bf[chunk]);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the whole tile is in registers: the stage may be staged again ...
-    WSK_STAMP_IT(3, lab_it);
     if (kt + 4 < nk) dma(kt + 4);                        // ... and the wave's next tile flies under this tile's 16 MFMAs
     if (do_rowsum) {                                     // lane (r, h): row r of the block, k-rows 16 h .. 16 h + 15 of the tile (= this lane's A fragments)
 #pragma unroll
@@ -179,10 +161,7 @@ __device__ __forceinline__ void gemm_f32_wsk_body(const GemmParams& p, int orig,
     for (int chunk = 0; chunk < 2; ++chunk)
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[chunk][kk], bf[chunk][kk], acc, 0, 0, 0);
-    WSK_STAMP_IT(4, lab_it);
-    ++lab_it;
   }
-  WSK_STAMP(14);
   // partial block of this wave -> its own (now idle) stage, [32][36]; its row sums behind it
 #pragma unroll
   for (int e = 0; e < 16; ++e) mine[((e & 3) + 8 * (e >> 2) + 4 * h) * CLD + r] = acc[e];
@@ -222,13 +201,6 @@ __device__ __forceinline__ void gemm_f32_wsk_body(const GemmParams& p, int orig,
   *reinterpret_cast<float4*>(smem + off) = v;             // read back by the same thread below
   __syncthreads();
   gemm_epilogue_rows<T, T, NT>(p, smem, m0, n0, tid, Cz);
-#ifdef MANSY_LAB
-  WSK_STAMP(15);
-  if (p.lab_stamps && orig == 0 && lane == 0) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) p.lab_stamps[wave * 16 + i] = (unsigned long long)lab_t[i];
-  }
-#endif
 }
 
 

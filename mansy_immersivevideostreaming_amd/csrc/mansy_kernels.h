@@ -222,7 +222,7 @@ int mansy_launch_predictor_bwd(const float* dy_a, long long sa, const float* dy_
 int mansy_launch_mtio_loss(const float* pred, const float* gt, long long n, float inv_2bt, double* loss_accum,
                            float* loss_out, float* dpred, hipStream_t st);
 int mansy_launch_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2,
-                       float eps, float wd, int step, int decoupled, hipStream_t st);
+                       float eps, float wd, int step, int decoupled, hipStream_t st, const float* bias_dev = nullptr);      // bias_dev: device [1 - b1^t, sqrt(1 - b2^t)] read by the kernel instead of the host's (hipGraph replays)
 // im2col for the circular k=3 conv: col[b*S+s, ci*3+t] = x[b, (s+t-1) mod S, ci]
 int mansy_launch_im2col3(const float* x, float* col, int B, int S, int C, hipStream_t st);
 // dx[b,s,ci] = sum_t dcol[b, (s-t+1) mod S, ci*3+t]

@@ -589,7 +589,7 @@ __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs args, const f
 //      is phase A's operand of the next step.
 // Operands written by another workgroup of the launch are read past this CU's L1 (sc1 LDS-DMA / sc1 loads; the L2 is the team's coherence point: plain
 // stores, drained before the barrier); weights, tables and uniforms do not change inside the launch.  Results are bit-identical to the three-launch path.
-struct RolloutCtl { unsigned claim[8]; unsigned started; unsigned err; unsigned pad[6]; unsigned bar[8][16]; unsigned long long prof[8]; };      // prof: lab builds only (phase clocks of one workgroup)
+struct RolloutCtl { unsigned claim[8]; unsigned started; unsigned err; unsigned pad[6]; unsigned bar[8][16]; unsigned long long reserved[8]; };
 static_assert(sizeof(RolloutCtl) <= MANSY_ROLLOUT_CTL_BYTES, "rollout control block");
 struct RolloutArgs {
   GemmParams p1, p2; int g1x, g2x, g2z;
@@ -644,12 +644,6 @@ __global__ __launch_bounds__(256) void rollout_team_kernel(RolloutArgs a, Rollou
     __syncthreads();
     return sh[3] != 0u;
   };
-#ifdef MANSY_LAB
-  long long tp_ = wall_clock64();
-#define PROF_(k) do { if (tid == 0 && m == 0 && ti == 0) { const long long n_ = wall_clock64(); ctl->prof[k] += (unsigned long long)(n_ - tp_); tp_ = n_; } } while (0)
-#else
-#define PROF_(k) do { } while (0)
-#endif
   const int chunks = (a.n_env + 31) / 32;
   bool ok = true;
   for (int chunk = ti; chunk < chunks && ok; chunk += nteams) {
@@ -667,10 +661,8 @@ __global__ __launch_bounds__(256) void rollout_team_kernel(RolloutArgs a, Rollou
           mansy_gemm::gemm_f32_wsk_body<false, false, true, true>(p, blk, a.g1x, 1, 1, smem);
         }
       }
-      PROF_(0);
       barrier_arrive();
       ok = barrier_wait();
-      PROF_(1);
       if (!ok) break;
       // ---- B: the fc product's slabs
       {
@@ -683,7 +675,6 @@ __global__ __launch_bounds__(256) void rollout_team_kernel(RolloutArgs a, Rollou
           mansy_gemm::gemm_f32_wsk_body<false, false, true, true>(p, blk, a.g2x, 1, a.g2z, smem);
         }
       }
-      PROF_(2);
       barrier_arrive();
       // ---- C: one wave per row: slab sums, output layer, sampling, environment step.  Everything that does not depend on phase B -- the output
       // layer's weights, the uniform, the environment's record and the table rows it names -- is requested HERE, between arrival and wait.
@@ -703,7 +694,6 @@ __global__ __launch_bounds__(256) void rollout_team_kernel(RolloutArgs a, Rollou
         eq_pre = envdev::env_step_requests(a.Tb, es_pre, lane);
       }
       ok = barrier_wait();
-      PROF_(3);
       if (!ok) break;
       for (int j = wave; ; j += 4) {
         const int rr = m + s * j;
@@ -752,10 +742,8 @@ __global__ __launch_bounds__(256) void rollout_team_kernel(RolloutArgs a, Rollou
         envdev::env_step_finish(a.Tb, a.st, erow, lane, act, es, eq, a.obs_next + (long long)t * a.obsn_ts, obs_cur, a.rew + (size_t)t * a.n_env,
                                 a.done + (size_t)t * a.n_env, a.qoe_parts, a.elog);
       }
-      PROF_(4);
       barrier_arrive();
       ok = barrier_wait();
-      PROF_(5);
     }
   }
   if (!ok && tid == 0) { ctl->err = 1u; __hip_atomic_store(a.err_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
@@ -1043,9 +1031,10 @@ __global__ __launch_bounds__(256) void clip_scale_kernel(float* __restrict__ g, 
 __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                        float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
                                                        float wd, float bc1, float sqrt_bc2, const double* __restrict__ parts,
-                                                       float max_norm) {
+                                                       float max_norm, const float* __restrict__ bias) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  if (bias) { bc1 = bias[0]; sqrt_bc2 = bias[1]; }
   const float coef = clip_coef(parts, max_norm);
   const float pp = p[i];
   const float grad = g[i] * coef + wd * pp;
@@ -1068,7 +1057,8 @@ struct TailNext { const float* g_src; const int* g_idx; float* g_dst; int g_rows
 __global__ __launch_bounds__(256) void step_tail_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ gz, float* __restrict__ m, float* __restrict__ v,
                                                        long long n, float lr, float b1, float b2, float eps, float wd, float bc1, float sqrt_bc2,
                                                        const double* __restrict__ parts, float max_norm, TailTab tab, float* __restrict__ Wbd,
-                                                       float* __restrict__ bbd, float* __restrict__ Wfc2, TailNext nx, int adam_blocks) {
+                                                       float* __restrict__ bbd, float* __restrict__ Wfc2, TailNext nx, int adam_blocks, const float* __restrict__ bias) {
+  if (bias) { bc1 = bias[0]; sqrt_bc2 = bias[1]; }      // a graph-replayed step: this replay's bias corrections from device memory (include/mansy_hip.h, adam_bias)
   if ((int)blockIdx.x >= adam_blocks) {
     const int rb = blockIdx.x - adam_blocks;
     if (rb == 0) {
@@ -1185,7 +1175,7 @@ size_t ppo_layout(int maxB, char* base, PWork& W) {
 
 #define RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
-// the launches that make up most of a cycle run compile-time instances of head_out_kernel (MODE 1 / 2 / 3); a -DMANSY_LAB build can send
+// the launches that make up most of a cycle run compile-time instances of head_out_kernel (MODE 1 / 2 / 3); a lab build (csrc/lab/) can send
 // them all to the generic instance (variant bit 0x1000) for A/B timing -- a release build reads no switch
 static bool head_out_modes() { return (mansy_variant_of(0) & 0x1000) == 0; }
 
@@ -1404,7 +1394,8 @@ struct PEng {
   // g_zero: the buffer the NEXT step accumulates its gradients into (zero-filled here); null = flat_g itself.  The data-parallel peer form hands over
   // the other exchange slot: this step's gradients were produced in one slot and averaged into flat_g, the next step's go into the other slot.
   int step_tail(const float* const* params, float* flat_p, float* flat_g, float* m, float* v, long long n, float max_norm, float lr, float wd, int step,
-                double* parts_cur, double* parts_next, const float* obs_all, const int* next_idx, int next_mb, const float* adv_all, float* g_zero = nullptr) {
+                double* parts_cur, double* parts_next, const float* obs_all, const int* next_idx, int next_mb, const float* adv_all, float* g_zero = nullptr,
+                const float* bias_dev = nullptr) {
     TailTab tab;
     static const std::vector<ParamInfo> t = net_table(0);       // (built once: 28 entries with std::string names -- this runs in every minibatch step)
     MANSY_REQUIRE(t.size() == 28, "step_tail: parameter table changed");
@@ -1423,7 +1414,7 @@ struct PEng {
     const double bc1 = 1.0 - pow(0.9, (double)step), bc2 = 1.0 - pow(0.999, (double)step);
     MANSY_REQUIRE(!g_zero || (reinterpret_cast<uintptr_t>(g_zero) & 15) == 0, "step_tail: the next gradient buffer must be 16-byte aligned");
     MANSY_LAUNCH(step_tail_kernel, dim3(adam_blocks + rider_blocks), dim3(256), 0, st, flat_p, (const float*)flat_g, g_zero ? g_zero : flat_g, m, v, n, lr, 0.9f, 0.999f, 1e-8f, wd,
-                       (float)bc1, (float)sqrt(bc2), parts_cur, max_norm, tab, W.Wbd, W.bbd, W.Wfc2, nx, adam_blocks);
+                       (float)bc1, (float)sqrt(bc2), parts_cur, max_norm, tab, W.Wbd, W.bbd, W.Wfc2, nx, adam_blocks, bias_dev);
     MANSY_LAUNCH_CHECK();
     return MANSY_OK;
   }
@@ -1431,7 +1422,7 @@ struct PEng {
   // their first gradient later than the rest: torch keeps one step counter per parameter); tail_step <= 0 never happens
   // with gradients present, so it is rejected.  The clip coefficient is the global one for both ranges.
   int clip_and_adam(float* flat_p, float* flat_g, float* m, float* v, long long n, float max_norm, float lr, float wd, int step,
-                    long long tail_from = -1, int tail_step = 0, bool have_sumsq = false) {
+                    long long tail_from = -1, int tail_step = 0, bool have_sumsq = false, const float* bias_dev = nullptr) {
     if (max_norm > 0.f) {
       if (!have_sumsq) MANSY_LAUNCH(sumsq_kernel, dim3(NORM_PARTS), dim3(256), 0, st, flat_g, n, W.acc);
       if (step <= 0) MANSY_LAUNCH(clip_scale_kernel, dim3(256), dim3(256), 0, st, flat_g, n, W.acc, max_norm);   // parity tests: clipped gradients
@@ -1440,19 +1431,20 @@ struct PEng {
     if (step <= 0) return MANSY_OK;
     const bool lag = tail_from >= 0 && tail_from < n && tail_step != step;
     if (lag) MANSY_REQUIRE(tail_step >= 1 && tail_from % 4 == 0, "adam: lagged tail needs tail_step >= 1 and a 16-byte aligned start");
+    MANSY_REQUIRE(!(lag && bias_dev), "adam: device-side bias corrections (adam_bias) and a lagged tail exclude each other");
     const long long n_head = lag ? tail_from : n;
     for (int part = 0; part < (lag ? 2 : 1); ++part) {
       const long long o = part ? tail_from : 0, cnt = part ? n - tail_from : n_head;
       const int stp = part ? tail_step : step;
       if (cnt <= 0) continue;
       if (max_norm <= 0.f) {                     // Adam with L2 (run_mansy.py:216,226)
-        int rc = mansy_launch_adamw(flat_p + o, flat_g + o, m + o, v + o, cnt, lr, 0.9f, 0.999f, 1e-8f, wd, stp, 0, st);
+        int rc = mansy_launch_adamw(flat_p + o, flat_g + o, m + o, v + o, cnt, lr, 0.9f, 0.999f, 1e-8f, wd, stp, 0, st, bias_dev);
         if (rc) return rc;
         continue;
       }
       const double bc1 = 1.0 - pow(0.9, (double)stp), bc2 = 1.0 - pow(0.999, (double)stp);
       MANSY_LAUNCH(clip_adam_kernel, dim3(mansy_ceil_div(cnt, 256)), dim3(256), 0, st, flat_p + o, flat_g + o, m + o, v + o, cnt, lr, 0.9f,
-                         0.999f, 1e-8f, wd, (float)bc1, (float)sqrt(bc2), W.acc, max_norm);
+                         0.999f, 1e-8f, wd, (float)bc1, (float)sqrt(bc2), W.acc, max_norm, bias_dev);
     }
     MANSY_LAUNCH_CHECK();
     return MANSY_OK;
@@ -1556,8 +1548,21 @@ int mansy_policy_rollout(const float* const* params, float* obs_slab, int n_env,
   ra.Tb = *Tb; ra.st = (envdev::EnvState*)env_state; ra.qoe_parts = qoe_parts;
   memset(&ra.elog, 0, sizeof(ra.elog));
   if (elog) ra.elog = *elog;
-  static const int wall_khz = [] { int dev = 0, khz = 0; return (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess && khz > 0) ? khz : 100000; }();
-  static const int n_cu = [] { int dev = 0, n = 0; return (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256; }();
+  // per DEVICE, not per process (a process that drives a second device or another SKU must not inherit the first one's CU count / clock rate)
+  int wall_khz = 100000, n_cu = 256;
+  {
+    static thread_local int cached_dev = -1, cached_khz = 0, cached_cu = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      if (dev != cached_dev) {
+        int khz = 0, n = 0;
+        cached_khz = (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess && khz > 0) ? khz : 100000;
+        cached_cu = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+        cached_dev = dev;
+      }
+      wall_khz = cached_khz; n_cu = cached_cu;
+    }
+  }
   ra.timeout_ticks = 2000LL * wall_khz;          // 2 s: a workgroup that never became resident (the device is shared) gives up loudly
   ra.err_host = err_host;
   MANSY_HIP_CHECK(hipMemsetAsync(ctl, 0, MANSY_ROLLOUT_CTL_BYTES, e.st));
@@ -1582,7 +1587,7 @@ int mansy_identifier_forward(const float* const* params, const float* obs, int B
 // the PPO minibatch step gathers its rows -- no separate gather launch, no shuffled copy of the buffer)
 int mansy_identifier_train_step(const float* const* params, float* const* grads, float* flat_p, float* flat_g, float* flat_m, float* flat_v,
                                 long long n_flat, const float* obs_all, const int* idx, int B, float lr, float weight_decay, int step, float* loss_out,
-                                void* workspace, int max_batch, void* xg_ctx, int precision, void* stream) {
+                                void* workspace, int max_batch, void* xg_ctx, const float* adam_bias, int precision, void* stream) {
   MANSY_REQUIRE(params && obs_all && loss_out && B >= 1 && B <= max_batch, "identifier_train_step: bad arguments");
   PEng e; RC(setup(workspace, max_batch, precision, (hipStream_t)stream, e));
   const bool train = step != 0;
@@ -1635,7 +1640,7 @@ int mansy_identifier_train_step(const float* const* params, float* const* grads,
   if (step < 0) return MANSY_OK;
   if (xg_ctx) RC(mansy_xg_reduce_avg(xg_ctx, g_avg, n_flat, nullptr, stream));
   if (comm) RC(mansy_allreduce_avg_f32(comm, g_avg, n_flat, stream));
-  return e.clip_and_adam(flat_p, g_avg, flat_m, flat_v, n_flat, 0.f, lr, weight_decay, step);
+  return e.clip_and_adam(flat_p, g_avg, flat_m, flat_v, n_flat, 0.f, lr, weight_decay, step, -1, 0, false, adam_bias);
 }
 
 int mansy_identifier_relabel(const float* const* params, const float* obs, float* rew, float* id_rew, int B, float lamb, void* workspace,
@@ -1701,7 +1706,7 @@ int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, fl
                              const float* logp_old_all, const float* v_old_all, const float* ret_all, int mb, float eps_clip, float vf_coef,
                              float ent_coef, int norm_adv, int value_clip, float dual_clip, float max_grad_norm, float lr, float weight_decay, int step,
                              long long tail_from, int tail_step, float* stats, void* workspace, int max_batch, int chain_in,
-                             const int* next_idx, int next_mb, void* xg_ctx, int precision, void* stream) {
+                             const int* next_idx, int next_mb, void* xg_ctx, const float* adam_bias, int precision, void* stream) {
   MANSY_REQUIRE(params && grads && flat_p && flat_g && flat_m && flat_v && obs_all && act_all && adv_all && logp_old_all && v_old_all && ret_all,
                 "ppo_minibatch_step: null pointer");
   // xg_ctx != NULL (round 5): the data-parallel step as ONE call -- this rank's raw gradients are produced straight in its exchange slot
@@ -1789,17 +1794,17 @@ int mansy_ppo_minibatch_step(const float* const* params, float* const* grads, fl
     MANSY_LAUNCH(sumsq_kernel, dim3(NORM_PARTS), dim3(256), 0, e.st, flat_g, n_flat, parts_cur);
     MANSY_LAUNCH_CHECK();
     return e.step_tail(params, flat_p, flat_g, flat_m, flat_v, n_flat, max_grad_norm, lr, weight_decay, step, parts_cur, parts_next, obs_all,
-                       next_idx, next_mb, adv_all);
+                       next_idx, next_mb, adv_all, nullptr, adam_bias);
   }
   if (xg_ctx) {
     RC(mansy_xg_reduce_avg(xg_ctx, g_avg, n_flat, parts_cur, stream));      // slot -> average in flat_g, sums of squares in this step's norm slots
     return e.step_tail(params, flat_p, g_avg, flat_m, flat_v, n_flat, max_grad_norm, lr, weight_decay, step, parts_cur, parts_next, obs_all,
-                       next_idx, next_mb, adv_all, slot_g[slot_cur ^ 1]);
+                       next_idx, next_mb, adv_all, slot_g[slot_cur ^ 1], adam_bias);
   }
   if (chain_ok)
     return e.step_tail(params, flat_p, flat_g, flat_m, flat_v, n_flat, max_grad_norm, lr, weight_decay, step, parts_cur, parts_next, obs_all,
-                       next_idx, next_mb, adv_all);
-  return e.clip_and_adam(flat_p, flat_g, flat_m, flat_v, n_flat, max_grad_norm, lr, weight_decay, step, tail_from, tail_step, ride);
+                       next_idx, next_mb, adv_all, nullptr, adam_bias);
+  return e.clip_and_adam(flat_p, flat_g, flat_m, flat_v, n_flat, max_grad_norm, lr, weight_decay, step, tail_from, tail_step, ride, adam_bias);
 }
 
 // Behaviour-cloning step (utils/mansy_utils.py:52-69): loss = CrossEntropy(actor logits, expert action) - ent_coef * mean
@@ -1831,23 +1836,24 @@ int mansy_bc_step(const float* const* params, float* const* grads, float* flat_p
 // gathers the next minibatch and takes its advantage statistics, so that the next mansy_ppo_minibatch_step passes chain_in = 1.
 int mansy_ppo_dp_tail(const float* const* params, float* flat_p, float* flat_g, float* flat_m, float* flat_v, long long n_flat, float max_grad_norm,
                       float lr, float weight_decay, int step, double* scratch, int have_sumsq, const float* obs_all, const float* adv_all,
-                      const int* next_idx, int next_mb, float* next_flat_g, void* workspace, int max_batch, int precision, void* stream) {
+                      const int* next_idx, int next_mb, float* next_flat_g, const float* adam_bias, void* workspace, int max_batch, int precision, void* stream) {
   MANSY_REQUIRE(params && flat_p && flat_g && flat_m && flat_v && scratch && step >= 1 && max_grad_norm > 0.f, "ppo_dp_tail: bad arguments");
   MANSY_REQUIRE(next_mb >= 0 && next_mb <= max_batch && (next_mb == 0 || (obs_all && adv_all)), "ppo_dp_tail: bad next minibatch");
   PEng e; RC(setup(workspace, max_batch, precision, (hipStream_t)stream, e));
   if (!have_sumsq) { MANSY_LAUNCH(sumsq_kernel, dim3(NORM_PARTS), dim3(256), 0, e.st, flat_g, n_flat, scratch); MANSY_LAUNCH_CHECK(); }
   return e.step_tail(params, flat_p, flat_g, flat_m, flat_v, n_flat, max_grad_norm, lr, weight_decay, step, scratch, e.W.acc + NORM_PARTS_C, obs_all,
-                     next_idx, next_mb, adv_all, next_flat_g);
+                     next_idx, next_mb, adv_all, next_flat_g, adam_bias);
 }
 
 // Global-norm clip (torch clip_grad_norm_ semantics; max_norm <= 0 disables) followed by Adam with L2 weight decay over
 // flat buffers.  Data-parallel callers run the minibatch step with step = 0 and max_grad_norm = 0 (raw gradients),
 // all-reduce flat_g over RCCL, then call this.  scratch: MANSY_CLIP_SCRATCH_DOUBLES doubles.
 int mansy_clip_grad_adam(float* flat_p, float* flat_g, float* flat_m, float* flat_v, long long n_flat, float max_grad_norm, float lr,
-                         float weight_decay, int step, long long tail_from, int tail_step, double* scratch, int have_sumsq, void* stream) {
+                         float weight_decay, int step, long long tail_from, int tail_step, double* scratch, int have_sumsq, const float* adam_bias,
+                         void* stream) {
   MANSY_REQUIRE(flat_p && flat_g && flat_m && flat_v && scratch && step >= 1, "clip_grad_adam: bad arguments");
   PEng e; e.st = (hipStream_t)stream; e.W.acc = scratch;
-  return e.clip_and_adam(flat_p, flat_g, flat_m, flat_v, n_flat, max_grad_norm, lr, weight_decay, step, tail_from, tail_step, have_sumsq != 0);
+  return e.clip_and_adam(flat_p, flat_g, flat_m, flat_v, n_flat, max_grad_norm, lr, weight_decay, step, tail_from, tail_step, have_sumsq != 0, adam_bias);
 }
 
 }  // extern "C"

@@ -37,7 +37,6 @@ struct XgCtx {
   unsigned* counter = nullptr;            // workgroups of this rank that have published (monotonic)
   int* err = nullptr;                     // sticky error word: pinned HOST memory the kernels write (system-scope store) and the host reads without a sync
   int* err_dev = nullptr;                 // its device address
-  unsigned long long launches = 0;        // copy-form launches only: the ticket counter advances XG_BLOCKS per such launch (the two forms may alternate on one context)
   double timeout_ms = 2000.0;
   int wall_khz = 100000;                  // wall_clock64 ticks at a constant rate (100 MHz on gfx9), read once at create
 };
@@ -48,10 +47,16 @@ constexpr int XG_THREADS = 256;        // (1 024-thread workgroups measured 1.4-
 // that step: mansy_xg_slot_ptrs), so this launch only publishes, waits and sums -- no 1.7 MB copy in front of the flag.
 template <bool COPY>
 __global__ __launch_bounds__(XG_THREADS) void xg_allreduce_kernel(float* __restrict__ g, long long n4, XgPeers peers, float* __restrict__ own_slot,
-                                                          unsigned* __restrict__ own_flag, long long slot_off, int rank, int world, unsigned epoch,
-                                                          float inv_world, double* __restrict__ parts, unsigned* __restrict__ counter, unsigned target,
+                                                          unsigned* __restrict__ own_flag, long long slot_off, int rank, int world, unsigned parity,
+                                                          float inv_world, double* __restrict__ parts, unsigned* __restrict__ counter,
                                                           int* __restrict__ err, long long timeout_ticks) {
   const long long gtid = (long long)blockIdx.x * XG_THREADS + threadIdx.x, gsize = (long long)gridDim.x * XG_THREADS;
+  // The epoch of THIS launch is derived on the device (round 6: a launch replayed from a captured hipGraph has frozen arguments, an epoch passed by
+  // value would be the capture's): the rank's own flag word holds the last epoch it published, E - 1, until this very launch stores E, and the
+  // slots alternate with the epoch, so E is the one of those two values whose low bit is the slot this launch works on (`parity`, frozen and
+  // right: a graph holds an even number of averages per context).  No other launch of this rank runs concurrently on the context (one stream).
+  const unsigned seen = __hip_atomic_load(own_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const unsigned epoch = seen + (((seen ^ parity) & 1u) ? 1u : 0u);
   // 1. publish this rank's gradient
   if (COPY) {
     for (long long i0 = gtid; i0 < n4; i0 += gsize * 4) {
@@ -72,7 +77,7 @@ __global__ __launch_bounds__(XG_THREADS) void xg_allreduce_kernel(float* __restr
       timed_out = 0;
       __atomic_thread_fence(__ATOMIC_RELEASE);                // system scope
       const unsigned prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-      if (prev + 1u == target) __hip_atomic_store(own_flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      if ((prev + 1u) % (unsigned)XG_BLOCKS == 0u) __hip_atomic_store(own_flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);      // the last of this launch's XG_BLOCKS tickets
     }
   } else {
     // The slot was written by EARLIER launches of this stream: the kernel boundary in front of this launch has already written their stores back
@@ -244,8 +249,7 @@ int mansy_xg_allreduce_avg(void* ctx, float* g, long long n, double* sumsq_parts
 }
 
 static int xg_launch(XgCtx* c, float* g, long long n, double* sumsq_parts, hipStream_t stream, bool copy) {
-  c->epoch += 1;
-  if (copy) c->launches += 1;
+  c->epoch += 1;          // host copy: only its low bit (which slot) is used; the epoch VALUE is derived on the device
   XgPeers peers;
   for (int p = 0; p < XG_MAX_WORLD; ++p) {
     const float* base = (const float*)c->peer_base[p < c->world ? p : c->rank];
@@ -256,12 +260,12 @@ static int xg_launch(XgCtx* c, float* g, long long n, double* sumsq_parts, hipSt
   const long long ticks = (long long)(c->timeout_ms * (double)c->wall_khz);      // (the rate is read once at create: two runtime calls per average were host time on a latency-bound cycle)
   if (copy)
     MANSY_LAUNCH(xg_allreduce_kernel<true>, dim3(XG_BLOCKS), dim3(XG_THREADS), 0, stream, g, n / 4, peers, c->own + XG_HEADER_FLOATS + slot_off,
-                       reinterpret_cast<unsigned*>(c->own), slot_off, c->rank, c->world, c->epoch, 1.0f / (float)c->world, sumsq_parts, c->counter,
-                       (unsigned)(c->launches * XG_BLOCKS), c->err_dev, ticks);
+                       reinterpret_cast<unsigned*>(c->own), slot_off, c->rank, c->world, c->epoch & 1u, 1.0f / (float)c->world, sumsq_parts, c->counter,
+                       c->err_dev, ticks);
   else
     MANSY_LAUNCH(xg_allreduce_kernel<false>, dim3(XG_BLOCKS), dim3(XG_THREADS), 0, stream, g, n / 4, peers, c->own + XG_HEADER_FLOATS + slot_off,
-                       reinterpret_cast<unsigned*>(c->own), slot_off, c->rank, c->world, c->epoch, 1.0f / (float)c->world, sumsq_parts, c->counter,
-                       (unsigned)(c->launches * XG_BLOCKS), c->err_dev, ticks);
+                       reinterpret_cast<unsigned*>(c->own), slot_off, c->rank, c->world, c->epoch & 1u, 1.0f / (float)c->world, sumsq_parts, c->counter,
+                       c->err_dev, ticks);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }

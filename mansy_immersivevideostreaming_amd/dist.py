@@ -21,6 +21,107 @@ def local_device_index(local):
     return local
 
 
+def pin_host_cores(local=None, local_world=None):
+    """Give this rank's threads a core set of their own: the cores this process may run on, split evenly by LOCAL_RANK (ranks of one node
+    then never contend for a core while enqueueing; the HIP / RCCL helper threads created later inherit the set, so it is a SET, not one
+    core).  Must run before anything touches the GPU (threads started earlier keep the old mask).  Returns the cores taken (the preflight
+    reports them); no-op -- the full mask -- with one rank per node or where sched_setaffinity does not exist."""
+    if local is None:
+        local = int(os.environ.get('LOCAL_RANK', '0'))
+    if local_world is None:
+        local_world = int(os.environ.get('LOCAL_WORLD_SIZE', os.environ.get('WORLD_SIZE', '1')))
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return []
+    if local_world <= 1 or len(cores) < local_world:
+        return cores
+    k = len(cores) // local_world
+    mine = cores[local * k:(local + 1) * k]
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return cores
+    return mine
+
+
+def preflight(world, rank, device=None, sizes=(1024,)):
+    """What the first real multi-GPU run needs to explain itself (one shot, on a box nobody watches): before any timed leg every rank
+    gathers -- and rank 0 returns for the bench line --
+      device_count / devices    what this process sees (name, index);
+      can_access_peer           the hipDeviceCanAccessPeer matrix over the visible devices;
+      library_allreduce         an all-reduce of ones over the process group (torch.distributed: RCCL on GPUs): sum == world on every rank;
+      peer_ipc                  per rank: a fine-grained allocation exported through hipIpc and opened by EVERY peer, one average of
+                                rank-dependent data through it checked against the closed form (csrc/xgmi.hip, both forms);
+      host_cores                the core set each rank's threads run on (pin_host_cores).
+    Every rank takes part in every exchange whatever failed locally; nothing here raises.  CPU / gloo: the GPU items read 'n/a'."""
+    rep = {'world': int(world), 'backend': dist.get_backend() if dist.is_initialized() else None}
+    cuda = torch.cuda.is_available() and device is not None and torch.device(device).type == 'cuda'
+    try:
+        rep['host_cores'] = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        rep['host_cores'] = []
+    if cuda:
+        n_dev = torch.cuda.device_count()
+        rep['device_count'] = n_dev
+        rep['device'] = [torch.device(device).index, torch.cuda.get_device_name(device)]
+        mat = []
+        for i in range(n_dev):
+            row = []
+            for j in range(n_dev):
+                try:
+                    row.append(1 if i == j else int(torch.cuda.can_device_access_peer(i, j)))
+                except Exception:          # noqa: BLE001
+                    row.append(-1)
+            mat.append(row)
+        rep['can_access_peer'] = mat
+    else:
+        rep.update(device_count=0, device='n/a', can_access_peer='n/a')
+    # library collective
+    try:
+        if world > 1 and dist.is_initialized():
+            t = torch.ones(1, dtype=torch.float32, device=device if (cuda and dist.get_backend() == 'nccl') else 'cpu')
+            dist.all_reduce(t)
+            rep['library_allreduce'] = {'sum_of_ones': float(t.item()), 'ok': float(t.item()) == float(world)}
+        else:
+            rep['library_allreduce'] = 'n/a (one rank)'
+    except Exception as e:          # noqa: BLE001
+        rep['library_allreduce'] = {'ok': False, 'error': str(e)[:200]}
+    # hipIpc + peer-memory average on small contexts (both forms), rank-dependent data with a closed-form answer
+    if cuda and world > 1 and dist.is_initialized():
+        ipc = {}
+        for n in sizes:
+            peer, err = PeerGradSync.try_create(int(n), world, rank, device, timeout_ms=5000)
+            ok, why = (1.0, '') if peer is not None else (0.0, str(err)[:200])
+            if peer is not None:
+                try:
+                    want = (world + 1) / 2.0
+                    x = torch.full((int(n),), float(rank + 1), device=device)
+                    peer(x)                                                  # copy form
+                    peer.slot_tensor(peer.next_slot()).fill_(float(rank + 1))
+                    y = torch.empty_like(x)
+                    peer.reduce_into(y)                                      # exchange-slot form
+                    torch.cuda.synchronize(device)
+                    peer.check()
+                    if abs(float(x[0]) - want) > 1e-6 or abs(float(y[-1]) - want) > 1e-6:
+                        ok, why = 0.0, f'rank {rank}: average {float(x[0])} / {float(y[-1])}, expected {want}'
+                except Exception as e:          # noqa: BLE001
+                    ok, why = 0.0, f'rank {rank}: {e}'[:200]
+            gathered = [None] * world
+            dist.all_gather_object(gathered, (ok, why))
+            if peer is not None:
+                peer.close()
+            ipc[str(n)] = {'ok': all(g[0] >= 1.0 for g in gathered), 'per_rank': [('ok' if g[0] >= 1.0 else g[1]) for g in gathered]}
+        rep['peer_ipc'] = ipc
+    else:
+        rep['peer_ipc'] = 'n/a'
+    if world > 1 and dist.is_initialized():
+        allrep = [None] * world
+        dist.all_gather_object(allrep, {'rank': rank, 'device': rep['device'], 'host_cores': rep['host_cores']})
+        rep['ranks'] = allrep
+    return rep
+
+
 def init_process_group(backend=None, force=False):
     """force=True initialises the process group even with WORLD_SIZE=1 (the RCCL self-test on a one-GPU box:
     tools/rccl_selftest.py)."""
@@ -123,6 +224,8 @@ class PeerGradSync:
     (`fused_sumsq` tells the caller it may).  `check()` surfaces a timed-out wait (the launch itself never hangs)."""
     fused_sumsq = True
 
+    _fail_setup_on_rank = None      # test seam (tests/test_gpu_dist.py sets it on the class): that rank's set-up raises -- the agreed-failure path
+
     def __init__(self, n_floats, world, rank, device=None, timeout_ms=None):
         # tolerant set-up here too: a rank whose local set-up fails still takes part in both host exchanges, so that EVERY rank gets
         # the error and raises together (a rank raising before all_gather_object would leave the others inside the collective)
@@ -165,7 +268,7 @@ class PeerGradSync:
         own = XgHandle()
 
         def create_export():
-            if os.environ.get('MANSY_XG_TEST_FAIL_RANK') == str(self.rank):      # test hook: one rank's set-up fails (tests/test_gpu_dist.py)
+            if PeerGradSync._fail_setup_on_rank == self.rank:
                 raise RuntimeError('injected set-up failure')
             ctx = ctypes.c_void_p()
             check(self._lib.mansy_xg_create(self.n, self.world, self.rank, ctypes.byref(ctx)), 'mansy_xg_create')

@@ -40,11 +40,30 @@ def test_release_library_has_no_process_wide_state_entry_points(built):
     bad = [n for n in names if n != 'mansy_set_error' and      # (the thread-local error string's internal writer)
            re.search(r'^mansy_(set_|get_gemm|lab_)|_variant$|mansy_gemm_col_group|mansy_gemm_f32_wsk|bn_sync_hook', n)]
     assert bad == ['mansy_xg_set_timeout_ms'] or bad == [], bad          # (a per-context setting of an opaque ctx is not process-wide state)
-    assert ctypes.CDLL(built).mansy_abi_version() == 8
+    assert ctypes.CDLL(built).mansy_abi_version() == 9
     csrc = os.path.join(ROOT, 'mansy_immersivevideostreaming_amd', 'csrc')
     for f in os.listdir(csrc):
         if f.endswith(('.hip', '.h')):
             assert 'getenv' not in open(os.path.join(csrc, f)).read(), f
+
+
+def test_package_reads_no_environment_except_the_launcher_variables():
+    """Round 6 hygiene: behaviour switches are constructor arguments / attributes, not environment variables.  The only reads under the package are
+    dist.py's launcher variables (RANK / WORLD_SIZE / LOCAL_RANK / LOCAL_WORLD_SIZE, the rendezvous backend and the shared-GPU functional-test switch,
+    HSA_ENABLE_IPC_MODE_LEGACY) and build_ext.py's HIPCC (a build tool, not the product path)."""
+    pkg = os.path.join(ROOT, 'mansy_immersivevideostreaming_amd')
+    hits = []
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                path = os.path.join(d, f)
+                for i, line in enumerate(open(path), 1):
+                    if re.search(r'os\.environ|getenv', line) and not line.lstrip().startswith('#'):
+                        hits.append((os.path.relpath(path, pkg), i))
+    assert {h[0] for h in hits} <= {'dist.py', 'build_ext.py'}, hits
+    for f in os.listdir(os.path.join(pkg, 'csrc')):            # and no lab conditional in any kernel source (csrc/lab/ is the lab build's own TU)
+        if f.endswith('.hip'):
+            assert 'MANSY_LAB' not in open(os.path.join(pkg, 'csrc', f)).read(), f
 
 
 def test_ctypes_table_matches_header(built):

@@ -34,7 +34,9 @@ def _worker(rank, world, port, out):
     local = torch.tensor([x.mean(), x.var(), float(len(x))], dtype=torch.float64)
     glob = mdist.global_running_moments(local, w)
     off, wn = mdist.shard_envs(256, rank, w)
-    out[rank] = (g.numpy().copy(), glob.numpy().copy(), local.numpy().copy(), off, wn, x)
+    cores = mdist.pin_host_cores(rank, w)
+    pf = mdist.preflight(w, rank, None)
+    out[rank] = (g.numpy().copy(), glob.numpy().copy(), local.numpy().copy(), off, wn, x, pf, cores)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -45,8 +47,16 @@ def test_two_process_gloo():
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
-    g0, glob0, loc0, off0, wn0, x0 = out[0]
-    g1, glob1, loc1, off1, wn1, x1 = out[1]
+    g0, glob0, loc0, off0, wn0, x0, pf0, cores0 = out[0]
+    g1, glob1, loc1, off1, wn1, x1, pf1, cores1 = out[1]
+    # the self-diagnosis object of a multi-rank run (bench.py prints it under dist.preflight): same keys on CPU / gloo, GPU items 'n/a'
+    for pf in (pf0, pf1):
+        assert {'world', 'backend', 'host_cores', 'device_count', 'device', 'can_access_peer', 'library_allreduce', 'peer_ipc', 'ranks'} <= set(pf)
+        assert pf['world'] == 2 and pf['backend'] == 'gloo' and pf['library_allreduce'] == {'sum_of_ones': 2.0, 'ok': True}
+        assert pf['peer_ipc'] == 'n/a' and [r['rank'] for r in pf['ranks']] == [0, 1]
+    if len(os.sched_getaffinity(0)) >= 2:        # each rank's threads on a core set of its own
+        assert cores0 and cores1 and not set(cores0) & set(cores1)
+        assert pf0['ranks'][0]['host_cores'] == cores0 and pf0['ranks'][1]['host_cores'] == cores1
     want = np.arange(1000, dtype=np.float32) * 1.5
     np.testing.assert_allclose(g0, want)
     np.testing.assert_allclose(g1, want)

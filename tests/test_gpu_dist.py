@@ -201,7 +201,7 @@ def test_bench_eight_ranks_functional_on_the_shared_gpu():
     peers' buffers (MANSY_PEER_SYNC=1) and leaves the PPO replicas bit-identical, SyncBN + the overlapped gradient all-reduce leave the
     VP replicas identical."""
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
-    env.update(MANSY_DIST_BACKEND='gloo', MANSY_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0', MANSY_PEER_SYNC='1')
+    env.update(MANSY_DIST_BACKEND='gloo', MANSY_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0', MANSY_PEER_SYNC='slot')
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '1', '--warmup', '1', '--batch', '64', '--no-cpu-baseline']
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -214,6 +214,15 @@ def test_bench_eight_ranks_functional_on_the_shared_gpu():
     assert sec['replica_param_spread'] == 0.0 and sec['value'] > 0 and np.isfinite(sec['final_loss'])
     n = sec['envs_per_gpu']
     assert sec['env_shards'] == [[r_ * n, 8 * n] for r_ in range(8)]
+    # round 6: the update half of the cycle is replayed from a captured hipGraph on every rank (peer averages in the exchange-slot form, epoch derived
+    # on the device) -- and the replicas above are STILL bit-identical; the run explains itself
+    assert sec['update_half'].startswith('hipGraph replay') and sec['grad_sync_report']['chosen'] == 'peer'
+    pf = out['dist']['preflight']
+    assert pf['world'] == 8 and pf['device_count'] >= 1 and pf['library_allreduce']['ok'] and len(pf['ranks']) == 8
+    assert all(v['ok'] for v in pf['peer_ipc'].values()), pf['peer_ipc']
+    assert len(pf['can_access_peer']) == pf['device_count'] and isinstance(pf['host_cores'], list)
+    assert len(sec['per_rank']['ms_per_cycle']) == 8 and len(sec['per_rank']['host_enqueue_ms_per_cycle']) == 8
+    assert 'us_per_average_wire_and_skew' in sec['wire_term'], sec['wire_term']
 
 
 @pytest.mark.gpu

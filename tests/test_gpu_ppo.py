@@ -167,7 +167,7 @@ def test_ppo_minibatch_loss_grads_clip_adam_vs_oracle(M):
         arr, garr = f.pointers(grads=True)
         check(lib().mansy_ppo_minibatch_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(d['obs']), None,
                                              ptr(d['act']), ptr(d['adv']), ptr(d['logp']), ptr(d['v']), ptr(d['ret']), len(obs), 0.2, 0.5, 0.02, 1, 1, 0.0,
-                                             max_norm, 5e-4, 1e-2, step, -1, 0, ptr(stats), ptr(eng.workspace()), eng.max_batch, 0, None, 0, None, eng.prec, stream_ptr()), 'ppo_mb')
+                                             max_norm, 5e-4, 1e-2, step, -1, 0, ptr(stats), ptr(eng.workspace()), eng.max_batch, 0, None, 0, None, None, eng.prec, stream_ptr()), 'ppo_mb')
     call(0, 0.0)                                  # gradients only, no clipping
     np.testing.assert_allclose(stats.cpu().numpy(), [loss, clip, vf, ent], rtol=2e-5, atol=2e-6)
     names = [n for n, _ in f.table]
@@ -200,8 +200,11 @@ def test_paired_launch_of_the_fc_weight_gradients_and_dF_is_bit_identical_to_two
     (gemm_f32_wsk_dual_kernel: the same two loop bodies on disjoint workgroup ranges of one grid).  ABI 8: the release library has no switch
     for it; the -DMANSY_LAB build of the same sources has (default variant 0x800 = no paired launch).  Every gradient, the loss statistics and
     the identifier's training step (fc_bwd_single's pair) are bit-identical either way -- and the release library agrees with both."""
+    import sys
     from mansy_immersivevideostreaming_amd import _lib as LB, build_ext
     from mansy_immersivevideostreaming_amd._lib import check, ptr, stream_ptr
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import lab_knobs                  # the lab-library harness lives with the tools (the package holds no swappable library handle)
     build_ext.build(lab=True)
     sd = po.make_policy_state_dict(int(Z['wseed']))
     obs, act, adv, v_old, ret, g = _minibatch_data()
@@ -217,15 +220,15 @@ def test_paired_launch_of_the_fc_weight_gradients_and_dF_is_bit_identical_to_two
         arr, garr = f.pointers(grads=True)
         check(L.mansy_ppo_minibatch_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(d['obs']), None,
                                          ptr(d['act']), ptr(d['adv']), ptr(d['logp']), ptr(d['v']), ptr(d['ret']), len(obs), 0.2, 0.5, 0.02, 1, 1, 0.0,
-                                         0.0, 5e-4, 1e-2, 0, -1, 0, ptr(stats), ptr(eng.workspace()), eng.max_batch, 0, None, 0, None, eng.prec, stream_ptr()), 'ppo_mb')
+                                         0.0, 5e-4, 1e-2, 0, -1, 0, ptr(stats), ptr(eng.workspace()), eng.max_batch, 0, None, 0, None, None, eng.prec, stream_ptr()), 'ppo_mb')
         iloss = torch.zeros((), device=dev)
         iarr, igarr = fi.pointers(grads=True)
         check(L.mansy_identifier_train_step(iarr, igarr, ptr(fi.flat_p), ptr(fi.flat_g), ptr(fi.m), ptr(fi.v), fi.flat_p.numel(), ptr(d['obs']), None,
-                                            len(obs), 1e-4, 1e-2, -1, ptr(iloss), ptr(eng.workspace()), eng.max_batch, None, eng.prec, stream_ptr()), 'ident')
+                                            len(obs), 1e-4, 1e-2, -1, ptr(iloss), ptr(eng.workspace()), eng.max_batch, None, None, eng.prec, stream_ptr()), 'ident')
         torch.cuda.synchronize()
         return (f.flat_g.clone(), stats.clone(), fi.flat_g.clone(), iloss.clone())
     for knob, variant in ((8, 0x800), (9, 0)):
-        with LB.lab_library(variant) as L:
+        with lab_knobs.lab_library(variant) as L:
             outs[knob] = run(L)
     rel = run(LB.lib())
     for a, b in zip(rel, outs[9]):
@@ -263,7 +266,7 @@ def test_ppo_minibatch_flag_combinations_incl_dual_clip_vs_oracle(M, flags):
     check(lib().mansy_ppo_minibatch_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(d['obs']), None,
                                          ptr(d['act']), ptr(d['adv']), ptr(d['logp']), ptr(d['v']), ptr(d['ret']), len(obs), 0.2, 0.5, 0.02,
                                          int(okw['norm_adv']), int(okw['value_clip']), float(okw['dual_clip'] or 0.0), 0.0, 5e-4, 1e-2, 0, -1, 0,
-                                         ptr(stats), ptr(eng.workspace()), eng.max_batch, 0, None, 0, None, eng.prec, stream_ptr()), 'ppo_mb')
+                                         ptr(stats), ptr(eng.workspace()), eng.max_batch, 0, None, 0, None, None, eng.prec, stream_ptr()), 'ppo_mb')
     np.testing.assert_allclose(stats.cpu().numpy(), [loss, clip, vf, ent], rtol=2e-5, atol=2e-6)
     for n_, o, p in zip([n for n, _ in f.table], f.offsets, f.params):
         got = f.flat_g[o:o + p.numel()].view(p.shape).cpu().numpy()
@@ -446,7 +449,7 @@ def test_update_teacher_forced_every_minibatch_step(M):
                 check(lib().mansy_ppo_minibatch_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(obs_d), ptr(idx),
                                                      ptr(act_d), ptr(data['adv']), ptr(data['logp_old']), ptr(data['v_s']), ptr(data['returns']),
                                                      idx.numel(), 0.2, 0.5, 0.02, 1, 1, 0.0, 1.0, lr, wd, f.step, *f.tail(), ptr(stats),
-                                                     ptr(eng.workspace()), eng.max_batch, 0, None, 0, None, eng.prec, stream_ptr()), 'mansy_ppo_minibatch_step')
+                                                     ptr(eng.workspace()), eng.max_batch, 0, None, 0, None, None, eng.prec, stream_ptr()), 'mansy_ppo_minibatch_step')
                 torch.cuda.synchronize()
                 np.testing.assert_allclose(stats.cpu().numpy(), rows[k], rtol=1e-5, atol=3e-6, err_msg=f'{(T, N, it, k)}')
                 n_el = n_bad = 0
@@ -598,7 +601,7 @@ def test_behaviour_cloning_steps_then_ppo_with_per_parameter_adam_steps(M):
         assert f.tail()[1] == k + 1
         check(lib().mansy_ppo_minibatch_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(d['obs']), None,
                                              ptr(d['act']), ptr(d['adv']), ptr(d['logp']), ptr(d['v']), ptr(d['ret']), len(obs), 0.2, 0.5, 0.02, 1, 1, 0.0,
-                                             1.0, 5e-4, 1e-2, f.step, *f.tail(), ptr(stats), ptr(eng.workspace()), eng.max_batch, 0, None, 0, None, eng.prec, stream_ptr()),
+                                             1.0, 5e-4, 1e-2, f.step, *f.tail(), ptr(stats), ptr(eng.workspace()), eng.max_batch, 0, None, 0, None, None, eng.prec, stream_ptr()),
               'ppo_mb')
         np.testing.assert_allclose(stats[0].item(), loss.item(), rtol=5e-5, atol=5e-6)
     compare('after PPO steps', 6e-6)
@@ -986,3 +989,90 @@ def test_shipped_trained_checkpoint_vs_reference(M, mode):
     np.testing.assert_allclose(pred.cpu().numpy(), G['ident'], atol=tol, rtol=0)
     assert (logits.argmax(-1).cpu().numpy() == G['logits'].argmax(-1)).all()
     np.testing.assert_allclose(buf.rew[:, 0].cpu().numpy(), G['ident_reward'], atol=tol, rtol=0)
+
+
+@pytest.mark.parametrize('form', ['single', 'peer-slot', 'rccl-comm-forced'])
+def test_graph_replayed_update_half_equals_direct_launches(M, form):
+    """Round 6: train_identifier() and update() replayed from captured hipGraphs (PPOPolicy.graph_update: first call direct, second call capture +
+    replay, then replays) against the same calls as direct launches, four cycles each on the same buffer contents and the same numpy seeds.
+    What a replay cannot take from its frozen kernel arguments comes from device memory: the permutations / the identifier's shuffle (staged
+    upload), the Adam bias corrections of the replay's step counts (`adam_bias`), the peer-memory epoch (derived from the rank's own flag word).
+    Same launches on the same data: loss rows, weights, Adam moments, return normaliser and identifier agree to float32 rounding (float atomics
+    in the bias-gradient sums order differently from run to run) -- and the step counters, which are host state, agree exactly."""
+    from mansy_immersivevideostreaming_amd import dist as mdist
+    sd = po.make_policy_state_dict(int(Z['wseed']))
+    T, N, bs = 16, 256, 512
+    rs = np.random.RandomState(21)
+    n = T * N
+    src = Z['obs']
+    obs = torch.from_numpy(src[rs.randint(0, len(src), size=n)].reshape(T, N, 780).copy())
+    obs_next = torch.from_numpy(src[rs.randint(0, len(src), size=n)].reshape(T, N, 780).copy())
+    act = torch.from_numpy(rs.randint(0, 15, size=(T, N)).astype(np.int32))
+    rew = torch.from_numpy(rs.randn(T, N).astype(np.float32))
+    done = torch.from_numpy((rs.rand(T, N) < 0.05).astype(np.uint8))
+    outs, comms = [], []
+    for graph in (False, 'auto'):
+        pol = build_policy(M, sd)
+        if form == 'peer-slot':
+            pol.set_data_parallel(1, None, peer=True, force=True, in_slot=True)
+        elif form == 'rccl-comm-forced':
+            comms.append(mdist.RcclComm(1, 0, torch.device('cuda', torch.cuda.current_device())))
+            pol.set_data_parallel(1, None, force=True, comm=comms[-1])
+        pol.graph_update = graph if not (graph and form == 'rccl-comm-forced') else True       # a library collective inside the graph: only when forced
+        buf = M.ppo.RolloutBuffer(T, N, 'cuda')
+        rows, ilosses = [], []
+        for it in range(4):
+            buf.obs.copy_(obs); buf.obs_next.copy_(obs_next); buf.act.copy_(act); buf.rew.copy_(rew + 0.1 * it); buf.done.copy_(done)
+            buf.filled = T
+            np.random.seed(300 + it)
+            losses, vloss = pol.train_identifier(buf, 2, verbose=False)
+            res = pol.update(0, buf, is_train=True, batch_size=bs, repeat=2)
+            ilosses.append([l.item() for l in losses] + [vloss.item()])
+            rows.append(np.stack([res['loss'], res['loss/clip'], res['loss/vf'], res['loss/ent']], 1))
+        torch.cuda.synchronize()
+        pol.sync_check()
+        assert pol.graph_replays == (6 if graph else 0), pol.graph_replays            # cycles 2, 3, 4 x (identifier, update)
+        assert pol.engine.ac.step == 64 and pol.engine.idn.step == 8
+        if graph:
+            assert sorted(g['launches'] for g in pol._graphs.values())[0] >= 10
+        outs.append((np.concatenate(rows), np.array(ilosses), pol.engine.ac.flat_p.clone(), pol.engine.ac.m.clone(), pol.engine.ac.v.clone(),
+                     pol.engine.idn.flat_p.clone(), pol.ret_rms().clone(), buf.rew.clone()))
+    for cm in comms:
+        cm.close()
+    a, b = outs
+    np.testing.assert_array_equal(a[0][0], b[0][0])                       # first step of the first (direct) cycle: identical launches
+    np.testing.assert_allclose(b[0], a[0], rtol=2e-4, atol=2e-5)          # 64 loss rows
+    np.testing.assert_allclose(b[1], a[1], rtol=1e-5, atol=1e-7)          # identifier losses (8 training rounds + 4 validations)
+    for x, y, lr in ((a[2], b[2], 5e-4), (a[3], b[3], 5e-4), (a[4], b[4], 5e-4), (a[5], b[5], 1e-4)):
+        err = (x - y).abs()
+        assert float((err > 0.02 * lr).float().mean()) <= 2e-3 and err.max().item() <= 4 * lr, (err.max().item(),)
+    np.testing.assert_allclose(b[6].cpu().numpy(), a[6].cpu().numpy(), rtol=1e-4)       # return normaliser after four updates
+    np.testing.assert_allclose(b[7].cpu().numpy(), a[7].cpu().numpy(), atol=5e-5)       # relabelled rewards of the last cycle
+
+
+def test_graph_replay_needs_an_even_step_count_and_falls_back_otherwise(M):
+    """1100 transitions at batch 512 and repeat 1 = 2 steps (even: replayed); 1536 at 512 and repeat 1 = 3 steps (odd: the norm-slot sets
+    would start a replay on the other parity) -> direct launches, same results as with graph_update = False."""
+    sd = po.make_policy_state_dict(int(Z['wseed']))
+    src = Z['obs']
+    for (T, N, want_replays) in ((11, 100, 2), (12, 128, 0)):
+        got = []
+        for graph in (False, 'auto'):
+            rs = np.random.RandomState(4)
+            n = T * N
+            pol = build_policy(M, sd)
+            pol.graph_update = graph
+            buf = M.ppo.RolloutBuffer(T, N, 'cuda')
+            buf.obs.copy_(torch.from_numpy(src[rs.randint(0, len(src), size=n)].reshape(T, N, 780).copy()))
+            buf.obs_next.copy_(torch.from_numpy(src[rs.randint(0, len(src), size=n)].reshape(T, N, 780).copy()))
+            buf.act.copy_(torch.from_numpy(rs.randint(0, 15, size=(T, N)).astype(np.int32)))
+            buf.done.copy_(torch.from_numpy((rs.rand(T, N) < 0.05).astype(np.uint8)))
+            for it in range(3):
+                buf.rew.copy_(torch.from_numpy(rs.randn(T, N).astype(np.float32)))
+                buf.filled = T
+                np.random.seed(it)
+                res = pol.update(0, buf, is_train=True, batch_size=512, repeat=1)
+            assert pol.graph_replays == (want_replays if graph else 0)
+            got.append((np.array(res['loss']), pol.engine.ac.flat_p.clone()))
+        np.testing.assert_allclose(got[1][0], got[0][0], rtol=2e-4, atol=2e-5)
+        assert (got[1][1] - got[0][1]).abs().max().item() <= 4 * 5e-4

@@ -8,13 +8,43 @@ import sys
 ROOT = os.environ.get('GRAFT_REPO_ROOT') or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 _state = {'word': 0, 'ctx': None, 'lab': None}
+_lab = None
+
+
+class lab_library:
+    """Test / tools harness only (it lives here, not in the package: the product's bindings hold no swappable library handle): inside the block every
+    host mirror of THIS process talks to the -DMANSY_LAB build of the same sources (libmansy_hip_lab.so: `python -m
+    mansy_immersivevideostreaming_amd.build_ext --lab`), the only build that exports mansy_lab_set_variant(v) -- a default kernel-selection variant
+    for calls that pass 0, so that whole engine steps can be run on two loops.  `variant` is set on entry and reset to 0 on exit."""
+
+    def __init__(self, variant=0):
+        self.variant = int(variant)
+
+    def __enter__(self):
+        import ctypes
+        from mansy_immersivevideostreaming_amd import _lib, build_ext
+        global _lab
+        if _lab is None:
+            _lab = _lib._load(build_ext.LAB_LIB)
+            _lab.mansy_lab_set_variant.argtypes = [ctypes.c_int]
+            _lab.mansy_lab_set_variant.restype = ctypes.c_int
+        self.prev_lib = _lib.lib()
+        _lab.mansy_lab_set_variant(self.variant)
+        _lib._lib = _lab
+        return _lab
+
+    def __exit__(self, *exc):
+        from mansy_immersivevideostreaming_amd import _lib
+        _lab.mansy_lab_set_variant(0)
+        _lib._lib = self.prev_lib
+        return False
 
 
 def enter():
-    from mansy_immersivevideostreaming_amd import _lib, build_ext
+    from mansy_immersivevideostreaming_amd import build_ext
     if _state['ctx'] is None:
         build_ext.build(lab=True)
-        _state['ctx'] = _lib.lab_library(0)
+        _state['ctx'] = lab_library(0)
         _state['lab'] = _state['ctx'].__enter__()
     return _state['lab']
 

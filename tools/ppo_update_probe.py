@@ -51,7 +51,7 @@ for it in range(2):
             check(lib().mansy_ppo_minibatch_step(arr, garr, ptr(f.flat_p), ptr(f.flat_g), ptr(f.m), ptr(f.v), f.flat_p.numel(), ptr(data['obs']),
                                                  ptr(idx), ptr(data['act']), ptr(data['adv']), ptr(data['logp_old']), ptr(data['v_s']),
                                                  ptr(data['returns']), idx.numel(), 0.2, 0.5, 0.02, 1, 1, 0.0, 1.0, 5e-4, 1e-2, f.step, -1, 0, ptr(stats),
-                                                 ptr(eng.workspace()), eng.max_batch, 0, None, 0, None, eng.prec, stream_ptr()), 'mb')
+                                                 ptr(eng.workspace()), eng.max_batch, 0, None, 0, None, None, eng.prec, stream_ptr()), 'mb')
             torch.cuda.synchronize()
             worst = ('', 0.0)
             for name, o, p in zip([x[0] for x in f.table], f.offsets, f.params):
