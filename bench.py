@@ -267,14 +267,16 @@ def bench_ppo_dp_form(dev, mdist, cycles=6, warmup=2, vp_leg=None):
     out = {'workload': '256 envs x 16 steps, identifier 2 rounds + relabel + PPO update (minibatch 512, repeat 2): 16 + 2 gradient averages per cycle',
            'cycles': cycles}
     ms, nl, _ = _ppo_cycle_time(_ppo_policy(dev), dev, cycles, warmup)
-    out['fused'] = {'ms_per_cycle': round(ms, 3), 'library_launches_per_cycle': round(nl, 1), 'host_enqueue_ms_per_cycle': round(_ppo_cycle_time.host_ms, 3)}
+    out['fused'] = {'ms_per_cycle': round(ms, 3), 'library_launches_per_cycle': round(nl, 1), 'host_enqueue_ms_per_cycle': round(_ppo_cycle_time.host_ms, 3),
+                    'update_graph_replays': _ppo_cycle_time.graph_replays}
     for key, in_slot in (('dp_peer_kernel', True), ('dp_peer_kernel_copy_form_r04', False)):      # slot form: one library call per step, as the fused step
         pol = _ppo_policy(dev)
         pol.peer_in_slot = in_slot      # True (round 5): gradients produced straight in the exchange slot; False: copied into it by the collective launch
         pol.set_data_parallel(1, None, peer=True, force=True)
         ms_x, nl_x, _ = _ppo_cycle_time(pol, dev, cycles, warmup)
         pol._check_peers()
-        out[key] = {'ms_per_cycle': round(ms_x, 3), 'library_launches_per_cycle': round(nl_x, 1), 'host_enqueue_ms_per_cycle': round(_ppo_cycle_time.host_ms, 3), 'vs_fused': round(ms_x / ms, 3),
+        out[key] = {'ms_per_cycle': round(ms_x, 3), 'library_launches_per_cycle': round(nl_x, 1), 'host_enqueue_ms_per_cycle': round(_ppo_cycle_time.host_ms, 3),
+                    'update_graph_replays': _ppo_cycle_time.graph_replays, 'vs_fused': round(ms_x / ms, 3),
                     'us_per_average': round((ms_x - ms) * 1e3 / 18, 2), 'implied_ceiling_8gpu': round(8 * ms / ms_x, 2)}
     try:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -295,10 +297,12 @@ def bench_ppo_dp_form(dev, mdist, cycles=6, warmup=2, vp_leg=None):
         comm = mdist.RcclComm(1, 0, dev)
         pol = _ppo_policy(dev)
         pol.set_data_parallel(1, None, peer=False, force=True, comm=comm)
+        pol.graph_update = True          # the update half incl. ncclAllReduce captured into the graph (forced: 'auto' keeps library collectives out of graphs)
         ms_c, nl_c, _ = _ppo_cycle_time(pol, dev, cycles, warmup)
         out['dp_rccl_one_call'] = {'ms_per_cycle': round(ms_c, 3), 'library_launches_per_cycle': round(nl_c, 1), 'host_enqueue_ms_per_cycle': round(_ppo_cycle_time.host_ms, 3),
                                    'vs_fused': round(ms_c / ms, 3), 'us_per_average': round((ms_c - ms) * 1e3 / 18, 2), 'implied_ceiling_8gpu': round(8 * ms / ms_c, 2),
-                                   'note': 'mansy_ppo_minibatch_step(..., sync = mansy_comm context): ncclAllReduce(avg) + norm launch inside the step call'}
+                                   'update_graph_replays': pol.graph_replays,
+                                   'note': 'mansy_ppo_minibatch_step(..., sync = mansy_comm context): ncclAllReduce(avg) + norm launch inside the step call; update half captured as hipGraphs with the collective inside (graph_update = True)'}
         comm.close()
         if vp_leg is not None:          # the VP step in ITS data-parallel form over the same one-rank RCCL group
             out['vp_step'] = vp_leg()
@@ -512,18 +516,22 @@ def bench_ppo(rank, world, dev, mdist, cycles=5, warmup=2, n_env=256, steps_per_
     # N-rank cycle after subtracting it is the wire + skew term w of DESIGN section 6, per average
     wire = None
     if world > 1:
-        try:
+        ms1, err1 = -1.0, ''
+        try:                            # rank-local work only inside the try: every rank reaches the collectives below whatever happened here
             pol1 = _ppo_policy(dev, rank)
             pol1.set_data_parallel(1, None, peer=True, force=True, in_slot=True)
             ms1, _, _ = _ppo_cycle_time(pol1, dev, cycles, 3, n_env=n_env, steps_per_env=steps_per_env, tables=tables)
             pol1._check_peers()
-            t1 = torch.tensor([ms1], device=dev, dtype=torch.float64)
-            dist.all_reduce(t1, op=dist.ReduceOp.MAX)
-            wire = {'dp_form_world1_ms_per_cycle_max_over_ranks': round(float(t1.item()), 3),
-                    'us_per_average_wire_and_skew': round((dt / cycles * 1e3 - float(t1.item())) * 1e3 / 18, 2),
-                    'design_budget': 'DESIGN section 6: 7.8x at w = 0, ~6.8x at w = 16 us, 6.0x at w = 30 us'}
         except Exception as e:          # noqa: BLE001
-            wire = {'error': str(e)[:200]}
+            ms1, err1 = -1.0, str(e)[:200]
+        t1 = torch.tensor([ms1, 0.0 if ms1 >= 0 else 1.0], device=dev, dtype=torch.float64)
+        dist.all_reduce(t1, op=dist.ReduceOp.MAX)
+        if float(t1[1]) > 0:
+            wire = {'error': err1 or 'the one-rank cycle failed on another rank'}
+        else:
+            wire = {'dp_form_world1_ms_per_cycle_max_over_ranks': round(float(t1[0]), 3),
+                    'us_per_average_wire_and_skew': round((dt / cycles * 1e3 - float(t1[0])) * 1e3 / 18, 2),
+                    'design_budget': 'DESIGN section 6: 7.8x at w = 0, ~6.8x at w = 16 us, 6.0x at w = 30 us'}
         dist.barrier()
     # rollout alone (outside the timed region): policy forward + sampling + environment step, hipGraph-replayed collects
     tc = time.perf_counter()

@@ -425,6 +425,16 @@ int mansy_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ld
 int mansy_weight_planes(const float* W, int N, int K, uint16_t* out, uint16_t* out_t, long long plane_stride, int n_planes, void* stream);
 int mansy_gemm_planes(const float* A, int lda, const float* B, int ldb, int b_kmajor, const uint16_t* planes, long long plane_stride,
                       int planes_ld, float* C, int ldc, int M, int N, int K, const mansy_gemm_epilogue* ep, int force_tile, void* stream);
+/* bf16-STORAGE product (round 6; the MANSY_PREC_BF16 perf mode's products when its operands live in HBM as bf16): both operands are bf16 images,
+ * staged by LDS-DMA without conversion, one v_mfma_f32_32x32x16_bf16 product, fp32 accumulate.  Two forms:
+ *   a_kmajor = b_kmajor = 0: C[M, N] = A16[M, K] * B16[N, K]^T (forward with B16 = bf16(W), dX with B16 = bf16(W^T)); full fused epilogue; the output
+ *     goes to C (fp32, nullable) and / or C16 (bf16 image of the final value, nullable);
+ *   a_kmajor = b_kmajor = 1: C[M, N] += A16[K, M]^T * B16[K, N] (weight gradient dW = dY^T X over the K rows of two activation slabs, split-K with
+ *     atomic accumulation; ep->accumulate must be set, ep->a_rowsum as in mansy_gemm_f32).
+ * K % 64 == 0, 16-byte aligned operands, leading dimensions % 8 == 0.  The reference's analogue: torch.set_float32_matmul_precision('high')
+ * (viewport_prediction/run_models.py:135). */
+int mansy_gemm_bf16(const uint16_t* A16, int lda, int a_kmajor, const uint16_t* B16, int ldb, int b_kmajor, float* C, int ldc, uint16_t* C16, int ldc16,
+                    int M, int N, int K, const mansy_gemm_epilogue* ep, int force_tile, int force_splitk, void* stream);
 typedef struct mansy_attn_shape {
   int nb, H, Lq, Lk, dh;
   long long q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;

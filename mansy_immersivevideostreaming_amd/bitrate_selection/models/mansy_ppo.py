@@ -298,7 +298,7 @@ class PPOPolicy(nn.Module):
                     if f.flat_p.numel() in peers:
                         self._peer[id(f)] = peers[f.flat_p.numel()]
             else:
-                rank = tdist.get_rank() if tdist.is_initialized() else 0
+                rank = tdist.get_rank() if (tdist.is_initialized() and self.world > 1) else 0      # (a forced one-rank context inside a multi-rank job is rank 0 of ITS world)
                 for f in flats:
                     self._peer[id(f)] = PeerGradSync(f.flat_p.numel(), self.world, rank, f.flat_p.device)
                 self.grad_sync_report = {'chosen': 'peer', 'reason': 'forced'}
@@ -456,12 +456,12 @@ class PPOPolicy(nn.Module):
         n = host_i32.size
         ring = self._pinned.get(key)
         if ring is None or ring['buf'].shape[1] < n:
-            # FOUR staging buffers used in turn: the host may run up to three cycles ahead of the device before it has to wait for an upload to
+            # EIGHT staging buffers used in turn: the host may run up to seven cycles ahead of the device before it has to wait for an upload to
             # have been consumed (with one buffer every cycle's staging waited for the previous cycle's copy, i.e. for the device: the host's
             # enqueue time then read as the device's cycle time)
-            ring = self._pinned[key] = dict(buf=torch.empty(4, max(n, 1), dtype=torch.int32).pin_memory(), ev=[None] * 4, i=0)
+            ring = self._pinned[key] = dict(buf=torch.empty(8, max(n, 1), dtype=torch.int32).pin_memory(), ev=[None] * 8, i=0)
         i = ring['i']
-        ring['i'] = (i + 1) % 4
+        ring['i'] = (i + 1) % 8
         if ring['ev'][i] is not None:
             ring['ev'][i].synchronize()
         ring['buf'][i, :n].copy_(torch.from_numpy(host_i32))
@@ -501,7 +501,8 @@ class PPOPolicy(nn.Module):
                 G['graph'].replay()
                 self.graph_replays += 1
                 self.graph_launches += G['launches']
-                losses, vloss = [l.clone() for l in G['losses']], (G['vloss'].clone() if G['vloss'] is not None else None)
+                snap = G['lossbuf'].clone()              # one copy: the graph's own buffer is overwritten by the next replay
+                losses, vloss = [snap[r] for r in range(update_round)], (snap[update_round] if G['vloss'] is not None else None)
             else:
                 self._graph_seen.add(key)
         if losses is None:
@@ -530,7 +531,7 @@ class PPOPolicy(nn.Module):
             f.step = step0
             return None
         f.step, self._pre_eval = step0, pre         # the capture executed nothing: the replay that follows takes these steps
-        G = self._graphs[key] = dict(graph=g, inp=inp, losses=losses, vloss=vloss, launches=nl)
+        G = self._graphs[key] = dict(graph=g, inp=inp, lossbuf=losses[0]._base if losses[0]._base is not None else losses[0], vloss=vloss, launches=nl)
         return G
 
     def _train_identifier_body(self, buffer, n, idx_t, update_round, bias=None):
@@ -544,6 +545,7 @@ class PPOPolicy(nn.Module):
         lr, wd = self._hyper(self.identifier_optim, 1e-4)
         f = eng.idn
         losses = []
+        lossbuf = torch.empty(update_round + 1, dtype=torch.float32, device=obs.device)       # [round losses ..., validation loss]
         # data parallel: each round's gradient average is on the critical path (1.05 MB, latency-bound).  The critic / log-prob passes
         # of the process_fn that follows (mansy_ppo.py:53: v_s + logp_old on obs, v_s_ on obs_next) depend on the actor-critic only,
         # which this function does not touch: round r's average flies on a side stream while pass r runs here; process_fn then finds
@@ -553,11 +555,11 @@ class PPOPolicy(nn.Module):
         for r in range(update_round):
             f.step += 1
             ov = (lambda part=r: self._pre_evaluate(buffer, part)) if hide and r < 2 else None
-            losses.append(self._identifier_step(obs, lr, wd, f.step, rows=tr, overlap=ov, bias=None if bias is None else bias[r]))
-        vloss = self._identifier_step(obs, lr, wd, 0, rows=va) if len(va) else None
+            losses.append(self._identifier_step(obs, lr, wd, f.step, rows=tr, overlap=ov, bias=None if bias is None else bias[r], loss=lossbuf[r]))
+        vloss = self._identifier_step(obs, lr, wd, 0, rows=va, loss=lossbuf[update_round]) if len(va) else None
         return losses, vloss
 
-    def _identifier_step(self, obs, lr, wd, step, rows=None, overlap=None, bias=None):
+    def _identifier_step(self, obs, lr, wd, step, rows=None, overlap=None, bias=None, loss=None):
         """One train_identifier step on `obs` (rows=None) or on its rows `rows` (device int32 indices).  bias: device [2] floats the Adam
         launch reads instead of deriving them from `step` (graph replays)."""
         eng, f = self.engine, self.engine.idn
@@ -565,7 +567,8 @@ class PPOPolicy(nn.Module):
         if B > eng.max_batch:
             raise MansyError(f'identifier batch {B} exceeds engine max_batch {eng.max_batch}')
         arr, garr = f.pointers(grads=True)
-        loss = torch.empty((), dtype=torch.float32, device=obs.device)
+        if loss is None:
+            loss = torch.empty((), dtype=torch.float32, device=obs.device)
         dp = self.grad_sync is not None and step > 0
         xg = self._xg_ctx(f) if dp else None
         if xg is not None:          # the data-parallel step as ONE call: gradients into the exchange slot, one launch averages them, Adam
@@ -723,7 +726,8 @@ class PPOPolicy(nn.Module):
             for k, chunk in enumerate(chunks):
                 flat.append((pi, k, perm[off:off + len(chunk)]))
                 off += len(chunk)
-        stats_all = [torch.empty(len(chunks), 4, dtype=torch.float32, device=dev) for chunks in passes]
+        stats_flat = torch.empty(sum(len(chunks) for chunks in passes), 4, dtype=torch.float32, device=dev)      # ONE tensor: a replay's snapshot is one copy
+        stats_all = list(stats_flat.split([len(chunks) for chunks in passes]))
         recompute = self._recompute_adv and repeat > 1
         # everything that does not change from step to step is converted for ctypes ONCE: the cycle is a chain of ~8 us launches and this loop's
         # host time per step (pointer tables of 28 tensors, ~35 argument conversions) must stay below the step's GPU time (tools/ppo_host_enqueue_probe.py)
@@ -755,7 +759,9 @@ class PPOPolicy(nn.Module):
                 self._sync_clip_adam(f, float(self._grad_norm or 0.0), lr, wd, tail=(data, nxt) if chain else None, bias=b_s)
         if dp and bias is None:
             self._check_peers()
-        return LazyLosses(('loss', 'loss/clip', 'loss/vf', 'loss/ent'), stats_all)
+        out = LazyLosses(('loss', 'loss/clip', 'loss/vf', 'loss/ent'), stats_all)
+        out._flat = stats_flat
+        return out
 
     def bc_step(self, obs, act, ent_coef=0.1, train=True):
         """One behaviour-cloning step on a demonstration (utils/mansy_utils.py:60-69) or, with train=False, its validation
@@ -822,7 +828,8 @@ class PPOPolicy(nn.Module):
                     self.updating = False
                     if self.grad_sync is not None:
                         self._check_peers()
-                    return LazyLosses(('loss', 'loss/clip', 'loss/vf', 'loss/ent'), [t.clone() for t in G['stats']])
+                    snap = G['stats_flat'].clone()           # (the graph's own tensor is overwritten by the next replay)
+                    return LazyLosses(('loss', 'loss/clip', 'loss/vf', 'loss/ent'), list(snap.split(G['stats_sizes'])))
                 # capture failed: the permutations are drawn -- run them directly
                 return self._update_body(buffer, batch_size, repeat, relabel, passes=passes)
             self._graph_seen.add(key)
@@ -867,5 +874,6 @@ class PPOPolicy(nn.Module):
             f.step, self.cnt, self._pre_eval, self.updating = step0, cnt0, pre, False
             return None
         f.step, self.cnt = step0, cnt0             # the capture executed nothing: the replay that follows takes these steps
-        G = self._graphs[key] = dict(graph=g, inp=inp, stats=res._pending, launches=nl, data=data, fresh=data is not None)
+        G = self._graphs[key] = dict(graph=g, inp=inp, stats_flat=res._flat, stats_sizes=[int(t.shape[0]) for t in res._pending], launches=nl, data=data,
+                                     fresh=data is not None)
         return G

@@ -20,7 +20,11 @@ struct AttnPtrs {
   const float* Q; const float* K; const float* V; float* O; float* P;
   const float* dO; float* dQ; float* dK; float* dV;
   float* dS_out; float* Pk_out;     // q1x4 backward, deferred dK/dV: [nb*H, Lk] score gradients / dropped probabilities
+  // bf16 images of the OUTPUT rows (bf16-storage mode, round 6; 4-heads-per-wave kernels only): the float4 stored at address a also goes, rounded, to
+  // img_s + (a - img_f) -- one mapping for O / dQ / dK / dV (they are rows of one slab).  Null: no image.
+  const float* img_f; unsigned short* img_s;
 };
+#define ATTN_IMG(p, addr, v) do { if ((p).img_s) mansy_st_bf16x4((p).img_s + ((addr) - (p).img_f), (v).x, (v).y, (v).z, (v).w); } while (0)
 
 __device__ __forceinline__ void load_rows(const float* base, long long rs, int L, int dh, int lane, float* lds) {
   for (int i = 0; i < L; ++i)
@@ -314,6 +318,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_fwd_q1x4_kernel(AttnPtrs p, A
     o.x = fmaf(pv, v[j].x, o.x); o.y = fmaf(pv, v[j].y, o.y); o.z = fmaf(pv, v[j].z, o.z); o.w = fmaf(pv, v[j].w, o.w);
   }
   *reinterpret_cast<float4*>(p.O + b * s.o_bs + col) = o;
+  ATTN_IMG(p, p.O + b * s.o_bs + col, o);
 }
 
 template <int LKT>
@@ -359,6 +364,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_q1x4_kernel(AttnPtrs p, A
     dq.x = fmaf(dS[j], k[j].x, dq.x); dq.y = fmaf(dS[j], k[j].y, dq.y); dq.z = fmaf(dS[j], k[j].z, dq.z); dq.w = fmaf(dS[j], k[j].w, dq.w);
   }
   *reinterpret_cast<float4*>(p.dQ + b * s.q_bs + col) = dq;
+  ATTN_IMG(p, p.dQ + b * s.q_bs + col, dq);
   if (p.dS_out) {          // deferred dK / dV (mansy_launch_attn_kvgrad): keep this step's coefficients, touch no K/V gradient row
     const int c = lane & 15;
 #pragma unroll
@@ -454,6 +460,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_selfpull_q1x4_kernel(Attn
     if (c == j && j < Lk) { dS_row[j] = dSj; Pk_row[j] = Pkj; }
   }
   *reinterpret_cast<float4*>(p.dQ + b * s.q_bs + col) = dq;
+  ATTN_IMG(p, p.dQ + b * s.q_bs + col, dq);
   float4 dk = make_float4(dS_own * q.x, dS_own * q.y, dS_own * q.z, dS_own * q.w);
   float4 dv = make_float4(Pk_own * dO.x, Pk_own * dO.y, Pk_own * dO.z, Pk_own * dO.w);
   for (int i0 = sp.step + 1; i0 < sp.T; i0 += 4) {          // later steps, four at a time: 8 row loads in flight
@@ -476,6 +483,8 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_selfpull_q1x4_kernel(Attn
   }
   *reinterpret_cast<float4*>(p.dK + b * s.k_bs + sp.step * s.k_rs + col) = dk;
   *reinterpret_cast<float4*>(p.dV + b * s.v_bs + sp.step * s.v_rs + col) = dv;
+  ATTN_IMG(p, p.dK + b * s.k_bs + sp.step * s.k_rs + col, dk);
+  ATTN_IMG(p, p.dV + b * s.v_bs + sp.step * s.v_rs + col, dv);
 }
 
 // Deferred K/V gradients of a Lq == 1 attention evaluated at TT query steps against the SAME K/V rows (decoder
@@ -583,6 +592,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_fwd_sx4_kernel(AttnPtrs p, At
         o.x = fmaf(pv, v[j].x, o.x); o.y = fmaf(pv, v[j].y, o.y); o.z = fmaf(pv, v[j].z, o.z); o.w = fmaf(pv, v[j].w, o.w);
       }
       *reinterpret_cast<float4*>(Ob + i * s.o_rs) = o;
+      ATTN_IMG(p, Ob + i * s.o_rs, o);
     }
   }
 }
@@ -639,6 +649,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_sx4_kernel(AttnPtrs p, At
         dq.x = fmaf(a, k[j].x, dq.x); dq.y = fmaf(a, k[j].y, dq.y); dq.z = fmaf(a, k[j].z, dq.z); dq.w = fmaf(a, k[j].w, dq.w);
       }
       *reinterpret_cast<float4*>(dQb + i * s.q_rs) = dq;
+      ATTN_IMG(p, dQb + i * s.q_rs, dq);
     }
   }
   // K / V rows are dead from here; the Q rows take their registers (fetched only now: all five row sets at once would
@@ -665,6 +676,8 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_sx4_kernel(AttnPtrs p, At
       }
       *reinterpret_cast<float4*>(dKb + j * s.k_rs) = dk;
       *reinterpret_cast<float4*>(dVb + j * s.v_rs) = dv;
+      ATTN_IMG(p, dKb + j * s.k_rs, dk);
+      ATTN_IMG(p, dVb + j * s.v_rs, dv);
     }
   }
 }
@@ -722,12 +735,13 @@ int check_shape(const AttnShape& s) {
 }  // namespace
 
 int mansy_launch_attn_fwd(const float* Q, const float* K, const float* V, float* O, float* P_save, const AttnShape& s,
-                          MansyDrop drop, hipStream_t st) {
+                          MansyDrop drop, hipStream_t st, const float* img_f, unsigned short* img_s) {
   int rc = check_shape(s); if (rc) return rc;
   MANSY_REQUIRE(Q && K && V && O, "attn_fwd: null pointer");
   const long long n = (long long)s.nb * s.H;
   if (n == 0) return MANSY_OK;
-  AttnPtrs p = {Q, K, V, O, P_save, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  AttnPtrs p = {Q, K, V, O, P_save, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, img_f, img_s};
+  MANSY_REQUIRE(!img_s || q1x4_ok(s, Q, K, V, O) || sx4_ok(s, Q, K, V, O), "attn_fwd: the bf16 image needs the 4-heads-per-wave kernels");
   if (q1x4_ok(s, Q, K, V, O))
     MANSY_Q1X4_DISPATCH(attn_fwd_q1x4_kernel, s.Lk, dim3(mansy_ceil_div(n / 4, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop)
   else if (sx4_ok(s, Q, K, V, O))
@@ -739,12 +753,13 @@ int mansy_launch_attn_fwd(const float* Q, const float* K, const float* V, float*
 }
 
 int mansy_launch_attn_bwd(const float* Q, const float* K, const float* V, const float* P_save, const float* dO, float* dQ,
-                          float* dK, float* dV, const AttnShape& s, MansyDrop drop, int accum_kv, hipStream_t st) {
+                          float* dK, float* dV, const AttnShape& s, MansyDrop drop, int accum_kv, hipStream_t st, const float* img_f, unsigned short* img_s) {
   int rc = check_shape(s); if (rc) return rc;
   MANSY_REQUIRE(Q && K && V && P_save && dO && dQ && dK && dV, "attn_bwd: null pointer");
   const long long n = (long long)s.nb * s.H;
   if (n == 0) return MANSY_OK;
-  AttnPtrs p = {Q, K, V, nullptr, const_cast<float*>(P_save), dO, dQ, dK, dV, nullptr, nullptr};
+  AttnPtrs p = {Q, K, V, nullptr, const_cast<float*>(P_save), dO, dQ, dK, dV, nullptr, nullptr, img_f, img_s};
+  MANSY_REQUIRE(!img_s || (sx4_ok(s, Q, K, V, dO) && sx4_ok(s, dQ, dK, dV, dO) && !q1x4_ok(s, Q, K, V, dO)), "attn_bwd: the bf16 image is kept by the encoder (S x S) kernel only");
   if (q1x4_ok(s, Q, K, V, dO) && q1x4_ok(s, dQ, dK, dV, dO))
     MANSY_Q1X4_DISPATCH(attn_bwd_q1x4_kernel, s.Lk, dim3(mansy_ceil_div(n / 4, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop, accum_kv)
   else if (sx4_ok(s, Q, K, V, dO) && sx4_ok(s, dQ, dK, dV, dO))
@@ -762,13 +777,13 @@ int mansy_attn_deferred_kv_ok(const AttnShape& s, int T) {
 }
 // One step: dQ only; dS_out / Pk_out [nb*H, Lk] receive the coefficients mansy_launch_attn_kvgrad sums over the steps.
 int mansy_launch_attn_bwd_dq(const float* Q, const float* K, const float* V, const float* P_save, const float* dO, float* dQ,
-                             float* dS_out, float* Pk_out, const AttnShape& s, MansyDrop drop, hipStream_t st) {
+                             float* dS_out, float* Pk_out, const AttnShape& s, MansyDrop drop, hipStream_t st, const float* img_f, unsigned short* img_s) {
   int rc = check_shape(s); if (rc) return rc;
   MANSY_REQUIRE(Q && K && V && P_save && dO && dQ && dS_out && Pk_out, "attn_bwd_dq: null pointer");
   MANSY_REQUIRE(q1x4_ok(s, Q, K, V, dO) && q1x4_ok(s, dQ, K, V, dO), "attn_bwd_dq: shape / alignment not on the 4-heads-per-wave path");
   const long long n = (long long)s.nb * s.H;
   if (n == 0) return MANSY_OK;
-  AttnPtrs p = {Q, K, V, nullptr, const_cast<float*>(P_save), dO, dQ, nullptr, nullptr, dS_out, Pk_out};
+  AttnPtrs p = {Q, K, V, nullptr, const_cast<float*>(P_save), dO, dQ, nullptr, nullptr, dS_out, Pk_out, img_f, img_s};
   MANSY_Q1X4_DISPATCH(attn_bwd_q1x4_kernel, s.Lk, dim3(mansy_ceil_div(n / 4, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop, 0)
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
@@ -796,7 +811,7 @@ int mansy_launch_attn_kvgrad(const float* Q_all, long long q_ts, const float* dO
 int mansy_attn_selfpull_ok(const AttnShape& s, int T) { return mansy_attn_deferred_kv_ok(s, T); }
 int mansy_launch_attn_bwd_selfpull(const float* Q_all, long long q_ts, const float* K, const float* V, const float* P_save,
                                    const float* dO_all, long long o_ts, float* dQ, float* dK, float* dV, float* dS_all, float* Pk_all,
-                                   const AttnShape& s, int T, int step, MansyDrop drop, hipStream_t st) {
+                                   const AttnShape& s, int T, int step, MansyDrop drop, hipStream_t st, const float* img_f, unsigned short* img_s) {
   int rc = check_shape(s); if (rc) return rc;
   MANSY_REQUIRE(Q_all && K && V && P_save && dO_all && dQ && dK && dV && dS_all && Pk_all, "attn_bwd_selfpull: null pointer");
   MANSY_REQUIRE(step >= 0 && step < T && s.Lk == step + 1 && mansy_attn_selfpull_ok(s, T) && (q_ts % 4) == 0 && (o_ts % 4) == 0,
@@ -804,7 +819,7 @@ int mansy_launch_attn_bwd_selfpull(const float* Q_all, long long q_ts, const flo
   MANSY_REQUIRE(q1x4_ok(s, Q_all, K, V, dO_all) && q1x4_ok(s, dQ, dK, dV, dO_all), "attn_bwd_selfpull: alignment");
   const long long n = (long long)s.nb * s.H;
   if (n == 0) return MANSY_OK;
-  AttnPtrs p = {nullptr, K, V, nullptr, const_cast<float*>(P_save), nullptr, dQ, dK, dV, nullptr, nullptr};
+  AttnPtrs p = {nullptr, K, V, nullptr, const_cast<float*>(P_save), nullptr, dQ, dK, dV, nullptr, nullptr, img_f, img_s};
   SelfPull sp = {Q_all, q_ts, dO_all, o_ts, dS_all, Pk_all, T, step};
   MANSY_Q1X4_DISPATCH(attn_bwd_selfpull_q1x4_kernel, s.Lk, dim3(mansy_ceil_div(n / 4, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop, sp)
   MANSY_LAUNCH_CHECK();

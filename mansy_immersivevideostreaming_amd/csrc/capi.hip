@@ -65,6 +65,22 @@ int mansy_gemm_planes(const float* A, int lda, const float* B, int ldb, int b_km
   return mansy_launch_gemm_f32(A, lda, 0, B, ldb, b_kmajor, C, ldc, M, N, K, e, force_tile, 0, (hipStream_t)stream);
 }
 
+int mansy_gemm_bf16(const uint16_t* A16, int lda, int a_kmajor, const uint16_t* B16, int ldb, int b_kmajor, float* C, int ldc, uint16_t* C16, int ldc16,
+                    int M, int N, int K, const mansy_gemm_epilogue* ep, int force_tile, int force_splitk, void* stream) {
+  GemmEpilogue e;
+  if (ep) {
+    e.bias = ep->bias; e.relu = ep->relu; e.mask_src = ep->mask_src; e.mask_ld = ep->mask_ld; e.mask_scale = ep->mask_scale;
+    e.drop.p = ep->drop_p; e.drop.seed = ep->drop_seed; e.drop.site = ep->drop_site;
+    e.resid = ep->resid; e.resid_ld = ep->resid_ld; e.accumulate = ep->accumulate; e.a_rowsum = ep->a_rowsum;
+  }
+  MANSY_REQUIRE(A16 && B16, "gemm_bf16: null operand");
+  MANSY_REQUIRE(force_tile == 0 || force_tile == 64 || force_tile == 96 || force_tile == 128, "gemm_bf16: force_tile must be 0, 64, 96 (128x64) or 128");
+  e.prec = 1; e.a16 = A16; e.a16_ld = lda; e.c16 = C16; e.c16_ld = ldc16;
+  if (a_kmajor && b_kmajor) { e.b16 = B16; e.b16_ld = ldb; }
+  else { MANSY_REQUIRE(!a_kmajor && !b_kmajor, "gemm_bf16: forms are (K-contiguous A, B [N, K] K-contiguous) and (K-major A, K-major B)"); e.b_planes = B16; e.b_planes_ld = ldb; e.b_plane_stride = 0; }
+  return mansy_launch_gemm_bf16a(a_kmajor, b_kmajor, C, ldc, M, N, K, e, force_tile, force_splitk, (hipStream_t)stream);
+}
+
 static AttnShape to_shape(const mansy_attn_shape* s) {
   AttnShape a;
   a.nb = s->nb; a.H = s->H; a.Lq = s->Lq; a.Lk = s->Lk; a.dh = s->dh;

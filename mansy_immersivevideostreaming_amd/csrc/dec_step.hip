@@ -61,6 +61,7 @@ __global__ __launch_bounds__(256) void dec_tail_fwd_kernel(MansyDecTailFwd p) {
     y[i].x = (v[i].x - mu) * rs * w3[i].x + b3[i].x; y[i].y = (v[i].y - mu) * rs * w3[i].y + b3[i].y;
     y[i].z = (v[i].z - mu) * rs * w3[i].z + b3[i].z; y[i].w = (v[i].w - mu) * rs * w3[i].w + b3[i].w;
     *reinterpret_cast<float4*>(p.y3 + base + i * 256) = y[i];
+    if (p.y3_16) mansy_st_bf16x4(p.y3_16 + base + i * 256, y[i].x, y[i].y, y[i].z, y[i].w);
   }
   // ---- dec_out = LN_dec(y3)
   s = 0.f;
@@ -137,6 +138,7 @@ __global__ __launch_bounds__(256) void dec_tail_fwd_kernel(MansyDecTailFwd p) {
         e[j] = a;
       }
       *reinterpret_cast<float4*>(p.emb_next + base + i * 256) = *reinterpret_cast<const float4*>(e);
+      if (p.emb_next16) mansy_st_bf16x4(p.emb_next16 + base + i * 256, e[0], e[1], e[2], e[3]);
     }
   }
 }
@@ -282,6 +284,7 @@ __global__ __launch_bounds__(64 * HEAD_WAVES) void dec_head_bwd_kernel(MansyDecH
         od.w = mansy_keep(p.drop3.seed, p.drop3.site, p.drop3.base + (uint32_t)(off + 3), p.drop3.p) ? o.w * dsc : 0.f;
       }
       *reinterpret_cast<float4*>(p.dbr3 + off) = od;
+      if (p.dbr3_16) mansy_st_bf16x4(p.dbr3_16 + off, od.x, od.y, od.z, od.w);
       adw_3[i].x += dy3[i].x * xh[i].x; adw_3[i].y += dy3[i].y * xh[i].y; adw_3[i].z += dy3[i].z * xh[i].z; adw_3[i].w += dy3[i].w * xh[i].w;
       adb_3[i].x += dy3[i].x; adb_3[i].y += dy3[i].y; adb_3[i].z += dy3[i].z; adb_3[i].w += dy3[i].w;
     }

@@ -20,7 +20,7 @@ template <int V, int NS>
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict__ x, int in_ch, const float* __restrict__ W,
                                                         const float* __restrict__ b, const float* __restrict__ pe,
                                                         float* __restrict__ out, int rows, int C, int S, int pos_fixed,
-                                                        MansyDrop drop) {
+                                                        MansyDrop drop, unsigned short* __restrict__ out16) {
   const long long idx = ((long long)blockIdx.x * 256 + threadIdx.x) * V;
   if (idx >= (long long)rows * C) return;
   const int c = (int)(idx % C);
@@ -47,6 +47,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict_
   }
   if (V == 4) *reinterpret_cast<float4*>(out + idx) = *reinterpret_cast<const float4*>(acc);
   else out[idx] = acc[0];
+  if (out16) { if (V == 4) mansy_st_bf16x4(out16 + idx, acc[0], acc[1], acc[2], acc[3]); else mansy_st_bf16(out16 + idx, acc[0]); }
 }
 
 // Many-row form (encoder: rows = B*S): a thread keeps its 4 channels' weights / bias in registers and walks rows, so a
@@ -57,7 +58,7 @@ template <int NS>
 __global__ __launch_bounds__(256) void embed_fwd_rows_kernel(const float* __restrict__ x, int in_ch, const float* __restrict__ W,
                                                              const float* __restrict__ b, const float* __restrict__ pe,
                                                              float* __restrict__ out, int rows, int C, int S, int pos_fixed,
-                                                             MansyDrop drop, int rows_per_wg) {
+                                                             MansyDrop drop, int rows_per_wg, unsigned short* __restrict__ out16) {
   constexpr int NK = small_bound<NS>();
   const int C4 = C >> 2, rpi = 256 / C4;                 // rows per iteration of the workgroup
   const int c = (threadIdx.x % C4) * 4, rsub = threadIdx.x / C4;
@@ -90,6 +91,7 @@ __global__ __launch_bounds__(256) void embed_fwd_rows_kernel(const float* __rest
       acc[j] = a;
     }
     *reinterpret_cast<float4*>(out + idx) = *reinterpret_cast<const float4*>(acc);
+    if (out16) mansy_st_bf16x4(out16 + idx, acc[0], acc[1], acc[2], acc[3]);
   }
 }
 
@@ -348,7 +350,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 // circular k=3 im2col for the DistillLayer conv: col[row, ci*3 + t] = x[(b, (s + t - 1) mod S), ci].
 // V = 4: a thread takes 4 channels: three 16-byte row reads (s-1, s, s+1), three 16-byte stores (12 contiguous floats).
 template <int V>
-__global__ __launch_bounds__(256) void im2col3_kernel(const float* __restrict__ x, float* __restrict__ col, int B, int S, int C) {
+__global__ __launch_bounds__(256) void im2col3_kernel(const float* __restrict__ x, float* __restrict__ col, int B, int S, int C, unsigned short* __restrict__ col16) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;     // over [B*S, C/V]
   const int CV = C / V;
   if (idx >= (long long)B * S * CV) return;
@@ -371,6 +373,10 @@ __global__ __launch_bounds__(256) void im2col3_kernel(const float* __restrict__ 
   if (V == 4) {
 #pragma unroll
     for (int q = 0; q < 3; ++q) *reinterpret_cast<float4*>(dst + 4 * q) = *reinterpret_cast<const float4*>(o + 4 * q);
+    if (col16) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) mansy_st_bf16x4(col16 + row * (3LL * C) + 3 * ci + 4 * q, o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+    }
   } else {
     dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
   }
@@ -590,7 +596,7 @@ int mansy_launch_periodic_mse(const float* a, const float* b, long long rows, in
 }
 
 int mansy_launch_embed_fwd(const float* x, int in_ch, const float* W, const float* b, const float* pe, float* out, int rows,
-                           int C, int S, int pos_fixed, MansyDrop drop, hipStream_t st) {
+                           int C, int S, int pos_fixed, MansyDrop drop, hipStream_t st, unsigned short* out16) {
   MANSY_REQUIRE(x && W && pe && out, "embed_fwd: null pointer");
   MANSY_REQUIRE(in_ch >= 1 && in_ch <= MAX_IN, "embed_fwd: in_ch %d unsupported", in_ch);
   if (rows <= 0) return MANSY_OK;
@@ -598,12 +604,12 @@ int mansy_launch_embed_fwd(const float* x, int in_ch, const float* W, const floa
   if (vec && rows >= 8192 && 256 % (C / 4) == 0) {
     const int rpw = 8 * (256 / (C / 4));                 // 8 iterations per workgroup
     const dim3 grid(mansy_ceil_div(rows, rpw));
-    if (in_ch == 2) MANSY_LAUNCH(embed_fwd_rows_kernel<2>, grid, dim3(256), 0, st, x, in_ch, W, b, pe, out, rows, C, S, pos_fixed, drop, rpw);
-    else if (in_ch == 6) MANSY_LAUNCH(embed_fwd_rows_kernel<6>, grid, dim3(256), 0, st, x, in_ch, W, b, pe, out, rows, C, S, pos_fixed, drop, rpw);
-    else MANSY_LAUNCH(embed_fwd_rows_kernel<0>, grid, dim3(256), 0, st, x, in_ch, W, b, pe, out, rows, C, S, pos_fixed, drop, rpw);
+    if (in_ch == 2) MANSY_LAUNCH(embed_fwd_rows_kernel<2>, grid, dim3(256), 0, st, x, in_ch, W, b, pe, out, rows, C, S, pos_fixed, drop, rpw, out16);
+    else if (in_ch == 6) MANSY_LAUNCH(embed_fwd_rows_kernel<6>, grid, dim3(256), 0, st, x, in_ch, W, b, pe, out, rows, C, S, pos_fixed, drop, rpw, out16);
+    else MANSY_LAUNCH(embed_fwd_rows_kernel<0>, grid, dim3(256), 0, st, x, in_ch, W, b, pe, out, rows, C, S, pos_fixed, drop, rpw, out16);
   } else {
     MANSY_SMALL_DISPATCH(embed_fwd_kernel, vec, in_ch, g1((long long)rows * C / 4), g1((long long)rows * C),
-                         x, in_ch, W, b, pe, out, rows, C, S, pos_fixed, drop);
+                         x, in_ch, W, b, pe, out, rows, C, S, pos_fixed, drop, out16);
   }
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
@@ -682,11 +688,11 @@ int mansy_launch_adamw(float* p, const float* g, float* m, float* v, long long n
   return MANSY_OK;
 }
 
-int mansy_launch_im2col3(const float* x, float* col, int B, int S, int C, hipStream_t st) {
+int mansy_launch_im2col3(const float* x, float* col, int B, int S, int C, hipStream_t st, unsigned short* col16) {
   MANSY_REQUIRE(x && col, "im2col3: null pointer");
   if ((long long)B * S * C <= 0) return MANSY_OK;
-  if (C % 4 == 0 && al16(x) && al16(col)) MANSY_LAUNCH(im2col3_kernel<4>, g1((long long)B * S * C / 4), dim3(256), 0, st, x, col, B, S, C);
-  else MANSY_LAUNCH(im2col3_kernel<1>, g1((long long)B * S * C), dim3(256), 0, st, x, col, B, S, C);
+  if (C % 4 == 0 && al16(x) && al16(col)) MANSY_LAUNCH(im2col3_kernel<4>, g1((long long)B * S * C / 4), dim3(256), 0, st, x, col, B, S, C, col16);
+  else MANSY_LAUNCH(im2col3_kernel<1>, g1((long long)B * S * C), dim3(256), 0, st, x, col, B, S, C, (unsigned short*)nullptr);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }

@@ -1,0 +1,303 @@
+// bf16-STORAGE products of the MANSY_PREC_BF16 perf mode (round 6): both operands are bf16 IN HBM and are staged by LDS-DMA as they are
+// -- no conversion on the way into LDS, half the HBM and L2 -> LDS bytes of the fp32-operand loops (gemm_bf16s.hip rounds fp32 operands at
+// fragment read: same arithmetic, twice the traffic) -- one v_mfma_f32_32x32x16_bf16 product, fp32 accumulate, the shared fused epilogue
+// (gemm_tile.h) which can store C as fp32, as bf16 (GemmEpilogue::c16), or both.
+//
+//   NN  (forward and dX products):  A16 [M, K] K-contiguous (an activation's bf16 image), B = a weight's leading bf16 plane [N, K]
+//       K-contiguous (GemmEpilogue::b_planes: W for the forward, W^T for dX).  K-tile = 64 bf16 = 128-byte rows: the LDS image, its XOR
+//       swizzle and the DMA piece geometry are those of the fp32 LDS-DMA loop (gemm_f32.hip); NS-stage ring with counted vmcnt waits and one
+//       raw s_barrier per K-tile as gemm_bf16h_kernel.  Fragment of lane (r = lane & 31, h = lane >> 5) at k-step s: the 16 bytes at chunk
+//       2 s + h of row r -- one ds_read_b128 per operand block and k-step.
+//   TN  (weight gradients dW = dY^T X): A16 = dY [K = rows, M] and B16 = X [K = rows, N], both K-MAJOR (rows of the activation slabs as
+//       they lie in HBM).  A K-tile is 64 rows of 128 columns = 256-byte LDS rows; the MFMA wants 8 consecutive k of ONE column per lane,
+//       i.e. a column of the image: ds_read_b64_tr_b16 (gfx950's transposing LDS read: per 16-lane group a 4-row x 16-column block,
+//       delivered column-major) -- two per operand block and k-step, on the guide's conflict-free image (b): 16-byte chunk ch of row k at
+//       256 k + 16 (ch ^ (((k & 3) << 2) | ((k >> 2) & 3))).  Split-K over the rows with atomic accumulation (as the fp32 dW products);
+//       the bias-gradient rider (row sums of dY^T) is one more MFMA per A block against a fragment of ones, in the first column tile only.
+#include "gemm_tile.h"
+
+using namespace mansy_gemm;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int BK16 = 64;          // bf16 elements per K-tile (128 bytes per K-contiguous row)
+
+// ------------------------------------------------------------------------------------------------------------------------------ NN
+template <int BM, int BN, int NS>
+__global__ __launch_bounds__(NT, (BM * BN <= 128 * 64) ? 2 : 1) void gemm_bf16a_nn_kernel(GemmParams p) {
+  constexpr int TM = BM / 64, TN = BN / 64 > 0 ? BN / 64 : 1, PA = BM / 32, PB = BN / 32, D = NS - 1;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int C_FLOATS = BM * (BN + 4);
+  constexpr int SMEM_FLOATS = (NS * STAGE_BYTES / 4) > C_FLOATS ? (NS * STAGE_BYTES / 4) : C_FLOATS;
+  constexpr int PPT = PA + PB;                                                                  // DMA pieces per wave and K-tile
+  static_assert(BN >= 64 && NS >= 2 && NS <= 4 && 2 * PPT <= 63, "piece counts must fit the counted waits");
+  __shared__ __attribute__((aligned(1024))) float smem[SMEM_FLOATS];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  int tile_x, tile_y;
+  {   // XCD-aware bijective remap: consecutive tiles (row panel by row panel) stay on one XCD, whose L2 then holds ONE A panel and the weight plane
+    const int nwg = gridDim.x * gridDim.y, orig = blockIdx.y * gridDim.x + blockIdx.x;
+    const int q = nwg >> 3, rem = nwg & 7, xcd = orig & 7, local = orig >> 3;
+    const int t = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + local;
+    tile_y = t / gridDim.x; tile_x = t - tile_y * gridDim.x;
+  }
+  const int m0 = tile_y * BM, n0 = tile_x * BN;
+  const int nk = p.K / BK16;
+  const unsigned short* const A16 = p.ep.a16;
+  const int lda = p.ep.a16_ld, ldb = p.ep.b_planes_ld;
+
+  // per-lane source byte offsets of this wave's DMA pieces (lane L of a piece lands at LDS piece base + 16 L: row L >> 3, slot L & 7 of a
+  // 128-byte row; the XOR swizzle is applied on the SOURCE side: slot s of row `row` receives chunk s ^ ((row >> 1) & 7))
+  unsigned voa[PA], vob[PB];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int row = i * 32 + wave * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    voa[i] = (unsigned)(((min(m0 + row, p.M - 1) - m0) * lda + c * 8) * 2);
+  }
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    const int row = i * 32 + wave * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    vob[i] = (unsigned)(((min(n0 + row, p.N - 1) - n0) * ldb + c * 8) * 2);
+  }
+  const unsigned short* const ca = A16 + (long long)m0 * lda;
+  const unsigned short* const cb = p.ep.b_planes + (long long)n0 * ldb;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem + (unsigned)wave * 1024u);
+  auto dma = [&](int stage, int kt) {
+    const unsigned base = lds0 + (unsigned)(stage * STAGE_BYTES);
+    const unsigned short* a_corner = ca + (long long)kt * BK16;
+    const unsigned short* b_corner = cb + (long long)kt * BK16;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) glds16(voa[i], a_corner, base + (unsigned)i * 4096u);
+#pragma unroll
+    for (int i = 0; i < PB; ++i) glds16(vob[i], b_corner, base + (unsigned)A_BYTES + (unsigned)i * 4096u);
+  };
+  // fragment byte offsets inside a stage: block row (i or j), k-step s
+  int fa[TM][4], fb[TN][4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { const int row = wm * (BM / 2) + i * 32 + r; fa[i][s] = row * 128 + (((2 * s + h) ^ ((row >> 1) & 7)) << 4); }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { const int row = wn * (BN / 2) + j * 32 + r; fb[j][s] = A_BYTES + row * 128 + (((2 * s + h) ^ ((row >> 1) & 7)) << 4); }
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (d < nk) dma(d, d);
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    // tiles still wanted in flight after tile kt has landed: min(D - 1, nk - 1 - kt) of them, PPT pieces each (the wait count is an immediate)
+    const int ahead = nk - 1 - kt;
+    if (D >= 3 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPT) : "memory");
+    else if (D >= 2 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + D < nk) dma(cur == 0 ? NS - 1 : cur - 1, kt + D);       // into the stage tile kt - 1 occupied
+    const char* const st_l = reinterpret_cast<const char*>(smem) + cur * STAGE_BYTES;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      bf16x8 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(st_l + fa[i][s]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(st_l + fb[j][s]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // LDS reads retired before the barrier that frees this buffer
+    cur = cur == NS - 1 ? 0 : cur + 1;
+  }
+  __syncthreads();                                        // staging LDS idle (every DMA was waited for): the epilogue reuses it
+  gemm_epilogue<BM, BN, SMEM_FLOATS>(p, acc, smem, m0, n0, tid, 0, p.C);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------ TN
+// ds_read_b64_tr_b16: lane 4 q + p of a 16-lane group supplies the address of row q, columns 4 p .. 4 p + 3 of the group's 4 x 16 block; lane i
+// of the group receives column i, row q in element q.  EXEC must be all ones (no divergence around it).
+__device__ __forceinline__ bf16x4 lds_tr4(unsigned addr) {
+  bf16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+
+// byte offset of 16-byte chunk ch (0..15) of row k in a [64][128 x bf16] image with 256-byte rows (guide T10, image (b))
+__device__ __forceinline__ unsigned tn_off(int k, int ch) { return (unsigned)(256 * k + 16 * (ch ^ (((k & 3) << 2) | ((k >> 2) & 3)))); }
+
+template <int NS>
+__global__ __launch_bounds__(NT, 2) void gemm_bf16a_tn_kernel(GemmParams p) {
+  constexpr int BM = 128, BN = 128, D = NS - 1;
+  constexpr int A_BYTES = BK16 * 256, B_BYTES = BK16 * 256, STAGE_BYTES = A_BYTES + B_BYTES;      // 32 KB per stage
+  constexpr int PA = 4, PB = 4, PPT = PA + PB;                                                     // 16 pieces of 1 KB per operand tile, 4 per wave
+  __shared__ __attribute__((aligned(1024))) char smem[NS * STAGE_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int split = blockIdx.z;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int k_begin = split * p.k_per_split, k_end = min(p.K, k_begin + p.k_per_split);
+  const int nk = (k_end - k_begin) / BK16;
+  const unsigned short* const A16 = p.ep.a16;           // [K][M] (dY rows), lda
+  const unsigned short* const B16 = p.ep.b16;           // [K][N] (X rows), ldb
+  const int lda = p.ep.a16_ld, ldb = p.ep.b16_ld;
+
+  // DMA: piece i of wave w = rows (i * 16 + w * 4) .. + 4 of the tile (4 rows x 256 B = 1 KB); lane L -> row L >> 4, slot L & 15; source chunk =
+  // slot ^ key(row).  Columns beyond M / N are clamped onto the last whole 8-column chunk (their accumulators are never stored).
+  unsigned voa[PA], vob[PB];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int k = i * 16 + wave * 4 + (lane >> 4);
+    const int ch = (lane & 15) ^ (((k & 3) << 2) | ((k >> 2) & 3));
+    voa[i] = (unsigned)((k * lda + min(ch * 8, p.M - m0 - 8)) * 2);
+    vob[i] = (unsigned)((k * ldb + min(ch * 8, p.N - n0 - 8)) * 2);
+  }
+  const unsigned short* const ca = A16 + (long long)k_begin * lda + m0;
+  const unsigned short* const cb = B16 + (long long)k_begin * ldb + n0;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem + (unsigned)wave * 1024u);
+  auto dma = [&](int stage, int kt) {
+    const unsigned base = lds0 + (unsigned)(stage * STAGE_BYTES);
+    const unsigned short* a_corner = ca + (long long)kt * BK16 * lda;
+    const unsigned short* b_corner = cb + (long long)kt * BK16 * ldb;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) glds16(voa[i], a_corner, base + (unsigned)i * 4096u);
+#pragma unroll
+    for (int i = 0; i < PB; ++i) glds16(vob[i], b_corner, base + (unsigned)A_BYTES + (unsigned)i * 4096u);
+  };
+  // transposed-read addresses: 16-lane group g = lane >> 4: column block cb16 = g & 1 (columns 16 cb16 ..), k half hh = g >> 1 (k = 8 hh ..);
+  // within the group lane 4 q + pp supplies row q, columns 4 pp ..: chunk = (column >> 3), + 8 bytes for the odd half of the chunk
+  const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+  const int cb16 = g & 1, hh = g >> 1;
+  unsigned ta[2][2], tb[2][2];        // [block][t]: byte offset at k-step 0 (k-step s adds s * 16 rows); t = which 4 of the lane's 8 k
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int k = 8 * hh + 4 * t + q;
+      const int col_a = wm * 64 + blk * 32 + 16 * cb16 + 4 * pp, col_b = wn * 64 + blk * 32 + 16 * cb16 + 4 * pp;
+      ta[blk][t] = tn_off(k, col_a >> 3) + 8u * ((col_a >> 2) & 1);
+      tb[blk][t] = (unsigned)A_BYTES + tn_off(k, col_b >> 3) + 8u * ((col_b >> 2) & 1);
+    }
+  // (row k + 16 s has the same swizzle key as row k -- the key depends on k & 15 only -- so k-step s is a constant + 4096 s bytes)
+
+  f32x16 acc[2][2], rs[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) rs[i][e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  }
+  const bool want_rs = p.ep.a_rowsum != nullptr && blockIdx.x == 0 && wn == 0;       // bias gradient: row sums of dY^T, taken once per row panel
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (d < nk) dma(d, d);
+  int cur = 0;
+  const unsigned smem_base = (unsigned)(uintptr_t)smem;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int ahead = nk - 1 - kt;
+    if (D >= 3 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPT) : "memory");
+    else if (D >= 2 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + D < nk) dma(cur == 0 ? NS - 1 : cur - 1, kt + D);
+    const unsigned st_l = smem_base + (unsigned)(cur * STAGE_BYTES);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      bf16x8 af[2], bf[2];
+      bf16x4 a0[2], a1[2], b0[2], b1[2];
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) {          // all eight transposed reads of the k-step in flight, ONE wait (inline asm: the compiler counts nothing)
+        a0[blk] = lds_tr4(st_l + ta[blk][0] + 4096u * s); a1[blk] = lds_tr4(st_l + ta[blk][1] + 4096u * s);
+        b0[blk] = lds_tr4(st_l + tb[blk][0] + 4096u * s); b1[blk] = lds_tr4(st_l + tb[blk][1] + 4096u * s);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { af[blk][e] = a0[blk][e]; af[blk][4 + e] = a1[blk][e]; bf[blk][e] = b0[blk][e]; bf[blk][4 + e] = b1[blk][e]; }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        if (want_rs) rs[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], ones, rs[i], 0, 0, 0);
+      }
+    }
+    cur = cur == NS - 1 ? 0 : cur + 1;
+  }
+  // accumulate: C[m][n] += acc (fp32 atomics: the K splits and the steps' other products add into the same gradient)
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + r;
+      if (col < p.N) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (row < p.M) atomicAdd(p.C + (long long)row * p.ldc + col, acc[i][j][e]);
+        }
+      }
+    }
+    if (want_rs && r == 0) {          // every column of rs holds the row sums: column 0's lanes (0 and 32) add them
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (row < p.M) atomicAdd(p.ep.a_rowsum + row, rs[i][e]);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// NN: A16 [M, K] bf16 (ep.a16, ep.a16_ld), B = ep.b_planes [N, K] bf16.  tile: 64 (64 x 64), 96 (128 x 64) or 128 (128 x 128).
+int mansy_gemm_bf16a_nn(const GemmParams& p, int tile, hipStream_t st) {
+  auto al16 = [](const void* x) { return (reinterpret_cast<uintptr_t>(x) & 15) == 0; };
+  MANSY_REQUIRE(p.ep.a16 && p.ep.b_planes && al16(p.ep.a16) && al16(p.ep.b_planes) && p.ep.a16_ld % 8 == 0 && p.ep.b_planes_ld % 8 == 0 && p.K % BK16 == 0 &&
+                    p.K >= BK16, "bf16-storage product: operands must be 16-byte aligned with leading dimensions %% 8 == 0 and K %% 64 == 0");
+  dim3 block(NT);
+  if (tile == 128) { dim3 grid(mansy_ceil_div(p.N, 128), mansy_ceil_div(p.M, 128), 1); MANSY_GEMM_LAUNCH((gemm_bf16a_nn_kernel<128, 128, 3>), grid, block, st, p); }
+  else if (tile == 96) { dim3 grid(mansy_ceil_div(p.N, 64), mansy_ceil_div(p.M, 128), 1); MANSY_GEMM_LAUNCH((gemm_bf16a_nn_kernel<128, 64, 3>), grid, block, st, p); }
+  else { dim3 grid(mansy_ceil_div(p.N, 64), mansy_ceil_div(p.M, 64), 1); MANSY_GEMM_LAUNCH((gemm_bf16a_nn_kernel<64, 64, 4>), grid, block, st, p); }
+  MANSY_LAUNCH_CHECK();
+  return MANSY_OK;
+}
+
+// TN: C[M, N] += A16^T B16 over K rows; A16 [K, M], B16 [K, N] bf16; k_per_split % 64 == 0; M, N >= 8 and multiples of 8.
+int mansy_gemm_bf16a_tn(const GemmParams& p, int splits, hipStream_t st) {
+  auto al16 = [](const void* x) { return (reinterpret_cast<uintptr_t>(x) & 15) == 0; };
+  MANSY_REQUIRE(p.ep.a16 && p.ep.b16 && al16(p.ep.a16) && al16(p.ep.b16) && p.ep.a16_ld % 8 == 0 && p.ep.b16_ld % 8 == 0 && p.M % 8 == 0 && p.N % 8 == 0 &&
+                    p.M >= 8 && p.N >= 8 && p.K % BK16 == 0 && p.k_per_split % BK16 == 0,
+                "bf16-storage weight-gradient product: 16-byte aligned operands, M, N multiples of 8, K and the split length multiples of 64");
+  dim3 grid(mansy_ceil_div(p.N, 128), mansy_ceil_div(p.M, 128), splits), block(NT);
+  MANSY_GEMM_LAUNCH((gemm_bf16a_tn_kernel<2>), grid, block, st, p);
+  MANSY_LAUNCH_CHECK();
+  return MANSY_OK;
+}

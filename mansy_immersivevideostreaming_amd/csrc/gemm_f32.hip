@@ -700,6 +700,59 @@ int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B,
 }
 
 
+// bf16-storage products (round 6; csrc/gemm_bf16a.hip): operands are bf16 images in HBM (ep.a16 + a weight plane ep.b_planes for the forward / dX
+// form, ep.a16 + ep.b16 K-major for the weight-gradient form); C fp32 (nullable when ep.c16 takes the output).  force_tile: 0 = by shape, 64 / 96 / 128.
+int mansy_launch_gemm_bf16a(int a_kmajor, int b_kmajor, float* C, int ldc, int M, int N, int K, const GemmEpilogue& ep, int force_tile, int force_splitk,
+                            hipStream_t st) {
+  MANSY_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm: negative dimension");
+  if (M == 0 || N == 0) return MANSY_OK;
+  MANSY_REQUIRE(ep.a16 && (C || ep.c16), "bf16-storage product: needs a16 and an output (C or c16)");
+  GemmParams p;
+  p.A = nullptr; p.B = nullptr; p.C = C; p.lda = ep.a16_ld; p.ldb = 0; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.ep = ep;
+  auto al16 = [](const void* x) { return (reinterpret_cast<uintptr_t>(x) & 15) == 0; };
+  auto al8 = [](const void* x) { return (reinterpret_cast<uintptr_t>(x) & 7) == 0; };
+  p.vec_ok = 1;
+  p.c_vec_ok = al16(C) && (!C || ldc % 4 == 0) && (N % 4 == 0) && (!ep.bias || al16(ep.bias)) && (!ep.c16 || (al8(ep.c16) && ep.c16_ld % 4 == 0)) &&
+               (!ep.mask_src || (al16(ep.mask_src) && ep.mask_ld % 4 == 0)) && (!ep.resid || (al16(ep.resid) && ep.resid_ld % 4 == 0)) && !ep.pre_a;
+  int rc;
+  double flops = 2.0 * (double)M * (double)N * (double)K;
+  const bool timed = g_prof.on;
+  if (timed) {
+    if (g_prof.used + 2 > g_prof.ev.size()) { for (int i = 0; i < 2; ++i) { hipEvent_t e; MANSY_HIP_CHECK(hipEventCreate(&e)); g_prof.ev.push_back(e); } }
+    mansy_gemm::g_ev_start = g_prof.ev[g_prof.used]; mansy_gemm::g_ev_stop = g_prof.ev[g_prof.used + 1];
+  }
+  if (a_kmajor && b_kmajor) {
+    MANSY_REQUIRE(ep.b16 && C && !ep.c16 && !ep.bias && !ep.relu && !ep.mask_src && ep.drop.p == 0.f && !ep.resid && ep.accumulate,
+                  "bf16-storage weight-gradient product: plain accumulating epilogue, K-major b16");
+    // split-K over the rows: one round of resident workgroups (2 per CU), at least 8 K-tiles of 64 per split
+    const long long tiles = (long long)mansy_ceil_div(M, 128) * mansy_ceil_div(N, 128);
+    int splits = force_splitk > 0 ? force_splitk : (int)(512 / tiles);
+    if (splits < 1) splits = 1;
+    const int max_splits = K / (64 * 8) > 0 ? K / (64 * 8) : 1;
+    if (splits > max_splits) splits = max_splits;
+    int kps = mansy_ceil_div(mansy_ceil_div(K, splits), 64) * 64;
+    if (kps <= 0) kps = 64;
+    splits = mansy_ceil_div(K, kps);
+    p.k_per_split = kps; p.splits_pp = splits;
+    rc = mansy_gemm_bf16a_tn(p, splits, st);
+  } else {
+    MANSY_REQUIRE(!a_kmajor && ep.b_planes && !ep.accumulate && ep.split_slab == 0 && p.c_vec_ok,
+                  "bf16-storage forward / dX product: K-contiguous a16, a weight plane, a storing row-major epilogue");
+    int tile = force_tile;
+    if (!tile) {
+      // [40 960-row] products: 128 x 128 (least L2 -> LDS traffic per flop) once that fills the chip; the [4 096-row] decoder-step products: 128 x 64
+      // = one workgroup per CU in ONE round (a launch of this size is latency-bound: fewer, fatter workgroups dispatch and drain faster)
+      const long long t128 = (long long)mansy_ceil_div(M, 128) * mansy_ceil_div(N, 128);
+      const long long t96 = (long long)mansy_ceil_div(M, 128) * mansy_ceil_div(N, 64);
+      tile = t128 >= 512 ? 128 : (t96 >= 192 ? 96 : 64);
+    }
+    p.k_per_split = K; p.splits_pp = 1;
+    rc = mansy_gemm_bf16a_nn(p, tile, st);
+  }
+  if (timed) { mansy_gemm::g_ev_start = mansy_gemm::g_ev_stop = nullptr; g_prof.used += 2; g_prof.flops += flops; }
+  return rc;
+}
+
 int mansy_gemm_effective_splits(int K, int requested) {
   if (requested <= 1 || K <= 0) return 1;
   int kps = mansy_ceil_div(mansy_ceil_div(K, requested), BK) * BK;

@@ -103,7 +103,12 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, const fl
         v.w = mansy_keep(ep.drop.seed, ep.drop.site, ep.drop.base + base + 3, ep.drop.p) ? v.w * drop_scale : 0.f;
       }
       v.x += rr[u].x; v.y += rr[u].y; v.z += rr[u].z; v.w += rr[u].w;
-      *reinterpret_cast<float4*>(Cz + (long long)row * p.ldc + col) = v;
+      if (Cz) *reinterpret_cast<float4*>(Cz + (long long)row * p.ldc + col) = v;
+      if (ep.c16) {          // bf16 image of the output (round 6: the bf16-storage mode's consumers read this one)
+        typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+        bf16x4_t o; o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+        *reinterpret_cast<bf16x4_t*>(ep.c16 + (long long)row * ep.c16_ld + col) = o;
+      }
     }
   }
 }
@@ -206,6 +211,9 @@ __device__ __forceinline__ void glds16(unsigned voff, const void* sbase, unsigne
 
 }  // namespace mansy_gemm
 
+// bf16-storage products (gemm_bf16a.hip): A16 / B planes K-contiguous (NN) and the K-major weight-gradient form (TN)
+int mansy_gemm_bf16a_nn(const mansy_gemm::GemmParams& p, int tile, hipStream_t st);
+int mansy_gemm_bf16a_tn(const mansy_gemm::GemmParams& p, int splits, hipStream_t st);
 // capture of wave-split-K launches (gemm_f32.hip): see there
 int mansy_gemm_capture_begin();
 int mansy_gemm_capture_end(mansy_gemm::GemmParams* out, int* variant, int* gx, int* gy, int* gz, int max_n);

@@ -95,3 +95,13 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 static inline int mansy_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- bf16 images of activations (MANSY_PREC_BF16 with bf16 storage, round 6): a row-wise kernel that produces an operand of a dense product also
+// stores its bf16 image (round to nearest even, what v_cvt_pk_bf16_f32 does), which the product then stages by LDS-DMA as it is (csrc/gemm_bf16a.hip).
+// `p16` is the image's address for the SAME element index as the float store; null = no image wanted.
+typedef __bf16 mansy_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mansy_st_bf16x4(unsigned short* p16, float x, float y, float z, float w) {
+  mansy_bf16x4 o; o[0] = (__bf16)x; o[1] = (__bf16)y; o[2] = (__bf16)z; o[3] = (__bf16)w;
+  *reinterpret_cast<mansy_bf16x4*>(p16) = o;
+}
+__device__ __forceinline__ void mansy_st_bf16(unsigned short* p16, float x) { *reinterpret_cast<__bf16*>(p16) = (__bf16)x; }

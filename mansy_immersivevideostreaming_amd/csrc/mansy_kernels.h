@@ -58,6 +58,14 @@ struct GemmEpilogue {
   // mansy_launch_weight_planes): plane t of B(k, n) at b_planes[t * b_plane_stride + n * b_planes_ld + k] (K-contiguous rows, 16-byte
   // aligned, b_planes_ld % 8 == 0).  With a K-contiguous A the product then stages B by LDS-DMA: no split work and no ds_write for it.
   const unsigned short* b_planes = nullptr; long long b_plane_stride = 0; int b_planes_ld = 0;
+  // bf16-STORAGE products (MANSY_PREC_BF16 only, round 6; csrc/gemm_bf16a.hip): the operands as bf16 images in HBM, staged by LDS-DMA without any
+  // conversion.  a16: the A operand in A's own logical layout (K-contiguous [M, K] or K-major [K, M]), leading dimension a16_ld (elements);
+  // b16: a K-major B ([K, N]: the X of a weight-gradient product), b16_ld.  With a16 set the float A / B pointers are not read.
+  const unsigned short* a16 = nullptr; int a16_ld = 0;
+  const unsigned short* b16 = nullptr; int b16_ld = 0;
+  // optional bf16 image of the OUTPUT (after the whole epilogue), written next to -- or, with a null C, instead of -- the fp32 store
+  // (row-major float4 epilogue only: c_vec_ok and no accumulation)
+  unsigned short* c16 = nullptr; int c16_ld = 0;
 };
 
 // ---- decoding of GemmEpilogue::variant (bit layout: include/mansy_hip.h, MANSY_VARIANT_*).  A release build has NO process-wide knob: a call
@@ -84,6 +92,9 @@ struct MansyWPlaneTab { const float* w[MANSY_WPLANE_MAX]; int N[MANSY_WPLANE_MAX
 int mansy_launch_weight_planes(const MansyWPlaneTab& tab, unsigned short* out, unsigned short* out_t, long long plane_stride, int n_planes,
                                hipStream_t st);
 int mansy_gemm_effective_splits(int K, int requested);
+// bf16-storage products (MANSY_PREC_BF16 with bf16 images of the operands: GemmEpilogue::a16 + b_planes, or a16 + b16 for dW = dY^T X)
+int mansy_launch_gemm_bf16a(int a_kmajor, int b_kmajor, float* C, int ldc, int M, int N, int K, const GemmEpilogue& ep, int force_tile, int force_splitk,
+                            hipStream_t st);
 int mansy_launch_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb, int b_kmajor,
                           float* C, int ldc, int M, int N, int K, const GemmEpilogue& ep, int force_tile,
                           int force_splitk, hipStream_t st);
@@ -99,13 +110,14 @@ struct AttnShape {
   float scale;
 };
 // P_save: [nb*H, Lq, Lk] softmax probabilities BEFORE dropout (needed by backward); may be null in eval.
+// img_f / img_s (all attention launchers; bf16-storage mode): the output rows' bf16 image -- the float4 stored at address a also goes to img_s + (a - img_f)
 int mansy_launch_attn_fwd(const float* Q, const float* K, const float* V, float* O, float* P_save,
-                          const AttnShape& s, MansyDrop drop, hipStream_t st);
+                          const AttnShape& s, MansyDrop drop, hipStream_t st, const float* img_f = nullptr, unsigned short* img_s = nullptr);
 // dQ is overwritten; dK/dV are accumulated (+=) when accum_kv != 0, else overwritten.
 // dq/dk/dv use the q/k/v strides of `s`; dO uses the o strides.
 int mansy_launch_attn_bwd(const float* Q, const float* K, const float* V, const float* P_save, const float* dO,
                           float* dQ, float* dK, float* dV, const AttnShape& s, MansyDrop drop, int accum_kv,
-                          hipStream_t st);
+                          hipStream_t st, const float* img_f = nullptr, unsigned short* img_s = nullptr);
 
 // Deferred K/V gradients for a Lq == 1 attention evaluated at T steps against the same K/V rows (decoder cross-attention):
 // per step mansy_launch_attn_bwd_dq writes dQ and the step's coefficients (dS, dropped P: [nb*H, Lk] each); one
@@ -113,7 +125,8 @@ int mansy_launch_attn_bwd(const float* Q, const float* K, const float* V, const 
 // Q_all / dO_all hold step i at + i*q_ts / + i*o_ts; dS_all / Pk_all are [T][nb*H][Lk].
 int mansy_attn_deferred_kv_ok(const AttnShape& s, int T);
 int mansy_launch_attn_bwd_dq(const float* Q, const float* K, const float* V, const float* P_save, const float* dO, float* dQ,
-                             float* dS_out, float* Pk_out, const AttnShape& s, MansyDrop drop, hipStream_t st);
+                             float* dS_out, float* Pk_out, const AttnShape& s, MansyDrop drop, hipStream_t st,
+                             const float* img_f = nullptr, unsigned short* img_s = nullptr);
 int mansy_launch_attn_kvgrad(const float* Q_all, long long q_ts, const float* dO_all, long long o_ts, const float* dS_all,
                              const float* Pk_all, float* dK, float* dV, const AttnShape& s, int T, int accum, hipStream_t st);
 
@@ -123,12 +136,14 @@ int mansy_launch_attn_kvgrad(const float* Q_all, long long q_ts, const float* dO
 int mansy_attn_selfpull_ok(const AttnShape& s, int T);
 int mansy_launch_attn_bwd_selfpull(const float* Q_all, long long q_ts, const float* K, const float* V, const float* P_save,
                                    const float* dO_all, long long o_ts, float* dQ, float* dK, float* dV, float* dS_all, float* Pk_all,
-                                   const AttnShape& s, int T, int step, MansyDrop drop, hipStream_t st);
+                                   const AttnShape& s, int T, int step, MansyDrop drop, hipStream_t st,
+                                   const float* img_f = nullptr, unsigned short* img_s = nullptr);
 
 // ---------------------------------------------------------------- norms (norm.hip)
 // z = a (+ b);  y = LN(z) * w (+ bias).  z_out may be null (not saved) or alias a when b == null.
 int mansy_launch_layernorm_fwd(const float* a, const float* b, const float* w, const float* bias, float* z_out,
-                               float* y, float* mean, float* rstd, int rows, int C, float eps, hipStream_t st);
+                               float* y, float* mean, float* rstd, int rows, int C, float eps, hipStream_t st,
+                               unsigned short* y16 = nullptr);      // y16: also store y's bf16 image (same element index; bf16-storage mode)
 // dz = LN'(dy); dz_drop (optional) = dz * dropout-mask(drop) ; dw += sum dy*xhat ; dbias += sum dy.
 // add_to (optional): dz += add_to (an extra gradient flowing into z's consumers' sum), applied before outputs.
 int mansy_launch_layernorm_bwd(const float* dy, const float* z, const float* mean, const float* rstd, const float* w,
@@ -142,7 +157,7 @@ int mansy_ln_bwd_parts(int rows);
 bool mansy_ln_bwd_partial_ok(int C);
 int mansy_launch_layernorm_bwd_partial(const float* dy, const float* z, const float* mean, const float* rstd, const float* w,
                                        float* dz, float* dz_drop, MansyDrop drop, float* partials, int accumulate, int rows, int C,
-                                       hipStream_t st);
+                                       hipStream_t st, unsigned short* dz_drop16 = nullptr);      // dz_drop16: bf16 image of dz_drop
 int mansy_launch_ln_partials_reduce(const float* partials, int nparts, int C, float* dw, float* dbias, hipStream_t st);
 // several slot sets in one launch (the end of a VP backward: every LayerNorm's weight / bias gradient)
 constexpr int LN_MULTI_MAX = 64;      // >= 2 halves x (3 x 8 layers + 1)
@@ -183,6 +198,7 @@ struct MansyDecTailFwd {
   const float* pw; const float* pb; float* tok_next; float* pred_bt; long long pred_stride;
   const float* ew; const float* eb; const float* pe_row; float* emb_next; MansyDrop edrop;
   int rows, C, C6; float eps;
+  unsigned short* y3_16 = nullptr; unsigned short* emb_next16 = nullptr;      // bf16 images of y3 / emb_next (bf16-storage mode: operands of the next products)
 };
 int mansy_dec_tail_ok(int C, int c6);
 int mansy_launch_dec_tail_fwd(const MansyDecTailFwd& p, hipStream_t st);
@@ -195,6 +211,7 @@ struct MansyDecHeadBwd {
   const float* y3; const float* md; const float* rd; const float* dn_w; float* part_dn;
   const float* z3; const float* m3; const float* r3; const float* n3_w; float* part_n3; float* gz; float* dbr3; MansyDrop drop3;
   int rows, C, C6;
+  unsigned short* dbr3_16 = nullptr;       // bf16 image of dbr3 (bf16-storage mode)
 };
 int mansy_launch_dec_head_bwd(const MansyDecHeadBwd& p, int n_slots, hipStream_t st);
 
@@ -202,7 +219,7 @@ int mansy_launch_dec_head_bwd(const MansyDecHeadBwd& p, int n_slots, hipStream_t
 // out[r, c] = sum_k x[r,k] W[c,k] + b[c] + pe[pos(r), c], dropout(site, r*C+c).
 // pos(r) = pos_fixed if pos_fixed >= 0 else (r % S).
 int mansy_launch_embed_fwd(const float* x, int in_ch, const float* W, const float* b, const float* pe, float* out,
-                           int rows, int C, int S, int pos_fixed, MansyDrop drop, hipStream_t st);
+                           int rows, int C, int S, int pos_fixed, MansyDrop drop, hipStream_t st, unsigned short* out16 = nullptr);      // out16: bf16 image of out
 // dE = dX * dropmask (stored, for the deferred dW) ; dtok[r,k] = sum_c dE[r,c] W[c,k]  (dtok may be null)
 int mansy_launch_embed_bwd(const float* dX, const float* W, float* dE, float* dtok, int in_ch, int rows, int C,
                            MansyDrop drop, hipStream_t st);
@@ -224,7 +241,7 @@ int mansy_launch_mtio_loss(const float* pred, const float* gt, long long n, floa
 int mansy_launch_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2,
                        float eps, float wd, int step, int decoupled, hipStream_t st, const float* bias_dev = nullptr);      // bias_dev: device [1 - b1^t, sqrt(1 - b2^t)] read by the kernel instead of the host's (hipGraph replays)
 // im2col for the circular k=3 conv: col[b*S+s, ci*3+t] = x[b, (s+t-1) mod S, ci]
-int mansy_launch_im2col3(const float* x, float* col, int B, int S, int C, hipStream_t st);
+int mansy_launch_im2col3(const float* x, float* col, int B, int S, int C, hipStream_t st, unsigned short* col16 = nullptr);      // col16: bf16 image of col
 // dx[b,s,ci] = sum_t dcol[b, (s-t+1) mod S, ci*3+t]
 int mansy_launch_col2im3(const float* dcol, float* dx, int B, int S, int C, hipStream_t st);
 // colsum: out[c] += sum_r x[r*ld + c]

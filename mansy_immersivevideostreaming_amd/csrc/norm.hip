@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                                                             const float* __restrict__ w, const float* __restrict__ bias,
                                                             float* __restrict__ z_out, float* __restrict__ y,
                                                             float* __restrict__ mean, float* __restrict__ rstd, int rows, int C,
-                                                            float eps) {
+                                                            float eps, unsigned short* __restrict__ y16) {
   const int lane = threadIdx.x & 63;
   const int wave_global = (blockIdx.x * 256 + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * 256) >> 6;
@@ -67,6 +67,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
       o.z = (v[i].z - mu) * rs * wv[i].z; o.w = (v[i].w - mu) * rs * wv[i].w;
       if (bias) { o.x += bv[i].x; o.y += bv[i].y; o.z += bv[i].z; o.w += bv[i].w; }
       *reinterpret_cast<float4*>(y + base + i * 256) = o;
+      if (y16) mansy_st_bf16x4(y16 + base + i * 256, o.x, o.y, o.z, o.w);
     }
   }
 }
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 const float* __restrict__ w, float* __restrict__ dz,
                                                                 float* __restrict__ dz_drop, MansyDrop drop, float* __restrict__ dw,
-                                                                float* __restrict__ dbias, int rows, int C) {
+                                                                float* __restrict__ dbias, int rows, int C, unsigned short* __restrict__ dz_drop16) {
   extern __shared__ float red[];      // [4 waves][2][C]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wave_global = (blockIdx.x * 256 + threadIdx.x) >> 6;
@@ -218,6 +219,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
               od.w = mansy_keep(drop.seed, drop.site, drop.base + (uint32_t)(off + 3), drop.p) ? o.w * dsc : 0.f;
             }
             *reinterpret_cast<float4*>(dz_drop + off) = od;
+            if (dz_drop16) mansy_st_bf16x4(dz_drop16 + off, od.x, od.y, od.z, od.w);
           }
           adw[i].x += di.x * xh[i].x; adw[i].y += di.y * xh[i].y; adw[i].z += di.z * xh[i].z; adw[i].w += di.w * xh[i].w;
           adb[i].x += di.x; adb[i].y += di.y; adb[i].z += di.z; adb[i].w += di.w;
@@ -492,16 +494,17 @@ __global__ __launch_bounds__(256) void distill_bwd_stage2(const float* __restric
 }  // namespace
 
 int mansy_launch_layernorm_fwd(const float* a, const float* b, const float* w, const float* bias, float* z_out, float* y,
-                               float* mean, float* rstd, int rows, int C, float eps, hipStream_t st) {
+                               float* mean, float* rstd, int rows, int C, float eps, hipStream_t st, unsigned short* y16) {
   MANSY_REQUIRE(a && w && y, "layernorm_fwd: null pointer");
+  MANSY_REQUIRE(!y16 || ((C % 256) == 0 && C <= 256 * LN_MAXV), "layernorm_fwd: the bf16 image needs the vectorised kernel (C %% 256 == 0)");
   if (rows <= 0) return MANSY_OK;
   const int grid = min(mansy_ceil_div(rows, 4), 2048);
   if ((C % 256) == 0 && C <= 256 * LN_MAXV) {
     switch (C / 256) {
-      case 1: MANSY_LAUNCH(layernorm_fwd_kernel<1>, dim3(grid), dim3(256), 0, st, a, b, w, bias, z_out, y, mean, rstd, rows, C, eps); break;
-      case 2: MANSY_LAUNCH(layernorm_fwd_kernel<2>, dim3(grid), dim3(256), 0, st, a, b, w, bias, z_out, y, mean, rstd, rows, C, eps); break;
-      case 3: MANSY_LAUNCH(layernorm_fwd_kernel<3>, dim3(grid), dim3(256), 0, st, a, b, w, bias, z_out, y, mean, rstd, rows, C, eps); break;
-      default: MANSY_LAUNCH(layernorm_fwd_kernel<4>, dim3(grid), dim3(256), 0, st, a, b, w, bias, z_out, y, mean, rstd, rows, C, eps); break;
+      case 1: MANSY_LAUNCH(layernorm_fwd_kernel<1>, dim3(grid), dim3(256), 0, st, a, b, w, bias, z_out, y, mean, rstd, rows, C, eps, y16); break;
+      case 2: MANSY_LAUNCH(layernorm_fwd_kernel<2>, dim3(grid), dim3(256), 0, st, a, b, w, bias, z_out, y, mean, rstd, rows, C, eps, y16); break;
+      case 3: MANSY_LAUNCH(layernorm_fwd_kernel<3>, dim3(grid), dim3(256), 0, st, a, b, w, bias, z_out, y, mean, rstd, rows, C, eps, y16); break;
+      default: MANSY_LAUNCH(layernorm_fwd_kernel<4>, dim3(grid), dim3(256), 0, st, a, b, w, bias, z_out, y, mean, rstd, rows, C, eps, y16); break;
     }
   } else
     MANSY_LAUNCH(layernorm_fwd_generic, dim3(grid), dim3(256), 0, st, a, b, w, bias, z_out, y, mean, rstd, rows, C, eps);
@@ -522,13 +525,13 @@ int mansy_launch_layernorm_bwd(const float* dy, const float* z, const float* mea
   MANSY_REQUIRE(lds <= 64 * 1024, "layernorm_bwd: C=%d too large", C);
   if ((C % 256) == 0 && C <= 256 * LN_MAXV) {
     switch (C / 256) {
-      case 1: MANSY_LAUNCH((layernorm_bwd_vec_kernel<1, false, 4>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C); break;
+      case 1: MANSY_LAUNCH((layernorm_bwd_vec_kernel<1, false, 4>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C, (unsigned short*)nullptr); break;
       case 2:      // (the same rows-per-wave rule as the partial-sum form: the two forms stay bit-identical per row)
-        if (ln_rows_per_wave(rows) == 2) MANSY_LAUNCH((layernorm_bwd_vec_kernel<2, false, 2>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C);
-        else MANSY_LAUNCH((layernorm_bwd_vec_kernel<2, false, 4>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C);
+        if (ln_rows_per_wave(rows) == 2) MANSY_LAUNCH((layernorm_bwd_vec_kernel<2, false, 2>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C, (unsigned short*)nullptr);
+        else MANSY_LAUNCH((layernorm_bwd_vec_kernel<2, false, 4>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C, (unsigned short*)nullptr);
         break;
-      case 3: MANSY_LAUNCH((layernorm_bwd_vec_kernel<3, false, 4>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C); break;
-      default: MANSY_LAUNCH((layernorm_bwd_vec_kernel<4, false, 4>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C); break;
+      case 3: MANSY_LAUNCH((layernorm_bwd_vec_kernel<3, false, 4>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C, (unsigned short*)nullptr); break;
+      default: MANSY_LAUNCH((layernorm_bwd_vec_kernel<4, false, 4>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C, (unsigned short*)nullptr); break;
     }
   } else
     MANSY_LAUNCH(layernorm_bwd_kernel, dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias,
@@ -596,14 +599,14 @@ bool mansy_ln_bwd_partial_ok(int C) { return (C % 256) == 0 && C <= 256 * LN_MAX
 // applied at T steps), else the slots are overwritten.
 int mansy_launch_layernorm_bwd_partial(const float* dy, const float* z, const float* mean, const float* rstd, const float* w,
                                        float* dz, float* dz_drop, MansyDrop drop, float* partials, int accumulate, int rows, int C,
-                                       hipStream_t st) {
+                                       hipStream_t st, unsigned short* dz_drop16) {
   MANSY_REQUIRE(dy && z && mean && rstd && w && dz && partials, "layernorm_bwd_partial: null pointer");
   MANSY_REQUIRE(mansy_ln_bwd_partial_ok(C), "layernorm_bwd_partial: C=%d unsupported", C);
   if (rows <= 0) return MANSY_OK;
   const int grid = mansy_ln_bwd_parts(rows);
   const size_t lds = (size_t)4 * 2 * C * sizeof(float);
   float* flag = accumulate ? partials : nullptr;      // the kernel only tests it for null
-#define LNB(NV, RBV) MANSY_LAUNCH((layernorm_bwd_vec_kernel<NV, true, RBV>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, partials, flag, rows, C)
+#define LNB(NV, RBV) MANSY_LAUNCH((layernorm_bwd_vec_kernel<NV, true, RBV>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, partials, flag, rows, C, dz_drop16)
   if (C / 256 == 2) { if (ln_rows_per_wave(rows) == 2) LNB(2, 2); else LNB(2, 4); }
   else if (C / 256 == 1) LNB(1, 4);
   else if (C / 256 == 3) LNB(3, 4);

@@ -135,6 +135,9 @@ struct Work {
   double* loss_acc;
   unsigned short *wpl, *wpl_t;                              // bf16 planes of the GEMM weights and of their transposes (split-bf16 modes)
   long long wpl_stride;                                     // elements per plane (sum of the listed weights)
+  // bf16-storage mode (MANSY_PREC_BF16, round 6): ONE image arena mirroring the float workspace element for element -- the bf16 image of the float at
+  // fbase + i lives at img + i.  Producers of dense-product operands store the image next to the float; the products stage it by LDS-DMA as it is.
+  const float* fbase; unsigned short* img;
 };
 struct BufInfo { std::string name; size_t off; size_t bytes; };
 
@@ -212,6 +215,10 @@ void build_layout(const mansy_vp_config& c, Layout& L, Work& W) {
   W.wpl_stride = (long long)wtot;
   W.wpl = (unsigned short*)L.add("wplanes", wtot * 2 * sizeof(unsigned short));
   W.wpl_t = (unsigned short*)L.add("wplanes_t", wtot * 2 * sizeof(unsigned short));
+  // image arena: 2 bytes per float of everything above (+ 50 % workspace, in every mode: a model may change its precision between calls)
+  const size_t floats_above = (L.total + 3) / 4;
+  W.fbase = (const float*)L.base;
+  W.img = (unsigned short*)L.add("bf16_images", floats_above * sizeof(unsigned short));
 }
 
 int check_cfg(const mansy_vp_config* c) {
@@ -248,6 +255,17 @@ struct Eng {
   }
   // ---- split-bf16 modes: the GEMM weights' planes (gemm_bf16s.hip, pre-split B)
   MansyWPlaneTab wtab; int prec = 0;
+  // ---- bf16-storage form of the MANSY_PREC_BF16 mode (round 6): every operand of a dense product has a bf16 image in HBM (written by its producer:
+  // LayerNorm, attention, embedding, the fused decoder tail / head, a product's own epilogue), the products stage the images by LDS-DMA without any
+  // conversion (csrc/gemm_bf16a.hip), the K/V cache is read as bf16 by the decoder attention.  Needs the vectorised row kernels and whole 64-wide
+  // K-tiles: d %% 256 == 0, d_ff %% 64 == 0, B %% 64 == 0; any other shape keeps the fp32-operand loops (same arithmetic, twice the traffic).
+  bool s16 = false;
+  unsigned short* im(const float* p) const { return s16 ? W.img + (p - W.fbase) : nullptr; }
+  bool s16_ok() const {
+    return prec == 1 && d % 256 == 0 && d <= 1024 && f % 64 == 0 && B % 64 == 0 && S <= 10 && dh == 64 && H % 4 == 0 && mansy_dec_tail_ok(d, C6) != 0 &&
+           mansy_ln_bwd_partial_ok(d) &&
+           mansy_attn_deferred_kv_ok(cross_shape(), T) != 0 && mansy_attn_selfpull_ok(self_shape(T - 1), T) != 0;
+  }
   MansyLnReduce ln_pending[LN_MULTI_MAX]; int ln_n_pending = 0;      // LayerNorm weight-gradient slot sets waiting for their reduce launch
   int flush_ln() {
     if (!ln_n_pending) return MANSY_OK;
@@ -276,6 +294,7 @@ struct Eng {
     long long tot = 0;
     for (int t = 0; t < wtab.n; ++t) tot += ((long long)wtab.N[t] * wtab.K[t] + 63) / 64 * 64;
     if (tot > W.wpl_stride) { wtab.n = 0; return MANSY_OK; }       // (cannot happen: same table as build_layout) -> in-loop split
+    s16 = s16_ok();
     return mansy_launch_weight_planes(wtab, W.wpl, W.wpl_t, W.wpl_stride, 2, st);
   }
   // planes of the sub-matrix starting at `w` (rows r0.. of a listed weight) for the forward (transposed = false: B = W [Nout, K]) or
@@ -300,30 +319,48 @@ struct Eng {
   // resid != nullptr: Y = resid + drop(X W^T + b) -- the sub-layer's residual sum z, written by the product's epilogue, so that
   // the LayerNorm that follows reads ONE tensor and writes one (it used to read x and the product, and write z and y).
   // Same fp32 operations in the same order as drop(product) stored and then added by the LayerNorm kernel: bit-identical.
+  // y_img: the product's output is itself an operand of a later product: its epilogue also stores the bf16 image (bf16-storage mode)
   int lin_fwd(const float* X, int rows, int K, const float* w, const float* b, int Nout, float* Y, int relu, MansyDrop drop,
-              const float* resid = nullptr) {
+              const float* resid = nullptr, bool y_img = false, bool x_img = true) {
     GemmEpilogue ep; ep.prec = prec; ep.bias = b; ep.relu = relu; ep.drop = drop; ep.resid = resid; ep.resid_ld = Nout;
     if (prec) attach_planes(ep, w, false);
+    if (s16 && x_img && ep.b_planes && K % 64 == 0) {
+      ep.a16 = im(X); ep.a16_ld = K;
+      if (y_img) { ep.c16 = im(Y); ep.c16_ld = Nout; }
+      return mansy_launch_gemm_bf16a(0, 0, Y, Nout, rows, Nout, K, ep, 0, 0, st);
+    }
     return mansy_launch_gemm_f32(X, K, 0, w, K, 0, Y, Nout, rows, Nout, K, ep, 0, 0, st);
   }
   // y = LN(z) for a z already formed by lin_fwd(..., resid)
   int ln_of(const float* z, const NormP& n, float* y, float* m, float* r, int rows) {
-    return mansy_launch_layernorm_fwd(z, nullptr, n.w, n.b, nullptr, y, m, r, rows, d, c.ln_eps, st);
+    return mansy_launch_layernorm_fwd(z, nullptr, n.w, n.b, nullptr, y, m, r, rows, d, c.ln_eps, st, im(y));
   }
   // dX[rows,K] = dY[rows,N] W[N,K] (+resid) (mask)
+  // dx_img: 0 = dX as floats only (it feeds a row-wise kernel), 1 = floats + bf16 image, 2 = the image ONLY (dX is nothing but an operand of later
+  // products: no float copy is written) -- bf16-storage mode; otherwise floats.  img_in = false: dY has no image (its producer keeps floats only).
   int lin_dx(const float* dY, int rows, int Nout, const float* w, int K, float* dX, const float* resid, const float* mask_src,
-             float mask_scale) {
+             float mask_scale, int dx_img = 0, bool img_in = true) {
     GemmEpilogue ep; ep.prec = prec; ep.resid = resid; ep.resid_ld = K; ep.mask_src = mask_src; ep.mask_ld = K; ep.mask_scale = mask_scale;
     if (prec) attach_planes(ep, w, true);
+    if (s16 && img_in && ep.b_planes && Nout % 64 == 0) {
+      ep.a16 = im(dY); ep.a16_ld = Nout;
+      if (dx_img) { ep.c16 = im(dX); ep.c16_ld = K; }
+      return mansy_launch_gemm_bf16a(0, 0, dx_img == 2 ? nullptr : dX, K, rows, K, Nout, ep, 0, 0, st);
+    }
     return mansy_launch_gemm_f32(dY, Nout, 0, w, K, 1, dX, K, rows, K, Nout, ep, 0, 0, st);
   }
   // gw[N,K] += dY[rows,N]^T X[rows,K] ; gb[N] += colsum(dY)
-  int lin_dw(const float* dY, const float* X, int rows, int Nout, int K, float* gw, float* gb) {
+  // img_in = false: one of the operands has no bf16 image (floats only): the fp32-operand loop
+  int lin_dw(const float* dY, const float* X, int rows, int Nout, int K, float* gw, float* gb, bool img_in = true) {
     GemmEpilogue ep; ep.prec = prec; ep.accumulate = 1; ep.a_rowsum = gb;      // bias gradient = row sums of dY^T, taken from the staged A tiles
+    if (s16 && img_in && rows % 64 == 0 && Nout % 8 == 0 && K % 8 == 0) {
+      ep.a16 = im(dY); ep.a16_ld = Nout; ep.b16 = im(X); ep.b16_ld = K;
+      return mansy_launch_gemm_bf16a(1, 1, gw, K, Nout, K, rows, ep, 0, 0, st);
+    }
     return mansy_launch_gemm_f32(dY, Nout, 1, X, K, 1, gw, K, Nout, K, rows, ep, 0, 0, st);
   }
   int ln_fwd(const float* a, const float* b, const NormP& n, float* z, float* y, float* m, float* r, int rows) {
-    return mansy_launch_layernorm_fwd(a, b, n.w, n.b, z, y, m, r, rows, d, c.ln_eps, st);
+    return mansy_launch_layernorm_fwd(a, b, n.w, n.b, z, y, m, r, rows, d, c.ln_eps, st, im(y));
   }
   // part_slot < 0: encoder LayerNorm (applied once): partial sums into the scratch set, reduced into the gradient right away.
   // part_slot >= 0: decoder LayerNorm #part_slot (applied at every step): accumulate into its slot set, reduced after the loop.
@@ -333,12 +370,12 @@ struct Eng {
     if (part_slot < 0) {          // encoder LayerNorm -(part_slot + 1): its own scratch set, overwritten; added into the gradient by the one reduce launch at the end
       const int e = -(part_slot + 1);
       float* set = W.lnp_enc + (size_t)e * mansy_ln_bwd_parts(rows) * 2 * d;
-      RC(mansy_launch_layernorm_bwd_partial(dy, z, m, r, n.w, dz, dz_drop, drop, set, 0, rows, d, st));
+      RC(mansy_launch_layernorm_bwd_partial(dy, z, m, r, n.w, dz, dz_drop, drop, set, 0, rows, d, st, dz_drop ? im(dz_drop) : nullptr));
       ln_pending[ln_n_pending++] = MansyLnReduce{set, mansy_ln_bwd_parts(rows), n.gw, n.gb};
       return MANSY_OK;
     }
     float* slots = W.lnp_dec + (size_t)part_slot * mansy_ln_bwd_parts(B) * 2 * d;
-    return mansy_launch_layernorm_bwd_partial(dy, z, m, r, n.w, dz, dz_drop, drop, slots, 1, rows, d, st);
+    return mansy_launch_layernorm_bwd_partial(dy, z, m, r, n.w, dz, dz_drop, drop, slots, 1, rows, d, st, dz_drop ? im(dz_drop) : nullptr);
   }
 
   AttnShape enc_shape() const {
@@ -363,29 +400,30 @@ struct Eng {
   // ------------------------------------------------------------------ forward
   int forward(const float* src, const float* cur, const float* pe, float* bn_rm, float* bn_rv, long long* bn_nbt, float* pred_bt) {
     RC(prepare_planes());
-    RC(mansy_launch_embed_fwd(src, C6, P.emb.w, P.emb.b, pe, W.x0, N, d, S, -1, dr(site_pe_src(), c.p_pe), st));
+    RC(mansy_launch_embed_fwd(src, C6, P.emb.w, P.emb.b, pe, W.x0, N, d, S, -1, dr(site_pe_src(), c.p_pe), st, im(W.x0)));
     const float* x = W.x0;
     for (int l = 0; l < c.n_enc; ++l) {
       const EncLayerP& p = P.enc[l]; EncBuf& e = W.enc[l];
       RC(lin_fwd(x, N, d, p.in_proj.w, p.in_proj.b, 3 * d, e.qkv, 0, mansy_no_drop()));
-      RC(mansy_launch_attn_fwd(e.qkv, e.qkv + d, e.qkv + 2 * d, e.ao, e.P, enc_shape(), dr(site_enc(l, 0), c.p_drop), st));
+      RC(mansy_launch_attn_fwd(e.qkv, e.qkv + d, e.qkv + 2 * d, e.ao, e.P, enc_shape(), dr(site_enc(l, 0), c.p_drop), st, W.fbase, im(W.fbase)));
       RC(lin_fwd(e.ao, N, d, p.out_proj.w, p.out_proj.b, d, e.z1, 0, dr(site_enc(l, 1), c.p_drop), x));          // z1 = x + drop(out_proj(ao))
       RC(ln_of(e.z1, p.n1, e.y1, e.m1, e.r1, N));
-      RC(lin_fwd(e.y1, N, d, p.lin1.w, p.lin1.b, f, e.h, 1, dr(site_enc(l, 2), c.p_drop)));
+      RC(lin_fwd(e.y1, N, d, p.lin1.w, p.lin1.b, f, e.h, 1, dr(site_enc(l, 2), c.p_drop), nullptr, true));
       RC(lin_fwd(e.h, N, f, p.lin2.w, p.lin2.b, d, e.z2, 0, dr(site_enc(l, 3), c.p_drop), e.y1));                // z2 = y1 + drop(lin2(h))
       RC(ln_of(e.z2, p.n2, e.y2, e.m2, e.r2, N));
       x = e.y2;
     }
     RC(ln_fwd(x, nullptr, P.enc_norm, nullptr, W.enc_out, W.me, W.re, N));
     // DistillLayer: circular conv k=3 as one K=3d GEMM on the im2col image, then BN+ELU+maxpool
-    RC(mansy_launch_im2col3(W.enc_out, W.col, B, S, d, st));
+    RC(mansy_launch_im2col3(W.enc_out, W.col, B, S, d, st, im(W.col)));
     RC(lin_fwd(W.col, N, 3 * d, P.conv.w, P.conv.b, d, W.conv, 0, mansy_no_drop()));
     DistillShape ds = {B, S, M, d, c.bn_sync_world > 1 ? c.bn_sync_world : 1, c.bn_sync_fn, c.bn_sync_user};
     RC(mansy_launch_distill_fwd(W.conv, P.bn.w, P.bn.b, bn_rm, bn_rv, bn_nbt, W.bn_mean, W.bn_rstd, W.mem, W.argmax, W.stats, ds,
                                 train ? 1 : 0, c.bn_eps, c.bn_momentum, st, W.dis_part));
     for (int l = 0; l < c.n_dec; ++l) {
       const DecLayerP& p = P.dec[l];
-      RC(lin_fwd(W.mem, B * M, d, p.ca_in.w + (size_t)d * d, p.ca_in.b ? p.ca_in.b + d : nullptr, 2 * d, W.dec[l].memkv, 0, mansy_no_drop()));
+      RC(lin_fwd(W.mem, B * M, d, p.ca_in.w + (size_t)d * d, p.ca_in.b ? p.ca_in.b + d : nullptr, 2 * d, W.dec[l].memkv, 0, mansy_no_drop(), nullptr, false,
+                 false));      // (the distilled memory has no bf16 image: the DistillLayer keeps floats)
     }
     MANSY_HIP_CHECK(hipMemcpyAsync(W.tok_all, cur, sizeof(float) * B * C6, hipMemcpyDeviceToDevice, st));
     // the four row-wise ops between the last product of step i and the first of step i+1 run as one launch (dec_step.hip)
@@ -435,7 +473,7 @@ struct Eng {
     const float* tok = W.tok_all + o * C6;
     float* emb = W.emb_all + o * d;
     float* t_dec = W.t_dec + (size_t)b0 * d;
-    if (i == 0 || !fuse_tail) RC(mansy_launch_embed_fwd(tok, C6, P.emb.w, P.emb.b, pe, emb, nb, d, 1, i, dr(site_pe_tgt(i), c.p_pe, (size_t)b0 * d), st));
+    if (i == 0 || !fuse_tail) RC(mansy_launch_embed_fwd(tok, C6, P.emb.w, P.emb.b, pe, emb, nb, d, 1, i, dr(site_pe_tgt(i), c.p_pe, (size_t)b0 * d), st, im(emb)));
     const float* xi = emb;
     for (int l = 0; l < c.n_dec; ++l) {
       const DecLayerP& p = P.dec[l]; DecBuf& e = W.dec[l];
@@ -444,15 +482,15 @@ struct Eng {
       const float* mkv = e.memkv + (size_t)b0 * M * 2 * d;
       RC(lin_fwd(xi, nb, d, p.sa_in.w, p.sa_in.b, 3 * d, qkv_i, 0, mansy_no_drop()));
       RC(mansy_launch_attn_fwd(qkv_i, kv0 + d, kv0 + 2 * d, e.ao1 + o * d, e.P1 + o * H * T, self_shape(i, nb),
-                               dr(site_dec(l, i, 0), c.p_drop, (size_t)b0 * H * (i + 1)), st));
+                               dr(site_dec(l, i, 0), c.p_drop, (size_t)b0 * H * (i + 1)), st, W.fbase, im(W.fbase)));
       RC(lin_fwd(e.ao1 + o * d, nb, d, p.sa_out.w, p.sa_out.b, d, e.z1 + o * d, 0, dr(site_dec(l, i, 1), c.p_drop, (size_t)b0 * d), xi));
       RC(ln_of(e.z1 + o * d, p.n1, e.y1 + o * d, e.m1 + o, e.r1 + o, nb));
       RC(lin_fwd(e.y1 + o * d, nb, d, p.ca_in.w, p.ca_in.b, d, e.qc + o * d, 0, mansy_no_drop()));
       RC(mansy_launch_attn_fwd(e.qc + o * d, mkv, mkv + d, e.ao2 + o * d, e.P2 + o * H * M, cross_shape(nb),
-                               dr(site_dec(l, i, 2), c.p_drop, (size_t)b0 * H * M), st));
+                               dr(site_dec(l, i, 2), c.p_drop, (size_t)b0 * H * M), st, W.fbase, im(W.fbase)));
       RC(lin_fwd(e.ao2 + o * d, nb, d, p.ca_out.w, p.ca_out.b, d, e.z2 + o * d, 0, dr(site_dec(l, i, 3), c.p_drop, (size_t)b0 * d), e.y1 + o * d));
       RC(ln_of(e.z2 + o * d, p.n2, e.y2 + o * d, e.m2 + o, e.r2 + o, nb));
-      RC(lin_fwd(e.y2 + o * d, nb, d, p.lin1.w, p.lin1.b, f, e.h + o * f, 1, dr(site_dec(l, i, 4), c.p_drop, (size_t)b0 * f)));
+      RC(lin_fwd(e.y2 + o * d, nb, d, p.lin1.w, p.lin1.b, f, e.h + o * f, 1, dr(site_dec(l, i, 4), c.p_drop, (size_t)b0 * f), nullptr, true));
       if (fuse_tail && l == c.n_dec - 1) {                  // LayerNorm3 of the last layer is the head of the fused tail (a + b form)
         RC(lin_fwd(e.h + o * f, nb, f, p.lin2.w, p.lin2.b, d, t_dec, 0, dr(site_dec(l, i, 5), c.p_drop, (size_t)b0 * d)));
         break;
@@ -473,6 +511,7 @@ struct Eng {
       tp.ew = P.emb.w; tp.eb = P.emb.b; tp.pe_row = pe + (size_t)(i + 1) * d; tp.emb_next = more ? W.emb_all + ((size_t)(i + 1) * B + b0) * d : nullptr;
       tp.edrop = dr(site_pe_tgt(i + 1), c.p_pe, (size_t)b0 * d);
       tp.rows = nb; tp.C = d; tp.C6 = C6; tp.eps = c.ln_eps;
+      tp.y3_16 = im(tp.y3); tp.emb_next16 = tp.emb_next ? im(tp.emb_next) : nullptr;
       return mansy_launch_dec_tail_fwd(tp, st);
     }
     RC(ln_fwd(xi, nullptr, P.dec_norm, nullptr, W.dec_out + o * d, W.md + o, W.rd + o, nb));
@@ -496,7 +535,7 @@ struct Eng {
     auto ln_bwd_dec = [&](const float* dy, const float* z, const float* m, const float* r, const NormP& n, float* dz, float* dz_drop, MansyDrop drop,
                           int slot) {
       if (!ln_parts) return mansy_launch_layernorm_bwd(dy, z, m, r, n.w, dz, dz_drop, drop, n.gw, n.gb, nb, d, st);
-      return mansy_launch_layernorm_bwd_partial(dy, z, m, r, n.w, dz, dz_drop, drop, lnp + (size_t)slot * lnp_set, 1, nb, d, st);
+      return mansy_launch_layernorm_bwd_partial(dy, z, m, r, n.w, dz, dz_drop, drop, lnp + (size_t)slot * lnp_set, 1, nb, d, st, dz_drop ? im(dz_drop) : nullptr);
     };
     if (fuse_head) {
       const int L = c.n_dec - 1;
@@ -510,7 +549,7 @@ struct Eng {
       hp.y3 = e.y3 + o * d; hp.md = W.md + o; hp.rd = W.rd + o; hp.dn_w = P.dec_norm.w; hp.part_dn = lnp + (size_t)(3 * c.n_dec) * lnp_set;
       hp.z3 = e.z3 + o * d; hp.m3 = e.m3 + o; hp.r3 = e.r3 + o; hp.n3_w = P.dec[L].n3.w; hp.part_n3 = lnp + (size_t)(3 * L + 2) * lnp_set;
       hp.gz = gz; hp.dbr3 = e.dbr3 + o * d; hp.drop3 = dr(site_dec(L, i, 5), c.p_drop, bd);
-      hp.rows = nb; hp.C = d; hp.C6 = C6;
+      hp.rows = nb; hp.C = d; hp.C6 = C6; hp.dbr3_16 = im(hp.dbr3);
       // (its own grid rule: 16 rows per workgroup as before -- 8 made this fused kernel 17.9 -> 22 us; it fills the first slots of its sets, the rest stay
       // zero from the memset and the reduce launches add them as such)
       RC(mansy_launch_dec_head_bwd(hp, std::min(mansy_ln_bwd_parts(nb), (nb + 15) / 16), st));
@@ -527,7 +566,7 @@ struct Eng {
       // norm3( y2 + drop(lin2(h)) )
       if (!(fuse_head && l == c.n_dec - 1))
         RC(ln_bwd_dec(gx, e.z3 + o * d, e.m3 + o, e.r3 + o, p.n3, gz, e.dbr3 + o * d, dr(site_dec(l, i, 5), c.p_drop, bd), 3 * l + 2));
-      RC(lin_dx(e.dbr3 + o * d, nb, d, p.lin2.w, f, e.da + o * f, nullptr, e.h + o * f, ms));
+      RC(lin_dx(e.dbr3 + o * d, nb, d, p.lin2.w, f, e.da + o * f, nullptr, e.h + o * f, ms, 2));      // da is an operand of two products and nothing else: image only
       RC(lin_dx(e.da + o * f, nb, f, p.lin1.w, d, gt, gz, nullptr, 1.f));                 // gt = d/dy2
       // norm2( y1 + drop(ca_out(ao2)) )
       RC(ln_bwd_dec(gt, e.z2 + o * d, e.m2 + o, e.r2 + o, p.n2, gz, e.dbr2 + o * d, dr(site_dec(l, i, 3), c.p_drop, bd), 3 * l + 1));
@@ -535,7 +574,7 @@ struct Eng {
         float* dao2_i = e.dao2 + o * d;
         RC(lin_dx(e.dbr2 + o * d, nb, d, p.ca_out.w, d, dao2_i, nullptr, nullptr, 1.f));   // d/dao2, kept for the deferred dV
         RC(mansy_launch_attn_bwd_dq(e.qc + o * d, mkv, mkv + d, e.P2 + o * H * M, dao2_i, e.dqc + o * d, e.dS2 + o * H * M,
-                                    e.Pk2 + o * H * M, cross_shape(nb), dr(site_dec(l, i, 2), c.p_drop, (size_t)b0 * H * M), st));
+                                    e.Pk2 + o * H * M, cross_shape(nb), dr(site_dec(l, i, 2), c.p_drop, (size_t)b0 * H * M), st, W.fbase, im(W.fbase)));
       } else {
         float* dmkv = e.dmemkv + (size_t)b0 * M * 2 * d;
         RC(lin_dx(e.dbr2 + o * d, nb, d, p.ca_out.w, d, gt, nullptr, nullptr, 1.f));       // gt = d/dao2
@@ -554,7 +593,7 @@ struct Eng {
         const size_t co = (size_t)b0 * T * H * T;
         RC(mansy_launch_attn_bwd_selfpull(kv0, (long long)B * 3 * d, kv0 + d, kv0 + 2 * d, e.P1 + o * H * T, e.dao1 + (size_t)b0 * d, (long long)B * d,
                                           dqkv_i, dkv0 + d, dkv0 + 2 * d, e.dS1 + co, e.Pk1 + co, self_shape(i, nb), T, i,
-                                          dr(site_dec(l, i, 0), c.p_drop, (size_t)b0 * H * (i + 1)), st));
+                                          dr(site_dec(l, i, 0), c.p_drop, (size_t)b0 * H * (i + 1)), st, W.fbase, im(W.fbase)));
       } else {
         RC(lin_dx(e.dbr1 + o * d, nb, d, p.sa_out.w, d, gt, nullptr, nullptr, 1.f));       // gt = d/dao1
         RC(mansy_launch_attn_bwd(qkv_at(e, o), kv0 + d, kv0 + 2 * d, e.P1 + o * H * T, gt, dqkv_i, dkv0 + d, dkv0 + 2 * d,
@@ -629,18 +668,18 @@ struct Eng {
       RC(lin_dw(e.dqc, e.y1, TB, d, d, p.ca_in.gw, p.ca_in.gb));
       if (defer_cross)
         RC(mansy_launch_attn_kvgrad(e.qc, (long long)B * d, e.dao2, (long long)B * d, e.dS2, e.Pk2, e.dmemkv, e.dmemkv + d, cross_shape(), T, 0, st));
-      RC(lin_dw(e.dmemkv, W.mem, B * M, 2 * d, d, p.ca_in.gw + (size_t)d * d, p.ca_in.gb ? p.ca_in.gb + d : nullptr));
+      RC(lin_dw(e.dmemkv, W.mem, B * M, 2 * d, d, p.ca_in.gw + (size_t)d * d, p.ca_in.gb ? p.ca_in.gb + d : nullptr, false));      // (floats only: the K/V-gradient pass and the DistillLayer keep no images)
       RC(lin_dw(e.dbr2, e.ao2, TB, d, d, p.ca_out.gw, p.ca_out.gb));
       RC(lin_dw(e.da, e.y2, TB, f, d, p.lin1.gw, p.lin1.gb));
       RC(lin_dw(e.dbr3, e.h, TB, d, f, p.lin2.gw, p.lin2.gb));
-      RC(lin_dx(e.dmemkv, B * M, 2 * d, p.ca_in.w + (size_t)d * d, d, W.dmem, l == 0 ? nullptr : W.dmem, nullptr, 1.f));
+      RC(lin_dx(e.dmemkv, B * M, 2 * d, p.ca_in.w + (size_t)d * d, d, W.dmem, l == 0 ? nullptr : W.dmem, nullptr, 1.f, 0, false));
     }
     // ---- DistillLayer
     DistillShape ds = {B, S, M, d, c.bn_sync_world > 1 ? c.bn_sync_world : 1, c.bn_sync_fn, c.bn_sync_user};
     RC(mansy_launch_distill_bwd(W.conv, W.dmem, W.argmax, P.bn.w, P.bn.b, W.bn_mean, W.bn_rstd, W.g_a, W.g_b, P.bn.gw, P.bn.gb, W.stats,
                                 ds, st, W.dis_part));
-    RC(lin_dw(W.g_b, W.col, N, d, 3 * d, P.conv.gw, P.conv.gb));
-    RC(lin_dx(W.g_b, N, d, P.conv.w, 3 * d, W.g_wide, nullptr, nullptr, 1.f));
+    RC(lin_dw(W.g_b, W.col, N, d, 3 * d, P.conv.gw, P.conv.gb, false));
+    RC(lin_dx(W.g_b, N, d, P.conv.w, 3 * d, W.g_wide, nullptr, nullptr, 1.f, 0, false));
     RC(mansy_launch_col2im3(W.g_wide, W.g_a, B, S, d, st));
     // Data parallel: every gradient from the first decoder layer to the end of the parameter table (decoder layers, decoder
     // norm, DistillLayer conv + BatchNorm, predictor -- two thirds of the flat buffer) is final here.  The host hook (which = 2)
@@ -655,14 +694,14 @@ struct Eng {
       const float* x_in = l == 0 ? W.x0 : W.enc[l - 1].y2;
       RC(ln_bwd(gx, e.z2, e.m2, e.r2, p.n2, gz, gt, dr(site_enc(l, 3), c.p_drop), N, -(2 + 2 * l)));        // gt = d/d(lin2 out)
       RC(lin_dw(gt, e.h, N, d, f, p.lin2.gw, p.lin2.gb));
-      RC(lin_dx(gt, N, d, p.lin2.w, f, W.g_ff, nullptr, e.h, ms));                             // g_ff = d/d(lin1 pre-act)
+      RC(lin_dx(gt, N, d, p.lin2.w, f, W.g_ff, nullptr, e.h, ms, 2));                          // g_ff = d/d(lin1 pre-act): an operand of two products only (image only)
       RC(lin_dw(W.g_ff, e.y1, N, f, d, p.lin1.gw, p.lin1.gb));
       RC(lin_dx(W.g_ff, N, f, p.lin1.w, d, gt, gz, nullptr, 1.f));                             // gt = d/dy1
       RC(ln_bwd(gt, e.z1, e.m1, e.r1, p.n1, gz, gx, dr(site_enc(l, 1), c.p_drop), N, -(3 + 2 * l)));         // gx = d/d(out_proj out)
       RC(lin_dw(gx, e.ao, N, d, d, p.out_proj.gw, p.out_proj.gb));
       RC(lin_dx(gx, N, d, p.out_proj.w, d, gt, nullptr, nullptr, 1.f));                        // gt = d/dao
       RC(mansy_launch_attn_bwd(e.qkv, e.qkv + d, e.qkv + 2 * d, e.P, gt, W.g_wide, W.g_wide + d, W.g_wide + 2 * d, enc_shape(),
-                               dr(site_enc(l, 0), c.p_drop), 0, st));
+                               dr(site_enc(l, 0), c.p_drop), 0, st, W.fbase, im(W.fbase)));
       RC(lin_dw(W.g_wide, x_in, N, 3 * d, d, p.in_proj.gw, p.in_proj.gb));
       RC(lin_dx(W.g_wide, N, 3 * d, p.in_proj.w, d, gx, gz, nullptr, 1.f));                    // gx = d/d(layer input)
     }

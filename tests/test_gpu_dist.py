@@ -50,7 +50,8 @@ def test_plain_bench_gpus_2_starts_two_ranks():
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['config']['global_batch'] == 512 and out['secondary']['n_gpus'] == 2
-    assert out['dist'] == {'backend': 'gloo', 'world_size': 2, 'ranks_reporting': 2, 'launcher': 'self-spawn'}
+    assert {k: out['dist'][k] for k in ('backend', 'world_size', 'ranks_reporting', 'launcher')} == {'backend': 'gloo', 'world_size': 2, 'ranks_reporting': 2, 'launcher': 'self-spawn'}
+    assert out['dist']['preflight']['world'] == 2 and out['dist']['preflight']['library_allreduce']['ok']
     assert out['replica_param_spread'] == 0.0 and out['secondary']['replica_param_spread'] == 0.0
     assert out['value'] > 0 and out['secondary']['value'] > 0
     # one GPU, two RCCL ranks, no sharing flag: must refuse loudly instead of printing a line

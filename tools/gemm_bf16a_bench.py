@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""Per-shape timing of the bf16-STORAGE products (csrc/gemm_bf16a.hip, round 6) against the fp32-operand plain-bf16 loops they replace in the
+MANSY_PREC_BF16 mode (gemm_bf16h / gemm_bf16s: operands fp32 in HBM, rounded on their way into the matrix pipe) and against the fp32 product.
+Operands rotate through 6 buffer sets (the step's products never find their operands in L2 either)."""
+import ctypes, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mansy_immersivevideostreaming_amd import _lib as L
+
+dev = 'cuda'
+lib = L.lib()
+NSET = 6
+
+
+def timeit(fn, iters=60):
+    for i in range(6):
+        fn(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(iters):
+        fn(i)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters * 1e6
+
+
+def nn(M, N, K, tile=0, out='f32'):
+    A = [torch.randn(M, K, device=dev).to(torch.bfloat16) for _ in range(NSET)]
+    W = torch.randn(N, K, device=dev).to(torch.bfloat16)
+    C = [torch.empty(M, N, device=dev) for _ in range(NSET)]
+    C16 = [torch.empty(M, N, device=dev, dtype=torch.bfloat16) for _ in range(NSET)]
+    ep = L.GemmEpilogue()
+    st = L.stream_ptr()
+
+    def f(i):
+        k = i % NSET
+        L.check(lib.mansy_gemm_bf16(L.ptr(A[k]), K, 0, L.ptr(W), K, 0, L.ptr(C[k]) if out != 'bf16' else None, N, L.ptr(C16[k]) if out != 'f32' else None, N,
+                                    M, N, K, ctypes.byref(ep), tile, 0, st))
+    return timeit(f)
+
+
+def nn_old(M, N, K, prec):
+    A = [torch.randn(M, K, device=dev) for _ in range(NSET)]
+    W = torch.randn(N, K, device=dev)
+    planes = torch.empty(2, N * K, dtype=torch.int16, device=dev)
+    planes_t = torch.empty(2, N * K, dtype=torch.int16, device=dev)
+    L.check(lib.mansy_weight_planes(L.ptr(W), N, K, L.ptr(planes), L.ptr(planes_t), N * K, 2, L.stream_ptr()))
+    C = [torch.empty(M, N, device=dev) for _ in range(NSET)]
+    ep = L.GemmEpilogue()
+    ep.prec = prec
+    st = L.stream_ptr()
+
+    def f(i):
+        k = i % NSET
+        L.check(lib.mansy_gemm_planes(L.ptr(A[k]), K, L.ptr(W), K, 0, L.ptr(planes), N * K, K, L.ptr(C[k]), N, M, N, K, ctypes.byref(ep), 0, st))
+    return timeit(f)
+
+
+def tn(M, N, K, splits=0):
+    dY = [torch.randn(K, M, device=dev).to(torch.bfloat16) for _ in range(NSET)]
+    X = [torch.randn(K, N, device=dev).to(torch.bfloat16) for _ in range(NSET)]
+    C = torch.zeros(M, N, device=dev)
+    rs = torch.zeros(M, device=dev)
+    ep = L.GemmEpilogue()
+    ep.accumulate = 1
+    ep.a_rowsum = L.ptr(rs)
+    st = L.stream_ptr()
+
+    def f(i):
+        k = i % NSET
+        L.check(lib.mansy_gemm_bf16(L.ptr(dY[k]), M, 1, L.ptr(X[k]), N, 1, L.ptr(C), N, None, 0, M, N, K, ctypes.byref(ep), 0, splits, st))
+    return timeit(f, 30)
+
+
+def tn_old(M, N, K, prec):
+    dY = [torch.randn(K, M, device=dev) for _ in range(NSET)]
+    X = [torch.randn(K, N, device=dev) for _ in range(NSET)]
+    C = torch.zeros(M, N, device=dev)
+    rs = torch.zeros(M, device=dev)
+    ep = L.GemmEpilogue()
+    ep.accumulate = 1
+    ep.a_rowsum = L.ptr(rs)
+    ep.prec = prec
+    st = L.stream_ptr()
+
+    def f(i):
+        k = i % NSET
+        L.check(lib.mansy_gemm_f32(L.ptr(dY[k]), M, 1, L.ptr(X[k]), N, 1, L.ptr(C), N, M, N, K, ctypes.byref(ep), 0, 0, st))
+    return timeit(f, 30)
+
+
+print('forward / dX form  C[M,N] = A16[M,K] W16[N,K]^T     (us per launch; bf16 MFMA time at 2.5 PF in brackets)')
+for (M, N, K) in ((4096, 512, 512), (4096, 1536, 512), (40960, 512, 512), (40960, 1536, 512), (40960, 512, 1536), (20480, 1024, 512)):
+    mf = 2.0 * M * N * K / 2.5e15 * 1e6
+    row = [f'[{M:5d},{N:4d},{K:4d}] ({mf:5.1f})']
+    for tile in ((64, 96, 128) if M <= 4096 else (96, 128)):
+        row.append(f'tile {tile}: f32-out {nn(M, N, K, tile):6.1f}  bf16-out {nn(M, N, K, tile, "bf16"):6.1f}')
+    row.append(f'| fp32-operand bf16 loop {nn_old(M, N, K, 1):6.1f}  fp32 product {nn_old(M, N, K, 0):6.1f}')
+    print('  '.join(row), flush=True)
+print('weight-gradient form  C[M,N] += dY16[K,M]^T X16[K,N]')
+for (M, N, K) in ((512, 512, 40960), (1536, 512, 40960), (512, 1536, 40960), (1024, 512, 20480)):
+    hb = (M + N) * K * 2 / 1e6
+    print(f'[{M:4d},{N:4d},{K:5d}] ({hb:6.1f} MB of bf16 operands)  bf16-storage {tn(M, N, K):6.1f}  | fp32-operand bf16 loop {tn_old(M, N, K, 1):6.1f}  fp32 product {tn_old(M, N, K, 0):6.1f}', flush=True)
