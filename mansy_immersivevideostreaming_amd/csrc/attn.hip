@@ -23,7 +23,19 @@ struct AttnPtrs {
   // bf16 images of the OUTPUT rows (bf16-storage mode, round 6; 4-heads-per-wave kernels only): the float4 stored at address a also goes, rounded, to
   // img_s + (a - img_f) -- one mapping for O / dQ / dK / dV (they are rows of one slab).  Null: no image.
   const float* img_f; unsigned short* img_s;
+  int img_only;                     // != 0 (with img_s): the rows are operands of dense products and nothing else -- the float4 store is skipped
+  int kv16;                         // != 0 (with img_s; q1x4 kernels): the K / V rows (and the pull form's Q rows) are READ from their bf16 images -- the
+                                    // K/V cache of the bf16-storage mode is bf16 in HBM (written by the projection's epilogue): half the cache traffic
 };
+// a 4-float piece of a K / V / Q row: from the float slab, or (kv16) from its bf16 image at the same element index
+__device__ __forceinline__ float4 attn_ld4(const AttnPtrs& p, const float* addr) {
+  if (p.kv16) {
+    const mansy_bf16x4 t = *reinterpret_cast<const mansy_bf16x4*>(p.img_s + (addr - p.img_f));
+    return make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]);
+  }
+  return *reinterpret_cast<const float4*>(addr);
+}
+#define ATTN_ST(p, addr, v) do { if (!(p).img_only) *reinterpret_cast<float4*>(addr) = (v); ATTN_IMG(p, addr, v); } while (0)
 #define ATTN_IMG(p, addr, v) do { if ((p).img_s) mansy_st_bf16x4((p).img_s + ((addr) - (p).img_f), (v).x, (v).y, (v).z, (v).w); } while (0)
 
 __device__ __forceinline__ void load_rows(const float* base, long long rs, int L, int dh, int lane, float* lds) {
@@ -294,8 +306,8 @@ __global__ __launch_bounds__(64 * WAVES) void attn_fwd_q1x4_kernel(AttnPtrs p, A
 #pragma unroll
   for (int j = 0; j < LKT; ++j) {
     const int jc = min(j, Lk - 1);
-    k[j] = *reinterpret_cast<const float4*>(Kb + jc * s.k_rs);
-    v[j] = *reinterpret_cast<const float4*>(Vb + jc * s.v_rs);
+    k[j] = attn_ld4(p, Kb + jc * s.k_rs);
+    v[j] = attn_ld4(p, Vb + jc * s.v_rs);
   }
   float m = -INFINITY;
 #pragma unroll
@@ -317,8 +329,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_fwd_q1x4_kernel(AttnPtrs p, A
     if (drop.p > 0.f) pv = mansy_keep(drop.seed, drop.site, drop.base + (uint32_t)pidx, drop.p) ? pv * ds : 0.f;
     o.x = fmaf(pv, v[j].x, o.x); o.y = fmaf(pv, v[j].y, o.y); o.z = fmaf(pv, v[j].z, o.z); o.w = fmaf(pv, v[j].w, o.w);
   }
-  *reinterpret_cast<float4*>(p.O + b * s.o_bs + col) = o;
-  ATTN_IMG(p, p.O + b * s.o_bs + col, o);
+  ATTN_ST(p, p.O + b * s.o_bs + col, o);
 }
 
 template <int LKT>
@@ -343,8 +354,8 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_q1x4_kernel(AttnPtrs p, A
 #pragma unroll
   for (int j = 0; j < LKT; ++j) {
     const int jc = min(j, Lk - 1);
-    k[j] = *reinterpret_cast<const float4*>(Kb + jc * s.k_rs);
-    vv[j] = *reinterpret_cast<const float4*>(Vb + jc * s.v_rs);
+    k[j] = attn_ld4(p, Kb + jc * s.k_rs);
+    vv[j] = attn_ld4(p, Vb + jc * s.v_rs);
     P[j] = p.P[bh * Lk + jc];
   }
   float delta = 0.f;
@@ -363,8 +374,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_q1x4_kernel(AttnPtrs p, A
     dS[j] = P[j] * (dP[j] - delta) * s.scale;      // 0 for j >= Lk
     dq.x = fmaf(dS[j], k[j].x, dq.x); dq.y = fmaf(dS[j], k[j].y, dq.y); dq.z = fmaf(dS[j], k[j].z, dq.z); dq.w = fmaf(dS[j], k[j].w, dq.w);
   }
-  *reinterpret_cast<float4*>(p.dQ + b * s.q_bs + col) = dq;
-  ATTN_IMG(p, p.dQ + b * s.q_bs + col, dq);
+  ATTN_ST(p, p.dQ + b * s.q_bs + col, dq);
   if (p.dS_out) {          // deferred dK / dV (mansy_launch_attn_kvgrad): keep this step's coefficients, touch no K/V gradient row
     const int c = lane & 15;
 #pragma unroll
@@ -434,8 +444,8 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_selfpull_q1x4_kernel(Attn
 #pragma unroll
   for (int j = 0; j < LKT; ++j) {
     const int jc = min(j, Lk - 1);
-    k[j] = *reinterpret_cast<const float4*>(Kb + jc * s.k_rs);
-    vv[j] = *reinterpret_cast<const float4*>(Vb + jc * s.v_rs);
+    k[j] = attn_ld4(p, Kb + jc * s.k_rs);
+    vv[j] = attn_ld4(p, Vb + jc * s.v_rs);
     P[j] = p.P[bh * Lk + jc];
   }
   float delta = 0.f;
@@ -459,8 +469,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_selfpull_q1x4_kernel(Attn
     if (j == Lk - 1) { dS_own = dSj; Pk_own = Pkj; }
     if (c == j && j < Lk) { dS_row[j] = dSj; Pk_row[j] = Pkj; }
   }
-  *reinterpret_cast<float4*>(p.dQ + b * s.q_bs + col) = dq;
-  ATTN_IMG(p, p.dQ + b * s.q_bs + col, dq);
+  ATTN_ST(p, p.dQ + b * s.q_bs + col, dq);
   float4 dk = make_float4(dS_own * q.x, dS_own * q.y, dS_own * q.z, dS_own * q.w);
   float4 dv = make_float4(Pk_own * dO.x, Pk_own * dO.y, Pk_own * dO.z, Pk_own * dO.w);
   for (int i0 = sp.step + 1; i0 < sp.T; i0 += 4) {          // later steps, four at a time: 8 row loads in flight
@@ -469,7 +478,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_selfpull_q1x4_kernel(Attn
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int ic = min(i0 + u, sp.T - 1);
-      qn[u] = *reinterpret_cast<const float4*>(sp.Q_all + ic * sp.q_ts + b * s.q_bs + col);
+      qn[u] = attn_ld4(p, sp.Q_all + ic * sp.q_ts + b * s.q_bs + col);
       gn[u] = *reinterpret_cast<const float4*>(sp.dO_all + ic * sp.o_ts + b * s.o_bs + col);
       const long long ci = ((long long)ic * nbh + bh) * sp.T + sp.step;
       a[u] = sp.dS_all[ci]; bb[u] = sp.Pk_all[ci];
@@ -481,10 +490,8 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_selfpull_q1x4_kernel(Attn
       dv.x = fmaf(bu, gn[u].x, dv.x); dv.y = fmaf(bu, gn[u].y, dv.y); dv.z = fmaf(bu, gn[u].z, dv.z); dv.w = fmaf(bu, gn[u].w, dv.w);
     }
   }
-  *reinterpret_cast<float4*>(p.dK + b * s.k_bs + sp.step * s.k_rs + col) = dk;
-  *reinterpret_cast<float4*>(p.dV + b * s.v_bs + sp.step * s.v_rs + col) = dv;
-  ATTN_IMG(p, p.dK + b * s.k_bs + sp.step * s.k_rs + col, dk);
-  ATTN_IMG(p, p.dV + b * s.v_bs + sp.step * s.v_rs + col, dv);
+  ATTN_ST(p, p.dK + b * s.k_bs + sp.step * s.k_rs + col, dk);
+  ATTN_ST(p, p.dV + b * s.v_bs + sp.step * s.v_rs + col, dv);
 }
 
 // Deferred K/V gradients of a Lq == 1 attention evaluated at TT query steps against the SAME K/V rows (decoder
@@ -591,8 +598,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_fwd_sx4_kernel(AttnPtrs p, At
         const float pv = __shfl(pc, gbase + j, 64);      // 0 for j >= S
         o.x = fmaf(pv, v[j].x, o.x); o.y = fmaf(pv, v[j].y, o.y); o.z = fmaf(pv, v[j].z, o.z); o.w = fmaf(pv, v[j].w, o.w);
       }
-      *reinterpret_cast<float4*>(Ob + i * s.o_rs) = o;
-      ATTN_IMG(p, Ob + i * s.o_rs, o);
+      ATTN_ST(p, Ob + i * s.o_rs, o);
     }
   }
 }
@@ -648,8 +654,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_sx4_kernel(AttnPtrs p, At
         const float a = __shfl(dSc[i], gbase + j, 64);
         dq.x = fmaf(a, k[j].x, dq.x); dq.y = fmaf(a, k[j].y, dq.y); dq.z = fmaf(a, k[j].z, dq.z); dq.w = fmaf(a, k[j].w, dq.w);
       }
-      *reinterpret_cast<float4*>(dQb + i * s.q_rs) = dq;
-      ATTN_IMG(p, dQb + i * s.q_rs, dq);
+      ATTN_ST(p, dQb + i * s.q_rs, dq);
     }
   }
   // K / V rows are dead from here; the Q rows take their registers (fetched only now: all five row sets at once would
@@ -674,10 +679,8 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_sx4_kernel(AttnPtrs p, At
         dk.x = fmaf(a, q[i].x, dk.x); dk.y = fmaf(a, q[i].y, dk.y); dk.z = fmaf(a, q[i].z, dk.z); dk.w = fmaf(a, q[i].w, dk.w);
         dv.x = fmaf(bb, go[i].x, dv.x); dv.y = fmaf(bb, go[i].y, dv.y); dv.z = fmaf(bb, go[i].z, dv.z); dv.w = fmaf(bb, go[i].w, dv.w);
       }
-      *reinterpret_cast<float4*>(dKb + j * s.k_rs) = dk;
-      *reinterpret_cast<float4*>(dVb + j * s.v_rs) = dv;
-      ATTN_IMG(p, dKb + j * s.k_rs, dk);
-      ATTN_IMG(p, dVb + j * s.v_rs, dv);
+      ATTN_ST(p, dKb + j * s.k_rs, dk);
+      ATTN_ST(p, dVb + j * s.v_rs, dv);
     }
   }
 }
@@ -735,12 +738,13 @@ int check_shape(const AttnShape& s) {
 }  // namespace
 
 int mansy_launch_attn_fwd(const float* Q, const float* K, const float* V, float* O, float* P_save, const AttnShape& s,
-                          MansyDrop drop, hipStream_t st, const float* img_f, unsigned short* img_s) {
+                          MansyDrop drop, hipStream_t st, const float* img_f, unsigned short* img_s, int img_only, int kv16) {
   int rc = check_shape(s); if (rc) return rc;
   MANSY_REQUIRE(Q && K && V && O, "attn_fwd: null pointer");
+  MANSY_REQUIRE(!kv16 || q1x4_ok(s, Q, K, V, O), "attn_fwd: the bf16 K/V cache is read by the 4-heads-per-wave Lq = 1 kernel only");
   const long long n = (long long)s.nb * s.H;
   if (n == 0) return MANSY_OK;
-  AttnPtrs p = {Q, K, V, O, P_save, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, img_f, img_s};
+  AttnPtrs p = {Q, K, V, O, P_save, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, img_f, img_s, img_s ? img_only : 0, img_s ? kv16 : 0};
   MANSY_REQUIRE(!img_s || q1x4_ok(s, Q, K, V, O) || sx4_ok(s, Q, K, V, O), "attn_fwd: the bf16 image needs the 4-heads-per-wave kernels");
   if (q1x4_ok(s, Q, K, V, O))
     MANSY_Q1X4_DISPATCH(attn_fwd_q1x4_kernel, s.Lk, dim3(mansy_ceil_div(n / 4, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop)
@@ -753,12 +757,12 @@ int mansy_launch_attn_fwd(const float* Q, const float* K, const float* V, float*
 }
 
 int mansy_launch_attn_bwd(const float* Q, const float* K, const float* V, const float* P_save, const float* dO, float* dQ,
-                          float* dK, float* dV, const AttnShape& s, MansyDrop drop, int accum_kv, hipStream_t st, const float* img_f, unsigned short* img_s) {
+                          float* dK, float* dV, const AttnShape& s, MansyDrop drop, int accum_kv, hipStream_t st, const float* img_f, unsigned short* img_s, int img_only) {
   int rc = check_shape(s); if (rc) return rc;
   MANSY_REQUIRE(Q && K && V && P_save && dO && dQ && dK && dV, "attn_bwd: null pointer");
   const long long n = (long long)s.nb * s.H;
   if (n == 0) return MANSY_OK;
-  AttnPtrs p = {Q, K, V, nullptr, const_cast<float*>(P_save), dO, dQ, dK, dV, nullptr, nullptr, img_f, img_s};
+  AttnPtrs p = {Q, K, V, nullptr, const_cast<float*>(P_save), dO, dQ, dK, dV, nullptr, nullptr, img_f, img_s, (img_s && !accum_kv) ? img_only : 0, 0};
   MANSY_REQUIRE(!img_s || (sx4_ok(s, Q, K, V, dO) && sx4_ok(s, dQ, dK, dV, dO) && !q1x4_ok(s, Q, K, V, dO)), "attn_bwd: the bf16 image is kept by the encoder (S x S) kernel only");
   if (q1x4_ok(s, Q, K, V, dO) && q1x4_ok(s, dQ, dK, dV, dO))
     MANSY_Q1X4_DISPATCH(attn_bwd_q1x4_kernel, s.Lk, dim3(mansy_ceil_div(n / 4, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop, accum_kv)
@@ -777,13 +781,13 @@ int mansy_attn_deferred_kv_ok(const AttnShape& s, int T) {
 }
 // One step: dQ only; dS_out / Pk_out [nb*H, Lk] receive the coefficients mansy_launch_attn_kvgrad sums over the steps.
 int mansy_launch_attn_bwd_dq(const float* Q, const float* K, const float* V, const float* P_save, const float* dO, float* dQ,
-                             float* dS_out, float* Pk_out, const AttnShape& s, MansyDrop drop, hipStream_t st, const float* img_f, unsigned short* img_s) {
+                             float* dS_out, float* Pk_out, const AttnShape& s, MansyDrop drop, hipStream_t st, const float* img_f, unsigned short* img_s, int img_only, int kv16) {
   int rc = check_shape(s); if (rc) return rc;
   MANSY_REQUIRE(Q && K && V && P_save && dO && dQ && dS_out && Pk_out, "attn_bwd_dq: null pointer");
   MANSY_REQUIRE(q1x4_ok(s, Q, K, V, dO) && q1x4_ok(s, dQ, K, V, dO), "attn_bwd_dq: shape / alignment not on the 4-heads-per-wave path");
   const long long n = (long long)s.nb * s.H;
   if (n == 0) return MANSY_OK;
-  AttnPtrs p = {Q, K, V, nullptr, const_cast<float*>(P_save), dO, dQ, nullptr, nullptr, dS_out, Pk_out, img_f, img_s};
+  AttnPtrs p = {Q, K, V, nullptr, const_cast<float*>(P_save), dO, dQ, nullptr, nullptr, dS_out, Pk_out, img_f, img_s, img_s ? img_only : 0, img_s ? kv16 : 0};
   MANSY_Q1X4_DISPATCH(attn_bwd_q1x4_kernel, s.Lk, dim3(mansy_ceil_div(n / 4, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop, 0)
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
@@ -811,7 +815,7 @@ int mansy_launch_attn_kvgrad(const float* Q_all, long long q_ts, const float* dO
 int mansy_attn_selfpull_ok(const AttnShape& s, int T) { return mansy_attn_deferred_kv_ok(s, T); }
 int mansy_launch_attn_bwd_selfpull(const float* Q_all, long long q_ts, const float* K, const float* V, const float* P_save,
                                    const float* dO_all, long long o_ts, float* dQ, float* dK, float* dV, float* dS_all, float* Pk_all,
-                                   const AttnShape& s, int T, int step, MansyDrop drop, hipStream_t st, const float* img_f, unsigned short* img_s) {
+                                   const AttnShape& s, int T, int step, MansyDrop drop, hipStream_t st, const float* img_f, unsigned short* img_s, int img_only, int kv16) {
   int rc = check_shape(s); if (rc) return rc;
   MANSY_REQUIRE(Q_all && K && V && P_save && dO_all && dQ && dK && dV && dS_all && Pk_all, "attn_bwd_selfpull: null pointer");
   MANSY_REQUIRE(step >= 0 && step < T && s.Lk == step + 1 && mansy_attn_selfpull_ok(s, T) && (q_ts % 4) == 0 && (o_ts % 4) == 0,
@@ -819,7 +823,7 @@ int mansy_launch_attn_bwd_selfpull(const float* Q_all, long long q_ts, const flo
   MANSY_REQUIRE(q1x4_ok(s, Q_all, K, V, dO_all) && q1x4_ok(s, dQ, dK, dV, dO_all), "attn_bwd_selfpull: alignment");
   const long long n = (long long)s.nb * s.H;
   if (n == 0) return MANSY_OK;
-  AttnPtrs p = {nullptr, K, V, nullptr, const_cast<float*>(P_save), nullptr, dQ, dK, dV, nullptr, nullptr, img_f, img_s};
+  AttnPtrs p = {nullptr, K, V, nullptr, const_cast<float*>(P_save), nullptr, dQ, dK, dV, nullptr, nullptr, img_f, img_s, img_s ? img_only : 0, img_s ? kv16 : 0};
   SelfPull sp = {Q_all, q_ts, dO_all, o_ts, dS_all, Pk_all, T, step};
   MANSY_Q1X4_DISPATCH(attn_bwd_selfpull_q1x4_kernel, s.Lk, dim3(mansy_ceil_div(n / 4, WAVES)), dim3(64 * WAVES), 0, st, p, s, drop, sp)
   MANSY_LAUNCH_CHECK();

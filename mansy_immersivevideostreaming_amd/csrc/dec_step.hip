@@ -283,7 +283,7 @@ __global__ __launch_bounds__(64 * HEAD_WAVES) void dec_head_bwd_kernel(MansyDecH
         od.z = mansy_keep(p.drop3.seed, p.drop3.site, p.drop3.base + (uint32_t)(off + 2), p.drop3.p) ? o.z * dsc : 0.f;
         od.w = mansy_keep(p.drop3.seed, p.drop3.site, p.drop3.base + (uint32_t)(off + 3), p.drop3.p) ? o.w * dsc : 0.f;
       }
-      *reinterpret_cast<float4*>(p.dbr3 + off) = od;
+      if (!p.dbr3_img_only) *reinterpret_cast<float4*>(p.dbr3 + off) = od;
       if (p.dbr3_16) mansy_st_bf16x4(p.dbr3_16 + off, od.x, od.y, od.z, od.w);
       adw_3[i].x += dy3[i].x * xh[i].x; adw_3[i].y += dy3[i].y * xh[i].y; adw_3[i].z += dy3[i].z * xh[i].z; adw_3[i].w += dy3[i].w * xh[i].w;
       adb_3[i].x += dy3[i].x; adb_3[i].y += dy3[i].y; adb_3[i].z += dy3[i].z; adb_3[i].w += dy3[i].w;

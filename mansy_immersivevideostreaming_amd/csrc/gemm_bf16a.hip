@@ -27,13 +27,13 @@ constexpr int BK16 = 64;          // bf16 elements per K-tile (128 bytes per K-c
 
 // ------------------------------------------------------------------------------------------------------------------------------ NN
 template <int BM, int BN, int NS>
-__global__ __launch_bounds__(NT, (BM * BN <= 128 * 64) ? 2 : 1) void gemm_bf16a_nn_kernel(GemmParams p) {
+__global__ __launch_bounds__(NT, (BM * BN <= 128 * 64 && NS <= 4) ? 2 : 1) void gemm_bf16a_nn_kernel(GemmParams p) {
   constexpr int TM = BM / 64, TN = BN / 64 > 0 ? BN / 64 : 1, PA = BM / 32, PB = BN / 32, D = NS - 1;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
   constexpr int C_FLOATS = BM * (BN + 4);
   constexpr int SMEM_FLOATS = (NS * STAGE_BYTES / 4) > C_FLOATS ? (NS * STAGE_BYTES / 4) : C_FLOATS;
   constexpr int PPT = PA + PB;                                                                  // DMA pieces per wave and K-tile
-  static_assert(BN >= 64 && NS >= 2 && NS <= 4 && 2 * PPT <= 63, "piece counts must fit the counted waits");
+  static_assert(BN >= 64 && NS >= 2 && NS <= 6 && (D - 1) * PPT <= 63, "piece counts must fit the counted waits");
   __shared__ __attribute__((aligned(1024))) float smem[SMEM_FLOATS];
 
   const int tid = threadIdx.x;
@@ -104,7 +104,9 @@ __global__ __launch_bounds__(NT, (BM * BN <= 128 * 64) ? 2 : 1) void gemm_bf16a_
   for (int kt = 0; kt < nk; ++kt) {
     // tiles still wanted in flight after tile kt has landed: min(D - 1, nk - 1 - kt) of them, PPT pieces each (the wait count is an immediate)
     const int ahead = nk - 1 - kt;
-    if (D >= 3 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPT) : "memory");
+    if (D >= 5 && ahead >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D >= 5 ? 4 * PPT : 0) : "memory");
+    else if (D >= 4 && ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D >= 4 ? 3 * PPT : 0) : "memory");
+    else if (D >= 3 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D >= 3 ? 2 * PPT : 0) : "memory");
     else if (D >= 2 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPT) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -284,7 +286,13 @@ int mansy_gemm_bf16a_nn(const GemmParams& p, int tile, hipStream_t st) {
                     p.K >= BK16, "bf16-storage product: operands must be 16-byte aligned with leading dimensions %% 8 == 0 and K %% 64 == 0");
   dim3 block(NT);
   if (tile == 128) { dim3 grid(mansy_ceil_div(p.N, 128), mansy_ceil_div(p.M, 128), 1); MANSY_GEMM_LAUNCH((gemm_bf16a_nn_kernel<128, 128, 3>), grid, block, st, p); }
-  else if (tile == 96) { dim3 grid(mansy_ceil_div(p.N, 64), mansy_ceil_div(p.M, 128), 1); MANSY_GEMM_LAUNCH((gemm_bf16a_nn_kernel<128, 64, 3>), grid, block, st, p); }
+  else if (tile == 96) {
+    dim3 grid(mansy_ceil_div(p.N, 64), mansy_ceil_div(p.M, 128), 1);
+    // a launch of at most one workgroup per CU (the [4 096, 512, K] decoder-step products: 256 tiles) is a latency chain of its own: SIX stages (144 KB, five
+    // of the eight K-tiles in flight) instead of three -- the tiles then arrive back to back behind ONE cold fetch instead of one fetch latency per two tiles
+    if ((long long)grid.x * grid.y <= 256) MANSY_GEMM_LAUNCH((gemm_bf16a_nn_kernel<128, 64, 6>), grid, block, st, p);
+    else MANSY_GEMM_LAUNCH((gemm_bf16a_nn_kernel<128, 64, 3>), grid, block, st, p);
+  }
   else { dim3 grid(mansy_ceil_div(p.N, 64), mansy_ceil_div(p.M, 64), 1); MANSY_GEMM_LAUNCH((gemm_bf16a_nn_kernel<64, 64, 4>), grid, block, st, p); }
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;

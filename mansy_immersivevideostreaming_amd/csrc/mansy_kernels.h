@@ -112,12 +112,13 @@ struct AttnShape {
 // P_save: [nb*H, Lq, Lk] softmax probabilities BEFORE dropout (needed by backward); may be null in eval.
 // img_f / img_s (all attention launchers; bf16-storage mode): the output rows' bf16 image -- the float4 stored at address a also goes to img_s + (a - img_f)
 int mansy_launch_attn_fwd(const float* Q, const float* K, const float* V, float* O, float* P_save,
-                          const AttnShape& s, MansyDrop drop, hipStream_t st, const float* img_f = nullptr, unsigned short* img_s = nullptr);
+                          const AttnShape& s, MansyDrop drop, hipStream_t st, const float* img_f = nullptr, unsigned short* img_s = nullptr, int img_only = 0,
+                          int kv16 = 0);      // kv16 (Lq = 1 kernels): K / V rows are read from their bf16 images (bf16 K/V cache)
 // dQ is overwritten; dK/dV are accumulated (+=) when accum_kv != 0, else overwritten.
 // dq/dk/dv use the q/k/v strides of `s`; dO uses the o strides.
 int mansy_launch_attn_bwd(const float* Q, const float* K, const float* V, const float* P_save, const float* dO,
                           float* dQ, float* dK, float* dV, const AttnShape& s, MansyDrop drop, int accum_kv,
-                          hipStream_t st, const float* img_f = nullptr, unsigned short* img_s = nullptr);
+                          hipStream_t st, const float* img_f = nullptr, unsigned short* img_s = nullptr, int img_only = 0);
 
 // Deferred K/V gradients for a Lq == 1 attention evaluated at T steps against the same K/V rows (decoder cross-attention):
 // per step mansy_launch_attn_bwd_dq writes dQ and the step's coefficients (dS, dropped P: [nb*H, Lk] each); one
@@ -126,7 +127,7 @@ int mansy_launch_attn_bwd(const float* Q, const float* K, const float* V, const 
 int mansy_attn_deferred_kv_ok(const AttnShape& s, int T);
 int mansy_launch_attn_bwd_dq(const float* Q, const float* K, const float* V, const float* P_save, const float* dO, float* dQ,
                              float* dS_out, float* Pk_out, const AttnShape& s, MansyDrop drop, hipStream_t st,
-                             const float* img_f = nullptr, unsigned short* img_s = nullptr);
+                             const float* img_f = nullptr, unsigned short* img_s = nullptr, int img_only = 0, int kv16 = 0);
 int mansy_launch_attn_kvgrad(const float* Q_all, long long q_ts, const float* dO_all, long long o_ts, const float* dS_all,
                              const float* Pk_all, float* dK, float* dV, const AttnShape& s, int T, int accum, hipStream_t st);
 
@@ -137,7 +138,7 @@ int mansy_attn_selfpull_ok(const AttnShape& s, int T);
 int mansy_launch_attn_bwd_selfpull(const float* Q_all, long long q_ts, const float* K, const float* V, const float* P_save,
                                    const float* dO_all, long long o_ts, float* dQ, float* dK, float* dV, float* dS_all, float* Pk_all,
                                    const AttnShape& s, int T, int step, MansyDrop drop, hipStream_t st,
-                                   const float* img_f = nullptr, unsigned short* img_s = nullptr);
+                                   const float* img_f = nullptr, unsigned short* img_s = nullptr, int img_only = 0, int kv16 = 0);
 
 // ---------------------------------------------------------------- norms (norm.hip)
 // z = a (+ b);  y = LN(z) * w (+ bias).  z_out may be null (not saved) or alias a when b == null.
@@ -212,6 +213,7 @@ struct MansyDecHeadBwd {
   const float* z3; const float* m3; const float* r3; const float* n3_w; float* part_n3; float* gz; float* dbr3; MansyDrop drop3;
   int rows, C, C6;
   unsigned short* dbr3_16 = nullptr;       // bf16 image of dbr3 (bf16-storage mode)
+  int dbr3_img_only = 0;                   // != 0 (with dbr3_16): dbr3 is an operand of dense products only -- no float store
 };
 int mansy_launch_dec_head_bwd(const MansyDecHeadBwd& p, int n_slots, hipStream_t st);
 

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
           o.x = rs[u] * (di.x * ww[i].x - s1 - xh[i].x * s2); o.y = rs[u] * (di.y * ww[i].y - s1 - xh[i].y * s2);
           o.z = rs[u] * (di.z * ww[i].z - s1 - xh[i].z * s2); o.w = rs[u] * (di.w * ww[i].w - s1 - xh[i].w * s2);
           *reinterpret_cast<float4*>(dz + off) = o;
-          if (dz_drop) {
+          if (dz_drop || dz_drop16) {
             float4 od = o;
             if (drop.p > 0.f) {
               od.x = mansy_keep(drop.seed, drop.site, drop.base + (uint32_t)(off + 0), drop.p) ? o.x * dsc : 0.f;
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
               od.z = mansy_keep(drop.seed, drop.site, drop.base + (uint32_t)(off + 2), drop.p) ? o.z * dsc : 0.f;
               od.w = mansy_keep(drop.seed, drop.site, drop.base + (uint32_t)(off + 3), drop.p) ? o.w * dsc : 0.f;
             }
-            *reinterpret_cast<float4*>(dz_drop + off) = od;
+            if (dz_drop) *reinterpret_cast<float4*>(dz_drop + off) = od;
             if (dz_drop16) mansy_st_bf16x4(dz_drop16 + off, od.x, od.y, od.z, od.w);
           }
           adw[i].x += di.x * xh[i].x; adw[i].y += di.y * xh[i].y; adw[i].z += di.z * xh[i].z; adw[i].w += di.w * xh[i].w;

@@ -324,9 +324,9 @@ struct Eng {
               const float* resid = nullptr, bool y_img = false, bool x_img = true) {
     GemmEpilogue ep; ep.prec = prec; ep.bias = b; ep.relu = relu; ep.drop = drop; ep.resid = resid; ep.resid_ld = Nout;
     if (prec) attach_planes(ep, w, false);
+    if (s16 && y_img) { ep.c16 = im(Y); ep.c16_ld = Nout; }          // (the shared epilogue stores it on either loop)
     if (s16 && x_img && ep.b_planes && K % 64 == 0) {
       ep.a16 = im(X); ep.a16_ld = K;
-      if (y_img) { ep.c16 = im(Y); ep.c16_ld = Nout; }
       return mansy_launch_gemm_bf16a(0, 0, Y, Nout, rows, Nout, K, ep, 0, 0, st);
     }
     return mansy_launch_gemm_f32(X, K, 0, w, K, 0, Y, Nout, rows, Nout, K, ep, 0, 0, st);
@@ -370,12 +370,12 @@ struct Eng {
     if (part_slot < 0) {          // encoder LayerNorm -(part_slot + 1): its own scratch set, overwritten; added into the gradient by the one reduce launch at the end
       const int e = -(part_slot + 1);
       float* set = W.lnp_enc + (size_t)e * mansy_ln_bwd_parts(rows) * 2 * d;
-      RC(mansy_launch_layernorm_bwd_partial(dy, z, m, r, n.w, dz, dz_drop, drop, set, 0, rows, d, st, dz_drop ? im(dz_drop) : nullptr));
+      RC(mansy_launch_layernorm_bwd_partial(dy, z, m, r, n.w, dz, s16 ? nullptr : dz_drop, drop, set, 0, rows, d, st, dz_drop ? im(dz_drop) : nullptr));      // (bf16 storage: dz_drop feeds products only -- image only)
       ln_pending[ln_n_pending++] = MansyLnReduce{set, mansy_ln_bwd_parts(rows), n.gw, n.gb};
       return MANSY_OK;
     }
     float* slots = W.lnp_dec + (size_t)part_slot * mansy_ln_bwd_parts(B) * 2 * d;
-    return mansy_launch_layernorm_bwd_partial(dy, z, m, r, n.w, dz, dz_drop, drop, slots, 1, rows, d, st, dz_drop ? im(dz_drop) : nullptr);
+    return mansy_launch_layernorm_bwd_partial(dy, z, m, r, n.w, dz, s16 ? nullptr : dz_drop, drop, slots, 1, rows, d, st, dz_drop ? im(dz_drop) : nullptr);
   }
 
   AttnShape enc_shape() const {
@@ -405,7 +405,7 @@ struct Eng {
     for (int l = 0; l < c.n_enc; ++l) {
       const EncLayerP& p = P.enc[l]; EncBuf& e = W.enc[l];
       RC(lin_fwd(x, N, d, p.in_proj.w, p.in_proj.b, 3 * d, e.qkv, 0, mansy_no_drop()));
-      RC(mansy_launch_attn_fwd(e.qkv, e.qkv + d, e.qkv + 2 * d, e.ao, e.P, enc_shape(), dr(site_enc(l, 0), c.p_drop), st, W.fbase, im(W.fbase)));
+      RC(mansy_launch_attn_fwd(e.qkv, e.qkv + d, e.qkv + 2 * d, e.ao, e.P, enc_shape(), dr(site_enc(l, 0), c.p_drop), st, W.fbase, im(W.fbase), 1));
       RC(lin_fwd(e.ao, N, d, p.out_proj.w, p.out_proj.b, d, e.z1, 0, dr(site_enc(l, 1), c.p_drop), x));          // z1 = x + drop(out_proj(ao))
       RC(ln_of(e.z1, p.n1, e.y1, e.m1, e.r1, N));
       RC(lin_fwd(e.y1, N, d, p.lin1.w, p.lin1.b, f, e.h, 1, dr(site_enc(l, 2), c.p_drop), nullptr, true));
@@ -422,8 +422,8 @@ struct Eng {
                                 train ? 1 : 0, c.bn_eps, c.bn_momentum, st, W.dis_part));
     for (int l = 0; l < c.n_dec; ++l) {
       const DecLayerP& p = P.dec[l];
-      RC(lin_fwd(W.mem, B * M, d, p.ca_in.w + (size_t)d * d, p.ca_in.b ? p.ca_in.b + d : nullptr, 2 * d, W.dec[l].memkv, 0, mansy_no_drop(), nullptr, false,
-                 false));      // (the distilled memory has no bf16 image: the DistillLayer keeps floats)
+      RC(lin_fwd(W.mem, B * M, d, p.ca_in.w + (size_t)d * d, p.ca_in.b ? p.ca_in.b + d : nullptr, 2 * d, W.dec[l].memkv, 0, mansy_no_drop(), nullptr, true,
+                 false));      // (the distilled memory has no bf16 image: the DistillLayer keeps floats; the projected K/V rows get one: the cross-attention cache)
     }
     MANSY_HIP_CHECK(hipMemcpyAsync(W.tok_all, cur, sizeof(float) * B * C6, hipMemcpyDeviceToDevice, st));
     // the four row-wise ops between the last product of step i and the first of step i+1 run as one launch (dec_step.hip)
@@ -480,14 +480,14 @@ struct Eng {
       float* qkv_i = e.qkv + o * 3 * d;
       const float* kv0 = e.qkv + (size_t)b0 * 3 * d;           // keys / values of step 0 for these rows (step stride B * 3d)
       const float* mkv = e.memkv + (size_t)b0 * M * 2 * d;
-      RC(lin_fwd(xi, nb, d, p.sa_in.w, p.sa_in.b, 3 * d, qkv_i, 0, mansy_no_drop()));
+      RC(lin_fwd(xi, nb, d, p.sa_in.w, p.sa_in.b, 3 * d, qkv_i, 0, mansy_no_drop(), nullptr, true));      // + bf16 image: the K/V cache of the bf16-storage mode
       RC(mansy_launch_attn_fwd(qkv_i, kv0 + d, kv0 + 2 * d, e.ao1 + o * d, e.P1 + o * H * T, self_shape(i, nb),
-                               dr(site_dec(l, i, 0), c.p_drop, (size_t)b0 * H * (i + 1)), st, W.fbase, im(W.fbase)));
+                               dr(site_dec(l, i, 0), c.p_drop, (size_t)b0 * H * (i + 1)), st, W.fbase, im(W.fbase), 1, s16 ? 1 : 0));
       RC(lin_fwd(e.ao1 + o * d, nb, d, p.sa_out.w, p.sa_out.b, d, e.z1 + o * d, 0, dr(site_dec(l, i, 1), c.p_drop, (size_t)b0 * d), xi));
       RC(ln_of(e.z1 + o * d, p.n1, e.y1 + o * d, e.m1 + o, e.r1 + o, nb));
       RC(lin_fwd(e.y1 + o * d, nb, d, p.ca_in.w, p.ca_in.b, d, e.qc + o * d, 0, mansy_no_drop()));
       RC(mansy_launch_attn_fwd(e.qc + o * d, mkv, mkv + d, e.ao2 + o * d, e.P2 + o * H * M, cross_shape(nb),
-                               dr(site_dec(l, i, 2), c.p_drop, (size_t)b0 * H * M), st, W.fbase, im(W.fbase)));
+                               dr(site_dec(l, i, 2), c.p_drop, (size_t)b0 * H * M), st, W.fbase, im(W.fbase), 1, s16 ? 1 : 0));
       RC(lin_fwd(e.ao2 + o * d, nb, d, p.ca_out.w, p.ca_out.b, d, e.z2 + o * d, 0, dr(site_dec(l, i, 3), c.p_drop, (size_t)b0 * d), e.y1 + o * d));
       RC(ln_of(e.z2 + o * d, p.n2, e.y2 + o * d, e.m2 + o, e.r2 + o, nb));
       RC(lin_fwd(e.y2 + o * d, nb, d, p.lin1.w, p.lin1.b, f, e.h + o * f, 1, dr(site_dec(l, i, 4), c.p_drop, (size_t)b0 * f), nullptr, true));
@@ -535,7 +535,7 @@ struct Eng {
     auto ln_bwd_dec = [&](const float* dy, const float* z, const float* m, const float* r, const NormP& n, float* dz, float* dz_drop, MansyDrop drop,
                           int slot) {
       if (!ln_parts) return mansy_launch_layernorm_bwd(dy, z, m, r, n.w, dz, dz_drop, drop, n.gw, n.gb, nb, d, st);
-      return mansy_launch_layernorm_bwd_partial(dy, z, m, r, n.w, dz, dz_drop, drop, lnp + (size_t)slot * lnp_set, 1, nb, d, st, dz_drop ? im(dz_drop) : nullptr);
+      return mansy_launch_layernorm_bwd_partial(dy, z, m, r, n.w, dz, s16 ? nullptr : dz_drop, drop, lnp + (size_t)slot * lnp_set, 1, nb, d, st, dz_drop ? im(dz_drop) : nullptr);
     };
     if (fuse_head) {
       const int L = c.n_dec - 1;
@@ -549,7 +549,7 @@ struct Eng {
       hp.y3 = e.y3 + o * d; hp.md = W.md + o; hp.rd = W.rd + o; hp.dn_w = P.dec_norm.w; hp.part_dn = lnp + (size_t)(3 * c.n_dec) * lnp_set;
       hp.z3 = e.z3 + o * d; hp.m3 = e.m3 + o; hp.r3 = e.r3 + o; hp.n3_w = P.dec[L].n3.w; hp.part_n3 = lnp + (size_t)(3 * L + 2) * lnp_set;
       hp.gz = gz; hp.dbr3 = e.dbr3 + o * d; hp.drop3 = dr(site_dec(L, i, 5), c.p_drop, bd);
-      hp.rows = nb; hp.C = d; hp.C6 = C6; hp.dbr3_16 = im(hp.dbr3);
+      hp.rows = nb; hp.C = d; hp.C6 = C6; hp.dbr3_16 = im(hp.dbr3); hp.dbr3_img_only = s16 ? 1 : 0;
       // (its own grid rule: 16 rows per workgroup as before -- 8 made this fused kernel 17.9 -> 22 us; it fills the first slots of its sets, the rest stay
       // zero from the memset and the reduce launches add them as such)
       RC(mansy_launch_dec_head_bwd(hp, std::min(mansy_ln_bwd_parts(nb), (nb + 15) / 16), st));
@@ -574,7 +574,7 @@ struct Eng {
         float* dao2_i = e.dao2 + o * d;
         RC(lin_dx(e.dbr2 + o * d, nb, d, p.ca_out.w, d, dao2_i, nullptr, nullptr, 1.f));   // d/dao2, kept for the deferred dV
         RC(mansy_launch_attn_bwd_dq(e.qc + o * d, mkv, mkv + d, e.P2 + o * H * M, dao2_i, e.dqc + o * d, e.dS2 + o * H * M,
-                                    e.Pk2 + o * H * M, cross_shape(nb), dr(site_dec(l, i, 2), c.p_drop, (size_t)b0 * H * M), st, W.fbase, im(W.fbase)));
+                                    e.Pk2 + o * H * M, cross_shape(nb), dr(site_dec(l, i, 2), c.p_drop, (size_t)b0 * H * M), st, W.fbase, im(W.fbase), 1, s16 ? 1 : 0));
       } else {
         float* dmkv = e.dmemkv + (size_t)b0 * M * 2 * d;
         RC(lin_dx(e.dbr2 + o * d, nb, d, p.ca_out.w, d, gt, nullptr, nullptr, 1.f));       // gt = d/dao2
@@ -593,7 +593,7 @@ struct Eng {
         const size_t co = (size_t)b0 * T * H * T;
         RC(mansy_launch_attn_bwd_selfpull(kv0, (long long)B * 3 * d, kv0 + d, kv0 + 2 * d, e.P1 + o * H * T, e.dao1 + (size_t)b0 * d, (long long)B * d,
                                           dqkv_i, dkv0 + d, dkv0 + 2 * d, e.dS1 + co, e.Pk1 + co, self_shape(i, nb), T, i,
-                                          dr(site_dec(l, i, 0), c.p_drop, (size_t)b0 * H * (i + 1)), st, W.fbase, im(W.fbase)));
+                                          dr(site_dec(l, i, 0), c.p_drop, (size_t)b0 * H * (i + 1)), st, W.fbase, im(W.fbase), 1, s16 ? 1 : 0));
       } else {
         RC(lin_dx(e.dbr1 + o * d, nb, d, p.sa_out.w, d, gt, nullptr, nullptr, 1.f));       // gt = d/dao1
         RC(mansy_launch_attn_bwd(qkv_at(e, o), kv0 + d, kv0 + 2 * d, e.P1 + o * H * T, gt, dqkv_i, dkv0 + d, dkv0 + 2 * d,
@@ -701,7 +701,7 @@ struct Eng {
       RC(lin_dw(gx, e.ao, N, d, d, p.out_proj.gw, p.out_proj.gb));
       RC(lin_dx(gx, N, d, p.out_proj.w, d, gt, nullptr, nullptr, 1.f));                        // gt = d/dao
       RC(mansy_launch_attn_bwd(e.qkv, e.qkv + d, e.qkv + 2 * d, e.P, gt, W.g_wide, W.g_wide + d, W.g_wide + 2 * d, enc_shape(),
-                               dr(site_enc(l, 0), c.p_drop), 0, st, W.fbase, im(W.fbase)));
+                               dr(site_enc(l, 0), c.p_drop), 0, st, W.fbase, im(W.fbase), 1));
       RC(lin_dw(W.g_wide, x_in, N, 3 * d, d, p.in_proj.gw, p.in_proj.gb));
       RC(lin_dx(W.g_wide, N, 3 * d, p.in_proj.w, d, gx, gz, nullptr, 1.f));                    // gx = d/d(layer input)
     }
