@@ -45,7 +45,7 @@ def source_digest():
     return h.hexdigest()
 
 
-GEMM_SOURCES = ('gemm_f32.hip', 'gemm_bf16s.hip', 'gemm_tile.h', 'gemm_wsk.h', 'mansy_kernels.h', 'mansy_common.h')
+GEMM_SOURCES = ('gemm_f32.hip', 'gemm_bf16s.hip', 'gemm_bf16a.hip', 'gemm_tile.h', 'gemm_wsk.h', 'mansy_kernels.h', 'mansy_common.h')
 
 
 def gemm_source_digest():

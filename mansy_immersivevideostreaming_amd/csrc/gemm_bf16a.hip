@@ -135,10 +135,24 @@ __global__ __launch_bounds__(NT, (BM * BN <= 128 * 64 && NS <= 4) ? 2 : 1) void 
 // ------------------------------------------------------------------------------------------------------------------------------ TN
 // ds_read_b64_tr_b16: lane 4 q + p of a 16-lane group supplies the address of row q, columns 4 p .. 4 p + 3 of the group's 4 x 16 block; lane i
 // of the group receives column i, row q in element q.  EXEC must be all ones (no divergence around it).
-__device__ __forceinline__ bf16x4 lds_tr4(unsigned addr) {
-  bf16x4 v;
-  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
-  return v;
+// The eight transposed reads of one k-step and the wait for them as ONE asm statement: the consumers of the results then depend on a statement that
+// contains the s_waitcnt.  (As separate statements -- reads, then `s_waitcnt lgkmcnt(0)` -- nothing ties the results to the wait: the compiler may schedule
+// the register moves / MFMAs that consume them ABOVE it, and they then read VGPRs the LDS has not written yet.  That passed every single-process test and
+// produced NaN weight gradients once two processes shared the device and LDS latencies grew: round 6, tools/vp_dp2_probe.py.)
+__device__ __forceinline__ void lds_tr4x8(bf16x4& r0, bf16x4& r1, bf16x4& r2, bf16x4& r3, bf16x4& r4, bf16x4& r5, bf16x4& r6, bf16x4& r7,
+                                          unsigned a0, unsigned a1, unsigned a2, unsigned a3, unsigned a4, unsigned a5, unsigned a6, unsigned a7) {
+  asm volatile("ds_read_b64_tr_b16 %0, %8\n\t"
+               "ds_read_b64_tr_b16 %1, %9\n\t"
+               "ds_read_b64_tr_b16 %2, %10\n\t"
+               "ds_read_b64_tr_b16 %3, %11\n\t"
+               "ds_read_b64_tr_b16 %4, %12\n\t"
+               "ds_read_b64_tr_b16 %5, %13\n\t"
+               "ds_read_b64_tr_b16 %6, %14\n\t"
+               "ds_read_b64_tr_b16 %7, %15\n\t"
+               "s_waitcnt lgkmcnt(0)"
+               : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+               : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7)
+               : "memory");
 }
 
 // byte offset of 16-byte chunk ch (0..15) of row k in a [64][128 x bf16] image with 256-byte rows (guide T10, image (b))
@@ -233,12 +247,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16a_tn_kernel(GemmParams p) {
     for (int s = 0; s < 4; ++s) {
       bf16x8 af[2], bf[2];
       bf16x4 a0[2], a1[2], b0[2], b1[2];
-#pragma unroll
-      for (int blk = 0; blk < 2; ++blk) {          // all eight transposed reads of the k-step in flight, ONE wait (inline asm: the compiler counts nothing)
-        a0[blk] = lds_tr4(st_l + ta[blk][0] + 4096u * s); a1[blk] = lds_tr4(st_l + ta[blk][1] + 4096u * s);
-        b0[blk] = lds_tr4(st_l + tb[blk][0] + 4096u * s); b1[blk] = lds_tr4(st_l + tb[blk][1] + 4096u * s);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      lds_tr4x8(a0[0], a1[0], b0[0], b1[0], a0[1], a1[1], b0[1], b1[1],
+                st_l + ta[0][0] + 4096u * s, st_l + ta[0][1] + 4096u * s, st_l + tb[0][0] + 4096u * s, st_l + tb[0][1] + 4096u * s,
+                st_l + ta[1][0] + 4096u * s, st_l + ta[1][1] + 4096u * s, st_l + tb[1][0] + 4096u * s, st_l + tb[1][1] + 4096u * s);
 #pragma unroll
       for (int blk = 0; blk < 2; ++blk)
 #pragma unroll

@@ -745,7 +745,8 @@ int mansy_launch_gemm_bf16a(int a_kmajor, int b_kmajor, float* C, int ldc, int M
       const long long t128 = (long long)mansy_ceil_div(M, 128) * mansy_ceil_div(N, 128);
       const long long t96 = (long long)mansy_ceil_div(M, 128) * mansy_ceil_div(N, 64);
       // (per-shape timing: profiles/r06_gemm_bf16a_bench.txt -- wide outputs (N >= 1024) run faster on 128 x 64 tiles, [40 960, 512, K] on 128 x 128)
-      tile = (t128 >= 512 && N < 1024) ? 128 : (t96 >= 192 ? 96 : 64);
+      // the [4 096-row] decoder-step products with N = 512 run fastest on 64 x 64 tiles, two workgroups per CU (7.2-7.8 us against 8.4-8.9 on 128 x 64)
+      tile = (t128 >= 512 && N < 1024) ? 128 : ((t96 >= 192 && (N >= 1024 || t96 > 512)) ? 96 : 64);
     }
     p.k_per_split = K; p.splits_pp = 1;
     rc = mansy_gemm_bf16a_nn(p, tile, st);

@@ -658,3 +658,37 @@ def test_role_split_256x128_loop_equals_the_other_loops_bit_for_bit(K):
                 assert torch.equal(K.gemm_planes(A, W, pl, force_tile=256), want[0])
         ref = A.double() @ W.double().t()
         assert ((want[0].double() - ref).abs().max() / ref.abs().max()).item() < GEMM_TOL['bf16x3']
+
+
+def test_bf16_storage_step_reads_no_image_it_has_not_written(K):
+    """The bf16-STORAGE form of precision 'bf16' (round 6: every operand of a dense product has a bf16 image in the workspace, written by the operand's
+    producer; csrc/vp_engine.hip, csrc/gemm_bf16a.hip): the WHOLE workspace -- float slabs and the image arena -- is poisoned with NaN bit patterns before
+    every call; four train steps and sample() must come out finite and agree with the un-poisoned run: nothing is read that the same call has not written."""
+    from mansy_immersivevideostreaming_amd.viewport_prediction.models import mtio
+    h, c, f = (t.cuda() for t in vo.synthetic_trajectories(256, 10, 10, seed=4))
+    outs = []
+    for poison in (False, True):
+        torch.manual_seed(0); random.seed(0); np.random.seed(0)
+        m = mtio.ViewportTransformerMTIO(in_channel=2, fut_window=10, d_model=512, dim_feedforward=512, device='cuda', seed=1)
+        m.load_state_dict(vo.make_state_dict(512, 3, bias=False))
+        m = m.to('cuda').train()
+        m.precision = 'bf16'
+        opt = mtio.FusedAdamW(m, lr=1e-4)
+        losses = []
+        for _ in range(4):
+            if poison:
+                ws = m._workspace(m._cfg(256, 10))
+                ws.view(torch.int16).fill_(0x7FC0)                  # bf16 NaN in every 16 bits = float NaN (0x7FC07FC0) in every 32
+            losses.append(m.train_step(h, c, f, opt).item())
+        m.eval()
+        if poison:
+            m._workspace(m._cfg(256, 10)).view(torch.int16).fill_(0x7FC0)
+        outs.append((losses, m.sample(h, c).cpu(), m._flat_p.clone().cpu()))
+    assert all(np.isfinite(outs[1][0])) and torch.isfinite(outs[1][1]).all() and torch.isfinite(outs[1][2]).all()
+    # the first step starts from identical weights: its loss is a pure function of the forward (no atomics): bit-equal.  Later steps start from weights
+    # that differ by rounding (the split-K atomics of the weight-gradient products add in another order from run to run)
+    assert outs[0][0][0] == outs[1][0][0]
+    np.testing.assert_allclose(outs[1][0], outs[0][0], rtol=2e-4)
+    d = (outs[0][1] - outs[1][1]).abs()
+    assert torch.minimum(d, 1 - d).max().item() <= 5e-3          # (sample() of two models whose weights differ by rounding after four bf16 steps)
+    assert (outs[0][2] - outs[1][2]).abs().max().item() <= 4e-4

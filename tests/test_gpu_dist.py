@@ -253,3 +253,24 @@ def test_library_rccl_communicator_wrappers_world1():
         assert torch.equal(s, ref) and got.shape == (1, 3) and torch.equal(got[0], rms)
     finally:
         comm.close()
+
+
+@pytest.mark.gpu
+def test_bf16_storage_step_in_two_processes_sharing_the_gpu():
+    """Round 6 regression: the weight-gradient loop of the bf16-storage mode (csrc/gemm_bf16a.hip, ds_read_b64_tr_b16) had its LDS wait in a separate asm
+    statement from the reads, so the compiler could schedule the consumers above it -- invisible in every single-process test, NaN gradients as soon as two
+    processes shared the device (longer LDS latencies).  Two ranks share the GPU and run the bf16 VP step data-parallel (gloo) for four steps: every loss, every
+    gradient and every parameter stays finite on both (tools/vp_dp2_probe.py)."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(MANSY_DIST_BACKEND='gloo', MANSY_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0', MODES='bf16x6,bf16', OVERLAP='1')
+    with socket.socket() as s_:
+        s_.bind(('127.0.0.1', 0))
+        port = s_.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.join(ROOT, 'tools', 'vp_dp2_probe.py')]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    import re
+    recs = re.findall(r'rank (\d) (\S+) step (\d) loss (\S+) grads finite (True|False) params finite (True|False)', r.stdout)      # (two ranks print into one pipe)
+    assert len(recs) == 2 * 2 * 4, r.stdout[-2000:]
+    assert all(g == 'True' and p_ == 'True' and np.isfinite(float(l)) for _, _, _, l, g, p_ in recs), recs

@@ -1,10 +1,10 @@
 #!/bin/bash
-# Round-5 profile set (as round 3; the VP step is profiled single-stream: two_stream off; new: PPO meta + PMC, per-shape GEMM traffic) (run on the GPU box through gpurun; outputs under gpurun_out/r02, summaries are copied to profiles/ by hand):
+# Round-6 profile set (as round 5 + the bf16-storage mode) (as round 3; the VP step is profiled single-stream: two_stream off; new: PPO meta + PMC, per-shape GEMM traffic) (run on the GPU box through gpurun; outputs under gpurun_out/r02, summaries are copied to profiles/ by hand):
 #   rocprofv3 kernel-trace + stats of the VP train step (B=4096) per precision mode, step breakdowns, PMC passes (FETCH_SIZE /
 #   WRITE_SIZE in SEPARATE runs, no tracing alongside) for the fp32 and the split-bf16 GEMM kernels, the PPO cycle, and the
 #   byte / integer kernels (tools/hbm_kernels_bench.py).
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -23,13 +23,13 @@ h, c, f = (t.cuda() for t in synthetic_trajectories(4096, 10, 10, seed=5))
 for _ in range(int(sys.argv[1])): m.train_step(h, c, f, opt)
 torch.cuda.synchronize()
 PY
-for mode in f32 bf16x3 bf16x6; do
+for mode in f32 bf16 bf16x3 bf16x6; do
   rm -rf gpurun_out/prof; mkdir -p gpurun_out/prof
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 /tmp/vp_only.py 5 $mode > $OUT/prof_$mode.log 2>&1; echo "trace $mode rc=$?"
   f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/vp_train_b4096_${mode}_kernel_stats.csv
   python3 tools/step_breakdown.py 45 > $OUT/vp_step_breakdown_$mode.txt 2>&1
 done
-for mode in f32 bf16x3 bf16x6; do
+for mode in f32 bf16 bf16x3 bf16x6; do
   rm -rf gpurun_out/pmc_r gpurun_out/pmc_w; mkdir -p gpurun_out/pmc_r gpurun_out/pmc_w
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_r -- python3 /tmp/vp_only.py 2 $mode > $OUT/pmc_r_$mode.log 2>&1; echo "pmc fetch $mode rc=$?"
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_w -- python3 /tmp/vp_only.py 2 $mode > $OUT/pmc_w_$mode.log 2>&1; echo "pmc write $mode rc=$?"
