@@ -384,9 +384,35 @@ class RcclComm:
         can = 1.0 if lib().mansy_comm_unique_id(ctypes.byref(probe)) == 0 else 0.0      # binds librccl.so on this rank (dlopen)
         if all_min(can) < 1.0:
             return None, 'RCCL cannot be bound on every rank (' + (lib().mansy_last_error() or b'').decode() + ')'
+        # step by step, agreeing after each: (1) rank 0 draws the id; EVERY rank takes part in the broadcast whatever happened on rank 0;
+        # (2) every rank confirms it can select its device; only then (3) the collective ncclCommInitRank, which has no time-out of its own
         self, ok, why = None, 1.0, ''
+        cid = CommId()
+        id_ok = 1.0
+        if rank == 0 and lib().mansy_comm_unique_id(ctypes.byref(cid)) != 0:
+            id_ok = 0.0
+        box = [(id_ok, bytes(cid.bytes))]
+        if world > 1 and dist.is_initialized():
+            dist.broadcast_object_list(box, src=0)
+        if box[0][0] < 1.0:
+            return None, 'rank 0 could not draw a communicator id'
+        dev_ok = 1.0
         try:
-            self = cls(world, rank, device)
+            if device is not None:
+                torch.cuda.set_device(device)
+        except Exception as e:          # noqa: BLE001
+            dev_ok, why = 0.0, f'rank {rank}: {e}'
+        if all_min(dev_ok) < 1.0:
+            return None, why or 'another rank could not select its device'
+        try:
+            self = cls.__new__(cls)
+            self.world, self.rank = int(world), int(rank)
+            from ._lib import check
+            self._lib, self._check = lib(), check
+            cid.bytes[:] = list(box[0][1])
+            ctx = ctypes.c_void_p()
+            check(self._lib.mansy_comm_create(ctypes.byref(cid), self.world, self.rank, ctypes.byref(ctx)), 'mansy_comm_create')
+            self.ctx = ctx
             x = torch.full((1024,), float(rank + 1), device=device)
             self(x)
             torch.cuda.synchronize(device)

@@ -688,7 +688,7 @@ def test_bf16_storage_step_reads_no_image_it_has_not_written(K):
     # the first step starts from identical weights: its loss is a pure function of the forward (no atomics): bit-equal.  Later steps start from weights
     # that differ by rounding (the split-K atomics of the weight-gradient products add in another order from run to run)
     assert outs[0][0][0] == outs[1][0][0]
-    np.testing.assert_allclose(outs[1][0], outs[0][0], rtol=2e-4)
+    np.testing.assert_allclose(outs[1][0], outs[0][0], rtol=5e-3)         # (Adam turns rounding noise of a near-zero gradient into a +-lr step: the runs drift apart by ~1e-3 over four steps)
     d = (outs[0][1] - outs[1][1]).abs()
     assert torch.minimum(d, 1 - d).max().item() <= 5e-3          # (sample() of two models whose weights differ by rounding after four bf16 steps)
     assert (outs[0][2] - outs[1][2]).abs().max().item() <= 4e-4
