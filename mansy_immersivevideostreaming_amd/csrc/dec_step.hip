@@ -24,7 +24,8 @@ __global__ __launch_bounds__(256) void dec_tail_fwd_kernel(MansyDecTailFwd p) {
   float4 v[NV], t[NV], w3[NV], b3[NV], wd[NV], bd[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    v[i] = *reinterpret_cast<const float4*>(p.a + base + i * 256);
+    if (p.a16) { const mansy_bf16x4 u = *reinterpret_cast<const mansy_bf16x4*>(p.a16 + base + i * 256); v[i] = make_float4((float)u[0], (float)u[1], (float)u[2], (float)u[3]); }
+    else v[i] = *reinterpret_cast<const float4*>(p.a + base + i * 256);
     t[i] = *reinterpret_cast<const float4*>(p.b + base + i * 256);
     w3[i] = *reinterpret_cast<const float4*>(p.n3_w + lane * 4 + i * 256);
     wd[i] = *reinterpret_cast<const float4*>(p.dn_w + lane * 4 + i * 256);
@@ -45,7 +46,10 @@ __global__ __launch_bounds__(256) void dec_tail_fwd_kernel(MansyDecTailFwd p) {
     s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
   }
 #pragma unroll
-  for (int i = 0; i < NV; ++i) *reinterpret_cast<float4*>(p.z3 + base + i * 256) = v[i];
+  for (int i = 0; i < NV; ++i) {
+    if (!p.img_only) *reinterpret_cast<float4*>(p.z3 + base + i * 256) = v[i];
+    if (p.z3_16) mansy_st_bf16x4(p.z3_16 + base + i * 256, v[i].x, v[i].y, v[i].z, v[i].w);
+  }
   float mu = wave_sum(s) / (float)C;
   float q = 0.f;
 #pragma unroll
@@ -60,7 +64,7 @@ __global__ __launch_bounds__(256) void dec_tail_fwd_kernel(MansyDecTailFwd p) {
   for (int i = 0; i < NV; ++i) {
     y[i].x = (v[i].x - mu) * rs * w3[i].x + b3[i].x; y[i].y = (v[i].y - mu) * rs * w3[i].y + b3[i].y;
     y[i].z = (v[i].z - mu) * rs * w3[i].z + b3[i].z; y[i].w = (v[i].w - mu) * rs * w3[i].w + b3[i].w;
-    *reinterpret_cast<float4*>(p.y3 + base + i * 256) = y[i];
+    if (!p.img_only) *reinterpret_cast<float4*>(p.y3 + base + i * 256) = y[i];
     if (p.y3_16) mansy_st_bf16x4(p.y3_16 + base + i * 256, y[i].x, y[i].y, y[i].z, y[i].w);
   }
   // ---- dec_out = LN_dec(y3)
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(256) void dec_tail_fwd_kernel(MansyDecTailFwd p) {
         if (p.edrop.p > 0.f) a = mansy_keep(p.edrop.seed, p.edrop.site, p.edrop.base + (uint32_t)((long long)row * C + c + j), p.edrop.p) ? a * dsc : 0.f;
         e[j] = a;
       }
-      *reinterpret_cast<float4*>(p.emb_next + base + i * 256) = *reinterpret_cast<const float4*>(e);
+      if (!p.img_only) *reinterpret_cast<float4*>(p.emb_next + base + i * 256) = *reinterpret_cast<const float4*>(e);
       if (p.emb_next16) mansy_st_bf16x4(p.emb_next16 + base + i * 256, e[0], e[1], e[2], e[3]);
     }
   }
@@ -176,8 +180,13 @@ __global__ __launch_bounds__(64 * HEAD_WAVES) void dec_head_bwd_kernel(MansyDecH
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       gn[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      zy[i] = *reinterpret_cast<const float4*>(p.y3 + base + i * 256);
-      zz[i] = *reinterpret_cast<const float4*>(p.z3 + base + i * 256);
+      if (p.y3_16) {           // bf16 residual stream: the forward kept y3 / z3 as images only
+        const mansy_bf16x4 u = *reinterpret_cast<const mansy_bf16x4*>(p.y3_16 + base + i * 256), w = *reinterpret_cast<const mansy_bf16x4*>(p.z3_16 + base + i * 256);
+        zy[i] = make_float4((float)u[0], (float)u[1], (float)u[2], (float)u[3]); zz[i] = make_float4((float)w[0], (float)w[1], (float)w[2], (float)w[3]);
+      } else {
+        zy[i] = *reinterpret_cast<const float4*>(p.y3 + base + i * 256);
+        zz[i] = *reinterpret_cast<const float4*>(p.z3 + base + i * 256);
+      }
     }
     if (p.gx_next) {
 #pragma unroll

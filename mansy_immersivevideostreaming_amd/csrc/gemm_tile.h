@@ -65,11 +65,23 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, const fl
       off_r[u] = (long long)row * ep.resid_ld + col; off_m[u] = (long long)row * ep.mask_ld + col;
       rr[u] = make_float4(0.f, 0.f, 0.f, 0.f); mk[u] = make_float4(1.f, 1.f, 1.f, 1.f);
     }
-    if (ep.resid) {          // one uniform branch around the group's loads, not one per load
+    if (ep.resid16) {        // bf16 residual stream (bf16-storage mode): 8-byte loads of the image
+#pragma unroll
+      for (int u = 0; u < GRP; ++u) {
+        const mansy_bf16x4 t = *reinterpret_cast<const mansy_bf16x4*>(ep.resid16 + off_r[u]);
+        rr[u] = make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]);
+      }
+    } else if (ep.resid) {   // one uniform branch around the group's loads, not one per load
 #pragma unroll
       for (int u = 0; u < GRP; ++u) rr[u] = *reinterpret_cast<const float4*>(ep.resid + off_r[u]);
     }
-    if (ep.mask_src) {
+    if (ep.mask16) {
+#pragma unroll
+      for (int u = 0; u < GRP; ++u) {
+        const mansy_bf16x4 t = *reinterpret_cast<const mansy_bf16x4*>(ep.mask16 + off_m[u]);
+        mk[u] = make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]);
+      }
+    } else if (ep.mask_src) {
 #pragma unroll
       for (int u = 0; u < GRP; ++u) mk[u] = *reinterpret_cast<const float4*>(ep.mask_src + off_m[u]);
     }
@@ -91,7 +103,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, const fl
         v.x = v.x > 0.f ? v.x : v.x * ep.relu_slope; v.y = v.y > 0.f ? v.y : v.y * ep.relu_slope;
         v.z = v.z > 0.f ? v.z : v.z * ep.relu_slope; v.w = v.w > 0.f ? v.w : v.w * ep.relu_slope;
       }
-      if (ep.mask_src) {
+      if (ep.mask_src || ep.mask16) {
         v.x = mk[u].x > 0.f ? v.x * ep.mask_scale : v.x * ep.mask_neg; v.y = mk[u].y > 0.f ? v.y * ep.mask_scale : v.y * ep.mask_neg;
         v.z = mk[u].z > 0.f ? v.z * ep.mask_scale : v.z * ep.mask_neg; v.w = mk[u].w > 0.f ? v.w * ep.mask_scale : v.w * ep.mask_neg;
       }

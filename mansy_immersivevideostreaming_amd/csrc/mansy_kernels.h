@@ -66,6 +66,9 @@ struct GemmEpilogue {
   // optional bf16 image of the OUTPUT (after the whole epilogue), written next to -- or, with a null C, instead of -- the fp32 store
   // (row-major float4 epilogue only: c_vec_ok and no accumulation)
   unsigned short* c16 = nullptr; int c16_ld = 0;
+  // the residual / the mask source read from their bf16 IMAGES instead of floats (bf16-storage mode with bf16 residual streams; row-major epilogue only;
+  // same leading dimensions resid_ld / mask_ld).  The mask only needs the sign of its source.
+  const unsigned short* resid16 = nullptr; const unsigned short* mask16 = nullptr;
 };
 
 // ---- decoding of GemmEpilogue::variant (bit layout: include/mansy_hip.h, MANSY_VARIANT_*).  A release build has NO process-wide knob: a call
@@ -144,7 +147,8 @@ int mansy_launch_attn_bwd_selfpull(const float* Q_all, long long q_ts, const flo
 // z = a (+ b);  y = LN(z) * w (+ bias).  z_out may be null (not saved) or alias a when b == null.
 int mansy_launch_layernorm_fwd(const float* a, const float* b, const float* w, const float* bias, float* z_out,
                                float* y, float* mean, float* rstd, int rows, int C, float eps, hipStream_t st,
-                               unsigned short* y16 = nullptr);      // y16: also store y's bf16 image (same element index; bf16-storage mode)
+                               unsigned short* y16 = nullptr, const unsigned short* a16 = nullptr);      // y16: also (or, with y null, only) store y's bf16 image;
+                                                                                                      // a16: read the input rows from their bf16 image (bf16 residual stream)
 // dz = LN'(dy); dz_drop (optional) = dz * dropout-mask(drop) ; dw += sum dy*xhat ; dbias += sum dy.
 // add_to (optional): dz += add_to (an extra gradient flowing into z's consumers' sum), applied before outputs.
 int mansy_launch_layernorm_bwd(const float* dy, const float* z, const float* mean, const float* rstd, const float* w,
@@ -158,7 +162,7 @@ int mansy_ln_bwd_parts(int rows);
 bool mansy_ln_bwd_partial_ok(int C);
 int mansy_launch_layernorm_bwd_partial(const float* dy, const float* z, const float* mean, const float* rstd, const float* w,
                                        float* dz, float* dz_drop, MansyDrop drop, float* partials, int accumulate, int rows, int C,
-                                       hipStream_t st, unsigned short* dz_drop16 = nullptr);      // dz_drop16: bf16 image of dz_drop
+                                       hipStream_t st, unsigned short* dz_drop16 = nullptr, const unsigned short* z16 = nullptr);      // dz_drop16: bf16 image of dz_drop; z16: z read from its image
 int mansy_launch_ln_partials_reduce(const float* partials, int nparts, int C, float* dw, float* dbias, hipStream_t st);
 // several slot sets in one launch (the end of a VP backward: every LayerNorm's weight / bias gradient)
 constexpr int LN_MULTI_MAX = 64;      // >= 2 halves x (3 x 8 layers + 1)
@@ -200,6 +204,8 @@ struct MansyDecTailFwd {
   const float* ew; const float* eb; const float* pe_row; float* emb_next; MansyDrop edrop;
   int rows, C, C6; float eps;
   unsigned short* y3_16 = nullptr; unsigned short* emb_next16 = nullptr;      // bf16 images of y3 / emb_next (bf16-storage mode: operands of the next products)
+  // bf16 residual stream (round 6): a16 = the first addend read from its image; z3_16 = image of z3; img_only != 0: z3 / y3 / emb_next are kept as images ONLY
+  const unsigned short* a16 = nullptr; unsigned short* z3_16 = nullptr; int img_only = 0;
 };
 int mansy_dec_tail_ok(int C, int c6);
 int mansy_launch_dec_tail_fwd(const MansyDecTailFwd& p, hipStream_t st);
@@ -214,6 +220,7 @@ struct MansyDecHeadBwd {
   int rows, C, C6;
   unsigned short* dbr3_16 = nullptr;       // bf16 image of dbr3 (bf16-storage mode)
   int dbr3_img_only = 0;                   // != 0 (with dbr3_16): dbr3 is an operand of dense products only -- no float store
+  const unsigned short* y3_16 = nullptr; const unsigned short* z3_16 = nullptr;      // (both or neither) y3 / z3 read from their images (bf16 residual stream)
 };
 int mansy_launch_dec_head_bwd(const MansyDecHeadBwd& p, int n_slots, hipStream_t st);
 

@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                                                             const float* __restrict__ w, const float* __restrict__ bias,
                                                             float* __restrict__ z_out, float* __restrict__ y,
                                                             float* __restrict__ mean, float* __restrict__ rstd, int rows, int C,
-                                                            float eps, unsigned short* __restrict__ y16) {
+                                                            float eps, unsigned short* __restrict__ y16, const unsigned short* __restrict__ a16) {
   const int lane = threadIdx.x & 63;
   const int wave_global = (blockIdx.x * 256 + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * 256) >> 6;
@@ -35,7 +35,13 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     const long long base = (long long)row * C + lane * 4;
     float4 v[NV], rv[NV];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) { v[i] = *reinterpret_cast<const float4*>(a + base + i * 256); rv[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    for (int i = 0; i < NV; ++i) {
+      if (a16) {           // bf16 residual stream: the input row is read from its image
+        const mansy_bf16x4 t = *reinterpret_cast<const mansy_bf16x4*>(a16 + base + i * 256);
+        v[i] = make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]);
+      } else v[i] = *reinterpret_cast<const float4*>(a + base + i * 256);
+      rv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     if (b) {
 #pragma unroll
       for (int i = 0; i < NV; ++i) rv[i] = *reinterpret_cast<const float4*>(b + base + i * 256);
@@ -66,7 +72,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
       o.x = (v[i].x - mu) * rs * wv[i].x; o.y = (v[i].y - mu) * rs * wv[i].y;
       o.z = (v[i].z - mu) * rs * wv[i].z; o.w = (v[i].w - mu) * rs * wv[i].w;
       if (bias) { o.x += bv[i].x; o.y += bv[i].y; o.z += bv[i].z; o.w += bv[i].w; }
-      *reinterpret_cast<float4*>(y + base + i * 256) = o;
+      if (y) *reinterpret_cast<float4*>(y + base + i * 256) = o;
       if (y16) mansy_st_bf16x4(y16 + base + i * 256, o.x, o.y, o.z, o.w);
     }
   }
@@ -159,7 +165,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 const float* __restrict__ w, float* __restrict__ dz,
                                                                 float* __restrict__ dz_drop, MansyDrop drop, float* __restrict__ dw,
-                                                                float* __restrict__ dbias, int rows, int C, unsigned short* __restrict__ dz_drop16) {
+                                                                float* __restrict__ dbias, int rows, int C, unsigned short* __restrict__ dz_drop16,
+                                                                const unsigned short* __restrict__ z16) {
   extern __shared__ float red[];      // [4 waves][2][C]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wave_global = (blockIdx.x * 256 + threadIdx.x) >> 6;
@@ -175,15 +182,31 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
   for (int row0 = wave_global * RB; row0 < rows; row0 += nwaves * RB) {
     float4 d[RB][NV], zz[RB][NV];
     float mu[RB], rs[RB];
+    // (ONE uniform branch around all loads of the iteration, not one per load: every dy / z load of the RB rows is issued before any is used)
+    if (z16) {           // bf16 residual stream: the LayerNorm's input was kept as its image only
 #pragma unroll
-    for (int u = 0; u < RB; ++u) {
-      const int row = min(row0 + u, rows - 1);          // rows past the end re-read the last row; they are not written / summed
-      mu[u] = mean[row]; rs[u] = rstd[row];
+      for (int u = 0; u < RB; ++u) {
+        const int row = min(row0 + u, rows - 1);          // rows past the end re-read the last row; they are not written / summed
+        mu[u] = mean[row]; rs[u] = rstd[row];
 #pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        const long long off = (long long)row * C + (i * 64 + lane) * 4;
-        d[u][i] = *reinterpret_cast<const float4*>(dy + off);
-        zz[u][i] = *reinterpret_cast<const float4*>(z + off);
+        for (int i = 0; i < NV; ++i) {
+          const long long off = (long long)row * C + (i * 64 + lane) * 4;
+          d[u][i] = *reinterpret_cast<const float4*>(dy + off);
+          const mansy_bf16x4 t = *reinterpret_cast<const mansy_bf16x4*>(z16 + off);
+          zz[u][i] = make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < RB; ++u) {
+        const int row = min(row0 + u, rows - 1);
+        mu[u] = mean[row]; rs[u] = rstd[row];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          const long long off = (long long)row * C + (i * 64 + lane) * 4;
+          d[u][i] = *reinterpret_cast<const float4*>(dy + off);
+          zz[u][i] = *reinterpret_cast<const float4*>(z + off);
+        }
       }
     }
 #pragma unroll
@@ -494,17 +517,18 @@ __global__ __launch_bounds__(256) void distill_bwd_stage2(const float* __restric
 }  // namespace
 
 int mansy_launch_layernorm_fwd(const float* a, const float* b, const float* w, const float* bias, float* z_out, float* y,
-                               float* mean, float* rstd, int rows, int C, float eps, hipStream_t st, unsigned short* y16) {
-  MANSY_REQUIRE(a && w && y, "layernorm_fwd: null pointer");
+                               float* mean, float* rstd, int rows, int C, float eps, hipStream_t st, unsigned short* y16, const unsigned short* a16) {
+  MANSY_REQUIRE((a || a16) && w && (y || y16), "layernorm_fwd: null pointer");
+  MANSY_REQUIRE(!a16 || (!b && !z_out && (C % 256) == 0 && C <= 256 * LN_MAXV), "layernorm_fwd: a bf16 input needs the vectorised kernel and no second addend");
   MANSY_REQUIRE(!y16 || ((C % 256) == 0 && C <= 256 * LN_MAXV), "layernorm_fwd: the bf16 image needs the vectorised kernel (C %% 256 == 0)");
   if (rows <= 0) return MANSY_OK;
   const int grid = min(mansy_ceil_div(rows, 4), 2048);
   if ((C % 256) == 0 && C <= 256 * LN_MAXV) {
     switch (C / 256) {
-      case 1: MANSY_LAUNCH(layernorm_fwd_kernel<1>, dim3(grid), dim3(256), 0, st, a, b, w, bias, z_out, y, mean, rstd, rows, C, eps, y16); break;
-      case 2: MANSY_LAUNCH(layernorm_fwd_kernel<2>, dim3(grid), dim3(256), 0, st, a, b, w, bias, z_out, y, mean, rstd, rows, C, eps, y16); break;
-      case 3: MANSY_LAUNCH(layernorm_fwd_kernel<3>, dim3(grid), dim3(256), 0, st, a, b, w, bias, z_out, y, mean, rstd, rows, C, eps, y16); break;
-      default: MANSY_LAUNCH(layernorm_fwd_kernel<4>, dim3(grid), dim3(256), 0, st, a, b, w, bias, z_out, y, mean, rstd, rows, C, eps, y16); break;
+      case 1: MANSY_LAUNCH(layernorm_fwd_kernel<1>, dim3(grid), dim3(256), 0, st, a, b, w, bias, z_out, y, mean, rstd, rows, C, eps, y16, a16); break;
+      case 2: MANSY_LAUNCH(layernorm_fwd_kernel<2>, dim3(grid), dim3(256), 0, st, a, b, w, bias, z_out, y, mean, rstd, rows, C, eps, y16, a16); break;
+      case 3: MANSY_LAUNCH(layernorm_fwd_kernel<3>, dim3(grid), dim3(256), 0, st, a, b, w, bias, z_out, y, mean, rstd, rows, C, eps, y16, a16); break;
+      default: MANSY_LAUNCH(layernorm_fwd_kernel<4>, dim3(grid), dim3(256), 0, st, a, b, w, bias, z_out, y, mean, rstd, rows, C, eps, y16, a16); break;
     }
   } else
     MANSY_LAUNCH(layernorm_fwd_generic, dim3(grid), dim3(256), 0, st, a, b, w, bias, z_out, y, mean, rstd, rows, C, eps);
@@ -525,13 +549,13 @@ int mansy_launch_layernorm_bwd(const float* dy, const float* z, const float* mea
   MANSY_REQUIRE(lds <= 64 * 1024, "layernorm_bwd: C=%d too large", C);
   if ((C % 256) == 0 && C <= 256 * LN_MAXV) {
     switch (C / 256) {
-      case 1: MANSY_LAUNCH((layernorm_bwd_vec_kernel<1, false, 4>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C, (unsigned short*)nullptr); break;
+      case 1: MANSY_LAUNCH((layernorm_bwd_vec_kernel<1, false, 4>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C, (unsigned short*)nullptr, (const unsigned short*)nullptr); break;
       case 2:      // (the same rows-per-wave rule as the partial-sum form: the two forms stay bit-identical per row)
-        if (ln_rows_per_wave(rows) == 2) MANSY_LAUNCH((layernorm_bwd_vec_kernel<2, false, 2>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C, (unsigned short*)nullptr);
-        else MANSY_LAUNCH((layernorm_bwd_vec_kernel<2, false, 4>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C, (unsigned short*)nullptr);
+        if (ln_rows_per_wave(rows) == 2) MANSY_LAUNCH((layernorm_bwd_vec_kernel<2, false, 2>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C, (unsigned short*)nullptr, (const unsigned short*)nullptr);
+        else MANSY_LAUNCH((layernorm_bwd_vec_kernel<2, false, 4>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C, (unsigned short*)nullptr, (const unsigned short*)nullptr);
         break;
-      case 3: MANSY_LAUNCH((layernorm_bwd_vec_kernel<3, false, 4>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C, (unsigned short*)nullptr); break;
-      default: MANSY_LAUNCH((layernorm_bwd_vec_kernel<4, false, 4>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C, (unsigned short*)nullptr); break;
+      case 3: MANSY_LAUNCH((layernorm_bwd_vec_kernel<3, false, 4>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C, (unsigned short*)nullptr, (const unsigned short*)nullptr); break;
+      default: MANSY_LAUNCH((layernorm_bwd_vec_kernel<4, false, 4>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias, rows, C, (unsigned short*)nullptr, (const unsigned short*)nullptr); break;
     }
   } else
     MANSY_LAUNCH(layernorm_bwd_kernel, dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, dw, dbias,
@@ -599,14 +623,14 @@ bool mansy_ln_bwd_partial_ok(int C) { return (C % 256) == 0 && C <= 256 * LN_MAX
 // applied at T steps), else the slots are overwritten.
 int mansy_launch_layernorm_bwd_partial(const float* dy, const float* z, const float* mean, const float* rstd, const float* w,
                                        float* dz, float* dz_drop, MansyDrop drop, float* partials, int accumulate, int rows, int C,
-                                       hipStream_t st, unsigned short* dz_drop16) {
-  MANSY_REQUIRE(dy && z && mean && rstd && w && dz && partials, "layernorm_bwd_partial: null pointer");
+                                       hipStream_t st, unsigned short* dz_drop16, const unsigned short* z16) {
+  MANSY_REQUIRE(dy && (z || z16) && mean && rstd && w && dz && partials, "layernorm_bwd_partial: null pointer");
   MANSY_REQUIRE(mansy_ln_bwd_partial_ok(C), "layernorm_bwd_partial: C=%d unsupported", C);
   if (rows <= 0) return MANSY_OK;
   const int grid = mansy_ln_bwd_parts(rows);
   const size_t lds = (size_t)4 * 2 * C * sizeof(float);
   float* flag = accumulate ? partials : nullptr;      // the kernel only tests it for null
-#define LNB(NV, RBV) MANSY_LAUNCH((layernorm_bwd_vec_kernel<NV, true, RBV>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, partials, flag, rows, C, dz_drop16)
+#define LNB(NV, RBV) MANSY_LAUNCH((layernorm_bwd_vec_kernel<NV, true, RBV>), dim3(grid), dim3(256), lds, st, dy, z, mean, rstd, w, dz, dz_drop, drop, partials, flag, rows, C, dz_drop16, z16)
   if (C / 256 == 2) { if (ln_rows_per_wave(rows) == 2) LNB(2, 2); else LNB(2, 4); }
   else if (C / 256 == 1) LNB(1, 4);
   else if (C / 256 == 3) LNB(3, 4);

@@ -319,20 +319,24 @@ struct Eng {
   // resid != nullptr: Y = resid + drop(X W^T + b) -- the sub-layer's residual sum z, written by the product's epilogue, so that
   // the LayerNorm that follows reads ONE tensor and writes one (it used to read x and the product, and write z and y).
   // Same fp32 operations in the same order as drop(product) stored and then added by the LayerNorm kernel: bit-identical.
-  // y_img: the product's output is itself an operand of a later product: its epilogue also stores the bf16 image (bf16-storage mode)
+  // y_img (bf16-storage mode): 0 = the output as floats, 1 = floats + bf16 image (it is also an operand of a later product / the K/V cache), 2 = the image
+  // ONLY.  A product with a residual forms a sub-layer's z = resid + drop(product): in the bf16-storage mode the residual stream is bf16 -- the residual
+  // is read from its image and z is kept as an image only (the LayerNorm that follows reads it there)
   int lin_fwd(const float* X, int rows, int K, const float* w, const float* b, int Nout, float* Y, int relu, MansyDrop drop,
-              const float* resid = nullptr, bool y_img = false, bool x_img = true) {
+              const float* resid = nullptr, int y_img = 0, bool x_img = true) {
     GemmEpilogue ep; ep.prec = prec; ep.bias = b; ep.relu = relu; ep.drop = drop; ep.resid = resid; ep.resid_ld = Nout;
     if (prec) attach_planes(ep, w, false);
+    if (s16 && resid) { ep.resid16 = im(resid); ep.resid = nullptr; y_img = 2; }
     if (s16 && y_img) { ep.c16 = im(Y); ep.c16_ld = Nout; }          // (the shared epilogue stores it on either loop)
     if (s16 && x_img && ep.b_planes && K % 64 == 0) {
       ep.a16 = im(X); ep.a16_ld = K;
-      return mansy_launch_gemm_bf16a(0, 0, Y, Nout, rows, Nout, K, ep, 0, 0, st);
+      return mansy_launch_gemm_bf16a(0, 0, y_img == 2 ? nullptr : Y, Nout, rows, Nout, K, ep, 0, 0, st);
     }
     return mansy_launch_gemm_f32(X, K, 0, w, K, 0, Y, Nout, rows, Nout, K, ep, 0, 0, st);
   }
   // y = LN(z) for a z already formed by lin_fwd(..., resid)
   int ln_of(const float* z, const NormP& n, float* y, float* m, float* r, int rows) {
+    if (s16) return mansy_launch_layernorm_fwd(nullptr, nullptr, n.w, n.b, nullptr, nullptr, m, r, rows, d, c.ln_eps, st, im(y), im(z));      // bf16 residual stream: image in, image out
     return mansy_launch_layernorm_fwd(z, nullptr, n.w, n.b, nullptr, y, m, r, rows, d, c.ln_eps, st, im(y));
   }
   // dX[rows,K] = dY[rows,N] W[N,K] (+resid) (mask)
@@ -344,6 +348,7 @@ struct Eng {
     if (prec) attach_planes(ep, w, true);
     if (s16 && img_in && ep.b_planes && Nout % 64 == 0) {
       ep.a16 = im(dY); ep.a16_ld = Nout;
+      if (mask_src) { ep.mask16 = im(mask_src); ep.mask_src = nullptr; }      // (the FFN hidden is kept as an image only: the ReLU mask needs its sign)
       if (dx_img) { ep.c16 = im(dX); ep.c16_ld = K; }
       return mansy_launch_gemm_bf16a(0, 0, dx_img == 2 ? nullptr : dX, K, rows, K, Nout, ep, 0, 0, st);
     }
@@ -360,6 +365,7 @@ struct Eng {
     return mansy_launch_gemm_f32(dY, Nout, 1, X, K, 1, gw, K, Nout, K, rows, ep, 0, 0, st);
   }
   int ln_fwd(const float* a, const float* b, const NormP& n, float* z, float* y, float* m, float* r, int rows) {
+    if (s16 && !b && !z) return mansy_launch_layernorm_fwd(nullptr, nullptr, n.w, n.b, nullptr, y, m, r, rows, d, c.ln_eps, st, im(y), im(a));   // (the input is a LayerNorm output: image only)
     return mansy_launch_layernorm_fwd(a, b, n.w, n.b, z, y, m, r, rows, d, c.ln_eps, st, im(y));
   }
   // part_slot < 0: encoder LayerNorm (applied once): partial sums into the scratch set, reduced into the gradient right away.
@@ -370,12 +376,13 @@ struct Eng {
     if (part_slot < 0) {          // encoder LayerNorm -(part_slot + 1): its own scratch set, overwritten; added into the gradient by the one reduce launch at the end
       const int e = -(part_slot + 1);
       float* set = W.lnp_enc + (size_t)e * mansy_ln_bwd_parts(rows) * 2 * d;
-      RC(mansy_launch_layernorm_bwd_partial(dy, z, m, r, n.w, dz, s16 ? nullptr : dz_drop, drop, set, 0, rows, d, st, dz_drop ? im(dz_drop) : nullptr));      // (bf16 storage: dz_drop feeds products only -- image only)
+      RC(mansy_launch_layernorm_bwd_partial(dy, s16 ? nullptr : z, m, r, n.w, dz, s16 ? nullptr : dz_drop, drop, set, 0, rows, d, st, dz_drop ? im(dz_drop) : nullptr,
+                                            im(z)));      // (bf16 storage: z is read from its image, dz_drop feeds products only -- image only)
       ln_pending[ln_n_pending++] = MansyLnReduce{set, mansy_ln_bwd_parts(rows), n.gw, n.gb};
       return MANSY_OK;
     }
     float* slots = W.lnp_dec + (size_t)part_slot * mansy_ln_bwd_parts(B) * 2 * d;
-    return mansy_launch_layernorm_bwd_partial(dy, z, m, r, n.w, dz, s16 ? nullptr : dz_drop, drop, slots, 1, rows, d, st, dz_drop ? im(dz_drop) : nullptr);
+    return mansy_launch_layernorm_bwd_partial(dy, s16 ? nullptr : z, m, r, n.w, dz, s16 ? nullptr : dz_drop, drop, slots, 1, rows, d, st, dz_drop ? im(dz_drop) : nullptr, im(z));
   }
 
   AttnShape enc_shape() const {
@@ -408,7 +415,7 @@ struct Eng {
       RC(mansy_launch_attn_fwd(e.qkv, e.qkv + d, e.qkv + 2 * d, e.ao, e.P, enc_shape(), dr(site_enc(l, 0), c.p_drop), st, W.fbase, im(W.fbase), 1));
       RC(lin_fwd(e.ao, N, d, p.out_proj.w, p.out_proj.b, d, e.z1, 0, dr(site_enc(l, 1), c.p_drop), x));          // z1 = x + drop(out_proj(ao))
       RC(ln_of(e.z1, p.n1, e.y1, e.m1, e.r1, N));
-      RC(lin_fwd(e.y1, N, d, p.lin1.w, p.lin1.b, f, e.h, 1, dr(site_enc(l, 2), c.p_drop), nullptr, true));
+      RC(lin_fwd(e.y1, N, d, p.lin1.w, p.lin1.b, f, e.h, 1, dr(site_enc(l, 2), c.p_drop), nullptr, 2));
       RC(lin_fwd(e.h, N, f, p.lin2.w, p.lin2.b, d, e.z2, 0, dr(site_enc(l, 3), c.p_drop), e.y1));                // z2 = y1 + drop(lin2(h))
       RC(ln_of(e.z2, p.n2, e.y2, e.m2, e.r2, N));
       x = e.y2;
@@ -422,7 +429,7 @@ struct Eng {
                                 train ? 1 : 0, c.bn_eps, c.bn_momentum, st, W.dis_part));
     for (int l = 0; l < c.n_dec; ++l) {
       const DecLayerP& p = P.dec[l];
-      RC(lin_fwd(W.mem, B * M, d, p.ca_in.w + (size_t)d * d, p.ca_in.b ? p.ca_in.b + d : nullptr, 2 * d, W.dec[l].memkv, 0, mansy_no_drop(), nullptr, true,
+      RC(lin_fwd(W.mem, B * M, d, p.ca_in.w + (size_t)d * d, p.ca_in.b ? p.ca_in.b + d : nullptr, 2 * d, W.dec[l].memkv, 0, mansy_no_drop(), nullptr, 1,
                  false));      // (the distilled memory has no bf16 image: the DistillLayer keeps floats; the projected K/V rows get one: the cross-attention cache)
     }
     MANSY_HIP_CHECK(hipMemcpyAsync(W.tok_all, cur, sizeof(float) * B * C6, hipMemcpyDeviceToDevice, st));
@@ -480,7 +487,7 @@ struct Eng {
       float* qkv_i = e.qkv + o * 3 * d;
       const float* kv0 = e.qkv + (size_t)b0 * 3 * d;           // keys / values of step 0 for these rows (step stride B * 3d)
       const float* mkv = e.memkv + (size_t)b0 * M * 2 * d;
-      RC(lin_fwd(xi, nb, d, p.sa_in.w, p.sa_in.b, 3 * d, qkv_i, 0, mansy_no_drop(), nullptr, true));      // + bf16 image: the K/V cache of the bf16-storage mode
+      RC(lin_fwd(xi, nb, d, p.sa_in.w, p.sa_in.b, 3 * d, qkv_i, 0, mansy_no_drop(), nullptr, 1));      // + bf16 image: the K/V cache of the bf16-storage mode
       RC(mansy_launch_attn_fwd(qkv_i, kv0 + d, kv0 + 2 * d, e.ao1 + o * d, e.P1 + o * H * T, self_shape(i, nb),
                                dr(site_dec(l, i, 0), c.p_drop, (size_t)b0 * H * (i + 1)), st, W.fbase, im(W.fbase), 1, s16 ? 1 : 0));
       RC(lin_fwd(e.ao1 + o * d, nb, d, p.sa_out.w, p.sa_out.b, d, e.z1 + o * d, 0, dr(site_dec(l, i, 1), c.p_drop, (size_t)b0 * d), xi));
@@ -490,7 +497,7 @@ struct Eng {
                                dr(site_dec(l, i, 2), c.p_drop, (size_t)b0 * H * M), st, W.fbase, im(W.fbase), 1, s16 ? 1 : 0));
       RC(lin_fwd(e.ao2 + o * d, nb, d, p.ca_out.w, p.ca_out.b, d, e.z2 + o * d, 0, dr(site_dec(l, i, 3), c.p_drop, (size_t)b0 * d), e.y1 + o * d));
       RC(ln_of(e.z2 + o * d, p.n2, e.y2 + o * d, e.m2 + o, e.r2 + o, nb));
-      RC(lin_fwd(e.y2 + o * d, nb, d, p.lin1.w, p.lin1.b, f, e.h + o * f, 1, dr(site_dec(l, i, 4), c.p_drop, (size_t)b0 * f), nullptr, true));
+      RC(lin_fwd(e.y2 + o * d, nb, d, p.lin1.w, p.lin1.b, f, e.h + o * f, 1, dr(site_dec(l, i, 4), c.p_drop, (size_t)b0 * f), nullptr, 2));
       if (fuse_tail && l == c.n_dec - 1) {                  // LayerNorm3 of the last layer is the head of the fused tail (a + b form)
         RC(lin_fwd(e.h + o * f, nb, f, p.lin2.w, p.lin2.b, d, t_dec, 0, dr(site_dec(l, i, 5), c.p_drop, (size_t)b0 * d)));
         break;
@@ -512,6 +519,7 @@ struct Eng {
       tp.edrop = dr(site_pe_tgt(i + 1), c.p_pe, (size_t)b0 * d);
       tp.rows = nb; tp.C = d; tp.C6 = C6; tp.eps = c.ln_eps;
       tp.y3_16 = im(tp.y3); tp.emb_next16 = tp.emb_next ? im(tp.emb_next) : nullptr;
+      tp.a16 = im(tp.a); tp.z3_16 = im(tp.z3); tp.img_only = s16 ? 1 : 0;          // bf16 residual stream: y2 read from its image, z3 / y3 / emb_next kept as images only
       return mansy_launch_dec_tail_fwd(tp, st);
     }
     RC(ln_fwd(xi, nullptr, P.dec_norm, nullptr, W.dec_out + o * d, W.md + o, W.rd + o, nb));
@@ -535,7 +543,8 @@ struct Eng {
     auto ln_bwd_dec = [&](const float* dy, const float* z, const float* m, const float* r, const NormP& n, float* dz, float* dz_drop, MansyDrop drop,
                           int slot) {
       if (!ln_parts) return mansy_launch_layernorm_bwd(dy, z, m, r, n.w, dz, dz_drop, drop, n.gw, n.gb, nb, d, st);
-      return mansy_launch_layernorm_bwd_partial(dy, z, m, r, n.w, dz, s16 ? nullptr : dz_drop, drop, lnp + (size_t)slot * lnp_set, 1, nb, d, st, dz_drop ? im(dz_drop) : nullptr);
+      return mansy_launch_layernorm_bwd_partial(dy, s16 ? nullptr : z, m, r, n.w, dz, s16 ? nullptr : dz_drop, drop, lnp + (size_t)slot * lnp_set, 1, nb, d, st,
+                                                dz_drop ? im(dz_drop) : nullptr, im(z));
     };
     if (fuse_head) {
       const int L = c.n_dec - 1;
@@ -550,6 +559,7 @@ struct Eng {
       hp.z3 = e.z3 + o * d; hp.m3 = e.m3 + o; hp.r3 = e.r3 + o; hp.n3_w = P.dec[L].n3.w; hp.part_n3 = lnp + (size_t)(3 * L + 2) * lnp_set;
       hp.gz = gz; hp.dbr3 = e.dbr3 + o * d; hp.drop3 = dr(site_dec(L, i, 5), c.p_drop, bd);
       hp.rows = nb; hp.C = d; hp.C6 = C6; hp.dbr3_16 = im(hp.dbr3); hp.dbr3_img_only = s16 ? 1 : 0;
+      hp.y3_16 = im(hp.y3); hp.z3_16 = im(hp.z3);
       // (its own grid rule: 16 rows per workgroup as before -- 8 made this fused kernel 17.9 -> 22 us; it fills the first slots of its sets, the rest stay
       // zero from the memset and the reduce launches add them as such)
       RC(mansy_launch_dec_head_bwd(hp, std::min(mansy_ln_bwd_parts(nb), (nb + 15) / 16), st));
