@@ -159,7 +159,7 @@ __device__ __forceinline__ void lds_tr4x8(bf16x4& r0, bf16x4& r1, bf16x4& r2, bf
 __device__ __forceinline__ unsigned tn_off(int k, int ch) { return (unsigned)(256 * k + 16 * (ch ^ (((k & 3) << 2) | ((k >> 2) & 3)))); }
 
 template <int NS>
-__global__ __launch_bounds__(NT, 2) void gemm_bf16a_tn_kernel(GemmParams p) {
+__global__ __launch_bounds__(NT, NS <= 2 ? 2 : 1) void gemm_bf16a_tn_kernel(GemmParams p) {
   constexpr int BM = 128, BN = 128, D = NS - 1;
   constexpr int A_BYTES = BK16 * 256, B_BYTES = BK16 * 256, STAGE_BYTES = A_BYTES + B_BYTES;      // 32 KB per stage
   constexpr int PA = 4, PB = 4, PPT = PA + PB;                                                     // 16 pieces of 1 KB per operand tile, 4 per wave
@@ -168,8 +168,18 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16a_tn_kernel(GemmParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int split = blockIdx.z;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  int split, tile_x, tile_y;
+  {   // XCD-aware bijective remap (workgroup ids go round-robin over the 8 XCDs): ALL output tiles of one K split run on ONE XCD, so a split's rows of dY and X
+      // are fetched from HBM / the Infinity Cache into ONE L2 and every other tile of the split hits there (as dispatched, the tiles sharing a panel sat on 4
+      // (dY) and 2 (X) different XCDs and every panel crossed the fabric that many times)
+    const int per = gridDim.x * gridDim.y, nwg = per * gridDim.z, orig = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const int q = nwg >> 3, rem = nwg & 7, xcd = orig & 7, local = orig >> 3;
+    const int t = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + local;
+    split = t / per;
+    const int tt = t - split * per;
+    tile_y = tt / gridDim.x; tile_x = tt - tile_y * gridDim.x;
+  }
+  const int m0 = tile_y * BM, n0 = tile_x * BN;
   const int k_begin = split * p.k_per_split, k_end = min(p.K, k_begin + p.k_per_split);
   const int nk = (k_end - k_begin) / BK16;
   const unsigned short* const A16 = p.ep.a16;           // [K][M] (dY rows), lda
@@ -224,7 +234,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16a_tn_kernel(GemmParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   }
-  const bool want_rs = p.ep.a_rowsum != nullptr && blockIdx.x == 0 && wn == 0;       // bias gradient: row sums of dY^T, taken once per row panel
+  const bool want_rs = p.ep.a_rowsum != nullptr && tile_x == 0 && wn == 0;       // bias gradient: row sums of dY^T, taken once per row panel
   bf16x8 ones;
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
@@ -297,6 +307,8 @@ int mansy_gemm_bf16a_nn(const GemmParams& p, int tile, hipStream_t st) {
                     p.K >= BK16, "bf16-storage product: operands must be 16-byte aligned with leading dimensions %% 8 == 0 and K %% 64 == 0");
   dim3 block(NT);
   if (tile == 128) { dim3 grid(mansy_ceil_div(p.N, 128), mansy_ceil_div(p.M, 128), 1); MANSY_GEMM_LAUNCH((gemm_bf16a_nn_kernel<128, 128, 3>), grid, block, st, p); }
+  else if (tile == 129) { dim3 grid(mansy_ceil_div(p.N, 128), mansy_ceil_div(p.M, 128), 1); MANSY_GEMM_LAUNCH((gemm_bf16a_nn_kernel<128, 128, 4>), grid, block, st, p); }
+  else if (tile == 97) { dim3 grid(mansy_ceil_div(p.N, 64), mansy_ceil_div(p.M, 128), 1); MANSY_GEMM_LAUNCH((gemm_bf16a_nn_kernel<128, 64, 4>), grid, block, st, p); }
   else if (tile == 96) {
     dim3 grid(mansy_ceil_div(p.N, 64), mansy_ceil_div(p.M, 128), 1);
     // a launch of at most one workgroup per CU (the [4 096, 512, K] decoder-step products: 256 tiles) is a latency chain of its own: SIX stages (144 KB, five
@@ -310,13 +322,14 @@ int mansy_gemm_bf16a_nn(const GemmParams& p, int tile, hipStream_t st) {
 }
 
 // TN: C[M, N] += A16^T B16 over K rows; A16 [K, M], B16 [K, N] bf16; k_per_split % 64 == 0; M, N >= 8 and multiples of 8.
-int mansy_gemm_bf16a_tn(const GemmParams& p, int splits, hipStream_t st) {
+int mansy_gemm_bf16a_tn(const GemmParams& p, int splits, int ns, hipStream_t st) {
   auto al16 = [](const void* x) { return (reinterpret_cast<uintptr_t>(x) & 15) == 0; };
   MANSY_REQUIRE(p.ep.a16 && p.ep.b16 && al16(p.ep.a16) && al16(p.ep.b16) && p.ep.a16_ld % 8 == 0 && p.ep.b16_ld % 8 == 0 && p.M % 8 == 0 && p.N % 8 == 0 &&
                     p.M >= 8 && p.N >= 8 && p.K % BK16 == 0 && p.k_per_split % BK16 == 0,
                 "bf16-storage weight-gradient product: 16-byte aligned operands, M, N multiples of 8, K and the split length multiples of 64");
   dim3 grid(mansy_ceil_div(p.N, 128), mansy_ceil_div(p.M, 128), splits), block(NT);
-  MANSY_GEMM_LAUNCH((gemm_bf16a_tn_kernel<2>), grid, block, st, p);
+  if (ns == 3) MANSY_GEMM_LAUNCH((gemm_bf16a_tn_kernel<3>), grid, block, st, p);
+  else MANSY_GEMM_LAUNCH((gemm_bf16a_tn_kernel<2>), grid, block, st, p);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }

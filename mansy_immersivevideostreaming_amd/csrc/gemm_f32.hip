@@ -734,7 +734,7 @@ int mansy_launch_gemm_bf16a(int a_kmajor, int b_kmajor, float* C, int ldc, int M
     if (kps <= 0) kps = 64;
     splits = mansy_ceil_div(K, kps);
     p.k_per_split = kps; p.splits_pp = splits;
-    rc = mansy_gemm_bf16a_tn(p, splits, st);
+    rc = mansy_gemm_bf16a_tn(p, splits, force_tile == 3 ? 3 : 2, st);
   } else {
     MANSY_REQUIRE(!a_kmajor && ep.b_planes && !ep.accumulate && ep.split_slab == 0 && p.c_vec_ok,
                   "bf16-storage forward / dX product: K-contiguous a16, a weight plane, a storing row-major epilogue");

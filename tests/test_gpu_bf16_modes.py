@@ -690,5 +690,7 @@ def test_bf16_storage_step_reads_no_image_it_has_not_written(K):
     assert outs[0][0][0] == outs[1][0][0]
     np.testing.assert_allclose(outs[1][0], outs[0][0], rtol=5e-3)         # (Adam turns rounding noise of a near-zero gradient into a +-lr step: the runs drift apart by ~1e-3 over four steps)
     d = (outs[0][1] - outs[1][1]).abs()
-    assert torch.minimum(d, 1 - d).max().item() <= 5e-3          # (sample() of two models whose weights differ by rounding after four bf16 steps)
+    # sample() of two models whose weights differ by +-lr steps after four bf16 steps, through bf16 residual streams (one bf16 ulp at |x| ~ 1 is 8e-3 and the
+    # decoder feeds its own output back 10 times).  A leaked poison value is a NaN, not a drift: the finiteness line above is the detector
+    assert torch.minimum(d, 1 - d).max().item() <= 2e-2
     assert (outs[0][2] - outs[1][2]).abs().max().item() <= 4e-4
