@@ -74,7 +74,7 @@ int mansy_gemm_bf16(const uint16_t* A16, int lda, int a_kmajor, const uint16_t* 
     e.resid = ep->resid; e.resid_ld = ep->resid_ld; e.accumulate = ep->accumulate; e.a_rowsum = ep->a_rowsum;
   }
   MANSY_REQUIRE(A16 && B16, "gemm_bf16: null operand");
-  MANSY_REQUIRE(force_tile == 0 || force_tile == 64 || force_tile == 96 || force_tile == 128 || force_tile == 97 || force_tile == 129 || force_tile == 3, "gemm_bf16: force_tile must be 0, 64, 96 (128x64) or 128");
+  MANSY_REQUIRE(force_tile == 0 || force_tile == 64 || force_tile == 96 || force_tile == 128, "gemm_bf16: force_tile must be 0, 64, 96 (128x64) or 128");
   e.prec = 1; e.a16 = A16; e.a16_ld = lda; e.c16 = C16; e.c16_ld = ldc16;
   if (a_kmajor && b_kmajor) { e.b16 = B16; e.b16_ld = ldb; }
   else { MANSY_REQUIRE(!a_kmajor && !b_kmajor, "gemm_bf16: forms are (K-contiguous A, B [N, K] K-contiguous) and (K-major A, K-major B)"); e.b_planes = B16; e.b_planes_ld = ldb; e.b_plane_stride = 0; }

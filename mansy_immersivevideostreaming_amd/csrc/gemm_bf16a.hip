@@ -14,6 +14,7 @@
 //       delivered column-major) -- two per operand block and k-step, on the guide's conflict-free image (b): 16-byte chunk ch of row k at
 //       256 k + 16 (ch ^ (((k & 3) << 2) | ((k >> 2) & 3))).  Split-K over the rows with atomic accumulation (as the fp32 dW products);
 //       the bias-gradient rider (row sums of dY^T) is one more MFMA per A block against a fragment of ones, in the first column tile only.
+#include <type_traits>
 #include "gemm_tile.h"
 
 using namespace mansy_gemm;
@@ -26,8 +27,14 @@ namespace {
 constexpr int BK16 = 64;          // bf16 elements per K-tile (128 bytes per K-contiguous row)
 
 // ------------------------------------------------------------------------------------------------------------------------------ NN
+// workgroups of one CU's 160 KB of LDS (ring or the epilogue's C staging, whichever is larger), at most 4
+constexpr int nn_wgs_per_cu(int BM, int BN, int NS) {
+  const int ring = NS * (BM + BN) * 128, c = BM * (BN + 4) * 4, lds = ring > c ? ring : c;
+  return 160 * 1024 / lds > 4 ? 4 : 160 * 1024 / lds;
+}
+
 template <int BM, int BN, int NS>
-__global__ __launch_bounds__(NT, (BM * BN <= 128 * 64 && NS <= 4) ? 2 : 1) void gemm_bf16a_nn_kernel(GemmParams p) {
+__global__ __launch_bounds__(NT, nn_wgs_per_cu(BM, BN, NS)) void gemm_bf16a_nn_kernel(GemmParams p) {
   constexpr int TM = BM / 64, TN = BN / 64 > 0 ? BN / 64 : 1, PA = BM / 32, PB = BN / 32, D = NS - 1;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
   constexpr int C_FLOATS = BM * (BN + 4);
@@ -133,26 +140,13 @@ __global__ __launch_bounds__(NT, (BM * BN <= 128 * 64 && NS <= 4) ? 2 : 1) void 
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------ TN
-// ds_read_b64_tr_b16: lane 4 q + p of a 16-lane group supplies the address of row q, columns 4 p .. 4 p + 3 of the group's 4 x 16 block; lane i
-// of the group receives column i, row q in element q.  EXEC must be all ones (no divergence around it).
-// The eight transposed reads of one k-step and the wait for them as ONE asm statement: the consumers of the results then depend on a statement that
-// contains the s_waitcnt.  (As separate statements -- reads, then `s_waitcnt lgkmcnt(0)` -- nothing ties the results to the wait: the compiler may schedule
-// the register moves / MFMAs that consume them ABOVE it, and they then read VGPRs the LDS has not written yet.  That passed every single-process test and
-// produced NaN weight gradients once two processes shared the device and LDS latencies grew: round 6, tools/vp_dp2_probe.py.)
-__device__ __forceinline__ void lds_tr4x8(bf16x4& r0, bf16x4& r1, bf16x4& r2, bf16x4& r3, bf16x4& r4, bf16x4& r5, bf16x4& r6, bf16x4& r7,
-                                          unsigned a0, unsigned a1, unsigned a2, unsigned a3, unsigned a4, unsigned a5, unsigned a6, unsigned a7) {
-  asm volatile("ds_read_b64_tr_b16 %0, %8\n\t"
-               "ds_read_b64_tr_b16 %1, %9\n\t"
-               "ds_read_b64_tr_b16 %2, %10\n\t"
-               "ds_read_b64_tr_b16 %3, %11\n\t"
-               "ds_read_b64_tr_b16 %4, %12\n\t"
-               "ds_read_b64_tr_b16 %5, %13\n\t"
-               "ds_read_b64_tr_b16 %6, %14\n\t"
-               "ds_read_b64_tr_b16 %7, %15\n\t"
-               "s_waitcnt lgkmcnt(0)"
-               : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
-               : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7)
-               : "memory");
+// ds_read_b64_tr_b16 (through its builtin, so that the compiler counts lgkmcnt for it): lane 4 q + p of a 16-lane group supplies the address of row q,
+// columns 4 p .. 4 p + 3 of the group's 4 x 16 block; lane i of the group receives column i, row q in element q.  EXEC must be all ones (no divergence
+// around it).  (Round 6 first issued it by inline asm with a separate `s_waitcnt lgkmcnt(0)` statement: nothing tied the results to the wait, the compiler
+// scheduled the consuming MFMAs above it, and the kernel produced NaN weight gradients once two processes shared the device -- tools/vp_dp2_probe.py.)
+typedef bf16x4 __attribute__((address_space(3))) * lds_bf16x4_ptr;
+__device__ __forceinline__ bf16x4 tr_read(unsigned lds_byte_address) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(uintptr_t)lds_byte_address);
 }
 
 // byte offset of 16-byte chunk ch (0..15) of row k in a [64][128 x bf16] image with 256-byte rows (guide T10, image (b))
@@ -234,7 +228,7 @@ __global__ __launch_bounds__(NT, NS <= 2 ? 2 : 1) void gemm_bf16a_tn_kernel(Gemm
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   }
-  const bool want_rs = p.ep.a_rowsum != nullptr && tile_x == 0 && wn == 0;       // bias gradient: row sums of dY^T, taken once per row panel
+  const bool want_rs = __builtin_amdgcn_readfirstlane((int)(p.ep.a_rowsum != nullptr && tile_x == 0 && wn == 0)) != 0;   // wave-uniform, in an SGPR       // bias gradient: row sums of dY^T, taken once per row panel
   bf16x8 ones;
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
@@ -242,8 +236,11 @@ __global__ __launch_bounds__(NT, NS <= 2 ? 2 : 1) void gemm_bf16a_tn_kernel(Gemm
 #pragma unroll
   for (int d = 0; d < D; ++d)
     if (d < nk) dma(d, d);
-  int cur = 0;
   const unsigned smem_base = (unsigned)(uintptr_t)smem;
+  // (the bias-gradient rider is decided OUTSIDE the K loop -- two copies of the loop -- so that each k-step is one basic block the scheduler can pipeline)
+  auto k_loop = [&](auto with_rs) {
+  constexpr bool RS = decltype(with_rs)::value;
+  int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
     const int ahead = nk - 1 - kt;
     if (D >= 3 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPT) : "memory");
@@ -253,26 +250,34 @@ __global__ __launch_bounds__(NT, NS <= 2 ? 2 : 1) void gemm_bf16a_tn_kernel(Gemm
     asm volatile("" ::: "memory");
     if (kt + D < nk) dma(cur == 0 ? NS - 1 : cur - 1, kt + D);
     const unsigned st_l = smem_base + (unsigned)(cur * STAGE_BYTES);
+    // k-step s + 1's eight transposed reads are issued before k-step s's MFMAs (the compiler tracks lgkmcnt for the builtin: the MFMAs of step s wait for
+    // exactly their own reads)
+    bf16x8 af[2][2], bf[2][2];
+    auto frag = [&](int buf, int s) {
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) {
+        const bf16x4 a0 = tr_read(st_l + ta[blk][0] + 4096u * s), a1 = tr_read(st_l + ta[blk][1] + 4096u * s);
+        const bf16x4 b0 = tr_read(st_l + tb[blk][0] + 4096u * s), b1 = tr_read(st_l + tb[blk][1] + 4096u * s);
+        af[buf][blk] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+        bf[buf][blk] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+    };
+    frag(0, 0);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      bf16x8 af[2], bf[2];
-      bf16x4 a0[2], a1[2], b0[2], b1[2];
-      lds_tr4x8(a0[0], a1[0], b0[0], b1[0], a0[1], a1[1], b0[1], b1[1],
-                st_l + ta[0][0] + 4096u * s, st_l + ta[0][1] + 4096u * s, st_l + tb[0][0] + 4096u * s, st_l + tb[0][1] + 4096u * s,
-                st_l + ta[1][0] + 4096u * s, st_l + ta[1][1] + 4096u * s, st_l + tb[1][0] + 4096u * s, st_l + tb[1][1] + 4096u * s);
-#pragma unroll
-      for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { af[blk][e] = a0[blk][e]; af[blk][4 + e] = a1[blk][e]; bf[blk][e] = b0[blk][e]; bf[blk][4 + e] = b1[blk][e]; }
+      if (s < 3) frag((s + 1) & 1, s + 1);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-        if (want_rs) rs[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], ones, rs[i], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][i], bf[s & 1][j], acc[i][j], 0, 0, 0);
+        if (RS) rs[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][i], ones, rs[i], 0, 0, 0);
       }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // LDS reads retired before the barrier that frees this buffer
     cur = cur == NS - 1 ? 0 : cur + 1;
   }
+  };
+  if (want_rs) k_loop(std::true_type{}); else k_loop(std::false_type{});
   // accumulate: C[m][n] += acc (fp32 atomics: the K splits and the steps' other products add into the same gradient)
   const int r = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -300,36 +305,30 @@ __global__ __launch_bounds__(NT, NS <= 2 ? 2 : 1) void gemm_bf16a_tn_kernel(Gemm
 
 }  // namespace
 
-// NN: A16 [M, K] bf16 (ep.a16, ep.a16_ld), B = ep.b_planes [N, K] bf16.  tile: 64 (64 x 64), 96 (128 x 64) or 128 (128 x 128).
+// NN: A16 [M, K] bf16 (ep.a16, ep.a16_ld), B = ep.b_planes [N, K] bf16.  tile: 64 (64 x 64, 3 stages), 96 (128 x 64, 2 stages) or 128 (128 x 128, 2 stages).
 int mansy_gemm_bf16a_nn(const GemmParams& p, int tile, hipStream_t st) {
   auto al16 = [](const void* x) { return (reinterpret_cast<uintptr_t>(x) & 15) == 0; };
   MANSY_REQUIRE(p.ep.a16 && p.ep.b_planes && al16(p.ep.a16) && al16(p.ep.b_planes) && p.ep.a16_ld % 8 == 0 && p.ep.b_planes_ld % 8 == 0 && p.K % BK16 == 0 &&
                     p.K >= BK16, "bf16-storage product: operands must be 16-byte aligned with leading dimensions %% 8 == 0 and K %% 64 == 0");
   dim3 block(NT);
-  if (tile == 128) { dim3 grid(mansy_ceil_div(p.N, 128), mansy_ceil_div(p.M, 128), 1); MANSY_GEMM_LAUNCH((gemm_bf16a_nn_kernel<128, 128, 3>), grid, block, st, p); }
-  else if (tile == 129) { dim3 grid(mansy_ceil_div(p.N, 128), mansy_ceil_div(p.M, 128), 1); MANSY_GEMM_LAUNCH((gemm_bf16a_nn_kernel<128, 128, 4>), grid, block, st, p); }
-  else if (tile == 97) { dim3 grid(mansy_ceil_div(p.N, 64), mansy_ceil_div(p.M, 128), 1); MANSY_GEMM_LAUNCH((gemm_bf16a_nn_kernel<128, 64, 4>), grid, block, st, p); }
-  else if (tile == 96) {
-    dim3 grid(mansy_ceil_div(p.N, 64), mansy_ceil_div(p.M, 128), 1);
-    // a launch of at most one workgroup per CU (the [4 096, 512, K] decoder-step products: 256 tiles) is a latency chain of its own: SIX stages (144 KB, five
-    // of the eight K-tiles in flight) instead of three -- the tiles then arrive back to back behind ONE cold fetch instead of one fetch latency per two tiles
-    if ((long long)grid.x * grid.y <= 256) MANSY_GEMM_LAUNCH((gemm_bf16a_nn_kernel<128, 64, 6>), grid, block, st, p);
-    else MANSY_GEMM_LAUNCH((gemm_bf16a_nn_kernel<128, 64, 3>), grid, block, st, p);
-  }
-  else { dim3 grid(mansy_ceil_div(p.N, 64), mansy_ceil_div(p.M, 64), 1); MANSY_GEMM_LAUNCH((gemm_bf16a_nn_kernel<64, 64, 4>), grid, block, st, p); }
+  // TWO-stage rings: what bounds these loops is how many workgroups a CU holds (each one's cold first fetch, epilogue and store drain overlap the others' K
+  // loops), not how deep one workgroup prefetches -- profiles/r06_gemm_bf16a_lab.txt: 128 x 128 with 2 stages (2 per CU) 47 us on [40960, 512, 512] against
+  // 57 with 3 stages (1 per CU) and 60 with 4; tools/fill_probe.hip: the K loop alone is 26 us of it
+  if (tile == 128) { dim3 grid(mansy_ceil_div(p.N, 128), mansy_ceil_div(p.M, 128), 1); MANSY_GEMM_LAUNCH((gemm_bf16a_nn_kernel<128, 128, 2>), grid, block, st, p); }
+  else if (tile == 96) { dim3 grid(mansy_ceil_div(p.N, 64), mansy_ceil_div(p.M, 128), 1); MANSY_GEMM_LAUNCH((gemm_bf16a_nn_kernel<128, 64, 2>), grid, block, st, p); }
+  else { dim3 grid(mansy_ceil_div(p.N, 64), mansy_ceil_div(p.M, 64), 1); MANSY_GEMM_LAUNCH((gemm_bf16a_nn_kernel<64, 64, 3>), grid, block, st, p); }
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }
 
 // TN: C[M, N] += A16^T B16 over K rows; A16 [K, M], B16 [K, N] bf16; k_per_split % 64 == 0; M, N >= 8 and multiples of 8.
-int mansy_gemm_bf16a_tn(const GemmParams& p, int splits, int ns, hipStream_t st) {
+int mansy_gemm_bf16a_tn(const GemmParams& p, int splits, hipStream_t st) {
   auto al16 = [](const void* x) { return (reinterpret_cast<uintptr_t>(x) & 15) == 0; };
   MANSY_REQUIRE(p.ep.a16 && p.ep.b16 && al16(p.ep.a16) && al16(p.ep.b16) && p.ep.a16_ld % 8 == 0 && p.ep.b16_ld % 8 == 0 && p.M % 8 == 0 && p.N % 8 == 0 &&
                     p.M >= 8 && p.N >= 8 && p.K % BK16 == 0 && p.k_per_split % BK16 == 0,
                 "bf16-storage weight-gradient product: 16-byte aligned operands, M, N multiples of 8, K and the split length multiples of 64");
   dim3 grid(mansy_ceil_div(p.N, 128), mansy_ceil_div(p.M, 128), splits), block(NT);
-  if (ns == 3) MANSY_GEMM_LAUNCH((gemm_bf16a_tn_kernel<3>), grid, block, st, p);
-  else MANSY_GEMM_LAUNCH((gemm_bf16a_tn_kernel<2>), grid, block, st, p);
+  MANSY_GEMM_LAUNCH((gemm_bf16a_tn_kernel<2>), grid, block, st, p);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }

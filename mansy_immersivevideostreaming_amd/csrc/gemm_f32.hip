@@ -734,19 +734,17 @@ int mansy_launch_gemm_bf16a(int a_kmajor, int b_kmajor, float* C, int ldc, int M
     if (kps <= 0) kps = 64;
     splits = mansy_ceil_div(K, kps);
     p.k_per_split = kps; p.splits_pp = splits;
-    rc = mansy_gemm_bf16a_tn(p, splits, force_tile == 3 ? 3 : 2, st);
+    rc = mansy_gemm_bf16a_tn(p, splits, st);
   } else {
     MANSY_REQUIRE(!a_kmajor && ep.b_planes && !ep.accumulate && ep.split_slab == 0 && p.c_vec_ok,
                   "bf16-storage forward / dX product: K-contiguous a16, a weight plane, a storing row-major epilogue");
     int tile = force_tile;
     if (!tile) {
-      // [40 960-row] products: 128 x 128 (least L2 -> LDS traffic per flop) once that fills the chip; the [4 096-row] decoder-step products: 128 x 64
-      // = one workgroup per CU in ONE round (a launch of this size is latency-bound: fewer, fatter workgroups dispatch and drain faster)
+      // per-shape timing: profiles/r06_gemm_bf16a_lab.txt.  [40 960-row] products: 128 x 128 (least L2 -> LDS traffic per flop) once that fills the chip;
+      // the [4 096-row] decoder-step products: 128 x 64 for wide outputs (N >= 1024: 13.7 us against 15.7 on 64 x 64), 64 x 64 otherwise (7.9 against 9.6)
       const long long t128 = (long long)mansy_ceil_div(M, 128) * mansy_ceil_div(N, 128);
       const long long t96 = (long long)mansy_ceil_div(M, 128) * mansy_ceil_div(N, 64);
-      // (per-shape timing: profiles/r06_gemm_bf16a_bench.txt -- wide outputs (N >= 1024) run faster on 128 x 64 tiles, [40 960, 512, K] on 128 x 128)
-      // the [4 096-row] decoder-step products with N = 512 run fastest on 64 x 64 tiles, two workgroups per CU (7.2-7.8 us against 8.4-8.9 on 128 x 64)
-      tile = (t128 >= 512 && N < 1024) ? 128 : ((t96 >= 192 && (N >= 1024 || t96 > 512)) ? 96 : 64);
+      tile = t128 >= 512 ? 128 : ((t96 >= 192 && (N >= 1024 || t96 > 512)) ? 96 : 64);
     }
     p.k_per_split = K; p.splits_pp = 1;
     rc = mansy_gemm_bf16a_nn(p, tile, st);

@@ -1,0 +1,137 @@
+// Where do the bf16-storage products' cycles go (round 6)?  The NN loop of csrc/gemm_bf16a.hip on the [40960, 512, 512] shape with its parts switched on one
+// at a time: LDS-DMA fill only / + fragment reads / + MFMAs (no epilogue: one guarded store keeps the work alive).  Build on the GPU box:
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I mansy_immersivevideostreaming_amd/csrc -I include tools/fill_probe.hip -o /tmp/fill_probe
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+#include <vector>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void glds16(unsigned voff, const void* sbase, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+constexpr int NT = 256, BK16 = 64;
+template <int BM, int BN, int NS, int MODE, int WGS>
+__global__ __launch_bounds__(NT, WGS) void k(const unsigned short* A16, const unsigned short* B16, float* out, int M, int N, int K) {
+  constexpr int TM = BM / 64, TN = BN / 64, PA = BM / 32, PB = BN / 32, D = NS - 1;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES, PPT = PA + PB;
+  __shared__ __attribute__((aligned(1024))) char smem[NS * STAGE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+  int tile_x, tile_y;
+  {
+    const int nwg = gridDim.x * gridDim.y, orig = blockIdx.y * gridDim.x + blockIdx.x;
+    const int q = nwg >> 3, rem = nwg & 7, xcd = orig & 7, local = orig >> 3;
+    const int t = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + local;
+    tile_y = t / gridDim.x; tile_x = t - tile_y * gridDim.x;
+  }
+  const int m0 = tile_y * BM, n0 = tile_x * BN, nk = K / BK16, lda = K, ldb = K;
+  unsigned voa[PA], vob[PB];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) { const int row = i * 32 + wave * 8 + (lane >> 3); const int c = (lane & 7) ^ ((row >> 1) & 7); voa[i] = (unsigned)((row * lda + c * 8) * 2); }
+#pragma unroll
+  for (int i = 0; i < PB; ++i) { const int row = i * 32 + wave * 8 + (lane >> 3); const int c = (lane & 7) ^ ((row >> 1) & 7); vob[i] = (unsigned)((row * ldb + c * 8) * 2); }
+  const unsigned short* const ca = A16 + (long long)m0 * lda;
+  const unsigned short* const cb = B16 + (long long)n0 * ldb;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem + (unsigned)wave * 1024u);
+  auto dma = [&](int stage, int kt) {
+    const unsigned base = lds0 + (unsigned)(stage * STAGE_BYTES);
+#pragma unroll
+    for (int i = 0; i < PA; ++i) glds16(voa[i], ca + (long long)kt * BK16, base + (unsigned)i * 4096u);
+#pragma unroll
+    for (int i = 0; i < PB; ++i) glds16(vob[i], cb + (long long)kt * BK16, base + (unsigned)A_BYTES + (unsigned)i * 4096u);
+  };
+  int fa[TM][4], fb[TN][4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { const int row = wm * (BM / 2) + i * 32 + r; fa[i][s] = row * 128 + (((2 * s + h) ^ ((row >> 1) & 7)) << 4); }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { const int row = wn * (BN / 2) + j * 32 + r; fb[j][s] = A_BYTES + row * 128 + (((2 * s + h) ^ ((row >> 1) & 7)) << 4); }
+  }
+  f32x16 acc[TM][TN];
+  i32x4 x = {0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+#pragma unroll
+  for (int d = 0; d < D; ++d) if (d < nk) dma(d, d);
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int ahead = nk - 1 - kt;
+    if (D >= 3 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D >= 3 ? 2 * PPT : 0) : "memory");
+    else if (D >= 2 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D >= 2 ? PPT : 0) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + D < nk) dma(cur == 0 ? NS - 1 : cur - 1, kt + D);
+    const char* const st_l = smem + cur * STAGE_BYTES;
+    if (MODE & 2) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        bf16x8 af[TM], bf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(st_l + fa[i][s]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(st_l + fb[j][s]);
+        if (MODE & 4) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) x ^= __builtin_bit_cast(i32x4, af[i]);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) x ^= __builtin_bit_cast(i32x4, bf[j]);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    cur = cur == NS - 1 ? 0 : cur + 1;
+  }
+  float sum = (float)(x[0] ^ x[1] ^ x[2] ^ x[3]);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sum += acc[i][j][e];
+  if (sum == 12345.678f) out[tid] = sum;
+}
+template <int BM, int BN, int NS, int MODE, int WGS>
+void run(const char* name, std::vector<unsigned short*>& A, unsigned short* B, float* out, int M, int N, int K) {
+  dim3 grid(N / BN, M / BM), block(NT);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 6; ++i) hipLaunchKernelGGL((k<BM, BN, NS, MODE, WGS>), grid, block, 0, 0, A[i % A.size()], B, out, M, N, K);
+  hipEventRecord(e0);
+  const int it = 30;
+  for (int i = 0; i < it; ++i) hipLaunchKernelGGL((k<BM, BN, NS, MODE, WGS>), grid, block, 0, 0, A[i % A.size()], B, out, M, N, K);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  const double fill = (double)(M / BM) * (N / BN) * (K / 64) * (BM + BN) * 128.0;
+  printf("%-44s %7.1f us   LDS fill %6.1f MB -> %5.2f TB/s\n", name, ms / it * 1e3, fill / 1e6, fill / (ms / it * 1e-3) / 1e12);
+}
+int main() {
+  const int M = 40960, N = 512, K = 512;
+  std::vector<unsigned short*> A(6); unsigned short* B; float* out;
+  for (auto& a : A) { hipMalloc(&a, (size_t)M * K * 2); hipMemset(a, 0x3c, (size_t)M * K * 2); }
+  hipMalloc(&B, (size_t)N * K * 2); hipMemset(B, 0x3c, (size_t)N * K * 2); hipMalloc(&out, 4096);
+  printf("[40960, 512, 512] bf16 NN loop, parts (1 = DMA, 3 = + fragment reads, 7 = + MFMA)\n");
+  run<128, 128, 3, 1, 1>("128x128 NS3 1/CU  DMA only", A, B, out, M, N, K);
+  run<128, 128, 3, 3, 1>("128x128 NS3 1/CU  DMA + reads", A, B, out, M, N, K);
+  run<128, 128, 3, 7, 1>("128x128 NS3 1/CU  DMA + reads + MFMA", A, B, out, M, N, K);
+  run<128, 128, 2, 1, 2>("128x128 NS2 2/CU  DMA only", A, B, out, M, N, K);
+  run<128, 128, 2, 3, 2>("128x128 NS2 2/CU  DMA + reads", A, B, out, M, N, K);
+  run<128, 128, 2, 7, 2>("128x128 NS2 2/CU  DMA + reads + MFMA", A, B, out, M, N, K);
+  run<128, 64, 2, 1, 3>("128x64 NS2 3/CU  DMA only", A, B, out, M, N, K);
+  run<128, 64, 2, 7, 3>("128x64 NS2 3/CU  DMA + reads + MFMA", A, B, out, M, N, K);
+  run<64, 64, 2, 1, 4>("64x64 NS2 4/CU  DMA only", A, B, out, M, N, K);
+  run<64, 64, 2, 7, 4>("64x64 NS2 4/CU  DMA + reads + MFMA", A, B, out, M, N, K);
+  return 0;
+}

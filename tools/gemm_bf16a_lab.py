@@ -33,7 +33,9 @@ def tn(M, N, K, splits, ns):
         L.check(lib.mansy_gemm_bf16(L.ptr(dY[k]), M, 1, L.ptr(X[k]), N, 1, L.ptr(C), N, None, 0, M, N, K, ctypes.byref(ep), ns, splits, st))
     return timeit(f, 30)
 
+for (M, N, K) in ((4096, 512, 512), (4096, 1536, 512)):
+    print(f'NN [{M},{N},{K}] bf16-out: ' + '  '.join(f'tile {t}: {nn(M, N, K, t, "bf16"):6.1f}' for t in (64, 66, 67, 96, 98)) + '   f32-out: ' + '  '.join(f'tile {t}: {nn(M, N, K, t, "f32"):6.1f}' for t in (64, 66, 67, 96, 98)), flush=True)
 for (M, N, K) in ((40960, 512, 512), (40960, 1536, 512), (40960, 512, 1536), (20480, 1024, 512)):
-    print(f'NN [{M},{N},{K}] bf16-out: ' + '  '.join(f'tile {t}: {nn(M, N, K, t, "bf16"):6.1f}' for t in (96, 97, 128, 129)) + '   f32-out: ' + '  '.join(f'tile {t}: {nn(M, N, K, t, "f32"):6.1f}' for t in (96, 128, 129)), flush=True)
+    print(f'NN [{M},{N},{K}] bf16-out: ' + '  '.join(f'tile {t}: {nn(M, N, K, t, "bf16"):6.1f}' for t in (96, 98, 128, 130)) + '   f32-out: ' + '  '.join(f'tile {t}: {nn(M, N, K, t, "f32"):6.1f}' for t in (96, 98, 128, 130)), flush=True)
 for (M, N, K) in ((512, 512, 40960), (1536, 512, 40960), (512, 1536, 40960), (1024, 512, 20480)):
-    print(f'TN [{M},{N},{K}]: ' + '  '.join(f'splits {s or "auto"} ns {ns or 2}: {tn(M, N, K, s, ns):6.1f}' for s in (0, 16, 64) for ns in (0, 3)), flush=True)
+    print(f'TN [{M},{N},{K}]: ' + '  '.join(f'splits {s or "auto"}: {tn(M, N, K, s, 0):6.1f}' for s in (0, 8, 16, 32)), flush=True)
