@@ -504,7 +504,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_kvgrad_q1x4_kernel(const floa
                                                                       const float* __restrict__ dO_all, long long o_ts,
                                                                       const float* __restrict__ dS_all, const float* __restrict__ Pk_all,
                                                                       float* __restrict__ dK, float* __restrict__ dV, AttnShape s, int T,
-                                                                      int accum) {
+                                                                      int accum, const float* img_f, unsigned short* img_s) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int hg = s.H >> 2;
   const long long g = (long long)blockIdx.x * WAVES + wave;
@@ -542,6 +542,10 @@ __global__ __launch_bounds__(64 * WAVES) void attn_kvgrad_q1x4_kernel(const floa
     }
     *reinterpret_cast<float4*>(dKb + j * s.k_rs) = dk;
     *reinterpret_cast<float4*>(dVb + j * s.v_rs) = dv;
+    if (img_s) {      // bf16-storage mode: the K/V gradient rows are operands of the memory projection's dW and dX products
+      mansy_st_bf16x4(img_s + (dKb + j * s.k_rs - img_f), dk.x, dk.y, dk.z, dk.w);
+      mansy_st_bf16x4(img_s + (dVb + j * s.v_rs - img_f), dv.x, dv.y, dv.z, dv.w);
+    }
   }
 }
 
@@ -794,14 +798,15 @@ int mansy_launch_attn_bwd_dq(const float* Q, const float* K, const float* V, con
 }
 // Q_all / dO_all: step i at + i*q_ts / + i*o_ts (batch strides from s); dS_all / Pk_all: [T][nb*H][Lk].
 int mansy_launch_attn_kvgrad(const float* Q_all, long long q_ts, const float* dO_all, long long o_ts, const float* dS_all,
-                             const float* Pk_all, float* dK, float* dV, const AttnShape& s, int T, int accum, hipStream_t st) {
+                             const float* Pk_all, float* dK, float* dV, const AttnShape& s, int T, int accum, hipStream_t st, const float* img_f,
+                             unsigned short* img_s) {
   MANSY_REQUIRE(Q_all && dO_all && dS_all && Pk_all && dK && dV, "attn_kvgrad: null pointer");
   MANSY_REQUIRE(mansy_attn_deferred_kv_ok(s, T) && (q_ts % 4) == 0 && (o_ts % 4) == 0, "attn_kvgrad: unsupported shape");
   auto al = [](const void* x) { return (reinterpret_cast<uintptr_t>(x) & 15) == 0; };
   MANSY_REQUIRE(al(Q_all) && al(dO_all) && al(dK) && al(dV), "attn_kvgrad: pointers must be 16-byte aligned");
   const long long n = (long long)s.nb * s.H;
   if (n == 0) return MANSY_OK;
-#define MANSY_KVGRAD_ARGS dim3(mansy_ceil_div(n / 4, WAVES)), dim3(64 * WAVES), 0, st, Q_all, q_ts, dO_all, o_ts, dS_all, Pk_all, dK, dV, s, T, accum
+#define MANSY_KVGRAD_ARGS dim3(mansy_ceil_div(n / 4, WAVES)), dim3(64 * WAVES), 0, st, Q_all, q_ts, dO_all, o_ts, dS_all, Pk_all, dK, dV, s, T, accum, img_f, img_s
   MANSY_Q1X4_DISPATCH(attn_kvgrad_q1x4_kernel, T, MANSY_KVGRAD_ARGS)
 #undef MANSY_KVGRAD_ARGS
   MANSY_LAUNCH_CHECK();

@@ -152,14 +152,20 @@ __device__ __forceinline__ bf16x4 tr_read(unsigned lds_byte_address) {
 // byte offset of 16-byte chunk ch (0..15) of row k in a [64][128 x bf16] image with 256-byte rows (guide T10, image (b))
 __device__ __forceinline__ unsigned tn_off(int k, int ch) { return (unsigned)(256 * k + 16 * (ch ^ (((k & 3) << 2) | ((k >> 2) & 3)))); }
 
-template <int NS>
-__global__ __launch_bounds__(NT, NS <= 2 ? 2 : 1) void gemm_bf16a_tn_kernel(GemmParams p) {
+// KG = 2 ("K groups"): a workgroup of EIGHT waves; waves 0-3 take the even K-tiles of the workgroup's K range, waves 4-7 the odd ones, each group on a ring
+// of its own, and the two partial tiles are added through LDS before the atomics.  The atomics are the expensive part of a split-K product here (fp32
+// atomic adds of all XCDs on one gradient run memory-side: tools/fill_probe_tn.hip -- [512, 512, 40960]: K loop 26 us at 32 splits / 36 us at 16, atomics
+// 30 us at 32 splits / 14 us at 16): one 8-wave workgroup per CU has the K loop of 32 four-wave splits and the atomics of 16.
+template <int NS, int KG>
+__global__ __launch_bounds__(NT * KG, KG == 1 ? 2 : 1) void gemm_bf16a_tn_kernel(GemmParams p) {
   constexpr int BM = 128, BN = 128, D = NS - 1;
+  static_assert(NS == 2 && (KG == 1 || KG == 2), "two-stage ring; one or two K groups");
   constexpr int A_BYTES = BK16 * 256, B_BYTES = BK16 * 256, STAGE_BYTES = A_BYTES + B_BYTES;      // 32 KB per stage
   constexpr int PA = 4, PB = 4, PPT = PA + PB;                                                     // 16 pieces of 1 KB per operand tile, 4 per wave
-  __shared__ __attribute__((aligned(1024))) char smem[NS * STAGE_BYTES];
+  __shared__ __attribute__((aligned(1024))) char smem_all[KG * NS * STAGE_BYTES];
 
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x & (NT - 1), kg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / NT));      // position inside the K group; the group
+  char* const smem = smem_all + kg * (NS * STAGE_BYTES);
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   int split, tile_x, tile_y;
@@ -175,7 +181,8 @@ __global__ __launch_bounds__(NT, NS <= 2 ? 2 : 1) void gemm_bf16a_tn_kernel(Gemm
   }
   const int m0 = tile_y * BM, n0 = tile_x * BN;
   const int k_begin = split * p.k_per_split, k_end = min(p.K, k_begin + p.k_per_split);
-  const int nk = (k_end - k_begin) / BK16;
+  const int nk_all = (k_end - k_begin) / BK16;
+  const int nk = (nk_all - kg + KG - 1) / KG, nit = (nk_all + KG - 1) / KG;      // this group's K-tiles (tile it of the group = K-tile it * KG + kg); iterations (barriers) of the workgroup
   const unsigned short* const A16 = p.ep.a16;           // [K][M] (dY rows), lda
   const unsigned short* const B16 = p.ep.b16;           // [K][N] (X rows), ldb
   const int lda = p.ep.a16_ld, ldb = p.ep.b16_ld;
@@ -195,8 +202,8 @@ __global__ __launch_bounds__(NT, NS <= 2 ? 2 : 1) void gemm_bf16a_tn_kernel(Gemm
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem + (unsigned)wave * 1024u);
   auto dma = [&](int stage, int kt) {
     const unsigned base = lds0 + (unsigned)(stage * STAGE_BYTES);
-    const unsigned short* a_corner = ca + (long long)kt * BK16 * lda;
-    const unsigned short* b_corner = cb + (long long)kt * BK16 * ldb;
+    const unsigned short* a_corner = ca + (long long)(kt * KG + kg) * BK16 * lda;
+    const unsigned short* b_corner = cb + (long long)(kt * KG + kg) * BK16 * ldb;
 #pragma unroll
     for (int i = 0; i < PA; ++i) glds16(voa[i], a_corner, base + (unsigned)i * 4096u);
 #pragma unroll
@@ -241,14 +248,12 @@ __global__ __launch_bounds__(NT, NS <= 2 ? 2 : 1) void gemm_bf16a_tn_kernel(Gemm
   auto k_loop = [&](auto with_rs) {
   constexpr bool RS = decltype(with_rs)::value;
   int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int ahead = nk - 1 - kt;
-    if (D >= 3 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPT) : "memory");
-    else if (D >= 2 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPT) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (int kt = 0; kt < nit; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (two stages: the one tile in flight is the one wanted)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (kt + D < nk) dma(cur == 0 ? NS - 1 : cur - 1, kt + D);
+    if (KG > 1 && kt >= nk) continue;                         // (an odd K-tile count: the second group sits out the last iteration, barrier included above)
     const unsigned st_l = smem_base + (unsigned)(cur * STAGE_BYTES);
     // k-step s + 1's eight transposed reads are issued before k-step s's MFMAs (the compiler tracks lgkmcnt for the builtin: the MFMAs of step s wait for
     // exactly their own reads)
@@ -280,8 +285,8 @@ __global__ __launch_bounds__(NT, NS <= 2 ? 2 : 1) void gemm_bf16a_tn_kernel(Gemm
   if (want_rs) k_loop(std::true_type{}); else k_loop(std::false_type{});
   // accumulate: C[m][n] += acc (fp32 atomics: the K splits and the steps' other products add into the same gradient)
   const int r = lane & 31, h = lane >> 5;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  auto add_block_row = [&](auto which) {
+    constexpr int i = decltype(which)::value;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = n0 + wn * 64 + j * 32 + r;
@@ -300,6 +305,42 @@ __global__ __launch_bounds__(NT, NS <= 2 ? 2 : 1) void gemm_bf16a_tn_kernel(Gemm
         if (row < p.M) atomicAdd(p.ep.a_rowsum + row, rs[i][e]);
       }
     }
+  };
+  if (KG == 2) {
+    // the two groups' partial tiles: group g keeps block row i == g, hands block row 1 - g to the other group through LDS (the rings are idle), and issues
+    // the atomics of its own block row only -- 32 staged floats per thread (+ 16 of the row sums), each read back by the thread at the same position.
+    // (Block rows are indexed by CONSTANTS in each branch: a run-time index into the accumulator arrays would move them to scratch memory.)
+    float* const xch = reinterpret_cast<float*>(smem_all);
+    auto hand_over = [&](auto send_c) {
+      constexpr int SEND = decltype(send_c)::value;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) xch[((SEND * 8 + wave * 2 + j) * 16 + e) * 64 + lane] = acc[SEND][j][e];
+      if (want_rs) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) xch[16384 + ((SEND * 4 + wave) * 16 + e) * 64 + lane] = rs[SEND][e];
+      }
+    };
+    auto take = [&](auto keep_c) {
+      constexpr int KEEP = decltype(keep_c)::value;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[KEEP][j][e] += xch[((KEEP * 8 + wave * 2 + j) * 16 + e) * 64 + lane];
+      if (want_rs) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) rs[KEEP][e] += xch[16384 + ((KEEP * 4 + wave) * 16 + e) * 64 + lane];
+      }
+    };
+    __syncthreads();
+    if (kg == 0) hand_over(std::integral_constant<int, 1>{}); else hand_over(std::integral_constant<int, 0>{});
+    __syncthreads();
+    if (kg == 0) { take(std::integral_constant<int, 0>{}); add_block_row(std::integral_constant<int, 0>{}); }
+    else { take(std::integral_constant<int, 1>{}); add_block_row(std::integral_constant<int, 1>{}); }
+  } else {
+    add_block_row(std::integral_constant<int, 0>{});
+    add_block_row(std::integral_constant<int, 1>{});
   }
 }
 
@@ -322,13 +363,14 @@ int mansy_gemm_bf16a_nn(const GemmParams& p, int tile, hipStream_t st) {
 }
 
 // TN: C[M, N] += A16^T B16 over K rows; A16 [K, M], B16 [K, N] bf16; k_per_split % 64 == 0; M, N >= 8 and multiples of 8.
-int mansy_gemm_bf16a_tn(const GemmParams& p, int splits, hipStream_t st) {
+int mansy_gemm_bf16a_tn(const GemmParams& p, int splits, int kgroups, hipStream_t st) {
   auto al16 = [](const void* x) { return (reinterpret_cast<uintptr_t>(x) & 15) == 0; };
   MANSY_REQUIRE(p.ep.a16 && p.ep.b16 && al16(p.ep.a16) && al16(p.ep.b16) && p.ep.a16_ld % 8 == 0 && p.ep.b16_ld % 8 == 0 && p.M % 8 == 0 && p.N % 8 == 0 &&
                     p.M >= 8 && p.N >= 8 && p.K % BK16 == 0 && p.k_per_split % BK16 == 0,
                 "bf16-storage weight-gradient product: 16-byte aligned operands, M, N multiples of 8, K and the split length multiples of 64");
-  dim3 grid(mansy_ceil_div(p.N, 128), mansy_ceil_div(p.M, 128), splits), block(NT);
-  MANSY_GEMM_LAUNCH((gemm_bf16a_tn_kernel<2>), grid, block, st, p);
+  dim3 grid(mansy_ceil_div(p.N, 128), mansy_ceil_div(p.M, 128), splits);
+  if (kgroups == 2) { dim3 block(2 * NT); MANSY_GEMM_LAUNCH((gemm_bf16a_tn_kernel<2, 2>), grid, block, st, p); }
+  else { dim3 block(NT); MANSY_GEMM_LAUNCH((gemm_bf16a_tn_kernel<2, 1>), grid, block, st, p); }
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }

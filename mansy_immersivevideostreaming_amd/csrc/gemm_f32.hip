@@ -724,17 +724,19 @@ int mansy_launch_gemm_bf16a(int a_kmajor, int b_kmajor, float* C, int ldc, int M
   if (a_kmajor && b_kmajor) {
     MANSY_REQUIRE(ep.b16 && C && !ep.c16 && !ep.bias && !ep.relu && !ep.mask_src && ep.drop.p == 0.f && !ep.resid && ep.accumulate,
                   "bf16-storage weight-gradient product: plain accumulating epilogue, K-major b16");
-    // split-K over the rows: one round of resident workgroups (2 per CU), at least 8 K-tiles of 64 per split
+    // split-K over the rows.  Eight-wave workgroups (two K groups: gemm_bf16a.hip), one per CU, at least 8 K-tiles of 64 per group; a reduce dimension too
+    // short for that (or force_tile == 64): four-wave workgroups, two per CU, at least 8 K-tiles per split
     const long long tiles = (long long)mansy_ceil_div(M, 128) * mansy_ceil_div(N, 128);
-    int splits = force_splitk > 0 ? force_splitk : (int)(512 / tiles);
+    int kgroups = (force_tile == 64 || K < 64 * 16) ? 1 : 2;
+    int splits = force_splitk > 0 ? force_splitk : (int)((kgroups == 2 ? 256 : 512) / tiles);
     if (splits < 1) splits = 1;
-    const int max_splits = K / (64 * 8) > 0 ? K / (64 * 8) : 1;
+    const int max_splits = K / (64 * 8 * kgroups) > 0 ? K / (64 * 8 * kgroups) : 1;
     if (splits > max_splits) splits = max_splits;
     int kps = mansy_ceil_div(mansy_ceil_div(K, splits), 64) * 64;
     if (kps <= 0) kps = 64;
     splits = mansy_ceil_div(K, kps);
     p.k_per_split = kps; p.splits_pp = splits;
-    rc = mansy_gemm_bf16a_tn(p, splits, st);
+    rc = mansy_gemm_bf16a_tn(p, splits, kgroups, st);
   } else {
     MANSY_REQUIRE(!a_kmajor && ep.b_planes && !ep.accumulate && ep.split_slab == 0 && p.c_vec_ok,
                   "bf16-storage forward / dX product: K-contiguous a16, a weight plane, a storing row-major epilogue");

@@ -225,7 +225,7 @@ __device__ __forceinline__ void glds16(unsigned voff, const void* sbase, unsigne
 
 // bf16-storage products (gemm_bf16a.hip): A16 / B planes K-contiguous (NN) and the K-major weight-gradient form (TN)
 int mansy_gemm_bf16a_nn(const mansy_gemm::GemmParams& p, int tile, hipStream_t st);
-int mansy_gemm_bf16a_tn(const mansy_gemm::GemmParams& p, int splits, hipStream_t st);
+int mansy_gemm_bf16a_tn(const mansy_gemm::GemmParams& p, int splits, int kgroups, hipStream_t st);
 // capture of wave-split-K launches (gemm_f32.hip): see there
 int mansy_gemm_capture_begin();
 int mansy_gemm_capture_end(mansy_gemm::GemmParams* out, int* variant, int* gx, int* gy, int* gz, int max_n);

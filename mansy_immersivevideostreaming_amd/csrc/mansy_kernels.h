@@ -132,7 +132,8 @@ int mansy_launch_attn_bwd_dq(const float* Q, const float* K, const float* V, con
                              float* dS_out, float* Pk_out, const AttnShape& s, MansyDrop drop, hipStream_t st,
                              const float* img_f = nullptr, unsigned short* img_s = nullptr, int img_only = 0, int kv16 = 0);
 int mansy_launch_attn_kvgrad(const float* Q_all, long long q_ts, const float* dO_all, long long o_ts, const float* dS_all,
-                             const float* Pk_all, float* dK, float* dV, const AttnShape& s, int T, int accum, hipStream_t st);
+                             const float* Pk_all, float* dK, float* dV, const AttnShape& s, int T, int accum, hipStream_t st,
+                             const float* img_f = nullptr, unsigned short* img_s = nullptr);      // + bf16 images of dK / dV at img_s + (p - img_f)
 
 // KV-cached decoder self-attention backward, "pull" form: the steps run T-1 -> 0; the call for step i records its coefficient
 // rows and writes row i of the K/V gradient complete (own term + the terms of the later steps, read from the Q / dO slabs),
@@ -187,11 +188,12 @@ constexpr int MANSY_DISTILL_PARTS = 512;
 int mansy_launch_distill_fwd(const float* conv, const float* bn_w, const float* bn_b, float* run_mean, float* run_var,
                              long long* num_batches, float* mean_out, float* rstd_out, float* mem, unsigned char* argmax,
                              double* stats_d, const DistillShape& s, int train, float eps, float momentum,
-                             hipStream_t st, double* part = nullptr);
+                             hipStream_t st, double* part = nullptr, unsigned short* mem16 = nullptr);
 // dconv [B*S,C] from dmem [B*M,C]; dbn_w/dbn_b accumulated (+=).  g_tmp: [B*S,C] scratch.
 int mansy_launch_distill_bwd(const float* conv, const float* dmem, const unsigned char* argmax, const float* bn_w,
                              const float* bn_b, const float* mean, const float* rstd, float* g_tmp, float* dconv,
-                             float* dbn_w, float* dbn_b, double* stats_d, const DistillShape& s, hipStream_t st, double* part = nullptr);
+                             float* dbn_w, float* dbn_b, double* stats_d, const DistillShape& s, hipStream_t st, double* part = nullptr,
+                             unsigned short* dconv16 = nullptr);      // mem16 / dconv16: bf16 images of the outputs (bf16-storage mode)
 
 // ---------------------------------------------------------------- fused decoder-step tail (dec_step.hip)
 // One launch for the four row-wise ops between the last product of decoder step i and the first of step i+1:

@@ -386,7 +386,7 @@ __device__ __forceinline__ float elu1(float v) { return v > 0.f ? v : expm1f(v);
 __global__ __launch_bounds__(256) void bn_elu_pool_kernel(const float* __restrict__ conv, const float* __restrict__ bn_w,
                                                           const float* __restrict__ bn_b, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, float* __restrict__ mem,
-                                                          unsigned char* __restrict__ argmax, DistillShape s) {
+                                                          unsigned char* __restrict__ argmax, DistillShape s, unsigned short* __restrict__ mem16) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long total = (long long)s.B * s.M * s.C;
   if (idx >= total) return;
@@ -402,6 +402,7 @@ __global__ __launch_bounds__(256) void bn_elu_pool_kernel(const float* __restric
     if (v > best) { best = v; bi = sp; }     // first maximum wins (torch max_pool1d tie rule)
   }
   mem[idx] = best;
+  if (mem16) mansy_st_bf16(mem16 + idx, best);      // bf16-storage mode: the memory is the A operand of every decoder layer's K/V projection
   if (argmax) argmax[idx] = (unsigned char)bi;
 }
 
@@ -498,7 +499,7 @@ __global__ __launch_bounds__(256) void distill_bwd_stage2(const float* __restric
                                                           const float* __restrict__ bn_w, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, const double* __restrict__ stats,
                                                           float* __restrict__ dconv, float* __restrict__ dbn_w, float* __restrict__ dbn_b,
-                                                          DistillShape s) {
+                                                          DistillShape s, unsigned short* __restrict__ dconv16) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long total = (long long)s.B * s.S * s.C;
   if (idx >= total) return;
@@ -507,7 +508,9 @@ __global__ __launch_bounds__(256) void distill_bwd_stage2(const float* __restric
   const float sg = (float)(stats[2 * s.C + c] / n), sgx = (float)(stats[3 * s.C + c] / n);
   const float rs = rstd[c];
   const float xh = (conv[idx] - mean[c]) * rs;
-  dconv[idx] = bn_w[c] * rs * (g[idx] - sg - xh * sgx);
+  const float dc = bn_w[c] * rs * (g[idx] - sg - xh * sgx);
+  dconv[idx] = dc;
+  if (dconv16) mansy_st_bf16(dconv16 + idx, dc);    // bf16-storage mode: operand of the conv's dW and dX products
   if (idx < s.C) {   // first row's threads publish the parameter gradients
     atomicAdd(dbn_w + c, (float)stats[5 * s.C + c]);
     atomicAdd(dbn_b + c, (float)stats[4 * s.C + c]);
@@ -566,7 +569,7 @@ int mansy_launch_layernorm_bwd(const float* dy, const float* z, const float* mea
 
 int mansy_launch_distill_fwd(const float* conv, const float* bn_w, const float* bn_b, float* run_mean, float* run_var,
                              long long* num_batches, float* mean_out, float* rstd_out, float* mem, unsigned char* argmax,
-                             double* stats_d, const DistillShape& s, int train, float eps, float momentum, hipStream_t st, double* part) {
+                             double* stats_d, const DistillShape& s, int train, float eps, float momentum, hipStream_t st, double* part, unsigned short* mem16) {
   MANSY_REQUIRE(conv && bn_w && bn_b && run_mean && run_var && mean_out && rstd_out && mem && stats_d, "distill_fwd: null pointer");
   MANSY_REQUIRE(s.M == (s.S - 1) / 2 + 1, "distill_fwd: M must be floor((S-1)/2)+1");
   MANSY_REQUIRE(s.S <= 255, "distill_fwd: S too large");
@@ -583,14 +586,14 @@ int mansy_launch_distill_fwd(const float* conv, const float* bn_w, const float* 
                      num_batches, mean_out, rstd_out, train, eps, momentum);
   const long long total = (long long)s.B * s.M * s.C;
   MANSY_LAUNCH(bn_elu_pool_kernel, dim3(mansy_ceil_div(total, 256)), dim3(256), 0, st, conv, bn_w, bn_b, mean_out, rstd_out,
-                     mem, argmax, s);
+                     mem, argmax, s, mem16);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }
 
 int mansy_launch_distill_bwd(const float* conv, const float* dmem, const unsigned char* argmax, const float* bn_w,
                              const float* bn_b, const float* mean, const float* rstd, float* g_tmp, float* dconv, float* dbn_w,
-                             float* dbn_b, double* stats_d, const DistillShape& s, hipStream_t st, double* part) {
+                             float* dbn_b, double* stats_d, const DistillShape& s, hipStream_t st, double* part, unsigned short* dconv16) {
   MANSY_REQUIRE(conv && dmem && argmax && bn_w && bn_b && mean && rstd && g_tmp && dconv && dbn_w && dbn_b && stats_d,
                 "distill_bwd: null pointer");
   const int rows = s.B * s.S;
@@ -611,7 +614,7 @@ int mansy_launch_distill_bwd(const float* conv, const float* dmem, const unsigne
   if (s.sync_world > 1) RC_HOOK(mansy_bn_sync_invoke(1, s.hook, s.hook_user));       // SyncBN backward: all-reduce [sum g, sum g*xhat]
   const long long total = (long long)rows * s.C;
   MANSY_LAUNCH(distill_bwd_stage2, dim3(mansy_ceil_div(total, 256)), dim3(256), 0, st, conv, g_tmp, bn_w, mean, rstd, stats_d,
-                     dconv, dbn_w, dbn_b, s);
+                     dconv, dbn_w, dbn_b, s, dconv16);
   MANSY_LAUNCH_CHECK();
   return MANSY_OK;
 }

@@ -426,11 +426,11 @@ struct Eng {
     RC(lin_fwd(W.col, N, 3 * d, P.conv.w, P.conv.b, d, W.conv, 0, mansy_no_drop()));
     DistillShape ds = {B, S, M, d, c.bn_sync_world > 1 ? c.bn_sync_world : 1, c.bn_sync_fn, c.bn_sync_user};
     RC(mansy_launch_distill_fwd(W.conv, P.bn.w, P.bn.b, bn_rm, bn_rv, bn_nbt, W.bn_mean, W.bn_rstd, W.mem, W.argmax, W.stats, ds,
-                                train ? 1 : 0, c.bn_eps, c.bn_momentum, st, W.dis_part));
+                                train ? 1 : 0, c.bn_eps, c.bn_momentum, st, W.dis_part, im(W.mem)));
     for (int l = 0; l < c.n_dec; ++l) {
       const DecLayerP& p = P.dec[l];
-      RC(lin_fwd(W.mem, B * M, d, p.ca_in.w + (size_t)d * d, p.ca_in.b ? p.ca_in.b + d : nullptr, 2 * d, W.dec[l].memkv, 0, mansy_no_drop(), nullptr, 1,
-                 false));      // (the distilled memory has no bf16 image: the DistillLayer keeps floats; the projected K/V rows get one: the cross-attention cache)
+      RC(lin_fwd(W.mem, B * M, d, p.ca_in.w + (size_t)d * d, p.ca_in.b ? p.ca_in.b + d : nullptr, 2 * d, W.dec[l].memkv, 0, mansy_no_drop(), nullptr, 1));
+      // (the projected K/V rows get an image: the cross-attention cache)
     }
     MANSY_HIP_CHECK(hipMemcpyAsync(W.tok_all, cur, sizeof(float) * B * C6, hipMemcpyDeviceToDevice, st));
     // the four row-wise ops between the last product of step i and the first of step i+1 run as one launch (dec_step.hip)
@@ -677,19 +677,19 @@ struct Eng {
       RC(lin_dw(e.dbr1, e.ao1, TB, d, d, p.sa_out.gw, p.sa_out.gb));
       RC(lin_dw(e.dqc, e.y1, TB, d, d, p.ca_in.gw, p.ca_in.gb));
       if (defer_cross)
-        RC(mansy_launch_attn_kvgrad(e.qc, (long long)B * d, e.dao2, (long long)B * d, e.dS2, e.Pk2, e.dmemkv, e.dmemkv + d, cross_shape(), T, 0, st));
-      RC(lin_dw(e.dmemkv, W.mem, B * M, 2 * d, d, p.ca_in.gw + (size_t)d * d, p.ca_in.gb ? p.ca_in.gb + d : nullptr, false));      // (floats only: the K/V-gradient pass and the DistillLayer keep no images)
+        RC(mansy_launch_attn_kvgrad(e.qc, (long long)B * d, e.dao2, (long long)B * d, e.dS2, e.Pk2, e.dmemkv, e.dmemkv + d, cross_shape(), T, 0, st, W.fbase, im(W.fbase)));
+      RC(lin_dw(e.dmemkv, W.mem, B * M, 2 * d, d, p.ca_in.gw + (size_t)d * d, p.ca_in.gb ? p.ca_in.gb + d : nullptr, defer_cross));      // (the per-step accumulating form of the K/V gradients keeps floats only)
       RC(lin_dw(e.dbr2, e.ao2, TB, d, d, p.ca_out.gw, p.ca_out.gb));
       RC(lin_dw(e.da, e.y2, TB, f, d, p.lin1.gw, p.lin1.gb));
       RC(lin_dw(e.dbr3, e.h, TB, d, f, p.lin2.gw, p.lin2.gb));
-      RC(lin_dx(e.dmemkv, B * M, 2 * d, p.ca_in.w + (size_t)d * d, d, W.dmem, l == 0 ? nullptr : W.dmem, nullptr, 1.f, 0, false));
+      RC(lin_dx(e.dmemkv, B * M, 2 * d, p.ca_in.w + (size_t)d * d, d, W.dmem, l == 0 ? nullptr : W.dmem, nullptr, 1.f, 0, defer_cross));
     }
     // ---- DistillLayer
     DistillShape ds = {B, S, M, d, c.bn_sync_world > 1 ? c.bn_sync_world : 1, c.bn_sync_fn, c.bn_sync_user};
     RC(mansy_launch_distill_bwd(W.conv, W.dmem, W.argmax, P.bn.w, P.bn.b, W.bn_mean, W.bn_rstd, W.g_a, W.g_b, P.bn.gw, P.bn.gb, W.stats,
-                                ds, st, W.dis_part));
-    RC(lin_dw(W.g_b, W.col, N, d, 3 * d, P.conv.gw, P.conv.gb, false));
-    RC(lin_dx(W.g_b, N, d, P.conv.w, 3 * d, W.g_wide, nullptr, nullptr, 1.f, 0, false));
+                                ds, st, W.dis_part, im(W.g_b)));
+    RC(lin_dw(W.g_b, W.col, N, d, 3 * d, P.conv.gw, P.conv.gb));
+    RC(lin_dx(W.g_b, N, d, P.conv.w, 3 * d, W.g_wide, nullptr, nullptr, 1.f));
     RC(mansy_launch_col2im3(W.g_wide, W.g_a, B, S, d, st));
     // Data parallel: every gradient from the first decoder layer to the end of the parameter table (decoder layers, decoder
     // norm, DistillLayer conv + BatchNorm, predictor -- two thirds of the flat buffer) is final here.  The host hook (which = 2)

@@ -69,8 +69,10 @@ def test_forward_form_fused_epilogue_and_bf16_only_output(L):
         assert err <= 2 ** -8 * float(want.abs().max()) + 1e-6, (kind, err)              # one bf16 rounding of the output
 
 
-@pytest.mark.parametrize('M,N,K,splits', [(512, 512, 40960, 0), (1536, 512, 8192, 0), (512, 1536, 8192, 4), (64, 64, 640, 0), (192, 64, 1280, 1), (512, 512, 4096, 1)])
-def test_weight_gradient_form_vs_torch(L, M, N, K, splits):
+@pytest.mark.parametrize('tile', [0, 64])      # 0: by shape (eight-wave workgroups with two K groups when the reduce dimension allows); 64: the four-wave kernel
+@pytest.mark.parametrize('M,N,K,splits', [(512, 512, 40960, 0), (1536, 512, 8192, 0), (512, 1536, 8192, 4), (64, 64, 640, 0), (192, 64, 1280, 1), (512, 512, 4096, 1),
+                                          (256, 128, 64 * 33, 1), (256, 384, 64 * 35, 2), (136, 72, 64 * 16, 0)])      # odd K-tile counts: the second K group sits out the last iteration
+def test_weight_gradient_form_vs_torch(L, M, N, K, splits, tile):
     g = torch.Generator(device='cpu').manual_seed(M * 7 + N + K)
     dY = _bf(torch.randn(K, M, generator=g) * 0.1).cuda()
     X = _bf(torch.randn(K, N, generator=g)).cuda()
@@ -82,7 +84,7 @@ def test_weight_gradient_form_vs_torch(L, M, N, K, splits):
     ep = L.GemmEpilogue()
     ep.accumulate = 1
     ep.a_rowsum = L.ptr(rs)
-    L.check(L.lib().mansy_gemm_bf16(L.ptr(dY), M, 1, L.ptr(X), N, 1, L.ptr(C), N, None, 0, M, N, K, ctypes.byref(ep), 0, splits, L.stream_ptr()), 'gemm_bf16')
+    L.check(L.lib().mansy_gemm_bf16(L.ptr(dY), M, 1, L.ptr(X), N, 1, L.ptr(C), N, None, 0, M, N, K, ctypes.byref(ep), tile, splits, L.stream_ptr()), 'gemm_bf16')
     torch.cuda.synchronize()
     scale = float(want.abs().max())
     assert float((C - C0 - want).abs().max()) <= 2e-5 * scale + 1e-5, float((C - C0 - want).abs().max())      # K up to 40 960 fp32 additions in another order (split-K atomics)

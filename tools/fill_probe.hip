@@ -14,11 +14,12 @@ __device__ __forceinline__ void glds16(unsigned voff, const void* sbase, unsigne
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 constexpr int NT = 256, BK16 = 64;
-template <int BM, int BN, int NS, int MODE, int WGS>
-__global__ __launch_bounds__(NT, WGS) void k(const unsigned short* A16, const unsigned short* B16, float* out, int M, int N, int K) {
+template <int BM, int BN, int NS, int MODE, int WGS, int EPI>
+__global__ __launch_bounds__(NT, WGS) void k(const unsigned short* A16, const unsigned short* B16, float* out, int M, int N, int K, unsigned short* C16, float* C32) {
   constexpr int TM = BM / 64, TN = BN / 64, PA = BM / 32, PB = BN / 32, D = NS - 1;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES, PPT = PA + PB;
-  __shared__ __attribute__((aligned(1024))) char smem[NS * STAGE_BYTES];
+  constexpr int CB = BM * (BN + 4) * 4, SB = NS * STAGE_BYTES > CB ? NS * STAGE_BYTES : CB;
+  __shared__ __attribute__((aligned(1024))) char smem[SB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
   int tile_x, tile_y;
   {
@@ -95,6 +96,42 @@ __global__ __launch_bounds__(NT, WGS) void k(const unsigned short* A16, const un
     }
     cur = cur == NS - 1 ? 0 : cur + 1;
   }
+  if (EPI == 1 || EPI == 2 || EPI == 4) {
+    constexpr int CLD = BN + 4, C4 = BN / 4;
+    float* sm = reinterpret_cast<float*>(smem);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sm[(wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * CLD + wn * (BN / 2) + j * 32 + r] = acc[i][j][e];
+    __syncthreads();
+    float4 keep = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < BM * C4 / NT; ++u) {
+      const int idx = tid + u * NT, lr = idx / C4, c4 = idx % C4;
+      const float4 v = *reinterpret_cast<const float4*>(sm + lr * CLD + c4 * 4);
+      if (EPI == 2) {
+        typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+        b4 o; o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+        *reinterpret_cast<b4*>(C16 + (long long)(m0 + lr) * N + n0 + c4 * 4) = o;
+      } else if (EPI == 4) *reinterpret_cast<float4*>(C32 + (long long)(m0 + lr) * N + n0 + c4 * 4) = v;
+      else { keep.x += v.x; keep.y += v.y; keep.z += v.z; keep.w += v.w; }
+    }
+    if (keep.x + keep.y + keep.z + keep.w == 12345.678f) out[tid] = keep.x;
+    return;
+  }
+  if (EPI == 3) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          reinterpret_cast<__bf16*>(C16)[(long long)(m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * N + n0 + wn * (BN / 2) + j * 32 + r] = (__bf16)acc[i][j][e];
+    return;
+  }
   float sum = (float)(x[0] ^ x[1] ^ x[2] ^ x[3]);
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -104,14 +141,15 @@ __global__ __launch_bounds__(NT, WGS) void k(const unsigned short* A16, const un
       for (int e = 0; e < 16; ++e) sum += acc[i][j][e];
   if (sum == 12345.678f) out[tid] = sum;
 }
-template <int BM, int BN, int NS, int MODE, int WGS>
+unsigned short* g_c16; float* g_c32;
+template <int BM, int BN, int NS, int MODE, int WGS, int EPI = 0>
 void run(const char* name, std::vector<unsigned short*>& A, unsigned short* B, float* out, int M, int N, int K) {
   dim3 grid(N / BN, M / BM), block(NT);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int i = 0; i < 6; ++i) hipLaunchKernelGGL((k<BM, BN, NS, MODE, WGS>), grid, block, 0, 0, A[i % A.size()], B, out, M, N, K);
+  for (int i = 0; i < 6; ++i) hipLaunchKernelGGL((k<BM, BN, NS, MODE, WGS, EPI>), grid, block, 0, 0, A[i % A.size()], B, out, M, N, K, g_c16, g_c32);
   hipEventRecord(e0);
   const int it = 30;
-  for (int i = 0; i < it; ++i) hipLaunchKernelGGL((k<BM, BN, NS, MODE, WGS>), grid, block, 0, 0, A[i % A.size()], B, out, M, N, K);
+  for (int i = 0; i < it; ++i) hipLaunchKernelGGL((k<BM, BN, NS, MODE, WGS, EPI>), grid, block, 0, 0, A[i % A.size()], B, out, M, N, K, g_c16, g_c32);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   const double fill = (double)(M / BM) * (N / BN) * (K / 64) * (BM + BN) * 128.0;
@@ -122,6 +160,7 @@ int main() {
   std::vector<unsigned short*> A(6); unsigned short* B; float* out;
   for (auto& a : A) { hipMalloc(&a, (size_t)M * K * 2); hipMemset(a, 0x3c, (size_t)M * K * 2); }
   hipMalloc(&B, (size_t)N * K * 2); hipMemset(B, 0x3c, (size_t)N * K * 2); hipMalloc(&out, 4096);
+  hipMalloc(&g_c16, (size_t)M * N * 2); hipMalloc(&g_c32, (size_t)M * N * 4);
   printf("[40960, 512, 512] bf16 NN loop, parts (1 = DMA, 3 = + fragment reads, 7 = + MFMA)\n");
   run<128, 128, 3, 1, 1>("128x128 NS3 1/CU  DMA only", A, B, out, M, N, K);
   run<128, 128, 3, 3, 1>("128x128 NS3 1/CU  DMA + reads", A, B, out, M, N, K);
@@ -133,5 +172,11 @@ int main() {
   run<128, 64, 2, 7, 3>("128x64 NS2 3/CU  DMA + reads + MFMA", A, B, out, M, N, K);
   run<64, 64, 2, 1, 4>("64x64 NS2 4/CU  DMA only", A, B, out, M, N, K);
   run<64, 64, 2, 7, 4>("64x64 NS2 4/CU  DMA + reads + MFMA", A, B, out, M, N, K);
+  printf("epilogue forms behind the full 128x128 NS2 2/CU loop\n");
+  run<128, 128, 2, 7, 2, 1>("  + LDS transposition, no store", A, B, out, M, N, K);
+  run<128, 128, 2, 7, 2, 2>("  + LDS transposition + bf16 row stores", A, B, out, M, N, K);
+  run<128, 128, 2, 7, 2, 4>("  + LDS transposition + f32 row stores", A, B, out, M, N, K);
+  run<128, 128, 2, 7, 2, 3>("  + direct 2-byte column stores", A, B, out, M, N, K);
+  run<128, 128, 2, 1, 2, 2>("  DMA only + transposition + bf16 row stores", A, B, out, M, N, K);
   return 0;
 }
