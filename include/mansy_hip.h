@@ -431,10 +431,13 @@ int mansy_gemm_planes(const float* A, int lda, const float* B, int ldb, int b_km
  *     goes to C (fp32, nullable) and / or C16 (bf16 image of the final value, nullable);
  *   a_kmajor = b_kmajor = 1: C[M, N] += A16[K, M]^T * B16[K, N] (weight gradient dW = dY^T X over the K rows of two activation slabs, split-K with
  *     atomic accumulation; ep->accumulate must be set, ep->a_rowsum as in mansy_gemm_f32).
+ * resid16 / mask16 (forward form, nullable): bf16 images of the residual / the mask source, read INSTEAD of ep->resid / ep->mask_src with the same leading
+ * dimensions ep->resid_ld / ep->mask_ld (the bf16-storage mode's residual streams and ReLU masks are bf16 images: csrc/vp_engine.hip).
+ * force_tile: 0 = by shape; 64, 96 (128 x 64), 128.
  * K % 64 == 0, 16-byte aligned operands, leading dimensions % 8 == 0.  The reference's analogue: torch.set_float32_matmul_precision('high')
  * (viewport_prediction/run_models.py:135). */
 int mansy_gemm_bf16(const uint16_t* A16, int lda, int a_kmajor, const uint16_t* B16, int ldb, int b_kmajor, float* C, int ldc, uint16_t* C16, int ldc16,
-                    int M, int N, int K, const mansy_gemm_epilogue* ep, int force_tile, int force_splitk, void* stream);
+                    int M, int N, int K, const mansy_gemm_epilogue* ep, const uint16_t* resid16, const uint16_t* mask16, int force_tile, int force_splitk, void* stream);
 typedef struct mansy_attn_shape {
   int nb, H, Lq, Lk, dh;
   long long q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;

@@ -93,7 +93,7 @@ _PROTOS = {
     'mansy_gemm_f32': [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, P, c_int, c_int, P],
     'mansy_weight_planes': [P, c_int, c_int, P, P, c_ll, c_int, P],
     'mansy_gemm_planes': [P, c_int, P, c_int, c_int, P, c_ll, c_int, P, c_int, c_int, c_int, c_int, P, c_int, P],
-    'mansy_gemm_bf16': [P, c_int, c_int, P, c_int, c_int, P, c_int, P, c_int, c_int, c_int, c_int, P, c_int, c_int, P],
+    'mansy_gemm_bf16': [P, c_int, c_int, P, c_int, c_int, P, c_int, P, c_int, c_int, c_int, c_int, P, P, P, c_int, c_int, P],
     'mansy_attn_fwd': [P, P, P, P, P, P, c_float, c_u32, c_u32, P],
     'mansy_attn_bwd': [P, P, P, P, P, P, P, P, P, c_float, c_u32, c_u32, c_int, P],
     'mansy_layernorm_fwd': [P, P, P, P, P, P, P, P, c_int, c_int, c_float, P],

@@ -66,7 +66,7 @@ int mansy_gemm_planes(const float* A, int lda, const float* B, int ldb, int b_km
 }
 
 int mansy_gemm_bf16(const uint16_t* A16, int lda, int a_kmajor, const uint16_t* B16, int ldb, int b_kmajor, float* C, int ldc, uint16_t* C16, int ldc16,
-                    int M, int N, int K, const mansy_gemm_epilogue* ep, int force_tile, int force_splitk, void* stream) {
+                    int M, int N, int K, const mansy_gemm_epilogue* ep, const uint16_t* resid16, const uint16_t* mask16, int force_tile, int force_splitk, void* stream) {
   GemmEpilogue e;
   if (ep) {
     e.bias = ep->bias; e.relu = ep->relu; e.mask_src = ep->mask_src; e.mask_ld = ep->mask_ld; e.mask_scale = ep->mask_scale;
@@ -74,6 +74,9 @@ int mansy_gemm_bf16(const uint16_t* A16, int lda, int a_kmajor, const uint16_t* 
     e.resid = ep->resid; e.resid_ld = ep->resid_ld; e.accumulate = ep->accumulate; e.a_rowsum = ep->a_rowsum;
   }
   MANSY_REQUIRE(A16 && B16, "gemm_bf16: null operand");
+  MANSY_REQUIRE((!resid16 && !mask16) || (ep && !a_kmajor), "gemm_bf16: resid16 / mask16 belong to the forward form and take their leading dimensions from ep");
+  if (resid16) { MANSY_REQUIRE((reinterpret_cast<uintptr_t>(resid16) & 7) == 0 && ep->resid_ld % 4 == 0, "gemm_bf16: resid16 must be 8-byte aligned, resid_ld %% 4 == 0"); e.resid16 = resid16; e.resid = nullptr; }
+  if (mask16) { MANSY_REQUIRE((reinterpret_cast<uintptr_t>(mask16) & 7) == 0 && ep->mask_ld % 4 == 0, "gemm_bf16: mask16 must be 8-byte aligned, mask_ld %% 4 == 0"); e.mask16 = mask16; e.mask_src = nullptr; }
   MANSY_REQUIRE(force_tile == 0 || force_tile == 64 || force_tile == 96 || force_tile == 128, "gemm_bf16: force_tile must be 0, 64, 96 (128x64) or 128");
   e.prec = 1; e.a16 = A16; e.a16_ld = lda; e.c16 = C16; e.c16_ld = ldc16;
   if (a_kmajor && b_kmajor) { e.b16 = B16; e.b16_ld = ldb; }

@@ -354,7 +354,9 @@ int mansy_gemm_bf16a_nn(const GemmParams& p, int tile, hipStream_t st) {
   dim3 block(NT);
   // TWO-stage rings: what bounds these loops is how many workgroups a CU holds (each one's cold first fetch, epilogue and store drain overlap the others' K
   // loops), not how deep one workgroup prefetches -- profiles/r06_gemm_bf16a_lab.txt: 128 x 128 with 2 stages (2 per CU) 47 us on [40960, 512, 512] against
-  // 57 with 3 stages (1 per CU) and 60 with 4; tools/fill_probe.hip: the K loop alone is 26 us of it
+  // 57 with 3 stages (1 per CU) and 60 with 4; tools/fill_probe.hip: the K loop alone is 20-26 us of it, the 42 MB of stores 15 us, nothing overlapped.
+  // (Round 6 also tried PERSISTENT workgroups for these shapes -- two per CU walking tile lists, the next tile's first K-tile in flight under the epilogue,
+  // staggered starts: 10-14 % faster launch by launch on rotating buffers (profiles/r06_gemm_bf16a_nnp_lab.txt), nothing in the step; not kept.)
   if (tile == 128) { dim3 grid(mansy_ceil_div(p.N, 128), mansy_ceil_div(p.M, 128), 1); MANSY_GEMM_LAUNCH((gemm_bf16a_nn_kernel<128, 128, 2>), grid, block, st, p); }
   else if (tile == 96) { dim3 grid(mansy_ceil_div(p.N, 64), mansy_ceil_div(p.M, 128), 1); MANSY_GEMM_LAUNCH((gemm_bf16a_nn_kernel<128, 64, 2>), grid, block, st, p); }
   else { dim3 grid(mansy_ceil_div(p.N, 64), mansy_ceil_div(p.M, 64), 1); MANSY_GEMM_LAUNCH((gemm_bf16a_nn_kernel<64, 64, 3>), grid, block, st, p); }

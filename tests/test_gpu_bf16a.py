@@ -25,7 +25,8 @@ def _bf(x):
 
 
 @pytest.mark.parametrize('M,N,K,tile', [(4096, 512, 512, 0), (4096, 512, 512, 64), (4096, 512, 512, 96), (4096, 512, 512, 128), (4096, 1536, 512, 0),
-                                        (1000, 512, 512, 0), (1000, 192, 64, 64), (160, 64, 192, 0), (40960, 512, 512, 0), (20480, 1024, 512, 0)])
+                                        (1000, 512, 512, 0), (1000, 192, 64, 64), (160, 64, 192, 0), (40960, 512, 512, 0), (20480, 1024, 512, 0),
+                                        (40960, 512, 512, 128), (40000 + 72, 1536, 512, 128), (33000, 200, 1536, 0)])      # (ragged last row panel / column tile)
 def test_forward_form_vs_torch(L, M, N, K, tile):
     g = torch.Generator(device='cpu').manual_seed(M + N + K)
     A = _bf(torch.randn(M, K, generator=g)).cuda()
@@ -34,15 +35,16 @@ def test_forward_form_vs_torch(L, M, N, K, tile):
     C = torch.full((M, N), float('nan'), device='cuda')
     C16 = torch.zeros(M, N, dtype=torch.bfloat16, device='cuda')
     ep = L.GemmEpilogue()
-    L.check(L.lib().mansy_gemm_bf16(L.ptr(A), K, 0, L.ptr(W), K, 0, L.ptr(C), N, L.ptr(C16), N, M, N, K, ctypes.byref(ep), tile, 0, L.stream_ptr()), 'gemm_bf16')
+    L.check(L.lib().mansy_gemm_bf16(L.ptr(A), K, 0, L.ptr(W), K, 0, L.ptr(C), N, L.ptr(C16), N, M, N, K, ctypes.byref(ep), None, None, tile, 0, L.stream_ptr()), 'gemm_bf16')
     torch.cuda.synchronize()
     scale = float(want.abs().max())
     assert float((C - want).abs().max()) <= 2e-6 * scale + 1e-6
     assert torch.equal(C16, C.to(torch.bfloat16))                                   # the bf16 image is the rounded final value
 
 
-def test_forward_form_fused_epilogue_and_bf16_only_output(L):
-    M, N, K = 4096, 512, 512
+@pytest.mark.parametrize('M,tile', [(4096, 0), (40960, 128), (40960 - 56, 96)])
+def test_forward_form_fused_epilogue_and_bf16_only_output(L, M, tile):
+    N, K = 512, 512
     g = torch.Generator(device='cpu').manual_seed(3)
     A = _bf(torch.randn(M, K, generator=g)).cuda()
     W = _bf(torch.randn(N, K, generator=g) * 0.05).cuda()
@@ -63,10 +65,33 @@ def test_forward_form_fused_epilogue_and_bf16_only_output(L):
             ep.mask_src, ep.mask_ld, ep.mask_scale = L.ptr(mask), N, 1.25
             want = torch.where(mask > 0, base * 1.25, torch.zeros_like(base))
         C16 = torch.zeros(M, N, dtype=torch.bfloat16, device='cuda')
-        L.check(L.lib().mansy_gemm_bf16(L.ptr(A), K, 0, L.ptr(W), K, 0, None, N, L.ptr(C16), N, M, N, K, ctypes.byref(ep), 0, 0, L.stream_ptr()), 'gemm_bf16')
+        r16 = m16 = None
+        if tile:                  # the residual / the mask source as bf16 images (as the engine's bf16-storage mode keeps them)
+            resid16, mask16 = _bf(resid), _bf(mask)
+            if kind == 'resid':
+                r16, ep.resid, want = L.ptr(resid16), None, base + resid16.float()
+            if kind == 'mask':
+                m16, ep.mask_src = L.ptr(mask16), None
+                want = torch.where(mask16.float() > 0, base * 1.25, torch.zeros_like(base))
+        L.check(L.lib().mansy_gemm_bf16(L.ptr(A), K, 0, L.ptr(W), K, 0, None, N, L.ptr(C16), N, M, N, K, ctypes.byref(ep), r16, m16, tile, 0, L.stream_ptr()), 'gemm_bf16')
         torch.cuda.synchronize()
         err = (C16.float() - want).abs().max().item()
         assert err <= 2 ** -8 * float(want.abs().max()) + 1e-6, (kind, err)              # one bf16 rounding of the output
+    if tile:
+        # two tile shapes on the same operands and images: the same arithmetic in the same order, bit for bit (dropout on: the mask is a function of the
+        # element's index, not of the workgroup that draws it); in-place residual (C16 aliases resid16)
+        ep = L.GemmEpilogue()
+        ep.bias, ep.drop_p, ep.drop_seed, ep.drop_site, ep.resid_ld, ep.mask_ld, ep.mask_scale = L.ptr(bias), 0.1, 77, 5, N, N, 0.5
+        outs = []
+        for t in (128, 64):
+            z16 = _bf(resid).clone()
+            Cf = torch.zeros(M, N, device='cuda')
+            L.check(L.lib().mansy_gemm_bf16(L.ptr(A), K, 0, L.ptr(W), K, 0, L.ptr(Cf), N, L.ptr(z16), N, M, N, K, ctypes.byref(ep), L.ptr(z16), L.ptr(_bf(mask)), t, 0,
+                                            L.stream_ptr()), 'gemm_bf16')
+            torch.cuda.synchronize()
+            outs.append((Cf, z16))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        assert 0.4 < float((outs[1][0] == _bf(resid).float()).float().mean()) < 0.7          # masked (~50 %) or dropped (10 %) elements: the residual alone
 
 
 @pytest.mark.parametrize('tile', [0, 64])      # 0: by shape (eight-wave workgroups with two K groups when the reduce dimension allows); 64: the four-wave kernel
@@ -84,7 +109,7 @@ def test_weight_gradient_form_vs_torch(L, M, N, K, splits, tile):
     ep = L.GemmEpilogue()
     ep.accumulate = 1
     ep.a_rowsum = L.ptr(rs)
-    L.check(L.lib().mansy_gemm_bf16(L.ptr(dY), M, 1, L.ptr(X), N, 1, L.ptr(C), N, None, 0, M, N, K, ctypes.byref(ep), tile, splits, L.stream_ptr()), 'gemm_bf16')
+    L.check(L.lib().mansy_gemm_bf16(L.ptr(dY), M, 1, L.ptr(X), N, 1, L.ptr(C), N, None, 0, M, N, K, ctypes.byref(ep), None, None, tile, splits, L.stream_ptr()), 'gemm_bf16')
     torch.cuda.synchronize()
     scale = float(want.abs().max())
     assert float((C - C0 - want).abs().max()) <= 2e-5 * scale + 1e-5, float((C - C0 - want).abs().max())      # K up to 40 960 fp32 additions in another order (split-K atomics)

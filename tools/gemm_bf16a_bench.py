@@ -34,7 +34,7 @@ def nn(M, N, K, tile=0, out='f32'):
     def f(i):
         k = i % NSET
         L.check(lib.mansy_gemm_bf16(L.ptr(A[k]), K, 0, L.ptr(W), K, 0, L.ptr(C[k]) if out != 'bf16' else None, N, L.ptr(C16[k]) if out != 'f32' else None, N,
-                                    M, N, K, ctypes.byref(ep), tile, 0, st))
+                                    M, N, K, ctypes.byref(ep), None, None, tile, 0, st))
     return timeit(f)
 
 
@@ -67,7 +67,7 @@ def tn(M, N, K, splits=0):
 
     def f(i):
         k = i % NSET
-        L.check(lib.mansy_gemm_bf16(L.ptr(dY[k]), M, 1, L.ptr(X[k]), N, 1, L.ptr(C), N, None, 0, M, N, K, ctypes.byref(ep), 0, splits, st))
+        L.check(lib.mansy_gemm_bf16(L.ptr(dY[k]), M, 1, L.ptr(X[k]), N, 1, L.ptr(C), N, None, 0, M, N, K, ctypes.byref(ep), None, None, 0, splits, st))
     return timeit(f, 30)
 
 
