@@ -223,6 +223,40 @@ def _ppo_policy(dev, rank=0, precision=None):
     return pol
 
 
+PPO_BLOCKS = 5      # a PPO leg = the MEDIAN of this many timed blocks of `cycles` cycles (6 cycles are 11 ms: one 1-ms hiccup of the host thread moved a single-block figure by 10 %)
+
+
+def _timed_blocks(cycle, cycles, blocks=PPO_BLOCKS, barrier=None):
+    """`blocks` back-to-back timed blocks of `cycles` calls of cycle(), each bracketed by a device sync (and `barrier()`), Python's collector off.  Returns
+    ([(wall s, host-enqueue s)] per block, last result).  The host never gets a whole block ahead of the device, so the ring of pinned staging buffers of the
+    graph-replayed update never makes it wait."""
+    import gc
+    import torch
+    gc.collect()
+    out, res = [], None
+    gc.disable()
+    try:
+        for _ in range(blocks):
+            if barrier:
+                barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(cycles):
+                res = cycle()
+            t_host = time.perf_counter() - t0      # the host has enqueued everything (it runs ahead of the GPU unless the cycle is host-bound)
+            torch.cuda.synchronize()
+            if barrier:
+                barrier()
+            out.append((time.perf_counter() - t0, t_host))
+    finally:
+        gc.enable()
+    return out, res
+
+
+def _median_block(blocks):
+    return sorted(blocks)[len(blocks) // 2]
+
+
 def _ppo_cycle_time(pol, dev, cycles, warmup, n_env=256, steps_per_env=16, qoe_weights=QOE_TRAIN, seed=5, tables=None):
     """(ms per cycle, library launches per cycle incl. the rollout graph's) of collect -> train_identifier (2 rounds) -> relabel + PPO update."""
     import torch
@@ -243,21 +277,11 @@ def _ppo_cycle_time(pol, dev, cycles, warmup, n_env=256, steps_per_env=16, qoe_w
         cycle()
     # Python's cyclic collector must not run inside the timed cycles: the previous leg's policy (an nn.Module: reference cycles) holds captured hipGraphs and
     # their memory pools, and tearing those down costs tens of ms whenever the collector happens to fire (seen as one 25-70 ms cycle in a leg of six)
-    import gc
-    gc.collect()
-    torch.cuda.synchronize()
-    gc.disable()
-    try:
-        n0 = lib().mansy_prof_launch_count() + pol.graph_launches
-        t0 = time.perf_counter()
-        for _ in range(cycles):
-            res = cycle()
-        n1 = lib().mansy_prof_launch_count() + pol.graph_launches      # direct launches + the ones the update half's graph replays re-ran
-        t_host = time.perf_counter() - t0           # the host has enqueued everything (it runs ahead of the GPU unless the cycle is host-bound)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-    finally:
-        gc.enable()
+    n0 = lib().mansy_prof_launch_count() + pol.graph_launches
+    blocks, res = _timed_blocks(cycle, cycles)
+    n1 = lib().mansy_prof_launch_count() + pol.graph_launches      # direct launches + the ones the update half's graph replays re-ran
+    dt, t_host = _median_block(blocks)
+    n1 = n0 + (n1 - n0) / float(len(blocks))
     import numpy as np
     loss = float(np.mean(res['loss']))
     _ppo_cycle_time.host_ms = t_host / cycles * 1e3
@@ -273,7 +297,7 @@ def bench_ppo_dp_form(dev, mdist, cycles=6, warmup=2, vp_leg=None):
     import torch
     import torch.distributed as dist
     out = {'workload': '256 envs x 16 steps, identifier 2 rounds + relabel + PPO update (minibatch 512, repeat 2): 16 + 2 gradient averages per cycle',
-           'cycles': cycles}
+           'cycles': cycles, 'timing': 'median of %d blocks of %d cycles' % (PPO_BLOCKS, cycles)}
     ms, nl, _ = _ppo_cycle_time(_ppo_policy(dev), dev, cycles, warmup)
     out['fused'] = {'ms_per_cycle': round(ms, 3), 'library_launches_per_cycle': round(nl, 1), 'host_enqueue_ms_per_cycle': round(_ppo_cycle_time.host_ms, 3),
                     'update_graph_replays': _ppo_cycle_time.graph_replays}
@@ -495,35 +519,27 @@ def bench_ppo(rank, world, dev, mdist, cycles=5, warmup=2, n_env=256, steps_per_
         return pol.update(0, buf, is_train=True, batch_size=512, repeat=2)
     for _ in range(warmup):
         cycle()
-    import gc
-    gc.collect()                  # (the cyclic collector must not tear down an earlier leg's graphs / pools inside the timed cycles: see _ppo_cycle_time)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
     from mansy_immersivevideostreaming_amd._lib import lib
-    gc.disable()
     launches0 = lib().mansy_prof_launch_count() + pol.graph_launches
-    t0 = time.perf_counter()
-    for _ in range(cycles):
-        res = cycle()
-    launches1 = lib().mansy_prof_launch_count() + pol.graph_launches      # (the update half replays captured graphs from the third cycle on)
-    t_host = time.perf_counter() - t0
-    torch.cuda.synchronize()
-    gc.enable()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+    blocks, res = _timed_blocks(cycle, cycles, barrier=dist.barrier if world > 1 else None)      # (the update half replays captured graphs from the third cycle on)
+    launches1 = lib().mansy_prof_launch_count() + pol.graph_launches
+    launches1 = launches0 + (launches1 - launches0) / float(len(blocks))
+    if world > 1:          # a block's time = the slowest rank's; then the median block
+        tb = torch.tensor([b[0] for b in blocks], device=dev, dtype=torch.float64)
+        dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+        order = sorted(range(len(blocks)), key=lambda i: float(tb[i]))[len(blocks) // 2]
+        dt_max, (dt, t_host) = float(tb[order]), blocks[order]
+    else:
+        dt, t_host = _median_block(blocks)
     per_rank = None
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
         # every rank's own view: cycle time to its last sync and the time its host needed to ENQUEUE the cycles (a straggling enqueue thread
         # is what every other rank's peer kernel then waits for)
         mine = torch.tensor([dt / cycles * 1e3, t_host / cycles * 1e3], device=dev, dtype=torch.float64)
         allv = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allv, mine)
         per_rank = {'ms_per_cycle': [round(float(v[0]), 3) for v in allv], 'host_enqueue_ms_per_cycle': [round(float(v[1]), 3) for v in allv]}
-        dt = t.item()
+        dt = dt_max
     # the cycle in its data-parallel FORM on a ONE-rank peer context, on every rank at once (no wire, no waiting for anyone): what is left of the
     # N-rank cycle after subtracting it is the wire + skew term w of DESIGN section 6, per average
     wire = None
@@ -597,6 +613,7 @@ def bench_ppo(rank, world, dev, mdist, cycles=5, warmup=2, n_env=256, steps_per_
             ps.check()                       # a timed-out wait would have poisoned the gradients with NaN: fail loudly
     spread = max(replica_spread(pol.engine.ac.flat_p, world), replica_spread(pol.engine.idn.flat_p, world))
     return {'metric': 'PPO env-steps/sec', 'value': round(steps / dt, 1), 'unit': 'env-steps/s', 'n_gpus': world, 'cycles': cycles,
+            'timing': 'median of %d timed blocks of %d cycles each (a block = barrier + sync, cycles, sync + barrier; max over ranks per block)' % (PPO_BLOCKS, cycles),
             'replica_param_spread': spread, 'env_shards': shards, 'envs_per_gpu': n_env,
             'grad_sync': sync_desc, 'grad_sync_report': rep, 'per_rank': per_rank, 'wire_term': wire,
             'update_half': ('hipGraph replay' if pol.graph_replays else 'direct launches') + f' ({pol.graph_replays} replays so far)',
