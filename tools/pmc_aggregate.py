@@ -30,7 +30,7 @@ suffix = sys.argv[4] if len(sys.argv) > 4 else ''                   # file name 
 fetch, n = total('pmc_r', 'FETCH_SIZE')
 write, n2 = total('pmc_w', 'WRITE_SIZE')
 assert n == n2 and n > 0, (n, n2)
-out = {'kernel': 'gemm_f32_dma_kernel / gemm_f32_kernel' if KERNEL == 'gemm_f32' else 'gemm_bf16s_kernel / gemm_bf16p_kernel', 'launches': n, 'fetch_bytes_per_launch': 2.0 * fetch / n, 'write_bytes_per_launch': write / n,
+out = {'kernel': 'gemm_f32_dma_kernel / gemm_f32_kernel' if KERNEL == 'gemm_f32' else ('gemm_bf16a_nn_kernel / gemm_bf16a_tn_kernel (bf16-storage products)' if suffix == '_bf16' else 'gemm_bf16s_kernel / gemm_bf16p_kernel'), 'launches': n, 'fetch_bytes_per_launch': 2.0 * fetch / n, 'write_bytes_per_launch': write / n,
        'traffic_bytes_per_launch': (2.0 * fetch + write) / n, 'algorithmic_bytes_per_launch': alg,
        'gemm_source_digest': build_ext.gemm_source_digest(),      # bench.py flags the figure as stale when the kernels have changed since
        'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over 2 train steps (B=4096, 285 GEMM launches per step); '
