@@ -41,8 +41,10 @@ __global__ __launch_bounds__(NT, WGS) void k(const unsigned short* A16, const un
     const unsigned base = lds0 + (unsigned)(stage * STAGE_BYTES);
 #pragma unroll
     for (int i = 0; i < PA; ++i) glds16(voa[i], ca + (long long)kt * BK16, base + (unsigned)i * 4096u);
+    if (!(MODE & 8)) {
 #pragma unroll
     for (int i = 0; i < PB; ++i) glds16(vob[i], cb + (long long)kt * BK16, base + (unsigned)A_BYTES + (unsigned)i * 4096u);
+    }
   };
   int fa[TM][4], fb[TN][4];
 #pragma unroll
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(NT, WGS) void k(const unsigned short* A16, const un
     }
     cur = cur == NS - 1 ? 0 : cur + 1;
   }
-  if (EPI == 1 || EPI == 2 || EPI == 4) {
+  if (EPI == 1 || EPI == 2 || EPI == 4 || EPI == 5 || EPI == 6) {
     constexpr int CLD = BN + 4, C4 = BN / 4;
     float* sm = reinterpret_cast<float*>(smem);
     __syncthreads();
@@ -112,10 +114,13 @@ __global__ __launch_bounds__(NT, WGS) void k(const unsigned short* A16, const un
     for (int u = 0; u < BM * C4 / NT; ++u) {
       const int idx = tid + u * NT, lr = idx / C4, c4 = idx % C4;
       const float4 v = *reinterpret_cast<const float4*>(sm + lr * CLD + c4 * 4);
-      if (EPI == 2) {
+      if (EPI == 2 || EPI == 5 || EPI == 6) {
         typedef __bf16 b4 __attribute__((ext_vector_type(4)));
         b4 o; o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
-        *reinterpret_cast<b4*>(C16 + (long long)(m0 + lr) * N + n0 + c4 * 4) = o;
+        b4* dst = reinterpret_cast<b4*>(C16 + (long long)(m0 + lr) * N + n0 + c4 * 4);
+        if (EPI == 5) __builtin_nontemporal_store(o, dst);
+        else if (EPI == 6) { unsigned long long bits = __builtin_bit_cast(unsigned long long, o); asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" :: "v"(dst), "v"(bits) : "memory"); }
+        else *dst = o;
       } else if (EPI == 4) *reinterpret_cast<float4*>(C32 + (long long)(m0 + lr) * N + n0 + c4 * 4) = v;
       else { keep.x += v.x; keep.y += v.y; keep.z += v.z; keep.w += v.w; }
     }
@@ -142,6 +147,72 @@ __global__ __launch_bounds__(NT, WGS) void k(const unsigned short* A16, const un
   if (sum == 12345.678f) out[tid] = sum;
 }
 unsigned short* g_c16; float* g_c32;
+// Row-panel reads: a workgroup fetches ROWS whole rows of A (K bf16 = 1 KB each, contiguous) in one go -- the HBM-side access pattern of a loop that keeps a whole
+// [rows, K] panel in LDS, against the K-tiled pattern above (128-byte pieces of the rows, eight visits per row).  DMA only.
+template <int ROWS>
+__global__ __launch_bounds__(NT, 2) void rowpanel(const unsigned short* A16, float* out, int K) {
+  __shared__ __attribute__((aligned(1024))) char smem[ROWS * 1024];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned short* base = A16 + (long long)blockIdx.x * ROWS * K;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
+#pragma unroll
+  for (int i = 0; i < ROWS / 4; ++i) {          // wave w: rows w, w + 4, ...: one instruction = one whole 1 KB row
+    const int row = i * 4 + wave;
+    glds16((unsigned)(lane * 16 + row * K * 2), base, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)row * 1024u));
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (reinterpret_cast<float*>(smem)[tid] == 12345.678f) out[tid] = 1.f;
+}
+// Stores only: 42 MB of bf16 output written (a) as 128 x 128 tiles (256-byte row pieces at a 1 KB row stride: what the product's epilogue does) and (b) as whole
+// 1 KB rows (what a workgroup owning [rows, N] would do).  8 bytes per lane either way.
+template <int FORM>
+__global__ __launch_bounds__(NT, 2) void stores(unsigned short* C16, int M, int N) {
+  typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+  b4 o; o[0] = (__bf16)1.f; o[1] = (__bf16)2.f; o[2] = (__bf16)3.f; o[3] = (__bf16)4.f;
+  const int tid = threadIdx.x;
+  if (FORM == 0) {          // blockIdx.x = tile (4 column tiles per row panel): thread -> 16 positions of the tile
+    const int ty = blockIdx.x >> 2, tx = blockIdx.x & 3;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int idx = tid + u * NT, lr = idx >> 5, c4 = idx & 31;
+      *reinterpret_cast<b4*>(C16 + (long long)(ty * 128 + lr) * N + tx * 128 + c4 * 4) = o;
+    }
+  } else {                  // blockIdx.x = 32 whole rows: thread -> 16 positions, a wave instruction = half a row (512 B contiguous), a workgroup instruction = 2 rows
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int idx = tid + u * NT, lr = idx >> 7, c4 = idx & 127;
+      *reinterpret_cast<b4*>(C16 + (long long)(blockIdx.x * 32 + lr) * N + c4 * 4) = o;
+    }
+  }
+}
+template <int FORM>
+void run_stores(const char* name, int M, int N) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  std::vector<unsigned short*> C(6);
+  for (auto& c : C) hipMalloc(&c, (size_t)M * N * 2);
+  for (int i = 0; i < 6; ++i) hipLaunchKernelGGL((stores<FORM>), dim3(M / 32), dim3(NT), 0, 0, C[i % 6], M, N);
+  hipEventRecord(e0);
+  const int it = 30;
+  for (int i = 0; i < it; ++i) hipLaunchKernelGGL((stores<FORM>), dim3(M / 32), dim3(NT), 0, 0, C[i % 6], M, N);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  printf("%-44s %7.1f us   %5.2f TB/s written\n", name, ms / it * 1e3, (double)M * N * 2 / (ms / it * 1e-3) / 1e12);
+  for (auto& c : C) hipFree(c);
+}
+
+template <int ROWS>
+void run_rowpanel(const char* name, std::vector<unsigned short*>& A, float* out, int M, int K) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 6; ++i) hipLaunchKernelGGL((rowpanel<ROWS>), dim3(M / ROWS), dim3(NT), 0, 0, A[i % A.size()], out, K);
+  hipEventRecord(e0);
+  const int it = 30;
+  for (int i = 0; i < it; ++i) hipLaunchKernelGGL((rowpanel<ROWS>), dim3(M / ROWS), dim3(NT), 0, 0, A[i % A.size()], out, K);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  printf("%-44s %7.1f us   A from HBM %5.2f TB/s\n", name, ms / it * 1e3, (double)M * K * 2 / (ms / it * 1e-3) / 1e12);
+}
+
 template <int BM, int BN, int NS, int MODE, int WGS, int EPI = 0>
 void run(const char* name, std::vector<unsigned short*>& A, unsigned short* B, float* out, int M, int N, int K) {
   dim3 grid(N / BN, M / BM), block(NT);
@@ -172,9 +243,18 @@ int main() {
   run<128, 64, 2, 7, 3>("128x64 NS2 3/CU  DMA + reads + MFMA", A, B, out, M, N, K);
   run<64, 64, 2, 1, 4>("64x64 NS2 4/CU  DMA only", A, B, out, M, N, K);
   run<64, 64, 2, 7, 4>("64x64 NS2 4/CU  DMA + reads + MFMA", A, B, out, M, N, K);
+  printf("A only (42 MB per launch from HBM / Infinity Cache; the K-tiled pattern fetches every byte into 4 workgroups of one XCD)\n");
+  run<128, 128, 2, 9, 2>("128x128 NS2 2/CU  K-tiled, A pieces only", A, B, out, M, N, K);
+  run_rowpanel<64>("row panels of 64 whole rows (64 KB, 2/CU)", A, out, M, K);
+  run_rowpanel<32>("row panels of 32 whole rows (32 KB)", A, out, M, K);
+  printf("stores only, 42 MB of bf16 per launch\n");
+  run_stores<0>("as 128 x 128 tiles (256-byte row pieces)", M, N);
+  run_stores<1>("as whole 1 KB rows", M, N);
   printf("epilogue forms behind the full 128x128 NS2 2/CU loop\n");
   run<128, 128, 2, 7, 2, 1>("  + LDS transposition, no store", A, B, out, M, N, K);
   run<128, 128, 2, 7, 2, 2>("  + LDS transposition + bf16 row stores", A, B, out, M, N, K);
+  run<128, 128, 2, 7, 2, 5>("  + LDS transposition + bf16 row stores, nontemporal", A, B, out, M, N, K);
+  run<128, 128, 2, 7, 2, 6>("  + LDS transposition + bf16 row stores, sc0 sc1 (write-through)", A, B, out, M, N, K);
   run<128, 128, 2, 7, 2, 4>("  + LDS transposition + f32 row stores", A, B, out, M, N, K);
   run<128, 128, 2, 7, 2, 3>("  + direct 2-byte column stores", A, B, out, M, N, K);
   run<128, 128, 2, 1, 2, 2>("  DMA only + transposition + bf16 row stores", A, B, out, M, N, K);
