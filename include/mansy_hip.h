@@ -433,7 +433,8 @@ int mansy_gemm_planes(const float* A, int lda, const float* B, int ldb, int b_km
  *     atomic accumulation; ep->accumulate must be set, ep->a_rowsum as in mansy_gemm_f32).
  * resid16 / mask16 (forward form, nullable): bf16 images of the residual / the mask source, read INSTEAD of ep->resid / ep->mask_src with the same leading
  * dimensions ep->resid_ld / ep->mask_ld (the bf16-storage mode's residual streams and ReLU masks are bf16 images: csrc/vp_engine.hip).
- * force_tile: 0 = by shape; 64, 96 (128 x 64), 128.
+ * force_tile: 0 = by shape; forward form: 64, 96 (128 x 64), 128 = that tile; weight-gradient form: 64 = four-wave workgroups (two per CU) instead of the
+ * eight-wave ones with two K groups (same sums in another order).  force_splitk (weight-gradient form): number of K splits, 0 = by shape.
  * K % 64 == 0, 16-byte aligned operands, leading dimensions % 8 == 0.  The reference's analogue: torch.set_float32_matmul_precision('high')
  * (viewport_prediction/run_models.py:135). */
 int mansy_gemm_bf16(const uint16_t* A16, int lda, int a_kmajor, const uint16_t* B16, int ldb, int b_kmajor, float* C, int ldc, uint16_t* C16, int ldc16,

@@ -400,7 +400,7 @@ int launch_dma(const GemmParams& p, int a_kmajor, int b_kmajor, int splits, hipS
   if (BM == 64 && BN == 64 && p.ep.tile_list) grid = dim3(p.ep.tile_list_n, 1, splits);      // only the listed tiles
   dim3 block(NT);
   // the plain form (the decoder-step products on 64 x 64 tiles, the [40 960-row] forward / dX products on 128 x 64): its own instance (see the kernel).
-  // Measured on the VP step (tools/vp_knob_ab.py f32_wsk 14 15): 22.49 -> 22.34 ms with the 64 x 64 instance, -0.05 ms more with the 128 x 64 one
+  // Measured on the VP step (round 4's lab-build A/B): 22.49 -> 22.34 ms with the 64 x 64 instance, -0.05 ms more with the 128 x 64 one
   const bool plain_form = ((BM == 64 && BN == 64) || (BM == 128 && BN == 64)) && !mansy_var_no_plain(p.ep.variant) && !a_kmajor && splits == 1 && !p.A2 && !p.ep.tile_list && !p.ep.tile_nrange && !p.ep.tile_krange &&
                           !p.ep.a_rowsum && !p.ep.accumulate && p.ep.split_slab == 0 && p.c_vec_ok && !(p.col_group > 0 && (int)grid.x > p.col_group);
   if (plain_form) {

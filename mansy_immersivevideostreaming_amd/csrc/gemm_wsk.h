@@ -36,7 +36,7 @@ __device__ __forceinline__ void read_frag_dma(const float* __restrict__ lds, int
 // barrier inside the loop: a wave only reads what it staged itself, ordered by its own vmcnt; the next tile is requested as soon as the current one
 // sits in registers and flies under its MFMAs; 32 KB of LDS per workgroup, so five fit a CU), the four partial blocks are summed
 // through LDS in wave order (deterministic), then the shared row-major epilogue runs.  A K-contiguous; B K-contiguous or K-major.
-// Round 5 (tools/wsk_phase_lab.py, profiles/r05_wsk_phase_lab_two_stage.txt): inside a [32, 512, 512] launch a wave spends 0.44 us before its first DMA is out,
+// Round 5 (in-kernel phase stamps of the lab build, since deleted; profiles/r05_wsk_phase_lab_two_stage.txt): inside a [32, 512, 512] launch a wave spends 0.44 us before its first DMA is out,
 // 0.36 us until the tile has landed, 4 x 0.68 us on its K-tiles (16 dependent MFMAs ~0.47 us -- the block's 256 MFMAs are 1.7 us of the CU's four matrix pipes
 // however the waves are arranged --, fragment reads ~0.12, DMA issue ~0.13) and 0.44 us on the cross-wave sum and the epilogue.  A second stage per wave with the
 // fragment reads and the DMA issue interleaved BEHIND the MFMAs (built, bit-identical) made the K-tile no shorter (0.72 us: the dependent MFMA chain is the period)
