@@ -12,6 +12,7 @@ torch.manual_seed(5); random.seed(5); np.random.seed(5)
 dev = torch.device('cuda', 0)
 m = ViewportTransformerMTIO(in_channel=2, fut_window=10, d_model=512, dim_feedforward=512, device=dev).to(dev); m.train()
 opt = FusedAdamW(m, lr=1e-4)
+m.precision = os.environ.get('SOAK_PRECISION') or None          # e.g. bf16: the bf16-storage mode (round 6)
 sets = [tuple(t.to(dev) for t in bench.synthetic_trajectories(1024, 10, 10, seed=s)) for s in range(8)]
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
 losses = []
@@ -22,7 +23,7 @@ for i in range(steps):
     if i == 50:
         torch.cuda.synchronize(); mem0 = torch.cuda.memory_allocated()
 l = torch.stack(losses).cpu().numpy()
-print('VP steps', steps, 'loss first/last 50 mean', l[:50].mean(), l[-50:].mean(), 'finite', np.isfinite(l).all(),
+print('VP steps', steps, 'precision', m.precision, 'loss first/last 50 mean', l[:50].mean(), l[-50:].mean(), 'finite', np.isfinite(l).all(),
       'mem growth MB', (torch.cuda.memory_allocated() - mem0) / 1e6)
 m.eval()
 with torch.no_grad():
