@@ -146,7 +146,7 @@ __global__ __launch_bounds__(NT, WGS) void k(const unsigned short* A16, const un
       for (int e = 0; e < 16; ++e) sum += acc[i][j][e];
   if (sum == 12345.678f) out[tid] = sum;
 }
-unsigned short* g_c16; float* g_c32;
+unsigned short* g_c16; float* g_c32;      // (ONE output buffer for every launch: the non-temporal line below gains 30 % on it and NOTHING on rotating outputs -- tools/gemm_bf16a_bench.py with the same hint in the product's epilogue: 47.9 against 47.2 us)
 // Row-panel reads: a workgroup fetches ROWS whole rows of A (K bf16 = 1 KB each, contiguous) in one go -- the HBM-side access pattern of a loop that keeps a whole
 // [rows, K] panel in LDS, against the K-tiled pattern above (128-byte pieces of the rows, eight visits per row).  DMA only.
 template <int ROWS>
@@ -201,6 +201,43 @@ void run_stores(const char* name, int M, int N) {
   for (auto& c : C) hipFree(c);
 }
 
+// Row-panel reads AND whole-row stores in one launch (no MFMA): what a row-panel product would put on the memory system -- 42 MB in, 42 MB out.
+template <int ROWS>
+__global__ __launch_bounds__(NT, 2) void rowpanel_rw(const unsigned short* A16, unsigned short* C16, float* out, int K, int N) {
+  __shared__ __attribute__((aligned(1024))) char smem[ROWS * 1024];
+  typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned short* base = A16 + (long long)blockIdx.x * ROWS * K;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
+#pragma unroll
+  for (int i = 0; i < ROWS / 4; ++i) {
+    const int row = i * 4 + wave;
+    glds16((unsigned)(lane * 16 + row * K * 2), base, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)row * 1024u));
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < ROWS * 128 / NT; ++u) {      // the panel written back out as [ROWS, N = 512] bf16 rows, 8 bytes per lane
+    const int idx = tid + u * NT, lr = idx >> 7, c4 = idx & 127;
+    const b4 v = *reinterpret_cast<const b4*>(smem + lr * 1024 + c4 * 8);
+    *reinterpret_cast<b4*>(C16 + (long long)(blockIdx.x * ROWS + lr) * N + c4 * 4) = v;
+  }
+}
+template <int ROWS>
+void run_rowpanel_rw(const char* name, std::vector<unsigned short*>& A, float* out, int M, int K, int N) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  std::vector<unsigned short*> C(6);
+  for (auto& c : C) hipMalloc(&c, (size_t)M * N * 2);
+  for (int i = 0; i < 6; ++i) hipLaunchKernelGGL((rowpanel_rw<ROWS>), dim3(M / ROWS), dim3(NT), 0, 0, A[i % A.size()], C[i % 6], out, K, N);
+  hipEventRecord(e0);
+  const int it = 30;
+  for (int i = 0; i < it; ++i) hipLaunchKernelGGL((rowpanel_rw<ROWS>), dim3(M / ROWS), dim3(NT), 0, 0, A[i % A.size()], C[i % 6], out, K, N);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  printf("%-44s %7.1f us   %5.2f TB/s in + out\n", name, ms / it * 1e3, (double)M * (K + N) * 2 / (ms / it * 1e-3) / 1e12);
+  for (auto& c : C) hipFree(c);
+}
+
 template <int ROWS>
 void run_rowpanel(const char* name, std::vector<unsigned short*>& A, float* out, int M, int K) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -247,6 +284,8 @@ int main() {
   run<128, 128, 2, 9, 2>("128x128 NS2 2/CU  K-tiled, A pieces only", A, B, out, M, N, K);
   run_rowpanel<64>("row panels of 64 whole rows (64 KB, 2/CU)", A, out, M, K);
   run_rowpanel<32>("row panels of 32 whole rows (32 KB)", A, out, M, K);
+  run_rowpanel_rw<64>("row panels of 64 rows in, 64 rows out", A, out, M, K, N);
+  run_rowpanel_rw<32>("row panels of 32 rows in, 32 rows out", A, out, M, K, N);
   printf("stores only, 42 MB of bf16 per launch\n");
   run_stores<0>("as 128 x 128 tiles (256-byte row pieces)", M, N);
   run_stores<1>("as whole 1 KB rows", M, N);
