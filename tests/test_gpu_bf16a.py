@@ -114,3 +114,32 @@ def test_weight_gradient_form_vs_torch(L, M, N, K, splits, tile):
     scale = float(want.abs().max())
     assert float((C - C0 - want).abs().max()) <= 2e-5 * scale + 1e-5, float((C - C0 - want).abs().max())      # K up to 40 960 fp32 additions in another order (split-K atomics)
     assert float((rs - want_rs).abs().max()) <= 2e-5 * float(want_rs.abs().max()) + 1e-4
+
+
+def test_bf16_image_arguments_are_validated(L):
+    """include/mansy_hip.h: resid16 / mask16 belong to the forward form, take their leading dimensions from ep and must be 8-byte aligned; force_tile takes
+    0 / 64 / 96 / 128; the weight-gradient form needs an accumulating epilogue.  Every violation is an error return with a message, never a launch."""
+    M = N = K = 256
+    A = _bf(torch.randn(M, K)).cuda()
+    W = _bf(torch.randn(N, K)).cuda()
+    C = torch.zeros(M, N, device='cuda')
+    img = _bf(torch.randn(M, N + 8)).cuda()
+    lib, st = L.lib(), L.stream_ptr()
+
+    def call(ep, r16=None, m16=None, tile=0, ak=0, bk=0):
+        return lib.mansy_gemm_bf16(L.ptr(A), K, ak, L.ptr(W), K, bk, L.ptr(C), N, None, 0, M, N, K, ctypes.byref(ep) if ep is not None else None, r16, m16, tile, 0, st)
+    ep = L.GemmEpilogue()
+    ep.resid_ld = ep.mask_ld = N + 8
+    assert call(ep, L.ptr(img), L.ptr(img)) == 0                                    # (the well-formed call)
+    torch.cuda.synchronize()
+    assert call(None, L.ptr(img)) != 0                                               # an image without an epilogue to take its leading dimension from
+    assert call(ep, ctypes.c_void_p(img.data_ptr() + 2)) != 0 and b'8-byte' in lib.mansy_last_error()     # misaligned image
+    ep.resid_ld = N + 6
+    assert call(ep, L.ptr(img)) != 0                                                 # leading dimension % 4
+    ep.resid_ld = N + 8
+    assert call(ep, tile=256) != 0 and call(ep, tile=32) != 0                        # tile codes that do not exist
+    ep.accumulate = 1
+    assert call(ep, L.ptr(img), ak=1, bk=1) != 0                                     # images on the weight-gradient form
+    ep.accumulate = 0
+    assert call(ep, ak=1, bk=1) != 0                                                 # weight-gradient form without an accumulating epilogue
+    assert call(ep, ak=1, bk=0) != 0                                                 # mixed operand forms
