@@ -668,20 +668,35 @@ struct Eng {
       RC(flush_ln());      // here: the decoder-side gradients must be final before the hook below (which = 2) hands them to the all-reduce
     }
     // ---- deferred decoder weight gradients: one reduce-dim-(T*B) GEMM per weight
-    RC(mansy_launch_outer_reduce(W.dz_all, C6, W.dec_out, TB, d, P.pred.gw, 0, nullptr, P.pred.gb, st));
-    RC(mansy_launch_outer_reduce(W.tok_all, C6, W.dE_all, TB, d, P.emb.gw, 1, P.emb.gb, nullptr, st));
-    for (int l = 0; l < c.n_dec; ++l) {
+    // They are LEAVES of the backward (only the optimizer -- or, data parallel, the gradient hook below -- reads them), while the memory gradient, the
+    // DistillLayer and the encoder backward that follow are one dependent chain: with the two-stream schedule on and no hook to feed, the leaves go to the
+    // side stream and run beside that chain (their split-K atomics' tails and the chain's launch gaps fill each other); joined at the end of the backward.
+    // Every product still adds into a gradient buffer of its own, so nothing about the sums changes.
+    const bool side_dw = split && c.bn_sync_world <= 1;
+    if (side_dw) RC(fork());
+    {
+      hipStream_t keep = st;
+      if (side_dw) st = st2;
+      int rc = mansy_launch_outer_reduce(W.dz_all, C6, W.dec_out, TB, d, P.pred.gw, 0, nullptr, P.pred.gb, st);
+      if (!rc) rc = mansy_launch_outer_reduce(W.tok_all, C6, W.dE_all, TB, d, P.emb.gw, 1, P.emb.gb, nullptr, st);
+      for (int l = 0; l < c.n_dec && !rc; ++l) {
+        const DecLayerP& p = P.dec[l]; DecBuf& e = W.dec[l];
+        const float* x_all = l == 0 ? W.emb_all : W.dec[l - 1].y3;
+        rc = lin_dw(e.dqkv, x_all, TB, 3 * d, d, p.sa_in.gw, p.sa_in.gb);
+        if (!rc) rc = lin_dw(e.dbr1, e.ao1, TB, d, d, p.sa_out.gw, p.sa_out.gb);
+        if (!rc) rc = lin_dw(e.dqc, e.y1, TB, d, d, p.ca_in.gw, p.ca_in.gb);
+        if (!rc) rc = lin_dw(e.dbr2, e.ao2, TB, d, d, p.ca_out.gw, p.ca_out.gb);
+        if (!rc) rc = lin_dw(e.da, e.y2, TB, f, d, p.lin1.gw, p.lin1.gb);
+        if (!rc) rc = lin_dw(e.dbr3, e.h, TB, d, f, p.lin2.gw, p.lin2.gb);
+      }
+      st = keep;
+      RC(rc);
+    }
+    for (int l = 0; l < c.n_dec; ++l) {      // the chain: K/V gradients of the memory -> their projection's gradients -> the memory gradient
       const DecLayerP& p = P.dec[l]; DecBuf& e = W.dec[l];
-      const float* x_all = l == 0 ? W.emb_all : W.dec[l - 1].y3;
-      RC(lin_dw(e.dqkv, x_all, TB, 3 * d, d, p.sa_in.gw, p.sa_in.gb));
-      RC(lin_dw(e.dbr1, e.ao1, TB, d, d, p.sa_out.gw, p.sa_out.gb));
-      RC(lin_dw(e.dqc, e.y1, TB, d, d, p.ca_in.gw, p.ca_in.gb));
       if (defer_cross)
         RC(mansy_launch_attn_kvgrad(e.qc, (long long)B * d, e.dao2, (long long)B * d, e.dS2, e.Pk2, e.dmemkv, e.dmemkv + d, cross_shape(), T, 0, st, W.fbase, im(W.fbase)));
       RC(lin_dw(e.dmemkv, W.mem, B * M, 2 * d, d, p.ca_in.gw + (size_t)d * d, p.ca_in.gb ? p.ca_in.gb + d : nullptr, defer_cross));      // (the per-step accumulating form of the K/V gradients keeps floats only)
-      RC(lin_dw(e.dbr2, e.ao2, TB, d, d, p.ca_out.gw, p.ca_out.gb));
-      RC(lin_dw(e.da, e.y2, TB, f, d, p.lin1.gw, p.lin1.gb));
-      RC(lin_dw(e.dbr3, e.h, TB, d, f, p.lin2.gw, p.lin2.gb));
       RC(lin_dx(e.dmemkv, B * M, 2 * d, p.ca_in.w + (size_t)d * d, d, W.dmem, l == 0 ? nullptr : W.dmem, nullptr, 1.f, 0, defer_cross));
     }
     // ---- DistillLayer
@@ -717,7 +732,9 @@ struct Eng {
     }
     RC(mansy_launch_embed_bwd(gx, P.emb.w, gt, nullptr, C6, N, d, dr(site_pe_src(), c.p_pe), st));
     RC(mansy_launch_outer_reduce(src, C6, gt, N, d, P.emb.gw, 1, P.emb.gb, nullptr, st));
-    return flush_ln();      // the encoder's five LayerNorm weight / bias gradients: one launch
+    RC(flush_ln());      // the encoder's five LayerNorm weight / bias gradients: one launch
+    if (side_dw) RC(join());      // the decoder's weight gradients, taken beside everything since the decoder recurrence
+    return MANSY_OK;
   }
 };
 
