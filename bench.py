@@ -254,7 +254,8 @@ def _timed_blocks(cycle, cycles, blocks=PPO_BLOCKS, barrier=None):
 
 
 def _median_block(blocks):
-    return sorted(blocks)[len(blocks) // 2]
+    """(median wall time, median host-enqueue time) over the blocks -- each on its own: a block's host time moves independently of its wall time."""
+    return sorted(b[0] for b in blocks)[len(blocks) // 2], sorted(b[1] for b in blocks)[len(blocks) // 2]
 
 
 def _ppo_cycle_time(pol, dev, cycles, warmup, n_env=256, steps_per_env=16, qoe_weights=QOE_TRAIN, seed=5, tables=None):
@@ -527,8 +528,8 @@ def bench_ppo(rank, world, dev, mdist, cycles=5, warmup=2, n_env=256, steps_per_
     if world > 1:          # a block's time = the slowest rank's; then the median block
         tb = torch.tensor([b[0] for b in blocks], device=dev, dtype=torch.float64)
         dist.all_reduce(tb, op=dist.ReduceOp.MAX)
-        order = sorted(range(len(blocks)), key=lambda i: float(tb[i]))[len(blocks) // 2]
-        dt_max, (dt, t_host) = float(tb[order]), blocks[order]
+        dt_max = sorted(float(x) for x in tb)[len(blocks) // 2]
+        dt, t_host = _median_block(blocks)
     else:
         dt, t_host = _median_block(blocks)
     per_rank = None
